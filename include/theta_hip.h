@@ -1,0 +1,158 @@
+/*
+ * theta_hip.h -- C ABI of libtheta_hip.so: the MI355X (gfx950) implementation of THetA's
+ * combinatorial likelihood search.
+ *
+ * Every entry point replaces one operator of the reference's hot path (citations are
+ * file:line into the reference's python/ directory).  Plain pointers and sizes only; the caller
+ * owns every buffer; the library keeps no pointer after a call returns.  All functions return
+ * THETA_OK (0) or a positive error code; theta_last_error() gives the message of the last failure
+ * on the calling thread.
+ *
+ * Conventions
+ *   n        number of populations, 2 or 3 (column 0 of C is the normal genome, == tau)
+ *   m        number of intervals of the search (rows of C), 2 <= m <= THETA_MAX_M
+ *   r, rN    tumour / normal read counts AFTER the reference's sort_r (DataTools.py:95-118),
+ *            int64, rN[i] > 0
+ *   lb, ub   per-interval copy-number bounds as given to Enumerator(...) (Enumerator.py:39);
+ *            the library applies _check_bound_order (Enumerator.py:90-113) itself
+ *   rank     position of a candidate in the reference's enumeration order
+ *            (Enumerator.generate_next_C, Enumerator.py:74-87), 0-based, as 128 bits
+ *            {lo, hi} little-endian pair of uint64
+ *   C (u8)   a candidate is stored without its constant column: m*(n-1) bytes, row-major
+ *            [interval][tumour column]
+ */
+#ifndef THETA_HIP_H
+#define THETA_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define THETA_MAX_M 256          /* intervals in one search                                   */
+#define THETA_MAX_COPY 15        /* largest copy number an entry of C may take                */
+
+enum {
+    THETA_OK = 0,
+    THETA_ERR_ARG = 1,           /* bad argument (shape, range, null pointer)                 */
+    THETA_ERR_NO_CANDIDATES = 2, /* bounds admit no matrix (RunTHetA.py:217-219 exits here)   */
+    THETA_ERR_HIP = 3,           /* HIP runtime failure (no device, launch error, OOM)        */
+    THETA_ERR_OVERFLOW = 4,      /* candidate count does not fit 128 bits (n=3) / 64 bits (n=2)*/
+    THETA_ERR_CAPACITY = 5       /* output capacity too small; *n_out holds the needed size   */
+};
+
+typedef struct theta_ctx theta_ctx;         /* one per process, bound to one GPU              */
+typedef struct theta_problem theta_problem; /* one search instance resident in HBM            */
+
+/* ---- context ------------------------------------------------------------------------------ */
+int theta_create(int device_id, theta_ctx **out);
+void theta_destroy(theta_ctx *ctx);
+const char *theta_last_error(void);
+/* name[cap] receives the device name; cu = compute units; hbm_bytes = total device memory.    */
+int theta_device_info(theta_ctx *ctx, char *name, int cap, int *cu, uint64_t *hbm_bytes);
+
+/* ---- search instance ---------------------------------------------------------------------- */
+/*
+ * Replaces the construction `Enumerator(n,m,k,tau,lb,ub,multi_event)` + `Optimizer(r,rN,m,n,tau,
+ * upper_bound=max_normal)` of RunTHetA.py:134-135 / 181-182.  Uploads r, rN and the bounds, and
+ * builds the rank<->candidate counting tables in HBM (exact: the n=2 table is the cumulative form
+ * of TimeEstimate.count_number_matrices_2, TimeEstimate.py:91-111; the n=3 table counts the
+ * matrices Enumerator._generate_next_C_3 really yields, Enumerator.py:172-214).
+ * max_normal is only enforced for n=2, like the reference (Optimizer.py:107-110).
+ */
+int theta_problem_create(theta_ctx *ctx, int n, int m, int tau, const int64_t *r, const int64_t *rN,
+                         const int32_t *lb, const int32_t *ub, double max_normal,
+                         theta_problem **out);
+void theta_problem_destroy(theta_problem *p);
+/* Number of candidates generate_next_C() would yield (excludes the Q1 duplicate first matrix). */
+int theta_problem_count(theta_problem *p, uint64_t count[2]);
+
+/* Search statistics, all counters are per call. */
+typedef struct theta_search_stats {
+    uint64_t evaluated;      /* candidates enumerated and solved                                */
+    uint64_t accepted;       /* candidates with an admissible optimum (Optimizer.solve != None) */
+    uint64_t degenerate;     /* candidates with an all-zero tumour column (reference: NaN)      */
+    uint64_t iterations;     /* solver iterations summed over candidates                        */
+    uint64_t terms;          /* likelihood terms (interval groups) summed over candidates       */
+    uint64_t list_overflow;  /* records dropped because the device tie list was full            */
+    uint64_t flops;          /* FP64 operations executed by the solver (counted in-kernel)      */
+    double best_nll;         /* smallest accepted NLL seen by the kernel (fused arithmetic)     */
+    double rejected_bound;   /* smallest lower bound on the NLL of any REJECTED candidate       */
+    uint64_t rejected_rank[2];
+    double kernel_ms;        /* duration of the search kernel, HIP events on its stream         */
+    double setup_ms;         /* duration of the unranking / task set-up kernels                 */
+} theta_search_stats;
+
+/*
+ * Fused enumerate + solve + arg-min over the candidates with rank in [rank_begin, rank_end).
+ * Replaces the loop of do_optimization_single (RunTHetA.py:191-208): Enumerator.generate_next_C
+ * (Enumerator.py:74-87), Optimizer.solve (Optimizer.py:68-88) and the running minimum.
+ *
+ * Returns, in increasing rank order, every accepted candidate whose NLL is within `window` of the
+ * smallest NLL found in the range (the host replays the reference's sequential isClose rule,
+ * Misc.py:36-47, on this list).  nll/mu come from the fused arithmetic (group-aggregated sums);
+ * use theta_solve_batch on the returned C for values in the reference's own summation order.
+ *
+ *   cap        capacity (records) of the output arrays
+ *   nll[cap], mu[cap*n], rank[cap*2], C[cap*m*(n-1)]
+ *   n_out      number of records written (or needed, with THETA_ERR_CAPACITY)
+ *   stats      may be NULL
+ */
+int theta_search(theta_problem *p, const uint64_t rank_begin[2], const uint64_t rank_end[2],
+                 double window, int cap, double *nll, double *mu, uint64_t *rank, uint8_t *C,
+                 int *n_out, theta_search_stats *stats);
+
+/*
+ * Per-candidate dump of the fused kernel over ranks rank_begin .. rank_begin+count-1: the
+ * reference's --GET_VALUES developer aid (RunTHetA.py:210-215, FileIO.py:114).  nll[count]
+ * (NaN where Optimizer.solve would return None), mu[count*n].  Diagnostic / parity entry point.
+ */
+int theta_search_values(theta_problem *p, const uint64_t rank_begin[2], uint64_t count, double *nll,
+                        double *mu, theta_search_stats *stats);
+
+/*
+ * Materialised generator: writes candidates rank_begin .. rank_begin+count-1 in the reference's
+ * order.  Replaces repeated Enumerator.generate_next_C() (Enumerator.py:74-87, 119-152, 172-214).
+ * out[count * m * (n-1)].
+ */
+int theta_enumerate(theta_problem *p, const uint64_t rank_begin[2], uint64_t count, uint8_t *out);
+
+/*
+ * Per-candidate solve in the reference's own arithmetic order (per-interval sums, the brenth
+ * iteration for n=2): replaces Optimizer.solve(C) (Optimizer.py:68-165) for a batch of B
+ * materialised candidates C[B*m*(n-1)].
+ *   ok[B]      1 = solution, 0 = the reference's `None`
+ *   mu[B*n], nll[B]
+ *   vals[B*m]  the per-interval p* (third element of the reference's tuple); may be NULL
+ */
+int theta_solve_batch(theta_ctx *ctx, int n, int m, int tau, const int64_t *r, const int64_t *rN,
+                      double max_normal, int B, const uint8_t *C, uint8_t *ok, double *mu,
+                      double *nll, double *vals);
+
+/*
+ * Batched CalcAllC.L2 / CalcAllC.L3 (CalcAllC.py:44-76) on literal float matrices: B weighted
+ * matrices Cw[B*m*n] (row-major m x n, float64, exactly what the reference passes), mu[B*n]
+ * (for n=2 only mu[b*2] is used, like the reference's scalar mu), r[m] float64.
+ * Row validity, the in-place scaling of L2 and the NaN behaviour follow the
+ * reference; the library never modifies Cw (the host wrapper applies L2's mutation).
+ *   nll[B]; vals[B*m] may be NULL; valid[B*m] (1 = row counted, 0 = the reference's 'X') may be NULL
+ */
+int theta_score_batch(theta_ctx *ctx, int n, int m, int B, const double *Cw, const double *mu,
+                      const double *r, double *nll, double *vals, uint8_t *valid);
+
+/*
+ * Compact scorer for interval-subset resampling: B candidates as bytes C[B*m*(n-1)] with weights
+ * w[m] (the normal counts), mu[B*n], and S row masks mask[S*ceil(m/64)] (uint64 words, bit i =
+ * interval i takes part; NULL = one all-ones mask).  Computes CalcAllC.L3/L2's NLL for every
+ * (candidate, mask) pair with the masked rows' column 0 treated as 0 (CalcAllC.py:70-75).
+ * nll[B*S], candidate-major.
+ */
+int theta_score_masked(theta_ctx *ctx, int n, int m, int tau, int B, int S, const uint8_t *C,
+                       const double *w, const double *r, const double *mu, const uint64_t *mask,
+                       double *nll, double *kernel_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* THETA_HIP_H */

@@ -1,0 +1,427 @@
+"""
+GPU parity tests (run with `-m gpu` on the MI355X box): the HIP path, called through the C ABI,
+against (a) the golden fixtures produced by the reference itself and (b) the CPU oracle on the same
+seeded inputs.  Integer results (enumeration order, chosen C, ranks, counts) must be bit-exact;
+mu / NLL within 1e-6 relative (the tolerance BASELINE.json's north_star states), usually far tighter.
+"""
+import hashlib
+import math
+
+import numpy as np
+import pytest
+
+import theta_oracle as orc
+from conftest import load_json, unfl
+
+pytestmark = pytest.mark.gpu
+
+REL = 1e-6
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import theta_amd
+    return theta_amd.default_context()
+
+
+def _problem(ctx, n, m, lb, ub, r=None, rN=None, max_normal=1.0, tau=2):
+    import theta_amd
+    r = [1] * m if r is None else r
+    rN = [1] * m if rN is None else rN
+    return theta_amd.Problem(ctx, n, m, tau, r, rN, lb, ub, max_normal)
+
+
+def _rel(a, b):
+    return abs(a - b) / max(abs(a), abs(b), 1e-300)
+
+
+# ---------------------------------------------------------------------------------------------------
+# enumeration order and counts (bit-exact)
+# ---------------------------------------------------------------------------------------------------
+def test_enumeration_order_and_counts(ctx):
+    for case in load_json("enum_order.json")["cases"]:
+        n, m = case["n"], case["m"]
+        p = _problem(ctx, n, m, case["lb"], case["ub"])
+        assert p.count == case["count"], (n, m, case["lb"], case["ub"])
+        got = p.enumerate(0, p.count)
+        if "seq" in case:
+            want = np.array(case["seq"], dtype=np.uint8).reshape(got.shape)
+            assert np.array_equal(got, want)
+        else:
+            h = hashlib.sha256()
+            h.update(bytes(np.ascontiguousarray(got).reshape(-1)))
+            assert h.hexdigest() == case["sha256_u8"]
+        # a window in the middle starts at the right candidate
+        if p.count > 7:
+            mid = p.enumerate(p.count // 2, 3)
+            assert np.array_equal(mid, got[p.count // 2: p.count // 2 + 3])
+        p.close()
+
+
+def test_enumerator_class_matches_reference_interface(ctx):
+    from theta_amd.Enumerator import Enumerator
+    case = [c for c in load_json("enum_order.json")["cases"] if c["n"] == 2 and "seq" in c][2]
+    lb, ub = list(case["lb"]), list(case["ub"])
+    e = Enumerator(2, case["m"], case["k"], 2, lb, ub)
+    first = e._C_to_array()
+    assert first[:, 0].tolist() == [2.0] * case["m"] and first[:, 1].tolist() == [float(v) for v in orc.check_bound_order(case["lb"], case["ub"])[0]]
+    assert lb == orc.check_bound_order(case["lb"], case["ub"])[0]   # bounds adjusted in place like the reference
+    seq = []
+    C = e.generate_next_C()
+    while C is not False:
+        assert C.dtype == np.float64 and C.shape == (case["m"], 2)
+        seq.append([[int(v)] for v in C[:, 1]])
+        C = e.generate_next_C()
+    assert seq == case["seq"]
+    case3 = [c for c in load_json("enum_order.json")["cases"] if c["n"] == 3 and "seq" in c][0]
+    e3 = Enumerator(3, case3["m"], case3["k"], 2, list(case3["lb"]), list(case3["ub"]))
+    assert e3._C_to_array().tolist() == [[2.0, 0.0, 0.0]] * case3["m"]          # quirk Q1
+    C = e3.generate_next_C()
+    assert C[:, 1:].astype(int).tolist() == case3["seq"][0]
+
+
+# ---------------------------------------------------------------------------------------------------
+# n = 2 per-candidate tables
+# ---------------------------------------------------------------------------------------------------
+def test_n2_fused_values_match_reference_tables(ctx):
+    for case in load_json("solve_n2.json")["cases"]:
+        m = case["m"]
+        p = _problem(ctx, 2, m, case["lb"], case["ub"], case["r"], case["rN"], case["max_normal"])
+        tab = case["table"]
+        assert p.count == len(tab)
+        nll, mu, st = p.values(0, p.count)
+        assert st["evaluated"] == p.count
+        for i, ref in enumerate(tab):
+            if ref is None:
+                assert math.isnan(nll[i]), (i, nll[i])
+            else:
+                assert not math.isnan(nll[i]), i
+                assert abs(mu[i, 0] - ref[0][0]) < 1e-9 and abs(mu[i, 1] - ref[0][1]) < 1e-9
+                assert _rel(nll[i], ref[1]) < 1e-11
+        p.close()
+
+
+def test_n2_solve_batch_matches_reference_tables(ctx):
+    for case in load_json("solve_n2.json")["cases"]:
+        m = case["m"]
+        cols = np.array(list(orc.enumerate_n2(m, 2, case["lb"], case["ub"])), dtype=np.uint8)
+        ok, mu, nll, vals = ctx.solve_batch(2, 2, case["r"], case["rN"], cols, case["max_normal"])
+        for i, ref in enumerate(case["table"]):
+            assert bool(ok[i]) == (ref is not None), i
+            if ref is None:
+                continue
+            assert abs(mu[i, 0] - ref[0][0]) < 1e-11           # same brenth iteration in the same arithmetic
+            assert _rel(nll[i], ref[1]) < 1e-13
+            if len(ref) > 2:
+                assert np.allclose(vals[i], [unfl(v) for v in ref[2]], rtol=1e-12, atol=0)
+
+
+def test_n2_degenerate_cases_through_optimizer_class(ctx):
+    from theta_amd.Optimizer import Optimizer
+    d = load_json("solve_n2.json")["degenerate"]
+    for c in d["cases"]:
+        opt = Optimizer(d["r"], d["rN"], 4, 2, 2, upper_bound=c["max_normal"])
+        s = opt.solve(orc.col_to_matrix_n2(c["col"], 2))
+        assert (s is None) == (c["soln"] is None), c
+        if s is not None:
+            assert isinstance(s[0], tuple) and len(s[0]) == 2 and len(s[2]) == 4
+            assert abs(s[0][0] - unfl(c["soln"][0][0])) < 1e-11
+            assert _rel(s[1], unfl(c["soln"][1])) < 1e-13
+            assert np.allclose(s[2], [unfl(v) for v in c["soln"][2]], rtol=1e-12)
+
+
+# ---------------------------------------------------------------------------------------------------
+# n = 3 per-candidate tables
+# ---------------------------------------------------------------------------------------------------
+def _check_n3_table(C, nll, mu, ref_acc, ref_mu, ref_nll):
+    """
+    The GPU accept set is "likelihood minimum inside the simplex"; the reference's is a
+    scipy-trajectory-dependent superset.  What must hold:
+      * whatever the reference reports for a candidate is never below the GPU's optimum;
+      * where the reference converged to the optimum (same NLL), mu agrees (unless the candidate is
+        rank-deficient, where the minimiser is a line);
+      * the GPU never accepts a candidate with an optimum below the reference's best.
+    """
+    B = len(nll)
+    ours = ~np.isnan(nll)
+    both = ours & ref_acc & ~np.isnan(ref_nll)
+    assert (ref_nll[both] >= nll[both] * (1 - 1e-9)).all()
+    same = both & (np.abs(ref_nll - nll) <= 1e-9 * np.abs(nll))
+    rank3 = np.array([np.linalg.matrix_rank(np.column_stack([np.ones(C.shape[1]), C[b, :, 0], C[b, :, 1]])) == 3
+                      for b in range(B)])
+    chk = same & rank3
+    assert chk.sum() > 0.5 * both.sum()
+    assert np.abs(mu[chk] - ref_mu[chk]).max() < 1e-6
+    # the winner is the same candidate with the same value
+    ref_best = np.nanmin(ref_nll)
+    our_best = np.nanmin(nll)
+    assert _rel(ref_best, our_best) < 1e-9
+    return both.sum(), chk.sum()
+
+
+def test_n3_fused_values_small_tables(ctx):
+    for case in load_json("solve_n3_small.json")["cases"]:
+        m = case["m"]
+        p = _problem(ctx, 3, m, case["lb"], case["ub"], case["r"], case["rN"])
+        tab = case["table"]
+        assert p.count == len(tab)
+        nll, mu, st = p.values(0, p.count)
+        C = p.enumerate(0, p.count).astype(float)
+        ref_acc = np.array([t is not None for t in tab])
+        ref_nll = np.array([unfl(t[1]) if t is not None else np.nan for t in tab])
+        ref_mu = np.array([[unfl(x) for x in t[0]] if t is not None else [np.nan] * 3 for t in tab])
+        _check_n3_table(C, nll, mu, ref_acc, ref_mu, ref_nll)
+        p.close()
+
+
+def test_n3_fused_values_m6k3_all_candidates(ctx):
+    g = np.load(__import__("os").path.join(__import__("conftest").GOLD, "solve_n3_m6k3.npz"))
+    m = 6
+    p = _problem(ctx, 3, m, g["lb"].tolist(), g["ub"].tolist(), g["r"].tolist(), g["rN"].tolist())
+    assert p.count == len(g["accepted"]) == 21050
+    got = p.enumerate(0, p.count)
+    assert np.array_equal(got, g["C"])                          # DFS order, all 21 050 matrices
+    nll, mu, st = p.values(0, p.count)
+    assert st["evaluated"] == 21050
+    _check_n3_table(got.astype(float), nll, mu, g["accepted"].astype(bool), g["mu"], g["nll"])
+    # the batch solver (per-interval sums) agrees with the fused kernel (group sums)
+    ok, mu_b, nll_b, _ = ctx.solve_batch(3, 2, g["r"], g["rN"], got, 1.0)
+    fused_ok = ~np.isnan(nll)
+    assert (ok != fused_ok).sum() <= 5                          # borderline admissibility only
+    both = ok & fused_ok
+    assert (np.abs(nll_b[both] - nll[both]) / nll[both]).max() < 1e-11
+    p.close()
+
+
+# ---------------------------------------------------------------------------------------------------
+# the driver: `best` against the reference's do_optimization_single
+# ---------------------------------------------------------------------------------------------------
+def _compare_best(best, ref_best, n):
+    ref = [b for b in ref_best if not (isinstance(b["nll"], str))]     # NaN entries: see search.py docstring
+    assert len(best) == len(ref), ([b[2] for b in best], [b["nll"] for b in ref])
+    for b, rb in zip(best, ref):
+        assert np.array_equal(b[0], np.array(rb["C"]))                 # chosen C: bit-exact, original order
+        assert _rel(b[2], rb["nll"]) < REL
+        Cm = np.array(rb["C"])
+        full_rank = n == 2 or np.linalg.matrix_rank(np.column_stack([np.ones(len(Cm)), Cm[:, 1], Cm[:, 2]])) == 3
+        if full_rank and len(Cm) > 6:
+            for a, c in zip(b[1], rb["mu"]):
+                assert abs(a - unfl(c)) < REL
+            assert np.allclose(b[3], [unfl(v) for v in rb["vals"]], rtol=1e-6)
+
+
+def test_best_matches_reference_on_synthetic_inputs(ctx):
+    from theta_amd.search import do_optimization_single, do_optimization
+    for case in load_json("best_synth.json")["cases"]:
+        n, m = case["n"], case["m"]
+        args = (n, m, case["k"], 2, list(case["lb"]), list(case["ub"]), case["r"], case["rN"], case["max_normal"],
+                case["order"])
+        best = do_optimization_single(*args, False, False)
+        _compare_best(best, case["best"], n)
+        best2 = do_optimization(*args, 4, False, False)                # NUM_PROCESSES invariance
+        assert len(best2) == len(best) and all(np.array_equal(a[0], b[0]) for a, b in zip(best, best2))
+
+
+def test_config1_example_intervals_n2(ctx):
+    """BASELINE config 1: example/Example.intervals -n 2 -k 3 (61 selected intervals, 142 560 candidates)."""
+    from theta_amd.search import do_optimization_single
+    import theta_amd.search as S
+    e = load_json("example_n2.json")
+    best = do_optimization_single(2, e["m"], e["k"], e["tau"], list(e["lb"]), list(e["ub"]), e["r"], e["rN"],
+                                  e["max_normal"], e["sorted_index"], False, False)
+    assert S.last_report.candidates == 142560
+    assert S.last_report.stats["evaluated"] == 142560
+    _compare_best(best, e["best"], 2)
+    assert _rel(best[0][2], 5497732728.26462) < 1e-12
+    assert abs(best[0][1][0] - 0.535405337835399) < 1e-9
+
+
+# ---------------------------------------------------------------------------------------------------
+# CalcAllC.L2 / L3
+# ---------------------------------------------------------------------------------------------------
+def test_calcallc_known_answers(ctx):
+    from theta_amd import CalcAllC
+    kat = load_json("kat_calcallc.json")
+    e = kat["L2"]
+    C = np.array(e["C"], float)
+    nll, vals = CalcAllC.L2(e["mu"], C, e["m"], np.array(e["r"], float))
+    assert _rel(nll, e["branch"]["nll"]) < 1e-13
+    for v, w in zip(vals, e["branch"]["vals"]):
+        assert (v == 'X') == (w == 'X')
+        if v != 'X':
+            assert _rel(v, w) < 1e-13
+    ref = np.array(e["C"], float)
+    assert np.allclose(C[:, 0], ref[:, 0] * e["mu"]) and np.allclose(C[:, 1], ref[:, 1] * (1 - e["mu"]))  # quirk Q7
+    e = kat["L3"]
+    nll, vals = CalcAllC.L3(e["mu"], np.array(e["C"], float), e["m"], np.array(e["r"], float), e["n"])
+    assert _rel(nll, e["branch"]["nll"]) < 1e-13
+    for v, w in zip(vals, e["branch"]["vals"]):
+        assert (v == 'X') == (w == 'X')
+        if v != 'X':
+            assert _rel(v, w) < 1e-13
+    q = kat["Q10"]
+    assert math.isnan(CalcAllC.L3(q["mu"], np.array(q["C_nan"]), 4, np.array(q["r"], float), 3)[0])
+    assert _rel(CalcAllC.L3(q["mu"], np.array(q["C_ok"]), 4, np.array(q["r"], float), 3)[0], unfl(q["nll_ok"])) < 1e-13
+    with pytest.raises(ValueError):
+        CalcAllC.L2(0.5, np.ones((3, 2)), 2, np.ones(2))
+    with pytest.raises(ValueError):
+        CalcAllC.L3([.2, .3, .5], np.ones((2, 2)), 2, np.ones(2), 3)
+
+
+def test_score_masked_against_oracle(ctx):
+    rng = np.random.RandomState(5)
+    for n, m in ((3, 200), (2, 70), (3, 64)):
+        B, S, tau = 37, 9, 2
+        C = rng.randint(0, 8, (B, m, n - 1)).astype(np.uint8)
+        if n == 2:
+            C = C[:, :, 0]
+        w = rng.randint(1000, 90000, m).astype(float)
+        r = rng.randint(1000, 90000, m).astype(float)
+        mu = rng.dirichlet(np.ones(n) * 3, B)
+        words = (m + 63) // 64
+        bits = rng.rand(S, m) < 0.8
+        bits[0, :] = True
+        masks = np.zeros((S, words), np.uint64)
+        for s in range(S):
+            for i in range(m):
+                if bits[s, i]:
+                    masks[s, i // 64] |= np.uint64(1) << np.uint64(i % 64)
+        nll, ms = ctx.score_masked(n, tau, C, w, r, mu, masks)
+        nll1, _ = ctx.score_masked(n, tau, C, w, r, mu, None)
+        assert np.allclose(nll1[:, 0], nll[:, 0], rtol=1e-14)            # all-ones mask == no mask
+        for b in range(0, B, 6):
+            for s in range(S):
+                Cw = np.zeros((m, n))
+                Cw[:, 0] = tau * w * bits[s]                              # masked rows: column 0 zeroed (CalcAllC.py:70)
+                Cw[:, 1:] = (C[b].reshape(m, n - 1)) * w[:, None]
+                want = orc.calc_L3(mu[b], Cw, m, r, n)[0] if n == 3 else orc.calc_L2(mu[b, 0], Cw, m, r)[0]
+                if math.isnan(want):
+                    assert math.isnan(nll[b, s])
+                else:
+                    assert _rel(nll[b, s], want) < 1e-12, (n, m, b, s)
+
+
+# ---------------------------------------------------------------------------------------------------
+# solve_batch against the oracle on seeded inputs at benchmark shapes
+# ---------------------------------------------------------------------------------------------------
+def test_solve_batch_vs_oracle_benchmark_shapes(ctx):
+    rng = np.random.RandomState(11)
+    # config 2 shape: m=25, n=2, k=5
+    r, rN, L, Ct, mut = orc.synth_counts(25, 2, 5, 101)
+    r, rN, order = orc.sort_r(rN, r)
+    cols = np.sort(rng.randint(0, 6, (120, 25)), axis=1).astype(np.uint8)
+    ok, mu, nll, vals = ctx.solve_batch(2, 2, r, rN, cols, 1.0)
+    for b in range(len(cols)):
+        s = orc.solve_n2(orc.col_to_matrix_n2(cols[b], 2), r, rN, 1)
+        assert bool(ok[b]) == (s is not None)
+        if s is not None:
+            assert abs(mu[b, 0] - s[0][0]) < 1e-11 and _rel(nll[b], s[1]) < 1e-13
+    # config 3 shape: m=50, n=3, k=4 -- a few candidates near the truth (the oracle needs ~30 ms each)
+    r, rN, L, Ct, mut = orc.synth_counts(50, 3, 4, 102)
+    rs, rNs, order = orc.sort_r(rN, r)
+    Cs = Ct[order, 1:].astype(np.uint8)
+    cands = [Cs.copy()]
+    for t in range(5):
+        c = Cs.copy()
+        i = rng.randint(0, 50)
+        c[i, rng.randint(0, 2)] = (c[i, 0] + 1 + t) % 5
+        cands.append(c)
+    cands = np.array(cands)
+    ok, mu, nll, vals = ctx.solve_batch(3, 2, rs, rNs, cands, 1.0)
+    for b in range(len(cands)):
+        s = orc.solve_n3(orc.rows_to_matrix_n3([tuple(x) for x in cands[b]], 2), rs, rNs)
+        if s is None or not ok[b]:
+            continue
+        if _rel(nll[b], s[1]) < 1e-9:
+            assert np.abs(mu[b] - s[0]).max() < 1e-6
+        assert s[1] >= nll[b] * (1 - 1e-9)
+    assert ok[0]
+
+
+# ---------------------------------------------------------------------------------------------------
+# full-size, size-independent properties (BASELINE configs 2 and 3)
+# ---------------------------------------------------------------------------------------------------
+def test_config2_full_search_properties(ctx):
+    """m=25, n=2, k=5, bounds [0,5]: all C(30,5) = 142 506 candidates."""
+    import theta_amd
+    r, rN, L, Ct, mut = orc.synth_counts(25, 2, 5, 202)
+    r, rN, order = orc.sort_r(rN, r)
+    p = theta_amd.Problem(ctx, 2, 25, 2, r, rN, [0] * 25, [5] * 25, 1.0)
+    assert p.count == 142506 == orc.count_n2(25, [0] * 25, [5] * 25)
+    res = p.search(0, p.count, window=0.5)
+    assert res["stats"]["evaluated"] == 142506
+    nll, mu, st = p.values(0, p.count)
+    k = int(np.nanargmin(nll))
+    assert k in res["rank"]
+    i = res["rank"].index(k)
+    assert res["nll"][i] == nll[k]
+    # sharding the rank space changes nothing (idempotence of the arg-min over a partition)
+    parts = [p.search(p.count * g // 8, p.count * (g + 1) // 8, window=0.5) for g in range(8)]
+    merged_min = min(x["nll"].min() for x in parts if len(x["nll"]))
+    assert merged_min == res["nll"].min()
+    assert sum(x["stats"]["evaluated"] for x in parts) == 142506
+    # the winner, re-solved by the oracle on the CPU
+    c = res["C"][i]
+    s = orc.solve_n2(orc.col_to_matrix_n2(c, 2), r, rN, 1)
+    assert abs(s[0][0] - res["mu"][i, 0]) < 1e-9 and _rel(s[1], res["nll"][i]) < 1e-11
+    # truth recovery on noise-free-ish synthetic data: the winner is the generating column
+    assert np.array_equal(c, Ct[order, 1].astype(np.uint8))
+    p.close()
+
+
+def test_config3_shape_rank_ranges_and_tight_bounds_parity(ctx):
+    """m=50, n=3, k=4.  (a) tight bounds around the truth vs the oracle's exhaustive search;
+    (b) full bounds: rank-range searches agree with their own sub-ranges and with enumerate+solve_batch."""
+    import theta_amd
+    from theta_amd.search import do_optimization_single
+    r, rN, L, Ct, mut = orc.synth_counts(50, 3, 4, 303)
+    rs, rNs, order = orc.sort_r(rN, r)
+    truth = Ct[order, 1:].astype(int)
+    lb = np.minimum.accumulate(truth.min(axis=1)[::-1])[::-1].copy()
+    ub = np.maximum.accumulate(truth.max(axis=1)).copy()
+    lb = np.minimum(lb, truth.min(axis=1))
+    # (a) a +-0 window almost everywhere, free on three intervals
+    lbt = truth.min(axis=1).copy()
+    ubt = truth.max(axis=1).copy()
+    for i in (7, 23, 41):
+        lbt[i] = max(0, lbt[i] - 1)
+        ubt[i] = min(4, ubt[i] + 1)
+    p = theta_amd.Problem(ctx, 3, 50, 2, rs, rNs, lbt.tolist(), ubt.tolist(), 1.0)
+    cnt = p.count
+    assert 0 < cnt < 5000
+    seq = list(orc.enumerate_n3(50, 2, lbt.tolist(), ubt.tolist()))
+    assert len(seq) == cnt
+    got = p.enumerate(0, cnt)
+    assert np.array_equal(got, np.array(seq, dtype=np.uint8))
+    best = do_optimization_single(3, 50, 4, 2, lbt.tolist(), ubt.tolist(), rs, rNs, 1.0, order, False, False)
+    ref_best, _ = orc.search_single(3, 50, 2, lbt.tolist(), ubt.tolist(), rs, rNs, 1.0, order, limit=min(cnt + 1, 400))
+    if cnt + 1 <= 400:
+        ref = [b for b in ref_best if b[2] == b[2]]
+        assert len(best) == len(ref)
+        for b, rb in zip(best, ref):
+            assert np.array_equal(b[0], rb[0])
+            assert _rel(b[2], rb[2]) < REL and np.abs(np.array(b[1]) - np.array(rb[1])).max() < REL
+    p.close()
+    # (b) full bounds [0,4]: 4.07e27 candidates; ranges far apart in the space
+    p = theta_amd.Problem(ctx, 3, 50, 2, rs, rNs, [0] * 50, [4] * 50, 1.0)
+    assert p.count > 10 ** 27
+    for start in (0, p.count // 3, p.count - 20000):
+        nll, mu, st = p.values(start, 20000)
+        assert st["evaluated"] == 20000
+        C = p.enumerate(start, 20000)
+        ok, mu_b, nll_b, _ = ctx.solve_batch(3, 2, rs, rNs, C, 1.0, want_vals=False)
+        fused_ok = ~np.isnan(nll)
+        assert (ok != fused_ok).sum() <= 20
+        both = ok & fused_ok
+        if both.any():
+            assert (np.abs(nll_b[both] - nll[both]) / nll[both]).max() < 1e-10
+        res = p.search(start, start + 20000, window=0.5)
+        if fused_ok.any():
+            k = int(np.nanargmin(nll))
+            assert start + k in res["rank"]
+            a = p.search(start, start + 7001, window=0.5)
+            b = p.search(start + 7001, start + 20000, window=0.5)
+            assert min(a["nll"].min() if len(a["nll"]) else np.inf, b["nll"].min() if len(b["nll"]) else np.inf) == res["nll"].min()
+        # consecutive enumerated matrices are in strictly increasing DFS order: re-ranking by search ranks
+        assert np.array_equal(p.enumerate(start + 123, 1)[0], C[123])
+    p.close()

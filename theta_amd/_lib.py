@@ -1,0 +1,251 @@
+"""
+ctypes binding of libtheta_hip.so (C ABI in include/theta_hip.h).  numpy in, numpy out, no torch.
+
+The shared library IS the compute path.  If it is missing, or no MI355X is visible, every entry
+point raises -- there is no CPU fallback anywhere in this package.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtheta_hip.so")
+
+THETA_OK, ERR_ARG, ERR_NO_CANDIDATES, ERR_HIP, ERR_OVERFLOW, ERR_CAPACITY = range(6)
+
+
+class ThetaError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("libtheta_hip error %d: %s" % (code, msg))
+        self.code = code
+
+
+class NoCandidates(ThetaError):
+    """The bounds admit no matrix (the reference prints an error and exits, RunTHetA.py:217-219)."""
+
+
+class SearchStats(C.Structure):
+    _fields_ = [("evaluated", C.c_uint64), ("accepted", C.c_uint64), ("degenerate", C.c_uint64),
+                ("iterations", C.c_uint64), ("terms", C.c_uint64), ("list_overflow", C.c_uint64),
+                ("flops", C.c_uint64), ("best_nll", C.c_double), ("rejected_bound", C.c_double),
+                ("rejected_rank", C.c_uint64 * 2), ("kernel_ms", C.c_double), ("setup_ms", C.c_double)]
+
+    def as_dict(self):
+        d = {k: getattr(self, k) for k, _ in self._fields_ if k != "rejected_rank"}
+        d["rejected_rank"] = int(self.rejected_rank[0]) | (int(self.rejected_rank[1]) << 64)
+        return d
+
+
+_lib = None
+
+# every symbol include/theta_hip.h declares
+EXPORTS = ["theta_create", "theta_destroy", "theta_last_error", "theta_device_info", "theta_problem_create",
+           "theta_problem_destroy", "theta_problem_count", "theta_search", "theta_search_values", "theta_enumerate",
+           "theta_solve_batch", "theta_score_batch", "theta_score_masked"]
+
+
+def load():
+    """dlopen the library (no GPU needed for this) and declare prototypes."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("%s not found: build it with `python -m theta_amd.build` (hipcc, gfx950). "
+                          "theta_amd has no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    vp, i32, u64p, dp, u8p = C.c_void_p, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_double), C.POINTER(C.c_uint8)
+    i64p, i32p = C.POINTER(C.c_int64), C.POINTER(C.c_int32)
+    lib.theta_last_error.restype = C.c_char_p
+    lib.theta_create.argtypes = [i32, C.POINTER(vp)]
+    lib.theta_destroy.argtypes = [vp]
+    lib.theta_destroy.restype = None
+    lib.theta_device_info.argtypes = [vp, C.c_char_p, i32, C.POINTER(i32), u64p]
+    lib.theta_problem_create.argtypes = [vp, i32, i32, i32, i64p, i64p, i32p, i32p, C.c_double, C.POINTER(vp)]
+    lib.theta_problem_destroy.argtypes = [vp]
+    lib.theta_problem_destroy.restype = None
+    lib.theta_problem_count.argtypes = [vp, u64p]
+    lib.theta_search.argtypes = [vp, u64p, u64p, C.c_double, i32, dp, dp, u64p, u8p, C.POINTER(i32), C.POINTER(SearchStats)]
+    lib.theta_search_values.argtypes = [vp, u64p, C.c_uint64, dp, dp, C.POINTER(SearchStats)]
+    lib.theta_enumerate.argtypes = [vp, u64p, C.c_uint64, u8p]
+    lib.theta_solve_batch.argtypes = [vp, i32, i32, i32, i64p, i64p, C.c_double, i32, u8p, u8p, dp, dp, dp]
+    lib.theta_score_batch.argtypes = [vp, i32, i32, i32, dp, dp, dp, dp, dp, u8p]
+    lib.theta_score_masked.argtypes = [vp, i32, i32, i32, i32, i32, u8p, dp, dp, dp, u64p, dp, dp]
+    _lib = lib
+    return lib
+
+
+def _check(rc):
+    if rc != THETA_OK:
+        msg = load().theta_last_error().decode()
+        raise (NoCandidates if rc == ERR_NO_CANDIDATES else ThetaError)(rc, msg)
+
+
+def _p(arr, ctype):
+    return arr.ctypes.data_as(C.POINTER(ctype))
+
+
+def _u128(v):
+    v = int(v)
+    return (C.c_uint64 * 2)(v & 0xFFFFFFFFFFFFFFFF, v >> 64)
+
+
+class Context:
+    """One per process, bound to one GPU (theta_create)."""
+
+    def __init__(self, device=None):
+        lib = load()
+        if device is None:
+            device = int(os.environ.get("LOCAL_RANK", "0"))
+        h = C.c_void_p()
+        _check(lib.theta_create(int(device), C.byref(h)))
+        self._h = h
+        self.device = int(device)
+        name = C.create_string_buffer(128)
+        cu = C.c_int()
+        hbm = C.c_uint64()
+        _check(lib.theta_device_info(h, name, 128, C.byref(cu), C.byref(hbm)))
+        self.name, self.cu_count, self.hbm_bytes = name.value.decode(), cu.value, hbm.value
+
+    def close(self):
+        if getattr(self, "_h", None):
+            load().theta_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- materialised operators ---------------------------------------------------------------
+    def solve_batch(self, n, tau, r, rN, C_u8, max_normal=1.0, want_vals=True):
+        """Optimizer.solve on a batch: C_u8 is (B, m) for n=2 or (B, m, 2) for n=3."""
+        C_u8 = np.ascontiguousarray(C_u8, dtype=np.uint8)
+        B = C_u8.shape[0]
+        m = C_u8.shape[1]
+        r = np.ascontiguousarray(r, dtype=np.int64)
+        rN = np.ascontiguousarray(rN, dtype=np.int64)
+        ok = np.zeros(B, np.uint8)
+        mu = np.zeros((B, n))
+        nll = np.zeros(B)
+        vals = np.zeros((B, m)) if want_vals else None
+        _check(load().theta_solve_batch(self._h, n, m, int(tau), _p(r, C.c_int64), _p(rN, C.c_int64), float(max_normal),
+                                        B, _p(C_u8, C.c_uint8), _p(ok, C.c_uint8), _p(mu, C.c_double), _p(nll, C.c_double),
+                                        _p(vals, C.c_double) if want_vals else None))
+        return ok.astype(bool), mu, nll, vals
+
+    def score_batch(self, n, Cw, mu, r):
+        """CalcAllC.L2/L3 on B literal matrices Cw (B, m, n); mu (B, n); returns nll, vals, valid."""
+        Cw = np.ascontiguousarray(Cw, dtype=np.float64)
+        B, m, nn = Cw.shape
+        assert nn == n
+        mu = np.ascontiguousarray(mu, dtype=np.float64).reshape(B, n)
+        r = np.ascontiguousarray(r, dtype=np.float64)
+        nll = np.zeros(B)
+        vals = np.zeros((B, m))
+        valid = np.zeros((B, m), np.uint8)
+        _check(load().theta_score_batch(self._h, n, m, B, _p(Cw, C.c_double), _p(mu, C.c_double), _p(r, C.c_double),
+                                        _p(nll, C.c_double), _p(vals, C.c_double), _p(valid, C.c_uint8)))
+        return nll, vals, valid.astype(bool)
+
+    def score_masked(self, n, tau, C_u8, w, r, mu, masks=None):
+        """Byte candidates x row masks; masks is (S, ceil(m/64)) uint64 or None. Returns (nll (B,S), kernel_ms)."""
+        C_u8 = np.ascontiguousarray(C_u8, dtype=np.uint8)
+        B, m = C_u8.shape[0], C_u8.shape[1]
+        w = np.ascontiguousarray(w, dtype=np.float64)
+        r = np.ascontiguousarray(r, dtype=np.float64)
+        mu = np.ascontiguousarray(mu, dtype=np.float64).reshape(B, n)
+        S = 1 if masks is None else masks.shape[0]
+        if masks is not None:
+            masks = np.ascontiguousarray(masks, dtype=np.uint64)
+        nll = np.zeros((B, S))
+        ms = C.c_double()
+        _check(load().theta_score_masked(self._h, n, m, int(tau), B, S, _p(C_u8, C.c_uint8), _p(w, C.c_double),
+                                         _p(r, C.c_double), _p(mu, C.c_double),
+                                         _p(masks, C.c_uint64) if masks is not None else None, _p(nll, C.c_double),
+                                         C.byref(ms)))
+        return nll, ms.value
+
+
+_default_ctx = None
+
+
+def default_context():
+    """Process-wide context on cuda:LOCAL_RANK (created on first use)."""
+    global _default_ctx
+    if _default_ctx is None:
+        _default_ctx = Context()
+    return _default_ctx
+
+
+class Problem:
+    """One search instance resident in HBM (theta_problem_create)."""
+
+    def __init__(self, ctx, n, m, tau, r, rN, lb, ub, max_normal=1.0):
+        self.ctx, self.n, self.m, self.tau = ctx, int(n), int(m), int(tau)
+        r = np.ascontiguousarray(r, dtype=np.int64)
+        rN = np.ascontiguousarray(rN, dtype=np.int64)
+        lb = np.ascontiguousarray(lb, dtype=np.int32)
+        ub = np.ascontiguousarray(ub, dtype=np.int32)
+        if not (len(r) == len(rN) == len(lb) == len(ub) == m):
+            raise ValueError("r, rN, lb, ub must all have length m")
+        h = C.c_void_p()
+        _check(load().theta_problem_create(ctx._h, self.n, self.m, self.tau, _p(r, C.c_int64), _p(rN, C.c_int64),
+                                           _p(lb, C.c_int32), _p(ub, C.c_int32), float(max_normal), C.byref(h)))
+        self._h = h
+        cnt = (C.c_uint64 * 2)()
+        _check(load().theta_problem_count(h, cnt))
+        self.count = int(cnt[0]) | (int(cnt[1]) << 64)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            load().theta_problem_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _shape_C(self, flat, k):
+        return flat.reshape(k, self.m) if self.n == 2 else flat.reshape(k, self.m, 2)
+
+    def search(self, begin=0, end=None, window=0.5, cap=4096):
+        """Fused search over ranks [begin, end).  Returns dict(nll, mu, rank (python ints), C, stats)."""
+        end = self.count if end is None else end
+        st = SearchStats()
+        while True:
+            nll = np.zeros(cap)
+            mu = np.zeros((cap, self.n))
+            rank = np.zeros((cap, 2), np.uint64)
+            Cb = np.zeros(cap * self.m * (self.n - 1), np.uint8)
+            n_out = C.c_int()
+            rc = load().theta_search(self._h, _u128(begin), _u128(end), float(window), cap, _p(nll, C.c_double),
+                                     _p(mu, C.c_double), _p(rank, C.c_uint64), _p(Cb, C.c_uint8), C.byref(n_out),
+                                     C.byref(st))
+            if rc == ERR_CAPACITY and n_out.value > cap:
+                cap = n_out.value
+                continue
+            _check(rc)
+            break
+        k = n_out.value
+        ranks = [int(rank[i, 0]) | (int(rank[i, 1]) << 64) for i in range(k)]
+        return {"nll": nll[:k].copy(), "mu": mu[:k].copy(), "rank": ranks,
+                "C": self._shape_C(Cb[:k * self.m * (self.n - 1)], k).copy(), "stats": st.as_dict()}
+
+    def values(self, begin, count):
+        """Per-candidate (nll, mu) of the fused kernel (NaN = None): the --GET_VALUES dump."""
+        nll = np.zeros(count)
+        mu = np.zeros((count, self.n))
+        st = SearchStats()
+        _check(load().theta_search_values(self._h, _u128(begin), int(count), _p(nll, C.c_double), _p(mu, C.c_double),
+                                          C.byref(st)))
+        return nll, mu, st.as_dict()
+
+    def enumerate(self, begin, count):
+        """Candidates begin .. begin+count-1 in the reference's order, as uint8 (count, m[, 2])."""
+        out = np.zeros(int(count) * self.m * (self.n - 1), np.uint8)
+        _check(load().theta_enumerate(self._h, _u128(begin), int(count), _p(out, C.c_uint8)))
+        return self._shape_C(out, int(count))

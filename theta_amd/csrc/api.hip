@@ -1,0 +1,690 @@
+// C ABI of libtheta_hip.so (see include/theta_hip.h).  Host-side glue only: argument checks,
+// HBM residency of a search instance, kernel launches on the context's stream, HIP-event timing,
+// and the merge of the device tie list.
+#include <math.h>
+#include <stdarg.h>
+#include <stdlib.h>
+
+#include <algorithm>
+
+#include "n2.hpp"
+#include "n3_core.hpp"
+
+// ---- implemented in n2.hip / n3.hip / batch.hip ------------------------------------------------
+void n2_launch_search(const N2Dev &P, const SearchArgs &A, unsigned long long begin, unsigned long long end,
+                      int per_thread, hipStream_t st);
+void n2_launch_enumerate(const N2Dev &P, unsigned long long begin, unsigned long long count, unsigned char *out,
+                         hipStream_t st);
+void n2_launch_unrank_list(const N2Dev &P, const TieRecord *recs, int count, unsigned char *out, hipStream_t st);
+
+int n3_build_host(int m, const int32_t *lb_in, const int32_t *ub_in, N3Host &h);
+int n3_run_dp(const N3Dev &P, u128 *cnt, unsigned *overflow_dev, unsigned long long *total_dev, hipStream_t st);
+void n3_launch_tasks(const N3Dev &P, u128 begin, u128 end, uint64_t per_task, int ntasks, N3Task *tasks,
+                     unsigned *stbuf, hipStream_t st);
+void n3_launch_search(const N3Dev &P, const SearchArgs &A, const N3Task *tasks, const unsigned *stbuf, int ntasks,
+                      uint64_t per_task, hipStream_t st);
+void n3_launch_unrank_list(const N3Dev &P, const TieRecord *recs, int count, unsigned char *out, hipStream_t st);
+void n3_launch_enumerate(const N3Dev &P, u128 begin, unsigned long long count, unsigned char *out, hipStream_t st);
+
+void batch_launch_solve(int n, int m, int tau, const double *r, const double *rN, double max_normal, int B,
+                        const unsigned char *C, unsigned char *ok, double *mu, double *nll, double *vals,
+                        hipStream_t st);
+void batch_launch_score(int n, int m, int B, const double *Cw, const double *mu, const double *r, double *nll,
+                        double *vals, unsigned char *valid, hipStream_t st);
+void batch_launch_score_masked(int n, int m, int tau, int B, int S, const unsigned char *C, const double *w,
+                               const double *r, const double *mu, const unsigned long long *mask, double *nll,
+                               hipStream_t st);
+
+// ---- error string ---------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+void theta_set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char *theta_last_error(void) { return g_err; }
+
+// ---- context -------------------------------------------------------------------------------------
+extern "C" int theta_create(int device_id, theta_ctx **out) {
+    if (!out) {
+        theta_set_error("theta_create: null output pointer");
+        return THETA_ERR_ARG;
+    }
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev == 0) {
+        theta_set_error("no HIP device available (%s)", e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+        return THETA_ERR_HIP;
+    }
+    if (device_id < 0 || device_id >= ndev) {
+        theta_set_error("device %d out of range (%d devices)", device_id, ndev);
+        return THETA_ERR_ARG;
+    }
+    HIP_TRY(hipSetDevice(device_id));
+    theta_ctx *c = new theta_ctx();
+    c->device = device_id;
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device_id));
+    c->cu_count = prop.multiProcessorCount;
+    c->hbm_bytes = prop.totalGlobalMem;
+    snprintf(c->name, sizeof(c->name), "%s (%s)", prop.name, prop.gcnArchName);
+    HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreate(&c->ev0));
+    HIP_TRY(hipEventCreate(&c->ev1));
+    HIP_TRY(hipEventCreate(&c->ev2));
+    *out = c;
+    return THETA_OK;
+}
+
+extern "C" void theta_destroy(theta_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipEventDestroy(c->ev0);
+    (void)hipEventDestroy(c->ev1);
+    (void)hipEventDestroy(c->ev2);
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+extern "C" int theta_device_info(theta_ctx *c, char *name, int cap, int *cu, uint64_t *hbm_bytes) {
+    if (!c) {
+        theta_set_error("null context");
+        return THETA_ERR_ARG;
+    }
+    if (name && cap > 0) snprintf(name, cap, "%s", c->name);
+    if (cu) *cu = c->cu_count;
+    if (hbm_bytes) *hbm_bytes = c->hbm_bytes;
+    return THETA_OK;
+}
+
+// ---- search instance ------------------------------------------------------------------------------
+#define LIST_CAP (1u << 20)
+#define N3_MAX_TASKS (1 << 16)
+
+struct theta_problem {
+    theta_ctx *ctx = nullptr;
+    int n = 0, m = 0, tau = 0;
+    double max_normal = 1.0;
+    N2Host n2h;
+    N2Dev n2{};
+    N3Host n3h;
+    N3Dev n3{};
+    uint64_t total[2] = {0, 0};
+    DevBuf d_r, d_rN, d_small, d_P, d_PR, d_PN, d_cnt, d_ctr, d_list, d_tasks, d_stbuf, d_misc;
+};
+
+static int upload(DevBuf &b, const void *src, size_t bytes, hipStream_t st) {
+    int rc = b.alloc(bytes);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, st));
+    return THETA_OK;
+}
+
+extern "C" void theta_problem_destroy(theta_problem *p) {
+    if (!p) return;
+    (void)hipSetDevice(p->ctx->device);
+    delete p;
+}
+
+extern "C" int theta_problem_create(theta_ctx *ctx, int n, int m, int tau, const int64_t *r, const int64_t *rN,
+                                    const int32_t *lb, const int32_t *ub, double max_normal, theta_problem **out) {
+    if (!ctx || !r || !rN || !lb || !ub || !out) {
+        theta_set_error("theta_problem_create: null argument");
+        return THETA_ERR_ARG;
+    }
+    if (n != 2 && n != 3) {
+        theta_set_error("n must be 2 or 3 (got %d)", n);
+        return THETA_ERR_ARG;
+    }
+    int max_m = (n == 2) ? THETA_MAX_M : N3_MAX_M;
+    if (m < 2 || m > max_m) {
+        theta_set_error("m must be in [2, %d] for n=%d (got %d)", max_m, n, m);
+        return THETA_ERR_ARG;
+    }
+    if (tau < 0 || tau > THETA_MAX_COPY) {
+        theta_set_error("tau out of range");
+        return THETA_ERR_ARG;
+    }
+    if (!(max_normal >= 0.0 && max_normal <= 1.0)) {
+        theta_set_error("max_normal must be in [0,1]");
+        return THETA_ERR_ARG;
+    }
+    std::vector<double> rd(m), rnd(m);
+    long double N = 0, Rt = 0;
+    for (int i = 0; i < m; i++) {
+        if (rN[i] <= 0 || r[i] < 0) {
+            theta_set_error("interval %d: need normal count > 0 and tumour count >= 0 (got %lld, %lld)", i,
+                            (long long)rN[i], (long long)r[i]);
+            return THETA_ERR_ARG;
+        }
+        rd[i] = (double)r[i];
+        rnd[i] = (double)rN[i];
+        N += rN[i];
+        Rt += r[i];
+    }
+    if (N >= 9.0e15L || Rt >= 9.0e15L) {
+        theta_set_error("read-count totals exceed 2^53");
+        return THETA_ERR_ARG;
+    }
+    long double k0 = 0;
+    for (int i = 0; i < m; i++)
+        if (r[i] > 0) k0 -= (long double)r[i] * logl((long double)rN[i] / N);
+
+    HIP_TRY(hipSetDevice(ctx->device));
+    theta_problem *p = new theta_problem();
+    p->ctx = ctx;
+    p->n = n;
+    p->m = m;
+    p->tau = tau;
+    p->max_normal = max_normal;
+    hipStream_t st = ctx->stream;
+    int rc;
+#define TRY(x)          \
+    do {                \
+        rc = (x);       \
+        if (rc) {       \
+            delete p;   \
+            return rc;  \
+        }               \
+    } while (0)
+    TRY(upload(p->d_r, rd.data(), m * sizeof(double), st));
+    TRY(upload(p->d_rN, rnd.data(), m * sizeof(double), st));
+    TRY(p->d_ctr.alloc(sizeof(SearchCounters)));
+    TRY(p->d_list.alloc((size_t)LIST_CAP * sizeof(TieRecord)));
+
+    if (n == 2) {
+        TRY(n2_build_host(m, lb, ub, p->n2h));
+        const N2Host &h = p->n2h;
+        // small arrays: lb[m] ub[m] (bytes) then lbpos (shorts)
+        std::vector<unsigned char> small(2 * (size_t)m + 64, 0);
+        for (int i = 0; i < m; i++) {
+            small[i] = (unsigned char)h.lb[i];
+            small[m + i] = (unsigned char)h.ub[i];
+        }
+        size_t off = ((2 * (size_t)m + 7) / 8) * 8;
+        small.resize(off + (N2_KVS + 1) * sizeof(short));
+        short *lbpos = (short *)(small.data() + off);
+        for (int v = 0; v <= N2_KVS; v++) {
+            int pos = m;
+            for (int i = 0; i < m; i++)
+                if (h.lb[i] >= v) {
+                    pos = i;
+                    break;
+                }
+            lbpos[v] = (short)pos;
+        }
+        TRY(upload(p->d_small, small.data(), small.size(), st));
+        TRY(upload(p->d_P, h.P.data(), h.P.size() * sizeof(unsigned long long), st));
+        std::vector<double> PR(m + 1, 0.0), PN(m + 1, 0.0);
+        for (int i = 0; i < m; i++) {
+            PR[i + 1] = PR[i] + rd[i];
+            PN[i + 1] = PN[i] + rnd[i];
+        }
+        TRY(upload(p->d_PR, PR.data(), PR.size() * sizeof(double), st));
+        TRY(upload(p->d_PN, PN.data(), PN.size() * sizeof(double), st));
+        N2Dev &D = p->n2;
+        D.m = m;
+        D.kv = h.kv;
+        D.tau = tau;
+        D.max_normal = max_normal;
+        D.N = (double)N;
+        D.Rtot = (double)Rt;
+        D.K0 = (double)k0;
+        D.PR = (const double *)p->d_PR.p;
+        D.PN = (const double *)p->d_PN.p;
+        D.P = (const unsigned long long *)p->d_P.p;
+        D.lb = (const unsigned char *)p->d_small.p;
+        D.ub = D.lb + m;
+        D.lbpos = (const short *)((const unsigned char *)p->d_small.p + off);
+        D.total = h.total;
+        p->total[0] = h.total;
+        p->total[1] = 0;
+    } else {
+        TRY(n3_build_host(m, lb, ub, p->n3h));
+        const N3Host &h = p->n3h;
+        std::vector<unsigned char> small(2 * (size_t)m + h.ridx.size(), 0);
+        for (int i = 0; i < m; i++) {
+            small[i] = (unsigned char)h.lb[i];
+            small[m + i] = (unsigned char)h.ub[i];
+        }
+        memcpy(small.data() + 2 * m, h.ridx.data(), h.ridx.size());
+        TRY(upload(p->d_small, small.data(), small.size(), st));
+        N3Dev &D = p->n3;
+        D.m = m;
+        D.K = h.K;
+        D.Q = h.Q;
+        D.tau = tau;
+        D.NT = h.NT;
+        int L = (m >= 3) ? 2 : 1;
+        if (const char *e = getenv("THETA_N3_LEAF_LEVELS")) {
+            int v = atoi(e);
+            if (v >= 1 && v <= 3) L = v;
+        }
+        if (L > m - 1) L = m - 1;
+        D.L = L;
+        D.N = (double)N;
+        D.Rtot = (double)Rt;
+        D.K0 = (double)k0;
+        D.r = (const double *)p->d_r.p;
+        D.rN = (const double *)p->d_rN.p;
+        D.lb = (const unsigned char *)p->d_small.p;
+        D.ub = D.lb + m;
+        D.ridx = D.lb + 2 * m;
+        size_t per_level = (size_t)h.Q * 2 * (h.NT + 1) * (h.NT + 1);
+        size_t cnt_bytes = per_level * m * sizeof(u128);
+        if (cnt_bytes > (size_t)ctx->hbm_bytes / 2) {
+            theta_set_error("n=3 counting table needs %zu bytes (device has %llu)", cnt_bytes,
+                            (unsigned long long)ctx->hbm_bytes);
+            delete p;
+            return THETA_ERR_HIP;
+        }
+        TRY(p->d_cnt.alloc(cnt_bytes));
+        D.cnt = (const u128 *)p->d_cnt.p;
+        TRY(p->d_misc.alloc(64));
+        HIP_TRY(hipMemsetAsync(p->d_misc.p, 0, 64, st));
+        unsigned *ovf = (unsigned *)p->d_misc.p;
+        unsigned long long *tot = (unsigned long long *)((char *)p->d_misc.p + 16);
+        n3_run_dp(D, (u128 *)p->d_cnt.p, ovf, tot, st);
+        unsigned char hostmisc[64];
+        HIP_TRY(hipMemcpyAsync(hostmisc, p->d_misc.p, 64, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        HIP_TRY(hipGetLastError());
+        unsigned hov;
+        memcpy(&hov, hostmisc, 4);
+        if (hov) {
+            theta_set_error("n=3 candidate count exceeds 128 bits; tighten the bounds or shard by prefix");
+            delete p;
+            return THETA_ERR_OVERFLOW;
+        }
+        memcpy(p->total, hostmisc + 16, 16);
+        D.total_lo = p->total[0];
+        D.total_hi = p->total[1];
+        TRY(p->d_tasks.alloc((size_t)N3_MAX_TASKS * sizeof(N3Task)));
+        TRY(p->d_stbuf.alloc((size_t)N3_MAX_TASKS * N3_MAX_M * sizeof(unsigned)));
+    }
+    HIP_TRY(hipStreamSynchronize(st));
+#undef TRY
+    *out = p;
+    return THETA_OK;
+}
+
+extern "C" int theta_problem_count(theta_problem *p, uint64_t count[2]) {
+    if (!p || !count) {
+        theta_set_error("null argument");
+        return THETA_ERR_ARG;
+    }
+    count[0] = p->total[0];
+    count[1] = p->total[1];
+    return THETA_OK;
+}
+
+static inline u128 mk128(const uint64_t v[2]) { return ((u128)v[1] << 64) | v[0]; }
+
+static int check_range(theta_problem *p, const uint64_t rb[2], const uint64_t re[2], u128 &b, u128 &e) {
+    if (!p || !rb || !re) {
+        theta_set_error("null argument");
+        return THETA_ERR_ARG;
+    }
+    u128 tot = mk128(p->total);
+    if (tot == 0) {
+        theta_set_error("no valid copy number profiles exist within the bounds");
+        return THETA_ERR_NO_CANDIDATES;
+    }
+    b = mk128(rb);
+    e = mk128(re);
+    if (b > e || e > tot) {
+        theta_set_error("rank range out of bounds");
+        return THETA_ERR_ARG;
+    }
+    return THETA_OK;
+}
+
+// Runs the fused kernel over [b, e).  dump arrays are device pointers or null.
+static int run_search(theta_problem *p, u128 b, u128 e, double window, double *dump_nll, double *dump_mu,
+                      SearchCounters &hc, std::vector<TieRecord> &recs, double &kernel_ms, double &setup_ms) {
+    theta_ctx *ctx = p->ctx;
+    hipStream_t st = ctx->stream;
+    SearchArgs A;
+    A.ctr = (SearchCounters *)p->d_ctr.p;
+    A.list = (TieRecord *)p->d_list.p;
+    A.list_cap = LIST_CAP;
+    A.window = window;
+    A.dump_nll = dump_nll;
+    A.dump_mu = dump_mu;
+    memset(&hc, 0, sizeof(hc));
+    hc.best_bits = order_bits(INFINITY);
+    hc.rej_bits = order_bits(INFINITY);
+    kernel_ms = setup_ms = 0.0;
+    for (int pass = 0; pass < 3; pass++) {
+        HIP_TRY(hipMemcpyAsync(p->d_ctr.p, &hc, sizeof(hc), hipMemcpyHostToDevice, st));
+        HIP_TRY(hipEventRecord(ctx->ev0, st));
+        if (p->n == 2) {
+            unsigned long long nb = (unsigned long long)b, ne = (unsigned long long)e, cnt = ne - nb;
+            unsigned long long want = (unsigned long long)ctx->cu_count * 2048ull * 4ull;  // threads to keep every CU fed
+            unsigned long long per = (cnt + want - 1) / want;
+            if (per < 8) per = 8;
+            if (per > 512) per = 512;
+            HIP_TRY(hipEventRecord(ctx->ev1, st));
+            n2_launch_search(p->n2, A, nb, ne, (int)per, st);
+        } else {
+            u128 cnt = e - b;
+            uint64_t per_task = 4096;
+            u128 nt = (cnt + per_task - 1) / per_task;
+            if (nt > N3_MAX_TASKS) {
+                nt = N3_MAX_TASKS;
+                u128 pt = (cnt + nt - 1) / nt;
+                if (pt > (u128)0x7fffffffffffull) {
+                    theta_set_error("rank range too large for one call (%d tasks of at most 2^47 candidates)", N3_MAX_TASKS);
+                    return THETA_ERR_ARG;
+                }
+                per_task = (uint64_t)pt;
+                nt = (cnt + per_task - 1) / per_task;
+            }
+            int ntasks = (int)nt;
+            n3_launch_tasks(p->n3, b, e, per_task, ntasks, (N3Task *)p->d_tasks.p, (unsigned *)p->d_stbuf.p, st);
+            HIP_TRY(hipEventRecord(ctx->ev1, st));
+            n3_launch_search(p->n3, A, (const N3Task *)p->d_tasks.p, (const unsigned *)p->d_stbuf.p, ntasks, per_task, st);
+        }
+        HIP_TRY(hipEventRecord(ctx->ev2, st));
+        SearchCounters got;
+        HIP_TRY(hipMemcpyAsync(&got, p->d_ctr.p, sizeof(got), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        HIP_TRY(hipGetLastError());
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, ctx->ev1, ctx->ev2));
+        kernel_ms += ms;
+        HIP_TRY(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+        setup_ms += ms;
+        if (got.list_count <= LIST_CAP || pass == 2) {
+            unsigned long long dropped = got.list_count > LIST_CAP ? got.list_count - LIST_CAP : 0;
+            hc = got;
+            hc.pad = (unsigned)std::min<unsigned long long>(dropped, 0xffffffffu);
+            break;
+        }
+        // The list overflowed while the running minimum was still loose: go again with the minimum
+        // found so far as the starting threshold (the kernels lower best_bits even when a record is dropped).
+        SearchCounters keep;
+        memset(&keep, 0, sizeof(keep));
+        keep.best_bits = got.best_bits;
+        keep.rej_bits = order_bits(INFINITY);
+        hc = keep;
+    }
+    unsigned nrec = std::min<unsigned>(hc.list_count, LIST_CAP);
+    recs.resize(nrec);
+    if (nrec) {
+        HIP_TRY(hipMemcpyAsync(recs.data(), p->d_list.p, (size_t)nrec * sizeof(TieRecord), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+    }
+    return THETA_OK;
+}
+
+static const double FLOPS_PER_TERM_ITER_N3 = 26.0;  // see DESIGN.md: 2 sub, 2 fma(q), rcp+NR(1+4), 1 mul, 2 fma, 3 mul, 3 fma
+static const double FLOPS_PER_TERM_ITER_N2 = 10.0;  // fma(den), rcp+NR(5), mul, fma(f), mul+fma(f')
+static const double FLOPS_PER_FINAL_TERM = 4.0;     // fma/fma(q), log, fma(acc)
+
+extern "C" int theta_search(theta_problem *p, const uint64_t rank_begin[2], const uint64_t rank_end[2], double window,
+                            int cap, double *nll, double *mu, uint64_t *rank, uint8_t *C, int *n_out,
+                            theta_search_stats *stats) {
+    u128 b, e;
+    int rc = check_range(p, rank_begin, rank_end, b, e);
+    if (rc) return rc;
+    if (!n_out || cap < 0 || (cap > 0 && (!nll || !mu || !rank || !C))) {
+        theta_set_error("theta_search: null output");
+        return THETA_ERR_ARG;
+    }
+    if (!(window >= 0.0)) {
+        theta_set_error("window must be >= 0");
+        return THETA_ERR_ARG;
+    }
+    HIP_TRY(hipSetDevice(p->ctx->device));
+    *n_out = 0;
+    if (stats) memset(stats, 0, sizeof(*stats));
+    if (b == e) return THETA_OK;
+    SearchCounters hc;
+    std::vector<TieRecord> recs;
+    double kms, sms;
+    rc = run_search(p, b, e, window, nullptr, nullptr, hc, recs, kms, sms);
+    if (rc) return rc;
+    double best = order_unbits(hc.best_bits);
+    if (stats) {
+        stats->evaluated = hc.evaluated;
+        stats->accepted = hc.accepted;
+        stats->degenerate = hc.degenerate;
+        stats->iterations = hc.iterations;
+        stats->terms = hc.terms;
+        stats->list_overflow = hc.pad;
+        double per = (p->n == 2) ? FLOPS_PER_TERM_ITER_N2 : FLOPS_PER_TERM_ITER_N3;
+        stats->flops = (uint64_t)(per * (double)hc.terms + FLOPS_PER_FINAL_TERM * (double)hc.final_terms);
+        stats->best_nll = best;
+        stats->rejected_bound = order_unbits(hc.rej_bits);
+        stats->rejected_rank[0] = hc.rej_rank_lo;
+        stats->rejected_rank[1] = hc.rej_rank_hi;
+        stats->kernel_ms = kms;
+        stats->setup_ms = sms;
+    }
+    // keep what lies within the window of the final minimum, in rank order
+    std::vector<TieRecord> keep;
+    for (const TieRecord &t : recs)
+        if (t.nll <= best + window) keep.push_back(t);
+    std::sort(keep.begin(), keep.end(), [](const TieRecord &x, const TieRecord &y) {
+        return x.rank_hi != y.rank_hi ? x.rank_hi < y.rank_hi : x.rank_lo < y.rank_lo;
+    });
+    *n_out = (int)keep.size();
+    if ((int)keep.size() > cap) {
+        theta_set_error("%zu candidates within the window but capacity is %d", keep.size(), cap);
+        return THETA_ERR_CAPACITY;
+    }
+    if (keep.empty()) return THETA_OK;
+    // materialise their matrices on the device
+    hipStream_t st = p->ctx->stream;
+    size_t cb = (size_t)p->m * (p->n - 1);
+    DevBuf d_rec, d_C;
+    rc = d_rec.alloc(keep.size() * sizeof(TieRecord));
+    if (rc) return rc;
+    rc = d_C.alloc(keep.size() * cb);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(d_rec.p, keep.data(), keep.size() * sizeof(TieRecord), hipMemcpyHostToDevice, st));
+    if (p->n == 2) n2_launch_unrank_list(p->n2, (const TieRecord *)d_rec.p, (int)keep.size(), (unsigned char *)d_C.p, st);
+    else n3_launch_unrank_list(p->n3, (const TieRecord *)d_rec.p, (int)keep.size(), (unsigned char *)d_C.p, st);
+    HIP_TRY(hipMemcpyAsync(C, d_C.p, keep.size() * cb, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(hipGetLastError());
+    for (size_t i = 0; i < keep.size(); i++) {
+        nll[i] = keep[i].nll;
+        for (int j = 0; j < p->n; j++) mu[i * p->n + j] = keep[i].mu[j];
+        rank[2 * i] = keep[i].rank_lo;
+        rank[2 * i + 1] = keep[i].rank_hi;
+    }
+    return THETA_OK;
+}
+
+// Per-candidate dump of the fused kernel (the reference's --GET_VALUES, RunTHetA.py:210-215):
+// nll[count] (NaN = None), mu[count*n].  Diagnostic / parity entry point.
+extern "C" int theta_search_values(theta_problem *p, const uint64_t rank_begin[2], uint64_t count, double *nll,
+                                   double *mu, theta_search_stats *stats) {
+    uint64_t re[2];
+    u128 b0 = rank_begin ? mk128(rank_begin) : 0;
+    u128 e0 = b0 + count;
+    re[0] = (uint64_t)e0;
+    re[1] = (uint64_t)(e0 >> 64);
+    u128 b, e;
+    int rc = check_range(p, rank_begin, re, b, e);
+    if (rc) return rc;
+    if (!nll || !mu) {
+        theta_set_error("null output");
+        return THETA_ERR_ARG;
+    }
+    if (count == 0) return THETA_OK;
+    HIP_TRY(hipSetDevice(p->ctx->device));
+    hipStream_t st = p->ctx->stream;
+    DevBuf d_nll, d_mu;
+    rc = d_nll.alloc(count * sizeof(double));
+    if (rc) return rc;
+    rc = d_mu.alloc(count * p->n * sizeof(double));
+    if (rc) return rc;
+    HIP_TRY(hipMemsetAsync(d_nll.p, 0xff, count * sizeof(double), st));
+    HIP_TRY(hipMemsetAsync(d_mu.p, 0xff, count * p->n * sizeof(double), st));
+    SearchCounters hc;
+    std::vector<TieRecord> recs;
+    double kms, sms;
+    rc = run_search(p, b, e, 0.0, (double *)d_nll.p, (double *)d_mu.p, hc, recs, kms, sms);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(nll, d_nll.p, count * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(mu, d_mu.p, count * p->n * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (stats) {
+        memset(stats, 0, sizeof(*stats));
+        stats->evaluated = hc.evaluated;
+        stats->accepted = hc.accepted;
+        stats->degenerate = hc.degenerate;
+        stats->iterations = hc.iterations;
+        stats->terms = hc.terms;
+        stats->best_nll = order_unbits(hc.best_bits);
+        stats->rejected_bound = order_unbits(hc.rej_bits);
+        stats->kernel_ms = kms;
+        stats->setup_ms = sms;
+    }
+    return THETA_OK;
+}
+
+extern "C" int theta_enumerate(theta_problem *p, const uint64_t rank_begin[2], uint64_t count, uint8_t *out) {
+    uint64_t re[2];
+    u128 b0 = rank_begin ? mk128(rank_begin) : 0;
+    u128 e0 = b0 + count;
+    re[0] = (uint64_t)e0;
+    re[1] = (uint64_t)(e0 >> 64);
+    u128 b, e;
+    int rc = check_range(p, rank_begin, re, b, e);
+    if (rc) return rc;
+    if (count == 0) return THETA_OK;
+    if (!out) {
+        theta_set_error("null output");
+        return THETA_ERR_ARG;
+    }
+    HIP_TRY(hipSetDevice(p->ctx->device));
+    hipStream_t st = p->ctx->stream;
+    size_t cb = (size_t)p->m * (p->n - 1);
+    DevBuf d_C;
+    rc = d_C.alloc(count * cb);
+    if (rc) return rc;
+    if (p->n == 2) n2_launch_enumerate(p->n2, (unsigned long long)b, count, (unsigned char *)d_C.p, st);
+    else n3_launch_enumerate(p->n3, b, count, (unsigned char *)d_C.p, st);
+    HIP_TRY(hipMemcpyAsync(out, d_C.p, count * cb, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(hipGetLastError());
+    return THETA_OK;
+}
+
+// ---- materialised operators -----------------------------------------------------------------------
+extern "C" int theta_solve_batch(theta_ctx *ctx, int n, int m, int tau, const int64_t *r, const int64_t *rN,
+                                 double max_normal, int B, const uint8_t *C, uint8_t *ok, double *mu, double *nll,
+                                 double *vals) {
+    if (!ctx || !r || !rN || !C || !ok || !mu || !nll || B < 0) {
+        theta_set_error("theta_solve_batch: null argument");
+        return THETA_ERR_ARG;
+    }
+    if ((n != 2 && n != 3) || m < 1 || m > 4096) {
+        theta_set_error("theta_solve_batch: bad shape n=%d m=%d", n, m);
+        return THETA_ERR_ARG;
+    }
+    if (B == 0) return THETA_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    std::vector<double> rd(m), rnd(m);
+    for (int i = 0; i < m; i++) {
+        rd[i] = (double)r[i];
+        rnd[i] = (double)rN[i];
+    }
+    size_t cb = (size_t)m * (n - 1);
+    DevBuf d_r, d_rN, d_C, d_ok, d_mu, d_nll, d_vals;
+    int rc;
+    if ((rc = upload(d_r, rd.data(), m * sizeof(double), st))) return rc;
+    if ((rc = upload(d_rN, rnd.data(), m * sizeof(double), st))) return rc;
+    if ((rc = upload(d_C, C, (size_t)B * cb, st))) return rc;
+    if ((rc = d_ok.alloc(B))) return rc;
+    if ((rc = d_mu.alloc((size_t)B * n * sizeof(double)))) return rc;
+    if ((rc = d_nll.alloc((size_t)B * sizeof(double)))) return rc;
+    if (vals && (rc = d_vals.alloc((size_t)B * m * sizeof(double)))) return rc;
+    batch_launch_solve(n, m, tau, (const double *)d_r.p, (const double *)d_rN.p, max_normal, B, (const unsigned char *)d_C.p,
+                       (unsigned char *)d_ok.p, (double *)d_mu.p, (double *)d_nll.p, vals ? (double *)d_vals.p : nullptr, st);
+    HIP_TRY(hipMemcpyAsync(ok, d_ok.p, B, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(mu, d_mu.p, (size_t)B * n * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(nll, d_nll.p, (size_t)B * sizeof(double), hipMemcpyDeviceToHost, st));
+    if (vals) HIP_TRY(hipMemcpyAsync(vals, d_vals.p, (size_t)B * m * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(hipGetLastError());
+    return THETA_OK;
+}
+
+extern "C" int theta_score_batch(theta_ctx *ctx, int n, int m, int B, const double *Cw, const double *mu,
+                                 const double *r, double *nll, double *vals, uint8_t *valid) {
+    if (!ctx || !Cw || !mu || !r || !nll || B < 0) {
+        theta_set_error("theta_score_batch: null argument");
+        return THETA_ERR_ARG;
+    }
+    if ((n != 2 && n != 3) || m < 1) {
+        theta_set_error("theta_score_batch: bad shape n=%d m=%d", n, m);
+        return THETA_ERR_ARG;
+    }
+    if (B == 0) return THETA_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    DevBuf d_C, d_mu, d_r, d_nll, d_vals, d_valid;
+    int rc;
+    if ((rc = upload(d_C, Cw, (size_t)B * m * n * sizeof(double), st))) return rc;
+    if ((rc = upload(d_mu, mu, (size_t)B * n * sizeof(double), st))) return rc;
+    if ((rc = upload(d_r, r, (size_t)m * sizeof(double), st))) return rc;
+    if ((rc = d_nll.alloc((size_t)B * sizeof(double)))) return rc;
+    if (vals && (rc = d_vals.alloc((size_t)B * m * sizeof(double)))) return rc;
+    if (valid && (rc = d_valid.alloc((size_t)B * m))) return rc;
+    batch_launch_score(n, m, B, (const double *)d_C.p, (const double *)d_mu.p, (const double *)d_r.p, (double *)d_nll.p,
+                       vals ? (double *)d_vals.p : nullptr, valid ? (unsigned char *)d_valid.p : nullptr, st);
+    HIP_TRY(hipMemcpyAsync(nll, d_nll.p, (size_t)B * sizeof(double), hipMemcpyDeviceToHost, st));
+    if (vals) HIP_TRY(hipMemcpyAsync(vals, d_vals.p, (size_t)B * m * sizeof(double), hipMemcpyDeviceToHost, st));
+    if (valid) HIP_TRY(hipMemcpyAsync(valid, d_valid.p, (size_t)B * m, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(hipGetLastError());
+    return THETA_OK;
+}
+
+extern "C" int theta_score_masked(theta_ctx *ctx, int n, int m, int tau, int B, int S, const uint8_t *C, const double *w,
+                                  const double *r, const double *mu, const uint64_t *mask, double *nll,
+                                  double *kernel_ms) {
+    if (!ctx || !C || !w || !r || !mu || !nll || B < 0 || S < 1) {
+        theta_set_error("theta_score_masked: bad argument");
+        return THETA_ERR_ARG;
+    }
+    if ((n != 2 && n != 3) || m < 1 || m > 256) {
+        theta_set_error("theta_score_masked: need n in {2,3}, 1 <= m <= 256");
+        return THETA_ERR_ARG;
+    }
+    if (B == 0) return THETA_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    int words = (m + 63) / 64;
+    DevBuf d_C, d_w, d_r, d_mu, d_mask, d_nll;
+    int rc;
+    if ((rc = upload(d_C, C, (size_t)B * m * (n - 1), st))) return rc;
+    if ((rc = upload(d_w, w, (size_t)m * sizeof(double), st))) return rc;
+    if ((rc = upload(d_r, r, (size_t)m * sizeof(double), st))) return rc;
+    if ((rc = upload(d_mu, mu, (size_t)B * n * sizeof(double), st))) return rc;
+    if (mask && (rc = upload(d_mask, mask, (size_t)S * words * sizeof(uint64_t), st))) return rc;
+    if ((rc = d_nll.alloc((size_t)B * S * sizeof(double)))) return rc;
+    HIP_TRY(hipEventRecord(ctx->ev0, st));
+    batch_launch_score_masked(n, m, tau, B, S, (const unsigned char *)d_C.p, (const double *)d_w.p, (const double *)d_r.p,
+                              (const double *)d_mu.p, mask ? (const unsigned long long *)d_mask.p : nullptr,
+                              (double *)d_nll.p, st);
+    HIP_TRY(hipEventRecord(ctx->ev1, st));
+    HIP_TRY(hipMemcpyAsync(nll, d_nll.p, (size_t)B * S * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(hipGetLastError());
+    if (kernel_ms) {
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+        *kernel_ms = ms;
+    }
+    return THETA_OK;
+}

@@ -1,0 +1,336 @@
+// Materialised-candidate operators for gfx950 (compiled with -ffp-contract=off so that the
+// per-interval arithmetic below rounds exactly like the reference's Python/numpy expressions):
+//
+//   solve_batch   Optimizer.solve on B given candidates          Optimizer.py:68-165
+//   score_batch   CalcAllC.L2 / CalcAllC.L3 on literal matrices  CalcAllC.py:44-76
+//   score_masked  the same likelihood on byte candidates x row masks (interval-subset resampling)
+#include "n3_core.hpp"
+
+// ------------------------------------------------------------------------------------------------
+// n = 2: faithful per-interval dL/dnu (Optimizer.py:208-221) + the Bus-Dekker/Brent hyperbolic
+// root finder the reference calls (scipy.optimize.brenth, default xtol=2e-12, rtol=4*eps,
+// maxiter=100), restated from its published algorithm.  One thread per candidate.
+// ------------------------------------------------------------------------------------------------
+struct N2Exact {
+    int m;
+    const double *w0, *rr, *rn;  // rN_i*tau, r_i, rN_i  (LDS)
+    const unsigned char *c;      // the candidate's tumour column (global)
+    double S0, S1;
+    __device__ double f(double x) const {
+        double acc = 0.0;
+        double omx = 1.0 - x;
+        for (int i = 0; i < m; i++) {
+            double a = w0[i] / S0;
+            double b = (rn[i] * (double)c[i]) / S1;
+            double num = rr[i] * (a - b);
+            acc = acc + num / ((a * x) + (b * omx));
+        }
+        return -acc;
+    }
+};
+
+// returns 0 = converged, 1 = sign error, 2 = no convergence, 3 = NaN function value
+__device__ int brenth_root(const N2Exact &F, double xa, double xb, double &root) {
+    const double xtol = 2e-12, rtol = 8.881784197001252e-16;
+    double xpre = xa, xcur = xb, xblk = 0.0, fblk = 0.0, spre = 0.0, scur = 0.0;
+    double fpre = F.f(xpre), fcur = F.f(xcur);
+    if (fpre != fpre || fcur != fcur) return 3;
+    if (fpre == 0.0) { root = xpre; return 0; }
+    if (fcur == 0.0) { root = xcur; return 0; }
+    if (signbit(fpre) == signbit(fcur)) return 1;
+    for (int it = 0; it < 100; it++) {
+        if (fpre != 0.0 && fcur != 0.0 && signbit(fpre) != signbit(fcur)) {
+            xblk = xpre;
+            fblk = fpre;
+            spre = scur = xcur - xpre;
+        }
+        if (fabs(fblk) < fabs(fcur)) {
+            xpre = xcur; xcur = xblk; xblk = xpre;
+            fpre = fcur; fcur = fblk; fblk = fpre;
+        }
+        double delta = (xtol + rtol * fabs(xcur)) / 2.0;
+        double sbis = (xblk - xcur) / 2.0;
+        if (fcur == 0.0 || fabs(sbis) < delta) { root = xcur; return 0; }
+        if (fabs(spre) > delta && fabs(fcur) < fabs(fpre)) {
+            double stry;
+            if (xpre == xblk) {
+                stry = -fcur * (xcur - xpre) / (fcur - fpre);            // secant
+            } else {
+                double dpre = (fpre - fcur) / (xpre - xcur);              // hyperbolic extrapolation
+                double dblk = (fblk - fcur) / (xblk - xcur);
+                stry = -fcur * (fblk - fpre) / (fblk * dpre - fpre * dblk);
+            }
+            double lim = fmin(fabs(spre), 3.0 * fabs(sbis) - delta);
+            if (2.0 * fabs(stry) < lim) { spre = scur; scur = stry; }
+            else { spre = sbis; scur = sbis; }
+        } else {
+            spre = sbis;
+            scur = sbis;
+        }
+        xpre = xcur;
+        fpre = fcur;
+        if (fabs(scur) > delta) xcur += scur;
+        else xcur += (sbis > 0.0 ? delta : -delta);
+        fcur = F.f(xcur);
+        if (fcur != fcur) return 3;
+    }
+    return 2;
+}
+
+__global__ __launch_bounds__(64) void solve_batch_n2_kernel(int m, int tau, const double *r, const double *rN,
+                                                            double max_normal, int B, const unsigned char *C,
+                                                            unsigned char *ok, double *mu, double *nll, double *vals) {
+    extern __shared__ double sm[];
+    double *w0 = sm, *rr = sm + m, *rn = sm + 2 * m;
+    for (int i = threadIdx.x; i < m; i += blockDim.x) {
+        w0[i] = rN[i] * (double)tau;   // weighted_C column 0 (Optimizer.py:176-182)
+        rr[i] = r[i];
+        rn[i] = rN[i];
+    }
+    __syncthreads();
+    int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    N2Exact F;
+    F.m = m; F.w0 = w0; F.rr = rr; F.rn = rn;
+    F.c = C + (size_t)b * m;
+    double S0 = 0.0, S1 = 0.0;
+    for (int i = 0; i < m; i++) {      // normalize_C column sums (Optimizer.py:169)
+        S0 = S0 + w0[i];
+        S1 = S1 + rn[i] * (double)F.c[i];
+    }
+    F.S0 = S0; F.S1 = S1;
+    double lo = 0.0, hi = max_normal;
+    if (hi != 1.0) {                   // M2_Rev (Optimizer.py:228-231)
+        double num = -hi * S0;
+        double den = (hi - 1.0) * S1 + num;
+        hi = num / den;
+    }
+    double root = 0.0;
+    int st = brenth_root(F, lo, hi, root);
+    if (st != 0) {
+        ok[b] = 0;
+        mu[2 * b] = mu[2 * b + 1] = nll[b] = __builtin_nan("");
+        if (vals) for (int i = 0; i < m; i++) vals[(size_t)b * m + i] = __builtin_nan("");
+        return;
+    }
+    double num = -root * S1;           // M2 (Optimizer.py:223-226)
+    double den = (root - 1.0) * S0 + num;
+    double muv = num / den;
+    double mu1 = 1.0 - muv;
+    double dsum = 0.0;                 // L2 (Optimizer.py:187-196)
+    for (int j = 0; j < m; j++) dsum = dsum + (w0[j] * muv + (rn[j] * (double)F.c[j]) * mu1);
+    double tot = 0.0;
+    for (int i = 0; i < m; i++) {
+        double nm = w0[i] * muv + (rn[i] * (double)F.c[i]) * mu1;
+        double p = nm / dsum;
+        tot = tot + rr[i] * log(p);
+        if (vals) vals[(size_t)b * m + i] = p;
+    }
+    ok[b] = 1;
+    mu[2 * b] = muv;
+    mu[2 * b + 1] = mu1;
+    nll[b] = -tot;
+}
+
+// ------------------------------------------------------------------------------------------------
+// n = 3: per-interval Newton (same core as the fused kernel, one likelihood term per interval),
+// admissibility as Optimizer._solve_n3plus (Optimizer.py:150-160), then nu -> mu (closed form of M3)
+// and Optimizer.L3 (Optimizer.py:236-244) in the reference's summation order.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void solve_batch_n3_kernel(int m, int tau, const double *r, const double *rN, int B,
+                                                            const unsigned char *C, unsigned char *ok, double *mu,
+                                                            double *nll, double *vals) {
+    extern __shared__ double sm[];
+    double *rr = sm, *rn = sm + m;
+    for (int i = threadIdx.x; i < m; i += blockDim.x) {
+        rr[i] = r[i];
+        rn[i] = rN[i];
+    }
+    __syncthreads();
+    int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const unsigned char *c = C + (size_t)b * m * 2;
+    double N = 0.0, S1 = 0.0, S2 = 0.0, Rtot = 0.0;
+    for (int i = 0; i < m; i++) {
+        N += rn[i];
+        S1 += rn[i] * (double)c[2 * i];
+        S2 += rn[i] * (double)c[2 * i + 1];
+        Rtot += rr[i];
+    }
+    bool good = !(S1 == 0.0 || S2 == 0.0);
+    N3Newton Sv;
+    double s1 = S1 / N, s2 = S2 / N;
+    if (good) {
+        auto terms = [&](auto &&body) {
+            for (int i = 0; i < m; i++) body((double)c[2 * i], (double)c[2 * i + 1], rr[i]);
+        };
+        Sv.u1 = (1.0 / 3.0) / s1;
+        Sv.u2 = (1.0 / 3.0) / s2;
+        Sv.p1 = Sv.u1; Sv.p2 = Sv.u2;
+        Sv.h11 = Sv.h12 = Sv.h22 = Sv.g1 = Sv.g2 = Sv.lam = 0.0;
+        Sv.iters = 0;
+        Sv.status = 0;
+        while (Sv.status == 0) n3_newton_step(terms, s1, s2, Rtot, Sv);
+        good = (Sv.status == 1) && n3_admissible(Sv, s1, s2);
+    }
+    if (!good) {
+        ok[b] = 0;
+        mu[3 * b] = mu[3 * b + 1] = mu[3 * b + 2] = nll[b] = __builtin_nan("");
+        if (vals) for (int i = 0; i < m; i++) vals[(size_t)b * m + i] = __builtin_nan("");
+        return;
+    }
+    double dtau = (double)tau;
+    double u0 = (1.0 - s1 * Sv.u1 - s2 * Sv.u2) / dtau;
+    double us = u0 + Sv.u1 + Sv.u2;
+    double m0 = u0 / us, m1 = Sv.u1 / us, m2 = Sv.u2 / us;
+    // Optimizer.L3: denom accumulates column by column (for j ... for h ...), numer left to right
+    double den = 0.0;
+    for (int h = 0; h < m; h++) den = den + (rn[h] * dtau) * m0;
+    for (int h = 0; h < m; h++) den = den + (rn[h] * (double)c[2 * h]) * m1;
+    for (int h = 0; h < m; h++) den = den + (rn[h] * (double)c[2 * h + 1]) * m2;
+    double tot = 0.0;
+    for (int i = 0; i < m; i++) {
+        double nm = ((rn[i] * dtau) * m0 + (rn[i] * (double)c[2 * i]) * m1) + (rn[i] * (double)c[2 * i + 1]) * m2;
+        double p = nm / den;
+        tot = tot + rr[i] * log(p);
+        if (vals) vals[(size_t)b * m + i] = p;
+    }
+    ok[b] = 1;
+    mu[3 * b] = m0;
+    mu[3 * b + 1] = m1;
+    mu[3 * b + 2] = m2;
+    nll[b] = -tot;
+}
+
+// ------------------------------------------------------------------------------------------------
+// CalcAllC.L2 / L3 on literal float matrices: one wave per matrix, lanes over rows.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
+    return v;
+}
+
+__global__ __launch_bounds__(64) void score_batch_kernel(int n, int m, int B, const double *Cw, const double *mu,
+                                                         const double *r, double *nll, double *vals,
+                                                         unsigned char *valid) {
+    int b = blockIdx.x;
+    int lane = threadIdx.x;
+    const double *M = Cw + (size_t)b * m * n;
+    const double *mv = mu + (size_t)b * n;
+    double m0 = mv[0];
+    double den = 0.0;
+    // pass 1: C.mu per row and the masked denominator
+    for (int i = lane; i < m; i += WAVE) {
+        double s;
+        bool v;
+        if (n == 2) {
+            v = (m0 != 0.0) ? (M[i * 2] != 0.0) : (M[i * 2 + 1] != 0.0);          // CalcAllC.py:49-52
+            s = M[i * 2] * m0 + M[i * 2 + 1] * (1.0 - m0);                        // CalcAllC.py:54-56
+        } else {
+            v = M[i * 3] != 0.0;                                                  // CalcAllC.py:70
+            s = (M[i * 3] * m0 + M[i * 3 + 1] * mv[1]) + M[i * 3 + 2] * mv[2];    // CalcAllC.py:71
+        }
+        den += s * (v ? 1.0 : 0.0);
+    }
+    den = wave_sum_f64(den);
+    double tot = 0.0;
+    for (int i = lane; i < m; i += WAVE) {
+        double s;
+        bool v;
+        if (n == 2) {
+            v = (m0 != 0.0) ? (M[i * 2] != 0.0) : (M[i * 2 + 1] != 0.0);
+            s = M[i * 2] * m0 + M[i * 2 + 1] * (1.0 - m0);
+        } else {
+            v = M[i * 3] != 0.0;
+            s = (M[i * 3] * m0 + M[i * 3 + 1] * mv[1]) + M[i * 3 + 2] * mv[2];
+        }
+        double p = s / den;
+        tot += (log(p) * (v ? 1.0 : 0.0)) * r[i];   // log(0)*0 = NaN is part of the contract (quirk Q10)
+        if (vals) vals[(size_t)b * m + i] = p;
+        if (valid) valid[(size_t)b * m + i] = v ? 1 : 0;
+    }
+    tot = wave_sum_f64(tot);
+    if (lane == 0) nll[b] = -tot;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Interval-subset resampling: B byte candidates x S row masks.  One wave per candidate: the row
+// terms C.mu and r ln(C.mu) are computed once and kept in registers (4 rows per lane cover
+// m <= 256); every mask then costs one 8-byte word load per lane-row group and three wave sums.
+// ------------------------------------------------------------------------------------------------
+#define SM_ROWS 4
+__global__ __launch_bounds__(256) void score_masked_kernel(int n, int m, int tau, int B, int S, const unsigned char *C,
+                                                           const double *w, const double *r, const double *mu,
+                                                           const unsigned long long *mask, double *nll) {
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + wv;
+    if (b >= B) return;
+    const int nc = n - 1;
+    const unsigned char *c = C + (size_t)b * m * nc;
+    const double *mv = mu + (size_t)b * n;
+    const double m0 = mv[0], m1 = (n == 2) ? 1.0 - mv[0] : mv[1], m2 = (n == 3) ? mv[2] : 0.0;
+    const int words = (m + 63) / 64;
+    double cm[SM_ROWS], tl[SM_ROWS], rr[SM_ROWS], off[SM_ROWS];
+    // row k of this lane is interval k*64 + lane: each mask word is then one coalesced 8-byte load
+#pragma unroll
+    for (int k = 0; k < SM_ROWS; k++) {
+        int i = k * 64 + lane;
+        cm[k] = tl[k] = rr[k] = off[k] = 0.0;
+        if (i < m) {
+            double x = (double)c[i * nc], y = (nc == 2) ? (double)c[i * nc + 1] : 0.0;
+            double tum = x * m1 + y * m2;
+            cm[k] = w[i] * ((double)tau * m0 + tum);
+            off[k] = w[i] * tum;             // value of the row once its column 0 is zeroed
+            rr[k] = r[i];
+            tl[k] = rr[k] * log(cm[k]);
+        }
+    }
+    for (int s = 0; s < S; s++) {
+        double den = 0.0, tot = 0.0, rs = 0.0;
+        bool poison = false;
+#pragma unroll
+        for (int k = 0; k < SM_ROWS; k++) {
+            if (k < words) {
+                unsigned long long wd = mask ? mask[(size_t)s * words + k] : ~0ull;
+                int i = k * 64 + lane;
+                bool on = (wd >> lane) & 1ull;
+                if (i < m) {
+                    if (on) { den += cm[k]; tot += tl[k]; rs += rr[k]; }
+                    else if (!(off[k] > 0.0)) poison = true;   // ln(0) * 0 = NaN in the reference (quirk Q10)
+                }
+            }
+        }
+        den = wave_sum_f64(den);
+        tot = wave_sum_f64(tot);
+        rs = wave_sum_f64(rs);
+        bool anyp = ballot64(poison) != 0ull;
+        if (lane == 0) nll[(size_t)b * S + s] = anyp ? __builtin_nan("") : -(tot - rs * log(den));
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------------
+void batch_launch_solve(int n, int m, int tau, const double *r, const double *rN, double max_normal, int B,
+                        const unsigned char *C, unsigned char *ok, double *mu, double *nll, double *vals,
+                        hipStream_t st) {
+    unsigned blocks = (unsigned)((B + 63) / 64);
+    if (n == 2)
+        hipLaunchKernelGGL(solve_batch_n2_kernel, dim3(blocks), dim3(64), (size_t)m * 3 * sizeof(double), st, m, tau, r, rN,
+                           max_normal, B, C, ok, mu, nll, vals);
+    else
+        hipLaunchKernelGGL(solve_batch_n3_kernel, dim3(blocks), dim3(64), (size_t)m * 2 * sizeof(double), st, m, tau, r, rN,
+                           B, C, ok, mu, nll, vals);
+}
+
+void batch_launch_score(int n, int m, int B, const double *Cw, const double *mu, const double *r, double *nll,
+                        double *vals, unsigned char *valid, hipStream_t st) {
+    hipLaunchKernelGGL(score_batch_kernel, dim3(B), dim3(64), 0, st, n, m, B, Cw, mu, r, nll, vals, valid);
+}
+
+void batch_launch_score_masked(int n, int m, int tau, int B, int S, const unsigned char *C, const double *w,
+                               const double *r, const double *mu, const unsigned long long *mask, double *nll,
+                               hipStream_t st) {
+    hipLaunchKernelGGL(score_masked_kernel, dim3((B + 3) / 4), dim3(256), 0, st, n, m, tau, B, S, C, w, r, mu, mask, nll);
+}

@@ -1,0 +1,180 @@
+// Shared helpers for libtheta_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+#include "../../include/theta_hip.h"
+
+typedef unsigned __int128 u128;
+
+// ---------------------------------------------------------------------------------------------
+// host side: error plumbing
+// ---------------------------------------------------------------------------------------------
+void theta_set_error(const char *fmt, ...);
+
+#define HIP_TRY(expr)                                                                       \
+    do {                                                                                    \
+        hipError_t _e = (expr);                                                             \
+        if (_e != hipSuccess) {                                                             \
+            theta_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, \
+                            __LINE__);                                                      \
+            return THETA_ERR_HIP;                                                           \
+        }                                                                                   \
+    } while (0)
+
+struct theta_ctx {
+    int device;
+    hipStream_t stream;
+    hipEvent_t ev0, ev1, ev2;
+    int cu_count;
+    uint64_t hbm_bytes;
+    char name[128];
+};
+
+// Device buffer that frees itself (host RAII; one search instance owns a handful of these).
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+    int alloc(size_t n) {
+        release();
+        if (n == 0) n = 8;
+        hipError_t e = hipMalloc(&p, n);
+        if (e != hipSuccess) {
+            p = nullptr;
+            theta_set_error("hipMalloc(%zu bytes) failed: %s", n, hipGetErrorString(e));
+            return THETA_ERR_HIP;
+        }
+        bytes = n;
+        return THETA_OK;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+    ~DevBuf() { release(); }
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+};
+
+// Record the search kernels append to the device-side tie list.
+struct TieRecord {
+    uint64_t rank_lo, rank_hi;
+    double nll;
+    double mu[3];
+};
+
+// Counters every search kernel accumulates (one instance in HBM, zeroed per call).
+struct SearchCounters {
+    unsigned long long evaluated, accepted, degenerate, iterations, terms, final_terms;
+    unsigned long long best_bits;      // order-preserving bits of the smallest accepted NLL
+    unsigned long long rej_bits;       // same for the smallest rejected lower bound
+    unsigned long long rej_rank_lo, rej_rank_hi;
+    unsigned int list_count;           // records appended (may exceed capacity)
+    unsigned int pad;
+};
+
+// What a search kernel writes to (all device pointers).
+struct SearchArgs {
+    SearchCounters *ctr;
+    TieRecord *list;
+    unsigned list_cap;
+    double window;
+    double *dump_nll;  // optional per-candidate dump (the reference's --GET_VALUES), else null
+    double *dump_mu;
+};
+
+// ---------------------------------------------------------------------------------------------
+// device side
+// ---------------------------------------------------------------------------------------------
+#define WAVE 64
+
+// Monotone map double -> uint64 (so unsigned atomicMin orders doubles, negatives included).
+__host__ __device__ inline unsigned long long order_bits(double x) {
+    unsigned long long b;
+    memcpy(&b, &x, 8);
+    return (b & 0x8000000000000000ull) ? ~b : (b | 0x8000000000000000ull);
+}
+__host__ __device__ inline double order_unbits(unsigned long long b) {
+    b = (b & 0x8000000000000000ull) ? (b & 0x7fffffffffffffffull) : ~b;
+    double x;
+    memcpy(&x, &b, 8);
+    return x;
+}
+
+#ifdef __HIPCC__
+// 1/x to ~2^-44 relative: v_rcp_f64 seed + one Newton-Raphson step.  Used only inside solver
+// iterations, where the fixed point -- not each iterate -- decides the answer.
+__device__ __forceinline__ double rcp_nr1(double x) {
+    double y = __builtin_amdgcn_rcp(x);
+    double e = __builtin_fma(-x, y, 1.0);
+    return __builtin_fma(y, e, y);
+}
+// Two steps: full double accuracy (final values).
+__device__ __forceinline__ double rcp_nr2(double x) {
+    double y = __builtin_amdgcn_rcp(x);
+    double e = __builtin_fma(-x, y, 1.0);
+    y = __builtin_fma(y, e, y);
+    e = __builtin_fma(-x, y, 1.0);
+    return __builtin_fma(y, e, y);
+}
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & (WAVE - 1); }
+
+// number of set bits of `mask` strictly below this lane
+__device__ __forceinline__ int mbcnt(unsigned long long mask) {
+    return __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+}
+
+__device__ __forceinline__ unsigned long long ballot64(bool p) { return __ballot(p); }
+
+__device__ __forceinline__ double wave_min(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o, WAVE));
+    return v;
+}
+__device__ __forceinline__ long long wave_sum_i64(long long v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
+    return v;
+}
+__device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
+    return v;
+}
+
+// LDS hand-off between lanes of ONE wave (no other wave involved): make the compiler keep the
+// order and wait for the LDS queue.  Waves of a block run independent tasks, so __syncthreads()
+// is not usable here.
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+__device__ __forceinline__ unsigned long long load_agent_u64(const unsigned long long *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Append one record to the device tie list and lower the global best (device scope atomics).
+__device__ __forceinline__ void tie_append(SearchCounters *ctr, TieRecord *list, unsigned cap, u128 rank,
+                                           double nll, double mu0, double mu1, double mu2) {
+    unsigned idx = atomicAdd(&ctr->list_count, 1u);
+    if (idx < cap) {
+        TieRecord rec;
+        rec.rank_lo = (uint64_t)rank;
+        rec.rank_hi = (uint64_t)(rank >> 64);
+        rec.nll = nll;
+        rec.mu[0] = mu0;
+        rec.mu[1] = mu1;
+        rec.mu[2] = mu2;
+        list[idx] = rec;
+    }
+}
+#endif

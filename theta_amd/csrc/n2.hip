@@ -1,0 +1,382 @@
+// n = 2 fused search for gfx950: rank -> candidate unranking, colex successor on run
+// break-points, group-aggregated root solve of dL/dnu, NLL, running minimum + tie list.
+//
+// Reference operators replaced (file:line into the reference's python/):
+//   Enumerator._generate_next_C_2 / _C_to_array      Enumerator.py:119-160
+//   Optimizer._solve_n2, dL_dMu, M2, M2_Rev, L2       Optimizer.py:90-126, 187-231
+//   the running minimum of do_optimization_single     RunTHetA.py:191-208
+//
+// A candidate is a non-decreasing column c_0..c_{m-1}; intervals with the same copy number v form
+// one contiguous run [s_v, s_{v+1}).  Every likelihood sum of the reference factorises over these
+// runs: with R_v = sum r_i and N_v = sum rN_i over the run (exact integers from prefix sums),
+//   dL/dnu(x) = -sum_v R_v (sigma - v) / (v + x (sigma - v)),     sigma = sum_v v N_v / sum rN
+//   NLL       = K0 - sum_v R_v ln(tau mu + v (1-mu)) + Rtot ln(tau mu + sigma (1-mu))
+// so one candidate costs O(k) instead of O(m) and touches no HBM.
+#include "n2.hpp"
+
+// ------------------------------------------------------------------------------------------------
+// host: order-adjusted bounds + cumulative counts
+// ------------------------------------------------------------------------------------------------
+int n2_build_host(int m, const int32_t *lb_in, const int32_t *ub_in, N2Host &h) {
+    h.m = m;
+    h.lb.assign(lb_in, lb_in + m);
+    h.ub.assign(ub_in, ub_in + m);
+    for (int i = 1; i < m; i++)
+        if (h.lb[i] < h.lb[i - 1]) h.lb[i] = h.lb[i - 1];
+    for (int i = m - 2; i >= 0; i--)
+        if (h.ub[i] > h.ub[i + 1]) h.ub[i] = h.ub[i + 1];
+    int top = 0;
+    for (int i = 0; i < m; i++) {
+        if (h.lb[i] < 0 || h.ub[i] > THETA_MAX_COPY) {
+            theta_set_error("copy-number bounds must lie in [0, %d] (interval %d: [%d, %d])", THETA_MAX_COPY, i,
+                            h.lb[i], h.ub[i]);
+            return THETA_ERR_ARG;
+        }
+        if (h.ub[i] > top) top = h.ub[i];
+    }
+    h.kv = top + 1;
+    h.P.assign((size_t)m * N2_KVS, 0);
+    // W = number of admissible prefixes ending in value v; P = its running sum over v.
+    unsigned long long W[N2_KVS], Wn[N2_KVS];
+    for (int v = 0; v < N2_KVS; v++) W[v] = (v >= h.lb[0] && v <= h.ub[0]) ? 1 : 0;
+    for (int i = 0; i < m; i++) {
+        if (i > 0) {
+            unsigned long long run = 0;
+            for (int v = 0; v < N2_KVS; v++) {
+                unsigned long long nr = run + W[v];
+                if (nr < run) {
+                    theta_set_error("n=2 candidate count exceeds 64 bits");
+                    return THETA_ERR_OVERFLOW;
+                }
+                run = nr;
+                Wn[v] = (v >= h.lb[i] && v <= h.ub[i]) ? run : 0;
+            }
+            memcpy(W, Wn, sizeof(W));
+        }
+        unsigned long long cum = 0;
+        for (int v = 0; v < N2_KVS; v++) {
+            unsigned long long nc = cum + W[v];
+            if (nc < cum) {
+                theta_set_error("n=2 candidate count exceeds 64 bits");
+                return THETA_ERR_OVERFLOW;
+            }
+            cum = nc;
+            h.P[(size_t)i * N2_KVS + v] = cum;
+        }
+    }
+    h.total = h.P[(size_t)(m - 1) * N2_KVS + (N2_KVS - 1)];
+    return THETA_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// device
+// ------------------------------------------------------------------------------------------------
+template <int KV>
+struct N2Cand {
+    int s[KV + 1];  // s[v] = first position with c >= v; s[KV] = m
+};
+
+// Rank -> break-points (colex order: c_{m-1} is the most significant digit).
+template <int KV>
+__device__ void n2_unrank(const N2Dev &P, const unsigned long long *Pl, unsigned long long rho, N2Cand<KV> &c) {
+#pragma unroll
+    for (int v = 0; v <= KV; v++) c.s[v] = P.m;
+    c.s[0] = 0;
+    for (int i = P.m - 1; i >= 0; i--) {
+        const unsigned long long *row = Pl + i * N2_KVS;
+        int v = 0;
+        while (v < KV - 1 && row[v] <= rho) v++;  // smallest v with P[i][v] > rho
+        if (v > 0) rho -= row[v - 1];
+#pragma unroll
+        for (int w = 1; w < KV; w++)
+            if (w <= v) c.s[w] = i;  // c_i >= w, and i decreases, so the last write is the first position
+    }
+}
+
+// The reference's successor (Enumerator.py:134-152) on the break-point form. Returns false at the end.
+template <int KV>
+__device__ bool n2_next(const N2Dev &P, const unsigned char *ubl, const short *lbposl, N2Cand<KV> &c) {
+    int e = -1, nv = 0;
+#pragma unroll
+    for (int v = 0; v < KV; v++) {
+        if (e < 0 && c.s[v + 1] > c.s[v]) {  // first run not yet handled
+            int end = c.s[v + 1] - 1;
+            if (v < (int)ubl[end]) {
+                e = end;
+                nv = v + 1;
+            } else if (end == P.m - 1) {
+                return false;  // last run cannot be raised: enumeration exhausted
+            }
+        }
+    }
+    if (e < 0) return false;
+#pragma unroll
+    for (int w = 1; w < KV; w++) {
+        int lp = lbposl[w];
+        c.s[w] = (lp < e) ? lp : ((w <= nv) ? e : c.s[w]);
+    }
+    return true;
+}
+
+struct N2Result {
+    bool ok, degenerate;
+    double mu, nll;
+    int iters, terms;
+};
+
+// Group-aggregated restatement of Optimizer._solve_n2 (Optimizer.py:90-126).
+template <int KV>
+__device__ N2Result n2_solve(const N2Dev &P, const double *PRl, const double *PNl, const N2Cand<KV> &c) {
+    N2Result out;
+    out.ok = false;
+    out.degenerate = false;
+    out.mu = 0;
+    out.nll = 0;
+    out.iters = 0;
+    double R[KV], w[KV];
+    double S1 = 0;
+    int ng = 0;
+#pragma unroll
+    for (int v = 0; v < KV; v++) {
+        int a = c.s[v], b = c.s[v + 1];
+        double Nv = PNl[b] - PNl[a];
+        R[v] = PRl[b] - PRl[a];
+        S1 += (double)v * Nv;
+        ng += (b > a);
+    }
+    out.terms = ng;
+    if (S1 == 0.0) {  // all-zero tumour column: the reference's Chat is NaN -> brenth raises -> None (quirk Q4)
+        out.degenerate = true;
+        return out;
+    }
+    const double sigma = S1 / P.N;
+    const double tau = (double)P.tau;
+#pragma unroll
+    for (int v = 0; v < KV; v++) w[v] = sigma - (double)v;
+
+    // bracket [lo, hi] in nu-space; hi = M2_Rev(max_normal) (Optimizer.py:107-110, 228-231)
+    double lo = 0.0, hi = 1.0;
+    if (P.max_normal != 1.0) hi = P.max_normal * tau / ((1.0 - P.max_normal) * sigma + P.max_normal * tau);
+
+    auto feval = [&](double x, double &fp) {
+        double f = 0.0;
+        fp = 0.0;
+#pragma unroll
+        for (int v = 0; v < KV; v++) {
+            if (R[v] != 0.0) {
+                double den = __builtin_fma(x, w[v], (double)v);
+                double t = w[v] / den;  // exact division: the bracket test must see +-inf at a pole
+                f = __builtin_fma(-R[v], t, f);
+                fp = __builtin_fma(R[v] * t, t, fp);
+            }
+        }
+        return f;
+    };
+    double fp;
+    double flo = feval(lo, fp);
+    double fhi = feval(hi, fp);
+    double x;
+    if (flo == 0.0) {
+        x = lo;  // brenth returns the left end when f(lo) == 0 (proportional columns, quirk Q3)
+    } else if (fhi == 0.0) {
+        x = hi;
+    } else if (flo != flo || fhi != fhi || (flo < 0) == (fhi < 0)) {
+        return out;  // no sign change on [lo, hi]: brenth raises -> None (quirk Q6)
+    } else {
+        // f is increasing; keep f(a) < 0 < f(b).  Newton with bisection safeguard.
+        double a = lo, b = hi;
+        x = 0.5 * (a + b);
+        for (int it = 0; it < 100; it++) {
+            out.iters++;
+            double f = 0.0, d = 0.0;
+#pragma unroll
+            for (int v = 0; v < KV; v++) {
+                if (R[v] != 0.0) {
+                    double den = __builtin_fma(x, w[v], (double)v);
+                    double t = w[v] * rcp_nr1(den);
+                    f = __builtin_fma(-R[v], t, f);
+                    d = __builtin_fma(R[v] * t, t, d);
+                }
+            }
+            if (f == 0.0) break;
+            if (f < 0) a = x; else b = x;
+            double xn = x - f / d;
+            if (!(xn > a && xn < b)) xn = 0.5 * (a + b);
+            double dx = fabs(xn - x);
+            x = xn;
+            if (dx <= 2e-16 * fmax(x, 1e-300) || b - a <= 1e-300) break;
+        }
+    }
+    // nu -> mu (M2, Optimizer.py:223-226) and the NLL (L2, Optimizer.py:187-196) in group form
+    double mu = x * sigma / ((1.0 - x) * tau + x * sigma);
+    double nu1 = 1.0 - mu;
+    double acc = 0.0;
+#pragma unroll
+    for (int v = 0; v < KV; v++)
+        if (R[v] != 0.0) acc = __builtin_fma(R[v], log(__builtin_fma((double)v, nu1, tau * mu)), acc);
+    out.nll = P.K0 - acc + P.Rtot * log(__builtin_fma(sigma, nu1, tau * mu));
+    out.mu = mu;
+    out.ok = true;
+    return out;
+}
+
+template <int KV>
+__global__ __launch_bounds__(256) void n2_search_kernel(N2Dev P, SearchArgs A, unsigned long long begin,
+                                                        unsigned long long end, int per_thread) {
+    extern __shared__ unsigned char smem[];
+    // LDS staging of everything the candidates share
+    double *PRl = (double *)smem;
+    double *PNl = PRl + (P.m + 1);
+    unsigned long long *Pl = (unsigned long long *)(PNl + (P.m + 1));
+    short *lbposl = (short *)(Pl + (size_t)P.m * N2_KVS);
+    unsigned char *ubl = (unsigned char *)(lbposl + (N2_KVS + 1) + 3);
+    for (int i = threadIdx.x; i <= P.m; i += blockDim.x) {
+        PRl[i] = P.PR[i];
+        PNl[i] = P.PN[i];
+    }
+    for (int i = threadIdx.x; i < P.m * N2_KVS; i += blockDim.x) Pl[i] = P.P[i];
+    for (int i = threadIdx.x; i <= N2_KVS; i += blockDim.x) lbposl[i] = P.lbpos[i];
+    for (int i = threadIdx.x; i < P.m; i += blockDim.x) ubl[i] = P.ub[i];
+    __syncthreads();
+
+    unsigned long long tid = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long t0 = begin + tid * (unsigned long long)per_thread;
+    unsigned long long n_eval = 0, n_acc = 0, n_deg = 0, n_it = 0, n_terms = 0, n_fin = 0;
+    if (t0 < end) {
+        unsigned long long t1 = t0 + (unsigned long long)per_thread;
+        if (t1 > end) t1 = end;
+        N2Cand<KV> c;
+        n2_unrank<KV>(P, Pl, t0, c);
+        double best = order_unbits(load_agent_u64(&A.ctr->best_bits));
+        for (unsigned long long rank = t0; rank < t1; rank++) {
+            N2Result rs = n2_solve<KV>(P, PRl, PNl, c);
+            n_eval++;
+            n_it += rs.iters;
+            n_terms += (unsigned long long)rs.iters * rs.terms;
+            n_deg += rs.degenerate;
+            if (rs.ok) {
+                n_acc++;
+                n_fin += rs.terms + 1;
+                if (rs.nll <= best + A.window) {
+                    // refresh: another thread may have lowered the global minimum meanwhile
+                    best = fmin(best, order_unbits(load_agent_u64(&A.ctr->best_bits)));
+                    if (rs.nll <= best + A.window) {
+                        tie_append(A.ctr, A.list, A.list_cap, (u128)rank, rs.nll, rs.mu, 1.0 - rs.mu, 0.0);
+                        if (rs.nll < best) {
+                            atomicMin(&A.ctr->best_bits, order_bits(rs.nll));
+                            best = rs.nll;
+                        }
+                    }
+                }
+            }
+            if (A.dump_nll) {
+                A.dump_nll[rank - begin] = rs.ok ? rs.nll : __builtin_nan("");
+                A.dump_mu[(rank - begin) * 2] = rs.ok ? rs.mu : __builtin_nan("");
+                A.dump_mu[(rank - begin) * 2 + 1] = rs.ok ? 1.0 - rs.mu : __builtin_nan("");
+            }
+            if (rank + 1 < t1 && !n2_next<KV>(P, ubl, lbposl, c)) break;
+        }
+    }
+    // one atomic per wave per counter
+    n_eval = wave_sum_u64(n_eval);
+    n_acc = wave_sum_u64(n_acc);
+    n_deg = wave_sum_u64(n_deg);
+    n_it = wave_sum_u64(n_it);
+    n_terms = wave_sum_u64(n_terms);
+    n_fin = wave_sum_u64(n_fin);
+    if (lane_id() == 0 && n_eval) {
+        atomicAdd(&A.ctr->evaluated, n_eval);
+        atomicAdd(&A.ctr->accepted, n_acc);
+        atomicAdd(&A.ctr->degenerate, n_deg);
+        atomicAdd(&A.ctr->iterations, n_it);
+        atomicAdd(&A.ctr->terms, n_terms);
+        atomicAdd(&A.ctr->final_terms, n_fin);
+    }
+}
+
+// Materialise candidates: thread t writes `per_thread` consecutive candidates starting at begin+t*per_thread.
+template <int KV>
+__global__ __launch_bounds__(256) void n2_enumerate_kernel(N2Dev P, unsigned long long begin, unsigned long long count,
+                                                           int per_thread, unsigned char *out) {
+    extern __shared__ unsigned char smem[];
+    unsigned long long *Pl = (unsigned long long *)smem;
+    short *lbposl = (short *)(Pl + (size_t)P.m * N2_KVS);
+    unsigned char *ubl = (unsigned char *)(lbposl + (N2_KVS + 1) + 3);
+    for (int i = threadIdx.x; i < P.m * N2_KVS; i += blockDim.x) Pl[i] = P.P[i];
+    for (int i = threadIdx.x; i <= N2_KVS; i += blockDim.x) lbposl[i] = P.lbpos[i];
+    for (int i = threadIdx.x; i < P.m; i += blockDim.x) ubl[i] = P.ub[i];
+    __syncthreads();
+    unsigned long long tid = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long k0 = tid * (unsigned long long)per_thread;
+    if (k0 >= count) return;
+    unsigned long long k1 = k0 + per_thread;
+    if (k1 > count) k1 = count;
+    N2Cand<KV> c;
+    n2_unrank<KV>(P, Pl, begin + k0, c);
+    for (unsigned long long k = k0; k < k1; k++) {
+        unsigned char *dst = out + k * (unsigned long long)P.m;
+        // value at position i = number of v >= 1 with s[v] <= i
+        for (int i = 0; i < P.m; i++) {
+            int val = 0;
+#pragma unroll
+            for (int v = 1; v < KV; v++) val += (c.s[v] <= i);
+            dst[i] = (unsigned char)val;
+        }
+        if (k + 1 < k1 && !n2_next<KV>(P, ubl, lbposl, c)) break;
+    }
+}
+
+// Candidates for an explicit list of ranks (tie-list materialisation).
+template <int KV>
+__global__ __launch_bounds__(64) void n2_unrank_list_kernel(N2Dev P, const TieRecord *recs, int count, unsigned char *out) {
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= count) return;
+    N2Cand<KV> c;
+    n2_unrank<KV>(P, P.P, recs[k].rank_lo, c);
+    unsigned char *dst = out + (size_t)k * P.m;
+    for (int i = 0; i < P.m; i++) {
+        int val = 0;
+#pragma unroll
+        for (int v = 1; v < KV; v++) val += (c.s[v] <= i);
+        dst[i] = (unsigned char)val;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------------
+static size_t n2_smem_bytes(const N2Dev &P) {
+    return (size_t)(P.m + 1) * 16 + (size_t)P.m * N2_KVS * 8 + (N2_KVS + 1 + 3) * 2 + P.m + 16;
+}
+
+void n2_launch_search(const N2Dev &P, const SearchArgs &A, unsigned long long begin, unsigned long long end,
+                      int per_thread, hipStream_t st) {
+    unsigned long long n = end - begin;
+    unsigned long long threads = (n + per_thread - 1) / per_thread;
+    unsigned blocks = (unsigned)((threads + 255) / 256);
+    size_t sm = n2_smem_bytes(P);
+    if (P.kv <= 8)
+        hipLaunchKernelGGL(n2_search_kernel<8>, dim3(blocks), dim3(256), sm, st, P, A, begin, end, per_thread);
+    else
+        hipLaunchKernelGGL(n2_search_kernel<16>, dim3(blocks), dim3(256), sm, st, P, A, begin, end, per_thread);
+}
+
+void n2_launch_enumerate(const N2Dev &P, unsigned long long begin, unsigned long long count, unsigned char *out,
+                         hipStream_t st) {
+    const int per_thread = 16;
+    unsigned long long threads = (count + per_thread - 1) / per_thread;
+    unsigned blocks = (unsigned)((threads + 255) / 256);
+    size_t sm = n2_smem_bytes(P);
+    if (P.kv <= 8)
+        hipLaunchKernelGGL(n2_enumerate_kernel<8>, dim3(blocks), dim3(256), sm, st, P, begin, count, per_thread, out);
+    else
+        hipLaunchKernelGGL(n2_enumerate_kernel<16>, dim3(blocks), dim3(256), sm, st, P, begin, count, per_thread, out);
+}
+
+void n2_launch_unrank_list(const N2Dev &P, const TieRecord *recs, int count, unsigned char *out, hipStream_t st) {
+    unsigned blocks = (unsigned)((count + 63) / 64);
+    if (P.kv <= 8)
+        hipLaunchKernelGGL(n2_unrank_list_kernel<8>, dim3(blocks), dim3(64), 0, st, P, recs, count, out);
+    else
+        hipLaunchKernelGGL(n2_unrank_list_kernel<16>, dim3(blocks), dim3(64), 0, st, P, recs, count, out);
+}

@@ -1,0 +1,196 @@
+// n = 3: pieces shared by the fused search kernel (n3.hip) and the per-candidate batch solver
+// (batch.hip): the row alphabet / edge rules of the reference's enumerator and the Newton core of
+// the mixture solve.
+#pragma once
+#include "common.hpp"
+
+#define N3_MAX_K 8               // largest copy number in an n=3 search (alphabet (K+1)^2 <= 81)
+#define N3_MAX_Q ((N3_MAX_K + 1) * (N3_MAX_K + 1))
+#define N3_MAX_M 64              // one interval per lane
+#define N3_RIDX_W (2 * N3_MAX_K + 1)
+
+// Wave-uniform description of one n=3 search instance.
+struct N3Dev {
+    int m, K, Q, tau;            // Q = (K+1)^2 grid slots; slot s <-> row (a, b) = (s % (K+1), s / (K+1))
+    int NT;                      // number of distinct finite ratio values; lo in [0..NT], hi in [1..NT+1]
+    int L;                       // levels enumerated by lanes (leaf levels); D = m - L prefix levels
+    double N, Rtot, K0;
+    const double *r, *rN;        // [m] as doubles (exact)
+    const unsigned char *lb, *ub;   // [m] order-adjusted bounds
+    const unsigned char *ridx;   // [N3_RIDX_W * N3_RIDX_W] rank of the ratio dy/(-dx) in the sorted table (1-based)
+    const u128 *cnt;             // [m][Q][2][NT+1][NT+1] completions below a DFS node
+    unsigned long long total_lo, total_hi;
+};
+
+__host__ __device__ inline size_t n3_cnt_index(const N3Dev &P, int d, int slot, int sw, int lo, int hi) {
+    // lo in [0..NT] (0 = -inf), hi in [1..NT+1] (NT+1 = +inf) stored as hi-1
+    return ((((size_t)d * P.Q + slot) * 2 + sw) * (P.NT + 1) + lo) * (P.NT + 1) + (hi - 1);
+}
+
+struct N3Task {
+    uint64_t base_lo, base_hi;   // rank of the first candidate of the task
+    uint64_t count;              // candidates in the task
+    uint64_t skip;               // leaves of the first prefix that precede base
+};
+
+struct N3Host {
+    int m = 0, K = 0, Q = 0, NT = 0;
+    std::vector<int> lb, ub;
+    std::vector<unsigned char> ridx;
+};
+
+struct N3State {
+    int slot;   // row at this depth
+    int sw;     // 1 while every row so far had a == b (Enumerator.py:181-183,199-202)
+    int lo, hi; // feasible interval of the ratio mu1/mu2 as ranks in the sorted ratio table
+};
+
+// Enumerator._is_valid_row with allow_multi_event hard-wired True (Enumerator.py:55,262-264,286).
+__host__ __device__ inline bool n3_valid_row(int a, int b, int tau) { return (tau - a) * (tau - b) >= 0; }
+
+// First row of a matrix (Enumerator.py:175-186): in bounds, a <= b.
+__host__ __device__ inline bool n3_first_row(const N3Dev &P, int slot, N3State &out) {
+    int K1 = P.K + 1, a = slot % K1, b = slot / K1;
+    if (!n3_valid_row(a, b, P.tau)) return false;
+    int l = P.lb[0], u = P.ub[0];
+    if (a < l || a > u || b < l || b > u) return false;
+    if (a > b) return false;
+    out.slot = slot;
+    out.sw = (a == b);
+    out.lo = 0;
+    out.hi = P.NT + 1;
+    return true;
+}
+
+// One DFS edge (Enumerator.py:192-212): may row `slot` at depth d follow state `par`?
+__host__ __device__ inline bool n3_edge(const N3Dev &P, const N3State &par, int slot, int d, N3State &out) {
+    int K1 = P.K + 1, a = slot % K1, b = slot / K1;
+    if (!n3_valid_row(a, b, P.tau)) return false;
+    int l = P.lb[d], u = P.ub[d];
+    if (a < l || a > u || b < l || b > u) return false;            // _in_bounds, :241
+    int pa = par.slot % K1, pb = par.slot / K1;
+    if (!(slot == par.slot || a > pa || b > pb)) return false;     // _is_valid_edge, :258-260
+    int sw = 0;
+    if (par.sw) {                                                  // symmetry breaking, :199-202
+        if (a > b) return false;
+        sw = (a == b);
+    }
+    int lo = par.lo, hi = par.hi;
+    int dx = a - pa, dy = b - pb;
+    if (dx != 0 && dy != 0) {                                      // _get_mu_bounds, :225-239
+        int t = P.ridx[(dy + N3_MAX_K) * N3_RIDX_W + (dx + N3_MAX_K)];
+        if (dx > 0) lo = (t > lo) ? t : lo; else hi = (t < hi) ? t : hi;
+    }
+    if (lo > hi) return false;                                     // :212
+    out.slot = slot;
+    out.sw = sw;
+    out.lo = lo;
+    out.hi = hi;
+    return true;
+}
+
+#ifdef __HIPCC__
+// ---------------------------------------------------------------------------------------------
+// Mixture solve for n = 3 in the scaled variables u_j = nu_j N / S_j (S_j = column sums of the
+// weighted matrix, sigma_j = S_j / N):  with u_0 eliminated through sum_j sigma_j u_j = 1,
+//      p_i = (rN_i / N) q_i,     q_i = 1 + (x_i - sigma_1) u_1 + (y_i - sigma_2) u_2,
+//      NLL(u) = K0 - sum_i r_i ln q_i      (convex; R-weighted log barrier => self-concordant)
+// One Newton step of that 2-D problem.  `terms(body)` calls body(x, y, R) for every likelihood
+// term (interval or group of intervals sharing a row).  Restates the stationarity system of
+// Optimizer.equations / jacobian (Optimizer.py:273-316) after eliminating the multiplier.
+// ---------------------------------------------------------------------------------------------
+struct N3Newton {
+    double u1, u2;       // current iterate
+    double p1, p2;       // previous feasible iterate (for the q <= 0 safeguard)
+    double h11, h12, h22, g1, g2;
+    double lam;          // Newton decrement of NLL / Rtot
+    int iters;
+    int status;          // 0 running, 1 converged, 2 failed (diverged / iteration cap)
+};
+
+#define N3_MAX_ITERS 60
+
+template <class Terms>
+__device__ __forceinline__ void n3_newton_step(Terms &&terms, double s1, double s2, double Rtot, N3Newton &S) {
+    double g1 = 0, g2 = 0, h11 = 0, h12 = 0, h22 = 0;
+    bool bad = false;
+    const double u1 = S.u1, u2 = S.u2;
+    terms([&](double x, double y, double R) {
+        double a = x - s1, b = y - s2;
+        double q = __builtin_fma(a, u1, __builtin_fma(b, u2, 1.0));
+        bad |= !(q > 0.0);
+        double w = rcp_nr1(q);
+        double t = R * w;
+        g1 = __builtin_fma(t, a, g1);
+        g2 = __builtin_fma(t, b, g2);
+        double tw = t * w;
+        double ta = tw * a, tb = tw * b;
+        h11 = __builtin_fma(ta, a, h11);
+        h12 = __builtin_fma(ta, b, h12);
+        h22 = __builtin_fma(tb, b, h22);
+    });
+    S.iters++;
+    if (bad) {  // stepped out of the domain (only possible through round-off): halve the step
+        S.u1 = 0.5 * (S.u1 + S.p1);
+        S.u2 = 0.5 * (S.u2 + S.p2);
+        if (S.iters >= N3_MAX_ITERS) S.status = 2;
+        return;
+    }
+    S.g1 = g1; S.g2 = g2; S.h11 = h11; S.h12 = h12; S.h22 = h22;
+    if (h11 + h22 == 0.0) {  // every row equals (sigma1, sigma2): the likelihood does not depend on u
+        S.lam = 0.0;
+        S.status = 1;
+        return;
+    }
+    double reg = 1e-13 * (h11 + h22);              // Levenberg floor: rank-deficient candidates stay solvable
+    double a11 = h11 + reg, a22 = h22 + reg;
+    double det = a11 * a22 - h12 * h12;
+    double idet = 1.0 / det;
+    double d1 = (a22 * g1 - h12 * g2) * idet;      // H d = g   (g = -grad NLL)
+    double d2 = (a11 * g2 - h12 * g1) * idet;
+    double l2 = (g1 * d1 + g2 * d2) / Rtot;
+    double lam = sqrt(fmax(l2, 0.0));
+    S.lam = lam;
+    if (!(lam == lam) || !(fabs(d1) + fabs(d2) < 1e30)) {  // NaN / overflow: give up on this candidate
+        S.status = 2;
+        return;
+    }
+    double step = (lam > 0.3) ? 1.0 / (1.0 + lam) : 1.0;   // damped phase keeps q > 0 (self-concordance)
+    S.p1 = u1; S.p2 = u2;
+    S.u1 = __builtin_fma(step, d1, u1);
+    S.u2 = __builtin_fma(step, d2, u2);
+    if (lam < 1e-9) S.status = 1;
+    else if (S.iters >= N3_MAX_ITERS || fabs(S.u1) + fabs(S.u2) > 1e8) S.status = 2;
+}
+
+// After convergence: decide admissibility the way Optimizer._solve_n3plus does (all nu_j in [0,1],
+// Optimizer.py:150-160).  For rank-deficient candidates the minimiser is a line; the reference
+// accepts when its root finder happens to land inside the simplex, so the line is intersected with
+// the simplex and a point inside is taken when one exists.  Returns true if admissible.
+__device__ __forceinline__ bool n3_admissible(N3Newton &S, double s1, double s2) {
+    double n1 = s1 * S.u1, n2 = s2 * S.u2, n0 = 1.0 - n1 - n2;
+    bool in = (n0 >= 0.0 && n0 <= 1.0 && n1 >= 0.0 && n1 <= 1.0 && n2 >= 0.0 && n2 <= 1.0);
+    if (in) return true;
+    double det0 = S.h11 * S.h22 - S.h12 * S.h12;
+    if (!(det0 <= 1e-10 * S.h11 * S.h22)) return false;   // regular optimum outside the simplex: None
+    // null direction of H
+    double v1, v2;
+    if (S.h11 >= S.h22) { v1 = -S.h12; v2 = S.h11; } else { v1 = S.h22; v2 = -S.h12; }
+    double nrm = sqrt(v1 * v1 + v2 * v2);
+    if (!(nrm > 0.0)) return false;
+    v1 /= nrm; v2 /= nrm;
+    double dn[3] = {-(s1 * v1 + s2 * v2), s1 * v1, s2 * v2};
+    double nu[3] = {n0, n1, n2};
+    double slo = -1e300, shi = 1e300;
+    for (int j = 0; j < 3; j++) {
+        if (dn[j] > 0) { slo = fmax(slo, -nu[j] / dn[j]); shi = fmin(shi, (1.0 - nu[j]) / dn[j]); }
+        else if (dn[j] < 0) { slo = fmax(slo, (1.0 - nu[j]) / dn[j]); shi = fmin(shi, -nu[j] / dn[j]); }
+        else if (nu[j] < 0.0 || nu[j] > 1.0) return false;
+    }
+    if (!(slo <= shi)) return false;
+    double s = 0.5 * (slo + shi);
+    S.u1 += s * v1;
+    S.u2 += s * v2;
+    return true;
+}
+#endif

@@ -1,0 +1,328 @@
+"""
+The search driver: drop-ins for `do_optimization_single` / `do_optimization` / `find_mins`
+(python/RunTHetA.py:107-220) on top of the fused HIP search.
+
+What runs where
+  GPU  theta_search       every candidate of the rank range: enumerate + solve + NLL + running minimum;
+                          returns the few candidates within COLLECT_WINDOW of the minimum
+  GPU  theta_solve_batch  those finalists again, in the reference's own summation order (mu, NLL, p*)
+  host this file          the reference's *sequential* tie rule (isClose with margin 1e-3 against the
+                          first running minimum, RunTHetA.py:198-206) replayed in enumeration order,
+                          un-sorting of rows (DataTools.py:132-159), and -- with several GPUs -- one
+                          small RCCL exchange of the per-shard finalists.
+
+Deviations from the reference that are deliberate:
+  * candidates whose NLL the reference computes as NaN (all-zero tumour column) are appended to its
+    `best` list by the isClose(NaN) quirk (Misc.py:44-46); they carry no information and are not
+    reproduced;
+  * for n=3 the accept set is "the likelihood has its minimum inside the simplex" -- the reference's
+    set is a scipy-trajectory-dependent superset; `SearchReport.parity_uncertain`
+    is raised when a rejected candidate's lower bound comes within the tie window of the winner.
+"""
+import sys
+
+import numpy as np
+
+from . import _lib
+
+TIE_MARGIN = 10e-4        # Misc.py:36
+COLLECT_WINDOW = 0.5      # how far above the minimum the GPU reports candidates (>> TIE_MARGIN)
+
+pre = "theta"             # prefix of the --GET_VALUES dump (the reference keeps it in a module global, RunTHetA.py:307-308)
+
+
+def isClose(v1, v2, margin=TIE_MARGIN):
+    """Misc.py:36-47 (NaN counts as close)."""
+    for a, b in zip(v1, v2):
+        if abs(a - b) > margin:
+            return False
+    return True
+
+
+def inRange(v1, minVal=0, maxVal=1):
+    """Misc.py:49-57 (NaN counts as in range)."""
+    for v in v1:
+        if v < minVal or v > maxVal:
+            return False
+    return True
+
+
+def reverse_sort_C(C, sorted_index):
+    """DataTools.py:132-146."""
+    out = np.zeros(C.shape)
+    out[np.asarray(sorted_index, dtype=np.int64), :] = C
+    return out
+
+
+def reverse_sort_list(vec, sorted_index):
+    """DataTools.py:148-159."""
+    out = [0] * len(sorted_index)
+    for i, dst in enumerate(sorted_index):
+        out[dst] = vec[i]
+    return out
+
+
+def find_mins(best):
+    """RunTHetA.py:107-122: merge per-worker lists; only each list's first entry is compared."""
+    lowest = float('inf')
+    out = []
+    for solns in best:
+        if len(solns) == 0:
+            continue
+        nll = solns[0][2]
+        if isClose([lowest], [nll]):
+            out += solns
+        elif nll < lowest:
+            lowest = nll
+            out = solns
+    return out
+
+
+class SearchReport(object):
+    """What the last search did (counters from the kernel, flags from the host replay)."""
+
+    def __init__(self):
+        self.stats = {}
+        self.candidates = 0
+        self.finalists = 0
+        self.tie_ambiguous = False
+        self.parity_uncertain = False
+        self.seconds = 0.0
+
+
+last_report = SearchReport()
+
+
+def _full_matrix(c_u8, n, tau):
+    m = c_u8.shape[0]
+    C = np.zeros((m, n))
+    C[:, 0] = tau
+    if n == 2:
+        C[:, 1] = c_u8
+    else:
+        C[:, 1:] = c_u8
+    return C
+
+
+def collect_finalists(problem, ctx, r, rN, max_normal, begin, end, window=COLLECT_WINDOW):
+    """
+    GPU part: fused search over [begin, end) then the exact-order re-solve of the finalists.
+    Returns (records, stats); a record is dict(rank, c (uint8), mu (n floats), nll, vals (m floats)).
+    """
+    res = problem.search(begin, end, window=window)
+    k = len(res["rank"])
+    recs = []
+    if k:
+        ok, mu, nll, vals = ctx.solve_batch(problem.n, problem.tau, r, rN, res["C"], max_normal, want_vals=True)
+        for i in range(k):
+            if not ok[i]:
+                continue  # borderline: admissible in the fused arithmetic, not in the reference-order arithmetic
+            recs.append({"rank": res["rank"][i], "c": res["C"][i], "mu": mu[i].copy(), "nll": float(nll[i]),
+                         "vals": vals[i].copy()})
+    return recs, res["stats"]
+
+
+def replay_ties(recs, n, tau, sorted_index, first_duplicate, report=None, q1_first=None):
+    """
+    Host part: the reference's running-minimum rule (RunTHetA.py:194-206) replayed in enumeration
+    order over the finalists.  `recs` must hold every candidate within COLLECT_WINDOW of the minimum.
+    first_duplicate: n=2 evaluates the rank-0 matrix twice (quirk Q1, RunTHetA.py:188,208).
+    q1_first: optional record of the n=3 [tau,0,0] matrix the reference evaluates first.
+    """
+    if not recs and q1_first is None:
+        return []
+    recs = sorted(recs, key=lambda t: t["rank"])
+    # cut the finalists at the first gap wider than the tie margin: nothing above it can interact
+    # with the running minimum ("tie replay")
+    if recs:
+        vals_sorted = sorted(t["nll"] for t in recs)
+        cut = vals_sorted[-1]
+        found_gap = False
+        for a, b in zip(vals_sorted, vals_sorted[1:]):
+            if b - a > TIE_MARGIN:
+                cut = a
+                found_gap = True
+                break
+        if not found_gap and vals_sorted[-1] - vals_sorted[0] > COLLECT_WINDOW - 2 * TIE_MARGIN and report is not None:
+            report.tie_ambiguous = True
+        recs = [t for t in recs if t["nll"] <= cut]
+    seq = []
+    if q1_first is not None:
+        seq.append(q1_first)
+    for t in recs:
+        if first_duplicate and t["rank"] == 0:
+            seq.append(t)
+        seq.append(t)
+    best = []
+    lowest = float("inf")
+    for t in seq:
+        L = t["nll"]
+        if isClose([L], [lowest]):
+            best.append(t)
+        elif L < lowest:
+            best = [t]
+            lowest = L
+    out = []
+    for t in best:
+        C = reverse_sort_C(_full_matrix(t["c"], n, tau), sorted_index)
+        vals = reverse_sort_list([float(v) for v in t["vals"]], sorted_index)
+        mu = (float(t["mu"][0]), float(t["mu"][1])) if n == 2 else np.array(t["mu"], dtype=np.float64)
+        out.append((C, mu, float(t["nll"]), vals))
+    return out
+
+
+def _q1_record(ctx, n, m, tau, r, rN):
+    """
+    Quirk Q1 for n=3: the reference first evaluates [tau,0,0]*m whatever the bounds
+    (Enumerator.py:154-160, RunTHetA.py:188).  Its solver runs on NaNs and returns the
+    uniform-by-normal-count model (p_i = rN_i / sum rN) with an arbitrary mu; the likelihood of that
+    model is scored here by the L3 kernel with mu = (1,0,0).
+    """
+    Cw = np.zeros((1, m, 3))
+    Cw[0, :, 0] = np.asarray(rN, dtype=np.float64) * tau
+    nll, vals, valid = ctx.score_batch(3, Cw, np.array([[1.0, 0.0, 0.0]]), np.asarray(r, dtype=np.float64))
+    return {"rank": -1, "c": np.zeros((m, 2), np.uint8), "mu": np.array([1.0, 0.0, 0.0]), "nll": float(nll[0]),
+            "vals": vals[0].copy()}
+
+
+def _dump_values(problem, n, m):
+    """--GET_VALUES (RunTHetA.py:210-215): '<C column 1 as digits>\\t<mu0>\\t<NLL>' per accepted candidate."""
+    with open(pre + ".likelihoods", "w") as f:
+        step = 1 << 16
+        for b in range(0, problem.count, step):
+            cnt = min(step, problem.count - b)
+            nll, mu, _ = problem.values(b, cnt)
+            C = problem.enumerate(b, cnt)
+            col = C if n == 2 else C[:, :, 0]
+            for i in range(cnt):
+                if nll[i] == nll[i]:
+                    f.write("".join(str(int(v)) for v in col[i]) + "\t" + str(float(mu[i, 0])) + "\t" + str(float(nll[i])) + "\n")
+
+
+def _search_local(n, m, tau, lower_bounds, upper_bounds, r, rN, max_normal, shard=(0, 1), ctx=None):
+    ctx = ctx or _lib.default_context()
+    r = [int(x) for x in r]
+    rN = [int(x) for x in rN]
+    problem = _lib.Problem(ctx, n, m, tau, r, rN, [int(v) for v in lower_bounds], [int(v) for v in upper_bounds],
+                           max_normal)
+    if problem.count == 0:
+        raise _lib.NoCandidates(_lib.ERR_NO_CANDIDATES, "no valid copy number profiles within the bounds")
+    g, G = shard
+    begin = problem.count * g // G
+    end = problem.count * (g + 1) // G
+    recs, stats = collect_finalists(problem, ctx, r, rN, max_normal, begin, end)
+    return problem, ctx, recs, stats
+
+
+def do_optimization_single(n, m, k, tau, lower_bounds, upper_bounds, r, rN, max_normal, sorted_index, multi_event=False,
+                           get_values=False):
+    """
+    RunTHetA.py:173-220 -- same arguments, same return value: list of
+    (C in the ORIGINAL interval order as float64 (m, n) with column 0 == tau, mu, NLL, vals).
+    """
+    import time
+    t0 = time.time()
+    global last_report
+    rep = SearchReport()
+    try:
+        problem, ctx, recs, stats = _search_local(n, m, tau, lower_bounds, upper_bounds, r, rN, max_normal)
+    except _lib.NoCandidates:
+        print("Error: No valid Copy Number Profiles exist for these intervals within the bounds specified. Exiting...")
+        sys.exit(1)
+    q1 = _q1_record(ctx, n, m, tau, r, rN) if n == 3 else None
+    best = replay_ties(recs, n, tau, sorted_index, first_duplicate=(n == 2), report=rep, q1_first=q1)
+    if get_values:
+        _dump_values(problem, n, m)
+    rep.stats = stats
+    rep.candidates = problem.count
+    rep.finalists = len(recs)
+    if best and stats["rejected_bound"] < best[0][2] + TIE_MARGIN:
+        rep.parity_uncertain = True
+    rep.seconds = time.time() - t0
+    last_report = rep
+    return best
+
+
+def do_optimization(n, m, k, tau, lower_bounds, upper_bounds, r, rN, max_normal, sorted_index, max_processes=1,
+                    multi_event=False, get_values=False):
+    """
+    RunTHetA.py:124-171.  The reference fans candidates out to max_processes-1 workers through a
+    multiprocessing.Queue; here one GPU evaluates them all, so max_processes only keeps the
+    signature.  (Several GPUs: do_optimization_distributed.)
+    """
+    return do_optimization_single(n, m, k, tau, lower_bounds, upper_bounds, r, rN, max_normal, sorted_index,
+                                  multi_event, get_values)
+
+
+# --------------------------------------------------------------------------------------------------
+# several GPUs: one process per GPU, candidate ranks sharded, ONE small exchange at the end
+# --------------------------------------------------------------------------------------------------
+def exchange_finalists(recs, n, m, device, group=None):
+    """
+    The only communication of a sharded search (replaces find_mins, RunTHetA.py:107-122):
+    all-reduce(min) of the shard minima, then an all-gather of the finalists that survive the global
+    window.  Runs over torch.distributed (backend "nccl" == RCCL over xGMI on the GPU box; "gloo" in
+    the CPU tests).  Returns the merged finalists of all shards (identical on every rank).
+    """
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    local_min = min([t["nll"] for t in recs], default=float("inf"))
+    gmin = torch.tensor([local_min], dtype=torch.float64, device=device)
+    dist.all_reduce(gmin, op=dist.ReduceOp.MIN, group=group)
+    gmin = float(gmin.item())
+    keep = [t for t in recs if t["nll"] <= gmin + COLLECT_WINDOW]
+    cnt = torch.tensor([len(keep)], dtype=torch.int64, device=device)
+    counts = [torch.zeros_like(cnt) for _ in range(world)]
+    dist.all_gather(counts, cnt, group=group)
+    counts = [int(c.item()) for c in counts]
+    cap = max(counts)
+    if cap == 0:
+        return []
+    nc = n - 1
+    W = 1 + n + m                      # nll, mu[n], vals[m]
+    fl = torch.zeros((cap, W), dtype=torch.float64)
+    ii = torch.zeros((cap, 2), dtype=torch.int64)
+    cc = torch.zeros((cap, m * nc), dtype=torch.uint8)
+    mask64 = (1 << 64) - 1
+    for i, t in enumerate(keep):
+        fl[i, 0] = t["nll"]
+        fl[i, 1:1 + n] = torch.from_numpy(np.asarray(t["mu"], dtype=np.float64))
+        fl[i, 1 + n:] = torch.from_numpy(np.asarray(t["vals"], dtype=np.float64))
+        lo, hi = t["rank"] & mask64, (t["rank"] >> 64) & mask64
+        ii[i, 0] = lo - (1 << 64) if lo >= (1 << 63) else lo     # two's complement transport of uint64
+        ii[i, 1] = hi - (1 << 64) if hi >= (1 << 63) else hi
+        cc[i] = torch.from_numpy(np.ascontiguousarray(t["c"], dtype=np.uint8).reshape(-1))
+    fl, ii, cc = fl.to(device), ii.to(device), cc.to(device)
+    gfl = [torch.zeros_like(fl) for _ in range(world)]
+    gii = [torch.zeros_like(ii) for _ in range(world)]
+    gcc = [torch.zeros_like(cc) for _ in range(world)]
+    dist.all_gather(gfl, fl, group=group)
+    dist.all_gather(gii, ii, group=group)
+    dist.all_gather(gcc, cc, group=group)
+    merged = []
+    for g in range(world):
+        f, i2, c2 = gfl[g].cpu().numpy(), gii[g].cpu().numpy(), gcc[g].cpu().numpy()
+        for j in range(counts[g]):
+            lo, hi = int(i2[j, 0]) & mask64, int(i2[j, 1]) & mask64
+            c = c2[j].reshape(m) if n == 2 else c2[j].reshape(m, 2)
+            merged.append({"rank": lo | (hi << 64), "c": c.copy(), "mu": f[j, 1:1 + n].copy(), "nll": float(f[j, 0]),
+                           "vals": f[j, 1 + n:].copy()})
+    return merged
+
+
+def do_optimization_distributed(n, m, k, tau, lower_bounds, upper_bounds, r, rN, max_normal, sorted_index, group=None,
+                                device=None):
+    """
+    One process per GPU (torch.distributed already initialised).  Rank g searches the candidate ranks
+    [N*g/G, N*(g+1)/G); every rank returns the same `best` as do_optimization_single would.
+    """
+    import torch
+    import torch.distributed as dist
+    g, G = dist.get_rank(group), dist.get_world_size(group)
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+    problem, ctx, recs, stats = _search_local(n, m, tau, lower_bounds, upper_bounds, r, rN, max_normal, shard=(g, G))
+    merged = exchange_finalists(recs, n, m, device, group)
+    q1 = _q1_record(ctx, n, m, tau, r, rN) if n == 3 else None
+    return replay_ties(merged, n, tau, sorted_index, first_duplicate=(n == 2), q1_first=q1)
