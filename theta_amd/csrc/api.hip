@@ -421,9 +421,11 @@ static int run_search(theta_problem *p, u128 b, u128 e, double window, double *d
     return THETA_OK;
 }
 
-static const double FLOPS_PER_TERM_ITER_N3 = 26.0;  // see DESIGN.md: 2 sub, 2 fma(q), rcp+NR(1+4), 1 mul, 2 fma, 3 mul, 3 fma
-static const double FLOPS_PER_TERM_ITER_N2 = 10.0;  // fma(den), rcp+NR(5), mul, fma(f), mul+fma(f')
-static const double FLOPS_PER_FINAL_TERM = 4.0;     // fma/fma(q), log, fma(acc)
+// FP64 operations per likelihood term (an FMA counts 2, rcp / log / div count 1); see DESIGN.md "Roofline".
+static const double FLOPS_PER_TERM_ITER_N3 = 25.0;  // 2 sub, 2 fma (q), rcp + 2 fma, mul, 2 fma (grad), 3 mul, 3 fma (Hessian)
+static const double FLOPS_PER_TERM_ITER_N2 = 13.0;  // fma (den), rcp + 2 fma, mul, fma (f), mul, fma (f')
+static const double FLOPS_PER_FINAL_TERM_N3 = 14.0; // 2 sub, 2 fma, log, fma, div, 2 fma
+static const double FLOPS_PER_FINAL_TERM_N2 = 5.0;  // fma, log, fma
 
 extern "C" int theta_search(theta_problem *p, const uint64_t rank_begin[2], const uint64_t rank_end[2], double window,
                             int cap, double *nll, double *mu, uint64_t *rank, uint8_t *C, int *n_out,
@@ -457,7 +459,8 @@ extern "C" int theta_search(theta_problem *p, const uint64_t rank_begin[2], cons
         stats->terms = hc.terms;
         stats->list_overflow = hc.pad;
         double per = (p->n == 2) ? FLOPS_PER_TERM_ITER_N2 : FLOPS_PER_TERM_ITER_N3;
-        stats->flops = (uint64_t)(per * (double)hc.terms + FLOPS_PER_FINAL_TERM * (double)hc.final_terms);
+        double fin = (p->n == 2) ? FLOPS_PER_FINAL_TERM_N2 : FLOPS_PER_FINAL_TERM_N3;
+        stats->flops = (uint64_t)(per * (double)hc.terms + fin * (double)hc.final_terms);
         stats->best_nll = best;
         stats->rejected_bound = order_unbits(hc.rej_bits);
         stats->rejected_rank[0] = hc.rej_rank_lo;
