@@ -67,15 +67,16 @@ def _cpu_init(r, rN):
 
 
 def _cpu_work(args):
-    cands, deadline = args
+    cands, budget = args
     orc = _W["orc"]
     done = 0
+    t0 = time.time()
     for c in cands:
-        if time.time() > deadline:
+        if time.time() - t0 > budget:
             break
         orc.solve_n3(orc.rows_to_matrix_n3([tuple(x) for x in c], TAU), _W["r"], _W["rN"])
         done += 1
-    return done
+    return done, time.time() - t0
 
 
 def cpu_baseline(cands, r, rN, budget_s=15.0):
@@ -95,15 +96,14 @@ def cpu_baseline(cands, r, rN, budget_s=15.0):
     # all cores (the reference's multiprocessing path: NUM_PROCESSES = cores)
     chunks = [cands[i::cores] for i in range(cores)]
     ctx = mp.get_context("fork")
-    t0 = time.time()
     with ctx.Pool(cores, initializer=_cpu_init, initargs=(r, rN)) as pool:
-        deadline = time.time() + budget_s * 2 / 3
-        done = sum(pool.map(_cpu_work, [(ch, deadline) for ch in chunks]))
-    dt = time.time() - t0
+        res = pool.map(_cpu_work, [(ch, budget_s * 2 / 3) for ch in chunks], chunksize=1)
+    done = sum(x[0] for x in res)
+    dt = max(x[1] for x in res)          # workers run concurrently; process start-up is not charged to the CPU
     return {"value": done / dt, "unit": "candidates/s", "cores": cores, "kind": "port",
             "per_process": per_process,
             "sample": "%d candidates drawn from the GPU run's own rank ranges, oracle.solve_n3 (scipy fsolve/BFGS), "
-                      "%d processes, %.1f s" % (done, cores, dt)}
+                      "%d concurrent processes, %.1f s of solving each" % (done, cores, dt)}
 
 
 def main():

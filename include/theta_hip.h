@@ -82,6 +82,9 @@ typedef struct theta_search_stats {
     uint64_t rejected_rank[2];
     double kernel_ms;        /* duration of the search kernel, HIP events on its stream         */
     double setup_ms;         /* duration of the unranking / task set-up kernels                 */
+    uint64_t phase_cycles[8];/* shader cycles per kernel phase summed over waves (diagnostic):
+                                0 group tile, 1 leaf scan, 2 solver iterations, 3 values+tracking,
+                                4 prefix successor, 5 whole wave                               */
 } theta_search_stats;
 
 /*

@@ -29,10 +29,12 @@ class SearchStats(C.Structure):
     _fields_ = [("evaluated", C.c_uint64), ("accepted", C.c_uint64), ("degenerate", C.c_uint64),
                 ("iterations", C.c_uint64), ("terms", C.c_uint64), ("list_overflow", C.c_uint64),
                 ("flops", C.c_uint64), ("best_nll", C.c_double), ("rejected_bound", C.c_double),
-                ("rejected_rank", C.c_uint64 * 2), ("kernel_ms", C.c_double), ("setup_ms", C.c_double)]
+                ("rejected_rank", C.c_uint64 * 2), ("kernel_ms", C.c_double), ("setup_ms", C.c_double),
+                ("phase_cycles", C.c_uint64 * 8)]
 
     def as_dict(self):
-        d = {k: getattr(self, k) for k, _ in self._fields_ if k != "rejected_rank"}
+        d = {k: getattr(self, k) for k, _ in self._fields_ if k not in ("rejected_rank", "phase_cycles")}
+        d["phase_cycles"] = [int(x) for x in self.phase_cycles]
         d["rejected_rank"] = int(self.rejected_rank[0]) | (int(self.rejected_rank[1]) << 64)
         return d
 

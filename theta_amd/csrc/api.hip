@@ -467,6 +467,7 @@ extern "C" int theta_search(theta_problem *p, const uint64_t rank_begin[2], cons
         stats->rejected_rank[1] = hc.rej_rank_hi;
         stats->kernel_ms = kms;
         stats->setup_ms = sms;
+        for (int i = 0; i < 8; i++) stats->phase_cycles[i] = hc.prof[i];
     }
     // keep what lies within the window of the final minimum, in rank order
     std::vector<TieRecord> keep;

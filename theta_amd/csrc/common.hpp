@@ -77,6 +77,7 @@ struct SearchCounters {
     unsigned long long rej_rank_lo, rej_rank_hi;
     unsigned int list_count;           // records appended (may exceed capacity)
     unsigned int pad;
+    unsigned long long prof[8];        // shader cycles per kernel phase, summed over waves (diagnostic)
 };
 
 // What a search kernel writes to (all device pointers).

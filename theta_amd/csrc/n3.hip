@@ -15,6 +15,7 @@
 // prefix once per prefix and every lane's Newton iteration streams that tile (LDS broadcast reads)
 // plus its own L rows.  Nothing but the tie records ever goes to HBM.
 #include <algorithm>
+#include <type_traits>
 
 #include "n3_core.hpp"
 
@@ -91,7 +92,7 @@ __global__ __launch_bounds__(256) void n3_dp_kernel(N3Dev P, u128 *cnt, int d, u
         if (d == P.m - 1) {
             sum = 1;
         } else {
-            N3State par{slot, sw, lo, hi}, ch;
+            N3State par{slot, sw, lo, hi, slot % (P.K + 1), slot / (P.K + 1)}, ch;
             for (int c = 0; c < P.Q; c++) {
                 if (n3_edge(P, par, c, d + 1, ch)) {
                     u128 v = cnt[n3_cnt_index(P, d + 1, ch.slot, ch.sw, ch.lo, ch.hi)];
@@ -144,15 +145,19 @@ __device__ bool n3_unrank(const N3Dev &P, u128 rho, int depth, N3State *st, u128
     return true;
 }
 
+// 32-bit form of a DFS node: slot 7 bits | sw | lo 8 | hi 8 | a 4 | b 4
 __device__ __forceinline__ unsigned n3_pack(const N3State &s) {
-    return (unsigned)s.slot | ((unsigned)s.sw << 8) | ((unsigned)s.lo << 16) | ((unsigned)s.hi << 24);
+    return (unsigned)s.slot | ((unsigned)s.sw << 7) | ((unsigned)s.lo << 8) | ((unsigned)s.hi << 16) |
+           ((unsigned)s.a << 24) | ((unsigned)s.b << 28);
 }
 __device__ __forceinline__ N3State n3_unpack(unsigned v) {
     N3State s;
-    s.slot = v & 0xff;
-    s.sw = (v >> 8) & 1;
-    s.lo = (v >> 16) & 0xff;
-    s.hi = (v >> 24) & 0xff;
+    s.slot = v & 0x7f;
+    s.sw = (v >> 7) & 1;
+    s.lo = (v >> 8) & 0xff;
+    s.hi = (v >> 16) & 0xff;
+    s.a = (v >> 24) & 0xf;
+    s.b = (v >> 28) & 0xf;
     return s;
 }
 
@@ -219,18 +224,26 @@ __device__ __forceinline__ double readlane_f64(double v, int l) {
 }
 
 #define N3_WAVES 4
-#define N3_QCAP 128
+#define N3_QCAP 256     // leaves of one prefix held in LDS at a time (per wave)
 
 struct N3Lds {
     double gX[N3_WAVES][N3_MAX_Q + 1], gY[N3_WAVES][N3_MAX_Q + 1], gR[N3_WAVES][N3_MAX_Q + 1];
-    unsigned qCode[N3_WAVES][N3_QCAP], qOff[N3_WAVES][N3_QCAP];
+    double resU1[N3_WAVES][N3_QCAP], resU2[N3_WAVES][N3_QCAP];
+    unsigned qCode[N3_WAVES][N3_QCAP], qOff[N3_WAVES][N3_QCAP], resSt[N3_WAVES][N3_QCAP];
     unsigned char lb[N3_MAX_M], ub[N3_MAX_M];
     unsigned char ridx[N3_RIDX_W * N3_RIDX_W + 3];
 };
 
+// status word of a solved leaf: bits 0-1 state (1 converged, 2 failed, 3 degenerate), bit 2 singular Hessian,
+// bits 8.. iterations
+#define RES_CONV 1u
+#define RES_FAIL 2u
+#define RES_DEGEN 3u
+#define RES_SINGULAR 4u
+
 template <int L, bool DUMP>
 __global__ __launch_bounds__(64 * N3_WAVES) void n3_search_kernel(N3Dev Pg, SearchArgs A, const N3Task *tasks,
-                                                                const unsigned *stbuf, int ntasks, uint64_t per_task) {
+                                                                   const unsigned *stbuf, int ntasks, uint64_t per_task) {
     __shared__ N3Lds S;
     // stage what every wave of the block shares
     for (int i = threadIdx.x; i < Pg.m; i += blockDim.x) {
@@ -250,12 +263,14 @@ __global__ __launch_bounds__(64 * N3_WAVES) void n3_search_kernel(N3Dev Pg, Sear
     const int m = P.m, D = m - L, Q = P.Q, K1 = P.K + 1;
     const double tau = (double)P.tau;
     double *gX = S.gX[wv], *gY = S.gY[wv], *gR = S.gR[wv];
-    unsigned *qCode = S.qCode[wv], *qOff = S.qOff[wv];
+    double *resU1 = S.resU1[wv], *resU2 = S.resU2[wv];
+    unsigned *qCode = S.qCode[wv], *qOff = S.qOff[wv], *resSt = S.resSt[wv];
 
-    // lane i holds interval i
+    // lane i holds interval i; lane s (+64) also stands for alphabet slot s when children are tested
     const double r_i = lane < m ? Pg.r[lane] : 0.0;
     const double rN_i = lane < m ? Pg.rN[lane] : 0.0;
     unsigned st = lane < D ? stbuf[(size_t)task * N3_MAX_M + lane] : 0u;
+    const int sa0 = lane % K1, sb0 = lane / K1, sa1 = (lane + WAVE) % K1, sb1 = (lane + WAVE) / K1;
 
     const N3Task tk = tasks[task];
     const u128 base = ((u128)tk.base_hi << 64) | tk.base_lo;
@@ -269,26 +284,31 @@ __global__ __launch_bounds__(64 * N3_WAVES) void n3_search_kernel(N3Dev Pg, Sear
         leafR[l] = readlane_f64(r_i, D + l);
         leafN[l] = readlane_f64(rN_i, D + l);
     }
-    int QL = 1;
-#pragma unroll
-    for (int l = 0; l < L; l++) QL *= Q;
+    // screening margin for the single-precision NLL: |error| <= Rtot * (|ln q| * 2^-23 + 2^-22) stays far below this
+    const double screen_margin = 2e-5 * P.Rtot + 1.0;
 
     unsigned long long n_eval = 0, n_acc = 0, n_deg = 0, n_it = 0, n_terms = 0, n_fin = 0;
     double best = order_unbits(load_agent_u64(&A.ctr->best_bits));
     double rej_best = order_unbits(load_agent_u64(&A.ctr->rej_bits));
+    // warm start (wave-uniform): mixture fractions of the best candidate of the previous batch, pulled
+    // towards the centre of the simplex so that it is interior for every candidate
+    double ws1 = 1.0 / 3.0, ws2 = 1.0 / 3.0;
 
+    unsigned long long pc0 = 0, pc1 = 0, pc2 = 0, pc3 = 0, pc4 = 0;
+    const unsigned long long t_begin = __builtin_readcyclecounter();
     while (remaining > 0) {
+        unsigned long long t0 = __builtin_readcyclecounter();
         // ---------------- group tile of the prefix --------------------------------------------
         int G = 0;
         double S1p = 0.0, S2p = 0.0;
         {
             const bool inp = lane < D;
-            const int myslot = st & 0xff;
+            const unsigned myrow = st >> 24;  // a | b << 4
             unsigned long long todo = ballot64(inp);
             while (todo) {
                 int leader = __builtin_ctzll(todo);
-                int q = __builtin_amdgcn_readlane(myslot, leader);
-                bool match = inp && myslot == q;
+                unsigned q = (unsigned)__builtin_amdgcn_readlane((int)myrow, leader);
+                bool match = inp && myrow == q;
                 todo &= ~ballot64(match);
                 double Rs = match ? r_i : 0.0, Ns = match ? rN_i : 0.0;
 #pragma unroll
@@ -296,7 +316,7 @@ __global__ __launch_bounds__(64 * N3_WAVES) void n3_search_kernel(N3Dev Pg, Sear
                     Rs += __shfl_xor(Rs, o, WAVE);
                     Ns += __shfl_xor(Ns, o, WAVE);
                 }
-                double a = (double)(q % K1), b = (double)(q / K1);
+                double a = (double)(q & 15u), b = (double)(q >> 4);
                 if (lane == 0) {
                     gX[G] = a;
                     gY[G] = b;
@@ -309,182 +329,309 @@ __global__ __launch_bounds__(64 * N3_WAVES) void n3_search_kernel(N3Dev Pg, Sear
         }
         wave_lds_sync();
 
-        // ---------------- scan the L leaf levels, compact, solve ------------------------------
+        pc0 += __builtin_readcyclecounter() - t0;
         const N3State par = n3_unpack((unsigned)__builtin_amdgcn_readlane((int)st, D - 1));
         unsigned long long leaf_idx = 0;
         int qcount = 0;
 
-        auto process = [&](int cnt) {
-            const bool have = lane < cnt;
-            unsigned code = have ? qCode[lane] : 0u;
-            const unsigned long long rel = processed + (have ? qOff[lane] : 0u);
-            double lx[L], ly[L];
-            {
-                unsigned cc = code;
-#pragma unroll
-                for (int l = L - 1; l >= 0; l--) {
-                    int s = cc % Q;
-                    cc /= Q;
-                    lx[l] = (double)(s % K1);
-                    ly[l] = (double)(s / K1);
-                }
-            }
-            double S1 = S1p, S2 = S2p;
-#pragma unroll
-            for (int l = 0; l < L; l++) {
-                S1 = __builtin_fma(lx[l], leafN[l], S1);
-                S2 = __builtin_fma(ly[l], leafN[l], S2);
-            }
-            const bool degenerate = have && (S1 == 0.0 || S2 == 0.0);
-            const double s1 = S1 / P.N, s2 = S2 / P.N;
+        // ---- solve every queued leaf: persistent lanes, refilled from the queue as they converge -------
+        auto drain = [&]() {
+            if (qcount == 0) return;
+            const unsigned long long td0 = __builtin_readcyclecounter();
+            int head = 0;
+            bool have = false;
+            int myidx = 0;
+            double lx[L], ly[L], s1 = 1.0, s2 = 1.0;
+            N3Newton Sv;
+            Sv.status = 0;
             auto terms = [&](auto &&body) {
+#pragma unroll 2
                 for (int g = 0; g < G; g++) body(gX[g], gY[g], gR[g]);
 #pragma unroll
                 for (int l = 0; l < L; l++) body(lx[l], ly[l], leafR[l]);
             };
-            N3Newton Sv;
-            Sv.u1 = (1.0 / 3.0) / s1;  // nu = (1/3,1/3,1/3): the reference's start (Optimizer.py:147)
-            Sv.u2 = (1.0 / 3.0) / s2;
-            Sv.p1 = Sv.u1; Sv.p2 = Sv.u2;
-            Sv.h11 = Sv.h12 = Sv.h22 = Sv.g1 = Sv.g2 = 0.0;
-            Sv.lam = 0.0;
-            Sv.iters = 0;
-            Sv.status = 0;
-            bool run = have && !degenerate;
-            while (ballot64(run)) {
-                if (run) {
-                    n3_newton_step(terms, s1, s2, P.Rtot, Sv);
-                    run = (Sv.status == 0);
-                }
-            }
-            // ---- value at the optimum / lower bound for rejected candidates
-            bool solved = have && !degenerate;
-            bool conv = solved && Sv.status == 1;
-            bool accept = conv && n3_admissible(Sv, s1, s2);
-            double eu1 = conv ? Sv.u1 : Sv.p1, eu2 = conv ? Sv.u2 : Sv.p2;   // non-converged: last feasible iterate
-            double acc = 0.0, g1 = 0.0, g2 = 0.0;
-            if (solved) {
-                terms([&](double x, double y, double R) {
-                    double a = x - s1, b = y - s2;
-                    double q = __builtin_fma(a, eu1, __builtin_fma(b, eu2, 1.0));
-                    acc = __builtin_fma(R, log(q), acc);
-                    double t = R / q;
-                    g1 = __builtin_fma(t, a, g1);
-                    g2 = __builtin_fma(t, b, g2);
-                });
-            }
-            double nll = P.K0 - acc;
-            // Frank-Wolfe bound: NLL(z) >= NLL(u) + grad.(z - u) for every z in the simplex; minimum at a vertex
-            double lbnd = nll;
-            if (solved && !accept) {
-                double e0 = g1 * eu1 + g2 * eu2;                 // -grad.(v0 - u), v0 = (0,0)
-                double e1 = e0 - g1 / s1, e2 = e0 - g2 / s2;     // v1 = (1/s1,0), v2 = (0,1/s2)
-                lbnd = nll + fmin(e0, fmin(e1, e2));
-            }
-            double u0 = (1.0 - s1 * Sv.u1 - s2 * Sv.u2) / tau;
-            double usum = u0 + Sv.u1 + Sv.u2;
-            double mu0 = u0 / usum, mu1 = Sv.u1 / usum, mu2 = Sv.u2 / usum;  // closed form of M3 (Optimizer.py:318-330)
-
-            if (accept && nll <= best + A.window) {
-                best = fmin(best, order_unbits(load_agent_u64(&A.ctr->best_bits)));
-                if (nll <= best + A.window) {
-                    tie_append(A.ctr, A.list, A.list_cap, base + rel, nll, mu0, mu1, mu2);
-                    if (nll < best) atomicMin(&A.ctr->best_bits, order_bits(nll));
-                }
-            }
-            double wbest = wave_min(accept ? nll : __builtin_inf());
-            best = fmin(best, wbest);
-            if (solved && !accept && lbnd < rej_best) {
-                unsigned long long old = atomicMin(&A.ctr->rej_bits, order_bits(lbnd));
-                if (old > order_bits(lbnd)) {  // we hold the minimum (racy pair, diagnostic only)
-                    u128 rk = base + rel;
-                    A.ctr->rej_rank_lo = (unsigned long long)rk;
-                    A.ctr->rej_rank_hi = (unsigned long long)(rk >> 64);
-                }
-                rej_best = lbnd;
-            }
-            if (DUMP && have) {
-                double nan = __builtin_nan("");
-                const unsigned long long di = dump_base + rel;
-                A.dump_nll[di] = accept ? nll : nan;
-                A.dump_mu[di * 3 + 0] = accept ? mu0 : nan;
-                A.dump_mu[di * 3 + 1] = accept ? mu1 : nan;
-                A.dump_mu[di * 3 + 2] = accept ? mu2 : nan;
-            }
-            n_eval += have;
-            n_acc += accept;
-            n_deg += degenerate;
-            n_it += solved ? Sv.iters : 0;
-            n_terms += solved ? (unsigned long long)Sv.iters * (G + L) : 0;
-            n_fin += solved ? (G + L) : 0;
-        };
-
-        for (int cbase = 0; cbase < QL; cbase += WAVE) {
-            int code = cbase + lane;
-            bool feas = code < QL;
-            if (feas) {
-                int dig[L];
-                int cc = code;
+            while (true) {
+                // refill idle lanes
+                unsigned long long idle = ballot64(!have);
+                if (head < qcount && idle) {
+                    int want = head + mbcnt(idle);
+                    bool take = !have && want < qcount;
+                    int ntake = __builtin_popcountll(idle);
+                    if (ntake > qcount - head) ntake = qcount - head;
+                    head += ntake;
+                    if (take) {
+                        myidx = want;
+                        unsigned code = qCode[want];
+                        double S1 = S1p, S2 = S2p;
 #pragma unroll
-                for (int l = L - 1; l >= 0; l--) {
-                    dig[l] = cc % Q;
-                    cc /= Q;
+                        for (int l = 0; l < L; l++) {
+                            unsigned rw = (code >> (8 * l)) & 0xffu;
+                            lx[l] = (double)(rw & 15u);
+                            ly[l] = (double)(rw >> 4);
+                            S1 = __builtin_fma(lx[l], leafN[l], S1);
+                            S2 = __builtin_fma(ly[l], leafN[l], S2);
+                        }
+                        if (S1 == 0.0 || S2 == 0.0) {      // all-zero tumour column: the reference's Chat is NaN
+                            resSt[want] = RES_DEGEN;
+                        } else {
+                            have = true;
+                            s1 = S1 / P.N;
+                            s2 = S2 / P.N;
+                            Sv.u1 = ws1 / s1;               // nu -> u
+                            Sv.u2 = ws2 / s2;
+                            Sv.p1 = Sv.u1; Sv.p2 = Sv.u2;
+                            Sv.h11 = Sv.h12 = Sv.h22 = Sv.g1 = Sv.g2 = Sv.lam = 0.0;
+                            Sv.iters = 0;
+                            Sv.status = 0;
+                        }
+                    }
                 }
-                N3State cur = par, nx;
+                if (!ballot64(have)) {
+                    if (head >= qcount) break;
+                    continue;   // only degenerate leaves were taken this round
+                }
+                if (have) {
+                    n3_newton_step(terms, s1, s2, P.Rtot, Sv);
+                    if (Sv.status != 0) {
+                        double det0 = Sv.h11 * Sv.h22 - Sv.h12 * Sv.h12;
+                        unsigned sing = (det0 <= 1e-10 * Sv.h11 * Sv.h22) ? RES_SINGULAR : 0u;
+                        bool conv = Sv.status == 1;
+                        resU1[myidx] = conv ? Sv.u1 : Sv.p1;      // failed: last feasible iterate
+                        resU2[myidx] = conv ? Sv.u2 : Sv.p2;
+                        resSt[myidx] = (conv ? RES_CONV : RES_FAIL) | sing | ((unsigned)Sv.iters << 8);
+                        have = false;
+                    }
+                }
+            }
+            wave_lds_sync();
+            const unsigned long long td1 = __builtin_readcyclecounter();
+            pc2 += td1 - td0;
+
+            // ---- values, admissibility, minimum tracking: full 64-wide batches ------------------------
+            for (int b0 = 0; b0 < qcount; b0 += WAVE) {
+                const int idx = b0 + lane;
+                const bool live = idx < qcount;
+                unsigned code = live ? qCode[idx] : 0u;
+                unsigned stw = live ? resSt[idx] : RES_DEGEN;
+                double u1 = live ? resU1[idx] : 0.0, u2 = live ? resU2[idx] : 0.0;
+                const unsigned long long rel = processed + (live ? qOff[idx] : 0u);
+                double S1 = S1p, S2 = S2p;
 #pragma unroll
                 for (int l = 0; l < L; l++) {
-                    if (feas) {
-                        feas = n3_edge(P, cur, dig[l], D + l, nx);
-                        cur = nx;
+                    unsigned rw = (code >> (8 * l)) & 0xffu;
+                    lx[l] = (double)(rw & 15u);
+                    ly[l] = (double)(rw >> 4);
+                    S1 = __builtin_fma(lx[l], leafN[l], S1);
+                    S2 = __builtin_fma(ly[l], leafN[l], S2);
+                }
+                const unsigned kind = stw & 3u;
+                const bool degenerate = live && kind == RES_DEGEN;
+                const bool solved = live && kind != RES_DEGEN;
+                const bool conv = solved && kind == RES_CONV;
+                s1 = solved ? S1 / P.N : 1.0;
+                s2 = solved ? S2 / P.N : 1.0;
+                const int iters = (int)(stw >> 8);
+                // admissibility (Optimizer.py:150-160): all nu_j in [0,1]
+                bool accept = false;
+                if (conv) {
+                    double n1 = s1 * u1, n2 = s2 * u2, n0 = 1.0 - n1 - n2;
+                    accept = (n0 >= 0.0 && n0 <= 1.0 && n1 >= 0.0 && n1 <= 1.0 && n2 >= 0.0 && n2 <= 1.0);
+                    if (!accept && (stw & RES_SINGULAR)) {
+                        // rank-deficient candidate: the minimiser is a line; rebuild H and intersect with the simplex
+                        N3Newton T;
+                        T.u1 = u1; T.u2 = u2;
+                        T.h11 = T.h12 = T.h22 = 0.0;
+                        terms([&](double x, double y, double R) {
+                            double a = x - s1, b = y - s2;
+                            double q = __builtin_fma(a, u1, __builtin_fma(b, u2, 1.0));
+                            double tw = R / (q * q);
+                            T.h11 = __builtin_fma(tw * a, a, T.h11);
+                            T.h12 = __builtin_fma(tw * a, b, T.h12);
+                            T.h22 = __builtin_fma(tw * b, b, T.h22);
+                        });
+                        accept = n3_admissible(T, s1, s2);
+                        u1 = T.u1;
+                        u2 = T.u2;
                     }
                 }
+                // single-precision screen of sum R ln q, then the exact value only for contenders
+                double accf = 0.0, g1 = 0.0, g2 = 0.0;
+                if (solved) {
+                    terms([&](double x, double y, double R) {
+                        double a = x - s1, b = y - s2;
+                        double q = __builtin_fma(a, u1, __builtin_fma(b, u2, 1.0));
+                        accf = __builtin_fma(R, (double)__logf((float)q), accf);
+                        double t = R * rcp_nr1(q);
+                        g1 = __builtin_fma(t, a, g1);
+                        g2 = __builtin_fma(t, b, g2);
+                    });
+                }
+                double nll = P.K0 - accf;
+                // Frank-Wolfe bound for rejected candidates: NLL(z) >= NLL(u) + grad.(z - u), z in the simplex
+                double fw = 0.0;
+                if (solved && !accept) {
+                    double e0 = g1 * u1 + g2 * u2;                  // vertex nu = e0  <-> u = (0, 0)
+                    double e1 = e0 - g1 / s1, e2 = e0 - g2 / s2;    // vertices (1/s1, 0), (0, 1/s2)
+                    fw = fmin(e0, fmin(e1, e2));
+                }
+                bool contender = solved && (DUMP || (nll + fw - screen_margin <= (accept ? best + A.window : rej_best)));
+                if (contender) {
+                    double acc = 0.0;
+                    terms([&](double x, double y, double R) {
+                        double q = __builtin_fma(x - s1, u1, __builtin_fma(y - s2, u2, 1.0));
+                        acc = __builtin_fma(R, log(q), acc);
+                    });
+                    nll = P.K0 - acc;
+                }
+                const double lbnd = nll + fw;
+                double u0 = (1.0 - s1 * u1 - s2 * u2) / tau;
+                double usum = u0 + u1 + u2;
+                double mu0 = u0 / usum, mu1 = u1 / usum, mu2 = u2 / usum;  // closed form of M3 (Optimizer.py:318-330)
+
+                if (accept && contender && nll <= best + A.window) {
+                    best = fmin(best, order_unbits(load_agent_u64(&A.ctr->best_bits)));
+                    if (nll <= best + A.window) {
+                        tie_append(A.ctr, A.list, A.list_cap, base + rel, nll, mu0, mu1, mu2);
+                        if (nll < best) atomicMin(&A.ctr->best_bits, order_bits(nll));
+                    }
+                }
+                // wave-wide: new minimum and the warm start for the next batch
+                double mine = (accept && contender) ? nll : __builtin_inf();
+                double wbest = wave_min(mine);
+                if (wbest < __builtin_inf()) {
+                    best = fmin(best, wbest);
+                    unsigned long long who = ballot64(mine == wbest);
+                    int src = __builtin_ctzll(who);
+                    double b1 = readlane_f64(s1 * u1, src), b2 = readlane_f64(s2 * u2, src);
+                    ws1 = 0.75 * b1 + 0.25 / 3.0;
+                    ws2 = 0.75 * b2 + 0.25 / 3.0;
+                }
+                if (solved && !accept && contender && lbnd < rej_best) {
+                    unsigned long long old = atomicMin(&A.ctr->rej_bits, order_bits(lbnd));
+                    if (old > order_bits(lbnd)) {  // we hold the minimum (racy pair, diagnostic only)
+                        u128 rk = base + rel;
+                        A.ctr->rej_rank_lo = (unsigned long long)rk;
+                        A.ctr->rej_rank_hi = (unsigned long long)(rk >> 64);
+                    }
+                    rej_best = lbnd;
+                }
+                if (DUMP && live) {
+                    double nan = __builtin_nan("");
+                    const unsigned long long di = dump_base + rel;
+                    A.dump_nll[di] = accept ? nll : nan;
+                    A.dump_mu[di * 3 + 0] = accept ? mu0 : nan;
+                    A.dump_mu[di * 3 + 1] = accept ? mu1 : nan;
+                    A.dump_mu[di * 3 + 2] = accept ? mu2 : nan;
+                }
+                n_eval += live;
+                n_acc += accept;
+                n_deg += degenerate;
+                n_it += solved ? iters : 0;
+                n_terms += solved ? (unsigned long long)iters * (G + L) : 0;
+                n_fin += solved ? (G + L) : 0;
             }
-            unsigned long long mask = ballot64(feas);
-            if (!mask) continue;
-            unsigned long long off = leaf_idx + mbcnt(mask);
-            leaf_idx += __builtin_popcountll(mask);
-            bool sel = feas && off >= skip && (off - skip) < remaining;
-            unsigned long long smask = ballot64(sel);
-            if (smask) {
-                int pos = qcount + mbcnt(smask);
-                if (sel) {
-                    qCode[pos] = (unsigned)code;
-                    qOff[pos] = (unsigned)(off - skip);
-                }
-                qcount += __builtin_popcountll(smask);
-                wave_lds_sync();
-                if (qcount >= WAVE) {
-                    process(WAVE);
-                    // move the tail of the queue to the front
-                    unsigned c2 = 0, o2 = 0;
-                    bool mv = WAVE + lane < qcount;
-                    if (mv) {
-                        c2 = qCode[WAVE + lane];
-                        o2 = qOff[WAVE + lane];
-                    }
-                    wave_lds_sync();
-                    if (mv) {
-                        qCode[lane] = c2;
-                        qOff[lane] = o2;
-                    }
-                    qcount -= WAVE;
-                    wave_lds_sync();
-                }
-            }
-            if (leaf_idx >= skip + remaining) break;  // the task's quota ends inside this subtree
-        }
-        if (qcount > 0) {
-            process(qcount);
             qcount = 0;
+            wave_lds_sync();
+            pc3 += __builtin_readcyclecounter() - td1;
+        };
+
+        // ---- enumerate the leaves below the prefix -------------------------------------------------------
+        // Explicit wave-uniform DFS over the L leaf levels (resumable, so that the solver above has a single
+        // call site).  At a non-leaf level the 64 lanes test the children of the current node in parallel
+        // (one edge test each) and the feasible ones are visited in slot order; at the last level the
+        // feasible lanes ARE the leaves, in enumeration order.
+        N3State node[L];
+        unsigned long long pend[L];
+        unsigned kids[L], pref[L];
+        int cbv[L];
+#pragma unroll
+        for (int l = 0; l < L; l++) {
+            node[l] = par;
+            pend[l] = 0;
+            kids[l] = 0;
+            pref[l] = 0;
+            cbv[l] = 0;
         }
+        int lvl = 0;
+        bool scanning = true;
+        auto step = [&](auto lv) {
+            constexpr int LV = decltype(lv)::value;
+            if constexpr (LV == L - 1) {
+                const int cb = cbv[LV];
+                const int slot = cb + lane;
+                const int ca = cb ? sa1 : sa0, cbb = cb ? sb1 : sb0;
+                N3State nx;
+                bool feas = slot < Q && n3_edge_ab(P, node[LV], ca, cbb, slot, D + LV, nx);
+                unsigned long long mask = ballot64(feas);
+                if (mask) {
+                    unsigned long long off = leaf_idx + mbcnt(mask);
+                    leaf_idx += __builtin_popcountll(mask);
+                    bool sel = feas && off >= skip && (off - skip) < remaining;
+                    unsigned long long smask = ballot64(sel);
+                    if (smask) {
+                        int pos = qcount + mbcnt(smask);
+                        if (sel) {
+                            qCode[pos] = pref[LV] | ((unsigned)(ca | (cbb << 4)) << (8 * LV));
+                            qOff[pos] = (unsigned)(off - skip);
+                        }
+                        qcount += __builtin_popcountll(smask);
+                    }
+                }
+                cbv[LV] = cb + WAVE;
+                if (leaf_idx >= skip + remaining) scanning = false;   // the task's quota ends inside this subtree
+                else if (cbv[LV] >= Q) {
+                    lvl = LV - 1;
+                    if (LV == 0) scanning = false;
+                }
+            } else {
+                if (pend[LV] == 0) {
+                    if (cbv[LV] >= Q) {
+                        lvl = LV - 1;
+                        if (LV == 0) scanning = false;
+                        return;
+                    }
+                    const int cb = cbv[LV];
+                    const int slot = cb + lane;
+                    const int ca = cb ? sa1 : sa0, cbb = cb ? sb1 : sb0;
+                    N3State nx;
+                    bool ok = slot < Q && n3_edge_ab(P, node[LV], ca, cbb, slot, D + LV, nx);
+                    pend[LV] = ballot64(ok);
+                    kids[LV] = ok ? n3_pack(nx) : 0u;
+                    cbv[LV] = cb + WAVE;
+                    return;
+                }
+                int bpos = __builtin_ctzll(pend[LV]);
+                pend[LV] &= pend[LV] - 1;
+                N3State child = n3_unpack((unsigned)__builtin_amdgcn_readlane((int)kids[LV], bpos));
+                node[LV + 1] = child;
+                pref[LV + 1] = pref[LV] | ((unsigned)(child.a | (child.b << 4)) << (8 * LV));
+                cbv[LV + 1] = 0;
+                pend[LV + 1] = 0;
+                lvl = LV + 1;
+            }
+        };
+        const unsigned long long ts0 = __builtin_readcyclecounter();
+        const unsigned long long in_drain0 = pc2 + pc3;
+        while (true) {
+            if (scanning) {
+                if (lvl == 0) step(std::integral_constant<int, 0>{});
+                else if (lvl == 1) { if constexpr (L > 1) step(std::integral_constant<int, 1>{}); }
+                else { if constexpr (L > 2) step(std::integral_constant<int, 2>{}); }
+            }
+            if (!scanning || qcount + WAVE > N3_QCAP) {
+                wave_lds_sync();
+                drain();
+                if (!scanning) break;
+            }
+        }
+        pc1 += (__builtin_readcyclecounter() - ts0) - ((pc2 + pc3) - in_drain0);
+        const unsigned long long tn0 = __builtin_readcyclecounter();
         unsigned long long consumed = 0;
         if (leaf_idx > skip) {
             consumed = leaf_idx - skip;
             if (consumed > remaining) consumed = remaining;
-            skip = 0;
-        } else {
-            skip -= leaf_idx;
         }
+        if (leaf_idx > skip) skip = 0; else skip -= leaf_idx;
         processed += consumed;
         remaining -= consumed;
         if (remaining == 0) break;
@@ -494,15 +641,17 @@ __global__ __launch_bounds__(64 * N3_WAVES) void n3_search_kernel(N3Dev Pg, Sear
             int d = D - 1;
             bool fresh = false, alive = true;
             while (true) {
-                int cur_slot = __builtin_amdgcn_readlane((int)st, d) & 0xff;
+                int cur_slot = __builtin_amdgcn_readlane((int)st, d) & 0x7f;
                 int start = fresh ? 0 : cur_slot + 1;
                 N3State pst = n3_unpack((unsigned)__builtin_amdgcn_readlane((int)st, d > 0 ? d - 1 : 0));
                 bool found = false;
                 unsigned packed = 0;
                 for (int cb = (start / WAVE) * WAVE; cb < Q && !found; cb += WAVE) {
-                    int s = cb + lane;
+                    const int s = cb + lane;
+                    const int ca = cb ? sa1 : sa0, cbb = cb ? sb1 : sb0;
                     N3State nx;
-                    bool ok = s >= start && s < Q && (d == 0 ? n3_first_row(P, s, nx) : n3_edge(P, pst, s, d, nx));
+                    bool ok = s >= start && s < Q &&
+                              (d == 0 ? n3_first_row_ab(P, ca, cbb, s, nx) : n3_edge_ab(P, pst, ca, cbb, s, d, nx));
                     unsigned long long mk = ballot64(ok);
                     if (mk) {
                         int first = __builtin_ctzll(mk);
@@ -527,6 +676,7 @@ __global__ __launch_bounds__(64 * N3_WAVES) void n3_search_kernel(N3Dev Pg, Sear
             }
             if (!alive) break;  // end of the enumeration (cannot happen inside a valid rank range)
         }
+        pc4 += __builtin_readcyclecounter() - tn0;
     }
 
     n_eval = wave_sum_u64(n_eval);
@@ -542,6 +692,12 @@ __global__ __launch_bounds__(64 * N3_WAVES) void n3_search_kernel(N3Dev Pg, Sear
         atomicAdd(&A.ctr->iterations, n_it);
         atomicAdd(&A.ctr->terms, n_terms);
         atomicAdd(&A.ctr->final_terms, n_fin);
+        atomicAdd(&A.ctr->prof[0], pc0);
+        atomicAdd(&A.ctr->prof[1], pc1);
+        atomicAdd(&A.ctr->prof[2], pc2);
+        atomicAdd(&A.ctr->prof[3], pc3);
+        atomicAdd(&A.ctr->prof[4], pc4);
+        atomicAdd(&A.ctr->prof[5], __builtin_readcyclecounter() - t_begin);
     }
 }
 

@@ -40,17 +40,17 @@ struct N3Host {
 };
 
 struct N3State {
-    int slot;   // row at this depth
+    int slot;   // row at this depth, slot = a + (K+1) b
     int sw;     // 1 while every row so far had a == b (Enumerator.py:181-183,199-202)
     int lo, hi; // feasible interval of the ratio mu1/mu2 as ranks in the sorted ratio table
+    int a, b;   // the row itself
 };
 
 // Enumerator._is_valid_row with allow_multi_event hard-wired True (Enumerator.py:55,262-264,286).
 __host__ __device__ inline bool n3_valid_row(int a, int b, int tau) { return (tau - a) * (tau - b) >= 0; }
 
-// First row of a matrix (Enumerator.py:175-186): in bounds, a <= b.
-__host__ __device__ inline bool n3_first_row(const N3Dev &P, int slot, N3State &out) {
-    int K1 = P.K + 1, a = slot % K1, b = slot / K1;
+// First row of a matrix (Enumerator.py:175-186): in bounds, a <= b.  (a, b) given, no division.
+__host__ __device__ inline bool n3_first_row_ab(const N3Dev &P, int a, int b, int slot, N3State &out) {
     if (!n3_valid_row(a, b, P.tau)) return false;
     int l = P.lb[0], u = P.ub[0];
     if (a < l || a > u || b < l || b > u) return false;
@@ -59,16 +59,21 @@ __host__ __device__ inline bool n3_first_row(const N3Dev &P, int slot, N3State &
     out.sw = (a == b);
     out.lo = 0;
     out.hi = P.NT + 1;
+    out.a = a;
+    out.b = b;
     return true;
 }
+__host__ __device__ inline bool n3_first_row(const N3Dev &P, int slot, N3State &out) {
+    int K1 = P.K + 1;
+    return n3_first_row_ab(P, slot % K1, slot / K1, slot, out);
+}
 
-// One DFS edge (Enumerator.py:192-212): may row `slot` at depth d follow state `par`?
-__host__ __device__ inline bool n3_edge(const N3Dev &P, const N3State &par, int slot, int d, N3State &out) {
-    int K1 = P.K + 1, a = slot % K1, b = slot / K1;
+// One DFS edge (Enumerator.py:192-212): may row (a, b) at depth d follow state `par`?
+__host__ __device__ inline bool n3_edge_ab(const N3Dev &P, const N3State &par, int a, int b, int slot, int d, N3State &out) {
     if (!n3_valid_row(a, b, P.tau)) return false;
     int l = P.lb[d], u = P.ub[d];
     if (a < l || a > u || b < l || b > u) return false;            // _in_bounds, :241
-    int pa = par.slot % K1, pb = par.slot / K1;
+    int pa = par.a, pb = par.b;
     if (!(slot == par.slot || a > pa || b > pb)) return false;     // _is_valid_edge, :258-260
     int sw = 0;
     if (par.sw) {                                                  // symmetry breaking, :199-202
@@ -86,7 +91,13 @@ __host__ __device__ inline bool n3_edge(const N3Dev &P, const N3State &par, int 
     out.sw = sw;
     out.lo = lo;
     out.hi = hi;
+    out.a = a;
+    out.b = b;
     return true;
+}
+__host__ __device__ inline bool n3_edge(const N3Dev &P, const N3State &par, int slot, int d, N3State &out) {
+    int K1 = P.K + 1;
+    return n3_edge_ab(P, par, slot % K1, slot / K1, slot, d, out);
 }
 
 #ifdef __HIPCC__
@@ -159,7 +170,7 @@ __device__ __forceinline__ void n3_newton_step(Terms &&terms, double s1, double 
     S.p1 = u1; S.p2 = u2;
     S.u1 = __builtin_fma(step, d1, u1);
     S.u2 = __builtin_fma(step, d2, u2);
-    if (lam < 1e-9) S.status = 1;
+    if (lam < 1e-6) S.status = 1;             // quadratic phase: the step just taken leaves an error ~lam^2
     else if (S.iters >= N3_MAX_ITERS || fabs(S.u1) + fabs(S.u2) > 1e8) S.status = 2;
 }
 
@@ -179,14 +190,18 @@ __device__ __forceinline__ bool n3_admissible(N3Newton &S, double s1, double s2)
     double nrm = sqrt(v1 * v1 + v2 * v2);
     if (!(nrm > 0.0)) return false;
     v1 /= nrm; v2 /= nrm;
-    double dn[3] = {-(s1 * v1 + s2 * v2), s1 * v1, s2 * v2};
-    double nu[3] = {n0, n1, n2};
+    const double d0 = -(s1 * v1 + s2 * v2), d1 = s1 * v1, d2 = s2 * v2;
     double slo = -1e300, shi = 1e300;
-    for (int j = 0; j < 3; j++) {
-        if (dn[j] > 0) { slo = fmax(slo, -nu[j] / dn[j]); shi = fmin(shi, (1.0 - nu[j]) / dn[j]); }
-        else if (dn[j] < 0) { slo = fmax(slo, (1.0 - nu[j]) / dn[j]); shi = fmin(shi, -nu[j] / dn[j]); }
-        else if (nu[j] < 0.0 || nu[j] > 1.0) return false;
-    }
+    bool dead = false;
+    auto clip = [&](double nu, double dn) {   // 0 <= nu + s dn <= 1
+        if (dn > 0) { slo = fmax(slo, -nu / dn); shi = fmin(shi, (1.0 - nu) / dn); }
+        else if (dn < 0) { slo = fmax(slo, (1.0 - nu) / dn); shi = fmin(shi, -nu / dn); }
+        else if (nu < 0.0 || nu > 1.0) dead = true;
+    };
+    clip(n0, d0);
+    clip(n1, d1);
+    clip(n2, d2);
+    if (dead) return false;
     if (!(slo <= shi)) return false;
     double s = 0.5 * (slo + shi);
     S.u1 += s * v1;
