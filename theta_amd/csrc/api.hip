@@ -17,7 +17,7 @@ void n2_launch_enumerate(const N2Dev &P, unsigned long long begin, unsigned long
                          hipStream_t st);
 void n2_launch_unrank_list(const N2Dev &P, const TieRecord *recs, int count, unsigned char *out, hipStream_t st);
 
-int n3_build_host(int m, const int32_t *lb_in, const int32_t *ub_in, N3Host &h);
+int n3_build_host(int m, int tau, const int32_t *lb_in, const int32_t *ub_in, N3Host &h);
 int n3_run_dp(const N3Dev &P, u128 *cnt, unsigned *overflow_dev, unsigned long long *total_dev, hipStream_t st);
 void n3_launch_tasks(const N3Dev &P, u128 begin, u128 end, uint64_t per_task, int ntasks, N3Task *tasks,
                      unsigned *stbuf, hipStream_t st);
@@ -113,7 +113,7 @@ struct theta_problem {
     N3Host n3h;
     N3Dev n3{};
     uint64_t total[2] = {0, 0};
-    DevBuf d_r, d_rN, d_small, d_P, d_PR, d_PN, d_cnt, d_ctr, d_list, d_tasks, d_stbuf, d_misc;
+    DevBuf d_r, d_rN, d_small, d_P, d_PR, d_PN, d_cnt, d_ctr, d_list, d_tasks, d_stbuf, d_misc, d_smask;
 };
 
 static int upload(DevBuf &b, const void *src, size_t bytes, hipStream_t st) {
@@ -243,25 +243,27 @@ extern "C" int theta_problem_create(theta_ctx *ctx, int n, int m, int tau, const
         p->total[0] = h.total;
         p->total[1] = 0;
     } else {
-        TRY(n3_build_host(m, lb, ub, p->n3h));
+        TRY(n3_build_host(m, tau, lb, ub, p->n3h));
         const N3Host &h = p->n3h;
-        std::vector<unsigned char> small(2 * (size_t)m + h.ridx.size(), 0);
+        std::vector<unsigned char> small(2 * (size_t)m + h.ridx.size() + h.rowtab.size(), 0);
         for (int i = 0; i < m; i++) {
             small[i] = (unsigned char)h.lb[i];
             small[m + i] = (unsigned char)h.ub[i];
         }
         memcpy(small.data() + 2 * m, h.ridx.data(), h.ridx.size());
+        memcpy(small.data() + 2 * m + h.ridx.size(), h.rowtab.data(), h.rowtab.size());
         TRY(upload(p->d_small, small.data(), small.size(), st));
+        TRY(upload(p->d_smask, h.smask.data(), h.smask.size() * sizeof(unsigned long long), st));
         N3Dev &D = p->n3;
         D.m = m;
         D.K = h.K;
         D.Q = h.Q;
         D.tau = tau;
         D.NT = h.NT;
-        int L = (m >= 3) ? 2 : 1;
+        int L = 5;   // leaf levels enumerated by the lanes (tuned on MI355X)
         if (const char *e = getenv("THETA_N3_LEAF_LEVELS")) {
             int v = atoi(e);
-            if (v >= 1 && v <= 3) L = v;
+            if (v >= 1 && v <= 8) L = v;
         }
         if (L > m - 1) L = m - 1;
         D.L = L;
@@ -273,6 +275,10 @@ extern "C" int theta_problem_create(theta_ctx *ctx, int n, int m, int tau, const
         D.lb = (const unsigned char *)p->d_small.p;
         D.ub = D.lb + m;
         D.ridx = D.lb + 2 * m;
+        D.rowtab = D.ridx + h.ridx.size();
+        D.smask = (const unsigned long long *)p->d_smask.p;
+        D.swmask[0] = h.swmask[0];
+        D.swmask[1] = h.swmask[1];
         size_t per_level = (size_t)h.Q * 2 * (h.NT + 1) * (h.NT + 1);
         size_t cnt_bytes = per_level * m * sizeof(u128);
         if (cnt_bytes > (size_t)ctx->hbm_bytes / 2) {
@@ -371,7 +377,11 @@ static int run_search(theta_problem *p, u128 b, u128 e, double window, double *d
             n2_launch_search(p->n2, A, nb, ne, (int)per, st);
         } else {
             u128 cnt = e - b;
-            uint64_t per_task = 4096;
+            uint64_t per_task = 16384;   // candidates per wave; each lane then walks ~256 consecutive leaves
+            if (const char *e = getenv("THETA_N3_PER_TASK")) {
+                long long v = atoll(e);
+                if (v >= 64) per_task = (uint64_t)v;
+            }
             u128 nt = (cnt + per_task - 1) / per_task;
             if (nt > N3_MAX_TASKS) {
                 nt = N3_MAX_TASKS;

@@ -167,11 +167,33 @@ __global__ __launch_bounds__(64) void solve_batch_n3_kernel(int m, int tau, cons
         Sv.u1 = (1.0 / 3.0) / s1;
         Sv.u2 = (1.0 / 3.0) / s2;
         Sv.p1 = Sv.u1; Sv.p2 = Sv.u2;
-        Sv.h11 = Sv.h12 = Sv.h22 = Sv.g1 = Sv.g2 = Sv.lam = 0.0;
         Sv.iters = 0;
         Sv.status = 0;
-        while (Sv.status == 0) n3_newton_step(terms, s1, s2, Rtot, Sv);
-        good = (Sv.status == 1) && n3_admissible(Sv, s1, s2);
+        Sv.singular = false;
+        const double inv_R = 1.0 / Rtot;
+        while (Sv.status == 0) n3_newton_step(terms, s1, s2, inv_R, Sv);
+        good = Sv.status == 1;
+        if (good) {
+            double n1 = s1 * Sv.u1, n2 = s2 * Sv.u2, n0 = 1.0 - n1 - n2;
+            bool in = (n0 >= 0.0 && n0 <= 1.0 && n1 >= 0.0 && n1 <= 1.0 && n2 >= 0.0 && n2 <= 1.0);
+            if (!in && Sv.singular) {   // rank-deficient: the minimiser is a line, intersect it with the simplex
+                N3Hess H;
+                H.u1 = Sv.u1; H.u2 = Sv.u2;
+                H.h11 = H.h12 = H.h22 = 0.0;
+                terms([&](double x, double y, double R) {
+                    double a = x - s1, bb = y - s2;
+                    double q = __builtin_fma(a, H.u1, __builtin_fma(bb, H.u2, 1.0));
+                    double tw = R / (q * q);
+                    H.h11 = __builtin_fma(tw * a, a, H.h11);
+                    H.h12 = __builtin_fma(tw * a, bb, H.h12);
+                    H.h22 = __builtin_fma(tw * bb, bb, H.h22);
+                });
+                in = n3_admissible(H, s1, s2);
+                Sv.u1 = H.u1;
+                Sv.u2 = H.u2;
+            }
+            good = in;
+        }
     }
     if (!good) {
         ok[b] = 0;

@@ -22,7 +22,7 @@
 // ------------------------------------------------------------------------------------------------
 // host: bounds, ratio table
 // ------------------------------------------------------------------------------------------------
-int n3_build_host(int m, const int32_t *lb_in, const int32_t *ub_in, N3Host &h) {
+int n3_build_host(int m, int tau, const int32_t *lb_in, const int32_t *ub_in, N3Host &h) {
     h.m = m;
     h.lb.assign(lb_in, lb_in + m);
     h.ub.assign(ub_in, ub_in + m);
@@ -71,6 +71,26 @@ int n3_build_host(int m, const int32_t *lb_in, const int32_t *ub_in, N3Host &h) 
             if (v.d < 0) { v.n = -v.n; v.d = -v.d; }
             int idx = (int)(std::lower_bound(fr.begin(), fr.end(), v, less) - fr.begin());
             h.ridx[(dy + N3_MAX_K) * N3_RIDX_W + (dx + N3_MAX_K)] = (unsigned char)(idx + 1);
+        }
+    // slot -> row, and for every depth d and parent row the set of rows that may follow it by the static
+    // rules (valid row, bounds of depth d, Enumerator._is_valid_edge); the kernels add the dynamic ones
+    const int K1 = top + 1;
+    h.rowtab.assign(h.Q, 0);
+    for (int s = 0; s < h.Q; s++) {
+        int a = s % K1, b = s / K1;
+        h.rowtab[s] = (unsigned char)(a | (b << 4));
+        if (a <= b) h.swmask[s >> 6] |= 1ull << (s & 63);
+    }
+    h.smask.assign((size_t)m * N3_MAX_Q * 2, 0ull);
+    for (int d = 0; d < m; d++)
+        for (int ps = 0; ps < h.Q; ps++) {
+            int pa = ps % K1, pb = ps / K1;
+            for (int s = 0; s < h.Q; s++) {
+                int a = s % K1, b = s / K1;
+                bool ok = n3_valid_row(a, b, tau) && a >= h.lb[d] && a <= h.ub[d] && b >= h.lb[d] && b <= h.ub[d] &&
+                          (s == ps || a > pa || b > pb);
+                if (ok) h.smask[((size_t)d * N3_MAX_Q + ps) * 2 + (s >> 6)] |= 1ull << (s & 63);
+            }
         }
     return THETA_OK;
 }
@@ -224,14 +244,20 @@ __device__ __forceinline__ double readlane_f64(double v, int l) {
 }
 
 #define N3_WAVES 4
-#define N3_QCAP 256     // leaves of one prefix held in LDS at a time (per wave)
+#define N3_QCAP 128     // leaves solved per round (per wave)
+#define N3_MAX_L 8      // leaf levels (one byte of the 64-bit leaf code each)
 
 struct N3Lds {
-    double gX[N3_WAVES][N3_MAX_Q + 1], gY[N3_WAVES][N3_MAX_Q + 1], gR[N3_WAVES][N3_MAX_Q + 1];
+    double gX[N3_WAVES][N3_MAX_Q + N3_MAX_L], gY[N3_WAVES][N3_MAX_Q + N3_MAX_L], gR[N3_WAVES][N3_MAX_Q + N3_MAX_L];
     double resU1[N3_WAVES][N3_QCAP], resU2[N3_WAVES][N3_QCAP];
-    unsigned qCode[N3_WAVES][N3_QCAP], qOff[N3_WAVES][N3_QCAP], resSt[N3_WAVES][N3_QCAP];
+    unsigned long long qCode[N3_WAVES][N3_QCAP];
+    unsigned resSt[N3_WAVES][N3_QCAP], qOff[N3_WAVES][N3_QCAP];
+    unsigned stk[N3_WAVES][N3_MAX_L][WAVE];      // lane-private DFS stacks over the leaf levels
+    unsigned long long smask[N3_MAX_L][N3_MAX_Q][2];  // static child masks of the leaf depths
+    double leafR[N3_MAX_L], leafN[N3_MAX_L];
     unsigned char lb[N3_MAX_M], ub[N3_MAX_M];
     unsigned char ridx[N3_RIDX_W * N3_RIDX_W + 3];
+    unsigned char rowtab[N3_MAX_Q + 3];
 };
 
 // status word of a solved leaf: bits 0-1 state (1 converged, 2 failed, 3 degenerate), bit 2 singular Hessian,
@@ -241,16 +267,45 @@ struct N3Lds {
 #define RES_DEGEN 3u
 #define RES_SINGULAR 4u
 
-template <int L, bool DUMP>
-__global__ __launch_bounds__(64 * N3_WAVES) void n3_search_kernel(N3Dev Pg, SearchArgs A, const N3Task *tasks,
-                                                                   const unsigned *stbuf, int ntasks, uint64_t per_task) {
+// Dynamic part of the edge test for a child that already passed the static mask (valid row, bounds,
+// edge rule) and the symmetry mask: only the ratio window remains (Enumerator.py:204-212).
+__device__ __forceinline__ bool n3_child_dyn(const unsigned char *ridx, const unsigned char *rowtab, const N3State &par,
+                                             int slot, N3State &out) {
+    unsigned rw = rowtab[slot];
+    int a = rw & 15, b = rw >> 4;
+    int lo = par.lo, hi = par.hi;
+    int dx = a - par.a, dy = b - par.b;
+    if (dx != 0 && dy != 0) {
+        int t = ridx[(dy + N3_MAX_K) * N3_RIDX_W + (dx + N3_MAX_K)];
+        if (dx > 0) lo = (t > lo) ? t : lo; else hi = (t < hi) ? t : hi;
+    }
+    out.slot = slot;
+    out.sw = par.sw && (a == b);
+    out.lo = lo;
+    out.hi = hi;
+    out.a = a;
+    out.b = b;
+    return lo <= hi;
+}
+
+template <bool DUMP>
+__global__ __launch_bounds__(64 * N3_WAVES, 3) void n3_search_kernel(N3Dev Pg, SearchArgs A, const N3Task *tasks,
+                                                                const unsigned *stbuf, int ntasks, uint64_t per_task) {
     __shared__ N3Lds S;
+    const int m = Pg.m, L = Pg.L, D = m - L, Q = Pg.Q;
     // stage what every wave of the block shares
-    for (int i = threadIdx.x; i < Pg.m; i += blockDim.x) {
+    for (int i = threadIdx.x; i < m; i += blockDim.x) {
         S.lb[i] = Pg.lb[i];
         S.ub[i] = Pg.ub[i];
     }
     for (int i = threadIdx.x; i < N3_RIDX_W * N3_RIDX_W; i += blockDim.x) S.ridx[i] = Pg.ridx[i];
+    for (int i = threadIdx.x; i < Q; i += blockDim.x) S.rowtab[i] = Pg.rowtab[i];
+    for (int i = threadIdx.x; i < L * N3_MAX_Q * 2; i += blockDim.x)
+        (&S.smask[0][0][0])[i] = Pg.smask[(size_t)D * N3_MAX_Q * 2 + i];
+    for (int i = threadIdx.x; i < L; i += blockDim.x) {
+        S.leafR[i] = Pg.r[D + i];
+        S.leafN[i] = Pg.rN[D + i];
+    }
     __syncthreads();
     N3Dev P = Pg;
     P.lb = S.lb;
@@ -260,16 +315,18 @@ __global__ __launch_bounds__(64 * N3_WAVES) void n3_search_kernel(N3Dev Pg, Sear
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int task = blockIdx.x * N3_WAVES + wv;
     if (task >= ntasks) return;  // whole wave leaves together; no block barrier below
-    const int m = P.m, D = m - L, Q = P.Q, K1 = P.K + 1;
     const double tau = (double)P.tau;
     double *gX = S.gX[wv], *gY = S.gY[wv], *gR = S.gR[wv];
     double *resU1 = S.resU1[wv], *resU2 = S.resU2[wv];
-    unsigned *qCode = S.qCode[wv], *qOff = S.qOff[wv], *resSt = S.resSt[wv];
+    unsigned long long *qCode = S.qCode[wv];
+    unsigned *resSt = S.resSt[wv], *qOff = S.qOff[wv];
+    const unsigned long long swm0 = Pg.swmask[0], swm1 = Pg.swmask[1];
 
-    // lane i holds interval i; lane s (+64) also stands for alphabet slot s when children are tested
+    // lane i holds interval i; lane s (+64) also stands for alphabet slot s in the prefix successor
     const double r_i = lane < m ? Pg.r[lane] : 0.0;
     const double rN_i = lane < m ? Pg.rN[lane] : 0.0;
     unsigned st = lane < D ? stbuf[(size_t)task * N3_MAX_M + lane] : 0u;
+    const int K1 = P.K + 1;
     const int sa0 = lane % K1, sb0 = lane / K1, sa1 = (lane + WAVE) % K1, sb1 = (lane + WAVE) / K1;
 
     const N3Task tk = tasks[task];
@@ -277,15 +334,9 @@ __global__ __launch_bounds__(64 * N3_WAVES) void n3_search_kernel(N3Dev Pg, Sear
     unsigned long long remaining = tk.count, skip = tk.skip, processed = 0;
     const unsigned long long dump_base = (unsigned long long)task * per_task;  // position of the task in the dump arrays
 
-    // leaf rows' shared data (wave-uniform)
-    double leafR[L], leafN[L];
-#pragma unroll
-    for (int l = 0; l < L; l++) {
-        leafR[l] = readlane_f64(r_i, D + l);
-        leafN[l] = readlane_f64(rN_i, D + l);
-    }
     // screening margin for the single-precision NLL: |error| <= Rtot * (|ln q| * 2^-23 + 2^-22) stays far below this
     const double screen_margin = 2e-5 * P.Rtot + 1.0;
+    const double inv_N = 1.0 / P.N, inv_Rtot = 1.0 / P.Rtot;
 
     unsigned long long n_eval = 0, n_acc = 0, n_deg = 0, n_it = 0, n_terms = 0, n_fin = 0;
     double best = order_unbits(load_agent_u64(&A.ctr->best_bits));
@@ -293,6 +344,39 @@ __global__ __launch_bounds__(64 * N3_WAVES) void n3_search_kernel(N3Dev Pg, Sear
     // warm start (wave-uniform): mixture fractions of the best candidate of the previous batch, pulled
     // towards the centre of the simplex so that it is interior for every candidate
     double ws1 = 1.0 / 3.0, ws2 = 1.0 / 3.0;
+
+    // ---- lane-private DFS over the leaf levels -----------------------------------------------------------
+    // children of `node` at leaf level l, as a 128-bit mask of alphabet slots (static rules + symmetry)
+    auto child_mask = [&](const N3State &node, int l, unsigned long long &m0, unsigned long long &m1) {
+        m0 = S.smask[l][node.slot][0];
+        m1 = S.smask[l][node.slot][1];
+        if (node.sw) {
+            m0 &= swm0;
+            m1 &= swm1;
+        }
+    };
+    // first feasible child of `node` at level l with slot >= from; returns false if none
+    auto next_child = [&](const N3State &node, int l, int from, N3State &out) -> bool {
+        unsigned long long m0, m1;
+        child_mask(node, l, m0, m1);
+        if (from >= 64) {
+            m0 = 0;
+            m1 &= (from >= 128) ? 0ull : (~0ull << (from - 64));
+        } else {
+            m0 &= ~0ull << from;
+        }
+        while (m0) {
+            int s = __builtin_ctzll(m0);
+            m0 &= m0 - 1;
+            if (n3_child_dyn(S.ridx, S.rowtab, node, s, out)) return true;
+        }
+        while (m1) {
+            int s = 64 + __builtin_ctzll(m1);
+            m1 &= m1 - 1;
+            if (n3_child_dyn(S.ridx, S.rowtab, node, s, out)) return true;
+        }
+        return false;
+    };
 
     unsigned long long pc0 = 0, pc1 = 0, pc2 = 0, pc3 = 0, pc4 = 0;
     const unsigned long long t_begin = __builtin_readcyclecounter();
@@ -328,314 +412,311 @@ __global__ __launch_bounds__(64 * N3_WAVES) void n3_search_kernel(N3Dev Pg, Sear
             }
         }
         wave_lds_sync();
-
         pc0 += __builtin_readcyclecounter() - t0;
+
         const N3State par = n3_unpack((unsigned)__builtin_amdgcn_readlane((int)st, D - 1));
-        unsigned long long leaf_idx = 0;
-        int qcount = 0;
+        // number of leaves below the prefix (exact, from the counting table); only its low part matters
+        // here because a task never holds more than 2^47 candidates
+        unsigned long long T;
+        {
+            u128 tv = Pg.cnt[n3_cnt_index(Pg, D - 1, par.slot, par.sw, par.lo, par.hi)];
+            T = (tv >> 64) ? ~0ull : (unsigned long long)tv;
+        }
+        const unsigned long long lo_idx = skip < T ? skip : T;
+        unsigned long long hi_idx = (T - lo_idx > remaining) ? lo_idx + remaining : T;
 
-        // ---- solve every queued leaf: persistent lanes, refilled from the queue as they converge -------
-        auto drain = [&]() {
-            if (qcount == 0) return;
-            const unsigned long long td0 = __builtin_readcyclecounter();
-            int head = 0;
-            bool have = false;
-            int myidx = 0;
-            double lx[L], ly[L], s1 = 1.0, s2 = 1.0;
-            N3Newton Sv;
-            Sv.status = 0;
-            auto terms = [&](auto &&body) {
-#pragma unroll 2
-                for (int g = 0; g < G; g++) body(gX[g], gY[g], gR[g]);
-#pragma unroll
-                for (int l = 0; l < L; l++) body(lx[l], ly[l], leafR[l]);
-            };
-            while (true) {
-                // refill idle lanes
-                unsigned long long idle = ballot64(!have);
-                if (head < qcount && idle) {
-                    int want = head + mbcnt(idle);
-                    bool take = !have && want < qcount;
-                    int ntake = __builtin_popcountll(idle);
-                    if (ntake > qcount - head) ntake = qcount - head;
-                    head += ntake;
-                    if (take) {
-                        myidx = want;
-                        unsigned code = qCode[want];
-                        double S1 = S1p, S2 = S2p;
-#pragma unroll
-                        for (int l = 0; l < L; l++) {
-                            unsigned rw = (code >> (8 * l)) & 0xffu;
-                            lx[l] = (double)(rw & 15u);
-                            ly[l] = (double)(rw >> 4);
-                            S1 = __builtin_fma(lx[l], leafN[l], S1);
-                            S2 = __builtin_fma(ly[l], leafN[l], S2);
+        // ---- lane-private enumeration: the prefix's leaves [lo_idx, hi_idx) are cut into 64 contiguous chunks;
+        // every lane unranks the first leaf of its chunk ONCE (counting table) and then walks its chunk with
+        // the DFS successor, a few leaves per round.
+        const unsigned long long nleaf = hi_idx - lo_idx;
+        const unsigned long long chunk = (nleaf + WAVE - 1) / WAVE;
+        unsigned long long my_first = (unsigned long long)lane * chunk;
+        unsigned long long my_left = my_first < nleaf ? ((nleaf - my_first < chunk) ? nleaf - my_first : chunk) : 0;
+        unsigned my_rel = (unsigned)(processed + my_first);
+        unsigned long long code = 0;
+        {
+            const unsigned long long tu0 = __builtin_readcyclecounter();
+            if (my_left > 0) {
+                unsigned long long idx = lo_idx + my_first;
+                N3State node = par, ch;
+                bool okp = true;
+                for (int l = 0; l < L && okp; l++) {
+                    int from = 0;
+                    bool found = false;
+                    while (next_child(node, l, from, ch)) {
+                        unsigned long long cv = 1;
+                        if (l < L - 1) {
+                            u128 tv = Pg.cnt[n3_cnt_index(Pg, D + l, ch.slot, ch.sw, ch.lo, ch.hi)];
+                            cv = (tv >> 64) ? ~0ull : (unsigned long long)tv;
                         }
-                        if (S1 == 0.0 || S2 == 0.0) {      // all-zero tumour column: the reference's Chat is NaN
-                            resSt[want] = RES_DEGEN;
-                        } else {
-                            have = true;
-                            s1 = S1 / P.N;
-                            s2 = S2 / P.N;
-                            Sv.u1 = ws1 / s1;               // nu -> u
-                            Sv.u2 = ws2 / s2;
-                            Sv.p1 = Sv.u1; Sv.p2 = Sv.u2;
-                            Sv.h11 = Sv.h12 = Sv.h22 = Sv.g1 = Sv.g2 = Sv.lam = 0.0;
-                            Sv.iters = 0;
-                            Sv.status = 0;
+                        if (idx < cv) {
+                            found = true;
+                            break;
                         }
+                        idx -= cv;
+                        from = ch.slot + 1;
+                    }
+                    okp = found;
+                    if (found) {
+                        S.stk[wv][l][lane] = n3_pack(ch);
+                        code |= (unsigned long long)(ch.a | (ch.b << 4)) << (8 * l);
+                        node = ch;
                     }
                 }
-                if (!ballot64(have)) {
-                    if (head >= qcount) break;
-                    continue;   // only degenerate leaves were taken this round
-                }
-                if (have) {
-                    n3_newton_step(terms, s1, s2, P.Rtot, Sv);
-                    if (Sv.status != 0) {
-                        double det0 = Sv.h11 * Sv.h22 - Sv.h12 * Sv.h12;
-                        unsigned sing = (det0 <= 1e-10 * Sv.h11 * Sv.h22) ? RES_SINGULAR : 0u;
-                        bool conv = Sv.status == 1;
-                        resU1[myidx] = conv ? Sv.u1 : Sv.p1;      // failed: last feasible iterate
-                        resU2[myidx] = conv ? Sv.u2 : Sv.p2;
-                        resSt[myidx] = (conv ? RES_CONV : RES_FAIL) | sing | ((unsigned)Sv.iters << 8);
-                        have = false;
-                    }
-                }
+                if (!okp) my_left = 0;   // cannot happen: the counting table says the leaf exists
             }
-            wave_lds_sync();
-            const unsigned long long td1 = __builtin_readcyclecounter();
-            pc2 += td1 - td0;
-
-            // ---- values, admissibility, minimum tracking: full 64-wide batches ------------------------
-            for (int b0 = 0; b0 < qcount; b0 += WAVE) {
-                const int idx = b0 + lane;
-                const bool live = idx < qcount;
-                unsigned code = live ? qCode[idx] : 0u;
-                unsigned stw = live ? resSt[idx] : RES_DEGEN;
-                double u1 = live ? resU1[idx] : 0.0, u2 = live ? resU2[idx] : 0.0;
-                const unsigned long long rel = processed + (live ? qOff[idx] : 0u);
-                double S1 = S1p, S2 = S2p;
-#pragma unroll
-                for (int l = 0; l < L; l++) {
-                    unsigned rw = (code >> (8 * l)) & 0xffu;
-                    lx[l] = (double)(rw & 15u);
-                    ly[l] = (double)(rw >> 4);
-                    S1 = __builtin_fma(lx[l], leafN[l], S1);
-                    S2 = __builtin_fma(ly[l], leafN[l], S2);
+            pc1 += __builtin_readcyclecounter() - tu0;
+        }
+        for (unsigned long long done = 0; done < nleaf;) {
+            const unsigned long long ts0 = __builtin_readcyclecounter();
+            int qcount = 0;
+            for (int j = 0; j < N3_QCAP / WAVE; j++) {
+                const bool act = my_left > 0;
+                const unsigned long long mk = ballot64(act);
+                if (!mk) break;
+                if (act) {
+                    const int pos = qcount + mbcnt(mk);
+                    qCode[pos] = code;
+                    qOff[pos] = my_rel;
+                    my_rel++;
+                    my_left--;
+                    if (my_left > 0) {   // next leaf of this lane's chunk in DFS order
+                        int l = L - 1;
+                        bool fresh = false;
+                        N3State ch;
+                        while (true) {
+                            N3State pn = (l == 0) ? par : n3_unpack(S.stk[wv][l - 1][lane]);
+                            int from = fresh ? 0 : (int)(S.stk[wv][l][lane] & 0x7f) + 1;
+                            if (next_child(pn, l, from, ch)) {
+                                S.stk[wv][l][lane] = n3_pack(ch);
+                                code = (code & ~(0xffull << (8 * l))) | ((unsigned long long)(ch.a | (ch.b << 4)) << (8 * l));
+                                if (l == L - 1) break;
+                                l++;
+                                fresh = true;
+                            } else {
+                                l--;
+                                fresh = false;
+                                if (l < 0) {
+                                    my_left = 0;   // cannot happen inside the counted range
+                                    break;
+                                }
+                            }
+                        }
+                    }
                 }
-                const unsigned kind = stw & 3u;
-                const bool degenerate = live && kind == RES_DEGEN;
-                const bool solved = live && kind != RES_DEGEN;
-                const bool conv = solved && kind == RES_CONV;
-                s1 = solved ? S1 / P.N : 1.0;
-                s2 = solved ? S2 / P.N : 1.0;
-                const int iters = (int)(stw >> 8);
-                // admissibility (Optimizer.py:150-160): all nu_j in [0,1]
-                bool accept = false;
-                if (conv) {
-                    double n1 = s1 * u1, n2 = s2 * u2, n0 = 1.0 - n1 - n2;
-                    accept = (n0 >= 0.0 && n0 <= 1.0 && n1 >= 0.0 && n1 <= 1.0 && n2 >= 0.0 && n2 <= 1.0);
-                    if (!accept && (stw & RES_SINGULAR)) {
-                        // rank-deficient candidate: the minimiser is a line; rebuild H and intersect with the simplex
-                        N3Newton T;
-                        T.u1 = u1; T.u2 = u2;
-                        T.h11 = T.h12 = T.h22 = 0.0;
+                qcount += __builtin_popcountll(mk);
+            }
+            done += (unsigned long long)qcount;
+            if (qcount == 0) break;
+            wave_lds_sync();
+            const unsigned long long td0 = __builtin_readcyclecounter();
+            pc1 += td0 - ts0;
+
+            // ---- solve every queued leaf: persistent lanes, refilled from the queue as they converge -------
+            {
+                int head = 0;
+                bool have = false;
+                int myidx = 0;
+                unsigned long long mycode = 0;
+                double s1 = 1.0, s2 = 1.0;
+                N3Newton Sv;
+                Sv.status = 0;
+                auto terms = [&](auto &&body) {
+#pragma unroll 4
+                    for (int g = 0; g < G; g++) body(gX[g], gY[g], gR[g]);
+                    for (int l = 0; l < L; l++) {
+                        unsigned rw = (unsigned)(mycode >> (8 * l)) & 0xffu;
+                        body((double)(rw & 15u), (double)(rw >> 4), S.leafR[l]);
+                    }
+                };
+                while (true) {
+                    unsigned long long idle = ballot64(!have);
+                    if (head < qcount && idle) {
+                        int want = head + mbcnt(idle);
+                        bool take = !have && want < qcount;
+                        int ntake = __builtin_popcountll(idle);
+                        if (ntake > qcount - head) ntake = qcount - head;
+                        head += ntake;
+                        if (take) {
+                            myidx = want;
+                            mycode = qCode[want];
+                            double S1 = S1p, S2 = S2p;
+                            for (int l = 0; l < L; l++) {
+                                unsigned rw = (unsigned)(mycode >> (8 * l)) & 0xffu;
+                                S1 = __builtin_fma((double)(rw & 15u), S.leafN[l], S1);
+                                S2 = __builtin_fma((double)(rw >> 4), S.leafN[l], S2);
+                            }
+                            if (S1 == 0.0 || S2 == 0.0 || mycode == ~0ull) {   // all-zero tumour column: Chat is NaN
+                                resSt[want] = RES_DEGEN;
+                            } else {
+                                have = true;
+                                s1 = S1 * inv_N;
+                                s2 = S2 * inv_N;
+                                Sv.u1 = ws1 * rcp_nr2(s1);      // nu -> u
+                                Sv.u2 = ws2 * rcp_nr2(s2);
+                                Sv.p1 = Sv.u1; Sv.p2 = Sv.u2;
+                                Sv.iters = 0;
+                                Sv.status = 0;
+                                Sv.singular = false;
+                            }
+                        }
+                    }
+                    if (!ballot64(have)) {
+                        if (head >= qcount) break;
+                        continue;   // only degenerate leaves were taken this round
+                    }
+                    if (have) {
+                        n3_newton_step(terms, s1, s2, inv_Rtot, Sv);
+                        if (Sv.status != 0) {
+                            unsigned sing = Sv.singular ? RES_SINGULAR : 0u;
+                            bool conv = Sv.status == 1;
+                            resU1[myidx] = conv ? Sv.u1 : Sv.p1;      // failed: last feasible iterate
+                            resU2[myidx] = conv ? Sv.u2 : Sv.p2;
+                            resSt[myidx] = (conv ? RES_CONV : RES_FAIL) | sing | ((unsigned)Sv.iters << 8);
+                            have = false;
+                        }
+                    }
+                }
+                wave_lds_sync();
+                const unsigned long long td1 = __builtin_readcyclecounter();
+                pc2 += td1 - td0;
+
+                // ---- values, admissibility, minimum tracking: full 64-wide batches ------------------------
+                for (int b0 = 0; b0 < qcount; b0 += WAVE) {
+                    const int idx = b0 + lane;
+                    const bool live = idx < qcount;
+                    mycode = live ? qCode[idx] : ~0ull;
+                    unsigned stw = live ? resSt[idx] : RES_DEGEN;
+                    double u1 = live ? resU1[idx] : 0.0, u2 = live ? resU2[idx] : 0.0;
+                    const unsigned long long rel = live ? qOff[idx] : 0u;
+                    double S1 = S1p, S2 = S2p;
+                    for (int l = 0; l < L; l++) {
+                        unsigned rw = (unsigned)(mycode >> (8 * l)) & 0xffu;
+                        S1 = __builtin_fma((double)(rw & 15u), S.leafN[l], S1);
+                        S2 = __builtin_fma((double)(rw >> 4), S.leafN[l], S2);
+                    }
+                    const unsigned kind = stw & 3u;
+                    const bool degenerate = live && kind == RES_DEGEN;
+                    const bool solved = live && kind != RES_DEGEN;
+                    const bool conv = solved && kind == RES_CONV;
+                    s1 = solved ? S1 * inv_N : 1.0;
+                    s2 = solved ? S2 * inv_N : 1.0;
+                    const int iters = (int)(stw >> 8);
+                    // admissibility (Optimizer.py:150-160): all nu_j in [0,1]
+                    bool accept = false;
+                    if (conv) {
+                        double n1 = s1 * u1, n2 = s2 * u2, n0 = 1.0 - n1 - n2;
+                        accept = (n0 >= 0.0 && n0 <= 1.0 && n1 >= 0.0 && n1 <= 1.0 && n2 >= 0.0 && n2 <= 1.0);
+                        if (!accept && (stw & RES_SINGULAR)) {
+                            // rank-deficient candidate: the minimiser is a line; rebuild H and intersect with the simplex
+                            N3Hess T2;
+                            T2.u1 = u1; T2.u2 = u2;
+                            T2.h11 = T2.h12 = T2.h22 = 0.0;
+                            terms([&](double x, double y, double R) {
+                                double a = x - s1, b = y - s2;
+                                double q = __builtin_fma(a, u1, __builtin_fma(b, u2, 1.0));
+                                double tw = R / (q * q);
+                                T2.h11 = __builtin_fma(tw * a, a, T2.h11);
+                                T2.h12 = __builtin_fma(tw * a, b, T2.h12);
+                                T2.h22 = __builtin_fma(tw * b, b, T2.h22);
+                            });
+                            accept = n3_admissible(T2, s1, s2);
+                            u1 = T2.u1;
+                            u2 = T2.u2;
+                        }
+                    }
+                    // single-precision screen of sum R ln q, then the exact value only for contenders
+                    double accf = 0.0, g1 = 0.0, g2 = 0.0;
+                    if (solved) {
                         terms([&](double x, double y, double R) {
                             double a = x - s1, b = y - s2;
                             double q = __builtin_fma(a, u1, __builtin_fma(b, u2, 1.0));
-                            double tw = R / (q * q);
-                            T.h11 = __builtin_fma(tw * a, a, T.h11);
-                            T.h12 = __builtin_fma(tw * a, b, T.h12);
-                            T.h22 = __builtin_fma(tw * b, b, T.h22);
+                            accf = __builtin_fma(R, (double)__logf((float)q), accf);
+                            double t = R * rcp_nr1(q);
+                            g1 = __builtin_fma(t, a, g1);
+                            g2 = __builtin_fma(t, b, g2);
                         });
-                        accept = n3_admissible(T, s1, s2);
-                        u1 = T.u1;
-                        u2 = T.u2;
                     }
-                }
-                // single-precision screen of sum R ln q, then the exact value only for contenders
-                double accf = 0.0, g1 = 0.0, g2 = 0.0;
-                if (solved) {
-                    terms([&](double x, double y, double R) {
-                        double a = x - s1, b = y - s2;
-                        double q = __builtin_fma(a, u1, __builtin_fma(b, u2, 1.0));
-                        accf = __builtin_fma(R, (double)__logf((float)q), accf);
-                        double t = R * rcp_nr1(q);
-                        g1 = __builtin_fma(t, a, g1);
-                        g2 = __builtin_fma(t, b, g2);
-                    });
-                }
-                double nll = P.K0 - accf;
-                // Frank-Wolfe bound for rejected candidates: NLL(z) >= NLL(u) + grad.(z - u), z in the simplex
-                double fw = 0.0;
-                if (solved && !accept) {
-                    double e0 = g1 * u1 + g2 * u2;                  // vertex nu = e0  <-> u = (0, 0)
-                    double e1 = e0 - g1 / s1, e2 = e0 - g2 / s2;    // vertices (1/s1, 0), (0, 1/s2)
-                    fw = fmin(e0, fmin(e1, e2));
-                }
-                bool contender = solved && (DUMP || (nll + fw - screen_margin <= (accept ? best + A.window : rej_best)));
-                if (contender) {
-                    double acc = 0.0;
-                    terms([&](double x, double y, double R) {
-                        double q = __builtin_fma(x - s1, u1, __builtin_fma(y - s2, u2, 1.0));
-                        acc = __builtin_fma(R, log(q), acc);
-                    });
-                    nll = P.K0 - acc;
-                }
-                const double lbnd = nll + fw;
-                double u0 = (1.0 - s1 * u1 - s2 * u2) / tau;
-                double usum = u0 + u1 + u2;
-                double mu0 = u0 / usum, mu1 = u1 / usum, mu2 = u2 / usum;  // closed form of M3 (Optimizer.py:318-330)
+                    double nll = P.K0 - accf;
+                    // Frank-Wolfe bound for rejected candidates: NLL(z) >= NLL(u) + grad.(z - u), z in the simplex
+                    double fw = 0.0;
+                    if (solved && !accept) {
+                        double e0 = g1 * u1 + g2 * u2;                  // vertex nu = e0  <-> u = (0, 0)
+                        double e1 = e0 - g1 * rcp_nr2(s1), e2 = e0 - g2 * rcp_nr2(s2);    // vertices (1/s1, 0), (0, 1/s2)
+                        fw = fmin(e0, fmin(e1, e2));
+                    }
+                    bool contender = solved && (DUMP || (nll + fw - screen_margin <= (accept ? best + A.window : rej_best)));
+                    if (contender) {
+                        double acc = 0.0;
+                        terms([&](double x, double y, double R) {
+                            double q = __builtin_fma(x - s1, u1, __builtin_fma(y - s2, u2, 1.0));
+                            acc = __builtin_fma(R, log(q), acc);
+                        });
+                        nll = P.K0 - acc;
+                    }
+                    const double lbnd = nll + fw;
+                    double mu0 = 0.0, mu1 = 0.0, mu2 = 0.0;
+                    if (accept && contender) {   // closed form of M3 (Optimizer.py:318-330)
+                        double u0 = (1.0 - s1 * u1 - s2 * u2) / tau;
+                        double usum = u0 + u1 + u2;
+                        mu0 = u0 / usum;
+                        mu1 = u1 / usum;
+                        mu2 = u2 / usum;
+                    }
 
-                if (accept && contender && nll <= best + A.window) {
-                    best = fmin(best, order_unbits(load_agent_u64(&A.ctr->best_bits)));
-                    if (nll <= best + A.window) {
-                        tie_append(A.ctr, A.list, A.list_cap, base + rel, nll, mu0, mu1, mu2);
-                        if (nll < best) atomicMin(&A.ctr->best_bits, order_bits(nll));
-                    }
-                }
-                // wave-wide: new minimum and the warm start for the next batch
-                double mine = (accept && contender) ? nll : __builtin_inf();
-                double wbest = wave_min(mine);
-                if (wbest < __builtin_inf()) {
-                    best = fmin(best, wbest);
-                    unsigned long long who = ballot64(mine == wbest);
-                    int src = __builtin_ctzll(who);
-                    double b1 = readlane_f64(s1 * u1, src), b2 = readlane_f64(s2 * u2, src);
-                    ws1 = 0.75 * b1 + 0.25 / 3.0;
-                    ws2 = 0.75 * b2 + 0.25 / 3.0;
-                }
-                if (solved && !accept && contender && lbnd < rej_best) {
-                    unsigned long long old = atomicMin(&A.ctr->rej_bits, order_bits(lbnd));
-                    if (old > order_bits(lbnd)) {  // we hold the minimum (racy pair, diagnostic only)
-                        u128 rk = base + rel;
-                        A.ctr->rej_rank_lo = (unsigned long long)rk;
-                        A.ctr->rej_rank_hi = (unsigned long long)(rk >> 64);
-                    }
-                    rej_best = lbnd;
-                }
-                if (DUMP && live) {
-                    double nan = __builtin_nan("");
-                    const unsigned long long di = dump_base + rel;
-                    A.dump_nll[di] = accept ? nll : nan;
-                    A.dump_mu[di * 3 + 0] = accept ? mu0 : nan;
-                    A.dump_mu[di * 3 + 1] = accept ? mu1 : nan;
-                    A.dump_mu[di * 3 + 2] = accept ? mu2 : nan;
-                }
-                n_eval += live;
-                n_acc += accept;
-                n_deg += degenerate;
-                n_it += solved ? iters : 0;
-                n_terms += solved ? (unsigned long long)iters * (G + L) : 0;
-                n_fin += solved ? (G + L) : 0;
-            }
-            qcount = 0;
-            wave_lds_sync();
-            pc3 += __builtin_readcyclecounter() - td1;
-        };
-
-        // ---- enumerate the leaves below the prefix -------------------------------------------------------
-        // Explicit wave-uniform DFS over the L leaf levels (resumable, so that the solver above has a single
-        // call site).  At a non-leaf level the 64 lanes test the children of the current node in parallel
-        // (one edge test each) and the feasible ones are visited in slot order; at the last level the
-        // feasible lanes ARE the leaves, in enumeration order.
-        N3State node[L];
-        unsigned long long pend[L];
-        unsigned kids[L], pref[L];
-        int cbv[L];
-#pragma unroll
-        for (int l = 0; l < L; l++) {
-            node[l] = par;
-            pend[l] = 0;
-            kids[l] = 0;
-            pref[l] = 0;
-            cbv[l] = 0;
-        }
-        int lvl = 0;
-        bool scanning = true;
-        auto step = [&](auto lv) {
-            constexpr int LV = decltype(lv)::value;
-            if constexpr (LV == L - 1) {
-                const int cb = cbv[LV];
-                const int slot = cb + lane;
-                const int ca = cb ? sa1 : sa0, cbb = cb ? sb1 : sb0;
-                N3State nx;
-                bool feas = slot < Q && n3_edge_ab(P, node[LV], ca, cbb, slot, D + LV, nx);
-                unsigned long long mask = ballot64(feas);
-                if (mask) {
-                    unsigned long long off = leaf_idx + mbcnt(mask);
-                    leaf_idx += __builtin_popcountll(mask);
-                    bool sel = feas && off >= skip && (off - skip) < remaining;
-                    unsigned long long smask = ballot64(sel);
-                    if (smask) {
-                        int pos = qcount + mbcnt(smask);
-                        if (sel) {
-                            qCode[pos] = pref[LV] | ((unsigned)(ca | (cbb << 4)) << (8 * LV));
-                            qOff[pos] = (unsigned)(off - skip);
+                    if (accept && contender && nll <= best + A.window) {
+                        best = fmin(best, order_unbits(load_agent_u64(&A.ctr->best_bits)));
+                        if (nll <= best + A.window) {
+                            tie_append(A.ctr, A.list, A.list_cap, base + rel, nll, mu0, mu1, mu2);
+                            if (nll < best) atomicMin(&A.ctr->best_bits, order_bits(nll));
                         }
-                        qcount += __builtin_popcountll(smask);
                     }
-                }
-                cbv[LV] = cb + WAVE;
-                if (leaf_idx >= skip + remaining) scanning = false;   // the task's quota ends inside this subtree
-                else if (cbv[LV] >= Q) {
-                    lvl = LV - 1;
-                    if (LV == 0) scanning = false;
-                }
-            } else {
-                if (pend[LV] == 0) {
-                    if (cbv[LV] >= Q) {
-                        lvl = LV - 1;
-                        if (LV == 0) scanning = false;
-                        return;
+                    // wave-wide: new minimum and the warm start for the next batch
+                    double mine = (accept && contender) ? nll : __builtin_inf();
+                    double wbest = wave_min(mine);
+                    if (wbest < __builtin_inf()) {
+                        best = fmin(best, wbest);
+                        unsigned long long who = ballot64(mine == wbest);
+                        int src = __builtin_ctzll(who);
+                        double b1 = readlane_f64(s1 * u1, src), b2 = readlane_f64(s2 * u2, src);
+                        ws1 = 0.75 * b1 + 0.25 / 3.0;
+                        ws2 = 0.75 * b2 + 0.25 / 3.0;
                     }
-                    const int cb = cbv[LV];
-                    const int slot = cb + lane;
-                    const int ca = cb ? sa1 : sa0, cbb = cb ? sb1 : sb0;
-                    N3State nx;
-                    bool ok = slot < Q && n3_edge_ab(P, node[LV], ca, cbb, slot, D + LV, nx);
-                    pend[LV] = ballot64(ok);
-                    kids[LV] = ok ? n3_pack(nx) : 0u;
-                    cbv[LV] = cb + WAVE;
-                    return;
+                    if (solved && !accept && contender && lbnd < rej_best) {
+                        unsigned long long old = atomicMin(&A.ctr->rej_bits, order_bits(lbnd));
+                        if (old > order_bits(lbnd)) {  // we hold the minimum (racy pair, diagnostic only)
+                            u128 rk = base + rel;
+                            A.ctr->rej_rank_lo = (unsigned long long)rk;
+                            A.ctr->rej_rank_hi = (unsigned long long)(rk >> 64);
+                        }
+                        rej_best = lbnd;
+                    }
+                    if (DUMP && live) {
+                        double nan = __builtin_nan("");
+                        const unsigned long long di = dump_base + rel;
+                        A.dump_nll[di] = accept ? nll : nan;
+                        A.dump_mu[di * 3 + 0] = accept ? mu0 : nan;
+                        A.dump_mu[di * 3 + 1] = accept ? mu1 : nan;
+                        A.dump_mu[di * 3 + 2] = accept ? mu2 : nan;
+                    }
+                    n_eval += live;
+                    n_acc += accept;
+                    n_deg += degenerate;
+                    n_it += solved ? iters : 0;
+                    n_terms += solved ? (unsigned long long)iters * (G + L) : 0;
+                    n_fin += solved ? (G + L) : 0;
                 }
-                int bpos = __builtin_ctzll(pend[LV]);
-                pend[LV] &= pend[LV] - 1;
-                N3State child = n3_unpack((unsigned)__builtin_amdgcn_readlane((int)kids[LV], bpos));
-                node[LV + 1] = child;
-                pref[LV + 1] = pref[LV] | ((unsigned)(child.a | (child.b << 4)) << (8 * LV));
-                cbv[LV + 1] = 0;
-                pend[LV + 1] = 0;
-                lvl = LV + 1;
-            }
-        };
-        const unsigned long long ts0 = __builtin_readcyclecounter();
-        const unsigned long long in_drain0 = pc2 + pc3;
-        while (true) {
-            if (scanning) {
-                if (lvl == 0) step(std::integral_constant<int, 0>{});
-                else if (lvl == 1) { if constexpr (L > 1) step(std::integral_constant<int, 1>{}); }
-                else { if constexpr (L > 2) step(std::integral_constant<int, 2>{}); }
-            }
-            if (!scanning || qcount + WAVE > N3_QCAP) {
                 wave_lds_sync();
-                drain();
-                if (!scanning) break;
+                pc3 += __builtin_readcyclecounter() - td1;
             }
         }
-        pc1 += (__builtin_readcyclecounter() - ts0) - ((pc2 + pc3) - in_drain0);
-        const unsigned long long tn0 = __builtin_readcyclecounter();
-        unsigned long long consumed = 0;
-        if (leaf_idx > skip) {
-            consumed = leaf_idx - skip;
-            if (consumed > remaining) consumed = remaining;
-        }
-        if (leaf_idx > skip) skip = 0; else skip -= leaf_idx;
+        const unsigned long long consumed = hi_idx - lo_idx;
+        skip -= lo_idx;
         processed += consumed;
         remaining -= consumed;
         if (remaining == 0) break;
 
+        const unsigned long long tn0 = __builtin_readcyclecounter();
         // ---------------- next prefix in DFS order (wave-uniform) -----------------------------
         {
             int d = D - 1;
@@ -721,12 +802,10 @@ void n3_launch_tasks(const N3Dev &P, u128 begin, u128 end, uint64_t per_task, in
 void n3_launch_search(const N3Dev &P, const SearchArgs &A, const N3Task *tasks, const unsigned *stbuf, int ntasks,
                       uint64_t per_task, hipStream_t st) {
     dim3 grid((ntasks + N3_WAVES - 1) / N3_WAVES), block(64 * N3_WAVES);
-    bool dump = A.dump_nll != nullptr;
-#define LAUNCH(LL)                                                                                       \
-    if (dump) hipLaunchKernelGGL((n3_search_kernel<LL, true>), grid, block, 0, st, P, A, tasks, stbuf, ntasks, per_task); \
-    else hipLaunchKernelGGL((n3_search_kernel<LL, false>), grid, block, 0, st, P, A, tasks, stbuf, ntasks, per_task);
-    if (P.L == 1) { LAUNCH(1) } else if (P.L == 2) { LAUNCH(2) } else { LAUNCH(3) }
-#undef LAUNCH
+    if (A.dump_nll != nullptr)
+        hipLaunchKernelGGL((n3_search_kernel<true>), grid, block, 0, st, P, A, tasks, stbuf, ntasks, per_task);
+    else
+        hipLaunchKernelGGL((n3_search_kernel<false>), grid, block, 0, st, P, A, tasks, stbuf, ntasks, per_task);
 }
 
 void n3_launch_unrank_list(const N3Dev &P, const TieRecord *recs, int count, unsigned char *out, hipStream_t st) {

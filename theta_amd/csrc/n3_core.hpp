@@ -19,6 +19,9 @@ struct N3Dev {
     const unsigned char *lb, *ub;   // [m] order-adjusted bounds
     const unsigned char *ridx;   // [N3_RIDX_W * N3_RIDX_W] rank of the ratio dy/(-dx) in the sorted table (1-based)
     const u128 *cnt;             // [m][Q][2][NT+1][NT+1] completions below a DFS node
+    const unsigned char *rowtab; // [Q] slot -> a | b << 4
+    const unsigned long long *smask; // [m][N3_MAX_Q][2] slots that may follow a parent row at depth d (static rules)
+    unsigned long long swmask[2];    // slots with a <= b
     unsigned long long total_lo, total_hi;
 };
 
@@ -36,7 +39,9 @@ struct N3Task {
 struct N3Host {
     int m = 0, K = 0, Q = 0, NT = 0;
     std::vector<int> lb, ub;
-    std::vector<unsigned char> ridx;
+    std::vector<unsigned char> ridx, rowtab;
+    std::vector<unsigned long long> smask;
+    unsigned long long swmask[2] = {0, 0};
 };
 
 struct N3State {
@@ -113,16 +118,20 @@ __host__ __device__ inline bool n3_edge(const N3Dev &P, const N3State &par, int 
 struct N3Newton {
     double u1, u2;       // current iterate
     double p1, p2;       // previous feasible iterate (for the q <= 0 safeguard)
-    double h11, h12, h22, g1, g2;
-    double lam;          // Newton decrement of NLL / Rtot
     int iters;
     int status;          // 0 running, 1 converged, 2 failed (diverged / iteration cap)
+    bool singular;       // Hessian numerically rank-deficient at the last evaluation
+};
+
+// 2x2 Hessian of a converged point, only needed by n3_admissible for rank-deficient candidates
+struct N3Hess {
+    double u1, u2, h11, h12, h22;
 };
 
 #define N3_MAX_ITERS 60
 
 template <class Terms>
-__device__ __forceinline__ void n3_newton_step(Terms &&terms, double s1, double s2, double Rtot, N3Newton &S) {
+__device__ __forceinline__ void n3_newton_step(Terms &&terms, double s1, double s2, double inv_Rtot, N3Newton &S) {
     double g1 = 0, g2 = 0, h11 = 0, h12 = 0, h22 = 0;
     bool bad = false;
     const double u1 = S.u1, u2 = S.u2;
@@ -147,30 +156,29 @@ __device__ __forceinline__ void n3_newton_step(Terms &&terms, double s1, double 
         if (S.iters >= N3_MAX_ITERS) S.status = 2;
         return;
     }
-    S.g1 = g1; S.g2 = g2; S.h11 = h11; S.h12 = h12; S.h22 = h22;
+    const double hh = h11 * h22;
+    S.singular = (hh - h12 * h12) <= 1e-10 * hh;
     if (h11 + h22 == 0.0) {  // every row equals (sigma1, sigma2): the likelihood does not depend on u
-        S.lam = 0.0;
         S.status = 1;
         return;
     }
     double reg = 1e-13 * (h11 + h22);              // Levenberg floor: rank-deficient candidates stay solvable
     double a11 = h11 + reg, a22 = h22 + reg;
     double det = a11 * a22 - h12 * h12;
-    double idet = 1.0 / det;
+    double idet = rcp_nr2(det);
     double d1 = (a22 * g1 - h12 * g2) * idet;      // H d = g   (g = -grad NLL)
     double d2 = (a11 * g2 - h12 * g1) * idet;
-    double l2 = (g1 * d1 + g2 * d2) / Rtot;
-    double lam = sqrt(fmax(l2, 0.0));
-    S.lam = lam;
-    if (!(lam == lam) || !(fabs(d1) + fabs(d2) < 1e30)) {  // NaN / overflow: give up on this candidate
+    double l2 = (g1 * d1 + g2 * d2) * inv_Rtot;    // squared Newton decrement of NLL / Rtot
+    if (!(l2 == l2) || !(fabs(d1) + fabs(d2) < 1e30)) {  // NaN / overflow: give up on this candidate
         S.status = 2;
         return;
     }
-    double step = (lam > 0.3) ? 1.0 / (1.0 + lam) : 1.0;   // damped phase keeps q > 0 (self-concordance)
+    double step = 1.0;
+    if (l2 > 0.09) step = 1.0 / (1.0 + sqrt(l2));          // damped phase keeps q > 0 (self-concordance)
     S.p1 = u1; S.p2 = u2;
     S.u1 = __builtin_fma(step, d1, u1);
     S.u2 = __builtin_fma(step, d2, u2);
-    if (lam < 1e-6) S.status = 1;             // quadratic phase: the step just taken leaves an error ~lam^2
+    if (l2 < 1e-12) S.status = 1;             // quadratic phase: the step just taken leaves an error ~lam^2
     else if (S.iters >= N3_MAX_ITERS || fabs(S.u1) + fabs(S.u2) > 1e8) S.status = 2;
 }
 
@@ -178,7 +186,7 @@ __device__ __forceinline__ void n3_newton_step(Terms &&terms, double s1, double 
 // Optimizer.py:150-160).  For rank-deficient candidates the minimiser is a line; the reference
 // accepts when its root finder happens to land inside the simplex, so the line is intersected with
 // the simplex and a point inside is taken when one exists.  Returns true if admissible.
-__device__ __forceinline__ bool n3_admissible(N3Newton &S, double s1, double s2) {
+__device__ __forceinline__ bool n3_admissible(N3Hess &S, double s1, double s2) {
     double n1 = s1 * S.u1, n2 = s2 * S.u2, n0 = 1.0 - n1 - n2;
     bool in = (n0 >= 0.0 && n0 <= 1.0 && n1 >= 0.0 && n1 <= 1.0 && n2 >= 0.0 && n2 <= 1.0);
     if (in) return true;
