@@ -195,6 +195,14 @@ def main():
         k_ms = allv[0, 3]
         ach = allv[0, 2] / (k_ms * 1e-3) / 1e12
         launches = args.steps
+        # HBM bytes per launch of the search kernel from the rocprofv3 PMC passes committed under profiles/
+        # (FETCH_SIZE x2 per MI355X_MICROARCH.md's gfx950 correction, + WRITE_SIZE; both in KiB) -- not re-measured here
+        traffic = None
+        try:
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r1", "pmc_n3_search_kernel.json")))
+            traffic = (2.0 * pm["FETCH_SIZE"]["mean_per_launch"] + pm["WRITE_SIZE"]["mean_per_launch"]) * 1024.0
+        except Exception:
+            pass
         out = {
             "metric": "candidate C-matrices evaluated/sec (whole node)",
             "value": value, "unit": "candidates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -205,8 +213,8 @@ def main():
                        "candidates_per_step_per_gpu": args.batch, "total_candidates_in_space": float(total),
                        "parallelism": "rank-range sharding x%d, one RCCL exchange of finalists" % world},
             "roofline": {"bound": "fp64-valu", "achieved": ach, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": ach / FP64_VECTOR_PEAK_TFLOPS, "traffic": None,
-                         "kernel": "n3_search_kernel<2,false>", "kernel_ms_per_launch": k_ms / launches,
+                         "frac": ach / FP64_VECTOR_PEAK_TFLOPS, "traffic": traffic,
+                         "kernel": "n3_search_kernel<false>", "kernel_ms_per_launch": k_ms / launches,
                          "flop_per_candidate": allv[0, 2] / max(allv[0, 0], 1.0),
                          "newton_iters_per_candidate": allv[0, 5] / max(allv[0, 0], 1.0),
                          "terms_per_iteration": allv[0, 4] / max(allv[0, 5], 1.0),

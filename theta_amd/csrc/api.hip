@@ -260,13 +260,17 @@ extern "C" int theta_problem_create(theta_ctx *ctx, int n, int m, int tau, const
         D.Q = h.Q;
         D.tau = tau;
         D.NT = h.NT;
-        int L = 5;   // leaf levels enumerated by the lanes (tuned on MI355X)
+        int L = 6;   // leaf levels enumerated by the lanes (tuned on MI355X)
         if (const char *e = getenv("THETA_N3_LEAF_LEVELS")) {
             int v = atoi(e);
             if (v >= 1 && v <= 8) L = v;
         }
         if (L > m - 1) L = m - 1;
         D.L = L;
+        D.warm_blend = 0.9;
+        D.conv_l2 = 1e-8;    // lambda < 1e-4 before the last step => ~1e-8 after it
+        if (const char *e = getenv("THETA_N3_WARM_BLEND")) D.warm_blend = atof(e);
+        if (const char *e = getenv("THETA_N3_CONV_L2")) D.conv_l2 = atof(e);
         D.N = (double)N;
         D.Rtot = (double)Rt;
         D.K0 = (double)k0;

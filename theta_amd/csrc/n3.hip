@@ -357,8 +357,13 @@ __global__ __launch_bounds__(64 * N3_WAVES, 3) void n3_search_kernel(N3Dev Pg, S
     };
     // first feasible child of `node` at level l with slot >= from; returns false if none
     auto next_child = [&](const N3State &node, int l, int from, N3State &out) -> bool {
-        unsigned long long m0, m1;
-        child_mask(node, l, m0, m1);
+        unsigned long long m0, m1 = 0;
+        if (Q <= 64) {   // wave-uniform: one mask word is enough for K <= 7
+            m0 = S.smask[l][node.slot][0];
+            if (node.sw) m0 &= swm0;
+        } else {
+            child_mask(node, l, m0, m1);
+        }
         if (from >= 64) {
             m0 = 0;
             m1 &= (from >= 128) ? 0ull : (~0ull << (from - 64));
@@ -566,7 +571,7 @@ __global__ __launch_bounds__(64 * N3_WAVES, 3) void n3_search_kernel(N3Dev Pg, S
                         continue;   // only degenerate leaves were taken this round
                     }
                     if (have) {
-                        n3_newton_step(terms, s1, s2, inv_Rtot, Sv);
+                        n3_newton_step(terms, s1, s2, inv_Rtot, Sv, P.conv_l2);
                         if (Sv.status != 0) {
                             unsigned sing = Sv.singular ? RES_SINGULAR : 0u;
                             bool conv = Sv.status == 1;
@@ -626,21 +631,24 @@ __global__ __launch_bounds__(64 * N3_WAVES, 3) void n3_search_kernel(N3Dev Pg, S
                         }
                     }
                     // single-precision screen of sum R ln q, then the exact value only for contenders
-                    double accf = 0.0, g1 = 0.0, g2 = 0.0;
+                    double accf = 0.0;
                     if (solved) {
                         terms([&](double x, double y, double R) {
-                            double a = x - s1, b = y - s2;
-                            double q = __builtin_fma(a, u1, __builtin_fma(b, u2, 1.0));
+                            double q = __builtin_fma(x - s1, u1, __builtin_fma(y - s2, u2, 1.0));
                             accf = __builtin_fma(R, (double)__logf((float)q), accf);
-                            double t = R * rcp_nr1(q);
-                            g1 = __builtin_fma(t, a, g1);
-                            g2 = __builtin_fma(t, b, g2);
                         });
                     }
                     double nll = P.K0 - accf;
                     // Frank-Wolfe bound for rejected candidates: NLL(z) >= NLL(u) + grad.(z - u), z in the simplex
                     double fw = 0.0;
                     if (solved && !accept) {
+                        double g1 = 0.0, g2 = 0.0;
+                        terms([&](double x, double y, double R) {
+                            double a = x - s1, b = y - s2;
+                            double t = R * rcp_nr1(__builtin_fma(a, u1, __builtin_fma(b, u2, 1.0)));
+                            g1 = __builtin_fma(t, a, g1);
+                            g2 = __builtin_fma(t, b, g2);
+                        });
                         double e0 = g1 * u1 + g2 * u2;                  // vertex nu = e0  <-> u = (0, 0)
                         double e1 = e0 - g1 * rcp_nr2(s1), e2 = e0 - g2 * rcp_nr2(s2);    // vertices (1/s1, 0), (0, 1/s2)
                         fw = fmin(e0, fmin(e1, e2));
@@ -679,8 +687,8 @@ __global__ __launch_bounds__(64 * N3_WAVES, 3) void n3_search_kernel(N3Dev Pg, S
                         unsigned long long who = ballot64(mine == wbest);
                         int src = __builtin_ctzll(who);
                         double b1 = readlane_f64(s1 * u1, src), b2 = readlane_f64(s2 * u2, src);
-                        ws1 = 0.75 * b1 + 0.25 / 3.0;
-                        ws2 = 0.75 * b2 + 0.25 / 3.0;
+                        ws1 = P.warm_blend * b1 + (1.0 - P.warm_blend) / 3.0;
+                        ws2 = P.warm_blend * b2 + (1.0 - P.warm_blend) / 3.0;
                     }
                     if (solved && !accept && contender && lbnd < rej_best) {
                         unsigned long long old = atomicMin(&A.ctr->rej_bits, order_bits(lbnd));

@@ -22,6 +22,8 @@ struct N3Dev {
     const unsigned char *rowtab; // [Q] slot -> a | b << 4
     const unsigned long long *smask; // [m][N3_MAX_Q][2] slots that may follow a parent row at depth d (static rules)
     unsigned long long swmask[2];    // slots with a <= b
+    double warm_blend;           // weight of the previous optimum in the warm start (rest: simplex centre)
+    double conv_l2;              // convergence threshold on the squared Newton decrement
     unsigned long long total_lo, total_hi;
 };
 
@@ -131,7 +133,8 @@ struct N3Hess {
 #define N3_MAX_ITERS 60
 
 template <class Terms>
-__device__ __forceinline__ void n3_newton_step(Terms &&terms, double s1, double s2, double inv_Rtot, N3Newton &S) {
+__device__ __forceinline__ void n3_newton_step(Terms &&terms, double s1, double s2, double inv_Rtot, N3Newton &S,
+                                               double conv_l2 = 1e-12) {
     double g1 = 0, g2 = 0, h11 = 0, h12 = 0, h22 = 0;
     bool bad = false;
     const double u1 = S.u1, u2 = S.u2;
@@ -178,7 +181,7 @@ __device__ __forceinline__ void n3_newton_step(Terms &&terms, double s1, double 
     S.p1 = u1; S.p2 = u2;
     S.u1 = __builtin_fma(step, d1, u1);
     S.u2 = __builtin_fma(step, d2, u2);
-    if (l2 < 1e-12) S.status = 1;             // quadratic phase: the step just taken leaves an error ~lam^2
+    if (l2 < conv_l2) S.status = 1;             // quadratic phase: the step just taken leaves an error ~lam^2
     else if (S.iters >= N3_MAX_ITERS || fabs(S.u1) + fabs(S.u2) > 1e8) S.status = 2;
 }
 
