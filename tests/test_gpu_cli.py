@@ -1,0 +1,82 @@
+"""
+The RunTHetA command line on the GPU search against the output FILES the reference's own CLI wrote
+(tests/golden/cli/, produced by tests/golden/make_golden_cli.py).  Files are compared by value
+(Python 2/3 float formatting differs): bounds and C bit-exact, NLL / mu / p* within 1e-6 relative.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLD, ROOT
+
+pytestmark = pytest.mark.gpu
+CLI = os.path.join(GOLD, "cli")
+
+
+def _parse_results(path):
+    out = []
+    with open(path) as f:
+        for line in f:
+            if line.startswith("#"):
+                continue
+            nll, mu, C, p = line.rstrip("\n").split("\t")
+            out.append((float(nll), [float(x) for x in mu.split(",")], C, p.split(",")))
+    return out
+
+
+def _compare_results(mine, ref):
+    a, b = _parse_results(mine), _parse_results(ref)
+    assert len(a) == len(b)
+    for (n1, m1, c1, p1), (n2, m2, c2, p2) in zip(a, b):
+        assert c1 == c2                                      # the copy-number profile of ALL intervals, bit-exact
+        assert abs(n1 - n2) <= 1e-6 * abs(n2)
+        assert np.allclose(m1, m2, rtol=0, atol=1e-6)
+        assert len(p1) == len(p2)
+        for x, y in zip(p1, p2):
+            assert (x == "X") == (y == "X")
+            if x != "X":
+                assert abs(float(x) - float(y)) <= 1e-6 * abs(float(y))
+
+
+def _run(argv, tmp_path):
+    from theta_amd import RunTHetA
+    RunTHetA.main(argv + ["-d", str(tmp_path)])
+
+
+def test_cli_synthetic_n2_matches_reference_files(tmp_path):
+    _run([os.path.join(CLI, "syn14.intervals"), "-n", "2", "-k", "3", "-p", "syn14"], tmp_path)
+    assert open(tmp_path / "syn14.n2.withBounds").read() == open(os.path.join(CLI, "syn14.n2.withBounds")).read()
+    _compare_results(tmp_path / "syn14.n2.results", os.path.join(CLI, "syn14.n2.results"))
+    assert os.path.exists(tmp_path / "syn14.RunN3.bash")
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(CLI, "Example.n2.results")), reason="Example golden not generated")
+def test_cli_config1_example_matches_reference_files(tmp_path):
+    """BASELINE config 1 end to end: Example.intervals -n 2 -k 3 (incl. the Q7-affected calc_all_c_2)."""
+    src = os.path.join(GOLD, "cli", "Example.intervals")
+    _run([src, "-n", "2", "-k", "3", "-p", "Example"], tmp_path)
+    assert open(tmp_path / "Example.n2.withBounds").read() == open(os.path.join(CLI, "Example.n2.withBounds")).read()
+    _compare_results(tmp_path / "Example.n2.results", os.path.join(CLI, "Example.n2.results"))
+
+
+def test_cli_default_pipeline_n2_then_n3_then_model_selection(tmp_path):
+    """`RunTHetA <file>` with no -n: n=2, n=3 from the n=2 bounds/results, ModelSelection (RunTHetA.py:290-295)."""
+    from theta_amd import CalcAllC
+    _run([os.path.join(CLI, "syn14.intervals"), "-k", "3", "-p", "s", "--FORCE"], tmp_path)
+    for f in ("s.n2.withBounds", "s.n2.results", "s.n3.withBounds", "s.n3.results", "s.BEST.results"):
+        assert os.path.exists(tmp_path / f), f
+    res3 = _parse_results(tmp_path / "s.n3.results")
+    assert len(res3) >= 1
+    nll, mu, C, p = res3[0]
+    assert abs(sum(mu) - 1) < 1e-9 and len(mu) == 3
+    # the reported NLL is CalcAllC.L3 of the reported C over all intervals with the reported mu
+    rows = [r.split(",") for r in C.split(":")]
+    counts = [l.split("\t") for l in open(os.path.join(CLI, "syn14.intervals")) if not l.startswith("#")]
+    tum = np.array([float(c[4]) for c in counts])
+    nrm = np.array([float(c[5]) for c in counts])
+    Cm = np.array([[2.0] + [(-1.0 if v == "X" else float(v)) for v in r] for r in rows])
+    again = CalcAllC.L3(np.array(mu), Cm * nrm[:, None], len(rows), tum, 3)[0]
+    assert abs(again - nll) <= 1e-9 * abs(nll)
+    best = _parse_results(tmp_path / "s.BEST.results")
+    assert best[0][0] in (res3[0][0], _parse_results(tmp_path / "s.n2.results")[0][0])

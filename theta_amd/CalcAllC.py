@@ -4,6 +4,8 @@
 and -- like the reference -- `L2` rescales its argument C in place (CalcAllC.py:54-55).
 `L2_many` / `L3_many` score a batch of matrices in one launch.
 """
+import math
+
 import numpy as np
 
 from . import _lib
@@ -52,3 +54,181 @@ def L3(mu, C, m, r, n):
     if n != C.shape[1]:
         raise ValueError('n not equal to second dimension of C')
     return L3_many([mu], np.asarray(C, dtype=np.float64)[None, :, :], m, r, n)[0]
+
+
+# --------------------------------------------------------------------------------------------------
+# extension of the searched C to all intervals (python/CalcAllC.py:78-328), batched on the GPU scorer
+# --------------------------------------------------------------------------------------------------
+def weighted_C(C, rN):
+    """Optimizer.py:176-182."""
+    return np.asarray(C, dtype=np.float64) * np.asarray(rN, dtype=np.float64)[:, None]
+
+
+def calculateX(tumorI, normalI, sumR, sumAll, mu, n, row, h):
+    """CalcAllC.py:78-89: real-valued optimum of entry h of one extra row."""
+    row = [x * normalI for x in row]
+    nR = float(tumorI) / (sumR + tumorI)
+    sumRow = sum([row[i] * mu[i] for i in range(n) if i != h])
+    return float(nR * (sumAll + sumRow) - sumRow) / ((1 - nR) * mu[h])
+
+
+def _common(c, mu, r, rN, all_tumor, intervals_used):
+    m, n = c.shape
+    c_new = np.zeros((m + 1, n))
+    c_new[:m, :] = c
+    c_new = weighted_C(c_new, list(rN) + [0])
+    c_all = np.zeros((len(all_tumor), n))
+    for i, val in enumerate(intervals_used):
+        c_all[val] = c[i]
+    sum_all = sum([c_new[j][k] * mu[k] for j in range(m) for k in range(n)])
+    return m, n, c_new, c_all, sum_all, sum(r)
+
+
+def calc_all_c_2(best, r, rN, all_tumor, all_normal, intervals_used, compat=True):
+    """
+    CalcAllC.py:92-143.  compat=True reproduces the fork's behaviour exactly: CalcAllC.L2 rescales its
+    argument in place (CalcAllC.py:54-55), so the shared (m+1)-row matrix is multiplied by (mu, 1-mu)
+    again on EVERY call.  That mutation does not depend on any likelihood, so all the
+    literal matrices are built on the host and scored in one kernel launch.  compat=False scores the
+    intended, unscaled matrices.
+    """
+    out = []
+    used = set(intervals_used)
+    for c, mu, likelihood, vals in best:
+        m, n, c_new, c_all, sum_all, sum_r = _common(c, mu, r, rN, all_tumor, intervals_used)
+        mats, rs, slots = [], [], []
+        for i in range(len(all_tumor)):
+            if i in used:
+                continue
+            if all_normal[i] == 0:
+                c_all[i][0] = 2
+                c_all[i][1] = -1
+                continue
+            c_all[i][0] = 2
+            x = calculateX(all_tumor[i], all_normal[i], sum_r, sum_all, mu, n, [2, 0], 1) / all_normal[i]
+            if x < 0:
+                c_all[i][1] = 0
+                continue
+            bot, top = math.floor(x), math.ceil(x)
+            rr = list(r) + [all_tumor[i]]
+            c_new[m][0] = 2 * all_normal[i]
+            for v in (bot, top):
+                c_new[m][1] = v * all_normal[i]
+                mats.append(c_new.copy())
+                rs.append(rr)
+                if compat:                       # what the reference's L2 does to its argument
+                    c_new[:, 0] *= mu[0]
+                    c_new[:, 1] *= (1 - mu[0])
+            slots.append((i, int(bot), int(top)))
+        if mats:
+            ctx = _lib.default_context()
+            nlls = []
+            # r differs per interval (one extra entry), so group launches by r: one matrix pair per interval
+            for k in range(0, len(mats), 2):
+                res = L2_many([mu[0], mu[0]], np.array(mats[k:k + 2]), m + 1, np.asarray(rs[k], dtype=np.float64), ctx)
+                nlls += [res[0][0], res[1][0]]
+            for k, (i, bot, top) in enumerate(slots):
+                c_all[i][1] = bot if nlls[2 * k] < nlls[2 * k + 1] else top
+        c_all_w = weighted_C(c_all, all_normal)
+        like, v = L2(mu[0], c_all_w, len(all_tumor), np.asarray(all_tumor, dtype=np.float64))
+        out.append([(c_all, mu, like, v)])
+    return out
+
+
+def _score_rows_n3(c_new, m, mu, n, r_ext, rows, normal):
+    """L3 of c_new with its last row replaced by each (a, b) in rows (weighted by normal): one launch."""
+    mats = np.repeat(c_new[None, :, :], len(rows), axis=0)
+    for k, (a, b) in enumerate(rows):
+        mats[k, m, 0] = 2 * normal
+        mats[k, m, 1] = a * normal
+        mats[k, m, 2] = b * normal
+    res = L3_many(np.repeat(np.asarray(mu, dtype=np.float64)[None, :], len(rows), axis=0), mats, m + 1,
+                  np.asarray(r_ext, dtype=np.float64), n)
+    return [x[0] for x in res]
+
+
+def calc_all_c_3(best, r, rN, all_tumor, all_normal, intervals_used):
+    """CalcAllC.py:145-243 (the --NO_MULTI_EVENT variant): floor/ceil with one column at 2, plus the diagonal scan."""
+    out = []
+    used = set(intervals_used)
+    for c, mu, likelihood, vals in best:
+        m, n, c_new, c_all, sum_all, sum_r = _common(c, mu, r, rN, all_tumor, intervals_used)
+        for i in range(len(all_tumor)):
+            if i in used:
+                continue
+            c_all[i][0] = 2
+            if all_normal[i] == 0:
+                c_all[i][1] = -1
+                c_all[i][2] = -1
+                continue
+            nrm = all_normal[i]
+            x = calculateX(all_tumor[i], nrm, sum_r, sum_all, mu, n, [2, 0, 2], 1) / nrm
+            xt, xb = int(max(0, math.ceil(x))), int(max(0, math.floor(x)))
+            y = calculateX(all_tumor[i], nrm, sum_r, sum_all, mu, n, [2, 2, 0], 2) / nrm
+            yt, yb = int(max(0, math.ceil(y))), int(max(0, math.floor(y)))
+            rows = [(xb, 2), (xt, 2), (2, yb), (2, yt)]
+            r_ext = list(r) + [all_tumor[i]]
+            cand = []
+            diag, prev, j = [], float("inf"), 0
+            # the reference walks the diagonal until the NLL rises (CalcAllC.py:223-232); score it in blocks
+            done = False
+            first = True
+            while not done:
+                blk = [(jj, jj) for jj in range(j, j + 8)]
+                nl = _score_rows_n3(c_new, m, mu, n, r_ext, (rows if first else []) + blk, nrm)
+                if first:
+                    cand += [(nl[0], [xb, 2]), (nl[1], [xt, 2]), (nl[2], [2, yb]), (nl[3], [2, yt])]
+                    nl = nl[4:]
+                    first = False
+                for jj, l in zip(range(j, j + 8), nl):
+                    cand.append((l, [jj, jj]))
+                    if l > prev or l != l:
+                        done = True
+                        break
+                    prev = l
+                j += 8
+            cand.sort()
+            c_all[i][1], c_all[i][2] = cand[0][1]
+        c_all_w = weighted_C(c_all, all_normal)
+        like, v = L3(mu, c_all_w, len(all_tumor), np.asarray(all_tumor, dtype=np.float64), n)
+        out.append([(c_all, mu, like, v)])
+    return out
+
+
+def calc_all_c_3_multi_event(best, r, rN, all_tumor, all_normal, intervals_used):
+    """CalcAllC.py:245-328 (default for n=3): for every x in 0..ceil(x*) the best of floor/ceil(y*(x))."""
+    out = []
+    used = set(intervals_used)
+    for c, mu, likelihood, vals in best:
+        m, n, c_new, c_all, sum_all, sum_r = _common(c, mu, r, rN, all_tumor, intervals_used)
+        for i in range(len(all_tumor)):
+            if i in used:
+                continue
+            c_all[i][0] = 2
+            if all_normal[i] == 0:
+                c_all[i][1] = -1
+                c_all[i][2] = -1
+                continue
+            nrm = all_normal[i]
+            maxX = math.ceil(calculateX(all_tumor[i], nrm, sum_r, sum_all, mu, n, [2, 0, 0], 1) / nrm)
+            if maxX < 0:
+                maxX = 0
+            rows = []
+            for x in range(int(maxX) + 1):
+                y = calculateX(all_tumor[i], nrm, sum_r, sum_all, mu, n, [2, x, 0], 2) / nrm
+                bot, top = int(max(0, math.floor(y))), int(max(0, math.ceil(y)))
+                if x < 2:
+                    bot, top = min(bot, 2), min(top, 2)
+                elif x > 2:
+                    bot, top = max(2, bot), max(2, top)
+                rows += [(x, bot), (x, top)]
+            nl = _score_rows_n3(c_new, m, mu, n, list(r) + [all_tumor[i]], rows, nrm)
+            lmin, row_min = float("inf"), None
+            for (x, yv), l in zip(rows, nl):       # strict '<' in evaluation order, like the reference
+                if l < lmin:
+                    lmin, row_min = l, (x, yv)
+            c_all[i][1], c_all[i][2] = row_min
+        c_all_w = weighted_C(c_all, all_normal)
+        like, v = L3(mu, c_all_w, len(all_tumor), np.asarray(all_tumor, dtype=np.float64), n)
+        out.append([(c_all, mu, like, v)])
+    return out
