@@ -121,10 +121,16 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
     import torch
+    local = local % max(torch.cuda.device_count(), 1)      # (lets a 2-rank smoke test share one GPU)
     torch.cuda.set_device(local)
+    backend = os.environ.get("THETA_BENCH_BACKEND", "nccl")  # "nccl" == RCCL over xGMI; "gloo" only for smoke tests
+    comm_dev = torch.device("cuda", local) if backend == "nccl" else torch.device("cpu")
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
     if args.gpus != world and rank == 0:
         print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
 
@@ -175,12 +181,12 @@ def main():
             for j in range(len(best["rank"])):
                 recs.append({"rank": best["rank"][j], "c": best["C"][j], "mu": best["mu"][j], "nll": float(best["nll"][j]),
                              "vals": np.zeros(M)})
-        merged = exchange_finalists(recs, N_POP, M, torch.device("cuda", local))
+        merged = exchange_finalists(recs, N_POP, M, comm_dev)
     barrier()
     dt = time.time() - t0
 
     tot = torch.tensor([float(evaluated), dt, float(flops), kernel_ms, float(terms), float(iters), float(accepted), setup_ms],
-                       dtype=torch.float64, device="cuda")
+                       dtype=torch.float64, device=comm_dev)
     if dist is not None:
         allv = [torch.zeros_like(tot) for _ in range(world)]
         dist.all_gather(allv, tot)

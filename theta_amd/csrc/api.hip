@@ -113,7 +113,7 @@ struct theta_problem {
     N3Host n3h;
     N3Dev n3{};
     uint64_t total[2] = {0, 0};
-    DevBuf d_r, d_rN, d_small, d_P, d_PR, d_PN, d_cnt, d_ctr, d_list, d_tasks, d_stbuf, d_misc, d_smask;
+    DevBuf d_r, d_rN, d_small, d_P, d_PR, d_PN, d_cnt, d_ctr, d_list, d_tasks, d_stbuf, d_misc, d_smask, d_dynmask;
 };
 
 static int upload(DevBuf &b, const void *src, size_t bytes, hipStream_t st) {
@@ -254,6 +254,7 @@ extern "C" int theta_problem_create(theta_ctx *ctx, int n, int m, int tau, const
         memcpy(small.data() + 2 * m + h.ridx.size(), h.rowtab.data(), h.rowtab.size());
         TRY(upload(p->d_small, small.data(), small.size(), st));
         TRY(upload(p->d_smask, h.smask.data(), h.smask.size() * sizeof(unsigned long long), st));
+        TRY(upload(p->d_dynmask, h.dynmask.data(), h.dynmask.size() * sizeof(unsigned long long), st));
         N3Dev &D = p->n3;
         D.m = m;
         D.K = h.K;
@@ -263,7 +264,7 @@ extern "C" int theta_problem_create(theta_ctx *ctx, int n, int m, int tau, const
         int L = 6;   // leaf levels enumerated by the lanes (tuned on MI355X)
         if (const char *e = getenv("THETA_N3_LEAF_LEVELS")) {
             int v = atoi(e);
-            if (v >= 1 && v <= 8) L = v;
+            if (v >= 1 && v <= 6) L = v;
         }
         if (L > m - 1) L = m - 1;
         D.L = L;
@@ -281,8 +282,8 @@ extern "C" int theta_problem_create(theta_ctx *ctx, int n, int m, int tau, const
         D.ridx = D.lb + 2 * m;
         D.rowtab = D.ridx + h.ridx.size();
         D.smask = (const unsigned long long *)p->d_smask.p;
-        D.swmask[0] = h.swmask[0];
-        D.swmask[1] = h.swmask[1];
+        D.dynmask = (const unsigned long long *)p->d_dynmask.p;
+        D.swmask = h.swmask;
         size_t per_level = (size_t)h.Q * 2 * (h.NT + 1) * (h.NT + 1);
         size_t cnt_bytes = per_level * m * sizeof(u128);
         if (cnt_bytes > (size_t)ctx->hbm_bytes / 2) {

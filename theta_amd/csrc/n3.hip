@@ -72,16 +72,17 @@ int n3_build_host(int m, int tau, const int32_t *lb_in, const int32_t *ub_in, N3
             int idx = (int)(std::lower_bound(fr.begin(), fr.end(), v, less) - fr.begin());
             h.ridx[(dy + N3_MAX_K) * N3_RIDX_W + (dx + N3_MAX_K)] = (unsigned char)(idx + 1);
         }
-    // slot -> row, and for every depth d and parent row the set of rows that may follow it by the static
-    // rules (valid row, bounds of depth d, Enumerator._is_valid_edge); the kernels add the dynamic ones
-    const int K1 = top + 1;
+    // slot -> row; for every depth d and parent row the set of rows that may follow it by the static rules
+    // (valid row, bounds of depth d, Enumerator._is_valid_edge); and for every (parent row, lo, hi) the set of
+    // rows that keep the ratio window non-empty (Enumerator._get_mu_bounds + the lo <= hi test, :204-212).
+    const int K1 = top + 1, NT1 = h.NT + 1;
     h.rowtab.assign(h.Q, 0);
     for (int s = 0; s < h.Q; s++) {
         int a = s % K1, b = s / K1;
         h.rowtab[s] = (unsigned char)(a | (b << 4));
-        if (a <= b) h.swmask[s >> 6] |= 1ull << (s & 63);
+        if (a <= b) h.swmask |= 1ull << s;
     }
-    h.smask.assign((size_t)m * N3_MAX_Q * 2, 0ull);
+    h.smask.assign((size_t)m * N3_MAX_Q, 0ull);
     for (int d = 0; d < m; d++)
         for (int ps = 0; ps < h.Q; ps++) {
             int pa = ps % K1, pb = ps / K1;
@@ -89,9 +90,28 @@ int n3_build_host(int m, int tau, const int32_t *lb_in, const int32_t *ub_in, N3
                 int a = s % K1, b = s / K1;
                 bool ok = n3_valid_row(a, b, tau) && a >= h.lb[d] && a <= h.ub[d] && b >= h.lb[d] && b <= h.ub[d] &&
                           (s == ps || a > pa || b > pb);
-                if (ok) h.smask[((size_t)d * N3_MAX_Q + ps) * 2 + (s >> 6)] |= 1ull << (s & 63);
+                if (ok) h.smask[(size_t)d * N3_MAX_Q + ps] |= 1ull << s;
             }
         }
+    h.dynmask.assign((size_t)h.Q * NT1 * NT1, 0ull);
+    for (int ps = 0; ps < h.Q; ps++) {
+        int pa = ps % K1, pb = ps / K1;
+        for (int lo = 0; lo <= h.NT; lo++)
+            for (int hi = 1; hi <= h.NT + 1; hi++) {
+                if (lo > hi) continue;
+                unsigned long long mk = 0;
+                for (int s = 0; s < h.Q; s++) {
+                    int dx = s % K1 - pa, dy = s / K1 - pb;
+                    int l2 = lo, h2 = hi;
+                    if (dx != 0 && dy != 0) {
+                        int t = h.ridx[(dy + N3_MAX_K) * N3_RIDX_W + (dx + N3_MAX_K)];
+                        if (dx > 0) l2 = std::max(lo, t); else h2 = std::min(hi, t);
+                    }
+                    if (l2 <= h2) mk |= 1ull << s;
+                }
+                h.dynmask[((size_t)ps * NT1 + lo) * NT1 + (hi - 1)] = mk;
+            }
+    }
     return THETA_OK;
 }
 
@@ -245,15 +265,17 @@ __device__ __forceinline__ double readlane_f64(double v, int l) {
 
 #define N3_WAVES 4
 #define N3_QCAP 128     // leaves solved per round (per wave)
-#define N3_MAX_L 8      // leaf levels (one byte of the 64-bit leaf code each)
+#define N3_MAX_L 6      // leaf levels (one byte of the 64-bit leaf code each)
 
 struct N3Lds {
     double gX[N3_WAVES][N3_MAX_Q + N3_MAX_L], gY[N3_WAVES][N3_MAX_Q + N3_MAX_L], gR[N3_WAVES][N3_MAX_Q + N3_MAX_L];
+    float fX[N3_WAVES][N3_MAX_Q + N3_MAX_L], fY[N3_WAVES][N3_MAX_Q + N3_MAX_L], fR[N3_WAVES][N3_MAX_Q + N3_MAX_L];  // f32 copy (screening pass)
     double resU1[N3_WAVES][N3_QCAP], resU2[N3_WAVES][N3_QCAP];
     unsigned long long qCode[N3_WAVES][N3_QCAP];
     unsigned resSt[N3_WAVES][N3_QCAP], qOff[N3_WAVES][N3_QCAP];
-    unsigned stk[N3_WAVES][N3_MAX_L][WAVE];      // lane-private DFS stacks over the leaf levels
-    unsigned long long smask[N3_MAX_L][N3_MAX_Q][2];  // static child masks of the leaf depths
+    unsigned stkS[N3_WAVES][N3_MAX_L][WAVE];            // lane-private DFS stack: node chosen at each leaf level
+    unsigned long long stkM[N3_WAVES][N3_MAX_L][WAVE];  // ... and the siblings still to visit at that level
+    unsigned long long smask[N3_MAX_L][N3_MAX_Q];       // static child masks of the leaf depths
     double leafR[N3_MAX_L], leafN[N3_MAX_L];
     unsigned char lb[N3_MAX_M], ub[N3_MAX_M];
     unsigned char ridx[N3_RIDX_W * N3_RIDX_W + 3];
@@ -300,8 +322,7 @@ __global__ __launch_bounds__(64 * N3_WAVES, 3) void n3_search_kernel(N3Dev Pg, S
     }
     for (int i = threadIdx.x; i < N3_RIDX_W * N3_RIDX_W; i += blockDim.x) S.ridx[i] = Pg.ridx[i];
     for (int i = threadIdx.x; i < Q; i += blockDim.x) S.rowtab[i] = Pg.rowtab[i];
-    for (int i = threadIdx.x; i < L * N3_MAX_Q * 2; i += blockDim.x)
-        (&S.smask[0][0][0])[i] = Pg.smask[(size_t)D * N3_MAX_Q * 2 + i];
+    for (int i = threadIdx.x; i < L * N3_MAX_Q; i += blockDim.x) (&S.smask[0][0])[i] = Pg.smask[(size_t)D * N3_MAX_Q + i];
     for (int i = threadIdx.x; i < L; i += blockDim.x) {
         S.leafR[i] = Pg.r[D + i];
         S.leafN[i] = Pg.rN[D + i];
@@ -317,10 +338,12 @@ __global__ __launch_bounds__(64 * N3_WAVES, 3) void n3_search_kernel(N3Dev Pg, S
     if (task >= ntasks) return;  // whole wave leaves together; no block barrier below
     const double tau = (double)P.tau;
     double *gX = S.gX[wv], *gY = S.gY[wv], *gR = S.gR[wv];
+    float *fX = S.fX[wv], *fY = S.fY[wv], *fR = S.fR[wv];
     double *resU1 = S.resU1[wv], *resU2 = S.resU2[wv];
     unsigned long long *qCode = S.qCode[wv];
     unsigned *resSt = S.resSt[wv], *qOff = S.qOff[wv];
-    const unsigned long long swm0 = Pg.swmask[0], swm1 = Pg.swmask[1];
+    const unsigned long long swm = Pg.swmask;
+    const int NT1 = Pg.NT + 1;
 
     // lane i holds interval i; lane s (+64) also stands for alphabet slot s in the prefix successor
     const double r_i = lane < m ? Pg.r[lane] : 0.0;
@@ -346,44 +369,20 @@ __global__ __launch_bounds__(64 * N3_WAVES, 3) void n3_search_kernel(N3Dev Pg, S
     double ws1 = 1.0 / 3.0, ws2 = 1.0 / 3.0;
 
     // ---- lane-private DFS over the leaf levels -----------------------------------------------------------
-    // children of `node` at leaf level l, as a 128-bit mask of alphabet slots (static rules + symmetry)
-    auto child_mask = [&](const N3State &node, int l, unsigned long long &m0, unsigned long long &m1) {
-        m0 = S.smask[l][node.slot][0];
-        m1 = S.smask[l][node.slot][1];
-        if (node.sw) {
-            m0 &= swm0;
-            m1 &= swm1;
-        }
+    // feasible children of `node` when they sit at leaf level l: static rules (LDS) & symmetry & ratio window
+    // (one 8-byte read of the precomputed table, L2 resident)
+    auto child_mask = [&](const N3State &node, int l) -> unsigned long long {
+        unsigned long long mk = S.smask[l][node.slot] & Pg.dynmask[((size_t)node.slot * NT1 + node.lo) * NT1 + (node.hi - 1)];
+        return node.sw ? (mk & swm) : mk;
     };
-    // first feasible child of `node` at level l with slot >= from; returns false if none
-    auto next_child = [&](const N3State &node, int l, int from, N3State &out) -> bool {
-        unsigned long long m0, m1 = 0;
-        if (Q <= 64) {   // wave-uniform: one mask word is enough for K <= 7
-            m0 = S.smask[l][node.slot][0];
-            if (node.sw) m0 &= swm0;
-        } else {
-            child_mask(node, l, m0, m1);
-        }
-        if (from >= 64) {
-            m0 = 0;
-            m1 &= (from >= 128) ? 0ull : (~0ull << (from - 64));
-        } else {
-            m0 &= ~0ull << from;
-        }
-        while (m0) {
-            int s = __builtin_ctzll(m0);
-            m0 &= m0 - 1;
-            if (n3_child_dyn(S.ridx, S.rowtab, node, s, out)) return true;
-        }
-        while (m1) {
-            int s = 64 + __builtin_ctzll(m1);
-            m1 &= m1 - 1;
-            if (n3_child_dyn(S.ridx, S.rowtab, node, s, out)) return true;
-        }
-        return false;
+    // state of child `s` of `node` (the child is known to be feasible)
+    auto child_state = [&](const N3State &node, int s) -> N3State {
+        N3State ch;
+        n3_child_dyn(S.ridx, S.rowtab, node, s, ch);
+        return ch;
     };
 
-    unsigned long long pc0 = 0, pc1 = 0, pc2 = 0, pc3 = 0, pc4 = 0;
+    unsigned long long pc0 = 0, pc1 = 0, pc2 = 0, pc3 = 0, pc4 = 0, pc6 = 0, n_prefix = 0;
     const unsigned long long t_begin = __builtin_readcyclecounter();
     while (remaining > 0) {
         unsigned long long t0 = __builtin_readcyclecounter();
@@ -410,6 +409,9 @@ __global__ __launch_bounds__(64 * N3_WAVES, 3) void n3_search_kernel(N3Dev Pg, S
                     gX[G] = a;
                     gY[G] = b;
                     gR[G] = Rs;
+                    fX[G] = (float)a;
+                    fY[G] = (float)b;
+                    fR[G] = (float)Rs;
                 }
                 S1p += a * Ns;
                 S2p += b * Ns;
@@ -438,78 +440,109 @@ __global__ __launch_bounds__(64 * N3_WAVES, 3) void n3_search_kernel(N3Dev Pg, S
         unsigned long long my_first = (unsigned long long)lane * chunk;
         unsigned long long my_left = my_first < nleaf ? ((nleaf - my_first < chunk) ? nleaf - my_first : chunk) : 0;
         unsigned my_rel = (unsigned)(processed + my_first);
-        unsigned long long code = 0;
+        unsigned long long code = 0, mcur = 0;   // mcur: children of `cur` still to visit at level lv
+        N3State cur = par;                      // parent of the level the lane is enumerating
+        int lv = L - 1;
         {
             const unsigned long long tu0 = __builtin_readcyclecounter();
             if (my_left > 0) {
                 unsigned long long idx = lo_idx + my_first;
-                N3State node = par, ch;
+                cur = par;
                 bool okp = true;
                 for (int l = 0; l < L && okp; l++) {
-                    int from = 0;
+                    unsigned long long mk = child_mask(cur, l);
                     bool found = false;
-                    while (next_child(node, l, from, ch)) {
-                        unsigned long long cv = 1;
-                        if (l < L - 1) {
+                    if (l == L - 1) {                       // leaves count 1 each: take the idx-th set bit
+                        while (mk && idx > 0) {
+                            mk &= mk - 1;
+                            idx--;
+                        }
+                        found = mk != 0ull;
+                        mcur = mk;                          // the chosen leaf is still in the mask: emitted first
+                    } else {
+                        while (mk) {
+                            int s = __builtin_ctzll(mk);
+                            mk &= mk - 1;
+                            N3State ch = child_state(cur, s);
                             u128 tv = Pg.cnt[n3_cnt_index(Pg, D + l, ch.slot, ch.sw, ch.lo, ch.hi)];
-                            cv = (tv >> 64) ? ~0ull : (unsigned long long)tv;
+                            unsigned long long cv = (tv >> 64) ? ~0ull : (unsigned long long)tv;
+                            if (idx < cv) {
+                                found = true;
+                                S.stkS[wv][l][lane] = n3_pack(ch);
+                                S.stkM[wv][l][lane] = mk;   // siblings after the chosen child
+                                code |= (unsigned long long)(ch.a | (ch.b << 4)) << (8 * l);
+                                cur = ch;
+                                break;
+                            }
+                            idx -= cv;
                         }
-                        if (idx < cv) {
-                            found = true;
-                            break;
-                        }
-                        idx -= cv;
-                        from = ch.slot + 1;
                     }
                     okp = found;
-                    if (found) {
-                        S.stk[wv][l][lane] = n3_pack(ch);
-                        code |= (unsigned long long)(ch.a | (ch.b << 4)) << (8 * l);
-                        node = ch;
-                    }
                 }
+                lv = L - 1;
                 if (!okp) my_left = 0;   // cannot happen: the counting table says the leaf exists
             }
-            pc1 += __builtin_readcyclecounter() - tu0;
+            pc6 += __builtin_readcyclecounter() - tu0;
+            n_prefix++;
         }
         for (unsigned long long done = 0; done < nleaf;) {
             const unsigned long long ts0 = __builtin_readcyclecounter();
             int qcount = 0;
-            for (int j = 0; j < N3_QCAP / WAVE; j++) {
-                const bool act = my_left > 0;
-                const unsigned long long mk = ballot64(act);
-                if (!mk) break;
-                if (act) {
-                    const int pos = qcount + mbcnt(mk);
-                    qCode[pos] = code;
-                    qOff[pos] = my_rel;
-                    my_rel++;
-                    my_left--;
-                    if (my_left > 0) {   // next leaf of this lane's chunk in DFS order
-                        int l = L - 1;
-                        bool fresh = false;
-                        N3State ch;
-                        while (true) {
-                            N3State pn = (l == 0) ? par : n3_unpack(S.stk[wv][l - 1][lane]);
-                            int from = fresh ? 0 : (int)(S.stk[wv][l][lane] & 0x7f) + 1;
-                            if (next_child(pn, l, from, ch)) {
-                                S.stk[wv][l][lane] = n3_pack(ch);
-                                code = (code & ~(0xffull << (8 * l))) | ((unsigned long long)(ch.a | (ch.b << 4)) << (8 * l));
-                                if (l == L - 1) break;
-                                l++;
-                                fresh = true;
+            // Every lane produces up to N3_QCAP/64 leaves of its chunk.  One DFS micro-step per lane per trip, all
+            // lanes in the same straight-line code: take the next sibling (a leaf at the last level), or descend
+            // (one LUT read + one mask read), or pop a level.
+            {
+                const int want = (my_left < (unsigned long long)(N3_QCAP / WAVE)) ? (int)my_left : N3_QCAP / WAVE;
+                const unsigned long long wmask = ballot64(want > 0);
+                // queue slots: lanes in order, `want` consecutive entries each
+                int posb = 0;
+                {
+                    int v = want;   // exclusive prefix sum over lanes
+#pragma unroll
+                    for (int o = 1; o < WAVE; o <<= 1) {
+                        int t = __shfl_up(v, o, WAVE);
+                        if (lane >= o) v += t;
+                    }
+                    posb = v - want;
+                    qcount = __shfl(v, WAVE - 1, WAVE);
+                }
+                (void)wmask;
+                int produced = 0;
+                bool adv = want > 0;
+                while (ballot64(adv)) {
+                    if (adv) {
+                        if (mcur == 0ull) {                    // level exhausted: pop
+                            lv--;
+                            if (lv < 0) {
+                                my_left = 0;                   // cannot happen inside the counted range
+                                adv = false;
                             } else {
-                                l--;
-                                fresh = false;
-                                if (l < 0) {
-                                    my_left = 0;   // cannot happen inside the counted range
-                                    break;
-                                }
+                                mcur = S.stkM[wv][lv][lane];
+                                cur = (lv == 0) ? par : n3_unpack(S.stkS[wv][lv - 1][lane]);
+                            }
+                        } else {
+                            const int s = __builtin_ctzll(mcur);
+                            mcur &= mcur - 1;
+                            if (lv == L - 1) {                 // a leaf
+                                const unsigned rw = S.rowtab[s];
+                                qCode[posb + produced] = (code & ~(0xffull << (8 * lv))) | ((unsigned long long)rw << (8 * lv));
+                                qOff[posb + produced] = my_rel;
+                                my_rel++;
+                                my_left--;
+                                produced++;
+                                adv = produced < want;
+                            } else {                           // descend into child s
+                                N3State ch = child_state(cur, s);
+                                S.stkS[wv][lv][lane] = n3_pack(ch);
+                                S.stkM[wv][lv][lane] = mcur;
+                                code = (code & ~(0xffull << (8 * lv))) | ((unsigned long long)(ch.a | (ch.b << 4)) << (8 * lv));
+                                cur = ch;
+                                lv++;
+                                mcur = child_mask(ch, lv);
                             }
                         }
                     }
                 }
-                qcount += __builtin_popcountll(mk);
             }
             done += (unsigned long long)qcount;
             if (qcount == 0) break;
@@ -630,18 +663,27 @@ __global__ __launch_bounds__(64 * N3_WAVES, 3) void n3_search_kernel(N3Dev Pg, S
                             u2 = T2.u2;
                         }
                     }
-                    // single-precision screen of sum R ln q, then the exact value only for contenders
-                    double accf = 0.0;
+                    // single-precision screen of sum R ln q (f32 tile, f32 log), the exact value only for contenders
+                    float accf = 0.0f;
                     if (solved) {
-                        terms([&](double x, double y, double R) {
-                            double q = __builtin_fma(x - s1, u1, __builtin_fma(y - s2, u2, 1.0));
-                            accf = __builtin_fma(R, (double)__logf((float)q), accf);
-                        });
+                        const float fs1 = (float)s1, fs2 = (float)s2, fu1 = (float)u1, fu2 = (float)u2;
+#pragma unroll 4
+                        for (int g = 0; g < G; g++) {
+                            float q = __builtin_fmaf(fX[g] - fs1, fu1, __builtin_fmaf(fY[g] - fs2, fu2, 1.0f));
+                            accf = __builtin_fmaf(fR[g], __logf(q), accf);
+                        }
+                        for (int l = 0; l < L; l++) {
+                            unsigned rw = (unsigned)(mycode >> (8 * l)) & 0xffu;
+                            float q = __builtin_fmaf((float)(rw & 15u) - fs1, fu1, __builtin_fmaf((float)(rw >> 4) - fs2, fu2, 1.0f));
+                            accf = __builtin_fmaf((float)S.leafR[l], __logf(q), accf);
+                        }
                     }
-                    double nll = P.K0 - accf;
-                    // Frank-Wolfe bound for rejected candidates: NLL(z) >= NLL(u) + grad.(z - u), z in the simplex
+                    double nll = P.K0 - (double)accf;
+                    // Lower bound of what the reference could report for a rejected candidate.  Converged outside
+                    // the simplex: the unconstrained minimum itself (NLL(u) - O(lambda^2 sum r), inside the margin).
+                    // Not converged: Frank-Wolfe, NLL(z) >= NLL(u) + grad.(z - u) for every z in the simplex.
                     double fw = 0.0;
-                    if (solved && !accept) {
+                    if (solved && kind == RES_FAIL) {
                         double g1 = 0.0, g2 = 0.0;
                         terms([&](double x, double y, double R) {
                             double a = x - s1, b = y - s2;
@@ -787,6 +829,8 @@ __global__ __launch_bounds__(64 * N3_WAVES, 3) void n3_search_kernel(N3Dev Pg, S
         atomicAdd(&A.ctr->prof[3], pc3);
         atomicAdd(&A.ctr->prof[4], pc4);
         atomicAdd(&A.ctr->prof[5], __builtin_readcyclecounter() - t_begin);
+        atomicAdd(&A.ctr->prof[6], pc6);
+        atomicAdd(&A.ctr->prof[7], n_prefix);
     }
 }
 

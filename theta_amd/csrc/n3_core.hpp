@@ -4,7 +4,7 @@
 #pragma once
 #include "common.hpp"
 
-#define N3_MAX_K 8               // largest copy number in an n=3 search (alphabet (K+1)^2 <= 81)
+#define N3_MAX_K 7               // largest copy number in an n=3 search: the alphabet (K+1)^2 <= 64 fits one mask word
 #define N3_MAX_Q ((N3_MAX_K + 1) * (N3_MAX_K + 1))
 #define N3_MAX_M 64              // one interval per lane
 #define N3_RIDX_W (2 * N3_MAX_K + 1)
@@ -20,8 +20,9 @@ struct N3Dev {
     const unsigned char *ridx;   // [N3_RIDX_W * N3_RIDX_W] rank of the ratio dy/(-dx) in the sorted table (1-based)
     const u128 *cnt;             // [m][Q][2][NT+1][NT+1] completions below a DFS node
     const unsigned char *rowtab; // [Q] slot -> a | b << 4
-    const unsigned long long *smask; // [m][N3_MAX_Q][2] slots that may follow a parent row at depth d (static rules)
-    unsigned long long swmask[2];    // slots with a <= b
+    const unsigned long long *smask; // [m][N3_MAX_Q] slots that may follow a parent row at depth d (static rules)
+    const unsigned long long *dynmask; // [Q][NT+1][NT+1] slots that keep the ratio window [lo,hi] non-empty after a parent row
+    unsigned long long swmask;       // slots with a <= b
     double warm_blend;           // weight of the previous optimum in the warm start (rest: simplex centre)
     double conv_l2;              // convergence threshold on the squared Newton decrement
     unsigned long long total_lo, total_hi;
@@ -42,8 +43,8 @@ struct N3Host {
     int m = 0, K = 0, Q = 0, NT = 0;
     std::vector<int> lb, ub;
     std::vector<unsigned char> ridx, rowtab;
-    std::vector<unsigned long long> smask;
-    unsigned long long swmask[2] = {0, 0};
+    std::vector<unsigned long long> smask, dynmask;
+    unsigned long long swmask = 0;
 };
 
 struct N3State {
