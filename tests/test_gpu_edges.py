@@ -1,0 +1,142 @@
+"""
+Edge cases of the C-ABI path on the GPU: empty and tiny ranges, the smallest and largest supported
+shapes, error codes, capacity growth, ragged bounds, window semantics, list-overflow recovery.
+"""
+import numpy as np
+import pytest
+
+import theta_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import theta_amd
+    return theta_amd.default_context()
+
+
+def test_error_codes_and_messages(ctx):
+    import theta_amd
+    from theta_amd import _lib
+    with pytest.raises(theta_amd.ThetaError) as e:
+        theta_amd.Problem(ctx, 4, 5, 2, [1] * 5, [1] * 5, [0] * 5, [2] * 5)
+    assert e.value.code == _lib.ERR_ARG and "n must be 2 or 3" in str(e.value)
+    with pytest.raises(theta_amd.ThetaError):
+        theta_amd.Problem(ctx, 2, 1, 2, [1], [1], [0], [2])                      # m >= 2 (FileIO.py:437-439)
+    with pytest.raises(theta_amd.ThetaError):
+        theta_amd.Problem(ctx, 2, 3, 2, [1, 2, 3], [1, 0, 3], [0] * 3, [2] * 3)  # normal count 0
+    with pytest.raises(theta_amd.ThetaError):
+        theta_amd.Problem(ctx, 3, 3, 2, [1, 2, 3], [1, 1, 3], [0] * 3, [9] * 3)  # n=3 alphabet limit
+    with pytest.raises(theta_amd.ThetaError):
+        theta_amd.Problem(ctx, 3, 65, 2, [1] * 65, [1] * 65, [0] * 65, [2] * 65)  # n=3: one interval per lane
+    p = theta_amd.Problem(ctx, 2, 3, 2, [5, 6, 7], [5, 5, 5], [2, 2, 2], [1, 1, 1])  # lb > ub: nothing to enumerate
+    assert p.count == 0
+    with pytest.raises(theta_amd.NoCandidates):
+        p.search(0, 0)
+    p2 = theta_amd.Problem(ctx, 2, 3, 2, [5, 6, 7], [5, 5, 5], [0] * 3, [2] * 3)
+    with pytest.raises(theta_amd.ThetaError):
+        p2.search(0, p2.count + 1)                                                # range beyond the end
+    res = p2.search(4, 4)
+    assert len(res["rank"]) == 0 and res["stats"]["evaluated"] == 0              # empty range is fine
+
+
+def test_driver_exits_like_reference_when_no_candidates(ctx):
+    from theta_amd.search import do_optimization_single
+    with pytest.raises(SystemExit) as e:
+        do_optimization_single(2, 3, 2, 2, [2, 2, 2], [1, 1, 1], [5, 6, 7], [5, 5, 5], 1.0, [0, 1, 2])
+    assert e.value.code == 1                                                      # RunTHetA.py:217-219
+
+
+def test_smallest_shapes_m2(ctx):
+    import theta_amd
+    r, rN = [900, 1400], [1000, 1000]
+    for n in (2, 3):
+        p = theta_amd.Problem(ctx, n, 2, 2, r, rN, [0, 0], [3, 3])
+        seq = list(orc.enumerate_n2(2, 2, [0, 0], [3, 3])) if n == 2 else list(orc.enumerate_n3(2, 2, [0, 0], [3, 3]))
+        assert p.count == len(seq)
+        got = p.enumerate(0, p.count)
+        assert np.array_equal(got, np.array(seq, dtype=np.uint8).reshape(got.shape))
+        nll, mu, st = p.values(0, p.count)
+        assert st["evaluated"] == p.count
+        for i, c in enumerate(seq):
+            C = orc.col_to_matrix_n2(c, 2) if n == 2 else orc.rows_to_matrix_n3(c, 2)
+            s = orc.solve(C, r, rN, 1)
+            if n == 2:
+                assert (s is None) == bool(np.isnan(nll[i]))
+            if s is not None and not np.isnan(nll[i]) and np.isfinite(s[1]):
+                assert s[1] >= nll[i] * (1 - 1e-9)
+
+
+def test_largest_shapes(ctx):
+    """n=2 with m=256 intervals and copy numbers up to 15; n=3 with m=64 and the full K=7 alphabet."""
+    import theta_amd
+    rng = np.random.RandomState(3)
+    m = 256
+    rN = rng.randint(5000, 9000, m)
+    c = np.sort(rng.randint(0, 16, m))                  # copy numbers up to THETA_MAX_COPY
+    r = rng.poisson(rN * (2 * 0.4 + c * 0.6) / 3.0)
+    rs, rNs, order = orc.sort_r([int(x) for x in rN], [int(x) for x in r])
+    lbv, ubv = c.copy(), c.copy()
+    lbv[-60:] = np.maximum(lbv[-60:] - 1, 0)            # the last 60 intervals are free within -1: 3 696 candidates
+    p = theta_amd.Problem(ctx, 2, m, 2, rs, rNs, lbv.tolist(), ubv.tolist())
+    assert p.count == orc.count_n2(m, lbv.tolist(), ubv.tolist()) == 3696
+    res = p.search(0, p.count)
+    assert res["stats"]["evaluated"] == p.count
+    k = int(np.argmin(res["nll"]))
+    s = orc.solve_n2(orc.col_to_matrix_n2(res["C"][k], 2), rs, rNs, 1)
+    assert s is not None and abs(s[1] - res["nll"][k]) <= 1e-9 * abs(s[1])
+    # n=3: m=64 with the full K=7 alphabet has more than 2^128 matrices -> a clean overflow error
+    m = 64
+    r3 = [int(x) for x in rng.randint(1000, 5000, m)]
+    rN3 = [int(x) for x in rng.randint(1000, 5000, m)]
+    with pytest.raises(theta_amd.ThetaError) as e:
+        theta_amd.Problem(ctx, 3, m, 2, r3, rN3, [0] * m, [7] * m)
+    assert e.value.code == theta_amd._lib.ERR_OVERFLOW
+    # ... m=64, K=7 with rising lower bounds fits
+    lb3 = [min(6, i // 9) for i in range(m)]
+    ub3 = [min(7, v + 1) for v in lb3]
+    p3 = theta_amd.Problem(ctx, 3, m, 2, r3, rN3, lb3, ub3)
+    assert p3.count == orc.count_n3_exact(m, 2, lb3, ub3) > 10 ** 23      # 128-bit table vs Python integers
+    for start in (0, p3.count // 2, p3.count - 5000):
+        C = p3.enumerate(start, 300)
+        assert C.shape == (300, m, 2) and C.max() <= 7 and (C.min(axis=2) >= np.array(lb3)[None, :]).all()
+        nll, mu, st = p3.values(start, 5000)
+        assert st["evaluated"] == 5000
+        ok, mu_b, nll_b, _ = ctx.solve_batch(3, 2, r3, rN3, p3.enumerate(start, 5000), 1.0, want_vals=False)
+        both = ok & ~np.isnan(nll)
+        assert (ok != ~np.isnan(nll)).sum() <= 10
+        if both.any():
+            assert (np.abs(nll_b[both] - nll[both]) / nll[both]).max() < 1e-10
+
+
+def test_ragged_bounds_and_capacity_growth(ctx):
+    """Bounds that need _check_bound_order; a window so wide that the first capacity guess is too small."""
+    import theta_amd
+    r, rN, L, Ct, mu = orc.synth_counts(9, 2, 4, 55)
+    rs, rNs, order = orc.sort_r(rN, r)
+    lb = [0, 1, 0, 2, 1, 0, 3, 1, 2]
+    ub = [4, 2, 3, 4, 2, 4, 4, 3, 4]
+    p = theta_amd.Problem(ctx, 2, 9, 2, rs, rNs, lb, ub)
+    assert p.count == orc.count_n2(9, lb, ub)
+    big = p.search(0, p.count, window=1e300, cap=4)          # every accepted candidate is "within the window"
+    nll, mu_, st = p.values(0, p.count)
+    assert len(big["rank"]) == int((~np.isnan(nll)).sum()) > 4
+    assert big["rank"] == sorted(big["rank"])
+    assert np.array_equal(big["nll"], nll[~np.isnan(nll)])
+    zero = p.search(0, p.count, window=0.0)
+    assert len(zero["rank"]) >= 1 and zero["nll"].min() == np.nanmin(nll)
+
+
+def test_tie_list_overflow_is_recovered(ctx):
+    """More than 2^20 records within the window: the library re-runs with the tightened threshold."""
+    import theta_amd
+    m = 40
+    rs, rNs = [1000 + 3 * i for i in range(m)], [1000] * m
+    p = theta_amd.Problem(ctx, 2, m, 2, rs, rNs, [0] * m, [6] * m)   # C(46,6) = 9.4e6 candidates
+    assert p.count == 9366819
+    res = p.search(0, p.count, window=0.5)
+    nll, mu_, st = p.values(0, p.count)
+    assert res["stats"]["evaluated"] == p.count
+    assert res["nll"].min() == np.nanmin(nll)
+    assert res["rank"][int(np.argmin(res["nll"]))] == int(np.nanargmin(nll))

@@ -433,7 +433,7 @@ def test_config3_shape_rank_ranges_and_tight_bounds_parity(ctx):
     p.close()
     # (b) full bounds [0,4]: 4.07e27 candidates; ranges far apart in the space
     p = theta_amd.Problem(ctx, 3, 50, 2, rs, rNs, [0] * 50, [4] * 50, 1.0)
-    assert p.count > 10 ** 26
+    assert p.count == orc.count_n3_exact(50, 2, [0] * 50, [4] * 50) > 10 ** 26      # 4.07e27, exact
     for start in (0, p.count // 3, p.count - 20000):
         nll, mu, st = p.values(start, 20000)
         assert st["evaluated"] == 20000
