@@ -1,0 +1,90 @@
+"""
+CPU tests of the host-side feeders of the search (rows f2/f3 of SURVEY.md section 8) against what the
+reference computed for the same input (tests/golden/example_n2.json, written by make_golden.py by calling
+the reference's read_interval_file / select_intervals_n2 / sort_r / calculate_bounds_heuristic), and of the
+file readers/writers against the reference CLI's own output files (tests/golden/cli/).
+"""
+import os
+
+import numpy as np
+
+from conftest import GOLD, load_json
+
+CLI = os.path.join(GOLD, "cli")
+
+
+def test_example_preprocessing_matches_reference():
+    from theta_amd import DataTools, FileIO, SelectIntervals
+    e = load_json("example_n2.json")
+    lengths, tumor, normal, m, ub, lb = FileIO.read_interval_file(os.path.join(CLI, "Example.intervals"))
+    assert m == e["m_all"] == 84 and ub is None and lb is None
+    order, lengths_s, tumor_s, norm_s = SelectIntervals.select_intervals_n2(lengths, tumor, normal, m, e["k"], False, 100)
+    assert [int(x) for x in order] == e["order"] and len(order) == e["m"] == 61
+    DataTools.set_total_read_counts(sum(tumor_s), sum(norm_s))      # RunTHetA.py:388-390
+    r, rN, sorted_index = DataTools.sort_r(norm_s, tumor_s)
+    assert r == e["r"] and rN == e["rN"] and sorted_index == e["sorted_index"]   # stable sort incl. duplicate rows (Q8)
+    ubs, lbs = DataTools.calculate_bounds_heuristic(0.5, r, rN, len(r), e["tau"], e["k"])
+    assert [int(x) for x in ubs] == e["ub"] and [int(x) for x in lbs] == e["lb"]
+    frac = DataTools.determine_frac_copy_num(normal, tumor, lengths, 0.1)
+    assert 0.05 < frac <= 1.0
+    # un-sorting is the inverse of sorting
+    assert DataTools.reverse_sort_list(DataTools.sort_by_sorted_index(list(range(61)), sorted_index), sorted_index) == list(range(61))
+
+
+def test_bounds_file_and_results_file_round_trip(tmp_path):
+    from theta_amd import FileIO
+    e = load_json("example_n2.json")
+    src = os.path.join(CLI, "Example.intervals")
+    # .withBounds exactly as the reference wrote it
+    from theta_amd.DataTools import reverse_sort_list
+    ub_out = reverse_sort_list(e["ub"], e["sorted_index"])
+    lb_out = reverse_sort_list(e["lb"], e["sorted_index"])
+    path = FileIO.write_out_bounds(str(tmp_path), "Example", src, ub_out, lb_out, 2, e["order"])
+    assert open(path).read() == open(os.path.join(CLI, "Example.n2.withBounds")).read()
+    # reading it back gives string bounds with X for unselected intervals, like the reference
+    lengths, tumor, normal, m, ub, lb = FileIO.read_interval_file(path)
+    assert m == 84 and ub.count("X") == 84 - 61 and all(isinstance(v, str) for v in ub)
+    # results writer / reader
+    copy = FileIO.read_results_file(os.path.join(CLI, "Example.n2.results"))
+    assert len(copy) == 84 and set(copy) <= set("0123456789X") | {str(i) for i in range(16)}
+    C = np.zeros((84, 2))
+    C[:, 0] = 2
+    C[:, 1] = [(-1 if v == "X" else int(v)) for v in copy]
+    out = FileIO.write_out_result(str(tmp_path), "rt", [(C, (0.25, 0.75), 123.5, [0.5] * 83 + ["X"])], 2)
+    assert FileIO.read_results_file(out) == copy
+    line = open(out).read().splitlines()[1].split("\t")
+    assert line[0] == "123.5" and line[1] == "0.25,0.75" and line[3].endswith(",X")
+
+
+def test_argument_parser_matches_reference_defaults():
+    from theta_amd import FileIO
+    a = FileIO.parse_arguments(["x/y/sample.intervals"], silent=True)
+    assert len(a) == 27
+    (filename, results, n, k, tau, directory, prefix, max_normal, bh, nbh, hlb, hub, nproc, bounds_only, multi_event,
+     force, get_values, choose, num_intervals, rdf, gfmt, baf, ratio_dev, min_frac, tf, nf, nocl) = a
+    assert (n, k, tau, directory, prefix, max_normal) == (None, 3, 2, "./", "sample", 1.0)
+    assert (bh, nbh, hlb, hub, nproc) == (False, False, 0.9, 1.1, 1)
+    assert (bounds_only, multi_event, force, get_values, choose, num_intervals) == (False, True, False, False, True, 100)
+    assert (ratio_dev, min_frac) == (0.1, 0.05)
+    assert FileIO.parse_arguments(["f.intervals", "-n", "3"], silent=True)[18] == 20        # FileIO.py:170
+    assert FileIO.parse_arguments(["f.intervals", "-n", "3", "--NUM_INTERVALS", "12"], silent=True)[18] == 12
+    import pytest
+    with pytest.raises(ValueError):
+        FileIO.parse_arguments(["f.intervals", "-n", "4"], silent=True)
+    with pytest.raises(ValueError):
+        FileIO.parse_arguments(["f.intervals", "-m", "1.5"], silent=True)
+
+
+def test_select_intervals_n3_rules():
+    """SelectIntervals.py:50-125 on a hand-made case: 75 % changed intervals, 25 % normal ones, new bounds."""
+    from theta_amd.SelectIntervals import select_intervals_n3
+    m = 8
+    lengths = [6_000_000, 7_000_000, 4_000_000, 9_000_000, 8_000_000, 5_500_000, 6_500_000, 10_000_000]
+    tumor, normal = list(range(100, 108)), list(range(200, 208))
+    ub = ["2", "3", "2", "X", "4", "2", "3", "2"]
+    lb = ["0", "2", "0", "X", "2", "0", "2", "0"]
+    copy = ["1", "3", "0", "X", "2", "2", "3", "0"]
+    order, ln, t, nrm, ub2, lb2, cp = select_intervals_n3(lengths, tumor, normal, m, ub, lb, copy, 2, True, 4)
+    # b = 3 changed intervals (longest first: idx 7 (c=0), 1 (c=3), 6 (c=3)), c = 1 normal with ub == 2 (idx 5)
+    assert order == [1, 5, 6, 7]
+    assert ub2 == [3, 2, 3, 2] and lb2 == [2, 1, 2, 0] and cp == [3, 2, 3, 0]

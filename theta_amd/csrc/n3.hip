@@ -273,10 +273,11 @@ struct N3Lds {
     double resU1[N3_WAVES][N3_QCAP], resU2[N3_WAVES][N3_QCAP];
     unsigned long long qCode[N3_WAVES][N3_QCAP];
     unsigned resSt[N3_WAVES][N3_QCAP], qOff[N3_WAVES][N3_QCAP];
+    double lastN1[N3_WAVES][WAVE], lastN2[N3_WAVES][WAVE];   // mixture of the last admissible leaf each lane's chunk produced
+    unsigned char qSrc[N3_WAVES][N3_QCAP];                   // lane whose chunk the queue entry comes from
     unsigned stkS[N3_WAVES][N3_MAX_L][WAVE];            // lane-private DFS stack: node chosen at each leaf level
     unsigned long long stkM[N3_WAVES][N3_MAX_L][WAVE];  // ... and the siblings still to visit at that level
     unsigned long long smask[N3_MAX_L][N3_MAX_Q];       // static child masks of the leaf depths
-    double leafR[N3_MAX_L], leafN[N3_MAX_L];
     unsigned char lb[N3_MAX_M], ub[N3_MAX_M];
     unsigned char ridx[N3_RIDX_W * N3_RIDX_W + 3];
     unsigned char rowtab[N3_MAX_Q + 3];
@@ -310,11 +311,11 @@ __device__ __forceinline__ bool n3_child_dyn(const unsigned char *ridx, const un
     return lo <= hi;
 }
 
-template <bool DUMP>
+template <int L, bool DUMP>
 __global__ __launch_bounds__(64 * N3_WAVES, 3) void n3_search_kernel(N3Dev Pg, SearchArgs A, const N3Task *tasks,
                                                                 const unsigned *stbuf, int ntasks, uint64_t per_task) {
     __shared__ N3Lds S;
-    const int m = Pg.m, L = Pg.L, D = m - L, Q = Pg.Q;
+    const int m = Pg.m, D = m - L, Q = Pg.Q;
     // stage what every wave of the block shares
     for (int i = threadIdx.x; i < m; i += blockDim.x) {
         S.lb[i] = Pg.lb[i];
@@ -323,10 +324,6 @@ __global__ __launch_bounds__(64 * N3_WAVES, 3) void n3_search_kernel(N3Dev Pg, S
     for (int i = threadIdx.x; i < N3_RIDX_W * N3_RIDX_W; i += blockDim.x) S.ridx[i] = Pg.ridx[i];
     for (int i = threadIdx.x; i < Q; i += blockDim.x) S.rowtab[i] = Pg.rowtab[i];
     for (int i = threadIdx.x; i < L * N3_MAX_Q; i += blockDim.x) (&S.smask[0][0])[i] = Pg.smask[(size_t)D * N3_MAX_Q + i];
-    for (int i = threadIdx.x; i < L; i += blockDim.x) {
-        S.leafR[i] = Pg.r[D + i];
-        S.leafN[i] = Pg.rN[D + i];
-    }
     __syncthreads();
     N3Dev P = Pg;
     P.lb = S.lb;
@@ -342,6 +339,8 @@ __global__ __launch_bounds__(64 * N3_WAVES, 3) void n3_search_kernel(N3Dev Pg, S
     double *resU1 = S.resU1[wv], *resU2 = S.resU2[wv];
     unsigned long long *qCode = S.qCode[wv];
     unsigned *resSt = S.resSt[wv], *qOff = S.qOff[wv];
+    double *lastN1 = S.lastN1[wv], *lastN2 = S.lastN2[wv];
+    unsigned char *qSrc = S.qSrc[wv];
     const unsigned long long swm = Pg.swmask;
     const int NT1 = Pg.NT + 1;
 
@@ -357,6 +356,13 @@ __global__ __launch_bounds__(64 * N3_WAVES, 3) void n3_search_kernel(N3Dev Pg, S
     unsigned long long remaining = tk.count, skip = tk.skip, processed = 0;
     const unsigned long long dump_base = (unsigned long long)task * per_task;  // position of the task in the dump arrays
 
+    // leaf rows' shared data (wave-uniform)
+    double leafR[L], leafN[L];
+#pragma unroll
+    for (int l = 0; l < L; l++) {
+        leafR[l] = readlane_f64(r_i, D + l);
+        leafN[l] = readlane_f64(rN_i, D + l);
+    }
     // screening margin for the single-precision NLL: |error| <= Rtot * (|ln q| * 2^-23 + 2^-22) stays far below this
     const double screen_margin = 2e-5 * P.Rtot + 1.0;
     const double inv_N = 1.0 / P.N, inv_Rtot = 1.0 / P.Rtot;
@@ -440,6 +446,7 @@ __global__ __launch_bounds__(64 * N3_WAVES, 3) void n3_search_kernel(N3Dev Pg, S
         unsigned long long my_first = (unsigned long long)lane * chunk;
         unsigned long long my_left = my_first < nleaf ? ((nleaf - my_first < chunk) ? nleaf - my_first : chunk) : 0;
         unsigned my_rel = (unsigned)(processed + my_first);
+        lastN1[lane] = __builtin_nan("");         // no predecessor yet in this lane's chunk
         unsigned long long code = 0, mcur = 0;   // mcur: children of `cur` still to visit at level lv
         N3State cur = par;                      // parent of the level the lane is enumerating
         int lv = L - 1;
@@ -527,6 +534,7 @@ __global__ __launch_bounds__(64 * N3_WAVES, 3) void n3_search_kernel(N3Dev Pg, S
                                 const unsigned rw = S.rowtab[s];
                                 qCode[posb + produced] = (code & ~(0xffull << (8 * lv))) | ((unsigned long long)rw << (8 * lv));
                                 qOff[posb + produced] = my_rel;
+                                qSrc[posb + produced] = (unsigned char)lane;
                                 my_rel++;
                                 my_left--;
                                 produced++;
@@ -556,15 +564,26 @@ __global__ __launch_bounds__(64 * N3_WAVES, 3) void n3_search_kernel(N3Dev Pg, S
                 bool have = false;
                 int myidx = 0;
                 unsigned long long mycode = 0;
+                double lx[L], ly[L];
                 double s1 = 1.0, s2 = 1.0;
                 N3Newton Sv;
                 Sv.status = 0;
                 auto terms = [&](auto &&body) {
 #pragma unroll 4
                     for (int g = 0; g < G; g++) body(gX[g], gY[g], gR[g]);
+#pragma unroll
+                    for (int l = 0; l < L; l++) body(lx[l], ly[l], leafR[l]);
+                };
+                auto decode = [&](unsigned long long code_, double &S1, double &S2) {   // rows of the L leaf levels
+                    S1 = S1p;
+                    S2 = S2p;
+#pragma unroll
                     for (int l = 0; l < L; l++) {
-                        unsigned rw = (unsigned)(mycode >> (8 * l)) & 0xffu;
-                        body((double)(rw & 15u), (double)(rw >> 4), S.leafR[l]);
+                        unsigned rw = (unsigned)(code_ >> (8 * l)) & 0xffu;
+                        lx[l] = (double)(rw & 15u);
+                        ly[l] = (double)(rw >> 4);
+                        S1 = __builtin_fma(lx[l], leafN[l], S1);
+                        S2 = __builtin_fma(ly[l], leafN[l], S2);
                     }
                 };
                 while (true) {
@@ -578,20 +597,24 @@ __global__ __launch_bounds__(64 * N3_WAVES, 3) void n3_search_kernel(N3Dev Pg, S
                         if (take) {
                             myidx = want;
                             mycode = qCode[want];
-                            double S1 = S1p, S2 = S2p;
-                            for (int l = 0; l < L; l++) {
-                                unsigned rw = (unsigned)(mycode >> (8 * l)) & 0xffu;
-                                S1 = __builtin_fma((double)(rw & 15u), S.leafN[l], S1);
-                                S2 = __builtin_fma((double)(rw >> 4), S.leafN[l], S2);
-                            }
+                            double S1, S2;
+                            decode(mycode, S1, S2);
                             if (S1 == 0.0 || S2 == 0.0 || mycode == ~0ull) {   // all-zero tumour column: Chat is NaN
                                 resSt[want] = RES_DEGEN;
                             } else {
                                 have = true;
                                 s1 = S1 * inv_N;
                                 s2 = S2 * inv_N;
-                                Sv.u1 = ws1 * rcp_nr2(s1);      // nu -> u
-                                Sv.u2 = ws2 * rcp_nr2(s2);
+                                // start: the optimum of the previous leaf of the same chunk (it differs in the last
+                                // rows only), else the best candidate of the previous batch; both pulled slightly
+                                // towards the simplex centre so that they are interior for every candidate
+                                const int src = qSrc[want];
+                                double n1 = lastN1[src], n2 = lastN2[src];
+                                const bool pred = n1 == n1;
+                                n1 = pred ? __builtin_fma(0.98, n1, 0.02 / 3.0) : ws1;
+                                n2 = pred ? __builtin_fma(0.98, n2, 0.02 / 3.0) : ws2;
+                                Sv.u1 = n1 * rcp_nr2(s1);       // nu -> u
+                                Sv.u2 = n2 * rcp_nr2(s2);
                                 Sv.p1 = Sv.u1; Sv.p2 = Sv.u2;
                                 Sv.iters = 0;
                                 Sv.status = 0;
@@ -627,12 +650,8 @@ __global__ __launch_bounds__(64 * N3_WAVES, 3) void n3_search_kernel(N3Dev Pg, S
                     unsigned stw = live ? resSt[idx] : RES_DEGEN;
                     double u1 = live ? resU1[idx] : 0.0, u2 = live ? resU2[idx] : 0.0;
                     const unsigned long long rel = live ? qOff[idx] : 0u;
-                    double S1 = S1p, S2 = S2p;
-                    for (int l = 0; l < L; l++) {
-                        unsigned rw = (unsigned)(mycode >> (8 * l)) & 0xffu;
-                        S1 = __builtin_fma((double)(rw & 15u), S.leafN[l], S1);
-                        S2 = __builtin_fma((double)(rw >> 4), S.leafN[l], S2);
-                    }
+                    double S1, S2;
+                    decode(mycode, S1, S2);
                     const unsigned kind = stw & 3u;
                     const bool degenerate = live && kind == RES_DEGEN;
                     const bool solved = live && kind != RES_DEGEN;
@@ -672,10 +691,10 @@ __global__ __launch_bounds__(64 * N3_WAVES, 3) void n3_search_kernel(N3Dev Pg, S
                             float q = __builtin_fmaf(fX[g] - fs1, fu1, __builtin_fmaf(fY[g] - fs2, fu2, 1.0f));
                             accf = __builtin_fmaf(fR[g], __logf(q), accf);
                         }
+#pragma unroll
                         for (int l = 0; l < L; l++) {
-                            unsigned rw = (unsigned)(mycode >> (8 * l)) & 0xffu;
-                            float q = __builtin_fmaf((float)(rw & 15u) - fs1, fu1, __builtin_fmaf((float)(rw >> 4) - fs2, fu2, 1.0f));
-                            accf = __builtin_fmaf((float)S.leafR[l], __logf(q), accf);
+                            float q = __builtin_fmaf((float)lx[l] - fs1, fu1, __builtin_fmaf((float)ly[l] - fs2, fu2, 1.0f));
+                            accf = __builtin_fmaf((float)leafR[l], __logf(q), accf);
                         }
                     }
                     double nll = P.K0 - (double)accf;
@@ -719,6 +738,14 @@ __global__ __launch_bounds__(64 * N3_WAVES, 3) void n3_search_kernel(N3Dev Pg, S
                         if (nll <= best + A.window) {
                             tie_append(A.ctr, A.list, A.list_cap, base + rel, nll, mu0, mu1, mu2);
                             if (nll < best) atomicMin(&A.ctr->best_bits, order_bits(nll));
+                        }
+                    }
+                    if (accept) {   // remember it for the next leaf of the same chunk (the last entry of a lane wins)
+                        const int src = qSrc[idx];
+                        const bool last_of_src = (idx + 1 >= qcount) || (qSrc[idx + 1] != src);
+                        if (last_of_src) {
+                            lastN1[src] = s1 * u1;
+                            lastN2[src] = s2 * u2;
                         }
                     }
                     // wave-wide: new minimum and the warm start for the next batch
@@ -854,10 +881,14 @@ void n3_launch_tasks(const N3Dev &P, u128 begin, u128 end, uint64_t per_task, in
 void n3_launch_search(const N3Dev &P, const SearchArgs &A, const N3Task *tasks, const unsigned *stbuf, int ntasks,
                       uint64_t per_task, hipStream_t st) {
     dim3 grid((ntasks + N3_WAVES - 1) / N3_WAVES), block(64 * N3_WAVES);
-    if (A.dump_nll != nullptr)
-        hipLaunchKernelGGL((n3_search_kernel<true>), grid, block, 0, st, P, A, tasks, stbuf, ntasks, per_task);
-    else
-        hipLaunchKernelGGL((n3_search_kernel<false>), grid, block, 0, st, P, A, tasks, stbuf, ntasks, per_task);
+    const bool dump = A.dump_nll != nullptr;
+#define LAUNCH(LL)                                                                                                     \
+    case LL:                                                                                                           \
+        if (dump) hipLaunchKernelGGL((n3_search_kernel<LL, true>), grid, block, 0, st, P, A, tasks, stbuf, ntasks, per_task); \
+        else hipLaunchKernelGGL((n3_search_kernel<LL, false>), grid, block, 0, st, P, A, tasks, stbuf, ntasks, per_task);     \
+        break;
+    switch (P.L) { LAUNCH(1) LAUNCH(2) LAUNCH(3) LAUNCH(4) LAUNCH(5) default: LAUNCH(6) }
+#undef LAUNCH
 }
 
 void n3_launch_unrank_list(const N3Dev &P, const TieRecord *recs, int count, unsigned char *out, hipStream_t st) {
