@@ -33,7 +33,7 @@ void batch_launch_score(int n, int m, int B, const double *Cw, const double *mu,
                         double *vals, unsigned char *valid, hipStream_t st);
 void batch_launch_score_masked(int n, int m, int tau, int B, int S, const unsigned char *C, const double *w,
                                const double *r, const double *mu, const unsigned long long *mask, double *nll,
-                               hipStream_t st);
+                               double *rsum_scratch, hipStream_t st);
 
 // ---- error string ---------------------------------------------------------------------------------
 static thread_local char g_err[512] = "";
@@ -684,7 +684,7 @@ extern "C" int theta_score_masked(theta_ctx *ctx, int n, int m, int tau, int B, 
     HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
     int words = (m + 63) / 64;
-    DevBuf d_C, d_w, d_r, d_mu, d_mask, d_nll;
+    DevBuf d_C, d_w, d_r, d_mu, d_mask, d_nll, d_rsum;
     int rc;
     if ((rc = upload(d_C, C, (size_t)B * m * (n - 1), st))) return rc;
     if ((rc = upload(d_w, w, (size_t)m * sizeof(double), st))) return rc;
@@ -692,10 +692,11 @@ extern "C" int theta_score_masked(theta_ctx *ctx, int n, int m, int tau, int B, 
     if ((rc = upload(d_mu, mu, (size_t)B * n * sizeof(double), st))) return rc;
     if (mask && (rc = upload(d_mask, mask, (size_t)S * words * sizeof(uint64_t), st))) return rc;
     if ((rc = d_nll.alloc((size_t)B * S * sizeof(double)))) return rc;
+    if ((rc = d_rsum.alloc((size_t)S * sizeof(double)))) return rc;
     HIP_TRY(hipEventRecord(ctx->ev0, st));
     batch_launch_score_masked(n, m, tau, B, S, (const unsigned char *)d_C.p, (const double *)d_w.p, (const double *)d_r.p,
                               (const double *)d_mu.p, mask ? (const unsigned long long *)d_mask.p : nullptr,
-                              (double *)d_nll.p, st);
+                              (double *)d_nll.p, (double *)d_rsum.p, st);
     HIP_TRY(hipEventRecord(ctx->ev1, st));
     HIP_TRY(hipMemcpyAsync(nll, d_nll.p, (size_t)B * S * sizeof(double), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));

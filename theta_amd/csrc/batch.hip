@@ -332,6 +332,106 @@ __global__ __launch_bounds__(256) void score_masked_kernel(int n, int m, int tau
 }
 
 // ------------------------------------------------------------------------------------------------
+// The same operator as a dense FP64 GEMM on the matrix cores: for a block of 8 candidates the masked sums
+// over intervals are   D[S x 16] = MASK[S x m] . X[m x 16],   X[:, 2c] = C.mu of candidate c, X[:, 2c+1] =
+// r ln(C.mu): the 0/1 mask matrix is shared by all candidates -- a genuine GEMM (K = m), so it runs on
+// v_mfma_f64_16x16x4_f64.  The X tile is built once per block (all the logarithms) and stays in LDS; each
+// wave walks 16-mask chunks, 4 rows of X per MFMA step.  Fragment maps (f64 form): A[i][k]: i = lane&15,
+// k = lane>>4; B[k][j]: j = lane&15, k = lane>>4; D[row][col]: col = lane&15, row = (lane>>4) + 4*reg.
+// ------------------------------------------------------------------------------------------------
+typedef double mfma_d4 __attribute__((ext_vector_type(4)));
+#define SMX_CAND 8
+#define SMX_MAXM 256
+
+__global__ __launch_bounds__(64) void mask_rsum_kernel(int m, int S, const double *r, const unsigned long long *mask,
+                                                       double *rsum) {
+    int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= S) return;
+    int words = (m + 63) / 64;
+    double acc = 0.0;
+    for (int i = 0; i < m; i++)
+        if ((mask[(size_t)s * words + (i >> 6)] >> (i & 63)) & 1ull) acc += r[i];
+    rsum[s] = acc;
+}
+
+__global__ __launch_bounds__(256) void score_masked_mfma_kernel(int n, int m, int tau, int B, int S,
+                                                                const unsigned char *C, const double *w, const double *r,
+                                                                const double *mu, const unsigned long long *mask,
+                                                                const double *rsum, double *nll) {
+    __shared__ double X[SMX_MAXM][16];                     // 32 KB: rows = intervals, 2 columns per candidate
+    __shared__ unsigned long long zrow[SMX_CAND][4];       // per candidate: rows that become 0 once masked (NaN poison)
+    const int b0 = blockIdx.x * SMX_CAND;
+    const int nc = n - 1, words = (m + 63) / 64, mpad = (m + 3) & ~3;
+    for (int i = threadIdx.x; i < SMX_CAND * 4; i += blockDim.x) (&zrow[0][0])[i] = 0ull;
+    __syncthreads();
+    // ---- phase 1: the per-row terms of the 8 candidates (one thread per (candidate, row) pair, rows strided by 32)
+    {
+        const int c = threadIdx.x >> 5, b = b0 + c;
+        const bool live = b < B;
+        double m0 = 0, m1 = 0, m2 = 0;
+        if (live) {
+            const double *mv = mu + (size_t)b * n;
+            m0 = mv[0];
+            m1 = (n == 2) ? 1.0 - mv[0] : mv[1];
+            m2 = (n == 3) ? mv[2] : 0.0;
+        }
+        for (int i = threadIdx.x & 31; i < mpad; i += 32) {
+            double cm = 0.0, tl = 0.0;
+            if (live && i < m) {
+                const unsigned char *cc = C + ((size_t)b * m + i) * nc;
+                double x = (double)cc[0], y = (nc == 2) ? (double)cc[1] : 0.0;
+                double tum = x * m1 + y * m2;
+                cm = w[i] * ((double)tau * m0 + tum);
+                tl = r[i] * log(cm);
+                if (!(w[i] * tum > 0.0)) atomicOr(&zrow[c][i >> 6], 1ull << (i & 63));
+            }
+            X[i][2 * c] = cm;
+            X[i][2 * c + 1] = tl;
+        }
+    }
+    __syncthreads();
+    // ---- phase 2: masked sums on the matrix cores
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int li = lane & 15, lk = lane >> 4;
+    for (int s0 = wv * 16; s0 < S; s0 += 64) {
+        const int sA = s0 + li;                             // mask row this lane feeds into A
+        unsigned long long mw0 = 0, mw1 = 0, mw2 = 0, mw3 = 0;
+        if (sA < S) {
+            const unsigned long long *mp = mask + (size_t)sA * words;
+            mw0 = mp[0];
+            if (words > 1) mw1 = mp[1];
+            if (words > 2) mw2 = mp[2];
+            if (words > 3) mw3 = mp[3];
+        }
+        mfma_d4 acc = {0.0, 0.0, 0.0, 0.0};
+        for (int kk = 0; kk < mpad; kk += 4) {
+            const int k = kk + lk;
+            unsigned long long wd = (k < 64) ? mw0 : (k < 128) ? mw1 : (k < 192) ? mw2 : mw3;
+            double a = (double)((wd >> (k & 63)) & 1ull);
+            double bv = X[k][li];
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bv, acc, 0, 0, 0);
+        }
+        // D[row = lk + 4*reg][col = li]; col 2c = sum of C.mu (den), col 2c+1 = sum of r ln(C.mu) (tot)
+        const int c = li >> 1, b = b0 + c;
+#pragma unroll
+        for (int reg = 0; reg < 4; reg++) {
+            double v = acc[reg];
+            double den = __shfl_xor(v, 1, WAVE);            // partner column of the same candidate
+            const int s = s0 + lk + 4 * reg;
+            if ((li & 1) && s < S && b < B) {
+                const unsigned long long *mp = mask + (size_t)s * words;
+                bool poison = false;
+                for (int q = 0; q < words; q++) {
+                    unsigned long long live_bits = (q == words - 1 && (m & 63)) ? ((1ull << (m & 63)) - 1ull) : ~0ull;
+                    if (~mp[q] & zrow[c][q] & live_bits) poison = true;
+                }
+                nll[(size_t)b * S + s] = poison ? __builtin_nan("") : -(v - rsum[s] * log(den));
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------
 void batch_launch_solve(int n, int m, int tau, const double *r, const double *rN, double max_normal, int B,
@@ -353,6 +453,12 @@ void batch_launch_score(int n, int m, int B, const double *Cw, const double *mu,
 
 void batch_launch_score_masked(int n, int m, int tau, int B, int S, const unsigned char *C, const double *w,
                                const double *r, const double *mu, const unsigned long long *mask, double *nll,
-                               hipStream_t st) {
-    hipLaunchKernelGGL(score_masked_kernel, dim3((B + 3) / 4), dim3(256), 0, st, n, m, tau, B, S, C, w, r, mu, mask, nll);
+                               double *rsum_scratch, hipStream_t st) {
+    if (mask != nullptr && S >= 16 && rsum_scratch != nullptr) {   // enough masks to fill the 16-row MFMA tiles
+        hipLaunchKernelGGL(mask_rsum_kernel, dim3((S + 63) / 64), dim3(64), 0, st, m, S, r, mask, rsum_scratch);
+        hipLaunchKernelGGL(score_masked_mfma_kernel, dim3((B + SMX_CAND - 1) / SMX_CAND), dim3(256), 0, st, n, m, tau, B, S, C,
+                           w, r, mu, mask, rsum_scratch, nll);
+    } else {
+        hipLaunchKernelGGL(score_masked_kernel, dim3((B + 3) / 4), dim3(256), 0, st, n, m, tau, B, S, C, w, r, mu, mask, nll);
+    }
 }
