@@ -345,13 +345,13 @@ typedef double mfma_d4 __attribute__((ext_vector_type(4)));
 
 __global__ __launch_bounds__(64) void mask_rsum_kernel(int m, int S, const double *r, const unsigned long long *mask,
                                                        double *rsum) {
-    int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= S) return;
-    int words = (m + 63) / 64;
+    const int s = blockIdx.x, lane = threadIdx.x;     // one wave per mask
+    const int words = (m + 63) / 64;
     double acc = 0.0;
-    for (int i = 0; i < m; i++)
+    for (int i = lane; i < m; i += WAVE)
         if ((mask[(size_t)s * words + (i >> 6)] >> (i & 63)) & 1ull) acc += r[i];
-    rsum[s] = acc;
+    acc = wave_sum_f64(acc);
+    if (lane == 0) rsum[s] = acc;
 }
 
 __global__ __launch_bounds__(256) void score_masked_mfma_kernel(int n, int m, int tau, int B, int S,
@@ -455,7 +455,7 @@ void batch_launch_score_masked(int n, int m, int tau, int B, int S, const unsign
                                const double *r, const double *mu, const unsigned long long *mask, double *nll,
                                double *rsum_scratch, hipStream_t st) {
     if (mask != nullptr && S >= 16 && rsum_scratch != nullptr) {   // enough masks to fill the 16-row MFMA tiles
-        hipLaunchKernelGGL(mask_rsum_kernel, dim3((S + 63) / 64), dim3(64), 0, st, m, S, r, mask, rsum_scratch);
+        hipLaunchKernelGGL(mask_rsum_kernel, dim3(S), dim3(64), 0, st, m, S, r, mask, rsum_scratch);
         hipLaunchKernelGGL(score_masked_mfma_kernel, dim3((B + SMX_CAND - 1) / SMX_CAND), dim3(256), 0, st, n, m, tau, B, S, C,
                            w, r, mu, mask, rsum_scratch, nll);
     } else {

@@ -61,7 +61,7 @@ def main():
         mu = rng.dirichlet(np.ones(3) * 3, B)
         masks = rng.randint(0, 2 ** 63, (S, words), dtype=np.int64).astype(np.uint64)
         ctx.score_masked(nn, 2, C[:1024], w, rr, mu[:1024], masks)
-        nll, ms = ctx.score_masked(nn, 2, C, w, rr, mu, masks)
+        ms = min(ctx.score_masked(nn, 2, C, w, rr, mu, masks)[1] for _ in range(5))
         algo_bytes = B * (m * 2 + 8 * nn) + B * S * 8 + S * words * 8      # candidates + mu read, NLL written, masks
         flops = 2.0 * S * m * 2 * B                                        # the two masked sums as a GEMM
         out["config5_scorer_m200_k7_S%d" % S] = {
