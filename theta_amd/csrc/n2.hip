@@ -119,19 +119,25 @@ __device__ bool n2_next(const N2Dev &P, const unsigned char *ubl, const short *l
 }
 
 struct N2Result {
-    bool ok, degenerate;
-    double mu, nll;
+    bool ok, degenerate, exact;
+    double mu, nll, x;
     int iters, terms;
 };
 
 // Group-aggregated restatement of Optimizer._solve_n2 (Optimizer.py:90-126).
-template <int KV>
-__device__ N2Result n2_solve(const N2Dev &P, const double *PRl, const double *PNl, const N2Cand<KV> &c) {
+//   warm      root of the previous accepted candidate of this thread (NaN: none) -- neighbours in the colex
+//             order differ in a few rows only, so it is an excellent Newton start
+//   screen    NLL above which the exact (FP64 log) value is not needed; the f32 value is returned then
+template <int KV, bool EXACT>
+__device__ N2Result n2_solve(const N2Dev &P, const double *PRl, const double *PNl, const N2Cand<KV> &c, double warm,
+                             double screen) {
     N2Result out;
     out.ok = false;
     out.degenerate = false;
+    out.exact = true;
     out.mu = 0;
     out.nll = 0;
+    out.x = warm;
     out.iters = 0;
     double R[KV], w[KV];
     double S1 = 0;
@@ -155,26 +161,20 @@ __device__ N2Result n2_solve(const N2Dev &P, const double *PRl, const double *PN
     for (int v = 0; v < KV; v++) w[v] = sigma - (double)v;
 
     // bracket [lo, hi] in nu-space; hi = M2_Rev(max_normal) (Optimizer.py:107-110, 228-231)
-    double lo = 0.0, hi = 1.0;
+    const double lo = 0.0;
+    double hi = 1.0;
     if (P.max_normal != 1.0) hi = P.max_normal * tau / ((1.0 - P.max_normal) * sigma + P.max_normal * tau);
 
-    auto feval = [&](double x, double &fp) {
+    // f = dL/dnu is increasing (the NLL is convex in nu); exact divisions at the ends so that a pole gives +-inf
+    auto fend = [&](double x) {
         double f = 0.0;
-        fp = 0.0;
 #pragma unroll
-        for (int v = 0; v < KV; v++) {
-            if (R[v] != 0.0) {
-                double den = __builtin_fma(x, w[v], (double)v);
-                double t = w[v] / den;  // exact division: the bracket test must see +-inf at a pole
-                f = __builtin_fma(-R[v], t, f);
-                fp = __builtin_fma(R[v] * t, t, fp);
-            }
-        }
+        for (int v = 0; v < KV; v++)
+            if (R[v] != 0.0) f = __builtin_fma(-R[v], w[v] / __builtin_fma(x, w[v], (double)v), f);
         return f;
     };
-    double fp;
-    double flo = feval(lo, fp);
-    double fhi = feval(hi, fp);
+    const double flo = (R[0] != 0.0) ? -__builtin_inf() : fend(lo);   // a run of zeros puts a pole at nu = 0
+    const double fhi = fend(hi);
     double x;
     if (flo == 0.0) {
         x = lo;  // brenth returns the left end when f(lo) == 0 (proportional columns, quirk Q3)
@@ -183,44 +183,65 @@ __device__ N2Result n2_solve(const N2Dev &P, const double *PRl, const double *PN
     } else if (flo != flo || fhi != fhi || (flo < 0) == (fhi < 0)) {
         return out;  // no sign change on [lo, hi]: brenth raises -> None (quirk Q6)
     } else {
-        // f is increasing; keep f(a) < 0 < f(b).  Newton with bisection safeguard.
+        // Damped Newton on the self-concordant NLL/Rtot, safeguarded by the bracket f(a) < 0 < f(b).
         double a = lo, b = hi;
-        x = 0.5 * (a + b);
+        x = (warm > lo && warm < hi) ? warm : 0.5 * (a + b);
+        const double inv_R = 1.0 / P.Rtot;
         for (int it = 0; it < 100; it++) {
             out.iters++;
             double f = 0.0, d = 0.0;
 #pragma unroll
             for (int v = 0; v < KV; v++) {
                 if (R[v] != 0.0) {
-                    double den = __builtin_fma(x, w[v], (double)v);
-                    double t = w[v] * rcp_nr1(den);
+                    double t = w[v] * rcp_nr1(__builtin_fma(x, w[v], (double)v));
                     f = __builtin_fma(-R[v], t, f);
                     d = __builtin_fma(R[v] * t, t, d);
                 }
             }
             if (f == 0.0) break;
             if (f < 0) a = x; else b = x;
-            double xn = x - f / d;
+            const double dx = f * rcp_nr2(d);
+            const double l2 = f * dx * inv_R;             // squared Newton decrement
+            double step = 1.0;
+            if (l2 > 0.09) step = 1.0 / (1.0 + sqrt(l2));
+            double xn = __builtin_fma(-step, dx, x);
             if (!(xn > a && xn < b)) xn = 0.5 * (a + b);
-            double dx = fabs(xn - x);
             x = xn;
-            if (dx <= 2e-16 * fmax(x, 1e-300) || b - a <= 1e-300) break;
+            if (l2 < 1e-12 || b - a <= 1e-300) break;     // the step just taken leaves an error ~ l2
         }
     }
     // nu -> mu (M2, Optimizer.py:223-226) and the NLL (L2, Optimizer.py:187-196) in group form
-    double mu = x * sigma / ((1.0 - x) * tau + x * sigma);
-    double nu1 = 1.0 - mu;
+    const double mu = x * sigma / ((1.0 - x) * tau + x * sigma);
+    const double nu1 = 1.0 - mu;
+    const double dall = __builtin_fma(sigma, nu1, tau * mu);
+    if (!EXACT) {   // single-precision screen first: most candidates are far above the running minimum
+        float acc = 0.0f;
+        const float fnu1 = (float)nu1, ftm = (float)(tau * mu);
+#pragma unroll
+        for (int v = 0; v < KV; v++)
+            if (R[v] != 0.0) acc = __builtin_fmaf((float)R[v], __logf(__builtin_fmaf((float)v, fnu1, ftm)), acc);
+        double approx = P.K0 - (double)acc + P.Rtot * (double)__logf((float)dall);
+        if (approx > screen) {
+            out.nll = approx;
+            out.exact = false;
+            out.mu = mu;
+            out.x = x;
+            out.ok = true;
+            return out;
+        }
+    }
     double acc = 0.0;
 #pragma unroll
     for (int v = 0; v < KV; v++)
         if (R[v] != 0.0) acc = __builtin_fma(R[v], log(__builtin_fma((double)v, nu1, tau * mu)), acc);
-    out.nll = P.K0 - acc + P.Rtot * log(__builtin_fma(sigma, nu1, tau * mu));
+    out.nll = P.K0 - acc + P.Rtot * log(dall);
     out.mu = mu;
+    out.x = x;
     out.ok = true;
     return out;
 }
 
-template <int KV>
+template <int KV, bool DUMP>
 __global__ __launch_bounds__(256) void n2_search_kernel(N2Dev P, SearchArgs A, unsigned long long begin,
                                                         unsigned long long end, int per_thread) {
     extern __shared__ unsigned char smem[];
@@ -248,8 +269,12 @@ __global__ __launch_bounds__(256) void n2_search_kernel(N2Dev P, SearchArgs A, u
         N2Cand<KV> c;
         n2_unrank<KV>(P, Pl, t0, c);
         double best = order_unbits(load_agent_u64(&A.ctr->best_bits));
+        double warm = __builtin_nan("");
+        // f32 screen: |error| <= ~1e-6 * Rtot * ln(range) -- a margin of 2e-5 Rtot is far outside it
+        const double margin = 2e-5 * P.Rtot + 1.0;
         for (unsigned long long rank = t0; rank < t1; rank++) {
-            N2Result rs = n2_solve<KV>(P, PRl, PNl, c);
+            N2Result rs = n2_solve<KV, DUMP>(P, PRl, PNl, c, warm, best + A.window + margin);
+            if (rs.ok) warm = rs.x;
             n_eval++;
             n_it += rs.iters;
             n_terms += (unsigned long long)rs.iters * rs.terms;
@@ -257,7 +282,7 @@ __global__ __launch_bounds__(256) void n2_search_kernel(N2Dev P, SearchArgs A, u
             if (rs.ok) {
                 n_acc++;
                 n_fin += rs.terms + 1;
-                if (rs.nll <= best + A.window) {
+                if (rs.exact && rs.nll <= best + A.window) {
                     // refresh: another thread may have lowered the global minimum meanwhile
                     best = fmin(best, order_unbits(load_agent_u64(&A.ctr->best_bits)));
                     if (rs.nll <= best + A.window) {
@@ -269,7 +294,7 @@ __global__ __launch_bounds__(256) void n2_search_kernel(N2Dev P, SearchArgs A, u
                     }
                 }
             }
-            if (A.dump_nll) {
+            if (DUMP) {
                 A.dump_nll[rank - begin] = rs.ok ? rs.nll : __builtin_nan("");
                 A.dump_mu[(rank - begin) * 2] = rs.ok ? rs.mu : __builtin_nan("");
                 A.dump_mu[(rank - begin) * 2 + 1] = rs.ok ? 1.0 - rs.mu : __builtin_nan("");
@@ -355,10 +380,14 @@ void n2_launch_search(const N2Dev &P, const SearchArgs &A, unsigned long long be
     unsigned long long threads = (n + per_thread - 1) / per_thread;
     unsigned blocks = (unsigned)((threads + 255) / 256);
     size_t sm = n2_smem_bytes(P);
-    if (P.kv <= 8)
-        hipLaunchKernelGGL(n2_search_kernel<8>, dim3(blocks), dim3(256), sm, st, P, A, begin, end, per_thread);
-    else
-        hipLaunchKernelGGL(n2_search_kernel<16>, dim3(blocks), dim3(256), sm, st, P, A, begin, end, per_thread);
+    const bool dump = A.dump_nll != nullptr;
+    if (P.kv <= 8) {
+        if (dump) hipLaunchKernelGGL((n2_search_kernel<8, true>), dim3(blocks), dim3(256), sm, st, P, A, begin, end, per_thread);
+        else hipLaunchKernelGGL((n2_search_kernel<8, false>), dim3(blocks), dim3(256), sm, st, P, A, begin, end, per_thread);
+    } else {
+        if (dump) hipLaunchKernelGGL((n2_search_kernel<16, true>), dim3(blocks), dim3(256), sm, st, P, A, begin, end, per_thread);
+        else hipLaunchKernelGGL((n2_search_kernel<16, false>), dim3(blocks), dim3(256), sm, st, P, A, begin, end, per_thread);
+    }
 }
 
 void n2_launch_enumerate(const N2Dev &P, unsigned long long begin, unsigned long long count, unsigned char *out,
