@@ -140,3 +140,21 @@ def test_tie_list_overflow_is_recovered(ctx):
     assert res["stats"]["evaluated"] == p.count
     assert res["nll"].min() == np.nanmin(nll)
     assert res["rank"][int(np.argmin(res["nll"]))] == int(np.nanargmin(nll))
+
+
+def test_ranges_beyond_one_call_are_walked_in_pieces(ctx):
+    """Problem.search splits ranges larger than one theta_search call can take and merges the finalists."""
+    import theta_amd
+    r, rN, L, Ct, mu = orc.synth_counts(12, 3, 3, 91)
+    rs, rNs, order = orc.sort_r(rN, r)
+    p = theta_amd.Problem(ctx, 3, 12, 2, rs, rNs, [0] * 12, [3] * 12)
+    whole = p.search(0, p.count, window=0.5)
+    old = dict(theta_amd.Problem.MAX_PER_CALL)
+    try:
+        theta_amd.Problem.MAX_PER_CALL[3] = max(1000, p.count // 7)
+        pieces = p.search(0, p.count, window=0.5)
+    finally:
+        theta_amd.Problem.MAX_PER_CALL.update(old)
+    assert pieces["rank"] == whole["rank"]
+    assert np.array_equal(pieces["nll"], whole["nll"]) and np.array_equal(pieces["C"], whole["C"])
+    assert pieces["stats"]["evaluated"] == whole["stats"]["evaluated"] == p.count

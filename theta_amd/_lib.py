@@ -214,9 +214,42 @@ class Problem:
     def _shape_C(self, flat, k):
         return flat.reshape(k, self.m) if self.n == 2 else flat.reshape(k, self.m, 2)
 
+    # one theta_search call takes at most this many candidates (n=3: 2^18 wave tasks of 2^14 candidates)
+    MAX_PER_CALL = {2: 1 << 40, 3: 1 << 32}
+
     def search(self, begin=0, end=None, window=0.5, cap=4096):
-        """Fused search over ranks [begin, end).  Returns dict(nll, mu, rank (python ints), C, stats)."""
+        """
+        Fused search over ranks [begin, end).  Returns dict(nll, mu, rank (python ints), C, stats).
+        Ranges larger than one call can take are walked in pieces; the pieces' finalists are merged here
+        (same rule as across GPUs: keep what lies within `window` of the overall minimum).
+        """
         end = self.count if end is None else end
+        step = self.MAX_PER_CALL[self.n]
+        if end - begin <= step:
+            return self._search_once(begin, end, window, cap)
+        parts = [self._search_once(b, min(b + step, end), window, cap) for b in range(begin, end, step)]
+        stats = dict(parts[0]["stats"])
+        for p in parts[1:]:
+            for k, v in p["stats"].items():
+                if k in ("evaluated", "accepted", "degenerate", "iterations", "terms", "list_overflow", "flops"):
+                    stats[k] += v
+                elif k in ("kernel_ms", "setup_ms"):
+                    stats[k] += v
+                elif k == "phase_cycles":
+                    stats[k] = [a + b for a, b in zip(stats[k], v)]
+                elif k == "best_nll":
+                    stats[k] = min(stats[k], v)
+                elif k == "rejected_bound" and v < stats[k]:
+                    stats[k], stats["rejected_rank"] = v, p["stats"]["rejected_rank"]
+        nll = np.concatenate([p["nll"] for p in parts])
+        keep = nll <= (nll.min() if len(nll) else 0.0) + window
+        mu = np.concatenate([p["mu"] for p in parts])[keep]
+        Cc = np.concatenate([p["C"] for p in parts])[keep]
+        ranks = [r for p in parts for r in p["rank"]]
+        ranks = [r for r, k in zip(ranks, keep) if k]
+        return {"nll": nll[keep], "mu": mu, "rank": ranks, "C": Cc, "stats": stats}
+
+    def _search_once(self, begin, end, window, cap):
         st = SearchStats()
         while True:
             nll = np.zeros(cap)

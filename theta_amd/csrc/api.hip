@@ -102,7 +102,7 @@ extern "C" int theta_device_info(theta_ctx *c, char *name, int cap, int *cu, uin
 
 // ---- search instance ------------------------------------------------------------------------------
 #define LIST_CAP (1u << 20)
-#define N3_MAX_TASKS (1 << 16)
+#define N3_MAX_TASKS (1 << 18)
 
 struct theta_problem {
     theta_ctx *ctx = nullptr;
@@ -385,18 +385,13 @@ static int run_search(theta_problem *p, u128 b, u128 e, double window, double *d
             uint64_t per_task = 16384;   // candidates per wave; each lane then walks ~256 consecutive leaves
             if (const char *e = getenv("THETA_N3_PER_TASK")) {
                 long long v = atoll(e);
-                if (v >= 64) per_task = (uint64_t)v;
+                if (v >= 64 && v <= 65535) per_task = (uint64_t)v;   // the kernel keeps in-task offsets in 16 bits
             }
             u128 nt = (cnt + per_task - 1) / per_task;
             if (nt > N3_MAX_TASKS) {
-                nt = N3_MAX_TASKS;
-                u128 pt = (cnt + nt - 1) / nt;
-                if (pt > (u128)0x7fffffffffffull) {
-                    theta_set_error("rank range too large for one call (%d tasks of at most 2^47 candidates)", N3_MAX_TASKS);
-                    return THETA_ERR_ARG;
-                }
-                per_task = (uint64_t)pt;
-                nt = (cnt + per_task - 1) / per_task;
+                theta_set_error("n=3 rank range too large for one call: at most %llu candidates (split the range; "
+                                "theta_amd.Problem.search does)", (unsigned long long)N3_MAX_TASKS * per_task);
+                return THETA_ERR_ARG;
             }
             int ntasks = (int)nt;
             n3_launch_tasks(p->n3, b, e, per_task, ntasks, (N3Task *)p->d_tasks.p, (unsigned *)p->d_stbuf.p, st);

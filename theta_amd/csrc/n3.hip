@@ -269,11 +269,11 @@ __device__ __forceinline__ double readlane_f64(double v, int l) {
 
 struct N3Lds {
     double gX[N3_WAVES][N3_MAX_Q + N3_MAX_L], gY[N3_WAVES][N3_MAX_Q + N3_MAX_L], gR[N3_WAVES][N3_MAX_Q + N3_MAX_L];
-    float fX[N3_WAVES][N3_MAX_Q + N3_MAX_L], fY[N3_WAVES][N3_MAX_Q + N3_MAX_L], fR[N3_WAVES][N3_MAX_Q + N3_MAX_L];  // f32 copy (screening pass)
+    float4 fT[N3_WAVES][N3_MAX_Q + N3_MAX_L];   // f32 copy {a, b, sum r, -} of the tile (screening pass: one 16-byte read per term)
     double resU1[N3_WAVES][N3_QCAP], resU2[N3_WAVES][N3_QCAP];
     unsigned long long qCode[N3_WAVES][N3_QCAP];
-    unsigned resSt[N3_WAVES][N3_QCAP], qOff[N3_WAVES][N3_QCAP];
-    double lastN1[N3_WAVES][WAVE], lastN2[N3_WAVES][WAVE];   // mixture of the last admissible leaf each lane's chunk produced
+    unsigned short resSt[N3_WAVES][N3_QCAP], qOff[N3_WAVES][N3_QCAP];   // (a task holds < 65536 candidates)
+    float lastN1[N3_WAVES][WAVE], lastN2[N3_WAVES][WAVE];     // mixture of the last admissible leaf each lane's chunk produced
     unsigned char qSrc[N3_WAVES][N3_QCAP];                   // lane whose chunk the queue entry comes from
     unsigned stkS[N3_WAVES][N3_MAX_L][WAVE];            // lane-private DFS stack: node chosen at each leaf level
     unsigned long long stkM[N3_WAVES][N3_MAX_L][WAVE];  // ... and the siblings still to visit at that level
@@ -335,11 +335,11 @@ __global__ __launch_bounds__(64 * N3_WAVES, 3) void n3_search_kernel(N3Dev Pg, S
     if (task >= ntasks) return;  // whole wave leaves together; no block barrier below
     const double tau = (double)P.tau;
     double *gX = S.gX[wv], *gY = S.gY[wv], *gR = S.gR[wv];
-    float *fX = S.fX[wv], *fY = S.fY[wv], *fR = S.fR[wv];
+    float4 *fT = S.fT[wv];
     double *resU1 = S.resU1[wv], *resU2 = S.resU2[wv];
     unsigned long long *qCode = S.qCode[wv];
-    unsigned *resSt = S.resSt[wv], *qOff = S.qOff[wv];
-    double *lastN1 = S.lastN1[wv], *lastN2 = S.lastN2[wv];
+    unsigned short *resSt = S.resSt[wv], *qOff = S.qOff[wv];
+    float *lastN1 = S.lastN1[wv], *lastN2 = S.lastN2[wv];
     unsigned char *qSrc = S.qSrc[wv];
     const unsigned long long swm = Pg.swmask;
     const int NT1 = Pg.NT + 1;
@@ -415,9 +415,7 @@ __global__ __launch_bounds__(64 * N3_WAVES, 3) void n3_search_kernel(N3Dev Pg, S
                     gX[G] = a;
                     gY[G] = b;
                     gR[G] = Rs;
-                    fX[G] = (float)a;
-                    fY[G] = (float)b;
-                    fR[G] = (float)Rs;
+                    fT[G] = make_float4((float)a, (float)b, (float)Rs, 0.0f);
                 }
                 S1p += a * Ns;
                 S2p += b * Ns;
@@ -446,7 +444,7 @@ __global__ __launch_bounds__(64 * N3_WAVES, 3) void n3_search_kernel(N3Dev Pg, S
         unsigned long long my_first = (unsigned long long)lane * chunk;
         unsigned long long my_left = my_first < nleaf ? ((nleaf - my_first < chunk) ? nleaf - my_first : chunk) : 0;
         unsigned my_rel = (unsigned)(processed + my_first);
-        lastN1[lane] = __builtin_nan("");         // no predecessor yet in this lane's chunk
+        lastN1[lane] = __builtin_nanf("");        // no predecessor yet in this lane's chunk
         unsigned long long code = 0, mcur = 0;   // mcur: children of `cur` still to visit at level lv
         N3State cur = par;                      // parent of the level the lane is enumerating
         int lv = L - 1;
@@ -533,7 +531,7 @@ __global__ __launch_bounds__(64 * N3_WAVES, 3) void n3_search_kernel(N3Dev Pg, S
                             if (lv == L - 1) {                 // a leaf
                                 const unsigned rw = S.rowtab[s];
                                 qCode[posb + produced] = (code & ~(0xffull << (8 * lv))) | ((unsigned long long)rw << (8 * lv));
-                                qOff[posb + produced] = my_rel;
+                                qOff[posb + produced] = (unsigned short)my_rel;
                                 qSrc[posb + produced] = (unsigned char)lane;
                                 my_rel++;
                                 my_left--;
@@ -600,7 +598,7 @@ __global__ __launch_bounds__(64 * N3_WAVES, 3) void n3_search_kernel(N3Dev Pg, S
                             double S1, S2;
                             decode(mycode, S1, S2);
                             if (S1 == 0.0 || S2 == 0.0 || mycode == ~0ull) {   // all-zero tumour column: Chat is NaN
-                                resSt[want] = RES_DEGEN;
+                                resSt[want] = (unsigned short)RES_DEGEN;
                             } else {
                                 have = true;
                                 s1 = S1 * inv_N;
@@ -609,7 +607,7 @@ __global__ __launch_bounds__(64 * N3_WAVES, 3) void n3_search_kernel(N3Dev Pg, S
                                 // rows only), else the best candidate of the previous batch; both pulled slightly
                                 // towards the simplex centre so that they are interior for every candidate
                                 const int src = qSrc[want];
-                                double n1 = lastN1[src], n2 = lastN2[src];
+                                double n1 = (double)lastN1[src], n2 = (double)lastN2[src];
                                 const bool pred = n1 == n1;
                                 n1 = pred ? __builtin_fma(0.98, n1, 0.02 / 3.0) : ws1;
                                 n2 = pred ? __builtin_fma(0.98, n2, 0.02 / 3.0) : ws2;
@@ -633,7 +631,7 @@ __global__ __launch_bounds__(64 * N3_WAVES, 3) void n3_search_kernel(N3Dev Pg, S
                             bool conv = Sv.status == 1;
                             resU1[myidx] = conv ? Sv.u1 : Sv.p1;      // failed: last feasible iterate
                             resU2[myidx] = conv ? Sv.u2 : Sv.p2;
-                            resSt[myidx] = (conv ? RES_CONV : RES_FAIL) | sing | ((unsigned)Sv.iters << 8);
+                            resSt[myidx] = (unsigned short)((conv ? RES_CONV : RES_FAIL) | sing | ((unsigned)Sv.iters << 8));
                             have = false;
                         }
                     }
@@ -688,8 +686,9 @@ __global__ __launch_bounds__(64 * N3_WAVES, 3) void n3_search_kernel(N3Dev Pg, S
                         const float fs1 = (float)s1, fs2 = (float)s2, fu1 = (float)u1, fu2 = (float)u2;
 #pragma unroll 4
                         for (int g = 0; g < G; g++) {
-                            float q = __builtin_fmaf(fX[g] - fs1, fu1, __builtin_fmaf(fY[g] - fs2, fu2, 1.0f));
-                            accf = __builtin_fmaf(fR[g], __logf(q), accf);
+                            const float4 t = fT[g];
+                            float q = __builtin_fmaf(t.x - fs1, fu1, __builtin_fmaf(t.y - fs2, fu2, 1.0f));
+                            accf = __builtin_fmaf(t.z, __logf(q), accf);
                         }
 #pragma unroll
                         for (int l = 0; l < L; l++) {
@@ -744,14 +743,15 @@ __global__ __launch_bounds__(64 * N3_WAVES, 3) void n3_search_kernel(N3Dev Pg, S
                         const int src = qSrc[idx];
                         const bool last_of_src = (idx + 1 >= qcount) || (qSrc[idx + 1] != src);
                         if (last_of_src) {
-                            lastN1[src] = s1 * u1;
-                            lastN2[src] = s2 * u2;
+                            lastN1[src] = (float)(s1 * u1);
+                            lastN2[src] = (float)(s2 * u2);
                         }
                     }
-                    // wave-wide: new minimum and the warm start for the next batch
-                    double mine = (accept && contender) ? nll : __builtin_inf();
-                    double wbest = wave_min(mine);
-                    if (wbest < __builtin_inf()) {
+                    // wave-wide (only when some lane holds an exact contender): new minimum, warm start for chunk starts
+                    const bool cand = accept && contender;
+                    if (ballot64(cand)) {
+                        double mine = cand ? nll : __builtin_inf();
+                        double wbest = wave_min(mine);
                         best = fmin(best, wbest);
                         unsigned long long who = ballot64(mine == wbest);
                         int src = __builtin_ctzll(who);
