@@ -220,7 +220,7 @@ def main():
                        "parallelism": "rank-range sharding x%d, one RCCL exchange of finalists" % world},
             "roofline": {"bound": "fp64-valu", "achieved": ach, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach / FP64_VECTOR_PEAK_TFLOPS, "traffic": traffic,
-                         "kernel": "n3_search_kernel<6,false>", "kernel_ms_per_launch": k_ms / launches,
+                         "kernel": "n3_search_kernel<5,false>", "kernel_ms_per_launch": k_ms / launches,
                          "flop_per_candidate": allv[0, 2] / max(allv[0, 0], 1.0),
                          "newton_iters_per_candidate": allv[0, 5] / max(allv[0, 0], 1.0),
                          "terms_per_iteration": allv[0, 4] / max(allv[0, 5], 1.0),

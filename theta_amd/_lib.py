@@ -214,8 +214,8 @@ class Problem:
     def _shape_C(self, flat, k):
         return flat.reshape(k, self.m) if self.n == 2 else flat.reshape(k, self.m, 2)
 
-    # one theta_search call takes at most this many candidates (n=3: 2^18 wave tasks of 2^14 candidates)
-    MAX_PER_CALL = {2: 1 << 40, 3: 1 << 32}
+    # one theta_search call takes at most this many candidates (n=3: 2^18 wave tasks of 2^13 candidates)
+    MAX_PER_CALL = {2: 1 << 40, 3: 1 << 31}
 
     def search(self, begin=0, end=None, window=0.5, cap=4096):
         """

@@ -261,7 +261,7 @@ extern "C" int theta_problem_create(theta_ctx *ctx, int n, int m, int tau, const
         D.Q = h.Q;
         D.tau = tau;
         D.NT = h.NT;
-        int L = 6;   // leaf levels enumerated by the lanes (tuned on MI355X)
+        int L = 5;   // leaf levels enumerated by the lanes (tuned on MI355X)
         if (const char *e = getenv("THETA_N3_LEAF_LEVELS")) {
             int v = atoi(e);
             if (v >= 1 && v <= 6) L = v;
@@ -382,7 +382,7 @@ static int run_search(theta_problem *p, u128 b, u128 e, double window, double *d
             n2_launch_search(p->n2, A, nb, ne, (int)per, st);
         } else {
             u128 cnt = e - b;
-            uint64_t per_task = 16384;   // candidates per wave; each lane then walks ~256 consecutive leaves
+            uint64_t per_task = 8192;    // candidates per wave task (each lane walks ~128 consecutive leaves); tuned, DESIGN.md
             if (const char *e = getenv("THETA_N3_PER_TASK")) {
                 long long v = atoll(e);
                 if (v >= 64 && v <= 65535) per_task = (uint64_t)v;   // the kernel keeps in-task offsets in 16 bits

@@ -201,39 +201,79 @@ __device__ __forceinline__ N3State n3_unpack(unsigned v) {
     return s;
 }
 
-// one thread per task: where does the task start?
-__global__ __launch_bounds__(64) void n3_task_kernel(N3Dev P, uint64_t b_lo, uint64_t b_hi, uint64_t e_lo, uint64_t e_hi,
-                                                     uint64_t per_task, int ntasks, N3Task *tasks, unsigned *stbuf) {
-    int t = blockIdx.x * blockDim.x + threadIdx.x;
+// Wave-cooperative rank -> DFS path: at every level the 64 lanes test the 64 alphabet slots and read their
+// children's counts in ONE memory round trip (the serial walk above chains ~5 dependent HBM reads per level);
+// the wave then scans the feasible children in slot order.  Lane d ends up holding the packed node of depth d.
+__device__ bool n3_unrank_wave(const N3Dev &P, u128 rho, int depth, int lane, unsigned &st_out, u128 &rem) {
+    const int K1 = P.K + 1, sa = lane % K1, sb = lane / K1;
+    N3State par{0, 0, 0, 0, 0, 0};
+    st_out = 0u;
+    for (int d = 0; d < depth; d++) {
+        N3State nx{0, 0, 0, 0, 0, 0};
+        bool ok = lane < P.Q && (d == 0 ? n3_first_row_ab(P, sa, sb, lane, nx) : n3_edge_ab(P, par, sa, sb, lane, d, nx));
+        u128 v = 0;
+        if (ok) v = P.cnt[n3_cnt_index(P, d, nx.slot, nx.sw, nx.lo, nx.hi)];
+        unsigned v0 = (unsigned)v, v1 = (unsigned)(v >> 32), v2 = (unsigned)(v >> 64), v3 = (unsigned)(v >> 96);
+        unsigned long long mk = ballot64(ok);
+        int chosen = -1;
+        while (mk) {
+            int b = __builtin_ctzll(mk);
+            mk &= mk - 1;
+            u128 vb = ((u128)(unsigned)__builtin_amdgcn_readlane((int)v3, b) << 96) |
+                      ((u128)(unsigned)__builtin_amdgcn_readlane((int)v2, b) << 64) |
+                      ((u128)(unsigned)__builtin_amdgcn_readlane((int)v1, b) << 32) |
+                      (u128)(unsigned)__builtin_amdgcn_readlane((int)v0, b);
+            if (rho < vb) {
+                chosen = b;
+                break;
+            }
+            rho -= vb;
+        }
+        if (chosen < 0) return false;
+        unsigned mine = ok ? n3_pack(nx) : 0u;
+        unsigned packed = (unsigned)__builtin_amdgcn_readlane((int)mine, chosen);
+        par = n3_unpack(packed);
+        if (lane == d) st_out = packed;
+    }
+    rem = rho;
+    return true;
+}
+
+// one wave per task: where does the task start?
+__global__ __launch_bounds__(256) void n3_task_kernel(N3Dev P, uint64_t b_lo, uint64_t b_hi, uint64_t e_lo, uint64_t e_hi,
+                                                      uint64_t per_task, int ntasks, N3Task *tasks, unsigned *stbuf) {
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (t >= ntasks) return;
     const u128 begin = ((u128)b_hi << 64) | b_lo, end = ((u128)e_hi << 64) | e_lo;
     u128 base = begin + (u128)t * per_task;
     u128 left = end - base;
     uint64_t count = left < (u128)per_task ? (uint64_t)left : per_task;
-    int D = P.m - P.L;
-    N3State st[N3_MAX_M];
+    const int D = P.m - P.L;
+    unsigned st = 0;
     u128 rem = 0;
-    bool ok = n3_unrank(P, base, D, st, rem);
-    N3Task tk;
-    tk.base_lo = (uint64_t)base;
-    tk.base_hi = (uint64_t)(base >> 64);
-    tk.count = ok ? count : 0;
-    tk.skip = (uint64_t)rem;
-    tasks[t] = tk;
-    for (int d = 0; d < D; d++) stbuf[(size_t)t * N3_MAX_M + d] = n3_pack(st[d]);
+    bool ok = n3_unrank_wave(P, base, D, lane, st, rem);
+    if (lane == 0) {
+        N3Task tk;
+        tk.base_lo = (uint64_t)base;
+        tk.base_hi = (uint64_t)(base >> 64);
+        tk.count = ok ? count : 0;
+        tk.skip = (uint64_t)rem;
+        tasks[t] = tk;
+    }
+    if (lane < D) stbuf[(size_t)t * N3_MAX_M + lane] = st;
 }
 
-__global__ __launch_bounds__(64) void n3_unrank_list_kernel(N3Dev P, const TieRecord *recs, int count, unsigned char *out) {
-    int k = blockIdx.x * blockDim.x + threadIdx.x;
+// one wave per tie record: its matrix
+__global__ __launch_bounds__(256) void n3_unrank_list_kernel(N3Dev P, const TieRecord *recs, int count, unsigned char *out) {
+    const int k = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (k >= count) return;
-    N3State st[N3_MAX_M];
     u128 rho = ((u128)recs[k].rank_hi << 64) | recs[k].rank_lo, rem;
-    bool ok = n3_unrank(P, rho, P.m, st, rem);
-    unsigned char *dst = out + (size_t)k * P.m * 2;
-    int K1 = P.K + 1;
-    for (int i = 0; i < P.m; i++) {
-        dst[2 * i] = ok ? (unsigned char)(st[i].slot % K1) : 255;
-        dst[2 * i + 1] = ok ? (unsigned char)(st[i].slot / K1) : 255;
+    unsigned st = 0;
+    bool ok = n3_unrank_wave(P, rho, P.m, lane, st, rem);
+    if (lane < P.m) {
+        unsigned char *dst = out + (size_t)k * P.m * 2 + 2 * lane;
+        dst[0] = ok ? (unsigned char)((st >> 24) & 15u) : 255;
+        dst[1] = ok ? (unsigned char)(st >> 28) : 255;
     }
 }
 
@@ -874,7 +914,7 @@ int n3_run_dp(const N3Dev &P, u128 *cnt, unsigned *overflow_dev, unsigned long l
 
 void n3_launch_tasks(const N3Dev &P, u128 begin, u128 end, uint64_t per_task, int ntasks, N3Task *tasks,
                      unsigned *stbuf, hipStream_t st) {
-    hipLaunchKernelGGL(n3_task_kernel, dim3((ntasks + 63) / 64), dim3(64), 0, st, P, (uint64_t)begin, (uint64_t)(begin >> 64),
+    hipLaunchKernelGGL(n3_task_kernel, dim3((ntasks + 3) / 4), dim3(256), 0, st, P, (uint64_t)begin, (uint64_t)(begin >> 64),
                        (uint64_t)end, (uint64_t)(end >> 64), per_task, ntasks, tasks, stbuf);
 }
 
@@ -892,7 +932,7 @@ void n3_launch_search(const N3Dev &P, const SearchArgs &A, const N3Task *tasks, 
 }
 
 void n3_launch_unrank_list(const N3Dev &P, const TieRecord *recs, int count, unsigned char *out, hipStream_t st) {
-    hipLaunchKernelGGL(n3_unrank_list_kernel, dim3((count + 63) / 64), dim3(64), 0, st, P, recs, count, out);
+    hipLaunchKernelGGL(n3_unrank_list_kernel, dim3((count + 3) / 4), dim3(256), 0, st, P, recs, count, out);
 }
 
 void n3_launch_enumerate(const N3Dev &P, u128 begin, unsigned long long count, unsigned char *out, hipStream_t st) {
