@@ -80,3 +80,31 @@ def test_cli_default_pipeline_n2_then_n3_then_model_selection(tmp_path):
     assert abs(again - nll) <= 1e-9 * abs(nll)
     best = _parse_results(tmp_path / "s.BEST.results")
     assert best[0][0] in (res3[0][0], _parse_results(tmp_path / "s.n2.results")[0][0])
+
+
+def test_calc_all_c_variants_match_reference_vectors():
+    """calc_all_c_2 / _3 / _3_multi_event (CalcAllC.py:92-328) on the reference's own inputs and outputs."""
+    import json
+    import math
+    from theta_amd import CalcAllC
+    cases = json.load(open(os.path.join(GOLD, "calc_all_c.json")))["cases"]
+    seen = set()
+    for c in cases:
+        n = c["n"]
+        mu = tuple(c["mu"]) if n == 2 else np.array(c["mu"])
+        for name, ref in c["out"].items():
+            fn = getattr(CalcAllC, name)
+            best = [(np.array(c["c"]), mu, 0.0, [])]
+            (c_all, mu_o, nll, vals), = fn(best, list(c["r"]), list(c["rN"]), list(c["all_tumor"]), list(c["all_normal"]),
+                                          list(c["used"]))[0]
+            seen.add(name)
+            assert np.array_equal(np.asarray(c_all), np.array(ref["c_all"])), name      # chosen copy numbers: bit-exact
+            if ref["nll"] == "nan":
+                assert math.isnan(nll)                                                  # zero-normal interval, quirk Q10
+            else:
+                assert abs(nll - ref["nll"]) <= 1e-9 * abs(ref["nll"])
+                for a, b in zip(vals, ref["vals"]):
+                    assert (a == "X") == (b == "X")
+                    if a != "X":
+                        assert abs(a - b) <= 1e-9 * abs(b)
+    assert seen == {"calc_all_c_2", "calc_all_c_3", "calc_all_c_3_multi_event"}
