@@ -107,6 +107,22 @@ int theta_search(theta_problem *p, const uint64_t rank_begin[2], const uint64_t 
                  int *n_out, theta_search_stats *stats);
 
 /*
+ * "Suspects" of the last theta_search call on this problem (n=3): candidates the search REJECTED (likelihood
+ * optimum outside the simplex, where Optimizer._solve_n3plus returns None unless its root finder stalls inside
+ * [0,1]^3, Optimizer.py:150-160) whose lower bound lies within `window` of the minimum.  rank[cap*2],
+ * lbound[cap] (unconstrained minimum of the NLL), C[cap*m*(n-1)].  Feed C to theta_boundary_min to certify that
+ * none of them can reach the winner.  n_out = number available.
+ */
+int theta_search_suspects(theta_problem *p, int cap, uint64_t *rank, double *lbound, uint8_t *C, int *n_out);
+
+/*
+ * Exact minimum of the n=3 NLL over the BOUNDARY of the simplex (some nu_j = 0) for B materialised candidates:
+ * the smallest value the reference could report for a candidate whose optimum lies outside the simplex.
+ */
+int theta_boundary_min(theta_ctx *ctx, int m, int tau, const int64_t *r, const int64_t *rN, int B, const uint8_t *C,
+                       double *bound);
+
+/*
  * Per-candidate dump of the fused kernel over ranks rank_begin .. rank_begin+count-1: the
  * reference's --GET_VALUES developer aid (RunTHetA.py:210-215, FileIO.py:114).  nll[count]
  * (NaN where Optimizer.solve would return None), mu[count*n].  Diagnostic / parity entry point.

@@ -457,3 +457,49 @@ def test_config3_shape_rank_ranges_and_tight_bounds_parity(ctx):
         # consecutive enumerated matrices are in strictly increasing DFS order: re-ranking by search ranks
         assert np.array_equal(p.enumerate(start + 123, 1)[0], C[123])
     p.close()
+
+
+# ---------------------------------------------------------------------------------------------------
+# n = 3: the certificate for rejected candidates
+# ---------------------------------------------------------------------------------------------------
+def test_boundary_minimum_kernel_against_brute_force(ctx):
+    rng = np.random.RandomState(17)
+    m = 9
+    r = rng.randint(2000, 90000, m)
+    rN = rng.randint(2000, 90000, m)
+    C = rng.randint(0, 5, (40, m, 2)).astype(np.uint8)
+    C[0, :, 0] = 0                                               # an all-zero column: only one face is usable
+    got = ctx.boundary_min(2, r, rN, C)
+    t = np.linspace(0.0, 1.0, 20001)[:, None]
+    for b in range(len(C)):
+        cols = np.stack([2.0 * rN, C[b, :, 0] * rN, C[b, :, 1] * rN], 1).astype(float)
+        best = np.inf
+        for ja, jb in ((0, 1), (0, 2), (1, 2)):
+            if cols[:, ja].sum() == 0 or cols[:, jb].sum() == 0:
+                continue
+            a, bb = cols[:, ja] / cols[:, ja].sum(), cols[:, jb] / cols[:, jb].sum()
+            with np.errstate(all="ignore"):
+                f = -(r * np.log(a * t + bb * (1 - t))).sum(1)
+            best = min(best, np.nanmin(f))
+        assert got[b] <= best * (1 + 1e-12)                          # the kernel's minimum is at least as low as the grid's
+        assert abs(got[b] - best) <= 1e-6 * abs(best)
+
+
+def test_rejected_candidates_are_certified_harmless(ctx):
+    """An instance where a REJECTED matrix has an unconstrained optimum below the winner: its exact minimum over
+    the simplex boundary is far above the winner, so nothing the reference's solver could report for it matters."""
+    from theta_amd.search import do_optimization_single
+    import theta_amd.search as S
+    r, rN, L, Ct, mu = orc.synth_counts(10, 3, 3, 1)
+    rs, rNs, order = orc.sort_r(rN, r)
+    best = do_optimization_single(3, 10, 3, 2, [0] * 10, [3] * 10, rs, rNs, 1.0, order)
+    rep = S.last_report
+    assert rep.candidates == orc.count_n3_exact(10, 2, [0] * 10, [3] * 10) == 2695553
+    assert rep.suspects >= 1
+    assert rep.stats["rejected_bound"] < best[0][2]                  # unconstrained optimum of a rejected matrix is lower ...
+    assert rep.suspect_bound > best[0][2] + 100.0                    # ... but on the simplex it cannot come near the winner
+    assert not rep.parity_uncertain
+    # the winner itself, checked by the oracle's port of Optimizer.solve
+    Cw = best[0][0][order]
+    s = orc.solve_n3(Cw, rs, rNs)
+    assert s is not None and abs(s[1] - best[0][2]) <= 1e-9 * abs(s[1]) and np.abs(np.array(s[0]) - best[0][1]).max() < 1e-6

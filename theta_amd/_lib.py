@@ -44,7 +44,7 @@ _lib = None
 # every symbol include/theta_hip.h declares
 EXPORTS = ["theta_create", "theta_destroy", "theta_last_error", "theta_device_info", "theta_problem_create",
            "theta_problem_destroy", "theta_problem_count", "theta_search", "theta_search_values", "theta_enumerate",
-           "theta_solve_batch", "theta_score_batch", "theta_score_masked"]
+           "theta_solve_batch", "theta_score_batch", "theta_score_masked", "theta_search_suspects", "theta_boundary_min"]
 
 
 def load():
@@ -70,6 +70,8 @@ def load():
     lib.theta_search.argtypes = [vp, u64p, u64p, C.c_double, i32, dp, dp, u64p, u8p, C.POINTER(i32), C.POINTER(SearchStats)]
     lib.theta_search_values.argtypes = [vp, u64p, C.c_uint64, dp, dp, C.POINTER(SearchStats)]
     lib.theta_enumerate.argtypes = [vp, u64p, C.c_uint64, u8p]
+    lib.theta_search_suspects.argtypes = [vp, i32, u64p, dp, u8p, C.POINTER(i32)]
+    lib.theta_boundary_min.argtypes = [vp, i32, i32, i64p, i64p, i32, u8p, dp]
     lib.theta_solve_batch.argtypes = [vp, i32, i32, i32, i64p, i64p, C.c_double, i32, u8p, u8p, dp, dp, dp]
     lib.theta_score_batch.argtypes = [vp, i32, i32, i32, dp, dp, dp, dp, dp, u8p]
     lib.theta_score_masked.argtypes = [vp, i32, i32, i32, i32, i32, u8p, dp, dp, dp, u64p, dp, dp]
@@ -137,6 +139,17 @@ class Context:
                                         _p(vals, C.c_double) if want_vals else None))
         return ok.astype(bool), mu, nll, vals
 
+    def boundary_min(self, tau, r, rN, C_u8):
+        """n=3: exact minimum of the NLL over the simplex boundary for each candidate C_u8 (B, m, 2)."""
+        C_u8 = np.ascontiguousarray(C_u8, dtype=np.uint8)
+        B, m = C_u8.shape[0], C_u8.shape[1]
+        r = np.ascontiguousarray(r, dtype=np.int64)
+        rN = np.ascontiguousarray(rN, dtype=np.int64)
+        out = np.zeros(B)
+        _check(load().theta_boundary_min(self._h, m, int(tau), _p(r, C.c_int64), _p(rN, C.c_int64), B,
+                                         _p(C_u8, C.c_uint8), _p(out, C.c_double)))
+        return out
+
     def score_batch(self, n, Cw, mu, r):
         """CalcAllC.L2/L3 on B literal matrices Cw (B, m, n); mu (B, n); returns nll, vals, valid."""
         Cw = np.ascontiguousarray(Cw, dtype=np.float64)
@@ -199,6 +212,7 @@ class Problem:
         cnt = (C.c_uint64 * 2)()
         _check(load().theta_problem_count(h, cnt))
         self.count = int(cnt[0]) | (int(cnt[1]) << 64)
+        self.last_suspects = ([], np.zeros(0), None)
 
     def close(self):
         if getattr(self, "_h", None):
@@ -226,8 +240,17 @@ class Problem:
         end = self.count if end is None else end
         step = self.MAX_PER_CALL[self.n]
         if end - begin <= step:
-            return self._search_once(begin, end, window, cap)
-        parts = [self._search_once(b, min(b + step, end), window, cap) for b in range(begin, end, step)]
+            res = self._search_once(begin, end, window, cap)
+            self.last_suspects = self.suspects() if self.n == 3 else ([], np.zeros(0), None)
+            return res
+        parts, sus = [], ([], [], [])
+        for b in range(begin, end, step):
+            parts.append(self._search_once(b, min(b + step, end), window, cap))
+            if self.n == 3:
+                rk, lb, Cs = self.suspects()
+                sus[0].extend(rk)
+                sus[1].extend(lb.tolist())
+                sus[2].extend(list(Cs))
         stats = dict(parts[0]["stats"])
         for p in parts[1:]:
             for k, v in p["stats"].items():
@@ -242,6 +265,10 @@ class Problem:
                 elif k == "rejected_bound" and v < stats[k]:
                     stats[k], stats["rejected_rank"] = v, p["stats"]["rejected_rank"]
         nll = np.concatenate([p["nll"] for p in parts])
+        gmin = nll.min() if len(nll) else float("inf")
+        ks = [i for i, v in enumerate(sus[1]) if v <= gmin + window]
+        self.last_suspects = ([sus[0][i] for i in ks], np.array([sus[1][i] for i in ks]),
+                              np.array([sus[2][i] for i in ks], dtype=np.uint8).reshape(len(ks), self.m, 2) if self.n == 3 else None)
         keep = nll <= (nll.min() if len(nll) else 0.0) + window
         mu = np.concatenate([p["mu"] for p in parts])[keep]
         Cc = np.concatenate([p["C"] for p in parts])[keep]
@@ -269,6 +296,20 @@ class Problem:
         ranks = [int(rank[i, 0]) | (int(rank[i, 1]) << 64) for i in range(k)]
         return {"nll": nll[:k].copy(), "mu": mu[:k].copy(), "rank": ranks,
                 "C": self._shape_C(Cb[:k * self.m * (self.n - 1)], k).copy(), "stats": st.as_dict()}
+
+    def suspects(self):
+        """Rejected candidates of the last search whose lower bound lies within the window: (ranks, lbound, C)."""
+        n_out = C.c_int()
+        rc = load().theta_search_suspects(self._h, 0, None, None, None, C.byref(n_out))
+        k = n_out.value
+        if k == 0:
+            return [], np.zeros(0), self._shape_C(np.zeros(0, np.uint8), 0)
+        rank = np.zeros((k, 2), np.uint64)
+        lb = np.zeros(k)
+        Cb = np.zeros(k * self.m * (self.n - 1), np.uint8)
+        _check(load().theta_search_suspects(self._h, k, _p(rank, C.c_uint64), _p(lb, C.c_double), _p(Cb, C.c_uint8),
+                                            C.byref(n_out)))
+        return [int(rank[i, 0]) | (int(rank[i, 1]) << 64) for i in range(k)], lb, self._shape_C(Cb, k)
 
     def values(self, begin, count):
         """Per-candidate (nll, mu) of the fused kernel (NaN = None): the --GET_VALUES dump."""

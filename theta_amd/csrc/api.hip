@@ -31,6 +31,8 @@ void batch_launch_solve(int n, int m, int tau, const double *r, const double *rN
                         hipStream_t st);
 void batch_launch_score(int n, int m, int B, const double *Cw, const double *mu, const double *r, double *nll,
                         double *vals, unsigned char *valid, hipStream_t st);
+void batch_launch_boundary_min(int m, int tau, const double *r, const double *rN, int B, const unsigned char *C,
+                               double *bound, hipStream_t st);
 void batch_launch_score_masked(int n, int m, int tau, int B, int S, const unsigned char *C, const double *w,
                                const double *r, const double *mu, const unsigned long long *mask, double *nll,
                                double *rsum_scratch, hipStream_t st);
@@ -113,6 +115,7 @@ struct theta_problem {
     N3Host n3h;
     N3Dev n3{};
     uint64_t total[2] = {0, 0};
+    std::vector<TieRecord> suspects;   // rejected candidates near the minimum, from the last theta_search
     DevBuf d_r, d_rN, d_small, d_P, d_PR, d_PN, d_cnt, d_ctr, d_list, d_tasks, d_stbuf, d_misc, d_smask, d_dynmask;
 };
 
@@ -481,11 +484,17 @@ extern "C" int theta_search(theta_problem *p, const uint64_t rank_begin[2], cons
     }
     // keep what lies within the window of the final minimum, in rank order
     std::vector<TieRecord> keep;
-    for (const TieRecord &t : recs)
-        if (t.nll <= best + window) keep.push_back(t);
-    std::sort(keep.begin(), keep.end(), [](const TieRecord &x, const TieRecord &y) {
+    p->suspects.clear();
+    for (const TieRecord &t : recs) {
+        if (!(t.nll <= best + window)) continue;
+        if (t.mu[0] != t.mu[0]) p->suspects.push_back(t);   // NaN marker: a rejected candidate (lower bound in .nll)
+        else keep.push_back(t);
+    }
+    auto by_rank = [](const TieRecord &x, const TieRecord &y) {
         return x.rank_hi != y.rank_hi ? x.rank_hi < y.rank_hi : x.rank_lo < y.rank_lo;
-    });
+    };
+    std::sort(p->suspects.begin(), p->suspects.end(), by_rank);
+    std::sort(keep.begin(), keep.end(), by_rank);
     *n_out = (int)keep.size();
     if ((int)keep.size() > cap) {
         theta_set_error("%zu candidates within the window but capacity is %d", keep.size(), cap);
@@ -561,6 +570,67 @@ extern "C" int theta_search_values(theta_problem *p, const uint64_t rank_begin[2
         stats->kernel_ms = kms;
         stats->setup_ms = sms;
     }
+    return THETA_OK;
+}
+
+extern "C" int theta_search_suspects(theta_problem *p, int cap, uint64_t *rank, double *lbound, uint8_t *C, int *n_out) {
+    if (!p || !n_out) {
+        theta_set_error("null argument");
+        return THETA_ERR_ARG;
+    }
+    const std::vector<TieRecord> &sv = p->suspects;
+    *n_out = (int)sv.size();
+    if (sv.empty()) return THETA_OK;
+    if ((int)sv.size() > cap || !rank || !lbound || !C) {
+        theta_set_error("%zu suspects but capacity is %d", sv.size(), cap);
+        return THETA_ERR_CAPACITY;
+    }
+    HIP_TRY(hipSetDevice(p->ctx->device));
+    hipStream_t st = p->ctx->stream;
+    size_t cb = (size_t)p->m * (p->n - 1);
+    DevBuf d_rec, d_C;
+    int rc;
+    if ((rc = d_rec.alloc(sv.size() * sizeof(TieRecord)))) return rc;
+    if ((rc = d_C.alloc(sv.size() * cb))) return rc;
+    HIP_TRY(hipMemcpyAsync(d_rec.p, sv.data(), sv.size() * sizeof(TieRecord), hipMemcpyHostToDevice, st));
+    if (p->n == 2) n2_launch_unrank_list(p->n2, (const TieRecord *)d_rec.p, (int)sv.size(), (unsigned char *)d_C.p, st);
+    else n3_launch_unrank_list(p->n3, (const TieRecord *)d_rec.p, (int)sv.size(), (unsigned char *)d_C.p, st);
+    HIP_TRY(hipMemcpyAsync(C, d_C.p, sv.size() * cb, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(hipGetLastError());
+    for (size_t i = 0; i < sv.size(); i++) {
+        rank[2 * i] = sv[i].rank_lo;
+        rank[2 * i + 1] = sv[i].rank_hi;
+        lbound[i] = sv[i].nll;
+    }
+    return THETA_OK;
+}
+
+extern "C" int theta_boundary_min(theta_ctx *ctx, int m, int tau, const int64_t *r, const int64_t *rN, int B,
+                                  const uint8_t *C, double *bound) {
+    if (!ctx || !r || !rN || !C || !bound || B < 0 || m < 1 || m > 4096) {
+        theta_set_error("theta_boundary_min: bad argument");
+        return THETA_ERR_ARG;
+    }
+    if (B == 0) return THETA_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    std::vector<double> rd(m), rnd(m);
+    for (int i = 0; i < m; i++) {
+        rd[i] = (double)r[i];
+        rnd[i] = (double)rN[i];
+    }
+    DevBuf d_r, d_rN, d_C, d_b;
+    int rc;
+    if ((rc = upload(d_r, rd.data(), m * sizeof(double), st))) return rc;
+    if ((rc = upload(d_rN, rnd.data(), m * sizeof(double), st))) return rc;
+    if ((rc = upload(d_C, C, (size_t)B * m * 2, st))) return rc;
+    if ((rc = d_b.alloc((size_t)B * sizeof(double)))) return rc;
+    batch_launch_boundary_min(m, tau, (const double *)d_r.p, (const double *)d_rN.p, B, (const unsigned char *)d_C.p,
+                              (double *)d_b.p, st);
+    HIP_TRY(hipMemcpyAsync(bound, d_b.p, (size_t)B * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(hipGetLastError());
     return THETA_OK;
 }
 

@@ -225,6 +225,81 @@ __global__ __launch_bounds__(64) void solve_batch_n3_kernel(int m, int tau, cons
 }
 
 // ------------------------------------------------------------------------------------------------
+// Smallest NLL a candidate can take anywhere on the BOUNDARY of the simplex (some nu_j = 0), per-interval
+// sums.  For a candidate whose optimum lies outside the simplex this is the lowest value the reference's solver
+// could ever report for it (its iterates stay inside [0,1]^3 or are rejected, Optimizer.py:150-160), so
+// "boundary minimum > winner + tie margin" certifies that the candidate cannot change the result.
+// Each face nu_j = 0 is a 1-D convex problem in t: p_i = Chat_ia t + Chat_ib (1 - t).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void boundary_min_n3_kernel(int m, int tau, const double *r, const double *rN, int B,
+                                                             const unsigned char *C, double *bound) {
+    extern __shared__ double sm[];
+    double *rr = sm, *rn = sm + m;
+    for (int i = threadIdx.x; i < m; i += blockDim.x) {
+        rr[i] = r[i];
+        rn[i] = rN[i];
+    }
+    __syncthreads();
+    int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const unsigned char *c = C + (size_t)b * m * 2;
+    double S[3] = {0.0, 0.0, 0.0};
+    for (int i = 0; i < m; i++) {
+        S[0] += rn[i] * (double)tau;
+        S[1] += rn[i] * (double)c[2 * i];
+        S[2] += rn[i] * (double)c[2 * i + 1];
+    }
+    auto col = [&](int j, int i) -> double {   // normalised column entry Chat_ij (Optimizer.py:167-174)
+        double cij = (j == 0) ? (double)tau : (double)c[2 * i + (j - 1)];
+        return (rn[i] * cij) / S[j];
+    };
+    double best = __builtin_inf();
+    for (int ja = 0; ja < 3; ja++)
+        for (int jb = ja + 1; jb < 3; jb++) {
+            if (S[ja] == 0.0 || S[jb] == 0.0) continue;   // an all-zero column cannot carry weight
+            auto fval = [&](double t, double &g, double &h) {
+                double f = 0.0;
+                g = 0.0;
+                h = 0.0;
+                for (int i = 0; i < m; i++) {
+                    double a = col(ja, i), bb = col(jb, i);
+                    double p = a * t + bb * (1.0 - t);
+                    double d = a - bb;
+                    f -= rr[i] * log(p);
+                    g -= rr[i] * d / p;
+                    h += rr[i] * d * d / (p * p);
+                }
+                return f;
+            };
+            // minimise over t in [0,1]: bisection on the sign of the derivative, then Newton polish
+            double lo = 0.0, hi = 1.0, g, h;
+            double f0 = fval(0.0, g, h);
+            double g0 = g;
+            double f1 = fval(1.0, g, h);
+            double g1 = g;
+            double fmin_face;
+            if (!(g0 < 0.0)) fmin_face = f0;                // increasing from t = 0 (or NaN/inf): vertex
+            else if (!(g1 > 0.0)) fmin_face = f1;
+            else {
+                double t = 0.5;
+                for (int it = 0; it < 200; it++) {
+                    fval(t, g, h);
+                    if (g > 0.0) hi = t; else lo = t;
+                    double tn = t - g / h;
+                    if (!(tn > lo && tn < hi)) tn = 0.5 * (lo + hi);
+                    if (fabs(tn - t) <= 1e-15) { t = tn; break; }
+                    t = tn;
+                }
+                fmin_face = fval(t, g, h);
+            }
+            if (fmin_face == fmin_face && fmin_face < best) best = fmin_face;
+            if (f0 == f0 && f0 < best) best = f0;
+            if (f1 == f1 && f1 < best) best = f1;
+        }
+    bound[b] = best;
+}
+
+// ------------------------------------------------------------------------------------------------
 // CalcAllC.L2 / L3 on literal float matrices: one wave per matrix, lanes over rows.
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ double wave_sum_f64(double v) {
@@ -444,6 +519,12 @@ void batch_launch_solve(int n, int m, int tau, const double *r, const double *rN
     else
         hipLaunchKernelGGL(solve_batch_n3_kernel, dim3(blocks), dim3(64), (size_t)m * 2 * sizeof(double), st, m, tau, r, rN,
                            B, C, ok, mu, nll, vals);
+}
+
+void batch_launch_boundary_min(int m, int tau, const double *r, const double *rN, int B, const unsigned char *C,
+                               double *bound, hipStream_t st) {
+    hipLaunchKernelGGL(boundary_min_n3_kernel, dim3((B + 63) / 64), dim3(64), (size_t)m * 2 * sizeof(double), st, m, tau, r, rN, B,
+                       C, bound);
 }
 
 void batch_launch_score(int n, int m, int B, const double *Cw, const double *mu, const double *r, double *nll,

@@ -753,7 +753,9 @@ __global__ __launch_bounds__(64 * N3_WAVES, 3) void n3_search_kernel(N3Dev Pg, S
                         double e1 = e0 - g1 * rcp_nr2(s1), e2 = e0 - g2 * rcp_nr2(s2);    // vertices (1/s1, 0), (0, 1/s2)
                         fw = fmin(e0, fmin(e1, e2));
                     }
-                    bool contender = solved && (DUMP || (nll + fw - screen_margin <= (accept ? best + A.window : rej_best)));
+                    // rejected candidates are contenders when their lower bound comes within the window of the running
+                    // minimum (they become "suspects", see below) or below the smallest bound seen so far
+                    bool contender = solved && (DUMP || (nll + fw - screen_margin <= (accept ? best + A.window : fmax(rej_best, best + A.window))));
                     if (contender) {
                         double acc = 0.0;
                         terms([&](double x, double y, double R) {
@@ -799,6 +801,11 @@ __global__ __launch_bounds__(64 * N3_WAVES, 3) void n3_search_kernel(N3Dev Pg, S
                         ws1 = P.warm_blend * b1 + (1.0 - P.warm_blend) / 3.0;
                         ws2 = P.warm_blend * b2 + (1.0 - P.warm_blend) / 3.0;
                     }
+                    // Suspects: rejected candidates whose lower bound is within the window of the minimum.  The reference
+                    // could in principle report a stalled iterate for them; the host computes their exact simplex-
+                    // boundary minimum (theta_boundary_min) to certify that none can reach the winner.  Marked by mu0 = NaN.
+                    if (solved && !accept && contender && !DUMP && lbnd <= best + A.window)
+                        tie_append(A.ctr, A.list, A.list_cap, base + rel, lbnd, __builtin_nan(""), 0.0, 0.0);
                     if (solved && !accept && contender && lbnd < rej_best) {
                         unsigned long long old = atomicMin(&A.ctr->rej_bits, order_bits(lbnd));
                         if (old > order_bits(lbnd)) {  // we hold the minimum (racy pair, diagnostic only)

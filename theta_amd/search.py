@@ -87,6 +87,8 @@ class SearchReport(object):
         self.finalists = 0
         self.tie_ambiguous = False
         self.parity_uncertain = False
+        self.suspects = 0              # rejected candidates whose unconstrained optimum is within the window
+        self.suspect_bound = float("inf")  # smallest NLL any of them can take on the simplex boundary
         self.seconds = 0.0
 
 
@@ -236,8 +238,16 @@ def do_optimization_single(n, m, k, tau, lower_bounds, upper_bounds, r, rN, max_
     rep.stats = stats
     rep.candidates = problem.count
     rep.finalists = len(recs)
-    if best and stats["rejected_bound"] < best[0][2] + TIE_MARGIN:
-        rep.parity_uncertain = True
+    # n=3: candidates rejected because their optimum lies outside the simplex.  The reference returns None
+    # for them unless its root finder stalls inside [0,1]^3; whatever it could report is at least their minimum
+    # over the simplex boundary, computed exactly on the GPU.  Above the winner => they cannot change `best`.
+    if n == 3 and best:
+        ranks, lbound, Cs = problem.last_suspects
+        rep.suspects = len(ranks)
+        if len(ranks):
+            bmin = ctx.boundary_min(tau, [int(x) for x in r], [int(x) for x in rN], Cs)
+            rep.suspect_bound = float(bmin.min())
+            rep.parity_uncertain = bool(rep.suspect_bound < best[0][2] + TIE_MARGIN)
     rep.seconds = time.time() - t0
     last_report = rep
     return best
