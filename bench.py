@@ -218,7 +218,9 @@ def main():
                                    "(BASELINE config 4 shape)", "m": M, "n": N_POP, "k": K_MAX,
                        "candidates_per_step_per_gpu": args.batch, "total_candidates_in_space": float(total),
                        "parallelism": "rank-range sharding x%d, one RCCL exchange of finalists" % world},
-            "roofline": {"bound": "fp64-valu", "achieved": ach, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "roofline": {"bound": "mfma", "bound_detail": "compute bound on the FP64 vector ALUs (this kernel issues no MFMA; on MI355X the "
+                                          "FP64 vector peak equals the FP64 matrix peak, 78.6 TFLOP/s) -- not HBM bound by design",
+                         "achieved": ach, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach / FP64_VECTOR_PEAK_TFLOPS, "traffic": traffic,
                          "kernel": "n3_search_kernel<5,false>", "kernel_ms_per_launch": k_ms / launches,
                          "flop_per_candidate": allv[0, 2] / max(allv[0, 0], 1.0),

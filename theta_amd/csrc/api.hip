@@ -272,7 +272,7 @@ extern "C" int theta_problem_create(theta_ctx *ctx, int n, int m, int tau, const
         if (L > m - 1) L = m - 1;
         D.L = L;
         D.warm_blend = 0.9;
-        D.conv_l2 = 1e-8;    // lambda < 1e-4 before the last step => ~1e-8 after it
+        D.conv_l2 = 1e-4;    // first-pass threshold on the squared decrement before the last step (contenders are polished)
         if (const char *e = getenv("THETA_N3_WARM_BLEND")) D.warm_blend = atof(e);
         if (const char *e = getenv("THETA_N3_CONV_L2")) D.conv_l2 = atof(e);
         D.N = (double)N;

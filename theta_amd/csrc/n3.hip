@@ -406,6 +406,10 @@ __global__ __launch_bounds__(64 * N3_WAVES, 3) void n3_search_kernel(N3Dev Pg, S
     // screening margin for the single-precision NLL: |error| <= Rtot * (|ln q| * 2^-23 + 2^-22) stays far below this
     const double screen_margin = 2e-5 * P.Rtot + 1.0;
     const double inv_N = 1.0 / P.N, inv_Rtot = 1.0 / P.Rtot;
+    // First pass: stop once the squared Newton decrement BEFORE the last step is below conv_l2 (1e-4): by
+    // self-concordance the step then leaves lambda^2 <= ~1e-8, i.e. an NLL error <= ~1e-8 sum(r)/2 -- far inside the
+    // screening margin.  Only contenders are polished to 1e-12 (below); the --GET_VALUES dump polishes everything.
+    const double conv_main = DUMP ? 1e-12 : P.conv_l2;
 
     unsigned long long n_eval = 0, n_acc = 0, n_deg = 0, n_it = 0, n_terms = 0, n_fin = 0;
     double best = order_unbits(load_agent_u64(&A.ctr->best_bits));
@@ -665,7 +669,7 @@ __global__ __launch_bounds__(64 * N3_WAVES, 3) void n3_search_kernel(N3Dev Pg, S
                         continue;   // only degenerate leaves were taken this round
                     }
                     if (have) {
-                        n3_newton_step(terms, s1, s2, inv_Rtot, Sv, P.conv_l2);
+                        n3_newton_step(terms, s1, s2, inv_Rtot, Sv, conv_main);
                         if (Sv.status != 0) {
                             unsigned sing = Sv.singular ? RES_SINGULAR : 0u;
                             bool conv = Sv.status == 1;
@@ -757,6 +761,37 @@ __global__ __launch_bounds__(64 * N3_WAVES, 3) void n3_search_kernel(N3Dev Pg, S
                     // minimum (they become "suspects", see below) or below the smallest bound seen so far
                     bool contender = solved && (DUMP || (nll + fw - screen_margin <= (accept ? best + A.window : fmax(rej_best, best + A.window))));
                     if (contender) {
+                        if (!DUMP && conv) {   // polish the coarse optimum, then decide admissibility again
+                            N3Newton T;
+                            T.u1 = T.p1 = u1;
+                            T.u2 = T.p2 = u2;
+                            T.iters = 0;
+                            T.status = 0;
+                            T.singular = false;
+                            while (T.status == 0 && T.iters < 12) n3_newton_step(terms, s1, s2, inv_Rtot, T, 1e-12);
+                            if (T.status == 1) {
+                                u1 = T.u1;
+                                u2 = T.u2;
+                                double n1 = s1 * u1, n2 = s2 * u2, n0 = 1.0 - n1 - n2;
+                                accept = (n0 >= 0.0 && n0 <= 1.0 && n1 >= 0.0 && n1 <= 1.0 && n2 >= 0.0 && n2 <= 1.0);
+                                if (!accept && T.singular) {
+                                    N3Hess T2;
+                                    T2.u1 = u1; T2.u2 = u2;
+                                    T2.h11 = T2.h12 = T2.h22 = 0.0;
+                                    terms([&](double x, double y, double R) {
+                                        double a = x - s1, b = y - s2;
+                                        double q = __builtin_fma(a, u1, __builtin_fma(b, u2, 1.0));
+                                        double tw = R / (q * q);
+                                        T2.h11 = __builtin_fma(tw * a, a, T2.h11);
+                                        T2.h12 = __builtin_fma(tw * a, b, T2.h12);
+                                        T2.h22 = __builtin_fma(tw * b, b, T2.h22);
+                                    });
+                                    accept = n3_admissible(T2, s1, s2);
+                                    u1 = T2.u1;
+                                    u2 = T2.u2;
+                                }
+                            }
+                        }
                         double acc = 0.0;
                         terms([&](double x, double y, double R) {
                             double q = __builtin_fma(x - s1, u1, __builtin_fma(y - s2, u2, 1.0));
