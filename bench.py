@@ -145,9 +145,18 @@ def main():
     nsteps = args.warmup + args.steps
     stride = (shard1 - shard0 - args.batch) // max(nsteps, 1)
 
+    running = [float("inf")]
+
     def step(i):
+        # one chunk of the rank-range job; like Problem.search's own chunking, a chunk starts from the minimum the job has
+        # found so far (theta_problem_hint) -- that is what keeps tie / suspect lists short in ranges whose own minimum is poor
         b = shard0 + i * stride
-        return problem.search(b, b + args.batch, window=COLLECT_WINDOW)
+        if running[0] < float("inf"):
+            problem.hint(running[0])
+        res = problem.search(b, b + args.batch, window=COLLECT_WINDOW)
+        if len(res["nll"]):
+            running[0] = min(running[0], float(res["nll"].min()))
+        return res
 
     for i in range(args.warmup):
         step(i)

@@ -111,9 +111,17 @@ int theta_search(theta_problem *p, const uint64_t rank_begin[2], const uint64_t 
  * optimum outside the simplex, where Optimizer._solve_n3plus returns None unless its root finder stalls inside
  * [0,1]^3, Optimizer.py:150-160) whose lower bound lies within `window` of the minimum.  rank[cap*2],
  * lbound[cap] (unconstrained minimum of the NLL), C[cap*m*(n-1)].  Feed C to theta_boundary_min to certify that
- * none of them can reach the winner.  n_out = number available.
+ * none of them can reach the winner.  n_out = number available; the device list holds 65 536, call with cap = -1
+ * to learn how many more were dropped (a range whose own minimum is poor can have millions: pass a hint, below).
  */
 int theta_search_suspects(theta_problem *p, int cap, uint64_t *rank, double *lbound, uint8_t *C, int *n_out);
+
+/*
+ * One-shot hint for the next theta_search on this problem: an NLL some candidate is already known to reach (e.g. the
+ * minimum of a previously searched rank range or shard).  Starting the running minimum there keeps the tie list and
+ * the suspect list short; it never changes the result as long as the hint is attainable.
+ */
+int theta_problem_hint(theta_problem *p, double nll_upper_bound);
 
 /*
  * Exact minimum of the n=3 NLL over the BOUNDARY of the simplex (some nu_j = 0) for B materialised candidates:

@@ -486,20 +486,49 @@ def test_boundary_minimum_kernel_against_brute_force(ctx):
 
 
 def test_rejected_candidates_are_certified_harmless(ctx):
-    """An instance where a REJECTED matrix has an unconstrained optimum below the winner: its exact minimum over
-    the simplex boundary is far above the winner, so nothing the reference's solver could report for it matters."""
+    """An instance where a REJECTED matrix has an unconstrained optimum 5.1 BELOW the winner.  The kernel's
+    self-concordance bound (distance of that optimum from the simplex in the Hessian norm) already shows that on the
+    simplex the matrix stays > 200 above the winner; the exact boundary minimum (theta_boundary_min) is 253 above."""
     from theta_amd.search import do_optimization_single
+    import theta_amd
     import theta_amd.search as S
     r, rN, L, Ct, mu = orc.synth_counts(10, 3, 3, 1)
     rs, rNs, order = orc.sort_r(rN, r)
     best = do_optimization_single(3, 10, 3, 2, [0] * 10, [3] * 10, rs, rNs, 1.0, order)
     rep = S.last_report
     assert rep.candidates == orc.count_n3_exact(10, 2, [0] * 10, [3] * 10) == 2695553
-    assert rep.suspects >= 1
-    assert rep.stats["rejected_bound"] < best[0][2]                  # unconstrained optimum of a rejected matrix is lower ...
-    assert rep.suspect_bound > best[0][2] + 100.0                    # ... but on the simplex it cannot come near the winner
-    assert not rep.parity_uncertain
+    assert not rep.parity_uncertain and rep.certificate_complete
+    assert rep.stats["rejected_bound"] > best[0][2] + 100.0          # lower bound of every rejected matrix, on the simplex
+    # the matrix in question, found through the per-candidate dump: rejected, unconstrained optimum below the winner
+    p = theta_amd.Problem(ctx, 3, 10, 2, rs, rNs, [0] * 10, [3] * 10)
+    nll, mu_d, st = p.values(0, p.count)
+    Cs = p.enumerate(0, p.count)
+    rej = np.isnan(nll)
+    bmin = ctx.boundary_min(2, rs, rNs, Cs[rej][:200000])
+    assert bmin.min() > best[0][2] + 100.0                           # exact: no rejected matrix comes near on the boundary
+    assert rep.stats["rejected_bound"] <= bmin.min() + 1e-6          # and the kernel's bound really is a lower bound
     # the winner itself, checked by the oracle's port of Optimizer.solve
     Cw = best[0][0][order]
-    s = orc.solve_n3(Cw, rs, rNs)
-    assert s is not None and abs(s[1] - best[0][2]) <= 1e-9 * abs(s[1]) and np.abs(np.array(s[0]) - best[0][1]).max() < 1e-6
+    s_ = orc.solve_n3(Cw, rs, rNs)
+    assert s_ is not None and abs(s_[1] - best[0][2]) <= 1e-9 * abs(s_[1]) and np.abs(np.array(s_[0]) - best[0][1]).max() < 1e-6
+
+
+def test_suspects_and_hint_on_a_poor_rank_range(ctx):
+    """A rank range whose own minimum is poor has many rejected matrices below it (suspects); a hint of the
+    known global minimum removes them, and never changes the finalists."""
+    import theta_amd
+    r, rN, L, Ct, mu = orc.synth_counts(10, 3, 3, 1)
+    rs, rNs, order = orc.sort_r(rN, r)
+    p = theta_amd.Problem(ctx, 3, 10, 2, rs, rNs, [0] * 10, [3] * 10)
+    whole = p.search(0, p.count, window=0.5)
+    gmin = whole["nll"].min()
+    tail = p.search(p.count - 200000, p.count, window=0.5)           # the end of the enumeration: mostly exterior optima
+    n_sus = len(p.last_suspects[0]) + p.suspects_dropped
+    p.hint(gmin)
+    tail2 = p.search(p.count - 200000, p.count, window=0.5)
+    n_sus2 = len(p.last_suspects[0]) + p.suspects_dropped
+    assert n_sus2 <= n_sus
+    assert all(v <= gmin + 0.5 for v in tail2["nll"])                # with the hint only globally competitive records come back
+    if len(p.last_suspects[0]):
+        b = ctx.boundary_min(2, rs, rNs, p.last_suspects[2])
+        assert (b >= p.last_suspects[1] - 1e-6).all()                # suspects' bounds are lower bounds of the exact value

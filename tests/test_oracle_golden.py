@@ -74,7 +74,8 @@ def test_enumeration_order_matches_reference():
             assert orc.count_n3_upper(case["m"], case["lb"], case["ub"], case["tau"]) == case["count_ref_upper"]
         if case["n"] == 3:
             assert orc.count_n3_exact(case["m"], case["tau"], case["lb"], case["ub"]) == case["count"]
-            assert [list(x) for x in orc.row_graph(max(orc.check_bound_order(case["lb"], case["ub"])[1]), 2)[0]] == case["rows"]
+            if "rows" in case:
+                assert [list(x) for x in orc.row_graph(max(orc.check_bound_order(case["lb"], case["ub"])[1]), 2)[0]] == case["rows"]
 
 
 def _check_table(n, case, limit=None):

@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtheta_hip.so")
+LIB_PATH = os.environ.get("THETA_HIP_LIB") or os.path.join(_HERE, "libtheta_hip.so")   # THETA_HIP_LIB: A/B builds
 
 THETA_OK, ERR_ARG, ERR_NO_CANDIDATES, ERR_HIP, ERR_OVERFLOW, ERR_CAPACITY = range(6)
 
@@ -44,7 +44,7 @@ _lib = None
 # every symbol include/theta_hip.h declares
 EXPORTS = ["theta_create", "theta_destroy", "theta_last_error", "theta_device_info", "theta_problem_create",
            "theta_problem_destroy", "theta_problem_count", "theta_search", "theta_search_values", "theta_enumerate",
-           "theta_solve_batch", "theta_score_batch", "theta_score_masked", "theta_search_suspects", "theta_boundary_min"]
+           "theta_solve_batch", "theta_score_batch", "theta_score_masked", "theta_search_suspects", "theta_boundary_min", "theta_problem_hint"]
 
 
 def load():
@@ -72,6 +72,7 @@ def load():
     lib.theta_enumerate.argtypes = [vp, u64p, C.c_uint64, u8p]
     lib.theta_search_suspects.argtypes = [vp, i32, u64p, dp, u8p, C.POINTER(i32)]
     lib.theta_boundary_min.argtypes = [vp, i32, i32, i64p, i64p, i32, u8p, dp]
+    lib.theta_problem_hint.argtypes = [vp, C.c_double]
     lib.theta_solve_batch.argtypes = [vp, i32, i32, i32, i64p, i64p, C.c_double, i32, u8p, u8p, dp, dp, dp]
     lib.theta_score_batch.argtypes = [vp, i32, i32, i32, dp, dp, dp, dp, dp, u8p]
     lib.theta_score_masked.argtypes = [vp, i32, i32, i32, i32, i32, u8p, dp, dp, dp, u64p, dp, dp]
@@ -213,6 +214,7 @@ class Problem:
         _check(load().theta_problem_count(h, cnt))
         self.count = int(cnt[0]) | (int(cnt[1]) << 64)
         self.last_suspects = ([], np.zeros(0), None)
+        self.suspects_dropped = 0
 
     def close(self):
         if getattr(self, "_h", None):
@@ -244,8 +246,13 @@ class Problem:
             self.last_suspects = self.suspects() if self.n == 3 else ([], np.zeros(0), None)
             return res
         parts, sus = [], ([], [], [])
+        running = float("inf")
         for b in range(begin, end, step):
+            if running < float("inf"):
+                self.hint(running)               # later pieces start from the minimum found so far
             parts.append(self._search_once(b, min(b + step, end), window, cap))
+            if len(parts[-1]["nll"]):
+                running = min(running, float(parts[-1]["nll"].min()))
             if self.n == 3:
                 rk, lb, Cs = self.suspects()
                 sus[0].extend(rk)
@@ -276,6 +283,10 @@ class Problem:
         ranks = [r for r, k in zip(ranks, keep) if k]
         return {"nll": nll[keep], "mu": mu, "rank": ranks, "C": Cc, "stats": stats}
 
+    def hint(self, nll_upper_bound):
+        """One-shot: an NLL already known to be attainable (keeps the next search's lists short)."""
+        _check(load().theta_problem_hint(self._h, float(nll_upper_bound)))
+
     def _search_once(self, begin, end, window, cap):
         st = SearchStats()
         while True:
@@ -300,6 +311,8 @@ class Problem:
     def suspects(self):
         """Rejected candidates of the last search whose lower bound lies within the window: (ranks, lbound, C)."""
         n_out = C.c_int()
+        load().theta_search_suspects(self._h, -1, None, None, None, C.byref(n_out))
+        self.suspects_dropped = n_out.value
         rc = load().theta_search_suspects(self._h, 0, None, None, None, C.byref(n_out))
         k = n_out.value
         if k == 0:

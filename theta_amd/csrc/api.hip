@@ -104,6 +104,7 @@ extern "C" int theta_device_info(theta_ctx *c, char *name, int cap, int *cu, uin
 
 // ---- search instance ------------------------------------------------------------------------------
 #define LIST_CAP (1u << 20)
+#define SUS_CAP (1u << 16)
 #define N3_MAX_TASKS (1 << 18)
 
 struct theta_problem {
@@ -116,7 +117,9 @@ struct theta_problem {
     N3Dev n3{};
     uint64_t total[2] = {0, 0};
     std::vector<TieRecord> suspects;   // rejected candidates near the minimum, from the last theta_search
-    DevBuf d_r, d_rN, d_small, d_P, d_PR, d_PN, d_cnt, d_ctr, d_list, d_tasks, d_stbuf, d_misc, d_smask, d_dynmask;
+    uint64_t suspects_dropped = 0;     // ... and how many more did not fit the device list
+    double hint = INFINITY;            // upper bound of the minimum known to the caller (theta_problem_hint), one-shot
+    DevBuf d_r, d_rN, d_small, d_P, d_PR, d_PN, d_cnt, d_ctr, d_list, d_tasks, d_stbuf, d_misc, d_smask, d_dynmask, d_sus;
 };
 
 static int upload(DevBuf &b, const void *src, size_t bytes, hipStream_t st) {
@@ -197,6 +200,7 @@ extern "C" int theta_problem_create(theta_ctx *ctx, int n, int m, int tau, const
     TRY(upload(p->d_rN, rnd.data(), m * sizeof(double), st));
     TRY(p->d_ctr.alloc(sizeof(SearchCounters)));
     TRY(p->d_list.alloc((size_t)LIST_CAP * sizeof(TieRecord)));
+    TRY(p->d_sus.alloc((size_t)SUS_CAP * sizeof(TieRecord)));
 
     if (n == 2) {
         TRY(n2_build_host(m, lb, ub, p->n2h));
@@ -358,20 +362,25 @@ static int check_range(theta_problem *p, const uint64_t rb[2], const uint64_t re
 
 // Runs the fused kernel over [b, e).  dump arrays are device pointers or null.
 static int run_search(theta_problem *p, u128 b, u128 e, double window, double *dump_nll, double *dump_mu,
-                      SearchCounters &hc, std::vector<TieRecord> &recs, double &kernel_ms, double &setup_ms) {
+                      SearchCounters &hc, std::vector<TieRecord> &recs, double &kernel_ms, double &setup_ms,
+                      unsigned long long &dropped_out) {
     theta_ctx *ctx = p->ctx;
     hipStream_t st = ctx->stream;
     SearchArgs A;
     A.ctr = (SearchCounters *)p->d_ctr.p;
     A.list = (TieRecord *)p->d_list.p;
     A.list_cap = LIST_CAP;
+    A.sus = (TieRecord *)p->d_sus.p;
+    A.sus_cap = SUS_CAP;
     A.window = window;
     A.dump_nll = dump_nll;
     A.dump_mu = dump_mu;
     memset(&hc, 0, sizeof(hc));
-    hc.best_bits = order_bits(INFINITY);
+    hc.best_bits = order_bits(p->hint);   // a caller-supplied upper bound keeps tie and suspect lists short
+    p->hint = INFINITY;
     hc.rej_bits = order_bits(INFINITY);
     kernel_ms = setup_ms = 0.0;
+    unsigned long long list_dropped = 0;
     for (int pass = 0; pass < 3; pass++) {
         HIP_TRY(hipMemcpyAsync(p->d_ctr.p, &hc, sizeof(hc), hipMemcpyHostToDevice, st));
         HIP_TRY(hipEventRecord(ctx->ev0, st));
@@ -414,7 +423,7 @@ static int run_search(theta_problem *p, u128 b, u128 e, double window, double *d
         if (got.list_count <= LIST_CAP || pass == 2) {
             unsigned long long dropped = got.list_count > LIST_CAP ? got.list_count - LIST_CAP : 0;
             hc = got;
-            hc.pad = (unsigned)std::min<unsigned long long>(dropped, 0xffffffffu);
+            list_dropped = dropped;
             break;
         }
         // The list overflowed while the running minimum was still loose: go again with the minimum
@@ -427,10 +436,13 @@ static int run_search(theta_problem *p, u128 b, u128 e, double window, double *d
     }
     unsigned nrec = std::min<unsigned>(hc.list_count, LIST_CAP);
     recs.resize(nrec);
-    if (nrec) {
-        HIP_TRY(hipMemcpyAsync(recs.data(), p->d_list.p, (size_t)nrec * sizeof(TieRecord), hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
-    }
+    if (nrec) HIP_TRY(hipMemcpyAsync(recs.data(), p->d_list.p, (size_t)nrec * sizeof(TieRecord), hipMemcpyDeviceToHost, st));
+    unsigned nsus = std::min<unsigned>(hc.sus_count, SUS_CAP);
+    p->suspects.resize(nsus);
+    p->suspects_dropped = hc.sus_count > SUS_CAP ? hc.sus_count - SUS_CAP : 0;
+    if (nsus) HIP_TRY(hipMemcpyAsync(p->suspects.data(), p->d_sus.p, (size_t)nsus * sizeof(TieRecord), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    dropped_out = list_dropped;
     return THETA_OK;
 }
 
@@ -461,7 +473,8 @@ extern "C" int theta_search(theta_problem *p, const uint64_t rank_begin[2], cons
     SearchCounters hc;
     std::vector<TieRecord> recs;
     double kms, sms;
-    rc = run_search(p, b, e, window, nullptr, nullptr, hc, recs, kms, sms);
+    unsigned long long dropped = 0;
+    rc = run_search(p, b, e, window, nullptr, nullptr, hc, recs, kms, sms, dropped);
     if (rc) return rc;
     double best = order_unbits(hc.best_bits);
     if (stats) {
@@ -470,7 +483,7 @@ extern "C" int theta_search(theta_problem *p, const uint64_t rank_begin[2], cons
         stats->degenerate = hc.degenerate;
         stats->iterations = hc.iterations;
         stats->terms = hc.terms;
-        stats->list_overflow = hc.pad;
+        stats->list_overflow = dropped;
         double per = (p->n == 2) ? FLOPS_PER_TERM_ITER_N2 : FLOPS_PER_TERM_ITER_N3;
         double fin = (p->n == 2) ? FLOPS_PER_FINAL_TERM_N2 : FLOPS_PER_FINAL_TERM_N3;
         stats->flops = (uint64_t)(per * (double)hc.terms + fin * (double)hc.final_terms);
@@ -484,16 +497,18 @@ extern "C" int theta_search(theta_problem *p, const uint64_t rank_begin[2], cons
     }
     // keep what lies within the window of the final minimum, in rank order
     std::vector<TieRecord> keep;
-    p->suspects.clear();
-    for (const TieRecord &t : recs) {
-        if (!(t.nll <= best + window)) continue;
-        if (t.mu[0] != t.mu[0]) p->suspects.push_back(t);   // NaN marker: a rejected candidate (lower bound in .nll)
-        else keep.push_back(t);
-    }
+    for (const TieRecord &t : recs)
+        if (t.nll <= best + window) keep.push_back(t);
     auto by_rank = [](const TieRecord &x, const TieRecord &y) {
         return x.rank_hi != y.rank_hi ? x.rank_hi < y.rank_hi : x.rank_lo < y.rank_lo;
     };
-    std::sort(p->suspects.begin(), p->suspects.end(), by_rank);
+    {   // suspects: keep those whose bound is within the window of the FINAL minimum
+        std::vector<TieRecord> sk;
+        for (const TieRecord &t : p->suspects)
+            if (t.nll <= best + window) sk.push_back(t);
+        std::sort(sk.begin(), sk.end(), by_rank);
+        p->suspects.swap(sk);
+    }
     std::sort(keep.begin(), keep.end(), by_rank);
     *n_out = (int)keep.size();
     if ((int)keep.size() > cap) {
@@ -553,7 +568,8 @@ extern "C" int theta_search_values(theta_problem *p, const uint64_t rank_begin[2
     SearchCounters hc;
     std::vector<TieRecord> recs;
     double kms, sms;
-    rc = run_search(p, b, e, 0.0, (double *)d_nll.p, (double *)d_mu.p, hc, recs, kms, sms);
+    unsigned long long dropped = 0;
+    rc = run_search(p, b, e, 0.0, (double *)d_nll.p, (double *)d_mu.p, hc, recs, kms, sms, dropped);
     if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(nll, d_nll.p, count * sizeof(double), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(mu, d_mu.p, count * p->n * sizeof(double), hipMemcpyDeviceToHost, st));
@@ -573,6 +589,15 @@ extern "C" int theta_search_values(theta_problem *p, const uint64_t rank_begin[2
     return THETA_OK;
 }
 
+extern "C" int theta_problem_hint(theta_problem *p, double nll_upper_bound) {
+    if (!p) {
+        theta_set_error("null argument");
+        return THETA_ERR_ARG;
+    }
+    p->hint = (nll_upper_bound == nll_upper_bound) ? nll_upper_bound : INFINITY;
+    return THETA_OK;
+}
+
 extern "C" int theta_search_suspects(theta_problem *p, int cap, uint64_t *rank, double *lbound, uint8_t *C, int *n_out) {
     if (!p || !n_out) {
         theta_set_error("null argument");
@@ -580,6 +605,10 @@ extern "C" int theta_search_suspects(theta_problem *p, int cap, uint64_t *rank, 
     }
     const std::vector<TieRecord> &sv = p->suspects;
     *n_out = (int)sv.size();
+    if (cap < 0) {   // query: number of suspects that did not fit the device list
+        *n_out = (int)std::min<uint64_t>(p->suspects_dropped, 0x7fffffff);
+        return THETA_OK;
+    }
     if (sv.empty()) return THETA_OK;
     if ((int)sv.size() > cap || !rank || !lbound || !C) {
         theta_set_error("%zu suspects but capacity is %d", sv.size(), cap);

@@ -76,7 +76,7 @@ struct SearchCounters {
     unsigned long long rej_bits;       // same for the smallest rejected lower bound
     unsigned long long rej_rank_lo, rej_rank_hi;
     unsigned int list_count;           // records appended (may exceed capacity)
-    unsigned int pad;
+    unsigned int sus_count;            // suspects appended (may exceed capacity; never triggers a re-run)
     unsigned long long prof[8];        // shader cycles per kernel phase, summed over waves (diagnostic)
 };
 
@@ -85,6 +85,8 @@ struct SearchArgs {
     SearchCounters *ctr;
     TieRecord *list;
     unsigned list_cap;
+    TieRecord *sus;                    // rejected candidates near the minimum (n=3 certificate)
+    unsigned sus_cap;
     double window;
     double *dump_nll;  // optional per-candidate dump (the reference's --GET_VALUES), else null
     double *dump_mu;
@@ -161,6 +163,22 @@ __device__ __forceinline__ void wave_lds_sync() {
 
 __device__ __forceinline__ unsigned long long load_agent_u64(const unsigned long long *p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Append one suspect (rejected candidate whose lower bound is within the window).
+__device__ __forceinline__ void suspect_append(SearchCounters *ctr, TieRecord *list, unsigned cap, u128 rank, double lbound,
+                                               double unconstrained) {
+    unsigned idx = atomicAdd(&ctr->sus_count, 1u);
+    if (idx < cap) {
+        TieRecord rec;
+        rec.rank_lo = (uint64_t)rank;
+        rec.rank_hi = (uint64_t)(rank >> 64);
+        rec.nll = lbound;
+        rec.mu[0] = unconstrained;
+        rec.mu[1] = 0.0;
+        rec.mu[2] = 0.0;
+        list[idx] = rec;
+    }
 }
 
 // Append one record to the device tie list and lower the global best (device scope atomics).

@@ -351,6 +351,109 @@ __device__ __forceinline__ bool n3_child_dyn(const unsigned char *ridx, const un
     return lo <= hi;
 }
 
+// ---- the cold path of a candidate whose screened value is within the margin of the running minimum -------------
+template <int L>
+struct N3Leaf {
+    const double *gX, *gY, *gR;   // group tile of the prefix (LDS)
+    int G;
+    double lx[L], ly[L], lr[L];   // the candidate's own leaf rows and their weights
+    double s1, s2, inv_Rtot, Rmin, K0, thr, margin;
+};
+struct N3Cold {
+    double u1, u2, nll, sc_gain;
+    bool accept, contender;
+};
+
+// Polishes the coarse optimum to lambda^2 < 1e-12, re-decides admissibility, evaluates the exact FP64 NLL; for a
+// converged optimum y OUTSIDE the simplex it first tries to dismiss the candidate with the self-concordance bound
+//      NLL(z) >= NLL(y) + Rmin w(d / sqrt(Rmin)),   w(t) = t - ln(1 + t),   d = Hessian-norm distance from y to the simplex,
+// which bounds everything the reference could report for it (one extra term pass instead of polish + logs).
+template <int L>
+__device__ __noinline__ N3Cold n3_cold_path(N3Leaf<L> c, double u1, double u2, double nll, bool conv, bool accept, bool dump) {
+    N3Cold out;
+    out.sc_gain = 0.0;
+    out.contender = true;
+    const double s1 = c.s1, s2 = c.s2;
+    auto terms = [&](auto &&body) {
+        for (int g = 0; g < c.G; g++) body(c.gX[g], c.gY[g], c.gR[g]);
+#pragma unroll
+        for (int l = 0; l < L; l++) body(c.lx[l], c.ly[l], c.lr[l]);
+    };
+    if (!dump && conv && !accept) {
+        double h11 = 0.0, h12 = 0.0, h22 = 0.0;
+        terms([&](double x, double y, double R) {
+            double a = x - s1, b = y - s2;
+            double w = rcp_nr1(__builtin_fma(a, u1, __builtin_fma(b, u2, 1.0)));
+            double tw = R * w * w;
+            h11 = __builtin_fma(tw * a, a, h11);
+            h12 = __builtin_fma(tw * a, b, h12);
+            h22 = __builtin_fma(tw * b, b, h22);
+        });
+        // squared H-distance from y = (u1,u2) to the triangle (0,0), (1/s1,0), (0,1/s2): nearest point on an edge
+        const double vx[3] = {0.0, 1.0 / s1, 0.0}, vy[3] = {0.0, 0.0, 1.0 / s2};
+        double d2 = __builtin_inf();
+#pragma unroll
+        for (int e = 0; e < 3; e++) {
+            const int f = (e + 1) % 3;
+            double ex = vx[f] - vx[e], ey = vy[f] - vy[e];
+            double px = u1 - vx[e], py = u2 - vy[e];
+            double hex = h11 * ex + h12 * ey, hey = h12 * ex + h22 * ey;
+            double t = (px * hex + py * hey) / (ex * hex + ey * hey);
+            t = fmin(fmax(t, 0.0), 1.0);
+            double rx = px - t * ex, ry = py - t * ey;
+            d2 = fmin(d2, rx * (h11 * rx + h12 * ry) + ry * (h12 * rx + h22 * ry));
+        }
+        double tt = sqrt(fmax(d2, 0.0) / c.Rmin);
+        double gain = 0.98 * c.Rmin * (tt - log1p(tt));       // (2 % off for the rcp arithmetic above)
+        if (gain == gain) out.sc_gain = gain;
+        if (!(nll - c.margin + out.sc_gain <= c.thr)) {       // dismissed: cannot come within the window of the minimum
+            out.contender = false;
+            out.u1 = u1; out.u2 = u2; out.nll = nll; out.accept = accept;
+            return out;
+        }
+    }
+    if (!dump && conv) {   // polish the coarse optimum, then decide admissibility again
+        N3Newton T;
+        T.u1 = T.p1 = u1;
+        T.u2 = T.p2 = u2;
+        T.iters = 0;
+        T.status = 0;
+        T.singular = false;
+        while (T.status == 0 && T.iters < 12) n3_newton_step(terms, s1, s2, c.inv_Rtot, T, 1e-12);
+        if (T.status == 1) {
+            u1 = T.u1;
+            u2 = T.u2;
+            double n1 = s1 * u1, n2 = s2 * u2, n0 = 1.0 - n1 - n2;
+            accept = (n0 >= 0.0 && n0 <= 1.0 && n1 >= 0.0 && n1 <= 1.0 && n2 >= 0.0 && n2 <= 1.0);
+            if (!accept && T.singular) {
+                N3Hess T2;
+                T2.u1 = u1; T2.u2 = u2;
+                T2.h11 = T2.h12 = T2.h22 = 0.0;
+                terms([&](double x, double y, double R) {
+                    double a = x - s1, b = y - s2;
+                    double q = __builtin_fma(a, u1, __builtin_fma(b, u2, 1.0));
+                    double tw = R / (q * q);
+                    T2.h11 = __builtin_fma(tw * a, a, T2.h11);
+                    T2.h12 = __builtin_fma(tw * a, b, T2.h12);
+                    T2.h22 = __builtin_fma(tw * b, b, T2.h22);
+                });
+                accept = n3_admissible(T2, s1, s2);
+                u1 = T2.u1;
+                u2 = T2.u2;
+            }
+        }
+    }
+    double acc = 0.0;
+    terms([&](double x, double y, double R) {
+        double q = __builtin_fma(x - s1, u1, __builtin_fma(y - s2, u2, 1.0));
+        acc = __builtin_fma(R, log(q), acc);
+    });
+    out.u1 = u1; out.u2 = u2;
+    out.nll = c.K0 - acc;
+    out.accept = accept;
+    return out;
+}
+
 template <int L, bool DUMP>
 __global__ __launch_bounds__(64 * N3_WAVES, 3) void n3_search_kernel(N3Dev Pg, SearchArgs A, const N3Task *tasks,
                                                                 const unsigned *stbuf, int ntasks, uint64_t per_task) {
@@ -438,7 +541,7 @@ __global__ __launch_bounds__(64 * N3_WAVES, 3) void n3_search_kernel(N3Dev Pg, S
         unsigned long long t0 = __builtin_readcyclecounter();
         // ---------------- group tile of the prefix --------------------------------------------
         int G = 0;
-        double S1p = 0.0, S2p = 0.0;
+        double S1p = 0.0, S2p = 0.0, Rmin = __builtin_inf();   // Rmin: smallest weight of a likelihood term
         {
             const bool inp = lane < D;
             const unsigned myrow = st >> 24;  // a | b << 4
@@ -463,9 +566,14 @@ __global__ __launch_bounds__(64 * N3_WAVES, 3) void n3_search_kernel(N3Dev Pg, S
                 }
                 S1p += a * Ns;
                 S2p += b * Ns;
+                if (Rs > 0.0) Rmin = fmin(Rmin, Rs);
                 G++;
             }
         }
+#pragma unroll
+        for (int l = 0; l < L; l++)
+            if (leafR[l] > 0.0) Rmin = fmin(Rmin, leafR[l]);
+        if (!(Rmin < __builtin_inf())) Rmin = 1.0;
         wave_lds_sync();
         pc0 += __builtin_readcyclecounter() - t0;
 
@@ -757,49 +865,39 @@ __global__ __launch_bounds__(64 * N3_WAVES, 3) void n3_search_kernel(N3Dev Pg, S
                         double e1 = e0 - g1 * rcp_nr2(s1), e2 = e0 - g2 * rcp_nr2(s2);    // vertices (1/s1, 0), (0, 1/s2)
                         fw = fmin(e0, fmin(e1, e2));
                     }
-                    // rejected candidates are contenders when their lower bound comes within the window of the running
-                    // minimum (they become "suspects", see below) or below the smallest bound seen so far
-                    bool contender = solved && (DUMP || (nll + fw - screen_margin <= (accept ? best + A.window : fmax(rej_best, best + A.window))));
-                    if (contender) {
-                        if (!DUMP && conv) {   // polish the coarse optimum, then decide admissibility again
-                            N3Newton T;
-                            T.u1 = T.p1 = u1;
-                            T.u2 = T.p2 = u2;
-                            T.iters = 0;
-                            T.status = 0;
-                            T.singular = false;
-                            while (T.status == 0 && T.iters < 12) n3_newton_step(terms, s1, s2, inv_Rtot, T, 1e-12);
-                            if (T.status == 1) {
-                                u1 = T.u1;
-                                u2 = T.u2;
-                                double n1 = s1 * u1, n2 = s2 * u2, n0 = 1.0 - n1 - n2;
-                                accept = (n0 >= 0.0 && n0 <= 1.0 && n1 >= 0.0 && n1 <= 1.0 && n2 >= 0.0 && n2 <= 1.0);
-                                if (!accept && T.singular) {
-                                    N3Hess T2;
-                                    T2.u1 = u1; T2.u2 = u2;
-                                    T2.h11 = T2.h12 = T2.h22 = 0.0;
-                                    terms([&](double x, double y, double R) {
-                                        double a = x - s1, b = y - s2;
-                                        double q = __builtin_fma(a, u1, __builtin_fma(b, u2, 1.0));
-                                        double tw = R / (q * q);
-                                        T2.h11 = __builtin_fma(tw * a, a, T2.h11);
-                                        T2.h12 = __builtin_fma(tw * a, b, T2.h12);
-                                        T2.h22 = __builtin_fma(tw * b, b, T2.h22);
-                                    });
-                                    accept = n3_admissible(T2, s1, s2);
-                                    u1 = T2.u1;
-                                    u2 = T2.u2;
-                                }
-                            }
-                        }
-                        double acc = 0.0;
-                        terms([&](double x, double y, double R) {
-                            double q = __builtin_fma(x - s1, u1, __builtin_fma(y - s2, u2, 1.0));
-                            acc = __builtin_fma(R, log(q), acc);
-                        });
-                        nll = P.K0 - acc;
+                    // contenders (accepted or rejected): approximate value within the screening margin of the minimum.
+                    // Only they get polished and evaluated exactly.
+                    bool contender = solved && (DUMP || (nll + fw - screen_margin <= best + A.window));
+                    if (!DUMP && ballot64(contender) != 0) {
+                        // other waves lower the device-wide minimum: re-read it before paying for a contender (a
+                        // device-scope load goes past the XCD's L2, so not every round -- only when it can save work)
+                        best = fmin(best, order_unbits(load_agent_u64(&A.ctr->best_bits)));
+                        contender = contender && (nll + fw - screen_margin <= best + A.window);
                     }
-                    const double lbnd = nll + fw;
+                    double sc_gain = 0.0;
+                    if (contender) {   // rare: everything else about a contender happens out of line (keeps the hot loops lean)
+                        N3Leaf<L> lf;
+                        lf.gX = gX; lf.gY = gY; lf.gR = gR;
+                        lf.G = G;
+#pragma unroll
+                        for (int l = 0; l < L; l++) {
+                            lf.lx[l] = lx[l];
+                            lf.ly[l] = ly[l];
+                            lf.lr[l] = leafR[l];
+                        }
+                        lf.s1 = s1; lf.s2 = s2;
+                        lf.inv_Rtot = inv_Rtot; lf.Rmin = Rmin; lf.K0 = P.K0;
+                        lf.thr = best + A.window;
+                        lf.margin = screen_margin;
+                        N3Cold cr = n3_cold_path<L>(lf, u1, u2, nll, conv, accept, DUMP);
+                        u1 = cr.u1; u2 = cr.u2;
+                        nll = cr.nll;
+                        sc_gain = cr.sc_gain;
+                        accept = cr.accept;
+                        contender = cr.contender;
+                    }
+                    // lower bound of a rejected candidate: exact for contenders, else the screened value less its margin
+                    const double lbnd = (contender ? nll + fw : nll + fw - screen_margin) + sc_gain;
                     double mu0 = 0.0, mu1 = 0.0, mu2 = 0.0;
                     if (accept && contender) {   // closed form of M3 (Optimizer.py:318-330)
                         double u0 = (1.0 - s1 * u1 - s2 * u2) / tau;
@@ -838,10 +936,10 @@ __global__ __launch_bounds__(64 * N3_WAVES, 3) void n3_search_kernel(N3Dev Pg, S
                     }
                     // Suspects: rejected candidates whose lower bound is within the window of the minimum.  The reference
                     // could in principle report a stalled iterate for them; the host computes their exact simplex-
-                    // boundary minimum (theta_boundary_min) to certify that none can reach the winner.  Marked by mu0 = NaN.
+                    // boundary minimum (theta_boundary_min) to certify that none can reach the winner.
                     if (solved && !accept && contender && !DUMP && lbnd <= best + A.window)
-                        tie_append(A.ctr, A.list, A.list_cap, base + rel, lbnd, __builtin_nan(""), 0.0, 0.0);
-                    if (solved && !accept && contender && lbnd < rej_best) {
+                        suspect_append(A.ctr, A.sus, A.sus_cap, base + rel, lbnd, nll);
+                    if (solved && !accept && lbnd < rej_best) {
                         unsigned long long old = atomicMin(&A.ctr->rej_bits, order_bits(lbnd));
                         if (old > order_bits(lbnd)) {  // we hold the minimum (racy pair, diagnostic only)
                             u128 rk = base + rel;

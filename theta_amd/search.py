@@ -89,6 +89,7 @@ class SearchReport(object):
         self.parity_uncertain = False
         self.suspects = 0              # rejected candidates whose unconstrained optimum is within the window
         self.suspect_bound = float("inf")  # smallest NLL any of them can take on the simplex boundary
+        self.certificate_complete = True   # False if the device suspect list overflowed (poor sub-range without a hint)
         self.seconds = 0.0
 
 
@@ -244,6 +245,7 @@ def do_optimization_single(n, m, k, tau, lower_bounds, upper_bounds, r, rN, max_
     if n == 3 and best:
         ranks, lbound, Cs = problem.last_suspects
         rep.suspects = len(ranks)
+        rep.certificate_complete = problem.suspects_dropped == 0
         if len(ranks):
             bmin = ctx.boundary_min(tau, [int(x) for x in r], [int(x) for x in rN], Cs)
             rep.suspect_bound = float(bmin.min())
