@@ -304,19 +304,25 @@ __device__ __forceinline__ double readlane_f64(double v, int l) {
 }
 
 #define N3_WAVES 4
-#define N3_QCAP 128     // leaves solved per round (per wave)
+#ifndef N3_OCC
+#define N3_OCC 3       // blocks per CU the register budget is sized for
+#endif
+#ifndef N3_QCAP
+#define N3_QCAP 256     // leaves solved per round (per wave)
+#endif
 #define N3_MAX_L 6      // leaf levels (one byte of the 64-bit leaf code each)
 
+template <int L>
 struct N3Lds {
     double gX[N3_WAVES][N3_MAX_Q + N3_MAX_L], gY[N3_WAVES][N3_MAX_Q + N3_MAX_L], gR[N3_WAVES][N3_MAX_Q + N3_MAX_L];
     float4 fT[N3_WAVES][N3_MAX_Q + N3_MAX_L];   // f32 copy {a, b, sum r, -} of the tile (screening pass: one 16-byte read per term)
-    double resU1[N3_WAVES][N3_QCAP], resU2[N3_WAVES][N3_QCAP];
+    float resU1[N3_WAVES][N3_QCAP], resU2[N3_WAVES][N3_QCAP];   // coarse optimum (f32 is all the screen uses; contenders are polished in f64)
     unsigned long long qCode[N3_WAVES][N3_QCAP];
     unsigned short resSt[N3_WAVES][N3_QCAP], qOff[N3_WAVES][N3_QCAP];   // (a task holds < 65536 candidates)
     float lastN1[N3_WAVES][WAVE], lastN2[N3_WAVES][WAVE];     // mixture of the last admissible leaf each lane's chunk produced
     unsigned char qSrc[N3_WAVES][N3_QCAP];                   // lane whose chunk the queue entry comes from
-    unsigned stkS[N3_WAVES][N3_MAX_L][WAVE];            // lane-private DFS stack: node chosen at each leaf level
-    unsigned long long stkM[N3_WAVES][N3_MAX_L][WAVE];  // ... and the siblings still to visit at that level
+    unsigned stkS[N3_WAVES][L > 1 ? L - 1 : 1][WAVE];            // lane-private DFS stack: node chosen at each leaf level but the last
+    unsigned long long stkM[N3_WAVES][L > 1 ? L - 1 : 1][WAVE];  // ... and the siblings still to visit at that level
     unsigned long long smask[N3_MAX_L][N3_MAX_Q];       // static child masks of the leaf depths
     unsigned char lb[N3_MAX_M], ub[N3_MAX_M];
     unsigned char ridx[N3_RIDX_W * N3_RIDX_W + 3];
@@ -455,9 +461,9 @@ __device__ __noinline__ N3Cold n3_cold_path(N3Leaf<L> c, double u1, double u2, d
 }
 
 template <int L, bool DUMP>
-__global__ __launch_bounds__(64 * N3_WAVES, 3) void n3_search_kernel(N3Dev Pg, SearchArgs A, const N3Task *tasks,
+__global__ __launch_bounds__(64 * N3_WAVES, N3_OCC) void n3_search_kernel(N3Dev Pg, SearchArgs A, const N3Task *tasks,
                                                                 const unsigned *stbuf, int ntasks, uint64_t per_task) {
-    __shared__ N3Lds S;
+    __shared__ N3Lds<L> S;
     const int m = Pg.m, D = m - L, Q = Pg.Q;
     // stage what every wave of the block shares
     for (int i = threadIdx.x; i < m; i += blockDim.x) {
@@ -479,7 +485,7 @@ __global__ __launch_bounds__(64 * N3_WAVES, 3) void n3_search_kernel(N3Dev Pg, S
     const double tau = (double)P.tau;
     double *gX = S.gX[wv], *gY = S.gY[wv], *gR = S.gR[wv];
     float4 *fT = S.fT[wv];
-    double *resU1 = S.resU1[wv], *resU2 = S.resU2[wv];
+    float *resU1 = S.resU1[wv], *resU2 = S.resU2[wv];
     unsigned long long *qCode = S.qCode[wv];
     unsigned short *resSt = S.resSt[wv], *qOff = S.qOff[wv];
     float *lastN1 = S.lastN1[wv], *lastN2 = S.lastN2[wv];
@@ -781,8 +787,8 @@ __global__ __launch_bounds__(64 * N3_WAVES, 3) void n3_search_kernel(N3Dev Pg, S
                         if (Sv.status != 0) {
                             unsigned sing = Sv.singular ? RES_SINGULAR : 0u;
                             bool conv = Sv.status == 1;
-                            resU1[myidx] = conv ? Sv.u1 : Sv.p1;      // failed: last feasible iterate
-                            resU2[myidx] = conv ? Sv.u2 : Sv.p2;
+                            resU1[myidx] = (float)(conv ? Sv.u1 : Sv.p1);      // failed: last feasible iterate
+                            resU2[myidx] = (float)(conv ? Sv.u2 : Sv.p2);
                             resSt[myidx] = (unsigned short)((conv ? RES_CONV : RES_FAIL) | sing | ((unsigned)Sv.iters << 8));
                             have = false;
                         }
@@ -798,7 +804,7 @@ __global__ __launch_bounds__(64 * N3_WAVES, 3) void n3_search_kernel(N3Dev Pg, S
                     const bool live = idx < qcount;
                     mycode = live ? qCode[idx] : ~0ull;
                     unsigned stw = live ? resSt[idx] : RES_DEGEN;
-                    double u1 = live ? resU1[idx] : 0.0, u2 = live ? resU2[idx] : 0.0;
+                    double u1 = live ? (double)resU1[idx] : 0.0, u2 = live ? (double)resU2[idx] : 0.0;
                     const unsigned long long rel = live ? qOff[idx] : 0u;
                     double S1, S2;
                     decode(mycode, S1, S2);
@@ -855,15 +861,22 @@ __global__ __launch_bounds__(64 * N3_WAVES, 3) void n3_search_kernel(N3Dev Pg, S
                     double fw = 0.0;
                     if (solved && kind == RES_FAIL) {
                         double g1 = 0.0, g2 = 0.0;
+                        bool outside = false;    // (the stored iterate is rounded to f32: it may have left the domain)
                         terms([&](double x, double y, double R) {
                             double a = x - s1, b = y - s2;
-                            double t = R * rcp_nr1(__builtin_fma(a, u1, __builtin_fma(b, u2, 1.0)));
+                            double q = __builtin_fma(a, u1, __builtin_fma(b, u2, 1.0));
+                            outside |= !(q > 0.0);
+                            double t = R * rcp_nr1(q);
                             g1 = __builtin_fma(t, a, g1);
                             g2 = __builtin_fma(t, b, g2);
                         });
                         double e0 = g1 * u1 + g2 * u2;                  // vertex nu = e0  <-> u = (0, 0)
                         double e1 = e0 - g1 * rcp_nr2(s1), e2 = e0 - g2 * rcp_nr2(s2);    // vertices (1/s1, 0), (0, 1/s2)
                         fw = fmin(e0, fmin(e1, e2));
+                        if (outside || !(fw == fw) || !(nll == nll)) {   // no usable bound: hand it to the host as a suspect
+                            fw = 0.0;
+                            nll = -__builtin_inf();
+                        }
                     }
                     // contenders (accepted or rejected): approximate value within the screening margin of the minimum.
                     // Only they get polished and evaluated exactly.
@@ -897,7 +910,8 @@ __global__ __launch_bounds__(64 * N3_WAVES, 3) void n3_search_kernel(N3Dev Pg, S
                         contender = cr.contender;
                     }
                     // lower bound of a rejected candidate: exact for contenders, else the screened value less its margin
-                    const double lbnd = (contender ? nll + fw : nll + fw - screen_margin) + sc_gain;
+                    double lbnd = (contender ? nll + fw : nll + fw - screen_margin) + sc_gain;
+                    if (!(lbnd == lbnd)) lbnd = -__builtin_inf();   // unbounded: always a suspect
                     double mu0 = 0.0, mu1 = 0.0, mu2 = 0.0;
                     if (accept && contender) {   // closed form of M3 (Optimizer.py:318-330)
                         double u0 = (1.0 - s1 * u1 - s2 * u2) / tau;
