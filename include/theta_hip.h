@@ -77,6 +77,7 @@ typedef struct theta_search_stats {
     uint64_t terms;          /* likelihood terms (interval groups) summed over candidates       */
     uint64_t list_overflow;  /* records dropped because the device tie list was full            */
     uint64_t flops;          /* FP64 operations executed by the solver (counted in-kernel)      */
+    uint64_t flops_f32;      /* FP32 operations of the n=3 packed coarse pass and screen        */
     double best_nll;         /* smallest accepted NLL seen by the kernel (fused arithmetic)     */
     double rejected_bound;   /* smallest lower bound on the NLL of any REJECTED candidate       */
     uint64_t rejected_rank[2];

@@ -449,7 +449,8 @@ static int run_search(theta_problem *p, u128 b, u128 e, double window, double *d
 // FP64 operations per likelihood term (an FMA counts 2, rcp / log / div count 1); see DESIGN.md "Roofline".
 static const double FLOPS_PER_TERM_ITER_N3 = 25.0;  // 2 sub, 2 fma (q), rcp + 2 fma, mul, 2 fma (grad), 3 mul, 3 fma (Hessian)
 static const double FLOPS_PER_TERM_ITER_N2 = 13.0;  // fma (den), rcp + 2 fma, mul, fma (f), mul, fma (f')
-static const double FLOPS_PER_FINAL_TERM_N3 = 14.0; // 2 sub, 2 fma, log, fma, div, 2 fma
+static const double FLOPS_PER_TERM_ITER_N3_F32 = 21.0;  // packed coarse pass: 2 sub, 2 fma (q), rcp, mul, 2 fma (grad), 3 mul, 3 fma
+static const double FLOPS_PER_FINAL_TERM_N3 = 9.0;  // f32 screen: 2 sub, 2 fma, log, fma
 static const double FLOPS_PER_FINAL_TERM_N2 = 5.0;  // fma, log, fma
 
 extern "C" int theta_search(theta_problem *p, const uint64_t rank_begin[2], const uint64_t rank_end[2], double window,
@@ -486,7 +487,13 @@ extern "C" int theta_search(theta_problem *p, const uint64_t rank_begin[2], cons
         stats->list_overflow = dropped;
         double per = (p->n == 2) ? FLOPS_PER_TERM_ITER_N2 : FLOPS_PER_TERM_ITER_N3;
         double fin = (p->n == 2) ? FLOPS_PER_FINAL_TERM_N2 : FLOPS_PER_FINAL_TERM_N3;
-        stats->flops = (uint64_t)(per * (double)hc.terms + fin * (double)hc.final_terms);
+        if (p->n == 2) {
+            stats->flops = (uint64_t)(per * (double)hc.terms + fin * (double)hc.final_terms);
+            stats->flops_f32 = 0;
+        } else {   // n=3: FP64 iterations (dump, ill-conditioned candidates) + the packed-f32 coarse pass and screen
+            stats->flops = (uint64_t)(per * (double)hc.terms64);
+            stats->flops_f32 = (uint64_t)(FLOPS_PER_TERM_ITER_N3_F32 * (double)(hc.terms - hc.terms64) + fin * (double)hc.final_terms);
+        }
         stats->best_nll = best;
         stats->rejected_bound = order_unbits(hc.rej_bits);
         stats->rejected_rank[0] = hc.rej_rank_lo;

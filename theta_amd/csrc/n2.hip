@@ -315,6 +315,7 @@ __global__ __launch_bounds__(256) void n2_search_kernel(N2Dev P, SearchArgs A, u
         atomicAdd(&A.ctr->degenerate, n_deg);
         atomicAdd(&A.ctr->iterations, n_it);
         atomicAdd(&A.ctr->terms, n_terms);
+        atomicAdd(&A.ctr->terms64, n_terms);
         atomicAdd(&A.ctr->final_terms, n_fin);
     }
 }

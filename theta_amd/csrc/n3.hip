@@ -312,17 +312,27 @@ __device__ __forceinline__ double readlane_f64(double v, int l) {
 #endif
 #define N3_MAX_L 6      // leaf levels (one byte of the 64-bit leaf code each)
 
+// Everything a wave owns sits in ONE struct, so that a single base register (+ immediate offsets) addresses all of it.
+template <int L>
+struct N3WaveLds {
+    double gX[N3_MAX_Q + N3_MAX_L], gY[N3_MAX_Q + N3_MAX_L], gR[N3_MAX_Q + N3_MAX_L];   // group tile {a, b, sum r} of the prefix
+    // f32 copy of the tile, two terms per entry for the packed coarse pass and the screen: {a0, a1, b0, b1} and {R0, R1};
+    // an odd last term is paired with a copy of itself of weight 0
+    float4 fXY[(N3_MAX_Q + 2) / 2];
+    float2 fRR[(N3_MAX_Q + 2) / 2];
+    float2 fRL[(N3_MAX_L + 1) / 2];   // weights of the leaf rows, paired like fRR (an odd last one with 0)
+    float ws[2];                      // wave-wide warm start (mixture of the best candidate so far, blended)
+    float resU1[N3_QCAP], resU2[N3_QCAP];   // coarse optimum (f32 is all the screen uses; contenders are polished in f64)
+    unsigned long long qCode[N3_QCAP];
+    unsigned short resSt[N3_QCAP], qOff[N3_QCAP];   // (a task holds < 65536 candidates)
+    float lastN1[WAVE], lastN2[WAVE];     // mixture of the last admissible leaf each lane's chunk produced
+    unsigned char qSrc[N3_QCAP];          // lane whose chunk the queue entry comes from
+    unsigned stkS[L > 1 ? L - 1 : 1][WAVE];            // lane-private DFS stack: node chosen at each leaf level but the last
+    unsigned long long stkM[L > 1 ? L - 1 : 1][WAVE];  // ... and the siblings still to visit at that level
+};
 template <int L>
 struct N3Lds {
-    double gX[N3_WAVES][N3_MAX_Q + N3_MAX_L], gY[N3_WAVES][N3_MAX_Q + N3_MAX_L], gR[N3_WAVES][N3_MAX_Q + N3_MAX_L];
-    float4 fT[N3_WAVES][N3_MAX_Q + N3_MAX_L];   // f32 copy {a, b, sum r, -} of the tile (screening pass: one 16-byte read per term)
-    float resU1[N3_WAVES][N3_QCAP], resU2[N3_WAVES][N3_QCAP];   // coarse optimum (f32 is all the screen uses; contenders are polished in f64)
-    unsigned long long qCode[N3_WAVES][N3_QCAP];
-    unsigned short resSt[N3_WAVES][N3_QCAP], qOff[N3_WAVES][N3_QCAP];   // (a task holds < 65536 candidates)
-    float lastN1[N3_WAVES][WAVE], lastN2[N3_WAVES][WAVE];     // mixture of the last admissible leaf each lane's chunk produced
-    unsigned char qSrc[N3_WAVES][N3_QCAP];                   // lane whose chunk the queue entry comes from
-    unsigned stkS[N3_WAVES][L > 1 ? L - 1 : 1][WAVE];            // lane-private DFS stack: node chosen at each leaf level but the last
-    unsigned long long stkM[N3_WAVES][L > 1 ? L - 1 : 1][WAVE];  // ... and the siblings still to visit at that level
+    N3WaveLds<L> w[N3_WAVES];
     unsigned long long smask[N3_MAX_L][N3_MAX_Q];       // static child masks of the leaf depths
     unsigned char lb[N3_MAX_M], ub[N3_MAX_M];
     unsigned char ridx[N3_RIDX_W * N3_RIDX_W + 3];
@@ -483,19 +493,19 @@ __global__ __launch_bounds__(64 * N3_WAVES, N3_OCC) void n3_search_kernel(N3Dev 
     const int task = blockIdx.x * N3_WAVES + wv;
     if (task >= ntasks) return;  // whole wave leaves together; no block barrier below
     const double tau = (double)P.tau;
-    double *gX = S.gX[wv], *gY = S.gY[wv], *gR = S.gR[wv];
-    float4 *fT = S.fT[wv];
-    float *resU1 = S.resU1[wv], *resU2 = S.resU2[wv];
-    unsigned long long *qCode = S.qCode[wv];
-    unsigned short *resSt = S.resSt[wv], *qOff = S.qOff[wv];
-    float *lastN1 = S.lastN1[wv], *lastN2 = S.lastN2[wv];
-    unsigned char *qSrc = S.qSrc[wv];
+    N3WaveLds<L> &W = S.w[wv];
+    double *gX = W.gX, *gY = W.gY, *gR = W.gR;
+    float4 *fXY = W.fXY;
+    float2 *fRR = W.fRR;
+    float *resU1 = W.resU1, *resU2 = W.resU2;
+    unsigned long long *qCode = W.qCode;
+    unsigned short *resSt = W.resSt, *qOff = W.qOff;
+    float *lastN1 = W.lastN1, *lastN2 = W.lastN2;
+    unsigned char *qSrc = W.qSrc;
     const unsigned long long swm = Pg.swmask;
     const int NT1 = Pg.NT + 1;
 
     // lane i holds interval i; lane s (+64) also stands for alphabet slot s in the prefix successor
-    const double r_i = lane < m ? Pg.r[lane] : 0.0;
-    const double rN_i = lane < m ? Pg.rN[lane] : 0.0;
     unsigned st = lane < D ? stbuf[(size_t)task * N3_MAX_M + lane] : 0u;
     const int K1 = P.K + 1;
     const int sa0 = lane % K1, sb0 = lane / K1, sa1 = (lane + WAVE) % K1, sb1 = (lane + WAVE) / K1;
@@ -507,10 +517,12 @@ __global__ __launch_bounds__(64 * N3_WAVES, N3_OCC) void n3_search_kernel(N3Dev 
 
     // leaf rows' shared data (wave-uniform)
     double leafR[L], leafN[L];
+    float leafRf[L];
 #pragma unroll
     for (int l = 0; l < L; l++) {
-        leafR[l] = readlane_f64(r_i, D + l);
-        leafN[l] = readlane_f64(rN_i, D + l);
+        leafR[l] = Pg.r[D + l];      // (uniform address: scalar loads)
+        leafN[l] = Pg.rN[D + l];
+        leafRf[l] = (float)leafR[l];
     }
     // screening margin for the single-precision NLL: |error| <= Rtot * (|ln q| * 2^-23 + 2^-22) stays far below this
     const double screen_margin = 2e-5 * P.Rtot + 1.0;
@@ -520,12 +532,18 @@ __global__ __launch_bounds__(64 * N3_WAVES, N3_OCC) void n3_search_kernel(N3Dev 
     // screening margin.  Only contenders are polished to 1e-12 (below); the --GET_VALUES dump polishes everything.
     const double conv_main = DUMP ? 1e-12 : P.conv_l2;
 
-    unsigned long long n_eval = 0, n_acc = 0, n_deg = 0, n_it = 0, n_terms = 0, n_fin = 0;
+    // statistics are wave-uniform scalars (popcounts of ballots): no vector registers
+    unsigned long long n_eval = 0, n_acc = 0, n_deg = 0, n_it = 0, n_terms = 0, n_terms64 = 0, n_fin = 0;
     double best = order_unbits(load_agent_u64(&A.ctr->best_bits));
     double rej_best = order_unbits(load_agent_u64(&A.ctr->rej_bits));
     // warm start (wave-uniform): mixture fractions of the best candidate of the previous batch, pulled
     // towards the centre of the simplex so that it is interior for every candidate
-    double ws1 = 1.0 / 3.0, ws2 = 1.0 / 3.0;
+    if (lane == 0) {
+        W.ws[0] = W.ws[1] = 1.0f / 3.0f;
+#pragma unroll
+        for (int l = 0; l < L; l += 2) W.fRL[l >> 1] = make_float2(leafRf[l], l + 1 < L ? leafRf[l + 1] : 0.0f);
+    }
+    wave_lds_sync();
 
     // ---- lane-private DFS over the leaf levels -----------------------------------------------------------
     // feasible children of `node` when they sit at leaf level l: static rules (LDS) & symmetry & ratio window
@@ -551,6 +569,8 @@ __global__ __launch_bounds__(64 * N3_WAVES, N3_OCC) void n3_search_kernel(N3Dev 
         {
             const bool inp = lane < D;
             const unsigned myrow = st >> 24;  // a | b << 4
+            // lane i stands for interval i here; its counts are re-read per prefix (L2) instead of living in registers
+            const double r_i = inp ? Pg.r[lane] : 0.0, rN_i = inp ? Pg.rN[lane] : 0.0;
             unsigned long long todo = ballot64(inp);
             while (todo) {
                 int leader = __builtin_ctzll(todo);
@@ -568,7 +588,13 @@ __global__ __launch_bounds__(64 * N3_WAVES, N3_OCC) void n3_search_kernel(N3Dev 
                     gX[G] = a;
                     gY[G] = b;
                     gR[G] = Rs;
-                    fT[G] = make_float4((float)a, (float)b, (float)Rs, 0.0f);
+                    float *xy = (float *)&fXY[G >> 1];
+                    float *rr = (float *)&fRR[G >> 1];
+                    if (G & 1) {
+                        xy[1] = (float)a; xy[3] = (float)b; rr[1] = (float)Rs;
+                    } else {   // also fills the second half: stays as the weight-0 pad when this is the last term
+                        xy[0] = xy[1] = (float)a; xy[2] = xy[3] = (float)b; rr[0] = (float)Rs; rr[1] = 0.0f;
+                    }
                 }
                 S1p += a * Ns;
                 S2p += b * Ns;
@@ -631,8 +657,8 @@ __global__ __launch_bounds__(64 * N3_WAVES, N3_OCC) void n3_search_kernel(N3Dev 
                             unsigned long long cv = (tv >> 64) ? ~0ull : (unsigned long long)tv;
                             if (idx < cv) {
                                 found = true;
-                                S.stkS[wv][l][lane] = n3_pack(ch);
-                                S.stkM[wv][l][lane] = mk;   // siblings after the chosen child
+                                W.stkS[l][lane] = n3_pack(ch);
+                                W.stkM[l][lane] = mk;   // siblings after the chosen child
                                 code |= (unsigned long long)(ch.a | (ch.b << 4)) << (8 * l);
                                 cur = ch;
                                 break;
@@ -680,8 +706,8 @@ __global__ __launch_bounds__(64 * N3_WAVES, N3_OCC) void n3_search_kernel(N3Dev 
                                 my_left = 0;                   // cannot happen inside the counted range
                                 adv = false;
                             } else {
-                                mcur = S.stkM[wv][lv][lane];
-                                cur = (lv == 0) ? par : n3_unpack(S.stkS[wv][lv - 1][lane]);
+                                mcur = W.stkM[lv][lane];
+                                cur = (lv == 0) ? par : n3_unpack(W.stkS[lv - 1][lane]);
                             }
                         } else {
                             const int s = __builtin_ctzll(mcur);
@@ -697,8 +723,8 @@ __global__ __launch_bounds__(64 * N3_WAVES, N3_OCC) void n3_search_kernel(N3Dev 
                                 adv = produced < want;
                             } else {                           // descend into child s
                                 N3State ch = child_state(cur, s);
-                                S.stkS[wv][lv][lane] = n3_pack(ch);
-                                S.stkM[wv][lv][lane] = mcur;
+                                W.stkS[lv][lane] = n3_pack(ch);
+                                W.stkM[lv][lane] = mcur;
                                 code = (code & ~(0xffull << (8 * lv))) | ((unsigned long long)(ch.a | (ch.b << 4)) << (8 * lv));
                                 cur = ch;
                                 lv++;
@@ -720,15 +746,34 @@ __global__ __launch_bounds__(64 * N3_WAVES, N3_OCC) void n3_search_kernel(N3Dev 
                 bool have = false;
                 int myidx = 0;
                 unsigned long long mycode = 0;
-                double lx[L], ly[L];
+                float lx[L], ly[L];   // the candidate's leaf rows (small integers: exact in f32)
                 double s1 = 1.0, s2 = 1.0;
                 N3Newton Sv;
                 Sv.status = 0;
+                bool use64 = DUMP;      // FP64 iterations: the dump, and candidates whose Hessian f32 sums cannot resolve
                 auto terms = [&](auto &&body) {
 #pragma unroll 4
                     for (int g = 0; g < G; g++) body(gX[g], gY[g], gR[g]);
 #pragma unroll
-                    for (int l = 0; l < L; l++) body(lx[l], ly[l], leafR[l]);
+                    for (int l = 0; l < L; l++) body((double)lx[l], (double)ly[l], leafR[l]);
+                };
+                const int GP = (G + 1) >> 1;
+                auto pairs = [&](auto &&body) {
+#pragma unroll 2
+                    for (int p = 0; p < GP; p++) {
+                        const float4 xy = fXY[p];
+                        const float2 rr = fRR[p];
+                        body(v2f{xy.x, xy.y}, v2f{xy.z, xy.w}, v2f{rr.x, rr.y});
+                    }
+#pragma unroll
+                    for (int l = 0; l + 1 < L; l += 2) {
+                        const float2 rr = W.fRL[l >> 1];
+                        body(v2f{lx[l], lx[l + 1]}, v2f{ly[l], ly[l + 1]}, v2f{rr.x, rr.y});
+                    }
+                    if (L & 1) {
+                        const float2 rr = W.fRL[L >> 1];
+                        body(v2f{lx[L - 1], lx[L - 1]}, v2f{ly[L - 1], ly[L - 1]}, v2f{rr.x, rr.y});
+                    }
                 };
                 auto decode = [&](unsigned long long code_, double &S1, double &S2) {   // rows of the L leaf levels
                     S1 = S1p;
@@ -736,10 +781,10 @@ __global__ __launch_bounds__(64 * N3_WAVES, N3_OCC) void n3_search_kernel(N3Dev 
 #pragma unroll
                     for (int l = 0; l < L; l++) {
                         unsigned rw = (unsigned)(code_ >> (8 * l)) & 0xffu;
-                        lx[l] = (double)(rw & 15u);
-                        ly[l] = (double)(rw >> 4);
-                        S1 = __builtin_fma(lx[l], leafN[l], S1);
-                        S2 = __builtin_fma(ly[l], leafN[l], S2);
+                        lx[l] = (float)(rw & 15u);
+                        ly[l] = (float)(rw >> 4);
+                        S1 = __builtin_fma((double)(rw & 15u), leafN[l], S1);
+                        S2 = __builtin_fma((double)(rw >> 4), leafN[l], S2);
                     }
                 };
                 while (true) {
@@ -767,14 +812,19 @@ __global__ __launch_bounds__(64 * N3_WAVES, N3_OCC) void n3_search_kernel(N3Dev 
                                 const int src = qSrc[want];
                                 double n1 = (double)lastN1[src], n2 = (double)lastN2[src];
                                 const bool pred = n1 == n1;
-                                n1 = pred ? __builtin_fma(0.98, n1, 0.02 / 3.0) : ws1;
-                                n2 = pred ? __builtin_fma(0.98, n2, 0.02 / 3.0) : ws2;
+                                n1 = __builtin_fma(0.98, n1, 0.02 / 3.0);
+                                n2 = __builtin_fma(0.98, n2, 0.02 / 3.0);
+                                if (!pred) {   // first leaf of a chunk
+                                    n1 = (double)W.ws[0];
+                                    n2 = (double)W.ws[1];
+                                }
                                 Sv.u1 = n1 * rcp_nr2(s1);       // nu -> u
                                 Sv.u2 = n2 * rcp_nr2(s2);
                                 Sv.p1 = Sv.u1; Sv.p2 = Sv.u2;
                                 Sv.iters = 0;
                                 Sv.status = 0;
                                 Sv.singular = false;
+                                use64 = DUMP;
                             }
                         }
                     }
@@ -782,8 +832,15 @@ __global__ __launch_bounds__(64 * N3_WAVES, N3_OCC) void n3_search_kernel(N3Dev 
                         if (head >= qcount) break;
                         continue;   // only degenerate leaves were taken this round
                     }
+                    {
+                        const unsigned act = (unsigned)__builtin_popcountll(ballot64(have));
+                        n_it += act;
+                        n_terms += act * (unsigned)(G + L);
+                        n_terms64 += (unsigned)__builtin_popcountll(ballot64(have && use64)) * (unsigned)(G + L);
+                    }
                     if (have) {
-                        n3_newton_step(terms, s1, s2, inv_Rtot, Sv, conv_main);
+                        if (use64) n3_newton_step(terms, s1, s2, inv_Rtot, Sv, conv_main);
+                        else use64 = !n3_newton_step_pk(pairs, (float)s1, (float)s2, inv_Rtot, Sv, conv_main);
                         if (Sv.status != 0) {
                             unsigned sing = Sv.singular ? RES_SINGULAR : 0u;
                             bool conv = Sv.status == 1;
@@ -814,7 +871,6 @@ __global__ __launch_bounds__(64 * N3_WAVES, N3_OCC) void n3_search_kernel(N3Dev 
                     const bool conv = solved && kind == RES_CONV;
                     s1 = solved ? S1 * inv_N : 1.0;
                     s2 = solved ? S2 * inv_N : 1.0;
-                    const int iters = (int)(stw >> 8);
                     // admissibility (Optimizer.py:150-160): all nu_j in [0,1]
                     bool accept = false;
                     if (conv) {
@@ -842,17 +898,14 @@ __global__ __launch_bounds__(64 * N3_WAVES, N3_OCC) void n3_search_kernel(N3Dev 
                     float accf = 0.0f;
                     if (solved) {
                         const float fs1 = (float)s1, fs2 = (float)s2, fu1 = (float)u1, fu2 = (float)u2;
-#pragma unroll 4
-                        for (int g = 0; g < G; g++) {
-                            const float4 t = fT[g];
-                            float q = __builtin_fmaf(t.x - fs1, fu1, __builtin_fmaf(t.y - fs2, fu2, 1.0f));
-                            accf = __builtin_fmaf(t.z, __logf(q), accf);
-                        }
-#pragma unroll
-                        for (int l = 0; l < L; l++) {
-                            float q = __builtin_fmaf((float)lx[l] - fs1, fu1, __builtin_fmaf((float)ly[l] - fs2, fu2, 1.0f));
-                            accf = __builtin_fmaf((float)leafR[l], __logf(q), accf);
-                        }
+                        const v2f vs1 = {fs1, fs1}, vs2 = {fs2, fs2}, vu1 = {fu1, fu1}, vu2 = {fu2, fu2}, one = {1.f, 1.f};
+                        v2f acc2 = {0.f, 0.f};
+                        pairs([&](v2f x, v2f y, v2f R) {
+                            v2f q = __builtin_elementwise_fma(x - vs1, vu1, __builtin_elementwise_fma(y - vs2, vu2, one));
+                            v2f lg = {__builtin_amdgcn_logf(q.x), __builtin_amdgcn_logf(q.y)};   // log2
+                            acc2 = __builtin_elementwise_fma(R, lg, acc2);
+                        });
+                        accf = (acc2.x + acc2.y) * 0.69314718056f;
                     }
                     double nll = P.K0 - (double)accf;
                     // Lower bound of what the reference could report for a rejected candidate.  Converged outside
@@ -894,8 +947,8 @@ __global__ __launch_bounds__(64 * N3_WAVES, N3_OCC) void n3_search_kernel(N3Dev 
                         lf.G = G;
 #pragma unroll
                         for (int l = 0; l < L; l++) {
-                            lf.lx[l] = lx[l];
-                            lf.ly[l] = ly[l];
+                            lf.lx[l] = (double)lx[l];
+                            lf.ly[l] = (double)ly[l];
                             lf.lr[l] = leafR[l];
                         }
                         lf.s1 = s1; lf.s2 = s2;
@@ -945,8 +998,10 @@ __global__ __launch_bounds__(64 * N3_WAVES, N3_OCC) void n3_search_kernel(N3Dev 
                         unsigned long long who = ballot64(mine == wbest);
                         int src = __builtin_ctzll(who);
                         double b1 = readlane_f64(s1 * u1, src), b2 = readlane_f64(s2 * u2, src);
-                        ws1 = P.warm_blend * b1 + (1.0 - P.warm_blend) / 3.0;
-                        ws2 = P.warm_blend * b2 + (1.0 - P.warm_blend) / 3.0;
+                        if (lane == 0) {
+                            W.ws[0] = (float)(P.warm_blend * b1 + (1.0 - P.warm_blend) / 3.0);
+                            W.ws[1] = (float)(P.warm_blend * b2 + (1.0 - P.warm_blend) / 3.0);
+                        }
                     }
                     // Suspects: rejected candidates whose lower bound is within the window of the minimum.  The reference
                     // could in principle report a stalled iterate for them; the host computes their exact simplex-
@@ -970,12 +1025,10 @@ __global__ __launch_bounds__(64 * N3_WAVES, N3_OCC) void n3_search_kernel(N3Dev 
                         A.dump_mu[di * 3 + 1] = accept ? mu1 : nan;
                         A.dump_mu[di * 3 + 2] = accept ? mu2 : nan;
                     }
-                    n_eval += live;
-                    n_acc += accept;
-                    n_deg += degenerate;
-                    n_it += solved ? iters : 0;
-                    n_terms += solved ? (unsigned long long)iters * (G + L) : 0;
-                    n_fin += solved ? (G + L) : 0;
+                    n_eval += (unsigned)__builtin_popcountll(ballot64(live));
+                    n_acc += (unsigned)__builtin_popcountll(ballot64(accept));
+                    n_deg += (unsigned)__builtin_popcountll(ballot64(degenerate));
+                    n_fin += (unsigned)__builtin_popcountll(ballot64(solved)) * (unsigned)(G + L);
                 }
                 wave_lds_sync();
                 pc3 += __builtin_readcyclecounter() - td1;
@@ -1031,18 +1084,13 @@ __global__ __launch_bounds__(64 * N3_WAVES, N3_OCC) void n3_search_kernel(N3Dev 
         pc4 += __builtin_readcyclecounter() - tn0;
     }
 
-    n_eval = wave_sum_u64(n_eval);
-    n_acc = wave_sum_u64(n_acc);
-    n_deg = wave_sum_u64(n_deg);
-    n_it = wave_sum_u64(n_it);
-    n_terms = wave_sum_u64(n_terms);
-    n_fin = wave_sum_u64(n_fin);
     if (lane == 0) {
         atomicAdd(&A.ctr->evaluated, n_eval);
         atomicAdd(&A.ctr->accepted, n_acc);
         atomicAdd(&A.ctr->degenerate, n_deg);
         atomicAdd(&A.ctr->iterations, n_it);
         atomicAdd(&A.ctr->terms, n_terms);
+        atomicAdd(&A.ctr->terms64, n_terms64);
         atomicAdd(&A.ctr->final_terms, n_fin);
         atomicAdd(&A.ctr->prof[0], pc0);
         atomicAdd(&A.ctr->prof[1], pc1);

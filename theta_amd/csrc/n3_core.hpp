@@ -186,6 +186,70 @@ __device__ __forceinline__ void n3_newton_step(Terms &&terms, double s1, double 
     else if (S.iters >= N3_MAX_ITERS || fabs(S.u1) + fabs(S.u2) > 1e8) S.status = 2;
 }
 
+// ---- packed single-precision evaluation for the COARSE first pass of the fused search -------------------------
+// Two likelihood terms per VALU instruction (v_pk_fma_f32 & co.).  Only the coarse pass uses it: the iterate it
+// produces is screened in single precision anyway, and every contender is polished and evaluated in FP64.  With
+// gradient noise dg ~ 1e-7 sum|t a| the optimum moves by H^-1 dg, an NLL error ~ dg^2 / H ~ 1e-14 sum(r).
+// The 2x2 solve runs in FP64 on the five sums.  Returns false -- without stepping -- when the Hessian is too
+// ill-conditioned for single-precision sums (det < 1e-3 h11 h22, which includes the rank-deficient candidates):
+// the caller then iterates that candidate with n3_newton_step in FP64.
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+template <class Pairs>
+__device__ __forceinline__ bool n3_newton_step_pk(Pairs &&pairs, float s1, float s2, double inv_Rtot, N3Newton &S,
+                                                  double conv_l2) {
+    v2f g1 = {0.f, 0.f}, g2 = g1, h11 = g1, h12 = g1, h22 = g1;
+    float qmin = __builtin_inff();
+    const float u1 = (float)S.u1, u2 = (float)S.u2;
+    const v2f vs1 = {s1, s1}, vs2 = {s2, s2}, vu1 = {u1, u1}, vu2 = {u2, u2}, one = {1.f, 1.f};
+    pairs([&](v2f x, v2f y, v2f R) {
+        v2f a = x - vs1, b = y - vs2;
+        v2f q = __builtin_elementwise_fma(a, vu1, __builtin_elementwise_fma(b, vu2, one));
+        qmin = fminf(qmin, fminf(q.x, q.y));
+        v2f w = {__builtin_amdgcn_rcpf(q.x), __builtin_amdgcn_rcpf(q.y)};
+        v2f t = R * w;
+        g1 = __builtin_elementwise_fma(t, a, g1);
+        g2 = __builtin_elementwise_fma(t, b, g2);
+        v2f tw = t * w;
+        v2f ta = tw * a, tb = tw * b;
+        h11 = __builtin_elementwise_fma(ta, a, h11);
+        h12 = __builtin_elementwise_fma(ta, b, h12);
+        h22 = __builtin_elementwise_fma(tb, b, h22);
+    });
+    S.iters++;
+    if (!(qmin > 0.0f)) {   // stepped out of the domain: halve the step
+        S.u1 = 0.5 * (S.u1 + S.p1);
+        S.u2 = 0.5 * (S.u2 + S.p2);
+        if (S.iters >= N3_MAX_ITERS) S.status = 2;
+        return true;
+    }
+    const double G1 = (double)(g1.x + g1.y), G2 = (double)(g2.x + g2.y);
+    const double H11 = (double)(h11.x + h11.y), H12 = (double)(h12.x + h12.y), H22 = (double)(h22.x + h22.y);
+    const double hh = H11 * H22;
+    const double det = hh - H12 * H12;
+#ifndef N3_COND_MIN
+#define N3_COND_MIN 1e-3
+#endif
+    if (!(det > N3_COND_MIN * hh)) return false;
+    S.singular = false;
+    double idet = rcp_nr2(det);
+    double d1 = (H22 * G1 - H12 * G2) * idet;
+    double d2 = (H11 * G2 - H12 * G1) * idet;
+    double l2 = (G1 * d1 + G2 * d2) * inv_Rtot;
+    if (!(l2 == l2) || !(fabs(d1) + fabs(d2) < 1e30)) {
+        S.status = 2;
+        return true;
+    }
+    double step = 1.0;
+    if (l2 > 0.09) step = 1.0 / (1.0 + sqrt(l2));
+    S.p1 = S.u1; S.p2 = S.u2;
+    S.u1 = __builtin_fma(step, d1, S.u1);
+    S.u2 = __builtin_fma(step, d2, S.u2);
+    if (l2 < conv_l2) S.status = 1;
+    else if (S.iters >= N3_MAX_ITERS || fabs(S.u1) + fabs(S.u2) > 1e8) S.status = 2;
+    return true;
+}
+
 // After convergence: decide admissibility the way Optimizer._solve_n3plus does (all nu_j in [0,1],
 // Optimizer.py:150-160).  For rank-deficient candidates the minimiser is a line; the reference
 // accepts when its root finder happens to land inside the simplex, so the line is intersected with
