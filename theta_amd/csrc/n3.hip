@@ -818,8 +818,8 @@ __global__ __launch_bounds__(64 * N3_WAVES, N3_OCC) void n3_search_kernel(N3Dev 
                                     n1 = (double)W.ws[0];
                                     n2 = (double)W.ws[1];
                                 }
-                                Sv.u1 = n1 * rcp_nr2(s1);       // nu -> u
-                                Sv.u2 = n2 * rcp_nr2(s2);
+                                Sv.u1 = n1 * (double)__builtin_amdgcn_rcpf((float)s1);       // nu -> u (a starting point: f32 will do)
+                                Sv.u2 = n2 * (double)__builtin_amdgcn_rcpf((float)s2);
                                 Sv.p1 = Sv.u1; Sv.p2 = Sv.u2;
                                 Sv.iters = 0;
                                 Sv.status = 0;

@@ -190,10 +190,11 @@ __device__ __forceinline__ void n3_newton_step(Terms &&terms, double s1, double 
 // Two likelihood terms per VALU instruction (v_pk_fma_f32 & co.).  Only the coarse pass uses it: the iterate it
 // produces is screened in single precision anyway, and every contender is polished and evaluated in FP64.  With
 // gradient noise dg ~ 1e-7 sum|t a| the optimum moves by H^-1 dg, an NLL error ~ dg^2 / H ~ 1e-14 sum(r).
-// The 2x2 solve runs in FP64 on the five sums.  Returns false -- without stepping -- when the Hessian is too
+// The 2x2 solve is single precision too.  Returns false -- without stepping -- when the Hessian is too
 // ill-conditioned for single-precision sums (det < 1e-3 h11 h22, which includes the rank-deficient candidates):
 // the caller then iterates that candidate with n3_newton_step in FP64.
 typedef float v2f __attribute__((ext_vector_type(2)));
+#define N3_COND_MIN 1e-3   // smallest det / (h11 h22) the single-precision pass accepts
 
 template <class Pairs>
 __device__ __forceinline__ bool n3_newton_step_pk(Pairs &&pairs, float s1, float s2, double inv_Rtot, N3Newton &S,
@@ -223,29 +224,28 @@ __device__ __forceinline__ bool n3_newton_step_pk(Pairs &&pairs, float s1, float
         if (S.iters >= N3_MAX_ITERS) S.status = 2;
         return true;
     }
-    const double G1 = (double)(g1.x + g1.y), G2 = (double)(g2.x + g2.y);
-    const double H11 = (double)(h11.x + h11.y), H12 = (double)(h12.x + h12.y), H22 = (double)(h22.x + h22.y);
-    const double hh = H11 * H22;
-    const double det = hh - H12 * H12;
-#ifndef N3_COND_MIN
-#define N3_COND_MIN 1e-3
-#endif
-    if (!(det > N3_COND_MIN * hh)) return false;
+    // 2x2 solve in single precision as well: det > 1e-3 h11 h22 bounds the cancellation (relative error <= ~1e-4
+    // in the step, irrelevant for a pass that only has to reach lambda^2 < conv_l2)
+    const float G1 = g1.x + g1.y, G2 = g2.x + g2.y;
+    const float H11 = h11.x + h11.y, H12 = h12.x + h12.y, H22 = h22.x + h22.y;
+    const float hh = H11 * H22;
+    const float det = __builtin_fmaf(-H12, H12, hh);
+    if (!(det > (float)N3_COND_MIN * hh)) return false;
     S.singular = false;
-    double idet = rcp_nr2(det);
-    double d1 = (H22 * G1 - H12 * G2) * idet;
-    double d2 = (H11 * G2 - H12 * G1) * idet;
-    double l2 = (G1 * d1 + G2 * d2) * inv_Rtot;
-    if (!(l2 == l2) || !(fabs(d1) + fabs(d2) < 1e30)) {
+    const float idet = __builtin_amdgcn_rcpf(det);
+    const float d1 = (H22 * G1 - H12 * G2) * idet;
+    const float d2 = (H11 * G2 - H12 * G1) * idet;
+    const float l2 = (G1 * d1 + G2 * d2) * (float)inv_Rtot;
+    if (!(l2 == l2) || !(fabsf(d1) + fabsf(d2) < 1e30f)) {
         S.status = 2;
         return true;
     }
-    double step = 1.0;
-    if (l2 > 0.09) step = 1.0 / (1.0 + sqrt(l2));
+    float step = 1.0f;
+    if (l2 > 0.09f) step = __builtin_amdgcn_rcpf(1.0f + __builtin_sqrtf(l2));
     S.p1 = S.u1; S.p2 = S.u2;
-    S.u1 = __builtin_fma(step, d1, S.u1);
-    S.u2 = __builtin_fma(step, d2, S.u2);
-    if (l2 < conv_l2) S.status = 1;
+    S.u1 = (double)__builtin_fmaf(step, d1, u1);
+    S.u2 = (double)__builtin_fmaf(step, d2, u2);
+    if (l2 < (float)conv_l2) S.status = 1;
     else if (S.iters >= N3_MAX_ITERS || fabs(S.u1) + fabs(S.u2) > 1e8) S.status = 2;
     return true;
 }

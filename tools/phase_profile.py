@@ -1,13 +1,20 @@
+"""In-kernel phase breakdown of the n=3 search on the bench workload (three rank ranges, best of 4 launches each)."""
 import sys,os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench, theta_amd, numpy as np
 ctx=theta_amd.Context(0); r,rN,order=bench.synth()
 p=theta_amd.Problem(ctx,3,50,2,r,rN,[0]*50,[6]*50,1.0)
 tot=p.count
-for rep in range(2):
+tms=[]
+for rep in range(3):
     b=tot//3+rep*(tot//7)
-    res=p.search(b,b+(1<<27),window=0.5); st=res['stats']
-    pc=st['phase_cycles']; tw=pc[5]
-    print('kernel_ms %.1f  C/s %.3g iters %.2f terms/it %.1f'%(st['kernel_ms'], st['evaluated']/st['kernel_ms']*1e3, st['iterations']/st['evaluated'], st['terms']/st['iterations']))
-    print('  unrank %.1f%%  prefixes/wave %.1f leaves/prefix %.0f'%(100*pc[6]/tw, pc[7]/ (st['evaluated']/16384.0), st['evaluated']/max(pc[7],1)))
-    print('  phases%%: group %.1f scan %.1f newton %.1f values %.1f successor %.1f  (cycles/cand %.0f)'%tuple([100*x/tw for x in pc[:5]]+[tw/st['evaluated']]))
+    best=None
+    for it in range(4):
+        res=p.search(b,b+(1<<27),window=0.5); st=res['stats']
+        if best is None or st['kernel_ms']<best['kernel_ms']: best=st
+    st=best; pc=st['phase_cycles']; tw=pc[5]
+    tms.append(st['kernel_ms'])
+    print('kernel_ms %.2f  C/s %.3g iters %.2f terms/it %.1f  | phases%%: group %.1f scan %.1f newton %.1f values %.1f unrank %.1f | cycles/cand %.0f'%(
+        st['kernel_ms'], st['evaluated']/st['kernel_ms']*1e3, st['iterations']/st['evaluated'], st['terms']/st['iterations'],
+        *[100*x/tw for x in (pc[0],pc[1],pc[2],pc[3],pc[6])], tw/st['evaluated']))
+print('mean kernel_ms %.2f'%np.mean(tms))
