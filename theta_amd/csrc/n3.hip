@@ -677,28 +677,15 @@ __global__ __launch_bounds__(64 * N3_WAVES, N3_OCC) void n3_search_kernel(N3Dev 
         for (unsigned long long done = 0; done < nleaf;) {
             const unsigned long long ts0 = __builtin_readcyclecounter();
             int qcount = 0;
-            // Every lane produces up to N3_QCAP/64 leaves of its chunk.  One DFS micro-step per lane per trip, all
-            // lanes in the same straight-line code: take the next sibling (a leaf at the last level), or descend
-            // (one LUT read + one mask read), or pop a level.
+            // Every lane with leaves left takes ONE DFS micro-step per trip, all lanes in the same straight-line code: take
+            // the next sibling (at the last level: a leaf, which it emits), or descend (one LUT read + one mask read), or
+            // pop a level.  Emitting lanes get consecutive queue slots, trip after trip, until fewer than 64 slots are
+            // free -- no per-lane quota, so no lane waits for the ones that have to pop and descend.
             {
-                const int want = (my_left < (unsigned long long)(N3_QCAP / WAVE)) ? (int)my_left : N3_QCAP / WAVE;
-                const unsigned long long wmask = ballot64(want > 0);
-                // queue slots: lanes in order, `want` consecutive entries each
-                int posb = 0;
-                {
-                    int v = want;   // exclusive prefix sum over lanes
-#pragma unroll
-                    for (int o = 1; o < WAVE; o <<= 1) {
-                        int t = __shfl_up(v, o, WAVE);
-                        if (lane >= o) v += t;
-                    }
-                    posb = v - want;
-                    qcount = __shfl(v, WAVE - 1, WAVE);
-                }
-                (void)wmask;
-                int produced = 0;
-                bool adv = want > 0;
-                while (ballot64(adv)) {
+                bool adv = my_left > 0;
+                while (qcount + WAVE <= N3_QCAP && ballot64(adv)) {
+                    bool emit = false;
+                    unsigned rw = 0;
                     if (adv) {
                         if (mcur == 0ull) {                    // level exhausted: pop
                             lv--;
@@ -713,14 +700,8 @@ __global__ __launch_bounds__(64 * N3_WAVES, N3_OCC) void n3_search_kernel(N3Dev 
                             const int s = __builtin_ctzll(mcur);
                             mcur &= mcur - 1;
                             if (lv == L - 1) {                 // a leaf
-                                const unsigned rw = S.rowtab[s];
-                                qCode[posb + produced] = (code & ~(0xffull << (8 * lv))) | ((unsigned long long)rw << (8 * lv));
-                                qOff[posb + produced] = (unsigned short)my_rel;
-                                qSrc[posb + produced] = (unsigned char)lane;
-                                my_rel++;
-                                my_left--;
-                                produced++;
-                                adv = produced < want;
+                                rw = S.rowtab[s];
+                                emit = true;
                             } else {                           // descend into child s
                                 N3State ch = child_state(cur, s);
                                 W.stkS[lv][lane] = n3_pack(ch);
@@ -732,6 +713,17 @@ __global__ __launch_bounds__(64 * N3_WAVES, N3_OCC) void n3_search_kernel(N3Dev 
                             }
                         }
                     }
+                    const unsigned long long em = ballot64(emit);
+                    if (emit) {
+                        const int pos = qcount + mbcnt(em);
+                        qCode[pos] = (code & ~(0xffull << (8 * (L - 1)))) | ((unsigned long long)rw << (8 * (L - 1)));
+                        qOff[pos] = (unsigned short)my_rel;
+                        qSrc[pos] = (unsigned char)lane;
+                        my_rel++;
+                        my_left--;
+                        adv = my_left > 0;
+                    }
+                    qcount += __builtin_popcountll(em);
                 }
             }
             done += (unsigned long long)qcount;
@@ -981,13 +973,10 @@ __global__ __launch_bounds__(64 * N3_WAVES, N3_OCC) void n3_search_kernel(N3Dev 
                             if (nll < best) atomicMin(&A.ctr->best_bits, order_bits(nll));
                         }
                     }
-                    if (accept) {   // remember it for the next leaf of the same chunk (the last entry of a lane wins)
+                    if (accept) {   // remember it for the next leaves of the same chunk (within a batch any of a chunk's entries may win)
                         const int src = qSrc[idx];
-                        const bool last_of_src = (idx + 1 >= qcount) || (qSrc[idx + 1] != src);
-                        if (last_of_src) {
-                            lastN1[src] = (float)(s1 * u1);
-                            lastN2[src] = (float)(s2 * u2);
-                        }
+                        lastN1[src] = (float)(s1 * u1);
+                        lastN2[src] = (float)(s2 * u2);
                     }
                     // wave-wide (only when some lane holds an exact contender): new minimum, warm start for chunk starts
                     const bool cand = accept && contender;
