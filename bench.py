@@ -240,7 +240,7 @@ def main():
                          "achieved": ach, "peak": peak, "unit": "TFLOP/s",
                          "frac": ach / peak, "traffic": traffic,
                          "fp64_flop_share": f64 / max(f64 + f32, 1.0),
-                         "kernel": "n3_search_kernel<5,false>", "kernel_ms_per_launch": k_ms / launches,
+                         "kernel": "n3_search_kernel<6,false>", "kernel_ms_per_launch": k_ms / launches,
                          "flop_per_candidate": (f64 + f32) / max(allv[0, 0], 1.0),
                          "newton_iters_per_candidate": allv[0, 5] / max(allv[0, 0], 1.0),
                          "terms_per_iteration": allv[0, 4] / max(allv[0, 5], 1.0),

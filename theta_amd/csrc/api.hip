@@ -268,7 +268,7 @@ extern "C" int theta_problem_create(theta_ctx *ctx, int n, int m, int tau, const
         D.Q = h.Q;
         D.tau = tau;
         D.NT = h.NT;
-        int L = 5;   // leaf levels enumerated by the lanes (tuned on MI355X)
+        int L = 6;   // leaf levels enumerated by the lanes (tuned on MI355X for K = 3..6)
         if (const char *e = getenv("THETA_N3_LEAF_LEVELS")) {
             int v = atoi(e);
             if (v >= 1 && v <= 6) L = v;

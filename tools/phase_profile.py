@@ -2,8 +2,10 @@
 import sys,os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench, theta_amd, numpy as np
-ctx=theta_amd.Context(0); r,rN,order=bench.synth()
-p=theta_amd.Problem(ctx,3,50,2,r,rN,[0]*50,[6]*50,1.0)
+M=int(sys.argv[1]) if len(sys.argv)>1 else 50
+K=int(sys.argv[2]) if len(sys.argv)>2 else 6
+ctx=theta_amd.Context(0); r,rN,order=bench.synth(m=M,n=3,k=K) if (M,K)!=(50,6) else bench.synth()
+p=theta_amd.Problem(ctx,3,M,2,r,rN,[0]*M,[K]*M,1.0)
 tot=p.count
 tms=[]
 for rep in range(3):
@@ -17,4 +19,4 @@ for rep in range(3):
     print('kernel_ms %.2f  C/s %.3g iters %.2f terms/it %.1f  | phases%%: group %.1f scan %.1f newton %.1f values %.1f unrank %.1f | cycles/cand %.0f'%(
         st['kernel_ms'], st['evaluated']/st['kernel_ms']*1e3, st['iterations']/st['evaluated'], st['terms']/st['iterations'],
         *[100*x/tw for x in (pc[0],pc[1],pc[2],pc[3],pc[6])], tw/st['evaluated']))
-print('mean kernel_ms %.2f'%np.mean(tms))
+print('mean kernel_ms %.2f  prefixes/wave %.1f'%(np.mean(tms), pc[7]/(st['evaluated']/8192.0)))
