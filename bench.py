@@ -112,7 +112,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=1 << 27, help="candidates per step per GPU")
+    ap.add_argument("--batch", type=int, default=1 << 31, help="candidates per step per GPU (one theta_search call)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()

@@ -394,7 +394,10 @@ static int run_search(theta_problem *p, u128 b, u128 e, double window, double *d
             n2_launch_search(p->n2, A, nb, ne, (int)per, st);
         } else {
             u128 cnt = e - b;
-            uint64_t per_task = 8192;    // candidates per wave task (each lane walks ~128 consecutive leaves); tuned, DESIGN.md
+            // candidates per wave task: 8192 for launches up to 2^29 candidates, growing to 32768 so that a launch has
+            // ~65536 tasks (about 21 per resident wave: a short tail, and a cheap task set-up); tuned, DESIGN.md
+            uint64_t per_task = 8192;
+            while (per_task < 32768 && (u128)per_task * 65536u < cnt) per_task <<= 1;
             if (const char *e = getenv("THETA_N3_PER_TASK")) {
                 long long v = atoll(e);
                 if (v >= 64 && v <= 65535) per_task = (uint64_t)v;   // the kernel keeps in-task offsets in 16 bits
