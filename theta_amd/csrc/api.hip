@@ -278,6 +278,8 @@ extern "C" int theta_problem_create(theta_ctx *ctx, int n, int m, int tau, const
         D.warm_blend = 0.9;
         D.conv_l2 = 1e-4;    // first-pass threshold on the squared decrement before the last step (contenders are polished)
         if (const char *e = getenv("THETA_N3_WARM_BLEND")) D.warm_blend = atof(e);
+        D.force64 = 0;
+        if (const char *e = getenv("THETA_N3_FORCE_F64")) D.force64 = atoi(e) != 0;
         if (const char *e = getenv("THETA_N3_CONV_L2")) D.conv_l2 = atof(e);
         D.N = (double)N;
         D.Rtot = (double)Rt;

@@ -742,7 +742,8 @@ __global__ __launch_bounds__(64 * N3_WAVES, N3_OCC) void n3_search_kernel(N3Dev 
                 double s1 = 1.0, s2 = 1.0;
                 N3Newton Sv;
                 Sv.status = 0;
-                bool use64 = DUMP;      // FP64 iterations: the dump, and candidates whose Hessian f32 sums cannot resolve
+                const bool all64 = DUMP || P.force64 != 0;
+                bool use64 = all64;     // FP64 iterations: the dump, and candidates whose Hessian f32 sums cannot resolve
                 auto terms = [&](auto &&body) {
 #pragma unroll 4
                     for (int g = 0; g < G; g++) body(gX[g], gY[g], gR[g]);
@@ -816,7 +817,7 @@ __global__ __launch_bounds__(64 * N3_WAVES, N3_OCC) void n3_search_kernel(N3Dev 
                                 Sv.iters = 0;
                                 Sv.status = 0;
                                 Sv.singular = false;
-                                use64 = DUMP;
+                                use64 = all64;
                             }
                         }
                     }

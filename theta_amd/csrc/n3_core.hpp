@@ -24,6 +24,7 @@ struct N3Dev {
     const unsigned long long *dynmask; // [Q][NT+1][NT+1] slots that keep the ratio window [lo,hi] non-empty after a parent row
     unsigned long long swmask;       // slots with a <= b
     double warm_blend;           // weight of the previous optimum in the warm start (rest: simplex centre)
+    int force64;                 // 1: iterate every candidate in FP64 (THETA_N3_FORCE_F64; the packed-f32 pass is the default)
     double conv_l2;              // convergence threshold on the squared Newton decrement
     unsigned long long total_lo, total_hi;
 };
