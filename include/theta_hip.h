@@ -147,6 +147,14 @@ int theta_search_values(theta_problem *p, const uint64_t rank_begin[2], uint64_t
 int theta_enumerate(theta_problem *p, const uint64_t rank_begin[2], uint64_t count, uint8_t *out);
 
 /*
+ * Same candidates, written to DEVICE memory the caller owns (count * m * (n-1) bytes at d_out, a HIP device pointer
+ * on the context's GPU), for consumers that stay on the GPU (theta_score_masked, a caller's own kernels).
+ * kernel_ms (may be NULL) receives the HIP-event duration of the enumeration kernels.  No reference counterpart
+ * beyond generate_next_C itself (Enumerator.py:74-87): this is the generator without the PCIe copy.
+ */
+int theta_enumerate_device(theta_problem *p, const uint64_t rank_begin[2], uint64_t count, void *d_out, double *kernel_ms);
+
+/*
  * Per-candidate solve in the reference's own arithmetic order (per-interval sums, the brenth
  * iteration for n=2): replaces Optimizer.solve(C) (Optimizer.py:68-165) for a batch of B
  * materialised candidates C[B*m*(n-1)].

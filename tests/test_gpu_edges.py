@@ -158,3 +158,42 @@ def test_ranges_beyond_one_call_are_walked_in_pieces(ctx):
     assert pieces["rank"] == whole["rank"]
     assert np.array_equal(pieces["nll"], whole["nll"]) and np.array_equal(pieces["C"], whole["C"])
     assert pieces["stats"]["evaluated"] == whole["stats"]["evaluated"] == p.count
+
+
+def test_enumerate_all_shapes_and_the_device_variant(ctx):
+    """
+    The wave-cooperative generator against the oracle's enumeration: even and odd m (32-bit and 16-bit store paths),
+    a prefix shorter than a store word, ranges that start and end inside a prefix, requests of several tasks --
+    and theta_enumerate_device (same bytes, written to device memory the caller owns; here from hipMalloc via ctypes).
+    """
+    import ctypes as C
+    import theta_amd
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    hip.hipMemset.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    hip.hipFree.argtypes = [C.c_void_p]
+    rng = np.random.RandomState(99)
+    for (m, k) in [(7, 2), (8, 2), (9, 3), (10, 2), (11, 2)]:
+        r = rng.randint(1000, 5000, m).tolist()
+        rN = rng.randint(1000, 5000, m).tolist()
+        lb, ub = [0] * m, [k] * m
+        ref = np.array(list(orc.enumerate_n3(m, 2, lb, ub)), dtype=np.uint8)
+        p = theta_amd.Problem(ctx, 3, m, 2, r, rN, lb, ub, 1.0)
+        assert p.count == len(ref)
+        assert np.array_equal(p.enumerate(0, p.count), ref)
+        for b, c in [(1, 1), (p.count // 3, min(20000, p.count - p.count // 3)), (p.count - 2, 2)]:
+            assert np.array_equal(p.enumerate(b, c), ref[b:b + c])
+        nbytes = p.count * m * 2 + 64
+        dptr = C.c_void_p()
+        assert hip.hipMalloc(C.byref(dptr), nbytes) == 0
+        try:
+            assert hip.hipMemset(dptr, 0xEE, nbytes) == 0
+            ms = p.enumerate_device(5, p.count - 9, dptr.value + 16)
+            assert ms > 0
+            got = np.zeros(nbytes, np.uint8)
+            assert hip.hipMemcpy(got.ctypes.data_as(C.c_void_p), dptr, nbytes, 2) == 0          # device -> host
+        finally:
+            hip.hipFree(dptr)
+        assert (got[:16] == 0xEE).all() and (got[16 + (p.count - 9) * m * 2:] == 0xEE).all()       # nothing outside
+        assert np.array_equal(got[16:16 + (p.count - 9) * m * 2].reshape(-1, m, 2), ref[5:p.count - 4])

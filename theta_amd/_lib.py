@@ -43,7 +43,7 @@ _lib = None
 
 # every symbol include/theta_hip.h declares
 EXPORTS = ["theta_create", "theta_destroy", "theta_last_error", "theta_device_info", "theta_problem_create",
-           "theta_problem_destroy", "theta_problem_count", "theta_search", "theta_search_values", "theta_enumerate",
+           "theta_problem_destroy", "theta_problem_count", "theta_search", "theta_search_values", "theta_enumerate", "theta_enumerate_device",
            "theta_solve_batch", "theta_score_batch", "theta_score_masked", "theta_search_suspects", "theta_boundary_min", "theta_problem_hint"]
 
 
@@ -70,6 +70,7 @@ def load():
     lib.theta_search.argtypes = [vp, u64p, u64p, C.c_double, i32, dp, dp, u64p, u8p, C.POINTER(i32), C.POINTER(SearchStats)]
     lib.theta_search_values.argtypes = [vp, u64p, C.c_uint64, dp, dp, C.POINTER(SearchStats)]
     lib.theta_enumerate.argtypes = [vp, u64p, C.c_uint64, u8p]
+    lib.theta_enumerate_device.argtypes = [vp, u64p, C.c_uint64, vp, dp]
     lib.theta_search_suspects.argtypes = [vp, i32, u64p, dp, u8p, C.POINTER(i32)]
     lib.theta_boundary_min.argtypes = [vp, i32, i32, i64p, i64p, i32, u8p, dp]
     lib.theta_problem_hint.argtypes = [vp, C.c_double]
@@ -338,3 +339,10 @@ class Problem:
         out = np.zeros(int(count) * self.m * (self.n - 1), np.uint8)
         _check(load().theta_enumerate(self._h, _u128(begin), int(count), _p(out, C.c_uint8)))
         return self._shape_C(out, int(count))
+
+    def enumerate_device(self, begin, count, device_ptr):
+        """Same candidates written to device memory (`device_ptr`: address of count*m*(n-1) bytes on this GPU,
+        e.g. torch_tensor.data_ptr()).  Returns the kernels' duration in ms."""
+        ms = C.c_double(0.0)
+        _check(load().theta_enumerate_device(self._h, _u128(begin), int(count), C.c_void_p(int(device_ptr)), C.byref(ms)))
+        return ms.value

@@ -24,7 +24,8 @@ void n3_launch_tasks(const N3Dev &P, u128 begin, u128 end, uint64_t per_task, in
 void n3_launch_search(const N3Dev &P, const SearchArgs &A, const N3Task *tasks, const unsigned *stbuf, int ntasks,
                       uint64_t per_task, hipStream_t st);
 void n3_launch_unrank_list(const N3Dev &P, const TieRecord *recs, int count, unsigned char *out, hipStream_t st);
-void n3_launch_enumerate(const N3Dev &P, u128 begin, unsigned long long count, unsigned char *out, hipStream_t st);
+void n3_launch_enumerate(const N3Dev &P, const N3Task *tasks, const unsigned *stbuf, int ntasks, uint64_t per_task,
+                         unsigned char *out, hipStream_t st);
 
 void batch_launch_solve(int n, int m, int tau, const double *r, const double *rN, double max_normal, int B,
                         const unsigned char *C, unsigned char *ok, double *mu, double *nll, double *vals,
@@ -675,14 +676,52 @@ extern "C" int theta_boundary_min(theta_ctx *ctx, int m, int tau, const int64_t 
     return THETA_OK;
 }
 
-extern "C" int theta_enumerate(theta_problem *p, const uint64_t rank_begin[2], uint64_t count, uint8_t *out) {
+// candidates [b, b + count) into DEVICE memory; kernel_ms (optional): HIP-event time of the kernels on the stream
+static int enumerate_device(theta_problem *p, u128 b, uint64_t count, unsigned char *d_out, double *kernel_ms) {
+    theta_ctx *ctx = p->ctx;
+    hipStream_t st = ctx->stream;
+    const size_t cb = (size_t)p->m * (p->n - 1);
+    HIP_TRY(hipEventRecord(ctx->ev1, st));
+    if (p->n == 2) {
+        n2_launch_enumerate(p->n2, (unsigned long long)b, count, d_out, st);
+    } else {
+        // a wave task unranks 64 chunk starts per prefix (random reads of the counting table): fewer, longer tasks
+        // for big requests, but always enough of them (~8192) to fill the chip
+        uint64_t per_task = 8192;
+        while (per_task < 65536 && per_task * 8192 < count) per_task <<= 1;
+        const uint64_t piece = (uint64_t)N3_MAX_TASKS * per_task;
+        for (uint64_t off = 0; off < count; off += piece) {
+            const uint64_t c = std::min<uint64_t>(piece, count - off);
+            const int ntasks = (int)((c + per_task - 1) / per_task);
+            n3_launch_tasks(p->n3, b + off, b + off + c, per_task, ntasks, (N3Task *)p->d_tasks.p, (unsigned *)p->d_stbuf.p, st);
+            n3_launch_enumerate(p->n3, (const N3Task *)p->d_tasks.p, (const unsigned *)p->d_stbuf.p, ntasks, per_task,
+                                d_out + (size_t)off * cb, st);
+        }
+    }
+    HIP_TRY(hipEventRecord(ctx->ev2, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(hipGetLastError());
+    if (kernel_ms) {
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, ctx->ev1, ctx->ev2));
+        *kernel_ms = ms;
+    }
+    return THETA_OK;
+}
+
+static int enumerate_args(theta_problem *p, const uint64_t rank_begin[2], uint64_t count, u128 &b) {
     uint64_t re[2];
     u128 b0 = rank_begin ? mk128(rank_begin) : 0;
     u128 e0 = b0 + count;
     re[0] = (uint64_t)e0;
     re[1] = (uint64_t)(e0 >> 64);
-    u128 b, e;
-    int rc = check_range(p, rank_begin, re, b, e);
+    u128 e;
+    return check_range(p, rank_begin, re, b, e);
+}
+
+extern "C" int theta_enumerate(theta_problem *p, const uint64_t rank_begin[2], uint64_t count, uint8_t *out) {
+    u128 b;
+    int rc = enumerate_args(p, rank_begin, count, b);
     if (rc) return rc;
     if (count == 0) return THETA_OK;
     if (!out) {
@@ -690,17 +729,30 @@ extern "C" int theta_enumerate(theta_problem *p, const uint64_t rank_begin[2], u
         return THETA_ERR_ARG;
     }
     HIP_TRY(hipSetDevice(p->ctx->device));
-    hipStream_t st = p->ctx->stream;
     size_t cb = (size_t)p->m * (p->n - 1);
     DevBuf d_C;
     rc = d_C.alloc(count * cb);
     if (rc) return rc;
-    if (p->n == 2) n2_launch_enumerate(p->n2, (unsigned long long)b, count, (unsigned char *)d_C.p, st);
-    else n3_launch_enumerate(p->n3, b, count, (unsigned char *)d_C.p, st);
-    HIP_TRY(hipMemcpyAsync(out, d_C.p, count * cb, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    HIP_TRY(hipGetLastError());
+    rc = enumerate_device(p, b, count, (unsigned char *)d_C.p, nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(out, d_C.p, count * cb, hipMemcpyDeviceToHost, p->ctx->stream));
+    HIP_TRY(hipStreamSynchronize(p->ctx->stream));
     return THETA_OK;
+}
+
+extern "C" int theta_enumerate_device(theta_problem *p, const uint64_t rank_begin[2], uint64_t count, void *d_out,
+                                      double *kernel_ms) {
+    u128 b;
+    int rc = enumerate_args(p, rank_begin, count, b);
+    if (rc) return rc;
+    if (kernel_ms) *kernel_ms = 0.0;
+    if (count == 0) return THETA_OK;
+    if (!d_out) {
+        theta_set_error("null output");
+        return THETA_ERR_ARG;
+    }
+    HIP_TRY(hipSetDevice(p->ctx->device));
+    return enumerate_device(p, b, count, (unsigned char *)d_out, kernel_ms);
 }
 
 // ---- materialised operators -----------------------------------------------------------------------

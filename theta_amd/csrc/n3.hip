@@ -277,22 +277,6 @@ __global__ __launch_bounds__(256) void n3_unrank_list_kernel(N3Dev P, const TieR
     }
 }
 
-__global__ __launch_bounds__(64) void n3_enumerate_kernel(N3Dev P, uint64_t b_lo, uint64_t b_hi, unsigned long long count,
-                                                          unsigned char *out) {
-    unsigned long long k = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= count) return;
-    const u128 begin = ((u128)b_hi << 64) | b_lo;
-    N3State st[N3_MAX_M];
-    u128 rem;
-    bool ok = n3_unrank(P, begin + k, P.m, st, rem);
-    unsigned char *dst = out + (size_t)k * P.m * 2;
-    int K1 = P.K + 1;
-    for (int i = 0; i < P.m; i++) {
-        dst[2 * i] = ok ? (unsigned char)(st[i].slot % K1) : 255;
-        dst[2 * i + 1] = ok ? (unsigned char)(st[i].slot / K1) : 255;
-    }
-}
-
 // ------------------------------------------------------------------------------------------------
 // the fused search kernel
 // ------------------------------------------------------------------------------------------------
@@ -1093,6 +1077,258 @@ __global__ __launch_bounds__(64 * N3_WAVES, N3_OCC) void n3_search_kernel(N3Dev 
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// materialised generator (theta_enumerate): the search kernel's enumeration without the solver
+// ------------------------------------------------------------------------------------------------
+// One wave per rank range (the same tasks as the search).  The prefix rows are wave-uniform and staged once per prefix in
+// LDS as 16-bit rows {a, b}; each lane walks its chunk of the leaves with the mask-driven DFS and writes its candidates'
+// 2 m bytes itself: 32-bit stores (prefix words straight from LDS) when 2 m is a multiple of 4, 16-bit stores otherwise.
+// HBM bound: 2 m bytes written per candidate, nothing read but the 173 MB counting table at chunk starts.
+typedef unsigned n3_u4v __attribute__((ext_vector_type(4)));
+typedef n3_u4v N3U4 __attribute__((aligned(4)));   // a 16-byte store that is only 4-byte aligned
+
+template <int L>
+struct N3EnumLds {
+    struct {
+        alignas(16) unsigned short pre[N3_MAX_M + 8];       // rows of the prefix, a | b << 8
+        unsigned stkS[L > 1 ? L - 1 : 1][WAVE];
+        unsigned long long stkM[L > 1 ? L - 1 : 1][WAVE];
+    } w[N3_WAVES];
+    unsigned long long smask[N3_MAX_L][N3_MAX_Q];
+    unsigned char lb[N3_MAX_M], ub[N3_MAX_M];
+    unsigned char ridx[N3_RIDX_W * N3_RIDX_W + 3];
+    unsigned char rowtab[N3_MAX_Q + 3];
+};
+
+template <int L>
+__global__ __launch_bounds__(64 * N3_WAVES) void n3_enumerate_wave_kernel(N3Dev Pg, const N3Task *tasks, const unsigned *stbuf,
+                                                                          int ntasks, uint64_t per_task, unsigned char *out) {
+    __shared__ N3EnumLds<L> S;
+    const int m = Pg.m, D = m - L, Q = Pg.Q;
+    for (int i = threadIdx.x; i < m; i += blockDim.x) {
+        S.lb[i] = Pg.lb[i];
+        S.ub[i] = Pg.ub[i];
+    }
+    for (int i = threadIdx.x; i < N3_RIDX_W * N3_RIDX_W; i += blockDim.x) S.ridx[i] = Pg.ridx[i];
+    for (int i = threadIdx.x; i < Q; i += blockDim.x) S.rowtab[i] = Pg.rowtab[i];
+    for (int i = threadIdx.x; i < L * N3_MAX_Q; i += blockDim.x) (&S.smask[0][0])[i] = Pg.smask[(size_t)D * N3_MAX_Q + i];
+    __syncthreads();
+    N3Dev P = Pg;
+    P.lb = S.lb;
+    P.ub = S.ub;
+    P.ridx = S.ridx;
+
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int task = blockIdx.x * N3_WAVES + wv;
+    if (task >= ntasks) return;
+    auto &W = S.w[wv];
+    const unsigned long long swm = Pg.swmask;
+    const int NT1 = Pg.NT + 1;
+    unsigned st = lane < D ? stbuf[(size_t)task * N3_MAX_M + lane] : 0u;
+    const int K1 = P.K + 1;
+    const int sa0 = lane % K1, sb0 = lane / K1, sa1 = (lane + WAVE) % K1, sb1 = (lane + WAVE) / K1;
+    const N3Task tk = tasks[task];
+    unsigned long long remaining = tk.count, skip = tk.skip, processed = 0;
+    const size_t RS = (size_t)m * 2;                                      // bytes per candidate
+    unsigned char *const obase = out + (size_t)task * per_task * RS;     // tasks are consecutive rank ranges of per_task
+    const bool words = (RS & 3) == 0;
+
+    auto child_mask = [&](const N3State &node, int l) -> unsigned long long {
+        unsigned long long mk = S.smask[l][node.slot] & Pg.dynmask[((size_t)node.slot * NT1 + node.lo) * NT1 + (node.hi - 1)];
+        return node.sw ? (mk & swm) : mk;
+    };
+    auto child_state = [&](const N3State &node, int s) -> N3State {
+        N3State ch;
+        n3_child_dyn(S.ridx, S.rowtab, node, s, ch);
+        return ch;
+    };
+    auto leaf_row = [&](unsigned long long code, int l) -> unsigned {     // row l of the leaf levels as a | b << 8
+        unsigned rw = (unsigned)(code >> (8 * l)) & 0xffu;
+        return (rw & 15u) | ((rw >> 4) << 8);
+    };
+
+    while (remaining > 0) {
+        if (lane < D) W.pre[lane] = (unsigned short)(((st >> 24) & 15u) | ((st >> 28) << 8));
+        wave_lds_sync();
+        const N3State par = n3_unpack((unsigned)__builtin_amdgcn_readlane((int)st, D - 1));
+        unsigned long long T;
+        {
+            u128 tv = Pg.cnt[n3_cnt_index(Pg, D - 1, par.slot, par.sw, par.lo, par.hi)];
+            T = (tv >> 64) ? ~0ull : (unsigned long long)tv;
+        }
+        const unsigned long long lo_idx = skip < T ? skip : T;
+        const unsigned long long hi_idx = (T - lo_idx > remaining) ? lo_idx + remaining : T;
+        const unsigned long long nleaf = hi_idx - lo_idx;
+        const unsigned long long chunk = (nleaf + WAVE - 1) / WAVE;
+        const unsigned long long my_first = (unsigned long long)lane * chunk;
+        unsigned long long my_left = my_first < nleaf ? ((nleaf - my_first < chunk) ? nleaf - my_first : chunk) : 0;
+        unsigned long long my_rel = processed + my_first;
+        unsigned long long code = 0, mcur = 0;
+        N3State cur = par;
+        int lv = L - 1;
+        if (my_left > 0) {   // unrank the first leaf of the lane's chunk
+            unsigned long long idx = lo_idx + my_first;
+            bool okp = true;
+            for (int l = 0; l < L && okp; l++) {
+                unsigned long long mk = child_mask(cur, l);
+                bool found = false;
+                if (l == L - 1) {
+                    while (mk && idx > 0) {
+                        mk &= mk - 1;
+                        idx--;
+                    }
+                    found = mk != 0ull;
+                    mcur = mk;
+                } else {
+                    while (mk) {
+                        int s = __builtin_ctzll(mk);
+                        mk &= mk - 1;
+                        N3State ch = child_state(cur, s);
+                        unsigned long long cv;
+                        if (l == L - 2) {   // children of ch are leaves: count them from the masks (L2-resident table) instead
+                            cv = (unsigned long long)__builtin_popcountll(child_mask(ch, L - 1));   // of the 173 MB one
+                        } else {
+                            u128 tv = Pg.cnt[n3_cnt_index(Pg, D + l, ch.slot, ch.sw, ch.lo, ch.hi)];
+                            cv = (tv >> 64) ? ~0ull : (unsigned long long)tv;
+                        }
+                        if (idx < cv) {
+                            found = true;
+                            W.stkS[l][lane] = n3_pack(ch);
+                            W.stkM[l][lane] = mk;
+                            code |= (unsigned long long)(ch.a | (ch.b << 4)) << (8 * l);
+                            cur = ch;
+                            break;
+                        }
+                        idx -= cv;
+                    }
+                }
+                okp = found;
+            }
+            if (!okp) my_left = 0;
+        }
+        bool adv = my_left > 0;
+        while (ballot64(adv)) {
+            bool emit = false;
+            unsigned rw = 0;
+            if (adv) {
+                if (mcur == 0ull) {
+                    lv--;
+                    if (lv < 0) {
+                        my_left = 0;
+                        adv = false;
+                    } else {
+                        mcur = W.stkM[lv][lane];
+                        cur = (lv == 0) ? par : n3_unpack(W.stkS[lv - 1][lane]);
+                    }
+                } else {
+                    const int s = __builtin_ctzll(mcur);
+                    mcur &= mcur - 1;
+                    if (lv == L - 1) {
+                        rw = S.rowtab[s];
+                        emit = true;
+                    } else {
+                        N3State ch = child_state(cur, s);
+                        W.stkS[lv][lane] = n3_pack(ch);
+                        W.stkM[lv][lane] = mcur;
+                        code = (code & ~(0xffull << (8 * lv))) | ((unsigned long long)(ch.a | (ch.b << 4)) << (8 * lv));
+                        cur = ch;
+                        lv++;
+                        mcur = child_mask(ch, lv);
+                    }
+                }
+            }
+            if (emit) {
+                const unsigned long long full = (code & ~(0xffull << (8 * (L - 1)))) | ((unsigned long long)rw << (8 * (L - 1)));
+                unsigned char *dst = obase + (size_t)my_rel * RS;
+                if (words) {
+                    // 16-byte stores (the record is only 4-byte aligned: the hardware takes unaligned multi-dword stores)
+                    unsigned *d32 = (unsigned *)dst;
+                    const unsigned *p32 = (const unsigned *)W.pre;
+                    const int NW = m >> 1, pw = D >> 1, odd = D & 1;     // words per record; words entirely in the prefix
+                    const int pq = pw >> 2;                               // 16-byte chunks entirely in the prefix
+                    for (int c = 0; c < pq; c++) {
+                        const uint4 v = ((const uint4 *)p32)[c];
+                        *(N3U4 *)(d32 + 4 * c) = N3U4{v.x, v.y, v.z, v.w};
+                    }
+                    unsigned t[8];                                        // the rest: <= 3 prefix words, the straddling word, leaf words
+                    const int base = pq << 2, nt = NW - base;
+#pragma unroll
+                    for (int j = 0; j < 8; j++) {
+                        const int w = base + j;
+                        unsigned v = 0;
+                        if (w < pw) v = p32[w];
+                        else if (w < NW) {
+                            const int r0 = 2 * w - D;                     // first leaf row of the word (-1: the straddling word)
+                            const unsigned lo16 = r0 < 0 ? (unsigned)W.pre[D - 1] : leaf_row(full, r0);
+                            v = lo16 | (leaf_row(full, r0 + 1) << 16);
+                        }
+                        t[j] = v;
+                    }
+                    (void)odd;
+                    if (nt >= 4) *(N3U4 *)(d32 + base) = N3U4{t[0], t[1], t[2], t[3]};
+                    const int done4 = nt >= 4 ? 4 : 0;
+#pragma unroll
+                    for (int j = 0; j < 8; j++)
+                        if (j >= done4 && j < nt) d32[base + j] = t[j];
+                } else {
+                    unsigned short *d16 = (unsigned short *)dst;
+                    for (int i = 0; i < D; i++) d16[i] = W.pre[i];
+#pragma unroll
+                    for (int l = 0; l < L; l++) d16[D + l] = (unsigned short)leaf_row(full, l);
+                }
+                my_rel++;
+                my_left--;
+                adv = my_left > 0;
+            }
+        }
+        const unsigned long long consumed = hi_idx - lo_idx;
+        skip -= lo_idx;
+        processed += consumed;
+        remaining -= consumed;
+        if (remaining == 0) break;
+        {   // next prefix in DFS order (wave-uniform) -- same walk as in the search kernel
+            int d = D - 1;
+            bool fresh = false, alive = true;
+            while (true) {
+                int cur_slot = __builtin_amdgcn_readlane((int)st, d) & 0x7f;
+                int start = fresh ? 0 : cur_slot + 1;
+                N3State pst = n3_unpack((unsigned)__builtin_amdgcn_readlane((int)st, d > 0 ? d - 1 : 0));
+                bool found = false;
+                unsigned packed = 0;
+                for (int cb = (start / WAVE) * WAVE; cb < Q && !found; cb += WAVE) {
+                    const int s = cb + lane;
+                    const int ca = cb ? sa1 : sa0, cbb = cb ? sb1 : sb0;
+                    N3State nx;
+                    bool ok = s >= start && s < Q &&
+                              (d == 0 ? n3_first_row_ab(P, ca, cbb, s, nx) : n3_edge_ab(P, pst, ca, cbb, s, d, nx));
+                    unsigned long long mk = ballot64(ok);
+                    if (mk) {
+                        int first = __builtin_ctzll(mk);
+                        unsigned mine = ok ? n3_pack(nx) : 0u;
+                        packed = (unsigned)__builtin_amdgcn_readlane((int)mine, first);
+                        found = true;
+                    }
+                }
+                if (found) {
+                    if (lane == d) st = packed;
+                    if (d == D - 1) break;
+                    d++;
+                    fresh = true;
+                } else {
+                    d--;
+                    fresh = false;
+                    if (d < 0) {
+                        alive = false;
+                        break;
+                    }
+                }
+            }
+            if (!alive) break;
+        }
+        wave_lds_sync();   // the prefix rows in LDS are rewritten next
+    }
+}
 // ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------
@@ -1127,7 +1363,13 @@ void n3_launch_unrank_list(const N3Dev &P, const TieRecord *recs, int count, uns
     hipLaunchKernelGGL(n3_unrank_list_kernel, dim3((count + 3) / 4), dim3(256), 0, st, P, recs, count, out);
 }
 
-void n3_launch_enumerate(const N3Dev &P, u128 begin, unsigned long long count, unsigned char *out, hipStream_t st) {
-    hipLaunchKernelGGL(n3_enumerate_kernel, dim3((unsigned)((count + 63) / 64)), dim3(64), 0, st, P, (uint64_t)begin,
-                       (uint64_t)(begin >> 64), count, out);
+void n3_launch_enumerate(const N3Dev &P, const N3Task *tasks, const unsigned *stbuf, int ntasks, uint64_t per_task,
+                         unsigned char *out, hipStream_t st) {
+    dim3 grid((ntasks + N3_WAVES - 1) / N3_WAVES), block(64 * N3_WAVES);
+#define LAUNCH(LL)                                                                                                      \
+    case LL:                                                                                                            \
+        hipLaunchKernelGGL((n3_enumerate_wave_kernel<LL>), grid, block, 0, st, P, tasks, stbuf, ntasks, per_task, out); \
+        break;
+    switch (P.L) { LAUNCH(1) LAUNCH(2) LAUNCH(3) LAUNCH(4) LAUNCH(5) default: LAUNCH(6) }
+#undef LAUNCH
 }
