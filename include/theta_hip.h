@@ -71,13 +71,16 @@ int theta_problem_count(theta_problem *p, uint64_t count[2]);
 /* Search statistics, all counters are per call. */
 typedef struct theta_search_stats {
     uint64_t evaluated;      /* candidates enumerated and solved                                */
-    uint64_t accepted;       /* candidates with an admissible optimum (Optimizer.solve != None) */
+    uint64_t accepted;       /* candidates with an admissible optimum (Optimizer.solve != None);
+                                n=3 fused search: among the candidates that were not `dismissed`   */
     uint64_t degenerate;     /* candidates with an all-zero tumour column (reference: NaN)      */
     uint64_t iterations;     /* solver iterations summed over candidates                        */
     uint64_t terms;          /* likelihood terms (interval groups) summed over candidates       */
     uint64_t list_overflow;  /* records dropped because the device tie list was full            */
     uint64_t flops;          /* FP64 operations executed by the solver (counted in-kernel)      */
     uint64_t flops_f32;      /* FP32 operations of the n=3 packed coarse pass and screen        */
+    uint64_t dismissed;      /* n=3: candidates finished after one evaluation because a rigorous lower
+                                bound of their optimum lies beyond the window of the running minimum */
     double best_nll;         /* smallest accepted NLL seen by the kernel (fused arithmetic)     */
     double rejected_bound;   /* smallest lower bound on the NLL of any REJECTED candidate       */
     uint64_t rejected_rank[2];

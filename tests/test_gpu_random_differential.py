@@ -102,7 +102,8 @@ def test_n3_packed_f32_pass_and_fp64_iterations_return_the_same_finalists(monkey
         assert np.array_equal(a["C"], b["C"])
         assert np.allclose(a["nll"], b["nll"], rtol=1e-12, atol=0)
         assert np.allclose(a["mu"], b["mu"], rtol=0, atol=1e-9)
-        # the accept COUNT is a statistic of the coarse iterate (only contenders are polished): optima with a nu_j within
-        # ~1e-4 of 0 or 1 may be counted differently by the two arithmetics -- a fraction of a percent on these toy sizes
-        assert abs(int(a["stats"]["accepted"]) - int(b["stats"]["accepted"])) <= 3 + a["stats"]["evaluated"] // 1000
+        # statistics: with FP64 iterations every candidate is solved; the packed pass finishes most of them by the lower
+        # bound of their optimum ("dismissed") and counts admissible optima among the others only
+        assert b["stats"]["dismissed"] == 0 and a["stats"]["dismissed"] > 0
+        assert a["stats"]["accepted"] <= b["stats"]["accepted"] + 3 + a["stats"]["evaluated"] // 1000
         assert sorted(sa[0]) == sorted(sb[0])

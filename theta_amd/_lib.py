@@ -28,7 +28,7 @@ class NoCandidates(ThetaError):
 class SearchStats(C.Structure):
     _fields_ = [("evaluated", C.c_uint64), ("accepted", C.c_uint64), ("degenerate", C.c_uint64),
                 ("iterations", C.c_uint64), ("terms", C.c_uint64), ("list_overflow", C.c_uint64),
-                ("flops", C.c_uint64), ("flops_f32", C.c_uint64), ("best_nll", C.c_double), ("rejected_bound", C.c_double),
+                ("flops", C.c_uint64), ("flops_f32", C.c_uint64), ("dismissed", C.c_uint64), ("best_nll", C.c_double), ("rejected_bound", C.c_double),
                 ("rejected_rank", C.c_uint64 * 2), ("kernel_ms", C.c_double), ("setup_ms", C.c_double),
                 ("phase_cycles", C.c_uint64 * 8)]
 
@@ -262,7 +262,7 @@ class Problem:
         stats = dict(parts[0]["stats"])
         for p in parts[1:]:
             for k, v in p["stats"].items():
-                if k in ("evaluated", "accepted", "degenerate", "iterations", "terms", "list_overflow", "flops", "flops_f32"):
+                if k in ("evaluated", "accepted", "degenerate", "iterations", "terms", "list_overflow", "flops", "flops_f32", "dismissed"):
                     stats[k] += v
                 elif k in ("kernel_ms", "setup_ms"):
                     stats[k] += v

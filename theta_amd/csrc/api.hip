@@ -455,7 +455,7 @@ static int run_search(theta_problem *p, u128 b, u128 e, double window, double *d
 // FP64 operations per likelihood term (an FMA counts 2, rcp / log / div count 1); see DESIGN.md "Roofline".
 static const double FLOPS_PER_TERM_ITER_N3 = 25.0;  // 2 sub, 2 fma (q), rcp + 2 fma, mul, 2 fma (grad), 3 mul, 3 fma (Hessian)
 static const double FLOPS_PER_TERM_ITER_N2 = 13.0;  // fma (den), rcp + 2 fma, mul, fma (f), mul, fma (f')
-static const double FLOPS_PER_TERM_ITER_N3_F32 = 21.0;  // packed coarse pass: 2 sub, 2 fma (q), rcp, mul, 2 fma (grad), 3 mul, 3 fma
+static const double FLOPS_PER_TERM_ITER_N3_F32 = 24.0;  // packed pass: 2 sub, 2 fma (q), rcp, log + fma (value), mul, 2 fma (grad), 3 mul, 3 fma
 static const double FLOPS_PER_FINAL_TERM_N3 = 9.0;  // f32 screen: 2 sub, 2 fma, log, fma
 static const double FLOPS_PER_FINAL_TERM_N2 = 5.0;  // fma, log, fma
 
@@ -490,6 +490,7 @@ extern "C" int theta_search(theta_problem *p, const uint64_t rank_begin[2], cons
         stats->degenerate = hc.degenerate;
         stats->iterations = hc.iterations;
         stats->terms = hc.terms;
+        stats->dismissed = hc.dismissed;
         stats->list_overflow = dropped;
         double per = (p->n == 2) ? FLOPS_PER_TERM_ITER_N2 : FLOPS_PER_TERM_ITER_N3;
         double fin = (p->n == 2) ? FLOPS_PER_FINAL_TERM_N2 : FLOPS_PER_FINAL_TERM_N3;

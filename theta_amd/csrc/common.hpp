@@ -72,6 +72,7 @@ struct TieRecord {
 // Counters every search kernel accumulates (one instance in HBM, zeroed per call).
 struct SearchCounters {
     unsigned long long evaluated, accepted, degenerate, iterations, terms, final_terms;
+    unsigned long long dismissed;      // n=3: candidates finished by the lower bound of their optimum (not solved to convergence)
     unsigned long long terms64;        // of `terms`: term evaluations done by FP64 iterations (n=3: the rest is packed f32)
     unsigned long long best_bits;      // order-preserving bits of the smallest accepted NLL
     unsigned long long rej_bits;       // same for the smallest rejected lower bound

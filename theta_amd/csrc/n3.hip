@@ -311,6 +311,7 @@ struct N3WaveLds {
     unsigned short resSt[N3_QCAP], qOff[N3_QCAP];   // (a task holds < 65536 candidates)
     float lastN1[WAVE], lastN2[WAVE];     // mixture of the last admissible leaf each lane's chunk produced
     unsigned char qSrc[N3_QCAP];          // lane whose chunk the queue entry comes from
+    unsigned char cIdx[N3_QCAP];          // queue entries that still need the values pass (the rest was dismissed)
     unsigned stkS[L > 1 ? L - 1 : 1][WAVE];            // lane-private DFS stack: node chosen at each leaf level but the last
     unsigned long long stkM[L > 1 ? L - 1 : 1][WAVE];  // ... and the siblings still to visit at that level
 };
@@ -486,6 +487,7 @@ __global__ __launch_bounds__(64 * N3_WAVES, N3_OCC) void n3_search_kernel(N3Dev 
     unsigned short *resSt = W.resSt, *qOff = W.qOff;
     float *lastN1 = W.lastN1, *lastN2 = W.lastN2;
     unsigned char *qSrc = W.qSrc;
+    unsigned char *cIdx = W.cIdx;
     const unsigned long long swm = Pg.swmask;
     const int NT1 = Pg.NT + 1;
 
@@ -517,7 +519,7 @@ __global__ __launch_bounds__(64 * N3_WAVES, N3_OCC) void n3_search_kernel(N3Dev 
     const double conv_main = DUMP ? 1e-12 : P.conv_l2;
 
     // statistics are wave-uniform scalars (popcounts of ballots): no vector registers
-    unsigned long long n_eval = 0, n_acc = 0, n_deg = 0, n_it = 0, n_terms = 0, n_terms64 = 0, n_fin = 0;
+    unsigned long long n_eval = 0, n_acc = 0, n_deg = 0, n_it = 0, n_terms = 0, n_terms64 = 0, n_fin = 0, n_dis = 0;
     double best = order_unbits(load_agent_u64(&A.ctr->best_bits));
     double rej_best = order_unbits(load_agent_u64(&A.ctr->rej_bits));
     // warm start (wave-uniform): mixture fractions of the best candidate of the previous batch, pulled
@@ -590,6 +592,7 @@ __global__ __launch_bounds__(64 * N3_WAVES, N3_OCC) void n3_search_kernel(N3Dev 
         for (int l = 0; l < L; l++)
             if (leafR[l] > 0.0) Rmin = fmin(Rmin, leafR[l]);
         if (!(Rmin < __builtin_inf())) Rmin = 1.0;
+        const float rtot_f = (float)P.Rtot, rtot_over_rmin = (float)(P.Rtot / Rmin);
         wave_lds_sync();
         pc0 += __builtin_readcyclecounter() - t0;
 
@@ -720,7 +723,7 @@ __global__ __launch_bounds__(64 * N3_WAVES, N3_OCC) void n3_search_kernel(N3Dev 
             {
                 int head = 0;
                 bool have = false;
-                int myidx = 0;
+                int myidx = 0, mysrc = 0;
                 unsigned long long mycode = 0;
                 float lx[L], ly[L];   // the candidate's leaf rows (small integers: exact in f32)
                 double s1 = 1.0, s2 = 1.0;
@@ -787,6 +790,7 @@ __global__ __launch_bounds__(64 * N3_WAVES, N3_OCC) void n3_search_kernel(N3Dev 
                                 // rows only), else the best candidate of the previous batch; both pulled slightly
                                 // towards the simplex centre so that they are interior for every candidate
                                 const int src = qSrc[want];
+                                mysrc = src;
                                 double n1 = (double)lastN1[src], n2 = (double)lastN2[src];
                                 const bool pred = n1 == n1;
                                 n1 = __builtin_fma(0.98, n1, 0.02 / 3.0);
@@ -816,9 +820,35 @@ __global__ __launch_bounds__(64 * N3_WAVES, N3_OCC) void n3_search_kernel(N3Dev 
                         n_terms64 += (unsigned)__builtin_popcountll(ballot64(have && use64)) * (unsigned)(G + L);
                     }
                     if (have) {
+                        float val2 = 0.0f, l2v = -1.0f;
                         if (use64) n3_newton_step(terms, s1, s2, inv_Rtot, Sv, conv_main);
-                        else use64 = !n3_newton_step_pk(pairs, (float)s1, (float)s2, inv_Rtot, Sv, conv_main);
-                        if (Sv.status != 0) {
+                        else use64 = !n3_newton_step_pk<!DUMP>(pairs, (float)s1, (float)s2, inv_Rtot, Sv, conv_main, val2, l2v);
+                        // Dismissal without solving: NLL is self-concordant with parameter 2 / sqrt(Rmin), so its minimum is
+                        // at least NLL(u) - Rmin w*(lt), lt = lambda / sqrt(Rmin) < 1, w*(t) = -t - ln(1 - t) <= t^2 / (2 (1 - t)),
+                        // i.e. NLL(u) - lambda^2 / (2 (1 - lt)), evaluated at the iterate BEFORE the step.  A candidate whose
+                        // bound (less the f32 margin, plus 5 % for the f32 sums) is beyond the window of the running minimum
+                        // can be neither a finalist nor a suspect: it is finished here -- no further iteration, no values pass.
+                        if (!DUMP && l2v >= 0.0f && Sv.status != 2) {
+                            const float lt2 = l2v * rtot_over_rmin;
+                            if (lt2 < 0.25f) {
+                                const float lt = __builtin_sqrtf(lt2);
+                                const double gap = 1.05 * 0.5 * (double)(l2v * rtot_f * __builtin_amdgcn_rcpf(1.0f - lt));
+                                const double lb = (P.K0 - 0.6931471805599453 * (double)val2) - gap - screen_margin;
+                                if (lb > best + A.window) {
+                                    resSt[myidx] = (unsigned short)0;          // state 0: dismissed
+                                    // the stepped iterate still serves the next leaf of the chunk as a start, if interior
+                                    const double n1 = s1 * Sv.u1, n2 = s2 * Sv.u2, n0 = 1.0 - n1 - n2;
+                                    if (n0 > 0.0 && n1 > 0.0 && n2 > 0.0) {
+                                        lastN1[mysrc] = (float)n1;
+                                        lastN2[mysrc] = (float)n2;
+                                    }
+                                    Sv.status = 0;
+                                    have = false;
+                                }
+                            }
+                        }
+                        n_dis += (unsigned)__builtin_popcountll(ballot64(!have));
+                        if (have && Sv.status != 0) {
                             unsigned sing = Sv.singular ? RES_SINGULAR : 0u;
                             bool conv = Sv.status == 1;
                             resU1[myidx] = (float)(conv ? Sv.u1 : Sv.p1);      // failed: last feasible iterate
@@ -833,9 +863,23 @@ __global__ __launch_bounds__(64 * N3_WAVES, N3_OCC) void n3_search_kernel(N3Dev 
                 pc2 += td1 - td0;
 
                 // ---- values, admissibility, minimum tracking: full 64-wide batches ------------------------
+                // dismissed and degenerate leaves are only counted; the rest is compacted into dense batches
+                int nkeep = 0;
                 for (int b0 = 0; b0 < qcount; b0 += WAVE) {
                     const int idx = b0 + lane;
-                    const bool live = idx < qcount;
+                    const bool in = idx < qcount;
+                    const unsigned kind0 = in ? ((unsigned)resSt[idx] & 3u) : 0u;
+                    const bool keep = in && kind0 != 0u && (DUMP || kind0 != RES_DEGEN);
+                    n_eval += (unsigned)__builtin_popcountll(ballot64(in));
+                    n_deg += (unsigned)__builtin_popcountll(ballot64(in && kind0 == RES_DEGEN));
+                    const unsigned long long km = ballot64(keep);
+                    if (keep) cIdx[nkeep + mbcnt(km)] = (unsigned char)idx;
+                    nkeep += __builtin_popcountll(km);
+                }
+                wave_lds_sync();
+                for (int b0 = 0; b0 < nkeep; b0 += WAVE) {
+                    const bool live = b0 + lane < nkeep;
+                    const int idx = live ? (int)cIdx[b0 + lane] : 0;
                     mycode = live ? qCode[idx] : ~0ull;
                     unsigned stw = live ? resSt[idx] : RES_DEGEN;
                     double u1 = live ? (double)resU1[idx] : 0.0, u2 = live ? (double)resU2[idx] : 0.0;
@@ -843,7 +887,6 @@ __global__ __launch_bounds__(64 * N3_WAVES, N3_OCC) void n3_search_kernel(N3Dev 
                     double S1, S2;
                     decode(mycode, S1, S2);
                     const unsigned kind = stw & 3u;
-                    const bool degenerate = live && kind == RES_DEGEN;
                     const bool solved = live && kind != RES_DEGEN;
                     const bool conv = solved && kind == RES_CONV;
                     s1 = solved ? S1 * inv_N : 1.0;
@@ -999,9 +1042,7 @@ __global__ __launch_bounds__(64 * N3_WAVES, N3_OCC) void n3_search_kernel(N3Dev 
                         A.dump_mu[di * 3 + 1] = accept ? mu1 : nan;
                         A.dump_mu[di * 3 + 2] = accept ? mu2 : nan;
                     }
-                    n_eval += (unsigned)__builtin_popcountll(ballot64(live));
                     n_acc += (unsigned)__builtin_popcountll(ballot64(accept));
-                    n_deg += (unsigned)__builtin_popcountll(ballot64(degenerate));
                     n_fin += (unsigned)__builtin_popcountll(ballot64(solved)) * (unsigned)(G + L);
                 }
                 wave_lds_sync();
@@ -1065,6 +1106,7 @@ __global__ __launch_bounds__(64 * N3_WAVES, N3_OCC) void n3_search_kernel(N3Dev 
         atomicAdd(&A.ctr->iterations, n_it);
         atomicAdd(&A.ctr->terms, n_terms);
         atomicAdd(&A.ctr->terms64, n_terms64);
+        atomicAdd(&A.ctr->dismissed, n_dis);
         atomicAdd(&A.ctr->final_terms, n_fin);
         atomicAdd(&A.ctr->prof[0], pc0);
         atomicAdd(&A.ctr->prof[1], pc1);

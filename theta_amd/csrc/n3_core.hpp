@@ -197,11 +197,14 @@ __device__ __forceinline__ void n3_newton_step(Terms &&terms, double s1, double 
 typedef float v2f __attribute__((ext_vector_type(2)));
 #define N3_COND_MIN 1e-3   // smallest det / (h11 h22) the single-precision pass accepts
 
-template <class Pairs>
+// VAL: also return sum R log2 q and the decrement lambda^2 / sum(r), both at the point the evaluation was made at (the
+// iterate BEFORE the step) -- what the caller needs for the self-concordance lower bound of the optimum.
+template <bool VAL, class Pairs>
 __device__ __forceinline__ bool n3_newton_step_pk(Pairs &&pairs, float s1, float s2, double inv_Rtot, N3Newton &S,
-                                                  double conv_l2) {
-    v2f g1 = {0.f, 0.f}, g2 = g1, h11 = g1, h12 = g1, h22 = g1;
+                                                  double conv_l2, float &val_log2, float &l2_out) {
+    v2f g1 = {0.f, 0.f}, g2 = g1, h11 = g1, h12 = g1, h22 = g1, lg = g1;
     float qmin = __builtin_inff();
+    l2_out = -1.0f;
     const float u1 = (float)S.u1, u2 = (float)S.u2;
     const v2f vs1 = {s1, s1}, vs2 = {s2, s2}, vu1 = {u1, u1}, vu2 = {u2, u2}, one = {1.f, 1.f};
     pairs([&](v2f x, v2f y, v2f R) {
@@ -209,6 +212,7 @@ __device__ __forceinline__ bool n3_newton_step_pk(Pairs &&pairs, float s1, float
         v2f q = __builtin_elementwise_fma(a, vu1, __builtin_elementwise_fma(b, vu2, one));
         qmin = fminf(qmin, fminf(q.x, q.y));
         v2f w = {__builtin_amdgcn_rcpf(q.x), __builtin_amdgcn_rcpf(q.y)};
+        if (VAL) lg = __builtin_elementwise_fma(R, v2f{__builtin_amdgcn_logf(q.x), __builtin_amdgcn_logf(q.y)}, lg);
         v2f t = R * w;
         g1 = __builtin_elementwise_fma(t, a, g1);
         g2 = __builtin_elementwise_fma(t, b, g2);
@@ -237,6 +241,10 @@ __device__ __forceinline__ bool n3_newton_step_pk(Pairs &&pairs, float s1, float
     const float d1 = (H22 * G1 - H12 * G2) * idet;
     const float d2 = (H11 * G2 - H12 * G1) * idet;
     const float l2 = (G1 * d1 + G2 * d2) * (float)inv_Rtot;
+    if (VAL) {
+        val_log2 = lg.x + lg.y;
+        l2_out = l2;
+    }
     if (!(l2 == l2) || !(fabsf(d1) + fabsf(d2) < 1e30f)) {
         S.status = 2;
         return true;
