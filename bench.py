@@ -169,7 +169,7 @@ def main():
 
     barrier()
     t0 = time.time()
-    evaluated = flops = flops32 = terms = iters = accepted = 0
+    evaluated = flops = flops32 = terms = iters = accepted = dismissed = 0
     kernel_ms = setup_ms = 0.0
     best = None
     for i in range(args.warmup, nsteps):
@@ -177,6 +177,7 @@ def main():
         st = res["stats"]
         evaluated += st["evaluated"]
         accepted += st["accepted"]
+        dismissed += st["dismissed"]
         flops += st["flops"]
         flops32 += st["flops_f32"]
         terms += st["terms"]
@@ -197,7 +198,7 @@ def main():
     dt = time.time() - t0
 
     tot = torch.tensor([float(evaluated), dt, float(flops), kernel_ms, float(terms), float(iters), float(accepted), setup_ms,
-                        float(flops32)],
+                        float(flops32), float(dismissed)],
                        dtype=torch.float64, device=comm_dev)
     if dist is not None:
         allv = [torch.zeros_like(tot) for _ in range(world)]
@@ -247,7 +248,8 @@ def main():
                          "kernel_candidates_per_s": allv[0, 0] / (k_ms * 1e-3),
                          "note": "fused kernel: candidates are generated on chip, HBM bytes/candidate ~ 0 by design; "
                                  "see DESIGN.md section 'Roofline'"},
-            "accepted_fraction": allv[:, 6].sum() / max(ev_all, 1.0),
+            "dismissed_fraction": allv[:, 9].sum() / max(ev_all, 1.0),      # finished by the lower bound of their optimum
+            "accepted_fraction_of_solved": allv[:, 6].sum() / max(ev_all - allv[:, 9].sum(), 1.0),
             "setup_ms_per_step": allv[0, 7] / launches,
         }
         if world == 1 and not args.no_cpu_baseline:
