@@ -291,6 +291,9 @@ __device__ __forceinline__ double readlane_f64(double v, int l) {
 #ifndef N3_OCC
 #define N3_OCC 3       // blocks per CU the register budget is sized for
 #endif
+#ifndef N3_LAG
+#define N3_LAG 4      // lanes that may still be between leaves when the wave evaluates (they skip that round)
+#endif
 #ifndef N3_QCAP
 #define N3_QCAP 256     // leaves solved per round (per wave)
 #endif
@@ -661,63 +664,176 @@ __global__ __launch_bounds__(64 * N3_WAVES, N3_OCC) void n3_search_kernel(N3Dev 
             pc6 += __builtin_readcyclecounter() - tu0;
             n_prefix++;
         }
-        for (unsigned long long done = 0; done < nleaf;) {
+        float wn1 = __builtin_nanf(""), wn2 = wn1;   // the lane's chain: optimum (mixture) of its previous leaf
+        while (ballot64(my_left > 0)) {
             const unsigned long long ts0 = __builtin_readcyclecounter();
             int qcount = 0;
-            // Every lane with leaves left takes ONE DFS micro-step per trip, all lanes in the same straight-line code: take
-            // the next sibling (at the last level: a leaf, which it emits), or descend (one LUT read + one mask read), or
-            // pop a level.  Emitting lanes get consecutive queue slots, trip after trip, until fewer than 64 slots are
-            // free -- no per-lane quota, so no lane waits for the ones that have to pop and descend.
+            // Enumeration fused with the FIRST evaluation.  Phase A: every lane advances its DFS (pop / descend, one
+            // micro-step per trip) until it holds a leaf.  Phase B: all lanes take their leaf at once and evaluate it in
+            // place -- packed value, gradient, Hessian at the optimum of the lane's previous leaf -- and nearly always
+            // finish it right there by the lower bound of its optimum.  Only the survivors (and, for the dump / FP64
+            // mode, everything) go to the LDS queue for the persistent-lane solver and the values pass below.
             {
-                bool adv = my_left > 0;
-                while (qcount + WAVE <= N3_QCAP && ballot64(adv)) {
-                    bool emit = false;
-                    unsigned rw = 0;
-                    if (adv) {
-                        if (mcur == 0ull) {                    // level exhausted: pop
-                            lv--;
-                            if (lv < 0) {
-                                my_left = 0;                   // cannot happen inside the counted range
-                                adv = false;
-                            } else {
-                                mcur = W.stkM[lv][lane];
-                                cur = (lv == 0) ? par : n3_unpack(W.stkS[lv - 1][lane]);
-                            }
-                        } else {
-                            const int s = __builtin_ctzll(mcur);
-                            mcur &= mcur - 1;
-                            if (lv == L - 1) {                 // a leaf
-                                rw = S.rowtab[s];
-                                emit = true;
-                            } else {                           // descend into child s
+                float flx[L], fly[L];                 // rows of the lane's current path (the last one is set per leaf)
+                double S1u = S1p, S2u = S2p;          // column sums without the last row
+#pragma unroll
+                for (int l = 0; l + 1 < L; l++) {
+                    const unsigned rw = (unsigned)(code >> (8 * l)) & 0xffu;
+                    flx[l] = (float)(rw & 15u);
+                    fly[l] = (float)(rw >> 4);
+                    S1u = __builtin_fma((double)(rw & 15u), leafN[l], S1u);
+                    S2u = __builtin_fma((double)(rw >> 4), leafN[l], S2u);
+                }
+                flx[L - 1] = fly[L - 1] = 0.0f;
+                const int GPf = (G + 1) >> 1;
+                auto fpairs = [&](auto &&body) {
+#pragma unroll 2
+                    for (int p = 0; p < GPf; p++) {
+                        const float4 xy = fXY[p];
+                        const float2 rr = fRR[p];
+                        body(v2f{xy.x, xy.y}, v2f{xy.z, xy.w}, v2f{rr.x, rr.y});
+                    }
+#pragma unroll
+                    for (int l = 0; l + 1 < L; l += 2) {
+                        const float2 rr = W.fRL[l >> 1];
+                        body(v2f{flx[l], flx[l + 1]}, v2f{fly[l], fly[l + 1]}, v2f{rr.x, rr.y});
+                    }
+                    if (L & 1) {
+                        const float2 rr = W.fRL[L >> 1];
+                        body(v2f{flx[L - 1], flx[L - 1]}, v2f{fly[L - 1], fly[L - 1]}, v2f{rr.x, rr.y});
+                    }
+                };
+                const bool direct = DUMP || P.force64 != 0;    // no first evaluation here: everything is queued
+                while (qcount + WAVE <= N3_QCAP && ballot64(my_left > 0)) {
+                    // ---- phase A
+                    bool need = my_left > 0 && !(lv == L - 1 && mcur != 0ull);
+                    // (not until EVERY lane holds a leaf: the few that have to pop several levels catch up in later trips;
+                    // one trip is always made when any lane needs it, so every lane advances)
+                    int lag = 0;
+                    while (__builtin_popcountll(ballot64(need)) > lag) {
+                        lag = N3_LAG;
+                        if (need) {
+                            if (mcur == 0ull) {                    // level exhausted: pop
+                                lv--;
+                                if (lv < 0) {
+                                    my_left = 0;                   // cannot happen inside the counted range
+                                } else {
+                                    mcur = W.stkM[lv][lane];
+                                    cur = (lv == 0) ? par : n3_unpack(W.stkS[lv - 1][lane]);
+                                }
+                            } else {                               // descend into child s (lv < L - 1 here)
+                                const int s = __builtin_ctzll(mcur);
+                                mcur &= mcur - 1;
                                 N3State ch = child_state(cur, s);
                                 W.stkS[lv][lane] = n3_pack(ch);
                                 W.stkM[lv][lane] = mcur;
                                 code = (code & ~(0xffull << (8 * lv))) | ((unsigned long long)(ch.a | (ch.b << 4)) << (8 * lv));
+#pragma unroll
+                                for (int l = 0; l + 1 < L; l++)
+                                    if (l == lv) {
+                                        flx[l] = (float)ch.a;
+                                        fly[l] = (float)ch.b;
+                                    }
                                 cur = ch;
                                 lv++;
                                 mcur = child_mask(ch, lv);
+                                if (lv == L - 1) {                 // the path above the leaves is complete again
+                                    S1u = S1p;
+                                    S2u = S2p;
+#pragma unroll
+                                    for (int l = 0; l + 1 < L; l++) {
+                                        S1u = __builtin_fma((double)flx[l], leafN[l], S1u);
+                                        S2u = __builtin_fma((double)fly[l], leafN[l], S2u);
+                                    }
+                                }
+                            }
+                            need = my_left > 0 && !(lv == L - 1 && mcur != 0ull);
+                        }
+                    }
+                    // ---- phase B
+                    const bool act = my_left > 0 && lv == L - 1 && mcur != 0ull;
+                    bool push = false;
+                    unsigned long long full = 0;
+                    if (act) {
+                        const int s = __builtin_ctzll(mcur);
+                        mcur &= mcur - 1;
+                        const unsigned rw = S.rowtab[s];
+                        full = (code & ~(0xffull << (8 * (L - 1)))) | ((unsigned long long)rw << (8 * (L - 1)));
+                        push = true;
+                        const double S1 = __builtin_fma((double)(rw & 15u), leafN[L - 1], S1u);
+                        const double S2 = __builtin_fma((double)(rw >> 4), leafN[L - 1], S2u);
+                        if (!direct && S1 != 0.0 && S2 != 0.0) {
+                            flx[L - 1] = (float)(rw & 15u);
+                            fly[L - 1] = (float)(rw >> 4);
+                            const double fs1 = S1 * inv_N, fs2 = S2 * inv_N;
+                            double n1 = (double)wn1, n2 = (double)wn2;
+                            const bool pred = n1 == n1;
+                            n1 = __builtin_fma(0.98, n1, 0.02 / 3.0);
+                            n2 = __builtin_fma(0.98, n2, 0.02 / 3.0);
+                            if (!pred) {
+                                n1 = (double)W.ws[0];
+                                n2 = (double)W.ws[1];
+                            }
+                            N3Newton T;
+                            T.u1 = n1 * (double)__builtin_amdgcn_rcpf((float)fs1);
+                            T.u2 = n2 * (double)__builtin_amdgcn_rcpf((float)fs2);
+                            T.p1 = T.u1; T.p2 = T.u2;
+                            T.iters = 0;
+                            T.status = 0;
+                            T.singular = false;
+                            float val2 = 0.0f, l2v = -1.0f;
+                            const bool okc = n3_newton_step_pk<true>(fpairs, (float)fs1, (float)fs2, inv_Rtot, T, conv_main, val2, l2v);
+                            bool dismissed = false;
+                            if (okc && l2v >= 0.0f && T.status != 2) {
+                                const float lt2 = l2v * rtot_over_rmin;
+                                if (lt2 < 0.25f) {
+                                    const float lt = __builtin_sqrtf(lt2);
+                                    const double gap = 1.05 * 0.5 * (double)(l2v * rtot_f * __builtin_amdgcn_rcpf(1.0f - lt));
+                                    const double lb = (P.K0 - 0.6931471805599453 * (double)val2) - gap - screen_margin;
+                                    dismissed = lb > best + A.window;
+                                }
+                                // the stepped iterate is the start of the lane's next leaf (and of the solver, for a survivor)
+                                // (also when it lies outside the simplex: leaves whose optimum is far outside come in runs, and
+                                // a start outside the next leaf's domain is repaired by the step function)
+                                const double m1 = fs1 * T.u1, m2 = fs2 * T.u2;
+                                if (fabs(m1) + fabs(m2) < 1e6) {
+                                    wn1 = (float)m1;
+                                    wn2 = (float)m2;
+                                }
+                            }
+                            if (dismissed) push = false;
+                            else {
+                                lastN1[lane] = wn1;
+                                lastN2[lane] = wn2;
                             }
                         }
                     }
-                    const unsigned long long em = ballot64(emit);
-                    if (emit) {
+                    {
+                        const unsigned nev = (unsigned)__builtin_popcountll(ballot64(act && !direct));
+                        const unsigned ndm = (unsigned)__builtin_popcountll(ballot64(act && !push));
+                        n_it += nev;
+                        n_terms += nev * (unsigned)(G + L);
+                        n_eval += ndm;
+                        n_dis += ndm;
+                    }
+                    const unsigned long long em = ballot64(push);
+                    if (push) {
                         const int pos = qcount + mbcnt(em);
-                        qCode[pos] = (code & ~(0xffull << (8 * (L - 1)))) | ((unsigned long long)rw << (8 * (L - 1)));
+                        qCode[pos] = full;
                         qOff[pos] = (unsigned short)my_rel;
                         qSrc[pos] = (unsigned char)lane;
+                    }
+                    if (act) {
                         my_rel++;
                         my_left--;
-                        adv = my_left > 0;
                     }
                     qcount += __builtin_popcountll(em);
                 }
             }
-            done += (unsigned long long)qcount;
-            if (qcount == 0) break;
-            wave_lds_sync();
             const unsigned long long td0 = __builtin_readcyclecounter();
             pc1 += td0 - ts0;
+            if (qcount == 0) continue;     // everything was finished in place
+            wave_lds_sync();
 
             // ---- solve every queued leaf: persistent lanes, refilled from the queue as they converge -------
             {
@@ -837,8 +953,8 @@ __global__ __launch_bounds__(64 * N3_WAVES, N3_OCC) void n3_search_kernel(N3Dev 
                                 if (lb > best + A.window) {
                                     resSt[myidx] = (unsigned short)0;          // state 0: dismissed
                                     // the stepped iterate still serves the next leaf of the chunk as a start, if interior
-                                    const double n1 = s1 * Sv.u1, n2 = s2 * Sv.u2, n0 = 1.0 - n1 - n2;
-                                    if (n0 > 0.0 && n1 > 0.0 && n2 > 0.0) {
+                                    const double n1 = s1 * Sv.u1, n2 = s2 * Sv.u2;
+                                    if (fabs(n1) + fabs(n2) < 1e6) {
                                         lastN1[mysrc] = (float)n1;
                                         lastN2[mysrc] = (float)n2;
                                     }

@@ -155,7 +155,8 @@ __device__ __forceinline__ void n3_newton_step(Terms &&terms, double s1, double 
         h22 = __builtin_fma(tb, b, h22);
     });
     S.iters++;
-    if (bad) {  // stepped out of the domain (only possible through round-off): halve the step
+    if (bad) {  // outside the domain: halve the step; a START outside it falls back towards u = 0 (interior for every candidate)
+        if (S.p1 == S.u1 && S.p2 == S.u2) S.p1 = S.p2 = 0.0;
         S.u1 = 0.5 * (S.u1 + S.p1);
         S.u2 = 0.5 * (S.u2 + S.p2);
         if (S.iters >= N3_MAX_ITERS) S.status = 2;
@@ -223,7 +224,8 @@ __device__ __forceinline__ bool n3_newton_step_pk(Pairs &&pairs, float s1, float
         h22 = __builtin_elementwise_fma(tb, b, h22);
     });
     S.iters++;
-    if (!(qmin > 0.0f)) {   // stepped out of the domain: halve the step
+    if (!(qmin > 0.0f)) {   // outside the domain: halve the step; a START outside it falls back towards u = 0
+        if (S.p1 == S.u1 && S.p2 == S.u2) S.p1 = S.p2 = 0.0;
         S.u1 = 0.5 * (S.u1 + S.p1);
         S.u2 = 0.5 * (S.u2 + S.p2);
         if (S.iters >= N3_MAX_ITERS) S.status = 2;

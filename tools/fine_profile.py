@@ -8,7 +8,6 @@ for rep in range(2):
     b=tot//3+rep*(tot//7)
     res=p.search(b,b+(1<<27),window=0.5); st=res['stats']
     pc=st['phase_cycles']; tw=pc[5]; ev=st['evaluated']
-    rounds=ev/256.0
-    print('f64 evaluations per candidate %.4f'%(st['degenerate']/ev))
-    print('kernel_ms %.1f cycles/cand %.0f | newton trips/round %.2f: refill %.0f + step %.0f of %.0f cycles/trip | scan %.0f values %.0f cycles/cand'%(
-        st['kernel_ms'], tw/ev, pc[4]/rounds, pc[6]/max(pc[4],1), pc[0]/max(pc[4],1), pc[2]/max(pc[4],1), pc[1]/ev, pc[3]/ev))
+    outer=max(pc[6],1)
+    print('kernel_ms %.1f cycles/cand %.0f | outer iterations %d (%.1f cand each) | phase A: %.2f trips, %.0f cycles per outer; scan+eval total %.0f cycles per outer -> phase B %.0f'%(
+        st['kernel_ms'], tw/ev, outer, ev/outer, pc[4]/outer, pc[0]/outer, pc[1]/outer, (pc[1]-pc[0])/outer))
