@@ -704,6 +704,8 @@ __global__ __launch_bounds__(64 * N3_WAVES, N3_OCC) void n3_search_kernel(N3Dev 
                     }
                 };
                 const bool direct = DUMP || P.force64 != 0;    // no first evaluation here: everything is queued
+                int pf_slot = -1;                              // child of the current level-(L-2) node whose mask is prefetched
+                unsigned long long pf_mask = 0ull;
                 while (qcount + WAVE <= N3_QCAP && ballot64(my_left > 0)) {
                     // ---- phase A
                     bool need = my_left > 0 && !(lv == L - 1 && mcur != 0ull);
@@ -713,15 +715,19 @@ __global__ __launch_bounds__(64 * N3_WAVES, N3_OCC) void n3_search_kernel(N3Dev 
                     while (__builtin_popcountll(ballot64(need)) > lag) {
                         lag = N3_LAG;
                         if (need) {
-                            if (mcur == 0ull) {                    // level exhausted: pop
-                                lv--;
-                                if (lv < 0) {
-                                    my_left = 0;                   // cannot happen inside the counted range
-                                } else {
-                                    mcur = W.stkM[lv][lane];
-                                    cur = (lv == 0) ? par : n3_unpack(W.stkS[lv - 1][lane]);
+                            // one trip: pop while the level is exhausted (LDS only), then descend once
+#pragma unroll
+                            for (int rep = 0; rep < 2; rep++)
+                                if (mcur == 0ull && my_left > 0) {
+                                    lv--;
+                                    if (lv < 0) {
+                                        my_left = 0;                   // cannot happen inside the counted range
+                                    } else {
+                                        mcur = W.stkM[lv][lane];
+                                        cur = (lv == 0) ? par : n3_unpack(W.stkS[lv - 1][lane]);
+                                    }
                                 }
-                            } else {                               // descend into child s (lv < L - 1 here)
+                            if (my_left > 0 && mcur != 0ull && lv < L - 1) {   // descend into child s
                                 const int s = __builtin_ctzll(mcur);
                                 mcur &= mcur - 1;
                                 N3State ch = child_state(cur, s);
@@ -734,10 +740,26 @@ __global__ __launch_bounds__(64 * N3_WAVES, N3_OCC) void n3_search_kernel(N3Dev 
                                         flx[l] = (float)ch.a;
                                         fly[l] = (float)ch.b;
                                     }
+                                const unsigned long long sib = mcur;   // siblings still to come at this level
+                                const N3State parent = cur;
                                 cur = ch;
                                 lv++;
-                                mcur = child_mask(ch, lv);
-                                if (lv == L - 1) {                 // the path above the leaves is complete again
+                                unsigned long long mk = S.smask[lv][ch.slot];
+                                if (ch.sw) mk &= swm;
+                                // the ratio-window mask is a dependent read of the L2-resident table: at the deepest inner level
+                                // the NEXT sibling's is requested one descent ahead, so that this wait is usually not needed
+                                if (lv == L - 1 && pf_slot == s) mk &= pf_mask;
+                                else mk &= Pg.dynmask[((size_t)ch.slot * NT1 + ch.lo) * NT1 + (ch.hi - 1)];
+                                mcur = mk;
+                                pf_slot = -1;
+                                if (lv == L - 1) {
+                                    if (sib) {
+                                        const int s2 = __builtin_ctzll(sib);
+                                        N3State c2 = child_state(parent, s2);
+                                        pf_mask = Pg.dynmask[((size_t)c2.slot * NT1 + c2.lo) * NT1 + (c2.hi - 1)];
+                                        pf_slot = s2;
+                                    }
+                                    // the path above the leaves is complete again
                                     S1u = S1p;
                                     S2u = S2p;
 #pragma unroll
