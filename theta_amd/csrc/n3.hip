@@ -552,6 +552,8 @@ __global__ __launch_bounds__(64 * N3_WAVES, N3_OCC) void n3_search_kernel(N3Dev 
     const unsigned long long t_begin = __builtin_readcyclecounter();
     while (remaining > 0) {
         unsigned long long t0 = __builtin_readcyclecounter();
+        // the device-wide running minimum, once per prefix (thousands of candidates): the lower it is, the more is dismissed
+        best = fmin(best, order_unbits(load_agent_u64(&A.ctr->best_bits)));
         // ---------------- group tile of the prefix --------------------------------------------
         int G = 0;
         double S1p = 0.0, S2p = 0.0, Rmin = __builtin_inf();   // Rmin: smallest weight of a likelihood term
