@@ -269,13 +269,7 @@ extern "C" int theta_problem_create(theta_ctx *ctx, int n, int m, int tau, const
         D.Q = h.Q;
         D.tau = tau;
         D.NT = h.NT;
-        int L = 6;   // leaf levels enumerated by the lanes (tuned on MI355X for K = 3..6)
-        if (const char *e = getenv("THETA_N3_LEAF_LEVELS")) {
-            int v = atoi(e);
-            if (v >= 1 && v <= 6) L = v;
-        }
-        if (L > m - 1) L = m - 1;
-        D.L = L;
+        D.L = 1;   // (decided below, once the candidate count is known; the counting DP does not depend on it)
         D.warm_blend = 0.9;
         D.conv_l2 = 1e-4;    // first-pass threshold on the squared decrement before the last step (contenders are polished)
         if (const char *e = getenv("THETA_N3_WARM_BLEND")) D.warm_blend = atof(e);
@@ -323,6 +317,15 @@ extern "C" int theta_problem_create(theta_ctx *ctx, int n, int m, int tau, const
         memcpy(p->total, hostmisc + 16, 16);
         D.total_lo = p->total[0];
         D.total_hi = p->total[1];
+        // leaf levels enumerated by the lanes: the more, the better the per-prefix work (group tile, 64 unranks) is
+        // amortised -- 8 (one byte of the 64-bit leaf code each) was fastest for K = 3..6 on MI355X
+        int L = 8;
+        if (const char *e = getenv("THETA_N3_LEAF_LEVELS")) {
+            int v = atoi(e);
+            if (v >= 1 && v <= 8) L = v;
+        }
+        if (L > m - 1) L = m - 1;
+        D.L = L;
         TRY(p->d_tasks.alloc((size_t)N3_MAX_TASKS * sizeof(N3Task)));
         TRY(p->d_stbuf.alloc((size_t)N3_MAX_TASKS * N3_MAX_M * sizeof(unsigned)));
     }

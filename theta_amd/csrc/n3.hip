@@ -295,9 +295,9 @@ __device__ __forceinline__ double readlane_f64(double v, int l) {
 #define N3_LAG 4      // lanes that may still be between leaves when the wave evaluates (they skip that round)
 #endif
 #ifndef N3_QCAP
-#define N3_QCAP 256     // leaves solved per round (per wave)
+#define N3_QCAP 128     // capacity of a wave's queue of leaves for the solver (survivors of the first evaluation)
 #endif
-#define N3_MAX_L 6      // leaf levels (one byte of the 64-bit leaf code each)
+#define N3_MAX_L 8      // leaf levels (one byte of the 64-bit leaf code each)
 
 // Everything a wave owns sits in ONE struct, so that a single base register (+ immediate offsets) addresses all of it.
 template <int L>
@@ -307,7 +307,7 @@ struct N3WaveLds {
     // an odd last term is paired with a copy of itself of weight 0
     float4 fXY[(N3_MAX_Q + 2) / 2];
     float2 fRR[(N3_MAX_Q + 2) / 2];
-    float2 fRL[(N3_MAX_L + 1) / 2];   // weights of the leaf rows, paired like fRR (an odd last one with 0)
+    float2 fRL[(N3_MAX_L + 2) / 2];   // weights of the leaf rows, paired like fRR (an odd last one with 0)
     float ws[2];                      // wave-wide warm start (mixture of the best candidate so far, blended)
     float resU1[N3_QCAP], resU2[N3_QCAP];   // coarse optimum (f32 is all the screen uses; contenders are polished in f64)
     unsigned long long qCode[N3_QCAP];
@@ -776,8 +776,14 @@ __global__ __launch_bounds__(64 * N3_WAVES, N3_OCC) void n3_search_kernel(N3Dev 
                     }
                     // ---- phase B
                     const bool act = my_left > 0 && lv == L - 1 && mcur != 0ull;
-                    bool push = false;
+                    bool push = false, ev = false;
                     unsigned long long full = 0;
+                    double fs1 = 1.0, fs2 = 1.0;
+                    N3Newton T;
+                    T.u1 = T.u2 = T.p1 = T.p2 = 0.0;
+                    T.iters = 0;
+                    T.status = 0;
+                    T.singular = false;
                     if (act) {
                         const int s = __builtin_ctzll(mcur);
                         mcur &= mcur - 1;
@@ -787,9 +793,11 @@ __global__ __launch_bounds__(64 * N3_WAVES, N3_OCC) void n3_search_kernel(N3Dev 
                         const double S1 = __builtin_fma((double)(rw & 15u), leafN[L - 1], S1u);
                         const double S2 = __builtin_fma((double)(rw >> 4), leafN[L - 1], S2u);
                         if (!direct && S1 != 0.0 && S2 != 0.0) {
+                            ev = true;
                             flx[L - 1] = (float)(rw & 15u);
                             fly[L - 1] = (float)(rw >> 4);
-                            const double fs1 = S1 * inv_N, fs2 = S2 * inv_N;
+                            fs1 = S1 * inv_N;
+                            fs2 = S2 * inv_N;
                             double n1 = (double)wn1, n2 = (double)wn2;
                             const bool pred = n1 == n1;
                             n1 = __builtin_fma(0.98, n1, 0.02 / 3.0);
@@ -798,23 +806,32 @@ __global__ __launch_bounds__(64 * N3_WAVES, N3_OCC) void n3_search_kernel(N3Dev 
                                 n1 = (double)W.ws[0];
                                 n2 = (double)W.ws[1];
                             }
-                            N3Newton T;
                             T.u1 = n1 * (double)__builtin_amdgcn_rcpf((float)fs1);
                             T.u2 = n2 * (double)__builtin_amdgcn_rcpf((float)fs2);
                             T.p1 = T.u1; T.p2 = T.u2;
-                            T.iters = 0;
-                            T.status = 0;
-                            T.singular = false;
+                        }
+                    }
+                    // Evaluate in place.  Nearly always ONE trip: the bound finishes the leaf.  Where the optimum moves a lot
+                    // from leaf to leaf, many lanes need more steps before the bound applies: they take up to three more
+                    // here, in registers, as long as at least 8 of them do; whoever is left goes to the queue.
+                    for (int tries = 0;; tries++) {
+                        const unsigned long long evm = ballot64(ev);
+                        if (!evm || tries >= 4 || (tries > 0 && __builtin_popcountll(evm) < 8)) break;
+                        n_it += (unsigned)__builtin_popcountll(evm);
+                        n_terms += (unsigned)__builtin_popcountll(evm) * (unsigned)(G + L);
+                        if (ev) {
                             float val2 = 0.0f, l2v = -1.0f;
                             const bool okc = n3_newton_step_pk<true>(fpairs, (float)fs1, (float)fs2, inv_Rtot, T, conv_main, val2, l2v);
-                            bool dismissed = false;
                             if (okc && l2v >= 0.0f && T.status != 2) {
                                 const float lt2 = l2v * rtot_over_rmin;
                                 if (lt2 < 0.25f) {
                                     const float lt = __builtin_sqrtf(lt2);
                                     const double gap = 1.05 * 0.5 * (double)(l2v * rtot_f * __builtin_amdgcn_rcpf(1.0f - lt));
                                     const double lb = (P.K0 - 0.6931471805599453 * (double)val2) - gap - screen_margin;
-                                    dismissed = lb > best + A.window;
+                                    if (lb > best + A.window) {
+                                        push = false;          // dismissed
+                                        ev = false;
+                                    }
                                 }
                                 // the stepped iterate is the start of the lane's next leaf (and of the solver, for a survivor)
                                 // (also when it lies outside the simplex: leaves whose optimum is far outside come in runs, and
@@ -825,18 +842,15 @@ __global__ __launch_bounds__(64 * N3_WAVES, N3_OCC) void n3_search_kernel(N3Dev 
                                     wn2 = (float)m2;
                                 }
                             }
-                            if (dismissed) push = false;
-                            else {
-                                lastN1[lane] = wn1;
-                                lastN2[lane] = wn2;
-                            }
+                            if (!okc || T.status != 0) ev = false;   // ill-conditioned, converged (a contender?) or failed: the queue
                         }
                     }
+                    if (act && push && !direct) {
+                        lastN1[lane] = wn1;
+                        lastN2[lane] = wn2;
+                    }
                     {
-                        const unsigned nev = (unsigned)__builtin_popcountll(ballot64(act && !direct));
                         const unsigned ndm = (unsigned)__builtin_popcountll(ballot64(act && !push));
-                        n_it += nev;
-                        n_terms += nev * (unsigned)(G + L);
                         n_eval += ndm;
                         n_dis += ndm;
                     }
@@ -1537,7 +1551,7 @@ void n3_launch_search(const N3Dev &P, const SearchArgs &A, const N3Task *tasks, 
         if (dump) hipLaunchKernelGGL((n3_search_kernel<LL, true>), grid, block, 0, st, P, A, tasks, stbuf, ntasks, per_task); \
         else hipLaunchKernelGGL((n3_search_kernel<LL, false>), grid, block, 0, st, P, A, tasks, stbuf, ntasks, per_task);     \
         break;
-    switch (P.L) { LAUNCH(1) LAUNCH(2) LAUNCH(3) LAUNCH(4) LAUNCH(5) default: LAUNCH(6) }
+    switch (P.L) { LAUNCH(1) LAUNCH(2) LAUNCH(3) LAUNCH(4) LAUNCH(5) LAUNCH(6) LAUNCH(7) default: LAUNCH(8) }
 #undef LAUNCH
 }
 
@@ -1552,6 +1566,6 @@ void n3_launch_enumerate(const N3Dev &P, const N3Task *tasks, const unsigned *st
     case LL:                                                                                                            \
         hipLaunchKernelGGL((n3_enumerate_wave_kernel<LL>), grid, block, 0, st, P, tasks, stbuf, ntasks, per_task, out); \
         break;
-    switch (P.L) { LAUNCH(1) LAUNCH(2) LAUNCH(3) LAUNCH(4) LAUNCH(5) default: LAUNCH(6) }
+    switch (P.L) { LAUNCH(1) LAUNCH(2) LAUNCH(3) LAUNCH(4) LAUNCH(5) LAUNCH(6) LAUNCH(7) default: LAUNCH(8) }
 #undef LAUNCH
 }
