@@ -317,9 +317,15 @@ extern "C" int theta_problem_create(theta_ctx *ctx, int n, int m, int tau, const
         memcpy(p->total, hostmisc + 16, 16);
         D.total_lo = p->total[0];
         D.total_hi = p->total[1];
-        // leaf levels enumerated by the lanes: the more, the better the per-prefix work (group tile, 64 unranks) is
-        // amortised -- 8 (one byte of the 64-bit leaf code each) was fastest for K = 3..6 on MI355X
+        // leaf levels enumerated by the lanes (one byte of the 64-bit leaf code each, at most 8): enough of them that a
+        // prefix has >= 32 k leaves on average (growth factor of the candidate count per interval ^ L), so that the per-prefix
+        // work (group tile, 64 unranks) is amortised -- but no more, every leaf row is a likelihood term of its own.
+        // m=50: K=6 -> 6, K<=5 -> 8 (measured on MI355X)
         int L = 8;
+        {
+            const double lg = log((double)p->total[1] * 18446744073709551616.0 + (double)p->total[0]) / (double)m;
+            if (lg > 0.0 && 6.0 * lg >= log(32768.0)) L = 6;
+        }
         if (const char *e = getenv("THETA_N3_LEAF_LEVELS")) {
             int v = atoi(e);
             if (v >= 1 && v <= 8) L = v;

@@ -291,13 +291,18 @@ __device__ __forceinline__ double readlane_f64(double v, int l) {
 #ifndef N3_OCC
 #define N3_OCC 3       // blocks per CU the register budget is sized for
 #endif
+#ifndef N3_TRIES
+#define N3_TRIES 4    // evaluations a leaf may take in place before it is handed to the queue solver
+#endif
 #ifndef N3_LAG
 #define N3_LAG 4      // lanes that may still be between leaves when the wave evaluates (they skip that round)
 #endif
 #ifndef N3_QCAP
 #define N3_QCAP 128     // capacity of a wave's queue of leaves for the solver (survivors of the first evaluation)
 #endif
+#ifndef N3_MAX_L
 #define N3_MAX_L 8      // leaf levels (one byte of the 64-bit leaf code each)
+#endif
 
 // Everything a wave owns sits in ONE struct, so that a single base register (+ immediate offsets) addresses all of it.
 template <int L>
@@ -816,7 +821,7 @@ __global__ __launch_bounds__(64 * N3_WAVES, N3_OCC) void n3_search_kernel(N3Dev 
                     // here, in registers, as long as at least 8 of them do; whoever is left goes to the queue.
                     for (int tries = 0;; tries++) {
                         const unsigned long long evm = ballot64(ev);
-                        if (!evm || tries >= 4 || (tries > 0 && __builtin_popcountll(evm) < 8)) break;
+                        if (!evm || tries >= N3_TRIES || (tries > 0 && __builtin_popcountll(evm) < 8)) break;
                         n_it += (unsigned)__builtin_popcountll(evm);
                         n_terms += (unsigned)__builtin_popcountll(evm) * (unsigned)(G + L);
                         if (ev) {
@@ -1551,7 +1556,11 @@ void n3_launch_search(const N3Dev &P, const SearchArgs &A, const N3Task *tasks, 
         if (dump) hipLaunchKernelGGL((n3_search_kernel<LL, true>), grid, block, 0, st, P, A, tasks, stbuf, ntasks, per_task); \
         else hipLaunchKernelGGL((n3_search_kernel<LL, false>), grid, block, 0, st, P, A, tasks, stbuf, ntasks, per_task);     \
         break;
+    #if N3_MAX_L >= 8
     switch (P.L) { LAUNCH(1) LAUNCH(2) LAUNCH(3) LAUNCH(4) LAUNCH(5) LAUNCH(6) LAUNCH(7) default: LAUNCH(8) }
+#else
+    switch (P.L) { LAUNCH(1) LAUNCH(2) LAUNCH(3) LAUNCH(4) LAUNCH(5) default: LAUNCH(6) }
+#endif
 #undef LAUNCH
 }
 
@@ -1566,6 +1575,10 @@ void n3_launch_enumerate(const N3Dev &P, const N3Task *tasks, const unsigned *st
     case LL:                                                                                                            \
         hipLaunchKernelGGL((n3_enumerate_wave_kernel<LL>), grid, block, 0, st, P, tasks, stbuf, ntasks, per_task, out); \
         break;
+    #if N3_MAX_L >= 8
     switch (P.L) { LAUNCH(1) LAUNCH(2) LAUNCH(3) LAUNCH(4) LAUNCH(5) LAUNCH(6) LAUNCH(7) default: LAUNCH(8) }
+#else
+    switch (P.L) { LAUNCH(1) LAUNCH(2) LAUNCH(3) LAUNCH(4) LAUNCH(5) default: LAUNCH(6) }
+#endif
 #undef LAUNCH
 }
