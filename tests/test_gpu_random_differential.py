@@ -107,3 +107,31 @@ def test_n3_packed_f32_pass_and_fp64_iterations_return_the_same_finalists(monkey
         assert b["stats"]["dismissed"] == 0 and a["stats"]["dismissed"] > 0
         assert a["stats"]["accepted"] <= b["stats"]["accepted"] + 3 + a["stats"]["evaluated"] // 1000
         assert sorted(sa[0]) == sorted(sb[0])
+
+
+def test_bench_shape_packed_pass_dismissal_and_probe_do_not_change_the_finalists(monkeypatch):
+    """
+    m=50, n=3, k=6 (the bench's shape): a 2^26-candidate range searched (a) as shipped -- probe, packed single-precision
+    pass, dismissal by the lower bound -- and (b) with FP64 iterations and no dismissal, piecewise, must return the
+    same finalists; and the probe's hint must be attained inside the range.
+    """
+    import bench
+    import theta_amd
+    ctx = theta_amd.Context(0)
+    r, rN, order = bench.synth()
+    m, k = 50, 6
+    span = 1 << 26
+    out = []
+    for force in ("0", "1"):
+        monkeypatch.setenv("THETA_N3_FORCE_F64", force)
+        p = theta_amd.Problem(ctx, 3, m, 2, r, rN, [0] * m, [k] * m, 1.0)
+        b = p.count // 5
+        if force == "1":
+            monkeypatch.setattr(theta_amd.Problem, "PROBE_MIN_RANGE", 1 << 62)      # (b) without the probe
+        res = p.search(b, b + span, window=0.5)
+        out.append(res)
+    a, f = out
+    assert a["stats"]["dismissed"] > 0.9 * span and f["stats"]["dismissed"] == 0
+    assert a["rank"] == f["rank"] and len(a["rank"]) >= 1
+    assert np.array_equal(a["C"], f["C"])
+    assert np.allclose(a["nll"], f["nll"], rtol=1e-12, atol=0)

@@ -242,12 +242,14 @@ class Problem:
         """
         end = self.count if end is None else end
         step = self.MAX_PER_CALL[self.n]
+        running = self._probe(begin, end)
         if end - begin <= step:
+            if running < float("inf"):
+                self.hint(running)
             res = self._search_once(begin, end, window, cap)
             self.last_suspects = self.suspects() if self.n == 3 else ([], np.zeros(0), None)
             return res
         parts, sus = [], ([], [], [])
-        running = float("inf")
         for b in range(begin, end, step):
             if running < float("inf"):
                 self.hint(running)               # later pieces start from the minimum found so far
@@ -286,7 +288,32 @@ class Problem:
 
     def hint(self, nll_upper_bound):
         """One-shot: an NLL already known to be attainable (keeps the next search's lists short)."""
-        _check(load().theta_problem_hint(self._h, float(nll_upper_bound)))
+        self._hint = min(getattr(self, "_hint", float("inf")), float(nll_upper_bound))
+        _check(load().theta_problem_hint(self._h, self._hint))
+
+    PROBE_MIN_RANGE = 1 << 26     # n=3 ranges at least this long are probed first
+    PROBE_SAMPLES, PROBE_SIZE = 16, 1 << 16
+
+    def _probe(self, begin, end):
+        """
+        n=3: the minimum over a few short sub-ranges spread over [begin, end) -- an attainable NLL the real search can
+        start from (theta_problem_hint).  A range whose first stretch is poor (every optimum outside the simplex) would
+        otherwise fill the suspect list and solve everything to convergence until it meets a decent candidate.
+        Costs ~1e6 candidates; changes nothing in the result.  Includes a hint the caller set before.
+        """
+        running = getattr(self, "_hint", float("inf"))
+        self._hint = float("inf")
+        if self.n != 3 or end - begin < self.PROBE_MIN_RANGE or running < float("inf"):
+            return running                 # (a caller that already knows an attainable NLL needs no probe)
+        stride = (end - begin - self.PROBE_SIZE) // self.PROBE_SAMPLES
+        for i in range(self.PROBE_SAMPLES):
+            b = begin + i * stride
+            if running < float("inf"):
+                _check(load().theta_problem_hint(self._h, running))
+            res = self._search_once(b, b + self.PROBE_SIZE, 0.0, 64)
+            if len(res["nll"]):
+                running = min(running, float(res["nll"].min()))
+        return running
 
     def _search_once(self, begin, end, window, cap):
         st = SearchStats()
