@@ -135,3 +135,22 @@ def test_bench_shape_packed_pass_dismissal_and_probe_do_not_change_the_finalists
     assert a["rank"] == f["rank"] and len(a["rank"]) >= 1
     assert np.array_equal(a["C"], f["C"])
     assert np.allclose(a["nll"], f["nll"], rtol=1e-12, atol=0)
+
+
+def test_every_leaf_level_setting_returns_the_same_finalists(monkeypatch):
+    """The number of lane-enumerated rows (template parameter L of the n=3 search kernel; THETA_N3_LEAF_LEVELS) is a
+    tuning knob: every instantiation, incl. the ones with the prefix shorter than a wave task, must agree."""
+    import bench
+    import theta_amd
+    ctx = theta_amd.Context(0)
+    r, rN, order = bench.synth(seed=5, m=12, n=3, k=3)
+    ref = None
+    for L in (8, 6, 5, 3, 1):
+        monkeypatch.setenv("THETA_N3_LEAF_LEVELS", str(L))
+        p = theta_amd.Problem(ctx, 3, 12, 2, r, rN, [0] * 12, [3] * 12, 1.0)
+        res = p.search(0, p.count, window=0.5)
+        assert res["stats"]["evaluated"] == p.count
+        key = (res["rank"], np.round(res["nll"], 6).tolist(), res["C"].tolist())
+        if ref is None:
+            ref = key
+        assert key == ref, L
