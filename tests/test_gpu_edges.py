@@ -197,3 +197,50 @@ def test_enumerate_all_shapes_and_the_device_variant(ctx):
             hip.hipFree(dptr)
         assert (got[:16] == 0xEE).all() and (got[16 + (p.count - 9) * m * 2:] == 0xEE).all()       # nothing outside
         assert np.array_equal(got[16:16 + (p.count - 9) * m * 2].reshape(-1, m, 2), ref[5:p.count - 4])
+
+
+def test_burst_generator_against_oracle_and_lane_private_generator(ctx, monkeypatch):
+    """
+    The burst generator (n3_enum.hip: one output stream per wave, breadth-first over the last rows) against the oracle on
+    every small shape class -- m = 2..6 (1, 2 and 4 expanded rows, 32-bit and 16-bit units), ragged bounds, windows that
+    start and end inside a prefix -- and against the lane-private generator (THETA_ENUM_LEGACY=1) on the bench shape,
+    where a request spans many wave tasks and bursts are cut by the list capacities.
+    """
+    import theta_amd
+    rng = np.random.RandomState(17)
+    shapes = [(2, 2, None), (3, 2, None), (4, 3, None), (5, 2, None), (6, 3, None), (7, 3, None), (12, 2, None),
+              (9, 4, ([0, 0, 0, 1, 1, 1, 2, 2, 2], [1, 2, 2, 2, 3, 3, 3, 4, 4])),
+              (10, 5, ([0, 0, 1, 1, 1, 2, 2, 2, 2, 3], [1, 1, 2, 3, 3, 3, 4, 5, 5, 5]))]
+    for m, k, bounds in shapes:
+        lb, ub = bounds if bounds else ([0] * m, [k] * m)
+        r = rng.randint(1000, 5000, m).tolist()
+        rN = rng.randint(1000, 5000, m).tolist()
+        ref = np.array(list(orc.enumerate_n3(m, 2, lb, ub)), dtype=np.uint8)
+        p = theta_amd.Problem(ctx, 3, m, 2, r, rN, lb, ub, 1.0)
+        assert p.count == len(ref)
+        for levels in (None, "6"):
+            if levels:
+                monkeypatch.setenv("THETA_ENUM_LEVELS", levels)
+            assert np.array_equal(p.enumerate(0, p.count), ref), (m, k, levels)
+            for _ in range(4):
+                b = int(rng.randint(0, p.count))
+                c = int(rng.randint(1, min(p.count - b, 70000) + 1))
+                assert np.array_equal(p.enumerate(b, c), ref[b:b + c]), (m, k, b, c, levels)
+            monkeypatch.delenv("THETA_ENUM_LEVELS", raising=False)
+        p.close()
+    # bench shape: 3 tasks' worth from an odd start, both generators
+    import bench
+    for m, k in ((50, 6), (49, 5), (24, 7)):
+        r, rN, order = bench.synth(seed=3, m=m, n=3, k=k)
+        p = theta_amd.Problem(ctx, 3, m, 2, r, rN, [0] * m, [k] * m, 1.0)
+        for b, c in ((p.count // 7 + 12345, 3 * 8192 + 777), (0, 50000), (p.count - 40001, 40001)):
+            monkeypatch.setenv("THETA_ENUM_LEGACY", "1")
+            old = p.enumerate(b, c)
+            monkeypatch.delenv("THETA_ENUM_LEGACY")
+            for levels in (None, "6", "4", "2", "1"):          # expanded rows: the instance's own choice, and forced
+                if levels:
+                    monkeypatch.setenv("THETA_ENUM_LEVELS", levels)
+                new = p.enumerate(b, c)
+                monkeypatch.delenv("THETA_ENUM_LEVELS", raising=False)
+                assert np.array_equal(new, old), (m, k, b, c, levels)
+        p.close()

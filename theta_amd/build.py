@@ -17,6 +17,7 @@ ARCH = "gfx950"
 UNITS = [
     ("n2.hip", []),
     ("n3.hip", []),
+    ("n3_enum.hip", []),
     ("batch.hip", ["-ffp-contract=off"]),
     ("api.hip", []),
 ]

@@ -24,6 +24,9 @@ void n3_launch_tasks(const N3Dev &P, u128 begin, u128 end, uint64_t per_task, in
 void n3_launch_search(const N3Dev &P, const SearchArgs &A, const N3Task *tasks, const unsigned *stbuf, int ntasks,
                       uint64_t per_task, hipStream_t st);
 void n3_launch_unrank_list(const N3Dev &P, const TieRecord *recs, int count, unsigned char *out, hipStream_t st);
+int n3_enumerate_burst_levels(const N3Dev &P);
+void n3_launch_enumerate_burst(const N3Dev &P, const N3Task *tasks, const unsigned *stbuf, int ntasks, uint64_t per_task,
+                               unsigned char *out, hipStream_t st);
 void n3_launch_enumerate(const N3Dev &P, const N3Task *tasks, const unsigned *stbuf, int ntasks, uint64_t per_task,
                          unsigned char *out, hipStream_t st);
 
@@ -706,12 +709,20 @@ static int enumerate_device(theta_problem *p, u128 b, uint64_t count, unsigned c
         uint64_t per_task = 8192;
         while (per_task < 65536 && per_task * 8192 < count) per_task <<= 1;
         const uint64_t piece = (uint64_t)N3_MAX_TASKS * per_task;
+        // the burst generator (n3_enum.hip: one contiguous output stream per wave) cuts its tasks at its own depth
+        N3Dev PE = p->n3;
+        const int burst_levels = getenv("THETA_ENUM_LEGACY") ? 0 : n3_enumerate_burst_levels(PE);
+        if (burst_levels > 0) PE.L = burst_levels;
         for (uint64_t off = 0; off < count; off += piece) {
             const uint64_t c = std::min<uint64_t>(piece, count - off);
             const int ntasks = (int)((c + per_task - 1) / per_task);
-            n3_launch_tasks(p->n3, b + off, b + off + c, per_task, ntasks, (N3Task *)p->d_tasks.p, (unsigned *)p->d_stbuf.p, st);
-            n3_launch_enumerate(p->n3, (const N3Task *)p->d_tasks.p, (const unsigned *)p->d_stbuf.p, ntasks, per_task,
-                                d_out + (size_t)off * cb, st);
+            n3_launch_tasks(PE, b + off, b + off + c, per_task, ntasks, (N3Task *)p->d_tasks.p, (unsigned *)p->d_stbuf.p, st);
+            if (burst_levels > 0)
+                n3_launch_enumerate_burst(PE, (const N3Task *)p->d_tasks.p, (const unsigned *)p->d_stbuf.p, ntasks, per_task,
+                                          d_out + (size_t)off * cb, st);
+            else
+                n3_launch_enumerate(PE, (const N3Task *)p->d_tasks.p, (const unsigned *)p->d_stbuf.p, ntasks, per_task,
+                                    d_out + (size_t)off * cb, st);
         }
     }
     HIP_TRY(hipEventRecord(ctx->ev2, st));

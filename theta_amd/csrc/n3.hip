@@ -185,22 +185,6 @@ __device__ bool n3_unrank(const N3Dev &P, u128 rho, int depth, N3State *st, u128
     return true;
 }
 
-// 32-bit form of a DFS node: slot 7 bits | sw | lo 8 | hi 8 | a 4 | b 4
-__device__ __forceinline__ unsigned n3_pack(const N3State &s) {
-    return (unsigned)s.slot | ((unsigned)s.sw << 7) | ((unsigned)s.lo << 8) | ((unsigned)s.hi << 16) |
-           ((unsigned)s.a << 24) | ((unsigned)s.b << 28);
-}
-__device__ __forceinline__ N3State n3_unpack(unsigned v) {
-    N3State s;
-    s.slot = v & 0x7f;
-    s.sw = (v >> 7) & 1;
-    s.lo = (v >> 8) & 0xff;
-    s.hi = (v >> 16) & 0xff;
-    s.a = (v >> 24) & 0xf;
-    s.b = (v >> 28) & 0xf;
-    return s;
-}
-
 // Wave-cooperative rank -> DFS path: at every level the 64 lanes test the 64 alphabet slots and read their
 // children's counts in ONE memory round trip (the serial walk above chains ~5 dependent HBM reads per level);
 // the wave then scans the feasible children in slot order.  Lane d ends up holding the packed node of depth d.
@@ -338,27 +322,6 @@ struct N3Lds {
 #define RES_FAIL 2u
 #define RES_DEGEN 3u
 #define RES_SINGULAR 4u
-
-// Dynamic part of the edge test for a child that already passed the static mask (valid row, bounds,
-// edge rule) and the symmetry mask: only the ratio window remains (Enumerator.py:204-212).
-__device__ __forceinline__ bool n3_child_dyn(const unsigned char *ridx, const unsigned char *rowtab, const N3State &par,
-                                             int slot, N3State &out) {
-    unsigned rw = rowtab[slot];
-    int a = rw & 15, b = rw >> 4;
-    int lo = par.lo, hi = par.hi;
-    int dx = a - par.a, dy = b - par.b;
-    if (dx != 0 && dy != 0) {
-        int t = ridx[(dy + N3_MAX_K) * N3_RIDX_W + (dx + N3_MAX_K)];
-        if (dx > 0) lo = (t > lo) ? t : lo; else hi = (t < hi) ? t : hi;
-    }
-    out.slot = slot;
-    out.sw = par.sw && (a == b);
-    out.lo = lo;
-    out.hi = hi;
-    out.a = a;
-    out.b = b;
-    return lo <= hi;
-}
 
 // ---- the cold path of a candidate whose screened value is within the margin of the running minimum -------------
 template <int L>

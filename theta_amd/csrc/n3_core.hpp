@@ -110,6 +110,43 @@ __host__ __device__ inline bool n3_edge(const N3Dev &P, const N3State &par, int 
 }
 
 #ifdef __HIPCC__
+// 32-bit form of a DFS node: slot 7 bits | sw | lo 8 | hi 8 | a 4 | b 4
+__device__ __forceinline__ unsigned n3_pack(const N3State &s) {
+    return (unsigned)s.slot | ((unsigned)s.sw << 7) | ((unsigned)s.lo << 8) | ((unsigned)s.hi << 16) |
+           ((unsigned)s.a << 24) | ((unsigned)s.b << 28);
+}
+__device__ __forceinline__ N3State n3_unpack(unsigned v) {
+    N3State s;
+    s.slot = v & 0x7f;
+    s.sw = (v >> 7) & 1;
+    s.lo = (v >> 8) & 0xff;
+    s.hi = (v >> 16) & 0xff;
+    s.a = (v >> 24) & 0xf;
+    s.b = (v >> 28) & 0xf;
+    return s;
+}
+
+// Dynamic part of the edge test for a child that already passed the static mask (valid row, bounds,
+// edge rule) and the symmetry mask: only the ratio window remains (Enumerator.py:204-212).
+__device__ __forceinline__ bool n3_child_dyn(const unsigned char *ridx, const unsigned char *rowtab, const N3State &par,
+                                             int slot, N3State &out) {
+    unsigned rw = rowtab[slot];
+    int a = rw & 15, b = rw >> 4;
+    int lo = par.lo, hi = par.hi;
+    int dx = a - par.a, dy = b - par.b;
+    if (dx != 0 && dy != 0) {
+        int t = ridx[(dy + N3_MAX_K) * N3_RIDX_W + (dx + N3_MAX_K)];
+        if (dx > 0) lo = (t > lo) ? t : lo; else hi = (t < hi) ? t : hi;
+    }
+    out.slot = slot;
+    out.sw = par.sw && (a == b);
+    out.lo = lo;
+    out.hi = hi;
+    out.a = a;
+    out.b = b;
+    return lo <= hi;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Mixture solve for n = 3 in the scaled variables u_j = nu_j N / S_j (S_j = column sums of the
 // weighted matrix, sigma_j = S_j / N):  with u_0 eliminated through sum_j sigma_j u_j = 1,

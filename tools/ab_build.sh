@@ -1,10 +1,15 @@
 #!/bin/bash
-# A/B builds of the n3 search kernel: tools/ab_build.sh NAME [extra hipcc flags]  ->  build_ab/libNAME.so
+# A/B builds of one unit (UNIT=n3 by default, e.g. UNIT=n3_enum): tools/ab_build.sh NAME [extra hipcc flags]  ->  build_ab/libNAME.so
 set -e
 cd "$(dirname "$0")/.."
 name=$1; shift
 mkdir -p build_ab
 # (links against the other units' objects of the last regular build; never rebuilds the main library)
-/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -fno-gpu-rdc -Wno-unused-function "$@" -c theta_amd/csrc/n3.hip -o build_ab/n3_$name.o
-/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o build_ab/lib$name.so theta_amd/csrc/n2.o build_ab/n3_$name.o theta_amd/csrc/batch.o theta_amd/csrc/api.o
+unit=${UNIT:-n3}
+/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -fno-gpu-rdc -Wno-unused-function "$@" -c theta_amd/csrc/$unit.hip -o build_ab/${unit}_$name.o
+objs=""
+for u in n2 n3 n3_enum batch api; do
+    if [ "$u" = "$unit" ]; then objs="$objs build_ab/${unit}_$name.o"; else objs="$objs theta_amd/csrc/$u.o"; fi
+done
+/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o build_ab/lib$name.so $objs
 echo build_ab/lib$name.so
