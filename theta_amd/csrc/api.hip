@@ -704,15 +704,21 @@ static int enumerate_device(theta_problem *p, u128 b, uint64_t count, unsigned c
     if (p->n == 2) {
         n2_launch_enumerate(p->n2, (unsigned long long)b, count, d_out, st);
     } else {
-        // a wave task unranks 64 chunk starts per prefix (random reads of the counting table): fewer, longer tasks
-        // for big requests, but always enough of them (~8192) to fill the chip
-        uint64_t per_task = 8192;
-        while (per_task < 65536 && per_task * 8192 < count) per_task <<= 1;
-        const uint64_t piece = (uint64_t)N3_MAX_TASKS * per_task;
         // the burst generator (n3_enum.hip: one contiguous output stream per wave) cuts its tasks at its own depth
         N3Dev PE = p->n3;
         const int burst_levels = getenv("THETA_ENUM_LEGACY") ? 0 : n3_enumerate_burst_levels(PE);
         if (burst_levels > 0) PE.L = burst_levels;
+        // wave tasks of 8192 candidates (0.8 MB of output at m=50): a 2^28 request is 32768 tasks, 6.4 x the 5120 resident
+        // waves, so the last round of blocks leaves little of the chip idle (measured: 16384 is as good at K=6, worse at
+        // K=4; 65536 loses 15-40 %).  The lane-private generator unranks 64 chunk starts per prefix: fewer, longer tasks.
+        uint64_t per_task = 8192;
+        if (burst_levels == 0)
+            while (per_task < 65536 && per_task * 8192 < count) per_task <<= 1;
+        if (const char *e = getenv("THETA_ENUM_PER_TASK")) {
+            const long v = atol(e);
+            if (v >= 64 && v <= (1l << 24)) per_task = (uint64_t)v;
+        }
+        const uint64_t piece = (uint64_t)N3_MAX_TASKS * per_task;
         for (uint64_t off = 0; off < count; off += piece) {
             const uint64_t c = std::min<uint64_t>(piece, count - off);
             const int ntasks = (int)((c + per_task - 1) / per_task);

@@ -5,7 +5,7 @@ import torch
 import bench, theta_amd, numpy as np
 ctx = theta_amd.Context(0)
 out = {}
-for name, n, m, k, cnt in (("n3_m50_k6", 3, 50, 6, 1 << 26), ("n3_m50_k4", 3, 50, 4, 1 << 26), ("n3_m64_k3", 3, 64, 3, 1 << 26), ("n3_m25_k4", 3, 25, 4, 1 << 26),
+for name, n, m, k, cnt in (("n3_m50_k6", 3, 50, 6, 1 << 28), ("n3_m50_k4", 3, 50, 4, 1 << 28), ("n3_m64_k3", 3, 64, 3, 1 << 28), ("n3_m25_k4", 3, 25, 4, 1 << 28), ("n3_m49_k5", 3, 49, 5, 1 << 28),
                            ("n2_m50_k6", 2, 50, 6, 1 << 24), ("n2_m100_k5", 2, 100, 5, 1 << 26)):
     r, rN, order = bench.synth(seed=11, m=m, n=n, k=k)
     p = theta_amd.Problem(ctx, n, m, 2, r, rN, [0] * m, [k] * m, 1.0)
