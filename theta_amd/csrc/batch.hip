@@ -407,15 +407,35 @@ __global__ __launch_bounds__(256) void score_masked_kernel(int n, int m, int tau
 }
 
 // ------------------------------------------------------------------------------------------------
-// The same operator as a dense FP64 GEMM on the matrix cores: for a block of 8 candidates the masked sums
-// over intervals are   D[S x 16] = MASK[S x m] . X[m x 16],   X[:, 2c] = C.mu of candidate c, X[:, 2c+1] =
+// The same operator as a dense FP64 GEMM on the matrix cores: for a block of 16 candidates the masked sums
+// over intervals are   D[S x 32] = MASK[S x m] . X[m x 32],   X[:, 2c] = C.mu of candidate c, X[:, 2c+1] =
 // r ln(C.mu): the 0/1 mask matrix is shared by all candidates -- a genuine GEMM (K = m), so it runs on
 // v_mfma_f64_16x16x4_f64.  The X tile is built once per block (all the logarithms) and stays in LDS; each
 // wave walks 16-mask chunks, 4 rows of X per MFMA step.  Fragment maps (f64 form): A[i][k]: i = lane&15,
 // k = lane>>4; B[k][j]: j = lane&15, k = lane>>4; D[row][col]: col = lane&15, row = (lane>>4) + 4*reg.
 // ------------------------------------------------------------------------------------------------
 typedef double mfma_d4 __attribute__((ext_vector_type(4)));
-#define SMX_CAND 8
+
+// ln(x) for the epilogue of the masked scorer (one per (candidate, mask) pair): the classic reduction x = 2^k (1 + f),
+// 1 + f in [sqrt(1/2), sqrt(2)), ln(1 + f) = 2 atanh(s) with s = f / (2 + f) as a degree-7 polynomial in s^2 (the
+// coefficients of Sun's fdlibm e_log.c, error < 1 ulp), ~35 instructions instead of the library call's ~90.  Anything
+// that is not a positive normal number goes to the library.
+__device__ __forceinline__ double smx_log(double x) {
+    const int hx = __double2hiint(x);
+    if (!(hx >= 0x00100000 && hx < 0x7ff00000)) return log(x);
+    const int i = ((hx & 0x000fffff) + 0x95f64) & 0x100000;
+    const int k = (hx >> 20) - 1023 + (i >> 20);
+    const double f = __hiloint2double((hx & 0x000fffff) | (i ^ 0x3ff00000), __double2loint(x)) - 1.0;
+    const double s = f * rcp_nr2(2.0 + f), dk = (double)k;      // (reciprocal to full double accuracy, no division sequence)
+    const double z = s * s, w = z * z;
+    const double t1 = w * (3.999999999940941908e-01 + w * (2.222219843214978396e-01 + w * 1.531383769920937332e-01));
+    const double t2 = z * (6.666666666666735130e-01 +
+                           w * (2.857142874366239149e-01 + w * (1.818357216161805012e-01 + w * 1.479819860511658591e-01)));
+    const double R = t2 + t1, hfsq = 0.5 * f * f;
+    return dk * 6.93147180369123816490e-01 - ((hfsq - (s * (hfsq + R) + dk * 1.90821492927058770002e-10)) - f);
+}
+#define SMX_CAND 16
+#define SMX_WAVES 8
 #define SMX_MAXM 256
 
 __global__ __launch_bounds__(64) void mask_rsum_kernel(int m, int S, const double *r, const unsigned long long *mask,
@@ -429,17 +449,22 @@ __global__ __launch_bounds__(64) void mask_rsum_kernel(int m, int S, const doubl
     if (lane == 0) rsum[s] = acc;
 }
 
-__global__ __launch_bounds__(256) void score_masked_mfma_kernel(int n, int m, int tau, int B, int S,
-                                                                const unsigned char *C, const double *w, const double *r,
-                                                                const double *mu, const unsigned long long *mask,
-                                                                const double *rsum, double *nll) {
-    __shared__ double X[SMX_MAXM][16];                     // 32 KB: rows = intervals, 2 columns per candidate
-    __shared__ unsigned long long zrow[SMX_CAND][4];       // per candidate: rows that become 0 once masked (NaN poison)
-    const int b0 = blockIdx.x * SMX_CAND;
-    const int nc = n - 1, words = (m + 63) / 64, mpad = (m + 3) & ~3;
+// Block = 8 waves and 16 candidates: X has 32 columns (two 16-column B fragments), so that every A fragment -- the mask
+// bits, the only operand that costs vector instructions to build -- feeds two MFMAs with independent accumulators.
+// X is dynamic LDS, mpad x 32 doubles (53 KB at m=200: three blocks = 24 waves per CU); odd rows store their two
+// 16-column halves swapped, so that the four rows one ds_read_b64 touches alternate between the two halves of the banks.
+extern __shared__ double smx_lds[];
+__global__ __launch_bounds__(64 * SMX_WAVES) void score_masked_mfma_kernel(int n, int m, int tau, int B, int S,
+                                                                           const unsigned char *C, const double *w, const double *r,
+                                                                           const double *mu, const unsigned long long *mask,
+                                                                           const double *rsum, double *nll) {
+    const int nc = n - 1, words = (m + 63) / 64, mpad = (m + 15) & ~15;      // rows of X in 16-row groups (zero rows beyond m)
+    double *const X = smx_lds;                                                // [mpad][32]: columns 2c, 2c+1 = candidate c
+    unsigned long long(*const zrow)[4] = (unsigned long long(*)[4])(smx_lds + (size_t)mpad * 32);   // [SMX_CAND][4]: rows that
+    const int b0 = blockIdx.x * SMX_CAND;                                     // become 0 once masked (NaN poison, quirk Q10)
     for (int i = threadIdx.x; i < SMX_CAND * 4; i += blockDim.x) (&zrow[0][0])[i] = 0ull;
     __syncthreads();
-    // ---- phase 1: the per-row terms of the 8 candidates (one thread per (candidate, row) pair, rows strided by 32)
+    // ---- phase 1: the per-row terms of the 16 candidates (32 threads per candidate, rows strided by 32)
     {
         const int c = threadIdx.x >> 5, b = b0 + c;
         const bool live = b < B;
@@ -457,50 +482,86 @@ __global__ __launch_bounds__(256) void score_masked_mfma_kernel(int n, int m, in
                 double x = (double)cc[0], y = (nc == 2) ? (double)cc[1] : 0.0;
                 double tum = x * m1 + y * m2;
                 cm = w[i] * ((double)tau * m0 + tum);
-                tl = r[i] * log(cm);
+                tl = r[i] * smx_log(cm);
                 if (!(w[i] * tum > 0.0)) atomicOr(&zrow[c][i >> 6], 1ull << (i & 63));
             }
-            X[i][2 * c] = cm;
-            X[i][2 * c + 1] = tl;
+            const int col = (2 * c) ^ ((i & 1) << 4);
+            X[i * 32 + col] = cm;
+            X[i * 32 + col + 1] = tl;
         }
     }
     __syncthreads();
+    // (quirk Q10 needs a look at the mask only if some row of these candidates becomes 0 once its column 0 is masked)
+    bool any_zrow = false;
+    for (int i = 0; i < SMX_CAND * 4; i++) any_zrow |= (&zrow[0][0])[i] != 0ull;
     // ---- phase 2: masked sums on the matrix cores
+    // A[i][k] = mask bit k of mask row s0+i as a double: lane (li, lk) walks bits lk, lk+4, ... of its row -- a 16-bit
+    // group of a mask word shifted right by lk, then per MFMA step one sign-extending bit-field extract (0 / -1) and one
+    // AND with the high word of 1.0.
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int li = lane & 15, lk = lane >> 4;
-    for (int s0 = wv * 16; s0 < S; s0 += 64) {
+    const int colA = li ^ ((lk & 1) << 4), colB = colA ^ 16;       // this lane's column in the two B fragments (row parity = lk parity)
+    for (int s0 = wv * 16; s0 < S; s0 += 16 * SMX_WAVES) {
         const int sA = s0 + li;                             // mask row this lane feeds into A
-        unsigned long long mw0 = 0, mw1 = 0, mw2 = 0, mw3 = 0;
+        unsigned long long mw[4] = {0, 0, 0, 0};
         if (sA < S) {
             const unsigned long long *mp = mask + (size_t)sA * words;
-            mw0 = mp[0];
-            if (words > 1) mw1 = mp[1];
-            if (words > 2) mw2 = mp[2];
-            if (words > 3) mw3 = mp[3];
-        }
-        mfma_d4 acc = {0.0, 0.0, 0.0, 0.0};
-        for (int kk = 0; kk < mpad; kk += 4) {
-            const int k = kk + lk;
-            unsigned long long wd = (k < 64) ? mw0 : (k < 128) ? mw1 : (k < 192) ? mw2 : mw3;
-            double a = (double)((wd >> (k & 63)) & 1ull);
-            double bv = X[k][li];
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bv, acc, 0, 0, 0);
-        }
-        // D[row = lk + 4*reg][col = li]; col 2c = sum of C.mu (den), col 2c+1 = sum of r ln(C.mu) (tot)
-        const int c = li >> 1, b = b0 + c;
 #pragma unroll
-        for (int reg = 0; reg < 4; reg++) {
-            double v = acc[reg];
-            double den = __shfl_xor(v, 1, WAVE);            // partner column of the same candidate
-            const int s = s0 + lk + 4 * reg;
-            if ((li & 1) && s < S && b < B) {
-                const unsigned long long *mp = mask + (size_t)s * words;
-                bool poison = false;
-                for (int q = 0; q < words; q++) {
-                    unsigned long long live_bits = (q == words - 1 && (m & 63)) ? ((1ull << (m & 63)) - 1ull) : ~0ull;
-                    if (~mp[q] & zrow[c][q] & live_bits) poison = true;
+            for (int q = 0; q < 4; q++)
+                if (q < words) mw[q] = mp[q];
+        }
+        mfma_d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+        // 16 rows of X per group: eight LDS reads in flight, then eight MFMAs; the 16 groups are unrolled behind uniform guards
+#pragma unroll
+        for (int g = 0; g < SMX_MAXM / 16; g++) {
+            if (g * 16 < mpad) {
+                const unsigned long long wq = mw[g / 4];
+                const unsigned half = (g & 2) ? (unsigned)(wq >> 32) : (unsigned)wq;
+                const unsigned cur = ((g & 1) ? (half >> 16) : half) >> lk;          // bits 0, 4, 8, 12: rows g*16 + lk + 4 step
+                double bv0[4], bv1[4];
+#pragma unroll
+                for (int step = 0; step < 4; step++) {
+                    const double *row = X + (size_t)(g * 16 + step * 4 + lk) * 32;
+                    bv0[step] = row[colA];
+                    bv1[step] = row[colB];
                 }
-                nll[(size_t)b * S + s] = poison ? __builtin_nan("") : -(v - rsum[s] * log(den));
+#pragma unroll
+                for (int step = 0; step < 4; step++) {
+                    const int ahi = __builtin_amdgcn_sbfe((int)cur, 4 * step, 1) & 0x3ff00000;
+                    const double a = __hiloint2double(ahi, 0);
+                    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bv0[step], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bv1[step], acc1, 0, 0, 0);
+                }
+            }
+        }
+        // D[row = lk + 4*reg][col = li]; col 2c = sum of C.mu (den), col 2c+1 = sum of r ln(C.mu) (tot).  The 128 pairs of a
+        // fragment are two per lane: the even column's lane finishes rows lk, lk+4 (it gets tot from its odd neighbour), the
+        // odd column's lane rows lk+8, lk+12 (it gets den from its even neighbour) -- every lane evaluates two logarithms.
+        const int odd = li & 1;
+#pragma unroll
+        for (int f = 0; f < 2; f++) {
+            const mfma_d4 acc = f ? acc1 : acc0;
+            const int c = (li >> 1) + 8 * f, b = b0 + c;
+            const double x0 = __shfl_xor(odd ? acc[0] : acc[2], 1, WAVE);
+            const double x1 = __shfl_xor(odd ? acc[1] : acc[3], 1, WAVE);
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                const int reg = odd ? 2 + j : j;
+                const double own = odd ? (j ? acc[3] : acc[2]) : (j ? acc[1] : acc[0]);
+                const double got = j ? x1 : x0;
+                const double den = odd ? got : own, tot = odd ? own : got;
+                const int s = s0 + lk + 4 * reg;
+                if (s < S && b < B) {
+                    bool poison = false;
+                    if (any_zrow) {
+                        const unsigned long long *mp = mask + (size_t)s * words;
+                        for (int q = 0; q < words; q++) {
+                            unsigned long long live_bits = (q == words - 1 && (m & 63)) ? ((1ull << (m & 63)) - 1ull) : ~0ull;
+                            if (~mp[q] & zrow[c][q] & live_bits) poison = true;
+                        }
+                    }
+                    nll[(size_t)b * S + s] = poison ? __builtin_nan("") : -(tot - rsum[s] * smx_log(den));
+                }
             }
         }
     }
@@ -537,8 +598,14 @@ void batch_launch_score_masked(int n, int m, int tau, int B, int S, const unsign
                                double *rsum_scratch, hipStream_t st) {
     if (mask != nullptr && S >= 16 && rsum_scratch != nullptr) {   // enough masks to fill the 16-row MFMA tiles
         hipLaunchKernelGGL(mask_rsum_kernel, dim3(S), dim3(64), 0, st, m, S, r, mask, rsum_scratch);
-        hipLaunchKernelGGL(score_masked_mfma_kernel, dim3((B + SMX_CAND - 1) / SMX_CAND), dim3(256), 0, st, n, m, tau, B, S, C,
-                           w, r, mu, mask, rsum_scratch, nll);
+        const size_t lds = ((size_t)((m + 15) & ~15) * 32 + SMX_CAND * 4) * sizeof(double);
+        static size_t attr_bytes = 0;
+        if (attr_bytes < lds) {
+            (void)hipFuncSetAttribute((const void *)score_masked_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            attr_bytes = lds;
+        }
+        hipLaunchKernelGGL(score_masked_mfma_kernel, dim3((B + SMX_CAND - 1) / SMX_CAND), dim3(64 * SMX_WAVES), lds, st, n, m,
+                           tau, B, S, C, w, r, mu, mask, rsum_scratch, nll);
     } else {
         hipLaunchKernelGGL(score_masked_kernel, dim3((B + 3) / 4), dim3(256), 0, st, n, m, tau, B, S, C, w, r, mu, mask, nll);
     }

@@ -56,7 +56,7 @@ def main():
     w = rng.randint(1000, 90000, m).astype(float)
     rr = rng.randint(1000, 90000, m).astype(float)
     words = (m + 63) // 64
-    for B, S in ((1 << 16, 64), (1 << 14, 512)):
+    for B, S in ((1 << 16, 64), (1 << 14, 512), (1 << 17, 512)):
         C = rng.randint(0, 8, (B, m, 2)).astype(np.uint8)
         mu = rng.dirichlet(np.ones(3) * 3, B)
         masks = rng.randint(0, 2 ** 63, (S, words), dtype=np.int64).astype(np.uint64)
@@ -64,7 +64,7 @@ def main():
         ms = min(ctx.score_masked(nn, 2, C, w, rr, mu, masks)[1] for _ in range(5))
         algo_bytes = B * (m * 2 + 8 * nn) + B * S * 8 + S * words * 8      # candidates + mu read, NLL written, masks
         flops = 2.0 * S * m * 2 * B                                        # the two masked sums as a GEMM
-        out["config5_scorer_m200_k7_S%d" % S] = {
+        out["config5_scorer_m200_k7_S%d_B%d" % (S, B)] = {
             "pairs": B * S, "kernel_ms": ms, "pairs_per_s": B * S / (ms * 1e-3),
             "algorithmic_GBps": algo_bytes / (ms * 1e-3) / 1e9, "hbm_peak_GBps": 8000.0,
             "mfma_fp64_tflops": flops / (ms * 1e-3) / 1e12, "mfma_fp64_peak_tflops": 78.6}
