@@ -107,6 +107,84 @@ def cpu_baseline(cands, r, rN, budget_s=15.0):
                       "%d concurrent processes, %.1f s of solving each" % (done, cores, dt)}
 
 
+def extras(ctx, r, rN, cpu_seconds):
+    """
+    Secondary figures of the BASELINE metric, N=1 only, outside the timed region:
+    * full_solve: the same search with the lower-bound dismissal switched off (THETA_N3_NO_DISMISS=1) -- every candidate is
+      iterated to the coarse tolerance and valued, none is finished after one evaluation by its bound;
+    * wall_clock_to_best: end-to-end do_optimization_single (search + finalists in reference arithmetic + tie replay) on the
+      two exhaustible BASELINE configs -- config 1 (example/Example.intervals -n 2 -k 3 after interval selection: 142 560
+      candidates; fixture tests/golden/example_n2.json, which also holds the reference's own search time in the build
+      container) and config 2 (synthetic m=25, n=2, k=5: 142 506 candidates; the CPU side is the oracle on a sample of the
+      same candidates, extrapolated).
+    """
+    import theta_amd
+    from theta_amd.search import do_optimization_single
+    out = {}
+    os.environ["THETA_N3_NO_DISMISS"] = "1"
+    try:
+        p2 = theta_amd.Problem(ctx, N_POP, M, TAU, r, rN, [0] * M, [K_MAX] * M, 1.0)
+    finally:
+        del os.environ["THETA_N3_NO_DISMISS"]
+    total, batch = p2.count, 1 << 29
+    ev = 0
+    kms = 0.0
+    best = float("inf")
+    t0 = None
+    for i in range(3):
+        if i == 1:
+            t0 = time.time()
+        if best < float("inf"):
+            p2.hint(best)
+        res = p2.search(total // 7 * (i + 1), total // 7 * (i + 1) + batch, window=0.5)
+        if len(res["nll"]):
+            best = min(best, float(res["nll"].min()))
+        if i >= 1:
+            ev += res["stats"]["evaluated"]
+            kms += res["stats"]["kernel_ms"]
+            dis = res["stats"]["dismissed"]
+    dt = time.time() - t0
+    out["full_solve"] = {"value": ev / dt, "unit": "candidates/s", "kernel_candidates_per_s": ev / (kms * 1e-3),
+                         "dismissed": int(dis), "note": "THETA_N3_NO_DISMISS=1, 2 x 2^29 candidates of the same instance: no "
+                         "candidate is finished by its lower bound"}
+    p2.close()
+    w = {}
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import theta_oracle as orc
+    try:
+        e = json.load(open(os.path.join(ROOT, "tests", "golden", "example_n2.json")))
+        ts = []
+        for _ in range(3):
+            t = time.time()
+            b1 = do_optimization_single(2, e["m"], e["k"], e["tau"], list(e["lb"]), list(e["ub"]), e["r"], e["rN"],
+                                        e["max_normal"], e["sorted_index"], False, False)
+            ts.append(time.time() - t)
+        w["config1_example_n2_k3"] = {"candidates": 142560, "gpu_wall_s": min(ts), "nll": b1[0][2],
+                                      "reference_search_s": e.get("ref_search_seconds"),
+                                      "reference_note": "the reference's own search loop on this input, timed in the build container"}
+    except Exception as ex:       # the fixture is test data; the bench line does not depend on it
+        w["config1_example_n2_k3"] = {"error": str(ex)}
+    r2, rN2, order2 = synth(seed=11, m=25, n=2, k=5)
+    ts = []
+    for _ in range(3):
+        t = time.time()
+        b2 = do_optimization_single(2, 25, 5, TAU, [0] * 25, [5] * 25, r2, rN2, 1.0, order2, False, False)
+        ts.append(time.time() - t)
+    t = time.time()
+    n_s = 0
+    for c in orc.enumerate_n2(25, TAU, [0] * 25, [5] * 25):
+        orc.solve_n2(orc.col_to_matrix_n2(c, TAU), r2, rN2, 1.0)
+        n_s += 1
+        if time.time() - t > cpu_seconds / 3:
+            break
+    cpu_rate = n_s / (time.time() - t)
+    w["config2_m25_n2_k5"] = {"candidates": 142506, "gpu_wall_s": min(ts), "nll": b2[0][2],
+                              "cpu_oracle_candidates_per_s": cpu_rate, "cpu_oracle_estimated_s": 142506 / cpu_rate,
+                              "cpu_sample": "%d candidates, 1 process" % n_s}
+    out["wall_clock_to_best"] = w
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -259,6 +337,10 @@ def main():
             cands = np.concatenate([problem.enumerate(shard0 + i * stride + 12345, per) for i in range(nsteps)])
             out["cpu_baseline"] = cpu_baseline(cands, r, rN, args.cpu_seconds)
             out["speedup_vs_cpu_all_cores"] = value / out["cpu_baseline"]["value"]
+            try:
+                out.update(extras(ctx, r, rN, args.cpu_seconds))
+            except Exception as ex:
+                out["extras_error"] = str(ex)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))

@@ -279,6 +279,8 @@ extern "C" int theta_problem_create(theta_ctx *ctx, int n, int m, int tau, const
         D.force64 = 0;
         if (const char *e = getenv("THETA_N3_FORCE_F64")) D.force64 = atoi(e) != 0;
         if (const char *e = getenv("THETA_N3_CONV_L2")) D.conv_l2 = atof(e);
+        D.no_dismiss = 0;
+        if (const char *e = getenv("THETA_N3_NO_DISMISS")) D.no_dismiss = atoi(e) != 0;
         D.N = (double)N;
         D.Rtot = (double)Rt;
         D.K0 = (double)k0;

@@ -796,7 +796,7 @@ __global__ __launch_bounds__(64 * N3_WAVES, N3_OCC) void n3_search_kernel(N3Dev 
                                     const float lt = __builtin_sqrtf(lt2);
                                     const double gap = 1.05 * 0.5 * (double)(l2v * rtot_f * __builtin_amdgcn_rcpf(1.0f - lt));
                                     const double lb = (P.K0 - 0.6931471805599453 * (double)val2) - gap - screen_margin;
-                                    if (lb > best + A.window) {
+                                    if (lb > best + A.window && !P.no_dismiss) {
                                         push = false;          // dismissed
                                         ev = false;
                                     }
@@ -956,7 +956,7 @@ __global__ __launch_bounds__(64 * N3_WAVES, N3_OCC) void n3_search_kernel(N3Dev 
                                 const float lt = __builtin_sqrtf(lt2);
                                 const double gap = 1.05 * 0.5 * (double)(l2v * rtot_f * __builtin_amdgcn_rcpf(1.0f - lt));
                                 const double lb = (P.K0 - 0.6931471805599453 * (double)val2) - gap - screen_margin;
-                                if (lb > best + A.window) {
+                                if (lb > best + A.window && !P.no_dismiss) {
                                     resSt[myidx] = (unsigned short)0;          // state 0: dismissed
                                     // the stepped iterate still serves the next leaf of the chunk as a start, if interior
                                     const double n1 = s1 * Sv.u1, n2 = s2 * Sv.u2;

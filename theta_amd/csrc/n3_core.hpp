@@ -26,6 +26,7 @@ struct N3Dev {
     double warm_blend;           // weight of the previous optimum in the warm start (rest: simplex centre)
     int force64;                 // 1: iterate every candidate in FP64 (THETA_N3_FORCE_F64; the packed-f32 pass is the default)
     double conv_l2;              // convergence threshold on the squared Newton decrement
+    int no_dismiss;              // 1: never finish a candidate by its lower bound (THETA_N3_NO_DISMISS): every one is iterated to the coarse tolerance
     unsigned long long total_lo, total_hi;
 };
 
