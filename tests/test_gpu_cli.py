@@ -82,6 +82,38 @@ def test_cli_default_pipeline_n2_then_n3_then_model_selection(tmp_path):
     assert best[0][0] in (res3[0][0], _parse_results(tmp_path / "s.n2.results")[0][0])
 
 
+def test_cli_default_pipeline_on_example_with_force(tmp_path):
+    """
+    `RunTHetA example/Example.intervals --FORCE` (no -n): the n=2 stage must reproduce the reference CLI's files; the n=3
+    stage -- 16 selected intervals, 98 846 979 candidate matrices, which the reference cannot finish (stopped
+    after minutes at 30-800 candidates/s) -- must complete, and its reported solution must be self-consistent: the search
+    winner is an optimum the oracle's solver confirms, and the written NLL is CalcAllC.L3 of the written C and mu.
+    """
+    import sys
+    import theta_amd.search as S
+    from theta_amd import CalcAllC
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import theta_oracle as orc
+    _run([os.path.join(CLI, "Example.intervals"), "-k", "3", "-p", "ex", "--FORCE"], tmp_path)
+    _compare_results(tmp_path / "ex.n2.results", os.path.join(CLI, "Example.n2.results"))
+    rep = S.last_report                                       # of the n=3 search (the last one run)
+    assert rep.candidates == 98846979 and rep.stats["evaluated"] == rep.candidates
+    assert rep.certificate_complete and not rep.parity_uncertain
+    res3 = _parse_results(tmp_path / "ex.n3.results")
+    assert len(res3) >= 1
+    nll, mu, C, p = res3[0]
+    assert abs(sum(mu) - 1) < 1e-9 and len(mu) == 3 and min(mu) >= 0
+    rows = [r.split(",") for r in C.split(":")]
+    counts = [l.split("\t") for l in open(os.path.join(CLI, "Example.intervals")) if not l.startswith("#")]
+    tum = np.array([float(c[4]) for c in counts])
+    nrm = np.array([float(c[5]) for c in counts])
+    Cm = np.array([[2.0] + [(-1.0 if v == "X" else float(v)) for v in r] for r in rows])
+    again = CalcAllC.L3(np.array(mu), Cm * nrm[:, None], len(rows), tum, 3)[0]
+    assert abs(again - nll) <= 1e-9 * abs(nll)
+    best = _parse_results(tmp_path / "ex.BEST.results")
+    assert best[0][0] in (res3[0][0], _parse_results(tmp_path / "ex.n2.results")[0][0])
+
+
 def test_calc_all_c_variants_match_reference_vectors():
     """calc_all_c_2 / _3 / _3_multi_event (CalcAllC.py:92-328) on the reference's own inputs and outputs."""
     import json

@@ -135,6 +135,14 @@ def test_bench_shape_packed_pass_dismissal_and_probe_do_not_change_the_finalists
     assert a["rank"] == f["rank"] and len(a["rank"]) >= 1
     assert np.array_equal(a["C"], f["C"])
     assert np.allclose(a["nll"], f["nll"], rtol=1e-12, atol=0)
+    # (c) the packed pass with the dismissal alone switched off (bench.py's `full_solve` leg)
+    monkeypatch.setenv("THETA_N3_FORCE_F64", "0")
+    monkeypatch.setenv("THETA_N3_NO_DISMISS", "1")
+    p = theta_amd.Problem(ctx, 3, m, 2, r, rN, [0] * m, [k] * m, 1.0)
+    g = p.search(b, b + span, window=0.5)
+    assert g["stats"]["dismissed"] == 0 and g["stats"]["evaluated"] == span
+    assert g["rank"] == a["rank"] and np.array_equal(g["C"], a["C"])
+    assert np.allclose(g["nll"], a["nll"], rtol=1e-12, atol=0)
 
 
 def test_every_leaf_level_setting_returns_the_same_finalists(monkeypatch):
