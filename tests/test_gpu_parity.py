@@ -186,10 +186,25 @@ def test_n3_fused_values_m6k3_all_candidates(ctx):
     _check_n3_table(got.astype(float), nll, mu, g["accepted"].astype(bool), g["mu"], g["nll"])
     # the batch solver (per-interval sums) agrees with the fused kernel (group sums)
     ok, mu_b, nll_b, _ = ctx.solve_batch(3, 2, g["r"], g["rN"], got, 1.0)
+    fb = ctx.last_solve_fallback                                # optimum outside the simplex: the reference's nu = 1/3 fallback
     fused_ok = ~np.isnan(nll)
-    assert (ok != fused_ok).sum() <= 5                          # borderline admissibility only
-    both = ok & fused_ok
+    assert ((ok & ~fb) != fused_ok).sum() <= 5                  # borderline admissibility only
+    both = ok & ~fb & fused_ok
     assert (np.abs(nll_b[both] - nll[both]) / nll[both]).max() < 1e-11
+    # ... and against the reference's own table, entry by entry: an optimum inside the simplex is reported with the optimum,
+    # one outside with the value at nu = (1/3,1/3,1/3) -- 4 467 of the reference's 20 766 accepted entries are exactly that.
+    # What remains are scipy's accidents (a line search that walks into NaNs -> None / NaN; fsolve stopping unconverged).
+    acc = g["accepted"].astype(bool) & np.isfinite(g["nll"])
+    with np.errstate(invalid="ignore"):
+        same = ok & acc & (np.abs(nll_b - g["nll"]) <= 1e-9 * np.abs(g["nll"]))
+        same_mu = np.abs(mu_b - g["mu"]).max(axis=1) < 1e-6
+    assert (same & fb).sum() >= 3600 and (same & ~fb).sum() >= 16200      # measured: 3 678 and 16 269
+    assert same.sum() >= 0.955 * acc.sum()                                  # (19 947 of 20 753; 94.8 % of all 21 050 entries)
+    # the rest: the reference's fsolve ended on a root outside [0,1]^3 although the minimum lies inside the simplex (789,
+    # of which 598 are rank-deficient candidates whose minimiser is a line) -- its value is the fallback, the GPU's the minimum
+    full_rank = np.array([np.linalg.matrix_rank(np.column_stack([np.ones(m), c[:, 0], c[:, 1]])) == 3 for c in got.astype(float)])
+    assert (same & full_rank & ~same_mu).sum() <= 25            # (mu of near-singular candidates is ill-conditioned)
+    assert (ok & ~g["accepted"].astype(bool)).sum() <= 300      # the reference's `None`s: a BFGS that left its start
     p.close()
 
 
@@ -442,6 +457,7 @@ def test_config3_shape_rank_ranges_and_tight_bounds_parity(ctx):
         assert st["evaluated"] == 20000
         C = p.enumerate(start, 20000)
         ok, mu_b, nll_b, _ = ctx.solve_batch(3, 2, rs, rNs, C, 1.0, want_vals=False)
+        ok = ok & ~ctx.last_solve_fallback
         fused_ok = ~np.isnan(nll)
         assert (ok != fused_ok).sum() <= 20
         both = ok & fused_ok

@@ -139,6 +139,7 @@ class Context:
         _check(load().theta_solve_batch(self._h, n, m, int(tau), _p(r, C.c_int64), _p(rN, C.c_int64), float(max_normal),
                                         B, _p(C_u8, C.c_uint8), _p(ok, C.c_uint8), _p(mu, C.c_double), _p(nll, C.c_double),
                                         _p(vals, C.c_double) if want_vals else None))
+        self.last_solve_fallback = ok == 2     # n=3: entries that carry the reference's nu = (1/3,1/3,1/3) fallback
         return ok.astype(bool), mu, nll, vals
 
     def boundary_min(self, tau, r, rN, C_u8):
@@ -211,6 +212,7 @@ class Problem:
         _check(load().theta_problem_create(ctx._h, self.n, self.m, self.tau, _p(r, C.c_int64), _p(rN, C.c_int64),
                                            _p(lb, C.c_int32), _p(ub, C.c_int32), float(max_normal), C.byref(h)))
         self._h = h
+        self.r, self.rN, self.max_normal = r, rN, float(max_normal)
         cnt = (C.c_uint64 * 2)()
         _check(load().theta_problem_count(h, cnt))
         self.count = int(cnt[0]) | (int(cnt[1]) << 64)

@@ -157,7 +157,7 @@ __global__ __launch_bounds__(64) void solve_batch_n3_kernel(int m, int tau, cons
         S2 += rn[i] * (double)c[2 * i + 1];
         Rtot += rr[i];
     }
-    bool good = !(S1 == 0.0 || S2 == 0.0);
+    bool good = !(S1 == 0.0 || S2 == 0.0), fallback = false;
     N3Newton Sv;
     double s1 = S1 / N, s2 = S2 / N;
     if (good) {
@@ -192,6 +192,18 @@ __global__ __launch_bounds__(64) void solve_batch_n3_kernel(int m, int tau, cons
                 Sv.u1 = H.u1;
                 Sv.u2 = H.u2;
             }
+            if (!in) {
+                // The reference's solver on a candidate whose stationary point lies outside [0,1]^3 (Optimizer.py:150-160):
+                // fsolve's root is out of range, so fmin_bfgs is started from nu = (1/3, 1/3) with dL3_hat as its gradient --
+                // which has the sign of an ASCENT direction (Optimizer.py:255-265 against :246-252), so its first line search
+                // fails and it hands back its start.  nu = (1/3, 1/3, 1/3) is in range and is accepted: the candidate is
+                // reported with mu = M3(1/3, 1/3, 1/3) and the NLL of that point (21 % of the candidates of the m=6, K=3
+                // fixture table carry exactly this value).  In the scaled variables that point is the Newton start.
+                Sv.u1 = (1.0 / 3.0) / s1;
+                Sv.u2 = (1.0 / 3.0) / s2;
+                fallback = true;
+                in = true;
+            }
             good = in;
         }
     }
@@ -217,7 +229,7 @@ __global__ __launch_bounds__(64) void solve_batch_n3_kernel(int m, int tau, cons
         tot = tot + rr[i] * log(p);
         if (vals) vals[(size_t)b * m + i] = p;
     }
-    ok[b] = 1;
+    ok[b] = fallback ? 2 : 1;       // 2: the reference's nu = (1/3, 1/3, 1/3) fallback
     mu[3 * b] = m0;
     mu[3 * b + 1] = m1;
     mu[3 * b + 2] = m2;

@@ -15,9 +15,12 @@ Deviations from the reference that are deliberate:
   * candidates whose NLL the reference computes as NaN (all-zero tumour column) are appended to its
     `best` list by the isClose(NaN) quirk (Misc.py:44-46); they carry no information and are not
     reproduced;
-  * for n=3 the accept set is "the likelihood has its minimum inside the simplex" -- the reference's
-    set is a scipy-trajectory-dependent superset; `SearchReport.parity_uncertain`
-    is raised when a rejected candidate's lower bound comes within the tie window of the winner.
+  * for n=3 a candidate whose likelihood has its minimum inside the simplex is reported with that minimum, and one
+    whose minimum lies outside with the reference's nu = (1/3,1/3,1/3) fallback (`fallback_records`); what is not
+    reproduced is scipy's behaviour off that typical path (fsolve that stops unconverged inside [0,1]^3, a BFGS line
+    search that walks into NaNs: 1-2 % of the candidates of toy instances).
+    `SearchReport.parity_uncertain` is raised when some rejected candidate could, on such a path, report a value within
+    the tie window of the winner (its minimum over the simplex boundary is that low).
 """
 import sys
 
@@ -90,6 +93,7 @@ class SearchReport(object):
         self.suspects = 0              # rejected candidates whose unconstrained optimum is within the window
         self.suspect_bound = float("inf")  # smallest NLL any of them can take on the simplex boundary
         self.certificate_complete = True   # False if the device suspect list overflowed (poor sub-range without a hint)
+        self.fallback_finalists = 0        # n=3: rejected candidates that joined the finalists with the reference's nu = 1/3 value
         self.seconds = 0.0
 
 
@@ -123,6 +127,31 @@ def collect_finalists(problem, ctx, r, rN, max_normal, begin, end, window=COLLEC
             recs.append({"rank": res["rank"][i], "c": res["C"][i], "mu": mu[i].copy(), "nll": float(nll[i]),
                          "vals": vals[i].copy()})
     return recs, res["stats"]
+
+
+def fallback_records(problem, ctx, r, rN, max_normal, recs, window=COLLECT_WINDOW, report=None):
+    """
+    n=3: what the reference reports for candidates whose optimum lies OUTSIDE the simplex.  Its fsolve root is then out of
+    range, fmin_bfgs -- handed dL3_hat, which points uphill (Optimizer.py:246-265) -- returns its start, and
+    nu = (1/3, 1/3, 1/3) is accepted (Optimizer.py:150-160): such a candidate IS in the reference's running minimum, with
+    the NLL of that point (4 467 of the 21 050 entries of the reference's own m=6, K=3 table).  The fused kernel rejects
+    these candidates but lists the ones whose lower bound comes within the window ("suspects"); theta_solve_batch -- the
+    reference-order arithmetic -- evaluates the fallback point for them, and those within the window of the minimum join
+    the finalists.  Returns the extra records.
+    """
+    ranks, lbound, Cs = problem.last_suspects
+    if not len(ranks):
+        return []
+    ok, mu, nll, vals = ctx.solve_batch(3, problem.tau, r, rN, Cs, max_normal, want_vals=True)
+    lowest = min([t["nll"] for t in recs] + [float(v) for v, o in zip(nll, ok) if o], default=float("inf"))
+    have = set(t["rank"] for t in recs)
+    out = []
+    for i in range(len(ranks)):
+        if ok[i] and nll[i] <= lowest + window and ranks[i] not in have:
+            out.append({"rank": ranks[i], "c": Cs[i], "mu": mu[i].copy(), "nll": float(nll[i]), "vals": vals[i].copy()})
+    if report is not None:
+        report.fallback_finalists = len(out)
+    return out
 
 
 def replay_ties(recs, n, tau, sorted_index, first_duplicate, report=None, q1_first=None):
@@ -196,6 +225,13 @@ def _dump_values(problem, n, m):
             cnt = min(step, problem.count - b)
             nll, mu, _ = problem.values(b, cnt)
             C = problem.enumerate(b, cnt)
+            if n == 3 and np.isnan(nll).any():
+                # optimum outside the simplex: the reference dumps its nu = (1/3,1/3,1/3) fallback value (see fallback_records)
+                idx = np.flatnonzero(np.isnan(nll))
+                ok, mu_b, nll_b, _v = problem.ctx.solve_batch(3, problem.tau, problem.r, problem.rN, C[idx], problem.max_normal,
+                                                              want_vals=False)
+                nll[idx[ok]] = nll_b[ok]
+                mu[idx[ok]] = mu_b[ok]
             col = C if n == 2 else C[:, :, 0]
             for i in range(cnt):
                 if nll[i] == nll[i]:
@@ -233,15 +269,18 @@ def do_optimization_single(n, m, k, tau, lower_bounds, upper_bounds, r, rN, max_
         print("Error: No valid Copy Number Profiles exist for these intervals within the bounds specified. Exiting...")
         sys.exit(1)
     q1 = _q1_record(ctx, n, m, tau, r, rN) if n == 3 else None
+    if n == 3:
+        recs = recs + fallback_records(problem, ctx, [int(x) for x in r], [int(x) for x in rN], max_normal, recs, report=rep)
     best = replay_ties(recs, n, tau, sorted_index, first_duplicate=(n == 2), report=rep, q1_first=q1)
     if get_values:
         _dump_values(problem, n, m)
     rep.stats = stats
     rep.candidates = problem.count
     rep.finalists = len(recs)
-    # n=3: candidates rejected because their optimum lies outside the simplex.  The reference returns None
-    # for them unless its root finder stalls inside [0,1]^3; whatever it could report is at least their minimum
-    # over the simplex boundary, computed exactly on the GPU.  Above the winner => they cannot change `best`.
+    # n=3: candidates whose optimum lies outside the simplex take part with the reference's nu = 1/3 fallback value
+    # (fallback_records).  Should the reference's solver leave its typical path on one of them (stall inside [0,1]^3),
+    # whatever it reports is at least the candidate's minimum over the simplex boundary, computed exactly on the GPU:
+    # above the winner => no such accident can change `best`.
     if n == 3 and best:
         ranks, lbound, Cs = problem.last_suspects
         rep.suspects = len(ranks)
@@ -335,6 +374,8 @@ def do_optimization_distributed(n, m, k, tau, lower_bounds, upper_bounds, r, rN,
     if device is None:
         device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
     problem, ctx, recs, stats = _search_local(n, m, tau, lower_bounds, upper_bounds, r, rN, max_normal, shard=(g, G))
+    if n == 3:     # the shard's rejected candidates that the reference reports at nu = (1/3,1/3,1/3), see fallback_records
+        recs = recs + fallback_records(problem, ctx, [int(x) for x in r], [int(x) for x in rN], max_normal, recs)
     merged = exchange_finalists(recs, n, m, device, group)
     q1 = _q1_record(ctx, n, m, tau, r, rN) if n == 3 else None
     return replay_ties(merged, n, tau, sorted_index, first_duplicate=(n == 2), q1_first=q1)
