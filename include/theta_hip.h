@@ -112,10 +112,11 @@ int theta_search(theta_problem *p, const uint64_t rank_begin[2], const uint64_t 
 
 /*
  * "Suspects" of the last theta_search call on this problem (n=3): candidates the search REJECTED (likelihood
- * optimum outside the simplex, where Optimizer._solve_n3plus returns None unless its root finder stalls inside
- * [0,1]^3, Optimizer.py:150-160) whose lower bound lies within `window` of the minimum.  rank[cap*2],
- * lbound[cap] (unconstrained minimum of the NLL), C[cap*m*(n-1)].  Feed C to theta_boundary_min to certify that
- * none of them can reach the winner.  n_out = number available; the device list holds 65 536, call with cap = -1
+ * optimum outside the simplex) whose lower bound lies within `window` of the minimum.  The reference does report
+ * such a candidate -- at nu = (1/3,1/3,1/3), where its BFGS fallback stalls (Optimizer.py:150-160, 255-265) -- so
+ * feed C to theta_solve_batch (ok = 2 entries carry that value) and let the ones within the window join the
+ * finalists; theta_boundary_min bounds what an off-path scipy run could report instead.  rank[cap*2],
+ * lbound[cap] (lower bound of the NLL), C[cap*m*(n-1)].  n_out = number available; the device list holds 65 536, call with cap = -1
  * to learn how many more were dropped (a range whose own minimum is poor can have millions: pass a hint, below).
  */
 int theta_search_suspects(theta_problem *p, int cap, uint64_t *rank, double *lbound, uint8_t *C, int *n_out);
