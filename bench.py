@@ -230,8 +230,9 @@ def main():
         # one chunk of the rank-range job; like Problem.search's own chunking, a chunk starts from the minimum the job has
         # found so far (theta_problem_hint) -- that is what keeps tie / suspect lists short in ranges whose own minimum is poor
         b = shard0 + i * stride
-        if running[0] < float("inf"):
-            problem.hint(running[0])
+        # (the first warm-up step carries a trivial hint: without one Problem.search would first probe 16 short sub-ranges --
+        # 16 extra launches of the same kernel, which would blur the per-launch averages of the rocprofv3 runs of this command)
+        problem.hint(running[0] if running[0] < float("inf") else 1e300)
         res = problem.search(b, b + args.batch, window=COLLECT_WINDOW)
         if len(res["nll"]):
             running[0] = min(running[0], float(res["nll"].min()))

@@ -176,6 +176,9 @@ __global__ __launch_bounds__(64) void solve_batch_n3_kernel(int m, int tau, cons
         if (good) {
             double n1 = s1 * Sv.u1, n2 = s2 * Sv.u2, n0 = 1.0 - n1 - n2;
             bool in = (n0 >= 0.0 && n0 <= 1.0 && n1 >= 0.0 && n1 <= 1.0 && n2 >= 0.0 && n2 <= 1.0);
+#ifdef N3_SINGULAR_FALLBACK
+            if (Sv.singular) in = false;
+#endif
             if (!in && Sv.singular) {   // rank-deficient: the minimiser is a line, intersect it with the simplex
                 N3Hess H;
                 H.u1 = Sv.u1; H.u2 = Sv.u2;
@@ -191,6 +194,9 @@ __global__ __launch_bounds__(64) void solve_batch_n3_kernel(int m, int tau, cons
                 in = n3_admissible(H, s1, s2);
                 Sv.u1 = H.u1;
                 Sv.u2 = H.u2;
+#ifdef N3_SINGULAR_FALLBACK
+                in = false;
+#endif
             }
             if (!in) {
                 // The reference's solver on a candidate whose stationary point lies outside [0,1]^3 (Optimizer.py:150-160):
