@@ -176,6 +176,9 @@ __global__ __launch_bounds__(64) void solve_batch_n3_kernel(int m, int tau, cons
         if (good) {
             double n1 = s1 * Sv.u1, n2 = s2 * Sv.u2, n0 = 1.0 - n1 - n2;
             bool in = (n0 >= 0.0 && n0 <= 1.0 && n1 >= 0.0 && n1 <= 1.0 && n2 >= 0.0 && n2 <= 1.0);
+            // (A/B switch, measured in DESIGN.md section 5: report EVERY rank-deficient candidate at the fallback, which is what
+            // the reference does for 69 % of them -- per-candidate agreement with its table 94.8 % -> 96.6 %, but its tie lists
+            // then miss entries in 3 of 400 campaign instances instead of 2 wrong winners; the default keeps the optimum)
 #ifdef N3_SINGULAR_FALLBACK
             if (Sv.singular) in = false;
 #endif
