@@ -162,9 +162,11 @@ int theta_enumerate_device(theta_problem *p, const uint64_t rank_begin[2], uint6
  * Per-candidate solve in the reference's own arithmetic order (per-interval sums, the brenth
  * iteration for n=2): replaces Optimizer.solve(C) (Optimizer.py:68-165) for a batch of B
  * materialised candidates C[B*m*(n-1)].
- *   ok[B]      1 = solution, 0 = the reference's `None`; n=3 also 2 = the reference's fallback for a candidate whose
- *              stationary point lies outside [0,1]^3: fmin_bfgs is handed an ascent direction (Optimizer.py:255-265),
- *              returns its start nu = (1/3,1/3,1/3), which is in range and is reported (Optimizer.py:155-160)
+ *   ok[B]      1 = solution, 0 = the reference's `None`.  n=3: the reference's own decision procedure -- MINPACK's hybrj
+ *              (behind scipy's fsolve, Optimizer.py:148) restated on the Lagrangian system in the reference's operation
+ *              order; 1 = its iterate lies in [0,1]^3 and is reported, 2 = it does not, and the candidate is reported at
+ *              nu = (1/3,1/3,1/3), where the reference's fmin_bfgs call -- handed an ascent direction,
+ *              Optimizer.py:255-265 -- returns its start (Optimizer.py:155-160)
  *   mu[B*n], nll[B]
  *   vals[B*m]  the per-interval p* (third element of the reference's tuple); may be NULL
  */

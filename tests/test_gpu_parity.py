@@ -185,26 +185,28 @@ def test_n3_fused_values_m6k3_all_candidates(ctx):
     assert st["evaluated"] == 21050
     _check_n3_table(got.astype(float), nll, mu, g["accepted"].astype(bool), g["mu"], g["nll"])
     # the batch solver (per-interval sums) agrees with the fused kernel (group sums)
+    # theta_solve_batch decides like the reference: MINPACK's hybrj restated (hybrj4.hpp) on the Lagrangian system in the
+    # reference's operation order; its iterate in [0,1]^3 -> the candidate's own optimum, otherwise the nu = (1/3,1/3,1/3)
+    # fallback.  Against the reference's own table, entry by entry: the class (own optimum / fallback) of all 16 286 + 4 467
+    # such entries but one is reproduced (tools/hybrj_check.py), the values of 16 270 + 4 466 to 1e-9 (mu 1e-6 on full-rank
+    # candidates); what remains are the 284 `None`s and 13 NaNs of a BFGS line search that walked into NaNs.
     ok, mu_b, nll_b, _ = ctx.solve_batch(3, 2, g["r"], g["rN"], got, 1.0)
-    fb = ctx.last_solve_fallback                                # optimum outside the simplex: the reference's nu = 1/3 fallback
-    fused_ok = ~np.isnan(nll)
-    assert ((ok & ~fb) != fused_ok).sum() <= 5                  # borderline admissibility only
-    both = ok & ~fb & fused_ok
-    assert (np.abs(nll_b[both] - nll[both]) / nll[both]).max() < 1e-11
-    # ... and against the reference's own table, entry by entry: an optimum inside the simplex is reported with the optimum,
-    # one outside with the value at nu = (1/3,1/3,1/3) -- 4 467 of the reference's 20 766 accepted entries are exactly that.
-    # What remains are scipy's accidents (a line search that walks into NaNs -> None / NaN; fsolve stopping unconverged).
+    fb = ctx.last_solve_fallback
     acc = g["accepted"].astype(bool) & np.isfinite(g["nll"])
     with np.errstate(invalid="ignore"):
         same = ok & acc & (np.abs(nll_b - g["nll"]) <= 1e-9 * np.abs(g["nll"]))
         same_mu = np.abs(mu_b - g["mu"]).max(axis=1) < 1e-6
-    assert (same & fb).sum() >= 3600 and (same & ~fb).sum() >= 16200      # measured: 3 678 and 16 269
-    assert same.sum() >= 0.955 * acc.sum()                                  # (19 947 of 20 753; 94.8 % of all 21 050 entries)
-    # the rest: the reference's fsolve ended on a root outside [0,1]^3 although the minimum lies inside the simplex (789,
-    # of which 598 are rank-deficient candidates whose minimiser is a line) -- its value is the fallback, the GPU's the minimum
+    assert (same & ~fb).sum() >= 16260 and (same & fb).sum() >= 4460, ((same & ~fb).sum(), (same & fb).sum())   # 16 270, 4 466
+    assert (acc & ~same).sum() <= 30                            # (17: own-optimum entries whose value differs beyond 1e-9)
     full_rank = np.array([np.linalg.matrix_rank(np.column_stack([np.ones(m), c[:, 0], c[:, 1]])) == 3 for c in got.astype(float)])
     assert (same & full_rank & ~same_mu).sum() <= 25            # (mu of near-singular candidates is ill-conditioned)
     assert (ok & ~g["accepted"].astype(bool)).sum() <= 300      # the reference's `None`s: a BFGS that left its start
+    # the fused kernel's dump reports the optimum of every candidate whose minimum lies in the simplex; where the batch
+    # solver reports an own optimum too, the two agree to rounding (group sums against per-interval sums)
+    fused_ok = ~np.isnan(nll)
+    both = ok & ~fb & fused_ok
+    assert both.sum() >= 16200
+    assert ((np.abs(nll_b[both] - nll[both]) / nll[both]) >= 1e-9).sum() <= 25     # (hybrj stopped short of the optimum, in range)
     p.close()
 
 
@@ -456,17 +458,22 @@ def test_config3_shape_rank_ranges_and_tight_bounds_parity(ctx):
         nll, mu, st = p.values(start, 20000)
         assert st["evaluated"] == 20000
         C = p.enumerate(start, 20000)
-        ok, mu_b, nll_b, _ = ctx.solve_batch(3, 2, rs, rNs, C, 1.0, want_vals=False)
-        ok = ok & ~ctx.last_solve_fallback
-        fused_ok = ~np.isnan(nll)
-        assert (ok != fused_ok).sum() <= 20
+        any_ok, mu_b, nll_b, _ = ctx.solve_batch(3, 2, rs, rNs, C, 1.0, want_vals=False)
+        ok = any_ok & ~ctx.last_solve_fallback              # the reference's fsolve ends in [0,1]^3: own optimum
+        fused_ok = ~np.isnan(nll)                           # the likelihood has its minimum in the simplex
+        assert (ok & ~fused_ok).sum() <= 20                 # in range => minimum in the simplex (borderline cases aside)
+        assert (fused_ok & ~ok).sum() <= 0.25 * max(fused_ok.sum(), 80)   # ... but fsolve does not find every such minimum
         both = ok & fused_ok
         if both.any():
-            assert (np.abs(nll_b[both] - nll[both]) / nll[both]).max() < 1e-10
+            # (the batch solver reports the iterate fsolve stopped at, like the reference; the dump reports the minimum)
+            assert ((np.abs(nll_b[both] - nll[both]) / nll[both]) >= 1e-9).sum() <= 0.03 * both.sum() + 5
+            assert (nll_b[both] >= nll[both] * (1 - 1e-12)).all()
+        # the search reports what the reference reports: own optimum where its fsolve finds it, else the nu = 1/3 fallback
         res = p.search(start, start + 20000, window=0.5)
-        if fused_ok.any():
-            k = int(np.nanargmin(nll))
-            assert start + k in res["rank"]
+        if any_ok.any():
+            ref_vals = np.where(any_ok, nll_b, np.inf)
+            k = int(np.argmin(ref_vals))
+            assert start + k in res["rank"] or (start + k in p.last_suspects[0])
             a = p.search(start, start + 7001, window=0.5)
             b = p.search(start + 7001, start + 20000, window=0.5)
             assert min(a["nll"].min() if len(a["nll"]) else np.inf, b["nll"].min() if len(b["nll"]) else np.inf) == res["nll"].min()

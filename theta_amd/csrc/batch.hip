@@ -5,6 +5,7 @@
 //   score_batch   CalcAllC.L2 / CalcAllC.L3 on literal matrices  CalcAllC.py:44-76
 //   score_masked  the same likelihood on byte candidates x row masks (interval-subset resampling)
 #include "n3_core.hpp"
+#include "n3_refsys.hpp"
 
 // ------------------------------------------------------------------------------------------------
 // n = 2: faithful per-interval dL/dnu (Optimizer.py:208-221) + the Bus-Dekker/Brent hyperbolic
@@ -137,6 +138,17 @@ __global__ __launch_bounds__(64) void solve_batch_n2_kernel(int m, int tau, cons
 // admissibility as Optimizer._solve_n3plus (Optimizer.py:150-160), then nu -> mu (closed form of M3)
 // and Optimizer.L3 (Optimizer.py:236-244) in the reference's summation order.
 // ------------------------------------------------------------------------------------------------
+// What Optimizer._solve_n3plus reports for a candidate (Optimizer.py:128-165), decided the way the reference decides it:
+//   1. fsolve (MINPACK hybrj, restated in hybrj4.hpp) on the Lagrangian system in the reference's operation order
+//      (n3_refsys.hpp) from (1/3,1/3,1/3,1).  Whatever it returns is taken -- converged or not -- if every nu_j is in
+//      [0,1] (NaN passes, Misc.py:49-57): ok = 1.
+//   2. Otherwise fmin_bfgs is started from nu = (1/3,1/3) with dL3_hat as gradient, which points uphill
+//      (Optimizer.py:255-265 against :246-252): the line search fails, BFGS hands back its start, (1/3,1/3,1/3) is in
+//      range and is reported: ok = 2.  (Not reproduced: the 1-2 % of toy candidates where that line search walks into NaNs
+//      and the reference ends with None or NaN.)
+// On the reference's own m=6, K=3 table (21 050 entries) step 1 lands in range for exactly the 16 286 entries reported
+// with their own optimum and out of range for all 4 466 + 284 fallback / None entries (tools/hybrj_check.py).
+// nu -> mu is the closed form of M3 (Optimizer.py:318-330), the NLL Optimizer.L3's sums (Optimizer.py:236-244).
 __global__ __launch_bounds__(64) void solve_batch_n3_kernel(int m, int tau, const double *r, const double *rN, int B,
                                                             const unsigned char *C, unsigned char *ok, double *mu,
                                                             double *nll, double *vals) {
@@ -150,82 +162,29 @@ __global__ __launch_bounds__(64) void solve_batch_n3_kernel(int m, int tau, cons
     int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
     const unsigned char *c = C + (size_t)b * m * 2;
-    double N = 0.0, S1 = 0.0, S2 = 0.0, Rtot = 0.0;
-    for (int i = 0; i < m; i++) {
-        N += rn[i];
-        S1 += rn[i] * (double)c[2 * i];
-        S2 += rn[i] * (double)c[2 * i + 1];
-        Rtot += rr[i];
-    }
-    bool good = !(S1 == 0.0 || S2 == 0.0), fallback = false;
-    N3Newton Sv;
-    double s1 = S1 / N, s2 = S2 / N;
-    if (good) {
-        auto terms = [&](auto &&body) {
-            for (int i = 0; i < m; i++) body((double)c[2 * i], (double)c[2 * i + 1], rr[i]);
-        };
-        Sv.u1 = (1.0 / 3.0) / s1;
-        Sv.u2 = (1.0 / 3.0) / s2;
-        Sv.p1 = Sv.u1; Sv.p2 = Sv.u2;
-        Sv.iters = 0;
-        Sv.status = 0;
-        Sv.singular = false;
-        const double inv_R = 1.0 / Rtot;
-        while (Sv.status == 0) n3_newton_step(terms, s1, s2, inv_R, Sv);
-        good = Sv.status == 1;
-        if (good) {
-            double n1 = s1 * Sv.u1, n2 = s2 * Sv.u2, n0 = 1.0 - n1 - n2;
-            bool in = (n0 >= 0.0 && n0 <= 1.0 && n1 >= 0.0 && n1 <= 1.0 && n2 >= 0.0 && n2 <= 1.0);
-            // (A/B switch, measured in DESIGN.md section 5: report EVERY rank-deficient candidate at the fallback, which is what
-            // the reference does for 69 % of them -- per-candidate agreement with its table 94.8 % -> 96.6 %, but its tie lists
-            // then miss entries in 3 of 400 campaign instances instead of 2 wrong winners; the default keeps the optimum)
-#ifdef N3_SINGULAR_FALLBACK
-            if (Sv.singular) in = false;
-#endif
-            if (!in && Sv.singular) {   // rank-deficient: the minimiser is a line, intersect it with the simplex
-                N3Hess H;
-                H.u1 = Sv.u1; H.u2 = Sv.u2;
-                H.h11 = H.h12 = H.h22 = 0.0;
-                terms([&](double x, double y, double R) {
-                    double a = x - s1, bb = y - s2;
-                    double q = __builtin_fma(a, H.u1, __builtin_fma(bb, H.u2, 1.0));
-                    double tw = R / (q * q);
-                    H.h11 = __builtin_fma(tw * a, a, H.h11);
-                    H.h12 = __builtin_fma(tw * a, bb, H.h12);
-                    H.h22 = __builtin_fma(tw * bb, bb, H.h22);
-                });
-                in = n3_admissible(H, s1, s2);
-                Sv.u1 = H.u1;
-                Sv.u2 = H.u2;
-#ifdef N3_SINGULAR_FALLBACK
-                in = false;
-#endif
-            }
-            if (!in) {
-                // The reference's solver on a candidate whose stationary point lies outside [0,1]^3 (Optimizer.py:150-160):
-                // fsolve's root is out of range, so fmin_bfgs is started from nu = (1/3, 1/3) with dL3_hat as its gradient --
-                // which has the sign of an ASCENT direction (Optimizer.py:255-265 against :246-252), so its first line search
-                // fails and it hands back its start.  nu = (1/3, 1/3, 1/3) is in range and is accepted: the candidate is
-                // reported with mu = M3(1/3, 1/3, 1/3) and the NLL of that point (21 % of the candidates of the m=6, K=3
-                // fixture table carry exactly this value).  In the scaled variables that point is the Newton start.
-                Sv.u1 = (1.0 / 3.0) / s1;
-                Sv.u2 = (1.0 / 3.0) / s2;
-                fallback = true;
-                in = true;
-            }
-            good = in;
-        }
-    }
-    if (!good) {
+    N3RefSystem sys;
+    sys.m = m;
+    sys.tau = (double)tau;
+    sys.r = rr;
+    sys.rN = rn;
+    sys.c = c;
+    sys.init();
+    if (sys.S[1] == 0.0 || sys.S[2] == 0.0) {   // an all-zero tumour column: NaN everywhere in the reference (not reproduced)
         ok[b] = 0;
         mu[3 * b] = mu[3 * b + 1] = mu[3 * b + 2] = nll[b] = __builtin_nan("");
         if (vals) for (int i = 0; i < m; i++) vals[(size_t)b * m + i] = __builtin_nan("");
         return;
     }
-    double dtau = (double)tau;
-    double u0 = (1.0 - s1 * Sv.u1 - s2 * Sv.u2) / dtau;
-    double us = u0 + Sv.u1 + Sv.u2;
-    double m0 = u0 / us, m1 = Sv.u1 / us, m2 = Sv.u2 / us;
+    double nu[3];
+    n3_ref_fsolve(sys, nu, nullptr);
+    bool fallback = false;
+    for (int j = 0; j < 3; j++)
+        if (nu[j] < 0.0 || nu[j] > 1.0) fallback = true;
+    if (fallback) nu[0] = nu[1] = nu[2] = 1.0 / 3.0;
+    const double dtau = (double)tau;
+    const double w0 = nu[0] / sys.S[0], w1 = nu[1] / sys.S[1], w2 = nu[2] / sys.S[2];
+    const double ws = (w0 + w1) + w2;
+    const double m0 = w0 / ws, m1 = w1 / ws, m2 = w2 / ws;
     // Optimizer.L3: denom accumulates column by column (for j ... for h ...), numer left to right
     double den = 0.0;
     for (int h = 0; h < m; h++) den = den + (rn[h] * dtau) * m0;
@@ -238,7 +197,8 @@ __global__ __launch_bounds__(64) void solve_batch_n3_kernel(int m, int tau, cons
         tot = tot + rr[i] * log(p);
         if (vals) vals[(size_t)b * m + i] = p;
     }
-    ok[b] = fallback ? 2 : 1;       // 2: the reference's nu = (1/3, 1/3, 1/3) fallback
+    const bool nan_out = !(tot == tot);
+    ok[b] = nan_out ? 0 : (fallback ? 2 : 1);       // 2: the reference's nu = (1/3, 1/3, 1/3) fallback
     mu[3 * b] = m0;
     mu[3 * b + 1] = m1;
     mu[3 * b + 2] = m2;

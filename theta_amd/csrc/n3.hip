@@ -18,6 +18,8 @@
 #include <type_traits>
 
 #include "n3_core.hpp"
+#define HYBRJ4_MANAGE_CONTRACT     // this unit allows fused multiply-adds; the hybrj restatement must not use them
+#include "n3_refsys.hpp"
 
 // ------------------------------------------------------------------------------------------------
 // host: bounds, ratio table
@@ -304,6 +306,7 @@ struct N3WaveLds {
     float lastN1[WAVE], lastN2[WAVE];     // mixture of the last admissible leaf each lane's chunk produced
     unsigned char qSrc[N3_QCAP];          // lane whose chunk the queue entry comes from
     unsigned char cIdx[N3_QCAP];          // queue entries that still need the values pass (the rest was dismissed)
+    unsigned char preRow[N3_MAX_M];       // rows of the prefix, a | b << 4 (for the per-interval hybrj check of contenders)
     unsigned stkS[L > 1 ? L - 1 : 1][WAVE];            // lane-private DFS stack: node chosen at each leaf level but the last
     unsigned long long stkM[L > 1 ? L - 1 : 1][WAVE];  // ... and the siblings still to visit at that level
 };
@@ -330,6 +333,10 @@ struct N3Leaf {
     int G;
     double lx[L], ly[L], lr[L];   // the candidate's own leaf rows and their weights
     double s1, s2, inv_Rtot, Rmin, K0, thr, margin;
+    const unsigned char *pre;     // rows of the prefix, a | b << 4 (LDS), D of them
+    const double *r, *rN;         // per-interval counts (global)
+    int D;
+    double tau;
 };
 struct N3Cold {
     double u1, u2, nll, sc_gain;
@@ -340,6 +347,38 @@ struct N3Cold {
 // converged optimum y OUTSIDE the simplex it first tries to dismiss the candidate with the self-concordance bound
 //      NLL(z) >= NLL(y) + Rmin w(d / sqrt(Rmin)),   w(t) = t - ln(1 + t),   d = Hessian-norm distance from y to the simplex,
 // which bounds everything the reference could report for it (one extra term pass instead of polish + logs).
+// Would the reference's fsolve -- MINPACK hybrj from (1/3,1/3,1/3,1) on the Lagrangian system, restated operation by
+// operation in hybrj4.hpp / n3_refsys.hpp -- end inside [0,1]^3 on this candidate?  If not, the reference reports it at its
+// nu = 1/3 fallback although the likelihood has its minimum inside the simplex.  The candidate's rows
+// are put back together (prefix rows from LDS, leaf rows from the lane) and the system is evaluated per interval in the
+// reference's order, exactly as theta_solve_batch does: the landing point of hybrj on a rank-deficient system depends on
+// the last bit, so an aggregated evaluation would decide some of them differently.
+template <int L>
+__device__ __noinline__ bool n3_reference_finds_optimum(const N3Leaf<L> &c) {
+    unsigned char rows[2 * N3_MAX_M];
+    for (int i = 0; i < c.D; i++) {
+        rows[2 * i] = c.pre[i] & 15u;
+        rows[2 * i + 1] = c.pre[i] >> 4;
+    }
+#pragma unroll
+    for (int l = 0; l < L; l++) {
+        rows[2 * (c.D + l)] = (unsigned char)c.lx[l];
+        rows[2 * (c.D + l) + 1] = (unsigned char)c.ly[l];
+    }
+    N3RefSystem sys;
+    sys.m = c.D + L;
+    sys.tau = c.tau;
+    sys.r = c.r;
+    sys.rN = c.rN;
+    sys.c = rows;
+    sys.init();
+    double nu[3];
+    n3_ref_fsolve(sys, nu, nullptr);
+    for (int j = 0; j < 3; j++)
+        if (nu[j] < 0.0 || nu[j] > 1.0) return false;
+    return true;
+}
+
 template <int L>
 __device__ __noinline__ N3Cold n3_cold_path(N3Leaf<L> c, double u1, double u2, double nll, bool conv, bool accept, bool dump) {
     N3Cold out;
@@ -414,6 +453,13 @@ __device__ __noinline__ N3Cold n3_cold_path(N3Leaf<L> c, double u1, double u2, d
                 u2 = T2.u2;
             }
         }
+    }
+    // The minimum lies in the simplex -- but does the reference find it?  Its fsolve run may end on another root of the
+    // rational system, outside [0,1]^3; it then reports the candidate at nu = (1/3,1/3,1/3), and so does this kernel: the
+    // running minimum and the tie list follow what the reference reports, not what the likelihood could reach.
+    if (!dump && accept && !n3_reference_finds_optimum<L>(c)) {
+        u1 = (1.0 / 3.0) / s1;
+        u2 = (1.0 / 3.0) / s2;
     }
     double acc = 0.0;
     terms([&](double x, double y, double R) {
@@ -528,6 +574,7 @@ __global__ __launch_bounds__(64 * N3_WAVES, N3_OCC) void n3_search_kernel(N3Dev 
         {
             const bool inp = lane < D;
             const unsigned myrow = st >> 24;  // a | b << 4
+            if (inp) W.preRow[lane] = (unsigned char)myrow;
             // lane i stands for interval i here; its counts are re-read per prefix (L2) instead of living in registers
             const double r_i = inp ? Pg.r[lane] : 0.0, rN_i = inp ? Pg.rN[lane] : 0.0;
             unsigned long long todo = ballot64(inp);
@@ -1097,6 +1144,7 @@ __global__ __launch_bounds__(64 * N3_WAVES, N3_OCC) void n3_search_kernel(N3Dev 
                         lf.inv_Rtot = inv_Rtot; lf.Rmin = Rmin; lf.K0 = P.K0;
                         lf.thr = best + A.window;
                         lf.margin = screen_margin;
+                        lf.pre = W.preRow; lf.D = D; lf.r = Pg.r; lf.rN = Pg.rN; lf.tau = tau;
                         N3Cold cr = n3_cold_path<L>(lf, u1, u2, nll, conv, accept, DUMP);
                         u1 = cr.u1; u2 = cr.u2;
                         nll = cr.nll;

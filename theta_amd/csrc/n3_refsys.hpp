@@ -1,0 +1,81 @@
+// The n = 3 Lagrangian system of Optimizer._solve_n3plus in the reference's own operation order, as the FCN of
+// hybrj4::hybrj (host and device).  Restates, for one candidate C (m x 2 bytes; column 0 of the matrix is tau):
+//   weighted_C / normalize_C     Optimizer.py:167-182   Cw_ij = rN_i C_ij,  Chat_ij = Cw_ij / sum_i Cw_ij
+//   equations / dLambda_dMu      Optimizer.py:273-286, 313-316
+//   jacobian / second_deriv      Optimizer.py:288-311
+// Sums run over the intervals top to bottom like the reference's Python loops; no fused multiply-adds.
+#pragma once
+#include "hybrj4.hpp"
+
+struct N3RefSystem {
+    int m;
+    double tau;
+    const double *r, *rN;          // [m]
+    const unsigned char *c;        // [m][2]
+    double S[3];                   // column sums of the weighted matrix
+
+    HYBRJ4_HD void init() {
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+        for (int i = 0; i < m; i++) {
+            s0 = s0 + rN[i] * tau;
+            s1 = s1 + rN[i] * (double)c[2 * i];
+            s2 = s2 + rN[i] * (double)c[2 * i + 1];
+        }
+        S[0] = s0;
+        S[1] = s1;
+        S[2] = s2;
+    }
+    HYBRJ4_HD void chat(int i, double &h0, double &h1, double &h2) const {
+        h0 = (rN[i] * tau) / S[0];
+        h1 = (rN[i] * (double)c[2 * i]) / S[1];
+        h2 = (rN[i] * (double)c[2 * i + 1]) / S[2];
+    }
+    // x(1..4) = (nu0, nu1, nu2, lambda)
+    HYBRJ4_HD void f(const double *x, double *fv) const {
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+        for (int i = 0; i < m; i++) {
+            double h0, h1, h2;
+            chat(i, h0, h1, h2);
+            const double p = (h0 * x[1] + h1 * x[2]) + h2 * x[3];
+            a0 = a0 + (r[i] * h0) / p;
+            a1 = a1 + (r[i] * h1) / p;
+            a2 = a2 + (r[i] * h2) / p;
+        }
+        fv[1] = (-a0) - x[4];
+        fv[2] = (-a1) - x[4];
+        fv[3] = (-a2) - x[4];
+        fv[4] = 1.0 - ((x[1] + x[2]) + x[3]);
+    }
+    HYBRJ4_HD void jac(const double *x, double fj[hybrj4::N + 1][hybrj4::N + 1]) const {
+        double J[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+        for (int i = 0; i < m; i++) {
+            double h[3];
+            chat(i, h[0], h[1], h[2]);
+            const double p = (h[0] * x[1] + h[1] * x[2]) + h[2] * x[3];
+            const double den = p * p;
+            for (int k = 0; k < 3; k++)
+                for (int q = 0; q < 3; q++) J[k][q] = J[k][q] + ((r[i] * h[k]) * h[q]) / den;
+        }
+        for (int k = 0; k < 3; k++)
+            for (int q = 0; q < 3; q++) fj[k + 1][q + 1] = J[k][q];
+        for (int k = 1; k <= 3; k++) {
+            fj[4][k] = -1.0;
+            fj[k][4] = -1.0;
+        }
+        fj[4][4] = 0.0;
+    }
+};
+
+// fsolve(equations, [1/3,1/3,1/3,1], fprime=jacobian) with scipy's defaults (xtol 1.49012e-8, maxfev 100 (n+1), factor 100).
+HYBRJ4_HD inline int n3_ref_fsolve(N3RefSystem &sys, double nu[3], int *nfev) {
+    double x[hybrj4::N + 1] = {0.0, 1.0 / 3.0, 1.0 / 3.0, 1.0 / 3.0, 1.0};
+    const int info = hybrj4::hybrj(sys, x, 1.49012e-8, 100 * (hybrj4::N + 1), 100.0, nfev);
+    nu[0] = x[1];
+    nu[1] = x[2];
+    nu[2] = x[3];
+    return info;
+}
+
+#ifdef HYBRJ4_MANAGE_CONTRACT
+#pragma clang fp contract(fast)      // back to the device default for the rest of the including unit
+#endif

@@ -15,12 +15,11 @@ Deviations from the reference that are deliberate:
   * candidates whose NLL the reference computes as NaN (all-zero tumour column) are appended to its
     `best` list by the isClose(NaN) quirk (Misc.py:44-46); they carry no information and are not
     reproduced;
-  * for n=3 a candidate whose likelihood has its minimum inside the simplex is reported with that minimum, and one
-    whose minimum lies outside with the reference's nu = (1/3,1/3,1/3) fallback (`fallback_records`); what is not
-    reproduced is scipy's behaviour off that typical path (fsolve that stops unconverged inside [0,1]^3, a BFGS line
-    search that walks into NaNs: 1-2 % of the candidates of toy instances).
-    `SearchReport.parity_uncertain` is raised when some rejected candidate could, on such a path, report a value within
-    the tie window of the winner (its minimum over the simplex boundary is that low).
+  * for n=3 a candidate is reported the way Optimizer._solve_n3plus reports it: its own optimum where the reference's
+    fsolve run (MINPACK hybrj, restated in csrc/hybrj4.hpp) ends inside [0,1]^3, else the nu = (1/3,1/3,1/3) fallback
+    (`fallback_records`).  Not reproduced: the None / NaN outcomes of a BFGS line search that walks into NaNs (1-2 % of
+    the candidates of toy instances).  `SearchReport.parity_uncertain` is raised when such an outcome on some rejected
+    candidate could undercut the winner (its minimum over the simplex boundary is that low).
 """
 import sys
 

@@ -1,0 +1,13 @@
+// Host build of the hybrj restatement (theta_amd/csrc/hybrj4.hpp + n3_refsys.hpp) for checking it against scipy's fsolve:
+//   g++ -O2 -ffp-contract=off -shared -fPIC tools/hybrj_check.cpp -o build_ab/libhybrj_check.so
+#include "../theta_amd/csrc/n3_refsys.hpp"
+extern "C" int hybrj_check_solve(int m, int tau, const double *r, const double *rN, const unsigned char *c, double *nu, int *nfev) {
+    N3RefSystem s;
+    s.m = m;
+    s.tau = (double)tau;
+    s.r = r;
+    s.rN = rN;
+    s.c = c;
+    s.init();
+    return n3_ref_fsolve(s, nu, nfev);
+}

@@ -24,9 +24,39 @@ sys.path.insert(0, os.path.join(ROOT, "oracle"))
 
 import numpy as np
 
+SHAPE = "toy"
+
+
+def instance_mid(seed, n):
+    """m = 10..18 intervals with bounds tight around a planted truth (the shape interval selection + bounds heuristics give)."""
+    import theta_oracle as orc
+    rng = np.random.RandomState(seed)
+    m, k = int(rng.randint(10, 19)), int(rng.randint(3, 6))
+    tau = 2
+    L = rng.randint(2_000_000, 20_000_000, m)
+    rN = np.maximum(rng.poisson(L * rng.choice([0.001, 0.004, 0.01])), 5)
+    C = np.full((m, n), float(tau))
+    for j in range(1, n):
+        C[:, j] = rng.randint(0, k + 1, m)
+    if n == 3 and rng.rand() < 0.3:
+        C[:, 2] = C[:, 1]                       # a sample with ONE tumour population analysed with n=3
+    mu = rng.dirichlet(np.ones(n) * 3)
+    p = (C * rN[:, None]) @ mu
+    p = p / p.sum()
+    r = np.maximum(rng.multinomial(int(rN.sum() * rng.uniform(0.8, 1.5)), p), 1)
+    rs, rNs, order = orc.sort_r([int(x) for x in rN], [int(x) for x in r])
+    cs = np.maximum(C[:, 1:].max(axis=1), 0)[order]
+    cmin = C[:, 1:].min(axis=1)[order]
+    free = rng.rand(m) < (0.85 if n == 2 else 0.3)
+    lb = [int(max(0, a - (1 if f else 0))) for a, f in zip(cmin, free)]
+    ub = [int(min(k, b + (1 if f else 0))) for b, f in zip(cs, free)]
+    return dict(seed=seed, n=n, m=m, k=k, tau=tau, mx=1.0, r=rs, rN=rNs, order=order, lb=lb, ub=ub)
+
 
 def instance(seed, n):
     import theta_oracle as orc
+    if SHAPE == "mid":
+        return instance_mid(seed, n)
     rng = np.random.RandomState(seed)
     if n == 2:
         m, k = int(rng.randint(4, 14)), int(rng.randint(2, 6))
@@ -66,7 +96,10 @@ def main():
     ap.add_argument("--n2", type=int, default=240)
     ap.add_argument("--seconds", type=float, default=420.0)
     ap.add_argument("--max-candidates", type=int, default=25000)
+    ap.add_argument("--shape", choices=["toy", "mid"], default="toy")
     a = ap.parse_args()
+    global SHAPE
+    SHAPE = a.shape
     import theta_amd
     from theta_amd.search import do_optimization_single
     import theta_amd.search as S
@@ -114,7 +147,7 @@ def main():
         except mp.TimeoutError:
             pass
     pool.terminate()
-    out = {"instances": len(insts), "cores": cores, "gpu_seconds_all_instances": gpu_seconds, "unfinished": 0,
+    out = {"shape": a.shape, "instances": len(insts), "cores": cores, "gpu_seconds_all_instances": gpu_seconds, "unfinished": 0,
            "n2": {"checked": 0, "agree": 0, "both_empty": 0, "candidates": 0}, "n3": {"checked": 0, "agree": 0, "both_empty": 0,
                                                                                  "candidates": 0, "gpu_extra_tie_entries": 0,
                                                                                  "parity_uncertain_flagged": 0},
