@@ -229,7 +229,7 @@ def main():
     def step(i):
         # one chunk of the rank-range job; like Problem.search's own chunking, a chunk starts from the minimum the job has
         # found so far (theta_problem_hint) -- that is what keeps tie / suspect lists short in ranges whose own minimum is poor
-        b = shard0 + i * stride
+        b = shard0 + i * stride + stride // 2       # (mid-points: the very first ranks of the space are a stretch of near-ties)
         # (the first warm-up step carries a trivial hint: without one Problem.search would first probe 16 short sub-ranges --
         # 16 extra launches of the same kernel, which would blur the per-launch averages of the rocprofv3 runs of this command)
         problem.hint(running[0] if running[0] < float("inf") else 1e300)
@@ -335,7 +335,7 @@ def main():
             # bounded sample of the SAME candidates, materialised by the enumerate kernel, solved by the oracle on the host
             n_s = 96 * (os.cpu_count() or 1)
             per = max(1, n_s // nsteps)
-            cands = np.concatenate([problem.enumerate(shard0 + i * stride + 12345, per) for i in range(nsteps)])
+            cands = np.concatenate([problem.enumerate(shard0 + i * stride + stride // 2 + 12345, per) for i in range(nsteps)])
             out["cpu_baseline"] = cpu_baseline(cands, r, rN, args.cpu_seconds)
             out["speedup_vs_cpu_all_cores"] = value / out["cpu_baseline"]["value"]
             try:

@@ -457,15 +457,23 @@ __device__ __noinline__ N3Cold n3_cold_path(N3Leaf<L> c, double u1, double u2, d
     // The minimum lies in the simplex -- but does the reference find it?  Its fsolve run may end on another root of the
     // rational system, outside [0,1]^3; it then reports the candidate at nu = (1/3,1/3,1/3), and so does this kernel: the
     // running minimum and the tie list follow what the reference reports, not what the likelihood could reach.
-    if (!dump && accept && !n3_reference_finds_optimum<L>(c)) {
-        u1 = (1.0 / 3.0) / s1;
-        u2 = (1.0 / 3.0) / s2;
-    }
+    // (Only a candidate whose exact minimum is within the window needs the answer -- its fallback value is no smaller.  The
+    // screening margin that made it a contender is a thousand times wider than the window: in a stretch of near-ties,
+    // e.g. the first ranks of the space, millions of contenders end here after one exact value pass.)
     double acc = 0.0;
     terms([&](double x, double y, double R) {
         double q = __builtin_fma(x - s1, u1, __builtin_fma(y - s2, u2, 1.0));
         acc = __builtin_fma(R, log(q), acc);
     });
+    if (!dump && accept && c.K0 - acc <= c.thr && !n3_reference_finds_optimum<L>(c)) {
+        u1 = (1.0 / 3.0) / s1;
+        u2 = (1.0 / 3.0) / s2;
+        acc = 0.0;
+        terms([&](double x, double y, double R) {
+            double q = __builtin_fma(x - s1, u1, __builtin_fma(y - s2, u2, 1.0));
+            acc = __builtin_fma(R, log(q), acc);
+        });
+    }
     out.u1 = u1; out.u2 = u2;
     out.nll = c.K0 - acc;
     out.accept = accept;
