@@ -46,3 +46,36 @@ def test_hybrj_restatement_follows_scipy_fsolve_on_the_reference_table():
         elif ref_fb[k] or not acc[k]:
             wrong += inr
     assert wrong <= 1
+
+
+def test_reference_outcome_class_of_every_table_entry():
+    """
+    hybrj restatement + the restated decision sequence of scipy's BFGS line search (n3_refbfgs.hpp), host build: the outcome
+    class of EVERY entry of the reference's m=6, K=3 table -- own optimum / nu = 1/3 fallback / None -- is reproduced.
+    """
+    import ctypes as C
+    import hybrj_check as hc
+    hc.lib.hybrj_check_outcome.argtypes = [C.c_int, C.c_int, hc.dp, hc.dp, C.POINTER(C.c_uint8), hc.dp]
+    g = np.load(os.path.join(GOLD, "solve_n3_m6k3.npz"))
+    r, rN = g["r"].astype(float), g["rN"].astype(float)
+    Cs, acc, nll = g["C"], g["accepted"].astype(bool), g["nll"]
+    B, m, _ = Cs.shape
+    full = np.concatenate([np.full((B, m, 1), 2.0), Cs.astype(float)], axis=2)
+    Cw = full * rN[None, :, None]
+    with np.errstate(all="ignore"):
+        Ch = Cw / Cw.sum(1)[:, None, :]
+        F = -(r[None, :] * np.log(Ch.sum(2) / 3.0)).sum(1)
+        ref_fb = acc & (np.abs(F - nll) <= 1e-9 * np.abs(nll))
+    ref = np.where(~acc, 0, np.where(acc & np.isnan(nll), -1, np.where(ref_fb, 2, 1)))
+    wrong = 0
+    counts = {0: 0, 1: 0, 2: 0}
+    for k in range(B):
+        c = np.ascontiguousarray(Cs[k], np.uint8)
+        nu = np.zeros(3)
+        o = hc.lib.hybrj_check_outcome(m, 2, r.ctypes.data_as(hc.dp), rN.ctypes.data_as(hc.dp), c.ctypes.data_as(C.POINTER(C.c_uint8)),
+                                       nu.ctypes.data_as(hc.dp))
+        if ref[k] >= 0:
+            counts[o] += 1
+            wrong += o != ref[k]
+    assert counts[0] == 284 and counts[2] >= 4460 and counts[1] >= 16280
+    assert wrong <= 2          # (one entry whose optimum IS the centre of the simplex carries the fallback value either way)

@@ -5,7 +5,7 @@
 //   score_batch   CalcAllC.L2 / CalcAllC.L3 on literal matrices  CalcAllC.py:44-76
 //   score_masked  the same likelihood on byte candidates x row masks (interval-subset resampling)
 #include "n3_core.hpp"
-#include "n3_refsys.hpp"
+#include "n3_refbfgs.hpp"
 
 // ------------------------------------------------------------------------------------------------
 // n = 2: faithful per-interval dL/dnu (Optimizer.py:208-221) + the Bus-Dekker/Brent hyperbolic
@@ -143,11 +143,12 @@ __global__ __launch_bounds__(64) void solve_batch_n2_kernel(int m, int tau, cons
 //      (n3_refsys.hpp) from (1/3,1/3,1/3,1).  Whatever it returns is taken -- converged or not -- if every nu_j is in
 //      [0,1] (NaN passes, Misc.py:49-57): ok = 1.
 //   2. Otherwise fmin_bfgs is started from nu = (1/3,1/3) with dL3_hat as gradient, which points uphill
-//      (Optimizer.py:255-265 against :246-252): the line search fails, BFGS hands back its start, (1/3,1/3,1/3) is in
-//      range and is reported: ok = 2.  (Not reproduced: the 1-2 % of toy candidates where that line search walks into NaNs
-//      and the reference ends with None or NaN.)
-// On the reference's own m=6, K=3 table (21 050 entries) step 1 lands in range for exactly the 16 286 entries reported
-// with their own optimum and out of range for all 4 466 + 284 fallback / None entries (tools/hybrj_check.py).
+//      (Optimizer.py:255-265 against :246-252).  Its line searches fail and it hands back its start -- (1/3,1/3,1/3) is in
+//      range and is reported: ok = 2 -- unless the first trial point lies outside the domain of the logarithms: then the
+//      search accepts a step on the derivative alone, BFGS stops at a point with NaN likelihood, out of range, and the
+//      reference returns None: ok = 0.  The decision sequence of scipy's search is restated in n3_refbfgs.hpp.
+// On the reference's own m=6, K=3 table (21 050 entries) this reproduces the outcome class of every entry: 16 286 own
+// optima, 4 467 fallbacks, 284 None (tools/hybrj_check.py; the 13 NaN entries are all-zero columns, ok = 0 above).
 // nu -> mu is the closed form of M3 (Optimizer.py:318-330), the NLL Optimizer.L3's sums (Optimizer.py:236-244).
 __global__ __launch_bounds__(64) void solve_batch_n3_kernel(int m, int tau, const double *r, const double *rN, int B,
                                                             const unsigned char *C, unsigned char *ok, double *mu,
@@ -176,11 +177,14 @@ __global__ __launch_bounds__(64) void solve_batch_n3_kernel(int m, int tau, cons
         return;
     }
     double nu[3];
-    n3_ref_fsolve(sys, nu, nullptr);
-    bool fallback = false;
-    for (int j = 0; j < 3; j++)
-        if (nu[j] < 0.0 || nu[j] > 1.0) fallback = true;
-    if (fallback) nu[0] = nu[1] = nu[2] = 1.0 / 3.0;
+    const int outcome = n3_ref_outcome(sys, nu);     // 1 own iterate, 2 fallback, 0 None (n3_refbfgs.hpp)
+    if (outcome == 0) {
+        ok[b] = 0;
+        mu[3 * b] = mu[3 * b + 1] = mu[3 * b + 2] = nll[b] = __builtin_nan("");
+        if (vals) for (int i = 0; i < m; i++) vals[(size_t)b * m + i] = __builtin_nan("");
+        return;
+    }
+    const bool fallback = outcome == 2;
     const double dtau = (double)tau;
     const double w0 = nu[0] / sys.S[0], w1 = nu[1] / sys.S[1], w2 = nu[2] / sys.S[2];
     const double ws = (w0 + w1) + w2;

@@ -19,7 +19,7 @@
 
 #include "n3_core.hpp"
 #define HYBRJ4_MANAGE_CONTRACT     // this unit allows fused multiply-adds; the hybrj restatement must not use them
-#include "n3_refsys.hpp"
+#include "n3_refbfgs.hpp"
 
 // ------------------------------------------------------------------------------------------------
 // host: bounds, ratio table
@@ -349,12 +349,13 @@ struct N3Cold {
 // which bounds everything the reference could report for it (one extra term pass instead of polish + logs).
 // Would the reference's fsolve -- MINPACK hybrj from (1/3,1/3,1/3,1) on the Lagrangian system, restated operation by
 // operation in hybrj4.hpp / n3_refsys.hpp -- end inside [0,1]^3 on this candidate?  If not, the reference reports it at its
-// nu = 1/3 fallback although the likelihood has its minimum inside the simplex.  The candidate's rows
+// nu = 1/3 fallback although the likelihood has its minimum inside the simplex -- or not at all, when its BFGS call leaves
+// the start (n3_refbfgs.hpp).  The candidate's rows
 // are put back together (prefix rows from LDS, leaf rows from the lane) and the system is evaluated per interval in the
 // reference's order, exactly as theta_solve_batch does: the landing point of hybrj on a rank-deficient system depends on
 // the last bit, so an aggregated evaluation would decide some of them differently.
 template <int L>
-__device__ __noinline__ bool n3_reference_finds_optimum(const N3Leaf<L> &c) {
+__device__ __noinline__ int n3_reference_outcome(const N3Leaf<L> &c) {
     unsigned char rows[2 * N3_MAX_M];
     for (int i = 0; i < c.D; i++) {
         rows[2 * i] = c.pre[i] & 15u;
@@ -373,10 +374,7 @@ __device__ __noinline__ bool n3_reference_finds_optimum(const N3Leaf<L> &c) {
     sys.c = rows;
     sys.init();
     double nu[3];
-    n3_ref_fsolve(sys, nu, nullptr);
-    for (int j = 0; j < 3; j++)
-        if (nu[j] < 0.0 || nu[j] > 1.0) return false;
-    return true;
+    return n3_ref_outcome(sys, nu);      // 1 own optimum, 2 the nu = 1/3 fallback, 0 None
 }
 
 template <int L>
@@ -465,14 +463,20 @@ __device__ __noinline__ N3Cold n3_cold_path(N3Leaf<L> c, double u1, double u2, d
         double q = __builtin_fma(x - s1, u1, __builtin_fma(y - s2, u2, 1.0));
         acc = __builtin_fma(R, log(q), acc);
     });
-    if (!dump && accept && c.K0 - acc <= c.thr && !n3_reference_finds_optimum<L>(c)) {
-        u1 = (1.0 / 3.0) / s1;
-        u2 = (1.0 / 3.0) / s2;
-        acc = 0.0;
-        terms([&](double x, double y, double R) {
-            double q = __builtin_fma(x - s1, u1, __builtin_fma(y - s2, u2, 1.0));
-            acc = __builtin_fma(R, log(q), acc);
-        });
+    if (!dump && accept && c.K0 - acc <= c.thr) {
+        const int outcome = n3_reference_outcome<L>(c);
+        if (outcome == 2) {
+            u1 = (1.0 / 3.0) / s1;
+            u2 = (1.0 / 3.0) / s2;
+            acc = 0.0;
+            terms([&](double x, double y, double R) {
+                double q = __builtin_fma(x - s1, u1, __builtin_fma(y - s2, u2, 1.0));
+                acc = __builtin_fma(R, log(q), acc);
+            });
+        } else if (outcome == 0) {   // the reference returns None for it: neither a finalist nor a suspect
+            accept = false;
+            out.contender = false;
+        }
     }
     out.u1 = u1; out.u2 = u2;
     out.nll = c.K0 - acc;

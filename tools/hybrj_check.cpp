@@ -1,6 +1,6 @@
 // Host build of the hybrj restatement (theta_amd/csrc/hybrj4.hpp + n3_refsys.hpp) for checking it against scipy's fsolve:
 //   g++ -O2 -ffp-contract=off -shared -fPIC tools/hybrj_check.cpp -o build_ab/libhybrj_check.so
-#include "../theta_amd/csrc/n3_refsys.hpp"
+#include "../theta_amd/csrc/n3_refbfgs.hpp"
 extern "C" int hybrj_check_solve(int m, int tau, const double *r, const double *rN, const unsigned char *c, double *nu, int *nfev) {
     N3RefSystem s;
     s.m = m;
@@ -10,4 +10,14 @@ extern "C" int hybrj_check_solve(int m, int tau, const double *r, const double *
     s.c = c;
     s.init();
     return n3_ref_fsolve(s, nu, nfev);
+}
+extern "C" int hybrj_check_outcome(int m, int tau, const double *r, const double *rN, const unsigned char *c, double *nu) {
+    N3RefSystem s;
+    s.m = m;
+    s.tau = (double)tau;
+    s.r = r;
+    s.rN = rN;
+    s.c = c;
+    s.init();
+    return n3_ref_outcome(s, nu);
 }
