@@ -584,11 +584,8 @@ void batch_launch_score_masked(int n, int m, int tau, int B, int S, const unsign
     if (mask != nullptr && S >= 16 && rsum_scratch != nullptr) {   // enough masks to fill the 16-row MFMA tiles
         hipLaunchKernelGGL(mask_rsum_kernel, dim3(S), dim3(64), 0, st, m, S, r, mask, rsum_scratch);
         const size_t lds = ((size_t)((m + 15) & ~15) * 32 + SMX_CAND * 4) * sizeof(double);
-        static size_t attr_bytes = 0;
-        if (attr_bytes < lds) {
-            (void)hipFuncSetAttribute((const void *)score_masked_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            attr_bytes = lds;
-        }
+        // (set on every launch: the attribute belongs to the current device's copy of the kernel, and costs nothing)
+        (void)hipFuncSetAttribute((const void *)score_masked_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(score_masked_mfma_kernel, dim3((B + SMX_CAND - 1) / SMX_CAND), dim3(64 * SMX_WAVES), lds, st, n, m,
                            tau, B, S, C, w, r, mu, mask, rsum_scratch, nll);
     } else {
