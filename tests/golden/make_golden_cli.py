@@ -5,6 +5,11 @@ Golden OUTPUT FILES of the reference's command line (RunTHetA.py main) -- data o
 Runs the reference (converted 2->3 outside the repo, see make_golden.py) as a subprocess on
   * example/Example.intervals -n 2 -k 3                         (BASELINE config 1)
   * a seeded 14-interval synthetic file, -n 2, default flags
+  * the same file through the default two-stage pipeline (no -n, --FORCE, ONE process: n=2, then n=3 on the intervals and
+    bounds derived from the FIRST n=2 solution -- 571 341 candidate matrices, ~15 minutes of the reference --, then model
+    selection); prefix syn14d.  (With --NUM_PROCESSES 8 the reference lists the two tied n=2 solutions in the other order
+    -- find_mins concatenates the workers' lists, RunTHetA.py:107-122 -- so its n=3 stage starts from different bounds:
+    1 369 938 candidates.  The GPU driver mirrors the single-process order.)
 and copies the resulting .withBounds / .results files (and the synthetic inputs) to tests/golden/cli/.
 """
 import os
@@ -69,6 +74,8 @@ def main():
     # (bounds given in the file + --NO_INTERVAL_SELECTION reach the reference's Enumerator as strings, which
     #  neither Python 2 nor 3 survives for n=3 -- Enumerator.py:254 -- so there is no n=3 CLI golden)
     run([syn, "-n", "2", "-k", "3", "-d", tmp, "-p", "syn14"], tmp)
+    if "--skip-n3" not in sys.argv:
+        run([syn, "-k", "3", "-d", tmp, "-p", "syn14d", "--FORCE"], tmp)
     if "--skip-example" not in sys.argv:
         run(["/root/reference/example/Example.intervals", "-n", "2", "-k", "3", "-d", tmp, "-p", "Example"], tmp)
     for f in sorted(os.listdir(tmp)):

@@ -82,6 +82,25 @@ def test_cli_default_pipeline_n2_then_n3_then_model_selection(tmp_path):
     assert best[0][0] in (res3[0][0], _parse_results(tmp_path / "s.n2.results")[0][0])
 
 
+def test_cli_default_pipeline_matches_reference_files_n3(tmp_path):
+    """
+    The default two-stage pipeline against the files the reference's own CLI wrote for the same command
+    (`RunTHetA syn14.intervals -k 3 --FORCE`; tests/golden/cli/syn14d.*, make_golden_cli.py): n=2 stage, the n=3 bounds file
+    derived from it, the n=3 result of 571 341 candidate matrices (chosen C of all intervals bit-exact, NLL / mu / p*
+    1e-6) and the model-selection output.
+    """
+    import theta_amd.search as S
+    _run([os.path.join(CLI, "syn14.intervals"), "-k", "3", "-p", "s3", "--FORCE"], tmp_path)
+    assert S.last_report.candidates == 571341
+    _compare_results(tmp_path / "s3.n2.results", os.path.join(CLI, "syn14d.n2.results"))
+    for kind in ("n2", "n3"):
+        mine = [l.split("\t") for l in open(tmp_path / ("s3.%s.withBounds" % kind)) if not l.startswith("#")]
+        ref = [l.split("\t") for l in open(os.path.join(CLI, "syn14d.%s.withBounds" % kind)) if not l.startswith("#")]
+        assert [[x.strip() for x in l] for l in mine] == [[x.strip() for x in l] for l in ref]
+    _compare_results(tmp_path / "s3.n3.results", os.path.join(CLI, "syn14d.n3.results"))
+    _compare_results(tmp_path / "s3.BEST.results", os.path.join(CLI, "syn14d.BEST.results"))
+
+
 def test_cli_default_pipeline_on_example_with_force(tmp_path):
     """
     `RunTHetA example/Example.intervals --FORCE` (no -n): the n=2 stage must reproduce the reference CLI's files; the n=3

@@ -275,8 +275,8 @@ def test_get_values_dump_matches_oracle_trace(ctx, tmp_path):
             for (mu0, nll), s in zip(got[col], sols):
                 total += 1
                 agree += abs(nll - s[1]) <= 1e-6 * abs(s[1])
-        # (n=3: the dump holds column 1 only, so the lines of candidates that share it are compared only where the two sides
-        # accepted the same number of them; the accept sets differ on scipy's accidents)
-        assert total >= (0.9 if n == 2 else 0.6) * sum(len(v) for v in ref.values()), (n, total)
-        assert agree >= (1.0 if n == 2 else 0.85) * total, (n, agree, total)
+        # (n=3: the dump holds column 1 only; matrices that share it are compared where the two sides hold the same number of
+        # them -- with the reference's outcome reproduced that is everywhere but at all-zero tumour columns)
+        assert total >= (0.9 if n == 2 else 0.95) * sum(len(v) for v in ref.values()), (n, total)
+        assert agree >= (1.0 if n == 2 else 0.99) * total, (n, agree, total)
     S.pre = "theta"

@@ -222,15 +222,14 @@ def _dump_values(problem, n, m):
         step = 1 << 16
         for b in range(0, problem.count, step):
             cnt = min(step, problem.count - b)
-            nll, mu, _ = problem.values(b, cnt)
             C = problem.enumerate(b, cnt)
-            if n == 3 and np.isnan(nll).any():
-                # optimum outside the simplex: the reference dumps its nu = (1/3,1/3,1/3) fallback value (see fallback_records)
-                idx = np.flatnonzero(np.isnan(nll))
-                ok, mu_b, nll_b, _v = problem.ctx.solve_batch(3, problem.tau, problem.r, problem.rN, C[idx], problem.max_normal,
-                                                              want_vals=False)
-                nll[idx[ok]] = nll_b[ok]
-                mu[idx[ok]] = mu_b[ok]
+            if n == 2:
+                nll, mu, _ = problem.values(b, cnt)
+            else:
+                # n=3: what the reference dumps for a matrix is the outcome of its solver calls (own optimum / nu = 1/3
+                # fallback / nothing), which theta_solve_batch reproduces -- not the fused kernel's optimum
+                ok, mu, nll, _v = problem.ctx.solve_batch(3, problem.tau, problem.r, problem.rN, C, problem.max_normal, want_vals=False)
+                nll = np.where(ok, nll, np.nan)
             col = C if n == 2 else C[:, :, 0]
             for i in range(cnt):
                 if nll[i] == nll[i]:
