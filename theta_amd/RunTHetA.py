@@ -101,7 +101,8 @@ def run_fixed_N(n, args, intervals, resultsfile=None):
         sys.exit(1)
     rep = _search.last_report
     print("\tSearched %d candidate matrices in %.2f s on the GPU (%d finalists)%s" % (
-        rep.candidates, rep.seconds, rep.finalists, "; PARITY-UNCERTAIN (see DESIGN.md)" if rep.parity_uncertain else ""))
+        rep.candidates, rep.seconds, rep.finalists,
+        "" if rep.certificate_complete else "; suspect list overflowed: rerun with a tighter rank range (see DESIGN.md section 5)"))
 
     if n == 2 and best_near_max_contamination(best, max_normal):
         print("WARNING: At least one of the top solutions is near the upper bound on normal contamination. Further "
