@@ -6,10 +6,10 @@ Runs the reference (converted 2->3 outside the repo, see make_golden.py) as a su
   * example/Example.intervals -n 2 -k 3                         (BASELINE config 1)
   * a seeded 14-interval synthetic file, -n 2, default flags
   * the same file through the default two-stage pipeline (no -n, --FORCE, ONE process: n=2, then n=3 on the intervals and
-    bounds derived from the FIRST n=2 solution -- 571 341 candidate matrices, ~15 minutes of the reference --, then model
+    bounds derived from the FIRST n=2 solution -- 1 369 938 candidate matrices, ~55 minutes of the reference --, then model
     selection); prefix syn14d.  (With --NUM_PROCESSES 8 the reference lists the two tied n=2 solutions in the other order
-    -- find_mins concatenates the workers' lists, RunTHetA.py:107-122 -- so its n=3 stage starts from different bounds:
-    1 369 938 candidates.  The GPU driver mirrors the single-process order.)
+    -- find_mins concatenates the workers' lists, RunTHetA.py:107-122 -- so its n=3 stage starts from different bounds.
+    The GPU driver mirrors the single-process order.)
 and copies the resulting .withBounds / .results files (and the synthetic inputs) to tests/golden/cli/.
 """
 import os

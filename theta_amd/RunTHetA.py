@@ -135,10 +135,9 @@ def main(argv=None):
     else:
         resultsfile2, boundsfile2 = run_fixed_N(2, args, intervals)
         intervals = read_interval_file(boundsfile2)
-        args3 = list(args)
-        if args3[18] == 100:
-            args3[18] = 20                        # the n=3 default of NUM_INTERVALS (FileIO.py:170)
-        resultsfile3, boundsfile3 = run_fixed_N(3, tuple(args3), intervals, resultsfile2)
+        # (the same args for both stages, like the reference: its "20 intervals for n=3" default is applied by the parser
+        # only when -n 3 is given, FileIO.py:170 -- the two-stage run selects up to NUM_INTERVALS = 100 for n=3 as well)
+        resultsfile3, boundsfile3 = run_fixed_N(3, args, intervals, resultsfile2)
         ModelSelection(args[0], resultsfile2, resultsfile3)
 
 
