@@ -14,6 +14,7 @@ import torch.distributed as dist
 
 dist.init_process_group("gloo")
 rank = dist.get_rank()
+os.environ["LOCAL_RANK"] = str(int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1))   # ranks share the box's GPU(s)
 import parity_campaign as pc
 from theta_amd.search import do_optimization_single, do_optimization_distributed
 
@@ -29,10 +30,12 @@ for shape, seeds in (("toy", range(1001, 1041)), ("mid", range(2001, 2031))):
         except SystemExit:
             single = []
         except Exception as e:      # e.g. a count that overflows: same on every rank
+            print("rank", rank, "single failed", shape, seed, n, repr(e)[:100], flush=True)
             continue
         try:
             shard = do_optimization_distributed(*args, device=torch.device("cpu"))
         except SystemExit:
+            print("rank", rank, "distributed exit", shape, seed, n, flush=True)
             shard = []
         same = len(single) == len(shard) and all(np.array_equal(a[0], b[0]) and abs(a[2] - b[2]) <= 1e-9 * abs(a[2]) for a, b in zip(single, shard))
         if not same:
