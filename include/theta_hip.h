@@ -137,8 +137,10 @@ int theta_boundary_min(theta_ctx *ctx, int m, int tau, const int64_t *r, const i
 
 /*
  * Per-candidate dump of the fused kernel over ranks rank_begin .. rank_begin+count-1: the
- * reference's --GET_VALUES developer aid (RunTHetA.py:210-215, FileIO.py:114).  nll[count]
- * (NaN where Optimizer.solve would return None), mu[count*n].  Diagnostic / parity entry point.
+ * reference's --GET_VALUES developer aid (RunTHetA.py:210-215, FileIO.py:114).  nll[count], mu[count*n].
+ * n=2: NaN where Optimizer.solve returns None.  n=3: the MINIMUM of each candidate's likelihood where it lies in the
+ * simplex, else NaN -- a diagnostic of the fused arithmetic; what the reference REPORTS for an n=3 candidate (its own
+ * optimum, the nu = 1/3 fallback, or None) comes from theta_solve_batch (the --GET_VALUES file is written from that).
  */
 int theta_search_values(theta_problem *p, const uint64_t rank_begin[2], uint64_t count, double *nll,
                         double *mu, theta_search_stats *stats);
