@@ -157,6 +157,7 @@ int theta_enumerate(theta_problem *p, const uint64_t rank_begin[2], uint64_t cou
  * on the context's GPU), for consumers that stay on the GPU (theta_score_masked, a caller's own kernels).
  * kernel_ms (may be NULL) receives the HIP-event duration of the enumeration kernels.  No reference counterpart
  * beyond generate_next_C itself (Enumerator.py:74-87): this is the generator without the PCIe copy.
+ * d_out must be 4-byte aligned (THETA_ERR_ARG otherwise).
  */
 int theta_enumerate_device(theta_problem *p, const uint64_t rank_begin[2], uint64_t count, void *d_out, double *kernel_ms);
 

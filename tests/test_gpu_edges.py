@@ -192,6 +192,8 @@ def test_enumerate_all_shapes_and_the_device_variant(ctx):
             assert hip.hipMemset(dptr, 0xEE, nbytes) == 0
             ms = p.enumerate_device(5, p.count - 9, dptr.value + 16)
             assert ms > 0
+            with pytest.raises(theta_amd.ThetaError):                     # the output pointer must be 4-byte aligned
+                p.enumerate_device(5, 10, dptr.value + 2)
             got = np.zeros(nbytes, np.uint8)
             assert hip.hipMemcpy(got.ctypes.data_as(C.c_void_p), dptr, nbytes, 2) == 0          # device -> host
         finally:

@@ -786,6 +786,10 @@ extern "C" int theta_enumerate_device(theta_problem *p, const uint64_t rank_begi
         theta_set_error("null output");
         return THETA_ERR_ARG;
     }
+    if (((uintptr_t)d_out & 3u) != 0) {      // the generators store 32-bit (even m) / 16-bit (odd m) row units
+        theta_set_error("theta_enumerate_device: the output pointer must be 4-byte aligned");
+        return THETA_ERR_ARG;
+    }
     HIP_TRY(hipSetDevice(p->ctx->device));
     return enumerate_device(p, b, count, (unsigned char *)d_out, kernel_ms);
 }
