@@ -355,7 +355,7 @@ struct N3Cold {
 // reference's order, exactly as theta_solve_batch does: the landing point of hybrj on a rank-deficient system depends on
 // the last bit, so an aggregated evaluation would decide some of them differently.
 template <int L>
-__device__ __noinline__ int n3_reference_outcome(const N3Leaf<L> &c) {
+__device__ __noinline__ int n3_reference_outcome(const N3Leaf<L> &c, double nu[3]) {
     unsigned char rows[2 * N3_MAX_M];
     for (int i = 0; i < c.D; i++) {
         rows[2 * i] = c.pre[i] & 15u;
@@ -373,8 +373,7 @@ __device__ __noinline__ int n3_reference_outcome(const N3Leaf<L> &c) {
     sys.rN = c.rN;
     sys.c = rows;
     sys.init();
-    double nu[3];
-    return n3_ref_outcome(sys, nu);      // 1 own optimum, 2 the nu = 1/3 fallback, 0 None
+    return n3_ref_outcome(sys, nu);      // 1 own iterate (nu), 2 the nu = 1/3 fallback, 0 None
 }
 
 template <int L>
@@ -464,10 +463,13 @@ __device__ __noinline__ N3Cold n3_cold_path(N3Leaf<L> c, double u1, double u2, d
         acc = __builtin_fma(R, log(q), acc);
     });
     if (!dump && accept && c.K0 - acc <= c.thr) {
-        const int outcome = n3_reference_outcome<L>(c);
-        if (outcome == 2) {
-            u1 = (1.0 / 3.0) / s1;
-            u2 = (1.0 / 3.0) / s2;
+        double nu[3];
+        const int outcome = n3_reference_outcome<L>(c, nu);
+        if (outcome != 0) {
+            // the point the reference reports: the fallback, or the iterate its fsolve stopped at (which may fall short
+            // of the polished minimum by more than the tie margin)
+            u1 = nu[1] / s1;
+            u2 = nu[2] / s2;
             acc = 0.0;
             terms([&](double x, double y, double R) {
                 double q = __builtin_fma(x - s1, u1, __builtin_fma(y - s2, u2, 1.0));
