@@ -320,6 +320,9 @@ __global__ __launch_bounds__(256) void n2_search_kernel(N2Dev P, SearchArgs A, u
     }
 }
 
+typedef unsigned n2_u4v __attribute__((ext_vector_type(4)));
+typedef n2_u4v N2U4 __attribute__((aligned(4)));   // a 16-byte store that is only 4-byte aligned
+
 // Materialise candidates: thread t writes `per_thread` consecutive candidates starting at begin+t*per_thread.
 template <int KV>
 __global__ __launch_bounds__(256) void n2_enumerate_kernel(N2Dev P, unsigned long long begin, unsigned long long count,
@@ -339,16 +342,70 @@ __global__ __launch_bounds__(256) void n2_enumerate_kernel(N2Dev P, unsigned lon
     if (k1 > count) k1 = count;
     N2Cand<KV> c;
     n2_unrank<KV>(P, Pl, begin + k0, c);
+    const bool words = (P.m & 3) == 0 && (((unsigned long long)out) & 3ull) == 0ull;
+    const bool stream = !words && (((unsigned long long)(out + k0 * (unsigned long long)P.m)) & 3ull) == 0ull;
+    unsigned *s32 = (unsigned *)(out + k0 * (unsigned long long)P.m);
+    unsigned carry = 0;
+    int phase = 0;
     for (unsigned long long k = k0; k < k1; k++) {
         unsigned char *dst = out + k * (unsigned long long)P.m;
         // value at position i = number of v >= 1 with s[v] <= i
-        for (int i = 0; i < P.m; i++) {
-            int val = 0;
+        if (words) {
+            // four positions per 32-bit word: break-point v adds 1 to every byte at or after s[v]; 16-byte stores (a record
+            // is only 4-byte aligned: the hardware takes unaligned multi-dword stores)
+            unsigned *d32 = (unsigned *)dst;
+            const int nw = P.m >> 2;
+            auto word = [&](int w) -> unsigned {
+                unsigned val = 0;
 #pragma unroll
-            for (int v = 1; v < KV; v++) val += (c.s[v] <= i);
-            dst[i] = (unsigned char)val;
+                for (int v = 1; v < KV; v++) {
+                    const int d = c.s[v] - 4 * w;
+                    val += d <= 0 ? 0x01010101u : (d >= 4 ? 0u : (0x01010101u << (8 * d)));
+                }
+                return val;
+            };
+            int w = 0;
+            for (; w + 4 <= nw; w += 4) *(N2U4 *)(d32 + w) = N2U4{word(w), word(w + 1), word(w + 2), word(w + 3)};
+            for (; w < nw; w++) d32[w] = word(w);
+        } else if (stream) {
+            // m not a multiple of 4: the thread's candidates are one contiguous, 4-byte-aligned run of bytes -- emit it word
+            // by word, a word that straddles two records being finished by the next one (`carry` holds its first `phase` bytes)
+            int pos = -phase;                                   // record position of the first byte of the current word
+            while (pos < P.m) {
+                unsigned val = 0;
+#pragma unroll
+                for (int v = 1; v < KV; v++) {
+                    const int d = c.s[v] - pos;
+                    val += d <= 0 ? 0x01010101u : (d >= 4 ? 0u : (0x01010101u << (8 * d)));
+                }
+                if (pos < 0) val = (val & (0xffffffffu << (8 * (-pos)))) | carry;
+                const int over = pos + 4 - P.m;
+                if (over > 0) {
+                    carry = val & (0xffffffffu >> (8 * over));
+                    phase = 4 - over;
+                    break;
+                }
+                *s32++ = val;
+                carry = 0;
+                phase = 0;
+                pos += 4;
+            }
+        } else {
+            for (int i = 0; i < P.m; i++) {
+                int val = 0;
+#pragma unroll
+                for (int v = 1; v < KV; v++) val += (c.s[v] <= i);
+                dst[i] = (unsigned char)val;
+            }
         }
-        if (k + 1 < k1 && !n2_next<KV>(P, ubl, lbposl, c)) break;
+        if (k + 1 < k1 && !n2_next<KV>(P, ubl, lbposl, c)) {
+            k1 = k + 1;
+            break;
+        }
+    }
+    if (stream && phase > 0) {                                   // the last, partial word of the run
+        unsigned char *tail = (unsigned char *)s32;
+        for (int i = 0; i < phase; i++) tail[i] = (unsigned char)(carry >> (8 * i));
     }
 }
 
@@ -393,7 +450,7 @@ void n2_launch_search(const N2Dev &P, const SearchArgs &A, unsigned long long be
 
 void n2_launch_enumerate(const N2Dev &P, unsigned long long begin, unsigned long long count, unsigned char *out,
                          hipStream_t st) {
-    const int per_thread = 16;
+    const int per_thread = 16;     // (64 measured no better: the limit is the write pattern, one stream per lane)
     unsigned long long threads = (count + per_thread - 1) / per_thread;
     unsigned blocks = (unsigned)((threads + 255) / 256);
     size_t sm = n2_smem_bytes(P);
