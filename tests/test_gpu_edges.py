@@ -282,3 +282,16 @@ def test_get_values_dump_matches_oracle_trace(ctx, tmp_path):
         assert total >= (0.9 if n == 2 else 0.95) * sum(len(v) for v in ref.values()), (n, total)
         assert agree >= (1.0 if n == 2 else 0.99) * total, (n, agree, total)
     S.pre = "theta"
+
+
+def test_driver_exits_cleanly_when_the_search_is_beyond_the_library(ctx, capsys):
+    """n=3 with 70 intervals (the library holds one interval per lane: 64), or a space beyond 2^128 matrices: a message
+    and exit(1) like the reference's other input errors, not a traceback."""
+    from theta_amd.search import do_optimization_single
+    rng = np.random.RandomState(4)
+    for m, k in ((70, 2), (64, 7)):
+        r = rng.randint(1000, 5000, m).tolist()
+        rN = rng.randint(1000, 5000, m).tolist()
+        with pytest.raises(SystemExit):
+            do_optimization_single(3, m, k, 2, [0] * m, [k] * m, r, rN, 1.0, list(range(m)))
+        assert "ERROR" in capsys.readouterr().out

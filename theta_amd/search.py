@@ -266,6 +266,13 @@ def do_optimization_single(n, m, k, tau, lower_bounds, upper_bounds, r, rN, max_
     except _lib.NoCandidates:
         print("Error: No valid Copy Number Profiles exist for these intervals within the bounds specified. Exiting...")
         sys.exit(1)
+    except _lib.ThetaError as e:
+        if e.code in (_lib.ERR_OVERFLOW, _lib.ERR_ARG):
+            # a search the library cannot hold (n=3: more than 64 intervals, or more than 2^128 matrices -- the reference would
+            # enumerate such a space for years): say so instead of a traceback
+            print("ERROR: %s. Use fewer intervals (--NUM_INTERVALS) or tighter bounds. Exiting..." % e)
+            sys.exit(1)
+        raise
     q1 = _q1_record(ctx, n, m, tau, r, rN) if n == 3 else None
     if n == 3:
         recs = recs + fallback_records(problem, ctx, [int(x) for x in r], [int(x) for x in rN], max_normal, recs, report=rep)
