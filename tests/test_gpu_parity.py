@@ -135,8 +135,9 @@ def test_n2_degenerate_cases_through_optimizer_class(ctx):
 # ---------------------------------------------------------------------------------------------------
 def _check_n3_table(C, nll, mu, ref_acc, ref_mu, ref_nll):
     """
-    The GPU accept set is "likelihood minimum inside the simplex"; the reference's is a
-    scipy-trajectory-dependent superset.  What must hold:
+    The fused kernel's --GET_VALUES style dump (theta_search_values) reports the MINIMUM of a candidate's likelihood where
+    it lies in the simplex; the reference reports the outcome of its solver calls (own optimum / nu = 1/3 fallback / None),
+    which theta_solve_batch reproduces and the tests below check entry by entry.  What must hold for the dump:
       * whatever the reference reports for a candidate is never below the GPU's optimum;
       * where the reference converged to the optimum (same NLL), mu agrees (unless the candidate is
         rank-deficient, where the minimiser is a line);
