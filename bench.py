@@ -164,6 +164,26 @@ def extras(ctx, r, rN, cpu_seconds):
                                       "reference_note": "the reference's own search loop on this input, timed in the build container"}
     except Exception as ex:       # the fixture is test data; the bench line does not depend on it
         w["config1_example_n2_k3"] = {"error": str(ex)}
+    try:
+        # an exhaustible n=3 search with a reference time: the n=3 stage of `RunTHetA syn14.intervals -k 3 --FORCE`
+        # (tests/golden/cli/syn14d.n3.withBounds: 14 intervals, 1 369 938 candidate matrices; the reference's own CLI, one
+        # process, needed about 55 minutes for this stage in the build container -- tests/golden/make_golden_cli.py)
+        from theta_amd.DataTools import sort_r, set_total_read_counts
+        rows = [l.split() for l in open(os.path.join(ROOT, "tests", "golden", "cli", "syn14d.n3.withBounds")) if not l.startswith("#")]
+        tum, nrm = [int(x[4]) for x in rows], [int(x[5]) for x in rows]
+        ub3, lb3 = [int(x[6]) for x in rows], [int(x[7]) for x in rows]
+        set_total_read_counts(sum(tum), sum(nrm))
+        rs3, rNs3, order3 = sort_r(nrm, tum)
+        lbs3, ubs3 = [lb3[i] for i in order3], [ub3[i] for i in order3]
+        ts = []
+        for _ in range(3):
+            t = time.time()
+            b3 = do_optimization_single(3, len(rows), 3, TAU, list(lbs3), list(ubs3), rs3, rNs3, 1.0, order3, False, False)
+            ts.append(time.time() - t)
+        w["syn14_n3_stage"] = {"candidates": 1369938, "gpu_wall_s": min(ts), "nll": b3[0][2], "reference_search_s_approx": 3300.0,
+                               "reference_note": "the reference CLI's n=3 stage on this input, one process, build container"}
+    except Exception as ex:
+        w["syn14_n3_stage"] = {"error": str(ex)}
     r2, rN2, order2 = synth(seed=11, m=25, n=2, k=5)
     ts = []
     for _ in range(3):
