@@ -345,6 +345,12 @@ def main():
                          "newton_iters_per_candidate": allv[0, 5] / max(allv[0, 0], 1.0),
                          "terms_per_iteration": allv[0, 4] / max(allv[0, 5], 1.0),
                          "kernel_candidates_per_s": allv[0, 0] / (k_ms * 1e-3),
+                         # SURVEY.md 8(d)'s per-unit figure (a per-interval FP64 Newton solve: ~160 FP64 op per interval, 8.0
+                         # kFLOP per candidate at m=50) x the launch's candidates: what the same throughput would cost a kernel
+                         # that did that work -- the distance to `achieved` is what the algorithm saves (group tile, warm
+                         # start, one packed-FP32 evaluation, dismissal by a lower bound), not ALU efficiency
+                         "survey_flop_per_candidate": 160.0 * M,
+                         "survey_equivalent_tflops": 160.0 * M * allv[0, 0] / (k_ms * 1e-3) / 1e12,
                          "note": "fused kernel: candidates are generated on chip, HBM bytes/candidate ~ 0 by design; "
                                  "see DESIGN.md section 'Roofline'"},
             "dismissed_fraction": allv[:, 9].sum() / max(ev_all, 1.0),      # finished by the lower bound of their optimum
