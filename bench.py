@@ -1,31 +1,42 @@
 #!/usr/bin/env python3
 """
-bench.py -- candidate C-matrices evaluated per second (BASELINE.json metric) on MI355X.
+bench.py -- candidate C-matrices evaluated per second (BASELINE.json metric) on MI355X.  No torch: numpy + the C ABI.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ... -- the launcher only
+     provides RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT; the collectives are the library's own RCCL
+     communicator, theta_comm_create)
 
-Workload (config.workload): BASELINE config 4's shape -- synthetic m=50 intervals, n=3, k=6, full
-bounds [0,6] (2.6e38 admissible matrices, inexhaustible) -- searched as rank ranges of the
-reference's enumeration order.  One "step" = one theta_search call over `--batch` consecutive
-candidates (enumerate + solve + NLL + arg-min, fused in one kernel).  Each GPU owns the contiguous
-shard [N*g/G, N*(g+1)/G) of the rank space and its steps are spread evenly through that shard, so
-the sampled candidates are representative of the whole space.  Weak scaling: per-GPU work is fixed.
-With N > 1 the per-shard finalists are merged with ONE small RCCL exchange (all-reduce min +
-all-gather) inside the timed region.
+Workload (config.workload): BASELINE config 4's shape -- synthetic m=50 intervals, n=3, k=6, full bounds [0,6] (2.6e38
+admissible matrices, inexhaustible) -- searched as rank ranges of the reference's enumeration order.  One "step" = one
+theta_search call over `--batch` consecutive candidates (enumerate + solve + NLL + arg-min, fused in one kernel).  Each GPU
+owns the contiguous shard [N*g/G, N*(g+1)/G) of the rank space and its steps are spread evenly through that shard.  Weak
+scaling: per-GPU work is fixed.  With N > 1 the per-shard finalists are merged with ONE RCCL exchange
+(theta_exchange_finalists) inside the timed region.
 
-Prints ONE JSON line (rank 0).  `value` = candidates evaluated by all GPUs / max-over-ranks wall time.
-`roofline`: the fused search kernel is FP64-VALU bound (no HBM traffic per candidate by design), so
-the achieved figure is executed FP64 operations (counted inside the kernel) over the kernel time
-measured with HIP events on its stream, against the MI355X FP64 vector peak.
-`cpu_baseline`: the CPU oracle (oracle/theta_oracle.py, a port of the reference's Python) timed on
-this host's cores on a bounded sample of the same candidates.
+Prints ONE JSON line (rank 0).
+  value      candidates SEARCHED by all GPUs / max-over-ranks wall time of the K timed steps, the shipped search: a
+             branch-and-bound in which a candidate whose rigorous lower bound lies beyond the window of the running minimum
+             is finished after one packed-FP32 evaluation (roofline.legs.search.dismissed_fraction says how many).
+  roofline   dominant kernel n3_search_kernel, vector-ALU bound (candidates are generated on chip: ~0 algorithmic HBM
+             bytes).  THREE legs on the same rank ranges, each timed by HIP events on the kernel's stream (N = 1):
+               search           as shipped                                      executed FLOP vs the packed-FP32 peak
+               full_solve_f32   no candidate dismissed by its bound: every one   executed FLOP vs the packed-FP32 peak
+                                iterated to the coarse tolerance and valued
+               full_solve_f64   the same in FP64 throughout -- SURVEY 8(d)'s      executed FLOP vs the FP64 vector peak
+                                "passed through the full solve"
+             `achieved/peak/frac` at the top of the object are the shipped search's.
+             traffic: HBM bytes per launch, measured by two rocprofv3 --pmc passes of this same command on two steps
+             (FETCH_SIZE, WRITE_SIZE; gfx950 corrections of MI355X_MICROARCH.md), or null when that is not possible.
+  cpu_baseline  the CPU oracle (oracle/theta_oracle.py, a port of the reference's Python) on this host's cores, bounded sample.
 """
 import argparse
 import json
 import multiprocessing as mp
 import os
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -35,6 +46,7 @@ import numpy as np
 
 FP64_VECTOR_PEAK_TFLOPS = 78.6     # MI355X FP64 vector peak (AMD spec; = 256 CU x 4 SIMD x 16 FMA lanes x 2 x 2.4 GHz)
 FP32_VECTOR_PEAK_TFLOPS = 157.3    # MI355X FP32 vector peak (packed v_pk_fma_f32: two FP32 FMAs per FP64 lane)
+FP64_MFMA_PEAK_TFLOPS = 78.6       # MI355X FP64 matrix peak (dense)
 HBM_PEAK_GBS = 8000.0
 
 M, N_POP, K_MAX, TAU, SEED = 50, 3, 6, 2, 4242
@@ -107,47 +119,109 @@ def cpu_baseline(cands, r, rN, budget_s=15.0):
                       "%d concurrent processes, %.1f s of solving each" % (done, cores, dt)}
 
 
-def extras(ctx, r, rN, cpu_seconds):
-    """
-    Secondary figures of the BASELINE metric, N=1 only, outside the timed region:
-    * full_solve: the same search with the lower-bound dismissal switched off (THETA_N3_NO_DISMISS=1) -- every candidate is
-      iterated to the coarse tolerance and valued, none is finished after one evaluation by its bound;
-    * wall_clock_to_best: end-to-end do_optimization_single (search + finalists in reference arithmetic + tie replay) on the
-      two exhaustible BASELINE configs -- config 1 (example/Example.intervals -n 2 -k 3 after interval selection: 142 560
-      candidates; fixture tests/golden/example_n2.json, which also holds the reference's own search time in the build
-      container) and config 2 (synthetic m=25, n=2, k=5: 142 506 candidates; the CPU side is the oracle on a sample of the
-      same candidates, extrapolated).
-    """
-    import theta_amd
-    from theta_amd.search import do_optimization_single
-    out = {}
-    os.environ["THETA_N3_NO_DISMISS"] = "1"
-    try:
-        p2 = theta_amd.Problem(ctx, N_POP, M, TAU, r, rN, [0] * M, [K_MAX] * M, 1.0)
-    finally:
-        del os.environ["THETA_N3_NO_DISMISS"]
-    total, batch = p2.count, 1 << 29
-    ev = 0
-    kms = 0.0
-    best = float("inf")
-    t0 = None
-    for i in range(3):
-        if i == 1:
-            t0 = time.time()
-        if best < float("inf"):
-            p2.hint(best)
-        res = p2.search(total // 7 * (i + 1), total // 7 * (i + 1) + batch, window=0.5)
+# ---- the legs --------------------------------------------------------------------------------------
+class Leg:
+    """K timed theta_search calls over the rank ranges of the bench, chained like the pieces of one job (each starts from
+    the minimum found so far, theta_problem_hint)."""
+
+    def __init__(self, problem, begins, batch, window):
+        self.p, self.begins, self.batch, self.window = problem, begins, batch, window
+        self.running = float("inf")
+        self.best = None
+        self.tot = {k: 0 for k in ("evaluated", "accepted", "dismissed", "flops", "flops_f32", "terms", "iterations")}
+        self.kernel_ms = self.setup_ms = 0.0
+        self.launches = 0
+
+    def step(self, i, count=True):
+        b = self.begins[i]
+        # (the first step carries a trivial hint: without one Problem.search would first probe 16 short sub-ranges -- 16
+        # extra launches of the same kernel, which would blur the per-launch averages of the rocprofv3 runs of this command)
+        self.p.hint(self.running if self.running < float("inf") else 1e300)
+        res = self.p.search(b, b + self.batch, window=self.window)
         if len(res["nll"]):
-            best = min(best, float(res["nll"].min()))
-        if i >= 1:
-            ev += res["stats"]["evaluated"]
-            kms += res["stats"]["kernel_ms"]
-            dis = res["stats"]["dismissed"]
-    dt = time.time() - t0
-    out["full_solve"] = {"value": ev / dt, "unit": "candidates/s", "kernel_candidates_per_s": ev / (kms * 1e-3),
-                         "dismissed": int(dis), "note": "THETA_N3_NO_DISMISS=1, 2 x 2^29 candidates of the same instance: no "
-                         "candidate is finished by its lower bound"}
-    p2.close()
+            self.running = min(self.running, float(res["nll"].min()))
+        if count:
+            st = res["stats"]
+            for k in self.tot:
+                self.tot[k] += st[k]
+            self.kernel_ms += st["kernel_ms"]
+            self.setup_ms += st["setup_ms"]
+            self.launches += 1
+            if len(res["nll"]) and (self.best is None or res["nll"].min() < self.best["nll"].min()):
+                self.best = res
+        return res
+
+    def summary(self, wall_s, name, dtype):
+        f64, f32, ev = float(self.tot["flops"]), float(self.tot["flops_f32"]), float(self.tot["evaluated"])
+        k_s = self.kernel_ms * 1e-3
+        ach = (f64 + f32) / k_s / 1e12 if k_s > 0 else 0.0
+        # time-weighted peak of the executed mix: an FP64 op costs two packed-FP32 slots
+        peak = (f64 + f32) / (f64 / FP64_VECTOR_PEAK_TFLOPS + f32 / FP32_VECTOR_PEAK_TFLOPS) if f64 + f32 > 0 else FP32_VECTOR_PEAK_TFLOPS
+        return {"leg": name, "dtype": dtype, "launches": self.launches, "candidates_per_launch": self.batch,
+                "value": ev / wall_s if wall_s > 0 else 0.0, "unit": "candidates/s", "wall_ms_per_launch": 1e3 * wall_s / max(self.launches, 1),
+                "kernel_ms_per_launch": self.kernel_ms / max(self.launches, 1), "kernel_candidates_per_s": ev / k_s if k_s > 0 else 0.0,
+                "executed_flop_per_launch": (f64 + f32) / max(self.launches, 1), "fp64_flop_share": f64 / max(f64 + f32, 1.0),
+                "flop_per_candidate": (f64 + f32) / max(ev, 1.0), "achieved": ach, "peak": peak, "unit_roofline": "TFLOP/s",
+                "frac": ach / peak, "newton_iters_per_candidate": self.tot["iterations"] / max(ev, 1.0),
+                "terms_per_iteration": self.tot["terms"] / max(self.tot["iterations"], 1),
+                "dismissed_fraction": self.tot["dismissed"] / max(ev, 1.0),
+                "accepted_fraction_of_solved": self.tot["accepted"] / max(ev - self.tot["dismissed"], 1.0),
+                # SURVEY.md 8(d)'s per-unit figure (a per-interval FP64 Newton solve, ~160 FP64 op per interval): what this
+                # leg's throughput would cost a kernel doing THAT work -- for the f64 full solve the distance to `achieved`
+                # is what the group tile and the warm start save, not ALU efficiency
+                "survey_flop_per_candidate": 160.0 * M,
+                "survey_equivalent_tflops": 160.0 * M * ev / k_s / 1e12 if k_s > 0 else 0.0}
+
+
+def measure_traffic(args):
+    """
+    HBM bytes per launch of the search kernel: two rocprofv3 --pmc passes (FETCH_SIZE, then WRITE_SIZE -- separate passes,
+    the two do not fit the TCC's counter slots together) of THIS command on a warm-up step and two timed steps, no trace
+    options.  Corrections of MI355X_MICROARCH.md (HBM section): both counters are in KB; on gfx950 FETCH_SIZE reports half
+    of the bytes read, so it is doubled; WRITE_SIZE is taken as is.  Returns (bytes per launch or None, note).
+    """
+    exe = None
+    for c in ("/opt/rocm/bin/rocprofv3", "rocprofv3"):
+        if os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c):
+            exe = c
+            break
+    got = {}
+    try:
+        with tempfile.TemporaryDirectory(prefix="theta_pmc_", dir="/tmp") as td:
+            env = dict(os.environ, TMPDIR="/tmp")
+            for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+                out = os.path.join(td, ctr)
+                cmd = [exe, "--pmc", ctr, "--output-format", "csv", "-d", out, "-o", "pmc", "--", sys.executable,
+                       os.path.abspath(__file__), "--gpus", "1", "--steps", "2", "--warmup", "1", "--batch", str(args.batch),
+                       "--no-cpu-baseline", "--no-legs", "--no-traffic", "--no-extras"]
+                subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240, check=True)
+                vals = []
+                for dp, _d, fs in os.walk(out):
+                    for f in fs:
+                        if f.endswith("counter_collection.csv"):
+                            import csv
+                            with open(os.path.join(dp, f)) as fh:
+                                for row in csv.DictReader(fh):
+                                    if "n3_search_kernel" in row.get("Kernel_Name", "") and row.get("Counter_Name") == ctr:
+                                        vals.append(float(row["Counter_Value"]))
+                if not vals:
+                    return None, "rocprofv3 produced no %s rows for the search kernel" % ctr
+                got[ctr] = sum(vals) / len(vals)
+    except Exception as ex:
+        return None, "rocprofv3 --pmc pass failed: %s" % (str(ex)[:200],)
+    byt = (2.0 * got["FETCH_SIZE"] + got["WRITE_SIZE"]) * 1024.0
+    return byt, "(2 x FETCH_SIZE + WRITE_SIZE) KB, mean over the search-kernel launches of two rocprofv3 --pmc passes of this command"
+
+
+def extras(ctx, cpu_seconds):
+    """
+    wall_clock_to_best -- the second half of BASELINE's metric -- end to end through do_optimization_single (search + finalists
+    in reference arithmetic + tie replay) on the exhaustible BASELINE configs: config 1 (example/Example.intervals -n 2 -k 3
+    after interval selection: 142 560 candidates; fixture tests/golden/example_n2.json, which also holds the reference's own
+    search time in the build container), config 2 (synthetic m=25, n=2, k=5: 142 506 candidates; CPU side = the oracle on a
+    sample, extrapolated) and the n=3 stage of the two-stage command on syn14.intervals.
+    """
+    from theta_amd.search import do_optimization_single
     w = {}
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import theta_oracle as orc
@@ -201,8 +275,39 @@ def extras(ctx, r, rN, cpu_seconds):
     w["config2_m25_n2_k5"] = {"candidates": 142506, "gpu_wall_s": min(ts), "nll": b2[0][2],
                               "cpu_oracle_candidates_per_s": cpu_rate, "cpu_oracle_estimated_s": 142506 / cpu_rate,
                               "cpu_sample": "%d candidates, 1 process" % n_s}
-    out["wall_clock_to_best"] = w
-    return out
+    return {"wall_clock_to_best": w}
+
+
+def config5_rider(ctx, problem_unused=None):
+    """
+    BASELINE config 5 (m=200, n=3, k=7, interval-subset resampling) as a rider with its own roofline: theta_score_masked on
+    B byte candidates x S row masks (CalcAllC.L3's valid_rows contract, CalcAllC.py:70-75); kernel time by HIP events.
+    For S >= 16 the masked sums run as an FP64 GEMM on the matrix cores, so the bound is the FP64 MFMA peak, and the HBM
+    figure (algorithmic bytes of SURVEY 8(d): m(n-1) + 8n per candidate, m/8 per mask, 8 per pair) is reported beside it.
+    """
+    m5, k5, B, S = 200, 7, 131072, 512
+    rng = np.random.RandomState(55)
+    Cb = rng.randint(0, k5 + 1, (B, m5, 2)).astype(np.uint8)
+    w = rng.poisson(100000, m5).astype(np.float64) + 1.0
+    r = rng.poisson(120000, m5).astype(np.float64)
+    mu = rng.dirichlet(np.ones(3) * 4, B)
+    words = (m5 + 63) // 64
+    bits = rng.rand(S, m5) < 0.8
+    masks = np.zeros((S, words), np.uint64)
+    for i in range(m5):
+        masks[:, i // 64] |= (bits[:, i].astype(np.uint64) << np.uint64(i % 64))
+    best = None
+    for _ in range(3):
+        _nll, ms = ctx.score_masked(3, TAU, Cb, w, r, mu, masks)
+        best = ms if best is None else min(best, ms)
+    pairs = B * S
+    flop = 2.0 * 2.0 * m5 * pairs                 # two masked sums (C.mu and r ln C.mu) of m terms per pair, as FMAs
+    byt = B * (m5 * 2 + 24) + S * words * 8 + pairs * 8
+    return {"config": "m=200, n=3, k=7: %d byte candidates x %d interval masks (theta_score_masked)" % (B, S),
+            "value": pairs / (best * 1e-3), "unit": "(candidate, mask) pairs/s", "kernel_ms": best, "dtype": "f64",
+            "roofline": {"bound": "mfma", "achieved": flop / (best * 1e-3) / 1e12, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": flop / (best * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS,
+                         "hbm_algorithmic_GBps": byt / (best * 1e-3) / 1e9, "hbm_frac": byt / (best * 1e-3) / 1e9 / HBM_PEAK_GBS}}
 
 
 def main():
@@ -212,30 +317,26 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=1 << 31, help="candidates per step per GPU (one theta_search call)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-legs", action="store_true", help="skip the full-solve legs (they run at N=1 only anyway)")
+    ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 --pmc passes that measure HBM traffic")
+    ap.add_argument("--no-extras", action="store_true", help="skip wall_clock_to_best and the config-5 rider")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = None
-    import torch
-    local = local % max(torch.cuda.device_count(), 1)      # (lets a 2-rank smoke test share one GPU)
-    torch.cuda.set_device(local)
-    backend = os.environ.get("THETA_BENCH_BACKEND", "nccl")  # "nccl" == RCCL over xGMI; "gloo" only for smoke tests
-    comm_dev = torch.device("cuda", local) if backend == "nccl" else torch.device("cpu")
-    if world > 1:
-        import torch.distributed as dist
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-        else:
-            dist.init_process_group(backend)
     if args.gpus != world and rank == 0:
         print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
 
     import theta_amd
-    from theta_amd.search import collect_finalists, exchange_finalists, COLLECT_WINDOW
-    ctx = theta_amd.Context(local)
+    from theta_amd.search import COLLECT_WINDOW
+    ndev = int(os.environ.get("THETA_BENCH_NDEV", "0")) or None      # (lets a 2-rank smoke test share one GPU)
+    ctx = theta_amd.Context(local % ndev if ndev else local)
+    comm = None
+    if world > 1:
+        # "rccl" = RCCL over xGMI (the library dlopens librccl.so); "host" only for smoke tests on a 1-GPU box
+        comm = theta_amd.Comm(ctx, rank=rank, world=world, transport=os.environ.get("THETA_BENCH_TRANSPORT", "rccl"))
     r, rN, order = synth()
     lb, ub = [0] * M, [K_MAX] * M
     problem = theta_amd.Problem(ctx, N_POP, M, TAU, r, rN, lb, ub, 1.0)   # builds the 173 MB counting table in HBM
@@ -243,136 +344,103 @@ def main():
     shard0, shard1 = total * rank // world, total * (rank + 1) // world
     nsteps = args.warmup + args.steps
     stride = (shard1 - shard0 - args.batch) // max(nsteps, 1)
-
-    running = [float("inf")]
-
-    def step(i):
-        # one chunk of the rank-range job; like Problem.search's own chunking, a chunk starts from the minimum the job has
-        # found so far (theta_problem_hint) -- that is what keeps tie / suspect lists short in ranges whose own minimum is poor
-        b = shard0 + i * stride + stride // 2       # (mid-points: the very first ranks of the space are a stretch of near-ties)
-        # (the first warm-up step carries a trivial hint: without one Problem.search would first probe 16 short sub-ranges --
-        # 16 extra launches of the same kernel, which would blur the per-launch averages of the rocprofv3 runs of this command)
-        problem.hint(running[0] if running[0] < float("inf") else 1e300)
-        res = problem.search(b, b + args.batch, window=COLLECT_WINDOW)
-        if len(res["nll"]):
-            running[0] = min(running[0], float(res["nll"].min()))
-        return res
-
-    for i in range(args.warmup):
-        step(i)
+    # (mid-points: the very first ranks of the space are a stretch of near-ties)
+    begins = [shard0 + i * stride + stride // 2 for i in range(nsteps)]
 
     def barrier():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
+        if comm is not None:
+            comm.barrier()
+        ctx.synchronize()
 
+    leg = Leg(problem, begins, args.batch, COLLECT_WINDOW)
+    for i in range(args.warmup):
+        leg.step(i, count=False)
     barrier()
     t0 = time.time()
-    evaluated = flops = flops32 = terms = iters = accepted = dismissed = 0
-    kernel_ms = setup_ms = 0.0
-    best = None
     for i in range(args.warmup, nsteps):
-        res = step(i)
-        st = res["stats"]
-        evaluated += st["evaluated"]
-        accepted += st["accepted"]
-        dismissed += st["dismissed"]
-        flops += st["flops"]
-        flops32 += st["flops_f32"]
-        terms += st["terms"]
-        iters += st["iterations"]
-        kernel_ms += st["kernel_ms"]
-        setup_ms += st["setup_ms"]
-        if len(res["nll"]) and (best is None or res["nll"].min() < best["nll"].min()):
-            best = res
-    if dist is not None:
-        # the single exchange of the sharded search: shard minima + finalists (a few hundred bytes)
+        leg.step(i)
+    if comm is not None:
+        # the single exchange of the sharded search: shard minima + finalists (a few hundred bytes), over RCCL
         recs = []
-        if best is not None:
-            for j in range(len(best["rank"])):
-                recs.append({"rank": best["rank"][j], "c": best["C"][j], "mu": best["mu"][j], "nll": float(best["nll"][j]),
+        if leg.best is not None:
+            for j in range(len(leg.best["rank"])):
+                recs.append({"rank": leg.best["rank"][j], "c": leg.best["C"][j], "mu": leg.best["mu"][j], "nll": float(leg.best["nll"][j]),
                              "vals": np.zeros(M)})
-        merged = exchange_finalists(recs, N_POP, M, comm_dev)
+        merged, gmin = comm.exchange_finalists(N_POP, M, recs, COLLECT_WINDOW)
     barrier()
     dt = time.time() - t0
 
-    tot = torch.tensor([float(evaluated), dt, float(flops), kernel_ms, float(terms), float(iters), float(accepted), setup_ms,
-                        float(flops32), float(dismissed)],
-                       dtype=torch.float64, device=comm_dev)
-    if dist is not None:
-        allv = [torch.zeros_like(tot) for _ in range(world)]
-        dist.all_gather(allv, tot)
-        allv = torch.stack(allv).cpu().numpy()
-    else:
-        allv = tot.cpu().numpy()[None, :]
+    mine = np.array([float(leg.tot["evaluated"]), dt], dtype=np.float64)
+    allv = comm.allgather(mine) if comm is not None else mine[None, :]
     if rank == 0:
         ev_all = allv[:, 0].sum()
         t_max = allv[:, 1].max()
         value = ev_all / t_max
-        # roofline of the dominant kernel (rank 0's device): executed FP64 ops / HIP-event kernel time
-        k_ms = allv[0, 3]
-        f64, f32 = allv[0, 2], allv[0, 8]
-        ach = (f64 + f32) / (k_ms * 1e-3) / 1e12
-        # time-weighted peak of the mix: an FP64 op costs two packed-FP32 slots
-        peak = (f64 + f32) / (f64 / FP64_VECTOR_PEAK_TFLOPS + f32 / FP32_VECTOR_PEAK_TFLOPS) if f64 + f32 > 0 else FP32_VECTOR_PEAK_TFLOPS
-        launches = args.steps
-        # HBM bytes per launch of the search kernel from the rocprofv3 PMC passes committed under profiles/
-        # (FETCH_SIZE x2 per MI355X_MICROARCH.md's gfx950 correction, + WRITE_SIZE; both in KiB) -- not re-measured here
-        traffic = None
-        try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r1", "pmc_n3_search_kernel.json")))
-            traffic = (2.0 * pm["FETCH_SIZE"]["mean_per_launch"] + pm["WRITE_SIZE"]["mean_per_launch"]) * 1024.0
-        except Exception:
-            pass
+        legs = {"search": leg.summary(dt, "search", "f32+f64")}
         out = {
-            "metric": "candidate C-matrices evaluated/sec (whole node)",
+            "metric": "candidate C-matrices evaluated/sec (whole node): candidates SEARCHED/s by the shipped branch-and-bound "
+                      "(bound-pruned; full-solve rates in roofline.legs)",
             "value": value, "unit": "candidates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * t_max / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32+f64", "data": "synthetic",
             "config": {"workload": "synthetic m=50 intervals, n=3, k=6, full bounds [0,6]: rank-range search "
                                    "(BASELINE config 4 shape)", "m": M, "n": N_POP, "k": K_MAX,
                        "candidates_per_step_per_gpu": args.batch, "total_candidates_in_space": float(total),
-                       "parallelism": "rank-range sharding x%d, one RCCL exchange of finalists" % world},
-            "roofline": {"bound": "mfma", "bound_detail": "compute bound on the vector ALUs, not HBM bound by design (this kernel issues no "
-                                          "MFMA: no GEMM in the path).  Executed work is the packed-FP32 coarse Newton pass + FP32 screen "
-                                          "(157.3 TFLOP/s vector peak) and FP64 for contenders (78.6 TFLOP/s); `peak` is the "
-                                          "time-weighted peak of that mix",
-                         "achieved": ach, "peak": peak, "unit": "TFLOP/s",
-                         "frac": ach / peak, "traffic": traffic,
-                         "fp64_flop_share": f64 / max(f64 + f32, 1.0),
-                         "kernel": "n3_search_kernel<6,false>", "kernel_ms_per_launch": k_ms / launches,
-                         "flop_per_candidate": (f64 + f32) / max(allv[0, 0], 1.0),
-                         "newton_iters_per_candidate": allv[0, 5] / max(allv[0, 0], 1.0),
-                         "terms_per_iteration": allv[0, 4] / max(allv[0, 5], 1.0),
-                         "kernel_candidates_per_s": allv[0, 0] / (k_ms * 1e-3),
-                         # SURVEY.md 8(d)'s per-unit figure (a per-interval FP64 Newton solve: ~160 FP64 op per interval, 8.0
-                         # kFLOP per candidate at m=50) x the launch's candidates: what the same throughput would cost a kernel
-                         # that did that work -- the distance to `achieved` is what the algorithm saves (group tile, warm
-                         # start, one packed-FP32 evaluation, dismissal by a lower bound), not ALU efficiency
-                         "survey_flop_per_candidate": 160.0 * M,
-                         "survey_equivalent_tflops": 160.0 * M * allv[0, 0] / (k_ms * 1e-3) / 1e12,
-                         "note": "fused kernel: candidates are generated on chip, HBM bytes/candidate ~ 0 by design; "
-                                 "see DESIGN.md section 'Roofline'"},
-            "dismissed_fraction": allv[:, 9].sum() / max(ev_all, 1.0),      # finished by the lower bound of their optimum
-            "accepted_fraction_of_solved": allv[:, 6].sum() / max(ev_all - allv[:, 9].sum(), 1.0),
-            "setup_ms_per_step": allv[0, 7] / launches,
+                       "parallelism": "rank-range sharding x%d, one RCCL exchange of finalists (library-owned communicator)" % world},
         }
+        if comm is not None:
+            out["comm"] = comm.info()
+        if world == 1 and not args.no_legs:
+            # the same rank ranges with no candidate dismissed by its bound -- in the default arithmetic, then in FP64 throughout
+            for name, opts, dtype, k_leg, batch in (("full_solve_f32", {"n3_no_dismiss": 1}, "f32+f64", 3, args.batch),
+                                                    ("full_solve_f64", {"n3_no_dismiss": 1, "n3_force_f64": 1}, "f64", 3, max(args.batch >> 2, 1))):
+                for k, v in opts.items():
+                    problem.set_option(k, v)
+                lg = Leg(problem, begins[args.warmup:], batch, COLLECT_WINDOW)
+                lg.running = leg.running           # (chained to the job: starts from the minimum found so far)
+                lg.step(0, count=False)
+                ctx.synchronize()
+                t1 = time.time()
+                for i in range(min(k_leg, len(lg.begins))):
+                    lg.step(i)
+                ctx.synchronize()
+                legs[name] = lg.summary(time.time() - t1, name, dtype)
+                for k in opts:
+                    problem.set_option(k, 0)
+        s = legs["search"]
+        traffic, tnote = (None, "not measured (--no-traffic or N > 1)")
+        if world == 1 and not args.no_traffic:
+            traffic, tnote = measure_traffic(args)
+        out["roofline"] = {
+            "bound": "valu", "bound_detail": "vector-ALU (VALU issue) bound, not HBM and not MFMA: candidates are generated on chip "
+            "(~0 algorithmic HBM bytes) and the per-candidate C.mu is an (18 x 3).(3) product after group aggregation -- no GEMM. "
+            "`peak` is the packed-FP32 vector peak (157.3 TFLOP/s) weighted with the FP64 vector peak (78.6) by the executed mix",
+            "kernel": "n3_search_kernel<6,false>", "achieved": s["achieved"], "peak": s["peak"], "unit": "TFLOP/s", "frac": s["frac"],
+            "traffic": traffic, "traffic_note": tnote, "algorithmic_bytes_per_launch": 0,
+            "kernel_ms_per_launch": s["kernel_ms_per_launch"], "legs": legs,
+            "note": "`achieved` = FLOP executed by the likelihood arithmetic (counted in-kernel from the evaluations and terms "
+                    "actually run) / HIP-event kernel time; see DESIGN.md section 6"}
+        out["dismissed_fraction"] = s["dismissed_fraction"]
+        out["setup_ms_per_step"] = leg.setup_ms / max(leg.launches, 1)
         if world == 1 and not args.no_cpu_baseline:
             # bounded sample of the SAME candidates, materialised by the enumerate kernel, solved by the oracle on the host
             n_s = 96 * (os.cpu_count() or 1)
             per = max(1, n_s // nsteps)
-            cands = np.concatenate([problem.enumerate(shard0 + i * stride + stride // 2 + 12345, per) for i in range(nsteps)])
+            cands = np.concatenate([problem.enumerate(b + 12345, per) for b in begins])
             out["cpu_baseline"] = cpu_baseline(cands, r, rN, args.cpu_seconds)
             out["speedup_vs_cpu_all_cores"] = value / out["cpu_baseline"]["value"]
-            try:
-                out.update(extras(ctx, r, rN, args.cpu_seconds))
-            except Exception as ex:
-                out["extras_error"] = str(ex)
         else:
             out["cpu_baseline"] = None
+        if world == 1 and not args.no_extras:
+            try:
+                out.update(extras(ctx, args.cpu_seconds))
+                out["riders"] = {"config5_masked_scorer": config5_rider(ctx)}
+            except Exception as ex:
+                out["extras_error"] = str(ex)
         print(json.dumps(out))
-    if dist is not None:
-        dist.destroy_process_group()
+    if comm is not None:
+        comm.barrier()
+        comm.close()
 
 
 if __name__ == "__main__":

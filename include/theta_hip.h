@@ -24,6 +24,7 @@
 #ifndef THETA_HIP_H
 #define THETA_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -51,6 +52,8 @@ void theta_destroy(theta_ctx *ctx);
 const char *theta_last_error(void);
 /* name[cap] receives the device name; cu = compute units; hbm_bytes = total device memory.    */
 int theta_device_info(theta_ctx *ctx, char *name, int cap, int *cu, uint64_t *hbm_bytes);
+/* hipDeviceSynchronize on the context's GPU (every entry point below already returns with its work finished). */
+int theta_synchronize(theta_ctx *ctx);
 
 /* ---- search instance ---------------------------------------------------------------------- */
 /*
@@ -122,6 +125,29 @@ int theta_search(theta_problem *p, const uint64_t rank_begin[2], const uint64_t 
 int theta_search_suspects(theta_problem *p, int cap, uint64_t *rank, double *lbound, uint8_t *C, int *n_out);
 
 /*
+ * n=3 candidates of the last theta_search call with an ALL-ZERO TUMOUR COLUMN, in rank order (at most C(m + tau, tau) of
+ * them exist in a whole space: every row is (0, b) with b non-decreasing and b <= tau).  The fused kernel cannot value
+ * them -- the reference's arithmetic is NaN from normalize_C on (Optimizer.py:167-174) -- but the reference still REPORTS
+ * something for each: its fsolve returns the start unchanged, (1/3,1/3,1/3) passes inRange (Misc.py:49-57), M3's second
+ * fsolve call (Optimizer.py:318-330) lands on a unit vector plus rounding residue, and L3 turns that into a finite NLL or
+ * NaN -- which the driver appends to `best` either way (isClose(NaN), Misc.py:44-46).  Feed C to theta_solve_batch, which
+ * reproduces that outcome, and replay.  rank[cap*2], C[cap*m*2]; cap = -1 queries how many did not fit the device list.
+ */
+int theta_search_degenerate(theta_problem *p, int cap, uint64_t *rank, uint8_t *C, int *n_out);
+
+/*
+ * Run-time switches of a search instance (no reference counterpart).  name / value:
+ *   "n3_no_dismiss"  1: no candidate is finished by the lower bound of its optimum after one evaluation -- every one is
+ *                    iterated to the coarse tolerance and valued ("passed through the full solve")
+ *   "n3_force_f64"   1: every Newton iteration in FP64 (default: packed FP32 coarse pass, FP64 for contenders)
+ *   "n3_conv_l2"     coarse-pass threshold on the squared Newton decrement (default 1e-4)
+ *   "n3_warm_blend"  weight of the previous optimum in a chunk's first warm start
+ *   "n3_per_task"    candidates per wave task (0 = automatic), "n2_per_thread" candidates per thread (0 = automatic)
+ * The THETA_N3_* environment variables of the same names only set the defaults at theta_problem_create.
+ */
+int theta_problem_set_option(theta_problem *p, const char *name, double value);
+
+/*
  * One-shot hint for the next theta_search on this problem: an NLL some candidate is already known to reach (e.g. the
  * minimum of a previously searched rank range or shard).  Starting the running minimum there keeps the tie list and
  * the suspect list short; it never changes the result as long as the hint is attainable.
@@ -169,7 +195,9 @@ int theta_enumerate_device(theta_problem *p, const uint64_t rank_begin[2], uint6
  *              (behind scipy's fsolve, Optimizer.py:148) restated on the Lagrangian system in the reference's operation
  *              order; 1 = its iterate lies in [0,1]^3 and is reported, 2 = it does not, and the candidate is reported at
  *              nu = (1/3,1/3,1/3), where the reference's fmin_bfgs call -- handed an ascent direction,
- *              Optimizer.py:255-265 -- returns its start (Optimizer.py:155-160)
+ *              Optimizer.py:255-265 -- returns its start (Optimizer.py:155-160).  nu -> mu is Optimizer.M3 as the reference
+ *              runs it (a second fsolve call, MINPACK hybrd with forward differences, restated).  A candidate whose NLL
+ *              comes out NaN (an all-zero tumour column, mostly) keeps ok = 1 / 2: the reference returns that tuple too
  *   mu[B*n], nll[B]
  *   vals[B*m]  the per-interval p* (third element of the reference's tuple); may be NULL
  */
@@ -198,6 +226,42 @@ int theta_score_batch(theta_ctx *ctx, int n, int m, int B, const double *Cw, con
 int theta_score_masked(theta_ctx *ctx, int n, int m, int tau, int B, int S, const uint8_t *C,
                        const double *w, const double *r, const double *mu, const uint64_t *mask,
                        double *nll, double *kernel_ms);
+
+/* ---- several GPUs: the one communication step of a sharded search --------------------------------------- */
+/*
+ * Candidates shard by rank range, one process per GPU, no data-path collective.  What replaces the reference's merge of
+ * its workers' lists (find_mins, RunTHetA.py:107-122, after the multiprocessing fan-out of RunTHetA.py:124-171) is one
+ * exchange at the end: all-reduce(min) of the shard minima + all-gather of the finalists within the window -- over RCCL
+ * (xGMI between the GPUs of a node), owned by this library: no torch, no MPI.
+ *
+ * theta_comm_create: collective over all ranks.  Rank 0 listens on addr:port (TCP), the others connect; rank 0's
+ * ncclUniqueId travels over that connection, then every rank joins ncclCommInitRank on its context's GPU (librccl.so is
+ * loaded here, on first use).  transport THETA_COMM_HOST keeps the TCP star for the collectives as well (ctx may be
+ * NULL): for multi-process tests on machines without GPUs; the entry points and the merge are the same.
+ * All buffers below are HOST memory (the payload is a few hundred bytes; the library stages it through HBM for RCCL).
+ */
+typedef struct theta_comm theta_comm;
+enum { THETA_COMM_RCCL = 0, THETA_COMM_HOST = 1 };
+int theta_comm_create(theta_ctx *ctx, int rank, int world, const char *addr, int port, int transport, theta_comm **out);
+void theta_comm_destroy(theta_comm *c);
+/* rccl_version: ncclGetVersion() (0 for the host transport); collectives: number issued so far on this communicator */
+int theta_comm_info(theta_comm *c, int *rank, int *world, int *transport, int *rccl_version, uint64_t *collectives);
+int theta_comm_barrier(theta_comm *c);
+int theta_comm_allreduce_min(theta_comm *c, double *v, int count);   /* in place */
+int theta_comm_allreduce_max(theta_comm *c, double *v, int count);
+int theta_comm_allreduce_sum(theta_comm *c, double *v, int count);
+int theta_comm_allgather(theta_comm *c, const void *send, size_t bytes, void *recv);   /* recv[world * bytes], rank-major */
+/*
+ * The exchange: `count` finalists of this rank's shard in (nll[count], mu[count*n], rank[count*2], C[count*m*(n-1)],
+ * vals[count*m]) -- reference-order values from theta_solve_batch.  Every rank receives, in increasing rank order, the
+ * finalists of ALL shards within `window` of the global minimum, plus every record whose NLL is NaN (the reference's
+ * isClose counts NaN as close, Misc.py:44-46, so the replay needs them).  n_out = their number (or the capacity needed,
+ * with THETA_ERR_CAPACITY); global_min (may be NULL) = the smallest finite NLL over all shards.
+ */
+int theta_exchange_finalists(theta_comm *c, int n, int m, int count, const double *nll, const double *mu,
+                             const uint64_t *rank, const uint8_t *C, const double *vals, double window, int cap,
+                             double *o_nll, double *o_mu, uint64_t *o_rank, uint8_t *o_C, double *o_vals, int *n_out,
+                             double *global_min);
 
 #ifdef __cplusplus
 }

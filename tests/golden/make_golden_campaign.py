@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""
+`best` of the REFERENCE ITSELF (python/RunTHetA.py do_optimization_single, imported the way make_golden.py imports it:
+lib2to3 copy under /tmp, three shims) on seeded random instances of tests/campaign.py -- complete lists, including the
+entries with a NaN likelihood the reference appends through isClose(NaN) (Misc.py:44-46) for matrices with an all-zero tumour
+column.  Runs only in the build container (needs /root/reference).  Data only is written: tests/golden/best_campaign.json.
+
+    python tests/golden/make_golden_campaign.py
+"""
+import json
+import multiprocessing as mp
+import os
+import sys
+import time
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.join(REPO, "tests"))
+sys.path.insert(0, os.path.join(REPO, "oracle"))
+
+import numpy as np
+
+import campaign
+from make_golden import fl, import_reference
+
+WANT = {(2, "toy"): 30, (2, "mid"): 20, (3, "toy"): 40, (3, "mid"): 30}
+LIMIT = {2: (50, 40000), 3: (50, 15000)}
+
+
+def run(inst):
+    R = import_reference()
+    t = time.time()
+    try:
+        best = R.do_optimization_single(inst["n"], inst["m"], inst["k"], inst["tau"], list(inst["lb"]), list(inst["ub"]),
+                                        list(inst["r"]), list(inst["rN"]), inst["mx"], list(inst["order"]), True, False)
+    except SystemExit:
+        best = []
+    out = dict(inst)
+    out["best"] = [{"C": np.asarray(b[0]).tolist(), "mu": [fl(x) for x in b[1]], "nll": fl(b[2])} for b in best]
+    out["ref_seconds"] = time.time() - t
+    return out
+
+
+def main():
+    insts = []
+    for (n, shape), want in WANT.items():
+        seed, got = 5000, 0
+        while got < want:
+            seed += 1
+            inst = campaign.instance(seed, n, shape)
+            cnt = campaign.count_candidates(inst)
+            if not (LIMIT[n][0] <= cnt <= LIMIT[n][1]):
+                continue
+            inst["count"] = int(cnt)
+            insts.append(inst)
+            got += 1
+    insts.sort(key=lambda i: -i["count"] * (40 if i["n"] == 3 else 1))
+    with mp.get_context("fork").Pool(os.cpu_count() or 1) as pool:
+        res = pool.map(run, insts, chunksize=1)
+    res.sort(key=lambda i: (i["n"], i["shape"], i["seed"]))
+    with open(os.path.join(HERE, "best_campaign.json"), "w") as f:
+        json.dump({"cases": res}, f, separators=(",", ":"))
+    nan_entries = sum(1 for c in res for b in c["best"] if b["nll"] == "nan")
+    print("wrote best_campaign.json: %d instances, %d candidates, %d NaN entries in the best lists, %.0f s of reference time"
+          % (len(res), sum(c["count"] for c in res), nan_entries, sum(c["ref_seconds"] for c in res)))
+
+
+if __name__ == "__main__":
+    main()

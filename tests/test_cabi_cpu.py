@@ -29,11 +29,11 @@ def test_library_exports_every_declared_symbol():
 
 def test_error_string_and_no_cpu_fallback():
     lib = _lib.load()
-    import torch
-    if torch.cuda.is_available():
-        pytest.skip("GPU present: the no-device path cannot be exercised")
     h = ctypes.c_void_p()
     rc = lib.theta_create(0, ctypes.byref(h))
+    if rc == _lib.THETA_OK:
+        lib.theta_destroy(h)
+        pytest.skip("GPU present: the no-device path cannot be exercised")
     assert rc == _lib.ERR_HIP
     assert b"HIP device" in lib.theta_last_error() or b"hip" in lib.theta_last_error().lower()
     with pytest.raises(theta_amd.ThetaError):
@@ -69,3 +69,27 @@ def test_host_tie_replay_semantics():
     a = [(None, None, 5.0, None)]
     b = [(None, None, 5.0004, None), (None, None, 5.0, None)]
     assert find_mins([list(a), [], list(b)]) == a + b
+
+
+def test_no_torch_in_the_product_path():
+    """north_star: host code is Python + numpy over ctypes, no PyTorch -- neither theta_amd nor bench.py imports it."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r); import theta_amd, theta_amd.search, theta_amd.RunTHetA, theta_amd.CalcAllC; "
+            "import importlib.util as u; s = u.spec_from_file_location('bench', %r); m = u.module_from_spec(s); s.loader.exec_module(m); "
+            "print('torch' in sys.modules)" % (ROOT, os.path.join(ROOT, "bench.py")))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    assert out.stdout.strip() == "False"
+
+
+def test_comm_argument_checks_without_a_gpu():
+    lib = _lib.load()
+    h = ctypes.c_void_p()
+    assert lib.theta_comm_create(None, 0, 1, b"127.0.0.1", 0, 0, ctypes.byref(h)) == _lib.ERR_ARG      # RCCL needs a context
+    assert lib.theta_comm_create(None, 2, 2, b"127.0.0.1", 1234, 1, ctypes.byref(h)) == _lib.ERR_ARG   # rank out of range
+    assert lib.theta_comm_create(None, 0, 1, b"127.0.0.1", 0, 1, ctypes.byref(h)) == _lib.THETA_OK     # a world of one, host transport
+    c = theta_amd.Comm.__new__(theta_amd.Comm)
+    c._h, c.world, c.rank = h, 1, 0
+    assert c.allreduce_min([4.0]).tolist() == [4.0] and c.info()["transport"] == "host"
+    c.close()

@@ -1,18 +1,17 @@
 """
-The N>1 path on CPU: two processes over gloo exercise the ONE exchange step of a sharded search
-(all-reduce(min) + all-gather of finalists, theta_amd.search.exchange_finalists) and the tie replay
-on the merged list.  The per-shard finalists are synthetic here (no GPU in this container); on the
-GPU box the same function runs over RCCL.
+The N>1 path on CPU: two (and three) processes call the library's OWN exchange -- theta_comm_create +
+theta_exchange_finalists (theta_amd/csrc/comm.hip, the C entry points a sharded search uses) -- over its host transport
+(the TCP star that also bootstraps RCCL), then replay the tie rule on the merged list.  The per-shard finalists are
+synthetic here (no GPU in this container); on the GPU box the same entry points run over RCCL (tests/test_gpu_comm.py).
+No torch anywhere in this path.
 """
+import multiprocessing as mp
 import os
 import socket
 import sys
 
 import numpy as np
 import pytest
-import torch
-import torch.distributed as dist
-import torch.multiprocessing as mp
 
 from conftest import ROOT
 
@@ -30,7 +29,7 @@ def _shard_records(rank, n, m):
     rng = np.random.RandomState(100 + rank)
     recs = []
     base = (1 << 70) * (rank + 1)
-    nlls = [5000.0 + 0.0004 * rank, 5000.2, 5003.0 + rank] if rank == 0 else [5000.0003, 4999.9998, 5000.45]
+    nlls = {0: [5000.0 + 0.0004 * rank, 5000.2, 5003.0 + rank], 1: [5000.0003, 4999.9998, 5000.45]}.get(rank, [6000.0, float("nan")])
     for j, v in enumerate(nlls):
         c = rng.randint(0, 5, (m, 2) if n == 3 else (m,)).astype(np.uint8)
         recs.append({"rank": base + 17 * j + rank, "c": c, "mu": rng.dirichlet(np.ones(n)), "nll": v,
@@ -38,29 +37,61 @@ def _shard_records(rank, n, m):
     return recs
 
 
-def _worker(rank, world, port, n, m, out):
-    sys.path.insert(0, ROOT)
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    from theta_amd.search import exchange_finalists, replay_ties
-    merged = exchange_finalists(_shard_records(rank, n, m), n, m, torch.device("cpu"))
-    best = replay_ties(merged, n, 2, list(range(m)), first_duplicate=False)
-    out[rank] = ([(t["rank"], t["nll"], t["c"].tolist(), t["mu"].tolist(), t["vals"].tolist()) for t in merged],
-                 [(b[2], b[0].tolist()) for b in best])
-    dist.destroy_process_group()
+def _worker(rank, world, port, n, m, q):
+    try:
+        sys.path.insert(0, ROOT)
+        import theta_amd
+        from theta_amd.search import replay_ties
+        comm = theta_amd.Comm(None, rank=rank, world=world, addr="127.0.0.1", port=port, transport="host")
+        assert comm.info()["transport"] == "host" and comm.info()["world"] == world
+        # the small collectives the drivers use
+        assert comm.allreduce_min([3.0 + rank, -rank])[1] == -(world - 1)
+        assert comm.allreduce_sum([1.0])[0] == world
+        g = comm.allgather(np.array([rank, 10 * rank], np.int64))
+        assert g.tolist() == [[k, 10 * k] for k in range(world)]
+        comm.barrier()
+        merged, gmin = comm.exchange_finalists(n, m, _shard_records(rank, n, m), 0.5)
+        best = replay_ties(merged, n, 2, list(range(m)), first_duplicate=False)
+        # an exchange in which NO rank has anything
+        empty, gmin0 = comm.exchange_finalists(n, m, [], 0.5)
+        assert empty == [] and gmin0 == float("inf")
+        ncoll = comm.info()["collectives"]
+        comm.close()
+        q.put((rank, [(t["rank"], t["nll"], t["c"].tolist(), t["mu"].tolist(), t["vals"].tolist()) for t in merged],
+               [(b[2], b[0].tolist()) for b in best], gmin, ncoll))
+    except Exception as e:      # a failed rank must not leave the parent waiting for ever
+        q.put((rank, "error: %r" % (e,), None, None, None))
+
+
+def _run(world, n, m):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, m, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = {}
+    for _ in range(world):
+        item = q.get(timeout=120)
+        out[item[0]] = item[1:]
+    for p in procs:
+        p.join(30)
+    return out
+
+
+def _same(a, b):
+    return a == b or (a != a and b != b)
 
 
 @pytest.mark.parametrize("n,m", [(3, 7), (2, 5)])
 def test_exchange_and_replay_two_ranks(n, m):
     world = 2
-    mgr = mp.Manager()
-    out = mgr.dict()
-    port = _free_port()
-    mp.spawn(_worker, args=(world, port, n, m, out), nprocs=world, join=True)
+    out = _run(world, n, m)
     assert set(out.keys()) == {0, 1}
-    assert out[0] == out[1]                                    # every rank ends with the same answer
-    merged, best = out[0]
+    assert not isinstance(out[0][0], str) and not isinstance(out[1][0], str), (out[0][0], out[1][0])
+    assert out[0][:3] == out[1][:3]                            # every rank ends with the same answer
+    merged, best, gmin, ncoll = out[0]
+    assert gmin == 4999.9998
     # expected: everything within the collection window of the global minimum (4999.9998), from both shards
     want = []
     for rk in range(world):
@@ -75,3 +106,22 @@ def test_exchange_and_replay_two_ranks(n, m):
     # sequential tie rule in rank order: shard 0's 5000.0 comes first, 5000.2 is dropped by the gap cut,
     # shard 1's 5000.0003 and 4999.9998 are within 1e-3 of the running minimum and are appended
     assert [b[0] for b in best] == [5000.0, 5000.0003, 4999.9998]
+
+
+def test_exchange_three_ranks_keeps_nan_records():
+    """A shard whose finalists are all beyond the window still contributes its NaN-likelihood record (isClose(NaN))."""
+    n, m, world = 3, 6, 3
+    out = _run(world, n, m)
+    assert set(out.keys()) == {0, 1, 2}
+    for r in range(world):
+        assert not isinstance(out[r][0], str), out[r][0]
+    m0, b0 = out[0][0], out[0][1]
+    for r in (1, 2):
+        assert len(out[r][0]) == len(m0)
+        for x, y in zip(out[r][0], m0):
+            assert x[0] == y[0] and _same(x[1], y[1])
+    assert len(m0) == 6 and sum(1 for t in m0 if t[1] != t[1]) == 1
+    assert m0[-1][1] != m0[-1][1]                              # rank order: shard 2's records come last
+    # the replay appends the NaN record to the list it finds (RunTHetA.py:198-201 with Misc.py:44-46)
+    nl = [b[0] for b in b0]
+    assert nl[:3] == [5000.0, 5000.0003, 4999.9998] and len(nl) == 4 and nl[3] != nl[3]

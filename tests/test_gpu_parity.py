@@ -185,26 +185,33 @@ def test_n3_fused_values_m6k3_all_candidates(ctx):
     nll, mu, st = p.values(0, p.count)
     assert st["evaluated"] == 21050
     _check_n3_table(got.astype(float), nll, mu, g["accepted"].astype(bool), g["mu"], g["nll"])
-    # the batch solver (per-interval sums) agrees with the fused kernel (group sums)
-    # theta_solve_batch decides like the reference: MINPACK's hybrj restated (hybrj4.hpp) on the Lagrangian system in the
-    # reference's operation order; its iterate in [0,1]^3 -> the candidate's own optimum, otherwise the nu = (1/3,1/3,1/3)
-    # fallback.  Against the reference's own table, entry by entry: the class (own optimum / fallback) of all 16 286 + 4 467
-    # such entries but one is reproduced (tools/hybrj_check.py), the values of 16 270 + 4 466 to 1e-9 (mu 1e-6 on full-rank
-    # candidates), and so are the 284 `None`s of a BFGS line search that walked out of the domain (n3_refbfgs.hpp); the 13 NaN
-    # entries (all-zero tumour columns) are not emitted.
+    # theta_solve_batch IS the reference's decision procedure: MINPACK's hybrj restated (hybrj4.hpp) on the Lagrangian system in
+    # the reference's operation order; its iterate in [0,1]^3 -> the candidate's own optimum, otherwise the nu = (1/3,1/3,1/3)
+    # fallback or None (the BFGS line search restated, n3_refbfgs.hpp); nu -> mu by M3's own fsolve call (MINPACK hybrd
+    # restated), which also decides what the 28 matrices with an all-zero tumour column come out as (finite or NaN).
+    # EVERY one of the 21 050 entries of the reference's table is held to the bar, entry by entry -- no allowances:
     ok, mu_b, nll_b, _ = ctx.solve_batch(3, 2, g["r"], g["rN"], got, 1.0)
     fb = ctx.last_solve_fallback
-    acc = g["accepted"].astype(bool) & np.isfinite(g["nll"])
+    ref_rep = g["accepted"].astype(bool)                            # the reference returned a tuple (not None)
+    ref_nll, ref_mu = g["nll"], g["mu"]
+    exceptions = []                                                 # (rank, reason): must stay empty
+    for k in np.nonzero(ok != ref_rep)[0]:
+        exceptions.append((int(k), "outcome class: reported %d here, %d in the reference" % (ok[k], ref_rep[k])))
+    both = ok & ref_rep
     with np.errstate(invalid="ignore"):
-        same = ok & acc & (np.abs(nll_b - g["nll"]) <= 1e-9 * np.abs(g["nll"]))
-        same_mu = np.abs(mu_b - g["mu"]).max(axis=1) < 1e-6
-    assert (same & ~fb).sum() >= 16260 and (same & fb).sum() >= 4460, ((same & ~fb).sum(), (same & fb).sum())   # 16 270, 4 466
-    assert (acc & ~same).sum() <= 30                            # (17: own-optimum entries whose value differs beyond 1e-9)
-    full_rank = np.array([np.linalg.matrix_rank(np.column_stack([np.ones(m), c[:, 0], c[:, 1]])) == 3 for c in got.astype(float)])
-    assert (same & full_rank & ~same_mu).sum() <= 25            # (mu of near-singular candidates is ill-conditioned)
-    assert (ok & ~g["accepted"].astype(bool)).sum() <= 3        # the reference's `None`s (a BFGS that left its start) are None here too
-    assert (~ok & acc).sum() <= 18       # (15: matrices with an all-zero tumour column, whose Chat is NaN in the reference -- its
-    #                                      fsolve returns the start unchanged and M3 / L3 still produce a number; not emitted here)
+        for k in np.nonzero(both & (np.isnan(nll_b) != np.isnan(ref_nll)))[0]:
+            exceptions.append((int(k), "NaN likelihood on one side only"))
+        fin = both & ~np.isnan(nll_b) & ~np.isnan(ref_nll)
+        rel = np.abs(nll_b - ref_nll) / np.abs(ref_nll)
+        for k in np.nonzero(fin & ~(rel <= 1e-9))[0]:               # (the bar is 1e-6; the restatement holds 1e-9)
+            exceptions.append((int(k), "NLL %r vs %r" % (nll_b[k], ref_nll[k])))
+        dmu = np.abs(mu_b - ref_mu).max(axis=1)
+        for k in np.nonzero(fin & ~(dmu < REL))[0]:                 # every entry, rank-deficient and all-zero columns included
+            exceptions.append((int(k), "mu %r vs %r" % (mu_b[k].tolist(), ref_mu[k].tolist())))
+    assert not exceptions, exceptions[:20]
+    zero_col = (got[:, :, 0].sum(axis=1) == 0) | (got[:, :, 1].sum(axis=1) == 0)
+    assert zero_col.sum() == 28 and ok[zero_col].all() and np.isnan(nll_b[zero_col]).sum() == 13     # 15 finite, 13 NaN
+    assert (ok & ~fb).sum() == 16300 and (ok & fb).sum() == 4466 and (~ok).sum() == 284      # own iterate / fallback / None
     # the fused kernel's dump reports the optimum of every candidate whose minimum lies in the simplex; where the batch
     # solver reports an own optimum too, the two agree to rounding (group sums against per-interval sums)
     fused_ok = ~np.isnan(nll)
@@ -218,31 +225,14 @@ def test_n3_fused_values_m6k3_all_candidates(ctx):
 # the driver: `best` against the reference's do_optimization_single
 # ---------------------------------------------------------------------------------------------------
 def _compare_best(best, ref_best, n, saturated=False):
-    ref = [b for b in ref_best if not (isinstance(b["nll"], str))]     # NaN entries: see search.py docstring
-    if saturated:
-        # m <= 5 with n = 3: the model is saturated, dozens of matrices fit the data exactly and tie at the
-        # same NLL.  The reference's fsolve/BFGS fails on a few of them (trajectory-dependent, SURVEY.md
-        # section 7), so its tie list is a sub-sequence of the GPU's, which holds every true tie.
-        it = iter(best)
-        picked = []
-        for rb in ref:
-            for b in it:
-                if np.array_equal(b[0], np.array(rb["C"])):
-                    picked.append(b)
-                    break
-        assert len(picked) == len(ref), "reference tie list is not a sub-sequence of the GPU tie list"
-        assert max(abs(b[2] - ref[0]["nll"]) for b in best) < 1e-3
-        best = picked
-    assert len(best) == len(ref), ([b[2] for b in best], [b["nll"] for b in ref])
-    for b, rb in zip(best, ref):
-        assert np.array_equal(b[0], np.array(rb["C"]))                 # chosen C: bit-exact, original order
-        assert _rel(b[2], rb["nll"]) < REL
-        Cm = np.array(rb["C"])
-        full_rank = n == 2 or np.linalg.matrix_rank(np.column_stack([np.ones(len(Cm)), Cm[:, 1], Cm[:, 2]])) == 3
-        if full_rank and len(Cm) > 6:
-            for a, c in zip(b[1], rb["mu"]):
-                assert abs(a - unfl(c)) < REL
-            assert np.allclose(b[3], [unfl(v) for v in rb["vals"]], rtol=1e-6)
+    """COMPLETE lists, entry by entry, NaN entries (isClose(NaN), Misc.py:44-46) included; tests/campaign.py: compare_best."""
+    import campaign
+    ref = [(b["C"], [unfl(x) for x in b["mu"]], unfl(b["nll"])) for b in ref_best]
+    why = campaign.compare_best(campaign.best_to_plain(best), ref)
+    assert why == "", (why, [b[2] for b in best], [b[2] for b in ref])
+    for b, rb in zip(best, ref_best):
+        if "vals" in rb and not isinstance(rb["nll"], str):
+            assert np.allclose(b[3], [unfl(v) for v in rb["vals"]], rtol=1e-6, equal_nan=True)
 
 
 def test_best_matches_reference_on_synthetic_inputs(ctx):

@@ -79,3 +79,49 @@ def test_reference_outcome_class_of_every_table_entry():
             wrong += o != ref[k]
     assert counts[0] == 284 and counts[2] >= 4460 and counts[1] >= 16280
     assert wrong <= 2          # (one entry whose optimum IS the centre of the simplex carries the fallback value either way)
+
+
+def test_restated_procedure_reproduces_every_entry_of_the_reference_table():
+    """n3_ref_solve -- the function theta_solve_batch's device kernel calls: hybrj, the BFGS decision, M3's hybrd call, L3's sums
+    -- compiled for the host, against ALL 21 050 entries of the reference's own table: outcome class, NaN-ness, NLL and mu."""
+    import hybrj_check as hc
+    g = np.load(os.path.join(GOLD, "solve_n3_m6k3.npz"))
+    ok, mu, nll = hc.solve_table(g["C"], g["r"], g["rN"])
+    acc = g["accepted"].astype(bool)
+    assert np.array_equal(ok > 0, acc)                                   # reported vs None: all 21 050
+    assert (ok == 0).sum() == 284
+    assert np.array_equal(np.isnan(nll[acc]), np.isnan(g["nll"][acc])) and np.isnan(g["nll"][acc]).sum() == 13
+    fin = acc & ~np.isnan(g["nll"])
+    assert (np.abs(nll[fin] - g["nll"][fin]) <= 1e-12 * np.abs(g["nll"][fin])).all()
+    assert np.abs(mu[fin] - g["mu"][fin]).max() < 1e-12                  # every entry: rank-deficient matrices and all-zero columns too
+    # the 28 matrices with an all-zero tumour column: mu is a unit vector plus hybrd's rounding residue, reproduced to the bit
+    z = (g["C"][:, :, 0].sum(axis=1) == 0) | (g["C"][:, :, 1].sum(axis=1) == 0)
+    assert z.sum() == 28 and np.array_equal(mu[z], g["mu"][z])
+
+
+def test_m3_restatement_follows_scipy_fsolve_without_jacobian():
+    """Optimizer.M3 = fsolve(M_eq, [.33,.33,.33,0]) (MINPACK hybrd, forward-difference Jacobian) on random column sums and
+    mixtures, regular and with a zero column: identical to the last bit."""
+    import warnings
+
+    import hybrj_check as hc
+    import theta_oracle as orc
+    rng = np.random.RandomState(3)
+    same = 0
+    for t in range(200):
+        m = int(rng.randint(4, 30))
+        Cm = np.zeros((m, 3))
+        Cm[:, 0] = 2
+        Cm[:, 1:] = rng.randint(0, 5, (m, 2))
+        if t % 4 == 0:
+            Cm[:, 1 + (t // 4) % 2] = 0
+        rN = rng.randint(100, 100000, m).astype(float)
+        Cw = orc.weighted_C(Cm, rN)
+        S = [sum([Cw[i][h] for i in range(m)]) for h in range(3)]
+        nu = rng.dirichlet(np.ones(3)) if t % 3 else np.array([1 / 3.0] * 3)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            ref = orc.map_M3(Cw, list(nu), m, 3)
+        got = hc.m3(S, nu)[0]
+        same += np.array_equal(got, ref) or (np.isnan(got) == np.isnan(ref)).all() and np.array_equal(got[~np.isnan(got)], ref[~np.isnan(ref)])
+    assert same == 200

@@ -132,3 +132,22 @@ def test_best_matches_reference_driver():
             assert _close(b[2], ref["nll"])
             for a, c in zip(b[3], ref["vals"]):
                 assert _close(a, c)
+
+
+def test_oracle_driver_matches_reference_best_lists_on_campaign_fixtures():
+    """tests/golden/best_campaign.json holds `best` of the REFERENCE's do_optimization_single on seeded random instances --
+    complete lists, NaN entries included.  The oracle's port of the driver reproduces them (the smaller instances here; the
+    -m gpu suite runs the HIP path against all of them)."""
+    import warnings
+
+    import campaign
+    cases = [c for c in load_json("best_campaign.json")["cases"] if c["count"] <= (600 if c["n"] == 3 else 6000)]
+    assert len(cases) >= 25
+    n_nan = 0
+    for c in cases:
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            best, cnt = orc.search_single(c["n"], c["m"], c["tau"], list(c["lb"]), list(c["ub"]), c["r"], c["rN"], c["mx"], c["order"])
+        ref = [(b["C"], [unfl(x) for x in b["mu"]], unfl(b["nll"])) for b in c["best"]]
+        n_nan += sum(1 for b in ref if b[2] != b[2])
+        assert campaign.compare_best(campaign.best_to_plain(best), ref, tol=1e-9) == "", (c["n"], c["shape"], c["seed"])

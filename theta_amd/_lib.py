@@ -44,7 +44,10 @@ _lib = None
 # every symbol include/theta_hip.h declares
 EXPORTS = ["theta_create", "theta_destroy", "theta_last_error", "theta_device_info", "theta_problem_create",
            "theta_problem_destroy", "theta_problem_count", "theta_search", "theta_search_values", "theta_enumerate", "theta_enumerate_device",
-           "theta_solve_batch", "theta_score_batch", "theta_score_masked", "theta_search_suspects", "theta_boundary_min", "theta_problem_hint"]
+           "theta_solve_batch", "theta_score_batch", "theta_score_masked", "theta_search_suspects", "theta_boundary_min", "theta_problem_hint",
+           "theta_search_degenerate", "theta_problem_set_option", "theta_synchronize",
+           "theta_comm_create", "theta_comm_destroy", "theta_comm_info", "theta_comm_barrier", "theta_comm_allreduce_min",
+           "theta_comm_allreduce_max", "theta_comm_allreduce_sum", "theta_comm_allgather", "theta_exchange_finalists"]
 
 
 def load():
@@ -74,6 +77,20 @@ def load():
     lib.theta_search_suspects.argtypes = [vp, i32, u64p, dp, u8p, C.POINTER(i32)]
     lib.theta_boundary_min.argtypes = [vp, i32, i32, i64p, i64p, i32, u8p, dp]
     lib.theta_problem_hint.argtypes = [vp, C.c_double]
+    lib.theta_synchronize.argtypes = [vp]
+    lib.theta_search_degenerate.argtypes = [vp, i32, u64p, u8p, C.POINTER(i32)]
+    lib.theta_problem_set_option.argtypes = [vp, C.c_char_p, C.c_double]
+    lib.theta_comm_create.argtypes = [vp, i32, i32, C.c_char_p, i32, i32, C.POINTER(vp)]
+    lib.theta_comm_destroy.argtypes = [vp]
+    lib.theta_comm_destroy.restype = None
+    lib.theta_comm_info.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), u64p]
+    lib.theta_comm_barrier.argtypes = [vp]
+    lib.theta_comm_allreduce_min.argtypes = [vp, dp, i32]
+    lib.theta_comm_allreduce_max.argtypes = [vp, dp, i32]
+    lib.theta_comm_allreduce_sum.argtypes = [vp, dp, i32]
+    lib.theta_comm_allgather.argtypes = [vp, vp, C.c_size_t, vp]
+    lib.theta_exchange_finalists.argtypes = [vp, i32, i32, i32, dp, dp, u64p, u8p, dp, C.c_double, i32, dp, dp, u64p, u8p, dp,
+                                             C.POINTER(i32), dp]
     lib.theta_solve_batch.argtypes = [vp, i32, i32, i32, i64p, i64p, C.c_double, i32, u8p, u8p, dp, dp, dp]
     lib.theta_score_batch.argtypes = [vp, i32, i32, i32, dp, dp, dp, dp, dp, u8p]
     lib.theta_score_masked.argtypes = [vp, i32, i32, i32, i32, i32, u8p, dp, dp, dp, u64p, dp, dp]
@@ -123,6 +140,9 @@ class Context:
             self.close()
         except Exception:
             pass
+
+    def synchronize(self):
+        _check(load().theta_synchronize(self._h))
 
     # -- materialised operators ---------------------------------------------------------------
     def solve_batch(self, n, tau, r, rN, C_u8, max_normal=1.0, want_vals=True):
@@ -217,7 +237,9 @@ class Problem:
         _check(load().theta_problem_count(h, cnt))
         self.count = int(cnt[0]) | (int(cnt[1]) << 64)
         self.last_suspects = ([], np.zeros(0), None)
+        self.last_degenerate = ([], None)
         self.suspects_dropped = 0
+        self.suspect_reruns = 0
 
     def close(self):
         if getattr(self, "_h", None):
@@ -236,35 +258,61 @@ class Problem:
     # one theta_search call takes at most this many candidates (n=3: 2^18 wave tasks of 2^13 candidates)
     MAX_PER_CALL = {2: 1 << 40, 3: 1 << 31}
 
+    def set_option(self, name, value):
+        """theta_problem_set_option: "n3_no_dismiss", "n3_force_f64", "n3_conv_l2", "n3_per_task", ..."""
+        _check(load().theta_problem_set_option(self._h, name.encode(), float(value)))
+
+    def _piece(self, b, e, window, cap, hint):
+        """One theta_search call with its side lists: (result, suspects, suspects_dropped, degenerate)."""
+        if hint < float("inf"):
+            _check(load().theta_problem_hint(self._h, hint))
+        res = self._search_once(b, e, window, cap)
+        if res["stats"]["list_overflow"]:
+            # the device tie list stayed full after the library's three passes: finalists were lost
+            raise ThetaError(ERR_CAPACITY, "%d finalists dropped by the device tie list in ranks [%d, %d): narrow the "
+                             "window or split the range" % (res["stats"]["list_overflow"], b, e))
+        if self.n != 3:
+            return res, ([], np.zeros(0), None), 0, ([], None)
+        sus = self.suspects()
+        return res, sus, self.suspects_dropped, self.degenerate()
+
     def search(self, begin=0, end=None, window=0.5, cap=4096):
         """
         Fused search over ranks [begin, end).  Returns dict(nll, mu, rank (python ints), C, stats).
         Ranges larger than one call can take are walked in pieces; the pieces' finalists are merged here
         (same rule as across GPUs: keep what lies within `window` of the overall minimum).
+
+        n=3 side lists of the whole range end up in self.last_suspects (rejected candidates whose lower bound is within the
+        window: the reference reports them at its nu = 1/3 fallback) and self.last_degenerate (all-zero tumour columns).
+        A piece whose device suspect list overflowed is searched AGAIN with the minimum of the whole range as its hint
+        (a piece whose own minimum is poor lists far too many); if it still overflows the call raises -- it never returns
+        an incomplete list.
         """
         end = self.count if end is None else end
         step = self.MAX_PER_CALL[self.n]
         running = self._probe(begin, end)
-        if end - begin <= step:
-            if running < float("inf"):
-                self.hint(running)
-            res = self._search_once(begin, end, window, cap)
-            self.last_suspects = self.suspects() if self.n == 3 else ([], np.zeros(0), None)
-            return res
-        parts, sus = [], ([], [], [])
-        for b in range(begin, end, step):
-            if running < float("inf"):
-                self.hint(running)               # later pieces start from the minimum found so far
-            parts.append(self._search_once(b, min(b + step, end), window, cap))
-            if len(parts[-1]["nll"]):
-                running = min(running, float(parts[-1]["nll"].min()))
-            if self.n == 3:
-                rk, lb, Cs = self.suspects()
-                sus[0].extend(rk)
-                sus[1].extend(lb.tolist())
-                sus[2].extend(list(Cs))
-        stats = dict(parts[0]["stats"])
-        for p in parts[1:]:
+        bounds = [(b, min(b + step, end)) for b in range(begin, end, step)]
+        parts, hints = [], []
+        for b, e in bounds:
+            hints.append(running)
+            parts.append(self._piece(b, e, window, cap, running))     # later pieces start from the minimum found so far
+            nl = parts[-1][0]["nll"]
+            if len(nl):
+                running = min(running, float(nl.min()))
+        self.suspect_reruns = 0
+        for i, (b, e) in enumerate(bounds):
+            if parts[i][2] > 0:
+                if not running < hints[i]:
+                    raise ThetaError(ERR_CAPACITY, "n=3 suspect list overflowed in ranks [%d, %d) (%d entries dropped) although "
+                                     "the search started from the range's own minimum" % (b, e, parts[i][2]))
+                parts[i] = self._piece(b, e, window, cap, running)
+                self.suspect_reruns += 1
+                if parts[i][2] > 0:
+                    raise ThetaError(ERR_CAPACITY, "n=3 suspect list overflowed in ranks [%d, %d) (%d entries dropped) with "
+                                     "the minimum of the whole range as hint" % (b, e, parts[i][2]))
+        self.suspects_dropped = 0
+        stats = dict(parts[0][0]["stats"])
+        for p, _s, _d, _g in parts[1:]:
             for k, v in p["stats"].items():
                 if k in ("evaluated", "accepted", "degenerate", "iterations", "terms", "list_overflow", "flops", "flops_f32", "dismissed"):
                     stats[k] += v
@@ -276,15 +324,23 @@ class Problem:
                     stats[k] = min(stats[k], v)
                 elif k == "rejected_bound" and v < stats[k]:
                     stats[k], stats["rejected_rank"] = v, p["stats"]["rejected_rank"]
-        nll = np.concatenate([p["nll"] for p in parts])
-        gmin = nll.min() if len(nll) else float("inf")
-        ks = [i for i, v in enumerate(sus[1]) if v <= gmin + window]
-        self.last_suspects = ([sus[0][i] for i in ks], np.array([sus[1][i] for i in ks]),
-                              np.array([sus[2][i] for i in ks], dtype=np.uint8).reshape(len(ks), self.m, 2) if self.n == 3 else None)
-        keep = nll <= (nll.min() if len(nll) else 0.0) + window
-        mu = np.concatenate([p["mu"] for p in parts])[keep]
-        Cc = np.concatenate([p["C"] for p in parts])[keep]
-        ranks = [r for p in parts for r in p["rank"]]
+        nll = np.concatenate([p[0]["nll"] for p in parts])
+        gmin = float(nll.min()) if len(nll) else float("inf")
+        if self.n == 3:
+            srk = [r for p in parts for r in p[1][0]]
+            slb = np.concatenate([p[1][1] for p in parts]) if parts else np.zeros(0)
+            sC = np.concatenate([p[1][2].reshape(-1, self.m, 2) for p in parts])
+            ks = np.nonzero(slb <= gmin + window)[0] if len(slb) else np.zeros(0, np.int64)
+            self.last_suspects = ([srk[i] for i in ks], slb[ks], sC[ks])
+            self.last_degenerate = ([r for p in parts for r in p[3][0]],
+                                    np.concatenate([p[3][1].reshape(-1, self.m, 2) for p in parts]))
+        else:
+            self.last_suspects = ([], np.zeros(0), None)
+            self.last_degenerate = ([], None)
+        keep = nll <= gmin + window if len(nll) else np.zeros(0, bool)
+        mu = np.concatenate([p[0]["mu"] for p in parts])[keep]
+        Cc = np.concatenate([p[0]["C"] for p in parts])[keep]
+        ranks = [r for p in parts for r in p[0]["rank"]]
         ranks = [r for r, k in zip(ranks, keep) if k]
         return {"nll": nll[keep], "mu": mu, "rank": ranks, "C": Cc, "stats": stats}
 
@@ -354,6 +410,21 @@ class Problem:
                                             C.byref(n_out)))
         return [int(rank[i, 0]) | (int(rank[i, 1]) << 64) for i in range(k)], lb, self._shape_C(Cb, k)
 
+    def degenerate(self):
+        """n=3 candidates of the last theta_search with an all-zero tumour column: (ranks, C)."""
+        n_out = C.c_int()
+        load().theta_search_degenerate(self._h, -1, None, None, C.byref(n_out))
+        if n_out.value:
+            raise ThetaError(ERR_CAPACITY, "%d degenerate candidates did not fit the device list" % n_out.value)
+        load().theta_search_degenerate(self._h, 0, None, None, C.byref(n_out))
+        k = n_out.value
+        if k == 0:
+            return [], self._shape_C(np.zeros(0, np.uint8), 0)
+        rank = np.zeros((k, 2), np.uint64)
+        Cb = np.zeros(k * self.m * (self.n - 1), np.uint8)
+        _check(load().theta_search_degenerate(self._h, k, _p(rank, C.c_uint64), _p(Cb, C.c_uint8), C.byref(n_out)))
+        return [int(rank[i, 0]) | (int(rank[i, 1]) << 64) for i in range(k)], self._shape_C(Cb, k)
+
     def values(self, begin, count):
         """Per-candidate (nll, mu) of the fused kernel (NaN = None): the --GET_VALUES dump."""
         nll = np.zeros(count)
@@ -375,3 +446,103 @@ class Problem:
         ms = C.c_double(0.0)
         _check(load().theta_enumerate_device(self._h, _u128(begin), int(count), C.c_void_p(int(device_ptr)), C.byref(ms)))
         return ms.value
+
+
+class Comm:
+    """
+    The library's communicator for a sharded search (theta_comm_create): one process per GPU, RCCL over xGMI -- or, with
+    transport="host", the library's TCP star (multi-process tests on machines without GPUs).  No torch anywhere.
+    Rendezvous: rank 0 listens on addr:port.  Under `python -m torch.distributed.run` / torchrun the launcher's own store
+    occupies MASTER_PORT, so the default port is MASTER_PORT + 1 (override with THETA_COMM_PORT).
+    """
+    RCCL, HOST = 0, 1
+
+    def __init__(self, ctx=None, rank=None, world=None, addr=None, port=None, transport="rccl"):
+        lib = load()
+        rank = int(os.environ.get("RANK", "0")) if rank is None else int(rank)
+        world = int(os.environ.get("WORLD_SIZE", "1")) if world is None else int(world)
+        addr = addr or os.environ.get("MASTER_ADDR", "127.0.0.1")
+        if port is None:
+            port = int(os.environ.get("THETA_COMM_PORT", 0)) or int(os.environ.get("MASTER_PORT", "29400")) + 1
+        tr = self.HOST if transport == "host" else self.RCCL
+        h = C.c_void_p()
+        _check(lib.theta_comm_create(ctx._h if ctx is not None else None, rank, world, addr.encode(), int(port), tr, C.byref(h)))
+        self._h, self.ctx, self.rank, self.world, self.transport = h, ctx, rank, world, transport
+
+    def close(self):
+        if getattr(self, "_h", None):
+            load().theta_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def info(self):
+        r, w, t, v = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        n = C.c_uint64()
+        _check(load().theta_comm_info(self._h, C.byref(r), C.byref(w), C.byref(t), C.byref(v), C.byref(n)))
+        return {"rank": r.value, "world": w.value, "transport": "host" if t.value == self.HOST else "rccl",
+                "rccl_version": v.value, "collectives": n.value}
+
+    def barrier(self):
+        _check(load().theta_comm_barrier(self._h))
+
+    def _allreduce(self, fn, values):
+        v = np.ascontiguousarray(np.atleast_1d(np.asarray(values, dtype=np.float64))).copy()
+        _check(fn(self._h, _p(v, C.c_double), len(v)))
+        return v
+
+    def allreduce_min(self, values):
+        return self._allreduce(load().theta_comm_allreduce_min, values)
+
+    def allreduce_max(self, values):
+        return self._allreduce(load().theta_comm_allreduce_max, values)
+
+    def allreduce_sum(self, values):
+        return self._allreduce(load().theta_comm_allreduce_sum, values)
+
+    def allgather(self, arr):
+        """Every rank's array (same shape and dtype everywhere) stacked along a new first axis."""
+        a = np.ascontiguousarray(arr)
+        out = np.zeros((self.world,) + a.shape, a.dtype)
+        _check(load().theta_comm_allgather(self._h, a.ctypes.data_as(C.c_void_p), a.nbytes, out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def exchange_finalists(self, n, m, recs, window):
+        """
+        theta_exchange_finalists on a list of records dict(rank, c, mu, nll, vals): returns (merged records of all shards
+        within `window` of the global minimum -- and every NaN-NLL record --, in rank order; the global minimum).
+        """
+        k = len(recs)
+        nc = n - 1
+        nll = np.array([t["nll"] for t in recs], dtype=np.float64).reshape(k)
+        mu = np.array([t["mu"] for t in recs], dtype=np.float64).reshape(k, n)
+        vals = np.array([t["vals"] for t in recs], dtype=np.float64).reshape(k, m)
+        rk = np.zeros((k, 2), np.uint64)
+        for i, t in enumerate(recs):
+            rk[i, 0], rk[i, 1] = t["rank"] & 0xFFFFFFFFFFFFFFFF, t["rank"] >> 64
+        Cb = np.array([np.asarray(t["c"], dtype=np.uint8).reshape(-1) for t in recs], dtype=np.uint8).reshape(k, m * nc)
+        cap = max(64, 2 * k)
+        while True:
+            o_nll, o_mu, o_vals = np.zeros(cap), np.zeros((cap, n)), np.zeros((cap, m))
+            o_rk, o_C = np.zeros((cap, 2), np.uint64), np.zeros((cap, m * nc), np.uint8)
+            n_out, gmin = C.c_int(), C.c_double()
+            rc = load().theta_exchange_finalists(self._h, n, m, k, _p(nll, C.c_double), _p(mu, C.c_double), _p(rk, C.c_uint64),
+                                                 _p(Cb, C.c_uint8), _p(vals, C.c_double), float(window), cap,
+                                                 _p(o_nll, C.c_double), _p(o_mu, C.c_double), _p(o_rk, C.c_uint64),
+                                                 _p(o_C, C.c_uint8), _p(o_vals, C.c_double), C.byref(n_out), C.byref(gmin))
+            if rc == ERR_CAPACITY and n_out.value > cap:
+                # (collective: every rank sees the same total and comes back with the same capacity)
+                cap = n_out.value
+                continue
+            _check(rc)
+            break
+        out = []
+        for i in range(n_out.value):
+            c = o_C[i].reshape(m) if n == 2 else o_C[i].reshape(m, 2)
+            out.append({"rank": int(o_rk[i, 0]) | (int(o_rk[i, 1]) << 64), "c": c.copy(), "mu": o_mu[i].copy(),
+                        "nll": float(o_nll[i]), "vals": o_vals[i].copy()})
+        return out, gmin.value

@@ -20,6 +20,7 @@ UNITS = [
     ("n3_enum.hip", []),
     ("batch.hip", ["-ffp-contract=off"]),
     ("api.hip", []),
+    ("comm.hip", []),
 ]
 COMMON = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-fgpu-rdc" if False else "-fno-gpu-rdc",
           "-Wall", "-Wno-unused-function"]

@@ -6,6 +6,7 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <memory>
 
 #include "n2.hpp"
 #include "n3_core.hpp"
@@ -95,6 +96,16 @@ extern "C" void theta_destroy(theta_ctx *c) {
     delete c;
 }
 
+extern "C" int theta_synchronize(theta_ctx *c) {
+    if (!c) {
+        theta_set_error("null context");
+        return THETA_ERR_ARG;
+    }
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipDeviceSynchronize());
+    return THETA_OK;
+}
+
 extern "C" int theta_device_info(theta_ctx *c, char *name, int cap, int *cu, uint64_t *hbm_bytes) {
     if (!c) {
         theta_set_error("null context");
@@ -108,7 +119,8 @@ extern "C" int theta_device_info(theta_ctx *c, char *name, int cap, int *cu, uin
 
 // ---- search instance ------------------------------------------------------------------------------
 #define LIST_CAP (1u << 20)
-#define SUS_CAP (1u << 16)
+#define SUS_CAP (1u << 20)
+#define DEG_CAP (1u << 16)
 #define N3_MAX_TASKS (1 << 18)
 
 struct theta_problem {
@@ -122,8 +134,12 @@ struct theta_problem {
     uint64_t total[2] = {0, 0};
     std::vector<TieRecord> suspects;   // rejected candidates near the minimum, from the last theta_search
     uint64_t suspects_dropped = 0;     // ... and how many more did not fit the device list
+    std::vector<TieRecord> degenerate; // n=3 candidates with an all-zero tumour column, from the last theta_search
+    uint64_t degenerate_dropped = 0;
     double hint = INFINITY;            // upper bound of the minimum known to the caller (theta_problem_hint), one-shot
-    DevBuf d_r, d_rN, d_small, d_P, d_PR, d_PN, d_cnt, d_ctr, d_list, d_tasks, d_stbuf, d_misc, d_smask, d_dynmask, d_sus;
+    uint64_t opt_per_task = 0;         // n=3 candidates per wave task (0: automatic), theta_problem_set_option
+    int opt_per_thread = 0;            // n=2 candidates per thread (0: automatic)
+    DevBuf d_r, d_rN, d_small, d_P, d_PR, d_PN, d_cnt, d_ctr, d_list, d_tasks, d_stbuf, d_misc, d_smask, d_dynmask, d_sus, d_deg;
 };
 
 static int upload(DevBuf &b, const void *src, size_t bytes, hipStream_t st) {
@@ -184,7 +200,8 @@ extern "C" int theta_problem_create(theta_ctx *ctx, int n, int m, int tau, const
         if (r[i] > 0) k0 -= (long double)r[i] * logl((long double)rN[i] / N);
 
     HIP_TRY(hipSetDevice(ctx->device));
-    theta_problem *p = new theta_problem();
+    std::unique_ptr<theta_problem> owner(new theta_problem());   // freed (with all its device buffers) on every error return
+    theta_problem *p = owner.get();
     p->ctx = ctx;
     p->n = n;
     p->m = m;
@@ -195,16 +212,14 @@ extern "C" int theta_problem_create(theta_ctx *ctx, int n, int m, int tau, const
 #define TRY(x)          \
     do {                \
         rc = (x);       \
-        if (rc) {       \
-            delete p;   \
-            return rc;  \
-        }               \
+        if (rc) return rc; \
     } while (0)
     TRY(upload(p->d_r, rd.data(), m * sizeof(double), st));
     TRY(upload(p->d_rN, rnd.data(), m * sizeof(double), st));
     TRY(p->d_ctr.alloc(sizeof(SearchCounters)));
     TRY(p->d_list.alloc((size_t)LIST_CAP * sizeof(TieRecord)));
     TRY(p->d_sus.alloc((size_t)SUS_CAP * sizeof(TieRecord)));
+    TRY(p->d_deg.alloc((size_t)DEG_CAP * sizeof(TieRecord)));
 
     if (n == 2) {
         TRY(n2_build_host(m, lb, ub, p->n2h));
@@ -251,6 +266,9 @@ extern "C" int theta_problem_create(theta_ctx *ctx, int n, int m, int tau, const
         D.ub = D.lb + m;
         D.lbpos = (const short *)((const unsigned char *)p->d_small.p + off);
         D.total = h.total;
+        D.first_zero_r = m;
+        for (int i = m - 1; i >= 0; i--)
+            if (r[i] == 0) D.first_zero_r = i;
         p->total[0] = h.total;
         p->total[1] = 0;
     } else {
@@ -298,7 +316,6 @@ extern "C" int theta_problem_create(theta_ctx *ctx, int n, int m, int tau, const
         if (cnt_bytes > (size_t)ctx->hbm_bytes / 2) {
             theta_set_error("n=3 counting table needs %zu bytes (device has %llu)", cnt_bytes,
                             (unsigned long long)ctx->hbm_bytes);
-            delete p;
             return THETA_ERR_HIP;
         }
         TRY(p->d_cnt.alloc(cnt_bytes));
@@ -316,7 +333,6 @@ extern "C" int theta_problem_create(theta_ctx *ctx, int n, int m, int tau, const
         memcpy(&hov, hostmisc, 4);
         if (hov) {
             theta_set_error("n=3 candidate count exceeds 128 bits; tighten the bounds or shard by prefix");
-            delete p;
             return THETA_ERR_OVERFLOW;
         }
         memcpy(p->total, hostmisc + 16, 16);
@@ -342,7 +358,29 @@ extern "C" int theta_problem_create(theta_ctx *ctx, int n, int m, int tau, const
     }
     HIP_TRY(hipStreamSynchronize(st));
 #undef TRY
-    *out = p;
+    *out = owner.release();
+    return THETA_OK;
+}
+
+/*
+ * Run-time switches of a search instance (the THETA_N3_* environment variables only set their defaults at creation).
+ */
+extern "C" int theta_problem_set_option(theta_problem *p, const char *name, double value) {
+    if (!p || !name) {
+        theta_set_error("null argument");
+        return THETA_ERR_ARG;
+    }
+    const std::string k(name);
+    if (k == "n3_force_f64") p->n3.force64 = value != 0.0;
+    else if (k == "n3_no_dismiss") p->n3.no_dismiss = value != 0.0;
+    else if (k == "n3_conv_l2" && value > 0.0) p->n3.conv_l2 = value;
+    else if (k == "n3_warm_blend" && value >= 0.0 && value <= 1.0) p->n3.warm_blend = value;
+    else if (k == "n3_per_task" && (value == 0.0 || (value >= 64 && value <= 65535))) p->opt_per_task = (uint64_t)value;
+    else if (k == "n2_per_thread" && (value == 0.0 || (value >= 1 && value <= 512))) p->opt_per_thread = (int)value;
+    else {
+        theta_set_error("unknown option or value out of range: %s = %g", name, value);
+        return THETA_ERR_ARG;
+    }
     return THETA_OK;
 }
 
@@ -389,6 +427,8 @@ static int run_search(theta_problem *p, u128 b, u128 e, double window, double *d
     A.list_cap = LIST_CAP;
     A.sus = (TieRecord *)p->d_sus.p;
     A.sus_cap = SUS_CAP;
+    A.deg = (TieRecord *)p->d_deg.p;
+    A.deg_cap = DEG_CAP;
     A.window = window;
     A.dump_nll = dump_nll;
     A.dump_mu = dump_mu;
@@ -413,6 +453,7 @@ static int run_search(theta_problem *p, u128 b, u128 e, double window, double *d
                 long long v = atoll(e);
                 if (v >= 1 && v <= 512) per = (unsigned long long)v;
             }
+            if (p->opt_per_thread > 0) per = (unsigned long long)p->opt_per_thread;
             HIP_TRY(hipEventRecord(ctx->ev1, st));
             n2_launch_search(p->n2, A, nb, ne, (int)per, st);
         } else {
@@ -425,6 +466,7 @@ static int run_search(theta_problem *p, u128 b, u128 e, double window, double *d
                 long long v = atoll(e);
                 if (v >= 64 && v <= 65535) per_task = (uint64_t)v;   // the kernel keeps in-task offsets in 16 bits
             }
+            if (p->opt_per_task > 0) per_task = p->opt_per_task;
             u128 nt = (cnt + per_task - 1) / per_task;
             if (nt > N3_MAX_TASKS) {
                 theta_set_error("n=3 rank range too large for one call: at most %llu candidates (split the range; "
@@ -467,6 +509,10 @@ static int run_search(theta_problem *p, u128 b, u128 e, double window, double *d
     p->suspects.resize(nsus);
     p->suspects_dropped = hc.sus_count > SUS_CAP ? hc.sus_count - SUS_CAP : 0;
     if (nsus) HIP_TRY(hipMemcpyAsync(p->suspects.data(), p->d_sus.p, (size_t)nsus * sizeof(TieRecord), hipMemcpyDeviceToHost, st));
+    unsigned ndeg = std::min<unsigned>(hc.deg_count, DEG_CAP);
+    p->degenerate.resize(ndeg);
+    p->degenerate_dropped = hc.deg_count > DEG_CAP ? hc.deg_count - DEG_CAP : 0;
+    if (ndeg) HIP_TRY(hipMemcpyAsync(p->degenerate.data(), p->d_deg.p, (size_t)ndeg * sizeof(TieRecord), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     dropped_out = list_dropped;
     return THETA_OK;
@@ -544,6 +590,7 @@ extern "C" int theta_search(theta_problem *p, const uint64_t rank_begin[2], cons
         p->suspects.swap(sk);
     }
     std::sort(keep.begin(), keep.end(), by_rank);
+    std::sort(p->degenerate.begin(), p->degenerate.end(), by_rank);
     *n_out = (int)keep.size();
     if ((int)keep.size() > cap) {
         theta_set_error("%zu candidates within the window but capacity is %d", keep.size(), cap);
@@ -632,20 +679,21 @@ extern "C" int theta_problem_hint(theta_problem *p, double nll_upper_bound) {
     return THETA_OK;
 }
 
-extern "C" int theta_search_suspects(theta_problem *p, int cap, uint64_t *rank, double *lbound, uint8_t *C, int *n_out) {
+// ranks (+ optional bounds) and materialised matrices of one of the side lists of the last search
+static int side_list_out(theta_problem *p, const std::vector<TieRecord> &sv, uint64_t dropped, const char *what, int cap,
+                         uint64_t *rank, double *lbound, uint8_t *C, int *n_out) {
     if (!p || !n_out) {
         theta_set_error("null argument");
         return THETA_ERR_ARG;
     }
-    const std::vector<TieRecord> &sv = p->suspects;
     *n_out = (int)sv.size();
-    if (cap < 0) {   // query: number of suspects that did not fit the device list
-        *n_out = (int)std::min<uint64_t>(p->suspects_dropped, 0x7fffffff);
+    if (cap < 0) {   // query: number of entries that did not fit the device list
+        *n_out = (int)std::min<uint64_t>(dropped, 0x7fffffff);
         return THETA_OK;
     }
     if (sv.empty()) return THETA_OK;
-    if ((int)sv.size() > cap || !rank || !lbound || !C) {
-        theta_set_error("%zu suspects but capacity is %d", sv.size(), cap);
+    if ((int)sv.size() > cap || !rank || !C) {
+        theta_set_error("%zu %s but capacity is %d", sv.size(), what, cap);
         return THETA_ERR_CAPACITY;
     }
     HIP_TRY(hipSetDevice(p->ctx->device));
@@ -664,9 +712,29 @@ extern "C" int theta_search_suspects(theta_problem *p, int cap, uint64_t *rank, 
     for (size_t i = 0; i < sv.size(); i++) {
         rank[2 * i] = sv[i].rank_lo;
         rank[2 * i + 1] = sv[i].rank_hi;
-        lbound[i] = sv[i].nll;
+        if (lbound) lbound[i] = sv[i].nll;
     }
     return THETA_OK;
+}
+
+extern "C" int theta_search_suspects(theta_problem *p, int cap, uint64_t *rank, double *lbound, uint8_t *C, int *n_out) {
+    if (!p) {
+        theta_set_error("null argument");
+        return THETA_ERR_ARG;
+    }
+    if (cap > 0 && !lbound) {
+        theta_set_error("null argument");
+        return THETA_ERR_ARG;
+    }
+    return side_list_out(p, p->suspects, p->suspects_dropped, "suspects", cap, rank, lbound, C, n_out);
+}
+
+extern "C" int theta_search_degenerate(theta_problem *p, int cap, uint64_t *rank, uint8_t *C, int *n_out) {
+    if (!p) {
+        theta_set_error("null argument");
+        return THETA_ERR_ARG;
+    }
+    return side_list_out(p, p->degenerate, p->degenerate_dropped, "degenerate candidates", cap, rank, nullptr, C, n_out);
 }
 
 extern "C" int theta_boundary_min(theta_ctx *ctx, int m, int tau, const int64_t *r, const int64_t *rN, int B,

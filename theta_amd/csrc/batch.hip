@@ -170,43 +170,23 @@ __global__ __launch_bounds__(64) void solve_batch_n3_kernel(int m, int tau, cons
     sys.rN = rn;
     sys.c = c;
     sys.init();
-    if (sys.S[1] == 0.0 || sys.S[2] == 0.0) {   // an all-zero tumour column: NaN everywhere in the reference (not reproduced)
-        ok[b] = 0;
-        mu[3 * b] = mu[3 * b + 1] = mu[3 * b + 2] = nll[b] = __builtin_nan("");
-        if (vals) for (int i = 0; i < m; i++) vals[(size_t)b * m + i] = __builtin_nan("");
-        return;
-    }
-    double nu[3];
-    const int outcome = n3_ref_outcome(sys, nu);     // 1 own iterate, 2 fallback, 0 None (n3_refbfgs.hpp)
+    // the reference's whole per-candidate procedure, restated (n3_refbfgs.hpp: n3_ref_solve) -- hybrj, the BFGS decision, M3's
+    // hybrd call, L3's sums; all-zero columns and NaN likelihoods come out the way the reference reports them
+    double mv[3], value = 0.0;
+    const int outcome = n3_ref_solve(sys, mv, value, vals ? vals + (size_t)b * m : nullptr);
     if (outcome == 0) {
         ok[b] = 0;
         mu[3 * b] = mu[3 * b + 1] = mu[3 * b + 2] = nll[b] = __builtin_nan("");
         if (vals) for (int i = 0; i < m; i++) vals[(size_t)b * m + i] = __builtin_nan("");
         return;
     }
-    const bool fallback = outcome == 2;
-    const double dtau = (double)tau;
-    const double w0 = nu[0] / sys.S[0], w1 = nu[1] / sys.S[1], w2 = nu[2] / sys.S[2];
-    const double ws = (w0 + w1) + w2;
-    const double m0 = w0 / ws, m1 = w1 / ws, m2 = w2 / ws;
-    // Optimizer.L3: denom accumulates column by column (for j ... for h ...), numer left to right
-    double den = 0.0;
-    for (int h = 0; h < m; h++) den = den + (rn[h] * dtau) * m0;
-    for (int h = 0; h < m; h++) den = den + (rn[h] * (double)c[2 * h]) * m1;
-    for (int h = 0; h < m; h++) den = den + (rn[h] * (double)c[2 * h + 1]) * m2;
-    double tot = 0.0;
-    for (int i = 0; i < m; i++) {
-        double nm = ((rn[i] * dtau) * m0 + (rn[i] * (double)c[2 * i]) * m1) + (rn[i] * (double)c[2 * i + 1]) * m2;
-        double p = nm / den;
-        tot = tot + rr[i] * log(p);
-        if (vals) vals[(size_t)b * m + i] = p;
-    }
-    const bool nan_out = !(tot == tot);
-    ok[b] = nan_out ? 0 : (fallback ? 2 : 1);       // 2: the reference's nu = (1/3, 1/3, 1/3) fallback
-    mu[3 * b] = m0;
-    mu[3 * b + 1] = m1;
-    mu[3 * b + 2] = m2;
-    nll[b] = -tot;
+    // A NaN likelihood is still a solution tuple in the reference (Optimizer.py:162-165 has no check), and its driver
+    // appends it to `best` through isClose(NaN) (Misc.py:44-46): ok stays 1 / 2, the host replays that.
+    ok[b] = (unsigned char)outcome;                  // 2: the reference's nu = (1/3, 1/3, 1/3) fallback
+    mu[3 * b] = mv[0];
+    mu[3 * b + 1] = mv[1];
+    mu[3 * b + 2] = mv[2];
+    nll[b] = value;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -79,6 +79,8 @@ struct SearchCounters {
     unsigned long long rej_rank_lo, rej_rank_hi;
     unsigned int list_count;           // records appended (may exceed capacity)
     unsigned int sus_count;            // suspects appended (may exceed capacity; never triggers a re-run)
+    unsigned int deg_count;            // n=3: candidates with an all-zero tumour column appended to the degenerate list
+    unsigned int pad0;
     unsigned long long prof[8];        // shader cycles per kernel phase, summed over waves (diagnostic)
 };
 
@@ -89,6 +91,8 @@ struct SearchArgs {
     unsigned list_cap;
     TieRecord *sus;                    // rejected candidates near the minimum (n=3 certificate)
     unsigned sus_cap;
+    TieRecord *deg;                    // n=3 candidates with an all-zero tumour column (rank only): what the reference reports
+    unsigned deg_cap;                  // for them hangs on MINPACK's rounding residue, reproduced by theta_solve_batch
     double window;
     double *dump_nll;  // optional per-candidate dump (the reference's --GET_VALUES), else null
     double *dump_mu;
@@ -179,6 +183,19 @@ __device__ __forceinline__ void suspect_append(SearchCounters *ctr, TieRecord *l
         rec.mu[0] = unconstrained;
         rec.mu[1] = 0.0;
         rec.mu[2] = 0.0;
+        list[idx] = rec;
+    }
+}
+
+// Append one degenerate candidate (all-zero tumour column): its rank is all the host needs.
+__device__ __forceinline__ void degenerate_append(SearchCounters *ctr, TieRecord *list, unsigned cap, u128 rank) {
+    unsigned idx = atomicAdd(&ctr->deg_count, 1u);
+    if (idx < cap) {
+        TieRecord rec;
+        rec.rank_lo = (uint64_t)rank;
+        rec.rank_hi = (uint64_t)(rank >> 64);
+        rec.nll = __builtin_nan("");
+        rec.mu[0] = rec.mu[1] = rec.mu[2] = 0.0;
         list[idx] = rec;
     }
 }

@@ -302,9 +302,13 @@ HYBRJ4_HD inline void r1mpyq(double a[M + 1][N + 1], const double *v, const doub
     }
 }
 
-// hybrj, mode 1 (automatic scaling), nprint 0.  x(1..4): start on entry, final iterate on return.  Returns MINPACK's info.
-template <class FCN>
-HYBRJ4_HD inline int hybrj(FCN &fcn, double *x, double xtol, int maxfev, double factor, int *nfev_out) {
+// hybrj / hybrd, mode 1 (automatic scaling), nprint 0.  x(1..4): start on entry, final iterate on return.  Returns
+// MINPACK's info.  FD = false: hybrj, the Jacobian comes from fcn.jac.  FD = true: hybrd, the Jacobian is built by
+// fdjac1's forward differences (dense form: ml + mu + 1 >= n, epsfcn = 0, i.e. steps of sqrt(epsmch) |x_j|), which costs N
+// function evaluations each time -- the solver behind scipy.optimize.fsolve(func, x0) WITHOUT fprime, which is how the
+// reference maps nu to mu (Optimizer.M3, Optimizer.py:327-330).
+template <bool FD, class FCN>
+HYBRJ4_HD inline int hybr(FCN &fcn, double *x, double xtol, int maxfev, double factor, int *nfev_out) {
     double fvec[N + 1], fjac[N + 1][N + 1], diag[N + 1], r[LR + 1], qtf[N + 1], wa1[N + 1], wa2[N + 1], wa3[N + 1], wa4[N + 1];
     int info = 0, nfev = 0;
     for (int j = 1; j <= N; j++) diag[j] = 1.0;
@@ -315,7 +319,21 @@ HYBRJ4_HD inline int hybrj(FCN &fcn, double *x, double xtol, int maxfev, double 
     double delta = 0.0, xnorm = 0.0;
     while (true) {                                   // outer loop: new Jacobian
         bool jeval = true;
-        fcn.jac(x, fjac);
+        if constexpr (FD) {                          // fdjac1, dense
+            const double eps = sqrt(EPSMCH);
+            for (int j = 1; j <= N; j++) {
+                const double temp = x[j];
+                double h = eps * fabs(temp);
+                if (h == 0.0) h = eps;
+                x[j] = temp + h;
+                fcn.f(x, wa1);
+                x[j] = temp;
+                for (int i = 1; i <= N; i++) fjac[i][j] = (wa1[i] - fvec[i]) / h;
+            }
+            nfev = nfev + N;
+        } else {
+            fcn.jac(x, fjac);
+        }
         qrfac(fjac, wa1, wa2);
         if (iter == 1) {
             for (int j = 1; j <= N; j++) {
@@ -430,6 +448,15 @@ HYBRJ4_HD inline int hybrj(FCN &fcn, double *x, double xtol, int maxfev, double 
 done:
     if (nfev_out) *nfev_out = nfev;
     return info;
+}
+
+template <class FCN>
+HYBRJ4_HD inline int hybrj(FCN &fcn, double *x, double xtol, int maxfev, double factor, int *nfev_out) {
+    return hybr<false>(fcn, x, xtol, maxfev, factor, nfev_out);
+}
+template <class FCN>
+HYBRJ4_HD inline int hybrd(FCN &fcn, double *x, double xtol, int maxfev, double factor, int *nfev_out) {
+    return hybr<true>(fcn, x, xtol, maxfev, factor, nfev_out);
 }
 
 }   // namespace hybrj4

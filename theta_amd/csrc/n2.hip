@@ -155,6 +155,10 @@ __device__ N2Result n2_solve(const N2Dev &P, const double *PRl, const double *PN
         out.degenerate = true;
         return out;
     }
+    // An interval with c_i = 0 AND r_i = 0 makes the reference's dL_dMu 0/0 = NaN at the left end nu = 0 (the term
+    // r_i (a_i - 0) / (a_i nu), Optimizer.py:208-221): brenth raises on the NaN and the candidate is None, whatever the
+    // other intervals of the run hold (inf + NaN = NaN).  The run of zeros is the prefix [0, s[1]).
+    if (c.s[1] > P.first_zero_r) return out;
     const double sigma = S1 / P.N;
     const double tau = (double)P.tau;
 #pragma unroll

@@ -12,6 +12,7 @@ struct N2Dev {
     const unsigned char *lb, *ub; // [m] order-adjusted bounds
     const short *lbpos;          // [N2_KVS+1] first index whose lb >= v (m if none)
     unsigned long long total;    // number of candidates
+    int first_zero_r;            // smallest interval index with r_i == 0 (m if none)
 };
 
 struct N2Host {

@@ -1055,6 +1055,9 @@ __global__ __launch_bounds__(64 * N3_WAVES, N3_OCC) void n3_search_kernel(N3Dev 
                     const bool keep = in && kind0 != 0u && (DUMP || kind0 != RES_DEGEN);
                     n_eval += (unsigned)__builtin_popcountll(ballot64(in));
                     n_deg += (unsigned)__builtin_popcountll(ballot64(in && kind0 == RES_DEGEN));
+                    // all-zero tumour column: the reference still reports something for it (Optimizer.py:128-165 on NaNs, then
+                    // M3 / L3) -- the host gets its rank and lets theta_solve_batch reproduce that outcome
+                    if (!DUMP && in && kind0 == RES_DEGEN && A.deg) degenerate_append(A.ctr, A.deg, A.deg_cap, base + qOff[idx]);
                     const unsigned long long km = ballot64(keep);
                     if (keep) cIdx[nkeep + mbcnt(km)] = (unsigned char)idx;
                     nkeep += __builtin_popcountll(km);

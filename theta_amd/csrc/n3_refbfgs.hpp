@@ -167,6 +167,36 @@ HYBRJ4_HD inline int n3_ref_outcome(N3RefSystem &sys, double nu[3]) {
     return 2;
 }
 
+// Everything Optimizer._solve_n3plus does for one candidate (Optimizer.py:128-165), as the reference does it: outcome of
+// the fsolve / fmin_bfgs calls (above), nu -> mu by M3's own fsolve call (n3_ref_M3), then Optimizer.L3's sums
+// (Optimizer.py:236-244: the denominator accumulates column by column -- for j ... for h ... --, the numerators left to
+// right).  Returns 0 = None, 1 = reported with its own iterate, 2 = reported at the nu = 1/3 fallback; mu, nll (NaN is a
+// legitimate value: the reference returns such tuples) and vals[m] (may be null) are filled for 1 / 2.
+// An all-zero tumour column makes Chat NaN: hybrj then returns its start unchanged, exactly like the reference's fsolve
+// call, nu = (1/3,1/3,1/3) passes inRange, M3 lands on a unit vector plus rounding residue, and L3 makes a finite number
+// or NaN of it -- reproduced, not special-cased.  Host and device run this same code.
+HYBRJ4_HD inline int n3_ref_solve(N3RefSystem &sys, double mu[3], double &nll, double *vals) {
+    double nu[3];
+    const int outcome = n3_ref_outcome(sys, nu);
+    if (outcome == 0) return 0;
+    n3_ref_M3(sys.S, nu, mu, nullptr);
+    const double m0 = mu[0], m1 = mu[1], m2 = mu[2];
+    const int m = sys.m;
+    double den = 0.0;
+    for (int h = 0; h < m; h++) den = den + (sys.rN[h] * sys.tau) * m0;
+    for (int h = 0; h < m; h++) den = den + (sys.rN[h] * (double)sys.c[2 * h]) * m1;
+    for (int h = 0; h < m; h++) den = den + (sys.rN[h] * (double)sys.c[2 * h + 1]) * m2;
+    double tot = 0.0;
+    for (int i = 0; i < m; i++) {
+        const double nm = ((sys.rN[i] * sys.tau) * m0 + (sys.rN[i] * (double)sys.c[2 * i]) * m1) + (sys.rN[i] * (double)sys.c[2 * i + 1]) * m2;
+        const double p = nm / den;
+        tot = tot + sys.r[i] * log(p);               // log of a negative number is NaN, like numpy's
+        if (vals) vals[i] = p;
+    }
+    nll = -tot;
+    return outcome;
+}
+
 #ifdef HYBRJ4_MANAGE_CONTRACT
 #pragma clang fp contract(fast)
 #endif

@@ -76,6 +76,38 @@ HYBRJ4_HD inline int n3_ref_fsolve(N3RefSystem &sys, double nu[3], int *nfev) {
     return info;
 }
 
+// Optimizer.M3 (Optimizer.py:318-330): nu -> mu as the reference computes it, fsolve(M_eq, [.33, .33, .33, 0]) WITHOUT a
+// Jacobian, i.e. MINPACK's hybrd with forward differences, on the LINEAR system
+//      eq_j = nu_j (sum_h x_h S_h) - x_j S_j - x_4   (j < 3),     eq_4 = (x_1 + x_2 + x_3) - 1
+// (S = column sums of the weighted matrix).  Its solution is the closed form mu_j = (nu_j / S_j) / sum_h (nu_h / S_h) --
+// unless a column sum is zero (an all-zero tumour column): then the exact solution puts ALL weight on that column, the
+// mixture C.mu vanishes, and what the reference goes on to report (a finite NLL or NaN, Optimizer.L3) hangs on the
+// rounding residue hybrd leaves in the other components (~1e-26).  Restated operation by operation, Python's sums left
+// to right from 0.
+struct N3RefM3 {
+    double S[3], nu[3];
+    HYBRJ4_HD void f(const double *x, double *fv) const {
+        for (int j = 0; j < 3; j++) {
+            const double t = ((x[1] * S[0]) + x[2] * S[1]) + x[3] * S[2];
+            fv[j + 1] = ((nu[j] * t) - (x[j + 1] * S[j])) - x[4];
+        }
+        fv[4] = ((x[1] + x[2]) + x[3]) - 1.0;
+    }
+};
+HYBRJ4_HD inline int n3_ref_M3(const double S[3], const double nu[3], double mu[3], int *nfev) {
+    N3RefM3 sys;
+    for (int j = 0; j < 3; j++) {
+        sys.S[j] = S[j];
+        sys.nu[j] = nu[j];
+    }
+    double x[hybrj4::N + 1] = {0.0, 0.33, 0.33, 0.33, 0.0};
+    const int info = hybrj4::hybrd(sys, x, 1.49012e-8, 200 * (hybrj4::N + 1), 100.0, nfev);
+    mu[0] = x[1];
+    mu[1] = x[2];
+    mu[2] = x[3];
+    return info;
+}
+
 #ifdef HYBRJ4_MANAGE_CONTRACT
 #pragma clang fp contract(fast)      // back to the device default for the rest of the including unit
 #endif

@@ -11,15 +11,15 @@ What runs where
                           un-sorting of rows (DataTools.py:132-159), and -- with several GPUs -- one
                           small RCCL exchange of the per-shard finalists.
 
-Deviations from the reference that are deliberate:
-  * candidates whose NLL the reference computes as NaN (all-zero tumour column) are appended to its
-    `best` list by the isClose(NaN) quirk (Misc.py:44-46); they carry no information and are not
-    reproduced;
-  * for n=3 a candidate is reported the way Optimizer._solve_n3plus reports it: its own optimum where the reference's
+How the reference's per-candidate outcome is followed:
+  * n=3 candidates are reported the way Optimizer._solve_n3plus reports them: their own optimum where the reference's
     fsolve run (MINPACK hybrj, restated in csrc/hybrj4.hpp) ends inside [0,1]^3, else the nu = (1/3,1/3,1/3) fallback
-    (`fallback_records`).  Not reproduced: the None / NaN outcomes of a BFGS line search that walks into NaNs (1-2 % of
-    the candidates of toy instances).  `SearchReport.parity_uncertain` is raised when such an outcome on some rejected
-    candidate could undercut the winner (its minimum over the simplex boundary is that low).
+    (`fallback_records`), or None where its BFGS line search walks out of the domain;
+  * candidates with an all-zero tumour column -- whose arithmetic is NaN in the reference from normalize_C on -- take part
+    with what the reference makes of them (`degenerate_records`): a finite NLL or NaN, decided by the rounding residue of
+    M3's fsolve call (MINPACK hybrd, restated too).  A NaN likelihood counts as "close" to anything (Misc.py:44-46), so the
+    reference appends such entries to `best` wherever they stand after the last replacement of the minimum; so does the
+    replay here.
 """
 import sys
 
@@ -93,6 +93,9 @@ class SearchReport(object):
         self.suspect_bound = float("inf")  # smallest NLL any of them can take on the simplex boundary
         self.certificate_complete = True   # False if the device suspect list overflowed (poor sub-range without a hint)
         self.fallback_finalists = 0        # n=3: rejected candidates that joined the finalists with the reference's nu = 1/3 value
+        self.degenerate = 0                # n=3: candidates with an all-zero tumour column (reported like the reference does)
+        self.dropped_not_ok = 0            # finalists of the fused kernel the reference-order re-solve returned None for
+        self.suspect_reruns = 0            # pieces of the range searched again because their suspect list overflowed
         self.seconds = 0.0
 
 
@@ -110,7 +113,7 @@ def _full_matrix(c_u8, n, tau):
     return C
 
 
-def collect_finalists(problem, ctx, r, rN, max_normal, begin, end, window=COLLECT_WINDOW):
+def collect_finalists(problem, ctx, r, rN, max_normal, begin, end, window=COLLECT_WINDOW, report=None):
     """
     GPU part: fused search over [begin, end) then the exact-order re-solve of the finalists.
     Returns (records, stats); a record is dict(rank, c (uint8), mu (n floats), nll, vals (m floats)).
@@ -118,14 +121,37 @@ def collect_finalists(problem, ctx, r, rN, max_normal, begin, end, window=COLLEC
     res = problem.search(begin, end, window=window)
     k = len(res["rank"])
     recs = []
+    dropped = 0
     if k:
         ok, mu, nll, vals = ctx.solve_batch(problem.n, problem.tau, r, rN, res["C"], max_normal, want_vals=True)
         for i in range(k):
             if not ok[i]:
-                continue  # borderline: admissible in the fused arithmetic, not in the reference-order arithmetic
+                dropped += 1   # borderline: admissible in the fused arithmetic, None in the reference-order arithmetic
+                continue
             recs.append({"rank": res["rank"][i], "c": res["C"][i], "mu": mu[i].copy(), "nll": float(nll[i]),
                          "vals": vals[i].copy()})
+    if report is not None:
+        report.dropped_not_ok = dropped
+        report.suspect_reruns = problem.suspect_reruns
     return recs, res["stats"]
+
+
+def degenerate_records(problem, ctx, r, rN, max_normal, report=None):
+    """
+    n=3 candidates of the searched range with an all-zero tumour column, valued the way the reference values them
+    (theta_solve_batch: hybrj on the NaN system returns its start, M3's hybrd call lands on a unit vector plus residue, L3
+    makes a finite number or NaN of it).  All of them are returned: the finite ones are ordinary finalists if they come
+    within the window, the NaN ones interact with the running minimum wherever they stand.
+    """
+    ranks, Cs = problem.last_degenerate
+    if not len(ranks):
+        return []
+    ok, mu, nll, vals = ctx.solve_batch(3, problem.tau, r, rN, Cs, max_normal, want_vals=True)
+    out = [{"rank": ranks[i], "c": Cs[i], "mu": mu[i].copy(), "nll": float(nll[i]), "vals": vals[i].copy()}
+           for i in range(len(ranks)) if ok[i]]
+    if report is not None:
+        report.degenerate = len(out)
+    return out
 
 
 def fallback_records(problem, ctx, r, rN, max_normal, recs, window=COLLECT_WINDOW, report=None):
@@ -142,7 +168,8 @@ def fallback_records(problem, ctx, r, rN, max_normal, recs, window=COLLECT_WINDO
     if not len(ranks):
         return []
     ok, mu, nll, vals = ctx.solve_batch(3, problem.tau, r, rN, Cs, max_normal, want_vals=True)
-    lowest = min([t["nll"] for t in recs] + [float(v) for v, o in zip(nll, ok) if o], default=float("inf"))
+    lowest = min([t["nll"] for t in recs if t["nll"] == t["nll"]] + [float(v) for v, o in zip(nll, ok) if o and v == v],
+                 default=float("inf"))
     have = set(t["rank"] for t in recs)
     out = []
     for i in range(len(ranks)):
@@ -164,9 +191,11 @@ def replay_ties(recs, n, tau, sorted_index, first_duplicate, report=None, q1_fir
         return []
     recs = sorted(recs, key=lambda t: t["rank"])
     # cut the finalists at the first gap wider than the tie margin: nothing above it can interact
-    # with the running minimum ("tie replay")
-    if recs:
-        vals_sorted = sorted(t["nll"] for t in recs)
+    # with the running minimum ("tie replay").  Records with a NaN likelihood always stay: isClose(NaN)
+    # is True (Misc.py:44-46), the reference appends them to whatever list it holds at that moment.
+    finite = [t["nll"] for t in recs if t["nll"] == t["nll"]]
+    if finite:
+        vals_sorted = sorted(finite)
         cut = vals_sorted[-1]
         found_gap = False
         for a, b in zip(vals_sorted, vals_sorted[1:]):
@@ -176,7 +205,7 @@ def replay_ties(recs, n, tau, sorted_index, first_duplicate, report=None, q1_fir
                 break
         if not found_gap and vals_sorted[-1] - vals_sorted[0] > COLLECT_WINDOW - 2 * TIE_MARGIN and report is not None:
             report.tie_ambiguous = True
-        recs = [t for t in recs if t["nll"] <= cut]
+        recs = [t for t in recs if not (t["nll"] > cut)]
     seq = []
     if q1_first is not None:
         seq.append(q1_first)
@@ -202,18 +231,18 @@ def replay_ties(recs, n, tau, sorted_index, first_duplicate, report=None, q1_fir
     return out
 
 
-def _q1_record(ctx, n, m, tau, r, rN):
+def _q1_record(ctx, n, m, tau, r, rN, max_normal=1.0):
     """
-    Quirk Q1 for n=3: the reference first evaluates [tau,0,0]*m whatever the bounds
-    (Enumerator.py:154-160, RunTHetA.py:188).  Its solver runs on NaNs and returns the
-    uniform-by-normal-count model (p_i = rN_i / sum rN) with an arbitrary mu; the likelihood of that
-    model is scored here by the L3 kernel with mu = (1,0,0).
+    Quirk Q1 for n=3: the reference first evaluates [tau,0,0]*m whatever the bounds (Enumerator.py:154-160,
+    RunTHetA.py:188).  Both tumour columns are zero, its solver runs on NaNs, and M3 / L3 end at the
+    uniform-by-normal-count model (p_i = rN_i / sum rN) with a mu that is rounding residue -- theta_solve_batch
+    reproduces both.  None if the reference's solve returns None for it.
     """
-    Cw = np.zeros((1, m, 3))
-    Cw[0, :, 0] = np.asarray(rN, dtype=np.float64) * tau
-    nll, vals, valid = ctx.score_batch(3, Cw, np.array([[1.0, 0.0, 0.0]]), np.asarray(r, dtype=np.float64))
-    return {"rank": -1, "c": np.zeros((m, 2), np.uint8), "mu": np.array([1.0, 0.0, 0.0]), "nll": float(nll[0]),
-            "vals": vals[0].copy()}
+    c0 = np.zeros((1, m, 2), np.uint8)
+    ok, mu, nll, vals = ctx.solve_batch(3, tau, [int(x) for x in r], [int(x) for x in rN], c0, max_normal, want_vals=True)
+    if not ok[0]:
+        return None
+    return {"rank": -1, "c": c0[0], "mu": mu[0].copy(), "nll": float(nll[0]), "vals": vals[0].copy()}
 
 
 def _dump_values(problem, n, m):
@@ -225,18 +254,26 @@ def _dump_values(problem, n, m):
             C = problem.enumerate(b, cnt)
             if n == 2:
                 nll, mu, _ = problem.values(b, cnt)
+                rep = nll == nll
             else:
                 # n=3: what the reference dumps for a matrix is the outcome of its solver calls (own optimum / nu = 1/3
                 # fallback / nothing), which theta_solve_batch reproduces -- not the fused kernel's optimum
                 ok, mu, nll, _v = problem.ctx.solve_batch(3, problem.tau, problem.r, problem.rN, C, problem.max_normal, want_vals=False)
-                nll = np.where(ok, nll, np.nan)
+                rep = ok
             col = C if n == 2 else C[:, :, 0]
             for i in range(cnt):
-                if nll[i] == nll[i]:
+                if rep[i]:        # (a NaN likelihood of a reported n=3 tuple is written as 'nan', like the reference does)
                     f.write("".join(str(int(v)) for v in col[i]) + "\t" + str(float(mu[i, 0])) + "\t" + str(float(nll[i])) + "\n")
 
 
-def _search_local(n, m, tau, lower_bounds, upper_bounds, r, rN, max_normal, shard=(0, 1), ctx=None):
+def _search_local(n, m, tau, lower_bounds, upper_bounds, r, rN, max_normal, shard=(0, 1), ctx=None, report=None, hint_exchange=None):
+    """
+    Everything one GPU does for its shard: the fused search, the finalists in reference arithmetic, and -- n=3 -- the
+    records the reference reports away from a candidate's own optimum (nu = 1/3 fallbacks, all-zero columns).
+    hint_exchange: with several shards, a function local_min -> global_min (an all-reduce) applied to the shard's PROBE
+    minimum before the search, so that a shard whose own candidates are poor starts from what the best shard can reach
+    instead of flooding its suspect list.
+    """
     ctx = ctx or _lib.default_context()
     r = [int(x) for x in r]
     rN = [int(x) for x in rN]
@@ -247,8 +284,38 @@ def _search_local(n, m, tau, lower_bounds, upper_bounds, r, rN, max_normal, shar
     g, G = shard
     begin = problem.count * g // G
     end = problem.count * (g + 1) // G
-    recs, stats = collect_finalists(problem, ctx, r, rN, max_normal, begin, end)
+    if hint_exchange is not None:
+        local = problem._probe(begin, end) if end > begin else float("inf")
+        shared = hint_exchange(local)
+        if shared < float("inf"):
+            problem.hint(shared)
+    recs, stats = collect_finalists(problem, ctx, r, rN, max_normal, begin, end, report=report)
+    if n == 3:
+        recs = recs + fallback_records(problem, ctx, r, rN, max_normal, recs, report=report)
+        recs = recs + degenerate_records(problem, ctx, r, rN, max_normal, report=report)
     return problem, ctx, recs, stats
+
+
+def _friendly_exit(e):
+    # a search the library cannot hold (n=3: more than 64 intervals, or more than 2^128 matrices -- the reference would
+    # enumerate such a space for years): say so instead of a traceback
+    print("ERROR: %s. Use fewer intervals (--NUM_INTERVALS) or tighter bounds. Exiting..." % e)
+    sys.exit(1)
+
+
+def _certificate(rep, problem, ctx, tau, r, rN, best):
+    # n=3: candidates whose optimum lies outside the simplex take part with the reference's nu = 1/3 fallback value
+    # (fallback_records).  Should the reference's solver leave its typical path on one of them (stall inside [0,1]^3),
+    # whatever it reports is at least the candidate's minimum over the simplex boundary, computed exactly on the GPU:
+    # above the winner => no such accident can change `best`.
+    ranks, lbound, Cs = problem.last_suspects
+    rep.suspects = len(ranks)
+    rep.certificate_complete = problem.suspects_dropped == 0      # (a search that lost suspects raises; kept for readers)
+    finite = [b[2] for b in best if b[2] == b[2]]
+    if len(ranks) and finite:
+        bmin = ctx.boundary_min(tau, [int(x) for x in r], [int(x) for x in rN], Cs)
+        rep.suspect_bound = float(bmin.min())
+        rep.parity_uncertain = bool(rep.suspect_bound < min(finite) + TIE_MARGIN)
 
 
 def do_optimization_single(n, m, k, tau, lower_bounds, upper_bounds, r, rN, max_normal, sorted_index, multi_event=False,
@@ -262,38 +329,23 @@ def do_optimization_single(n, m, k, tau, lower_bounds, upper_bounds, r, rN, max_
     global last_report
     rep = SearchReport()
     try:
-        problem, ctx, recs, stats = _search_local(n, m, tau, lower_bounds, upper_bounds, r, rN, max_normal)
+        problem, ctx, recs, stats = _search_local(n, m, tau, lower_bounds, upper_bounds, r, rN, max_normal, report=rep)
     except _lib.NoCandidates:
         print("Error: No valid Copy Number Profiles exist for these intervals within the bounds specified. Exiting...")
         sys.exit(1)
     except _lib.ThetaError as e:
         if e.code in (_lib.ERR_OVERFLOW, _lib.ERR_ARG):
-            # a search the library cannot hold (n=3: more than 64 intervals, or more than 2^128 matrices -- the reference would
-            # enumerate such a space for years): say so instead of a traceback
-            print("ERROR: %s. Use fewer intervals (--NUM_INTERVALS) or tighter bounds. Exiting..." % e)
-            sys.exit(1)
+            _friendly_exit(e)
         raise
-    q1 = _q1_record(ctx, n, m, tau, r, rN) if n == 3 else None
-    if n == 3:
-        recs = recs + fallback_records(problem, ctx, [int(x) for x in r], [int(x) for x in rN], max_normal, recs, report=rep)
+    q1 = _q1_record(ctx, n, m, tau, r, rN, max_normal) if n == 3 else None
     best = replay_ties(recs, n, tau, sorted_index, first_duplicate=(n == 2), report=rep, q1_first=q1)
     if get_values:
         _dump_values(problem, n, m)
     rep.stats = stats
     rep.candidates = problem.count
     rep.finalists = len(recs)
-    # n=3: candidates whose optimum lies outside the simplex take part with the reference's nu = 1/3 fallback value
-    # (fallback_records).  Should the reference's solver leave its typical path on one of them (stall inside [0,1]^3),
-    # whatever it reports is at least the candidate's minimum over the simplex boundary, computed exactly on the GPU:
-    # above the winner => no such accident can change `best`.
     if n == 3 and best:
-        ranks, lbound, Cs = problem.last_suspects
-        rep.suspects = len(ranks)
-        rep.certificate_complete = problem.suspects_dropped == 0
-        if len(ranks):
-            bmin = ctx.boundary_min(tau, [int(x) for x in r], [int(x) for x in rN], Cs)
-            rep.suspect_bound = float(bmin.min())
-            rep.parity_uncertain = bool(rep.suspect_bound < best[0][2] + TIE_MARGIN)
+        _certificate(rep, problem, ctx, tau, r, rN, best)
     rep.seconds = time.time() - t0
     last_report = rep
     return best
@@ -313,74 +365,31 @@ def do_optimization(n, m, k, tau, lower_bounds, upper_bounds, r, rN, max_normal,
 # --------------------------------------------------------------------------------------------------
 # several GPUs: one process per GPU, candidate ranks sharded, ONE small exchange at the end
 # --------------------------------------------------------------------------------------------------
-def exchange_finalists(recs, n, m, device, group=None):
+def do_optimization_distributed(n, m, k, tau, lower_bounds, upper_bounds, r, rN, max_normal, sorted_index, comm, ctx=None):
     """
-    The only communication of a sharded search (replaces find_mins, RunTHetA.py:107-122):
-    all-reduce(min) of the shard minima, then an all-gather of the finalists that survive the global
-    window.  Runs over torch.distributed (backend "nccl" == RCCL over xGMI on the GPU box; "gloo" in
-    the CPU tests).  Returns the merged finalists of all shards (identical on every rank).
+    One process per GPU; `comm` is a theta_amd.Comm (the library's communicator: RCCL over xGMI, or its host transport in
+    CPU-side tests).  Rank g searches the candidate ranks [N*g/G, N*(g+1)/G); the only communication is an all-reduce(min)
+    of the shards' probe minima before the search (a hint, it changes no result) and theta_exchange_finalists after it
+    (replaces find_mins, RunTHetA.py:107-122).  Every rank returns the same `best` as do_optimization_single would.
     """
-    import torch
-    import torch.distributed as dist
-    world = dist.get_world_size(group)
-    local_min = min([t["nll"] for t in recs], default=float("inf"))
-    gmin = torch.tensor([local_min], dtype=torch.float64, device=device)
-    dist.all_reduce(gmin, op=dist.ReduceOp.MIN, group=group)
-    gmin = float(gmin.item())
-    keep = [t for t in recs if t["nll"] <= gmin + COLLECT_WINDOW]
-    cnt = torch.tensor([len(keep)], dtype=torch.int64, device=device)
-    counts = [torch.zeros_like(cnt) for _ in range(world)]
-    dist.all_gather(counts, cnt, group=group)
-    counts = [int(c.item()) for c in counts]
-    cap = max(counts)
-    if cap == 0:
-        return []
-    nc = n - 1
-    W = 1 + n + m                      # nll, mu[n], vals[m]
-    fl = torch.zeros((cap, W), dtype=torch.float64)
-    ii = torch.zeros((cap, 2), dtype=torch.int64)
-    cc = torch.zeros((cap, m * nc), dtype=torch.uint8)
-    mask64 = (1 << 64) - 1
-    for i, t in enumerate(keep):
-        fl[i, 0] = t["nll"]
-        fl[i, 1:1 + n] = torch.from_numpy(np.asarray(t["mu"], dtype=np.float64))
-        fl[i, 1 + n:] = torch.from_numpy(np.asarray(t["vals"], dtype=np.float64))
-        lo, hi = t["rank"] & mask64, (t["rank"] >> 64) & mask64
-        ii[i, 0] = lo - (1 << 64) if lo >= (1 << 63) else lo     # two's complement transport of uint64
-        ii[i, 1] = hi - (1 << 64) if hi >= (1 << 63) else hi
-        cc[i] = torch.from_numpy(np.ascontiguousarray(t["c"], dtype=np.uint8).reshape(-1))
-    fl, ii, cc = fl.to(device), ii.to(device), cc.to(device)
-    gfl = [torch.zeros_like(fl) for _ in range(world)]
-    gii = [torch.zeros_like(ii) for _ in range(world)]
-    gcc = [torch.zeros_like(cc) for _ in range(world)]
-    dist.all_gather(gfl, fl, group=group)
-    dist.all_gather(gii, ii, group=group)
-    dist.all_gather(gcc, cc, group=group)
-    merged = []
-    for g in range(world):
-        f, i2, c2 = gfl[g].cpu().numpy(), gii[g].cpu().numpy(), gcc[g].cpu().numpy()
-        for j in range(counts[g]):
-            lo, hi = int(i2[j, 0]) & mask64, int(i2[j, 1]) & mask64
-            c = c2[j].reshape(m) if n == 2 else c2[j].reshape(m, 2)
-            merged.append({"rank": lo | (hi << 64), "c": c.copy(), "mu": f[j, 1:1 + n].copy(), "nll": float(f[j, 0]),
-                           "vals": f[j, 1 + n:].copy()})
-    return merged
+    global last_report
+    rep = SearchReport()
+    g, G = comm.rank, comm.world
 
+    def share(local_min):
+        return float(comm.allreduce_min([local_min])[0])
 
-def do_optimization_distributed(n, m, k, tau, lower_bounds, upper_bounds, r, rN, max_normal, sorted_index, group=None,
-                                device=None):
-    """
-    One process per GPU (torch.distributed already initialised).  Rank g searches the candidate ranks
-    [N*g/G, N*(g+1)/G); every rank returns the same `best` as do_optimization_single would.
-    """
-    import torch
-    import torch.distributed as dist
-    g, G = dist.get_rank(group), dist.get_world_size(group)
-    if device is None:
-        device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
-    problem, ctx, recs, stats = _search_local(n, m, tau, lower_bounds, upper_bounds, r, rN, max_normal, shard=(g, G))
-    if n == 3:     # the shard's rejected candidates that the reference reports at nu = (1/3,1/3,1/3), see fallback_records
-        recs = recs + fallback_records(problem, ctx, [int(x) for x in r], [int(x) for x in rN], max_normal, recs)
-    merged = exchange_finalists(recs, n, m, device, group)
-    q1 = _q1_record(ctx, n, m, tau, r, rN) if n == 3 else None
-    return replay_ties(merged, n, tau, sorted_index, first_duplicate=(n == 2), q1_first=q1)
+    try:
+        problem, ctx, recs, stats = _search_local(n, m, tau, lower_bounds, upper_bounds, r, rN, max_normal, shard=(g, G), ctx=ctx,
+                                                  report=rep, hint_exchange=share if G > 1 else None)
+    except _lib.NoCandidates:
+        print("Error: No valid Copy Number Profiles exist for these intervals within the bounds specified. Exiting...")
+        sys.exit(1)
+    merged, gmin = comm.exchange_finalists(n, m, recs, COLLECT_WINDOW)
+    q1 = _q1_record(ctx, n, m, tau, r, rN, max_normal) if n == 3 else None
+    best = replay_ties(merged, n, tau, sorted_index, first_duplicate=(n == 2), report=rep, q1_first=q1)
+    rep.stats = stats
+    rep.candidates = problem.count
+    rep.finalists = len(merged)
+    last_report = rep
+    return best

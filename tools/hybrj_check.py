@@ -18,10 +18,35 @@ from scipy import optimize
 
 so = os.path.join(ROOT, "build_ab", "libhybrj_check.so")
 os.makedirs(os.path.dirname(so), exist_ok=True)
-subprocess.check_call(["g++", "-O2", "-ffp-contract=off", "-shared", "-fPIC", os.path.join(ROOT, "tools", "hybrj_check.cpp"), "-o", so])
+subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-shared", "-fPIC", os.path.join(ROOT, "tools", "hybrj_check.cpp"), "-o", so])
 lib = C.CDLL(so)
 dp = C.POINTER(C.c_double)
 lib.hybrj_check_solve.argtypes = [C.c_int, C.c_int, dp, dp, C.POINTER(C.c_uint8), dp, C.POINTER(C.c_int)]
+lib.hybrj_check_M3.argtypes = [dp, dp, dp, C.POINTER(C.c_int)]
+lib.hybrj_check_table.argtypes = [C.c_int, C.c_int, C.c_int, dp, dp, C.POINTER(C.c_uint8), C.POINTER(C.c_uint8), dp, dp]
+
+
+def solve_table(C_u8, r, rN, tau=2):
+    """theta_solve_batch's per-candidate procedure (n3_ref_solve, the function the device kernel calls) on the host:
+    returns ok (0 None / 1 own iterate / 2 fallback), mu (B, 3), nll (B)."""
+    C_u8 = np.ascontiguousarray(C_u8, np.uint8)
+    B, m = C_u8.shape[0], C_u8.shape[1]
+    r = np.ascontiguousarray(r, np.float64)
+    rN = np.ascontiguousarray(rN, np.float64)
+    ok, mu, nll = np.zeros(B, np.uint8), np.zeros((B, 3)), np.zeros(B)
+    lib.hybrj_check_table(B, m, tau, r.ctypes.data_as(dp), rN.ctypes.data_as(dp), C_u8.ctypes.data_as(C.POINTER(C.c_uint8)),
+                          ok.ctypes.data_as(C.POINTER(C.c_uint8)), mu.ctypes.data_as(dp), nll.ctypes.data_as(dp))
+    return ok, mu, nll
+
+
+def m3(S, nu):
+    """Optimizer.M3 restated (hybrd): mu for column sums S and mixture nu."""
+    S = np.ascontiguousarray(S, np.float64)
+    nu = np.ascontiguousarray(nu, np.float64)
+    mu = np.zeros(3)
+    nf = C.c_int()
+    info = lib.hybrj_check_M3(S.ctypes.data_as(dp), nu.ctypes.data_as(dp), mu.ctypes.data_as(dp), C.byref(nf))
+    return mu, info, nf.value
 
 
 def mine(c_u8, r, rN, tau=2):

@@ -6,9 +6,8 @@ reference's solver, sequential isClose rule), the oracle side spread over the ho
     python tools/parity_campaign.py [--n3 240] [--n2 240] [--seconds 420] > gpurun_out/parity_campaign.json
 
 Checks per instance (the parity bar of BASELINE.json): chosen C identical, |d mu| < 1e-6, NLL within 1e-6 relative.
-n=2: the complete `best` list.  n=3: first entries agree and the reference's tie list is a sub-sequence of the GPU's
-(the reference's accept set depends on scipy trajectories; the GPU accepts the candidates whose optimum
-lies in the simplex, a superset on ties).  Instances whose oracle side does not finish inside the budget are reported
+The COMPLETE `best` lists are compared entry by entry, n=2 and n=3, entries with a NaN likelihood included
+(tests/campaign.py: compare_best).  Instances whose oracle side does not finish inside the budget are reported
 as "unfinished", not as passes.
 """
 import argparse
@@ -25,58 +24,12 @@ sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import numpy as np
 
 SHAPE = "toy"
-
-
-def instance_mid(seed, n):
-    """m = 10..18 intervals with bounds tight around a planted truth (the shape interval selection + bounds heuristics give)."""
-    import theta_oracle as orc
-    rng = np.random.RandomState(seed)
-    m, k = int(rng.randint(10, 19)), int(rng.randint(3, 6))
-    tau = 2
-    L = rng.randint(2_000_000, 20_000_000, m)
-    rN = np.maximum(rng.poisson(L * rng.choice([0.001, 0.004, 0.01])), 5)
-    C = np.full((m, n), float(tau))
-    for j in range(1, n):
-        C[:, j] = rng.randint(0, k + 1, m)
-    if n == 3 and rng.rand() < 0.3:
-        C[:, 2] = C[:, 1]                       # a sample with ONE tumour population analysed with n=3
-    mu = rng.dirichlet(np.ones(n) * 3)
-    p = (C * rN[:, None]) @ mu
-    p = p / p.sum()
-    r = np.maximum(rng.multinomial(int(rN.sum() * rng.uniform(0.8, 1.5)), p), 1)
-    rs, rNs, order = orc.sort_r([int(x) for x in rN], [int(x) for x in r])
-    cs = np.maximum(C[:, 1:].max(axis=1), 0)[order]
-    cmin = C[:, 1:].min(axis=1)[order]
-    free = rng.rand(m) < (0.85 if n == 2 else 0.3)
-    lb = [int(max(0, a - (1 if f else 0))) for a, f in zip(cmin, free)]
-    ub = [int(min(k, b + (1 if f else 0))) for b, f in zip(cs, free)]
-    return dict(seed=seed, n=n, m=m, k=k, tau=tau, mx=1.0, r=rs, rN=rNs, order=order, lb=lb, ub=ub)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import campaign
 
 
 def instance(seed, n):
-    import theta_oracle as orc
-    if SHAPE == "mid":
-        return instance_mid(seed, n)
-    rng = np.random.RandomState(seed)
-    if n == 2:
-        m, k = int(rng.randint(4, 14)), int(rng.randint(2, 6))
-    else:
-        m, k = int(rng.randint(4, 8)), int(rng.randint(2, 4))
-    tau = int(rng.choice([1, 2, 2, 2, 3])) if n == 2 else 2
-    mx = float(rng.choice([1.0, 1.0, 0.5, 0.7])) if n == 2 else 1.0
-    L = rng.randint(2_000_000, 20_000_000, m)
-    rN = np.maximum(rng.poisson(L * rng.choice([0.0005, 0.004, 0.01])), 5)
-    C = np.full((m, n), float(tau))
-    for j in range(1, n):
-        C[:, j] = rng.randint(0, k + 1, m)
-    mu = rng.dirichlet(np.ones(n) * 3)
-    p = (C * rN[:, None]) @ mu
-    p = p / p.sum()
-    r = np.maximum(rng.multinomial(int(rN.sum() * rng.uniform(0.8, 1.5)), p), 1)
-    rs, rNs, order = orc.sort_r([int(x) for x in rN], [int(x) for x in r])
-    lb = [int(x) for x in rng.randint(0, 2, m)]
-    ub = [int(x) for x in rng.randint(max(1, k - 1), k + 1, m)]
-    return dict(seed=seed, n=n, m=m, k=k, tau=tau, mx=mx, r=rs, rN=rNs, order=order, lb=lb, ub=ub)
+    return campaign.instance(seed, n, SHAPE)
 
 
 def oracle_side(inst):
@@ -86,8 +39,7 @@ def oracle_side(inst):
     t = time.time()
     best, cnt = orc.search_single(inst["n"], inst["m"], inst["tau"], list(inst["lb"]), list(inst["ub"]), inst["r"], inst["rN"],
                                   inst["mx"], inst["order"])
-    best = [b for b in best if b[2] == b[2]]
-    return inst["seed"], inst["n"], cnt, [(np.asarray(b[0]).tolist(), [float(x) for x in b[1]], float(b[2])) for b in best], time.time() - t
+    return inst["seed"], inst["n"], cnt, campaign.best_to_plain(best), time.time() - t
 
 
 def main():
@@ -171,25 +123,10 @@ def main():
         elif bool(ref) != bool(g["best"]):
             ok, why = False, "one side empty (ref %d, gpu %d)" % (len(ref), len(g["best"]))
         else:
-            def same(x, y):
-                if x[0] != y[0] or abs(x[2] - y[2]) > 1e-6 * abs(y[2]):
-                    return False
-                Cm = np.array(x[0])
-                if Cm.shape[1] == 3 and np.linalg.matrix_rank(np.column_stack([np.ones(len(Cm)), Cm[:, 1], Cm[:, 2]])) < 3:
-                    return True          # rank-deficient candidate: the minimiser is a line, mu is not determined
-                return max(abs(u - v) for u, v in zip(x[1], y[1])) < 1e-6
-            if inst["n"] == 2:
-                if len(ref) != len(g["best"]) or not all(same(x, y) for x, y in zip(g["best"], ref)):
-                    ok, why = False, "best lists differ"
-            else:
-                if not same(g["best"][0], ref[0]):
-                    # the first entries may differ only if both are in each other's tie window and the GPU's list holds the ref's
-                    ok = any(same(x, ref[0]) for x in g["best"]) and abs(g["best"][0][2] - ref[0][2]) <= 1e-3
-                    why = "" if ok else "winner differs"
-                it = iter(g["best"])
-                if ok and not all(any(x[0] == y[0] for x in it) for y in ref):
-                    ok, why = False, "reference tie entry missing from the GPU list"
-                out[tag]["gpu_extra_tie_entries"] += max(0, len(g["best"]) - len(ref))
+            # COMPLETE lists, entry by entry, NaN entries included (tests/campaign.py)
+            why = campaign.compare_best(g["best"], ref)
+            ok = why == ""
+            if inst["n"] == 3:
                 out[tag]["parity_uncertain_flagged"] += int(g["uncertain"])
         if ok:
             out[tag]["agree"] += 1
