@@ -455,7 +455,8 @@ def test_config3_shape_rank_ranges_and_tight_bounds_parity(ctx):
         any_ok, mu_b, nll_b, _ = ctx.solve_batch(3, 2, rs, rNs, C, 1.0, want_vals=False)
         ok = any_ok & ~ctx.last_solve_fallback              # the reference's fsolve ends in [0,1]^3: own optimum
         fused_ok = ~np.isnan(nll)                           # the likelihood has its minimum in the simplex
-        assert (ok & ~fused_ok).sum() <= 20                 # in range => minimum in the simplex (borderline cases aside)
+        zero_col = (C[:, :, 0].sum(axis=1) == 0) | (C[:, :, 1].sum(axis=1) == 0)   # reported by the reference off its NaN path
+        assert (ok & ~fused_ok & ~zero_col).sum() <= 20     # in range => minimum in the simplex (borderline cases aside)
         assert (fused_ok & ~ok).sum() <= 0.25 * max(fused_ok.sum(), 80)   # ... but fsolve does not find every such minimum
         both = ok & fused_ok
         if both.any():

@@ -214,7 +214,7 @@ def test_config4_tight_bounds_against_the_oracle(ctx):
     ref, lowest = [], float("inf")
     for Cm, s in seq_solns:
         L = s[1]
-        if orc.is_close([L], [lowest]):
+        if orc.is_close(L, lowest):
             ref.append((orc.reverse_sort_C(Cm, order), s[0], L))
         elif L < lowest:
             ref, lowest = [(orc.reverse_sort_C(Cm, order), s[0], L)], L

@@ -292,6 +292,9 @@ class Problem:
         step = self.MAX_PER_CALL[self.n]
         running = self._probe(begin, end)
         bounds = [(b, min(b + step, end)) for b in range(begin, end, step)]
+        if not bounds:                                   # an empty range (or an empty space: theta_search says so)
+            self.last_suspects, self.last_degenerate = ([], np.zeros(0), None), ([], None)
+            return self._search_once(begin, end, window, cap)
         parts, hints = [], []
         for b, e in bounds:
             hints.append(running)
