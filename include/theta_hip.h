@@ -92,6 +92,8 @@ typedef struct theta_search_stats {
     uint64_t phase_cycles[8];/* shader cycles per kernel phase summed over waves (diagnostic):
                                 0 group tile, 1 leaf scan, 2 solver iterations, 3 values+tracking,
                                 4 prefix successor, 5 whole wave                               */
+    uint64_t survivors;      /* n=3 fast path: contenders the sieve kernel handed to the finish kernel */
+    uint64_t fallback_candidates; /* n=3 fast path: candidates of slices redone by the fused kernel (contender list full) */
 } theta_search_stats;
 
 /*
@@ -142,6 +144,8 @@ int theta_search_degenerate(theta_problem *p, int cap, uint64_t *rank, uint8_t *
  *   "n3_force_f64"   1: every Newton iteration in FP64 (default: packed FP32 coarse pass, FP64 for contenders)
  *   "n3_conv_l2"     coarse-pass threshold on the squared Newton decrement (default 1e-4)
  *   "n3_warm_blend"  weight of the previous optimum in a chunk's first warm start
+ *   "n3_sieve"       1 (default): the two-kernel fast path (sieve + finish, n3_sieve.hip) where it applies; 0: the fused
+ *                    kernel of n3.hip throughout (also used for the dump, the FP64 mode and m < 8)
  *   "n3_per_task"    candidates per wave task (0 = automatic), "n2_per_thread" candidates per thread (0 = automatic)
  * The THETA_N3_* environment variables of the same names only set the defaults at theta_problem_create.
  */

@@ -389,3 +389,84 @@ def test_two_processes_share_the_gpu_and_exchange_through_the_library(ctx):
             if got >= 2:
                 break
     assert done == 4
+
+
+# ---------------------------------------------------------------------------------------------------
+# the two implementations of the n=3 search: sieve + finish kernels (n3_sieve.hip) against the fused kernel (n3.hip)
+# ---------------------------------------------------------------------------------------------------
+def _both_paths(ctx, p, begin, end, r, rN, window=0.5):
+    out = []
+    for sieve in (1, 0):
+        p.set_option("n3_sieve", sieve)
+        res = p.search(begin, end, window=window)
+        sus_rk, sus_lb, sus_C = p.last_suspects
+        fb = set()
+        if len(sus_rk):          # the suspects that matter: those whose nu = 1/3 fallback value comes within the window
+            ok, mu, nll, _ = ctx.solve_batch(3, p.tau, r, rN, sus_C, 1.0, want_vals=False)
+            gmin = res["nll"].min() if len(res["nll"]) else np.inf
+            fb = set(rk for rk, o, v in zip(sus_rk, ok, nll) if o and v <= min(gmin, np.nanmin(np.where(ok, nll, np.inf))) + window)
+        out.append((res, fb, list(p.last_degenerate[0])))
+    p.set_option("n3_sieve", 1)
+    return out
+
+
+def test_sieve_and_fused_search_kernels_return_identical_lists(ctx):
+    import bench
+    import theta_amd
+    cases = []
+    r, rN, order = bench.synth()                                    # the bench's instance: m=50, k=6 (burst depth 4)
+    cases.append(("bench m50 k6", 50, r, rN, [0] * 50, [6] * 50, [(0, 1 << 22), ("mid", 1 << 24), ("end", 1 << 22)]))
+    r4, rN4, _ = bench.synth(seed=7, m=50, n=3, k=4)                # k=4 branches less: burst depth 6
+    cases.append(("m50 k4", 50, r4, rN4, [0] * 50, [4] * 50, [(0, 1 << 21), ("mid", 1 << 23)]))
+    r5, rN5, _ = bench.synth(seed=8, m=49, n=3, k=5)                # odd m
+    cases.append(("m49 k5", 49, r5, rN5, [0] * 49, [5] * 49, [("mid", 1 << 22)]))
+    r6, rN6, _ = bench.synth(seed=9, m=14, n=3, k=3)                # exhaustible, whole space, ragged bounds
+    cases.append(("m14 k3", 14, r6, rN6, [0, 0, 0, 0, 1, 1, 1, 1, 1, 1, 1, 2, 2, 2], [2, 2, 3, 3, 3, 3, 3, 3, 3, 3, 3, 3, 3, 3], [("all", None)]))
+    r7, rN7, _ = bench.synth(seed=10, m=9, n=3, k=3)
+    cases.append(("m9 k3", 9, r7, rN7, [0] * 9, [3] * 9, [("all", None)]))
+    total_surv = 0
+    for name, m, rr, rn, lb, ub, ranges in cases:
+        p = theta_amd.Problem(ctx, 3, m, 2, rr, rn, lb, ub, 1.0)
+        for where, span in ranges:
+            if where == "all":
+                b, e = 0, p.count
+            elif where == "mid":
+                b, e = p.count // 3, p.count // 3 + span
+            elif where == "end":
+                b, e = p.count - span, p.count
+            else:
+                b, e = where, where + span
+            (a, fa, da), (f, ff, df) = _both_paths(ctx, p, b, e, rr, rn)
+            assert a["stats"]["evaluated"] == f["stats"]["evaluated"] == e - b, (name, where)
+            assert a["stats"]["fallback_candidates"] == 0 or where == 0          # (only a stretch of near-ties may overflow the list)
+            assert a["rank"] == f["rank"] and len(a["rank"]) >= 1, (name, where, len(a["rank"]), len(f["rank"]))
+            assert np.array_equal(a["C"], f["C"])
+            assert np.allclose(a["nll"], f["nll"], rtol=1e-11, atol=0)
+            assert fa == ff, (name, where, len(fa), len(ff))
+            assert da == df
+            assert a["stats"]["dismissed"] > 0.5 * (e - b) or e - b < 1 << 16
+            total_surv += a["stats"]["survivors"]
+        p.close()
+    assert total_surv > 0
+
+
+def test_sieve_end_to_end_against_the_fused_driver(ctx):
+    """do_optimization_single with the fast path on and off on campaign instances (mid shape, m >= 10: the sieve applies)."""
+    import theta_amd
+    checked = 0
+    for seed in range(9800, 9900):
+        inst = campaign.instance(seed, 3, "mid")
+        cnt = campaign.count_candidates(inst)
+        if not (2000 <= cnt <= 3000000):
+            continue
+        fast = _gpu_best(inst)
+        os.environ["THETA_N3_SIEVE"] = "0"
+        try:
+            fused = _gpu_best(inst)
+        finally:
+            del os.environ["THETA_N3_SIEVE"]
+        assert campaign.compare_best(fast, fused, tol=1e-9) == "", seed
+        checked += 1
+        if checked >= 12:
+            break
+    assert checked >= 8

@@ -30,7 +30,7 @@ class SearchStats(C.Structure):
                 ("iterations", C.c_uint64), ("terms", C.c_uint64), ("list_overflow", C.c_uint64),
                 ("flops", C.c_uint64), ("flops_f32", C.c_uint64), ("dismissed", C.c_uint64), ("best_nll", C.c_double), ("rejected_bound", C.c_double),
                 ("rejected_rank", C.c_uint64 * 2), ("kernel_ms", C.c_double), ("setup_ms", C.c_double),
-                ("phase_cycles", C.c_uint64 * 8)]
+                ("phase_cycles", C.c_uint64 * 8), ("survivors", C.c_uint64), ("fallback_candidates", C.c_uint64)]
 
     def as_dict(self):
         d = {k: getattr(self, k) for k, _ in self._fields_ if k not in ("rejected_rank", "phase_cycles")}
@@ -317,7 +317,8 @@ class Problem:
         stats = dict(parts[0][0]["stats"])
         for p, _s, _d, _g in parts[1:]:
             for k, v in p["stats"].items():
-                if k in ("evaluated", "accepted", "degenerate", "iterations", "terms", "list_overflow", "flops", "flops_f32", "dismissed"):
+                if k in ("evaluated", "accepted", "degenerate", "iterations", "terms", "list_overflow", "flops", "flops_f32", "dismissed",
+                         "survivors", "fallback_candidates"):
                     stats[k] += v
                 elif k in ("kernel_ms", "setup_ms"):
                     stats[k] += v

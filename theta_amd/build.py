@@ -18,6 +18,7 @@ UNITS = [
     ("n2.hip", []),
     ("n3.hip", []),
     ("n3_enum.hip", []),
+    ("n3_sieve.hip", []),
     ("batch.hip", ["-ffp-contract=off"]),
     ("api.hip", []),
     ("comm.hip", []),

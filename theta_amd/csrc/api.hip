@@ -10,6 +10,7 @@
 
 #include "n2.hpp"
 #include "n3_core.hpp"
+#include "n3_sieve.hpp"
 
 // ---- implemented in n2.hip / n3.hip / batch.hip ------------------------------------------------
 void n2_launch_search(const N2Dev &P, const SearchArgs &A, unsigned long long begin, unsigned long long end,
@@ -122,6 +123,9 @@ extern "C" int theta_device_info(theta_ctx *c, char *name, int cap, int *cu, uin
 #define SUS_CAP (1u << 20)
 #define DEG_CAP (1u << 16)
 #define N3_MAX_TASKS (1 << 18)
+#define SURV_CAP (1u << 20)           /* contenders per slice of the sieve (151 MB) */
+#define SIEVE_SLICE (1ull << 29)     /* candidates per sieve launch; the finish kernel runs in between and lowers the minimum */
+#define SIEVE_MAX_SLICES 64
 
 struct theta_problem {
     theta_ctx *ctx = nullptr;
@@ -139,7 +143,9 @@ struct theta_problem {
     double hint = INFINITY;            // upper bound of the minimum known to the caller (theta_problem_hint), one-shot
     uint64_t opt_per_task = 0;         // n=3 candidates per wave task (0: automatic), theta_problem_set_option
     int opt_per_thread = 0;            // n=2 candidates per thread (0: automatic)
-    DevBuf d_r, d_rN, d_small, d_P, d_PR, d_PN, d_cnt, d_ctr, d_list, d_tasks, d_stbuf, d_misc, d_smask, d_dynmask, d_sus, d_deg;
+    int opt_sieve = 1;                 // n=3: sieve + finish kernels (n3_sieve.hip); 0 = the fused kernel of n3.hip only
+    uint64_t last_survivors = 0, last_fallback = 0;   // of the last search: contenders listed by the sieve / candidates redone fused
+    DevBuf d_r, d_rN, d_small, d_P, d_PR, d_PN, d_cnt, d_ctr, d_list, d_tasks, d_stbuf, d_misc, d_smask, d_dynmask, d_sus, d_deg, d_surv, d_survcnt;
 };
 
 static int upload(DevBuf &b, const void *src, size_t bytes, hipStream_t st) {
@@ -299,6 +305,7 @@ extern "C" int theta_problem_create(theta_ctx *ctx, int n, int m, int tau, const
         if (const char *e = getenv("THETA_N3_CONV_L2")) D.conv_l2 = atof(e);
         D.no_dismiss = 0;
         if (const char *e = getenv("THETA_N3_NO_DISMISS")) D.no_dismiss = atoi(e) != 0;
+        if (const char *e = getenv("THETA_N3_SIEVE")) p->opt_sieve = atoi(e) != 0;
         D.N = (double)N;
         D.Rtot = (double)Rt;
         D.K0 = (double)k0;
@@ -375,6 +382,7 @@ extern "C" int theta_problem_set_option(theta_problem *p, const char *name, doub
     else if (k == "n3_no_dismiss") p->n3.no_dismiss = value != 0.0;
     else if (k == "n3_conv_l2" && value > 0.0) p->n3.conv_l2 = value;
     else if (k == "n3_warm_blend" && value >= 0.0 && value <= 1.0) p->n3.warm_blend = value;
+    else if (k == "n3_sieve") p->opt_sieve = value != 0.0;
     else if (k == "n3_per_task" && (value == 0.0 || (value >= 64 && value <= 65535))) p->opt_per_task = (uint64_t)value;
     else if (k == "n2_per_thread" && (value == 0.0 || (value >= 1 && value <= 512))) p->opt_per_thread = (int)value;
     else {
@@ -439,6 +447,8 @@ static int run_search(theta_problem *p, u128 b, u128 e, double window, double *d
     kernel_ms = setup_ms = 0.0;
     unsigned long long list_dropped = 0;
     for (int pass = 0; pass < 3; pass++) {
+        int sieve_slices = 0, sieve_per_slice = 0, sieve_ntasks = 0;
+        uint64_t sieve_per_task = 0;
         HIP_TRY(hipMemcpyAsync(p->d_ctr.p, &hc, sizeof(hc), hipMemcpyHostToDevice, st));
         HIP_TRY(hipEventRecord(ctx->ev0, st));
         if (p->n == 2) {
@@ -474,13 +484,44 @@ static int run_search(theta_problem *p, u128 b, u128 e, double window, double *d
                 return THETA_ERR_ARG;
             }
             int ntasks = (int)nt;
-            n3_launch_tasks(p->n3, b, e, per_task, ntasks, (N3Task *)p->d_tasks.p, (unsigned *)p->d_stbuf.p, st);
-            HIP_TRY(hipEventRecord(ctx->ev1, st));
-            n3_launch_search(p->n3, A, (const N3Task *)p->d_tasks.p, (const unsigned *)p->d_stbuf.p, ntasks, per_task, st);
+            N3Dev PS = p->n3;
+            const int sieve_levels = (p->opt_sieve && !dump_nll && !p->n3.force64) ? n3_sieve_levels(p->n3) : 0;
+            if (sieve_levels > 0) {
+                // fast path (n3_sieve.hip): sieve kernel per slice of the range, finish kernel on its contenders in between
+                PS.L = sieve_levels;
+                if (!p->d_surv.p) {
+                    int rc = p->d_surv.alloc((size_t)SURV_CAP * sizeof(SvSurvivor));
+                    if (rc) return rc;
+                    if ((rc = p->d_survcnt.alloc(SIEVE_MAX_SLICES * sizeof(unsigned)))) return rc;
+                }
+                HIP_TRY(hipMemsetAsync(p->d_survcnt.p, 0, SIEVE_MAX_SLICES * sizeof(unsigned), st));
+                n3_launch_tasks(PS, b, e, per_task, ntasks, (N3Task *)p->d_tasks.p, (unsigned *)p->d_stbuf.p, st);
+                HIP_TRY(hipEventRecord(ctx->ev1, st));
+                int per_slice = (int)std::max<uint64_t>(1, SIEVE_SLICE / per_task);
+                while ((ntasks + per_slice - 1) / per_slice > SIEVE_MAX_SLICES) per_slice *= 2;
+                const int nslices = (ntasks + per_slice - 1) / per_slice;
+                unsigned *cnts = (unsigned *)p->d_survcnt.p;
+                for (int sl = 0; sl < nslices; sl++) {
+                    const int t0 = sl * per_slice, nts = std::min(per_slice, ntasks - t0);
+                    n3_launch_sieve(PS, A, (const N3Task *)p->d_tasks.p + t0, (const unsigned *)p->d_stbuf.p + (size_t)t0 * N3_MAX_M, nts,
+                                    (SvSurvivor *)p->d_surv.p, SURV_CAP, cnts + sl, st);
+                    n3_launch_finish(PS, A, (const SvSurvivor *)p->d_surv.p, SURV_CAP, cnts + sl, st);
+                }
+                sieve_slices = nslices;
+                sieve_per_slice = per_slice;
+                sieve_ntasks = ntasks;
+                sieve_per_task = per_task;
+            } else {
+                n3_launch_tasks(p->n3, b, e, per_task, ntasks, (N3Task *)p->d_tasks.p, (unsigned *)p->d_stbuf.p, st);
+                HIP_TRY(hipEventRecord(ctx->ev1, st));
+                n3_launch_search(p->n3, A, (const N3Task *)p->d_tasks.p, (const unsigned *)p->d_stbuf.p, ntasks, per_task, st);
+            }
         }
         HIP_TRY(hipEventRecord(ctx->ev2, st));
         SearchCounters got;
+        unsigned hcnt[SIEVE_MAX_SLICES];
         HIP_TRY(hipMemcpyAsync(&got, p->d_ctr.p, sizeof(got), hipMemcpyDeviceToHost, st));
+        if (sieve_slices) HIP_TRY(hipMemcpyAsync(hcnt, p->d_survcnt.p, sieve_slices * sizeof(unsigned), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
         HIP_TRY(hipGetLastError());
         float ms = 0;
@@ -488,6 +529,34 @@ static int run_search(theta_problem *p, u128 b, u128 e, double window, double *d
         kernel_ms += ms;
         HIP_TRY(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
         setup_ms += ms;
+        // A slice of the sieve whose contender list overflowed (a stretch of near-ties) is redone by the fused kernel, which is
+        // complete by itself; its records join the same device lists (theta_search drops duplicates by rank).
+        uint64_t redone = 0;
+        for (int sl = 0; sl < sieve_slices; sl++) {
+            if (hcnt[sl] <= SURV_CAP) continue;
+            const int t0 = sl * sieve_per_slice, nts = std::min(sieve_per_slice, sieve_ntasks - t0);
+            const u128 sb = b + (u128)t0 * sieve_per_task;
+            u128 se = sb + (u128)nts * sieve_per_task;
+            if (se > e) se = e;
+            HIP_TRY(hipEventRecord(ctx->ev0, st));
+            n3_launch_tasks(p->n3, sb, se, sieve_per_task, nts, (N3Task *)p->d_tasks.p, (unsigned *)p->d_stbuf.p, st);
+            HIP_TRY(hipEventRecord(ctx->ev1, st));
+            n3_launch_search(p->n3, A, (const N3Task *)p->d_tasks.p, (const unsigned *)p->d_stbuf.p, nts, sieve_per_task, st);
+            HIP_TRY(hipEventRecord(ctx->ev2, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipEventElapsedTime(&ms, ctx->ev1, ctx->ev2));
+            kernel_ms += ms;
+            HIP_TRY(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+            setup_ms += ms;
+            redone += (uint64_t)(se - sb);
+        }
+        if (redone) {
+            HIP_TRY(hipMemcpyAsync(&got, p->d_ctr.p, sizeof(got), hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            got.evaluated -= redone;         // (counted once by the sieve, once more by the fused kernel)
+        }
+        p->last_fallback = redone;
         if (got.list_count <= LIST_CAP || pass == 2) {
             unsigned long long dropped = got.list_count > LIST_CAP ? got.list_count - LIST_CAP : 0;
             hc = got;
@@ -563,10 +632,13 @@ extern "C" int theta_search(theta_problem *p, const uint64_t rank_begin[2], cons
         if (p->n == 2) {
             stats->flops = (uint64_t)(per * (double)hc.terms + fin * (double)hc.final_terms);
             stats->flops_f32 = 0;
-        } else {   // n=3: FP64 iterations (dump, ill-conditioned candidates) + the packed-f32 coarse pass and screen
-            stats->flops = (uint64_t)(per * (double)hc.terms64);
+        } else {   // n=3: FP64 iterations (dump, ill-conditioned candidates, the finish kernel: m terms each) + the packed-f32
+                   // coarse pass and screen
+            stats->flops = (uint64_t)(per * ((double)hc.terms64 + (double)hc.finish_iterations * (double)p->m));
             stats->flops_f32 = (uint64_t)(FLOPS_PER_TERM_ITER_N3_F32 * (double)(hc.terms - hc.terms64) + fin * (double)hc.final_terms);
         }
+        stats->survivors = hc.sieve_survivors;
+        stats->fallback_candidates = p->last_fallback;
         stats->best_nll = best;
         stats->rejected_bound = order_unbits(hc.rej_bits);
         stats->rejected_rank[0] = hc.rej_rank_lo;
@@ -587,10 +659,15 @@ extern "C" int theta_search(theta_problem *p, const uint64_t rank_begin[2], cons
         for (const TieRecord &t : p->suspects)
             if (t.nll <= best + window) sk.push_back(t);
         std::sort(sk.begin(), sk.end(), by_rank);
+        sk.erase(std::unique(sk.begin(), sk.end(), [](const TieRecord &x, const TieRecord &y) {
+                     return x.rank_hi == y.rank_hi && x.rank_lo == y.rank_lo; }), sk.end());
         p->suspects.swap(sk);
     }
+    auto same_rank = [](const TieRecord &x, const TieRecord &y) { return x.rank_hi == y.rank_hi && x.rank_lo == y.rank_lo; };
     std::sort(keep.begin(), keep.end(), by_rank);
+    keep.erase(std::unique(keep.begin(), keep.end(), same_rank), keep.end());     // (a slice redone by the fused kernel lists twice)
     std::sort(p->degenerate.begin(), p->degenerate.end(), by_rank);
+    p->degenerate.erase(std::unique(p->degenerate.begin(), p->degenerate.end(), same_rank), p->degenerate.end());
     *n_out = (int)keep.size();
     if ((int)keep.size() > cap) {
         theta_set_error("%zu candidates within the window but capacity is %d", keep.size(), cap);

@@ -81,6 +81,8 @@ struct SearchCounters {
     unsigned int sus_count;            // suspects appended (may exceed capacity; never triggers a re-run)
     unsigned int deg_count;            // n=3: candidates with an all-zero tumour column appended to the degenerate list
     unsigned int pad0;
+    unsigned long long sieve_survivors;   // n=3 fast path: contenders the sieve kernel handed to the finish kernel
+    unsigned long long finish_iterations; // ... and the FP64 Newton iterations (m terms each) that kernel ran on them
     unsigned long long prof[8];        // shader cycles per kernel phase, summed over waves (diagnostic)
 };
 

@@ -1,0 +1,777 @@
+// n = 3 search, fast path for gfx950: a SIEVE kernel fed by the breadth-first burst enumerator, and a FINISH kernel for
+// the few candidates the sieve cannot dispose of.
+//
+// Reference operators replaced (file:line into the reference's python/): the same as n3.hip --
+//   Enumerator._generate_next_C_3(_recurse), _in_bounds, _get_mu_bounds          Enumerator.py:172-242
+//   Optimizer._solve_n3plus + equations / jacobian / M3 / L3                      Optimizer.py:128-165, 236-330
+//   the running minimum of do_optimization_single                                 RunTHetA.py:191-208
+//
+// Why two kernels.  In the fused kernel of n3.hip 99.998 % of the candidates of a large search are finished by a rigorous
+// lower bound of their optimum after ONE packed-FP32 evaluation, yet every wave carries the machinery of the other
+// 0.002 % (queue solver, values pass, polish, the hybrj restatement of the reference's outcome): 168 VGPRs plus spills, and
+// 9 of its 12.5 vector instructions per candidate are lane-private DFS and queue bookkeeping (profiles/r1).  Here:
+//
+//   n3_sieve_kernel   one wave per rank range.  The last LB rows of the matrices are expanded breadth-first, level by level,
+//                     all 64 lanes on 64 nodes of one level (the scheme of the materialised generator, n3_enum.hip: child
+//                     mask = static rules & symmetry & ratio window, DPP scan of the child counts, children written to the
+//                     next level's list in LDS); the last level's list is a BURST of <= 512 records = candidates.  Lane l
+//                     takes records l G .. (l+1) G - 1 of the burst, so a lane walks consecutive leaves and starts each
+//                     from the optimum of its previous one; ONE packed-FP32 evaluation (value, gradient, Hessian over the
+//                     prefix's group tile + the record's own rows) gives the self-concordance lower bound
+//                         min NLL >= NLL(u) - lambda^2 / (2 (1 - lambda / sqrt(Rmin)))
+//                     and a candidate whose bound lies beyond the window of the running minimum is DONE.  The others take
+//                     further Newton steps from a small LDS queue (64 at a time); what is still within the window once
+//                     converged -- a contender -- is written, rows and rank, to a device list.  No DFS stack, no values
+//                     pass, no cold path: the hot loop is the evaluation and little else.
+//   n3_finish_kernel  one LANE per listed contender: FP64 Newton per interval from the simplex centre, polish, admissibility
+//                     (Optimizer.py:150-160), exact NLL, and for what is within the window the reference's own outcome
+//                     (hybrj / BFGS restatement, n3_refbfgs.hpp) -- then the tie list, the suspect list and the device-wide
+//                     minimum exactly as n3.hip's cold path maintains them.
+//
+// The fused kernel of n3.hip stays: it is the --GET_VALUES dump, the FP64 / no-dismissal modes, the path for m < 8, the
+// fallback for a slice whose contender list overflows (a stretch of near-ties), and the second implementation the tests
+// compare this one with (identical finalists).
+#include <stddef.h>
+
+#include <type_traits>
+
+#include "n3_core.hpp"
+#define HYBRJ4_MANAGE_CONTRACT     // this unit allows fused multiply-adds; the hybrj restatement must not use them
+#include "n3_refbfgs.hpp"
+#include "n3_sieve.hpp"
+
+#define SV_WAVES 4
+#ifndef SV_CAP
+#define SV_CAP 128        // nodes per intermediate level list
+#endif
+#ifndef SV_QCAP
+#define SV_QCAP 128       // records waiting for further Newton steps
+#endif
+#ifndef SV_OCC
+#define SV_OCC 4          // blocks per CU the register budget is sized for
+#endif
+#ifndef SV_TRIES
+#define SV_TRIES 2        // evaluations a record may take in place when many lanes need another
+#endif
+
+template <int ML> struct SvCapR { static constexpr int v = ML <= 4 ? 512 : 288; };   // records per burst
+
+template <int ML>
+struct SvWave {
+    alignas(16) unsigned short pre[N3_MAX_M + 8];       // rows of the prefix, a | b << 8
+    uint2 list0[N3_MAX_Q];                              // level 1 nodes (children of the prefix's last node)
+    uint2 list[ML > 2 ? ML - 2 : 1][SV_CAP];            // level l >= 2: {packed parent node, ancestor slots (6 bits each) | slot << 24}
+    alignas(8) unsigned lwr[(SvCapR<ML>::v + 4) * (ML / 2)];   // the burst: ML rows per record, two rows {a, b, a, b} per dword
+    float4 fXY[(N3_MAX_Q + 2) / 2];                     // group tile of the prefix, two terms per entry {a0, a1, b0, b1}
+    float2 fRR[(N3_MAX_Q + 2) / 2];                     // ... and their weights {R0, R1} (an odd last term is paired with weight 0)
+    float2 fRL[ML / 2];                                 // weights of the leaf rows, paired
+    unsigned qRow[SV_QCAP][ML / 2];                     // queue: rows of a record that needs more Newton steps
+    float qU1[SV_QCAP], qU2[SV_QCAP];                   // ... the iterate it continues from
+    unsigned short qOff[SV_QCAP];                       // ... and its offset in the task (rank = task base + offset)
+};
+template <int ML>
+struct SvLds {
+    SvWave<ML> w[SV_WAVES];
+    unsigned long long smask[ML][N3_MAX_Q];             // static child masks of the ML last depths
+    unsigned char lb[N3_MAX_M], ub[N3_MAX_M];
+    unsigned char ridx[N3_RIDX_W * N3_RIDX_W + 3];
+    unsigned char rowtab[N3_MAX_Q + 3];
+    unsigned short row16[N3_MAX_Q];                     // slot -> a | b << 8
+};
+
+// inclusive scan over the wave with DPP row shifts / broadcasts (no LDS traffic)
+__device__ __forceinline__ int sv_incl_scan(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);   // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);   // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);   // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);   // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);   // row_bcast:15 into rows 1 and 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);   // row_bcast:31 into rows 2 and 3
+    return v;
+}
+
+// Everything a wave carries through the expansion (wave-uniform unless noted).
+template <int ML>
+struct SvCtx {
+    SvLds<ML> *S;
+    SvWave<ML> *W;
+    const unsigned long long *dynmask;
+    unsigned long long swm;
+    int NT1, lane, D, G, GP, m;
+    N3State par;
+    SearchArgs A;
+    SvSurvivor *surv;
+    unsigned surv_cap;
+    unsigned *surv_count;
+    u128 base;                       // rank of the task's first candidate
+    unsigned long long remaining, skip, done;    // candidates of the task still to come / to skip in the first prefix / done
+    // likelihood data of the current prefix
+    float S1p, S2p;                  // column sums of the prefix rows (weighted by the normal counts), / N
+    float leafN[ML];                 // normal counts of the leaf rows / N
+    float rtot_f, rtot_over_rmin, inv_Rtot, conv_l2;
+    double K0, screen_margin, thr;   // thr = running minimum + window, refreshed per prefix
+    int no_dismiss;
+    // lane-private chain: mixture fractions of the optimum of the lane's previous record
+    float wn1, wn2;
+    int qcount;
+    // statistics (wave-uniform scalars)
+    unsigned long long n_eval, n_dis, n_it, n_deg, n_surv;
+};
+
+typedef float sv2f __attribute__((ext_vector_type(2)));
+
+// One packed-FP32 evaluation of value, gradient and Hessian at (u1, u2) over the group tile and the record's rows, and the
+// Newton step.  The likelihood in the scaled variables of n3_core.hpp: q_i = 1 + (x_i - s1) u1 + (y_i - s2) u2,
+// NLL = K0 - sum R_i ln q_i.  Returns 0 = stepped (u1, u2 hold the new iterate; val2 = sum R log2 q and l2 = lambda^2 / Rtot
+// at the OLD one), 1 = stepped and converged (l2 < conv), 2 = outside the domain (u1, u2 halved towards 0), 3 = no usable
+// step (ill-conditioned Hessian, NaN).
+template <int ML>
+__device__ __forceinline__ int sv_step(const SvCtx<ML> &c, const unsigned (&rw)[ML / 2], float s1, float s2, float &u1, float &u2,
+                                       float &val2, float &l2) {
+    sv2f g1 = {0.f, 0.f}, g2 = g1, h11 = g1, h12 = g1, h22 = g1, lg = g1;
+    float qmin = __builtin_inff();
+    const sv2f vs1 = {s1, s1}, vs2 = {s2, s2}, vu1 = {u1, u1}, vu2 = {u2, u2}, one = {1.f, 1.f};
+    auto body = [&](sv2f x, sv2f y, sv2f R) {
+        sv2f a = x - vs1, b = y - vs2;
+        sv2f q = __builtin_elementwise_fma(a, vu1, __builtin_elementwise_fma(b, vu2, one));
+        qmin = fminf(qmin, fminf(q.x, q.y));
+        sv2f w = {__builtin_amdgcn_rcpf(q.x), __builtin_amdgcn_rcpf(q.y)};
+        lg = __builtin_elementwise_fma(R, sv2f{__builtin_amdgcn_logf(q.x), __builtin_amdgcn_logf(q.y)}, lg);
+        sv2f t = R * w;
+        g1 = __builtin_elementwise_fma(t, a, g1);
+        g2 = __builtin_elementwise_fma(t, b, g2);
+        sv2f tw = t * w;
+        sv2f ta = tw * a, tb = tw * b;
+        h11 = __builtin_elementwise_fma(ta, a, h11);
+        h12 = __builtin_elementwise_fma(ta, b, h12);
+        h22 = __builtin_elementwise_fma(tb, b, h22);
+    };
+    const float4 *fXY = c.W->fXY;
+    const float2 *fRR = c.W->fRR;
+#pragma unroll 2
+    for (int p = 0; p < c.GP; p++) {
+        const float4 xy = fXY[p];
+        const float2 rr = fRR[p];
+        body(sv2f{xy.x, xy.y}, sv2f{xy.z, xy.w}, sv2f{rr.x, rr.y});
+    }
+#pragma unroll
+    for (int j = 0; j < ML / 2; j++) {
+        const float2 rr = c.W->fRL[j];
+        const unsigned d = rw[j];      // bytes {a, b, a', b'}
+        body(sv2f{(float)(d & 0xffu), (float)((d >> 16) & 0xffu)}, sv2f{(float)((d >> 8) & 0xffu), (float)(d >> 24)}, sv2f{rr.x, rr.y});
+    }
+    if (!(qmin > 0.0f)) {
+        u1 *= 0.5f;
+        u2 *= 0.5f;
+        return 2;
+    }
+    const float G1 = g1.x + g1.y, G2 = g2.x + g2.y;
+    const float H11 = h11.x + h11.y, H12 = h12.x + h12.y, H22 = h22.x + h22.y;
+    const float hh = H11 * H22;
+    const float det = __builtin_fmaf(-H12, H12, hh);
+    if (!(det > (float)N3_COND_MIN * hh)) return 3;
+    const float idet = __builtin_amdgcn_rcpf(det);
+    const float d1 = (H22 * G1 - H12 * G2) * idet;
+    const float d2 = (H11 * G2 - H12 * G1) * idet;
+    l2 = (G1 * d1 + G2 * d2) * c.inv_Rtot;
+    val2 = lg.x + lg.y;
+    if (!(l2 == l2) || !(fabsf(d1) + fabsf(d2) < 1e30f)) return 3;
+    float step = 1.0f;
+    if (l2 > 0.09f) step = __builtin_amdgcn_rcpf(1.0f + __builtin_sqrtf(l2));
+    u1 = __builtin_fmaf(step, d1, u1);
+    u2 = __builtin_fmaf(step, d2, u2);
+    return l2 < c.conv_l2 ? 1 : 0;
+}
+
+// Is the candidate finished by the lower bound of its optimum?  (evaluated at the iterate BEFORE the step)
+template <int ML>
+__device__ __forceinline__ bool sv_dismissed(const SvCtx<ML> &c, float val2, float l2) {
+    const float lt2 = l2 * c.rtot_over_rmin;
+    if (!(lt2 < 0.25f) || c.no_dismiss) return false;
+    const float lt = __builtin_sqrtf(lt2);
+    const double gap = 1.05 * 0.5 * (double)(l2 * c.rtot_f * __builtin_amdgcn_rcpf(1.0f - lt));
+    const double lb = (c.K0 - 0.6931471805599453 * (double)val2) - gap - c.screen_margin;
+    return lb > c.thr;
+}
+
+// column sums / N of a record: (s1, s2); false if a tumour column is all zero (degenerate: the reference's Chat is NaN)
+template <int ML>
+__device__ __forceinline__ bool sv_sums(const SvCtx<ML> &c, const unsigned (&rw)[ML / 2], float &s1, float &s2) {
+    float a = c.S1p, b = c.S2p;
+#pragma unroll
+    for (int j = 0; j < ML / 2; j++) {
+        const unsigned d = rw[j];
+        a = __builtin_fmaf((float)(d & 0xffu), c.leafN[2 * j], a);
+        b = __builtin_fmaf((float)((d >> 8) & 0xffu), c.leafN[2 * j], b);
+        a = __builtin_fmaf((float)((d >> 16) & 0xffu), c.leafN[2 * j + 1], a);
+        b = __builtin_fmaf((float)(d >> 24), c.leafN[2 * j + 1], b);
+    }
+    s1 = a;
+    s2 = b;
+    return a > 0.0f && b > 0.0f;
+}
+
+// A contender (or a record the sieve cannot handle): rows and rank to the device list; the finish kernel takes it from there.
+template <int ML>
+__device__ __forceinline__ void sv_survivor(const SvCtx<ML> &c, const unsigned (&rw)[ML / 2], unsigned off) {
+    const unsigned idx = atomicAdd(c.surv_count, 1u);
+    if (idx >= c.surv_cap) return;            // the host sees the count and redoes the slice with the fused kernel
+    SvSurvivor *s = c.surv + idx;
+    const u128 rk = c.base + off;
+    s->rank_lo = (uint64_t)rk;
+    s->rank_hi = (uint64_t)(rk >> 64);
+    unsigned short *dst = (unsigned short *)s->rows;
+    for (int i = 0; i < c.D; i++) dst[i] = c.W->pre[i];
+#pragma unroll
+    for (int j = 0; j < ML / 2; j++) {
+        dst[c.D + 2 * j] = (unsigned short)(rw[j] & 0xffffu);
+        dst[c.D + 2 * j + 1] = (unsigned short)(rw[j] >> 16);
+    }
+}
+
+// Further Newton steps for the queued records, 64 at a time: until dismissed, converged (a contender) or given up.
+template <int ML>
+__device__ __forceinline__ void sv_drain(SvCtx<ML> &c) {
+    for (int b0 = 0; b0 < c.qcount; b0 += WAVE) {
+        const int idx = b0 + c.lane;
+        bool live = idx < c.qcount;
+        unsigned rw[ML / 2];
+#pragma unroll
+        for (int j = 0; j < ML / 2; j++) rw[j] = live ? c.W->qRow[idx][j] : 0u;
+        float u1 = live ? c.W->qU1[idx] : 0.f, u2 = live ? c.W->qU2[idx] : 0.f;
+        const unsigned off = live ? c.W->qOff[idx] : 0u;
+        float s1 = 1.f, s2 = 1.f;
+        sv_sums<ML>(c, rw, s1, s2);
+        int iters = 0;
+        bool surv = false;
+        while (ballot64(live)) {
+            c.n_it += (unsigned)__builtin_popcountll(ballot64(live));
+            if (live) {
+                float val2 = 0.f, l2 = 0.f;
+                const int st = sv_step<ML>(c, rw, s1, s2, u1, u2, val2, l2);
+                iters++;
+                if (st == 3 || iters >= 40) {
+                    surv = true;                 // ill-conditioned / stuck: the finish kernel solves it in FP64
+                    live = false;
+                } else if (st != 2) {
+                    if (sv_dismissed<ML>(c, val2, l2)) {
+                        live = false;
+                    } else if (st == 1) {
+                        // converged to the coarse tolerance: the step just taken leaves an NLL error far inside the screening
+                        // margin, so the value at the old iterate less lambda^2/2 is the optimum to that accuracy
+                        const double v = (c.K0 - 0.6931471805599453 * (double)val2) - 0.5 * (double)(l2 * c.rtot_f) - c.screen_margin;
+                        surv = !(v > c.thr);     // within the window of the running minimum: a contender
+                        live = false;
+                    }
+                }
+            }
+        }
+        if (!c.no_dismiss) c.n_dis += (unsigned)__builtin_popcountll(ballot64(idx < c.qcount && !surv));
+        c.n_surv += (unsigned)__builtin_popcountll(ballot64(surv));
+        if (surv) sv_survivor<ML>(c, rw, off);
+        // the lane keeps the last optimum it saw as a start for later records
+        if (idx < c.qcount && fabsf(s1 * u1) + fabsf(s2 * u2) < 1e6f) {
+            c.wn1 = s1 * u1;
+            c.wn2 = s2 * u2;
+        }
+    }
+    c.qcount = 0;
+}
+
+// The records [0, total) of the burst (less the task window): first evaluation in place, the rest to the queue.
+template <int ML>
+__device__ __forceinline__ void sv_burst(SvCtx<ML> &c, int total) {
+    const unsigned long long sk = c.skip < (unsigned long long)total ? c.skip : (unsigned long long)total;
+    c.skip -= sk;
+    const int lo = (int)sk;
+    const unsigned long long room = (unsigned long long)(total - lo);
+    const int nrec = (int)(room < c.remaining ? room : c.remaining);
+    if (nrec <= 0) return;
+    const int per = (nrec + WAVE - 1) / WAVE;            // records per lane, consecutive
+    const int first = c.lane * per;
+    for (int j = 0; j < per; j++) {
+        const int k = first + j;
+        const bool act = k < nrec;
+        unsigned rw[ML / 2];
+#pragma unroll
+        for (int q = 0; q < ML / 2; q++) rw[q] = act ? c.W->lwr[(lo + k) * (ML / 2) + q] : 0u;
+        float s1 = 1.f, s2 = 1.f;
+        const bool regular = sv_sums<ML>(c, rw, s1, s2);
+        const unsigned off = (unsigned)(c.done + (unsigned long long)k);
+        bool ev = act && regular;
+        if (act && !regular) degenerate_append(c.A.ctr, c.A.deg, c.A.deg_cap, c.base + off);
+        c.n_deg += (unsigned)__builtin_popcountll(ballot64(act && !regular));
+        // start: the optimum of the lane's previous record, pulled slightly towards the simplex centre (interior for every
+        // candidate); a start outside the domain is halved towards u = 0
+        float u1 = __builtin_fmaf(0.98f, c.wn1, 0.02f / 3.0f) * __builtin_amdgcn_rcpf(s1);
+        float u2 = __builtin_fmaf(0.98f, c.wn2, 0.02f / 3.0f) * __builtin_amdgcn_rcpf(s2);
+        bool push = false, surv = false;
+        for (int tries = 0;; tries++) {
+            const unsigned long long evm = ballot64(ev);
+            if (!evm) break;
+            if (tries >= SV_TRIES || (tries > 0 && __builtin_popcountll(evm) < 16)) {
+                push = ev;                   // few lanes left: they continue from the queue, 64 at a time
+                break;
+            }
+            c.n_it += (unsigned)__builtin_popcountll(evm);
+            if (ev) {
+                float val2 = 0.f, l2 = 0.f;
+                const int st = sv_step<ML>(c, rw, s1, s2, u1, u2, val2, l2);
+                if (st == 3) {
+                    surv = true;
+                    ev = false;
+                } else if (st != 2) {
+                    if (fabsf(s1 * u1) + fabsf(s2 * u2) < 1e6f) {     // the stepped iterate starts the lane's next record
+                        c.wn1 = s1 * u1;
+                        c.wn2 = s2 * u2;
+                    }
+                    if (sv_dismissed<ML>(c, val2, l2)) {
+                        ev = false;
+                    } else if (st == 1) {
+                        const double v = (c.K0 - 0.6931471805599453 * (double)val2) - 0.5 * (double)(l2 * c.rtot_f) - c.screen_margin;
+                        surv = !(v > c.thr);
+                        ev = false;
+                    }
+                }
+            }
+        }
+        c.n_eval += (unsigned)__builtin_popcountll(ballot64(act));
+        if (!c.no_dismiss) c.n_dis += (unsigned)__builtin_popcountll(ballot64(act && regular && !push && !surv));
+        c.n_surv += (unsigned)__builtin_popcountll(ballot64(surv));
+        if (surv) sv_survivor<ML>(c, rw, off);
+        const unsigned long long pm = ballot64(push);
+        if (pm) {
+            if (c.qcount + __builtin_popcountll(pm) > SV_QCAP) sv_drain<ML>(c);
+            if (push) {
+                const int pos = c.qcount + mbcnt(pm);
+#pragma unroll
+                for (int q = 0; q < ML / 2; q++) c.W->qRow[pos][q] = rw[q];
+                c.W->qU1[pos] = u1;
+                c.W->qU2[pos] = u2;
+                c.W->qOff[pos] = (unsigned short)off;
+            }
+            c.qcount += __builtin_popcountll(pm);
+            wave_lds_sync();
+        }
+    }
+    c.done += (unsigned long long)nrec;
+    c.remaining -= (unsigned long long)nrec;
+}
+
+template <int ML>
+__device__ __forceinline__ unsigned long long sv_child_mask(const SvCtx<ML> &c, const N3State &node, int l) {
+    unsigned long long mk = c.S->smask[l][node.slot] & c.dynmask[((size_t)node.slot * c.NT1 + node.lo) * c.NT1 + (node.hi - 1)];
+    return node.sw ? (mk & c.swm) : mk;
+}
+
+// Expand the nodes of leaf level LVL (LVL = 0: the prefix's last node; else the level's list [0 .. n_in)) in rank order.
+template <int ML, int LVL>
+__device__ __forceinline__ void sv_expand(SvCtx<ML> &c, int n_in) {
+    constexpr bool last = (LVL == ML - 1);
+    const int cap = last ? SvCapR<ML>::v : (LVL == 0 ? N3_MAX_Q : SV_CAP);
+    int pos = 0;
+    while (pos < n_in) {
+        const int i = pos + c.lane;
+        bool live = i < n_in;
+        N3State node = c.par;
+        unsigned code = 0;                                 // slots of rows D .. D+LVL-1, 6 bits each
+        if (LVL > 0) {
+            if (live) {
+                const uint2 e = (LVL == 1) ? c.W->list0[i] : c.W->list[LVL >= 2 ? LVL - 2 : 0][i];
+                const N3State pst = n3_unpack(e.x);
+                const unsigned slot = e.y >> 24;
+                n3_child_dyn(c.S->ridx, c.S->rowtab, pst, (int)slot, node);
+                code = (e.y & 0xffffffu) | (slot << (6 * (LVL > 0 ? LVL - 1 : 0)));
+            }
+        } else {
+            live = c.lane == 0;
+        }
+        unsigned long long mk = live ? sv_child_mask(c, node, LVL) : 0ull;
+        const int cnt = __builtin_popcountll(mk);
+        const int incl = sv_incl_scan(cnt);
+        const int t = __builtin_popcountll(ballot64(live && incl <= cap));   // nodes whose children all fit (a prefix of the lanes)
+        const int total = __builtin_amdgcn_readlane(incl, t - 1);
+        const int off = incl - cnt;
+        const bool take = live && c.lane < t;
+        if constexpr (last) {
+            if (take) {
+                // rows 0 .. LVL-1 of the record are the node's ancestors and itself (the same for all its children)
+                unsigned un[ML / 2];
+#pragma unroll
+                for (int j = 0; j < ML / 2; j++) {
+                    un[j] = c.S->row16[(code >> (12 * j)) & 63u];
+                    if (j < ML / 2 - 1) un[j] |= (unsigned)c.S->row16[(code >> (12 * j + 6)) & 63u] << 16;
+                }
+                unsigned *dst = c.W->lwr + off * (ML / 2);
+                while (mk) {
+                    const int s = __builtin_ctzll(mk);
+                    mk &= mk - 1;
+#pragma unroll
+                    for (int j = 0; j < ML / 2 - 1; j++) dst[j] = un[j];
+                    dst[ML / 2 - 1] = un[ML / 2 - 1] | ((unsigned)c.S->row16[s] << 16);
+                    dst += ML / 2;
+                }
+            }
+            wave_lds_sync();
+            sv_burst<ML>(c, total);
+            wave_lds_sync();
+        } else {
+            const unsigned ps = n3_pack(node);
+            if (take) {
+                uint2 *dst = ((LVL == 0) ? c.W->list0 : c.W->list[LVL >= 1 ? LVL - 1 : 0]) + off;
+                while (mk) {
+                    const int s = __builtin_ctzll(mk);
+                    mk &= mk - 1;
+                    *dst++ = make_uint2(ps, code | ((unsigned)s << 24));
+                }
+            }
+            wave_lds_sync();
+            sv_expand<ML, LVL + 1>(c, total);
+            wave_lds_sync();
+        }
+        if (c.remaining == 0) return;
+        pos += t;
+    }
+}
+
+// Next prefix in DFS order (wave-uniform): lane d holds the packed node of depth d.  Returns false at the end of the space.
+__device__ __forceinline__ bool sv_next_prefix(const N3Dev &P, unsigned &st, int D, int lane) {
+    const int K1 = P.K + 1, Q = P.Q;
+    const int sa = lane % K1, sb = lane / K1;          // Q <= 64: one alphabet slot per lane
+    int d = D - 1;
+    bool fresh = false;
+    while (true) {
+        const int cur_slot = __builtin_amdgcn_readlane((int)st, d) & 0x7f;
+        const int start = fresh ? 0 : cur_slot + 1;
+        const N3State pst = n3_unpack((unsigned)__builtin_amdgcn_readlane((int)st, d > 0 ? d - 1 : 0));
+        N3State nx{0, 0, 0, 0, 0, 0};
+        const bool ok = lane >= start && lane < Q &&
+                        (d == 0 ? n3_first_row_ab(P, sa, sb, lane, nx) : n3_edge_ab(P, pst, sa, sb, lane, d, nx));
+        const unsigned long long mk = ballot64(ok);
+        if (mk) {
+            const int first = __builtin_ctzll(mk);
+            const unsigned mine = ok ? n3_pack(nx) : 0u;
+            const unsigned packed = (unsigned)__builtin_amdgcn_readlane((int)mine, first);
+            if (lane == d) st = packed;
+            if (d == D - 1) return true;
+            d++;
+            fresh = true;
+        } else {
+            d--;
+            fresh = false;
+            if (d < 0) return false;
+        }
+    }
+}
+
+template <int ML>
+__global__ __launch_bounds__(64 * SV_WAVES, SV_OCC) void n3_sieve_kernel(N3Dev Pg, SearchArgs A, const N3Task *tasks, const unsigned *stbuf,
+                                                                          int ntasks, SvSurvivor *surv, unsigned surv_cap,
+                                                                          unsigned *surv_count) {
+    __shared__ SvLds<ML> S;
+    const int m = Pg.m, D = m - ML, Q = Pg.Q;
+    for (int i = threadIdx.x; i < m; i += blockDim.x) {
+        S.lb[i] = Pg.lb[i];
+        S.ub[i] = Pg.ub[i];
+    }
+    for (int i = threadIdx.x; i < N3_RIDX_W * N3_RIDX_W; i += blockDim.x) S.ridx[i] = Pg.ridx[i];
+    for (int i = threadIdx.x; i < Q; i += blockDim.x) {
+        const unsigned rw = Pg.rowtab[i];
+        S.rowtab[i] = (unsigned char)rw;
+        S.row16[i] = (unsigned short)((rw & 15u) | ((rw >> 4) << 8));
+    }
+    for (int i = threadIdx.x; i < ML * N3_MAX_Q; i += blockDim.x) (&S.smask[0][0])[i] = Pg.smask[(size_t)D * N3_MAX_Q + i];
+    __syncthreads();
+    N3Dev P = Pg;
+    P.lb = S.lb;
+    P.ub = S.ub;
+    P.ridx = S.ridx;
+
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int task = blockIdx.x * SV_WAVES + wv;
+    if (task >= ntasks) return;                        // whole wave leaves together; no block barrier below
+    const N3Task tk = tasks[task];
+    unsigned st = lane < D ? stbuf[(size_t)task * N3_MAX_M + lane] : 0u;
+
+    SvCtx<ML> c;
+    c.S = &S;
+    c.W = &S.w[wv];
+    c.dynmask = Pg.dynmask;
+    c.swm = Pg.swmask;
+    c.NT1 = Pg.NT + 1;
+    c.lane = lane;
+    c.D = D;
+    c.m = m;
+    c.A = A;
+    c.surv = surv;
+    c.surv_cap = surv_cap;
+    c.surv_count = surv_count;
+    c.base = ((u128)tk.base_hi << 64) | tk.base_lo;
+    c.remaining = tk.count;
+    c.skip = tk.skip;
+    c.done = 0;
+    c.K0 = Pg.K0;
+    c.screen_margin = 2e-5 * Pg.Rtot + 1.0;            // f32 sums: |error| <= Rtot (|ln q| 2^-23 + 2^-22) stays far below this
+    c.rtot_f = (float)Pg.Rtot;
+    c.inv_Rtot = (float)(1.0 / Pg.Rtot);
+    c.conv_l2 = (float)Pg.conv_l2;
+    c.no_dismiss = Pg.no_dismiss;
+    c.wn1 = c.wn2 = 1.0f / 3.0f;
+    c.qcount = 0;
+    c.n_eval = c.n_dis = c.n_it = c.n_deg = c.n_surv = 0;
+    const double inv_N = 1.0 / Pg.N;
+    double leafR[ML];
+#pragma unroll
+    for (int l = 0; l < ML; l++) {
+        leafR[l] = Pg.r[D + l];                        // (uniform address: scalar loads)
+        c.leafN[l] = (float)(Pg.rN[D + l] * inv_N);
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int l = 0; l < ML; l += 2) c.W->fRL[l >> 1] = make_float2((float)leafR[l], (float)leafR[l + 1]);
+    }
+    unsigned long long n_terms = 0;
+
+    while (c.remaining > 0) {
+        // the device-wide running minimum, once per prefix: the lower it is, the more is dismissed
+        c.thr = order_unbits(load_agent_u64(&A.ctr->best_bits)) + A.window;
+        // ---- group tile of the prefix: intervals with the same row collapse into one likelihood term {a, b, sum r}
+        int G = 0;
+        double S1p = 0.0, S2p = 0.0, Rmin = __builtin_inf();
+        {
+            const bool inp = lane < D;
+            const unsigned myrow = st >> 24;           // a | b << 4
+            if (inp) c.W->pre[lane] = (unsigned short)((myrow & 15u) | ((myrow >> 4) << 8));
+            const double r_i = inp ? Pg.r[lane] : 0.0, rN_i = inp ? Pg.rN[lane] : 0.0;
+            unsigned long long todo = ballot64(inp);
+            while (todo) {
+                const int leader = __builtin_ctzll(todo);
+                const unsigned q = (unsigned)__builtin_amdgcn_readlane((int)myrow, leader);
+                const bool match = inp && myrow == q;
+                todo &= ~ballot64(match);
+                double Rs = match ? r_i : 0.0, Ns = match ? rN_i : 0.0;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) {     // integer-valued doubles < 2^53: the sums are exact
+                    Rs += __shfl_xor(Rs, o, WAVE);
+                    Ns += __shfl_xor(Ns, o, WAVE);
+                }
+                const float a = (float)(q & 15u), b = (float)(q >> 4);
+                if (lane == 0) {
+                    float *xy = (float *)&c.W->fXY[G >> 1];
+                    float *rr = (float *)&c.W->fRR[G >> 1];
+                    if (G & 1) {
+                        xy[1] = a; xy[3] = b; rr[1] = (float)Rs;
+                    } else {   // also fills the second half: stays as the weight-0 pad when this is the last term
+                        xy[0] = xy[1] = a; xy[2] = xy[3] = b; rr[0] = (float)Rs; rr[1] = 0.0f;
+                    }
+                }
+                S1p += (double)a * Ns;
+                S2p += (double)b * Ns;
+                if (Rs > 0.0) Rmin = fmin(Rmin, Rs);
+                G++;
+            }
+        }
+#pragma unroll
+        for (int l = 0; l < ML; l++)
+            if (leafR[l] > 0.0) Rmin = fmin(Rmin, leafR[l]);
+        if (!(Rmin < __builtin_inf())) Rmin = 1.0;
+        c.G = G;
+        c.GP = (G + 1) >> 1;
+        c.S1p = (float)(S1p * inv_N);
+        c.S2p = (float)(S2p * inv_N);
+        c.rtot_over_rmin = (float)(Pg.Rtot / Rmin);
+        wave_lds_sync();
+        const unsigned long long it0 = c.n_it;
+        c.par = n3_unpack((unsigned)__builtin_amdgcn_readlane((int)st, D - 1));
+        sv_expand<ML, 0>(c, 1);
+        if (c.qcount) sv_drain<ML>(c);                 // the tile changes with the prefix: the queue is emptied first
+        n_terms += (c.n_it - it0) * (unsigned)(G + ML);
+        c.skip = 0;                                    // only the first prefix of a task starts mid-way
+        if (c.remaining == 0) break;
+        if (!sv_next_prefix(P, st, D, lane)) break;
+        wave_lds_sync();                               // the prefix rows in LDS are rewritten next
+    }
+    if (lane == 0) {
+        atomicAdd(&A.ctr->evaluated, c.n_eval);
+        atomicAdd(&A.ctr->degenerate, c.n_deg);
+        atomicAdd(&A.ctr->iterations, c.n_it);
+        atomicAdd(&A.ctr->terms, n_terms);
+        atomicAdd(&A.ctr->dismissed, c.n_dis);
+        atomicAdd(&A.ctr->sieve_survivors, c.n_surv);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// finish: one lane per contender
+// ------------------------------------------------------------------------------------------------------------------
+__device__ __noinline__ int sv_reference_outcome(int m, double tau, const double *r, const double *rN, const unsigned char *rows, double nu[3]) {
+    N3RefSystem sys;
+    sys.m = m;
+    sys.tau = tau;
+    sys.r = r;
+    sys.rN = rN;
+    sys.c = rows;
+    sys.init();
+    return n3_ref_outcome(sys, nu);      // 1 own iterate (nu), 2 the nu = 1/3 fallback, 0 None
+}
+
+__global__ __launch_bounds__(256) void n3_finish_kernel(N3Dev P, SearchArgs A, const SvSurvivor *surv, unsigned surv_cap,
+                                                        const unsigned *surv_count) {
+    __shared__ double rr[N3_MAX_M], rn[N3_MAX_M];
+    const int m = P.m;
+    unsigned n = *surv_count;
+    if (n > surv_cap) n = surv_cap;
+    if (blockIdx.x * blockDim.x >= n) return;        // (block-uniform: nothing to do for this block)
+    for (int i = threadIdx.x; i < m; i += blockDim.x) {
+        rr[i] = P.r[i];
+        rn[i] = P.rN[i];
+    }
+    __syncthreads();
+    const unsigned idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    const SvSurvivor *sv = surv + idx;
+    const unsigned char *rows = sv->rows;            // [m][2] bytes {a, b}
+    const u128 rank = ((u128)sv->rank_hi << 64) | sv->rank_lo;
+    const double tau = (double)P.tau, inv_Rtot = 1.0 / P.Rtot;
+    double S1 = 0.0, S2 = 0.0, Rmin = __builtin_inf();
+    for (int i = 0; i < m; i++) {
+        S1 = __builtin_fma((double)rows[2 * i], rn[i], S1);
+        S2 = __builtin_fma((double)rows[2 * i + 1], rn[i], S2);
+        if (rr[i] > 0.0) Rmin = fmin(Rmin, rr[i]);
+    }
+    if (!(Rmin < __builtin_inf())) Rmin = 1.0;
+    if (S1 == 0.0 || S2 == 0.0) return;              // (the sieve lists degenerate candidates elsewhere)
+    const double s1 = S1 / P.N, s2 = S2 / P.N;
+    auto terms = [&](auto &&body) {
+        for (int i = 0; i < m; i++) body((double)rows[2 * i], (double)rows[2 * i + 1], rr[i]);
+    };
+    // Newton from the simplex centre (interior for every candidate), to lambda^2 / Rtot < 1e-12
+    N3Newton T;
+    T.u1 = T.p1 = (1.0 / 3.0) / s1;
+    T.u2 = T.p2 = (1.0 / 3.0) / s2;
+    T.iters = 0;
+    T.status = 0;
+    T.singular = false;
+    while (T.status == 0) n3_newton_step(terms, s1, s2, inv_Rtot, T, 1e-12);
+    atomicAdd(&A.ctr->finish_iterations, (unsigned long long)T.iters);
+    double best = order_unbits(load_agent_u64(&A.ctr->best_bits));
+    double u1 = T.status == 1 ? T.u1 : T.p1, u2 = T.status == 1 ? T.u2 : T.p2;
+    bool conv = T.status == 1, accept = false;
+    if (conv) {
+        const double n1 = s1 * u1, n2 = s2 * u2, n0 = 1.0 - n1 - n2;
+        accept = (n0 >= 0.0 && n0 <= 1.0 && n1 >= 0.0 && n1 <= 1.0 && n2 >= 0.0 && n2 <= 1.0);
+    }
+    double h11 = 0.0, h12 = 0.0, h22 = 0.0, acc = 0.0, g1 = 0.0, g2 = 0.0;
+    bool outside = false;
+    terms([&](double x, double y, double R) {
+        const double a = x - s1, b = y - s2;
+        const double q = __builtin_fma(a, u1, __builtin_fma(b, u2, 1.0));
+        outside |= !(q > 0.0);
+        const double t = R / q, tw = t / q;
+        g1 = __builtin_fma(t, a, g1);
+        g2 = __builtin_fma(t, b, g2);
+        h11 = __builtin_fma(tw * a, a, h11);
+        h12 = __builtin_fma(tw * a, b, h12);
+        h22 = __builtin_fma(tw * b, b, h22);
+    });
+    if (conv && !accept && T.singular) {             // rank-deficient: the minimiser is a line; intersect it with the simplex
+        N3Hess T2;
+        T2.u1 = u1; T2.u2 = u2; T2.h11 = h11; T2.h12 = h12; T2.h22 = h22;
+        accept = n3_admissible(T2, s1, s2);
+        u1 = T2.u1;
+        u2 = T2.u2;
+    }
+    terms([&](double x, double y, double R) {
+        const double q = __builtin_fma(x - s1, u1, __builtin_fma(y - s2, u2, 1.0));
+        acc = __builtin_fma(R, log(q), acc);
+    });
+    double nll = P.K0 - acc;
+    if (accept) {
+        atomicAdd(&A.ctr->accepted, 1ull);
+        if (!(nll <= best + A.window)) return;       // its own minimum is beyond the window: whatever the reference reports is too
+        // The minimum lies in the simplex -- but does the reference find it?  (n3.hip, n3_cold_path: same decision.)
+        double nu[3];
+        const int outcome = sv_reference_outcome(m, tau, rr, rn, rows, nu);
+        if (outcome == 0) return;                    // the reference returns None for it: neither a finalist nor a suspect
+        u1 = nu[1] / s1;
+        u2 = nu[2] / s2;
+        acc = 0.0;
+        terms([&](double x, double y, double R) {
+            const double q = __builtin_fma(x - s1, u1, __builtin_fma(y - s2, u2, 1.0));
+            acc = __builtin_fma(R, log(q), acc);
+        });
+        nll = P.K0 - acc;
+        best = fmin(best, order_unbits(load_agent_u64(&A.ctr->best_bits)));
+        if (nll <= best + A.window) {
+            const double u0 = (1.0 - s1 * u1 - s2 * u2) / tau, usum = u0 + u1 + u2;    // closed form of M3 (Optimizer.py:318-330)
+            tie_append(A.ctr, A.list, A.list_cap, rank, nll, u0 / usum, u1 / usum, u2 / usum);
+            if (nll < best) atomicMin(&A.ctr->best_bits, order_bits(nll));
+        }
+        return;
+    }
+    // Rejected: a LOWER BOUND of anything the reference could report for it inside the simplex.  Converged outside the
+    // simplex: the unconstrained minimum plus the self-concordance gain Rmin w(d / sqrt(Rmin)), w(t) = t - ln(1 + t), d = the
+    // Hessian-norm distance from the optimum to the simplex.  Not converged: Frank-Wolfe from the last feasible iterate.
+    double lbnd;
+    if (conv) {
+        const double vx[3] = {0.0, 1.0 / s1, 0.0}, vy[3] = {0.0, 0.0, 1.0 / s2};
+        double d2 = __builtin_inf();
+#pragma unroll
+        for (int e = 0; e < 3; e++) {
+            const int f = (e + 1) % 3;
+            const double ex = vx[f] - vx[e], ey = vy[f] - vy[e];
+            const double px = u1 - vx[e], py = u2 - vy[e];
+            const double hex = h11 * ex + h12 * ey, hey = h12 * ex + h22 * ey;
+            double t = (px * hex + py * hey) / (ex * hex + ey * hey);
+            t = fmin(fmax(t, 0.0), 1.0);
+            const double rx = px - t * ex, ry = py - t * ey;
+            d2 = fmin(d2, rx * (h11 * rx + h12 * ry) + ry * (h12 * rx + h22 * ry));
+        }
+        const double tt = sqrt(fmax(d2, 0.0) / Rmin);
+        const double gain = 0.98 * Rmin * (tt - log1p(tt));
+        lbnd = nll + (gain == gain ? gain : 0.0);
+    } else {
+        const double e0 = g1 * u1 + g2 * u2, e1 = e0 - g1 / s1, e2 = e0 - g2 / s2;
+        const double fw = fmin(e0, fmin(e1, e2));
+        lbnd = (outside || !(fw == fw) || !(nll == nll)) ? -__builtin_inf() : nll + fw;
+    }
+    if (!(lbnd == lbnd)) lbnd = -__builtin_inf();
+    best = fmin(best, order_unbits(load_agent_u64(&A.ctr->best_bits)));
+    if (lbnd <= best + A.window) suspect_append(A.ctr, A.sus, A.sus_cap, rank, lbnd, nll);
+    if (lbnd < order_unbits(load_agent_u64(&A.ctr->rej_bits))) {
+        const unsigned long long old = atomicMin(&A.ctr->rej_bits, order_bits(lbnd));
+        if (old > order_bits(lbnd)) {  // we hold the minimum (racy pair, diagnostic only)
+            A.ctr->rej_rank_lo = (unsigned long long)rank;
+            A.ctr->rej_rank_hi = (unsigned long long)(rank >> 64);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------------------------------
+// P.L must be the burst depth (n3_sieve_levels) -- for the task kernel as well (tasks are cut at depth m - P.L).
+int n3_sieve_levels(const N3Dev &P) {
+    if (P.m < 8) return 0;                              // small searches stay on the fused kernel
+    int want = 4;
+    const double lg = log((double)P.total_hi * 18446744073709551616.0 + (double)P.total_lo) / (double)P.m;
+    if (lg > 0.0 && 4.0 * lg < log(600.0)) want = 6;   // the instance branches little: four rows would leave the bursts nearly empty
+    if (const char *e = getenv("THETA_SIEVE_LEVELS")) {
+        const int v = atoi(e);
+        if (v == 4 || v == 6) want = v;
+    }
+    return want;
+}
+
+void n3_launch_sieve(const N3Dev &P, const SearchArgs &A, const N3Task *tasks, const unsigned *stbuf, int ntasks, SvSurvivor *surv,
+                     unsigned surv_cap, unsigned *surv_count, hipStream_t st) {
+    dim3 grid((ntasks + SV_WAVES - 1) / SV_WAVES), block(64 * SV_WAVES);
+    if (P.L <= 4) hipLaunchKernelGGL((n3_sieve_kernel<4>), grid, block, 0, st, P, A, tasks, stbuf, ntasks, surv, surv_cap, surv_count);
+    else hipLaunchKernelGGL((n3_sieve_kernel<6>), grid, block, 0, st, P, A, tasks, stbuf, ntasks, surv, surv_cap, surv_count);
+}
+
+void n3_launch_finish(const N3Dev &P, const SearchArgs &A, const SvSurvivor *surv, unsigned surv_cap, const unsigned *surv_count,
+                      hipStream_t st) {
+    // (a grid for a full list: blocks beyond the count leave at once)
+    hipLaunchKernelGGL(n3_finish_kernel, dim3((surv_cap + 255) / 256), dim3(256), 0, st, P, A, surv, surv_cap, surv_count);
+}
