@@ -447,7 +447,7 @@ static int run_search(theta_problem *p, u128 b, u128 e, double window, double *d
     kernel_ms = setup_ms = 0.0;
     unsigned long long list_dropped = 0;
     for (int pass = 0; pass < 3; pass++) {
-        int sieve_slices = 0, sieve_per_slice = 0, sieve_ntasks = 0;
+        std::vector<std::pair<int, int>> slices;     // n=3 fast path: (first task, tasks) of every sieve launch of this pass
         uint64_t sieve_per_task = 0;
         HIP_TRY(hipMemcpyAsync(p->d_ctr.p, &hc, sizeof(hc), hipMemcpyHostToDevice, st));
         HIP_TRY(hipEventRecord(ctx->ev0, st));
@@ -498,18 +498,32 @@ static int run_search(theta_problem *p, u128 b, u128 e, double window, double *d
                 n3_launch_tasks(PS, b, e, per_task, ntasks, (N3Task *)p->d_tasks.p, (unsigned *)p->d_stbuf.p, st);
                 HIP_TRY(hipEventRecord(ctx->ev1, st));
                 int per_slice = (int)std::max<uint64_t>(1, SIEVE_SLICE / per_task);
-                while ((ntasks + per_slice - 1) / per_slice > SIEVE_MAX_SLICES) per_slice *= 2;
-                const int nslices = (ntasks + per_slice - 1) / per_slice;
+                while ((ntasks + per_slice - 1) / per_slice > SIEVE_MAX_SLICES - 4) per_slice *= 2;
+                // The sieve judges candidates against the running minimum, and only the finish kernel lowers it.  A call that
+                // starts without one (no hint, first pass) works its way up through short slices first -- 1, 8, 64, 512 tasks --
+                // so that the bulk of the range is sieved against a minimum that some candidate really attains.
+                slices.clear();
+                {
+                    int t = 0;
+                    if (hc.best_bits == order_bits(INFINITY))
+                        for (int sz = 1; sz <= 512 && t < ntasks; sz *= 8) {
+                            const int k = std::min(sz, ntasks - t);
+                            slices.push_back({t, k});
+                            t += k;
+                        }
+                    while (t < ntasks) {
+                        const int k = std::min(per_slice, ntasks - t);
+                        slices.push_back({t, k});
+                        t += k;
+                    }
+                }
                 unsigned *cnts = (unsigned *)p->d_survcnt.p;
-                for (int sl = 0; sl < nslices; sl++) {
-                    const int t0 = sl * per_slice, nts = std::min(per_slice, ntasks - t0);
+                for (size_t sl = 0; sl < slices.size(); sl++) {
+                    const int t0 = slices[sl].first, nts = slices[sl].second;
                     n3_launch_sieve(PS, A, (const N3Task *)p->d_tasks.p + t0, (const unsigned *)p->d_stbuf.p + (size_t)t0 * N3_MAX_M, nts,
                                     (SvSurvivor *)p->d_surv.p, SURV_CAP, cnts + sl, st);
                     n3_launch_finish(PS, A, (const SvSurvivor *)p->d_surv.p, SURV_CAP, cnts + sl, st);
                 }
-                sieve_slices = nslices;
-                sieve_per_slice = per_slice;
-                sieve_ntasks = ntasks;
                 sieve_per_task = per_task;
             } else {
                 n3_launch_tasks(p->n3, b, e, per_task, ntasks, (N3Task *)p->d_tasks.p, (unsigned *)p->d_stbuf.p, st);
@@ -521,7 +535,7 @@ static int run_search(theta_problem *p, u128 b, u128 e, double window, double *d
         SearchCounters got;
         unsigned hcnt[SIEVE_MAX_SLICES];
         HIP_TRY(hipMemcpyAsync(&got, p->d_ctr.p, sizeof(got), hipMemcpyDeviceToHost, st));
-        if (sieve_slices) HIP_TRY(hipMemcpyAsync(hcnt, p->d_survcnt.p, sieve_slices * sizeof(unsigned), hipMemcpyDeviceToHost, st));
+        if (!slices.empty()) HIP_TRY(hipMemcpyAsync(hcnt, p->d_survcnt.p, slices.size() * sizeof(unsigned), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
         HIP_TRY(hipGetLastError());
         float ms = 0;
@@ -532,9 +546,9 @@ static int run_search(theta_problem *p, u128 b, u128 e, double window, double *d
         // A slice of the sieve whose contender list overflowed (a stretch of near-ties) is redone by the fused kernel, which is
         // complete by itself; its records join the same device lists (theta_search drops duplicates by rank).
         uint64_t redone = 0;
-        for (int sl = 0; sl < sieve_slices; sl++) {
+        for (size_t sl = 0; sl < slices.size(); sl++) {
             if (hcnt[sl] <= SURV_CAP) continue;
-            const int t0 = sl * sieve_per_slice, nts = std::min(sieve_per_slice, sieve_ntasks - t0);
+            const int t0 = slices[sl].first, nts = slices[sl].second;
             const u128 sb = b + (u128)t0 * sieve_per_task;
             u128 se = sb + (u128)nts * sieve_per_task;
             if (se > e) se = e;

@@ -54,14 +54,17 @@
 #define SV_TRIES 2        // evaluations a record may take in place when many lanes need another
 #endif
 
-template <int ML> struct SvCapR { static constexpr int v = ML <= 4 ? 512 : 288; };   // records per burst
+#ifndef SV_KIDS
+#define SV_KIDS 768       // children (candidates) of one round of <= 64 last-level nodes
+#endif
 
 template <int ML>
 struct SvWave {
     alignas(16) unsigned short pre[N3_MAX_M + 8];       // rows of the prefix, a | b << 8
     uint2 list0[N3_MAX_Q];                              // level 1 nodes (children of the prefix's last node)
     uint2 list[ML > 2 ? ML - 2 : 1][SV_CAP];            // level l >= 2: {packed parent node, ancestor slots (6 bits each) | slot << 24}
-    alignas(8) unsigned lwr[(SvCapR<ML>::v + 4) * (ML / 2)];   // the burst: ML rows per record, two rows {a, b, a, b} per dword
+    unsigned short kid[SV_KIDS];                        // candidates of the current round: last row's slot | parent lane << 8
+    float4 par[WAVE][4];                                // per last-level node of the round: shared sums, column sums, point, path
     float4 fXY[(N3_MAX_Q + 2) / 2];                     // group tile of the prefix, two terms per entry {a0, a1, b0, b1}
     float2 fRR[(N3_MAX_Q + 2) / 2];                     // ... and their weights {R0, R1} (an odd last term is paired with weight 0)
     float2 fRL[ML / 2];                                 // weights of the leaf rows, paired
@@ -108,6 +111,7 @@ struct SvCtx {
     // likelihood data of the current prefix
     float S1p, S2p;                  // column sums of the prefix rows (weighted by the normal counts), / N
     float leafN[ML];                 // normal counts of the leaf rows / N
+    float leafRf[ML];                // tumour counts of the leaf rows
     float rtot_f, rtot_over_rmin, inv_Rtot, conv_l2;
     double K0, screen_margin, thr;   // thr = running minimum + window, refreshed per prefix
     int no_dismiss;
@@ -177,7 +181,7 @@ __device__ __forceinline__ int sv_step(const SvCtx<ML> &c, const unsigned (&rw)[
     val2 = lg.x + lg.y;
     if (!(l2 == l2) || !(fabsf(d1) + fabsf(d2) < 1e30f)) return 3;
     float step = 1.0f;
-    if (l2 > 0.09f) step = __builtin_amdgcn_rcpf(1.0f + __builtin_sqrtf(l2));
+    if (l2 > 0.09f) step = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_sqrtf(l2));
     u1 = __builtin_fmaf(step, d1, u1);
     u2 = __builtin_fmaf(step, d2, u2);
     return l2 < c.conv_l2 ? 1 : 0;
@@ -188,7 +192,7 @@ template <int ML>
 __device__ __forceinline__ bool sv_dismissed(const SvCtx<ML> &c, float val2, float l2) {
     const float lt2 = l2 * c.rtot_over_rmin;
     if (!(lt2 < 0.25f) || c.no_dismiss) return false;
-    const float lt = __builtin_sqrtf(lt2);
+    const float lt = __builtin_amdgcn_sqrtf(lt2);
     const double gap = 1.05 * 0.5 * (double)(l2 * c.rtot_f * __builtin_amdgcn_rcpf(1.0f - lt));
     const double lb = (c.K0 - 0.6931471805599453 * (double)val2) - gap - c.screen_margin;
     return lb > c.thr;
@@ -278,59 +282,169 @@ __device__ __forceinline__ void sv_drain(SvCtx<ML> &c) {
     c.qcount = 0;
 }
 
-// The records [0, total) of the burst (less the task window): first evaluation in place, the rest to the queue.
+// ---- first evaluation, shared between the children of one last-level node -------------------------------------------
+// In homogeneous coordinates w = (w0, u1, u2) a likelihood term is q_i = w0 + x_i u1 + y_i u2 -- it does not depend on the
+// candidate's normalisation z = (1, s1, s2) (column sums / N), which only enters through the slice z.w = 1 the candidate's
+// mixture lives on.  Candidates that differ in their LAST row only (the children of one node of the last expanded level)
+// therefore share, at a common point w, the value / gradient / Hessian sums of ALL their other terms:
+//      L = sum R log2 q,   T = sum (R/q) (1, x, y),   W = sum (R/q^2) (1, x, y)(1, x, y)^T         (10 numbers)
+// Phase P: the lane that owns the node computes them once (group tile of the prefix + the node's own path rows) at the
+// lane's chain point.  Phase C: one lane per CHILD adds the child's last row, restricts gradient and Hessian to the tangent
+// space of the child's slice (d0 = -s1 d1 - s2 d2), and has the Newton decrement and the lower bound of the child's optimum
+// for ~1/3 of the work of a full evaluation.  NLL = K0 - ln2 (L - Rtot log2(z.w)): scale invariant, so w needs no
+// normalisation.  Children the bound cannot finish go to the queue and continue with full evaluations at their own iterate.
+struct SvPar {
+    float L, T0, T1, T2, W00, W01, W02, W11, W12, W22, S1, S2, w0, u1, u2;
+    unsigned code;          // slots of the node's path rows (6 bits each) | usable << 31
+};
+
 template <int ML>
-__device__ __forceinline__ void sv_burst(SvCtx<ML> &c, int total) {
+__device__ __forceinline__ void sv_parent(SvCtx<ML> &c, bool take, unsigned code) {
+    // path rows D .. D+ML-2 of the node (its ancestors in the expanded levels and itself)
+    float px[ML - 1], py[ML - 1];
+    float S1 = c.S1p, S2 = c.S2p;
+#pragma unroll
+    for (int j = 0; j < ML - 1; j++) {
+        const unsigned r16 = c.S->row16[(code >> (6 * j)) & 63u];
+        px[j] = (float)(r16 & 0xffu);
+        py[j] = (float)(r16 >> 8);
+        S1 = __builtin_fmaf(px[j], c.leafN[j], S1);
+        S2 = __builtin_fmaf(py[j], c.leafN[j], S2);
+    }
+    // the lane's chain point as a direction: mixture (n1, n2) pulled slightly towards the simplex centre, u_j = n_j / s_j with
+    // the node's own (partial) column sums -- any scale is as good as any other
+    const float n1 = __builtin_fmaf(0.98f, c.wn1, 0.02f / 3.0f), n2 = __builtin_fmaf(0.98f, c.wn2, 0.02f / 3.0f);
+    const bool sums_ok = S1 > 0.0f && S2 > 0.0f;
+    const float w0 = 1.0f - n1 - n2;
+    const float u1 = n1 * __builtin_amdgcn_rcpf(sums_ok ? S1 : 1.0f), u2 = n2 * __builtin_amdgcn_rcpf(sums_ok ? S2 : 1.0f);
+    sv2f L = {0.f, 0.f}, T0 = L, T1 = L, T2 = L, W00 = L, W01 = L, W02 = L, W11 = L, W12 = L, W22 = L;
+    float qmin = __builtin_inff();
+    const sv2f vw0 = {w0, w0}, vu1 = {u1, u1}, vu2 = {u2, u2};
+    auto body = [&](sv2f x, sv2f y, sv2f R) {
+        sv2f q = __builtin_elementwise_fma(x, vu1, __builtin_elementwise_fma(y, vu2, vw0));
+        qmin = fminf(qmin, fminf(q.x, q.y));
+        sv2f w = {__builtin_amdgcn_rcpf(q.x), __builtin_amdgcn_rcpf(q.y)};
+        L = __builtin_elementwise_fma(R, sv2f{__builtin_amdgcn_logf(q.x), __builtin_amdgcn_logf(q.y)}, L);
+        sv2f t = R * w;
+        T0 += t;
+        T1 = __builtin_elementwise_fma(t, x, T1);
+        T2 = __builtin_elementwise_fma(t, y, T2);
+        sv2f tw = t * w;
+        W00 += tw;
+        sv2f twx = tw * x, twy = tw * y;
+        W01 += twx;
+        W02 += twy;
+        W11 = __builtin_elementwise_fma(twx, x, W11);
+        W12 = __builtin_elementwise_fma(twx, y, W12);
+        W22 = __builtin_elementwise_fma(twy, y, W22);
+    };
+    if (take) {
+        const float4 *fXY = c.W->fXY;
+        const float2 *fRR = c.W->fRR;
+#pragma unroll 2
+        for (int p = 0; p < c.GP; p++) {
+            const float4 xy = fXY[p];
+            const float2 rr = fRR[p];
+            body(sv2f{xy.x, xy.y}, sv2f{xy.z, xy.w}, sv2f{rr.x, rr.y});
+        }
+        // the ML - 1 path rows: pairs, an odd one with a copy of itself of weight 0
+#pragma unroll
+        for (int j = 0; j + 1 < ML - 1; j += 2) body(sv2f{px[j], px[j + 1]}, sv2f{py[j], py[j + 1]}, sv2f{c.leafRf[j], c.leafRf[j + 1]});
+        if ((ML - 1) & 1) body(sv2f{px[ML - 2], px[ML - 2]}, sv2f{py[ML - 2], py[ML - 2]}, sv2f{c.leafRf[ML - 2], 0.0f});
+        const bool usable = sums_ok && qmin > 0.0f;
+        float4 *dst = c.W->par[c.lane];
+        dst[0] = make_float4(L.x + L.y, T0.x + T0.y, T1.x + T1.y, T2.x + T2.y);
+        dst[1] = make_float4(W00.x + W00.y, W01.x + W01.y, W02.x + W02.y, W11.x + W11.y);
+        dst[2] = make_float4(W12.x + W12.y, W22.x + W22.y, S1, S2);
+        dst[3] = make_float4(w0, u1, u2, __uint_as_float(code | (usable ? 0x80000000u : 0u)));
+    }
+}
+
+// leaf rows of a child as the queue / the contender list hold them: two rows {a, b, a', b'} per dword
+template <int ML>
+__device__ __forceinline__ void sv_child_rows(const SvCtx<ML> &c, unsigned code, unsigned slot, unsigned (&rw)[ML / 2]) {
+#pragma unroll
+    for (int j = 0; j < ML / 2; j++) {
+        rw[j] = c.S->row16[(code >> (12 * j)) & 63u];
+        if (j < ML / 2 - 1) rw[j] |= (unsigned)c.S->row16[(code >> (12 * j + 6)) & 63u] << 16;
+    }
+    rw[ML / 2 - 1] |= (unsigned)c.S->row16[slot] << 16;
+}
+
+// The candidates [0, total) of the round (less the task window), one lane per child.
+template <int ML>
+__device__ __forceinline__ void sv_children(SvCtx<ML> &c, int total) {
     const unsigned long long sk = c.skip < (unsigned long long)total ? c.skip : (unsigned long long)total;
     c.skip -= sk;
     const int lo = (int)sk;
     const unsigned long long room = (unsigned long long)(total - lo);
     const int nrec = (int)(room < c.remaining ? room : c.remaining);
     if (nrec <= 0) return;
-    const int per = (nrec + WAVE - 1) / WAVE;            // records per lane, consecutive
-    const int first = c.lane * per;
-    for (int j = 0; j < per; j++) {
-        const int k = first + j;
+    const float Rl = c.leafRf[ML - 1], Nl = c.leafN[ML - 1];
+    for (int k0 = 0; k0 < nrec; k0 += WAVE) {
+        const int k = k0 + c.lane;
         const bool act = k < nrec;
-        unsigned rw[ML / 2];
-#pragma unroll
-        for (int q = 0; q < ML / 2; q++) rw[q] = act ? c.W->lwr[(lo + k) * (ML / 2) + q] : 0u;
-        float s1 = 1.f, s2 = 1.f;
-        const bool regular = sv_sums<ML>(c, rw, s1, s2);
+        const unsigned kd = act ? c.W->kid[lo + k] : 0u;
+        const unsigned slot = kd & 0xffu, pl = kd >> 8;
+        const float4 *P = c.W->par[pl];
+        const float4 p0 = P[0], p1 = P[1], p2 = P[2], p3 = P[3];
+        const unsigned code = __float_as_uint(p3.w);
+        const unsigned r16 = c.S->row16[slot];
+        const float x = (float)(r16 & 0xffu), y = (float)(r16 >> 8);
+        const float s1 = __builtin_fmaf(x, Nl, p2.z), s2 = __builtin_fmaf(y, Nl, p2.w);
+        const bool regular = s1 > 0.0f && s2 > 0.0f;
         const unsigned off = (unsigned)(c.done + (unsigned long long)k);
-        bool ev = act && regular;
         if (act && !regular) degenerate_append(c.A.ctr, c.A.deg, c.A.deg_cap, c.base + off);
         c.n_deg += (unsigned)__builtin_popcountll(ballot64(act && !regular));
-        // start: the optimum of the lane's previous record, pulled slightly towards the simplex centre (interior for every
-        // candidate); a start outside the domain is halved towards u = 0
-        float u1 = __builtin_fmaf(0.98f, c.wn1, 0.02f / 3.0f) * __builtin_amdgcn_rcpf(s1);
-        float u2 = __builtin_fmaf(0.98f, c.wn2, 0.02f / 3.0f) * __builtin_amdgcn_rcpf(s2);
-        bool push = false, surv = false;
-        for (int tries = 0;; tries++) {
-            const unsigned long long evm = ballot64(ev);
-            if (!evm) break;
-            if (tries >= SV_TRIES || (tries > 0 && __builtin_popcountll(evm) < 16)) {
-                push = ev;                   // few lanes left: they continue from the queue, 64 at a time
-                break;
-            }
-            c.n_it += (unsigned)__builtin_popcountll(evm);
-            if (ev) {
-                float val2 = 0.f, l2 = 0.f;
-                const int st = sv_step<ML>(c, rw, s1, s2, u1, u2, val2, l2);
-                if (st == 3) {
-                    surv = true;
-                    ev = false;
-                } else if (st != 2) {
-                    if (fabsf(s1 * u1) + fabsf(s2 * u2) < 1e6f) {     // the stepped iterate starts the lane's next record
-                        c.wn1 = s1 * u1;
-                        c.wn2 = s2 * u2;
+        const float w0 = p3.x, u1 = p3.y, u2 = p3.z;
+        const float q = __builtin_fmaf(x, u1, __builtin_fmaf(y, u2, w0));
+        bool ev = act && regular && (code >> 31) && q > 0.0f;
+        bool push = act && regular && !ev;                // no usable shared point: the child starts from the centre in the queue
+        bool surv = false;
+        float qu1 = (1.0f / 3.0f) * __builtin_amdgcn_rcpf(s1), qu2 = (1.0f / 3.0f) * __builtin_amdgcn_rcpf(s2);
+        c.n_it += (unsigned)__builtin_popcountll(ballot64(ev));
+        if (ev) {
+            const float w = __builtin_amdgcn_rcpf(q), t = Rl * w, tw = t * w, twx = tw * x, twy = tw * y;
+            const float L = __builtin_fmaf(Rl, __builtin_amdgcn_logf(q), p0.x);
+            const float T0 = p0.y + t, T1 = __builtin_fmaf(t, x, p0.z), T2 = __builtin_fmaf(t, y, p0.w);
+            const float W00 = p1.x + tw, W01 = p1.y + twx, W02 = p1.z + twy;
+            const float W11 = __builtin_fmaf(twx, x, p1.w), W12 = __builtin_fmaf(twx, y, p2.x), W22 = __builtin_fmaf(twy, y, p2.y);
+            // tangent space of the child's slice z.w = const: d = (-s1 d1 - s2 d2, d1, d2)
+            const float G1 = __builtin_fmaf(-s1, T0, T1), G2 = __builtin_fmaf(-s2, T0, T2);
+            const float A1 = __builtin_fmaf(-s1, W00, W01), A2 = __builtin_fmaf(-s2, W00, W02);      // W0j - s_j W00
+            const float H11 = __builtin_fmaf(-s1, A1, __builtin_fmaf(-s1, W01, W11));
+            const float H12 = __builtin_fmaf(-s2, A1, __builtin_fmaf(-s1, W02, W12));
+            const float H22 = __builtin_fmaf(-s2, A2, __builtin_fmaf(-s2, W02, W22));
+            const float hh = H11 * H22, det = __builtin_fmaf(-H12, H12, hh);
+            const float zw = __builtin_fmaf(s1, u1, __builtin_fmaf(s2, u2, w0));
+            if (!(det > (float)N3_COND_MIN * hh) || !(zw > 0.0f)) {
+                push = true;                              // ill-conditioned for these sums: full evaluations from the centre
+            } else {
+                const float idet = __builtin_amdgcn_rcpf(det);
+                const float d1 = (H22 * G1 - H12 * G2) * idet, d2 = (H11 * G2 - H12 * G1) * idet;
+                const float l2 = (G1 * d1 + G2 * d2) * c.inv_Rtot;
+                const float val2 = __builtin_fmaf(-c.rtot_f, __builtin_amdgcn_logf(zw), L);
+                if (!(l2 == l2) || !(fabsf(d1) + fabsf(d2) < 1e30f)) {
+                    push = true;
+                } else {
+                    float step = 1.0f;
+                    if (l2 > 0.09f) step = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_sqrtf(l2));
+                    // the stepped point on the child's own slice (z.d = 0, so z.w stays): mixture n_j = s_j u_j / z.w
+                    const float sc = __builtin_amdgcn_rcpf(zw);
+                    const float v1 = __builtin_fmaf(step, d1, u1) * sc, v2 = __builtin_fmaf(step, d2, u2) * sc;
+                    if (fabsf(s1 * v1) + fabsf(s2 * v2) < 1e6f) {
+                        c.wn1 = s1 * v1;                  // the lane's chain: a recent optimum of this neighbourhood
+                        c.wn2 = s2 * v2;
                     }
-                    if (sv_dismissed<ML>(c, val2, l2)) {
-                        ev = false;
-                    } else if (st == 1) {
-                        const double v = (c.K0 - 0.6931471805599453 * (double)val2) - 0.5 * (double)(l2 * c.rtot_f) - c.screen_margin;
-                        surv = !(v > c.thr);
-                        ev = false;
+                    if (!sv_dismissed<ML>(c, val2, l2)) {
+                        if (l2 < c.conv_l2) {
+                            const double v = (c.K0 - 0.6931471805599453 * (double)val2) - 0.5 * (double)(l2 * c.rtot_f) - c.screen_margin;
+                            surv = !(v > c.thr);
+                        } else {
+                            push = true;
+                            qu1 = v1;
+                            qu2 = v2;
+                        }
                     }
                 }
             }
@@ -338,20 +452,24 @@ __device__ __forceinline__ void sv_burst(SvCtx<ML> &c, int total) {
         c.n_eval += (unsigned)__builtin_popcountll(ballot64(act));
         if (!c.no_dismiss) c.n_dis += (unsigned)__builtin_popcountll(ballot64(act && regular && !push && !surv));
         c.n_surv += (unsigned)__builtin_popcountll(ballot64(surv));
-        if (surv) sv_survivor<ML>(c, rw, off);
-        const unsigned long long pm = ballot64(push);
-        if (pm) {
-            if (c.qcount + __builtin_popcountll(pm) > SV_QCAP) sv_drain<ML>(c);
-            if (push) {
-                const int pos = c.qcount + mbcnt(pm);
+        const unsigned long long pm = ballot64(push), sm = ballot64(surv);
+        if (pm | sm) {
+            unsigned rw[ML / 2];
+            sv_child_rows<ML>(c, code, slot, rw);
+            if (surv) sv_survivor<ML>(c, rw, off);
+            if (pm) {
+                if (c.qcount + __builtin_popcountll(pm) > SV_QCAP) sv_drain<ML>(c);
+                if (push) {
+                    const int pos = c.qcount + mbcnt(pm);
 #pragma unroll
-                for (int q = 0; q < ML / 2; q++) c.W->qRow[pos][q] = rw[q];
-                c.W->qU1[pos] = u1;
-                c.W->qU2[pos] = u2;
-                c.W->qOff[pos] = (unsigned short)off;
+                    for (int q2 = 0; q2 < ML / 2; q2++) c.W->qRow[pos][q2] = rw[q2];
+                    c.W->qU1[pos] = qu1;
+                    c.W->qU2[pos] = qu2;
+                    c.W->qOff[pos] = (unsigned short)off;
+                }
+                c.qcount += __builtin_popcountll(pm);
+                wave_lds_sync();
             }
-            c.qcount += __builtin_popcountll(pm);
-            wave_lds_sync();
         }
     }
     c.done += (unsigned long long)nrec;
@@ -368,7 +486,7 @@ __device__ __forceinline__ unsigned long long sv_child_mask(const SvCtx<ML> &c, 
 template <int ML, int LVL>
 __device__ __forceinline__ void sv_expand(SvCtx<ML> &c, int n_in) {
     constexpr bool last = (LVL == ML - 1);
-    const int cap = last ? SvCapR<ML>::v : (LVL == 0 ? N3_MAX_Q : SV_CAP);
+    const int cap = last ? SV_KIDS : (LVL == 0 ? N3_MAX_Q : SV_CAP);
     int pos = 0;
     while (pos < n_in) {
         const int i = pos + c.lane;
@@ -395,25 +513,17 @@ __device__ __forceinline__ void sv_expand(SvCtx<ML> &c, int n_in) {
         const bool take = live && c.lane < t;
         if constexpr (last) {
             if (take) {
-                // rows 0 .. LVL-1 of the record are the node's ancestors and itself (the same for all its children)
-                unsigned un[ML / 2];
-#pragma unroll
-                for (int j = 0; j < ML / 2; j++) {
-                    un[j] = c.S->row16[(code >> (12 * j)) & 63u];
-                    if (j < ML / 2 - 1) un[j] |= (unsigned)c.S->row16[(code >> (12 * j + 6)) & 63u] << 16;
-                }
-                unsigned *dst = c.W->lwr + off * (ML / 2);
+                unsigned short *dst = c.W->kid + off;
+                const unsigned tag = (unsigned)c.lane << 8;
                 while (mk) {
                     const int s = __builtin_ctzll(mk);
                     mk &= mk - 1;
-#pragma unroll
-                    for (int j = 0; j < ML / 2 - 1; j++) dst[j] = un[j];
-                    dst[ML / 2 - 1] = un[ML / 2 - 1] | ((unsigned)c.S->row16[s] << 16);
-                    dst += ML / 2;
+                    *dst++ = (unsigned short)((unsigned)s | tag);
                 }
             }
+            sv_parent<ML>(c, take && cnt > 0, code);
             wave_lds_sync();
-            sv_burst<ML>(c, total);
+            sv_children<ML>(c, total);
             wave_lds_sync();
         } else {
             const unsigned ps = n3_pack(node);
@@ -524,6 +634,7 @@ __global__ __launch_bounds__(64 * SV_WAVES, SV_OCC) void n3_sieve_kernel(N3Dev P
 #pragma unroll
     for (int l = 0; l < ML; l++) {
         leafR[l] = Pg.r[D + l];                        // (uniform address: scalar loads)
+        c.leafRf[l] = (float)leafR[l];
         c.leafN[l] = (float)(Pg.rN[D + l] * inv_N);
     }
     if (lane == 0) {
