@@ -147,6 +147,10 @@ class Leg:
             self.kernel_ms += st["kernel_ms"]
             self.setup_ms += st["setup_ms"]
             self.launches += 1
+            if os.environ.get("THETA_BENCH_VERBOSE"):
+                print("step %d: kernel %.2f ms, evaluated %d, dismissed %d, survivors %d, redone by the fused kernel %d, iters %d, diag %s" %
+                      (i, st["kernel_ms"], st["evaluated"], st["dismissed"], st.get("survivors", 0), st.get("fallback_candidates", 0),
+                       st["iterations"], st["phase_cycles"]), file=sys.stderr)
             if len(res["nll"]) and (self.best is None or res["nll"].min() < self.best["nll"].min()):
                 self.best = res
         return res

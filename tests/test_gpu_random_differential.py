@@ -106,7 +106,15 @@ def test_n3_packed_f32_pass_and_fp64_iterations_return_the_same_finalists(monkey
         # bound of their optimum ("dismissed") and counts admissible optima among the others only
         assert b["stats"]["dismissed"] == 0 and a["stats"]["dismissed"] > 0
         assert a["stats"]["accepted"] <= b["stats"]["accepted"] + 3 + a["stats"]["evaluated"] // 1000
-        assert sorted(sa[0]) == sorted(sb[0])
+        # suspects (rejected matrices whose LOWER BOUND is within the window): the two arithmetics bound borderline cases
+        # differently, but what decides `best` -- the ones whose nu = 1/3 fallback value is within the window -- must agree
+        def relevant(sus, res):
+            if not len(sus[0]):
+                return set()
+            ok, mu_s, nll_s, _ = ctx.solve_batch(3, 2, rs, rNs, sus[2], 1.0, want_vals=False)
+            gmin = min(float(res["nll"].min()), float(np.nanmin(np.where(ok, nll_s, np.inf))))
+            return set(rk for rk, o, v in zip(sus[0], ok, nll_s) if o and v <= gmin + 0.5)
+        assert relevant(sa, a) == relevant(sb, b)
 
 
 def test_bench_shape_packed_pass_dismissal_and_probe_do_not_change_the_finalists(monkeypatch):

@@ -42,7 +42,7 @@
 
 #define SV_WAVES 4
 #ifndef SV_CAP
-#define SV_CAP 128        // nodes per intermediate level list
+#define SV_CAP 64         // nodes per intermediate level list
 #endif
 #ifndef SV_QCAP
 #define SV_QCAP 128       // records waiting for further Newton steps
@@ -99,6 +99,8 @@ struct SvCtx {
     SvLds<ML> *S;
     SvWave<ML> *W;
     const unsigned long long *dynmask;
+    const u128 *cnt;                 // counting table (only read while a task skips to its first candidate)
+    int Q;
     unsigned long long swm;
     int NT1, lane, D, G, GP, m;
     N3State par;
@@ -120,6 +122,7 @@ struct SvCtx {
     int qcount;
     // statistics (wave-uniform scalars)
     unsigned long long n_eval, n_dis, n_it, n_deg, n_surv;
+    unsigned long long n_par, n_rounds, n_ctrips, n_drains, n_dtrips, n_prefix;   // diagnostics: parents evaluated, last-level rounds, ...
 };
 
 typedef float sv2f __attribute__((ext_vector_type(2)));
@@ -237,6 +240,7 @@ __device__ __forceinline__ void sv_survivor(const SvCtx<ML> &c, const unsigned (
 template <int ML>
 __device__ __forceinline__ void sv_drain(SvCtx<ML> &c) {
     for (int b0 = 0; b0 < c.qcount; b0 += WAVE) {
+        c.n_drains++;
         const int idx = b0 + c.lane;
         bool live = idx < c.qcount;
         unsigned rw[ML / 2];
@@ -249,6 +253,7 @@ __device__ __forceinline__ void sv_drain(SvCtx<ML> &c) {
         int iters = 0;
         bool surv = false;
         while (ballot64(live)) {
+            c.n_dtrips++;
             c.n_it += (unsigned)__builtin_popcountll(ballot64(live));
             if (live) {
                 float val2 = 0.f, l2 = 0.f;
@@ -382,6 +387,7 @@ __device__ __forceinline__ void sv_children(SvCtx<ML> &c, int total) {
     if (nrec <= 0) return;
     const float Rl = c.leafRf[ML - 1], Nl = c.leafN[ML - 1];
     for (int k0 = 0; k0 < nrec; k0 += WAVE) {
+        c.n_ctrips++;
         const int k = k0 + c.lane;
         const bool act = k < nrec;
         const unsigned kd = act ? c.W->kid[lo + k] : 0u;
@@ -504,6 +510,29 @@ __device__ __forceinline__ void sv_expand(SvCtx<ML> &c, int n_in) {
         } else {
             live = c.lane == 0;
         }
+        // A task starts `skip` leaves into its first prefix.  Whole subtrees that lie before that point are dropped by their
+        // exact sizes from the counting table instead of being expanded and thrown away (rare path: first prefix of a task).
+        if (LVL > 0 && c.skip > 0) {
+            unsigned long long sz = 0;
+            if (live) {
+                const size_t ci = ((((size_t)(c.D + LVL - 1) * c.Q + node.slot) * 2 + node.sw) * c.NT1 + node.lo) * c.NT1 + (node.hi - 1);
+                const u128 tv = c.cnt[ci];
+                sz = (tv >> 64) ? ~0ull : (unsigned long long)tv;
+            }
+            int drop = 0;
+            const int nl = n_in - pos < WAVE ? n_in - pos : WAVE;
+            for (int l = 0; l < nl; l++) {
+                const unsigned long long s_l = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(sz >> 32), l) << 32) |
+                                               (unsigned)__builtin_amdgcn_readlane((int)sz, l);
+                if (c.skip < s_l) break;
+                c.skip -= s_l;
+                drop++;
+            }
+            if (drop) {
+                pos += drop;
+                continue;
+            }
+        }
         unsigned long long mk = live ? sv_child_mask(c, node, LVL) : 0ull;
         const int cnt = __builtin_popcountll(mk);
         const int incl = sv_incl_scan(cnt);
@@ -522,6 +551,8 @@ __device__ __forceinline__ void sv_expand(SvCtx<ML> &c, int n_in) {
                 }
             }
             sv_parent<ML>(c, take && cnt > 0, code);
+            c.n_par += (unsigned)__builtin_popcountll(ballot64(take && cnt > 0));
+            c.n_rounds++;
             wave_lds_sync();
             sv_children<ML>(c, total);
             wave_lds_sync();
@@ -607,6 +638,8 @@ __global__ __launch_bounds__(64 * SV_WAVES, SV_OCC) void n3_sieve_kernel(N3Dev P
     c.S = &S;
     c.W = &S.w[wv];
     c.dynmask = Pg.dynmask;
+    c.cnt = Pg.cnt;
+    c.Q = Pg.Q;
     c.swm = Pg.swmask;
     c.NT1 = Pg.NT + 1;
     c.lane = lane;
@@ -629,6 +662,7 @@ __global__ __launch_bounds__(64 * SV_WAVES, SV_OCC) void n3_sieve_kernel(N3Dev P
     c.wn1 = c.wn2 = 1.0f / 3.0f;
     c.qcount = 0;
     c.n_eval = c.n_dis = c.n_it = c.n_deg = c.n_surv = 0;
+    c.n_par = c.n_rounds = c.n_ctrips = c.n_drains = c.n_dtrips = c.n_prefix = 0;
     const double inv_N = 1.0 / Pg.N;
     double leafR[ML];
 #pragma unroll
@@ -694,6 +728,7 @@ __global__ __launch_bounds__(64 * SV_WAVES, SV_OCC) void n3_sieve_kernel(N3Dev P
         wave_lds_sync();
         const unsigned long long it0 = c.n_it;
         c.par = n3_unpack((unsigned)__builtin_amdgcn_readlane((int)st, D - 1));
+        c.n_prefix++;
         sv_expand<ML, 0>(c, 1);
         if (c.qcount) sv_drain<ML>(c);                 // the tile changes with the prefix: the queue is emptied first
         n_terms += (c.n_it - it0) * (unsigned)(G + ML);
@@ -709,6 +744,12 @@ __global__ __launch_bounds__(64 * SV_WAVES, SV_OCC) void n3_sieve_kernel(N3Dev P
         atomicAdd(&A.ctr->terms, n_terms);
         atomicAdd(&A.ctr->dismissed, c.n_dis);
         atomicAdd(&A.ctr->sieve_survivors, c.n_surv);
+        atomicAdd(&A.ctr->prof[0], c.n_par);
+        atomicAdd(&A.ctr->prof[1], c.n_rounds);
+        atomicAdd(&A.ctr->prof[2], c.n_ctrips);
+        atomicAdd(&A.ctr->prof[3], c.n_drains);
+        atomicAdd(&A.ctr->prof[4], c.n_dtrips);
+        atomicAdd(&A.ctr->prof[7], c.n_prefix);
     }
 }
 
@@ -864,9 +905,9 @@ __global__ __launch_bounds__(256) void n3_finish_kernel(N3Dev P, SearchArgs A, c
 // P.L must be the burst depth (n3_sieve_levels) -- for the task kernel as well (tasks are cut at depth m - P.L).
 int n3_sieve_levels(const N3Dev &P) {
     if (P.m < 8) return 0;                              // small searches stay on the fused kernel
-    int want = 4;
-    const double lg = log((double)P.total_hi * 18446744073709551616.0 + (double)P.total_lo) / (double)P.m;
-    if (lg > 0.0 && 4.0 * lg < log(600.0)) want = 6;   // the instance branches little: four rows would leave the bursts nearly empty
+    // six expanded rows: a prefix then holds thousands of leaves, so that what a wave does once per prefix (group tile, a chain
+    // of dependent table reads down the first levels) is amortised; four for short matrices
+    int want = P.m >= 10 ? 6 : 4;
     if (const char *e = getenv("THETA_SIEVE_LEVELS")) {
         const int v = atoi(e);
         if (v == 4 || v == 6) want = v;
