@@ -53,7 +53,7 @@ def build(force=False, verbose=True):
         objs.append(o)
         if not force and _newer(o, [s] + headers):
             continue
-        cmd = [cc] + COMMON + extra + ["-c", s, "-o", o]
+        cmd = [cc] + COMMON + extra + os.environ.get("THETA_HIPCC_FLAGS", "").split() + ["-c", s, "-o", o]   # (tuning builds: -DSV_OCC=4 ...)
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((src, subprocess.Popen(cmd)))

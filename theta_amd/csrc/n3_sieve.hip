@@ -48,7 +48,7 @@
 #define SV_QCAP 128       // records waiting for further Newton steps
 #endif
 #ifndef SV_OCC
-#define SV_OCC 4          // blocks per CU the register budget is sized for
+#define SV_OCC 3          // blocks per CU the register budget is sized for (LDS: ~52 KB per 4-wave block)
 #endif
 #ifndef SV_TRIES
 #define SV_TRIES 2        // evaluations a record may take in place when many lanes need another
@@ -677,9 +677,9 @@ __global__ __launch_bounds__(64 * SV_WAVES, SV_OCC) void n3_sieve_kernel(N3Dev P
     }
     unsigned long long n_terms = 0;
 
+    // the device-wide running minimum: only the finish kernel lowers it, between sieve launches -- one load per task
+    c.thr = order_unbits(load_agent_u64(&A.ctr->best_bits)) + A.window;
     while (c.remaining > 0) {
-        // the device-wide running minimum, once per prefix: the lower it is, the more is dismissed
-        c.thr = order_unbits(load_agent_u64(&A.ctr->best_bits)) + A.window;
         // ---- group tile of the prefix: intervals with the same row collapse into one likelihood term {a, b, sum r}
         int G = 0;
         double S1p = 0.0, S2p = 0.0, Rmin = __builtin_inf();
