@@ -50,6 +50,7 @@ FP64_MFMA_PEAK_TFLOPS = 78.6       # MI355X FP64 matrix peak (dense)
 HBM_PEAK_GBS = 8000.0
 
 M, N_POP, K_MAX, TAU, SEED = 50, 3, 6, 2, 4242
+DOMINANT_KERNEL = "n3_sieve_kernel<6>"      # the shipped search's dominant kernel (n3_sieve.hip); rocprofv3 summaries under profiles/
 
 
 def synth(seed=SEED, m=M, n=N_POP, k=K_MAX):
@@ -206,7 +207,7 @@ def measure_traffic(args):
                             import csv
                             with open(os.path.join(dp, f)) as fh:
                                 for row in csv.DictReader(fh):
-                                    if "n3_search_kernel" in row.get("Kernel_Name", "") and row.get("Counter_Name") == ctr:
+                                    if DOMINANT_KERNEL.split("<")[0] in row.get("Kernel_Name", "") and row.get("Counter_Name") == ctr:
                                         vals.append(float(row["Counter_Value"]))
                 if not vals:
                     return None, "rocprofv3 produced no %s rows for the search kernel" % ctr
@@ -419,7 +420,7 @@ def main():
             "bound": "valu", "bound_detail": "vector-ALU (VALU issue) bound, not HBM and not MFMA: candidates are generated on chip "
             "(~0 algorithmic HBM bytes) and the per-candidate C.mu is an (18 x 3).(3) product after group aggregation -- no GEMM. "
             "`peak` is the packed-FP32 vector peak (157.3 TFLOP/s) weighted with the FP64 vector peak (78.6) by the executed mix",
-            "kernel": "n3_search_kernel<6,false>", "achieved": s["achieved"], "peak": s["peak"], "unit": "TFLOP/s", "frac": s["frac"],
+            "kernel": DOMINANT_KERNEL, "achieved": s["achieved"], "peak": s["peak"], "unit": "TFLOP/s", "frac": s["frac"],
             "traffic": traffic, "traffic_note": tnote, "algorithmic_bytes_per_launch": 0,
             "kernel_ms_per_launch": s["kernel_ms_per_launch"], "legs": legs,
             "note": "`achieved` = FLOP executed by the likelihood arithmetic (counted in-kernel from the evaluations and terms "

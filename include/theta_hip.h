@@ -220,6 +220,29 @@ int theta_solve_batch(theta_ctx *ctx, int n, int m, int tau, const int64_t *r, c
 int theta_score_batch(theta_ctx *ctx, int n, int m, int B, const double *Cw, const double *mu,
                       const double *r, double *nll, double *vals, uint8_t *valid);
 
+/* The same with one r per matrix, r[B*m]: matrices that differ in their rows' read counts -- e.g. the (m+1)-row matrices
+ * calc_all_c_* builds, one extra interval each (CalcAllC.py:92-328) -- in ONE launch. */
+int theta_score_batch_rows(theta_ctx *ctx, int n, int m, int B, const double *Cw, const double *mu,
+                           const double *r, double *nll, double *vals, uint8_t *valid);
+
+/*
+ * Device memory the caller owns, so that chains of operators stay in HBM (no reference counterpart: the reference
+ * allocates a fresh numpy array per candidate): theta_enumerate_device -> theta_solve_batch_device /
+ * theta_score_masked_device -> theta_device_copy of the few numbers wanted.  to_device: 1 = host to device, 0 = back.
+ */
+int theta_device_alloc(theta_ctx *ctx, size_t bytes, void **out);
+int theta_device_free(theta_ctx *ctx, void *p);
+int theta_device_copy(theta_ctx *ctx, void *dst, const void *src, size_t bytes, int to_device);
+/*
+ * theta_solve_batch / theta_score_masked on DEVICE-resident candidates and results (d_* are device pointers on the
+ * context's GPU: d_C u8[B*m*(n-1)], d_ok u8[B], d_mu f64[B*n], d_nll f64[B] or f64[B*S], d_vals f64[B*m] or NULL);
+ * r, rN, w, mask stay host arrays (a few KB).  kernel_ms (may be NULL): HIP-event duration of the kernel.
+ */
+int theta_solve_batch_device(theta_ctx *ctx, int n, int m, int tau, const int64_t *r, const int64_t *rN, double max_normal,
+                             int B, const void *d_C, void *d_ok, void *d_mu, void *d_nll, void *d_vals, double *kernel_ms);
+int theta_score_masked_device(theta_ctx *ctx, int n, int m, int tau, int B, int S, const void *d_C, const double *w,
+                              const double *r, const void *d_mu, const uint64_t *mask, void *d_nll, double *kernel_ms);
+
 /*
  * Compact scorer for interval-subset resampling: B candidates as bytes C[B*m*(n-1)] with weights
  * w[m] (the normal counts), mu[B*n], and S row masks mask[S*ceil(m/64)] (uint64 words, bit i =

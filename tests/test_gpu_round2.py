@@ -476,3 +476,48 @@ def test_sieve_end_to_end_against_the_fused_driver(ctx):
         if checked >= 12:
             break
     assert checked >= 8
+
+
+# ---------------------------------------------------------------------------------------------------
+# device-resident chain of the materialised operators; per-matrix r in the literal scorer
+# ---------------------------------------------------------------------------------------------------
+def test_device_resident_chain_matches_host_entry_points(ctx):
+    import bench
+    import theta_amd
+    for n, m, k in ((3, 20, 4), (2, 30, 5)):
+        r, rN, order = bench.synth(seed=21, m=m, n=n, k=k)
+        p = theta_amd.Problem(ctx, n, m, 2, r, rN, [0] * m, [k] * m, 1.0)
+        B = 20000
+        start = p.count // 2
+        d_C = ctx.device_array((B, m * (n - 1)), np.uint8)
+        p.enumerate_device(start, B, d_C)
+        C_host = p.enumerate(start, B)
+        assert np.array_equal(d_C.download().reshape(C_host.shape), C_host)
+        ok_d, mu_d, nll_d, vals_d, ms = ctx.solve_batch_device(n, 2, r, rN, d_C, B, m, 1.0, want_vals=True)
+        ok, mu, nll, vals = ctx.solve_batch(n, 2, r, rN, C_host, 1.0)
+        assert np.array_equal(ok_d.download().astype(bool), ok) and ms > 0
+        assert np.array_equal(nll_d.download(), nll, equal_nan=True) and np.array_equal(mu_d.download(), mu, equal_nan=True)
+        assert np.array_equal(vals_d.download(), vals, equal_nan=True)
+        mu_in = np.where(np.isnan(mu), 1.0 / n, mu)
+        d_mu = ctx.device_array((B, n), np.float64).upload(mu_in)
+        nll_s, ms2 = ctx.score_masked_device(n, 2, d_C, B, m, np.asarray(rN, float), np.asarray(r, float), d_mu)
+        ref, _ = ctx.score_masked(n, 2, C_host, np.asarray(rN, float), np.asarray(r, float), mu_in)
+        assert np.array_equal(nll_s.download(), ref, equal_nan=True)
+        p.close()
+
+
+def test_literal_scorer_with_one_r_per_matrix(ctx):
+    """theta_score_batch_rows: the (m+1)-row matrices of calc_all_c_* differ in their last row AND its read count."""
+    from theta_amd import CalcAllC
+    rng = np.random.RandomState(5)
+    m, B = 9, 40
+    Cs = rng.randint(0, 5, (B, m, 3)).astype(float) * rng.randint(100, 900, (1, m, 1))
+    Cs[:, :, 0] = 2.0 * rng.randint(100, 900, m)
+    mus = rng.dirichlet(np.ones(3), B)
+    rs = rng.randint(10, 1000, (B, m)).astype(float)
+    many = CalcAllC.L3_many(mus, Cs, m, rs, 3)
+    for b in range(B):
+        one = CalcAllC.L3(mus[b], Cs[b].copy(), m, rs[b], 3)
+        assert (one[0] == many[b][0]) or (one[0] != one[0] and many[b][0] != many[b][0])
+        nll_ref, _ = orc.calc_L3(mus[b], Cs[b].copy(), m, rs[b], 3)
+        assert (nll_ref != nll_ref and one[0] != one[0]) or abs(nll_ref - one[0]) <= 1e-12 * abs(nll_ref)

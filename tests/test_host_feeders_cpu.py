@@ -88,3 +88,33 @@ def test_select_intervals_n3_rules():
     # b = 3 changed intervals (longest first: idx 7 (c=0), 1 (c=3), 6 (c=3)), c = 1 normal with ub == 2 (idx 5)
     assert order == [1, 5, 6, 7]
     assert ub2 == [3, 2, 3, 2] and lb2 == [2, 1, 2, 0] and cp == [3, 2, 3, 0]
+
+
+def test_count_number_matrices_3_is_the_reference_upper_estimate():
+    """TimeEstimate.py:113-142 (host logic, no GPU): values computed by the reference itself (Python-2 integer halving)."""
+    from theta_amd.TimeEstimate import count_number_matrices_3
+    assert count_number_matrices_3(6, [3] * 6, [0] * 6) == 33535
+    assert count_number_matrices_3(5, [2, 3, 4, 4, 4], [0, 0, 1, 1, 2]) == 14620           # (29 241 // 2)
+    assert count_number_matrices_3(16, [2] * 16, [0] * 16) == 88008519310
+    assert count_number_matrices_3(7, [5] * 7, [1] * 7) == 7510603
+    assert abs(count_number_matrices_3(50, [6] * 50, [0] * 50) / 1.7242027048628996e+58 - 1) < 1e-12
+    assert abs(count_number_matrices_3(50, [4] * 50, [0] * 50) / 8.461084433153662e+35 - 1) < 1e-12
+
+
+def test_cli_k_limit_matches_the_reference_unless_extended():
+    """FileIO.py:43,136: k in 0..6; larger k only with the explicit (theta_amd-only) --ALLOW_LARGE_K."""
+    import pytest
+    from theta_amd.FileIO import parse_arguments
+    assert parse_arguments(["x.intervals", "-k", "6"], silent=True)[3] == 6
+    with pytest.raises(ValueError):
+        parse_arguments(["x.intervals", "-k", "7"], silent=True)
+    assert parse_arguments(["x.intervals", "-k", "7", "--ALLOW_LARGE_K"], silent=True)[3] == 7
+
+
+def test_time_estimate_refuses_n3_with_more_than_30_intervals_without_force(capsys):
+    """TimeEstimate.py:48-50 -- before anything touches the GPU."""
+    import pytest
+    from theta_amd.TimeEstimate import time_estimate
+    with pytest.raises(SystemExit):
+        time_estimate(3, 31, 3, 2, [0] * 31, [3] * 31, [10] * 31, [10] * 31, 1.0, list(range(31)), 1, True, False)
+    assert "runtime would likely be excessive" in capsys.readouterr().out

@@ -23,7 +23,7 @@ def L2_many(mus, Cs, m, r, ctx=None):
     mu2 = np.zeros((B, 2))
     mu2[:, 0] = mus
     mu2[:, 1] = 1 - np.asarray(mus, dtype=np.float64)
-    nll, vals, valid = (ctx or _lib.default_context()).score_batch(2, Cs[:, :, :2], mu2, r)
+    nll, vals, valid = (ctx or _lib.default_context()).score_batch(2, Cs[:, :, :2], mu2, r)   # r: (m,) or (B, m)
     return [(float(nll[b]), _vals(vals[b], valid[b])) for b in range(B)]
 
 
@@ -121,12 +121,9 @@ def calc_all_c_2(best, r, rN, all_tumor, all_normal, intervals_used, compat=True
                     c_new[:, 1] *= (1 - mu[0])
             slots.append((i, int(bot), int(top)))
         if mats:
-            ctx = _lib.default_context()
-            nlls = []
-            # r differs per interval (one extra entry), so group launches by r: one matrix pair per interval
-            for k in range(0, len(mats), 2):
-                res = L2_many([mu[0], mu[0]], np.array(mats[k:k + 2]), m + 1, np.asarray(rs[k], dtype=np.float64), ctx)
-                nlls += [res[0][0], res[1][0]]
+            # ONE launch for every unused interval: each matrix carries its own r (theta_score_batch_rows)
+            res = L2_many([mu[0]] * len(mats), np.array(mats), m + 1, np.asarray(rs, dtype=np.float64))
+            nlls = [x[0] for x in res]
             for k, (i, bot, top) in enumerate(slots):
                 c_all[i][1] = bot if nlls[2 * k] < nlls[2 * k + 1] else top
         c_all_w = weighted_C(c_all, all_normal)
@@ -135,24 +132,41 @@ def calc_all_c_2(best, r, rN, all_tumor, all_normal, intervals_used, compat=True
     return out
 
 
-def _score_rows_n3(c_new, m, mu, n, r_ext, rows, normal):
-    """L3 of c_new with its last row replaced by each (a, b) in rows (weighted by normal): one launch."""
-    mats = np.repeat(c_new[None, :, :], len(rows), axis=0)
-    for k, (a, b) in enumerate(rows):
-        mats[k, m, 0] = 2 * normal
-        mats[k, m, 1] = a * normal
-        mats[k, m, 2] = b * normal
-    res = L3_many(np.repeat(np.asarray(mu, dtype=np.float64)[None, :], len(rows), axis=0), mats, m + 1,
-                  np.asarray(r_ext, dtype=np.float64), n)
-    return [x[0] for x in res]
+def _score_rows_n3(c_new, m, mu, n, jobs):
+    """
+    L3 of c_new with its last row replaced, for a list of jobs (r_ext, normal, rows): every (a, b) of every job is one matrix
+    of ONE launch (theta_score_batch_rows: one r per matrix).  Returns the NLL lists, job by job.
+    """
+    total = sum(len(rows) for _r, _n, rows in jobs)
+    if total == 0:
+        return [[] for _ in jobs]
+    mats = np.repeat(c_new[None, :, :], total, axis=0)
+    rr = np.zeros((total, m + 1))
+    k = 0
+    for r_ext, normal, rows in jobs:
+        for (a, b) in rows:
+            mats[k, m, 0] = 2 * normal
+            mats[k, m, 1] = a * normal
+            mats[k, m, 2] = b * normal
+            rr[k] = r_ext
+            k += 1
+    res = L3_many(np.repeat(np.asarray(mu, dtype=np.float64)[None, :], total, axis=0), mats, m + 1, rr, n)
+    out, k = [], 0
+    for _r, _n, rows in jobs:
+        out.append([x[0] for x in res[k:k + len(rows)]])
+        k += len(rows)
+    return out
 
 
 def calc_all_c_3(best, r, rN, all_tumor, all_normal, intervals_used):
-    """CalcAllC.py:145-243 (the --NO_MULTI_EVENT variant): floor/ceil with one column at 2, plus the diagonal scan."""
+    """CalcAllC.py:145-243 (the --NO_MULTI_EVENT variant): floor/ceil with one column at 2, plus the diagonal scan.
+    All unused intervals advance together: one launch for their four floor/ceil rows and the first eight diagonal rows, then one
+    launch per further block of eight for the intervals whose NLL has not risen yet (CalcAllC.py:223-232)."""
     out = []
     used = set(intervals_used)
     for c, mu, likelihood, vals in best:
         m, n, c_new, c_all, sum_all, sum_r = _common(c, mu, r, rN, all_tumor, intervals_used)
+        state = {}
         for i in range(len(all_tumor)):
             if i in used:
                 continue
@@ -166,29 +180,37 @@ def calc_all_c_3(best, r, rN, all_tumor, all_normal, intervals_used):
             xt, xb = int(max(0, math.ceil(x))), int(max(0, math.floor(x)))
             y = calculateX(all_tumor[i], nrm, sum_r, sum_all, mu, n, [2, 2, 0], 2) / nrm
             yt, yb = int(max(0, math.ceil(y))), int(max(0, math.floor(y)))
-            rows = [(xb, 2), (xt, 2), (2, yb), (2, yt)]
-            r_ext = list(r) + [all_tumor[i]]
-            cand = []
-            diag, prev, j = [], float("inf"), 0
-            # the reference walks the diagonal until the NLL rises (CalcAllC.py:223-232); score it in blocks
-            done = False
-            first = True
-            while not done:
-                blk = [(jj, jj) for jj in range(j, j + 8)]
-                nl = _score_rows_n3(c_new, m, mu, n, r_ext, (rows if first else []) + blk, nrm)
-                if first:
-                    cand += [(nl[0], [xb, 2]), (nl[1], [xt, 2]), (nl[2], [2, yb]), (nl[3], [2, yt])]
+            state[i] = {"rows": [(xb, 2), (xt, 2), (2, yb), (2, yt)], "labels": [[xb, 2], [xt, 2], [2, yb], [2, yt]],
+                        "r_ext": list(r) + [all_tumor[i]], "nrm": nrm, "cand": [], "prev": float("inf"), "j": 0, "first": True}
+        live = list(state.keys())
+        while live:
+            jobs = []
+            for i in live:
+                st = state[i]
+                blk = [(jj, jj) for jj in range(st["j"], st["j"] + 8)]
+                jobs.append((st["r_ext"], st["nrm"], (st["rows"] if st["first"] else []) + blk))
+            res = _score_rows_n3(c_new, m, mu, n, jobs)
+            nxt = []
+            for i, nl in zip(live, res):
+                st = state[i]
+                if st["first"]:
+                    st["cand"] += [(nl[k], st["labels"][k]) for k in range(4)]
                     nl = nl[4:]
-                    first = False
-                for jj, l in zip(range(j, j + 8), nl):
-                    cand.append((l, [jj, jj]))
-                    if l > prev or l != l:
+                    st["first"] = False
+                done = False
+                for jj, l in zip(range(st["j"], st["j"] + 8), nl):
+                    st["cand"].append((l, [jj, jj]))
+                    if l > st["prev"] or l != l:
                         done = True
                         break
-                    prev = l
-                j += 8
-            cand.sort()
-            c_all[i][1], c_all[i][2] = cand[0][1]
+                    st["prev"] = l
+                st["j"] += 8
+                if not done:
+                    nxt.append(i)
+            live = nxt
+        for i, st in state.items():
+            st["cand"].sort()
+            c_all[i][1], c_all[i][2] = st["cand"][0][1]
         c_all_w = weighted_C(c_all, all_normal)
         like, v = L3(mu, c_all_w, len(all_tumor), np.asarray(all_tumor, dtype=np.float64), n)
         out.append([(c_all, mu, like, v)])
@@ -196,11 +218,13 @@ def calc_all_c_3(best, r, rN, all_tumor, all_normal, intervals_used):
 
 
 def calc_all_c_3_multi_event(best, r, rN, all_tumor, all_normal, intervals_used):
-    """CalcAllC.py:245-328 (default for n=3): for every x in 0..ceil(x*) the best of floor/ceil(y*(x))."""
+    """CalcAllC.py:245-328 (default for n=3): for every x in 0..ceil(x*) the best of floor/ceil(y*(x)).
+    The candidate rows of ALL unused intervals are scored in one launch."""
     out = []
     used = set(intervals_used)
     for c, mu, likelihood, vals in best:
         m, n, c_new, c_all, sum_all, sum_r = _common(c, mu, r, rN, all_tumor, intervals_used)
+        jobs, owners = [], []
         for i in range(len(all_tumor)):
             if i in used:
                 continue
@@ -222,7 +246,9 @@ def calc_all_c_3_multi_event(best, r, rN, all_tumor, all_normal, intervals_used)
                 elif x > 2:
                     bot, top = max(2, bot), max(2, top)
                 rows += [(x, bot), (x, top)]
-            nl = _score_rows_n3(c_new, m, mu, n, list(r) + [all_tumor[i]], rows, nrm)
+            jobs.append((list(r) + [all_tumor[i]], nrm, rows))
+            owners.append(i)
+        for i, (_r, _n, rows), nl in zip(owners, jobs, _score_rows_n3(c_new, m, mu, n, jobs)):
             lmin, row_min = float("inf"), None
             for (x, yv), l in zip(rows, nl):       # strict '<' in evaluation order, like the reference
                 if l < lmin:

@@ -9,7 +9,8 @@ import os
 import sys
 
 N_VALS = [None, 2, 3]     # FileIO.py:42
-MAX_K = 8                 # the reference stops at 7 (k in range(7), FileIO.py:43,136); the n=3 kernels go to 8
+K_VALS = range(7)         # FileIO.py:43: k = 0 .. 6
+MAX_K_EXTENDED = 8        # with --ALLOW_LARGE_K (not a flag of the reference): what the kernels hold (n=3: copy numbers <= 7)
 
 
 def parse_arguments(argv=None, silent=False):
@@ -42,12 +43,15 @@ def parse_arguments(argv=None, silent=False):
     p.add_argument("--RATIO_DEV", type=float, default=0.1)
     p.add_argument("--MIN_FRAC", type=float, default=0.05)
     p.add_argument("--NO_CLUSTERING", action="store_true", default=False)
+    p.add_argument("--ALLOW_LARGE_K", action="store_true", default=False,
+                   help="(theta_amd only) accept -k above the reference's limit of 6, up to %d" % MAX_K_EXTENDED)
     a = p.parse_args(argv)
 
     if a.N not in N_VALS:
         raise ValueError("Invalid value entered for n: " + str(a.N) + ". Currently supported values for n: " + str(N_VALS))
-    if a.MAX_K not in range(MAX_K + 1):
-        raise ValueError("Invalid value entered for k: " + str(a.MAX_K) + ". Supported values for k: 0-" + str(MAX_K))
+    k_vals = range(MAX_K_EXTENDED + 1) if a.ALLOW_LARGE_K else K_VALS          # FileIO.py:136
+    if a.MAX_K not in k_vals:
+        raise ValueError("Invalid value entered for k: " + str(a.MAX_K) + ". Supported values for k: 0-" + str(max(k_vals)))
     if a.TAU < 0:
         raise ValueError("Invalid value for tau: " + str(a.TAU) + ". Tau must be non-negative")
     if a.MAX_NORMAL < 0 or a.MAX_NORMAL > 1:

@@ -46,6 +46,8 @@ EXPORTS = ["theta_create", "theta_destroy", "theta_last_error", "theta_device_in
            "theta_problem_destroy", "theta_problem_count", "theta_search", "theta_search_values", "theta_enumerate", "theta_enumerate_device",
            "theta_solve_batch", "theta_score_batch", "theta_score_masked", "theta_search_suspects", "theta_boundary_min", "theta_problem_hint",
            "theta_search_degenerate", "theta_problem_set_option", "theta_synchronize",
+           "theta_score_batch_rows", "theta_device_alloc", "theta_device_free", "theta_device_copy", "theta_solve_batch_device",
+           "theta_score_masked_device",
            "theta_comm_create", "theta_comm_destroy", "theta_comm_info", "theta_comm_barrier", "theta_comm_allreduce_min",
            "theta_comm_allreduce_max", "theta_comm_allreduce_sum", "theta_comm_allgather", "theta_exchange_finalists"]
 
@@ -94,6 +96,12 @@ def load():
     lib.theta_solve_batch.argtypes = [vp, i32, i32, i32, i64p, i64p, C.c_double, i32, u8p, u8p, dp, dp, dp]
     lib.theta_score_batch.argtypes = [vp, i32, i32, i32, dp, dp, dp, dp, dp, u8p]
     lib.theta_score_masked.argtypes = [vp, i32, i32, i32, i32, i32, u8p, dp, dp, dp, u64p, dp, dp]
+    lib.theta_score_batch_rows.argtypes = [vp, i32, i32, i32, dp, dp, dp, dp, dp, u8p]
+    lib.theta_device_alloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
+    lib.theta_device_free.argtypes = [vp, vp]
+    lib.theta_device_copy.argtypes = [vp, vp, vp, C.c_size_t, i32]
+    lib.theta_solve_batch_device.argtypes = [vp, i32, i32, i32, i64p, i64p, C.c_double, i32, vp, vp, vp, vp, vp, dp]
+    lib.theta_score_masked_device.argtypes = [vp, i32, i32, i32, i32, i32, vp, dp, dp, vp, u64p, vp, dp]
     _lib = lib
     return lib
 
@@ -174,7 +182,8 @@ class Context:
         return out
 
     def score_batch(self, n, Cw, mu, r):
-        """CalcAllC.L2/L3 on B literal matrices Cw (B, m, n); mu (B, n); returns nll, vals, valid."""
+        """CalcAllC.L2/L3 on B literal matrices Cw (B, m, n); mu (B, n); r (m,) shared or (B, m) one per matrix;
+        returns nll, vals, valid."""
         Cw = np.ascontiguousarray(Cw, dtype=np.float64)
         B, m, nn = Cw.shape
         assert nn == n
@@ -183,9 +192,41 @@ class Context:
         nll = np.zeros(B)
         vals = np.zeros((B, m))
         valid = np.zeros((B, m), np.uint8)
-        _check(load().theta_score_batch(self._h, n, m, B, _p(Cw, C.c_double), _p(mu, C.c_double), _p(r, C.c_double),
-                                        _p(nll, C.c_double), _p(vals, C.c_double), _p(valid, C.c_uint8)))
+        fn = load().theta_score_batch_rows if r.ndim == 2 else load().theta_score_batch
+        assert r.shape == ((B, m) if r.ndim == 2 else (m,))
+        _check(fn(self._h, n, m, B, _p(Cw, C.c_double), _p(mu, C.c_double), _p(r, C.c_double),
+                  _p(nll, C.c_double), _p(vals, C.c_double), _p(valid, C.c_uint8)))
         return nll, vals, valid.astype(bool)
+
+    # -- device-resident chains -----------------------------------------------------------------
+    def device_array(self, shape, dtype):
+        """Uninitialised array in this GPU's HBM (DeviceArray): for chains enumerate_device -> solve / score -> download."""
+        return DeviceArray(self, shape, dtype)
+
+    def solve_batch_device(self, n, tau, r, rN, d_C, B, m, max_normal=1.0, want_vals=False):
+        """Optimizer.solve on B candidates already in HBM (d_C: DeviceArray u8).  Returns DeviceArrays ok, mu, nll, vals and
+        the kernel's duration in ms."""
+        r = np.ascontiguousarray(r, dtype=np.int64)
+        rN = np.ascontiguousarray(rN, dtype=np.int64)
+        ok, mu, nll = self.device_array((B,), np.uint8), self.device_array((B, n), np.float64), self.device_array((B,), np.float64)
+        vals = self.device_array((B, m), np.float64) if want_vals else None
+        ms = C.c_double()
+        _check(load().theta_solve_batch_device(self._h, n, m, int(tau), _p(r, C.c_int64), _p(rN, C.c_int64), float(max_normal), B,
+                                               d_C.ptr, ok.ptr, mu.ptr, nll.ptr, vals.ptr if vals is not None else None, C.byref(ms)))
+        return ok, mu, nll, vals, ms.value
+
+    def score_masked_device(self, n, tau, d_C, B, m, w, r, d_mu, masks=None):
+        """theta_score_masked on device-resident candidates and mixtures; returns (DeviceArray nll (B, S), kernel ms)."""
+        w = np.ascontiguousarray(w, dtype=np.float64)
+        r = np.ascontiguousarray(r, dtype=np.float64)
+        S = 1 if masks is None else masks.shape[0]
+        if masks is not None:
+            masks = np.ascontiguousarray(masks, dtype=np.uint64)
+        nll = self.device_array((B, S), np.float64)
+        ms = C.c_double()
+        _check(load().theta_score_masked_device(self._h, n, m, int(tau), B, S, d_C.ptr, _p(w, C.c_double), _p(r, C.c_double), d_mu.ptr,
+                                                _p(masks, C.c_uint64) if masks is not None else None, nll.ptr, C.byref(ms)))
+        return nll, ms.value
 
     def score_masked(self, n, tau, C_u8, w, r, mu, masks=None):
         """Byte candidates x row masks; masks is (S, ceil(m/64)) uint64 or None. Returns (nll (B,S), kernel_ms)."""
@@ -204,6 +245,39 @@ class Context:
                                          _p(masks, C.c_uint64) if masks is not None else None, _p(nll, C.c_double),
                                          C.byref(ms)))
         return nll, ms.value
+
+
+class DeviceArray:
+    """A typed block of HBM owned by the caller (theta_device_alloc); numpy in / out through upload() / download()."""
+
+    def __init__(self, ctx, shape, dtype):
+        self.ctx, self.shape, self.dtype = ctx, tuple(int(x) for x in shape), np.dtype(dtype)
+        self.nbytes = int(np.prod(self.shape, dtype=np.int64)) * self.dtype.itemsize
+        h = C.c_void_p()
+        _check(load().theta_device_alloc(ctx._h, self.nbytes, C.byref(h)))
+        self.ptr = h
+
+    def upload(self, arr):
+        a = np.ascontiguousarray(arr, dtype=self.dtype)
+        assert a.nbytes == self.nbytes
+        _check(load().theta_device_copy(self.ctx._h, self.ptr, a.ctypes.data_as(C.c_void_p), self.nbytes, 1))
+        return self
+
+    def download(self):
+        out = np.zeros(self.shape, self.dtype)
+        _check(load().theta_device_copy(self.ctx._h, out.ctypes.data_as(C.c_void_p), self.ptr, self.nbytes, 0))
+        return out
+
+    def free(self):
+        if getattr(self, "ptr", None):
+            load().theta_device_free(self.ctx._h, self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
 
 
 _default_ctx = None
@@ -448,6 +522,8 @@ class Problem:
         """Same candidates written to device memory (`device_ptr`: address of count*m*(n-1) bytes on this GPU,
         e.g. torch_tensor.data_ptr()).  Returns the kernels' duration in ms."""
         ms = C.c_double(0.0)
+        if isinstance(device_ptr, DeviceArray):
+            device_ptr = device_ptr.ptr.value
         _check(load().theta_enumerate_device(self._h, _u128(begin), int(count), C.c_void_p(int(device_ptr)), C.byref(ms)))
         return ms.value
 

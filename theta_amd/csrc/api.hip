@@ -35,7 +35,7 @@ void n3_launch_enumerate(const N3Dev &P, const N3Task *tasks, const unsigned *st
 void batch_launch_solve(int n, int m, int tau, const double *r, const double *rN, double max_normal, int B,
                         const unsigned char *C, unsigned char *ok, double *mu, double *nll, double *vals,
                         hipStream_t st);
-void batch_launch_score(int n, int m, int B, const double *Cw, const double *mu, const double *r, double *nll,
+void batch_launch_score(int n, int m, int B, const double *Cw, const double *mu, const double *r, int r_stride, double *nll,
                         double *vals, unsigned char *valid, hipStream_t st);
 void batch_launch_boundary_min(int m, int tau, const double *r, const double *rN, int B, const unsigned char *C,
                                double *bound, hipStream_t st);
@@ -606,6 +606,12 @@ static const double FLOPS_PER_TERM_ITER_N3 = 25.0;  // 2 sub, 2 fma (q), rcp + 2
 static const double FLOPS_PER_TERM_ITER_N2 = 13.0;  // fma (den), rcp + 2 fma, mul, fma (f), mul, fma (f')
 static const double FLOPS_PER_TERM_ITER_N3_F32 = 24.0;  // packed pass: 2 sub, 2 fma (q), rcp, log + fma (value), mul, 2 fma (grad), 3 mul, 3 fma
 static const double FLOPS_PER_FINAL_TERM_N3 = 9.0;  // f32 screen: 2 sub, 2 fma, log, fma
+// sieve (n3_sieve.hip), shared sums of a last-level node, per term: 2 fma (q), rcp, log + fma (L), mul (t), add + 2 fma (T), mul (tw),
+// add (W00), 2 mul + 2 add (W01, W02), 3 fma (W11, W12, W22)
+static const double FLOPS_PER_TERM_SIEVE_SHARED = 26.0;
+// ... and per child: its own term (26) + the restriction to its slice, the 2x2 solve, decrement, value and bound (6 + 6 fma, det 3,
+// z.w 2 fma, rcp, 2 x 3 + 2 (d), 3 (l2), log + fma, step 5, bound 8)
+static const double FLOPS_PER_SIEVE_CHILD = 90.0;
 static const double FLOPS_PER_FINAL_TERM_N2 = 5.0;  // fma, log, fma
 
 extern "C" int theta_search(theta_problem *p, const uint64_t rank_begin[2], const uint64_t rank_end[2], double window,
@@ -649,7 +655,8 @@ extern "C" int theta_search(theta_problem *p, const uint64_t rank_begin[2], cons
         } else {   // n=3: FP64 iterations (dump, ill-conditioned candidates, the finish kernel: m terms each) + the packed-f32
                    // coarse pass and screen
             stats->flops = (uint64_t)(per * ((double)hc.terms64 + (double)hc.finish_iterations * (double)p->m));
-            stats->flops_f32 = (uint64_t)(FLOPS_PER_TERM_ITER_N3_F32 * (double)(hc.terms - hc.terms64) + fin * (double)hc.final_terms);
+            stats->flops_f32 = (uint64_t)(FLOPS_PER_TERM_ITER_N3_F32 * (double)(hc.terms - hc.terms64) + fin * (double)hc.final_terms +
+                                          FLOPS_PER_TERM_SIEVE_SHARED * (double)hc.sieve_pterms + FLOPS_PER_SIEVE_CHILD * (double)hc.sieve_children);
         }
         stats->survivors = hc.sieve_survivors;
         stats->fallback_candidates = p->last_fallback;
@@ -994,8 +1001,8 @@ extern "C" int theta_solve_batch(theta_ctx *ctx, int n, int m, int tau, const in
     return THETA_OK;
 }
 
-extern "C" int theta_score_batch(theta_ctx *ctx, int n, int m, int B, const double *Cw, const double *mu,
-                                 const double *r, double *nll, double *vals, uint8_t *valid) {
+static int score_batch_impl(theta_ctx *ctx, int n, int m, int B, const double *Cw, const double *mu, const double *r,
+                            int r_per_matrix, double *nll, double *vals, uint8_t *valid) {
     if (!ctx || !Cw || !mu || !r || !nll || B < 0) {
         theta_set_error("theta_score_batch: null argument");
         return THETA_ERR_ARG;
@@ -1011,17 +1018,136 @@ extern "C" int theta_score_batch(theta_ctx *ctx, int n, int m, int B, const doub
     int rc;
     if ((rc = upload(d_C, Cw, (size_t)B * m * n * sizeof(double), st))) return rc;
     if ((rc = upload(d_mu, mu, (size_t)B * n * sizeof(double), st))) return rc;
-    if ((rc = upload(d_r, r, (size_t)m * sizeof(double), st))) return rc;
+    if ((rc = upload(d_r, r, (size_t)m * (r_per_matrix ? (size_t)B : 1) * sizeof(double), st))) return rc;
     if ((rc = d_nll.alloc((size_t)B * sizeof(double)))) return rc;
     if (vals && (rc = d_vals.alloc((size_t)B * m * sizeof(double)))) return rc;
     if (valid && (rc = d_valid.alloc((size_t)B * m))) return rc;
-    batch_launch_score(n, m, B, (const double *)d_C.p, (const double *)d_mu.p, (const double *)d_r.p, (double *)d_nll.p,
-                       vals ? (double *)d_vals.p : nullptr, valid ? (unsigned char *)d_valid.p : nullptr, st);
+    batch_launch_score(n, m, B, (const double *)d_C.p, (const double *)d_mu.p, (const double *)d_r.p, r_per_matrix ? m : 0,
+                       (double *)d_nll.p, vals ? (double *)d_vals.p : nullptr, valid ? (unsigned char *)d_valid.p : nullptr, st);
     HIP_TRY(hipMemcpyAsync(nll, d_nll.p, (size_t)B * sizeof(double), hipMemcpyDeviceToHost, st));
     if (vals) HIP_TRY(hipMemcpyAsync(vals, d_vals.p, (size_t)B * m * sizeof(double), hipMemcpyDeviceToHost, st));
     if (valid) HIP_TRY(hipMemcpyAsync(valid, d_valid.p, (size_t)B * m, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     HIP_TRY(hipGetLastError());
+    return THETA_OK;
+}
+
+extern "C" int theta_score_batch(theta_ctx *ctx, int n, int m, int B, const double *Cw, const double *mu,
+                                 const double *r, double *nll, double *vals, uint8_t *valid) {
+    return score_batch_impl(ctx, n, m, B, Cw, mu, r, 0, nll, vals, valid);
+}
+
+extern "C" int theta_score_batch_rows(theta_ctx *ctx, int n, int m, int B, const double *Cw, const double *mu,
+                                      const double *r, double *nll, double *vals, uint8_t *valid) {
+    return score_batch_impl(ctx, n, m, B, Cw, mu, r, 1, nll, vals, valid);
+}
+
+// ---- device memory the caller owns, for chains of operators that stay on the GPU ----------------------------------
+extern "C" int theta_device_alloc(theta_ctx *ctx, size_t bytes, void **out) {
+    if (!ctx || !out) {
+        theta_set_error("theta_device_alloc: null argument");
+        return THETA_ERR_ARG;
+    }
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipMalloc(out, bytes ? bytes : 8));
+    return THETA_OK;
+}
+
+extern "C" int theta_device_free(theta_ctx *ctx, void *p) {
+    if (!ctx) {
+        theta_set_error("null context");
+        return THETA_ERR_ARG;
+    }
+    if (!p) return THETA_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipFree(p));
+    return THETA_OK;
+}
+
+extern "C" int theta_device_copy(theta_ctx *ctx, void *dst, const void *src, size_t bytes, int to_device) {
+    if (!ctx || (bytes && (!dst || !src))) {
+        theta_set_error("theta_device_copy: null argument");
+        return THETA_ERR_ARG;
+    }
+    if (!bytes) return THETA_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipMemcpyAsync(dst, src, bytes, to_device ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return THETA_OK;
+}
+
+extern "C" int theta_solve_batch_device(theta_ctx *ctx, int n, int m, int tau, const int64_t *r, const int64_t *rN,
+                                        double max_normal, int B, const void *d_C, void *d_ok, void *d_mu, void *d_nll,
+                                        void *d_vals, double *kernel_ms) {
+    if (!ctx || !r || !rN || !d_C || !d_ok || !d_mu || !d_nll || B < 0) {
+        theta_set_error("theta_solve_batch_device: null argument");
+        return THETA_ERR_ARG;
+    }
+    if ((n != 2 && n != 3) || m < 1 || m > 4096) {
+        theta_set_error("theta_solve_batch_device: bad shape n=%d m=%d", n, m);
+        return THETA_ERR_ARG;
+    }
+    if (kernel_ms) *kernel_ms = 0.0;
+    if (B == 0) return THETA_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    std::vector<double> rd(m), rnd(m);
+    for (int i = 0; i < m; i++) {
+        rd[i] = (double)r[i];
+        rnd[i] = (double)rN[i];
+    }
+    DevBuf d_r, d_rN;
+    int rc;
+    if ((rc = upload(d_r, rd.data(), m * sizeof(double), st))) return rc;
+    if ((rc = upload(d_rN, rnd.data(), m * sizeof(double), st))) return rc;
+    HIP_TRY(hipEventRecord(ctx->ev0, st));
+    batch_launch_solve(n, m, tau, (const double *)d_r.p, (const double *)d_rN.p, max_normal, B, (const unsigned char *)d_C,
+                       (unsigned char *)d_ok, (double *)d_mu, (double *)d_nll, (double *)d_vals, st);
+    HIP_TRY(hipEventRecord(ctx->ev1, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(hipGetLastError());
+    if (kernel_ms) {
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+        *kernel_ms = ms;
+    }
+    return THETA_OK;
+}
+
+extern "C" int theta_score_masked_device(theta_ctx *ctx, int n, int m, int tau, int B, int S, const void *d_C, const double *w,
+                                         const double *r, const void *d_mu, const uint64_t *mask, void *d_nll,
+                                         double *kernel_ms) {
+    if (!ctx || !d_C || !w || !r || !d_mu || !d_nll || B < 0 || S < 1) {
+        theta_set_error("theta_score_masked_device: bad argument");
+        return THETA_ERR_ARG;
+    }
+    if ((n != 2 && n != 3) || m < 1 || m > 256) {
+        theta_set_error("theta_score_masked_device: need n in {2,3}, 1 <= m <= 256");
+        return THETA_ERR_ARG;
+    }
+    if (kernel_ms) *kernel_ms = 0.0;
+    if (B == 0) return THETA_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    int words = (m + 63) / 64;
+    DevBuf d_w, d_r, d_mask, d_rsum;
+    int rc;
+    if ((rc = upload(d_w, w, (size_t)m * sizeof(double), st))) return rc;
+    if ((rc = upload(d_r, r, (size_t)m * sizeof(double), st))) return rc;
+    if (mask && (rc = upload(d_mask, mask, (size_t)S * words * sizeof(uint64_t), st))) return rc;
+    if ((rc = d_rsum.alloc((size_t)S * sizeof(double)))) return rc;
+    HIP_TRY(hipEventRecord(ctx->ev0, st));
+    batch_launch_score_masked(n, m, tau, B, S, (const unsigned char *)d_C, (const double *)d_w.p, (const double *)d_r.p,
+                              (const double *)d_mu, mask ? (const unsigned long long *)d_mask.p : nullptr, (double *)d_nll,
+                              (double *)d_rsum.p, st);
+    HIP_TRY(hipEventRecord(ctx->ev1, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(hipGetLastError());
+    if (kernel_ms) {
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+        *kernel_ms = ms;
+    }
     return THETA_OK;
 }
 

@@ -274,10 +274,11 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
 }
 
 __global__ __launch_bounds__(64) void score_batch_kernel(int n, int m, int B, const double *Cw, const double *mu,
-                                                         const double *r, double *nll, double *vals,
+                                                         const double *r_all, int r_stride, double *nll, double *vals,
                                                          unsigned char *valid) {
     int b = blockIdx.x;
     int lane = threadIdx.x;
+    const double *r = r_all + (size_t)b * r_stride;     // r_stride = 0: one r for all matrices; m: one per matrix
     const double *M = Cw + (size_t)b * m * n;
     const double *mv = mu + (size_t)b * n;
     double m0 = mv[0];
@@ -553,9 +554,9 @@ void batch_launch_boundary_min(int m, int tau, const double *r, const double *rN
                        C, bound);
 }
 
-void batch_launch_score(int n, int m, int B, const double *Cw, const double *mu, const double *r, double *nll,
+void batch_launch_score(int n, int m, int B, const double *Cw, const double *mu, const double *r, int r_stride, double *nll,
                         double *vals, unsigned char *valid, hipStream_t st) {
-    hipLaunchKernelGGL(score_batch_kernel, dim3(B), dim3(64), 0, st, n, m, B, Cw, mu, r, nll, vals, valid);
+    hipLaunchKernelGGL(score_batch_kernel, dim3(B), dim3(64), 0, st, n, m, B, Cw, mu, r, r_stride, nll, vals, valid);
 }
 
 void batch_launch_score_masked(int n, int m, int tau, int B, int S, const unsigned char *C, const double *w,

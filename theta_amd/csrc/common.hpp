@@ -83,6 +83,8 @@ struct SearchCounters {
     unsigned int pad0;
     unsigned long long sieve_survivors;   // n=3 fast path: contenders the sieve kernel handed to the finish kernel
     unsigned long long finish_iterations; // ... and the FP64 Newton iterations (m terms each) that kernel ran on them
+    unsigned long long sieve_pterms;      // sieve: likelihood terms evaluated for last-level nodes (shared by a node's children)
+    unsigned long long sieve_children;    // sieve: candidates given their shared first evaluation (one own term + the 2-D reduction)
     unsigned long long prof[8];        // shader cycles per kernel phase, summed over waves (diagnostic)
 };
 

@@ -123,6 +123,7 @@ struct SvCtx {
     // statistics (wave-uniform scalars)
     unsigned long long n_eval, n_dis, n_it, n_deg, n_surv;
     unsigned long long n_par, n_rounds, n_ctrips, n_drains, n_dtrips, n_prefix;   // diagnostics: parents evaluated, last-level rounds, ...
+    unsigned long long n_child, n_dit;   // shared first evaluations (children) / full evaluations (queue)
 };
 
 typedef float sv2f __attribute__((ext_vector_type(2)));
@@ -255,6 +256,7 @@ __device__ __forceinline__ void sv_drain(SvCtx<ML> &c) {
         while (ballot64(live)) {
             c.n_dtrips++;
             c.n_it += (unsigned)__builtin_popcountll(ballot64(live));
+            c.n_dit += (unsigned)__builtin_popcountll(ballot64(live));
             if (live) {
                 float val2 = 0.f, l2 = 0.f;
                 const int st = sv_step<ML>(c, rw, s1, s2, u1, u2, val2, l2);
@@ -409,6 +411,7 @@ __device__ __forceinline__ void sv_children(SvCtx<ML> &c, int total) {
         bool surv = false;
         float qu1 = (1.0f / 3.0f) * __builtin_amdgcn_rcpf(s1), qu2 = (1.0f / 3.0f) * __builtin_amdgcn_rcpf(s2);
         c.n_it += (unsigned)__builtin_popcountll(ballot64(ev));
+        c.n_child += (unsigned)__builtin_popcountll(ballot64(ev));
         if (ev) {
             const float w = __builtin_amdgcn_rcpf(q), t = Rl * w, tw = t * w, twx = tw * x, twy = tw * y;
             const float L = __builtin_fmaf(Rl, __builtin_amdgcn_logf(q), p0.x);
@@ -663,6 +666,7 @@ __global__ __launch_bounds__(64 * SV_WAVES, SV_OCC) void n3_sieve_kernel(N3Dev P
     c.qcount = 0;
     c.n_eval = c.n_dis = c.n_it = c.n_deg = c.n_surv = 0;
     c.n_par = c.n_rounds = c.n_ctrips = c.n_drains = c.n_dtrips = c.n_prefix = 0;
+    c.n_child = c.n_dit = 0;
     const double inv_N = 1.0 / Pg.N;
     double leafR[ML];
 #pragma unroll
@@ -675,7 +679,7 @@ __global__ __launch_bounds__(64 * SV_WAVES, SV_OCC) void n3_sieve_kernel(N3Dev P
 #pragma unroll
         for (int l = 0; l < ML; l += 2) c.W->fRL[l >> 1] = make_float2((float)leafR[l], (float)leafR[l + 1]);
     }
-    unsigned long long n_terms = 0;
+    unsigned long long n_terms = 0, n_pterms = 0;
 
     // the device-wide running minimum: only the finish kernel lowers it, between sieve launches -- one load per task
     c.thr = order_unbits(load_agent_u64(&A.ctr->best_bits)) + A.window;
@@ -726,12 +730,13 @@ __global__ __launch_bounds__(64 * SV_WAVES, SV_OCC) void n3_sieve_kernel(N3Dev P
         c.S2p = (float)(S2p * inv_N);
         c.rtot_over_rmin = (float)(Pg.Rtot / Rmin);
         wave_lds_sync();
-        const unsigned long long it0 = c.n_it;
+        const unsigned long long it0 = c.n_dit, par0 = c.n_par;
         c.par = n3_unpack((unsigned)__builtin_amdgcn_readlane((int)st, D - 1));
         c.n_prefix++;
         sv_expand<ML, 0>(c, 1);
         if (c.qcount) sv_drain<ML>(c);                 // the tile changes with the prefix: the queue is emptied first
-        n_terms += (c.n_it - it0) * (unsigned)(G + ML);
+        n_terms += (c.n_dit - it0) * (unsigned)(G + ML);          // full evaluations: every term of the candidate
+        n_pterms += (c.n_par - par0) * (unsigned)(G + ML - 1);    // shared sums of a last-level node: all terms but its children's
         c.skip = 0;                                    // only the first prefix of a task starts mid-way
         if (c.remaining == 0) break;
         if (!sv_next_prefix(P, st, D, lane)) break;
@@ -744,6 +749,8 @@ __global__ __launch_bounds__(64 * SV_WAVES, SV_OCC) void n3_sieve_kernel(N3Dev P
         atomicAdd(&A.ctr->terms, n_terms);
         atomicAdd(&A.ctr->dismissed, c.n_dis);
         atomicAdd(&A.ctr->sieve_survivors, c.n_surv);
+        atomicAdd(&A.ctr->sieve_pterms, n_pterms);
+        atomicAdd(&A.ctr->sieve_children, c.n_child);
         atomicAdd(&A.ctr->prof[0], c.n_par);
         atomicAdd(&A.ctr->prof[1], c.n_rounds);
         atomicAdd(&A.ctr->prof[2], c.n_ctrips);
