@@ -41,7 +41,7 @@ void batch_launch_boundary_min(int m, int tau, const double *r, const double *rN
                                double *bound, hipStream_t st);
 void batch_launch_score_masked(int n, int m, int tau, int B, int S, const unsigned char *C, const double *w,
                                const double *r, const double *mu, const unsigned long long *mask, double *nll,
-                               double *rsum_scratch, hipStream_t st);
+                               double *rsum_scratch, hipStream_t st, double rsum_host, bool rsum_host_valid);
 
 // ---- error string ---------------------------------------------------------------------------------
 static thread_local char g_err[512] = "";
@@ -1042,6 +1042,12 @@ extern "C" int theta_score_batch_rows(theta_ctx *ctx, int n, int m, int B, const
     return score_batch_impl(ctx, n, m, B, Cw, mu, r, 1, nll, vals, valid);
 }
 
+static double host_sum(const double *v, int m) {
+    double s = 0.0;
+    for (int i = 0; i < m; i++) s += v[i];
+    return s;
+}
+
 // ---- device memory the caller owns, for chains of operators that stay on the GPU ----------------------------------
 extern "C" int theta_device_alloc(theta_ctx *ctx, size_t bytes, void **out) {
     if (!ctx || !out) {
@@ -1139,7 +1145,7 @@ extern "C" int theta_score_masked_device(theta_ctx *ctx, int n, int m, int tau, 
     HIP_TRY(hipEventRecord(ctx->ev0, st));
     batch_launch_score_masked(n, m, tau, B, S, (const unsigned char *)d_C, (const double *)d_w.p, (const double *)d_r.p,
                               (const double *)d_mu, mask ? (const unsigned long long *)d_mask.p : nullptr, (double *)d_nll,
-                              (double *)d_rsum.p, st);
+                              (double *)d_rsum.p, st, host_sum(r, m), true);
     HIP_TRY(hipEventRecord(ctx->ev1, st));
     HIP_TRY(hipStreamSynchronize(st));
     HIP_TRY(hipGetLastError());
@@ -1178,7 +1184,7 @@ extern "C" int theta_score_masked(theta_ctx *ctx, int n, int m, int tau, int B, 
     HIP_TRY(hipEventRecord(ctx->ev0, st));
     batch_launch_score_masked(n, m, tau, B, S, (const unsigned char *)d_C.p, (const double *)d_w.p, (const double *)d_r.p,
                               (const double *)d_mu.p, mask ? (const unsigned long long *)d_mask.p : nullptr,
-                              (double *)d_nll.p, (double *)d_rsum.p, st);
+                              (double *)d_nll.p, (double *)d_rsum.p, st, host_sum(r, m), true);
     HIP_TRY(hipEventRecord(ctx->ev1, st));
     HIP_TRY(hipMemcpyAsync(nll, d_nll.p, (size_t)B * S * sizeof(double), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));

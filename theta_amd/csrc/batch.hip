@@ -534,6 +534,42 @@ __global__ __launch_bounds__(64 * SMX_WAVES) void score_masked_mfma_kernel(int n
 }
 
 // ------------------------------------------------------------------------------------------------
+// No masks: the plain CalcAllC.L2 / L3 score of B byte candidates, one THREAD per candidate.  The wave-per-candidate kernel above
+// pays three wave reductions for every candidate; here a block stages its 256 candidates in LDS with coalesced 4-byte loads
+// (m (n-1) bytes each -- the algorithmic HBM traffic, plus 8 n bytes of mu in and 8 bytes out) and every thread walks its own
+// candidate's rows: two byte reads, the row's C.mu, one logarithm (smx_log) and two FMAs per interval.  Bound: the FP64
+// logarithm (~35 instructions per interval), not HBM.  NLL = -(sum r ln(C.mu) - sum r ln(sum C.mu)).
+// ------------------------------------------------------------------------------------------------
+extern __shared__ unsigned int spc_lds[];
+template <int NC>
+__global__ __launch_bounds__(256) void score_plain_kernel(int m, int tau, int B, const unsigned char *C, const double *w, const double *r,
+                                                          const double *mu, double rsum, double *nll) {
+    const int cb = m * NC;                       // bytes per candidate, a multiple of 4 (checked by the launcher)
+    const int cw = cb >> 2, pw = cw | 1;         // words per candidate; odd LDS stride: lanes fall on distinct banks
+    const long long b0 = (long long)blockIdx.x * 256;
+    const int nb = (int)((long long)B - b0 < 256 ? (long long)B - b0 : 256);
+    const unsigned int *src = (const unsigned int *)(C + (size_t)b0 * cb);
+    for (int idx = threadIdx.x; idx < nb * cw; idx += 256) {
+        const int cand = idx / cw, within = idx - cand * cw;
+        spc_lds[cand * pw + within] = src[idx];
+    }
+    __syncthreads();
+    if ((int)threadIdx.x >= nb) return;
+    const long long b = b0 + threadIdx.x;
+    const double *mv = mu + (size_t)b * (NC + 1);
+    const double m0 = (double)tau * mv[0], m1 = (NC == 1) ? 1.0 - mv[0] : mv[1], m2 = (NC == 2) ? mv[2] : 0.0;
+    const unsigned char *row = (const unsigned char *)(spc_lds + threadIdx.x * pw);
+    double den = 0.0, tot = 0.0;
+    for (int i = 0; i < m; i++) {
+        const double x = (double)row[i * NC], y = (NC == 2) ? (double)row[i * NC + 1] : 0.0;
+        const double cm = w[i] * __builtin_fma(x, m1, __builtin_fma(y, m2, m0));
+        den += cm;
+        tot = __builtin_fma(r[i], smx_log(cm), tot);
+    }
+    nll[b] = -(tot - rsum * smx_log(den));
+}
+
+// ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------
 void batch_launch_solve(int n, int m, int tau, const double *r, const double *rN, double max_normal, int B,
@@ -561,7 +597,7 @@ void batch_launch_score(int n, int m, int B, const double *Cw, const double *mu,
 
 void batch_launch_score_masked(int n, int m, int tau, int B, int S, const unsigned char *C, const double *w,
                                const double *r, const double *mu, const unsigned long long *mask, double *nll,
-                               double *rsum_scratch, hipStream_t st) {
+                               double *rsum_scratch, hipStream_t st, double rsum_host, bool rsum_host_valid) {
     if (mask != nullptr && S >= 16 && rsum_scratch != nullptr) {   // enough masks to fill the 16-row MFMA tiles
         hipLaunchKernelGGL(mask_rsum_kernel, dim3(S), dim3(64), 0, st, m, S, r, mask, rsum_scratch);
         const size_t lds = ((size_t)((m + 15) & ~15) * 32 + SMX_CAND * 4) * sizeof(double);
@@ -569,7 +605,23 @@ void batch_launch_score_masked(int n, int m, int tau, int B, int S, const unsign
         (void)hipFuncSetAttribute((const void *)score_masked_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(score_masked_mfma_kernel, dim3((B + SMX_CAND - 1) / SMX_CAND), dim3(64 * SMX_WAVES), lds, st, n, m,
                            tau, B, S, C, w, r, mu, mask, rsum_scratch, nll);
+    } else if (mask == nullptr && S == 1 && ((m * (n - 1)) & 3) == 0 && rsum_scratch != nullptr && rsum_host_valid) {
+        const size_t lds = (size_t)256 * (((m * (n - 1)) >> 2) | 1) * 4;
+        const unsigned blocks = (unsigned)(((long long)B + 255) / 256);
+        if (n == 2) {
+            (void)hipFuncSetAttribute((const void *)score_plain_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(score_plain_kernel<1>, dim3(blocks), dim3(256), lds, st, m, tau, B, C, w, r, mu, rsum_host, nll);
+        } else {
+            (void)hipFuncSetAttribute((const void *)score_plain_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(score_plain_kernel<2>, dim3(blocks), dim3(256), lds, st, m, tau, B, C, w, r, mu, rsum_host, nll);
+        }
     } else {
-        hipLaunchKernelGGL(score_masked_kernel, dim3((B + 3) / 4), dim3(256), 0, st, n, m, tau, B, S, C, w, r, mu, mask, nll);
+        // (a HIP grid holds fewer than 2^32 threads: 2^24 candidates -- one wave each -- per launch)
+        const int chunk = 1 << 24;
+        for (long long b0 = 0; b0 < B; b0 += chunk) {
+            const int nb = (int)((long long)B - b0 < chunk ? (long long)B - b0 : chunk);
+            hipLaunchKernelGGL(score_masked_kernel, dim3((nb + 3) / 4), dim3(256), 0, st, n, m, tau, nb, S,
+                               C + (size_t)b0 * m * (n - 1), w, r, mu + (size_t)b0 * n, mask, nll + (size_t)b0 * S);
+        }
     }
 }

@@ -268,10 +268,11 @@ __device__ __forceinline__ void sv_drain(SvCtx<ML> &c) {
                     if (sv_dismissed<ML>(c, val2, l2)) {
                         live = false;
                     } else if (st == 1) {
-                        // converged to the coarse tolerance: the step just taken leaves an NLL error far inside the screening
-                        // margin, so the value at the old iterate less lambda^2/2 is the optimum to that accuracy
+                        // Converged to the coarse tolerance and NOT finished by the rigorous bound: a contender -- the finish
+                        // kernel decides exactly.  (Only the no-dismissal mode, which values every candidate itself, drops it on
+                        // the value at the old iterate less lambda^2/2, the optimum up to the screening margin.)
                         const double v = (c.K0 - 0.6931471805599453 * (double)val2) - 0.5 * (double)(l2 * c.rtot_f) - c.screen_margin;
-                        surv = !(v > c.thr);     // within the window of the running minimum: a contender
+                        surv = !c.no_dismiss || !(v > c.thr);
                         live = false;
                     }
                 }
@@ -446,9 +447,9 @@ __device__ __forceinline__ void sv_children(SvCtx<ML> &c, int total) {
                         c.wn2 = s2 * v2;
                     }
                     if (!sv_dismissed<ML>(c, val2, l2)) {
-                        if (l2 < c.conv_l2) {
+                        if (l2 < c.conv_l2) {          // converged, not finished by the bound: a contender (see sv_drain)
                             const double v = (c.K0 - 0.6931471805599453 * (double)val2) - 0.5 * (double)(l2 * c.rtot_f) - c.screen_margin;
-                            surv = !(v > c.thr);
+                            surv = !c.no_dismiss || !(v > c.thr);
                         } else {
                             push = true;
                             qu1 = v1;
