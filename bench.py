@@ -18,14 +18,19 @@ Prints ONE JSON line (rank 0).
   value      candidates SEARCHED by all GPUs / max-over-ranks wall time of the K timed steps, the shipped search: a
              branch-and-bound in which a candidate whose rigorous lower bound lies beyond the window of the running minimum
              is finished after one packed-FP32 evaluation (roofline.legs.search.dismissed_fraction says how many).
-  roofline   dominant kernel n3_search_kernel, vector-ALU bound (candidates are generated on chip: ~0 algorithmic HBM
-             bytes).  THREE legs on the same rank ranges, each timed by HIP events on the kernel's stream (N = 1):
-               search           as shipped                                      executed FLOP vs the packed-FP32 peak
-               full_solve_f32   no candidate dismissed by its bound: every one   executed FLOP vs the packed-FP32 peak
+  roofline   dominant kernel n3_sieve_kernel<6> (n3_sieve.hip: burst enumeration + one evaluation shared by the children of a
+             last-level node + the self-concordance lower bound), vector-ALU bound -- candidates are generated on chip, ~0
+             algorithmic HBM bytes.  THREE legs on the same rank ranges, each timed by HIP events on the kernels' stream (N = 1):
+               search           as shipped (sieve + finish kernels)               executed FLOP vs the packed-FP32 peak
+               full_solve_f32   no candidate dismissed by its bound: every one     executed FLOP vs the packed-FP32 peak
                                 iterated to the coarse tolerance and valued
-               full_solve_f64   the same in FP64 throughout -- SURVEY 8(d)'s      executed FLOP vs the FP64 vector peak
-                                "passed through the full solve"
-             `achieved/peak/frac` at the top of the object are the shipped search's.
+                                (same kernels, "n3_no_dismiss")
+               full_solve_f64   the same in FP64 throughout -- SURVEY 8(d)'s        executed FLOP vs the FP64 vector peak
+                                "passed through the full solve" (the fused
+                                kernel of n3.hip, "n3_force_f64")
+             `achieved/peak/frac` at the top of the object are the shipped search's.  Executed FLOP are counted in-kernel
+             from the evaluations actually run; they FALL when the algorithm improves (sharing an evaluation between
+             siblings removed half of them), so `frac` is a statement about the kernel, not about progress.
              traffic: HBM bytes per launch, measured by two rocprofv3 --pmc passes of this same command on two steps
              (FETCH_SIZE, WRITE_SIZE; gfx950 corrections of MI355X_MICROARCH.md), or null when that is not possible.
   cpu_baseline  the CPU oracle (oracle/theta_oracle.py, a port of the reference's Python) on this host's cores, bounded sample.
@@ -135,9 +140,14 @@ class Leg:
 
     def step(self, i, count=True):
         b = self.begins[i]
-        # (the first step carries a trivial hint: without one Problem.search would first probe 16 short sub-ranges -- 16
-        # extra launches of the same kernel, which would blur the per-launch averages of the rocprofv3 runs of this command)
-        self.p.hint(self.running if self.running < float("inf") else 1e300)
+        if not self.running < float("inf"):
+            # the job's first step has no minimum to start from yet: a short search (2^16 candidates of the same range) gives
+            # it one that some candidate really attains -- Problem.search's own probe would launch 16 of them
+            res0 = self.p.search(b, b + (1 << 16), window=0.0)
+            if len(res0["nll"]):
+                self.running = float(res0["nll"].min())
+        if self.running < float("inf"):
+            self.p.hint(self.running)
         res = self.p.search(b, b + self.batch, window=self.window)
         if len(res["nll"]):
             self.running = min(self.running, float(res["nll"].min()))
@@ -156,13 +166,13 @@ class Leg:
                 self.best = res
         return res
 
-    def summary(self, wall_s, name, dtype):
+    def summary(self, wall_s, name, dtype, kernel=DOMINANT_KERNEL):
         f64, f32, ev = float(self.tot["flops"]), float(self.tot["flops_f32"]), float(self.tot["evaluated"])
         k_s = self.kernel_ms * 1e-3
         ach = (f64 + f32) / k_s / 1e12 if k_s > 0 else 0.0
         # time-weighted peak of the executed mix: an FP64 op costs two packed-FP32 slots
         peak = (f64 + f32) / (f64 / FP64_VECTOR_PEAK_TFLOPS + f32 / FP32_VECTOR_PEAK_TFLOPS) if f64 + f32 > 0 else FP32_VECTOR_PEAK_TFLOPS
-        return {"leg": name, "dtype": dtype, "launches": self.launches, "candidates_per_launch": self.batch,
+        return {"leg": name, "dtype": dtype, "kernel": kernel, "launches": self.launches, "candidates_per_launch": self.batch,
                 "value": ev / wall_s if wall_s > 0 else 0.0, "unit": "candidates/s", "wall_ms_per_launch": 1e3 * wall_s / max(self.launches, 1),
                 "kernel_ms_per_launch": self.kernel_ms / max(self.launches, 1), "kernel_candidates_per_s": ev / k_s if k_s > 0 else 0.0,
                 "executed_flop_per_launch": (f64 + f32) / max(self.launches, 1), "fp64_flop_share": f64 / max(f64 + f32, 1.0),
@@ -409,7 +419,7 @@ def main():
                 for i in range(min(k_leg, len(lg.begins))):
                     lg.step(i)
                 ctx.synchronize()
-                legs[name] = lg.summary(time.time() - t1, name, dtype)
+                legs[name] = lg.summary(time.time() - t1, name, dtype, DOMINANT_KERNEL if name == "full_solve_f32" else "n3_search_kernel<6,false>")
                 for k in opts:
                     problem.set_option(k, 0)
         s = legs["search"]
@@ -419,6 +429,7 @@ def main():
         out["roofline"] = {
             "bound": "valu", "bound_detail": "vector-ALU (VALU issue) bound, not HBM and not MFMA: candidates are generated on chip "
             "(~0 algorithmic HBM bytes) and the per-candidate C.mu is an (18 x 3).(3) product after group aggregation -- no GEMM. "
+            "Kernel time = sieve + finish kernels of a step (HIP events around both). "
             "`peak` is the packed-FP32 vector peak (157.3 TFLOP/s) weighted with the FP64 vector peak (78.6) by the executed mix",
             "kernel": DOMINANT_KERNEL, "achieved": s["achieved"], "peak": s["peak"], "unit": "TFLOP/s", "frac": s["frac"],
             "traffic": traffic, "traffic_note": tnote, "algorithmic_bytes_per_launch": 0,

@@ -1,7 +1,6 @@
 """theta_enumerate_device throughput (materialised generator into HBM): 2 m (n=3) / m (n=2) bytes written per candidate."""
 import sys, os, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import torch
 import bench, theta_amd, numpy as np
 ctx = theta_amd.Context(0)
 out = {}
@@ -12,11 +11,14 @@ for name, n, m, k, cnt in (("n3_m50_k6", 3, 50, 6, 1 << 28), ("n3_m50_k4", 3, 50
     cnt = int(min(cnt, p.count))
     b = (p.count - cnt) // 3
     nbytes = cnt * m * (n - 1)
-    buf = torch.empty(nbytes, dtype=torch.uint8, device="cuda:0")
-    p.enumerate_device(b, min(cnt, 1 << 16), buf.data_ptr())
-    ms = min(p.enumerate_device(b, cnt, buf.data_ptr()) for _ in range(3))
+    buf = ctx.device_array((nbytes,), np.uint8)          # (HBM owned by the caller: theta_device_alloc, no torch)
+    p.enumerate_device(b, min(cnt, 1 << 16), buf)
+    ms = min(p.enumerate_device(b, cnt, buf) for _ in range(3))
     chk = p.enumerate(b + cnt - 5, 5).reshape(-1)
-    assert np.array_equal(buf[-chk.size:].cpu().numpy(), chk)
+    tail = np.zeros(chk.size, np.uint8)
+    theta_amd._lib._check(theta_amd._lib.load().theta_device_copy(ctx._h, tail.ctypes.data, buf.ptr.value + nbytes - chk.size, chk.size, 0))
+    assert np.array_equal(tail, chk)
+    buf.free()
     out[name] = {"candidates": cnt, "bytes": nbytes, "kernel_ms": ms, "candidates_per_s": cnt / ms * 1e3, "GBps": nbytes / ms / 1e6,
                  "hbm_frac": nbytes / ms / 1e6 / 8000.0}
     print(name, out[name], file=sys.stderr)
