@@ -521,3 +521,31 @@ def test_literal_scorer_with_one_r_per_matrix(ctx):
         assert (one[0] == many[b][0]) or (one[0] != one[0] and many[b][0] != many[b][0])
         nll_ref, _ = orc.calc_L3(mus[b], Cs[b].copy(), m, rs[b], 3)
         assert (nll_ref != nll_ref and one[0] != one[0]) or abs(nll_ref - one[0]) <= 1e-12 * abs(nll_ref)
+
+
+def test_n2_whole_line_generator_equals_the_lane_stream_generator(ctx, monkeypatch):
+    """theta_enumerate for n=2 at sizes that take the whole-line writer (LDS transposition, n2_enumerate_lines_kernel) against the
+    one-stream-per-lane kernel (THETA_N2_ENUM_LEGACY=1) and, on a prefix, against the oracle's successor -- m multiple of 4,
+    even, odd, ragged bounds, ranges that start and end in the middle of a run."""
+    import bench
+    import theta_amd
+    for m, k, lb, ub in ((100, 5, None, None), (50, 6, None, None), (25, 5, None, None), (61, 3, None, None),
+                         (30, 4, [0] * 10 + [1] * 10 + [2] * 10, [2] * 10 + [3] * 10 + [4] * 10)):
+        r, rN, order = bench.synth(seed=3, m=m, n=2, k=k)
+        lb = [0] * m if lb is None else lb
+        ub = [k] * m if ub is None else ub
+        p = theta_amd.Problem(ctx, 2, m, 2, r, rN, lb, ub, 1.0)
+        for begin, cnt in ((0, min(p.count, 1 << 21)), (p.count // 3 + 5, min(p.count // 2, (1 << 20) + 77))):
+            if cnt < 1 << 18:
+                continue
+            monkeypatch.delenv("THETA_N2_ENUM_LEGACY", raising=False)
+            a = p.enumerate(begin, cnt)
+            monkeypatch.setenv("THETA_N2_ENUM_LEGACY", "1")
+            b = p.enumerate(begin, cnt)
+            monkeypatch.delenv("THETA_N2_ENUM_LEGACY", raising=False)
+            assert np.array_equal(a, b), (m, k, begin, cnt)
+            if begin == 0:
+                it = orc.enumerate_n2(m, 2, lb, ub)
+                ref = np.array([next(it) for _ in range(3000)], dtype=np.uint8)
+                assert np.array_equal(a[:3000], ref)
+        p.close()

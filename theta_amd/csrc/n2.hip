@@ -12,6 +12,8 @@
 //   dL/dnu(x) = -sum_v R_v (sigma - v) / (v + x (sigma - v)),     sigma = sum_v v N_v / sum rN
 //   NLL       = K0 - sum_v R_v ln(tau mu + v (1-mu)) + Rtot ln(tau mu + sigma (1-mu))
 // so one candidate costs O(k) instead of O(m) and touches no HBM.
+#include <stdlib.h>
+
 #include "n2.hpp"
 
 // ------------------------------------------------------------------------------------------------
@@ -413,6 +415,143 @@ __global__ __launch_bounds__(256) void n2_enumerate_kernel(N2Dev P, unsigned lon
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The same generator, written through an LDS transposition so that the memory system sees WHOLE CACHE LINES.
+// In the kernel above every lane owns one output stream: a store instruction touches 64 different 128-byte lines, 4e5
+// streams are open at once, and partial lines leave the L2 before they are complete (0.9-1.5 TB/s).  Here a thread's run is
+// T candidates with T m a multiple of 128 bytes (so every run starts on a line boundary); per line each lane builds its
+// eight 16-byte chunks into its own row of a per-wave LDS tile, and the wave then stores the tile line by line: one store
+// instruction = 8 complete lines (8 lanes x 16 bytes each).  The bytes come from an incremental form of the step function
+// "value at position i = #{v : s[v] <= i}": a 4-byte word with no break-point inside is `cur * 0x01010101`; only the
+// <= KV-1 words of a record that hold a break-point (and the word that straddles two records) take the general sum.
+// ------------------------------------------------------------------------------------------------
+#define N2L_STRIDE 36      // dwords per LDS row (128 bytes of payload + 16 of padding: spreads the rows over the banks)
+template <int KV>
+__global__ __launch_bounds__(256) void n2_enumerate_lines_kernel(N2Dev P, unsigned long long begin, unsigned long long count, int T,
+                                                                 unsigned char *out) {
+    extern __shared__ unsigned char smem[];
+    unsigned long long *Pl = (unsigned long long *)smem;
+    short *lbposl = (short *)(Pl + (size_t)P.m * N2_KVS);
+    unsigned char *ubl = (unsigned char *)(lbposl + (N2_KVS + 1) + 3);
+    unsigned *tile = (unsigned *)(smem + (((size_t)P.m * N2_KVS * 8 + (N2_KVS + 1 + 3) * 2 + P.m + 15) & ~(size_t)15)) +
+                     (threadIdx.x >> 6) * (WAVE * N2L_STRIDE);
+    for (int i = threadIdx.x; i < P.m * N2_KVS; i += blockDim.x) Pl[i] = P.P[i];
+    for (int i = threadIdx.x; i <= N2_KVS; i += blockDim.x) lbposl[i] = P.lbpos[i];
+    for (int i = threadIdx.x; i < P.m; i += blockDim.x) ubl[i] = P.ub[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, m = P.m;
+    const unsigned long long tid = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned long long wave_first = tid - lane;
+    const unsigned long long k0 = tid * (unsigned long long)T;
+    const unsigned long long RB = (unsigned long long)T * m;                 // bytes per run, a multiple of 128
+    const int lines = (int)(RB >> 7);
+    unsigned long long mine = k0 < count ? (count - k0 < (unsigned long long)T ? count - k0 : (unsigned long long)T) : 0;   // candidates of this lane
+    N2Cand<KV> c;
+    if (mine) n2_unrank<KV>(P, Pl, begin + k0, c);
+    else {
+#pragma unroll
+        for (int v = 0; v <= KV; v++) c.s[v] = m;
+    }
+    auto word_at = [&](int pos) -> unsigned {                                // bytes pos .. pos+3 of the current record
+        unsigned val = 0;
+#pragma unroll
+        for (int v = 1; v < KV; v++) {
+            const int d = c.s[v] - pos;
+            val += d <= 0 ? 0x01010101u : (d >= 4 ? 0u : (0x01010101u << (8 * d)));
+        }
+        return val;
+    };
+    auto next_break = [&](unsigned cur) -> int {                             // s[cur + 1]: first position whose value exceeds cur
+        int nb = m;
+#pragma unroll
+        for (int v = 1; v < KV; v++) nb = ((int)cur + 1 == v) ? c.s[v] : nb;
+        return nb;
+    };
+    int pos = 0;                                                             // position in the current record
+    unsigned cur = mine ? (word_at(0) & 0xffu) : 0u;                         // value at `pos`
+    int nb = next_break(cur);
+    while (nb <= pos && (int)cur < KV - 1) {                                 // (several break-points on one position)
+        cur++;
+        nb = next_break(cur);
+    }
+    unsigned long long left = mine;                                          // records still to finish, the current one included
+    auto advance = [&]() {                                                   // next record
+        left--;
+        if (left > 0 && n2_next<KV>(P, ubl, lbposl, c)) {
+            cur = word_at(0) & 0xffu;
+            nb = next_break(cur);
+        } else {
+            left = 0;
+        }
+        pos = 0;
+    };
+    auto next_word = [&]() -> unsigned {
+        if (left == 0) return 0u;
+        if (pos + 4 <= m && nb >= pos + 4) {                                 // no break-point inside: four equal bytes
+            const unsigned val = cur * 0x01010101u;
+            pos += 4;
+            if (pos == m) advance();
+            return val;
+        }
+        unsigned val = word_at(pos);
+        const int over = pos + 4 - m;
+        if (over > 0) {                                                      // the word straddles two records
+            const int keep = 4 - over;
+            val &= 0xffffffffu >> (8 * over);
+            advance();
+            if (left > 0) {
+                val |= word_at(0) << (8 * keep);
+                pos = over;
+                cur = word_at(pos) & 0xffu;
+                nb = next_break(cur);
+            }
+            return val;
+        }
+        pos += 4;
+        if (pos == m) {
+            advance();
+        } else {
+            cur = word_at(pos) & 0xffu;
+            nb = next_break(cur);
+        }
+        return val;
+    };
+    unsigned *row = tile + lane * N2L_STRIDE;
+    for (int line = 0; line < lines; line++) {
+#pragma unroll 2
+        for (int ch = 0; ch < 8; ch++) {
+            n2_u4v v;
+            v.x = next_word();
+            v.y = next_word();
+            v.z = next_word();
+            v.w = next_word();
+            *(n2_u4v *)(row + 4 * ch) = v;
+        }
+        wave_lds_sync();
+#pragma unroll
+        for (int sidx = 0; sidx < 8; sidx++) {
+            const int r = (lane >> 3) + 8 * sidx, ch = lane & 7;
+            const unsigned long long tt = wave_first + (unsigned long long)r;
+            const unsigned long long kk = tt * (unsigned long long)T;
+            if (kk < count) {
+                const unsigned long long nv = (count - kk < (unsigned long long)T ? count - kk : (unsigned long long)T) * (unsigned long long)m;
+                const unsigned long long off = ((unsigned long long)line << 7) + (unsigned long long)ch * 16;
+                if (off < nv) {
+                    const n2_u4v v = *(const n2_u4v *)(tile + r * N2L_STRIDE + 4 * ch);
+                    unsigned char *dst = out + tt * RB + off;
+                    if (off + 16 <= nv) {
+                        *(n2_u4v *)dst = v;
+                    } else {                                                 // the tail of the very last record
+                        const unsigned w4[4] = {v.x, v.y, v.z, v.w};
+                        for (int bidx = 0; bidx < (int)(nv - off); bidx++) dst[bidx] = (unsigned char)(w4[bidx >> 2] >> (8 * (bidx & 3)));
+                    }
+                }
+            }
+        }
+        wave_lds_sync();
+    }
+}
+
 // Candidates for an explicit list of ranks (tie-list materialisation).
 template <int KV>
 __global__ __launch_bounds__(64) void n2_unrank_list_kernel(N2Dev P, const TieRecord *recs, int count, unsigned char *out) {
@@ -454,6 +593,28 @@ void n2_launch_search(const N2Dev &P, const SearchArgs &A, unsigned long long be
 
 void n2_launch_enumerate(const N2Dev &P, unsigned long long begin, unsigned long long count, unsigned char *out,
                          hipStream_t st) {
+    // whole-line writer: runs of T candidates with T m a multiple of 128 bytes, output 128-byte aligned, enough work to fill
+    // the chip (THETA_N2_ENUM_LEGACY=1 keeps the one-stream-per-lane kernel: second implementation for the tests)
+    {
+        int g = 128, a = P.m;
+        while (a) { const int t = g % a; g = a; a = t; }      // gcd(m, 128)
+        int T = 128 / g;
+        while (T < 32) T *= 2;
+        if (!getenv("THETA_N2_ENUM_LEGACY") && P.m >= 4 && (((unsigned long long)out) & 127ull) == 0ull && T <= 256 && count >= (unsigned long long)T * 4096ull) {
+            const unsigned long long threads = (count + T - 1) / T;
+            const unsigned blocks = (unsigned)((threads + 255) / 256);
+            const size_t base = (((size_t)P.m * N2_KVS * 8 + (N2_KVS + 1 + 3) * 2 + P.m + 15) & ~(size_t)15);
+            const size_t sm2 = base + (size_t)4 * WAVE * N2L_STRIDE * 4;
+            if (P.kv <= 8) {
+                (void)hipFuncSetAttribute((const void *)n2_enumerate_lines_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm2);
+                hipLaunchKernelGGL(n2_enumerate_lines_kernel<8>, dim3(blocks), dim3(256), sm2, st, P, begin, count, T, out);
+            } else {
+                (void)hipFuncSetAttribute((const void *)n2_enumerate_lines_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm2);
+                hipLaunchKernelGGL(n2_enumerate_lines_kernel<16>, dim3(blocks), dim3(256), sm2, st, P, begin, count, T, out);
+            }
+            return;
+        }
+    }
     const int per_thread = 16;     // (64 measured no better: the limit is the write pattern, one stream per lane)
     unsigned long long threads = (count + per_thread - 1) / per_thread;
     unsigned blocks = (unsigned)((threads + 255) / 256);

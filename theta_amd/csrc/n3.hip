@@ -1006,6 +1006,10 @@ __global__ __launch_bounds__(64 * N3_WAVES, N3_OCC) void n3_search_kernel(N3Dev 
                         float val2 = 0.0f, l2v = -1.0f;
                         if (use64) n3_newton_step(terms, s1, s2, inv_Rtot, Sv, conv_main);
                         else use64 = !n3_newton_step_pk<!DUMP>(pairs, (float)s1, (float)s2, inv_Rtot, Sv, conv_main, val2, l2v);
+                        // "converged" rests on quadratic convergence, which self-concordance only grants once the decrement is
+                        // small against the SMALLEST term weight: with an interval of a handful of reads (Rmin << sum r) the
+                        // coarse threshold on lambda^2 / sum r is not enough -- keep iterating until lambda^2 < Rmin / 4 as well
+                        if (!DUMP && Sv.status == 1 && l2v >= 0.0f && l2v * rtot_over_rmin >= 0.25f && Sv.iters < N3_MAX_ITERS) Sv.status = 0;
                         // Dismissal without solving: NLL is self-concordant with parameter 2 / sqrt(Rmin), so its minimum is
                         // at least NLL(u) - Rmin w*(lt), lt = lambda / sqrt(Rmin) < 1, w*(t) = -t - ln(1 - t) <= t^2 / (2 (1 - t)),
                         // i.e. NLL(u) - lambda^2 / (2 (1 - lt)), evaluated at the iterate BEFORE the step.  A candidate whose

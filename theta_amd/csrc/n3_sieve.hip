@@ -188,7 +188,9 @@ __device__ __forceinline__ int sv_step(const SvCtx<ML> &c, const unsigned (&rw)[
     if (l2 > 0.09f) step = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_sqrtf(l2));
     u1 = __builtin_fmaf(step, d1, u1);
     u2 = __builtin_fmaf(step, d2, u2);
-    return l2 < c.conv_l2 ? 1 : 0;
+    // "converged" = the coarse threshold on lambda^2 / sum r AND lambda^2 < Rmin / 4 (quadratic convergence is only granted
+    // once the decrement is small against the smallest term weight)
+    return (l2 < c.conv_l2 && l2 * c.rtot_over_rmin < 0.25f) ? 1 : 0;
 }
 
 // Is the candidate finished by the lower bound of its optimum?  (evaluated at the iterate BEFORE the step)
@@ -447,7 +449,7 @@ __device__ __forceinline__ void sv_children(SvCtx<ML> &c, int total) {
                         c.wn2 = s2 * v2;
                     }
                     if (!sv_dismissed<ML>(c, val2, l2)) {
-                        if (l2 < c.conv_l2) {          // converged, not finished by the bound: a contender (see sv_drain)
+                        if (l2 < c.conv_l2 && l2 * c.rtot_over_rmin < 0.25f) {   // converged, not finished by the bound: a contender (see sv_drain)
                             const double v = (c.K0 - 0.6931471805599453 * (double)val2) - 0.5 * (double)(l2 * c.rtot_f) - c.screen_margin;
                             surv = !c.no_dismiss || !(v > c.thr);
                         } else {
