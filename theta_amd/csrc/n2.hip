@@ -421,9 +421,8 @@ __global__ __launch_bounds__(256) void n2_enumerate_kernel(N2Dev P, unsigned lon
 // streams are open at once, and partial lines leave the L2 before they are complete (0.9-1.5 TB/s).  Here a thread's run is
 // T candidates with T m a multiple of 128 bytes (so every run starts on a line boundary); per line each lane builds its
 // eight 16-byte chunks into its own row of a per-wave LDS tile, and the wave then stores the tile line by line: one store
-// instruction = 8 complete lines (8 lanes x 16 bytes each).  The bytes come from an incremental form of the step function
-// "value at position i = #{v : s[v] <= i}": a 4-byte word with no break-point inside is `cur * 0x01010101`; only the
-// <= KV-1 words of a record that hold a break-point (and the word that straddles two records) take the general sum.
+// instruction = 8 complete lines (8 lanes x 16 bytes each).  Control flow is wave-uniform (see `pos` below); the bytes of a word
+// are the SWAR sum over the break-points, as in the kernel above.
 // ------------------------------------------------------------------------------------------------
 #define N2L_STRIDE 36      // dwords per LDS row (128 bytes of payload + 16 of padding: spreads the rows over the banks)
 template <int KV>
@@ -461,58 +460,31 @@ __global__ __launch_bounds__(256) void n2_enumerate_lines_kernel(N2Dev P, unsign
         }
         return val;
     };
-    auto next_break = [&](unsigned cur) -> int {                             // s[cur + 1]: first position whose value exceeds cur
-        int nb = m;
-#pragma unroll
-        for (int v = 1; v < KV; v++) nb = ((int)cur + 1 == v) ? c.s[v] : nb;
-        return nb;
-    };
-    int pos = 0;                                                             // position in the current record
-    unsigned cur = mine ? (word_at(0) & 0xffu) : 0u;                         // value at `pos`
-    int nb = next_break(cur);
-    while (nb <= pos && (int)cur < KV - 1) {                                 // (several break-points on one position)
-        cur++;
-        nb = next_break(cur);
-    }
+    // Every lane's run starts on a record boundary AND on a line boundary, and all runs have the same length: the position
+    // inside the current record is the same for all 64 lanes at every word -- `pos` is wave-uniform, so is every branch on it
+    // (only the break-points differ from lane to lane).  A lane whose run is shorter (the last one) emits zeros, never stored.
+    int pos = 0;
     unsigned long long left = mine;                                          // records still to finish, the current one included
-    auto advance = [&]() {                                                   // next record
-        left--;
-        if (left > 0 && n2_next<KV>(P, ubl, lbposl, c)) {
-            cur = word_at(0) & 0xffu;
-            nb = next_break(cur);
-        } else {
-            left = 0;
+    auto advance = [&]() {                                                   // next record of this lane's run
+        if (left > 0) {
+            left--;
+            if (left > 0 && !n2_next<KV>(P, ubl, lbposl, c)) left = 0;
         }
-        pos = 0;
     };
     auto next_word = [&]() -> unsigned {
-        if (left == 0) return 0u;
-        if (pos + 4 <= m && nb >= pos + 4) {                                 // no break-point inside: four equal bytes
-            const unsigned val = cur * 0x01010101u;
-            pos += 4;
-            if (pos == m) advance();
-            return val;
-        }
-        unsigned val = word_at(pos);
-        const int over = pos + 4 - m;
+        unsigned val = left > 0 ? word_at(pos) : 0u;
+        const int over = pos + 4 - m;                                        // (uniform)
         if (over > 0) {                                                      // the word straddles two records
-            const int keep = 4 - over;
             val &= 0xffffffffu >> (8 * over);
             advance();
-            if (left > 0) {
-                val |= word_at(0) << (8 * keep);
-                pos = over;
-                cur = word_at(pos) & 0xffu;
-                nb = next_break(cur);
-            }
-            return val;
-        }
-        pos += 4;
-        if (pos == m) {
-            advance();
+            if (left > 0) val |= word_at(0) << (8 * (4 - over));
+            pos = over;
         } else {
-            cur = word_at(pos) & 0xffu;
-            nb = next_break(cur);
+            pos += 4;
+            if (pos == m) {
+                advance();
+                pos = 0;
+            }
         }
         return val;
     };

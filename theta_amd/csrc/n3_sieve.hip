@@ -122,7 +122,7 @@ struct SvCtx {
     int qcount;
     // statistics (wave-uniform scalars)
     unsigned long long n_eval, n_dis, n_it, n_deg, n_surv;
-    unsigned long long n_par, n_rounds, n_ctrips, n_drains, n_dtrips, n_prefix;   // diagnostics: parents evaluated, last-level rounds, ...
+    unsigned long long n_par, n_prefix;   // last-level nodes evaluated (phase P), prefixes walked
     unsigned long long n_child, n_dit;   // shared first evaluations (children) / full evaluations (queue)
 };
 
@@ -243,7 +243,6 @@ __device__ __forceinline__ void sv_survivor(const SvCtx<ML> &c, const unsigned (
 template <int ML>
 __device__ __forceinline__ void sv_drain(SvCtx<ML> &c) {
     for (int b0 = 0; b0 < c.qcount; b0 += WAVE) {
-        c.n_drains++;
         const int idx = b0 + c.lane;
         bool live = idx < c.qcount;
         unsigned rw[ML / 2];
@@ -256,7 +255,6 @@ __device__ __forceinline__ void sv_drain(SvCtx<ML> &c) {
         int iters = 0;
         bool surv = false;
         while (ballot64(live)) {
-            c.n_dtrips++;
             c.n_it += (unsigned)__builtin_popcountll(ballot64(live));
             c.n_dit += (unsigned)__builtin_popcountll(ballot64(live));
             if (live) {
@@ -392,7 +390,6 @@ __device__ __forceinline__ void sv_children(SvCtx<ML> &c, int total) {
     if (nrec <= 0) return;
     const float Rl = c.leafRf[ML - 1], Nl = c.leafN[ML - 1];
     for (int k0 = 0; k0 < nrec; k0 += WAVE) {
-        c.n_ctrips++;
         const int k = k0 + c.lane;
         const bool act = k < nrec;
         const unsigned kd = act ? c.W->kid[lo + k] : 0u;
@@ -558,7 +555,6 @@ __device__ __forceinline__ void sv_expand(SvCtx<ML> &c, int n_in) {
             }
             sv_parent<ML>(c, take && cnt > 0, code);
             c.n_par += (unsigned)__builtin_popcountll(ballot64(take && cnt > 0));
-            c.n_rounds++;
             wave_lds_sync();
             sv_children<ML>(c, total);
             wave_lds_sync();
@@ -668,7 +664,7 @@ __global__ __launch_bounds__(64 * SV_WAVES, SV_OCC) void n3_sieve_kernel(N3Dev P
     c.wn1 = c.wn2 = 1.0f / 3.0f;
     c.qcount = 0;
     c.n_eval = c.n_dis = c.n_it = c.n_deg = c.n_surv = 0;
-    c.n_par = c.n_rounds = c.n_ctrips = c.n_drains = c.n_dtrips = c.n_prefix = 0;
+    c.n_par = c.n_prefix = 0;
     c.n_child = c.n_dit = 0;
     const double inv_N = 1.0 / Pg.N;
     double leafR[ML];
@@ -755,10 +751,6 @@ __global__ __launch_bounds__(64 * SV_WAVES, SV_OCC) void n3_sieve_kernel(N3Dev P
         atomicAdd(&A.ctr->sieve_pterms, n_pterms);
         atomicAdd(&A.ctr->sieve_children, c.n_child);
         atomicAdd(&A.ctr->prof[0], c.n_par);
-        atomicAdd(&A.ctr->prof[1], c.n_rounds);
-        atomicAdd(&A.ctr->prof[2], c.n_ctrips);
-        atomicAdd(&A.ctr->prof[3], c.n_drains);
-        atomicAdd(&A.ctr->prof[4], c.n_dtrips);
         atomicAdd(&A.ctr->prof[7], c.n_prefix);
     }
 }
