@@ -207,7 +207,7 @@ def measure_traffic(args):
             for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
                 out = os.path.join(td, ctr)
                 cmd = [exe, "--pmc", ctr, "--output-format", "csv", "-d", out, "-o", "pmc", "--", sys.executable,
-                       os.path.abspath(__file__), "--gpus", "1", "--steps", "2", "--warmup", "1", "--batch", str(args.batch),
+                       os.path.abspath(__file__), "--gpus", "1", "--steps", "3", "--warmup", "2", "--batch", str(args.batch),
                        "--no-cpu-baseline", "--no-legs", "--no-traffic", "--no-extras"]
                 subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240, check=True)
                 vals = []
@@ -221,11 +221,14 @@ def measure_traffic(args):
                                         vals.append(float(row["Counter_Value"]))
                 if not vals:
                     return None, "rocprofv3 produced no %s rows for the search kernel" % ctr
-                got[ctr] = sum(vals) / len(vals)
+                # per launch: the job's first step also launches the kernel on a few short bootstrap slices, and its warm-up
+                # launches run against a poor minimum (many contenders written out) -- the median of the full-size launches
+                vals = sorted(v for v in vals if v >= 0.02 * max(vals)) or vals
+                got[ctr] = vals[len(vals) // 2] if len(vals) % 2 else 0.5 * (vals[len(vals) // 2 - 1] + vals[len(vals) // 2])
     except Exception as ex:
         return None, "rocprofv3 --pmc pass failed: %s" % (str(ex)[:200],)
     byt = (2.0 * got["FETCH_SIZE"] + got["WRITE_SIZE"]) * 1024.0
-    return byt, "(2 x FETCH_SIZE + WRITE_SIZE) KB, mean over the search-kernel launches of two rocprofv3 --pmc passes of this command"
+    return byt, "(2 x FETCH_SIZE + WRITE_SIZE) KB, median over the full-size launches of the dominant kernel in two rocprofv3 --pmc passes of this command (2 warm-up + 3 timed steps)"
 
 
 def extras(ctx, cpu_seconds):

@@ -124,7 +124,7 @@ extern "C" int theta_device_info(theta_ctx *c, char *name, int cap, int *cu, uin
 #define DEG_CAP (1u << 16)
 #define N3_MAX_TASKS (1 << 18)
 #define SURV_CAP (1u << 24)           /* contenders per slice of the sieve (2.4 GB of the 288 GB, allocated on first use) */
-#define SIEVE_SLICE (1ull << 30)     /* candidates per sieve launch; the finish kernel runs in between and lowers the minimum */
+#define SIEVE_SLICE (1ull << 31)     /* candidates per sieve launch; the finish kernel runs in between and lowers the minimum */
 #define SIEVE_MAX_SLICES 64
 
 struct theta_problem {
