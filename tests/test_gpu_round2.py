@@ -426,9 +426,21 @@ def test_sieve_and_fused_search_kernels_return_identical_lists(ctx):
     cases.append(("m14 k3", 14, r6, rN6, [0, 0, 0, 0, 1, 1, 1, 1, 1, 1, 1, 2, 2, 2], [2, 2, 3, 3, 3, 3, 3, 3, 3, 3, 3, 3, 3, 3], [("all", None)]))
     r7, rN7, _ = bench.synth(seed=10, m=9, n=3, k=3)
     cases.append(("m9 k3", 9, r7, rN7, [0] * 9, [3] * 9, [("all", None)]))
+    r8, rN8, _ = bench.synth(seed=12, m=20, n=3, k=7)               # the largest alphabet (K = 7: 64 slots)
+    cases.append(("m20 k7", 20, r8, rN8, [0] * 20, [7] * 20, [("mid", 1 << 23), (0, 1 << 21)]))
+    r9, rN9, _ = bench.synth(seed=13, m=64, n=3, k=2)               # the longest matrix the n=3 kernels hold
+    cases.append(("m64 k2", 64, r9, rN9, [0] * 64, [2] * 64, [("mid", 1 << 23)]))
+    ra, rNa, _ = bench.synth(seed=14, m=16, n=3, k=3)               # an interval with a handful of tumour reads: Rmin << sum r,
+    ra = list(ra)                                                   # the lower bound rarely applies (lambda^2 < Rmin / 4 is needed)
+    ra[0], ra[7] = 3, 11
+    cases.append(("m16 k3 tiny Rmin", 16, ra, rNa, [0] * 16, [3] * 16, [("mid", 1 << 21)]))
+    rb, rNb, _ = bench.synth(seed=15, m=12, n=3, k=4)               # tau = 3
+    cases.append(("m12 k4 tau3", 12, rb, rNb, [0] * 12, [4] * 12, [("all", None)], 3))
     total_surv = 0
-    for name, m, rr, rn, lb, ub, ranges in cases:
-        p = theta_amd.Problem(ctx, 3, m, 2, rr, rn, lb, ub, 1.0)
+    for case in cases:
+        name, m, rr, rn, lb, ub, ranges = case[:7]
+        tau = case[7] if len(case) > 7 else 2
+        p = theta_amd.Problem(ctx, 3, m, tau, rr, rn, lb, ub, 1.0)
         known = None
         for where, span in ranges:
             if where == "all":
@@ -549,3 +561,21 @@ def test_n2_whole_line_generator_equals_the_lane_stream_generator(ctx, monkeypat
                 ref = np.array([next(it) for _ in range(3000)], dtype=np.uint8)
                 assert np.array_equal(a[:3000], ref)
         p.close()
+
+
+def test_sieve_path_in_a_chunked_search(ctx, monkeypatch):
+    """Problem.search walks a range larger than one call in pieces (hint chained); with the sieve path each piece is sieve + finish.
+    Small pieces are forced here; the result must be the one-call result."""
+    import bench
+    import theta_amd
+    r, rN, order = bench.synth()
+    p = theta_amd.Problem(ctx, 3, 50, 2, r, rN, [0] * 50, [6] * 50, 1.0)
+    b = p.count // 7
+    span = (1 << 24) + 12345
+    whole = p.search(b, b + span, window=0.5)
+    monkeypatch.setattr(theta_amd.Problem, "MAX_PER_CALL", {2: 1 << 40, 3: 1 << 22})
+    parts = p.search(b, b + span, window=0.5)
+    assert parts["stats"]["evaluated"] == whole["stats"]["evaluated"] == span
+    assert parts["rank"] == whole["rank"] and np.allclose(parts["nll"], whole["nll"], rtol=1e-12)
+    assert list(p.last_degenerate[0]) == []
+    p.close()
