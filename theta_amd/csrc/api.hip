@@ -171,7 +171,7 @@ extern "C" int theta_problem_create(theta_ctx *ctx, int n, int m, int tau, const
         theta_set_error("n must be 2 or 3 (got %d)", n);
         return THETA_ERR_ARG;
     }
-    int max_m = (n == 2) ? THETA_MAX_M : N3_MAX_M;
+    int max_m = (n == 2) ? THETA_MAX_M : N3_MAX_M_WIDE;
     if (m < 2 || m > max_m) {
         theta_set_error("m must be in [2, %d] for n=%d (got %d)", max_m, n, m);
         return THETA_ERR_ARG;
@@ -361,7 +361,7 @@ extern "C" int theta_problem_create(theta_ctx *ctx, int n, int m, int tau, const
         if (L > m - 1) L = m - 1;
         D.L = L;
         TRY(p->d_tasks.alloc((size_t)N3_MAX_TASKS * sizeof(N3Task)));
-        TRY(p->d_stbuf.alloc((size_t)N3_MAX_TASKS * N3_MAX_M * sizeof(unsigned)));
+        TRY(p->d_stbuf.alloc((size_t)N3_MAX_TASKS * N3_STB * sizeof(unsigned)));
     }
     HIP_TRY(hipStreamSynchronize(st));
 #undef TRY
@@ -486,6 +486,11 @@ static int run_search(theta_problem *p, u128 b, u128 e, double window, double *d
             int ntasks = (int)nt;
             N3Dev PS = p->n3;
             const int sieve_levels = (p->opt_sieve && !dump_nll && !p->n3.force64) ? n3_sieve_levels(p->n3) : 0;
+            if (p->m > N3_MAX_M && sieve_levels == 0) {
+                theta_set_error("n=3 with more than %d intervals runs on the sieve path only (no --GET_VALUES dump, no FP64 mode, "
+                                "n3_sieve = 1)", N3_MAX_M);
+                return THETA_ERR_ARG;
+            }
             if (sieve_levels > 0) {
                 // fast path (n3_sieve.hip): sieve kernel per slice of the range, finish kernel on its contenders in between
                 PS.L = sieve_levels;
@@ -520,7 +525,7 @@ static int run_search(theta_problem *p, u128 b, u128 e, double window, double *d
                 unsigned *cnts = (unsigned *)p->d_survcnt.p;
                 for (size_t sl = 0; sl < slices.size(); sl++) {
                     const int t0 = slices[sl].first, nts = slices[sl].second;
-                    n3_launch_sieve(PS, A, (const N3Task *)p->d_tasks.p + t0, (const unsigned *)p->d_stbuf.p + (size_t)t0 * N3_MAX_M, nts,
+                    n3_launch_sieve(PS, A, (const N3Task *)p->d_tasks.p + t0, (const unsigned *)p->d_stbuf.p + (size_t)t0 * N3_STB, nts,
                                     (SvSurvivor *)p->d_surv.p, SURV_CAP, cnts + sl, st);
                     n3_launch_finish(PS, A, (const SvSurvivor *)p->d_surv.p, SURV_CAP, cnts + sl, st);
                 }
@@ -548,6 +553,11 @@ static int run_search(theta_problem *p, u128 b, u128 e, double window, double *d
         uint64_t redone = 0;
         for (size_t sl = 0; sl < slices.size(); sl++) {
             if (hcnt[sl] <= SURV_CAP) continue;
+            if (p->m > N3_MAX_M) {      // (the fused kernel holds one interval per lane)
+                theta_set_error("n=3, m = %d: %u contenders in one slice exceed the list (%u): pass a hint (theta_problem_hint) or "
+                                "search a shorter range", p->m, hcnt[sl], SURV_CAP);
+                return THETA_ERR_CAPACITY;
+            }
             const int t0 = slices[sl].first, nts = slices[sl].second;
             const u128 sb = b + (u128)t0 * sieve_per_task;
             u128 se = sb + (u128)nts * sieve_per_task;
@@ -911,6 +921,10 @@ static int enumerate_device(theta_problem *p, u128 b, uint64_t count, unsigned c
 }
 
 static int enumerate_args(theta_problem *p, const uint64_t rank_begin[2], uint64_t count, u128 &b) {
+    if (p && p->n == 3 && p->m > N3_MAX_M) {
+        theta_set_error("theta_enumerate: the n=3 generators hold at most %d intervals (m = %d)", N3_MAX_M, p->m);
+        return THETA_ERR_ARG;
+    }
     uint64_t re[2];
     u128 b0 = rank_begin ? mk128(rank_begin) : 0;
     u128 e0 = b0 + count;

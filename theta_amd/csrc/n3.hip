@@ -190,10 +190,12 @@ __device__ bool n3_unrank(const N3Dev &P, u128 rho, int depth, N3State *st, u128
 // Wave-cooperative rank -> DFS path: at every level the 64 lanes test the 64 alphabet slots and read their
 // children's counts in ONE memory round trip (the serial walk above chains ~5 dependent HBM reads per level);
 // the wave then scans the feasible children in slot order.  Lane d ends up holding the packed node of depth d.
-__device__ bool n3_unrank_wave(const N3Dev &P, u128 rho, int depth, int lane, unsigned &st_out, u128 &rem) {
+// (depth <= 128: lane d holds the node of depth d in st_out, and that of depth 64 + d in st_out1)
+__device__ bool n3_unrank_wave(const N3Dev &P, u128 rho, int depth, int lane, unsigned &st_out, unsigned &st_out1, u128 &rem) {
     const int K1 = P.K + 1, sa = lane % K1, sb = lane / K1;
     N3State par{0, 0, 0, 0, 0, 0};
     st_out = 0u;
+    st_out1 = 0u;
     for (int d = 0; d < depth; d++) {
         N3State nx{0, 0, 0, 0, 0, 0};
         bool ok = lane < P.Q && (d == 0 ? n3_first_row_ab(P, sa, sb, lane, nx) : n3_edge_ab(P, par, sa, sb, lane, d, nx));
@@ -220,6 +222,7 @@ __device__ bool n3_unrank_wave(const N3Dev &P, u128 rho, int depth, int lane, un
         unsigned packed = (unsigned)__builtin_amdgcn_readlane((int)mine, chosen);
         par = n3_unpack(packed);
         if (lane == d) st_out = packed;
+        if (lane + WAVE == d) st_out1 = packed;
     }
     rem = rho;
     return true;
@@ -235,9 +238,9 @@ __global__ __launch_bounds__(256) void n3_task_kernel(N3Dev P, uint64_t b_lo, ui
     u128 left = end - base;
     uint64_t count = left < (u128)per_task ? (uint64_t)left : per_task;
     const int D = P.m - P.L;
-    unsigned st = 0;
+    unsigned st = 0, st1 = 0;
     u128 rem = 0;
-    bool ok = n3_unrank_wave(P, base, D, lane, st, rem);
+    bool ok = n3_unrank_wave(P, base, D, lane, st, st1, rem);
     if (lane == 0) {
         N3Task tk;
         tk.base_lo = (uint64_t)base;
@@ -246,7 +249,8 @@ __global__ __launch_bounds__(256) void n3_task_kernel(N3Dev P, uint64_t b_lo, ui
         tk.skip = (uint64_t)rem;
         tasks[t] = tk;
     }
-    if (lane < D) stbuf[(size_t)t * N3_MAX_M + lane] = st;
+    if (lane < D) stbuf[(size_t)t * N3_STB + lane] = st;
+    if (lane + WAVE < D) stbuf[(size_t)t * N3_STB + WAVE + lane] = st1;
 }
 
 // one wave per tie record: its matrix
@@ -254,12 +258,17 @@ __global__ __launch_bounds__(256) void n3_unrank_list_kernel(N3Dev P, const TieR
     const int k = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (k >= count) return;
     u128 rho = ((u128)recs[k].rank_hi << 64) | recs[k].rank_lo, rem;
-    unsigned st = 0;
-    bool ok = n3_unrank_wave(P, rho, P.m, lane, st, rem);
+    unsigned st = 0, st1 = 0;
+    bool ok = n3_unrank_wave(P, rho, P.m, lane, st, st1, rem);
     if (lane < P.m) {
         unsigned char *dst = out + (size_t)k * P.m * 2 + 2 * lane;
         dst[0] = ok ? (unsigned char)((st >> 24) & 15u) : 255;
         dst[1] = ok ? (unsigned char)(st >> 28) : 255;
+    }
+    if (lane + WAVE < P.m) {
+        unsigned char *dst = out + (size_t)k * P.m * 2 + 2 * (lane + WAVE);
+        dst[0] = ok ? (unsigned char)((st1 >> 24) & 15u) : 255;
+        dst[1] = ok ? (unsigned char)(st1 >> 28) : 255;
     }
 }
 
@@ -523,7 +532,7 @@ __global__ __launch_bounds__(64 * N3_WAVES, N3_OCC) void n3_search_kernel(N3Dev 
     const int NT1 = Pg.NT + 1;
 
     // lane i holds interval i; lane s (+64) also stands for alphabet slot s in the prefix successor
-    unsigned st = lane < D ? stbuf[(size_t)task * N3_MAX_M + lane] : 0u;
+    unsigned st = lane < D ? stbuf[(size_t)task * N3_STB + lane] : 0u;
     const int K1 = P.K + 1;
     const int sa0 = lane % K1, sb0 = lane / K1, sa1 = (lane + WAVE) % K1, sb1 = (lane + WAVE) / K1;
 
@@ -1358,7 +1367,7 @@ __global__ __launch_bounds__(64 * N3_WAVES) void n3_enumerate_wave_kernel(N3Dev 
     auto &W = S.w[wv];
     const unsigned long long swm = Pg.swmask;
     const int NT1 = Pg.NT + 1;
-    unsigned st = lane < D ? stbuf[(size_t)task * N3_MAX_M + lane] : 0u;
+    unsigned st = lane < D ? stbuf[(size_t)task * N3_STB + lane] : 0u;
     const int K1 = P.K + 1;
     const int sa0 = lane % K1, sb0 = lane / K1, sa1 = (lane + WAVE) % K1, sb1 = (lane + WAVE) / K1;
     const N3Task tk = tasks[task];

@@ -6,7 +6,9 @@
 
 #define N3_MAX_K 7               // largest copy number in an n=3 search: the alphabet (K+1)^2 <= 64 fits one mask word
 #define N3_MAX_Q ((N3_MAX_K + 1) * (N3_MAX_K + 1))
-#define N3_MAX_M 64              // one interval per lane
+#define N3_MAX_M 64              // one interval per lane (fused kernel, generators)
+#define N3_MAX_M_WIDE 128        // two intervals per lane: the sieve path (n3_sieve.hip), task and unrank kernels
+#define N3_STB 128               // stride of the per-task prefix states (one packed DFS node per depth)
 #define N3_RIDX_W (2 * N3_MAX_K + 1)
 
 // Wave-uniform description of one n=3 search instance.

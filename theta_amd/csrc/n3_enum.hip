@@ -299,7 +299,7 @@ __global__ __launch_bounds__(64 * EB_WAVES, (ML <= 4 ? EB_OCC4 : EB_OCC6)) void 
     const int task = blockIdx.x * EB_WAVES + wv;
     if (task >= ntasks) return;
     const N3Task tk = tasks[task];
-    unsigned st = lane < D ? stbuf[(size_t)task * N3_MAX_M + lane] : 0u;
+    unsigned st = lane < D ? stbuf[(size_t)task * N3_STB + lane] : 0u;
 
     EbCtx<ML> c;
     c.S = &S;

@@ -60,7 +60,7 @@
 
 template <int ML>
 struct SvWave {
-    alignas(16) unsigned short pre[N3_MAX_M + 8];       // rows of the prefix, a | b << 8
+    alignas(16) unsigned short pre[N3_MAX_M_WIDE + 8];  // rows of the prefix, a | b << 8
     uint2 list0[N3_MAX_Q];                              // level 1 nodes (children of the prefix's last node)
     uint2 list[ML > 2 ? ML - 2 : 1][SV_CAP];            // level l >= 2: {packed parent node, ancestor slots (6 bits each) | slot << 24}
     unsigned short kid[SV_KIDS];                        // candidates of the current round: last row's slot | parent lane << 8
@@ -76,7 +76,7 @@ template <int ML>
 struct SvLds {
     SvWave<ML> w[SV_WAVES];
     unsigned long long smask[ML][N3_MAX_Q];             // static child masks of the ML last depths
-    unsigned char lb[N3_MAX_M], ub[N3_MAX_M];
+    unsigned char lb[N3_MAX_M_WIDE], ub[N3_MAX_M_WIDE];
     unsigned char ridx[N3_RIDX_W * N3_RIDX_W + 3];
     unsigned char rowtab[N3_MAX_Q + 3];
     unsigned short row16[N3_MAX_Q];                     // slot -> a | b << 8
@@ -577,16 +577,20 @@ __device__ __forceinline__ void sv_expand(SvCtx<ML> &c, int n_in) {
     }
 }
 
-// Next prefix in DFS order (wave-uniform): lane d holds the packed node of depth d.  Returns false at the end of the space.
-__device__ __forceinline__ bool sv_next_prefix(const N3Dev &P, unsigned &st, int D, int lane) {
+// Next prefix in DFS order (wave-uniform): lane d holds the packed node of depth d in st0 and that of depth 64 + d in st1
+// (m <= 128).  Returns false at the end of the space.
+__device__ __forceinline__ unsigned sv_state(unsigned st0, unsigned st1, int d) {
+    return (unsigned)__builtin_amdgcn_readlane((int)(d < WAVE ? st0 : st1), d & (WAVE - 1));
+}
+__device__ __forceinline__ bool sv_next_prefix(const N3Dev &P, unsigned &st0, unsigned &st1, int D, int lane) {
     const int K1 = P.K + 1, Q = P.Q;
     const int sa = lane % K1, sb = lane / K1;          // Q <= 64: one alphabet slot per lane
     int d = D - 1;
     bool fresh = false;
     while (true) {
-        const int cur_slot = __builtin_amdgcn_readlane((int)st, d) & 0x7f;
+        const int cur_slot = (int)(sv_state(st0, st1, d) & 0x7fu);
         const int start = fresh ? 0 : cur_slot + 1;
-        const N3State pst = n3_unpack((unsigned)__builtin_amdgcn_readlane((int)st, d > 0 ? d - 1 : 0));
+        const N3State pst = n3_unpack(sv_state(st0, st1, d > 0 ? d - 1 : 0));
         N3State nx{0, 0, 0, 0, 0, 0};
         const bool ok = lane >= start && lane < Q &&
                         (d == 0 ? n3_first_row_ab(P, sa, sb, lane, nx) : n3_edge_ab(P, pst, sa, sb, lane, d, nx));
@@ -595,7 +599,11 @@ __device__ __forceinline__ bool sv_next_prefix(const N3Dev &P, unsigned &st, int
             const int first = __builtin_ctzll(mk);
             const unsigned mine = ok ? n3_pack(nx) : 0u;
             const unsigned packed = (unsigned)__builtin_amdgcn_readlane((int)mine, first);
-            if (lane == d) st = packed;
+            if (d < WAVE) {
+                if (lane == d) st0 = packed;
+            } else if (lane == d - WAVE) {
+                st1 = packed;
+            }
             if (d == D - 1) return true;
             d++;
             fresh = true;
@@ -634,7 +642,8 @@ __global__ __launch_bounds__(64 * SV_WAVES, SV_OCC) void n3_sieve_kernel(N3Dev P
     const int task = blockIdx.x * SV_WAVES + wv;
     if (task >= ntasks) return;                        // whole wave leaves together; no block barrier below
     const N3Task tk = tasks[task];
-    unsigned st = lane < D ? stbuf[(size_t)task * N3_MAX_M + lane] : 0u;
+    unsigned st = lane < D ? stbuf[(size_t)task * N3_STB + lane] : 0u;
+    unsigned st1 = lane + WAVE < D ? stbuf[(size_t)task * N3_STB + WAVE + lane] : 0u;    // (m > 70: depths 64 .. D-1)
 
     SvCtx<ML> c;
     c.S = &S;
@@ -687,17 +696,22 @@ __global__ __launch_bounds__(64 * SV_WAVES, SV_OCC) void n3_sieve_kernel(N3Dev P
         int G = 0;
         double S1p = 0.0, S2p = 0.0, Rmin = __builtin_inf();
         {
-            const bool inp = lane < D;
-            const unsigned myrow = st >> 24;           // a | b << 4
+            // lane i stands for interval i and, for matrices of more than 64 + ML rows, for interval 64 + i as well
+            const bool inp = lane < D, inp1 = lane + WAVE < D;
+            const unsigned myrow = st >> 24, myrow1 = st1 >> 24;           // a | b << 4
             if (inp) c.W->pre[lane] = (unsigned short)((myrow & 15u) | ((myrow >> 4) << 8));
+            if (inp1) c.W->pre[WAVE + lane] = (unsigned short)((myrow1 & 15u) | ((myrow1 >> 4) << 8));
             const double r_i = inp ? Pg.r[lane] : 0.0, rN_i = inp ? Pg.rN[lane] : 0.0;
-            unsigned long long todo = ballot64(inp);
-            while (todo) {
-                const int leader = __builtin_ctzll(todo);
-                const unsigned q = (unsigned)__builtin_amdgcn_readlane((int)myrow, leader);
-                const bool match = inp && myrow == q;
+            const double r_j = inp1 ? Pg.r[WAVE + lane] : 0.0, rN_j = inp1 ? Pg.rN[WAVE + lane] : 0.0;
+            unsigned long long todo = ballot64(inp), todo1 = ballot64(inp1);
+            while (todo | todo1) {
+                unsigned q;
+                if (todo) q = (unsigned)__builtin_amdgcn_readlane((int)myrow, __builtin_ctzll(todo));
+                else q = (unsigned)__builtin_amdgcn_readlane((int)myrow1, __builtin_ctzll(todo1));
+                const bool match = inp && myrow == q, match1 = inp1 && myrow1 == q;
                 todo &= ~ballot64(match);
-                double Rs = match ? r_i : 0.0, Ns = match ? rN_i : 0.0;
+                todo1 &= ~ballot64(match1);
+                double Rs = (match ? r_i : 0.0) + (match1 ? r_j : 0.0), Ns = (match ? rN_i : 0.0) + (match1 ? rN_j : 0.0);
 #pragma unroll
                 for (int o = 32; o > 0; o >>= 1) {     // integer-valued doubles < 2^53: the sums are exact
                     Rs += __shfl_xor(Rs, o, WAVE);
@@ -730,7 +744,7 @@ __global__ __launch_bounds__(64 * SV_WAVES, SV_OCC) void n3_sieve_kernel(N3Dev P
         c.rtot_over_rmin = (float)(Pg.Rtot / Rmin);
         wave_lds_sync();
         const unsigned long long it0 = c.n_dit, par0 = c.n_par;
-        c.par = n3_unpack((unsigned)__builtin_amdgcn_readlane((int)st, D - 1));
+        c.par = n3_unpack(sv_state(st, st1, D - 1));
         c.n_prefix++;
         sv_expand<ML, 0>(c, 1);
         if (c.qcount) sv_drain<ML>(c);                 // the tile changes with the prefix: the queue is emptied first
@@ -738,7 +752,7 @@ __global__ __launch_bounds__(64 * SV_WAVES, SV_OCC) void n3_sieve_kernel(N3Dev P
         n_pterms += (c.n_par - par0) * (unsigned)(G + ML - 1);    // shared sums of a last-level node: all terms but its children's
         c.skip = 0;                                    // only the first prefix of a task starts mid-way
         if (c.remaining == 0) break;
-        if (!sv_next_prefix(P, st, D, lane)) break;
+        if (!sv_next_prefix(P, st, st1, D, lane)) break;
         wave_lds_sync();                               // the prefix rows in LDS are rewritten next
     }
     if (lane == 0) {
@@ -771,7 +785,7 @@ __device__ __noinline__ int sv_reference_outcome(int m, double tau, const double
 
 __global__ __launch_bounds__(256) void n3_finish_kernel(N3Dev P, SearchArgs A, const SvSurvivor *surv, unsigned surv_cap,
                                                         const unsigned *surv_count) {
-    __shared__ double rr[N3_MAX_M], rn[N3_MAX_M];
+    __shared__ double rr[N3_MAX_M_WIDE], rn[N3_MAX_M_WIDE];
     const int m = P.m;
     unsigned n = *surv_count;
     if (n > surv_cap) n = surv_cap;

@@ -6,7 +6,7 @@
 // sieve could not handle).  rows = the whole matrix, m x {a, b} bytes.
 struct SvSurvivor {
     uint64_t rank_lo, rank_hi;
-    unsigned char rows[2 * N3_MAX_M];
+    unsigned char rows[2 * N3_MAX_M_WIDE];
 };
 
 int n3_sieve_levels(const N3Dev &P);
