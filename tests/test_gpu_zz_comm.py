@@ -1,0 +1,110 @@
+"""
+The library's communicator on the GPU box (run with `-m gpu`): RCCL with world = 1 on this one-GPU box, and two processes
+sharing the GPU over the host transport.  The file sorts last on purpose: the oracle-side worker pools of the other GPU
+tests are forked from the pytest process, and nothing is forked from a process that has initialised RCCL.
+"""
+import multiprocessing as mp
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+import campaign
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import theta_amd
+    return theta_amd.default_context()
+
+
+def _gpu_best(inst):
+    from theta_amd.search import do_optimization_single
+    try:
+        best = do_optimization_single(inst["n"], inst["m"], inst["k"], inst["tau"], list(inst["lb"]), list(inst["ub"]), inst["r"],
+                                      inst["rN"], inst["mx"], inst["order"])
+    except SystemExit:
+        best = []
+    return campaign.best_to_plain(best)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _shard_worker(rank, world, port, inst, q):
+    try:
+        sys.path.insert(0, ROOT)
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import theta_amd
+        from theta_amd import search as S
+        import campaign as cp
+        c = theta_amd.Context(0)
+        comm = theta_amd.Comm(c, rank=rank, world=world, addr="127.0.0.1", port=port, transport="host")
+        best = S.do_optimization_distributed(inst["n"], inst["m"], inst["k"], inst["tau"], inst["lb"], inst["ub"], inst["r"], inst["rN"],
+                                             inst["mx"], inst["order"], comm, ctx=c)
+        comm.close()
+        q.put((rank, cp.best_to_plain(best)))
+    except BaseException as e:
+        q.put((rank, "error: %r" % (e,)))
+
+
+def test_two_processes_share_the_gpu_and_exchange_through_the_library(ctx):
+    """do_optimization_distributed with world = 2 on this box's single GPU (host transport: RCCL refuses two ranks on one
+    device): both ranks return the single-GPU `best`, n=2 and n=3."""
+    mpc = mp.get_context("spawn")
+    done = 0
+    for n, seeds in ((2, range(9500, 9600)), (3, range(9600, 9800))):
+        got = 0
+        for seed in seeds:
+            inst = campaign.instance(seed, n, "mid" if seed % 2 else "toy")
+            cnt = campaign.count_candidates(inst)
+            if not (300 <= cnt <= 100000):
+                continue
+            single = _gpu_best(inst)
+            q = mpc.Queue()
+            port = _free_port()
+            procs = [mpc.Process(target=_shard_worker, args=(rk, 2, port, inst, q)) for rk in range(2)]
+            for pr in procs:
+                pr.start()
+            out = dict(q.get(timeout=300) for _ in range(2))
+            for pr in procs:
+                pr.join(60)
+            for rk in range(2):
+                assert not isinstance(out[rk], str), out[rk]
+                assert campaign.compare_best(out[rk], single) == "", (n, seed, rk)
+            got += 1
+            done += 1
+            if got >= 2:
+                break
+    assert done == 4
+
+
+def test_rccl_communicator_world_of_one(ctx):
+    """ncclCommInitRank / ncclAllReduce / ncclAllGather through the library (librccl.so is dlopened here): one rank, this GPU."""
+    import theta_amd
+    comm = theta_amd.Comm(ctx, rank=0, world=1, transport="rccl")
+    info = comm.info()
+    assert info["transport"] == "rccl" and info["rccl_version"] > 20000
+    assert comm.allreduce_min([3.5, -1.0]).tolist() == [3.5, -1.0]
+    assert comm.allreduce_sum([2.0]).tolist() == [2.0]
+    assert comm.allgather(np.arange(5, dtype=np.int32)).tolist() == [[0, 1, 2, 3, 4]]
+    comm.barrier()
+    recs = [{"rank": (1 << 70) + 3, "c": np.ones((6, 2), np.uint8), "mu": np.array([.2, .3, .5]), "nll": 10.0, "vals": np.ones(6)},
+            {"rank": 5, "c": np.zeros((6, 2), np.uint8), "mu": np.array([.1, .1, .8]), "nll": float("nan"), "vals": np.ones(6)},
+            {"rank": 9, "c": np.zeros((6, 2), np.uint8), "mu": np.array([.1, .1, .8]), "nll": 11.0, "vals": np.ones(6)}]
+    merged, gmin = comm.exchange_finalists(3, 6, recs, 0.5)
+    assert gmin == 10.0 and [t["rank"] for t in merged] == [5, (1 << 70) + 3]
+    assert merged[0]["nll"] != merged[0]["nll"] and merged[1]["c"].tolist() == [[1, 1]] * 6
+    assert comm.info()["collectives"] >= 6
+    comm.close()
