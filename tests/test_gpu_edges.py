@@ -29,7 +29,7 @@ def test_error_codes_and_messages(ctx):
     with pytest.raises(theta_amd.ThetaError):
         theta_amd.Problem(ctx, 3, 3, 2, [1, 2, 3], [1, 1, 3], [0] * 3, [9] * 3)  # n=3 alphabet limit
     with pytest.raises(theta_amd.ThetaError):
-        theta_amd.Problem(ctx, 3, 65, 2, [1] * 65, [1] * 65, [0] * 65, [2] * 65)  # n=3: one interval per lane
+        theta_amd.Problem(ctx, 3, 129, 2, [1] * 129, [1] * 129, [0] * 129, [2] * 129)  # n=3: two intervals per lane at most
     p = theta_amd.Problem(ctx, 2, 3, 2, [5, 6, 7], [5, 5, 5], [2, 2, 2], [1, 1, 1])  # lb > ub: nothing to enumerate
     assert p.count == 0
     with pytest.raises(theta_amd.NoCandidates):
@@ -285,11 +285,19 @@ def test_get_values_dump_matches_oracle_trace(ctx, tmp_path):
 
 
 def test_driver_exits_cleanly_when_the_search_is_beyond_the_library(ctx, capsys):
-    """n=3 with 70 intervals (the library holds one interval per lane: 64), or a space beyond 2^128 matrices: a message
-    and exit(1) like the reference's other input errors, not a traceback."""
+    """n=3 with 130 intervals (the library holds 128), a space beyond 2^128 matrices (64 intervals, bounds [0, 7]), or one no
+    search can finish (70 intervals, bounds [0, 2]: 2.5e34 matrices -- refused at once, nothing of that size is materialised
+    on the host): a message and exit(1) like the reference's other input errors, not a traceback."""
+    import theta_amd
     from theta_amd.search import do_optimization_single
     rng = np.random.RandomState(4)
-    for m, k in ((70, 2), (64, 7)):
+    p = theta_amd.Problem(ctx, 3, 70, 2, [1] * 70, [1] * 70, [0] * 70, [2] * 70)
+    assert p.count == 25344449490209970329508701131116975
+    with pytest.raises(theta_amd.ThetaError) as e:
+        p.search(0, p.count)
+    assert e.value.code == theta_amd._lib.ERR_OVERFLOW
+    p.close()
+    for m, k in ((130, 2), (70, 2), (64, 7)):
         r = rng.randint(1000, 5000, m).tolist()
         rN = rng.randint(1000, 5000, m).tolist()
         with pytest.raises(SystemExit):

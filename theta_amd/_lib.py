@@ -291,6 +291,72 @@ def default_context():
     return _default_ctx
 
 
+class _Merged:
+    """Running merge of the pieces of one Problem.search call (finalists, n=3 suspects and all-zero-column entries, stats)."""
+    SUMMED = ("evaluated", "accepted", "degenerate", "iterations", "terms", "list_overflow", "flops", "flops_f32", "dismissed",
+              "survivors", "fallback_candidates", "kernel_ms", "setup_ms")
+
+    def __init__(self, n, m):
+        self.n, self.m = n, m
+        self.nll, self.mu, self.C, self.rank = np.zeros(0), np.zeros((0, n)), None, []
+        self.srk, self.slb, self.sC = [], np.zeros(0), np.zeros((0, m, 2), np.uint8)
+        self.drk, self.dC = [], np.zeros((0, m, 2), np.uint8)
+        self.stats = None
+        self.since_prune = 0
+
+    def add(self, part, running, window):
+        res, sus, _dropped, deg = part
+        if self.stats is None:
+            self.stats = dict(res["stats"])
+        else:
+            for k, v in res["stats"].items():
+                if k in self.SUMMED:
+                    self.stats[k] += v
+                elif k == "phase_cycles":
+                    self.stats[k] = [a + b for a, b in zip(self.stats[k], v)]
+                elif k == "best_nll":
+                    self.stats[k] = min(self.stats[k], v)
+                elif k == "rejected_bound" and v < self.stats[k]:
+                    self.stats[k], self.stats["rejected_rank"] = v, res["stats"]["rejected_rank"]
+        if len(res["nll"]):
+            self.nll = np.concatenate([self.nll, res["nll"]])
+            self.mu = np.concatenate([self.mu, res["mu"]])
+            self.C = res["C"] if self.C is None else np.concatenate([self.C, res["C"]])
+            self.rank += list(res["rank"])
+        if self.n == 3:
+            if len(sus[0]):
+                self.srk += list(sus[0])
+                self.slb = np.concatenate([self.slb, sus[1]])
+                self.sC = np.concatenate([self.sC, sus[2].reshape(-1, self.m, 2)])
+            if len(deg[0]):
+                self.drk += list(deg[0])
+                self.dC = np.concatenate([self.dC, deg[1].reshape(-1, self.m, 2)])
+        self.since_prune += 1
+        if self.since_prune >= 64:                       # long walks: drop what the minimum so far has already ruled out
+            self.prune(running, window)
+
+    def prune(self, gmin, window):
+        self.since_prune = 0
+        if len(self.nll):
+            keep = ~(self.nll > gmin + window)           # (NaN never arrives here: the device lists hold finite values)
+            self.nll, self.mu, self.C = self.nll[keep], self.mu[keep], self.C[keep]
+            self.rank = [r for r, k in zip(self.rank, keep) if k]
+        if len(self.slb):
+            ks = np.nonzero(self.slb <= gmin + window)[0]
+            self.srk, self.slb, self.sC = [self.srk[i] for i in ks], self.slb[ks], self.sC[ks]
+
+    def result(self, window):
+        gmin = float(self.nll.min()) if len(self.nll) else float("inf")
+        self.prune(gmin, window)
+        if self.n == 3:
+            suspects = (self.srk, self.slb, self.sC)
+            degenerate = (self.drk, self.dC)
+        else:
+            suspects, degenerate = ([], np.zeros(0), None), ([], None)
+        Cc = self.C if self.C is not None else np.zeros((0, self.m) if self.n == 2 else (0, self.m, 2), np.uint8)
+        return {"nll": self.nll, "mu": self.mu, "rank": self.rank, "C": Cc, "stats": self.stats}, suspects, degenerate
+
+
 class Problem:
     """One search instance resident in HBM (theta_problem_create)."""
 
@@ -364,63 +430,49 @@ class Problem:
         """
         end = self.count if end is None else end
         step = self.MAX_PER_CALL[self.n]
+        if end - begin > step * self.MAX_PIECES:
+            # e.g. 70 intervals with bounds [0, 2]: 2.5e34 matrices.  The reference would enumerate such a space for ever; here
+            # the call says so (the pieces are walked one by one, nothing of this size is ever materialised on the host)
+            raise ThetaError(ERR_OVERFLOW, "%d candidate matrices in one search: more than this library walks in one call "
+                             "(%d); tighten the bounds, use fewer intervals, or search rank sub-ranges" % (end - begin, step * self.MAX_PIECES))
         running = self._probe(begin, end)
-        bounds = [(b, min(b + step, end)) for b in range(begin, end, step)]
-        if not bounds:                                   # an empty range (or an empty space: theta_search says so)
+        if end <= begin:                                 # an empty range (or an empty space: theta_search says so)
             self.last_suspects, self.last_degenerate = ([], np.zeros(0), None), ([], None)
             return self._search_once(begin, end, window, cap)
-        parts, hints = [], []
-        for b, e in bounds:
-            hints.append(running)
-            parts.append(self._piece(b, e, window, cap, running))     # later pieces start from the minimum found so far
-            nl = parts[-1][0]["nll"]
+        # The pieces are walked in order and merged as they come: what is kept between pieces is what can still matter
+        # (finalists and suspects within `window` of the minimum so far, the all-zero-column list), not one entry per piece.
+        acc = _Merged(self.n, self.m)
+        redo = []                                        # pieces whose device suspect list overflowed: (b, e, hint used)
+        b = begin
+        while b < end:
+            e = min(b + step, end)
+            part = self._piece(b, e, window, cap, running)           # later pieces start from the minimum found so far
+            nl = part[0]["nll"]
+            hint_used = running
             if len(nl):
                 running = min(running, float(nl.min()))
+            if part[2] > 0:
+                redo.append((b, e, hint_used, part[2]))              # (its lists are incomplete: searched again below)
+            else:
+                acc.add(part, running, window)
+            b = e
         self.suspect_reruns = 0
-        for i, (b, e) in enumerate(bounds):
-            if parts[i][2] > 0:
-                if not running < hints[i]:
-                    raise ThetaError(ERR_CAPACITY, "n=3 suspect list overflowed in ranks [%d, %d) (%d entries dropped) although "
-                                     "the search started from the range's own minimum" % (b, e, parts[i][2]))
-                parts[i] = self._piece(b, e, window, cap, running)
-                self.suspect_reruns += 1
-                if parts[i][2] > 0:
-                    raise ThetaError(ERR_CAPACITY, "n=3 suspect list overflowed in ranks [%d, %d) (%d entries dropped) with "
-                                     "the minimum of the whole range as hint" % (b, e, parts[i][2]))
+        for b, e, hint_used, dropped in redo:
+            if not running < hint_used:
+                raise ThetaError(ERR_CAPACITY, "n=3 suspect list overflowed in ranks [%d, %d) (%d entries dropped) although "
+                                 "the search started from the range's own minimum" % (b, e, dropped))
+            part = self._piece(b, e, window, cap, running)
+            self.suspect_reruns += 1
+            if part[2] > 0:
+                raise ThetaError(ERR_CAPACITY, "n=3 suspect list overflowed in ranks [%d, %d) (%d entries dropped) with "
+                                 "the minimum of the whole range as hint" % (b, e, part[2]))
+            acc.add(part, running, window)
         self.suspects_dropped = 0
-        stats = dict(parts[0][0]["stats"])
-        for p, _s, _d, _g in parts[1:]:
-            for k, v in p["stats"].items():
-                if k in ("evaluated", "accepted", "degenerate", "iterations", "terms", "list_overflow", "flops", "flops_f32", "dismissed",
-                         "survivors", "fallback_candidates"):
-                    stats[k] += v
-                elif k in ("kernel_ms", "setup_ms"):
-                    stats[k] += v
-                elif k == "phase_cycles":
-                    stats[k] = [a + b for a, b in zip(stats[k], v)]
-                elif k == "best_nll":
-                    stats[k] = min(stats[k], v)
-                elif k == "rejected_bound" and v < stats[k]:
-                    stats[k], stats["rejected_rank"] = v, p["stats"]["rejected_rank"]
-        nll = np.concatenate([p[0]["nll"] for p in parts])
-        gmin = float(nll.min()) if len(nll) else float("inf")
-        if self.n == 3:
-            srk = [r for p in parts for r in p[1][0]]
-            slb = np.concatenate([p[1][1] for p in parts]) if parts else np.zeros(0)
-            sC = np.concatenate([p[1][2].reshape(-1, self.m, 2) for p in parts])
-            ks = np.nonzero(slb <= gmin + window)[0] if len(slb) else np.zeros(0, np.int64)
-            self.last_suspects = ([srk[i] for i in ks], slb[ks], sC[ks])
-            self.last_degenerate = ([r for p in parts for r in p[3][0]],
-                                    np.concatenate([p[3][1].reshape(-1, self.m, 2) for p in parts]))
-        else:
-            self.last_suspects = ([], np.zeros(0), None)
-            self.last_degenerate = ([], None)
-        keep = nll <= gmin + window if len(nll) else np.zeros(0, bool)
-        mu = np.concatenate([p[0]["mu"] for p in parts])[keep]
-        Cc = np.concatenate([p[0]["C"] for p in parts])[keep]
-        ranks = [r for p in parts for r in p[0]["rank"]]
-        ranks = [r for r, k in zip(ranks, keep) if k]
-        return {"nll": nll[keep], "mu": mu, "rank": ranks, "C": Cc, "stats": stats}
+        out, self.last_suspects, self.last_degenerate = acc.result(window)
+        return out
+
+    # pieces per search() call: 2^25 x 2^31 = 2^56 n=3 candidates (7e16: eleven days of this GPU at 7.5e10 candidates/s)
+    MAX_PIECES = 1 << 25
 
     def hint(self, nll_upper_bound):
         """One-shot: an NLL already known to be attainable (keeps the next search's lists short)."""
