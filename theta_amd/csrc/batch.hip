@@ -382,23 +382,32 @@ __global__ __launch_bounds__(256) void score_masked_kernel(int n, int m, int tau
 // ------------------------------------------------------------------------------------------------
 typedef double mfma_d4 __attribute__((ext_vector_type(4)));
 
-// ln(x) for the epilogue of the masked scorer (one per (candidate, mask) pair): the classic reduction x = 2^k (1 + f),
-// 1 + f in [sqrt(1/2), sqrt(2)), ln(1 + f) = 2 atanh(s) with s = f / (2 + f) as a degree-7 polynomial in s^2 (the
-// coefficients of Sun's fdlibm e_log.c, error < 1 ulp), ~35 instructions instead of the library call's ~90.  Anything
-// that is not a positive normal number goes to the library.
-__device__ __forceinline__ double smx_log(double x) {
+// ln(x) for the scorers below (one per (candidate, interval) and one per (candidate, mask) pair), table-driven:
+// x = 2^k m, m in [1, 2); entry j = top 7 mantissa bits holds inv_c ~ 1 / (1 + (j + 1/2)/128) and log_c = -ln(inv_c) of
+// that very double (tools/gen_log_table.py, 60-digit arithmetic), so ln x = k ln 2 + log_c + log1p(f) with
+// f = m inv_c - 1 from ONE fma, |f| <= 2^-8, and log1p by its series to f^6 (next term < 2e-18).  Absolute error
+// ~2e-16; 15 vector instructions and one 16-byte LDS read, against ~35 for the fdlibm reduction used before and ~90
+// for the library call.  Anything that is not a positive normal number goes to the library.
+__device__ const unsigned long long smx_log_table[256] = {
+#include "smx_log_table.inc"
+};
+#define SMX_TAB_BYTES 2048
+__device__ __forceinline__ void smx_log_stage(double2 *tab) {
+    for (int i = threadIdx.x; i < 128; i += blockDim.x) tab[i] = ((const double2 *)smx_log_table)[i];
+}
+__device__ __forceinline__ double smx_log(double x, const double2 *tab) {
     const int hx = __double2hiint(x);
-    if (!(hx >= 0x00100000 && hx < 0x7ff00000)) return log(x);
-    const int i = ((hx & 0x000fffff) + 0x95f64) & 0x100000;
-    const int k = (hx >> 20) - 1023 + (i >> 20);
-    const double f = __hiloint2double((hx & 0x000fffff) | (i ^ 0x3ff00000), __double2loint(x)) - 1.0;
-    const double s = f * rcp_nr2(2.0 + f), dk = (double)k;      // (reciprocal to full double accuracy, no division sequence)
-    const double z = s * s, w = z * z;
-    const double t1 = w * (3.999999999940941908e-01 + w * (2.222219843214978396e-01 + w * 1.531383769920937332e-01));
-    const double t2 = z * (6.666666666666735130e-01 +
-                           w * (2.857142874366239149e-01 + w * (1.818357216161805012e-01 + w * 1.479819860511658591e-01)));
-    const double R = t2 + t1, hfsq = 0.5 * f * f;
-    return dk * 6.93147180369123816490e-01 - ((hfsq - (s * (hfsq + R) + dk * 1.90821492927058770002e-10)) - f);
+    if ((unsigned)(hx - 0x00100000) >= 0x7fe00000u) return log(x);
+    const double2 e = tab[(hx >> 13) & 0x7f];
+    const double mnt = __hiloint2double((hx & 0x000fffff) | 0x3ff00000, __double2loint(x));
+    const double f = __builtin_fma(mnt, e.x, -1.0);
+    const double dk = (double)((hx >> 20) - 1023);
+    double p = __builtin_fma(f, -1.0 / 6.0, 0.2);
+    p = __builtin_fma(f, p, -0.25);
+    p = __builtin_fma(f, p, 1.0 / 3.0);
+    p = __builtin_fma(f, p, -0.5);
+    p = __builtin_fma(f, p, 1.0);
+    return __builtin_fma(f, p, __builtin_fma(dk, 6.931471805599453094e-01, e.y));
 }
 #define SMX_CAND 16
 #define SMX_WAVES 8
@@ -415,45 +424,64 @@ __global__ __launch_bounds__(64) void mask_rsum_kernel(int m, int S, const doubl
     if (lane == 0) rsum[s] = acc;
 }
 
-// Block = 8 waves and 16 candidates: X has 32 columns (two 16-column B fragments), so that every A fragment -- the mask
-// bits, the only operand that costs vector instructions to build -- feeds two MFMAs with independent accumulators.
-// X is dynamic LDS, mpad x 32 doubles (53 KB at m=200: three blocks = 24 waves per CU); odd rows store their two
-// 16-column halves swapped, so that the four rows one ds_read_b64 touches alternate between the two halves of the banks.
+// Block = 8 waves and 16 candidates.  X (dynamic LDS) is [row][candidate]{C.mu, r ln C.mu}: one ds_read_b128 hands a lane
+// the B operands of BOTH accumulators (fragment 0 = the sums of C.mu, fragment 1 = the sums of r ln C.mu of the same 16
+// candidates), so D[mask][candidate] of the two fragments meet in the same lane and register: the epilogue needs no
+// exchange.  On gfx950 the f64 MFMA does not overlap with vector instructions of other waves (tools/micro/mfma_f64_rate.hip),
+// so what counts is the number of vector instructions per MFMA; the A operand -- the mask bits -- is built with ONE:
+//   * K index: MFMA step `st` of 16-row group g takes matrix row g*16 + 4 lk + st for K-lane lk -- a lane's four bits of a
+//     group are adjacent in the mask word (one shift pair per group puts them on bits 27..30);
+//   * A = the double whose high word is the single exponent bit 27+st, i.e. 2^-895, 2^-767, 2^-511, 2 for st = 0..3 -- one
+//     v_and_b32 --, and phase 1 stores rows with (row & 3) == st multiplied by the inverse power of two (v_ldexp_f64):
+//     the products are exactly the unscaled terms.
+// LDS: m rows of 256 B, then the logarithm table (2 KB), which doubles as the rows m.. of the last 16-row group (finite
+// numbers under A = 0: mask bits >= m are cleared when the words are loaded), zero fill up to the group boundary if any
+// is left, then the Q10 bitmaps -- 53 760 B at m = 200: three blocks = 24 waves per CU.
 extern __shared__ double smx_lds[];
+__device__ __forceinline__ size_t smx_x_bytes(int m) {
+    const size_t a = (size_t)m * 256 + SMX_TAB_BYTES, b = (size_t)((m + 15) & ~15) * 256;
+    return a > b ? a : b;
+}
+template <int NG>                                                             // NG = 16-row groups = ceil(m / 16)
 __global__ __launch_bounds__(64 * SMX_WAVES) void score_masked_mfma_kernel(int n, int m, int tau, int B, int S,
                                                                            const unsigned char *C, const double *w, const double *r,
                                                                            const double *mu, const unsigned long long *mask,
                                                                            const double *rsum, double *nll) {
-    const int nc = n - 1, words = (m + 63) / 64, mpad = (m + 15) & ~15;      // rows of X in 16-row groups (zero rows beyond m)
-    double *const X = smx_lds;                                                // [mpad][32]: columns 2c, 2c+1 = candidate c
-    unsigned long long(*const zrow)[4] = (unsigned long long(*)[4])(smx_lds + (size_t)mpad * 32);   // [SMX_CAND][4]: rows that
+    constexpr int words = (NG + 3) / 4;
+    const int nc = n - 1;
+    double2 *const X = (double2 *)smx_lds;                                    // [row][16]: {C.mu, r ln C.mu} of candidate c
+    double2 *const tab = X + (size_t)m * 16;
+    const size_t xb = smx_x_bytes(m);
+    unsigned long long(*const zrow)[4] = (unsigned long long(*)[4])((char *)smx_lds + xb);   // [SMX_CAND][4]: rows that
     const int b0 = blockIdx.x * SMX_CAND;                                     // become 0 once masked (NaN poison, quirk Q10)
+    smx_log_stage(tab);
+    for (size_t i = (size_t)m * 256 + SMX_TAB_BYTES + threadIdx.x * 8; i < xb; i += blockDim.x * 8) *(double *)((char *)smx_lds + i) = 0.0;
     for (int i = threadIdx.x; i < SMX_CAND * 4; i += blockDim.x) (&zrow[0][0])[i] = 0ull;
     __syncthreads();
-    // ---- phase 1: the per-row terms of the 16 candidates (32 threads per candidate, rows strided by 32)
+    // ---- phase 1: the per-row terms of the 16 candidates; a wave covers 4 rows x 16 candidates per pass (256 B runs of LDS)
     {
-        const int c = threadIdx.x >> 5, b = b0 + c;
+        const int c = threadIdx.x & 15, b = b0 + c;
         const bool live = b < B;
         double m0 = 0, m1 = 0, m2 = 0;
         if (live) {
             const double *mv = mu + (size_t)b * n;
-            m0 = mv[0];
+            m0 = (double)tau * mv[0];
             m1 = (n == 2) ? 1.0 - mv[0] : mv[1];
             m2 = (n == 3) ? mv[2] : 0.0;
         }
-        for (int i = threadIdx.x & 31; i < mpad; i += 32) {
+        const int st = (threadIdx.x >> 4) & 3;                                // = row & 3: the MFMA step that consumes the row
+        const int ex = st == 0 ? 895 : st == 1 ? 767 : st == 2 ? 511 : -1;
+        for (int i = threadIdx.x >> 4; i < m; i += 32) {
             double cm = 0.0, tl = 0.0;
-            if (live && i < m) {
+            if (live) {
                 const unsigned char *cc = C + ((size_t)b * m + i) * nc;
-                double x = (double)cc[0], y = (nc == 2) ? (double)cc[1] : 0.0;
-                double tum = x * m1 + y * m2;
-                cm = w[i] * ((double)tau * m0 + tum);
-                tl = r[i] * smx_log(cm);
+                const double x = (double)cc[0], y = (nc == 2) ? (double)cc[1] : 0.0;
+                const double tum = x * m1 + y * m2;
+                cm = w[i] * (m0 + tum);
+                tl = r[i] * smx_log(cm, tab);
                 if (!(w[i] * tum > 0.0)) atomicOr(&zrow[c][i >> 6], 1ull << (i & 63));
             }
-            const int col = (2 * c) ^ ((i & 1) << 4);
-            X[i * 32 + col] = cm;
-            X[i * 32 + col + 1] = tl;
+            X[i * 16 + c] = double2{ldexp(cm, ex), ldexp(tl, ex)};
         }
     }
     __syncthreads();
@@ -461,12 +489,10 @@ __global__ __launch_bounds__(64 * SMX_WAVES) void score_masked_mfma_kernel(int n
     bool any_zrow = false;
     for (int i = 0; i < SMX_CAND * 4; i++) any_zrow |= (&zrow[0][0])[i] != 0ull;
     // ---- phase 2: masked sums on the matrix cores
-    // A[i][k] = mask bit k of mask row s0+i as a double: lane (li, lk) walks bits lk, lk+4, ... of its row -- a 16-bit
-    // group of a mask word shifted right by lk, then per MFMA step one sign-extending bit-field extract (0 / -1) and one
-    // AND with the high word of 1.0.
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int li = lane & 15, lk = lane >> 4;
-    const int colA = li ^ ((lk & 1) << 4), colB = colA ^ 16;       // this lane's column in the two B fragments (row parity = lk parity)
+    const unsigned sh0 = lk * 4, sh1 = lk * 4 + 16;
+    const double2 *const xl = X + lk * 64 + li;                               // row 4 lk (+ st), candidate li
     for (int s0 = wv * 16; s0 < S; s0 += 16 * SMX_WAVES) {
         const int sA = s0 + li;                             // mask row this lane feeds into A
         unsigned long long mw[4] = {0, 0, 0, 0};
@@ -474,60 +500,51 @@ __global__ __launch_bounds__(64 * SMX_WAVES) void score_masked_mfma_kernel(int n
             const unsigned long long *mp = mask + (size_t)sA * words;
 #pragma unroll
             for (int q = 0; q < 4; q++)
-                if (q < words) mw[q] = mp[q];
+                if (q < words) mw[q] = (q == words - 1 && (m & 63)) ? (mp[q] & ((1ull << (m & 63)) - 1ull)) : mp[q];
         }
         mfma_d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
-        // 16 rows of X per group: eight LDS reads in flight, then eight MFMAs; the 16 groups are unrolled behind uniform guards
+        // 16 rows of X per group, the NG groups unrolled; the four 16-byte LDS reads of group g+1 are
+        // issued before the eight MFMAs of group g (the scheduling barrier keeps the compiler from sinking them again)
+        double2 bv[4];
 #pragma unroll
-        for (int g = 0; g < SMX_MAXM / 16; g++) {
-            if (g * 16 < mpad) {
+        for (int st = 0; st < 4; st++) bv[st] = xl[st * 16];
+#pragma unroll
+        for (int g = 0; g < NG; g++) {
+            {
+                double2 nx[4] = {bv[0], bv[1], bv[2], bv[3]};
+                if (g + 1 < NG) {
+#pragma unroll
+                    for (int st = 0; st < 4; st++) nx[st] = xl[((g + 1) * 16 + st) * 16];
+                }
                 const unsigned long long wq = mw[g / 4];
                 const unsigned half = (g & 2) ? (unsigned)(wq >> 32) : (unsigned)wq;
-                const unsigned cur = ((g & 1) ? (half >> 16) : half) >> lk;          // bits 0, 4, 8, 12: rows g*16 + lk + 4 step
-                double bv0[4], bv1[4];
+                const unsigned al = (half >> ((g & 1) ? sh1 : sh0)) << 27;    // this lane's bits of the group on bits 27..30
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int step = 0; step < 4; step++) {
-                    const double *row = X + (size_t)(g * 16 + step * 4 + lk) * 32;
-                    bv0[step] = row[colA];
-                    bv1[step] = row[colB];
+                for (int st = 0; st < 4; st++) {
+                    const double a = __hiloint2double((int)(al & (1u << (27 + st))), 0);
+                    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bv[st].x, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bv[st].y, acc1, 0, 0, 0);
                 }
 #pragma unroll
-                for (int step = 0; step < 4; step++) {
-                    const int ahi = __builtin_amdgcn_sbfe((int)cur, 4 * step, 1) & 0x3ff00000;
-                    const double a = __hiloint2double(ahi, 0);
-                    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bv0[step], acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bv1[step], acc1, 0, 0, 0);
-                }
+                for (int st = 0; st < 4; st++) bv[st] = nx[st];
             }
         }
-        // D[row = lk + 4*reg][col = li]; col 2c = sum of C.mu (den), col 2c+1 = sum of r ln(C.mu) (tot).  The 128 pairs of a
-        // fragment are two per lane: the even column's lane finishes rows lk, lk+4 (it gets tot from its odd neighbour), the
-        // odd column's lane rows lk+8, lk+12 (it gets den from its even neighbour) -- every lane evaluates two logarithms.
-        const int odd = li & 1;
+        // D[row = lk + 4 reg][col = li]: acc0 = sum of C.mu (den), acc1 = sum of r ln(C.mu) (tot) of mask s0 + row, candidate li
+        const int b = b0 + li;
 #pragma unroll
-        for (int f = 0; f < 2; f++) {
-            const mfma_d4 acc = f ? acc1 : acc0;
-            const int c = (li >> 1) + 8 * f, b = b0 + c;
-            const double x0 = __shfl_xor(odd ? acc[0] : acc[2], 1, WAVE);
-            const double x1 = __shfl_xor(odd ? acc[1] : acc[3], 1, WAVE);
-#pragma unroll
-            for (int j = 0; j < 2; j++) {
-                const int reg = odd ? 2 + j : j;
-                const double own = odd ? (j ? acc[3] : acc[2]) : (j ? acc[1] : acc[0]);
-                const double got = j ? x1 : x0;
-                const double den = odd ? got : own, tot = odd ? own : got;
-                const int s = s0 + lk + 4 * reg;
-                if (s < S && b < B) {
-                    bool poison = false;
-                    if (any_zrow) {
-                        const unsigned long long *mp = mask + (size_t)s * words;
-                        for (int q = 0; q < words; q++) {
-                            unsigned long long live_bits = (q == words - 1 && (m & 63)) ? ((1ull << (m & 63)) - 1ull) : ~0ull;
-                            if (~mp[q] & zrow[c][q] & live_bits) poison = true;
-                        }
+        for (int reg = 0; reg < 4; reg++) {
+            const int s = s0 + lk + 4 * reg;
+            if (s < S && b < B) {
+                bool poison = false;
+                if (any_zrow) {
+                    const unsigned long long *mp = mask + (size_t)s * words;
+                    for (int q = 0; q < words; q++) {
+                        unsigned long long live_bits = (q == words - 1 && (m & 63)) ? ((1ull << (m & 63)) - 1ull) : ~0ull;
+                        if (~mp[q] & zrow[li][q] & live_bits) poison = true;
                     }
-                    nll[(size_t)b * S + s] = poison ? __builtin_nan("") : -(tot - rsum[s] * smx_log(den));
                 }
+                nll[(size_t)b * S + s] = poison ? __builtin_nan("") : -(acc1[reg] - rsum[s] * smx_log(acc0[reg], tab));
             }
         }
     }
@@ -538,7 +555,7 @@ __global__ __launch_bounds__(64 * SMX_WAVES) void score_masked_mfma_kernel(int n
 // pays three wave reductions for every candidate; here a block stages its 256 candidates in LDS with coalesced 4-byte loads
 // (m (n-1) bytes each -- the algorithmic HBM traffic, plus 8 n bytes of mu in and 8 bytes out) and every thread walks its own
 // candidate's rows: two byte reads, the row's C.mu, one logarithm (smx_log) and two FMAs per interval.  Bound: the FP64
-// logarithm (~35 instructions per interval), not HBM.  NLL = -(sum r ln(C.mu) - sum r ln(sum C.mu)).
+// logarithm (~15 instructions per interval), not HBM.  NLL = -(sum r ln(C.mu) - sum r ln(sum C.mu)).
 // ------------------------------------------------------------------------------------------------
 extern __shared__ unsigned int spc_lds[];
 template <int NC>
@@ -549,6 +566,8 @@ __global__ __launch_bounds__(256) void score_plain_kernel(int m, int tau, int B,
     const long long b0 = (long long)blockIdx.x * 256;
     const int nb = (int)((long long)B - b0 < 256 ? (long long)B - b0 : 256);
     const unsigned int *src = (const unsigned int *)(C + (size_t)b0 * cb);
+    const double2 *const tab = (const double2 *)(spc_lds + ((256 * pw + 3) & ~3));    // (16-byte aligned)
+    smx_log_stage((double2 *)tab);
     for (int idx = threadIdx.x; idx < nb * cw; idx += 256) {
         const int cand = idx / cw, within = idx - cand * cw;
         spc_lds[cand * pw + within] = src[idx];
@@ -564,9 +583,9 @@ __global__ __launch_bounds__(256) void score_plain_kernel(int m, int tau, int B,
         const double x = (double)row[i * NC], y = (NC == 2) ? (double)row[i * NC + 1] : 0.0;
         const double cm = w[i] * __builtin_fma(x, m1, __builtin_fma(y, m2, m0));
         den += cm;
-        tot = __builtin_fma(r[i], smx_log(cm), tot);
+        tot = __builtin_fma(r[i], smx_log(cm, tab), tot);
     }
-    nll[b] = -(tot - rsum * smx_log(den));
+    nll[b] = -(tot - rsum * smx_log(den, tab));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -600,13 +619,23 @@ void batch_launch_score_masked(int n, int m, int tau, int B, int S, const unsign
                                double *rsum_scratch, hipStream_t st, double rsum_host, bool rsum_host_valid) {
     if (mask != nullptr && S >= 16 && rsum_scratch != nullptr) {   // enough masks to fill the 16-row MFMA tiles
         hipLaunchKernelGGL(mask_rsum_kernel, dim3(S), dim3(64), 0, st, m, S, r, mask, rsum_scratch);
-        const size_t lds = ((size_t)((m + 15) & ~15) * 32 + SMX_CAND * 4) * sizeof(double);
+        const size_t xa = (size_t)m * 256 + SMX_TAB_BYTES, xb = (size_t)((m + 15) & ~15) * 256;
+        const size_t lds = (xa > xb ? xa : xb) + SMX_CAND * 4 * sizeof(unsigned long long);
         // (set on every launch: the attribute belongs to the current device's copy of the kernel, and costs nothing)
-        (void)hipFuncSetAttribute((const void *)score_masked_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(score_masked_mfma_kernel, dim3((B + SMX_CAND - 1) / SMX_CAND), dim3(64 * SMX_WAVES), lds, st, n, m,
-                           tau, B, S, C, w, r, mu, mask, rsum_scratch, nll);
+        const dim3 grid((B + SMX_CAND - 1) / SMX_CAND), block(64 * SMX_WAVES);
+        // (the attribute is set on every launch: it belongs to the current device's copy of the kernel, and costs nothing)
+#define SMX_LAUNCH(NG)                                                                                                            \
+    case NG:                                                                                                                      \
+        (void)hipFuncSetAttribute((const void *)score_masked_mfma_kernel<NG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL(score_masked_mfma_kernel<NG>, grid, block, lds, st, n, m, tau, B, S, C, w, r, mu, mask, rsum_scratch, nll); \
+        break;
+        switch ((m + 15) / 16) {
+            SMX_LAUNCH(1) SMX_LAUNCH(2) SMX_LAUNCH(3) SMX_LAUNCH(4) SMX_LAUNCH(5) SMX_LAUNCH(6) SMX_LAUNCH(7) SMX_LAUNCH(8)
+            SMX_LAUNCH(9) SMX_LAUNCH(10) SMX_LAUNCH(11) SMX_LAUNCH(12) SMX_LAUNCH(13) SMX_LAUNCH(14) SMX_LAUNCH(15) SMX_LAUNCH(16)
+        }
+#undef SMX_LAUNCH
     } else if (mask == nullptr && S == 1 && ((m * (n - 1)) & 3) == 0 && rsum_scratch != nullptr && rsum_host_valid) {
-        const size_t lds = (size_t)256 * (((m * (n - 1)) >> 2) | 1) * 4;
+        const size_t lds = (((size_t)256 * (((m * (n - 1)) >> 2) | 1) + 3) & ~(size_t)3) * 4 + SMX_TAB_BYTES;
         const unsigned blocks = (unsigned)(((long long)B + 255) / 256);
         if (n == 2) {
             (void)hipFuncSetAttribute((const void *)score_plain_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
