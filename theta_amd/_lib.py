@@ -292,19 +292,21 @@ def default_context():
 
 
 class _Merged:
-    """Running merge of the pieces of one Problem.search call (finalists, n=3 suspects and all-zero-column entries, stats)."""
+    """Running merge of the pieces of one Problem.search call (finalists, n=3 suspects and all-zero-column entries, stats).
+    Every entry remembers the index of its piece: the lists come out in piece order whatever the order of the add() calls
+    (a piece that had to be searched a second time is added last)."""
     SUMMED = ("evaluated", "accepted", "degenerate", "iterations", "terms", "list_overflow", "flops", "flops_f32", "dismissed",
               "survivors", "fallback_candidates", "kernel_ms", "setup_ms")
 
     def __init__(self, n, m):
         self.n, self.m = n, m
-        self.nll, self.mu, self.C, self.rank = np.zeros(0), np.zeros((0, n)), None, []
-        self.srk, self.slb, self.sC = [], np.zeros(0), np.zeros((0, m, 2), np.uint8)
-        self.drk, self.dC = [], np.zeros((0, m, 2), np.uint8)
+        self.nll, self.mu, self.C, self.rank, self.pi = np.zeros(0), np.zeros((0, n)), None, [], np.zeros(0, np.int64)
+        self.srk, self.slb, self.sC, self.spi = [], np.zeros(0), np.zeros((0, m, 2), np.uint8), np.zeros(0, np.int64)
+        self.drk, self.dC, self.dpi = [], np.zeros((0, m, 2), np.uint8), np.zeros(0, np.int64)
         self.stats = None
         self.since_prune = 0
 
-    def add(self, part, running, window):
+    def add(self, part, piece, running, window):
         res, sus, _dropped, deg = part
         if self.stats is None:
             self.stats = dict(res["stats"])
@@ -318,19 +320,23 @@ class _Merged:
                     self.stats[k] = min(self.stats[k], v)
                 elif k == "rejected_bound" and v < self.stats[k]:
                     self.stats[k], self.stats["rejected_rank"] = v, res["stats"]["rejected_rank"]
-        if len(res["nll"]):
+        k = len(res["nll"])
+        if k:
             self.nll = np.concatenate([self.nll, res["nll"]])
             self.mu = np.concatenate([self.mu, res["mu"]])
             self.C = res["C"] if self.C is None else np.concatenate([self.C, res["C"]])
             self.rank += list(res["rank"])
+            self.pi = np.concatenate([self.pi, np.full(k, piece, np.int64)])
         if self.n == 3:
             if len(sus[0]):
                 self.srk += list(sus[0])
                 self.slb = np.concatenate([self.slb, sus[1]])
                 self.sC = np.concatenate([self.sC, sus[2].reshape(-1, self.m, 2)])
+                self.spi = np.concatenate([self.spi, np.full(len(sus[0]), piece, np.int64)])
             if len(deg[0]):
                 self.drk += list(deg[0])
                 self.dC = np.concatenate([self.dC, deg[1].reshape(-1, self.m, 2)])
+                self.dpi = np.concatenate([self.dpi, np.full(len(deg[0]), piece, np.int64)])
         self.since_prune += 1
         if self.since_prune >= 64:                       # long walks: drop what the minimum so far has already ruled out
             self.prune(running, window)
@@ -339,22 +345,22 @@ class _Merged:
         self.since_prune = 0
         if len(self.nll):
             keep = ~(self.nll > gmin + window)           # (NaN never arrives here: the device lists hold finite values)
-            self.nll, self.mu, self.C = self.nll[keep], self.mu[keep], self.C[keep]
+            self.nll, self.mu, self.C, self.pi = self.nll[keep], self.mu[keep], self.C[keep], self.pi[keep]
             self.rank = [r for r, k in zip(self.rank, keep) if k]
         if len(self.slb):
             ks = np.nonzero(self.slb <= gmin + window)[0]
-            self.srk, self.slb, self.sC = [self.srk[i] for i in ks], self.slb[ks], self.sC[ks]
+            self.srk, self.slb, self.sC, self.spi = [self.srk[i] for i in ks], self.slb[ks], self.sC[ks], self.spi[ks]
 
     def result(self, window):
         gmin = float(self.nll.min()) if len(self.nll) else float("inf")
         self.prune(gmin, window)
-        if self.n == 3:
-            suspects = (self.srk, self.slb, self.sC)
-            degenerate = (self.drk, self.dC)
-        else:
-            suspects, degenerate = ([], np.zeros(0), None), ([], None)
-        Cc = self.C if self.C is not None else np.zeros((0, self.m) if self.n == 2 else (0, self.m, 2), np.uint8)
-        return {"nll": self.nll, "mu": self.mu, "rank": self.rank, "C": Cc, "stats": self.stats}, suspects, degenerate
+        o = np.argsort(self.pi, kind="stable")
+        Cc = self.C[o] if self.C is not None else np.zeros((0, self.m) if self.n == 2 else (0, self.m, 2), np.uint8)
+        out = {"nll": self.nll[o], "mu": self.mu[o], "rank": [self.rank[i] for i in o], "C": Cc, "stats": self.stats}
+        if self.n != 3:
+            return out, ([], np.zeros(0), None), ([], None)
+        so, do = np.argsort(self.spi, kind="stable"), np.argsort(self.dpi, kind="stable")
+        return out, ([self.srk[i] for i in so], self.slb[so], self.sC[so]), ([self.drk[i] for i in do], self.dC[do])
 
 
 class Problem:
@@ -442,8 +448,8 @@ class Problem:
         # The pieces are walked in order and merged as they come: what is kept between pieces is what can still matter
         # (finalists and suspects within `window` of the minimum so far, the all-zero-column list), not one entry per piece.
         acc = _Merged(self.n, self.m)
-        redo = []                                        # pieces whose device suspect list overflowed: (b, e, hint used)
-        b = begin
+        redo = []                                        # pieces whose device suspect list overflowed: (index, b, e, hint used)
+        b, piece = begin, 0
         while b < end:
             e = min(b + step, end)
             part = self._piece(b, e, window, cap, running)           # later pieces start from the minimum found so far
@@ -452,12 +458,12 @@ class Problem:
             if len(nl):
                 running = min(running, float(nl.min()))
             if part[2] > 0:
-                redo.append((b, e, hint_used, part[2]))              # (its lists are incomplete: searched again below)
+                redo.append((piece, b, e, hint_used, part[2]))       # (its lists are incomplete: searched again below)
             else:
-                acc.add(part, running, window)
-            b = e
+                acc.add(part, piece, running, window)
+            b, piece = e, piece + 1
         self.suspect_reruns = 0
-        for b, e, hint_used, dropped in redo:
+        for piece, b, e, hint_used, dropped in redo:
             if not running < hint_used:
                 raise ThetaError(ERR_CAPACITY, "n=3 suspect list overflowed in ranks [%d, %d) (%d entries dropped) although "
                                  "the search started from the range's own minimum" % (b, e, dropped))
@@ -466,7 +472,7 @@ class Problem:
             if part[2] > 0:
                 raise ThetaError(ERR_CAPACITY, "n=3 suspect list overflowed in ranks [%d, %d) (%d entries dropped) with "
                                  "the minimum of the whole range as hint" % (b, e, part[2]))
-            acc.add(part, running, window)
+            acc.add(part, piece, running, window)
         self.suspects_dropped = 0
         out, self.last_suspects, self.last_degenerate = acc.result(window)
         return out
