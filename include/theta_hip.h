@@ -107,6 +107,11 @@ typedef struct theta_search_stats {
  * Misc.py:36-47, on this list).  nll/mu come from the fused arithmetic (group-aggregated sums);
  * use theta_solve_batch on the returned C for values in the reference's own summation order.
  *
+ * One call takes at most 2^31 candidates at n=3 (2^40 at n=2; THETA_ERR_ARG beyond): a longer range is walked in
+ * pieces by the caller, each piece started from the minimum found so far (theta_problem_hint) and the pieces' lists merged
+ * within `window` of the overall minimum -- theta_amd.Problem.search does exactly that, one piece at a time, and refuses
+ * ranges of more than 2^25 pieces (THETA_ERR_OVERFLOW): a 70-interval space with bounds [0, 2] holds 2.5e34 matrices.
+ *
  *   cap        capacity (records) of the output arrays
  *   nll[cap], mu[cap*n], rank[cap*2], C[cap*m*(n-1)]
  *   n_out      number of records written (or needed, with THETA_ERR_CAPACITY)
@@ -122,7 +127,7 @@ int theta_search(theta_problem *p, const uint64_t rank_begin[2], const uint64_t 
  * such a candidate -- at nu = (1/3,1/3,1/3), where its BFGS fallback stalls (Optimizer.py:150-160, 255-265) -- so
  * feed C to theta_solve_batch (ok = 2 entries carry that value) and let the ones within the window join the
  * finalists; theta_boundary_min bounds what an off-path scipy run could report instead.  rank[cap*2],
- * lbound[cap] (lower bound of the NLL), C[cap*m*(n-1)].  n_out = number available; the device list holds 65 536, call with cap = -1
+ * lbound[cap] (lower bound of the NLL), C[cap*m*(n-1)].  n_out = number available; the device list holds 2^20, call with cap = -1
  * to learn how many more were dropped (a range whose own minimum is poor can have millions: pass a hint, below).
  */
 int theta_search_suspects(theta_problem *p, int cap, uint64_t *rank, double *lbound, uint8_t *C, int *n_out);
