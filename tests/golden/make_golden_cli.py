@@ -10,6 +10,9 @@ Runs the reference (converted 2->3 outside the repo, see make_golden.py) as a su
     selection); prefix syn14d.  (With --NUM_PROCESSES 8 the reference lists the two tied n=2 solutions in the other order
     -- find_mins concatenates the workers' lists, RunTHetA.py:107-122 -- so its n=3 stage starts from different bounds.
     The GPU driver mirrors the single-process order.)
+  * the same file through the two-stage pipeline with -k 3 --NUM_INTERVALS 9 (prefix syn14s; n=3 stage: 7 intervals, 3 576 matrices): small enough for the
+    CPU oracle, so that tests/test_host_cli_cpu.py can drive the command line over the stand-in device without a GPU
+    (`--only-small` regenerates just this one);
 and copies the resulting .withBounds / .results files (and the synthetic inputs) to tests/golden/cli/.
 """
 import os
@@ -73,7 +76,11 @@ def main():
     write_intervals(syn, 77, 14)
     # (bounds given in the file + --NO_INTERVAL_SELECTION reach the reference's Enumerator as strings, which
     #  neither Python 2 nor 3 survives for n=3 -- Enumerator.py:254 -- so there is no n=3 CLI golden)
-    run([syn, "-n", "2", "-k", "3", "-d", tmp, "-p", "syn14"], tmp)
+    run([syn, "-k", "3", "--NUM_INTERVALS", "9", "-d", tmp, "-p", "syn14s", "--FORCE"], tmp)
+    if "--only-small" in sys.argv:
+        sys.argv += ["--skip-n3", "--skip-example"]
+    else:
+        run([syn, "-n", "2", "-k", "3", "-d", tmp, "-p", "syn14"], tmp)
     if "--skip-n3" not in sys.argv:
         run([syn, "-k", "3", "-d", tmp, "-p", "syn14d", "--FORCE"], tmp)
     if "--skip-example" not in sys.argv:
