@@ -125,3 +125,70 @@ def test_exchange_three_ranks_keeps_nan_records():
     # the replay appends the NaN record to the list it finds (RunTHetA.py:198-201 with Misc.py:44-46)
     nl = [b[0] for b in b0]
     assert nl[:3] == [5000.0, 5000.0003, 4999.9998] and len(nl) == 4 and nl[3] != nl[3]
+
+
+# ---------------------------------------------------------------------------------------------------
+# the sharded DRIVER end to end: do_optimization_distributed over the stand-in device (tests/standin_device.py: every
+# candidate through the CPU oracle) and the library's host transport -- rank-range sharding, the probe-minimum all-reduce,
+# theta_exchange_finalists, the tie replay -- against the oracle's port of the reference's single-process driver
+# ---------------------------------------------------------------------------------------------------
+def _driver_worker(rank, world, port, inst, q):
+    try:
+        for pth in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+            sys.path.insert(0, pth)
+        import warnings
+        warnings.simplefilter("ignore")
+        import theta_amd
+        import campaign as cp
+        import standin_device as sd
+        from theta_amd import _lib, search as S
+        ctx = sd.StandinContext()
+        made = []
+
+        def make(c, *a, **k):
+            made.append(sd.StandinProblem(c, *a, **k))
+            return made[-1]
+        _lib.Problem = make
+        comm = theta_amd.Comm(None, rank=rank, world=world, addr="127.0.0.1", port=port, transport="host")
+        best = S.do_optimization_distributed(inst["n"], inst["m"], inst["k"], inst["tau"], inst["lb"], inst["ub"], inst["r"], inst["rN"],
+                                             inst["mx"], inst["order"], comm, ctx=ctx)
+        ncoll = comm.info()["collectives"]
+        comm.close()
+        lo, hi = made[-1].count * rank // world, made[-1].count * (rank + 1) // world
+        searched = [(b, e) for b, e, _ in made[-1].search_calls]
+        q.put((rank, cp.best_to_plain(best), (lo, hi), searched, ncoll))
+    except BaseException as e:
+        q.put((rank, "error: %r" % (e,), None, None, None))
+
+
+@pytest.mark.parametrize("n,seed,world", [(2, 9512, 2), (3, 10044, 2), (3, 10010, 3)])
+def test_sharded_driver_over_the_standin_device_equals_the_reference_driver(n, seed, world):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import warnings
+    import campaign
+    import theta_oracle as orc
+    inst = campaign.instance(seed, n, "toy")
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ref, cnt = orc.search_single(n, inst["m"], inst["tau"], list(inst["lb"]), list(inst["ub"]), inst["r"], inst["rN"], inst["mx"],
+                                     inst["order"])
+    ref = campaign.best_to_plain(ref)
+    assert ref and 40 <= cnt <= 2000
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_driver_worker, args=(rk, world, port, inst, q)) for rk in range(world)]
+    for p in procs:
+        p.start()
+    out = {}
+    for _ in range(world):
+        item = q.get(timeout=600)
+        out[item[0]] = item[1:]
+    for p in procs:
+        p.join(30)
+    for rk in range(world):
+        best, shard, searched, ncoll = out[rk]
+        assert not isinstance(best, str), best
+        assert campaign.compare_best(best, ref) == "", (rk, seed)                  # every rank returns the reference's list
+        assert searched and searched[0][0] == shard[0] and searched[-1][1] == shard[1]      # and searched only its own ranks
+        assert ncoll >= 2                                                            # the hint all-reduce and the exchange

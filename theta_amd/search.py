@@ -385,6 +385,10 @@ def do_optimization_distributed(n, m, k, tau, lower_bounds, upper_bounds, r, rN,
     except _lib.NoCandidates:
         print("Error: No valid Copy Number Profiles exist for these intervals within the bounds specified. Exiting...")
         sys.exit(1)
+    except _lib.ThetaError as e:
+        if e.code in (_lib.ERR_OVERFLOW, _lib.ERR_ARG):      # (the same on every rank: all of them leave here)
+            _friendly_exit(e)
+        raise
     merged, gmin = comm.exchange_finalists(n, m, recs, COLLECT_WINDOW)
     q1 = _q1_record(ctx, n, m, tau, r, rN, max_normal) if n == 3 else None
     best = replay_ties(merged, n, tau, sorted_index, first_duplicate=(n == 2), report=rep, q1_first=q1)
