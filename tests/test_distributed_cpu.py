@@ -2,7 +2,8 @@
 The N>1 path on CPU: two (and three) processes call the library's OWN exchange -- theta_comm_create +
 theta_exchange_finalists (theta_amd/csrc/comm.hip, the C entry points a sharded search uses) -- over its host transport
 (the TCP star that also bootstraps RCCL), then replay the tie rule on the merged list.  The per-shard finalists are
-synthetic here (no GPU in this container); on the GPU box the same entry points run over RCCL (tests/test_gpu_comm.py).
+synthetic in the first tests (no GPU in this container); on the GPU box the same entry points run over RCCL
+(tests/test_gpu_zz_comm.py).  The last test runs the sharded DRIVER end to end over a stand-in device.
 No torch anywhere in this path.
 """
 import multiprocessing as mp
