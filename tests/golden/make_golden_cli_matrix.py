@@ -1,0 +1,66 @@
+#!/usr/bin/env python3
+"""
+Golden outputs of the reference's command line over a MATRIX OF FLAGS -- data only.
+
+Every case runs the reference (converted 2->3 outside the repo, see make_golden.py / make_golden_cli.py) on the seeded
+14-interval synthetic file tests/golden/cli/syn14.intervals with one flag combination, small enough for the CPU oracle to
+follow (a few hundred n=2 matrices, a few thousand n=3 matrices), and stores the text of every output file it wrote
+(.withBounds, .results, .likelihoods, .BEST.results) in tests/golden/cli_matrix.json:
+    {case: {"args": [...], "rc": exit code, "files": {suffix: text}}}
+tests/test_host_cli_cpu.py replays the same command lines over the stand-in device and compares.
+"""
+import json
+import os
+import subprocess
+import sys
+import tempfile
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import make_golden  # noqa
+import make_golden_cli  # noqa
+
+SYN = os.path.join(HERE, "cli", "syn14.intervals")
+N2RES = os.path.join(HERE, "cli", "syn14s.n2.results")        # (the n=2 result the two-stage golden starts its n=3 stage from)
+N2BOUNDS = os.path.join(HERE, "cli", "syn14s.n2.withBounds")
+
+CASES = {
+    "n2_select9": [SYN, "-n", "2", "-k", "3", "--NUM_INTERVALS", "9"],
+    "n2_k4_maxnormal": [SYN, "-n", "2", "-k", "4", "--NUM_INTERVALS", "8", "-m", "0.6"],
+    "n2_bound_heuristic": [SYN, "-n", "2", "-k", "3", "--BOUND_HEURISTIC", "0.3"],
+    "n2_normal_bound_heuristic": [SYN, "-n", "2", "-k", "3", "--NORMAL_BOUND_HEURISTIC", "2", "--HEURISTIC_LB", "0.8", "--HEURISTIC_UB", "1.2"],
+    "n2_no_selection": [SYN, "-n", "2", "-k", "3", "--NO_INTERVAL_SELECTION"],
+    "n2_get_values": [SYN, "-n", "2", "-k", "3", "--NUM_INTERVALS", "9", "--GET_VALUES"],
+    "n2_bounds_only": [SYN, "-n", "2", "-k", "3", "--BOUNDS_ONLY"],
+    "n2_tau3": [SYN, "-n", "2", "-k", "4", "-t", "3", "--NUM_INTERVALS", "8"],
+    "n3_from_results": [N2BOUNDS, "-n", "3", "-k", "3", "--NUM_INTERVALS", "7", "--FORCE", "--RESULTS", N2RES],
+    "n3_no_multi_event": [N2BOUNDS, "-n", "3", "-k", "3", "--NUM_INTERVALS", "7", "--FORCE", "--RESULTS", N2RES, "--NO_MULTI_EVENT"],
+    "n3_get_values": [N2BOUNDS, "-n", "3", "-k", "2", "--NUM_INTERVALS", "6", "--FORCE", "--RESULTS", N2RES, "--GET_VALUES"],
+    "n3_without_results_file": [N2BOUNDS, "-n", "3", "-k", "3", "--NUM_INTERVALS", "7", "--FORCE"],
+}
+
+
+def main():
+    make_golden.import_reference()
+    out = {}
+    for name, args in CASES.items():
+        tmp = tempfile.mkdtemp(prefix="theta_clim_")
+        launcher = os.path.join(tmp, "_launch.py")
+        with open(launcher, "w") as f:
+            f.write(make_golden_cli.LAUNCH)
+        p = subprocess.run([sys.executable, launcher] + args + ["-d", tmp, "-p", "c"], cwd=tmp, stdout=subprocess.PIPE,
+                           stderr=subprocess.PIPE, text=True)
+        files = {}
+        for fn in sorted(os.listdir(tmp)):
+            if fn.startswith("c.") and (fn.endswith(".results") or fn.endswith(".withBounds") or fn.endswith(".likelihoods")):
+                files[fn[2:]] = open(os.path.join(tmp, fn)).read()
+        rel = [a.replace(HERE + os.sep, "") for a in args]
+        out[name] = {"args": rel, "rc": p.returncode, "files": files,
+                     "stdout_tail": [l for l in p.stdout.splitlines() if l.startswith("ERROR") or l.startswith("WARNING")][-3:]}
+        print(name, p.returncode, sorted(files), file=sys.stderr)
+    with open(os.path.join(HERE, "cli_matrix.json"), "w") as f:
+        json.dump(out, f, indent=1)
+
+
+if __name__ == "__main__":
+    main()

@@ -191,6 +191,15 @@ class StandinProblem(_lib.Problem):
         running, self._hint = self._hint, float("inf")
         return running
 
+    def values(self, begin, count):
+        """theta_search_values: per-candidate (nll, mu) of the fused solve, NaN where the candidate is rejected."""
+        nll, mu = np.full(count, np.nan), np.full((count, self.n), np.nan)
+        for i in range(count):
+            out, m_, v = self._entry(begin + i)
+            if out == 1:
+                nll[i], mu[i] = v, m_
+        return nll, mu, dict(STATS0)
+
     def enumerate(self, begin, count):
         shape = (count, self.m) if self.n == 2 else (count, self.m, 2)
         return np.array(self.cands[begin:begin + count], np.uint8).reshape(shape)

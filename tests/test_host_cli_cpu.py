@@ -57,3 +57,52 @@ def test_cli_two_stage_pipeline_over_the_standin_device_writes_the_reference_fil
         _compare_results(tmp_path / ("s.%s.results" % kind), os.path.join(CLI, "syn14s.%s.results" % kind))
     _compare_results(tmp_path / "s.BEST.results", os.path.join(CLI, "syn14s.BEST.results"))
     assert [(p.n, p.m, p.count) for p in standin] == [(2, 9, 105)] * 2 + [(3, 7, 3576)] * 2
+
+
+# ---------------------------------------------------------------------------------------------------
+# a matrix of flags: every case of tests/golden/cli_matrix.json (written by the reference's own command line,
+# tests/golden/make_golden_cli_matrix.py) replayed over the stand-in device
+# ---------------------------------------------------------------------------------------------------
+def _matrix():
+    import json
+    with open(os.path.join(GOLD, "cli_matrix.json")) as f:
+        return json.load(f)
+
+
+def _rows(text):
+    return [[x.strip() for x in l.split("\t")] for l in text.splitlines() if l and not l.startswith("#")]
+
+
+def _compare_likelihoods(mine, ref):
+    a, b = _rows(mine), _rows(ref)
+    assert len(a) == len(b)
+    for x, y in zip(a, b):
+        assert x[0] == y[0]                                                  # the copy-number digits, in enumeration order
+        for u, v in zip(x[1:], y[1:]):
+            fu, fv = float(u), float(v)
+            assert (fu != fu and fv != fv) or abs(fu - fv) <= 1e-6 * max(abs(fv), 1e-300) or abs(fu - fv) < 1e-9, (x, y)
+
+
+@pytest.mark.parametrize("case", sorted(_matrix().keys()))
+def test_cli_flag_matrix_over_the_standin_device(standin, tmp_path, case):
+    gold = _matrix()[case]
+    argv = [os.path.join(GOLD, a) if a.startswith("cli" + os.sep) else a for a in gold["args"]] + ["-p", "c"]
+    rc = 0
+    try:
+        _run(argv, tmp_path)
+    except SystemExit as e:
+        rc = e.code if isinstance(e.code, int) else (0 if e.code is None else 1)
+    assert rc == gold["rc"]
+    written = sorted(f[2:] for f in os.listdir(tmp_path)
+                     if f.startswith("c.") and (f.endswith(".results") or f.endswith(".withBounds") or f.endswith(".likelihoods")))
+    assert written == sorted(gold["files"].keys())
+    for suffix, text in gold["files"].items():
+        mine = open(tmp_path / ("c." + suffix)).read()
+        if suffix.endswith(".withBounds"):
+            assert _rows(mine) == _rows(text)
+        elif suffix.endswith(".results"):
+            ref_path = tmp_path / ("ref." + suffix)
+            ref_path.write_text(text)
+            _compare_results(tmp_path / ("c." + suffix), ref_path)
+        else:
+            _compare_likelihoods(mine, text)

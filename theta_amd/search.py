@@ -245,9 +245,13 @@ def _q1_record(ctx, n, m, tau, r, rN, max_normal=1.0):
     return {"rank": -1, "c": c0[0], "mu": mu[0].copy(), "nll": float(nll[0]), "vals": vals[0].copy()}
 
 
-def _dump_values(problem, n, m):
-    """--GET_VALUES (RunTHetA.py:210-215): '<C column 1 as digits>\\t<mu0>\\t<NLL>' per accepted candidate."""
+def _dump_values(problem, n, m, q1=None):
+    """--GET_VALUES (RunTHetA.py:210-215): '<C column 1 as digits> TAB <mu0> TAB <NLL>' per accepted candidate, in the order
+    the reference evaluates them -- quirk Q1 included: its first matrix (RunTHetA.py:188) is the first candidate once more
+    for n=2 (that line appears twice) and the [tau,0,0] matrix for n=3 (`q1`: a line of m zeros with M3's residue as mu0)."""
     with open(pre + ".likelihoods", "w") as f:
+        if q1 is not None:
+            f.write("0" * m + "\t" + str(float(q1["mu"][0])) + "\t" + str(float(q1["nll"])) + "\n")
         step = 1 << 16
         for b in range(0, problem.count, step):
             cnt = min(step, problem.count - b)
@@ -263,7 +267,8 @@ def _dump_values(problem, n, m):
             col = C if n == 2 else C[:, :, 0]
             for i in range(cnt):
                 if rep[i]:        # (a NaN likelihood of a reported n=3 tuple is written as 'nan', like the reference does)
-                    f.write("".join(str(int(v)) for v in col[i]) + "\t" + str(float(mu[i, 0])) + "\t" + str(float(nll[i])) + "\n")
+                    line = "".join(str(int(v)) for v in col[i]) + "\t" + str(float(mu[i, 0])) + "\t" + str(float(nll[i])) + "\n"
+                    f.write(line * 2 if (n == 2 and b + i == 0) else line)
 
 
 def _search_local(n, m, tau, lower_bounds, upper_bounds, r, rN, max_normal, shard=(0, 1), ctx=None, report=None, hint_exchange=None):
@@ -340,7 +345,7 @@ def do_optimization_single(n, m, k, tau, lower_bounds, upper_bounds, r, rN, max_
     q1 = _q1_record(ctx, n, m, tau, r, rN, max_normal) if n == 3 else None
     best = replay_ties(recs, n, tau, sorted_index, first_duplicate=(n == 2), report=rep, q1_first=q1)
     if get_values:
-        _dump_values(problem, n, m)
+        _dump_values(problem, n, m, q1)
     rep.stats = stats
     rep.candidates = problem.count
     rep.finalists = len(recs)
