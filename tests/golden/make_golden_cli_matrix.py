@@ -36,6 +36,12 @@ CASES = {
     "n3_from_results": [N2BOUNDS, "-n", "3", "-k", "3", "--NUM_INTERVALS", "7", "--FORCE", "--RESULTS", N2RES],
     "n3_no_multi_event": [N2BOUNDS, "-n", "3", "-k", "3", "--NUM_INTERVALS", "7", "--FORCE", "--RESULTS", N2RES, "--NO_MULTI_EVENT"],
     "n3_get_values": [N2BOUNDS, "-n", "3", "-k", "2", "--NUM_INTERVALS", "6", "--FORCE", "--RESULTS", N2RES, "--GET_VALUES"],
+    "n2_min_frac_exit": [SYN, "-n", "2", "-k", "3", "--MIN_FRAC", "0.9"],
+    "n2_ratio_dev": [SYN, "-n", "2", "-k", "3", "--NUM_INTERVALS", "9", "--RATIO_DEV", "0.3", "--MIN_FRAC", "0.2"],
+    # (no n=2 case on a file WITH bounds columns: the reference reads them as strings and dies in Enumerator.py:136 with a
+    #  TypeError -- `self.iter[i] += 1` on a str -- after writing its bounds file; theta_amd converts them and runs)
+    "n3_k4_six_intervals": [N2BOUNDS, "-n", "3", "-k", "4", "--NUM_INTERVALS", "6", "--FORCE", "--RESULTS", N2RES],
+    "n3_maxnormal_ignored": [N2BOUNDS, "-n", "3", "-k", "3", "--NUM_INTERVALS", "6", "--FORCE", "--RESULTS", N2RES, "-m", "0.5"],
     "n3_without_results_file": [N2BOUNDS, "-n", "3", "-k", "3", "--NUM_INTERVALS", "7", "--FORCE"],
 }
 
