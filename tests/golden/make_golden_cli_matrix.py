@@ -24,6 +24,34 @@ SYN = os.path.join(HERE, "cli", "syn14.intervals")
 N2RES = os.path.join(HERE, "cli", "syn14s.n2.results")        # (the n=2 result the two-stage golden starts its n=3 stage from)
 N2BOUNDS = os.path.join(HERE, "cli", "syn14s.n2.withBounds")
 
+def write_odd_intervals(path):
+    """20 intervals with the rows interval selection has rules for: two shorter than 1 Mb, one shorter than 5 Mb, one without
+    tumour reads, one without normal reads, one amplified beyond (k+1)/2, equal lengths (the stable sort decides)."""
+    import numpy as np
+    rng = np.random.RandomState(2020)
+    m = 20
+    L = rng.randint(6_000_000, 20_000_000, m)
+    L[3], L[11], L[15] = 400_000, 900_000, 3_000_000
+    L[6] = L[7] = 9_000_000
+    rN = rng.poisson(L * 0.01)
+    c = rng.randint(0, 4, m)
+    c[9] = 7
+    mu = 0.4
+    p = rN * (2 * mu + c * (1 - mu))
+    p = p / p.sum()
+    r = rng.multinomial(int(rN.sum() * 1.1), p)
+    r[13] = 0
+    rN[17] = 0
+    with open(path, "w") as f:
+        f.write("#ID\tchrm\tstart\tend\ttumorCount\tnormalCount\n")
+        pos = 1
+        for i in range(m):
+            f.write("%d\t%d\t%d\t%d\t%d\t%d\n" % (i + 1, 1 + i // 7, pos, pos + L[i], r[i], rN[i]))
+            pos += L[i] + 1
+
+
+ODD = os.path.join(HERE, "cli", "odd20.intervals")
+
 CASES = {
     "n2_select9": [SYN, "-n", "2", "-k", "3", "--NUM_INTERVALS", "9"],
     "n2_k4_maxnormal": [SYN, "-n", "2", "-k", "4", "--NUM_INTERVALS", "8", "-m", "0.6"],
@@ -42,12 +70,16 @@ CASES = {
     #  TypeError -- `self.iter[i] += 1` on a str -- after writing its bounds file; theta_amd converts them and runs)
     "n3_k4_six_intervals": [N2BOUNDS, "-n", "3", "-k", "4", "--NUM_INTERVALS", "6", "--FORCE", "--RESULTS", N2RES],
     "n3_maxnormal_ignored": [N2BOUNDS, "-n", "3", "-k", "3", "--NUM_INTERVALS", "6", "--FORCE", "--RESULTS", N2RES, "-m", "0.5"],
+    "odd_n2_select10": [ODD, "-n", "2", "-k", "3", "--NUM_INTERVALS", "10"],
+    "odd_n2_select12_k4": [ODD, "-n", "2", "-k", "4", "--NUM_INTERVALS", "12"],
+    "odd_two_stage": [ODD, "-k", "3", "--NUM_INTERVALS", "7", "--FORCE"],
     "n3_without_results_file": [N2BOUNDS, "-n", "3", "-k", "3", "--NUM_INTERVALS", "7", "--FORCE"],
 }
 
 
 def main():
     make_golden.import_reference()
+    write_odd_intervals(ODD)
     out = {}
     for name, args in CASES.items():
         tmp = tempfile.mkdtemp(prefix="theta_clim_")
