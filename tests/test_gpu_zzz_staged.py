@@ -77,3 +77,24 @@ def test_get_values_dump_line_for_line(tmp_path, n, m, k):
         assert col == wcol
         assert (float(nll) != float(nll) and wnll != wnll) or abs(float(nll) - wnll) <= 1e-6 * abs(wnll)
         assert abs(float(mu0) - wmu0) < 1e-6 or (float(mu0) != float(mu0) and wmu0 != wmu0)
+
+
+@pytest.mark.parametrize("m,k", [(50, 6), (100, 5), (25, 5), (7, 3), (64, 9), (130, 2)])
+def test_n2_render_generator_equals_the_lane_stream_generator(monkeypatch, m, k):
+    """THETA_N2_ENUM_RENDER=1 (n2_enumerate_render_kernel: records by scatter + prefix sum, verified lane by lane on the CPU in
+    tests/test_n2_render_cpu.py) against the one-stream-per-lane kernel, whole ranges and ragged sub-ranges."""
+    import theta_amd
+    ctx = theta_amd.default_context()
+    p = theta_amd.Problem(ctx, 2, m, 2, [1] * m, [1] * m, [0] * m, [k] * m)
+    cnt = int(min(p.count, 3_000_000))
+    for b, c in ((0, cnt), (p.count // 3, min(cnt, 1_000_001)), (max(0, p.count - 777_777), min(p.count, 777_777))):
+        if c < 1:
+            continue
+        monkeypatch.setenv("THETA_N2_ENUM_LEGACY", "1")
+        old = p.enumerate(b, c)
+        monkeypatch.delenv("THETA_N2_ENUM_LEGACY")
+        monkeypatch.setenv("THETA_N2_ENUM_RENDER", "1")
+        new = p.enumerate(b, c)
+        monkeypatch.delenv("THETA_N2_ENUM_RENDER")
+        assert np.array_equal(new, old), (m, k, b, c)
+    p.close()

@@ -73,52 +73,7 @@ int n2_build_host(int m, const int32_t *lb_in, const int32_t *ub_in, N2Host &h) 
 // ------------------------------------------------------------------------------------------------
 // device
 // ------------------------------------------------------------------------------------------------
-template <int KV>
-struct N2Cand {
-    int s[KV + 1];  // s[v] = first position with c >= v; s[KV] = m
-};
-
-// Rank -> break-points (colex order: c_{m-1} is the most significant digit).
-template <int KV>
-__device__ void n2_unrank(const N2Dev &P, const unsigned long long *Pl, unsigned long long rho, N2Cand<KV> &c) {
-#pragma unroll
-    for (int v = 0; v <= KV; v++) c.s[v] = P.m;
-    c.s[0] = 0;
-    for (int i = P.m - 1; i >= 0; i--) {
-        const unsigned long long *row = Pl + i * N2_KVS;
-        int v = 0;
-        while (v < KV - 1 && row[v] <= rho) v++;  // smallest v with P[i][v] > rho
-        if (v > 0) rho -= row[v - 1];
-#pragma unroll
-        for (int w = 1; w < KV; w++)
-            if (w <= v) c.s[w] = i;  // c_i >= w, and i decreases, so the last write is the first position
-    }
-}
-
-// The reference's successor (Enumerator.py:134-152) on the break-point form. Returns false at the end.
-template <int KV>
-__device__ bool n2_next(const N2Dev &P, const unsigned char *ubl, const short *lbposl, N2Cand<KV> &c) {
-    int e = -1, nv = 0;
-#pragma unroll
-    for (int v = 0; v < KV; v++) {
-        if (e < 0 && c.s[v + 1] > c.s[v]) {  // first run not yet handled
-            int end = c.s[v + 1] - 1;
-            if (v < (int)ubl[end]) {
-                e = end;
-                nv = v + 1;
-            } else if (end == P.m - 1) {
-                return false;  // last run cannot be raised: enumeration exhausted
-            }
-        }
-    }
-    if (e < 0) return false;
-#pragma unroll
-    for (int w = 1; w < KV; w++) {
-        int lp = lbposl[w];
-        c.s[w] = (lp < e) ? lp : ((w <= nv) ? e : c.s[w]);
-    }
-    return true;
-}
+#include "n2_cand.hpp"
 
 struct N2Result {
     bool ok, degenerate, exact;
@@ -524,6 +479,49 @@ __global__ __launch_bounds__(256) void n2_enumerate_lines_kernel(N2Dev P, unsign
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The whole-line generator with the records RENDERED by scatter + prefix sum (n2_render.hpp) instead of summed break-point by
+// break-point into every word.  Same run / tile / store scheme as n2_enumerate_lines_kernel.  Selected with
+// THETA_N2_ENUM_RENDER=1 (off by default in round 2: its per-lane logic is verified on the CPU -- tools/n2_render_emul.hip runs
+// this very code lane by lane against the oracle's enumeration, tests/test_n2_render_cpu.py -- but it has not been on the GPU).
+// ------------------------------------------------------------------------------------------------
+#include "n2_render.hpp"
+template <int KV>
+__global__ __launch_bounds__(256) void n2_enumerate_render_kernel(N2Dev P, unsigned long long begin, unsigned long long count, int T,
+                                                                  unsigned char *out) {
+    extern __shared__ unsigned char smem[];
+    unsigned long long *Pl = (unsigned long long *)smem;
+    short *lbposl = (short *)(Pl + (size_t)P.m * N2_KVS);
+    unsigned char *ubl = (unsigned char *)(lbposl + (N2_KVS + 1) + 3);
+    unsigned *tile = (unsigned *)(smem + (((size_t)P.m * N2_KVS * 8 + (N2_KVS + 1 + 3) * 2 + P.m + 15) & ~(size_t)15)) +
+                     (threadIdx.x >> 6) * (WAVE * N2L_STRIDE);
+    for (int i = threadIdx.x; i < P.m * N2_KVS; i += blockDim.x) Pl[i] = P.P[i];
+    for (int i = threadIdx.x; i <= N2_KVS; i += blockDim.x) lbposl[i] = P.lbpos[i];
+    for (int i = threadIdx.x; i < P.m; i += blockDim.x) ubl[i] = P.ub[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, m = P.m;
+    const unsigned long long tid = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned long long wave_first = tid - lane;
+    const unsigned long long k0 = tid * (unsigned long long)T;
+    const int lines = (int)(((unsigned long long)T * m) >> 7);
+    const unsigned long long mine = k0 < count ? (count - k0 < (unsigned long long)T ? count - k0 : (unsigned long long)T) : 0;
+    N2Run<KV> R;
+    n2r_begin<KV>(R, mine);
+    if (mine) n2_unrank<KV>(P, Pl, begin + k0, R.c);
+    else {
+#pragma unroll
+        for (int v = 0; v <= KV; v++) R.c.s[v] = m;
+    }
+    unsigned *row = tile + lane * N2L_STRIDE;
+    for (int line = 0; line < lines; line++) {
+        n2r_scatter_line<KV>(P, ubl, lbposl, R, row);
+        n2r_prefix_line(row);
+        wave_lds_sync();
+        n2r_store_line(lane, wave_first, line, T, m, count, tile, out);
+        wave_lds_sync();
+    }
+}
+
 // Candidates for an explicit list of ranks (tie-list materialisation).
 template <int KV>
 __global__ __launch_bounds__(64) void n2_unrank_list_kernel(N2Dev P, const TieRecord *recs, int count, unsigned char *out) {
@@ -577,6 +575,16 @@ void n2_launch_enumerate(const N2Dev &P, unsigned long long begin, unsigned long
             const unsigned blocks = (unsigned)((threads + 255) / 256);
             const size_t base = (((size_t)P.m * N2_KVS * 8 + (N2_KVS + 1 + 3) * 2 + P.m + 15) & ~(size_t)15);
             const size_t sm2 = base + (size_t)4 * WAVE * N2L_STRIDE * 4;
+            if (const char *e = getenv("THETA_N2_ENUM_RENDER"); e && atoi(e) > 0) {
+                if (P.kv <= 8) {
+                    (void)hipFuncSetAttribute((const void *)n2_enumerate_render_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm2);
+                    hipLaunchKernelGGL(n2_enumerate_render_kernel<8>, dim3(blocks), dim3(256), sm2, st, P, begin, count, T, out);
+                } else {
+                    (void)hipFuncSetAttribute((const void *)n2_enumerate_render_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm2);
+                    hipLaunchKernelGGL(n2_enumerate_render_kernel<16>, dim3(blocks), dim3(256), sm2, st, P, begin, count, T, out);
+                }
+                return;
+            }
             if (P.kv <= 8) {
                 (void)hipFuncSetAttribute((const void *)n2_enumerate_lines_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm2);
                 hipLaunchKernelGGL(n2_enumerate_lines_kernel<8>, dim3(blocks), dim3(256), sm2, st, P, begin, count, T, out);

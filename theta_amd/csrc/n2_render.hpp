@@ -1,0 +1,134 @@
+// n = 2 materialised generator, "render" form: a lane's run of records is produced 128 bytes (one output line) at a time by
+// SCATTER + PREFIX SUM instead of summing all break-points into every word.
+//
+// A record is a staircase: byte i = number of break-points s[v] (v = 1..KV-1, non-decreasing in v) at or before i.  The bytes
+// of consecutive records of a run, laid end to end, are therefore the running sum of a sparse increment string: +1 at every
+// break-point, and minus the record's last value where the next record begins.  Per line a lane
+//   1. zeroes its 128-byte row of the per-wave LDS tile,
+//   2. writes the increments of the records that intersect the line -- one byte store per DISTINCT position (equal positions
+//      are merged in registers: break-points come sorted; increments that fall before the line collapse onto its byte 0,
+//      which is what carries a record over a line boundary),
+//   3. turns the row into running sums, word by word (two shift-adds inside the word, the previous word's top byte carried in).
+//      The sums are taken MOD 16 in every byte (mask 0x0f0f0f0f after each add): copy numbers are at most 15, so the low nibble
+//      is the value itself, a "minus last" increment is stored as (16 - last) & 15, and no add can carry from one byte into
+//      its neighbour (plain 32-bit adds of 0xff-style negative bytes would).
+// Cost: ~7 vector instructions per break-point and ~7 per word, against one pass over ALL break-points per word (35
+// instructions per word at KV = 8) in n2_enumerate_lines_kernel.  The record boundaries inside a line are the same for all
+// lanes of a wave (equal run lengths, runs start on line boundaries), so the control flow is wave-uniform; only positions and
+// store predicates differ between lanes.
+//
+// Everything here is host + device (N2_HD): tools/n2_render_emul.hip executes the same code lane by lane on the CPU.
+#pragma once
+#include "n2_cand.hpp"
+
+#define N2R_LINE 128       // bytes per output line
+#define N2R_WORDS 32       // dwords of payload per LDS row
+
+template <int KV>
+struct N2Run {
+    N2Cand<KV> c;                 // current record
+    unsigned long long left;      // records still to produce, the current one included (0: the run is exhausted)
+    int recstart;                 // byte offset of the current record's first byte relative to the current line (<= 0 .. 127)
+    int reset;                    // increment pending at the current record's first byte: minus the previous record's last value
+};
+
+template <int KV>
+N2_HD inline void n2r_begin(N2Run<KV> &R, unsigned long long records) {
+    R.left = records;
+    R.recstart = 0;
+    R.reset = 0;
+}
+
+// the record after the current one (a run that ends early -- the last run of the range, or the end of the enumeration --
+// continues with "null" records: no break-points, so its bytes come out as zeros; they are never stored)
+template <int KV>
+N2_HD inline void n2r_advance(const N2Dev &P, const unsigned char *ubl, const short *lbposl, N2Run<KV> &R) {
+    if (R.left > 0) {
+        R.left--;
+        if (R.left > 0 && !n2_next<KV>(P, ubl, lbposl, R.c)) R.left = 0;
+    }
+}
+
+// Steps 1 and 2 for one line.  `row` is the lane's row of the tile (N2R_WORDS dwords, 16-byte aligned).
+template <int KV>
+N2_HD inline void n2r_scatter_line(const N2Dev &P, const unsigned char *ubl, const short *lbposl, N2Run<KV> &R, unsigned *row) {
+    const int m = P.m;
+#pragma unroll
+    for (int w = 0; w < N2R_WORDS; w++) row[w] = 0u;
+    unsigned char *bytes = (unsigned char *)row;
+    while (R.recstart < N2R_LINE) {                              // (uniform: recstart and m are the same in every lane)
+        const bool live = R.left > 0;
+        int curpos = R.recstart > 0 ? R.recstart : 0;
+        int cnt = R.recstart >= 0 ? R.reset : 0;                  // (a record that began before this line: its reset is behind us)
+        int last = 0;                                             // the record's last value: break-points inside the record
+#pragma unroll
+        for (int v = 1; v < KV; v++) {
+            const int sv = R.c.s[v];
+            const bool inrec = live && sv < m;
+            last += inrec ? 1 : 0;
+            int p = R.recstart + sv;
+            p = p < 0 ? 0 : p;
+            const bool act = inrec && p < N2R_LINE;
+            const bool same = !act || p == curpos;
+            if (!same) bytes[curpos] = (unsigned char)(cnt & 15); // (predicated byte store: positions are visited in order)
+            cnt = same ? cnt + (act ? 1 : 0) : 1;
+            curpos = same ? curpos : p;
+        }
+        bytes[curpos] = (unsigned char)(cnt & 15);
+        const int e = R.recstart + m;
+        if (e > N2R_LINE) break;                                  // the record continues in the next line
+        n2r_advance<KV>(P, ubl, lbposl, R);
+        R.recstart = e;                                           // (e == 128: the next record opens the next line)
+        R.reset = -last;
+    }
+    // next line: positions are relative to it; a record that opens it exactly needs no reset (nothing is carried over a line)
+    R.recstart -= N2R_LINE;
+    if (R.recstart == 0) R.reset = 0;
+}
+
+// Step 3: running sums (mod 16 per byte) over the row.
+N2_HD inline void n2r_prefix_line(unsigned *row) {
+    unsigned carry = 0u;
+#pragma unroll
+    for (int w = 0; w < N2R_WORDS; w++) {
+        unsigned x = row[w];                                      // every byte <= 15
+        x = (x + (x << 8)) & 0x0f0f0f0fu;
+        x = (x + (x << 16)) & 0x0f0f0f0fu;
+        x = (x + carry * 0x01010101u) & 0x0f0f0f0fu;
+        row[w] = x;
+        carry = x >> 24;
+    }
+}
+
+// Store stage of one line (after every lane of the wave has finished steps 1-3 and the tile is visible): lane (r8, ch) of
+// pass `sidx` moves the 16-byte chunk `ch` of row r = r8 + 8 sidx -- one store instruction of the wave = 8 complete 128-byte
+// lines.  `tile` is the wave's tile (64 rows of N2L_STRIDE dwords), wave_first the global index of the wave's first thread.
+#ifndef N2L_STRIDE
+#define N2L_STRIDE 36      // dwords per LDS row (128 bytes of payload + 16 of padding: spreads the rows over the banks)
+#endif
+struct n2r_u4 {
+    unsigned x, y, z, w;
+};
+N2_HD inline void n2r_store_line(int lane, unsigned long long wave_first, int line, int T, int m, unsigned long long count,
+                                 const unsigned *tile, unsigned char *out) {
+    const unsigned long long RB = (unsigned long long)T * (unsigned long long)m;       // bytes per run, a multiple of 128
+#pragma unroll
+    for (int sidx = 0; sidx < 8; sidx++) {
+        const int r = (lane >> 3) + 8 * sidx, ch = lane & 7;
+        const unsigned long long tt = wave_first + (unsigned long long)r;
+        const unsigned long long kk = tt * (unsigned long long)T;
+        if (kk < count) {
+            const unsigned long long nv = (count - kk < (unsigned long long)T ? count - kk : (unsigned long long)T) * (unsigned long long)m;
+            const unsigned long long off = ((unsigned long long)line << 7) + (unsigned long long)ch * 16;
+            if (off < nv) {
+                const unsigned *src = tile + r * N2L_STRIDE + 4 * ch;
+                unsigned char *dst = out + tt * RB + off;
+                if (off + 16 <= nv) {
+                    *(n2r_u4 *)dst = *(const n2r_u4 *)src;
+                } else {                                         // the tail of the very last record
+                    for (int bidx = 0; bidx < (int)(nv - off); bidx++) dst[bidx] = (unsigned char)(src[bidx >> 2] >> (8 * (bidx & 3)));
+                }
+            }
+        }
+    }
+}
