@@ -73,6 +73,13 @@ CASES = {
     "odd_n2_select10": [ODD, "-n", "2", "-k", "3", "--NUM_INTERVALS", "10"],
     "odd_n2_select12_k4": [ODD, "-n", "2", "-k", "4", "--NUM_INTERVALS", "12"],
     "odd_two_stage": [ODD, "-k", "3", "--NUM_INTERVALS", "7", "--FORCE"],
+    "example_n2_select8": [os.path.join(HERE, "cli", "Example.intervals"), "-n", "2", "-k", "3", "--NUM_INTERVALS", "8"],
+    "example_two_stage_select7": [os.path.join(HERE, "cli", "Example.intervals"), "-k", "2", "--NUM_INTERVALS", "7", "--FORCE"],
+    "n2_k6_select7": [SYN, "-n", "2", "-k", "6", "--NUM_INTERVALS", "7"],
+    "n2_maxnormal_03": [SYN, "-n", "2", "-k", "3", "--NUM_INTERVALS", "9", "-m", "0.3"],
+    "n2_two_processes": [SYN, "-n", "2", "-k", "4", "--NUM_INTERVALS", "8", "-m", "0.6", "--NUM_PROCESSES", "2"],
+    "two_stage_tau3": [SYN, "-k", "3", "-t", "3", "--NUM_INTERVALS", "8", "--FORCE"],
+    "n3_k4_five_intervals": [N2BOUNDS, "-n", "3", "-k", "4", "--NUM_INTERVALS", "5", "--FORCE", "--RESULTS", N2RES],
     "n3_without_results_file": [N2BOUNDS, "-n", "3", "-k", "3", "--NUM_INTERVALS", "7", "--FORCE"],
 }
 
