@@ -382,33 +382,7 @@ __global__ __launch_bounds__(256) void score_masked_kernel(int n, int m, int tau
 // ------------------------------------------------------------------------------------------------
 typedef double mfma_d4 __attribute__((ext_vector_type(4)));
 
-// ln(x) for the scorers below (one per (candidate, interval) and one per (candidate, mask) pair), table-driven:
-// x = 2^k m, m in [1, 2); entry j = top 7 mantissa bits holds inv_c ~ 1 / (1 + (j + 1/2)/128) and log_c = -ln(inv_c) of
-// that very double (tools/gen_log_table.py, 60-digit arithmetic), so ln x = k ln 2 + log_c + log1p(f) with
-// f = m inv_c - 1 from ONE fma, |f| <= 2^-8, and log1p by its series to f^6 (next term < 2e-18).  Absolute error
-// ~2e-16; 15 vector instructions and one 16-byte LDS read, against ~35 for the fdlibm reduction used before and ~90
-// for the library call.  Anything that is not a positive normal number goes to the library.
-__device__ const unsigned long long smx_log_table[256] = {
-#include "smx_log_table.inc"
-};
-#define SMX_TAB_BYTES 2048
-__device__ __forceinline__ void smx_log_stage(double2 *tab) {
-    for (int i = threadIdx.x; i < 128; i += blockDim.x) tab[i] = ((const double2 *)smx_log_table)[i];
-}
-__device__ __forceinline__ double smx_log(double x, const double2 *tab) {
-    const int hx = __double2hiint(x);
-    if ((unsigned)(hx - 0x00100000) >= 0x7fe00000u) return log(x);
-    const double2 e = tab[(hx >> 13) & 0x7f];
-    const double mnt = __hiloint2double((hx & 0x000fffff) | 0x3ff00000, __double2loint(x));
-    const double f = __builtin_fma(mnt, e.x, -1.0);
-    const double dk = (double)((hx >> 20) - 1023);
-    double p = __builtin_fma(f, -1.0 / 6.0, 0.2);
-    p = __builtin_fma(f, p, -0.25);
-    p = __builtin_fma(f, p, 1.0 / 3.0);
-    p = __builtin_fma(f, p, -0.5);
-    p = __builtin_fma(f, p, 1.0);
-    return __builtin_fma(f, p, __builtin_fma(dk, 6.931471805599453094e-01, e.y));
-}
+#include "smx_log.hpp"
 #define SMX_CAND 16
 #define SMX_WAVES 8
 #define SMX_MAXM 256
