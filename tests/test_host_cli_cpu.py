@@ -126,3 +126,10 @@ def test_cli_flag_matrix_over_the_standin_device(standin, tmp_path, case):
             _compare_results_nan_aware(tmp_path / ("c." + suffix), ref_path)
         else:
             _compare_likelihoods(mine, text)
+
+
+def test_calc_all_c_variants_over_the_standin_device(standin):
+    """calc_all_c_2 / _3 / _3_multi_event (CalcAllC.py:92-328) on the reference's own inputs and outputs
+    (tests/golden/calc_all_c.json): the GPU test's check, with the literal scorer of the stand-in device."""
+    from test_gpu_cli import test_calc_all_c_variants_match_reference_vectors as check
+    check()
