@@ -513,11 +513,13 @@ __global__ __launch_bounds__(256) void n2_enumerate_render_kernel(N2Dev P, unsig
         for (int v = 0; v <= KV; v++) R.c.s[v] = m;
     }
     unsigned *row = tile + lane * N2L_STRIDE;
+    N2RStore S;
+    n2r_store_prepare(lane, wave_first, T, m, count, out, S);
     for (int line = 0; line < lines; line++) {
         n2r_scatter_line<KV>(P, ubl, lbposl, R, row);
         n2r_prefix_line(row);
         wave_lds_sync();
-        n2r_store_line(lane, wave_first, line, T, m, count, tile, out);
+        n2r_store_line(lane, line, S, tile);
         wave_lds_sync();
     }
 }

@@ -109,25 +109,36 @@ N2_HD inline void n2r_prefix_line(unsigned *row) {
 struct n2r_u4 {
     unsigned x, y, z, w;
 };
-N2_HD inline void n2r_store_line(int lane, unsigned long long wave_first, int line, int T, int m, unsigned long long count,
-                                 const unsigned *tile, unsigned char *out) {
+// what a lane needs for its eight stores of every line, computed once per run: where row r = (lane >> 3) + 8 sidx of the tile
+// goes (chunk ch = lane & 7 included) and how many bytes of that row's run exist (0: the row's run lies beyond the range)
+struct N2RStore {
+    unsigned char *dst[8];
+    unsigned nv[8];
+};
+N2_HD inline void n2r_store_prepare(int lane, unsigned long long wave_first, int T, int m, unsigned long long count, unsigned char *out,
+                                    N2RStore &S) {
     const unsigned long long RB = (unsigned long long)T * (unsigned long long)m;       // bytes per run, a multiple of 128
 #pragma unroll
     for (int sidx = 0; sidx < 8; sidx++) {
         const int r = (lane >> 3) + 8 * sidx, ch = lane & 7;
         const unsigned long long tt = wave_first + (unsigned long long)r;
         const unsigned long long kk = tt * (unsigned long long)T;
-        if (kk < count) {
-            const unsigned long long nv = (count - kk < (unsigned long long)T ? count - kk : (unsigned long long)T) * (unsigned long long)m;
-            const unsigned long long off = ((unsigned long long)line << 7) + (unsigned long long)ch * 16;
-            if (off < nv) {
-                const unsigned *src = tile + r * N2L_STRIDE + 4 * ch;
-                unsigned char *dst = out + tt * RB + off;
-                if (off + 16 <= nv) {
-                    *(n2r_u4 *)dst = *(const n2r_u4 *)src;
-                } else {                                         // the tail of the very last record
-                    for (int bidx = 0; bidx < (int)(nv - off); bidx++) dst[bidx] = (unsigned char)(src[bidx >> 2] >> (8 * (bidx & 3)));
-                }
+        S.nv[sidx] = kk < count ? (unsigned)((count - kk < (unsigned long long)T ? count - kk : (unsigned long long)T) * (unsigned long long)m) : 0u;
+        S.dst[sidx] = out + tt * RB + (unsigned long long)ch * 16;
+    }
+}
+N2_HD inline void n2r_store_line(int lane, int line, const N2RStore &S, const unsigned *tile) {
+    const unsigned off = ((unsigned)line << 7) + (unsigned)(lane & 7) * 16u;             // byte offset of this lane's chunk in its row's run
+#pragma unroll
+    for (int sidx = 0; sidx < 8; sidx++) {
+        const unsigned nv = S.nv[sidx];
+        if (off < nv) {
+            const unsigned *src = tile + ((lane >> 3) + 8 * sidx) * N2L_STRIDE + 4 * (lane & 7);
+            unsigned char *dst = S.dst[sidx] + ((size_t)line << 7);
+            if (off + 16 <= nv) {
+                *(n2r_u4 *)dst = *(const n2r_u4 *)src;
+            } else {                                             // the tail of the very last record
+                for (int bidx = 0; bidx < (int)(nv - off); bidx++) dst[bidx] = (unsigned char)(src[bidx >> 2] >> (8 * (bidx & 3)));
             }
         }
     }

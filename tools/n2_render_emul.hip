@@ -16,6 +16,7 @@ static void emulate(const N2Dev &P, unsigned long long begin, unsigned long long
     const int lines = (int)(((unsigned long long)T * m) >> 7);
     std::vector<unsigned> tile((size_t)64 * N2L_STRIDE);
     std::vector<N2Run<KV>> R(64);
+    std::vector<N2RStore> S(64);
     for (unsigned long long w = 0; w < waves; w++) {
         const unsigned long long wave_first = w * 64;
         for (int lane = 0; lane < 64; lane++) {
@@ -25,6 +26,7 @@ static void emulate(const N2Dev &P, unsigned long long begin, unsigned long long
             if (mine) n2_unrank<KV>(P, P.P, begin + k0, R[lane].c);
             else
                 for (int v = 0; v <= KV; v++) R[lane].c.s[v] = m;
+            n2r_store_prepare(lane, wave_first, T, m, count, out, S[lane]);
         }
         for (int line = 0; line < lines; line++) {
             for (int lane = 0; lane < 64; lane++) {
@@ -32,7 +34,7 @@ static void emulate(const N2Dev &P, unsigned long long begin, unsigned long long
                 n2r_scatter_line<KV>(P, P.ub, P.lbpos, R[lane], row);
                 n2r_prefix_line(row);
             }
-            for (int lane = 0; lane < 64; lane++) n2r_store_line(lane, wave_first, line, T, m, count, tile.data(), out);
+            for (int lane = 0; lane < 64; lane++) n2r_store_line(lane, line, S[lane], tile.data());
         }
     }
 }
