@@ -42,7 +42,7 @@ def _newer(target, deps):
 
 
 def build(force=False, verbose=True):
-    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")]
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp") or f.endswith(".inc")]
     headers.append(os.path.join(os.path.dirname(HERE), "include", "theta_hip.h"))
     objs = []
     cc = hipcc()
