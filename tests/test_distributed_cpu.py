@@ -162,7 +162,7 @@ def _driver_worker(rank, world, port, inst, q):
         q.put((rank, "error: %r" % (e,), None, None, None))
 
 
-@pytest.mark.parametrize("n,seed,world", [(2, 9512, 2), (3, 10044, 2), (3, 10010, 3)])
+@pytest.mark.parametrize("n,seed,world", [(2, 9512, 2), (3, 10044, 2), (3, 10010, 3), (3, 10044, 8)])
 def test_sharded_driver_over_the_standin_device_equals_the_reference_driver(n, seed, world):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import warnings
