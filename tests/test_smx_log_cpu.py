@@ -80,3 +80,27 @@ def test_everything_else_goes_to_the_library(smx):
     got = smx(xs)
     for g, w in zip(got, want):
         assert (g != g and w != w) or g == w
+
+
+def test_power_of_two_row_scaling_of_the_masked_scorer_is_exact():
+    """score_masked_mfma_kernel feeds the mask bit of MFMA step st as the double whose high word is the single exponent bit
+    27 + st (2^-895, 2^-767, 2^-511, 2) and stores the rows that step consumes multiplied by the inverse power of two
+    (batch.hip): every product must be EXACTLY the unscaled term.  Checked here in IEEE double arithmetic over the magnitudes
+    row terms can take (|x| from 1e-300 to 2^126: C.mu of read counts up to 2^63, r ln(C.mu), M3's 1e-26 residues), for zeros,
+    infinities and NaN."""
+    import struct
+    a = [struct.unpack("<d", struct.pack("<Q", (1 << (27 + st)) << 32))[0] for st in range(4)]
+    assert a == [2.0 ** -895, 2.0 ** -767, 2.0 ** -511, 2.0]
+    ex = [895, 767, 511, -1]
+    rng = np.random.RandomState(3)
+    x = np.concatenate([np.exp(rng.uniform(np.log(1e-300), np.log(2.0 ** 126), 20000)) * rng.choice([-1.0, 1.0], 20000),
+                        rng.uniform(0, 1e7, 5000), -rng.uniform(0, 1e9, 5000), np.array([0.0, -0.0, 1e-26, 2.0 ** 126, -(2.0 ** 126)])])
+    with np.errstate(all="ignore"):
+        for st in range(4):
+            stored = np.ldexp(x, ex[st])
+            assert np.isfinite(stored).all()
+            assert np.array_equal(a[st] * stored, x)
+            for special in (np.inf, -np.inf):
+                assert a[st] * np.ldexp(special, ex[st]) == special
+            assert np.isnan(a[st] * np.ldexp(np.nan, ex[st]))
+            assert np.isnan(0.0 * np.ldexp(-np.inf, ex[st]))        # a masked row with ln 0: NaN, like log(0) * 0 in CalcAllC.L3 (Q10)
