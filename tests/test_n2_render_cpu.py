@@ -96,3 +96,26 @@ def test_other_run_lengths(emul, m, T):
     n = min(len(ref), 40000)
     got, _ = _emulate(emul, m, lb, ub, 3, n - 3, T)
     assert np.array_equal(got, ref[3:n])
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_ragged_bounds(emul, seed):
+    """Random per-interval bounds (not monotone as given: _check_bound_order adjusts them, Enumerator.py:90-113): both bound
+    tables of the successor (first position with lb >= w / ub >= w) at work."""
+    import itertools
+    rng = np.random.RandomState(100 + seed)
+    total = 0
+    while total == 0:                               # (ragged bounds often leave nothing: draw until the space is not empty)
+        m = int(rng.randint(5, 40))
+        lb = np.maximum.accumulate(rng.randint(0, 3, m)) - rng.randint(0, 2, m)      # mostly rising, with dips
+        lb = np.maximum(lb, 0)
+        ub = np.maximum.accumulate(lb) + rng.randint(0, 4, m)                          # above the adjusted lower bounds, ragged
+        total = orc.count_n2(m, lb.tolist(), ub.tolist())
+    n = int(min(total, 60000))
+    ref = np.array(list(itertools.islice(orc.enumerate_n2(m, 2, lb.tolist(), ub.tolist()), n)), np.uint8)
+    got, tot = _emulate(emul, m, lb.tolist(), ub.tolist(), 0, n)
+    assert tot == total and np.array_equal(got, ref)
+    if total > n:                                   # a range that does not start at rank 0
+        b = int(rng.randint(1, n - 1))
+        got, _ = _emulate(emul, m, lb.tolist(), ub.tolist(), b, n - b)
+        assert np.array_equal(got, ref[b:])

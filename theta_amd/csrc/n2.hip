@@ -499,6 +499,9 @@ __global__ __launch_bounds__(256) void n2_enumerate_render_kernel(N2Dev P, unsig
     for (int i = threadIdx.x; i <= N2_KVS; i += blockDim.x) lbposl[i] = P.lbpos[i];
     for (int i = threadIdx.x; i < P.m; i += blockDim.x) ubl[i] = P.ub[i];
     __syncthreads();
+    short *ubposl = (short *)(tile - (threadIdx.x >> 6) * (WAVE * N2L_STRIDE) + 4 * WAVE * N2L_STRIDE);   // behind the four tiles
+    if (threadIdx.x <= KV) ubposl[threadIdx.x] = n2r_ubpos(ubl, P.m, (int)threadIdx.x);
+    __syncthreads();
     const int lane = threadIdx.x & 63, m = P.m;
     const unsigned long long tid = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
     const unsigned long long wave_first = tid - lane;
@@ -516,7 +519,7 @@ __global__ __launch_bounds__(256) void n2_enumerate_render_kernel(N2Dev P, unsig
     N2RStore S;
     n2r_store_prepare(lane, wave_first, T, m, count, out, S);
     for (int line = 0; line < lines; line++) {
-        n2r_scatter_line<KV>(P, ubl, lbposl, R, row);
+        n2r_scatter_line<KV>(m, lbposl, ubposl, R, row);
         n2r_prefix_line(row);
         wave_lds_sync();
         n2r_store_line(lane, line, S, tile);
@@ -579,11 +582,11 @@ void n2_launch_enumerate(const N2Dev &P, unsigned long long begin, unsigned long
             const size_t sm2 = base + (size_t)4 * WAVE * N2L_STRIDE * 4;
             if (const char *e = getenv("THETA_N2_ENUM_RENDER"); e && atoi(e) > 0) {
                 if (P.kv <= 8) {
-                    (void)hipFuncSetAttribute((const void *)n2_enumerate_render_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm2);
-                    hipLaunchKernelGGL(n2_enumerate_render_kernel<8>, dim3(blocks), dim3(256), sm2, st, P, begin, count, T, out);
+                    (void)hipFuncSetAttribute((const void *)n2_enumerate_render_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sm2 + 64));
+                    hipLaunchKernelGGL(n2_enumerate_render_kernel<8>, dim3(blocks), dim3(256), sm2 + 64, st, P, begin, count, T, out);
                 } else {
-                    (void)hipFuncSetAttribute((const void *)n2_enumerate_render_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm2);
-                    hipLaunchKernelGGL(n2_enumerate_render_kernel<16>, dim3(blocks), dim3(256), sm2, st, P, begin, count, T, out);
+                    (void)hipFuncSetAttribute((const void *)n2_enumerate_render_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sm2 + 64));
+                    hipLaunchKernelGGL(n2_enumerate_render_kernel<16>, dim3(blocks), dim3(256), sm2 + 64, st, P, begin, count, T, out);
                 }
                 return;
             }

@@ -39,20 +39,58 @@ N2_HD inline void n2r_begin(N2Run<KV> &R, unsigned long long records) {
     R.reset = 0;
 }
 
+// The reference's successor (Enumerator.py:134-152; n2_next of n2_cand.hpp) with both bound tests on wave-uniform tables:
+//   lbp[w] = first position whose lower bound is >= w (m if none),  ubp[w] = first position whose upper bound is >= w (m if none).
+// Run v = [s[v], s[v+1]) can be raised at its end iff that end lies at or behind ubp[v+1] (the bounds are non-decreasing after
+// _check_bound_order), i.e. iff s[v+1] > max(s[v], ubp[v+1]) -- no per-lane bound reads; the first such run wins, and if there
+// is none the enumeration is exhausted (a blocked run ending at m-1 is the last one).  Then every break-point up to the raised
+// value moves to min(lbp[w], e).
+template <int KV>
+N2_HD inline bool n2r_next(const short *lbp, const short *ubp, N2Cand<KV> &c) {
+    int e = -1, nv = 0;
+    bool found = false;
+#pragma unroll
+    for (int v = 0; v < KV; v++) {
+        const int hi = c.s[v + 1], b = (int)ubp[v + 1];
+        const int lo = c.s[v] > b ? c.s[v] : b;
+        const bool take = hi > lo && !found;
+        e = take ? hi - 1 : e;
+        nv = take ? v + 1 : nv;
+        found = found || hi > lo;
+    }
+    if (!found) return false;
+#pragma unroll
+    for (int w = 1; w < KV; w++) {
+        const int lp = (int)lbp[w];
+        c.s[w] = w <= nv ? (lp < e ? lp : e) : c.s[w];
+    }
+    return true;
+}
+
+// ubp[0..KV] from the (non-decreasing) upper bounds: ubp[w] = number of positions whose bound is below w
+N2_HD inline short n2r_ubpos(const unsigned char *ub, int m, int w) {
+    int lo = 0, hi = m;                                           // first i with ub[i] >= w
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if ((int)ub[mid] >= w) hi = mid;
+        else lo = mid + 1;
+    }
+    return (short)lo;
+}
+
 // the record after the current one (a run that ends early -- the last run of the range, or the end of the enumeration --
 // continues with "null" records: no break-points, so its bytes come out as zeros; they are never stored)
 template <int KV>
-N2_HD inline void n2r_advance(const N2Dev &P, const unsigned char *ubl, const short *lbposl, N2Run<KV> &R) {
+N2_HD inline void n2r_advance(const short *lbp, const short *ubp, N2Run<KV> &R) {
     if (R.left > 0) {
         R.left--;
-        if (R.left > 0 && !n2_next<KV>(P, ubl, lbposl, R.c)) R.left = 0;
+        if (R.left > 0 && !n2r_next<KV>(lbp, ubp, R.c)) R.left = 0;
     }
 }
 
 // Steps 1 and 2 for one line.  `row` is the lane's row of the tile (N2R_WORDS dwords, 16-byte aligned).
 template <int KV>
-N2_HD inline void n2r_scatter_line(const N2Dev &P, const unsigned char *ubl, const short *lbposl, N2Run<KV> &R, unsigned *row) {
-    const int m = P.m;
+N2_HD inline void n2r_scatter_line(int m, const short *lbp, const short *ubp, N2Run<KV> &R, unsigned *row) {
 #pragma unroll
     for (int w = 0; w < N2R_WORDS; w++) row[w] = 0u;
     unsigned char *bytes = (unsigned char *)row;
@@ -77,7 +115,7 @@ N2_HD inline void n2r_scatter_line(const N2Dev &P, const unsigned char *ubl, con
         bytes[curpos] = (unsigned char)(cnt & 15);
         const int e = R.recstart + m;
         if (e > N2R_LINE) break;                                  // the record continues in the next line
-        n2r_advance<KV>(P, ubl, lbposl, R);
+        n2r_advance<KV>(lbp, ubp, R);
         R.recstart = e;                                           // (e == 128: the next record opens the next line)
         R.reset = -last;
     }

@@ -17,6 +17,8 @@ static void emulate(const N2Dev &P, unsigned long long begin, unsigned long long
     std::vector<unsigned> tile((size_t)64 * N2L_STRIDE);
     std::vector<N2Run<KV>> R(64);
     std::vector<N2RStore> S(64);
+    short ubp[KV + 1];
+    for (int w = 0; w <= KV; w++) ubp[w] = n2r_ubpos(P.ub, m, w);
     for (unsigned long long w = 0; w < waves; w++) {
         const unsigned long long wave_first = w * 64;
         for (int lane = 0; lane < 64; lane++) {
@@ -31,7 +33,7 @@ static void emulate(const N2Dev &P, unsigned long long begin, unsigned long long
         for (int line = 0; line < lines; line++) {
             for (int lane = 0; lane < 64; lane++) {
                 unsigned *row = tile.data() + (size_t)lane * N2L_STRIDE;
-                n2r_scatter_line<KV>(P, P.ub, P.lbpos, R[lane], row);
+                n2r_scatter_line<KV>(m, P.lbpos, ubp, R[lane], row);
                 n2r_prefix_line(row);
             }
             for (int lane = 0; lane < 64; lane++) n2r_store_line(lane, line, S[lane], tile.data());
