@@ -53,7 +53,7 @@ def test_cli_flag_matrix_on_the_gpu(tmp_path, case):
             _compare_likelihoods(mine, text)
 
 
-@pytest.mark.parametrize("n,m,k", [(2, 7, 3), (3, 7, 2)])
+@pytest.mark.parametrize("n,m,k", [(2, 7, 3), (3, 6, 2)])
 def test_get_values_dump_line_for_line(tmp_path, n, m, k):
     """RunTHetA.py:210-215 over the whole evaluation sequence of the reference driver (oracle trace), first matrix included."""
     import warnings
