@@ -28,9 +28,10 @@ def _matrix():
 
 
 @pytest.mark.parametrize("case", sorted(_matrix().keys()))
-def test_cli_flag_matrix_on_the_gpu(tmp_path, case):
+def test_cli_flag_matrix_on_the_gpu(tmp_path, monkeypatch, case):
     from theta_amd import RunTHetA
     gold = _matrix()[case]
+    monkeypatch.chdir(tmp_path)              # (like the reference, the --GET_VALUES dump is written to the working directory)
     argv = [os.path.join(GOLD, a) if a.startswith("cli" + os.sep) else a for a in gold["args"]] + ["-p", "c", "-d", str(tmp_path)]
     rc = 0
     try:

@@ -104,8 +104,9 @@ def _compare_likelihoods(mine, ref):
 
 
 @pytest.mark.parametrize("case", sorted(_matrix().keys()))
-def test_cli_flag_matrix_over_the_standin_device(standin, tmp_path, case):
+def test_cli_flag_matrix_over_the_standin_device(standin, tmp_path, monkeypatch, case):
     gold = _matrix()[case]
+    monkeypatch.chdir(tmp_path)              # (like the reference, the --GET_VALUES dump is written to the working directory)
     argv = [os.path.join(GOLD, a) if a.startswith("cli" + os.sep) else a for a in gold["args"]] + ["-p", "c"]
     rc = 0
     try:

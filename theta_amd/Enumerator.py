@@ -59,6 +59,16 @@ class Enumerator:
             C[:, 1:] = c
         return C
 
+    def get_graph(self):
+        """Enumerator.py:166-170, 272-298 (n=3; the reference's time estimate reads it): the row alphabet -- every (a, b) in
+        [0..k]^2 with (tau - a)(tau - b) >= 0, a fastest -- and for each row the rows that may follow it (the same row, or one
+        with a larger component)."""
+        if self.n != 2:
+            raise AttributeError("'Enumerator' object has no attribute 'rows'")      # (the reference builds the graph for n=3 only)
+        rows = [[a, b] for b in range(self.k + 1) for a in range(self.k + 1) if (self.tau - a) * (self.tau - b) >= 0]
+        edges = [[j for j, w in enumerate(rows) if (v == w or w[0] > v[0] or w[1] > v[1])] for v in rows]
+        return rows, edges
+
     def _C_to_array(self):
         """Enumerator.py:154-160 (for n=3 this is the [tau,0,0] matrix whatever the bounds, quirk Q1)."""
         C = numpy.zeros((self.m, self.n + 1))

@@ -31,7 +31,7 @@ def run_fixed_N(n, args, intervals, resultsfile=None):
      heuristic_ub, num_processes, bounds_only, multi_event, force, get_values, choose_intervals, num_intervals,
      read_depth_file, graph_format, runBAF, ratio_dev, min_frac, tumorfile, normalfile, noClustering) = args
     lengths, tumorCounts, normCounts, m, upper_bounds, lower_bounds = intervals
-    _search.pre = os.path.join(directory, prefix)
+    _search.pre = prefix          # RunTHetA.py:307-308: the --GET_VALUES dump goes to <prefix>.likelihoods in the WORKING directory, not -d
     if tumorfile is not None or normalfile is not None or runBAF:
         print("NOTE: SNP files / the BAF model / interval clustering are not part of this implementation; continuing without them.")
 

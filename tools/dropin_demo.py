@@ -6,7 +6,9 @@ two-line change the document describes.  No GPU here, so the library's Python su
 (tests/standin_device.py); on a GPU box the same two lines bind the HIP library.  The files the patched reference writes are
 compared with the files the unpatched reference wrote (tests/golden/cli/syn14s.*, tests/golden/cli_matrix.json).
 
-    python tools/dropin_demo.py        -> one line per command, "identical" or the difference
+    python tools/dropin_demo.py [--operators]       -> one line per command, "identical" or the difference
+With --operators it is section 2(b) instead: the reference's own driver loop keeps running, over theta_amd's Enumerator,
+Optimizer and CalcAllC.L2 / L3 classes.
 """
 import contextlib
 import io
@@ -54,20 +56,33 @@ def make(c, n, m, tau, r, rN, lb, ub, mx=1.0):
 _lib.Problem = make
 _lib.default_context = lambda: ctx
 
-# ---- the two lines of INTEGRATION.md 2(a) ------------------------------------------------------------------------------
-REF.do_optimization_single = S.do_optimization_single
-REF.do_optimization = S.do_optimization
-# ------------------------------------------------------------------------------------------------------------------------
+MODE = "operators" if "--operators" in sys.argv else "driver"
+if MODE == "driver":
+    # ---- the two lines of INTEGRATION.md 2(a) --------------------------------------------------------------------------
+    REF.do_optimization_single = S.do_optimization_single
+    REF.do_optimization = S.do_optimization
+else:
+    # ---- the reference's OWN driver loop (RunTHetA.py:173-220) over this repository's operator classes
+    import CalcAllC as REF_CALC
+    import TimeEstimate as REF_TIME
+    from theta_amd import CalcAllC as MY_CALC
+    from theta_amd.Enumerator import Enumerator as MyEnumerator
+    from theta_amd.Optimizer import Optimizer as MyOptimizer
+    REF.Enumerator = REF_TIME.Enumerator = MyEnumerator
+    REF.Optimizer = REF_TIME.Optimizer = MyOptimizer
+    REF_CALC.L2, REF_CALC.L3 = MY_CALC.L2, MY_CALC.L3
 
 GOLD = os.path.join(ROOT, "tests", "golden")
 matrix = json.load(open(os.path.join(GOLD, "cli_matrix.json")))
-cases = {k: v for k, v in matrix.items() if v["rc"] == 0 and "likelihoods" not in v["files"]}     # (--GET_VALUES writes from inside the replaced driver, via theta_amd.search.pre)
+cases = {k: v for k, v in matrix.items() if v["rc"] == 0}
+S.pre = "c"          # (driver mode: the replaced driver writes the --GET_VALUES dump itself; the reference sets its own global, RunTHetA.py:307)
 bad = 0
 for name in sorted(cases):
     gold = cases[name]
     d = tempfile.mkdtemp(prefix="theta_dropin_")
     argv = [os.path.join(GOLD, a) if a.startswith("cli" + os.sep) else a for a in gold["args"]] + ["-p", "c", "-d", d]
     sys.argv = ["RunTHetA.py"] + argv
+    os.chdir(d)                               # (the reference writes its --GET_VALUES dump to the working directory)
     rc = 0
     try:
         with contextlib.redirect_stdout(io.StringIO()):
@@ -86,6 +101,8 @@ for name in sorted(cases):
         try:
             if suffix.endswith(".withBounds"):
                 assert T._rows(mine) == T._rows(text)
+            elif suffix == "likelihoods":
+                T._compare_likelihoods(mine, text)
             else:
                 ref_path = os.path.join(d, "ref." + suffix)
                 open(ref_path, "w").write(text)
@@ -94,4 +111,4 @@ for name in sorted(cases):
             why.append("%s differs %s" % (suffix, str(e)[:150]))
     bad += bool(why)
     print("%-28s %s" % (name, "identical (%s)" % ", ".join(sorted(gold["files"])) if not why else "DIFFERENT: " + "; ".join(why)), flush=True)
-print("%d of %d commands of the patched reference reproduce the unpatched reference's files" % (len(cases) - bad, len(cases)))
+print("[%s replaced] %d of %d commands of the patched reference reproduce the unpatched reference's files" % (MODE, len(cases) - bad, len(cases)))
