@@ -108,3 +108,16 @@ def test_get_values_dump_line_for_line_over_the_standin_device(standin, tmp_path
     staged GPU test (tests/test_gpu_zzz_staged.py) makes, here over the stand-in device."""
     from test_gpu_zzz_staged import test_get_values_dump_line_for_line as check
     check(tmp_path, n, m, k)
+
+
+def test_enumerator_mirror_exposes_the_row_graph(standin):
+    """Enumerator.get_graph() (Enumerator.py:166-170): the reference's time estimate walks it (TimeEstimate.py:124)."""
+    from theta_amd.Enumerator import Enumerator
+    for K, tau in ((2, 2), (3, 2), (4, 2), (3, 3)):
+        e = Enumerator(3, 4, K, tau, [0] * 4, [K] * 4)
+        rows, edges = e.get_graph()
+        want_rows, want_edges = orc.row_graph(K, tau)
+        assert [list(r) for r in rows] == [list(r) for r in want_rows]
+        assert [list(x) for x in edges] == [list(x) for x in want_edges]
+    with pytest.raises(AttributeError):
+        Enumerator(2, 4, 3, 2, [0] * 4, [3] * 4).get_graph()          # (the reference builds the graph for n=3 only)
