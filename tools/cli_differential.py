@@ -120,6 +120,7 @@ def main():
         crashed = "Traceback" in p.stderr
         rc = 0
         buf = io.StringIO()
+        os.chdir(dmine)                           # (like the reference, the --GET_VALUES dump goes to the working directory)
         try:
             with contextlib.redirect_stdout(buf):
                 RunTHetA.main(args + ["-d", dmine, "-p", "c"])
