@@ -1,5 +1,5 @@
 """
-The CPU half of tests/test_gpu_00_wide.py, runnable without a GPU: the instance generator for more than 64 intervals and the
+The CPU half of tests/test_gpu_wide.py, runnable without a GPU: the instance generator for more than 64 intervals and the
 oracle-side worker pool (start method `spawn`, as on the GPU box), on a short prefix of one instance.
 """
 import multiprocessing as mp
@@ -7,7 +7,7 @@ import multiprocessing as mp
 import numpy as np
 
 import theta_oracle as orc
-import test_gpu_00_wide as wide
+import test_gpu_wide as wide
 
 
 def test_wide_instance_and_spawned_oracle_pool():
