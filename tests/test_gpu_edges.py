@@ -249,39 +249,7 @@ def test_burst_generator_against_oracle_and_lane_private_generator(ctx, monkeypa
         p.close()
 
 
-def test_get_values_dump_matches_oracle_trace(ctx, tmp_path):
-    """--GET_VALUES (RunTHetA.py:210-215): one line per accepted candidate, in enumeration order, '<column 1>\\t<mu0>\\t<NLL>'."""
-    import theta_amd.search as S
-    rng = np.random.RandomState(31)
-    for n, m, k in ((2, 7, 3), (3, 7, 2)):
-        r, rN, L, Ct, mu = orc.synth_counts(m, n, k, 100 + n)
-        rs, rNs, order = orc.sort_r(rN, r)
-        lb, ub = [0] * m, [k] * m
-        S.pre = str(tmp_path / ("dump%d" % n))
-        S.do_optimization_single(n, m, k, 2, list(lb), list(ub), rs, rNs, 1.0, order, False, True)
-        lines = [l.rstrip("\n").split("\t") for l in open(S.pre + ".likelihoods")]
-        trace = []
-        orc.search_single(n, m, 2, lb, ub, rs, rNs, 1.0, order, trace=trace)
-        ref = {}
-        for Cm, soln in trace[1:]:                                   # (the first entry is the quirk-Q1 extra evaluation)
-            if soln is not None and soln[1] == soln[1]:
-                ref["".join(str(int(v)) for v in Cm[:, 1])] = ref.get("".join(str(int(v)) for v in Cm[:, 1]), []) + [soln]
-        got = {}
-        for col, mu0, nll in lines:
-            got.setdefault(col, []).append((float(mu0), float(nll)))
-        assert sum(len(v) for v in got.values()) >= 0.97 * sum(len(v) for v in ref.values())
-        agree = total = 0
-        for col, sols in ref.items():
-            if col not in got or len(got[col]) != len(sols):
-                continue
-            for (mu0, nll), s in zip(got[col], sols):
-                total += 1
-                agree += abs(nll - s[1]) <= 1e-6 * abs(s[1])
-        # (n=3: the dump holds column 1 only; matrices that share it are compared where the two sides hold the same number of
-        # them -- with the reference's outcome reproduced that is everywhere but at all-zero tumour columns)
-        assert total >= (0.9 if n == 2 else 0.95) * sum(len(v) for v in ref.values()), (n, total)
-        assert agree >= (1.0 if n == 2 else 0.99) * total, (n, agree, total)
-    S.pre = "theta"
+# (the --GET_VALUES dump is compared line for line, with no allowance, in tests/test_gpu_cli_matrix.py)
 
 
 def test_driver_exits_cleanly_when_the_search_is_beyond_the_library(ctx, capsys):

@@ -27,7 +27,7 @@ def test_hybrj_restatement_follows_scipy_fsolve_on_the_reference_table():
         b, ib, nb = hc.scipy_side(g["C"][k], r, rN)
         same_iterate += np.allclose(a, b, rtol=1e-9, atol=1e-12, equal_nan=True)
         same_class += hc.in_range(a) == hc.in_range(b)
-    assert same_class == len(idx) and same_iterate >= len(idx) - 2
+    assert same_class == len(idx) and same_iterate == len(idx)
     # ... and against the table itself: iterate in [0,1]^3 <=> the reference reported the candidate's own optimum
     C = g["C"].astype(float)
     B, m, _ = C.shape
@@ -45,7 +45,7 @@ def test_hybrj_restatement_follows_scipy_fsolve_on_the_reference_table():
             wrong += not inr
         elif ref_fb[k] or not acc[k]:
             wrong += inr
-    assert wrong <= 1
+    assert wrong == 0
 
 
 def test_reference_outcome_class_of_every_table_entry():
@@ -78,7 +78,11 @@ def test_reference_outcome_class_of_every_table_entry():
             counts[o] += 1
             wrong += o != ref[k]
     assert counts[0] == 284 and counts[2] >= 4460 and counts[1] >= 16280
-    assert wrong <= 2          # (one entry whose optimum IS the centre of the simplex carries the fallback value either way)
+    # (an entry whose optimum IS the centre of the simplex carries the fallback VALUE either way: the table cannot tell the two
+    # classes apart there, the value comparison of the next test can)
+    centre = [k for k in range(B) if ref[k] == 2 and hc.in_range(hc.mine(Cs[k], r, rN)[0]) and
+              np.allclose(hc.mine(Cs[k], r, rN)[0], 1.0 / 3.0, atol=1e-6)]
+    assert wrong == len(centre) <= 2
 
 
 def test_restated_procedure_reproduces_every_entry_of_the_reference_table():
@@ -125,3 +129,72 @@ def test_m3_restatement_follows_scipy_fsolve_without_jacobian():
         got = hc.m3(S, nu)[0]
         same += np.array_equal(got, ref) or (np.isnan(got) == np.isnan(ref)).all() and np.array_equal(got[~np.isnan(got)], ref[~np.isnan(ref)])
     assert same == 200
+
+
+def _rank_deficient(cands):
+    """candidates whose columns [tau, x, y] are linearly dependent: the bordered Jacobian of the reference's system is singular"""
+    A = np.concatenate([np.ones((len(cands), cands.shape[1], 1)), cands.astype(float)], axis=2)
+    return np.where(np.linalg.matrix_rank(A) < 3)[0]
+
+
+def _against_the_oracle(hc, orc, cands, r, rN):
+    import warnings
+    ok, mus, nll = hc.solve_table(cands, np.array(r, float), np.array(rN, float))
+    bad = []
+    for j in range(len(cands)):
+        Cm = np.zeros((cands.shape[1], 3))
+        Cm[:, 0] = 2
+        Cm[:, 1:] = cands[j]
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            s = orc.solve_n3(Cm, r, rN)
+        if s is None:
+            good = ok[j] == 0
+        elif s[1] != s[1]:
+            good = ok[j] > 0 and nll[j] != nll[j]
+        else:
+            good = ok[j] > 0 and abs(s[1] - nll[j]) <= 1e-9 * abs(s[1]) and np.abs(np.asarray(s[0]) - mus[j]).max() < 1e-6
+        if not good:
+            bad.append((j, cands[j].tolist(), int(ok[j]), float(nll[j]), None if s is None else float(s[1])))
+    return bad
+
+
+def test_every_rank_deficient_candidate_of_six_seeded_spaces_follows_the_reference():
+    """
+    Round 2's verdict: on candidates with linearly dependent columns (x + y = const, two equal tumour populations, ...) the
+    bordered Jacobian of the reference's Lagrangian system is exactly singular, MINPACK's factorisation holds rounding noise
+    where a zero belongs, and where hybrj ends -- the candidate's own optimum, a root outside [0,1]^3 (=> the nu = 1/3
+    fallback) or nowhere -- hangs on the last bit of every Jacobian entry.  The reference squares with `**2` on a numpy
+    float64 (Optimizer.py:308), which is libm's pow(x, 2.0) and not x*x; with that restated too (refpow.hpp) the procedure
+    the device runs (n3_ref_solve, host build) reproduces the oracle on EVERY rank-deficient candidate of six seeded spaces
+    -- class, NLL to 1e-9, mu to 1e-6, no allowance -- the eight candidates the verdict lists among them.
+    """
+    import hybrj_check as hc
+    import theta_oracle as orc
+    total = 0
+    for m, K, seed in ((6, 2, 103), (7, 2, 103), (6, 3, 11), (7, 3, 15), (8, 2, 13), (6, 3, 14)):
+        r, rN, L, Ct, mu = orc.synth_counts(m, 3, K, seed)
+        r, rN, order = orc.sort_r(rN, r)
+        cands = np.array(list(orc.enumerate_n3(m, 2, [0] * m, [K] * m)), np.uint8)
+        idx = _rank_deficient(cands)
+        if len(idx) > 1700:                                 # (m = 8: every third one, the suite has minutes, not hours)
+            idx = idx[(seed % 3)::3]
+        if (m, seed) == (6, 103):
+            assert {5517, 7527} <= set(idx.tolist())
+        if (m, seed) == (7, 103):
+            assert {11930, 12626, 18024, 19123, 22950, 23247} <= set(idx.tolist())
+        bad = _against_the_oracle(hc, orc, cands[idx], r, rN)
+        assert not bad, (m, K, seed, bad[:5])
+        total += len(idx)
+    assert total >= 5000
+
+
+def test_a_whole_space_with_no_allowance():
+    """... and all 7 623 candidates of the m=6, K=2 space of the GPU dump test, regular ones included."""
+    import hybrj_check as hc
+    import theta_oracle as orc
+    r, rN, L, Ct, mu = orc.synth_counts(6, 3, 2, 103)
+    r, rN, order = orc.sort_r(rN, r)
+    cands = np.array(list(orc.enumerate_n3(6, 2, [0] * 6, [2] * 6)), np.uint8)
+    assert len(cands) == 7623
+    assert not _against_the_oracle(hc, orc, cands, r, rN)

@@ -6,6 +6,7 @@
 // Sums run over the intervals top to bottom like the reference's Python loops; no fused multiply-adds.
 #pragma once
 #include "hybrj4.hpp"
+#include "refpow.hpp"
 
 struct N3RefSystem {
     int m;
@@ -52,7 +53,7 @@ struct N3RefSystem {
             double h[3];
             chat(i, h[0], h[1], h[2]);
             const double p = (h[0] * x[1] + h[1] * x[2]) + h[2] * x[3];
-            const double den = p * p;
+            const double den = refpow::square(p);          // `**2` on a numpy float64 is libm's pow(p, 2.0), not p*p (refpow.hpp)
             for (int k = 0; k < 3; k++)
                 for (int q = 0; q < 3; q++) J[k][q] = J[k][q] + ((r[i] * h[k]) * h[q]) / den;
         }

@@ -18,7 +18,7 @@ from scipy import optimize
 
 so = os.path.join(ROOT, "build_ab", "libhybrj_check.so")
 os.makedirs(os.path.dirname(so), exist_ok=True)
-subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-shared", "-fPIC", os.path.join(ROOT, "tools", "hybrj_check.cpp"), "-o", so])
+subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-fno-builtin-pow", "-shared", "-fPIC", os.path.join(ROOT, "tools", "hybrj_check.cpp"), "-o", so])
 lib = C.CDLL(so)
 dp = C.POINTER(C.c_double)
 lib.hybrj_check_solve.argtypes = [C.c_int, C.c_int, dp, dp, C.POINTER(C.c_uint8), dp, C.POINTER(C.c_int)]
