@@ -9,29 +9,29 @@ bench.py -- candidate C-matrices evaluated per second (BASELINE.json metric) on 
 
 Workload (config.workload): BASELINE config 4's shape -- synthetic m=50 intervals, n=3, k=6, full bounds [0,6] (2.6e38
 admissible matrices, inexhaustible) -- searched as rank ranges of the reference's enumeration order.  One "step" = one
-theta_search call over `--batch` consecutive candidates (enumerate + solve + NLL + arg-min, fused in one kernel).  Each GPU
+theta_search call over `--batch` consecutive candidates (enumerate + solve + NLL + arg-min on the device).  Each GPU
 owns the contiguous shard [N*g/G, N*(g+1)/G) of the rank space and its steps are spread evenly through that shard.  Weak
 scaling: per-GPU work is fixed.  With N > 1 the per-shard finalists are merged with ONE RCCL exchange
 (theta_exchange_finalists) inside the timed region.
 
 Prints ONE JSON line (rank 0).
-  value      candidates SEARCHED by all GPUs / max-over-ranks wall time of the K timed steps, the shipped search: a
-             branch-and-bound in which a candidate whose rigorous lower bound lies beyond the window of the running minimum
-             is finished after one packed-FP32 evaluation (roofline.legs.search.dismissed_fraction says how many).
-  roofline   dominant kernel n3_sieve_kernel<6> (n3_sieve.hip: burst enumeration + one evaluation shared by the children of a
-             last-level node + the self-concordance lower bound), vector-ALU bound -- candidates are generated on chip, ~0
-             algorithmic HBM bytes.  THREE legs on the same rank ranges, each timed by HIP events on the kernels' stream (N = 1):
-               search           as shipped (sieve + finish kernels)               executed FLOP vs the packed-FP32 peak
-               full_solve_f32   no candidate dismissed by its bound: every one     executed FLOP vs the packed-FP32 peak
-                                iterated to the coarse tolerance and valued
-                                (same kernels, "n3_no_dismiss")
-               full_solve_f64   the same in FP64 throughout -- SURVEY 8(d)'s        executed FLOP vs the FP64 vector peak
-                                "passed through the full solve" (the fused
-                                kernel of n3.hip, "n3_force_f64")
-             `achieved/peak/frac` at the top of the object are the shipped search's.  Executed FLOP are counted in-kernel
-             from the evaluations actually run; they FALL when the algorithm improves (sharing an evaluation between
+  value      candidates PASSED THROUGH THE FULL SOLVE by all GPUs / max-over-ranks wall time of the K timed steps -- SURVEY 8(d)'s
+             definition at the reference's precision: every candidate of the range is generated, iterated in FP64 to the coarse
+             tolerance (lambda^2 / sum r < 1e-4) and valued; none is dismissed by a bound (leg "full_solve_f64":
+             n3_no_dismiss + n3_force_f64, the sieve kernel's double instantiation).  dtype "f64".
+  roofline   dominant kernel n3_sieve_kernel<6, double> (n3_sieve.hip: burst enumeration + one evaluation shared by the children
+             of a last-level node), vector-ALU bound -- candidates are generated on chip, ~0 algorithmic HBM bytes.  `achieved` =
+             FLOP executed by the likelihood arithmetic (counted in-kernel from the evaluations actually run) / HIP-event time
+             of the sieve + finish kernels; `peak` = the FP64 vector peak (78.6 TFLOP/s; the v_log_f32 of the screened value is
+             weighted with the FP32 peak).  Executed FLOP FALL when the algorithm improves (sharing an evaluation between
              siblings removed half of them), so `frac` is a statement about the kernel, not about progress.
-             traffic: HBM bytes per launch, measured by two rocprofv3 --pmc passes of this same command on two steps
+             legs (N = 1, after the timed region, on the same rank ranges; each with its own kernel time, FLOP and frac):
+               full_solve_f64   the headline, again as a leg record (per-step kernel ms min / median / max, counters)
+               full_solve_f32   the same in packed single precision (n3_no_dismiss)
+               search           the shipped branch-and-bound: a candidate whose rigorous lower bound lies beyond the window of
+                                the running minimum is finished after one shared packed-FP32 evaluation ("searched", not
+                                "fully solved": its rate is a rider, never the headline)
+             traffic: HBM bytes per launch, measured by two rocprofv3 --pmc passes of this same command on three steps
              (FETCH_SIZE, WRITE_SIZE; gfx950 corrections of MI355X_MICROARCH.md), or null when that is not possible.
   cpu_baseline  the CPU oracle (oracle/theta_oracle.py, a port of the reference's Python) on this host's cores, bounded sample.
 """
@@ -55,7 +55,11 @@ FP64_MFMA_PEAK_TFLOPS = 78.6       # MI355X FP64 matrix peak (dense)
 HBM_PEAK_GBS = 8000.0
 
 M, N_POP, K_MAX, TAU, SEED = 50, 3, 6, 2, 4242
-DOMINANT_KERNEL = "n3_sieve_kernel<6>"      # the shipped search's dominant kernel (n3_sieve.hip); rocprofv3 summaries under profiles/
+DOMINANT_KERNEL = "n3_sieve_kernel"         # (n3_sieve.hip; the headline runs its <6, double> instantiation); rocprofv3 summaries under profiles/
+# the legs: options of the search instance, arithmetic, kernel instantiation
+LEGS = {"full_solve_f64": ({"n3_no_dismiss": 1, "n3_force_f64": 1}, "f64", "n3_sieve_kernel<6, double>"),
+        "full_solve_f32": ({"n3_no_dismiss": 1}, "f32+f64", "n3_sieve_kernel<6, float>"),
+        "search": ({}, "f32+f64", "n3_sieve_kernel<6, float>")}
 
 
 def synth(seed=SEED, m=M, n=N_POP, k=K_MAX):
@@ -134,8 +138,10 @@ class Leg:
         self.p, self.begins, self.batch, self.window = problem, begins, batch, window
         self.running = float("inf")
         self.best = None
-        self.tot = {k: 0 for k in ("evaluated", "accepted", "dismissed", "flops", "flops_f32", "terms", "iterations")}
-        self.kernel_ms = self.setup_ms = 0.0
+        self.tot = {k: 0 for k in ("evaluated", "accepted", "dismissed", "flops", "flops_f32", "terms", "iterations", "survivors",
+                                   "fallback_candidates", "redo_flops", "redo_flops_f32", "degenerate")}
+        self.kernel_ms = self.setup_ms = self.redo_ms = 0.0
+        self.step_ms = []
         self.launches = 0
 
     def step(self, i, count=True):
@@ -155,7 +161,11 @@ class Leg:
             st = res["stats"]
             for k in self.tot:
                 self.tot[k] += st[k]
+            # every candidate is counted once (a slice redone by the fused kernel is reported apart, stats.redo_*)
+            assert st["evaluated"] == self.batch and st["dismissed"] <= st["evaluated"], (st["evaluated"], st["dismissed"])
             self.kernel_ms += st["kernel_ms"]
+            self.redo_ms += st["redo_kernel_ms"]
+            self.step_ms.append(st["kernel_ms"] + st["redo_kernel_ms"])
             self.setup_ms += st["setup_ms"]
             self.launches += 1
             if os.environ.get("THETA_BENCH_VERBOSE"):
@@ -172,9 +182,14 @@ class Leg:
         ach = (f64 + f32) / k_s / 1e12 if k_s > 0 else 0.0
         # time-weighted peak of the executed mix: an FP64 op costs two packed-FP32 slots
         peak = (f64 + f32) / (f64 / FP64_VECTOR_PEAK_TFLOPS + f32 / FP32_VECTOR_PEAK_TFLOPS) if f64 + f32 > 0 else FP32_VECTOR_PEAK_TFLOPS
+        sm = sorted(self.step_ms) or [0.0]
         return {"leg": name, "dtype": dtype, "kernel": kernel, "launches": self.launches, "candidates_per_launch": self.batch,
                 "value": ev / wall_s if wall_s > 0 else 0.0, "unit": "candidates/s", "wall_ms_per_launch": 1e3 * wall_s / max(self.launches, 1),
                 "kernel_ms_per_launch": self.kernel_ms / max(self.launches, 1), "kernel_candidates_per_s": ev / k_s if k_s > 0 else 0.0,
+                "step_kernel_ms": {"min": sm[0], "median": sm[len(sm) // 2], "max": sm[-1]},
+                "survivors": self.tot["survivors"], "fallback_candidates": self.tot["fallback_candidates"],
+                "redo_kernel_ms": self.redo_ms, "redo_flop": float(self.tot["redo_flops"] + self.tot["redo_flops_f32"]),
+                "degenerate": self.tot["degenerate"],
                 "executed_flop_per_launch": (f64 + f32) / max(self.launches, 1), "fp64_flop_share": f64 / max(f64 + f32, 1.0),
                 "flop_per_candidate": (f64 + f32) / max(ev, 1.0), "achieved": ach, "peak": peak, "unit_roofline": "TFLOP/s",
                 "frac": ach / peak, "newton_iters_per_candidate": self.tot["iterations"] / max(ev, 1.0),
@@ -208,7 +223,7 @@ def measure_traffic(args):
                 out = os.path.join(td, ctr)
                 cmd = [exe, "--pmc", ctr, "--output-format", "csv", "-d", out, "-o", "pmc", "--", sys.executable,
                        os.path.abspath(__file__), "--gpus", "1", "--steps", "3", "--warmup", "2", "--batch", str(args.batch),
-                       "--no-cpu-baseline", "--no-legs", "--no-traffic", "--no-extras"]
+                       "--leg", args.leg, "--no-cpu-baseline", "--no-legs", "--no-traffic", "--no-extras"]
                 subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240, check=True)
                 vals = []
                 for dp, _d, fs in os.walk(out):
@@ -217,7 +232,7 @@ def measure_traffic(args):
                             import csv
                             with open(os.path.join(dp, f)) as fh:
                                 for row in csv.DictReader(fh):
-                                    if DOMINANT_KERNEL.split("<")[0] in row.get("Kernel_Name", "") and row.get("Counter_Name") == ctr:
+                                    if DOMINANT_KERNEL in row.get("Kernel_Name", "") and row.get("Counter_Name") == ctr:
                                         vals.append(float(row["Counter_Value"]))
                 if not vals:
                     return None, "rocprofv3 produced no %s rows for the search kernel" % ctr
@@ -334,8 +349,9 @@ def main():
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=1 << 31, help="candidates per step per GPU (one theta_search call)")
+    ap.add_argument("--leg", default="full_solve_f64", choices=sorted(LEGS), help="what the timed region runs (the headline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-legs", action="store_true", help="skip the full-solve legs (they run at N=1 only anyway)")
+    ap.add_argument("--no-legs", action="store_true", help="skip the other legs (they run at N=1 only anyway)")
     ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 --pmc passes that measure HBM traffic")
     ap.add_argument("--no-extras", action="store_true", help="skip wall_clock_to_best and the config-5 rider")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
@@ -370,9 +386,22 @@ def main():
             comm.barrier()
         ctx.synchronize()
 
+    def set_opts(opts, on):
+        for k, v in opts.items():
+            problem.set_option(k, v if on else 0)
+
+    head_opts, head_dtype, head_kernel = LEGS[args.leg]
+    set_opts(head_opts, True)
     leg = Leg(problem, begins, args.batch, COLLECT_WINDOW)
     for i in range(args.warmup):
         leg.step(i, count=False)
+        if i == 0 and comm is not None:
+            # the one collective BEFORE a sharded search (search.do_optimization_distributed): the shards' probe minima are
+            # all-reduced (min) and every shard starts from the job's minimum, not its own -- a shard whose candidates are
+            # poor neither floods its lists nor lists contenders nobody needs
+            leg.running = float(comm.allreduce_min(leg.running)[0])
+    if args.warmup == 0 and comm is not None:
+        leg.running = float(comm.allreduce_min(leg.running)[0])
     barrier()
     t0 = time.time()
     for i in range(args.warmup, nsteps):
@@ -387,6 +416,7 @@ def main():
         merged, gmin = comm.exchange_finalists(N_POP, M, recs, COLLECT_WINDOW)
     barrier()
     dt = time.time() - t0
+    set_opts(head_opts, False)
 
     mine = np.array([float(leg.tot["evaluated"]), dt], dtype=np.float64)
     allv = comm.allgather(mine) if comm is not None else mine[None, :]
@@ -394,38 +424,40 @@ def main():
         ev_all = allv[:, 0].sum()
         t_max = allv[:, 1].max()
         value = ev_all / t_max
-        legs = {"search": leg.summary(dt, "search", "f32+f64")}
+        legs = {args.leg: leg.summary(dt, args.leg, head_dtype, head_kernel)}
+        what = {"full_solve_f64": "every candidate generated, iterated in FP64 to the coarse tolerance and valued; none dismissed by a bound",
+                "full_solve_f32": "every candidate generated, iterated in packed FP32 to the coarse tolerance and valued; none dismissed by a bound",
+                "search": "candidates SEARCHED by the shipped branch-and-bound (bound-pruned after one shared packed-FP32 evaluation)"}[args.leg]
         out = {
-            "metric": "candidate C-matrices evaluated/sec (whole node): candidates SEARCHED/s by the shipped branch-and-bound "
-                      "(bound-pruned; full-solve rates in roofline.legs)",
+            "metric": "candidate C-matrices evaluated/sec (whole node): " + what,
             "value": value, "unit": "candidates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * t_max / args.steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32+f64", "data": "synthetic",
+            "vs_baseline": None, "dtype": head_dtype, "data": "synthetic",
             "config": {"workload": "synthetic m=50 intervals, n=3, k=6, full bounds [0,6]: rank-range search "
-                                   "(BASELINE config 4 shape)", "m": M, "n": N_POP, "k": K_MAX,
+                                   "(BASELINE config 4 shape)", "m": M, "n": N_POP, "k": K_MAX, "leg": args.leg,
                        "candidates_per_step_per_gpu": args.batch, "total_candidates_in_space": float(total),
-                       "parallelism": "rank-range sharding x%d, one RCCL exchange of finalists (library-owned communicator)" % world},
+                       "parallelism": "rank-range sharding x%d, hint all-reduce before + one exchange of finalists after "
+                                      "(library-owned RCCL communicator)" % world},
         }
         if comm is not None:
             out["comm"] = comm.info()
         if world == 1 and not args.no_legs:
-            # the same rank ranges with no candidate dismissed by its bound -- in the default arithmetic, then in FP64 throughout
-            for name, opts, dtype, k_leg, batch in (("full_solve_f32", {"n3_no_dismiss": 1}, "f32+f64", 3, args.batch),
-                                                    ("full_solve_f64", {"n3_no_dismiss": 1, "n3_force_f64": 1}, "f64", 3, max(args.batch >> 2, 1))):
-                for k, v in opts.items():
-                    problem.set_option(k, v)
-                lg = Leg(problem, begins[args.warmup:], batch, COLLECT_WINDOW)
-                lg.running = leg.running           # (chained to the job: starts from the minimum found so far)
+            # the other legs on the same rank ranges, chained to the job (they start from the minimum found so far)
+            for name, (opts, dtype, kern) in LEGS.items():
+                if name == args.leg:
+                    continue
+                set_opts(opts, True)
+                lg = Leg(problem, begins[args.warmup:], args.batch, COLLECT_WINDOW)
+                lg.running = leg.running
                 lg.step(0, count=False)
                 ctx.synchronize()
                 t1 = time.time()
-                for i in range(min(k_leg, len(lg.begins))):
+                for i in range(min(4, len(lg.begins))):
                     lg.step(i)
                 ctx.synchronize()
-                legs[name] = lg.summary(time.time() - t1, name, dtype, DOMINANT_KERNEL if name == "full_solve_f32" else "n3_search_kernel<6,false>")
-                for k in opts:
-                    problem.set_option(k, 0)
-        s = legs["search"]
+                legs[name] = lg.summary(time.time() - t1, name, dtype, kern)
+                set_opts(opts, False)
+        s = legs[args.leg]
         traffic, tnote = (None, "not measured (--no-traffic or N > 1)")
         if world == 1 and not args.no_traffic:
             traffic, tnote = measure_traffic(args)
@@ -433,13 +465,13 @@ def main():
             "bound": "valu", "bound_detail": "vector-ALU (VALU issue) bound, not HBM and not MFMA: candidates are generated on chip "
             "(~0 algorithmic HBM bytes) and the per-candidate C.mu is an (18 x 3).(3) product after group aggregation -- no GEMM. "
             "Kernel time = sieve + finish kernels of a step (HIP events around both). "
-            "`peak` is the packed-FP32 vector peak (157.3 TFLOP/s) weighted with the FP64 vector peak (78.6) by the executed mix",
-            "kernel": DOMINANT_KERNEL, "achieved": s["achieved"], "peak": s["peak"], "unit": "TFLOP/s", "frac": s["frac"],
+            "`peak` is the FP64 vector peak (78.6 TFLOP/s) weighted with the packed-FP32 vector peak (157.3) by the executed mix",
+            "kernel": head_kernel, "achieved": s["achieved"], "peak": s["peak"], "unit": "TFLOP/s", "frac": s["frac"],
             "traffic": traffic, "traffic_note": tnote, "algorithmic_bytes_per_launch": 0,
             "kernel_ms_per_launch": s["kernel_ms_per_launch"], "legs": legs,
             "note": "`achieved` = FLOP executed by the likelihood arithmetic (counted in-kernel from the evaluations and terms "
-                    "actually run) / HIP-event kernel time; see DESIGN.md section 6"}
-        out["dismissed_fraction"] = s["dismissed_fraction"]
+                    "actually run; slices redone by the fused kernel are reported apart, redo_*) / HIP-event kernel time; "
+                    "see DESIGN.md section 6"}
         out["setup_ms_per_step"] = leg.setup_ms / max(leg.launches, 1)
         if world == 1 and not args.no_cpu_baseline:
             # bounded sample of the SAME candidates, materialised by the enumerate kernel, solved by the oracle on the host

@@ -95,6 +95,9 @@ typedef struct theta_search_stats {
                                 4 prefix successor, 5 whole wave                               */
     uint64_t survivors;      /* n=3 fast path: contenders the sieve kernel handed to the finish kernel */
     uint64_t fallback_candidates; /* n=3 fast path: candidates of slices redone by the fused kernel (contender list full) */
+    uint64_t redo_flops;     /* ... FP64 operations the fused kernel executed on those slices -- NOT part of `flops`:       */
+    uint64_t redo_flops_f32; /* ... every candidate is counted once in evaluated / dismissed / iterations / terms / flops,  */
+    double redo_kernel_ms;   /* ... and kernel_ms is the sieve + finish kernels' only; the redo's time is here              */
 } theta_search_stats;
 
 /*

@@ -128,6 +128,49 @@ def test_exchange_three_ranks_keeps_nan_records():
     assert nl[:3] == [5000.0, 5000.0003, 4999.9998] and len(nl) == 4 and nl[3] != nl[3]
 
 
+def _uneven_worker(rank, world, port, counts, q):
+    try:
+        sys.path.insert(0, ROOT)
+        import theta_amd
+        n, m = 3, 5
+        comm = theta_amd.Comm(None, rank=rank, world=world, addr="127.0.0.1", port=port, transport="host")
+        rng = np.random.RandomState(7 + rank)
+        recs = [{"rank": (rank << 40) + j, "c": rng.randint(0, 3, (m, 2)).astype(np.uint8), "mu": rng.dirichlet(np.ones(n)),
+                 "nll": float("nan") if j % 2 else 100.0 + 1e-4 * j, "vals": rng.dirichlet(np.ones(m))} for j in range(counts[rank])]
+        merged, gmin = comm.exchange_finalists(n, m, recs, 0.5)
+        merged2, _ = comm.exchange_finalists(n, m, recs[: counts[rank] // 3], 0.5)      # and again, other counts
+        comm.close()
+        q.put((rank, [t["rank"] for t in merged], len(merged2), gmin, None))
+    except Exception as e:
+        q.put((rank, "error: %r" % (e,), None, None, None))
+
+
+@pytest.mark.parametrize("counts", [(100, 0), (0, 300, 7)])
+def test_exchange_with_uneven_shards_is_one_collective_decision(counts):
+    """Round-2 advice (high): each rank sized its output room from its OWN record count, so with 100 records on one shard and
+    none on the other the ranks disagreed on whether to come back with more room -- one raised, the other hung in the next
+    collective.  The room is now agreed on by an all-reduce of the counts before the exchange."""
+    world = len(counts)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_uneven_worker, args=(r, world, port, counts, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = {}
+    for _ in range(world):
+        item = q.get(timeout=120)
+        out[item[0]] = item[1:]
+    for p in procs:
+        p.join(30)
+    for r in range(world):
+        assert not isinstance(out[r][0], str), out[r][0]
+        assert out[r][0] == out[0][0] and out[r][1] == out[0][1]
+    assert len(out[0][0]) == sum(counts)                   # all within the window or NaN: every record of every shard, in rank order
+    assert out[0][0] == sorted(out[0][0])
+    assert out[0][1] == sum(c // 3 for c in counts)
+
+
 # ---------------------------------------------------------------------------------------------------
 # the sharded DRIVER end to end: do_optimization_distributed over the stand-in device (tests/standin_device.py: every
 # candidate through the CPU oracle) and the library's host transport -- rank-range sharding, the probe-minimum all-reduce,
@@ -193,3 +236,74 @@ def test_sharded_driver_over_the_standin_device_equals_the_reference_driver(n, s
         assert campaign.compare_best(best, ref) == "", (rk, seed)                  # every rank returns the reference's list
         assert searched and searched[0][0] == shard[0] and searched[-1][1] == shard[1]      # and searched only its own ranks
         assert ncoll >= 2                                                            # the hint all-reduce and the exchange
+
+
+def _failing_worker(rank, world, port, inst, fail_rank, fail_in_probe, q):
+    try:
+        for pth in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+            sys.path.insert(0, pth)
+        import warnings
+        warnings.simplefilter("ignore")
+        import theta_amd
+        import standin_device as sd
+        from theta_amd import _lib, search as S
+
+        class Failing(sd.StandinProblem):
+            def _probe(self, begin, end):
+                if rank == fail_rank and fail_in_probe:
+                    raise _lib.ThetaError(_lib.ERR_CAPACITY, "device list full (injected)")
+                return super()._probe(begin, end)
+
+            def search(self, *a, **k):
+                if rank == fail_rank:
+                    raise _lib.ThetaError(_lib.ERR_CAPACITY, "device list full (injected)")
+                return super().search(*a, **k)
+
+        _lib.Problem = Failing
+        comm = theta_amd.Comm(None, rank=rank, world=world, addr="127.0.0.1", port=port, transport="host")
+        try:
+            S.do_optimization_distributed(inst["n"], inst["m"], inst["k"], inst["tau"], inst["lb"], inst["ub"], inst["r"], inst["rN"],
+                                          inst["mx"], inst["order"], comm, ctx=sd.StandinContext())
+            q.put((rank, "returned"))
+        except _lib.ThetaError as e:
+            q.put((rank, "ThetaError %d" % e.code))
+        comm.barrier()                                   # the communicator is still in step on every rank
+        comm.close()
+    except BaseException as e:
+        q.put((rank, "error: %r" % (e,)))
+
+
+@pytest.mark.parametrize("fail_in_probe", [False, True])
+def test_a_failing_shard_takes_every_rank_out_together(fail_in_probe):
+    """Round-2 advice (medium): a data-dependent failure of ONE shard (ERR_CAPACITY) used to leave the other ranks waiting in
+    theta_exchange_finalists for ever.  Now every rank raises the same status after an all-reduce of a flag."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import campaign
+    from theta_amd import _lib
+    inst = campaign.instance(10044, 3, "toy")
+    world = 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_failing_worker, args=(rk, world, port, inst, 1, fail_in_probe, q)) for rk in range(world)]
+    for p in procs:
+        p.start()
+    out = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(30)
+    assert out == {rk: "ThetaError %d" % _lib.ERR_CAPACITY for rk in range(world)}, out
+
+
+def test_a_rank_that_never_connects_is_reported_not_waited_for(monkeypatch):
+    """theta_comm_create: the rendezvous has a time-out (THETA_COMM_TIMEOUT_S) and says who is missing."""
+    import time
+    import theta_amd
+    monkeypatch.setenv("THETA_COMM_TIMEOUT_S", "2")
+    t = time.time()
+    with pytest.raises(theta_amd.ThetaError) as e:
+        theta_amd.Comm(None, rank=0, world=2, addr="127.0.0.1", port=_free_port(), transport="host")
+    assert "only 1 of 2 ranks" in str(e.value) and time.time() - t < 30
+    t = time.time()
+    with pytest.raises(theta_amd.ThetaError) as e:
+        theta_amd.Comm(None, rank=1, world=2, addr="127.0.0.1", port=_free_port(), transport="host")
+    assert "cannot reach rank 0" in str(e.value) and time.time() - t < 30

@@ -55,3 +55,84 @@ def test_rank_deficient_candidates_follow_the_reference_on_the_device(ctx, m, K,
             bad.append((int(k), cands[k].tolist(), bool(ok[j]), float(nll_b[j]), None if s is None else float(s[1])))
     assert not bad, bad[:5]
     assert len(idx) > 600
+
+
+def _search_mode(ctx, p, begin, end, r, rN, opts, window=0.5, hint=None):
+    for k, v in opts.items():
+        p.set_option(k, v)
+    try:
+        if hint is not None:
+            p.hint(hint)
+        res = p.search(begin, end, window=window)
+        sus_rk, sus_lb, sus_C = p.last_suspects
+        fb = set()
+        if len(sus_rk):          # the suspects that matter: those whose nu = 1/3 fallback value comes within the window
+            ok, mu, nll, _ = ctx.solve_batch(3, p.tau, r, rN, sus_C, 1.0, want_vals=False)
+            gmin = res["nll"].min() if len(res["nll"]) else np.inf
+            fb = set(rk for rk, o, v in zip(sus_rk, ok, nll) if o and v <= min(gmin, np.nanmin(np.where(ok, nll, np.inf))) + window)
+        return res, fb, list(p.last_degenerate[0])
+    finally:
+        for k in opts:
+            p.set_option(k, 0)
+
+
+def test_fp64_sieve_and_full_solve_modes_return_the_lists_of_the_shipped_search(ctx):
+    """
+    The sieve kernel's FP64 instantiation (n3_force_f64: every evaluation on doubles) and the full-solve modes (n3_no_dismiss: no
+    candidate finished by its bound -- the bench's headline leg) against the shipped packed-FP32 search on the same ranges:
+    same finalists (rank, C, NLL to 1e-11: all of them come out of the finish kernel's FP64 arithmetic), same fallback-relevant
+    suspects, same all-zero-column lists, every candidate counted once.
+    """
+    import bench
+    import theta_amd
+    cases = []
+    r, rN, order = bench.synth()
+    cases.append(("bench m50 k6", 50, r, rN, [0] * 50, [6] * 50, [("mid", 1 << 23), (0, 1 << 21), ("end", 1 << 21)], 2))
+    r4, rN4, _ = bench.synth(seed=7, m=50, n=3, k=4)
+    cases.append(("m50 k4", 50, r4, rN4, [0] * 50, [4] * 50, [("mid", 1 << 22)], 2))
+    r6, rN6, _ = bench.synth(seed=9, m=14, n=3, k=3)
+    cases.append(("m14 k3", 14, r6, rN6, [0, 0, 0, 0, 1, 1, 1, 1, 1, 1, 1, 2, 2, 2], [2, 2, 3, 3, 3, 3, 3, 3, 3, 3, 3, 3, 3, 3], [("all", None)], 2))
+    r7, rN7, _ = bench.synth(seed=10, m=9, n=3, k=3)
+    cases.append(("m9 k3", 9, r7, rN7, [0] * 9, [3] * 9, [("all", None)], 2))
+    r8, rN8, _ = bench.synth(seed=12, m=20, n=3, k=7)
+    cases.append(("m20 k7", 20, r8, rN8, [0] * 20, [7] * 20, [("mid", 1 << 22)], 2))
+    r9, rN9, _ = bench.synth(seed=13, m=100, n=3, k=2)              # two intervals per lane
+    cases.append(("m100 k2", 100, r9, rN9, [0] * 100, [2] * 100, [("mid", 1 << 22)], 2))
+    ra, rNa, _ = bench.synth(seed=14, m=16, n=3, k=3)
+    ra = list(ra)
+    ra[0], ra[7] = 3, 11
+    cases.append(("m16 k3 tiny Rmin", 16, ra, rNa, [0] * 16, [3] * 16, [("mid", 1 << 21)], 2))
+    rb, rNb, _ = bench.synth(seed=15, m=12, n=3, k=4)
+    cases.append(("m12 k4 tau3", 12, rb, rNb, [0] * 12, [4] * 12, [("all", None)], 3))
+    modes = [("f64", {"n3_force_f64": 1}), ("f64 full solve", {"n3_force_f64": 1, "n3_no_dismiss": 1}), ("f32 full solve", {"n3_no_dismiss": 1})]
+    for name, m, rr, rn, lb, ub, ranges, tau in cases:
+        p = theta_amd.Problem(ctx, 3, m, tau, rr, rn, lb, ub, 1.0)
+        known = None
+        for where, span in ranges:
+            if where == "all":
+                b, e = 0, p.count
+            elif where == "mid":
+                b, e = p.count // 3, min(p.count, p.count // 3 + span)
+            elif where == "end":
+                b, e = p.count - span, p.count
+            else:
+                b, e = where, where + span
+            a, fa, da = _search_mode(ctx, p, b, e, rr, rn, {}, hint=known)
+            assert a["stats"]["evaluated"] == e - b
+            for mode, opts in modes:
+                f, ff, df = _search_mode(ctx, p, b, e, rr, rn, opts, hint=known)
+                st = f["stats"]
+                assert st["evaluated"] == e - b, (name, where, mode)
+                assert st["dismissed"] <= st["evaluated"]
+                if "n3_no_dismiss" in opts:
+                    assert st["dismissed"] == 0
+                if "n3_force_f64" in opts and m >= 8:
+                    assert st["flops"] > 20 * st["flops_f32"], (name, mode, st["flops"], st["flops_f32"])     # FP64 throughout
+                assert a["rank"] == f["rank"], (name, where, mode, len(a["rank"]), len(f["rank"]))
+                assert np.array_equal(a["C"], f["C"])
+                assert np.allclose(a["nll"], f["nll"], rtol=1e-11, atol=0)
+                assert fa == ff, (name, where, mode, len(fa), len(ff))
+                assert da == df
+            if len(a["nll"]):
+                known = float(a["nll"].min()) if known is None else min(known, float(a["nll"].min()))
+        p.close()

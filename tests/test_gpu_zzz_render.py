@@ -12,7 +12,7 @@ m, k = int(sys.argv[2]), int(sys.argv[3])
 ctx = theta_amd.default_context()
 p = theta_amd.Problem(ctx, 2, m, 2, [1] * m, [1] * m, [0] * m, [k] * m)
 cnt = int(min(p.count, 3_000_000))
-for b, c in ((0, cnt), (p.count // 3, min(cnt, 1_000_001)), (max(0, p.count - 777_777), min(p.count, 777_777))):
+for b, c in ((0, cnt), (p.count // 3, min(cnt, 1_000_001, p.count - p.count // 3)), (max(0, p.count - 777_777), min(p.count, 777_777))):
     if c < 1:
         continue
     os.environ["THETA_N2_ENUM_LEGACY"] = "1"

@@ -30,7 +30,8 @@ class SearchStats(C.Structure):
                 ("iterations", C.c_uint64), ("terms", C.c_uint64), ("list_overflow", C.c_uint64),
                 ("flops", C.c_uint64), ("flops_f32", C.c_uint64), ("dismissed", C.c_uint64), ("best_nll", C.c_double), ("rejected_bound", C.c_double),
                 ("rejected_rank", C.c_uint64 * 2), ("kernel_ms", C.c_double), ("setup_ms", C.c_double),
-                ("phase_cycles", C.c_uint64 * 8), ("survivors", C.c_uint64), ("fallback_candidates", C.c_uint64)]
+                ("phase_cycles", C.c_uint64 * 8), ("survivors", C.c_uint64), ("fallback_candidates", C.c_uint64),
+                ("redo_flops", C.c_uint64), ("redo_flops_f32", C.c_uint64), ("redo_kernel_ms", C.c_double)]
 
     def as_dict(self):
         d = {k: getattr(self, k) for k, _ in self._fields_ if k not in ("rejected_rank", "phase_cycles")}
@@ -663,7 +664,11 @@ class Comm:
         for i, t in enumerate(recs):
             rk[i, 0], rk[i, 1] = t["rank"] & 0xFFFFFFFFFFFFFFFF, t["rank"] >> 64
         Cb = np.array([np.asarray(t["c"], dtype=np.uint8).reshape(-1) for t in recs], dtype=np.uint8).reshape(k, m * nc)
-        cap = max(64, 2 * k)
+        # The output capacity is agreed on BEFORE the exchange: every rank offers room for the records of ALL shards (one
+        # all-reduce of the counts), so no rank can find its own room sufficient while another comes back for more -- with
+        # uneven shards (all-zero-column records cluster at low ranks) the per-rank guess of round 2 left ranks in different
+        # collectives (round-2 advice).  The retry below is collective too: ERR_CAPACITY is returned on every rank.
+        cap = max(64, int(self.allreduce_sum(float(k))[0]))
         while True:
             o_nll, o_mu, o_vals = np.zeros(cap), np.zeros((cap, n)), np.zeros((cap, m))
             o_rk, o_C = np.zeros((cap, 2), np.uint64), np.zeros((cap, m * nc), np.uint8)
@@ -672,9 +677,9 @@ class Comm:
                                                  _p(Cb, C.c_uint8), _p(vals, C.c_double), float(window), cap,
                                                  _p(o_nll, C.c_double), _p(o_mu, C.c_double), _p(o_rk, C.c_uint64),
                                                  _p(o_C, C.c_uint8), _p(o_vals, C.c_double), C.byref(n_out), C.byref(gmin))
-            if rc == ERR_CAPACITY and n_out.value > cap:
-                # (collective: every rank sees the same total and comes back with the same capacity)
-                cap = n_out.value
+            if rc == ERR_CAPACITY:
+                # (collective: every rank sees the same total, gets the same status and comes back with the same capacity)
+                cap = max(2 * cap, n_out.value)
                 continue
             _check(rc)
             break

@@ -145,7 +145,10 @@ struct theta_problem {
     int opt_per_thread = 0;            // n=2 candidates per thread (0: automatic)
     int opt_sieve = 1;                 // n=3: sieve + finish kernels (n3_sieve.hip); 0 = the fused kernel of n3.hip only
     uint64_t last_survivors = 0, last_fallback = 0;   // of the last search: contenders listed by the sieve / candidates redone fused
-    DevBuf d_r, d_rN, d_small, d_P, d_PR, d_PN, d_cnt, d_ctr, d_list, d_tasks, d_stbuf, d_misc, d_smask, d_dynmask, d_sus, d_deg, d_surv, d_survcnt;
+    SearchCounters last_redo{};                        // ... what the fused kernel did on the redone slices (kept apart from the main counters)
+    double last_redo_ms = 0.0;
+    bool last_sieve64 = false;                         // ... and whether the sieve ran in FP64 (n3_force_f64)
+    DevBuf d_r, d_rN, d_small, d_P, d_PR, d_PN, d_cnt, d_ctr, d_list, d_tasks, d_stbuf, d_misc, d_smask, d_dynmask, d_sus, d_deg, d_surv, d_survcnt, d_survacc;
 };
 
 static int upload(DevBuf &b, const void *src, size_t bytes, hipStream_t st) {
@@ -446,6 +449,10 @@ static int run_search(theta_problem *p, u128 b, u128 e, double window, double *d
     hc.rej_bits = order_bits(INFINITY);
     kernel_ms = setup_ms = 0.0;
     unsigned long long list_dropped = 0;
+    memset(&p->last_redo, 0, sizeof(p->last_redo));
+    p->last_redo_ms = 0.0;
+    p->last_sieve64 = false;
+    p->last_fallback = 0;
     for (int pass = 0; pass < 3; pass++) {
         std::vector<std::pair<int, int>> slices;     // n=3 fast path: (first task, tasks) of every sieve launch of this pass
         uint64_t sieve_per_task = 0;
@@ -485,10 +492,9 @@ static int run_search(theta_problem *p, u128 b, u128 e, double window, double *d
             }
             int ntasks = (int)nt;
             N3Dev PS = p->n3;
-            const int sieve_levels = (p->opt_sieve && !dump_nll && !p->n3.force64) ? n3_sieve_levels(p->n3) : 0;
+            const int sieve_levels = (p->opt_sieve && !dump_nll) ? n3_sieve_levels(p->n3) : 0;   // (FP64 mode: the sieve's double instantiation)
             if (p->m > N3_MAX_M && sieve_levels == 0) {
-                theta_set_error("n=3 with more than %d intervals runs on the sieve path only (no --GET_VALUES dump, no FP64 mode, "
-                                "n3_sieve = 1)", N3_MAX_M);
+                theta_set_error("n=3 with more than %d intervals runs on the sieve path only (no --GET_VALUES dump, n3_sieve = 1)", N3_MAX_M);
                 return THETA_ERR_ARG;
             }
             if (sieve_levels > 0) {
@@ -498,8 +504,10 @@ static int run_search(theta_problem *p, u128 b, u128 e, double window, double *d
                     int rc = p->d_surv.alloc((size_t)SURV_CAP * sizeof(SvSurvivor));
                     if (rc) return rc;
                     if ((rc = p->d_survcnt.alloc(SIEVE_MAX_SLICES * sizeof(unsigned)))) return rc;
+                    if ((rc = p->d_survacc.alloc(SIEVE_MAX_SLICES * sizeof(unsigned)))) return rc;
                 }
                 HIP_TRY(hipMemsetAsync(p->d_survcnt.p, 0, SIEVE_MAX_SLICES * sizeof(unsigned), st));
+                HIP_TRY(hipMemsetAsync(p->d_survacc.p, 0, SIEVE_MAX_SLICES * sizeof(unsigned), st));
                 n3_launch_tasks(PS, b, e, per_task, ntasks, (N3Task *)p->d_tasks.p, (unsigned *)p->d_stbuf.p, st);
                 HIP_TRY(hipEventRecord(ctx->ev1, st));
                 int per_slice = (int)std::max<uint64_t>(1, SIEVE_SLICE / per_task);
@@ -527,9 +535,10 @@ static int run_search(theta_problem *p, u128 b, u128 e, double window, double *d
                     const int t0 = slices[sl].first, nts = slices[sl].second;
                     n3_launch_sieve(PS, A, (const N3Task *)p->d_tasks.p + t0, (const unsigned *)p->d_stbuf.p + (size_t)t0 * N3_STB, nts,
                                     (SvSurvivor *)p->d_surv.p, SURV_CAP, cnts + sl, st);
-                    n3_launch_finish(PS, A, (const SvSurvivor *)p->d_surv.p, SURV_CAP, cnts + sl, st);
+                    n3_launch_finish(PS, A, (const SvSurvivor *)p->d_surv.p, SURV_CAP, cnts + sl, (unsigned *)p->d_survacc.p + sl, st);
                 }
                 sieve_per_task = per_task;
+                p->last_sieve64 = p->n3.force64 != 0;
             } else {
                 n3_launch_tasks(p->n3, b, e, per_task, ntasks, (N3Task *)p->d_tasks.p, (unsigned *)p->d_stbuf.p, st);
                 HIP_TRY(hipEventRecord(ctx->ev1, st));
@@ -538,9 +547,12 @@ static int run_search(theta_problem *p, u128 b, u128 e, double window, double *d
         }
         HIP_TRY(hipEventRecord(ctx->ev2, st));
         SearchCounters got;
-        unsigned hcnt[SIEVE_MAX_SLICES];
+        unsigned hcnt[SIEVE_MAX_SLICES], hacc[SIEVE_MAX_SLICES];
         HIP_TRY(hipMemcpyAsync(&got, p->d_ctr.p, sizeof(got), hipMemcpyDeviceToHost, st));
-        if (!slices.empty()) HIP_TRY(hipMemcpyAsync(hcnt, p->d_survcnt.p, slices.size() * sizeof(unsigned), hipMemcpyDeviceToHost, st));
+        if (!slices.empty()) {
+            HIP_TRY(hipMemcpyAsync(hcnt, p->d_survcnt.p, slices.size() * sizeof(unsigned), hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(hacc, p->d_survacc.p, slices.size() * sizeof(unsigned), hipMemcpyDeviceToHost, st));
+        }
         HIP_TRY(hipStreamSynchronize(st));
         HIP_TRY(hipGetLastError());
         float ms = 0;
@@ -550,9 +562,11 @@ static int run_search(theta_problem *p, u128 b, u128 e, double window, double *d
         setup_ms += ms;
         // A slice of the sieve whose contender list overflowed (a stretch of near-ties) is redone by the fused kernel, which is
         // complete by itself; its records join the same device lists (theta_search drops duplicates by rank).
-        uint64_t redone = 0;
+        uint64_t redone = 0, redone_accepted_by_finish = 0;
+        double redo_ms = 0.0;
         for (size_t sl = 0; sl < slices.size(); sl++) {
             if (hcnt[sl] <= SURV_CAP) continue;
+            redone_accepted_by_finish += hacc[sl];
             if (p->m > N3_MAX_M) {      // (the fused kernel holds one interval per lane)
                 theta_set_error("n=3, m = %d: %u contenders in one slice exceed the list (%u): pass a hint (theta_problem_hint) or "
                                 "search a shorter range", p->m, hcnt[sl], SURV_CAP);
@@ -570,17 +584,43 @@ static int run_search(theta_problem *p, u128 b, u128 e, double window, double *d
             HIP_TRY(hipStreamSynchronize(st));
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipEventElapsedTime(&ms, ctx->ev1, ctx->ev2));
-            kernel_ms += ms;
+            redo_ms += ms;
             HIP_TRY(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
             setup_ms += ms;
             redone += (uint64_t)(se - sb);
         }
         if (redone) {
-            HIP_TRY(hipMemcpyAsync(&got, p->d_ctr.p, sizeof(got), hipMemcpyDeviceToHost, st));
+            // The redone slices were counted once by the sieve; what the fused kernel did on them is reported APART
+            // (stats->redo_*): the main counters stay those of the sieve + finish kernels, so that every candidate is counted
+            // once in evaluated / dismissed / iterations / terms and the executed-FLOP figures of the two kernels do not mix.
+            // `accepted`: the finish kernel's count for an overflowed slice covers the listed part only -- replaced by the
+            // fused kernel's, which saw the whole slice.
+            SearchCounters after;
+            HIP_TRY(hipMemcpyAsync(&after, p->d_ctr.p, sizeof(after), hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));
-            got.evaluated -= redone;         // (counted once by the sieve, once more by the fused kernel)
+            SearchCounters &R = p->last_redo;
+            R.evaluated = after.evaluated - got.evaluated;
+            R.accepted = after.accepted - got.accepted;
+            R.degenerate = after.degenerate - got.degenerate;
+            R.iterations = after.iterations - got.iterations;
+            R.terms = after.terms - got.terms;
+            R.final_terms = after.final_terms - got.final_terms;
+            R.dismissed = after.dismissed - got.dismissed;
+            R.terms64 = after.terms64 - got.terms64;
+            const unsigned long long acc = got.accepted - std::min<unsigned long long>(got.accepted, redone_accepted_by_finish) + R.accepted;
+            SearchCounters merged = after;                     // lists, minima and list counts: the latest
+            merged.evaluated = got.evaluated;
+            merged.degenerate = got.degenerate;
+            merged.iterations = got.iterations;
+            merged.terms = got.terms;
+            merged.final_terms = got.final_terms;
+            merged.dismissed = got.dismissed;
+            merged.terms64 = got.terms64;
+            merged.accepted = acc;
+            got = merged;
+            p->last_redo_ms += redo_ms;
         }
-        p->last_fallback = redone;
+        p->last_fallback += redone;
         if (got.list_count <= LIST_CAP || pass == 2) {
             unsigned long long dropped = got.list_count > LIST_CAP ? got.list_count - LIST_CAP : 0;
             hc = got;
@@ -641,7 +681,14 @@ extern "C" int theta_search(theta_problem *p, const uint64_t rank_begin[2], cons
     HIP_TRY(hipSetDevice(p->ctx->device));
     *n_out = 0;
     if (stats) memset(stats, 0, sizeof(*stats));
-    if (b == e) return THETA_OK;
+    if (b == e) {            // an empty range: nothing found -- and nothing left over from the previous call either
+        p->suspects.clear();
+        p->degenerate.clear();
+        p->suspects_dropped = p->degenerate_dropped = 0;
+        p->last_fallback = 0;
+        p->hint = INFINITY;
+        return THETA_OK;
+    }
     SearchCounters hc;
     std::vector<TieRecord> recs;
     double kms, sms;
@@ -662,11 +709,25 @@ extern "C" int theta_search(theta_problem *p, const uint64_t rank_begin[2], cons
         if (p->n == 2) {
             stats->flops = (uint64_t)(per * (double)hc.terms + fin * (double)hc.final_terms);
             stats->flops_f32 = 0;
+        } else if (p->last_sieve64) {
+            // n=3, the sieve in FP64 (n3_force_f64): every evaluation on doubles; the one single-precision operation per term is
+            // the logarithm of the screened value (v_log_f32).  FP64 reciprocals are v_rcp_f64 + one Newton-Raphson step (+ 4).
+            const double full = (double)(hc.terms - hc.terms64);
+            stats->flops = (uint64_t)(per * ((double)hc.terms64 + (double)hc.finish_iterations * (double)p->m) +
+                                      (FLOPS_PER_TERM_ITER_N3_F32 + 3.0) * full + (FLOPS_PER_TERM_SIEVE_SHARED + 3.0) * (double)hc.sieve_pterms +
+                                      (FLOPS_PER_SIEVE_CHILD + 14.0) * (double)hc.sieve_children);
+            stats->flops_f32 = (uint64_t)(full + (double)hc.sieve_pterms + 2.0 * (double)hc.sieve_children);
         } else {   // n=3: FP64 iterations (dump, ill-conditioned candidates, the finish kernel: m terms each) + the packed-f32
                    // coarse pass and screen
             stats->flops = (uint64_t)(per * ((double)hc.terms64 + (double)hc.finish_iterations * (double)p->m));
             stats->flops_f32 = (uint64_t)(FLOPS_PER_TERM_ITER_N3_F32 * (double)(hc.terms - hc.terms64) + fin * (double)hc.final_terms +
                                           FLOPS_PER_TERM_SIEVE_SHARED * (double)hc.sieve_pterms + FLOPS_PER_SIEVE_CHILD * (double)hc.sieve_children);
+        }
+        {   // slices redone by the fused kernel (contender list full): its work, apart
+            const SearchCounters &R = p->last_redo;
+            stats->redo_flops = (uint64_t)(per * (double)R.terms64);
+            stats->redo_flops_f32 = (uint64_t)(FLOPS_PER_TERM_ITER_N3_F32 * (double)(R.terms - R.terms64) + fin * (double)R.final_terms);
+            stats->redo_kernel_ms = p->last_redo_ms;
         }
         stats->survivors = hc.sieve_survivors;
         stats->fallback_candidates = p->last_fallback;

@@ -113,14 +113,26 @@ int recv_all(int fd, void *buf, size_t n) {
     return THETA_OK;
 }
 
-void tune_socket(int fd) {
-    int one = 1;
-    setsockopt(fd, IPPROTO_TCP, TCP_NODELAY, &one, sizeof(one));
+// seconds a rank waits for the others at the RENDEZVOUS (THETA_COMM_TIMEOUT_S, default 300): a rank that never shows up must
+// not hang the others for ever
+int rendezvous_timeout_s() {
+    if (const char *e = getenv("THETA_COMM_TIMEOUT_S")) {
+        const int v = atoi(e);
+        if (v > 0) return v;
+    }
+    return 300;
+}
+void set_timeouts(int fd, int seconds) {
     struct timeval tv;
-    tv.tv_sec = 600;    // a rank that never shows up must not hang the others for ever
+    tv.tv_sec = seconds;    // 0: block for ever
     tv.tv_usec = 0;
     setsockopt(fd, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof(tv));
     setsockopt(fd, SOL_SOCKET, SO_SNDTIMEO, &tv, sizeof(tv));
+}
+void tune_socket(int fd) {
+    int one = 1;
+    setsockopt(fd, IPPROTO_TCP, TCP_NODELAY, &one, sizeof(one));
+    set_timeouts(fd, rendezvous_timeout_s());
 }
 
 }   // namespace
@@ -172,15 +184,20 @@ static int star_connect(theta_comm *c, const char *addr, int port) {
             freeaddrinfo(res);
             return THETA_ERR_HIP;
         }
+        const int tmo = rendezvous_timeout_s();
         struct timeval tv;
-        tv.tv_sec = 600;
+        tv.tv_sec = tmo;
         tv.tv_usec = 0;
         setsockopt(ls, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof(tv));
         c->peers.assign(c->world, -1);
         for (int k = 1; k < c->world && rc == THETA_OK; k++) {
             int fd = ::accept(ls, nullptr, nullptr);
             if (fd < 0) {
-                theta_set_error("comm: accept failed: %s", strerror(errno));
+                if (errno == EAGAIN || errno == EWOULDBLOCK)
+                    theta_set_error("comm: only %d of %d ranks reached rank 0 on port %d within %d s (THETA_COMM_TIMEOUT_S): a rank "
+                                    "failed to start, or MASTER_ADDR / the port differ between ranks", k, c->world, port, tmo);
+                else
+                    theta_set_error("comm: accept failed: %s", strerror(errno));
                 rc = THETA_ERR_HIP;
                 break;
             }
@@ -197,7 +214,7 @@ static int star_connect(theta_comm *c, const char *addr, int port) {
         ::close(ls);
     } else {
         int fd = -1;
-        const double t_end = (double)time(nullptr) + 300.0;
+        const double t_end = (double)time(nullptr) + (double)rendezvous_timeout_s();
         while (true) {
             fd = ::socket(AF_INET, SOCK_STREAM, 0);
             if (::connect(fd, res->ai_addr, res->ai_addrlen) == 0) break;
@@ -207,7 +224,8 @@ static int star_connect(theta_comm *c, const char *addr, int port) {
             usleep(50 * 1000);      // rank 0 may not be listening yet
         }
         if (fd < 0) {
-            theta_set_error("comm: rank %d cannot reach rank 0 at %s:%d", c->rank, addr, port);
+            theta_set_error("comm: rank %d cannot reach rank 0 at %s:%d within %d s (THETA_COMM_TIMEOUT_S)", c->rank, addr, port,
+                            rendezvous_timeout_s());
             rc = THETA_ERR_HIP;
         } else {
             tune_socket(fd);
@@ -219,6 +237,16 @@ static int star_connect(theta_comm *c, const char *addr, int port) {
     freeaddrinfo(res);
     if (rc != THETA_OK) close_star(c);
     return rc;
+}
+
+// The rendezvous is over: the sockets now carry the collectives of a search whose shards may reach the exchange many minutes
+// apart -- no time-out there (THETA_COMM_COLLECTIVE_TIMEOUT_S sets one, in seconds, for debugging).
+static void star_collective_mode(theta_comm *c) {
+    int tmo = 0;
+    if (const char *e = getenv("THETA_COMM_COLLECTIVE_TIMEOUT_S")) tmo = atoi(e) > 0 ? atoi(e) : 0;
+    for (int fd : c->peers)
+        if (fd >= 0) set_timeouts(fd, tmo);
+    if (c->up >= 0) set_timeouts(c->up, tmo);
 }
 
 // rank 0's buffer to everybody (TCP star)
@@ -287,12 +315,17 @@ extern "C" int theta_comm_create(theta_ctx *ctx, int rank, int world, const char
                 rc = THETA_ERR_HIP;
             }
         }
-        // rank 0 tells the others whether an id is coming, so that nobody waits inside ncclCommInitRank for ever
-        int rc2 = star_bcast(c, &okflag, sizeof(okflag));
-        if (rc2 == THETA_OK && okflag) rc2 = star_bcast(c, &id, sizeof(id));
+        // EVERY rank's status is gathered (a rank whose librccl.so does not load must not let the others wait inside
+        // ncclCommInitRank for ever), then rank 0's id travels
+        std::vector<int32_t> flags((size_t)world, 0);
+        int rc2 = star_allgather(c, &okflag, sizeof(okflag), flags.data());
+        int bad_rank = -1;
+        for (int k = 0; k < world && rc2 == THETA_OK; k++)
+            if (!flags[k] && bad_rank < 0) bad_rank = k;
+        if (rc2 == THETA_OK && bad_rank < 0) rc2 = star_bcast(c, &id, sizeof(id));
         if (rc == THETA_OK && rc2 != THETA_OK) rc = rc2;
-        if (rc == THETA_OK && !okflag) {
-            theta_set_error("comm: rank 0 could not create the RCCL id");
+        if (rc == THETA_OK && bad_rank >= 0) {
+            theta_set_error("comm: rank %d could not set up RCCL (librccl.so / ncclGetUniqueId): no rank joins the communicator", bad_rank);
             rc = THETA_ERR_HIP;
         }
         close_star(c);                           // from here on everything goes over RCCL
@@ -315,6 +348,7 @@ extern "C" int theta_comm_create(theta_ctx *ctx, int rank, int world, const char
             return rc;
         }
     }
+    if (transport == THETA_COMM_HOST) star_collective_mode(c);
     *out = c;
     return THETA_OK;
 }

@@ -50,6 +50,9 @@
 #ifndef SV_OCC
 #define SV_OCC 3          // blocks per CU the register budget is sized for (LDS: ~52 KB per 4-wave block)
 #endif
+#ifndef SV_OCC64
+#define SV_OCC64 2        // ... of the FP64 instantiation (two VGPRs per number, ~74 KB of LDS per block)
+#endif
 #ifndef SV_TRIES
 #define SV_TRIES 2        // evaluations a record may take in place when many lanes need another
 #endif
@@ -58,23 +61,80 @@
 #define SV_KIDS 768       // children (candidates) of one round of <= 64 last-level nodes
 #endif
 
-template <int ML>
+// ---- the scalar type F of the likelihood arithmetic ---------------------------------------------------------------------
+// float: the shipped search -- two likelihood terms per packed instruction (v_pk_fma_f32), v_rcp_f32, sums in single
+// precision behind a rigorous margin.  double: the same kernel in FP64 throughout -- value, gradient, Hessian, the 2x2 solve
+// and the step of every evaluation (v_fma_f64, v_rcp_f64 + one Newton-Raphson step); SURVEY 8(d)'s "passed through the full
+// solve" when no candidate is dismissed (n3_no_dismiss).  In both, log2 q is v_log_f32's (the value is a SCREEN: what lies
+// within the margin of the threshold goes to the finish kernel, which takes exact FP64 logarithms).
+__device__ __forceinline__ float sv_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ double sv_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+__device__ __forceinline__ float sv_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ double sv_rcp(double x) { return rcp_nr1(x); }
+__device__ __forceinline__ float sv_lg2(float x) { return __builtin_amdgcn_logf(x); }
+__device__ __forceinline__ double sv_lg2(double x) { return (double)__builtin_amdgcn_logf((float)x); }
+__device__ __forceinline__ float sv_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+__device__ __forceinline__ double sv_sqrt(double x) { return (double)__builtin_amdgcn_sqrtf((float)x); }   // (damping factor, bound gap)
+__device__ __forceinline__ float sv_abs(float x) { return fabsf(x); }
+__device__ __forceinline__ double sv_abs(double x) { return fabs(x); }
+__device__ __forceinline__ float sv_min(float a, float b) { return fminf(a, b); }
+__device__ __forceinline__ double sv_min(double a, double b) { return fmin(a, b); }
+template <class F> struct SvVec;
+template <> struct SvVec<float> { typedef float v2 __attribute__((ext_vector_type(2))); };
+template <> struct SvVec<double> { typedef double v2 __attribute__((ext_vector_type(2))); };
+template <class F> struct alignas(16) Sv4 { F x, y, z, w; };
+template <class F> struct alignas(2 * sizeof(F)) Sv2 { F x, y; };
+// the record of a last-level node -- 15 numbers (shared sums L, T0..T2, W00..W22, column sums, the point) -- as planes of
+// 16-byte vectors indexed [plane][node]: a wave reads one plane with consecutive 16-byte addresses (round 2 held the record
+// node-major, 64 bytes apart: four lanes per bank group, SQ_LDS_BANK_CONFLICT / SQ_ACTIVE_INST_LDS = 0.79)
+template <class F> struct SvPlanes;
+template <> struct SvPlanes<float> {
+    float4 q[4][WAVE];
+    __device__ __forceinline__ void put(int n, const float (&v)[16]) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) q[k][n] = make_float4(v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]);
+    }
+    __device__ __forceinline__ void get(int n, float (&v)[16]) const {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const float4 t = q[k][n];
+            v[4 * k] = t.x; v[4 * k + 1] = t.y; v[4 * k + 2] = t.z; v[4 * k + 3] = t.w;
+        }
+    }
+};
+template <> struct SvPlanes<double> {
+    double2 q[8][WAVE];
+    __device__ __forceinline__ void put(int n, const double (&v)[16]) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) q[k][n] = make_double2(v[2 * k], v[2 * k + 1]);
+    }
+    __device__ __forceinline__ void get(int n, double (&v)[16]) const {
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const double2 t = q[k][n];
+            v[2 * k] = t.x; v[2 * k + 1] = t.y;
+        }
+    }
+};
+
+template <int ML, class F>
 struct SvWave {
     alignas(16) unsigned short pre[N3_MAX_M_WIDE + 8];  // rows of the prefix, a | b << 8
     uint2 list0[N3_MAX_Q];                              // level 1 nodes (children of the prefix's last node)
     uint2 list[ML > 2 ? ML - 2 : 1][SV_CAP];            // level l >= 2: {packed parent node, ancestor slots (6 bits each) | slot << 24}
     unsigned short kid[SV_KIDS];                        // candidates of the current round: last row's slot | parent lane << 8
-    float4 par[WAVE][4];                                // per last-level node of the round: shared sums, column sums, point, path
-    float4 fXY[(N3_MAX_Q + 2) / 2];                     // group tile of the prefix, two terms per entry {a0, a1, b0, b1}
-    float2 fRR[(N3_MAX_Q + 2) / 2];                     // ... and their weights {R0, R1} (an odd last term is paired with weight 0)
-    float2 fRL[ML / 2];                                 // weights of the leaf rows, paired
+    SvPlanes<F> par;                                    // per last-level node of the round: shared sums, column sums, point
+    unsigned pcode[WAVE];                               // ... and the slots of its path rows (6 bits each) | usable << 31
+    Sv4<F> fXY[(N3_MAX_Q + 2) / 2];                     // group tile of the prefix, two terms per entry {a0, a1, b0, b1}
+    Sv2<F> fRR[(N3_MAX_Q + 2) / 2];                     // ... and their weights {R0, R1} (an odd last term is paired with weight 0)
+    Sv2<F> fRL[ML / 2];                                 // weights of the leaf rows, paired
     unsigned qRow[SV_QCAP][ML / 2];                     // queue: rows of a record that needs more Newton steps
-    float qU1[SV_QCAP], qU2[SV_QCAP];                   // ... the iterate it continues from
+    F qU1[SV_QCAP], qU2[SV_QCAP];                       // ... the iterate it continues from
     unsigned short qOff[SV_QCAP];                       // ... and its offset in the task (rank = task base + offset)
 };
-template <int ML>
+template <int ML, class F>
 struct SvLds {
-    SvWave<ML> w[SV_WAVES];
+    SvWave<ML, F> w[SV_WAVES];
     unsigned long long smask[ML][N3_MAX_Q];             // static child masks of the ML last depths
     unsigned char lb[N3_MAX_M_WIDE], ub[N3_MAX_M_WIDE];
     unsigned char ridx[N3_RIDX_W * N3_RIDX_W + 3];
@@ -94,10 +154,10 @@ __device__ __forceinline__ int sv_incl_scan(int v) {
 }
 
 // Everything a wave carries through the expansion (wave-uniform unless noted).
-template <int ML>
+template <int ML, class F>
 struct SvCtx {
-    SvLds<ML> *S;
-    SvWave<ML> *W;
+    SvLds<ML, F> *S;
+    SvWave<ML, F> *W;
     const unsigned long long *dynmask;
     const u128 *cnt;                 // counting table (only read while a task skips to its first candidate)
     int Q;
@@ -111,14 +171,14 @@ struct SvCtx {
     u128 base;                       // rank of the task's first candidate
     unsigned long long remaining, skip, done;    // candidates of the task still to come / to skip in the first prefix / done
     // likelihood data of the current prefix
-    float S1p, S2p;                  // column sums of the prefix rows (weighted by the normal counts), / N
-    float leafN[ML];                 // normal counts of the leaf rows / N
-    float leafRf[ML];                // tumour counts of the leaf rows
-    float rtot_f, rtot_over_rmin, inv_Rtot, conv_l2;
+    F S1p, S2p;                      // column sums of the prefix rows (weighted by the normal counts), / N
+    F leafN[ML];                     // normal counts of the leaf rows / N
+    F leafRf[ML];                    // tumour counts of the leaf rows
+    F rtot_f, rtot_over_rmin, inv_Rtot, conv_l2;
     double K0, screen_margin, thr;   // thr = running minimum + window, refreshed per prefix
     int no_dismiss;
     // lane-private chain: mixture fractions of the optimum of the lane's previous record
-    float wn1, wn2;
+    F wn1, wn2;
     int qcount;
     // statistics (wave-uniform scalars)
     unsigned long long n_eval, n_dis, n_it, n_deg, n_surv;
@@ -126,104 +186,103 @@ struct SvCtx {
     unsigned long long n_child, n_dit;   // shared first evaluations (children) / full evaluations (queue)
 };
 
-typedef float sv2f __attribute__((ext_vector_type(2)));
 
-// One packed-FP32 evaluation of value, gradient and Hessian at (u1, u2) over the group tile and the record's rows, and the
-// Newton step.  The likelihood in the scaled variables of n3_core.hpp: q_i = 1 + (x_i - s1) u1 + (y_i - s2) u2,
-// NLL = K0 - sum R_i ln q_i.  Returns 0 = stepped (u1, u2 hold the new iterate; val2 = sum R log2 q and l2 = lambda^2 / Rtot
-// at the OLD one), 1 = stepped and converged (l2 < conv), 2 = outside the domain (u1, u2 halved towards 0), 3 = no usable
-// step (ill-conditioned Hessian, NaN).
-template <int ML>
-__device__ __forceinline__ int sv_step(const SvCtx<ML> &c, const unsigned (&rw)[ML / 2], float s1, float s2, float &u1, float &u2,
-                                       float &val2, float &l2) {
-    sv2f g1 = {0.f, 0.f}, g2 = g1, h11 = g1, h12 = g1, h22 = g1, lg = g1;
-    float qmin = __builtin_inff();
-    const sv2f vs1 = {s1, s1}, vs2 = {s2, s2}, vu1 = {u1, u1}, vu2 = {u2, u2}, one = {1.f, 1.f};
-    auto body = [&](sv2f x, sv2f y, sv2f R) {
-        sv2f a = x - vs1, b = y - vs2;
-        sv2f q = __builtin_elementwise_fma(a, vu1, __builtin_elementwise_fma(b, vu2, one));
-        qmin = fminf(qmin, fminf(q.x, q.y));
-        sv2f w = {__builtin_amdgcn_rcpf(q.x), __builtin_amdgcn_rcpf(q.y)};
-        lg = __builtin_elementwise_fma(R, sv2f{__builtin_amdgcn_logf(q.x), __builtin_amdgcn_logf(q.y)}, lg);
-        sv2f t = R * w;
+// One evaluation of value, gradient and Hessian at (u1, u2) over the group tile and the record's rows, two terms at a time
+// (F = float: packed instructions), and the Newton step.  The likelihood in the scaled variables of n3_core.hpp:
+// q_i = 1 + (x_i - s1) u1 + (y_i - s2) u2, NLL = K0 - sum R_i ln q_i.  Returns 0 = stepped (u1, u2 hold the new iterate;
+// val2 = sum R log2 q and l2 = lambda^2 / Rtot at the OLD one), 1 = stepped and converged (l2 < conv), 2 = outside the domain
+// (u1, u2 halved towards 0), 3 = no usable step (ill-conditioned Hessian, NaN).
+template <int ML, class F>
+__device__ __forceinline__ int sv_step(const SvCtx<ML, F> &c, const unsigned (&rw)[ML / 2], F s1, F s2, F &u1, F &u2, F &val2, F &l2) {
+    typedef typename SvVec<F>::v2 v2;
+    v2 g1 = {F(0), F(0)}, g2 = g1, h11 = g1, h12 = g1, h22 = g1, lg = g1;
+    F qmin = F(__builtin_inff());
+    const v2 vs1 = {s1, s1}, vs2 = {s2, s2}, vu1 = {u1, u1}, vu2 = {u2, u2}, one = {F(1), F(1)};
+    auto body = [&](v2 x, v2 y, v2 R) {
+        v2 a = x - vs1, b = y - vs2;
+        v2 q = __builtin_elementwise_fma(a, vu1, __builtin_elementwise_fma(b, vu2, one));
+        qmin = sv_min(qmin, sv_min(q.x, q.y));
+        v2 w = {sv_rcp(q.x), sv_rcp(q.y)};
+        lg = __builtin_elementwise_fma(R, v2{sv_lg2(q.x), sv_lg2(q.y)}, lg);
+        v2 t = R * w;
         g1 = __builtin_elementwise_fma(t, a, g1);
         g2 = __builtin_elementwise_fma(t, b, g2);
-        sv2f tw = t * w;
-        sv2f ta = tw * a, tb = tw * b;
+        v2 tw = t * w;
+        v2 ta = tw * a, tb = tw * b;
         h11 = __builtin_elementwise_fma(ta, a, h11);
         h12 = __builtin_elementwise_fma(ta, b, h12);
         h22 = __builtin_elementwise_fma(tb, b, h22);
     };
-    const float4 *fXY = c.W->fXY;
-    const float2 *fRR = c.W->fRR;
+    const Sv4<F> *fXY = c.W->fXY;
+    const Sv2<F> *fRR = c.W->fRR;
 #pragma unroll 2
     for (int p = 0; p < c.GP; p++) {
-        const float4 xy = fXY[p];
-        const float2 rr = fRR[p];
-        body(sv2f{xy.x, xy.y}, sv2f{xy.z, xy.w}, sv2f{rr.x, rr.y});
+        const Sv4<F> xy = fXY[p];
+        const Sv2<F> rr = fRR[p];
+        body(v2{xy.x, xy.y}, v2{xy.z, xy.w}, v2{rr.x, rr.y});
     }
 #pragma unroll
     for (int j = 0; j < ML / 2; j++) {
-        const float2 rr = c.W->fRL[j];
+        const Sv2<F> rr = c.W->fRL[j];
         const unsigned d = rw[j];      // bytes {a, b, a', b'}
-        body(sv2f{(float)(d & 0xffu), (float)((d >> 16) & 0xffu)}, sv2f{(float)((d >> 8) & 0xffu), (float)(d >> 24)}, sv2f{rr.x, rr.y});
+        body(v2{(F)(d & 0xffu), (F)((d >> 16) & 0xffu)}, v2{(F)((d >> 8) & 0xffu), (F)(d >> 24)}, v2{rr.x, rr.y});
     }
-    if (!(qmin > 0.0f)) {
-        u1 *= 0.5f;
-        u2 *= 0.5f;
+    if (!(qmin > F(0))) {
+        u1 *= F(0.5);
+        u2 *= F(0.5);
         return 2;
     }
-    const float G1 = g1.x + g1.y, G2 = g2.x + g2.y;
-    const float H11 = h11.x + h11.y, H12 = h12.x + h12.y, H22 = h22.x + h22.y;
-    const float hh = H11 * H22;
-    const float det = __builtin_fmaf(-H12, H12, hh);
-    if (!(det > (float)N3_COND_MIN * hh)) return 3;
-    const float idet = __builtin_amdgcn_rcpf(det);
-    const float d1 = (H22 * G1 - H12 * G2) * idet;
-    const float d2 = (H11 * G2 - H12 * G1) * idet;
+    const F G1 = g1.x + g1.y, G2 = g2.x + g2.y;
+    const F H11 = h11.x + h11.y, H12 = h12.x + h12.y, H22 = h22.x + h22.y;
+    const F hh = H11 * H22;
+    const F det = sv_fma(-H12, H12, hh);
+    if (!(det > (F)N3_COND_MIN * hh)) return 3;
+    const F idet = sv_rcp(det);
+    const F d1 = (H22 * G1 - H12 * G2) * idet;
+    const F d2 = (H11 * G2 - H12 * G1) * idet;
     l2 = (G1 * d1 + G2 * d2) * c.inv_Rtot;
     val2 = lg.x + lg.y;
-    if (!(l2 == l2) || !(fabsf(d1) + fabsf(d2) < 1e30f)) return 3;
-    float step = 1.0f;
-    if (l2 > 0.09f) step = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_sqrtf(l2));
-    u1 = __builtin_fmaf(step, d1, u1);
-    u2 = __builtin_fmaf(step, d2, u2);
+    if (!(l2 == l2) || !(sv_abs(d1) + sv_abs(d2) < F(1e30))) return 3;
+    F step = F(1);
+    if (l2 > F(0.09)) step = sv_rcp(F(1) + sv_sqrt(l2));
+    u1 = sv_fma(step, d1, u1);
+    u2 = sv_fma(step, d2, u2);
     // "converged" = the coarse threshold on lambda^2 / sum r AND lambda^2 < Rmin / 4 (quadratic convergence is only granted
     // once the decrement is small against the smallest term weight)
-    return (l2 < c.conv_l2 && l2 * c.rtot_over_rmin < 0.25f) ? 1 : 0;
+    return (l2 < c.conv_l2 && l2 * c.rtot_over_rmin < F(0.25)) ? 1 : 0;
 }
 
 // Is the candidate finished by the lower bound of its optimum?  (evaluated at the iterate BEFORE the step)
-template <int ML>
-__device__ __forceinline__ bool sv_dismissed(const SvCtx<ML> &c, float val2, float l2) {
-    const float lt2 = l2 * c.rtot_over_rmin;
-    if (!(lt2 < 0.25f) || c.no_dismiss) return false;
-    const float lt = __builtin_amdgcn_sqrtf(lt2);
-    const double gap = 1.05 * 0.5 * (double)(l2 * c.rtot_f * __builtin_amdgcn_rcpf(1.0f - lt));
+template <int ML, class F>
+__device__ __forceinline__ bool sv_dismissed(const SvCtx<ML, F> &c, F val2, F l2) {
+    const F lt2 = l2 * c.rtot_over_rmin;
+    if (!(lt2 < F(0.25)) || c.no_dismiss) return false;
+    const F lt = sv_sqrt(lt2);
+    const double gap = 1.05 * 0.5 * (double)(l2 * c.rtot_f * sv_rcp(F(1) - lt));
     const double lb = (c.K0 - 0.6931471805599453 * (double)val2) - gap - c.screen_margin;
     return lb > c.thr;
 }
 
 // column sums / N of a record: (s1, s2); false if a tumour column is all zero (degenerate: the reference's Chat is NaN)
-template <int ML>
-__device__ __forceinline__ bool sv_sums(const SvCtx<ML> &c, const unsigned (&rw)[ML / 2], float &s1, float &s2) {
-    float a = c.S1p, b = c.S2p;
+template <int ML, class F>
+__device__ __forceinline__ bool sv_sums(const SvCtx<ML, F> &c, const unsigned (&rw)[ML / 2], F &s1, F &s2) {
+    F a = c.S1p, b = c.S2p;
 #pragma unroll
     for (int j = 0; j < ML / 2; j++) {
         const unsigned d = rw[j];
-        a = __builtin_fmaf((float)(d & 0xffu), c.leafN[2 * j], a);
-        b = __builtin_fmaf((float)((d >> 8) & 0xffu), c.leafN[2 * j], b);
-        a = __builtin_fmaf((float)((d >> 16) & 0xffu), c.leafN[2 * j + 1], a);
-        b = __builtin_fmaf((float)(d >> 24), c.leafN[2 * j + 1], b);
+        a = sv_fma((F)(d & 0xffu), c.leafN[2 * j], a);
+        b = sv_fma((F)((d >> 8) & 0xffu), c.leafN[2 * j], b);
+        a = sv_fma((F)((d >> 16) & 0xffu), c.leafN[2 * j + 1], a);
+        b = sv_fma((F)(d >> 24), c.leafN[2 * j + 1], b);
     }
     s1 = a;
     s2 = b;
-    return a > 0.0f && b > 0.0f;
+    return a > F(0) && b > F(0);
 }
 
 // A contender (or a record the sieve cannot handle): rows and rank to the device list; the finish kernel takes it from there.
-template <int ML>
-__device__ __forceinline__ void sv_survivor(const SvCtx<ML> &c, const unsigned (&rw)[ML / 2], unsigned off) {
+template <int ML, class F>
+__device__ __forceinline__ void sv_survivor(const SvCtx<ML, F> &c, const unsigned (&rw)[ML / 2], unsigned off) {
     const unsigned idx = atomicAdd(c.surv_count, 1u);
     if (idx >= c.surv_cap) return;            // the host sees the count and redoes the slice with the fused kernel
     SvSurvivor *s = c.surv + idx;
@@ -240,32 +299,32 @@ __device__ __forceinline__ void sv_survivor(const SvCtx<ML> &c, const unsigned (
 }
 
 // Further Newton steps for the queued records, 64 at a time: until dismissed, converged (a contender) or given up.
-template <int ML>
-__device__ __forceinline__ void sv_drain(SvCtx<ML> &c) {
+template <int ML, class F>
+__device__ __forceinline__ void sv_drain(SvCtx<ML, F> &c) {
     for (int b0 = 0; b0 < c.qcount; b0 += WAVE) {
         const int idx = b0 + c.lane;
         bool live = idx < c.qcount;
         unsigned rw[ML / 2];
 #pragma unroll
         for (int j = 0; j < ML / 2; j++) rw[j] = live ? c.W->qRow[idx][j] : 0u;
-        float u1 = live ? c.W->qU1[idx] : 0.f, u2 = live ? c.W->qU2[idx] : 0.f;
+        F u1 = live ? c.W->qU1[idx] : F(0), u2 = live ? c.W->qU2[idx] : F(0);
         const unsigned off = live ? c.W->qOff[idx] : 0u;
-        float s1 = 1.f, s2 = 1.f;
-        sv_sums<ML>(c, rw, s1, s2);
+        F s1 = F(1), s2 = F(1);
+        sv_sums<ML, F>(c, rw, s1, s2);
         int iters = 0;
         bool surv = false;
         while (ballot64(live)) {
             c.n_it += (unsigned)__builtin_popcountll(ballot64(live));
             c.n_dit += (unsigned)__builtin_popcountll(ballot64(live));
             if (live) {
-                float val2 = 0.f, l2 = 0.f;
-                const int st = sv_step<ML>(c, rw, s1, s2, u1, u2, val2, l2);
+                F val2 = F(0), l2 = F(0);
+                const int st = sv_step<ML, F>(c, rw, s1, s2, u1, u2, val2, l2);
                 iters++;
                 if (st == 3 || iters >= 40) {
                     surv = true;                 // ill-conditioned / stuck: the finish kernel solves it in FP64
                     live = false;
                 } else if (st != 2) {
-                    if (sv_dismissed<ML>(c, val2, l2)) {
+                    if (sv_dismissed<ML, F>(c, val2, l2)) {
                         live = false;
                     } else if (st == 1) {
                         // Converged to the coarse tolerance and NOT finished by the rigorous bound: a contender -- the finish
@@ -280,9 +339,9 @@ __device__ __forceinline__ void sv_drain(SvCtx<ML> &c) {
         }
         if (!c.no_dismiss) c.n_dis += (unsigned)__builtin_popcountll(ballot64(idx < c.qcount && !surv));
         c.n_surv += (unsigned)__builtin_popcountll(ballot64(surv));
-        if (surv) sv_survivor<ML>(c, rw, off);
+        if (surv) sv_survivor<ML, F>(c, rw, off);
         // the lane keeps the last optimum it saw as a start for later records
-        if (idx < c.qcount && fabsf(s1 * u1) + fabsf(s2 * u2) < 1e6f) {
+        if (idx < c.qcount && sv_abs(s1 * u1) + sv_abs(s2 * u2) < F(1e6)) {
             c.wn1 = s1 * u1;
             c.wn2 = s2 * u2;
         }
@@ -301,45 +360,42 @@ __device__ __forceinline__ void sv_drain(SvCtx<ML> &c) {
 // space of the child's slice (d0 = -s1 d1 - s2 d2), and has the Newton decrement and the lower bound of the child's optimum
 // for ~1/3 of the work of a full evaluation.  NLL = K0 - ln2 (L - Rtot log2(z.w)): scale invariant, so w needs no
 // normalisation.  Children the bound cannot finish go to the queue and continue with full evaluations at their own iterate.
-struct SvPar {
-    float L, T0, T1, T2, W00, W01, W02, W11, W12, W22, S1, S2, w0, u1, u2;
-    unsigned code;          // slots of the node's path rows (6 bits each) | usable << 31
-};
-
-template <int ML>
-__device__ __forceinline__ void sv_parent(SvCtx<ML> &c, bool take, unsigned code) {
+// Record of a node (SvPlanes, 16 numbers): 0 L, 1..3 T0 T1 T2, 4..9 W00 W01 W02 W11 W12 W22, 10 11 S1 S2, 12..14 w0 u1 u2.
+template <int ML, class F>
+__device__ __forceinline__ void sv_parent(SvCtx<ML, F> &c, bool take, unsigned code) {
+    typedef typename SvVec<F>::v2 v2;
     // path rows D .. D+ML-2 of the node (its ancestors in the expanded levels and itself)
-    float px[ML - 1], py[ML - 1];
-    float S1 = c.S1p, S2 = c.S2p;
+    F px[ML - 1], py[ML - 1];
+    F S1 = c.S1p, S2 = c.S2p;
 #pragma unroll
     for (int j = 0; j < ML - 1; j++) {
         const unsigned r16 = c.S->row16[(code >> (6 * j)) & 63u];
-        px[j] = (float)(r16 & 0xffu);
-        py[j] = (float)(r16 >> 8);
-        S1 = __builtin_fmaf(px[j], c.leafN[j], S1);
-        S2 = __builtin_fmaf(py[j], c.leafN[j], S2);
+        px[j] = (F)(r16 & 0xffu);
+        py[j] = (F)(r16 >> 8);
+        S1 = sv_fma(px[j], c.leafN[j], S1);
+        S2 = sv_fma(py[j], c.leafN[j], S2);
     }
     // the lane's chain point as a direction: mixture (n1, n2) pulled slightly towards the simplex centre, u_j = n_j / s_j with
     // the node's own (partial) column sums -- any scale is as good as any other
-    const float n1 = __builtin_fmaf(0.98f, c.wn1, 0.02f / 3.0f), n2 = __builtin_fmaf(0.98f, c.wn2, 0.02f / 3.0f);
-    const bool sums_ok = S1 > 0.0f && S2 > 0.0f;
-    const float w0 = 1.0f - n1 - n2;
-    const float u1 = n1 * __builtin_amdgcn_rcpf(sums_ok ? S1 : 1.0f), u2 = n2 * __builtin_amdgcn_rcpf(sums_ok ? S2 : 1.0f);
-    sv2f L = {0.f, 0.f}, T0 = L, T1 = L, T2 = L, W00 = L, W01 = L, W02 = L, W11 = L, W12 = L, W22 = L;
-    float qmin = __builtin_inff();
-    const sv2f vw0 = {w0, w0}, vu1 = {u1, u1}, vu2 = {u2, u2};
-    auto body = [&](sv2f x, sv2f y, sv2f R) {
-        sv2f q = __builtin_elementwise_fma(x, vu1, __builtin_elementwise_fma(y, vu2, vw0));
-        qmin = fminf(qmin, fminf(q.x, q.y));
-        sv2f w = {__builtin_amdgcn_rcpf(q.x), __builtin_amdgcn_rcpf(q.y)};
-        L = __builtin_elementwise_fma(R, sv2f{__builtin_amdgcn_logf(q.x), __builtin_amdgcn_logf(q.y)}, L);
-        sv2f t = R * w;
+    const F n1 = sv_fma(F(0.98), c.wn1, F(0.02 / 3.0)), n2 = sv_fma(F(0.98), c.wn2, F(0.02 / 3.0));
+    const bool sums_ok = S1 > F(0) && S2 > F(0);
+    const F w0 = F(1) - n1 - n2;
+    const F u1 = n1 * sv_rcp(sums_ok ? S1 : F(1)), u2 = n2 * sv_rcp(sums_ok ? S2 : F(1));
+    v2 L = {F(0), F(0)}, T0 = L, T1 = L, T2 = L, W00 = L, W01 = L, W02 = L, W11 = L, W12 = L, W22 = L;
+    F qmin = F(__builtin_inff());
+    const v2 vw0 = {w0, w0}, vu1 = {u1, u1}, vu2 = {u2, u2};
+    auto body = [&](v2 x, v2 y, v2 R) {
+        v2 q = __builtin_elementwise_fma(x, vu1, __builtin_elementwise_fma(y, vu2, vw0));
+        qmin = sv_min(qmin, sv_min(q.x, q.y));
+        v2 w = {sv_rcp(q.x), sv_rcp(q.y)};
+        L = __builtin_elementwise_fma(R, v2{sv_lg2(q.x), sv_lg2(q.y)}, L);
+        v2 t = R * w;
         T0 += t;
         T1 = __builtin_elementwise_fma(t, x, T1);
         T2 = __builtin_elementwise_fma(t, y, T2);
-        sv2f tw = t * w;
+        v2 tw = t * w;
         W00 += tw;
-        sv2f twx = tw * x, twy = tw * y;
+        v2 twx = tw * x, twy = tw * y;
         W01 += twx;
         W02 += twy;
         W11 = __builtin_elementwise_fma(twx, x, W11);
@@ -347,30 +403,29 @@ __device__ __forceinline__ void sv_parent(SvCtx<ML> &c, bool take, unsigned code
         W22 = __builtin_elementwise_fma(twy, y, W22);
     };
     if (take) {
-        const float4 *fXY = c.W->fXY;
-        const float2 *fRR = c.W->fRR;
+        const Sv4<F> *fXY = c.W->fXY;
+        const Sv2<F> *fRR = c.W->fRR;
 #pragma unroll 2
         for (int p = 0; p < c.GP; p++) {
-            const float4 xy = fXY[p];
-            const float2 rr = fRR[p];
-            body(sv2f{xy.x, xy.y}, sv2f{xy.z, xy.w}, sv2f{rr.x, rr.y});
+            const Sv4<F> xy = fXY[p];
+            const Sv2<F> rr = fRR[p];
+            body(v2{xy.x, xy.y}, v2{xy.z, xy.w}, v2{rr.x, rr.y});
         }
         // the ML - 1 path rows: pairs, an odd one with a copy of itself of weight 0
 #pragma unroll
-        for (int j = 0; j + 1 < ML - 1; j += 2) body(sv2f{px[j], px[j + 1]}, sv2f{py[j], py[j + 1]}, sv2f{c.leafRf[j], c.leafRf[j + 1]});
-        if ((ML - 1) & 1) body(sv2f{px[ML - 2], px[ML - 2]}, sv2f{py[ML - 2], py[ML - 2]}, sv2f{c.leafRf[ML - 2], 0.0f});
-        const bool usable = sums_ok && qmin > 0.0f;
-        float4 *dst = c.W->par[c.lane];
-        dst[0] = make_float4(L.x + L.y, T0.x + T0.y, T1.x + T1.y, T2.x + T2.y);
-        dst[1] = make_float4(W00.x + W00.y, W01.x + W01.y, W02.x + W02.y, W11.x + W11.y);
-        dst[2] = make_float4(W12.x + W12.y, W22.x + W22.y, S1, S2);
-        dst[3] = make_float4(w0, u1, u2, __uint_as_float(code | (usable ? 0x80000000u : 0u)));
+        for (int j = 0; j + 1 < ML - 1; j += 2) body(v2{px[j], px[j + 1]}, v2{py[j], py[j + 1]}, v2{c.leafRf[j], c.leafRf[j + 1]});
+        if ((ML - 1) & 1) body(v2{px[ML - 2], px[ML - 2]}, v2{py[ML - 2], py[ML - 2]}, v2{c.leafRf[ML - 2], F(0)});
+        const bool usable = sums_ok && qmin > F(0);
+        const F rec[16] = {L.x + L.y, T0.x + T0.y, T1.x + T1.y, T2.x + T2.y, W00.x + W00.y, W01.x + W01.y, W02.x + W02.y, W11.x + W11.y,
+                           W12.x + W12.y, W22.x + W22.y, S1, S2, w0, u1, u2, F(0)};
+        c.W->par.put(c.lane, rec);
+        c.W->pcode[c.lane] = code | (usable ? 0x80000000u : 0u);
     }
 }
 
 // leaf rows of a child as the queue / the contender list hold them: two rows {a, b, a', b'} per dword
-template <int ML>
-__device__ __forceinline__ void sv_child_rows(const SvCtx<ML> &c, unsigned code, unsigned slot, unsigned (&rw)[ML / 2]) {
+template <int ML, class F>
+__device__ __forceinline__ void sv_child_rows(const SvCtx<ML, F> &c, unsigned code, unsigned slot, unsigned (&rw)[ML / 2]) {
 #pragma unroll
     for (int j = 0; j < ML / 2; j++) {
         rw[j] = c.S->row16[(code >> (12 * j)) & 63u];
@@ -380,73 +435,73 @@ __device__ __forceinline__ void sv_child_rows(const SvCtx<ML> &c, unsigned code,
 }
 
 // The candidates [0, total) of the round (less the task window), one lane per child.
-template <int ML>
-__device__ __forceinline__ void sv_children(SvCtx<ML> &c, int total) {
+template <int ML, class F>
+__device__ __forceinline__ void sv_children(SvCtx<ML, F> &c, int total) {
     const unsigned long long sk = c.skip < (unsigned long long)total ? c.skip : (unsigned long long)total;
     c.skip -= sk;
     const int lo = (int)sk;
     const unsigned long long room = (unsigned long long)(total - lo);
     const int nrec = (int)(room < c.remaining ? room : c.remaining);
     if (nrec <= 0) return;
-    const float Rl = c.leafRf[ML - 1], Nl = c.leafN[ML - 1];
+    const F Rl = c.leafRf[ML - 1], Nl = c.leafN[ML - 1];
     for (int k0 = 0; k0 < nrec; k0 += WAVE) {
         const int k = k0 + c.lane;
         const bool act = k < nrec;
         const unsigned kd = act ? c.W->kid[lo + k] : 0u;
         const unsigned slot = kd & 0xffu, pl = kd >> 8;
-        const float4 *P = c.W->par[pl];
-        const float4 p0 = P[0], p1 = P[1], p2 = P[2], p3 = P[3];
-        const unsigned code = __float_as_uint(p3.w);
+        F P[16];
+        c.W->par.get(pl, P);
+        const unsigned code = c.W->pcode[pl];
         const unsigned r16 = c.S->row16[slot];
-        const float x = (float)(r16 & 0xffu), y = (float)(r16 >> 8);
-        const float s1 = __builtin_fmaf(x, Nl, p2.z), s2 = __builtin_fmaf(y, Nl, p2.w);
-        const bool regular = s1 > 0.0f && s2 > 0.0f;
+        const F x = (F)(r16 & 0xffu), y = (F)(r16 >> 8);
+        const F s1 = sv_fma(x, Nl, P[10]), s2 = sv_fma(y, Nl, P[11]);
+        const bool regular = s1 > F(0) && s2 > F(0);
         const unsigned off = (unsigned)(c.done + (unsigned long long)k);
         if (act && !regular) degenerate_append(c.A.ctr, c.A.deg, c.A.deg_cap, c.base + off);
         c.n_deg += (unsigned)__builtin_popcountll(ballot64(act && !regular));
-        const float w0 = p3.x, u1 = p3.y, u2 = p3.z;
-        const float q = __builtin_fmaf(x, u1, __builtin_fmaf(y, u2, w0));
-        bool ev = act && regular && (code >> 31) && q > 0.0f;
+        const F w0 = P[12], u1 = P[13], u2 = P[14];
+        const F q = sv_fma(x, u1, sv_fma(y, u2, w0));
+        bool ev = act && regular && (code >> 31) && q > F(0);
         bool push = act && regular && !ev;                // no usable shared point: the child starts from the centre in the queue
         bool surv = false;
-        float qu1 = (1.0f / 3.0f) * __builtin_amdgcn_rcpf(s1), qu2 = (1.0f / 3.0f) * __builtin_amdgcn_rcpf(s2);
+        F qu1 = F(1.0 / 3.0) * sv_rcp(s1), qu2 = F(1.0 / 3.0) * sv_rcp(s2);
         c.n_it += (unsigned)__builtin_popcountll(ballot64(ev));
         c.n_child += (unsigned)__builtin_popcountll(ballot64(ev));
         if (ev) {
-            const float w = __builtin_amdgcn_rcpf(q), t = Rl * w, tw = t * w, twx = tw * x, twy = tw * y;
-            const float L = __builtin_fmaf(Rl, __builtin_amdgcn_logf(q), p0.x);
-            const float T0 = p0.y + t, T1 = __builtin_fmaf(t, x, p0.z), T2 = __builtin_fmaf(t, y, p0.w);
-            const float W00 = p1.x + tw, W01 = p1.y + twx, W02 = p1.z + twy;
-            const float W11 = __builtin_fmaf(twx, x, p1.w), W12 = __builtin_fmaf(twx, y, p2.x), W22 = __builtin_fmaf(twy, y, p2.y);
+            const F w = sv_rcp(q), t = Rl * w, tw = t * w, twx = tw * x, twy = tw * y;
+            const F L = sv_fma(Rl, sv_lg2(q), P[0]);
+            const F T0 = P[1] + t, T1 = sv_fma(t, x, P[2]), T2 = sv_fma(t, y, P[3]);
+            const F W00 = P[4] + tw, W01 = P[5] + twx, W02 = P[6] + twy;
+            const F W11 = sv_fma(twx, x, P[7]), W12 = sv_fma(twx, y, P[8]), W22 = sv_fma(twy, y, P[9]);
             // tangent space of the child's slice z.w = const: d = (-s1 d1 - s2 d2, d1, d2)
-            const float G1 = __builtin_fmaf(-s1, T0, T1), G2 = __builtin_fmaf(-s2, T0, T2);
-            const float A1 = __builtin_fmaf(-s1, W00, W01), A2 = __builtin_fmaf(-s2, W00, W02);      // W0j - s_j W00
-            const float H11 = __builtin_fmaf(-s1, A1, __builtin_fmaf(-s1, W01, W11));
-            const float H12 = __builtin_fmaf(-s2, A1, __builtin_fmaf(-s1, W02, W12));
-            const float H22 = __builtin_fmaf(-s2, A2, __builtin_fmaf(-s2, W02, W22));
-            const float hh = H11 * H22, det = __builtin_fmaf(-H12, H12, hh);
-            const float zw = __builtin_fmaf(s1, u1, __builtin_fmaf(s2, u2, w0));
-            if (!(det > (float)N3_COND_MIN * hh) || !(zw > 0.0f)) {
+            const F G1 = sv_fma(-s1, T0, T1), G2 = sv_fma(-s2, T0, T2);
+            const F A1 = sv_fma(-s1, W00, W01), A2 = sv_fma(-s2, W00, W02);      // W0j - s_j W00
+            const F H11 = sv_fma(-s1, A1, sv_fma(-s1, W01, W11));
+            const F H12 = sv_fma(-s2, A1, sv_fma(-s1, W02, W12));
+            const F H22 = sv_fma(-s2, A2, sv_fma(-s2, W02, W22));
+            const F hh = H11 * H22, det = sv_fma(-H12, H12, hh);
+            const F zw = sv_fma(s1, u1, sv_fma(s2, u2, w0));
+            if (!(det > (F)N3_COND_MIN * hh) || !(zw > F(0))) {
                 push = true;                              // ill-conditioned for these sums: full evaluations from the centre
             } else {
-                const float idet = __builtin_amdgcn_rcpf(det);
-                const float d1 = (H22 * G1 - H12 * G2) * idet, d2 = (H11 * G2 - H12 * G1) * idet;
-                const float l2 = (G1 * d1 + G2 * d2) * c.inv_Rtot;
-                const float val2 = __builtin_fmaf(-c.rtot_f, __builtin_amdgcn_logf(zw), L);
-                if (!(l2 == l2) || !(fabsf(d1) + fabsf(d2) < 1e30f)) {
+                const F idet = sv_rcp(det);
+                const F d1 = (H22 * G1 - H12 * G2) * idet, d2 = (H11 * G2 - H12 * G1) * idet;
+                const F l2 = (G1 * d1 + G2 * d2) * c.inv_Rtot;
+                const F val2 = sv_fma(-c.rtot_f, sv_lg2(zw), L);
+                if (!(l2 == l2) || !(sv_abs(d1) + sv_abs(d2) < F(1e30))) {
                     push = true;
                 } else {
-                    float step = 1.0f;
-                    if (l2 > 0.09f) step = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_sqrtf(l2));
+                    F step = F(1);
+                    if (l2 > F(0.09)) step = sv_rcp(F(1) + sv_sqrt(l2));
                     // the stepped point on the child's own slice (z.d = 0, so z.w stays): mixture n_j = s_j u_j / z.w
-                    const float sc = __builtin_amdgcn_rcpf(zw);
-                    const float v1 = __builtin_fmaf(step, d1, u1) * sc, v2 = __builtin_fmaf(step, d2, u2) * sc;
-                    if (fabsf(s1 * v1) + fabsf(s2 * v2) < 1e6f) {
+                    const F sc = sv_rcp(zw);
+                    const F v1 = sv_fma(step, d1, u1) * sc, v2 = sv_fma(step, d2, u2) * sc;
+                    if (sv_abs(s1 * v1) + sv_abs(s2 * v2) < F(1e6)) {
                         c.wn1 = s1 * v1;                  // the lane's chain: a recent optimum of this neighbourhood
                         c.wn2 = s2 * v2;
                     }
-                    if (!sv_dismissed<ML>(c, val2, l2)) {
-                        if (l2 < c.conv_l2 && l2 * c.rtot_over_rmin < 0.25f) {   // converged, not finished by the bound: a contender (see sv_drain)
+                    if (!sv_dismissed<ML, F>(c, val2, l2)) {
+                        if (l2 < c.conv_l2 && l2 * c.rtot_over_rmin < F(0.25)) {   // converged, not finished by the bound: a contender (see sv_drain)
                             const double v = (c.K0 - 0.6931471805599453 * (double)val2) - 0.5 * (double)(l2 * c.rtot_f) - c.screen_margin;
                             surv = !c.no_dismiss || !(v > c.thr);
                         } else {
@@ -464,10 +519,10 @@ __device__ __forceinline__ void sv_children(SvCtx<ML> &c, int total) {
         const unsigned long long pm = ballot64(push), sm = ballot64(surv);
         if (pm | sm) {
             unsigned rw[ML / 2];
-            sv_child_rows<ML>(c, code, slot, rw);
-            if (surv) sv_survivor<ML>(c, rw, off);
+            sv_child_rows<ML, F>(c, code, slot, rw);
+            if (surv) sv_survivor<ML, F>(c, rw, off);
             if (pm) {
-                if (c.qcount + __builtin_popcountll(pm) > SV_QCAP) sv_drain<ML>(c);
+                if (c.qcount + __builtin_popcountll(pm) > SV_QCAP) sv_drain<ML, F>(c);
                 if (push) {
                     const int pos = c.qcount + mbcnt(pm);
 #pragma unroll
@@ -485,15 +540,15 @@ __device__ __forceinline__ void sv_children(SvCtx<ML> &c, int total) {
     c.remaining -= (unsigned long long)nrec;
 }
 
-template <int ML>
-__device__ __forceinline__ unsigned long long sv_child_mask(const SvCtx<ML> &c, const N3State &node, int l) {
+template <int ML, class F>
+__device__ __forceinline__ unsigned long long sv_child_mask(const SvCtx<ML, F> &c, const N3State &node, int l) {
     unsigned long long mk = c.S->smask[l][node.slot] & c.dynmask[((size_t)node.slot * c.NT1 + node.lo) * c.NT1 + (node.hi - 1)];
     return node.sw ? (mk & c.swm) : mk;
 }
 
 // Expand the nodes of leaf level LVL (LVL = 0: the prefix's last node; else the level's list [0 .. n_in)) in rank order.
-template <int ML, int LVL>
-__device__ __forceinline__ void sv_expand(SvCtx<ML> &c, int n_in) {
+template <int ML, int LVL, class F>
+__device__ __forceinline__ void sv_expand(SvCtx<ML, F> &c, int n_in) {
     constexpr bool last = (LVL == ML - 1);
     const int cap = last ? SV_KIDS : (LVL == 0 ? N3_MAX_Q : SV_CAP);
     int pos = 0;
@@ -553,10 +608,10 @@ __device__ __forceinline__ void sv_expand(SvCtx<ML> &c, int n_in) {
                     *dst++ = (unsigned short)((unsigned)s | tag);
                 }
             }
-            sv_parent<ML>(c, take && cnt > 0, code);
+            sv_parent<ML, F>(c, take && cnt > 0, code);
             c.n_par += (unsigned)__builtin_popcountll(ballot64(take && cnt > 0));
             wave_lds_sync();
-            sv_children<ML>(c, total);
+            sv_children<ML, F>(c, total);
             wave_lds_sync();
         } else {
             const unsigned ps = n3_pack(node);
@@ -569,7 +624,7 @@ __device__ __forceinline__ void sv_expand(SvCtx<ML> &c, int n_in) {
                 }
             }
             wave_lds_sync();
-            sv_expand<ML, LVL + 1>(c, total);
+            sv_expand<ML, LVL + 1, F>(c, total);
             wave_lds_sync();
         }
         if (c.remaining == 0) return;
@@ -615,11 +670,11 @@ __device__ __forceinline__ bool sv_next_prefix(const N3Dev &P, unsigned &st0, un
     }
 }
 
-template <int ML>
-__global__ __launch_bounds__(64 * SV_WAVES, SV_OCC) void n3_sieve_kernel(N3Dev Pg, SearchArgs A, const N3Task *tasks, const unsigned *stbuf,
+template <int ML, class F>
+__global__ __launch_bounds__(64 * SV_WAVES, sizeof(F) == 4 ? SV_OCC : SV_OCC64) void n3_sieve_kernel(N3Dev Pg, SearchArgs A, const N3Task *tasks, const unsigned *stbuf,
                                                                           int ntasks, SvSurvivor *surv, unsigned surv_cap,
                                                                           unsigned *surv_count) {
-    __shared__ SvLds<ML> S;
+    __shared__ SvLds<ML, F> S;
     const int m = Pg.m, D = m - ML, Q = Pg.Q;
     for (int i = threadIdx.x; i < m; i += blockDim.x) {
         S.lb[i] = Pg.lb[i];
@@ -645,7 +700,7 @@ __global__ __launch_bounds__(64 * SV_WAVES, SV_OCC) void n3_sieve_kernel(N3Dev P
     unsigned st = lane < D ? stbuf[(size_t)task * N3_STB + lane] : 0u;
     unsigned st1 = lane + WAVE < D ? stbuf[(size_t)task * N3_STB + WAVE + lane] : 0u;    // (m > 70: depths 64 .. D-1)
 
-    SvCtx<ML> c;
+    SvCtx<ML, F> c;
     c.S = &S;
     c.W = &S.w[wv];
     c.dynmask = Pg.dynmask;
@@ -666,11 +721,11 @@ __global__ __launch_bounds__(64 * SV_WAVES, SV_OCC) void n3_sieve_kernel(N3Dev P
     c.done = 0;
     c.K0 = Pg.K0;
     c.screen_margin = 2e-5 * Pg.Rtot + 1.0;            // f32 sums: |error| <= Rtot (|ln q| 2^-23 + 2^-22) stays far below this
-    c.rtot_f = (float)Pg.Rtot;
-    c.inv_Rtot = (float)(1.0 / Pg.Rtot);
-    c.conv_l2 = (float)Pg.conv_l2;
+    c.rtot_f = (F)Pg.Rtot;
+    c.inv_Rtot = (F)(1.0 / Pg.Rtot);
+    c.conv_l2 = (F)Pg.conv_l2;
     c.no_dismiss = Pg.no_dismiss;
-    c.wn1 = c.wn2 = 1.0f / 3.0f;
+    c.wn1 = c.wn2 = F(1.0 / 3.0);
     c.qcount = 0;
     c.n_eval = c.n_dis = c.n_it = c.n_deg = c.n_surv = 0;
     c.n_par = c.n_prefix = 0;
@@ -680,12 +735,12 @@ __global__ __launch_bounds__(64 * SV_WAVES, SV_OCC) void n3_sieve_kernel(N3Dev P
 #pragma unroll
     for (int l = 0; l < ML; l++) {
         leafR[l] = Pg.r[D + l];                        // (uniform address: scalar loads)
-        c.leafRf[l] = (float)leafR[l];
-        c.leafN[l] = (float)(Pg.rN[D + l] * inv_N);
+        c.leafRf[l] = (F)leafR[l];
+        c.leafN[l] = (F)(Pg.rN[D + l] * inv_N);
     }
     if (lane == 0) {
 #pragma unroll
-        for (int l = 0; l < ML; l += 2) c.W->fRL[l >> 1] = make_float2((float)leafR[l], (float)leafR[l + 1]);
+        for (int l = 0; l < ML; l += 2) c.W->fRL[l >> 1] = Sv2<F>{(F)leafR[l], (F)leafR[l + 1]};
     }
     unsigned long long n_terms = 0, n_pterms = 0;
 
@@ -717,14 +772,14 @@ __global__ __launch_bounds__(64 * SV_WAVES, SV_OCC) void n3_sieve_kernel(N3Dev P
                     Rs += __shfl_xor(Rs, o, WAVE);
                     Ns += __shfl_xor(Ns, o, WAVE);
                 }
-                const float a = (float)(q & 15u), b = (float)(q >> 4);
+                const F a = (F)(q & 15u), b = (F)(q >> 4);
                 if (lane == 0) {
-                    float *xy = (float *)&c.W->fXY[G >> 1];
-                    float *rr = (float *)&c.W->fRR[G >> 1];
+                    F *xy = (F *)&c.W->fXY[G >> 1];
+                    F *rr = (F *)&c.W->fRR[G >> 1];
                     if (G & 1) {
-                        xy[1] = a; xy[3] = b; rr[1] = (float)Rs;
+                        xy[1] = a; xy[3] = b; rr[1] = (F)Rs;
                     } else {   // also fills the second half: stays as the weight-0 pad when this is the last term
-                        xy[0] = xy[1] = a; xy[2] = xy[3] = b; rr[0] = (float)Rs; rr[1] = 0.0f;
+                        xy[0] = xy[1] = a; xy[2] = xy[3] = b; rr[0] = (F)Rs; rr[1] = F(0);
                     }
                 }
                 S1p += (double)a * Ns;
@@ -739,15 +794,15 @@ __global__ __launch_bounds__(64 * SV_WAVES, SV_OCC) void n3_sieve_kernel(N3Dev P
         if (!(Rmin < __builtin_inf())) Rmin = 1.0;
         c.G = G;
         c.GP = (G + 1) >> 1;
-        c.S1p = (float)(S1p * inv_N);
-        c.S2p = (float)(S2p * inv_N);
-        c.rtot_over_rmin = (float)(Pg.Rtot / Rmin);
+        c.S1p = (F)(S1p * inv_N);
+        c.S2p = (F)(S2p * inv_N);
+        c.rtot_over_rmin = (F)(Pg.Rtot / Rmin);
         wave_lds_sync();
         const unsigned long long it0 = c.n_dit, par0 = c.n_par;
         c.par = n3_unpack(sv_state(st, st1, D - 1));
         c.n_prefix++;
-        sv_expand<ML, 0>(c, 1);
-        if (c.qcount) sv_drain<ML>(c);                 // the tile changes with the prefix: the queue is emptied first
+        sv_expand<ML, 0, F>(c, 1);
+        if (c.qcount) sv_drain<ML, F>(c);                 // the tile changes with the prefix: the queue is emptied first
         n_terms += (c.n_dit - it0) * (unsigned)(G + ML);          // full evaluations: every term of the candidate
         n_pterms += (c.n_par - par0) * (unsigned)(G + ML - 1);    // shared sums of a last-level node: all terms but its children's
         c.skip = 0;                                    // only the first prefix of a task starts mid-way
@@ -784,7 +839,7 @@ __device__ __noinline__ int sv_reference_outcome(int m, double tau, const double
 }
 
 __global__ __launch_bounds__(256) void n3_finish_kernel(N3Dev P, SearchArgs A, const SvSurvivor *surv, unsigned surv_cap,
-                                                        const unsigned *surv_count) {
+                                                        const unsigned *surv_count, unsigned *accepted_count) {
     __shared__ double rr[N3_MAX_M_WIDE], rn[N3_MAX_M_WIDE];
     const int m = P.m;
     unsigned n = *surv_count;
@@ -856,6 +911,7 @@ __global__ __launch_bounds__(256) void n3_finish_kernel(N3Dev P, SearchArgs A, c
     double nll = P.K0 - acc;
     if (accept) {
         atomicAdd(&A.ctr->accepted, 1ull);
+        atomicAdd(accepted_count, 1u);               // (per slice: a slice redone by the fused kernel takes that kernel's count)
         if (!(nll <= best + A.window)) return;       // its own minimum is beyond the window: whatever the reference reports is too
         // The minimum lies in the simplex -- but does the reference find it?  (n3.hip, n3_cold_path: same decision.)
         double nu[3];
@@ -934,12 +990,17 @@ int n3_sieve_levels(const N3Dev &P) {
 void n3_launch_sieve(const N3Dev &P, const SearchArgs &A, const N3Task *tasks, const unsigned *stbuf, int ntasks, SvSurvivor *surv,
                      unsigned surv_cap, unsigned *surv_count, hipStream_t st) {
     dim3 grid((ntasks + SV_WAVES - 1) / SV_WAVES), block(64 * SV_WAVES);
-    if (P.L <= 4) hipLaunchKernelGGL((n3_sieve_kernel<4>), grid, block, 0, st, P, A, tasks, stbuf, ntasks, surv, surv_cap, surv_count);
-    else hipLaunchKernelGGL((n3_sieve_kernel<6>), grid, block, 0, st, P, A, tasks, stbuf, ntasks, surv, surv_cap, surv_count);
+    if (P.force64) {       // FP64 throughout (n3_force_f64): the same kernel on doubles
+        if (P.L <= 4) hipLaunchKernelGGL((n3_sieve_kernel<4, double>), grid, block, 0, st, P, A, tasks, stbuf, ntasks, surv, surv_cap, surv_count);
+        else hipLaunchKernelGGL((n3_sieve_kernel<6, double>), grid, block, 0, st, P, A, tasks, stbuf, ntasks, surv, surv_cap, surv_count);
+    } else {
+        if (P.L <= 4) hipLaunchKernelGGL((n3_sieve_kernel<4, float>), grid, block, 0, st, P, A, tasks, stbuf, ntasks, surv, surv_cap, surv_count);
+        else hipLaunchKernelGGL((n3_sieve_kernel<6, float>), grid, block, 0, st, P, A, tasks, stbuf, ntasks, surv, surv_cap, surv_count);
+    }
 }
 
 void n3_launch_finish(const N3Dev &P, const SearchArgs &A, const SvSurvivor *surv, unsigned surv_cap, const unsigned *surv_count,
-                      hipStream_t st) {
+                      unsigned *accepted_count, hipStream_t st) {
     // (a grid for a full list: blocks beyond the count leave at once)
-    hipLaunchKernelGGL(n3_finish_kernel, dim3((surv_cap + 255) / 256), dim3(256), 0, st, P, A, surv, surv_cap, surv_count);
+    hipLaunchKernelGGL(n3_finish_kernel, dim3((surv_cap + 255) / 256), dim3(256), 0, st, P, A, surv, surv_cap, surv_count, accepted_count);
 }

@@ -13,4 +13,4 @@ int n3_sieve_levels(const N3Dev &P);
 void n3_launch_sieve(const N3Dev &P, const SearchArgs &A, const N3Task *tasks, const unsigned *stbuf, int ntasks, SvSurvivor *surv,
                      unsigned surv_cap, unsigned *surv_count, hipStream_t st);
 void n3_launch_finish(const N3Dev &P, const SearchArgs &A, const SvSurvivor *surv, unsigned surv_cap, const unsigned *surv_count,
-                      hipStream_t st);
+                      unsigned *accepted_count, hipStream_t st);

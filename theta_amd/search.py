@@ -381,19 +381,38 @@ def do_optimization_distributed(n, m, k, tau, lower_bounds, upper_bounds, r, rN,
     rep = SearchReport()
     g, G = comm.rank, comm.world
 
+    shared = []
+
     def share(local_min):
+        shared.append(True)
         return float(comm.allreduce_min([local_min])[0])
 
+    # Every rank goes through the SAME sequence of collectives whatever happens to it: a data-dependent failure of one shard
+    # (a device list that stays full, ERR_CAPACITY) must not leave the others waiting in the exchange -- RCCL has no time-out.
+    # A rank that fails still takes part in the hint all-reduce (with +inf) and in an all-reduce(max) of a status flag right
+    # after the search; then all ranks leave together, each with the failing rank's error code (round-2 advice).
+    failure = None
+    problem = recs = stats = None
     try:
         problem, ctx, recs, stats = _search_local(n, m, tau, lower_bounds, upper_bounds, r, rN, max_normal, shard=(g, G), ctx=ctx,
                                                   report=rep, hint_exchange=share if G > 1 else None)
     except _lib.NoCandidates:
         print("Error: No valid Copy Number Profiles exist for these intervals within the bounds specified. Exiting...")
-        sys.exit(1)
+        sys.exit(1)                                           # (a property of the problem: the same on every rank)
     except _lib.ThetaError as e:
         if e.code in (_lib.ERR_OVERFLOW, _lib.ERR_ARG):      # (the same on every rank: all of them leave here)
             _friendly_exit(e)
-        raise
+        failure = e
+    if G > 1:
+        if failure is not None and not shared:
+            share(float("inf"))
+        worst = int(comm.allreduce_max([float(failure.code) if failure is not None else 0.0])[0])
+        if worst:
+            if failure is not None:
+                raise failure
+            raise _lib.ThetaError(worst, "another rank's shard failed with this status; all ranks leave together")
+    elif failure is not None:
+        raise failure
     merged, gmin = comm.exchange_finalists(n, m, recs, COLLECT_WINDOW)
     q1 = _q1_record(ctx, n, m, tau, r, rN, max_normal) if n == 3 else None
     best = replay_ties(merged, n, tau, sorted_index, first_duplicate=(n == 2), report=rep, q1_first=q1)
