@@ -96,8 +96,9 @@ def test_fp64_sieve_and_full_solve_modes_return_the_lists_of_the_shipped_search(
     cases.append(("m9 k3", 9, r7, rN7, [0] * 9, [3] * 9, [("all", None)], 2))
     r8, rN8, _ = bench.synth(seed=12, m=20, n=3, k=7)
     cases.append(("m20 k7", 20, r8, rN8, [0] * 20, [7] * 20, [("mid", 1 << 22)], 2))
-    r9, rN9, _ = bench.synth(seed=13, m=100, n=3, k=2)              # two intervals per lane
-    cases.append(("m100 k2", 100, r9, rN9, [0] * 100, [2] * 100, [("mid", 1 << 22)], 2))
+    from test_gpu_wide import _wide_instance
+    rs9, rNs9, _o, _t, lb9, ub9 = _wide_instance(100, 501, 2)       # two intervals per lane
+    cases.append(("m100 wide", 100, rs9, rNs9, lb9, ub9, [("all", None)], 2))
     ra, rNa, _ = bench.synth(seed=14, m=16, n=3, k=3)
     ra = list(ra)
     ra[0], ra[7] = 3, 11

@@ -511,7 +511,7 @@ static int run_search(theta_problem *p, u128 b, u128 e, double window, double *d
                 n3_launch_tasks(PS, b, e, per_task, ntasks, (N3Task *)p->d_tasks.p, (unsigned *)p->d_stbuf.p, st);
                 HIP_TRY(hipEventRecord(ctx->ev1, st));
                 int per_slice = (int)std::max<uint64_t>(1, SIEVE_SLICE / per_task);
-                while ((ntasks + per_slice - 1) / per_slice > SIEVE_MAX_SLICES - 4) per_slice *= 2;
+                while ((ntasks + per_slice - 1) / per_slice > SIEVE_MAX_SLICES - 6) per_slice *= 2;   // (+ 4 bootstrap slices; the last counter is the redo's)
                 // The sieve judges candidates against the running minimum, and only the finish kernel lowers it.  A call that
                 // starts without one (no hint, first pass) works its way up through short slices first -- 1, 8, 64, 512 tasks --
                 // so that the bulk of the range is sieved against a minimum that some candidate really attains.
@@ -560,34 +560,69 @@ static int run_search(theta_problem *p, u128 b, u128 e, double window, double *d
         kernel_ms += ms;
         HIP_TRY(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
         setup_ms += ms;
-        // A slice of the sieve whose contender list overflowed (a stretch of near-ties) is redone by the fused kernel, which is
-        // complete by itself; its records join the same device lists (theta_search drops duplicates by rank).
+        // A slice of the sieve whose contender list overflowed is redone.  The usual cause is a STALE minimum: the slice runs into
+        // a region whose candidates beat the running minimum it was judged against, so a large share of them looks like a
+        // contender.  The finish kernel has meanwhile gone through the 2^24 that were listed and lowered the minimum, so the same
+        // slice, sieved again, lists few; if it overflows again it is cut into 8 parts (each part's finish lowers the minimum
+        // for the next); a part that still overflows -- a genuine stretch of 2^24 near-ties -- goes to the fused kernel, which
+        // is complete by itself.  Records join the same device lists (theta_search drops duplicates by rank).
         uint64_t redone = 0, redone_accepted_by_finish = 0;
         double redo_ms = 0.0;
         for (size_t sl = 0; sl < slices.size(); sl++) {
             if (hcnt[sl] <= SURV_CAP) continue;
             redone_accepted_by_finish += hacc[sl];
-            if (p->m > N3_MAX_M) {      // (the fused kernel holds one interval per lane)
-                theta_set_error("n=3, m = %d: %u contenders in one slice exceed the list (%u): pass a hint (theta_problem_hint) or "
-                                "search a shorter range", p->m, hcnt[sl], SURV_CAP);
-                return THETA_ERR_CAPACITY;
-            }
             const int t0 = slices[sl].first, nts = slices[sl].second;
             const u128 sb = b + (u128)t0 * sieve_per_task;
             u128 se = sb + (u128)nts * sieve_per_task;
             if (se > e) se = e;
-            HIP_TRY(hipEventRecord(ctx->ev0, st));
-            n3_launch_tasks(p->n3, sb, se, sieve_per_task, nts, (N3Task *)p->d_tasks.p, (unsigned *)p->d_stbuf.p, st);
-            HIP_TRY(hipEventRecord(ctx->ev1, st));
-            n3_launch_search(p->n3, A, (const N3Task *)p->d_tasks.p, (const unsigned *)p->d_stbuf.p, nts, sieve_per_task, st);
-            HIP_TRY(hipEventRecord(ctx->ev2, st));
-            HIP_TRY(hipStreamSynchronize(st));
-            HIP_TRY(hipGetLastError());
-            HIP_TRY(hipEventElapsedTime(&ms, ctx->ev1, ctx->ev2));
-            redo_ms += ms;
-            HIP_TRY(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
-            setup_ms += ms;
             redone += (uint64_t)(se - sb);
+            N3Dev PS = p->n3;
+            PS.L = n3_sieve_levels(p->n3);
+            unsigned *cnt2 = (unsigned *)p->d_survcnt.p + (SIEVE_MAX_SLICES - 1), *acc2 = (unsigned *)p->d_survacc.p + (SIEVE_MAX_SLICES - 1);
+            // sieve + finish over tasks [ta, ta + na) of the rebuilt task list of this slice; returns the contender count
+            auto again = [&](int ta, int na, unsigned &count) -> int {
+                HIP_TRY(hipMemsetAsync(cnt2, 0, sizeof(unsigned), st));
+                HIP_TRY(hipEventRecord(ctx->ev1, st));
+                n3_launch_sieve(PS, A, (const N3Task *)p->d_tasks.p + ta, (const unsigned *)p->d_stbuf.p + (size_t)ta * N3_STB, na,
+                                (SvSurvivor *)p->d_surv.p, SURV_CAP, cnt2, st);
+                n3_launch_finish(PS, A, (const SvSurvivor *)p->d_surv.p, SURV_CAP, cnt2, acc2, st);
+                HIP_TRY(hipEventRecord(ctx->ev2, st));
+                HIP_TRY(hipMemcpyAsync(&count, cnt2, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+                HIP_TRY(hipStreamSynchronize(st));
+                HIP_TRY(hipGetLastError());
+                HIP_TRY(hipEventElapsedTime(&ms, ctx->ev1, ctx->ev2));
+                redo_ms += ms;
+                return THETA_OK;
+            };
+            n3_launch_tasks(PS, sb, se, sieve_per_task, nts, (N3Task *)p->d_tasks.p, (unsigned *)p->d_stbuf.p, st);
+            unsigned count = 0;
+            int rc2 = again(0, nts, count);
+            if (rc2) return rc2;
+            if (count <= SURV_CAP) continue;
+            const int part = (nts + 7) / 8;
+            for (int ta = 0; ta < nts; ta += part) {
+                const int na = std::min(part, nts - ta);
+                if ((rc2 = again(ta, na, count))) return rc2;
+                if (count <= SURV_CAP) continue;
+                if (p->m > N3_MAX_M) {      // (the fused kernel holds one interval per lane)
+                    theta_set_error("n=3, m = %d: %u contenders in one slice exceed the list (%u): pass a hint (theta_problem_hint) or "
+                                    "search a shorter range", p->m, count, SURV_CAP);
+                    return THETA_ERR_CAPACITY;
+                }
+                const u128 fb = sb + (u128)ta * sieve_per_task;
+                u128 fe = fb + (u128)na * sieve_per_task;
+                if (fe > se) fe = se;
+                n3_launch_tasks(p->n3, fb, fe, sieve_per_task, na, (N3Task *)p->d_tasks.p, (unsigned *)p->d_stbuf.p, st);
+                HIP_TRY(hipEventRecord(ctx->ev1, st));
+                n3_launch_search(p->n3, A, (const N3Task *)p->d_tasks.p, (const unsigned *)p->d_stbuf.p, na, sieve_per_task, st);
+                HIP_TRY(hipEventRecord(ctx->ev2, st));
+                HIP_TRY(hipStreamSynchronize(st));
+                HIP_TRY(hipGetLastError());
+                HIP_TRY(hipEventElapsedTime(&ms, ctx->ev1, ctx->ev2));
+                redo_ms += ms;
+                // (the sieve's task list of this slice is rebuilt for the parts that follow)
+                n3_launch_tasks(PS, sb, se, sieve_per_task, nts, (N3Task *)p->d_tasks.p, (unsigned *)p->d_stbuf.p, st);
+            }
         }
         if (redone) {
             // The redone slices were counted once by the sieve; what the fused kernel did on them is reported APART
@@ -607,6 +642,10 @@ static int run_search(theta_problem *p, u128 b, u128 e, double window, double *d
             R.final_terms = after.final_terms - got.final_terms;
             R.dismissed = after.dismissed - got.dismissed;
             R.terms64 = after.terms64 - got.terms64;
+            R.sieve_pterms = after.sieve_pterms - got.sieve_pterms;
+            R.sieve_children = after.sieve_children - got.sieve_children;
+            R.sieve_survivors = after.sieve_survivors - got.sieve_survivors;
+            R.finish_iterations = after.finish_iterations - got.finish_iterations;
             const unsigned long long acc = got.accepted - std::min<unsigned long long>(got.accepted, redone_accepted_by_finish) + R.accepted;
             SearchCounters merged = after;                     // lists, minima and list counts: the latest
             merged.evaluated = got.evaluated;
@@ -616,6 +655,10 @@ static int run_search(theta_problem *p, u128 b, u128 e, double window, double *d
             merged.final_terms = got.final_terms;
             merged.dismissed = got.dismissed;
             merged.terms64 = got.terms64;
+            merged.sieve_pterms = got.sieve_pterms;
+            merged.sieve_children = got.sieve_children;
+            merged.sieve_survivors = got.sieve_survivors;
+            merged.finish_iterations = got.finish_iterations;
             merged.accepted = acc;
             got = merged;
             p->last_redo_ms += redo_ms;
@@ -704,31 +747,31 @@ extern "C" int theta_search(theta_problem *p, const uint64_t rank_begin[2], cons
         stats->terms = hc.terms;
         stats->dismissed = hc.dismissed;
         stats->list_overflow = dropped;
-        double per = (p->n == 2) ? FLOPS_PER_TERM_ITER_N2 : FLOPS_PER_TERM_ITER_N3;
-        double fin = (p->n == 2) ? FLOPS_PER_FINAL_TERM_N2 : FLOPS_PER_FINAL_TERM_N3;
-        if (p->n == 2) {
-            stats->flops = (uint64_t)(per * (double)hc.terms + fin * (double)hc.final_terms);
-            stats->flops_f32 = 0;
-        } else if (p->last_sieve64) {
-            // n=3, the sieve in FP64 (n3_force_f64): every evaluation on doubles; the one single-precision operation per term is
-            // the logarithm of the screened value (v_log_f32).  FP64 reciprocals are v_rcp_f64 + one Newton-Raphson step (+ 4).
-            const double full = (double)(hc.terms - hc.terms64);
-            stats->flops = (uint64_t)(per * ((double)hc.terms64 + (double)hc.finish_iterations * (double)p->m) +
-                                      (FLOPS_PER_TERM_ITER_N3_F32 + 3.0) * full + (FLOPS_PER_TERM_SIEVE_SHARED + 3.0) * (double)hc.sieve_pterms +
-                                      (FLOPS_PER_SIEVE_CHILD + 14.0) * (double)hc.sieve_children);
-            stats->flops_f32 = (uint64_t)(full + (double)hc.sieve_pterms + 2.0 * (double)hc.sieve_children);
-        } else {   // n=3: FP64 iterations (dump, ill-conditioned candidates, the finish kernel: m terms each) + the packed-f32
-                   // coarse pass and screen
-            stats->flops = (uint64_t)(per * ((double)hc.terms64 + (double)hc.finish_iterations * (double)p->m));
-            stats->flops_f32 = (uint64_t)(FLOPS_PER_TERM_ITER_N3_F32 * (double)(hc.terms - hc.terms64) + fin * (double)hc.final_terms +
-                                          FLOPS_PER_TERM_SIEVE_SHARED * (double)hc.sieve_pterms + FLOPS_PER_SIEVE_CHILD * (double)hc.sieve_children);
-        }
-        {   // slices redone by the fused kernel (contender list full): its work, apart
-            const SearchCounters &R = p->last_redo;
-            stats->redo_flops = (uint64_t)(per * (double)R.terms64);
-            stats->redo_flops_f32 = (uint64_t)(FLOPS_PER_TERM_ITER_N3_F32 * (double)(R.terms - R.terms64) + fin * (double)R.final_terms);
-            stats->redo_kernel_ms = p->last_redo_ms;
-        }
+        const double per = (p->n == 2) ? FLOPS_PER_TERM_ITER_N2 : FLOPS_PER_TERM_ITER_N3;
+        const double fin = (p->n == 2) ? FLOPS_PER_FINAL_TERM_N2 : FLOPS_PER_FINAL_TERM_N3;
+        auto count_flops = [&](const SearchCounters &k, uint64_t &f64, uint64_t &f32) {
+            if (p->n == 2) {
+                f64 = (uint64_t)(per * (double)k.terms + fin * (double)k.final_terms);
+                f32 = 0;
+            } else if (p->last_sieve64) {
+                // n=3, the sieve in FP64 (n3_force_f64): every evaluation on doubles; the one single-precision operation per term is
+                // the logarithm of the screened value (v_log_f32).  FP64 reciprocals are v_rcp_f64 + one Newton-Raphson step (+ 4
+                // per reciprocal), the error bound of the logarithms one more FMA per term (+ 2).
+                const double full = (double)(k.terms - k.terms64);
+                f64 = (uint64_t)(per * ((double)k.terms64 + (double)k.finish_iterations * (double)p->m) +
+                                 (FLOPS_PER_TERM_ITER_N3_F32 + 5.0) * full + (FLOPS_PER_TERM_SIEVE_SHARED + 5.0) * (double)k.sieve_pterms +
+                                 (FLOPS_PER_SIEVE_CHILD + 18.0) * (double)k.sieve_children + fin * (double)k.final_terms);
+                f32 = (uint64_t)(full + (double)k.sieve_pterms + 2.0 * (double)k.sieve_children);
+            } else {   // n=3: FP64 iterations (dump, ill-conditioned candidates, the finish kernel: m terms each) + the packed-f32
+                       // coarse pass and screen
+                f64 = (uint64_t)(per * ((double)k.terms64 + (double)k.finish_iterations * (double)p->m));
+                f32 = (uint64_t)(FLOPS_PER_TERM_ITER_N3_F32 * (double)(k.terms - k.terms64) + fin * (double)k.final_terms +
+                                 FLOPS_PER_TERM_SIEVE_SHARED * (double)k.sieve_pterms + FLOPS_PER_SIEVE_CHILD * (double)k.sieve_children);
+            }
+        };
+        count_flops(hc, stats->flops, stats->flops_f32);
+        count_flops(p->last_redo, stats->redo_flops, stats->redo_flops_f32);    // slices redone (contender list full): apart
+        stats->redo_kernel_ms = p->last_redo_ms;
         stats->survivors = hc.sieve_survivors;
         stats->fallback_candidates = p->last_fallback;
         stats->best_nll = best;

@@ -482,7 +482,7 @@ __global__ __launch_bounds__(256) void n2_enumerate_lines_kernel(N2Dev P, unsign
 // ------------------------------------------------------------------------------------------------
 // The whole-line generator with the records RENDERED by scatter + prefix sum (n2_render.hpp) instead of summed break-point by
 // break-point into every word.  Same run / tile / store scheme as n2_enumerate_lines_kernel.  Selected with
-// THETA_N2_ENUM_RENDER=1 (off by default in round 2: its per-lane logic is verified on the CPU -- tools/n2_render_emul.hip runs
+// (the default since round 3; THETA_N2_ENUM_RENDER=0 selects the summing writer) -- its per-lane logic is verified on the CPU: tools/n2_render_emul.hip runs
 // this very code lane by lane against the oracle's enumeration, tests/test_n2_render_cpu.py -- but it has not been on the GPU).
 // ------------------------------------------------------------------------------------------------
 #include "n2_render.hpp"
@@ -580,7 +580,7 @@ void n2_launch_enumerate(const N2Dev &P, unsigned long long begin, unsigned long
             const unsigned blocks = (unsigned)((threads + 255) / 256);
             const size_t base = (((size_t)P.m * N2_KVS * 8 + (N2_KVS + 1 + 3) * 2 + P.m + 15) & ~(size_t)15);
             const size_t sm2 = base + (size_t)4 * WAVE * N2L_STRIDE * 4;
-            if (const char *e = getenv("THETA_N2_ENUM_RENDER"); e && atoi(e) > 0) {
+            if (const char *e = getenv("THETA_N2_ENUM_RENDER"); !e || atoi(e) > 0) {      // the default since round 3 (0: the summing whole-line writer)
                 if (P.kv <= 8) {
                     (void)hipFuncSetAttribute((const void *)n2_enumerate_render_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sm2 + 64));
                     hipLaunchKernelGGL(n2_enumerate_render_kernel<8>, dim3(blocks), dim3(256), sm2 + 64, st, P, begin, count, T, out);

@@ -174,8 +174,8 @@ struct SvCtx {
     F S1p, S2p;                      // column sums of the prefix rows (weighted by the normal counts), / N
     F leafN[ML];                     // normal counts of the leaf rows / N
     F leafRf[ML];                    // tumour counts of the leaf rows
-    F rtot_f, rtot_over_rmin, inv_Rtot, conv_l2;
-    double K0, screen_margin, thr;   // thr = running minimum + window, refreshed per prefix
+    F rtot_f, rtot_over_rmin, inv_Rtot, conv_l2, fine_l2;
+    double K0, screen_margin, thr;   // thr = running minimum + window, refreshed per prefix; screen_margin: see sv_bound
     int no_dismiss;
     // lane-private chain: mixture fractions of the optimum of the lane's previous record
     F wn1, wn2;
@@ -193,9 +193,9 @@ struct SvCtx {
 // val2 = sum R log2 q and l2 = lambda^2 / Rtot at the OLD one), 1 = stepped and converged (l2 < conv), 2 = outside the domain
 // (u1, u2 halved towards 0), 3 = no usable step (ill-conditioned Hessian, NaN).
 template <int ML, class F>
-__device__ __forceinline__ int sv_step(const SvCtx<ML, F> &c, const unsigned (&rw)[ML / 2], F s1, F s2, F &u1, F &u2, F &val2, F &l2) {
+__device__ __forceinline__ int sv_step(const SvCtx<ML, F> &c, const unsigned (&rw)[ML / 2], F s1, F s2, F &u1, F &u2, F &val2, F &l2, F &la) {
     typedef typename SvVec<F>::v2 v2;
-    v2 g1 = {F(0), F(0)}, g2 = g1, h11 = g1, h12 = g1, h22 = g1, lg = g1;
+    v2 g1 = {F(0), F(0)}, g2 = g1, h11 = g1, h12 = g1, h22 = g1, lg = g1, lga = g1;
     F qmin = F(__builtin_inff());
     const v2 vs1 = {s1, s1}, vs2 = {s2, s2}, vu1 = {u1, u1}, vu2 = {u2, u2}, one = {F(1), F(1)};
     auto body = [&](v2 x, v2 y, v2 R) {
@@ -203,7 +203,9 @@ __device__ __forceinline__ int sv_step(const SvCtx<ML, F> &c, const unsigned (&r
         v2 q = __builtin_elementwise_fma(a, vu1, __builtin_elementwise_fma(b, vu2, one));
         qmin = sv_min(qmin, sv_min(q.x, q.y));
         v2 w = {sv_rcp(q.x), sv_rcp(q.y)};
-        lg = __builtin_elementwise_fma(R, v2{sv_lg2(q.x), sv_lg2(q.y)}, lg);
+        const v2 l = {sv_lg2(q.x), sv_lg2(q.y)};
+        lg = __builtin_elementwise_fma(R, l, lg);
+        if constexpr (sizeof(F) == 8) lga = __builtin_elementwise_fma(R, v2{sv_abs(l.x), sv_abs(l.y)}, lga);   // (error bound of the f32 logarithms, sv_bound)
         v2 t = R * w;
         g1 = __builtin_elementwise_fma(t, a, g1);
         g2 = __builtin_elementwise_fma(t, b, g2);
@@ -242,6 +244,7 @@ __device__ __forceinline__ int sv_step(const SvCtx<ML, F> &c, const unsigned (&r
     const F d2 = (H11 * G2 - H12 * G1) * idet;
     l2 = (G1 * d1 + G2 * d2) * c.inv_Rtot;
     val2 = lg.x + lg.y;
+    la = lga.x + lga.y;
     if (!(l2 == l2) || !(sv_abs(d1) + sv_abs(d2) < F(1e30))) return 3;
     F step = F(1);
     if (l2 > F(0.09)) step = sv_rcp(F(1) + sv_sqrt(l2));
@@ -252,15 +255,25 @@ __device__ __forceinline__ int sv_step(const SvCtx<ML, F> &c, const unsigned (&r
     return (l2 < c.conv_l2 && l2 * c.rtot_over_rmin < F(0.25)) ? 1 : 0;
 }
 
-// Is the candidate finished by the lower bound of its optimum?  (evaluated at the iterate BEFORE the step)
+// A rigorous LOWER BOUND of the candidate's optimum from one evaluation (value sum val2 = sum R log2 q and decrement
+// l2 = lambda^2 / Rtot at the same point): NLL is self-concordant with parameter 2 / sqrt(Rmin), hence
+//      min NLL >= NLL(u) - lambda^2 / (2 (1 - lambda / sqrt(Rmin)))        whenever lambda / sqrt(Rmin) < 1/2,
+// less what the computed value may be off by:
+//   F = float   sums in single precision: 2e-5 Rtot + 1 (screen_margin; |error| <= Rtot (|ln q| 2^-23 + 2^-22) stays far below)
+//   F = double  the sums are exact to ~1e-15; only the logarithms are single precision (v_log_f32 of (float) q: |error| <=
+//               2^-24 / ln 2 from the conversion + one ulp of the result), so the value is off by at most
+//               8.7e-8 Rtot + 1.3e-7 sum R |log2 q| (`la`, accumulated next to the value) -- a few units instead of 133 on the
+//               bench's data: the contender list of the FP64 mode holds genuine near-ties only.
+// -inf when the bound does not apply (lambda / sqrt(Rmin) >= 1/2).
 template <int ML, class F>
-__device__ __forceinline__ bool sv_dismissed(const SvCtx<ML, F> &c, F val2, F l2) {
+__device__ __forceinline__ double sv_bound(const SvCtx<ML, F> &c, F val2, F l2, F la) {
     const F lt2 = l2 * c.rtot_over_rmin;
-    if (!(lt2 < F(0.25)) || c.no_dismiss) return false;
+    if (!(lt2 < F(0.25))) return -__builtin_inf();
     const F lt = sv_sqrt(lt2);
     const double gap = 1.05 * 0.5 * (double)(l2 * c.rtot_f * sv_rcp(F(1) - lt));
-    const double lb = (c.K0 - 0.6931471805599453 * (double)val2) - gap - c.screen_margin;
-    return lb > c.thr;
+    double margin = c.screen_margin;
+    if constexpr (sizeof(F) == 8) margin = 0.6931471805599453 * (8.7e-8 * (double)c.rtot_f + 1.3e-7 * (double)la) + 1e-3;
+    return (c.K0 - 0.6931471805599453 * (double)val2) - gap - margin;
 }
 
 // column sums / N of a record: (s1, s2); false if a tumour column is all zero (degenerate: the reference's Chat is NaN)
@@ -317,21 +330,22 @@ __device__ __forceinline__ void sv_drain(SvCtx<ML, F> &c) {
             c.n_it += (unsigned)__builtin_popcountll(ballot64(live));
             c.n_dit += (unsigned)__builtin_popcountll(ballot64(live));
             if (live) {
-                F val2 = F(0), l2 = F(0);
-                const int st = sv_step<ML, F>(c, rw, s1, s2, u1, u2, val2, l2);
+                F val2 = F(0), l2 = F(0), la = F(0);
+                const int st = sv_step<ML, F>(c, rw, s1, s2, u1, u2, val2, l2, la);
                 iters++;
                 if (st == 3 || iters >= 40) {
                     surv = true;                 // ill-conditioned / stuck: the finish kernel solves it in FP64
                     live = false;
                 } else if (st != 2) {
-                    if (sv_dismissed<ML, F>(c, val2, l2)) {
+                    // the bound finishes a candidate as soon as it applies (not in the full-solve mode, which iterates every
+                    // candidate to the coarse tolerance first); a converged candidate it does not finish is a contender -- once
+                    // the decrement is below fine_l2 (FP64: the gap of the bound is then a fraction of a unit; float: at once,
+                    // the margin of the single-precision sums dominates anyway).  The finish kernel decides exactly.
+                    const bool beyond = sv_bound<ML, F>(c, val2, l2, la) > c.thr;
+                    if (beyond && (!c.no_dismiss || st == 1)) {
                         live = false;
-                    } else if (st == 1) {
-                        // Converged to the coarse tolerance and NOT finished by the rigorous bound: a contender -- the finish
-                        // kernel decides exactly.  (Only the no-dismissal mode, which values every candidate itself, drops it on
-                        // the value at the old iterate less lambda^2/2, the optimum up to the screening margin.)
-                        const double v = (c.K0 - 0.6931471805599453 * (double)val2) - 0.5 * (double)(l2 * c.rtot_f) - c.screen_margin;
-                        surv = !c.no_dismiss || !(v > c.thr);
+                    } else if (st == 1 && l2 < c.fine_l2) {
+                        surv = true;
                         live = false;
                     }
                 }
@@ -360,7 +374,8 @@ __device__ __forceinline__ void sv_drain(SvCtx<ML, F> &c) {
 // space of the child's slice (d0 = -s1 d1 - s2 d2), and has the Newton decrement and the lower bound of the child's optimum
 // for ~1/3 of the work of a full evaluation.  NLL = K0 - ln2 (L - Rtot log2(z.w)): scale invariant, so w needs no
 // normalisation.  Children the bound cannot finish go to the queue and continue with full evaluations at their own iterate.
-// Record of a node (SvPlanes, 16 numbers): 0 L, 1..3 T0 T1 T2, 4..9 W00 W01 W02 W11 W12 W22, 10 11 S1 S2, 12..14 w0 u1 u2.
+// Record of a node (SvPlanes, 16 numbers): 0 L, 1..3 T0 T1 T2, 4..9 W00 W01 W02 W11 W12 W22, 10 11 S1 S2, 12..14 w0 u1 u2,
+// 15 sum R |log2 q| (F = double: the error bound of the single-precision logarithms, sv_bound).
 template <int ML, class F>
 __device__ __forceinline__ void sv_parent(SvCtx<ML, F> &c, bool take, unsigned code) {
     typedef typename SvVec<F>::v2 v2;
@@ -381,14 +396,16 @@ __device__ __forceinline__ void sv_parent(SvCtx<ML, F> &c, bool take, unsigned c
     const bool sums_ok = S1 > F(0) && S2 > F(0);
     const F w0 = F(1) - n1 - n2;
     const F u1 = n1 * sv_rcp(sums_ok ? S1 : F(1)), u2 = n2 * sv_rcp(sums_ok ? S2 : F(1));
-    v2 L = {F(0), F(0)}, T0 = L, T1 = L, T2 = L, W00 = L, W01 = L, W02 = L, W11 = L, W12 = L, W22 = L;
+    v2 L = {F(0), F(0)}, T0 = L, T1 = L, T2 = L, W00 = L, W01 = L, W02 = L, W11 = L, W12 = L, W22 = L, LA = L;
     F qmin = F(__builtin_inff());
     const v2 vw0 = {w0, w0}, vu1 = {u1, u1}, vu2 = {u2, u2};
     auto body = [&](v2 x, v2 y, v2 R) {
         v2 q = __builtin_elementwise_fma(x, vu1, __builtin_elementwise_fma(y, vu2, vw0));
         qmin = sv_min(qmin, sv_min(q.x, q.y));
         v2 w = {sv_rcp(q.x), sv_rcp(q.y)};
-        L = __builtin_elementwise_fma(R, v2{sv_lg2(q.x), sv_lg2(q.y)}, L);
+        const v2 l = {sv_lg2(q.x), sv_lg2(q.y)};
+        L = __builtin_elementwise_fma(R, l, L);
+        if constexpr (sizeof(F) == 8) LA = __builtin_elementwise_fma(R, v2{sv_abs(l.x), sv_abs(l.y)}, LA);
         v2 t = R * w;
         T0 += t;
         T1 = __builtin_elementwise_fma(t, x, T1);
@@ -417,7 +434,7 @@ __device__ __forceinline__ void sv_parent(SvCtx<ML, F> &c, bool take, unsigned c
         if ((ML - 1) & 1) body(v2{px[ML - 2], px[ML - 2]}, v2{py[ML - 2], py[ML - 2]}, v2{c.leafRf[ML - 2], F(0)});
         const bool usable = sums_ok && qmin > F(0);
         const F rec[16] = {L.x + L.y, T0.x + T0.y, T1.x + T1.y, T2.x + T2.y, W00.x + W00.y, W01.x + W01.y, W02.x + W02.y, W11.x + W11.y,
-                           W12.x + W12.y, W22.x + W22.y, S1, S2, w0, u1, u2, F(0)};
+                           W12.x + W12.y, W22.x + W22.y, S1, S2, w0, u1, u2, LA.x + LA.y};
         c.W->par.put(c.lane, rec);
         c.W->pcode[c.lane] = code | (usable ? 0x80000000u : 0u);
     }
@@ -469,7 +486,8 @@ __device__ __forceinline__ void sv_children(SvCtx<ML, F> &c, int total) {
         c.n_child += (unsigned)__builtin_popcountll(ballot64(ev));
         if (ev) {
             const F w = sv_rcp(q), t = Rl * w, tw = t * w, twx = tw * x, twy = tw * y;
-            const F L = sv_fma(Rl, sv_lg2(q), P[0]);
+            const F lq = sv_lg2(q);
+            const F L = sv_fma(Rl, lq, P[0]);
             const F T0 = P[1] + t, T1 = sv_fma(t, x, P[2]), T2 = sv_fma(t, y, P[3]);
             const F W00 = P[4] + tw, W01 = P[5] + twx, W02 = P[6] + twy;
             const F W11 = sv_fma(twx, x, P[7]), W12 = sv_fma(twx, y, P[8]), W22 = sv_fma(twy, y, P[9]);
@@ -487,7 +505,10 @@ __device__ __forceinline__ void sv_children(SvCtx<ML, F> &c, int total) {
                 const F idet = sv_rcp(det);
                 const F d1 = (H22 * G1 - H12 * G2) * idet, d2 = (H11 * G2 - H12 * G1) * idet;
                 const F l2 = (G1 * d1 + G2 * d2) * c.inv_Rtot;
-                const F val2 = sv_fma(-c.rtot_f, sv_lg2(zw), L);
+                const F lz = sv_lg2(zw);
+                const F val2 = sv_fma(-c.rtot_f, lz, L);
+                F la = F(0);
+                if constexpr (sizeof(F) == 8) la = sv_fma(c.rtot_f, sv_abs(lz), sv_fma(Rl, sv_abs(lq), P[15]));
                 if (!(l2 == l2) || !(sv_abs(d1) + sv_abs(d2) < F(1e30))) {
                     push = true;
                 } else {
@@ -500,15 +521,17 @@ __device__ __forceinline__ void sv_children(SvCtx<ML, F> &c, int total) {
                         c.wn1 = s1 * v1;                  // the lane's chain: a recent optimum of this neighbourhood
                         c.wn2 = s2 * v2;
                     }
-                    if (!sv_dismissed<ML, F>(c, val2, l2)) {
-                        if (l2 < c.conv_l2 && l2 * c.rtot_over_rmin < F(0.25)) {   // converged, not finished by the bound: a contender (see sv_drain)
-                            const double v = (c.K0 - 0.6931471805599453 * (double)val2) - 0.5 * (double)(l2 * c.rtot_f) - c.screen_margin;
-                            surv = !c.no_dismiss || !(v > c.thr);
-                        } else {
-                            push = true;
-                            qu1 = v1;
-                            qu2 = v2;
-                        }
+                    // (same decisions as in sv_drain)
+                    const bool conv = l2 < c.conv_l2 && l2 * c.rtot_over_rmin < F(0.25);
+                    const bool beyond = sv_bound<ML, F>(c, val2, l2, la) > c.thr;
+                    if (beyond && (!c.no_dismiss || conv)) {
+                        // finished: the bound (search) / converged and valued beyond the window (full solve)
+                    } else if (conv && l2 < c.fine_l2) {
+                        surv = true;
+                    } else {
+                        push = true;
+                        qu1 = v1;
+                        qu2 = v2;
                     }
                 }
             }
@@ -724,6 +747,7 @@ __global__ __launch_bounds__(64 * SV_WAVES, sizeof(F) == 4 ? SV_OCC : SV_OCC64) 
     c.rtot_f = (F)Pg.Rtot;
     c.inv_Rtot = (F)(1.0 / Pg.Rtot);
     c.conv_l2 = (F)Pg.conv_l2;
+    c.fine_l2 = sizeof(F) == 8 ? (F)fmin(Pg.conv_l2, 1e-8) : c.conv_l2;
     c.no_dismiss = Pg.no_dismiss;
     c.wn1 = c.wn2 = F(1.0 / 3.0);
     c.qcount = 0;

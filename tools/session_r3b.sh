@@ -9,5 +9,5 @@ timeout 900 python -m pytest tests/test_gpu_round3.py tests/test_gpu_zzz_render.
 tail -30 $OUT/pytest_gpu.log
 THETA_BENCH_VERBOSE=1 timeout 500 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-traffic --no-extras > $OUT/bench_short.json 2> $OUT/bench_short.err
 tail -c 2500 $OUT/bench_short.json; tail -30 $OUT/bench_short.err
-THETA_N2_ENUM_RENDER=1 timeout 200 python tools/enum_profile.py > $OUT/enumerate_render.json 2> $OUT/enumerate_render.err
+timeout 200 python tools/enum_profile.py > $OUT/enumerate_render.json 2> $OUT/enumerate_render.err
 grep "n2_" $OUT/enumerate_render.err
