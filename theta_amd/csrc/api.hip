@@ -560,6 +560,14 @@ static int run_search(theta_problem *p, u128 b, u128 e, double window, double *d
         kernel_ms += ms;
         HIP_TRY(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
         setup_ms += ms;
+        const SearchCounters raw = got;          // (as the device wrote them)
+        // the sieve does not count what its bound finishes: every regular candidate ends dismissed or listed as a contender
+        auto sieve_dismissed = [&](const SearchCounters &k) -> unsigned long long {
+            if (p->n3.no_dismiss) return 0ull;
+            const unsigned long long gone = k.degenerate + k.sieve_survivors;
+            return k.evaluated > gone ? k.evaluated - gone : 0ull;
+        };
+        if (!slices.empty()) got.dismissed = raw.dismissed + sieve_dismissed(raw);
         // A slice of the sieve whose contender list overflowed is redone.  The usual cause is a STALE minimum: the slice runs into
         // a region whose candidates beat the running minimum it was judged against, so a large share of them looks like a
         // contender.  The finish kernel has meanwhile gone through the 2^24 that were listed and lowered the minimum, so the same
@@ -634,18 +642,18 @@ static int run_search(theta_problem *p, u128 b, u128 e, double window, double *d
             HIP_TRY(hipMemcpyAsync(&after, p->d_ctr.p, sizeof(after), hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));
             SearchCounters &R = p->last_redo;
-            R.evaluated = after.evaluated - got.evaluated;
-            R.accepted = after.accepted - got.accepted;
-            R.degenerate = after.degenerate - got.degenerate;
-            R.iterations = after.iterations - got.iterations;
-            R.terms = after.terms - got.terms;
-            R.final_terms = after.final_terms - got.final_terms;
-            R.dismissed = after.dismissed - got.dismissed;
-            R.terms64 = after.terms64 - got.terms64;
-            R.sieve_pterms = after.sieve_pterms - got.sieve_pterms;
-            R.sieve_children = after.sieve_children - got.sieve_children;
-            R.sieve_survivors = after.sieve_survivors - got.sieve_survivors;
-            R.finish_iterations = after.finish_iterations - got.finish_iterations;
+            R.evaluated = after.evaluated - raw.evaluated;
+            R.accepted = after.accepted - raw.accepted;
+            R.degenerate = after.degenerate - raw.degenerate;
+            R.iterations = after.iterations - raw.iterations;
+            R.terms = after.terms - raw.terms;
+            R.final_terms = after.final_terms - raw.final_terms;
+            R.terms64 = after.terms64 - raw.terms64;
+            R.sieve_pterms = after.sieve_pterms - raw.sieve_pterms;
+            R.sieve_children = after.sieve_children - raw.sieve_children;
+            R.sieve_survivors = after.sieve_survivors - raw.sieve_survivors;
+            R.finish_iterations = after.finish_iterations - raw.finish_iterations;
+            R.dismissed = after.dismissed - raw.dismissed;
             const unsigned long long acc = got.accepted - std::min<unsigned long long>(got.accepted, redone_accepted_by_finish) + R.accepted;
             SearchCounters merged = after;                     // lists, minima and list counts: the latest
             merged.evaluated = got.evaluated;

@@ -169,7 +169,8 @@ struct SvCtx {
     unsigned surv_cap;
     unsigned *surv_count;
     u128 base;                       // rank of the task's first candidate
-    unsigned long long remaining, skip, done;    // candidates of the task still to come / to skip in the first prefix / done
+    unsigned remaining, done;        // candidates of the task still to come / done (a task holds < 2^16)
+    unsigned long long skip;         // leaves of the task's first prefix that precede its first candidate
     // likelihood data of the current prefix
     F S1p, S2p;                      // column sums of the prefix rows (weighted by the normal counts), / N
     F leafN[ML];                     // normal counts of the leaf rows / N
@@ -181,9 +182,11 @@ struct SvCtx {
     F wn1, wn2;
     int qcount;
     // statistics (wave-uniform scalars)
-    unsigned long long n_eval, n_dis, n_it, n_deg, n_surv;
-    unsigned long long n_par, n_prefix;   // last-level nodes evaluated (phase P), prefixes walked
-    unsigned long long n_child, n_dit;   // shared first evaluations (children) / full evaluations (queue)
+    // (32 bits each: a task holds < 2^16 candidates.  Degenerate candidates and contenders are counted where they are listed --
+    // rare paths --, `dismissed` follows on the host: every regular candidate ends dismissed or listed.  Round 2 kept nine 64-bit
+    // counters and six ballots per round of children: scalar registers the kernel does not have, they lived in VGPR lanes.)
+    unsigned n_par, n_prefix;        // last-level nodes evaluated (phase P), prefixes walked
+    unsigned n_child, n_dit;         // shared first evaluations (children) / full evaluations (queue)
 };
 
 
@@ -297,7 +300,8 @@ __device__ __forceinline__ bool sv_sums(const SvCtx<ML, F> &c, const unsigned (&
 template <int ML, class F>
 __device__ __forceinline__ void sv_survivor(const SvCtx<ML, F> &c, const unsigned (&rw)[ML / 2], unsigned off) {
     const unsigned idx = atomicAdd(c.surv_count, 1u);
-    if (idx >= c.surv_cap) return;            // the host sees the count and redoes the slice with the fused kernel
+    atomicAdd(&c.A.ctr->sieve_survivors, 1ull);
+    if (idx >= c.surv_cap) return;            // the host sees the count and redoes the slice
     SvSurvivor *s = c.surv + idx;
     const u128 rk = c.base + off;
     s->rank_lo = (uint64_t)rk;
@@ -311,53 +315,68 @@ __device__ __forceinline__ void sv_survivor(const SvCtx<ML, F> &c, const unsigne
     }
 }
 
-// Further Newton steps for the queued records, 64 at a time: until dismissed, converged (a contender) or given up.
+// Further Newton steps for the queued records: until dismissed, converged (a contender) or given up.  PERSISTENT LANES: a lane
+// whose record is finished takes the next queue entry at once (ballot + prefix count of the idle lanes), so the wave iterates
+// as long as there is work for most of its lanes -- round 2 took the queue 64 at a time in lock step, and with a third of the
+// records needing a second or third step every batch ran three iterations at a fraction of its lanes.
 template <int ML, class F>
 __device__ __forceinline__ void sv_drain(SvCtx<ML, F> &c) {
-    for (int b0 = 0; b0 < c.qcount; b0 += WAVE) {
-        const int idx = b0 + c.lane;
-        bool live = idx < c.qcount;
-        unsigned rw[ML / 2];
+    int next = 0;                                   // (wave-uniform) queue entries handed out so far
+    bool live = false;
+    unsigned rw[ML / 2];
 #pragma unroll
-        for (int j = 0; j < ML / 2; j++) rw[j] = live ? c.W->qRow[idx][j] : 0u;
-        F u1 = live ? c.W->qU1[idx] : F(0), u2 = live ? c.W->qU2[idx] : F(0);
-        const unsigned off = live ? c.W->qOff[idx] : 0u;
-        F s1 = F(1), s2 = F(1);
-        sv_sums<ML, F>(c, rw, s1, s2);
-        int iters = 0;
-        bool surv = false;
-        while (ballot64(live)) {
-            c.n_it += (unsigned)__builtin_popcountll(ballot64(live));
-            c.n_dit += (unsigned)__builtin_popcountll(ballot64(live));
-            if (live) {
-                F val2 = F(0), l2 = F(0), la = F(0);
-                const int st = sv_step<ML, F>(c, rw, s1, s2, u1, u2, val2, l2, la);
-                iters++;
-                if (st == 3 || iters >= 40) {
-                    surv = true;                 // ill-conditioned / stuck: the finish kernel solves it in FP64
-                    live = false;
-                } else if (st != 2) {
-                    // the bound finishes a candidate as soon as it applies (not in the full-solve mode, which iterates every
-                    // candidate to the coarse tolerance first); a converged candidate it does not finish is a contender -- once
-                    // the decrement is below fine_l2 (FP64: the gap of the bound is then a fraction of a unit; float: at once,
-                    // the margin of the single-precision sums dominates anyway).  The finish kernel decides exactly.
-                    const bool beyond = sv_bound<ML, F>(c, val2, l2, la) > c.thr;
-                    if (beyond && (!c.no_dismiss || st == 1)) {
-                        live = false;
-                    } else if (st == 1 && l2 < c.fine_l2) {
-                        surv = true;
-                        live = false;
-                    }
+    for (int j = 0; j < ML / 2; j++) rw[j] = 0u;
+    F u1 = F(0), u2 = F(0), s1 = F(1), s2 = F(1);
+    unsigned off = 0u;
+    int iters = 0;
+    while (true) {
+        const unsigned long long idle = ballot64(!live);
+        if (next < c.qcount && idle) {
+            const int idx = next + mbcnt(idle);
+            if (!live && idx < c.qcount) {
+#pragma unroll
+                for (int j = 0; j < ML / 2; j++) rw[j] = c.W->qRow[idx][j];
+                u1 = c.W->qU1[idx];
+                u2 = c.W->qU2[idx];
+                off = c.W->qOff[idx];
+                sv_sums<ML, F>(c, rw, s1, s2);
+                iters = 0;
+                live = true;
+            }
+            const int room = c.qcount - next, nid = __builtin_popcountll(idle);
+            next += nid < room ? nid : room;
+        }
+        const unsigned long long lm = ballot64(live);
+        if (!lm) break;
+        c.n_dit += (unsigned)__builtin_popcountll(lm);
+        bool fin = false, surv = false;
+        if (live) {
+            F val2 = F(0), l2 = F(0), la = F(0);
+            const int st = sv_step<ML, F>(c, rw, s1, s2, u1, u2, val2, l2, la);
+            iters++;
+            if (st == 3 || iters >= 40) {
+                surv = fin = true;               // ill-conditioned / stuck: the finish kernel solves it in FP64
+            } else if (st != 2) {
+                // the bound finishes a candidate as soon as it applies (not in the full-solve mode, which iterates every
+                // candidate to the coarse tolerance first); a converged candidate it does not finish is a contender -- once
+                // the decrement is below fine_l2 (FP64: the gap of the bound is then a fraction of a unit; float: at once,
+                // the margin of the single-precision sums dominates anyway).  The finish kernel decides exactly.
+                const bool beyond = sv_bound<ML, F>(c, val2, l2, la) > c.thr;
+                if (beyond && (!c.no_dismiss || st == 1)) {
+                    fin = true;
+                } else if (st == 1 && l2 < c.fine_l2) {
+                    surv = fin = true;
                 }
             }
         }
-        if (!c.no_dismiss) c.n_dis += (unsigned)__builtin_popcountll(ballot64(idx < c.qcount && !surv));
-        c.n_surv += (unsigned)__builtin_popcountll(ballot64(surv));
         if (surv) sv_survivor<ML, F>(c, rw, off);
-        // the lane keeps the last optimum it saw as a start for later records
-        if (idx < c.qcount && sv_abs(s1 * u1) + sv_abs(s2 * u2) < F(1e6)) {
-            c.wn1 = s1 * u1;
-            c.wn2 = s2 * u2;
+        if (fin) {
+            // the lane keeps the last optimum it saw as a start for later records
+            if (sv_abs(s1 * u1) + sv_abs(s2 * u2) < F(1e6)) {
+                c.wn1 = s1 * u1;
+                c.wn2 = s2 * u2;
+            }
+            live = false;
         }
     }
     c.qcount = 0;
@@ -458,7 +477,7 @@ __device__ __forceinline__ void sv_children(SvCtx<ML, F> &c, int total) {
     c.skip -= sk;
     const int lo = (int)sk;
     const unsigned long long room = (unsigned long long)(total - lo);
-    const int nrec = (int)(room < c.remaining ? room : c.remaining);
+    const int nrec = (int)(room < (unsigned long long)c.remaining ? room : (unsigned long long)c.remaining);
     if (nrec <= 0) return;
     const F Rl = c.leafRf[ML - 1], Nl = c.leafN[ML - 1];
     for (int k0 = 0; k0 < nrec; k0 += WAVE) {
@@ -473,16 +492,17 @@ __device__ __forceinline__ void sv_children(SvCtx<ML, F> &c, int total) {
         const F x = (F)(r16 & 0xffu), y = (F)(r16 >> 8);
         const F s1 = sv_fma(x, Nl, P[10]), s2 = sv_fma(y, Nl, P[11]);
         const bool regular = s1 > F(0) && s2 > F(0);
-        const unsigned off = (unsigned)(c.done + (unsigned long long)k);
-        if (act && !regular) degenerate_append(c.A.ctr, c.A.deg, c.A.deg_cap, c.base + off);
-        c.n_deg += (unsigned)__builtin_popcountll(ballot64(act && !regular));
+        const unsigned off = c.done + (unsigned)k;
+        if (act && !regular) {
+            degenerate_append(c.A.ctr, c.A.deg, c.A.deg_cap, c.base + off);
+            atomicAdd(&c.A.ctr->degenerate, 1ull);
+        }
         const F w0 = P[12], u1 = P[13], u2 = P[14];
         const F q = sv_fma(x, u1, sv_fma(y, u2, w0));
         bool ev = act && regular && (code >> 31) && q > F(0);
         bool push = act && regular && !ev;                // no usable shared point: the child starts from the centre in the queue
         bool surv = false;
         F qu1 = F(1.0 / 3.0) * sv_rcp(s1), qu2 = F(1.0 / 3.0) * sv_rcp(s2);
-        c.n_it += (unsigned)__builtin_popcountll(ballot64(ev));
         c.n_child += (unsigned)__builtin_popcountll(ballot64(ev));
         if (ev) {
             const F w = sv_rcp(q), t = Rl * w, tw = t * w, twx = tw * x, twy = tw * y;
@@ -536,9 +556,6 @@ __device__ __forceinline__ void sv_children(SvCtx<ML, F> &c, int total) {
                 }
             }
         }
-        c.n_eval += (unsigned)__builtin_popcountll(ballot64(act));
-        if (!c.no_dismiss) c.n_dis += (unsigned)__builtin_popcountll(ballot64(act && regular && !push && !surv));
-        c.n_surv += (unsigned)__builtin_popcountll(ballot64(surv));
         const unsigned long long pm = ballot64(push), sm = ballot64(surv);
         if (pm | sm) {
             unsigned rw[ML / 2];
@@ -559,8 +576,8 @@ __device__ __forceinline__ void sv_children(SvCtx<ML, F> &c, int total) {
             }
         }
     }
-    c.done += (unsigned long long)nrec;
-    c.remaining -= (unsigned long long)nrec;
+    c.done += (unsigned)nrec;
+    c.remaining -= (unsigned)nrec;
 }
 
 template <int ML, class F>
@@ -739,7 +756,7 @@ __global__ __launch_bounds__(64 * SV_WAVES, sizeof(F) == 4 ? SV_OCC : SV_OCC64) 
     c.surv_cap = surv_cap;
     c.surv_count = surv_count;
     c.base = ((u128)tk.base_hi << 64) | tk.base_lo;
-    c.remaining = tk.count;
+    c.remaining = (unsigned)tk.count;
     c.skip = tk.skip;
     c.done = 0;
     c.K0 = Pg.K0;
@@ -751,7 +768,6 @@ __global__ __launch_bounds__(64 * SV_WAVES, sizeof(F) == 4 ? SV_OCC : SV_OCC64) 
     c.no_dismiss = Pg.no_dismiss;
     c.wn1 = c.wn2 = F(1.0 / 3.0);
     c.qcount = 0;
-    c.n_eval = c.n_dis = c.n_it = c.n_deg = c.n_surv = 0;
     c.n_par = c.n_prefix = 0;
     c.n_child = c.n_dit = 0;
     const double inv_N = 1.0 / Pg.N;
@@ -822,29 +838,26 @@ __global__ __launch_bounds__(64 * SV_WAVES, sizeof(F) == 4 ? SV_OCC : SV_OCC64) 
         c.S2p = (F)(S2p * inv_N);
         c.rtot_over_rmin = (F)(Pg.Rtot / Rmin);
         wave_lds_sync();
-        const unsigned long long it0 = c.n_dit, par0 = c.n_par;
+        const unsigned it0 = c.n_dit, par0 = c.n_par;
         c.par = n3_unpack(sv_state(st, st1, D - 1));
         c.n_prefix++;
         sv_expand<ML, 0, F>(c, 1);
         if (c.qcount) sv_drain<ML, F>(c);                 // the tile changes with the prefix: the queue is emptied first
-        n_terms += (c.n_dit - it0) * (unsigned)(G + ML);          // full evaluations: every term of the candidate
-        n_pterms += (c.n_par - par0) * (unsigned)(G + ML - 1);    // shared sums of a last-level node: all terms but its children's
+        n_terms += (unsigned long long)(c.n_dit - it0) * (unsigned)(G + ML);          // full evaluations: every term of the candidate
+        n_pterms += (unsigned long long)(c.n_par - par0) * (unsigned)(G + ML - 1);    // shared sums of a last-level node: all terms but its children's
         c.skip = 0;                                    // only the first prefix of a task starts mid-way
         if (c.remaining == 0) break;
         if (!sv_next_prefix(P, st, st1, D, lane)) break;
         wave_lds_sync();                               // the prefix rows in LDS are rewritten next
     }
     if (lane == 0) {
-        atomicAdd(&A.ctr->evaluated, c.n_eval);
-        atomicAdd(&A.ctr->degenerate, c.n_deg);
-        atomicAdd(&A.ctr->iterations, c.n_it);
+        atomicAdd(&A.ctr->evaluated, (unsigned long long)c.done);
+        atomicAdd(&A.ctr->iterations, (unsigned long long)c.n_child + c.n_dit);
         atomicAdd(&A.ctr->terms, n_terms);
-        atomicAdd(&A.ctr->dismissed, c.n_dis);
-        atomicAdd(&A.ctr->sieve_survivors, c.n_surv);
         atomicAdd(&A.ctr->sieve_pterms, n_pterms);
-        atomicAdd(&A.ctr->sieve_children, c.n_child);
-        atomicAdd(&A.ctr->prof[0], c.n_par);
-        atomicAdd(&A.ctr->prof[7], c.n_prefix);
+        atomicAdd(&A.ctr->sieve_children, (unsigned long long)c.n_child);
+        atomicAdd(&A.ctr->prof[0], (unsigned long long)c.n_par);
+        atomicAdd(&A.ctr->prof[7], (unsigned long long)c.n_prefix);
     }
 }
 
