@@ -524,6 +524,14 @@ static int run_search(theta_problem *p, u128 b, u128 e, double window, double *d
                             slices.push_back({t, k});
                             t += k;
                         }
+                    // A call that starts WITH a minimum may still run into a region whose candidates beat it (a stale minimum: a
+                    // tenth of the bench's candidates looked like contenders in one stretch of twenty).  One short slice first --
+                    // 2048 tasks, one round of the resident waves, 1/32 of a full call -- lets the finish kernel lower the
+                    // minimum on a sample of the range before the bulk is judged against it.
+                    if (t == 0 && ntasks >= 8 * 2048) {
+                        slices.push_back({0, 2048});
+                        t = 2048;
+                    }
                     while (t < ntasks) {
                         const int k = std::min(per_slice, ntasks - t);
                         slices.push_back({t, k});

@@ -176,7 +176,9 @@ struct SvCtx {
     F leafN[ML];                     // normal counts of the leaf rows / N
     F leafRf[ML];                    // tumour counts of the leaf rows
     F rtot_f, rtot_over_rmin, inv_Rtot, conv_l2, fine_l2;
-    double K0, screen_margin, thr;   // thr = running minimum + window, refreshed per prefix; screen_margin: see sv_bound
+    double K0, screen_margin, thr;   // thr = running minimum + window, loaded per task; screen_margin: see sv_beyond
+    F Tcmp;                          // the threshold of sv_beyond's comparison, in F (per task)
+    F sqrt_ror;                      // sqrt(Rtot / Rmin) (per prefix)
     int no_dismiss;
     // lane-private chain: mixture fractions of the optimum of the lane's previous record
     F wn1, wn2;
@@ -185,6 +187,9 @@ struct SvCtx {
     // (32 bits each: a task holds < 2^16 candidates.  Degenerate candidates and contenders are counted where they are listed --
     // rare paths --, `dismissed` follows on the host: every regular candidate ends dismissed or listed.  Round 2 kept nine 64-bit
     // counters and six ballots per round of children: scalar registers the kernel does not have, they lived in VGPR lanes.)
+#ifdef SV_PROF
+    unsigned long long pt[6];        // cycles: 0 group tile, 1 parent phase, 2 children phase (less its drains), 3 drain, 4 prefix successor, 5 whole wave
+#endif
     unsigned n_par, n_prefix;        // last-level nodes evaluated (phase P), prefixes walked
     unsigned n_child, n_dit;         // shared first evaluations (children) / full evaluations (queue)
 };
@@ -208,7 +213,7 @@ __device__ __forceinline__ int sv_step(const SvCtx<ML, F> &c, const unsigned (&r
         v2 w = {sv_rcp(q.x), sv_rcp(q.y)};
         const v2 l = {sv_lg2(q.x), sv_lg2(q.y)};
         lg = __builtin_elementwise_fma(R, l, lg);
-        if constexpr (sizeof(F) == 8) lga = __builtin_elementwise_fma(R, v2{sv_abs(l.x), sv_abs(l.y)}, lga);   // (error bound of the f32 logarithms, sv_bound)
+        if constexpr (sizeof(F) == 8) lga = __builtin_elementwise_fma(R, v2{sv_abs(l.x), sv_abs(l.y)}, lga);   // (error bound of the f32 logarithms, sv_beyond)
         v2 t = R * w;
         g1 = __builtin_elementwise_fma(t, a, g1);
         g2 = __builtin_elementwise_fma(t, b, g2);
@@ -258,25 +263,37 @@ __device__ __forceinline__ int sv_step(const SvCtx<ML, F> &c, const unsigned (&r
     return (l2 < c.conv_l2 && l2 * c.rtot_over_rmin < F(0.25)) ? 1 : 0;
 }
 
-// A rigorous LOWER BOUND of the candidate's optimum from one evaluation (value sum val2 = sum R log2 q and decrement
-// l2 = lambda^2 / Rtot at the same point): NLL is self-concordant with parameter 2 / sqrt(Rmin), hence
-//      min NLL >= NLL(u) - lambda^2 / (2 (1 - lambda / sqrt(Rmin)))        whenever lambda / sqrt(Rmin) < 1/2,
+// Is a rigorous LOWER BOUND of the candidate's optimum beyond the threshold (running minimum + window)?  From one evaluation
+// (value sum val2 = sum R log2 q and decrement l2 = lambda^2 / Rtot at the same point): NLL is self-concordant with parameter
+// 2 / sqrt(Rmin), hence with t = lambda / sqrt(Rmin) < 1/2
+//      min NLL >= NLL(u) - lambda^2 / (2 (1 - t)) >= NLL(u) - (lambda^2 / 2) (1 + t + 2 t^2)         (1/(1-t) <= 1 + t + 2 t^2 on [0, 1/2])
 // less what the computed value may be off by:
 //   F = float   sums in single precision: 2e-5 Rtot + 1 (screen_margin; |error| <= Rtot (|ln q| 2^-23 + 2^-22) stays far below)
 //   F = double  the sums are exact to ~1e-15; only the logarithms are single precision (v_log_f32 of (float) q: |error| <=
 //               2^-24 / ln 2 from the conversion + one ulp of the result), so the value is off by at most
 //               8.7e-8 Rtot + 1.3e-7 sum R |log2 q| (`la`, accumulated next to the value) -- a few units instead of 133 on the
 //               bench's data: the contender list of the FP64 mode holds genuine near-ties only.
-// -inf when the bound does not apply (lambda / sqrt(Rmin) >= 1/2).
+// The test  K0 - ln2 val2 - gap - margin > thr  is made as  ln2 val2 + gap (+ margin) < T  in F, with T = K0 - thr (- margin)
+// rounded DOWN into F by more than the comparison's own rounding (sv_set_threshold) -- no conversions in the hot path.
+// false when the bound does not apply (t >= 1/2).  sl = sqrt(l2), which the caller has anyway.
 template <int ML, class F>
-__device__ __forceinline__ double sv_bound(const SvCtx<ML, F> &c, F val2, F l2, F la) {
-    const F lt2 = l2 * c.rtot_over_rmin;
-    if (!(lt2 < F(0.25))) return -__builtin_inf();
-    const F lt = sv_sqrt(lt2);
-    const double gap = 1.05 * 0.5 * (double)(l2 * c.rtot_f * sv_rcp(F(1) - lt));
-    double margin = c.screen_margin;
-    if constexpr (sizeof(F) == 8) margin = 0.6931471805599453 * (8.7e-8 * (double)c.rtot_f + 1.3e-7 * (double)la) + 1e-3;
-    return (c.K0 - 0.6931471805599453 * (double)val2) - gap - margin;
+__device__ __forceinline__ bool sv_beyond(const SvCtx<ML, F> &c, F val2, F l2, F sl, F la) {
+    const F t = sl * c.sqrt_ror;
+    const F gap = F(1.05 * 0.5) * (l2 * c.rtot_f) * sv_fma(t, sv_fma(F(2), t, F(1)), F(1));
+    F lhs = sv_fma(F(0.6931471805599453), val2, gap);
+    if constexpr (sizeof(F) == 8) lhs += 0.6931471805599453 * (8.7e-8 * c.rtot_f + 1.3e-7 * la) + 1e-3;
+    return t < F(0.5) && lhs < c.Tcmp;
+}
+template <int ML, class F>
+__device__ __forceinline__ void sv_set_threshold(SvCtx<ML, F> &c, double thr) {
+    c.thr = thr;
+    if constexpr (sizeof(F) == 8) {
+        c.Tcmp = c.K0 - thr;                            // (the margin depends on the evaluation: added to the left side)
+    } else {
+        // float: lhs carries <= 3 roundings of relative 2^-24 on magnitudes <= |T| + ~1000 wherever the comparison could flip
+        const double T = c.K0 - thr - c.screen_margin;
+        c.Tcmp = (float)(T - 4e-7 * (fabs(T) + 1000.0) - 0.01);
+    }
 }
 
 // column sums / N of a record: (s1, s2); false if a tumour column is all zero (degenerate: the reference's Chat is NaN)
@@ -321,6 +338,9 @@ __device__ __forceinline__ void sv_survivor(const SvCtx<ML, F> &c, const unsigne
 // records needing a second or third step every batch ran three iterations at a fraction of its lanes.
 template <int ML, class F>
 __device__ __forceinline__ void sv_drain(SvCtx<ML, F> &c) {
+#ifdef SV_PROF
+    const unsigned long long pt0 = __builtin_amdgcn_s_memtime();
+#endif
     int next = 0;                                   // (wave-uniform) queue entries handed out so far
     bool live = false;
     unsigned rw[ML / 2];
@@ -340,6 +360,10 @@ __device__ __forceinline__ void sv_drain(SvCtx<ML, F> &c) {
                 u2 = c.W->qU2[idx];
                 off = c.W->qOff[idx];
                 sv_sums<ML, F>(c, rw, s1, s2);
+                if (!(u1 == u1)) {                    // (no usable first point: from the simplex centre)
+                    u1 = F(1.0 / 3.0) * sv_rcp(s1);
+                    u2 = F(1.0 / 3.0) * sv_rcp(s2);
+                }
                 iters = 0;
                 live = true;
             }
@@ -361,7 +385,7 @@ __device__ __forceinline__ void sv_drain(SvCtx<ML, F> &c) {
                 // candidate to the coarse tolerance first); a converged candidate it does not finish is a contender -- once
                 // the decrement is below fine_l2 (FP64: the gap of the bound is then a fraction of a unit; float: at once,
                 // the margin of the single-precision sums dominates anyway).  The finish kernel decides exactly.
-                const bool beyond = sv_bound<ML, F>(c, val2, l2, la) > c.thr;
+                const bool beyond = sv_beyond<ML, F>(c, val2, l2, sv_sqrt(l2), la);
                 if (beyond && (!c.no_dismiss || st == 1)) {
                     fin = true;
                 } else if (st == 1 && l2 < c.fine_l2) {
@@ -380,6 +404,9 @@ __device__ __forceinline__ void sv_drain(SvCtx<ML, F> &c) {
         }
     }
     c.qcount = 0;
+#ifdef SV_PROF
+    c.pt[3] += __builtin_amdgcn_s_memtime() - pt0;
+#endif
 }
 
 // ---- first evaluation, shared between the children of one last-level node -------------------------------------------
@@ -394,7 +421,7 @@ __device__ __forceinline__ void sv_drain(SvCtx<ML, F> &c) {
 // for ~1/3 of the work of a full evaluation.  NLL = K0 - ln2 (L - Rtot log2(z.w)): scale invariant, so w needs no
 // normalisation.  Children the bound cannot finish go to the queue and continue with full evaluations at their own iterate.
 // Record of a node (SvPlanes, 16 numbers): 0 L, 1..3 T0 T1 T2, 4..9 W00 W01 W02 W11 W12 W22, 10 11 S1 S2, 12..14 w0 u1 u2,
-// 15 sum R |log2 q| (F = double: the error bound of the single-precision logarithms, sv_bound).
+// 15 sum R |log2 q| (F = double: the error bound of the single-precision logarithms, sv_beyond).
 template <int ML, class F>
 __device__ __forceinline__ void sv_parent(SvCtx<ML, F> &c, bool take, unsigned code) {
     typedef typename SvVec<F>::v2 v2;
@@ -470,7 +497,92 @@ __device__ __forceinline__ void sv_child_rows(const SvCtx<ML, F> &c, unsigned co
     rw[ML / 2 - 1] |= (unsigned)c.S->row16[slot] << 16;
 }
 
-// The candidates [0, total) of the round (less the task window), one lane per child.
+// What the shared first evaluation of one child comes to (sv_child_eval): all a lane carries from the arithmetic to the
+// bookkeeping, so that the arithmetic of SEVERAL children per lane can be one straight-line block.
+template <class F>
+struct SvChild {
+    bool act, regular, ev, push, surv;
+    unsigned slot, code, off;
+    F qu1, qu2;                // where the child continues in the queue
+    F n1, n2;                  // its stepped mixture (the lane's chain point), valid if `chain`
+    bool chain;
+};
+
+// Phase C arithmetic for the child k of the round, BRANCH-FREE: every lane computes everything (on harmless inputs where the
+// child does not exist or has no usable shared point) and the outcome is a handful of selects.  A lane's evaluation is one
+// chain of ~100 dependent operations; with two or three waves per SIMD that chain's latency, not the issue rate, was what the
+// children phase cost (44 % of the search kernel's wave cycles, profiles/r3).  Without branches the scheduler interleaves the
+// chains of the SV_CPL children a lane takes per trip.
+template <int ML, class F>
+__device__ __forceinline__ void sv_child_eval(const SvCtx<ML, F> &c, int lo, int k, int nrec, SvChild<F> &o) {
+    const F Rl = c.leafRf[ML - 1], Nl = c.leafN[ML - 1];
+    o.act = k < nrec;
+    const unsigned kd = o.act ? c.W->kid[lo + k] : 0u;
+    o.slot = kd & 0xffu;
+    const unsigned pl = kd >> 8;
+    F P[16];
+    c.W->par.get(pl, P);
+    o.code = c.W->pcode[pl];
+    const unsigned r16 = c.S->row16[o.slot];
+    const F x = (F)(r16 & 0xffu), y = (F)(r16 >> 8);
+    const F s1 = sv_fma(x, Nl, P[10]), s2 = sv_fma(y, Nl, P[11]);
+    o.regular = s1 > F(0) && s2 > F(0);
+    o.off = c.done + (unsigned)k;
+    const F w0 = P[12], u1 = P[13], u2 = P[14];
+    const F q = sv_fma(x, u1, sv_fma(y, u2, w0));
+    o.ev = o.act && o.regular && (o.code >> 31) && q > F(0);
+    const F qs = o.ev ? q : F(1);                     // (lanes without a usable point compute on 1: no NaN factories)
+    const F w = sv_rcp(qs), t = Rl * w, tw = t * w, twx = tw * x, twy = tw * y;
+    const F lq = sv_lg2(qs);
+    const F L = sv_fma(Rl, lq, P[0]);
+    const F T0 = P[1] + t, T1 = sv_fma(t, x, P[2]), T2 = sv_fma(t, y, P[3]);
+    const F W00 = P[4] + tw, W01 = P[5] + twx, W02 = P[6] + twy;
+    const F W11 = sv_fma(twx, x, P[7]), W12 = sv_fma(twx, y, P[8]), W22 = sv_fma(twy, y, P[9]);
+    // tangent space of the child's slice z.w = const: d = (-s1 d1 - s2 d2, d1, d2)
+    const F G1 = sv_fma(-s1, T0, T1), G2 = sv_fma(-s2, T0, T2);
+    const F A1 = sv_fma(-s1, W00, W01), A2 = sv_fma(-s2, W00, W02);      // W0j - s_j W00
+    const F H11 = sv_fma(-s1, A1, sv_fma(-s1, W01, W11));
+    const F H12 = sv_fma(-s2, A1, sv_fma(-s1, W02, W12));
+    const F H22 = sv_fma(-s2, A2, sv_fma(-s2, W02, W22));
+    const F hh = H11 * H22, det = sv_fma(-H12, H12, hh);
+    const F zw = sv_fma(s1, u1, sv_fma(s2, u2, w0));
+    const bool cond_ok = det > (F)N3_COND_MIN * hh && zw > F(0);          // else: ill-conditioned for these sums
+    const F idet = sv_rcp(cond_ok ? det : F(1));
+    const F d1 = (H22 * G1 - H12 * G2) * idet, d2 = (H11 * G2 - H12 * G1) * idet;
+    const F l2 = (G1 * d1 + G2 * d2) * c.inv_Rtot;
+    const F zs = cond_ok ? zw : F(1);
+    const F lz = sv_lg2(zs);
+    const F val2 = sv_fma(-c.rtot_f, lz, L);
+    F la = F(0);
+    if constexpr (sizeof(F) == 8) la = sv_fma(c.rtot_f, sv_abs(lz), sv_fma(Rl, sv_abs(lq), P[15]));
+    const bool num_ok = l2 == l2 && sv_abs(d1) + sv_abs(d2) < F(1e30);
+    const F sl = sv_sqrt(l2);
+    F step = F(1);
+    if (ballot64(l2 > F(0.09))) step = l2 > F(0.09) ? sv_rcp(F(1) + sl) : F(1);      // (damped phase: rare, the branch is wave-uniform)
+    // the stepped point on the child's own slice (z.d = 0, so z.w stays): mixture n_j = s_j u_j / z.w
+    const F sc = sv_rcp(zs);
+    const F v1 = sv_fma(step, d1, u1) * sc, v2 = sv_fma(step, d2, u2) * sc;
+    const bool good = o.ev && cond_ok && num_ok;
+    o.n1 = s1 * v1;
+    o.n2 = s2 * v2;
+    o.chain = good && sv_abs(o.n1) + sv_abs(o.n2) < F(1e6);
+    // (same decisions as in sv_drain)
+    const bool conv = l2 < c.conv_l2 && l2 * c.rtot_over_rmin < F(0.25);
+    const bool beyond = sv_beyond<ML, F>(c, val2, l2, sl, la);
+    const bool done = good && beyond && (!c.no_dismiss || conv);         // the bound (search) / converged and valued beyond the window (full solve)
+    o.surv = good && !done && conv && l2 < c.fine_l2;
+    // queued: another step from the stepped point -- or, without a usable shared point / with ill-conditioned sums, from the
+    // simplex centre (NaN marks that: sv_drain has the record's column sums anyway)
+    o.push = o.act && o.regular && !done && !o.surv;
+    o.qu1 = good ? v1 : F(__builtin_nanf(""));
+    o.qu2 = v2;
+}
+
+#ifndef SV_CPL
+#define SV_CPL 1          // children a lane evaluates per trip (2 measured 3 % slower: the phase is issue bound, not latency bound, and two sets of live values spill)
+#endif
+
+// The candidates [0, total) of the round (less the task window), SV_CPL children per lane and trip.
 template <int ML, class F>
 __device__ __forceinline__ void sv_children(SvCtx<ML, F> &c, int total) {
     const unsigned long long sk = c.skip < (unsigned long long)total ? c.skip : (unsigned long long)total;
@@ -479,100 +591,41 @@ __device__ __forceinline__ void sv_children(SvCtx<ML, F> &c, int total) {
     const unsigned long long room = (unsigned long long)(total - lo);
     const int nrec = (int)(room < (unsigned long long)c.remaining ? room : (unsigned long long)c.remaining);
     if (nrec <= 0) return;
-    const F Rl = c.leafRf[ML - 1], Nl = c.leafN[ML - 1];
-    for (int k0 = 0; k0 < nrec; k0 += WAVE) {
-        const int k = k0 + c.lane;
-        const bool act = k < nrec;
-        const unsigned kd = act ? c.W->kid[lo + k] : 0u;
-        const unsigned slot = kd & 0xffu, pl = kd >> 8;
-        F P[16];
-        c.W->par.get(pl, P);
-        const unsigned code = c.W->pcode[pl];
-        const unsigned r16 = c.S->row16[slot];
-        const F x = (F)(r16 & 0xffu), y = (F)(r16 >> 8);
-        const F s1 = sv_fma(x, Nl, P[10]), s2 = sv_fma(y, Nl, P[11]);
-        const bool regular = s1 > F(0) && s2 > F(0);
-        const unsigned off = c.done + (unsigned)k;
-        if (act && !regular) {
-            degenerate_append(c.A.ctr, c.A.deg, c.A.deg_cap, c.base + off);
-            atomicAdd(&c.A.ctr->degenerate, 1ull);
-        }
-        const F w0 = P[12], u1 = P[13], u2 = P[14];
-        const F q = sv_fma(x, u1, sv_fma(y, u2, w0));
-        bool ev = act && regular && (code >> 31) && q > F(0);
-        bool push = act && regular && !ev;                // no usable shared point: the child starts from the centre in the queue
-        bool surv = false;
-        F qu1 = F(1.0 / 3.0) * sv_rcp(s1), qu2 = F(1.0 / 3.0) * sv_rcp(s2);
-        c.n_child += (unsigned)__builtin_popcountll(ballot64(ev));
-        if (ev) {
-            const F w = sv_rcp(q), t = Rl * w, tw = t * w, twx = tw * x, twy = tw * y;
-            const F lq = sv_lg2(q);
-            const F L = sv_fma(Rl, lq, P[0]);
-            const F T0 = P[1] + t, T1 = sv_fma(t, x, P[2]), T2 = sv_fma(t, y, P[3]);
-            const F W00 = P[4] + tw, W01 = P[5] + twx, W02 = P[6] + twy;
-            const F W11 = sv_fma(twx, x, P[7]), W12 = sv_fma(twx, y, P[8]), W22 = sv_fma(twy, y, P[9]);
-            // tangent space of the child's slice z.w = const: d = (-s1 d1 - s2 d2, d1, d2)
-            const F G1 = sv_fma(-s1, T0, T1), G2 = sv_fma(-s2, T0, T2);
-            const F A1 = sv_fma(-s1, W00, W01), A2 = sv_fma(-s2, W00, W02);      // W0j - s_j W00
-            const F H11 = sv_fma(-s1, A1, sv_fma(-s1, W01, W11));
-            const F H12 = sv_fma(-s2, A1, sv_fma(-s1, W02, W12));
-            const F H22 = sv_fma(-s2, A2, sv_fma(-s2, W02, W22));
-            const F hh = H11 * H22, det = sv_fma(-H12, H12, hh);
-            const F zw = sv_fma(s1, u1, sv_fma(s2, u2, w0));
-            if (!(det > (F)N3_COND_MIN * hh) || !(zw > F(0))) {
-                push = true;                              // ill-conditioned for these sums: full evaluations from the centre
-            } else {
-                const F idet = sv_rcp(det);
-                const F d1 = (H22 * G1 - H12 * G2) * idet, d2 = (H11 * G2 - H12 * G1) * idet;
-                const F l2 = (G1 * d1 + G2 * d2) * c.inv_Rtot;
-                const F lz = sv_lg2(zw);
-                const F val2 = sv_fma(-c.rtot_f, lz, L);
-                F la = F(0);
-                if constexpr (sizeof(F) == 8) la = sv_fma(c.rtot_f, sv_abs(lz), sv_fma(Rl, sv_abs(lq), P[15]));
-                if (!(l2 == l2) || !(sv_abs(d1) + sv_abs(d2) < F(1e30))) {
-                    push = true;
-                } else {
-                    F step = F(1);
-                    if (l2 > F(0.09)) step = sv_rcp(F(1) + sv_sqrt(l2));
-                    // the stepped point on the child's own slice (z.d = 0, so z.w stays): mixture n_j = s_j u_j / z.w
-                    const F sc = sv_rcp(zw);
-                    const F v1 = sv_fma(step, d1, u1) * sc, v2 = sv_fma(step, d2, u2) * sc;
-                    if (sv_abs(s1 * v1) + sv_abs(s2 * v2) < F(1e6)) {
-                        c.wn1 = s1 * v1;                  // the lane's chain: a recent optimum of this neighbourhood
-                        c.wn2 = s2 * v2;
-                    }
-                    // (same decisions as in sv_drain)
-                    const bool conv = l2 < c.conv_l2 && l2 * c.rtot_over_rmin < F(0.25);
-                    const bool beyond = sv_bound<ML, F>(c, val2, l2, la) > c.thr;
-                    if (beyond && (!c.no_dismiss || conv)) {
-                        // finished: the bound (search) / converged and valued beyond the window (full solve)
-                    } else if (conv && l2 < c.fine_l2) {
-                        surv = true;
-                    } else {
-                        push = true;
-                        qu1 = v1;
-                        qu2 = v2;
-                    }
-                }
-            }
-        }
-        const unsigned long long pm = ballot64(push), sm = ballot64(surv);
-        if (pm | sm) {
-            unsigned rw[ML / 2];
-            sv_child_rows<ML, F>(c, code, slot, rw);
-            if (surv) sv_survivor<ML, F>(c, rw, off);
-            if (pm) {
-                if (c.qcount + __builtin_popcountll(pm) > SV_QCAP) sv_drain<ML, F>(c);
-                if (push) {
-                    const int pos = c.qcount + mbcnt(pm);
+    for (int k0 = 0; k0 < nrec; k0 += WAVE * SV_CPL) {
+        SvChild<F> ch[SV_CPL];
 #pragma unroll
-                    for (int q2 = 0; q2 < ML / 2; q2++) c.W->qRow[pos][q2] = rw[q2];
-                    c.W->qU1[pos] = qu1;
-                    c.W->qU2[pos] = qu2;
-                    c.W->qOff[pos] = (unsigned short)off;
+        for (int e = 0; e < SV_CPL; e++) sv_child_eval<ML, F>(c, lo, k0 + e * WAVE + c.lane, nrec, ch[e]);
+#pragma unroll
+        for (int e = 0; e < SV_CPL; e++) {
+            const SvChild<F> &o = ch[e];
+            if (k0 + e * WAVE >= nrec) break;             // (wave-uniform)
+            if (o.act && !o.regular) {
+                degenerate_append(c.A.ctr, c.A.deg, c.A.deg_cap, c.base + o.off);
+                atomicAdd(&c.A.ctr->degenerate, 1ull);
+            }
+            c.n_child += (unsigned)__builtin_popcountll(ballot64(o.ev));
+            if (o.chain) {
+                c.wn1 = o.n1;                             // the lane's chain: a recent optimum of this neighbourhood
+                c.wn2 = o.n2;
+            }
+            const unsigned long long pm = ballot64(o.push), sm = ballot64(o.surv);
+            if (pm | sm) {
+                unsigned rw[ML / 2];
+                sv_child_rows<ML, F>(c, o.code, o.slot, rw);
+                if (o.surv) sv_survivor<ML, F>(c, rw, o.off);
+                if (pm) {
+                    if (c.qcount + __builtin_popcountll(pm) > SV_QCAP) sv_drain<ML, F>(c);
+                    if (o.push) {
+                        const int pos = c.qcount + mbcnt(pm);
+#pragma unroll
+                        for (int q2 = 0; q2 < ML / 2; q2++) c.W->qRow[pos][q2] = rw[q2];
+                        c.W->qU1[pos] = o.qu1;
+                        c.W->qU2[pos] = o.qu2;
+                        c.W->qOff[pos] = (unsigned short)o.off;
+                    }
+                    c.qcount += __builtin_popcountll(pm);
+                    wave_lds_sync();
                 }
-                c.qcount += __builtin_popcountll(pm);
-                wave_lds_sync();
             }
         }
     }
@@ -648,11 +701,21 @@ __device__ __forceinline__ void sv_expand(SvCtx<ML, F> &c, int n_in) {
                     *dst++ = (unsigned short)((unsigned)s | tag);
                 }
             }
+#ifdef SV_PROF
+            const unsigned long long pa = __builtin_amdgcn_s_memtime();
+#endif
             sv_parent<ML, F>(c, take && cnt > 0, code);
             c.n_par += (unsigned)__builtin_popcountll(ballot64(take && cnt > 0));
             wave_lds_sync();
+#ifdef SV_PROF
+            const unsigned long long pb = __builtin_amdgcn_s_memtime(), dr0 = c.pt[3];
+            c.pt[1] += pb - pa;
+#endif
             sv_children<ML, F>(c, total);
             wave_lds_sync();
+#ifdef SV_PROF
+            c.pt[2] += (__builtin_amdgcn_s_memtime() - pb) - (c.pt[3] - dr0);
+#endif
         } else {
             const unsigned ps = n3_pack(node);
             if (take) {
@@ -770,6 +833,10 @@ __global__ __launch_bounds__(64 * SV_WAVES, sizeof(F) == 4 ? SV_OCC : SV_OCC64) 
     c.qcount = 0;
     c.n_par = c.n_prefix = 0;
     c.n_child = c.n_dit = 0;
+#ifdef SV_PROF
+    for (int i = 0; i < 6; i++) c.pt[i] = 0;
+    const unsigned long long pw0 = __builtin_amdgcn_s_memtime();
+#endif
     const double inv_N = 1.0 / Pg.N;
     double leafR[ML];
 #pragma unroll
@@ -785,9 +852,12 @@ __global__ __launch_bounds__(64 * SV_WAVES, sizeof(F) == 4 ? SV_OCC : SV_OCC64) 
     unsigned long long n_terms = 0, n_pterms = 0;
 
     // the device-wide running minimum: only the finish kernel lowers it, between sieve launches -- one load per task
-    c.thr = order_unbits(load_agent_u64(&A.ctr->best_bits)) + A.window;
+    sv_set_threshold<ML, F>(c, order_unbits(load_agent_u64(&A.ctr->best_bits)) + A.window);
     while (c.remaining > 0) {
         // ---- group tile of the prefix: intervals with the same row collapse into one likelihood term {a, b, sum r}
+#ifdef SV_PROF
+        const unsigned long long pg0 = __builtin_amdgcn_s_memtime();
+#endif
         int G = 0;
         double S1p = 0.0, S2p = 0.0, Rmin = __builtin_inf();
         {
@@ -837,17 +907,28 @@ __global__ __launch_bounds__(64 * SV_WAVES, sizeof(F) == 4 ? SV_OCC : SV_OCC64) 
         c.S1p = (F)(S1p * inv_N);
         c.S2p = (F)(S2p * inv_N);
         c.rtot_over_rmin = (F)(Pg.Rtot / Rmin);
+        c.sqrt_ror = (F)sqrt(Pg.Rtot / Rmin);
         wave_lds_sync();
         const unsigned it0 = c.n_dit, par0 = c.n_par;
         c.par = n3_unpack(sv_state(st, st1, D - 1));
         c.n_prefix++;
+#ifdef SV_PROF
+        c.pt[0] += __builtin_amdgcn_s_memtime() - pg0;
+#endif
         sv_expand<ML, 0, F>(c, 1);
         if (c.qcount) sv_drain<ML, F>(c);                 // the tile changes with the prefix: the queue is emptied first
         n_terms += (unsigned long long)(c.n_dit - it0) * (unsigned)(G + ML);          // full evaluations: every term of the candidate
         n_pterms += (unsigned long long)(c.n_par - par0) * (unsigned)(G + ML - 1);    // shared sums of a last-level node: all terms but its children's
         c.skip = 0;                                    // only the first prefix of a task starts mid-way
         if (c.remaining == 0) break;
+#ifdef SV_PROF
+        const unsigned long long pn0 = __builtin_amdgcn_s_memtime();
+        const bool more = sv_next_prefix(P, st, st1, D, lane);
+        c.pt[4] += __builtin_amdgcn_s_memtime() - pn0;
+        if (!more) break;
+#else
         if (!sv_next_prefix(P, st, st1, D, lane)) break;
+#endif
         wave_lds_sync();                               // the prefix rows in LDS are rewritten next
     }
     if (lane == 0) {
@@ -856,7 +937,13 @@ __global__ __launch_bounds__(64 * SV_WAVES, sizeof(F) == 4 ? SV_OCC : SV_OCC64) 
         atomicAdd(&A.ctr->terms, n_terms);
         atomicAdd(&A.ctr->sieve_pterms, n_pterms);
         atomicAdd(&A.ctr->sieve_children, (unsigned long long)c.n_child);
+#ifdef SV_PROF
+        c.pt[5] = __builtin_amdgcn_s_memtime() - pw0;
+        for (int i = 0; i < 6; i++) atomicAdd(&A.ctr->prof[i], c.pt[i]);
+        atomicAdd(&A.ctr->prof[6], (unsigned long long)c.n_par);
+#else
         atomicAdd(&A.ctr->prof[0], (unsigned long long)c.n_par);
+#endif
         atomicAdd(&A.ctr->prof[7], (unsigned long long)c.n_prefix);
     }
 }
