@@ -10,8 +10,9 @@
  *
  * Conventions
  *   n        number of populations, 2 or 3 (column 0 of C is the normal genome, == tau)
- *   m        number of intervals of the search (rows of C), 2 <= m <= THETA_MAX_M (n=3: <= 128; the materialised
- *            generators, the --GET_VALUES dump and the FP64 mode of n=3 hold 64)
+ *   m        number of intervals of the search (rows of C), 2 <= m <= THETA_MAX_M (n=3: <= 128 -- search, FP64 mode,
+ *            materialised generator and theta_solve_batch alike; only theta_search_values, the fused kernel's own
+ *            per-candidate dump, holds 64)
  *   r, rN    tumour / normal read counts AFTER the reference's sort_r (DataTools.py:95-118),
  *            int64, rN[i] > 0
  *   lb, ub   per-interval copy-number bounds as given to Enumerator(...) (Enumerator.py:39);

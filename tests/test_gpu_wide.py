@@ -95,6 +95,38 @@ def test_n3_search_over_more_than_64_intervals_against_the_oracle(ctx, m, seed, 
     res = p.search(0, cnt, window=0.5)
     for rk, Cm in zip(res["rank"], res["C"]):
         assert np.array_equal(Cm, seq[rk])
-    with pytest.raises(theta_amd.ThetaError):
-        p.enumerate(0, 10)                               # the materialised generators stay at 64 intervals
+    # the materialised generator holds 128 intervals too (round 3): the whole space, ragged sub-ranges, the device variant
+    assert np.array_equal(p.enumerate(0, cnt), seq)
+    for b, c in ((cnt // 3, min(777, cnt - cnt // 3)), (cnt - 5, 5), (1, 1)):
+        assert np.array_equal(p.enumerate(b, c), seq[b:b + c])
     p.close()
+
+
+def test_get_values_dump_over_more_than_64_intervals(ctx, tmp_path):
+    """--GET_VALUES (RunTHetA.py:210-215) for an n=3 search of 72 intervals: line for line the oracle's trace of the reference
+    driver (enumerate + theta_solve_batch; the fused kernel's dump stays at 64 intervals and is not on this path)."""
+    import theta_amd.search as S
+    m = 72
+    rs, rNs, order, truth, lb, ub = _wide_instance(m, 502, 1)
+    S.pre = str(tmp_path / "dumpwide")
+    try:
+        S.do_optimization_single(3, m, 4, 2, list(lb), list(ub), rs, rNs, 1.0, order, False, True)
+    finally:
+        pre, S.pre = S.pre, "theta"
+    lines = [l.rstrip("\n").split("\t") for l in open(pre + ".likelihoods")]
+    seq = np.array(list(orc.enumerate_n3(m, 2, lb, ub)), dtype=np.uint8)
+    procs = max(1, min(64, (os.cpu_count() or 2) - 2))
+    chunks = np.array_split(np.arange(len(seq)), procs)
+    with mp.get_context("spawn").Pool(procs) as pool:
+        parts = pool.map(_oracle_solve_chunk, [(seq[c], rs, rNs) for c in chunks], chunksize=1)
+    table = [t for part in parts for t in part]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        first = orc.solve_n3(orc.first_matrix_n3(m, 2), rs, rNs)
+    want = ([("0" * m, float(first[0][0]), float(first[1]))] if first is not None else []) + \
+           [("".join(str(int(v)) for v in seq[k][:, 0]), t[0][0], t[1]) for k, t in enumerate(table) if t is not None]
+    assert len(lines) == len(want) > 50
+    for (col, mu0, nll), (wcol, wmu0, wnll) in zip(lines, want):
+        assert col == wcol
+        assert (float(nll) != float(nll) and wnll != wnll) or abs(float(nll) - wnll) <= 1e-6 * abs(wnll)
+        assert abs(float(mu0) - wmu0) < 1e-6 or (float(mu0) != float(mu0) and wmu0 != wmu0)

@@ -108,3 +108,37 @@ def test_rccl_communicator_world_of_one(ctx):
     assert merged[0]["nll"] != merged[0]["nll"] and merged[1]["c"].tolist() == [[1, 1]] * 6
     assert comm.info()["collectives"] >= 6
     comm.close()
+
+
+def test_bench_with_two_ranks_on_one_gpu():
+    """
+    bench.py itself as the driver launches it for N = 2 -- two processes with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their
+    environment (what `python -m torch.distributed.run` provides; nothing imports torch) -- sharing this box's single GPU over the
+    library's host transport (THETA_BENCH_NDEV=1, THETA_BENCH_TRANSPORT=host; on an 8-GPU node the same code runs one rank per
+    GPU over RCCL).  Checks the JSON line: n_gpus, the hint all-reduce + the exchange happened, every rank's candidates counted,
+    and the two time-shared ranks together are not slower than half of one rank alone.
+    """
+    import json
+    import subprocess
+    port = _free_port()
+    base = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE="2", THETA_BENCH_NDEV="1",
+                THETA_BENCH_TRANSPORT="host", THETA_COMM_TIMEOUT_S="120")
+    args = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", str(1 << 29)]
+    procs = [subprocess.Popen(args, env=dict(base, RANK=str(rk), LOCAL_RANK=str(rk)), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+             for rk in range(2)]
+    outs = [p.communicate(timeout=600) for p in procs]
+    assert all(p.returncode == 0 for p in procs), [o[1][-800:] for o in outs]
+    assert outs[1][0].strip() == ""                                   # only rank 0 prints
+    line = json.loads(outs[0][0].strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["steps"] == 3 and line["scaling"] == "weak" and line["dtype"] == "f64"
+    assert line["comm"]["world"] == 2 and line["comm"]["collectives"] >= 4      # hint all-reduce, exchange (all-reduces + all-gather), barriers
+    assert line["cpu_baseline"] is None and line["roofline"]["traffic"] is None
+    leg = line["roofline"]["legs"]["full_solve_f64"]
+    assert leg["launches"] == 3 and leg["candidates_per_launch"] == 1 << 29
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--batch", str(1 << 29),
+                          "--no-cpu-baseline", "--no-legs", "--no-traffic", "--no-extras"], capture_output=True, text=True, timeout=600)
+    assert one.returncode == 0, one.stderr[-800:]
+    single = json.loads(one.stdout.strip().splitlines()[-1])
+    assert single["n_gpus"] == 1
+    # whole-job rate of two ranks time-sharing ONE GPU: about the single-rank rate (not twice, the GPU is the same); within 2x
+    assert 0.5 * single["value"] <= line["value"] <= 2.0 * single["value"], (line["value"], single["value"])

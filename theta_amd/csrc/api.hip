@@ -1041,8 +1041,8 @@ static int enumerate_device(theta_problem *p, u128 b, uint64_t count, unsigned c
 }
 
 static int enumerate_args(theta_problem *p, const uint64_t rank_begin[2], uint64_t count, u128 &b) {
-    if (p && p->n == 3 && p->m > N3_MAX_M) {
-        theta_set_error("theta_enumerate: the n=3 generators hold at most %d intervals (m = %d)", N3_MAX_M, p->m);
+    if (p && p->n == 3 && p->m > N3_MAX_M && getenv("THETA_ENUM_LEGACY")) {
+        theta_set_error("theta_enumerate: the lane-private n=3 generator (THETA_ENUM_LEGACY) holds at most %d intervals (m = %d)", N3_MAX_M, p->m);
         return THETA_ERR_ARG;
     }
     uint64_t re[2];

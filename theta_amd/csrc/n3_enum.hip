@@ -47,7 +47,7 @@ template <int ML> struct EbCapR { static constexpr int v = ML <= 4 ? 512 : 288; 
 
 template <int ML>
 struct EbWave {
-    alignas(16) unsigned short pre[N3_MAX_M + 8];      // rows of the prefix, a | b << 8
+    alignas(16) unsigned short pre[N3_MAX_M_WIDE + 8]; // rows of the prefix, a | b << 8 (up to 128 intervals: two per lane)
     uint2 list0[N3_MAX_Q];                             // level 1 nodes (children of the prefix's last node)
     uint2 list[ML > 2 ? ML - 2 : 1][EB_CAP];           // level l >= 2: {packed parent node, ancestor slots (6 bits each) | slot << 24}
     alignas(8) unsigned short lwr[(EbCapR<ML>::v + 4) * ML];   // records of the current burst: their LB last rows, a | b << 8
@@ -56,7 +56,7 @@ template <int ML>
 struct EbLds {
     EbWave<ML> w[EB_WAVES];
     unsigned long long smask[ML][N3_MAX_Q];             // static child masks of the LB last depths
-    unsigned char lb[N3_MAX_M], ub[N3_MAX_M];
+    unsigned char lb[N3_MAX_M_WIDE], ub[N3_MAX_M_WIDE];
     unsigned char ridx[N3_RIDX_W * N3_RIDX_W + 3];
     unsigned char rowtab[N3_MAX_Q + 3];
     unsigned short row16[N3_MAX_Q];                     // slot -> a | b << 8
@@ -243,16 +243,20 @@ __device__ void eb_expand(EbCtx<ML> &c, int n_in) {
     }
 }
 
-// Next prefix in DFS order (wave-uniform): lane d holds the packed node of depth d.  Returns false at the end of the space.
-__device__ __forceinline__ bool eb_next_prefix(const N3Dev &P, unsigned &st, int D, int lane) {
+// Next prefix in DFS order (wave-uniform): lane d holds the packed node of depth d in st0 and that of depth 64 + d in st1
+// (up to 128 intervals, like the sieve kernel's prefix).  Returns false at the end of the space.
+__device__ __forceinline__ unsigned eb_state(unsigned st0, unsigned st1, int d) {
+    return (unsigned)__builtin_amdgcn_readlane((int)(d < WAVE ? st0 : st1), d & (WAVE - 1));
+}
+__device__ __forceinline__ bool eb_next_prefix(const N3Dev &P, unsigned &st0, unsigned &st1, int D, int lane) {
     const int K1 = P.K + 1, Q = P.Q;
     const int sa = lane % K1, sb = lane / K1;          // Q <= 64: one alphabet slot per lane
     int d = D - 1;
     bool fresh = false;
     while (true) {
-        const int cur_slot = __builtin_amdgcn_readlane((int)st, d) & 0x7f;
+        const int cur_slot = (int)(eb_state(st0, st1, d) & 0x7fu);
         const int start = fresh ? 0 : cur_slot + 1;
-        const N3State pst = n3_unpack((unsigned)__builtin_amdgcn_readlane((int)st, d > 0 ? d - 1 : 0));
+        const N3State pst = n3_unpack(eb_state(st0, st1, d > 0 ? d - 1 : 0));
         N3State nx{0, 0, 0, 0, 0, 0};
         const bool ok = lane >= start && lane < Q &&
                         (d == 0 ? n3_first_row_ab(P, sa, sb, lane, nx) : n3_edge_ab(P, pst, sa, sb, lane, d, nx));
@@ -261,7 +265,11 @@ __device__ __forceinline__ bool eb_next_prefix(const N3Dev &P, unsigned &st, int
             const int first = __builtin_ctzll(mk);
             const unsigned mine = ok ? n3_pack(nx) : 0u;
             const unsigned packed = (unsigned)__builtin_amdgcn_readlane((int)mine, first);
-            if (lane == d) st = packed;
+            if (d < WAVE) {
+                if (lane == d) st0 = packed;
+            } else if (lane == d - WAVE) {
+                st1 = packed;
+            }
             if (d == D - 1) return true;
             d++;
             fresh = true;
@@ -300,6 +308,7 @@ __global__ __launch_bounds__(64 * EB_WAVES, (ML <= 4 ? EB_OCC4 : EB_OCC6)) void 
     if (task >= ntasks) return;
     const N3Task tk = tasks[task];
     unsigned st = lane < D ? stbuf[(size_t)task * N3_STB + lane] : 0u;
+    unsigned st1 = lane + WAVE < D ? stbuf[(size_t)task * N3_STB + WAVE + lane] : 0u;    // (m > 64 + LB: depths 64 .. D-1)
 
     EbCtx<ML> c;
     c.S = &S;
@@ -321,12 +330,13 @@ __global__ __launch_bounds__(64 * EB_WAVES, (ML <= 4 ? EB_OCC4 : EB_OCC6)) void 
 
     while (c.remaining > 0) {
         if (lane < D) c.W->pre[lane] = (unsigned short)(((st >> 24) & 15u) | ((st >> 28) << 8));
+        if (lane + WAVE < D) c.W->pre[WAVE + lane] = (unsigned short)(((st1 >> 24) & 15u) | ((st1 >> 28) << 8));
         wave_lds_sync();
-        c.par = n3_unpack((unsigned)__builtin_amdgcn_readlane((int)st, D - 1));
+        c.par = n3_unpack(eb_state(st, st1, D - 1));
         eb_expand<U, ML, 0>(c, 1);
         c.skip = 0;                                        // only the first prefix of a task starts mid-way
         if (c.remaining == 0) break;
-        if (!eb_next_prefix(P, st, D, lane)) break;
+        if (!eb_next_prefix(P, st, st1, D, lane)) break;
         wave_lds_sync();                                   // the prefix rows in LDS are rewritten next
     }
 }

@@ -1,22 +1,23 @@
 #!/bin/bash
-# Measurement set of one round, run ON THE GPU BOX:  tools/profile_round.sh r2   -> gpurun_out/prof_$R/ (copy what is to be judged
+# Measurement set of one round, run ON THE GPU BOX:  tools/profile_round.sh r3   -> gpurun_out/prof_$R/ (copy what is to be judged
 # into profiles/$R/).
-#   1. bench.py (the driver's command)                         -> bench_n1.json
-#   2. rocprofv3 --kernel-trace --stats of the same command     -> bench_kernel_stats.csv   (all three legs)
-#   3. PMC passes of the dominant kernel, one group per run     -> pmc_n3_sieve_kernel.json (tools/pmc_kernel.sh)
-#   4. other configs, materialised operators                    -> other_configs.json, enumerate.json, device_chain.json, batch_ops.json
-R=${1:-r2}
+#   1. bench.py as the driver runs it (--steps 20 --warmup 5)   -> bench_n1.json
+#   2. rocprofv3 --kernel-trace --stats of the same command      -> bench_kernel_stats.csv (all legs), bench_search_launches.csv
+#   3. PMC passes of the dominant kernel, one group per run      -> pmc_n3_sieve_kernel.json (tools/pmc_kernel.sh)
+#   4. phase cycles of the sieve kernel (build_ab/libprof.so)    -> phase_cycles.txt
+#   5. the riders, and rocprofv3 --kernel-trace --stats of them  -> riders.json, riders_kernel_stats.csv
+R=${1:-r3}
 cd "$(dirname "$0")/.."
 ROOT=$PWD
 OUT=$ROOT/gpurun_out/prof_$R
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-timeout 600 python $ROOT/bench.py > $OUT/bench_n1.json 2> $OUT/bench_n1.err
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o kt -- python $ROOT/bench.py --no-cpu-baseline --no-traffic --no-extras > $OUT/bench_under_rocprof.json 2> $OUT/kt.err
+timeout 900 python $ROOT/bench.py --steps 20 --warmup 5 > $OUT/bench_n1.json 2> $OUT/bench_n1.err
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o kt -- python $ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-traffic --no-extras > $OUT/bench_under_rocprof.json 2> $OUT/kt.err
 cp $(find $OUT/kt -name '*kernel_stats.csv' | head -1) $OUT/bench_kernel_stats.csv 2>/dev/null
-# every launch of the search kernels, in order (the averages of the stats file mix the short bootstrap launches of a job's first
-# step with the timed 2^31-candidate launches)
+# every launch of the search kernels, in order (the averages of the stats file mix the short bootstrap / first-slice launches
+# with the full-size ones)
 python - <<PY
 import csv, glob
 f = glob.glob("$OUT/kt/**/*kernel_trace.csv", recursive=True)
@@ -26,13 +27,20 @@ if f:
     with open("$OUT/bench_search_launches.csv", "w") as o:
         o.write("kernel,grid_size,duration_ms\n")
         for r in rows:
-            o.write("%s,%s,%.4f\n" % (r["Kernel_Name"].split("(")[0].replace("void ", ""), r.get("Grid_Size", ""), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6))
+            o.write("%s,%s,%.4f\n" % (r["Kernel_Name"].split("(")[0].replace("void ", "").replace(",", ";"), r.get("Grid_Size", ""), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6))
 PY
 rm -rf $OUT/kt
 $ROOT/tools/pmc_kernel.sh gpurun_out/prof_$R/pmc_sieve n3_sieve_kernel > $OUT/pmc_sieve.log 2>&1
 cp $OUT/pmc_sieve/pmc.json $OUT/pmc_n3_sieve_kernel.json 2>/dev/null
-timeout 300 python $ROOT/tools/bench_configs.py > $OUT/other_configs.json 2> $OUT/other_configs.err
-timeout 300 python $ROOT/tools/enum_profile.py > $OUT/enumerate.json 2> $OUT/enumerate.err
-timeout 300 python $ROOT/tools/device_chain.py 26 > $OUT/device_chain.json 2> $OUT/device_chain.err
-timeout 300 python $ROOT/tools/batch_profile.py > $OUT/batch_ops.json 2> $OUT/batch_ops.err
+if [ -f $ROOT/build_ab/libprof.so ]; then
+  for leg in full_solve_f64 full_solve_f32 search; do
+    echo "== $leg (cycles summed over waves: 0 group tile, 1 parent phase, 2 children phase, 3 queue drain, 4 prefix successor, 5 whole wave; 6 last-level nodes, 7 prefixes)"
+    THETA_HIP_LIB=$ROOT/build_ab/libprof.so THETA_BENCH_VERBOSE=1 timeout 300 python $ROOT/bench.py --steps 6 --warmup 2 --leg $leg --no-legs --no-cpu-baseline --no-traffic --no-extras 2>&1 >/dev/null | grep "^step"
+  done > $OUT/phase_cycles.txt
+fi
+timeout 600 python $ROOT/tools/riders.py > $OUT/riders.json 2> $OUT/riders.err
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kr -o kr -- python $ROOT/tools/riders.py > /dev/null 2> $OUT/kr.err
+cp $(find $OUT/kr -name '*kernel_stats.csv' | head -1) $OUT/riders_kernel_stats.csv 2>/dev/null
+rm -rf $OUT/kr
+for shape in "131072 512 200" "65536 64 200"; do timeout 100 python $ROOT/tools/scorer_probe.py $shape; done > $OUT/scorer_probe.txt 2>&1
 ls -la $OUT
