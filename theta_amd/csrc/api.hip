@@ -71,7 +71,7 @@ extern "C" int theta_create(int device_id, theta_ctx **out) {
         theta_set_error("device %d out of range (%d devices)", device_id, ndev);
         return THETA_ERR_ARG;
     }
-    HIP_TRY(hipSetDevice(device_id));
+    HIP_ENTER(device_id);
     theta_ctx *c = new theta_ctx();
     c->device = device_id;
     hipDeviceProp_t prop;
@@ -102,7 +102,7 @@ extern "C" int theta_synchronize(theta_ctx *c) {
         theta_set_error("null context");
         return THETA_ERR_ARG;
     }
-    HIP_TRY(hipSetDevice(c->device));
+    HIP_ENTER(c->device);
     HIP_TRY(hipDeviceSynchronize());
     return THETA_OK;
 }
@@ -144,6 +144,7 @@ struct theta_problem {
     uint64_t opt_per_task = 0;         // n=3 candidates per wave task (0: automatic), theta_problem_set_option
     int opt_per_thread = 0;            // n=2 candidates per thread (0: automatic)
     int opt_sieve = 1;                 // n=3: sieve + finish kernels (n3_sieve.hip); 0 = the fused kernel of n3.hip only
+    int device = 0;                                     // (= ctx->device: the destructor must not need the context)
     uint64_t last_survivors = 0, last_fallback = 0;   // of the last search: contenders listed by the sieve / candidates redone fused
     SearchCounters last_redo{};                        // ... what the fused kernel did on the redone slices (kept apart from the main counters)
     double last_redo_ms = 0.0;
@@ -160,8 +161,11 @@ static int upload(DevBuf &b, const void *src, size_t bytes, hipStream_t st) {
 
 extern "C" void theta_problem_destroy(theta_problem *p) {
     if (!p) return;
-    (void)hipSetDevice(p->ctx->device);
+    // (p->device, not p->ctx->device: a garbage collector may destroy the context first -- round 3: a dangling read here set
+    // the device to garbage, and the error stayed in HIP's per-thread state until the next hipGetLastError() of a search)
+    (void)hipSetDevice(p->device);
     delete p;
+    (void)hipGetLastError();
 }
 
 extern "C" int theta_problem_create(theta_ctx *ctx, int n, int m, int tau, const int64_t *r, const int64_t *rN,
@@ -208,10 +212,11 @@ extern "C" int theta_problem_create(theta_ctx *ctx, int n, int m, int tau, const
     for (int i = 0; i < m; i++)
         if (r[i] > 0) k0 -= (long double)r[i] * logl((long double)rN[i] / N);
 
-    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_ENTER(ctx->device);
     std::unique_ptr<theta_problem> owner(new theta_problem());   // freed (with all its device buffers) on every error return
     theta_problem *p = owner.get();
     p->ctx = ctx;
+    p->device = ctx->device;
     p->n = n;
     p->m = m;
     p->tau = tau;
@@ -737,7 +742,7 @@ extern "C" int theta_search(theta_problem *p, const uint64_t rank_begin[2], cons
         theta_set_error("window must be >= 0");
         return THETA_ERR_ARG;
     }
-    HIP_TRY(hipSetDevice(p->ctx->device));
+    HIP_ENTER(p->ctx->device);
     *n_out = 0;
     if (stats) memset(stats, 0, sizeof(*stats));
     if (b == e) {            // an empty range: nothing found -- and nothing left over from the previous call either
@@ -865,7 +870,7 @@ extern "C" int theta_search_values(theta_problem *p, const uint64_t rank_begin[2
         return THETA_ERR_ARG;
     }
     if (count == 0) return THETA_OK;
-    HIP_TRY(hipSetDevice(p->ctx->device));
+    HIP_ENTER(p->ctx->device);
     hipStream_t st = p->ctx->stream;
     DevBuf d_nll, d_mu;
     rc = d_nll.alloc(count * sizeof(double));
@@ -924,7 +929,7 @@ static int side_list_out(theta_problem *p, const std::vector<TieRecord> &sv, uin
         theta_set_error("%zu %s but capacity is %d", sv.size(), what, cap);
         return THETA_ERR_CAPACITY;
     }
-    HIP_TRY(hipSetDevice(p->ctx->device));
+    HIP_ENTER(p->ctx->device);
     hipStream_t st = p->ctx->stream;
     size_t cb = (size_t)p->m * (p->n - 1);
     DevBuf d_rec, d_C;
@@ -972,7 +977,7 @@ extern "C" int theta_boundary_min(theta_ctx *ctx, int m, int tau, const int64_t 
         return THETA_ERR_ARG;
     }
     if (B == 0) return THETA_OK;
-    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_ENTER(ctx->device);
     hipStream_t st = ctx->stream;
     std::vector<double> rd(m), rnd(m);
     for (int i = 0; i < m; i++) {
@@ -1063,7 +1068,7 @@ extern "C" int theta_enumerate(theta_problem *p, const uint64_t rank_begin[2], u
         theta_set_error("null output");
         return THETA_ERR_ARG;
     }
-    HIP_TRY(hipSetDevice(p->ctx->device));
+    HIP_ENTER(p->ctx->device);
     size_t cb = (size_t)p->m * (p->n - 1);
     DevBuf d_C;
     rc = d_C.alloc(count * cb);
@@ -1090,7 +1095,7 @@ extern "C" int theta_enumerate_device(theta_problem *p, const uint64_t rank_begi
         theta_set_error("theta_enumerate_device: the output pointer must be 4-byte aligned");
         return THETA_ERR_ARG;
     }
-    HIP_TRY(hipSetDevice(p->ctx->device));
+    HIP_ENTER(p->ctx->device);
     return enumerate_device(p, b, count, (unsigned char *)d_out, kernel_ms);
 }
 
@@ -1107,7 +1112,7 @@ extern "C" int theta_solve_batch(theta_ctx *ctx, int n, int m, int tau, const in
         return THETA_ERR_ARG;
     }
     if (B == 0) return THETA_OK;
-    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_ENTER(ctx->device);
     hipStream_t st = ctx->stream;
     std::vector<double> rd(m), rnd(m);
     for (int i = 0; i < m; i++) {
@@ -1146,7 +1151,7 @@ static int score_batch_impl(theta_ctx *ctx, int n, int m, int B, const double *C
         return THETA_ERR_ARG;
     }
     if (B == 0) return THETA_OK;
-    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_ENTER(ctx->device);
     hipStream_t st = ctx->stream;
     DevBuf d_C, d_mu, d_r, d_nll, d_vals, d_valid;
     int rc;
@@ -1188,7 +1193,7 @@ extern "C" int theta_device_alloc(theta_ctx *ctx, size_t bytes, void **out) {
         theta_set_error("theta_device_alloc: null argument");
         return THETA_ERR_ARG;
     }
-    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_ENTER(ctx->device);
     HIP_TRY(hipMalloc(out, bytes ? bytes : 8));
     return THETA_OK;
 }
@@ -1199,7 +1204,7 @@ extern "C" int theta_device_free(theta_ctx *ctx, void *p) {
         return THETA_ERR_ARG;
     }
     if (!p) return THETA_OK;
-    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_ENTER(ctx->device);
     HIP_TRY(hipFree(p));
     return THETA_OK;
 }
@@ -1210,7 +1215,7 @@ extern "C" int theta_device_copy(theta_ctx *ctx, void *dst, const void *src, siz
         return THETA_ERR_ARG;
     }
     if (!bytes) return THETA_OK;
-    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_ENTER(ctx->device);
     HIP_TRY(hipMemcpyAsync(dst, src, bytes, to_device ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return THETA_OK;
@@ -1229,7 +1234,7 @@ extern "C" int theta_solve_batch_device(theta_ctx *ctx, int n, int m, int tau, c
     }
     if (kernel_ms) *kernel_ms = 0.0;
     if (B == 0) return THETA_OK;
-    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_ENTER(ctx->device);
     hipStream_t st = ctx->stream;
     std::vector<double> rd(m), rnd(m);
     for (int i = 0; i < m; i++) {
@@ -1267,7 +1272,7 @@ extern "C" int theta_score_masked_device(theta_ctx *ctx, int n, int m, int tau, 
     }
     if (kernel_ms) *kernel_ms = 0.0;
     if (B == 0) return THETA_OK;
-    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_ENTER(ctx->device);
     hipStream_t st = ctx->stream;
     int words = (m + 63) / 64;
     DevBuf d_w, d_r, d_mask, d_rsum;
@@ -1303,7 +1308,7 @@ extern "C" int theta_score_masked(theta_ctx *ctx, int n, int m, int tau, int B, 
         return THETA_ERR_ARG;
     }
     if (B == 0) return THETA_OK;
-    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_ENTER(ctx->device);
     hipStream_t st = ctx->stream;
     int words = (m + 63) / 64;
     DevBuf d_C, d_w, d_r, d_mu, d_mask, d_nll, d_rsum;

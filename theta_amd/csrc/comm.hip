@@ -139,6 +139,7 @@ void tune_socket(int fd) {
 
 struct theta_comm {
     theta_ctx *ctx = nullptr;
+    int device = 0;                // (= ctx->device: the destructor must not need the context)
     int rank = 0, world = 1, transport = THETA_COMM_RCCL;
     // TCP star: rank 0 holds one socket per peer (index = peer rank), the others one socket to rank 0
     std::vector<int> peers;
@@ -294,6 +295,7 @@ extern "C" int theta_comm_create(theta_ctx *ctx, int rank, int world, const char
     }
     theta_comm *c = new theta_comm();
     c->ctx = ctx;
+    c->device = ctx ? ctx->device : 0;
     c->rank = rank;
     c->world = world;
     c->transport = transport;
@@ -356,9 +358,10 @@ extern "C" int theta_comm_create(theta_ctx *ctx, int rank, int world, const char
 extern "C" void theta_comm_destroy(theta_comm *c) {
     if (!c) return;
     if (c->nccl) {
-        (void)hipSetDevice(c->ctx->device);
-        (void)hipStreamSynchronize(c->ctx->stream);
+        (void)hipSetDevice(c->device);
+        (void)hipDeviceSynchronize();
         (void)g_rccl.CommDestroy(c->nccl);
+        (void)hipGetLastError();
     }
     close_star(c);
     delete c;

@@ -26,6 +26,14 @@ void theta_set_error(const char *fmt, ...);
         }                                                                                   \
     } while (0)
 
+// entry of an API call: select the device, and forget what earlier calls (of anybody) left in HIP's per-thread error state --
+// the hipGetLastError() checks after our launches must report OUR launches
+#define HIP_ENTER(dev)                 \
+    do {                               \
+        HIP_TRY(hipSetDevice(dev));    \
+        (void)hipGetLastError();       \
+    } while (0)
+
 struct theta_ctx {
     int device;
     hipStream_t stream;
