@@ -139,7 +139,7 @@ class Leg:
         self.running = float("inf")
         self.best = None
         self.tot = {k: 0 for k in ("evaluated", "accepted", "dismissed", "flops", "flops_f32", "terms", "iterations", "survivors",
-                                   "fallback_candidates", "redo_flops", "redo_flops_f32", "degenerate")}
+                                   "fallback_candidates", "redo_flops", "redo_flops_f32", "degenerate", "kernel_launches")}
         self.kernel_ms = self.setup_ms = self.redo_ms = 0.0
         self.step_ms = []
         self.launches = 0
@@ -187,6 +187,12 @@ class Leg:
                 "value": ev / wall_s if wall_s > 0 else 0.0, "unit": "candidates/s", "wall_ms_per_launch": 1e3 * wall_s / max(self.launches, 1),
                 "kernel_ms_per_launch": self.kernel_ms / max(self.launches, 1), "kernel_candidates_per_s": ev / k_s if k_s > 0 else 0.0,
                 "step_kernel_ms": {"min": sm[0], "median": sm[len(sm) // 2], "max": sm[-1]},
+                # a step = one theta_search call = a short first slice + the bulk: two launches of the
+                # sieve kernel, each followed by the finish kernel; per LAUNCH of the dominant kernel (what rocprofv3 --stats
+                # averages, profiles/r3/bench_search_launches.csv lists every one):
+                "kernel_launches": self.tot["kernel_launches"],
+                "kernel_ms_per_kernel_launch": self.kernel_ms / max(self.tot["kernel_launches"], 1),
+                "executed_flop_per_kernel_launch": (f64 + f32) / max(self.tot["kernel_launches"], 1),
                 "survivors": self.tot["survivors"], "fallback_candidates": self.tot["fallback_candidates"],
                 "redo_kernel_ms": self.redo_ms, "redo_flop": float(self.tot["redo_flops"] + self.tot["redo_flops_f32"]),
                 "degenerate": self.tot["degenerate"],

@@ -99,6 +99,7 @@ typedef struct theta_search_stats {
     uint64_t redo_flops;     /* ... FP64 operations the fused kernel executed on those slices -- NOT part of `flops`:       */
     uint64_t redo_flops_f32; /* ... every candidate is counted once in evaluated / dismissed / iterations / terms / flops,  */
     double redo_kernel_ms;   /* ... and kernel_ms is the sieve + finish kernels' only; the redo's time is here              */
+    uint64_t kernel_launches;/* launches of the search kernel behind kernel_ms (n=3 sieve: one per slice of the range)      */
 } theta_search_stats;
 
 /*

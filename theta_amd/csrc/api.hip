@@ -149,6 +149,7 @@ struct theta_problem {
     SearchCounters last_redo{};                        // ... what the fused kernel did on the redone slices (kept apart from the main counters)
     double last_redo_ms = 0.0;
     bool last_sieve64 = false;                         // ... and whether the sieve ran in FP64 (n3_force_f64)
+    uint64_t last_launches = 0;                        // launches of the search kernel behind kernel_ms (sieve: one per slice)
     DevBuf d_r, d_rN, d_small, d_P, d_PR, d_PN, d_cnt, d_ctr, d_list, d_tasks, d_stbuf, d_misc, d_smask, d_dynmask, d_sus, d_deg, d_surv, d_survcnt, d_survacc;
 };
 
@@ -458,6 +459,7 @@ static int run_search(theta_problem *p, u128 b, u128 e, double window, double *d
     p->last_redo_ms = 0.0;
     p->last_sieve64 = false;
     p->last_fallback = 0;
+    p->last_launches = 0;
     for (int pass = 0; pass < 3; pass++) {
         std::vector<std::pair<int, int>> slices;     // n=3 fast path: (first task, tasks) of every sieve launch of this pass
         uint64_t sieve_per_task = 0;
@@ -558,6 +560,7 @@ static int run_search(theta_problem *p, u128 b, u128 e, double window, double *d
                 n3_launch_search(p->n3, A, (const N3Task *)p->d_tasks.p, (const unsigned *)p->d_stbuf.p, ntasks, per_task, st);
             }
         }
+        p->last_launches += slices.empty() ? 1 : (uint64_t)slices.size();
         HIP_TRY(hipEventRecord(ctx->ev2, st));
         SearchCounters got;
         unsigned hcnt[SIEVE_MAX_SLICES], hacc[SIEVE_MAX_SLICES];
@@ -793,6 +796,7 @@ extern "C" int theta_search(theta_problem *p, const uint64_t rank_begin[2], cons
         count_flops(hc, stats->flops, stats->flops_f32);
         count_flops(p->last_redo, stats->redo_flops, stats->redo_flops_f32);    // slices redone (contender list full): apart
         stats->redo_kernel_ms = p->last_redo_ms;
+        stats->kernel_launches = p->last_launches;
         stats->survivors = hc.sieve_survivors;
         stats->fallback_candidates = p->last_fallback;
         stats->best_nll = best;

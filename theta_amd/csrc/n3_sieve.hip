@@ -128,9 +128,11 @@ struct SvWave {
     Sv4<F> fXY[(N3_MAX_Q + 2) / 2];                     // group tile of the prefix, two terms per entry {a0, a1, b0, b1}
     Sv2<F> fRR[(N3_MAX_Q + 2) / 2];                     // ... and their weights {R0, R1} (an odd last term is paired with weight 0)
     Sv2<F> fRL[ML / 2];                                 // weights of the leaf rows, paired
-    unsigned qRow[SV_QCAP][ML / 2];                     // queue: rows of a record that needs more Newton steps
+    uint2 qRec[SV_QCAP];                                // queue of records that need more Newton steps: {slots of the path rows (6 bits
+                                                        // each: the node's code), last row's slot | offset in the task << 8} -- the
+                                                        // rows are decoded by the lane that takes the entry (sv_drain), not by the
+                                                        // whole wave at every push
     F qU1[SV_QCAP], qU2[SV_QCAP];                       // ... the iterate it continues from
-    unsigned short qOff[SV_QCAP];                       // ... and its offset in the task (rank = task base + offset)
 };
 template <int ML, class F>
 struct SvLds {
@@ -332,6 +334,17 @@ __device__ __forceinline__ void sv_survivor(const SvCtx<ML, F> &c, const unsigne
     }
 }
 
+// leaf rows of a child as the queue / the contender list hold them: two rows {a, b, a', b'} per dword
+template <int ML, class F>
+__device__ __forceinline__ void sv_child_rows(const SvCtx<ML, F> &c, unsigned code, unsigned slot, unsigned (&rw)[ML / 2]) {
+#pragma unroll
+    for (int j = 0; j < ML / 2; j++) {
+        rw[j] = c.S->row16[(code >> (12 * j)) & 63u];
+        if (j < ML / 2 - 1) rw[j] |= (unsigned)c.S->row16[(code >> (12 * j + 6)) & 63u] << 16;
+    }
+    rw[ML / 2 - 1] |= (unsigned)c.S->row16[slot] << 16;
+}
+
 // Further Newton steps for the queued records: until dismissed, converged (a contender) or given up.  PERSISTENT LANES: a lane
 // whose record is finished takes the next queue entry at once (ballot + prefix count of the idle lanes), so the wave iterates
 // as long as there is work for most of its lanes -- round 2 took the queue 64 at a time in lock step, and with a third of the
@@ -354,11 +367,11 @@ __device__ __forceinline__ void sv_drain(SvCtx<ML, F> &c) {
         if (next < c.qcount && idle) {
             const int idx = next + mbcnt(idle);
             if (!live && idx < c.qcount) {
-#pragma unroll
-                for (int j = 0; j < ML / 2; j++) rw[j] = c.W->qRow[idx][j];
+                const uint2 qr = c.W->qRec[idx];
+                sv_child_rows<ML, F>(c, qr.x, qr.y & 0xffu, rw);
                 u1 = c.W->qU1[idx];
                 u2 = c.W->qU2[idx];
-                off = c.W->qOff[idx];
+                off = qr.y >> 8;
                 sv_sums<ML, F>(c, rw, s1, s2);
                 if (!(u1 == u1)) {                    // (no usable first point: from the simplex centre)
                     u1 = F(1.0 / 3.0) * sv_rcp(s1);
@@ -486,17 +499,6 @@ __device__ __forceinline__ void sv_parent(SvCtx<ML, F> &c, bool take, unsigned c
     }
 }
 
-// leaf rows of a child as the queue / the contender list hold them: two rows {a, b, a', b'} per dword
-template <int ML, class F>
-__device__ __forceinline__ void sv_child_rows(const SvCtx<ML, F> &c, unsigned code, unsigned slot, unsigned (&rw)[ML / 2]) {
-#pragma unroll
-    for (int j = 0; j < ML / 2; j++) {
-        rw[j] = c.S->row16[(code >> (12 * j)) & 63u];
-        if (j < ML / 2 - 1) rw[j] |= (unsigned)c.S->row16[(code >> (12 * j + 6)) & 63u] << 16;
-    }
-    rw[ML / 2 - 1] |= (unsigned)c.S->row16[slot] << 16;
-}
-
 // What the shared first evaluation of one child comes to (sv_child_eval): all a lane carries from the arithmetic to the
 // bookkeeping, so that the arithmetic of SEVERAL children per lane can be one straight-line block.
 template <class F>
@@ -609,23 +611,23 @@ __device__ __forceinline__ void sv_children(SvCtx<ML, F> &c, int total) {
                 c.wn2 = o.n2;
             }
             const unsigned long long pm = ballot64(o.push), sm = ballot64(o.surv);
-            if (pm | sm) {
-                unsigned rw[ML / 2];
-                sv_child_rows<ML, F>(c, o.code, o.slot, rw);
-                if (o.surv) sv_survivor<ML, F>(c, rw, o.off);
-                if (pm) {
-                    if (c.qcount + __builtin_popcountll(pm) > SV_QCAP) sv_drain<ML, F>(c);
-                    if (o.push) {
-                        const int pos = c.qcount + mbcnt(pm);
-#pragma unroll
-                        for (int q2 = 0; q2 < ML / 2; q2++) c.W->qRow[pos][q2] = rw[q2];
-                        c.W->qU1[pos] = o.qu1;
-                        c.W->qU2[pos] = o.qu2;
-                        c.W->qOff[pos] = (unsigned short)o.off;
-                    }
-                    c.qcount += __builtin_popcountll(pm);
-                    wave_lds_sync();
+            if (sm) {                                     // (rare: a contender straight from the shared evaluation)
+                if (o.surv) {
+                    unsigned rw[ML / 2];
+                    sv_child_rows<ML, F>(c, o.code, o.slot, rw);
+                    sv_survivor<ML, F>(c, rw, o.off);
                 }
+            }
+            if (pm) {
+                if (c.qcount + __builtin_popcountll(pm) > SV_QCAP) sv_drain<ML, F>(c);
+                if (o.push) {
+                    const int pos = c.qcount + mbcnt(pm);
+                    c.W->qRec[pos] = make_uint2(o.code, o.slot | (o.off << 8));
+                    c.W->qU1[pos] = o.qu1;
+                    c.W->qU2[pos] = o.qu2;
+                }
+                c.qcount += __builtin_popcountll(pm);
+                wave_lds_sync();
             }
         }
     }

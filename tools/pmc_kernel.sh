@@ -8,7 +8,7 @@ ROOT=$PWD
 mkdir -p $ROOT/$OUT
 export TMPDIR=/tmp
 for kv in "$@"; do export "$kv"; done
-BENCH="python $ROOT/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-legs --no-traffic --no-extras"
+BENCH="python $ROOT/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-legs --no-traffic --no-extras $PMC_BENCH_ARGS"
 cd /tmp
 i=0
 for grp in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" "SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY" \
