@@ -137,3 +137,38 @@ def test_fp64_sieve_and_full_solve_modes_return_the_lists_of_the_shipped_search(
             if len(a["nll"]):
                 known = float(a["nll"].min()) if known is None else min(known, float(a["nll"].min()))
         p.close()
+
+
+def test_masked_scorer_at_the_full_config5_shape_against_the_oracle(ctx):
+    """BASELINE config 5 at its bench size -- m=200, n=3, k=7, 131 072 byte candidates x 512 interval masks, one launch of the
+    FP64-MFMA kernel (67 M pairs) -- sampled against the oracle's CalcAllC.L3 with the masked rows' column 0 zeroed
+    (CalcAllC.py:70-75): 400 random pairs, the block and mask-chunk corners, and an all-ones mask against the unmasked score."""
+    import math
+    m, n, tau, B, S = 200, 3, 2, 131072, 512
+    rng = np.random.RandomState(55)
+    C = rng.randint(0, 8, (B, m, 2)).astype(np.uint8)
+    w = rng.poisson(100000, m).astype(np.float64) + 1.0
+    r = rng.poisson(120000, m).astype(np.float64)
+    mu = rng.dirichlet(np.ones(3) * 4, B)
+    words = (m + 63) // 64
+    bits = rng.rand(S, m) < 0.8
+    bits[0, :] = True
+    masks = np.zeros((S, words), np.uint64)
+    for i in range(m):
+        masks[:, i // 64] |= (bits[:, i].astype(np.uint64) << np.uint64(i % 64))
+    nll, ms = ctx.score_masked(n, tau, C, w, r, mu, masks)
+    assert nll.shape == (B, S)
+    pairs = [(int(rng.randint(B)), int(rng.randint(S))) for _ in range(400)]
+    pairs += [(0, 0), (0, S - 1), (B - 1, 0), (B - 1, S - 1), (15, 15), (16, 16), (B - 17, S - 17), (65535, 255), (65536, 256)]
+    for b, s in pairs:
+        Cw = np.zeros((m, n))
+        Cw[:, 0] = tau * w * bits[s]
+        Cw[:, 1:] = C[b] * w[:, None]
+        want = orc.calc_L3(mu[b], Cw, m, r, n)[0]
+        if math.isnan(want):
+            assert math.isnan(nll[b, s]), (b, s)
+        else:
+            assert abs(nll[b, s] - want) <= 1e-12 * abs(want), (b, s, nll[b, s], want)
+    sub = rng.choice(B, 64, replace=False)
+    plain, _ = ctx.score_masked(n, tau, np.ascontiguousarray(C[sub]), w, r, np.ascontiguousarray(mu[sub]), None)
+    assert np.allclose(plain[:, 0], nll[sub, 0], rtol=1e-13, atol=0)

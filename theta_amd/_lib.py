@@ -284,6 +284,15 @@ class DeviceArray:
 _default_ctx = None
 
 
+def _rss_bytes():
+    """resident set size of this process (0 where /proc is not available)"""
+    try:
+        with open("/proc/self/statm") as f:
+            return int(f.read().split()[1]) * os.sysconf("SC_PAGE_SIZE")
+    except Exception:
+        return 0
+
+
 def default_context():
     """Process-wide context on cuda:LOCAL_RANK (created on first use)."""
     global _default_ctx
@@ -451,8 +460,14 @@ class Problem:
         acc = _Merged(self.n, self.m)
         redo = []                                        # pieces whose device suspect list overflowed: (index, b, e, hint used)
         b, piece = begin, 0
+        rss0 = _rss_bytes()
         while b < end:
             e = min(b + step, end)
+            if piece and piece % 256 == 0 and _rss_bytes() - rss0 > self.MAX_HOST_GROWTH:
+                # a guard, not a code path: the merge keeps what can still matter, so the host footprint of a search does not
+                # grow with its length -- if it does (round 2 lost three GPU boxes to a list of 1e25 pieces), stop here
+                raise ThetaError(ERR_CAPACITY, "host memory grew by %.1f GB while walking ranks [%d, %d): refusing to go on"
+                                 % ((_rss_bytes() - rss0) / 2.0 ** 30, begin, b))
             part = self._piece(b, e, window, cap, running)           # later pieces start from the minimum found so far
             nl = part[0]["nll"]
             hint_used = running
@@ -480,6 +495,7 @@ class Problem:
 
     # pieces per search() call: 2^25 x 2^31 = 2^56 n=3 candidates (7e16: eleven days of this GPU at 7.5e10 candidates/s)
     MAX_PIECES = 1 << 25
+    MAX_HOST_GROWTH = 8 << 30            # bytes the host process may grow by during one search (guard, see search())
 
     def hint(self, nll_upper_bound):
         """One-shot: an NLL already known to be attainable (keeps the next search's lists short)."""

@@ -44,6 +44,9 @@
 #ifndef SV_CAP
 #define SV_CAP 64         // nodes per intermediate level list
 #endif
+// ... of the list of last-level nodes: as long as the block's LDS allows at the kernel's occupancy (float: 3 blocks of <= 52 KB
+// per CU -- one entry more and the third block no longer fits, measured: -15 %; double: 2 blocks of <= 80 KB)
+template <class F> struct SvCapL { static constexpr int v = sizeof(F) == 4 ? 160 : 192; };
 #ifndef SV_QCAP
 #define SV_QCAP 128       // records waiting for further Newton steps
 #endif
@@ -121,7 +124,10 @@ template <int ML, class F>
 struct SvWave {
     alignas(16) unsigned short pre[N3_MAX_M_WIDE + 8];  // rows of the prefix, a | b << 8
     uint2 list0[N3_MAX_Q];                              // level 1 nodes (children of the prefix's last node)
-    uint2 list[ML > 2 ? ML - 2 : 1][SV_CAP];            // level l >= 2: {packed parent node, ancestor slots (6 bits each) | slot << 24}
+    uint2 list[ML > 3 ? ML - 3 : 1][SV_CAP];            // level l = 2 .. ML-2: {packed parent node, ancestor slots (6 bits each) | slot << 24}
+    uint2 listL[SvCapL<F>::v];                               // level ML-1 (the last-level nodes): longer, so that a round of the level above
+                                                        // takes ~40 nodes instead of ~12 (with 64 entries and ~5 children per node its
+                                                        // rounds ran at a fifth of the lanes)
     unsigned short kid[SV_KIDS];                        // candidates of the current round: last row's slot | parent lane << 8
     SvPlanes<F> par;                                    // per last-level node of the round: shared sums, column sums, point
     unsigned pcode[WAVE];                               // ... and the slots of its path rows (6 bits each) | usable << 31
@@ -645,7 +651,7 @@ __device__ __forceinline__ unsigned long long sv_child_mask(const SvCtx<ML, F> &
 template <int ML, int LVL, class F>
 __device__ __forceinline__ void sv_expand(SvCtx<ML, F> &c, int n_in) {
     constexpr bool last = (LVL == ML - 1);
-    const int cap = last ? SV_KIDS : (LVL == 0 ? N3_MAX_Q : SV_CAP);
+    const int cap = last ? SV_KIDS : (LVL == ML - 2 ? SvCapL<F>::v : (LVL == 0 ? N3_MAX_Q : SV_CAP));
     int pos = 0;
     while (pos < n_in) {
         const int i = pos + c.lane;
@@ -654,7 +660,7 @@ __device__ __forceinline__ void sv_expand(SvCtx<ML, F> &c, int n_in) {
         unsigned code = 0;                                 // slots of rows D .. D+LVL-1, 6 bits each
         if (LVL > 0) {
             if (live) {
-                const uint2 e = (LVL == 1) ? c.W->list0[i] : c.W->list[LVL >= 2 ? LVL - 2 : 0][i];
+                const uint2 e = (LVL == 1) ? c.W->list0[i] : (LVL == ML - 1) ? c.W->listL[i] : c.W->list[LVL >= 2 && LVL < ML - 1 ? LVL - 2 : 0][i];
                 const N3State pst = n3_unpack(e.x);
                 const unsigned slot = e.y >> 24;
                 n3_child_dyn(c.S->ridx, c.S->rowtab, pst, (int)slot, node);
@@ -721,7 +727,7 @@ __device__ __forceinline__ void sv_expand(SvCtx<ML, F> &c, int n_in) {
         } else {
             const unsigned ps = n3_pack(node);
             if (take) {
-                uint2 *dst = ((LVL == 0) ? c.W->list0 : c.W->list[LVL >= 1 ? LVL - 1 : 0]) + off;
+                uint2 *dst = ((LVL == 0) ? c.W->list0 : (LVL == ML - 2) ? c.W->listL : c.W->list[LVL >= 1 && LVL < ML - 2 ? LVL - 1 : 0]) + off;
                 while (mk) {
                     const int s = __builtin_ctzll(mk);
                     mk &= mk - 1;
