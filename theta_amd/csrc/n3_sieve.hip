@@ -196,7 +196,8 @@ struct SvCtx {
     // rare paths --, `dismissed` follows on the host: every regular candidate ends dismissed or listed.  Round 2 kept nine 64-bit
     // counters and six ballots per round of children: scalar registers the kernel does not have, they lived in VGPR lanes.)
 #ifdef SV_PROF
-    unsigned long long pt[6];        // cycles: 0 group tile, 1 parent phase, 2 children phase (less its drains), 3 drain, 4 prefix successor, 5 whole wave
+    unsigned long long pt[7];        // cycles: 0 group tile, 1 parent phase, 2 children phase (less its drains), 3 drain, 4 prefix successor, 5 whole wave,
+                                     // 6 the last level's own expansion (list read, child masks, scan, kid list) -- the upper levels are the rest
 #endif
     unsigned n_par, n_prefix;        // last-level nodes evaluated (phase P), prefixes walked
     unsigned n_child, n_dit;         // shared first evaluations (children) / full evaluations (queue)
@@ -654,6 +655,9 @@ __device__ __forceinline__ void sv_expand(SvCtx<ML, F> &c, int n_in) {
     const int cap = last ? SV_KIDS : (LVL == ML - 2 ? SvCapL<F>::v : (LVL == 0 ? N3_MAX_Q : SV_CAP));
     int pos = 0;
     while (pos < n_in) {
+#ifdef SV_PROF
+        const unsigned long long pi = __builtin_amdgcn_s_memtime();
+#endif
         const int i = pos + c.lane;
         bool live = i < n_in;
         N3State node = c.par;
@@ -701,16 +705,24 @@ __device__ __forceinline__ void sv_expand(SvCtx<ML, F> &c, int n_in) {
         const bool take = live && c.lane < t;
         if constexpr (last) {
             if (take) {
+                // (the two 32-bit halves of the mask one after the other: half the instructions of a 64-bit ctz / clear per child)
                 unsigned short *dst = c.W->kid + off;
                 const unsigned tag = (unsigned)c.lane << 8;
-                while (mk) {
-                    const int s = __builtin_ctzll(mk);
-                    mk &= mk - 1;
-                    *dst++ = (unsigned short)((unsigned)s | tag);
+                unsigned mlo = (unsigned)mk, mhi = (unsigned)(mk >> 32);
+                while (mlo) {
+                    const unsigned s = (unsigned)__builtin_ctz(mlo);
+                    mlo &= mlo - 1;
+                    *dst++ = (unsigned short)(s | tag);
+                }
+                while (mhi) {
+                    const unsigned s = (unsigned)__builtin_ctz(mhi) + 32u;
+                    mhi &= mhi - 1;
+                    *dst++ = (unsigned short)(s | tag);
                 }
             }
 #ifdef SV_PROF
             const unsigned long long pa = __builtin_amdgcn_s_memtime();
+            c.pt[6] += pa - pi;
 #endif
             sv_parent<ML, F>(c, take && cnt > 0, code);
             c.n_par += (unsigned)__builtin_popcountll(ballot64(take && cnt > 0));
@@ -728,10 +740,16 @@ __device__ __forceinline__ void sv_expand(SvCtx<ML, F> &c, int n_in) {
             const unsigned ps = n3_pack(node);
             if (take) {
                 uint2 *dst = ((LVL == 0) ? c.W->list0 : (LVL == ML - 2) ? c.W->listL : c.W->list[LVL >= 1 && LVL < ML - 2 ? LVL - 1 : 0]) + off;
-                while (mk) {
-                    const int s = __builtin_ctzll(mk);
-                    mk &= mk - 1;
-                    *dst++ = make_uint2(ps, code | ((unsigned)s << 24));
+                unsigned mlo = (unsigned)mk, mhi = (unsigned)(mk >> 32);
+                while (mlo) {
+                    const unsigned s = (unsigned)__builtin_ctz(mlo);
+                    mlo &= mlo - 1;
+                    *dst++ = make_uint2(ps, code | (s << 24));
+                }
+                while (mhi) {
+                    const unsigned s = (unsigned)__builtin_ctz(mhi) + 32u;
+                    mhi &= mhi - 1;
+                    *dst++ = make_uint2(ps, code | (s << 24));
                 }
             }
             wave_lds_sync();
@@ -842,7 +860,7 @@ __global__ __launch_bounds__(64 * SV_WAVES, sizeof(F) == 4 ? SV_OCC : SV_OCC64) 
     c.n_par = c.n_prefix = 0;
     c.n_child = c.n_dit = 0;
 #ifdef SV_PROF
-    for (int i = 0; i < 6; i++) c.pt[i] = 0;
+    for (int i = 0; i < 7; i++) c.pt[i] = 0;
     const unsigned long long pw0 = __builtin_amdgcn_s_memtime();
 #endif
     const double inv_N = 1.0 / Pg.N;
@@ -947,8 +965,7 @@ __global__ __launch_bounds__(64 * SV_WAVES, sizeof(F) == 4 ? SV_OCC : SV_OCC64) 
         atomicAdd(&A.ctr->sieve_children, (unsigned long long)c.n_child);
 #ifdef SV_PROF
         c.pt[5] = __builtin_amdgcn_s_memtime() - pw0;
-        for (int i = 0; i < 6; i++) atomicAdd(&A.ctr->prof[i], c.pt[i]);
-        atomicAdd(&A.ctr->prof[6], (unsigned long long)c.n_par);
+        for (int i = 0; i < 7; i++) atomicAdd(&A.ctr->prof[i], c.pt[i]);
 #else
         atomicAdd(&A.ctr->prof[0], (unsigned long long)c.n_par);
 #endif
