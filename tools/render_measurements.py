@@ -1,0 +1,88 @@
+"""Renders DESIGN.md section 6's tables (and README's three headline figures) from the JSON files under profiles/rN/, so that
+the documents quote what the profiles hold.  python tools/render_measurements.py r3  ->  rewrites the block between the
+<!-- measurements:begin --> / <!-- measurements:end --> markers of DESIGN.md and the figures of README.md."""
+import json
+import os
+import re
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+R = sys.argv[1] if len(sys.argv) > 1 else "r3"
+P = os.path.join(ROOT, "profiles", R)
+b = json.load(open(os.path.join(P, "bench_n1.json")))
+rf, legs = b["roofline"], b["roofline"]["legs"]
+
+
+def e(x):
+    return ("%.2e" % x).replace("e+", "e")
+
+
+rows = []
+what = {"full_solve_f64": "**headline**: `n3_no_dismiss` + `n3_force_f64` — every candidate iterated in FP64 to the coarse tolerance and valued, none dismissed (§8(d)'s definition)",
+        "full_solve_f32": "`n3_no_dismiss`: the same in packed single precision",
+        "search": "as shipped: 99.9 % of the candidates finished by the lower bound after one shared evaluation (\"searched\", a rider)"}
+for name in ("full_solve_f64", "full_solve_f32", "search"):
+    l = legs[name]
+    sm = l["step_kernel_ms"]
+    rows.append("| `%s` | %s | %s | %.1f (%.1f / %.1f / %.1f) | %.2f | %.0f (%.0f %% FP64) | %.1f | %.3f of %.1f |" % (
+        name, what[name], e(l["value"]), l["kernel_ms_per_launch"], sm["min"], sm["median"], sm["max"], l["newton_iters_per_candidate"],
+        l["flop_per_candidate"], 100 * l["fp64_flop_share"], l["achieved"], l["frac"], l["peak"]))
+cpu = b["cpu_baseline"]
+w = b["wall_clock_to_best"]
+rid = b["riders"]["config5_masked_scorer"]
+h = legs[b["config"]["leg"]]
+txt = []
+txt.append("`python bench.py --steps %d --warmup %d` (N=1, the driver's layout; `profiles/%s/bench_n1.json`; no torch): **%s candidates/s** "
+           "whole-job, %.1f ms per step of 2^31 candidates = one `theta_search` call (a short first slice + the bulk: %d launches of the sieve "
+           "kernel per step, each followed by the finish kernel; %.1f ms of kernel time per launch), steps at the mid-points of %d equal "
+           "stretches of the rank space, chained like the pieces of one job.\n" % (
+               b["steps"], b["warmup"], R, e(b["value"]), b["ms_per_step"], h["kernel_launches"] // max(h["launches"], 1),
+               h["kernel_ms_per_kernel_launch"], b["steps"] + b["warmup"]))
+txt.append("| leg | what runs | candidates/s | kernel ms per step (min / median / max) | evaluations per candidate | executed FLOP per candidate | achieved TFLOP/s | of its vector peak |")
+txt.append("|---|---|---|---|---|---|---|---|")
+txt += rows
+txt.append("")
+txt.append("(The legs other than the headline run after the timed region on the first four of the same stretches.  `survivors` %d, "
+           "`fallback_candidates` %d, `redo_kernel_ms` %.1f over the headline's %d steps: no timed step fell back.)\n" % (
+               h["survivors"], h["fallback_candidates"], h["redo_kernel_ms"], h["launches"]))
+txt.append("HBM traffic (`roofline.traffic`, two `rocprofv3 --pmc` passes of the same command): %.2f GB per launch against 0 algorithmic "
+           "bytes — %.1f B per candidate: the counting table at task starts, contender records, counters.\n" % (
+               (rf["traffic"] or 0) / 1e9, (rf["traffic"] or 0) / 2 ** 31))
+txt.append("CPU beside it (`cpu_baseline`): %s — %s candidates/s on all %d cores, %.0f per process.\n" % (cpu["sample"], e(cpu["value"]), cpu["cores"], cpu["per_process"]))
+txt.append("`wall_clock_to_best` (second half of BASELINE's metric; end to end through `do_optimization_single`): config 1 "
+           "(`Example.intervals -n 2 -k 3`, 142 560 candidates) %.1f ms against %.1f s of the reference's own search loop; config 2 (m=25, n=2, "
+           "k=5) %.1f ms against ≈ %.0f s of the oracle; the n=3 stage of `syn14.intervals` (1 369 938 candidates) %.1f ms against ≈ 55 min of "
+           "the reference CLI, same winner, NLL %.9f.\n" % (
+               1e3 * w["config1_example_n2_k3"]["gpu_wall_s"], w["config1_example_n2_k3"]["reference_search_s"],
+               1e3 * w["config2_m25_n2_k5"]["gpu_wall_s"], w["config2_m25_n2_k5"]["cpu_oracle_estimated_s"],
+               1e3 * w["syn14_n3_stage"]["gpu_wall_s"], w["syn14_n3_stage"]["nll"]))
+txt.append("**Rider, config 5** (`riders.config5_masked_scorer`, m=200, n=3, k=7: 131 072 byte candidates × 512 interval masks): %s pairs/s = "
+           "%.1f TFLOP/s FP64 MFMA = %.2f of the 78.6 dense peak, %.2f TB/s of algorithmic traffic — MFMA-bound, not HBM-bound as "
+           "`north_star` labels it.\n" % (e(rid["value"]), rid["roofline"]["achieved"], rid["roofline"]["frac"], rid["roofline"]["hbm_algorithmic_GBps"] / 1e3))
+try:
+    rd = json.load(open(os.path.join(P, "riders.json")))
+    en, dc, bc = rd["enum_profile.py"], rd["device_chain.py"], rd["bench_configs.py"]
+    txt.append("Materialised operators, device resident (`profiles/%s/riders.json`, kernel times in `riders_kernel_stats.csv`): n=3 generator "
+               "%.1f / %.1f / %.1f TB/s written (m=50 K=6 / m=50 K=4 / m=64 K=3), n=2 generator %.1f / %.1f TB/s (m=50 / m=100); plain scorer "
+               "%.2f TB/s = %s candidates/s (n=3, m=50), %.2f TB/s (n=2, m=100); `theta_solve_batch_device` %s / %s candidates/s (n=3 / n=2).  "
+               "Other configs: config 2 (m=25, n=2, k=5: 142 506 candidates) %.2f ms; n=2, m=50, k=6 (3.2e7 candidates) %s/s; n=2, m=100, k=5 %s/s; "
+               "config 3 (m=50, n=3, k=4, 2^27 candidates searched) %s/s.\n" % (
+                   R, en["n3_m50_k6"]["GBps"] / 1e3, en["n3_m50_k4"]["GBps"] / 1e3, en["n3_m64_k3"]["GBps"] / 1e3, en["n2_m50_k6"]["GBps"] / 1e3,
+                   en["n2_m100_k5"]["GBps"] / 1e3, dc["n3_m50_k6"]["score_GBps"] / 1e3, e(dc["n3_m50_k6"]["score_candidates_per_s"]),
+                   dc["n2_m100_k5"]["score_GBps"] / 1e3, e(dc["n3_m50_k6"]["solve_batch_candidates_per_s"]), e(dc["n2_m100_k5"]["solve_batch_candidates_per_s"]),
+                   bc["config2_n2_m25_k5"]["wall_ms"], e(bc["n2_m50_k6"]["candidates_per_s_kernel"]), e(bc["n2_m100_k5"]["candidates_per_s_kernel"]),
+                   e(bc["config3_n3_m50_k4"]["candidates_per_s_kernel"])))
+except Exception as ex:
+    txt.append("(riders.json not readable: %s)\n" % ex)
+block = "\n".join(txt)
+for fn in ("DESIGN.md",):
+    p = os.path.join(ROOT, fn)
+    s = open(p).read()
+    s = re.sub(r"<!-- measurements:begin -->.*<!-- measurements:end -->", "<!-- measurements:begin -->\n" + block + "\n<!-- measurements:end -->", s, flags=re.S)
+    open(p, "w").write(s)
+p = os.path.join(ROOT, "README.md")
+s = open(p).read()
+s = re.sub(r"\*\*[0-9.e@F]+ candidates/s FP64 full solve\*\*", "**%s candidates/s FP64 full solve**" % e(legs["full_solve_f64"]["value"]), s)
+s = re.sub(r"\), [0-9.e@F]+ packed full solve, [0-9.e@SEARCH]+ searched", "), %s packed full solve, %s searched" % (e(legs["full_solve_f32"]["value"]), e(legs["search"]["value"])), s)
+open(p, "w").write(s)
+print(block[:1500])
