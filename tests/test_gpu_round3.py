@@ -172,3 +172,63 @@ def test_masked_scorer_at_the_full_config5_shape_against_the_oracle(ctx):
     sub = rng.choice(B, 64, replace=False)
     plain, _ = ctx.score_masked(n, tau, np.ascontiguousarray(C[sub]), w, r, np.ascontiguousarray(mu[sub]), None)
     assert np.allclose(plain[:, 0], nll[sub, 0], rtol=1e-13, atol=0)
+
+
+def test_n2_table_driven_plain_scorer_against_the_oracle_and_the_direct_kernel(ctx, monkeypatch):
+    """score_plain_n2_table_kernel (n = 2 without masks: 16 logarithms per candidate in an LDS table instead of one per interval)
+    against CalcAllC.L2 of the oracle on a sample, and against the per-interval kernel (THETA_SCORE_NO_TABLE=1) on every
+    candidate -- copy numbers above 15 (direct logarithm), mu0 at both ends of (0, 1), a block boundary in B."""
+    rng = np.random.RandomState(77)
+    for m, B in ((100, 1000), (52, 257), (8, 5)):
+        tau = 2
+        C = rng.randint(0, 7, (B, m)).astype(np.uint8)
+        C[3, :5] = [16, 17, 40, 255, 15]
+        w = rng.randint(1000, 90000, m).astype(float)
+        r = rng.randint(0, 90000, m).astype(float)
+        mu0 = rng.uniform(0.02, 0.98, B)
+        mu0[:2] = [1e-9, 1 - 1e-9]
+        mu = np.stack([mu0, 1 - mu0], 1)
+        got, _ = ctx.score_masked(2, tau, C, w, r, mu, None)
+        monkeypatch.setenv("THETA_SCORE_NO_TABLE", "1")
+        direct, _ = ctx.score_masked(2, tau, C, w, r, mu, None)
+        monkeypatch.delenv("THETA_SCORE_NO_TABLE")
+        assert got.shape == (B, 1)
+        assert np.allclose(got, direct, rtol=1e-13, atol=0)
+        for b in list(range(0, B, max(1, B // 25))) + [3]:
+            Cw = np.zeros((m, 2))
+            Cw[:, 0] = tau * w
+            Cw[:, 1] = C[b] * w
+            want = orc.calc_L2(mu[b, 0], Cw, m, r)[0]
+            assert abs(got[b, 0] - want) <= 1e-12 * abs(want), (m, b, got[b, 0], want)
+
+
+def test_plain_scorer_pipeline_over_tile_shapes(ctx):
+    """score_plain_kernel (persistent, double-buffered tiles) on the shapes that change its tiling: short and long records
+    (128-candidate tiles beyond 256 bytes), B below / at / above tile multiples and above one round of the persistent grid,
+    n = 2 and n = 3 -- against the oracle's CalcAllC.L2 / L3 on a sample and against the masked kernel with an all-ones mask."""
+    rng = np.random.RandomState(91)
+    for n, m, B in ((3, 200, 1000), (3, 200, 128), (3, 50, 256 * 1024 + 77), (2, 100, 256 * 1024 * 2 + 3), (3, 16, 300), (2, 256, 513), (3, 256, 129)):
+        tau = 2
+        C = rng.randint(0, 8, (B, m, n - 1)).astype(np.uint8)
+        if n == 2:
+            C = C[:, :, 0]
+        w = rng.randint(1000, 90000, m).astype(float)
+        r = rng.randint(1000, 90000, m).astype(float)
+        mu = rng.dirichlet(np.ones(n) * 3, B)
+        got, _ = ctx.score_masked(n, tau, C, w, r, mu, None)
+        assert got.shape == (B, 1) and np.isfinite(got).all()
+        for b in [0, 1, 127, 128, 255, 256, B // 2, B - 2, B - 1] + [int(x) for x in rng.randint(0, B, 12)]:
+            if b >= B:
+                continue
+            Cw = np.zeros((m, n))
+            Cw[:, 0] = tau * w
+            Cw[:, 1:] = C[b].reshape(m, n - 1) * w[:, None]
+            want = orc.calc_L3(mu[b], Cw, m, r, n)[0] if n == 3 else orc.calc_L2(mu[b, 0], Cw, m, r)[0]
+            assert abs(got[b, 0] - want) <= 1e-12 * abs(want), (n, m, B, b)
+        words = (m + 63) // 64
+        ones = np.zeros((16, words), np.uint64)
+        for i in range(m):
+            ones[:, i // 64] |= np.uint64(1) << np.uint64(i % 64)
+        sub = np.sort(rng.choice(B, min(B, 300), replace=False))
+        ref, _ = ctx.score_masked(n, tau, np.ascontiguousarray(C[sub]), w, r, np.ascontiguousarray(mu[sub]), ones)
+        assert np.allclose(ref[:, 0], got[sub, 0], rtol=1e-13, atol=0)

@@ -41,7 +41,8 @@ void batch_launch_boundary_min(int m, int tau, const double *r, const double *rN
                                double *bound, hipStream_t st);
 void batch_launch_score_masked(int n, int m, int tau, int B, int S, const unsigned char *C, const double *w,
                                const double *r, const double *mu, const unsigned long long *mask, double *nll,
-                               double *rsum_scratch, hipStream_t st, double rsum_host, bool rsum_host_valid);
+                               double *rsum_scratch, hipStream_t st, double rsum_host, bool rsum_host_valid, double rlogw_host,
+                               bool rlogw_valid);
 
 // ---- error string ---------------------------------------------------------------------------------
 static thread_local char g_err[512] = "";
@@ -1190,6 +1191,16 @@ static double host_sum(const double *v, int m) {
     for (int i = 0; i < m; i++) s += v[i];
     return s;
 }
+// sum r_i ln w_i for the n = 2 table-driven scorer (batch.hip): valid iff every weight is a positive finite number
+static bool host_rlogw(const double *w, const double *r, int m, double &out) {
+    double s = 0.0;
+    for (int i = 0; i < m; i++) {
+        if (!(w[i] > 0.0) || !(w[i] < INFINITY)) return false;
+        s += r[i] * log(w[i]);
+    }
+    out = s;
+    return true;
+}
 
 // ---- device memory the caller owns, for chains of operators that stay on the GPU ----------------------------------
 extern "C" int theta_device_alloc(theta_ctx *ctx, size_t bytes, void **out) {
@@ -1285,10 +1296,12 @@ extern "C" int theta_score_masked_device(theta_ctx *ctx, int n, int m, int tau, 
     if ((rc = upload(d_r, r, (size_t)m * sizeof(double), st))) return rc;
     if (mask && (rc = upload(d_mask, mask, (size_t)S * words * sizeof(uint64_t), st))) return rc;
     if ((rc = d_rsum.alloc((size_t)S * sizeof(double)))) return rc;
+    double rlogw = 0.0;
+    const bool rlogw_ok = host_rlogw(w, r, m, rlogw);
     HIP_TRY(hipEventRecord(ctx->ev0, st));
     batch_launch_score_masked(n, m, tau, B, S, (const unsigned char *)d_C, (const double *)d_w.p, (const double *)d_r.p,
                               (const double *)d_mu, mask ? (const unsigned long long *)d_mask.p : nullptr, (double *)d_nll,
-                              (double *)d_rsum.p, st, host_sum(r, m), true);
+                              (double *)d_rsum.p, st, host_sum(r, m), true, rlogw, rlogw_ok);
     HIP_TRY(hipEventRecord(ctx->ev1, st));
     HIP_TRY(hipStreamSynchronize(st));
     HIP_TRY(hipGetLastError());
@@ -1324,10 +1337,12 @@ extern "C" int theta_score_masked(theta_ctx *ctx, int n, int m, int tau, int B, 
     if (mask && (rc = upload(d_mask, mask, (size_t)S * words * sizeof(uint64_t), st))) return rc;
     if ((rc = d_nll.alloc((size_t)B * S * sizeof(double)))) return rc;
     if ((rc = d_rsum.alloc((size_t)S * sizeof(double)))) return rc;
+    double rlogw = 0.0;
+    const bool rlogw_ok = host_rlogw(w, r, m, rlogw);
     HIP_TRY(hipEventRecord(ctx->ev0, st));
     batch_launch_score_masked(n, m, tau, B, S, (const unsigned char *)d_C.p, (const double *)d_w.p, (const double *)d_r.p,
                               (const double *)d_mu.p, mask ? (const unsigned long long *)d_mask.p : nullptr,
-                              (double *)d_nll.p, (double *)d_rsum.p, st, host_sum(r, m), true);
+                              (double *)d_nll.p, (double *)d_rsum.p, st, host_sum(r, m), true, rlogw, rlogw_ok);
     HIP_TRY(hipEventRecord(ctx->ev1, st));
     HIP_TRY(hipMemcpyAsync(nll, d_nll.p, (size_t)B * S * sizeof(double), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));

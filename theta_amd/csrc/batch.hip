@@ -532,34 +532,103 @@ __global__ __launch_bounds__(64 * SMX_WAVES) void score_masked_mfma_kernel(int n
 // logarithm (~15 instructions per interval), not HBM.  NLL = -(sum r ln(C.mu) - sum r ln(sum C.mu)).
 // ------------------------------------------------------------------------------------------------
 extern __shared__ unsigned int spc_lds[];
-template <int NC>
+#define SPT_VALUES 8       // n = 2: logarithms tabulated per candidate (copy numbers 0..7; larger ones take the direct logarithm)
+// A tile = TS consecutive candidates (cw dwords each, contiguous in global memory) staged into LDS rows of odd stride pw
+// (lanes then read their own rows conflict-free): 16-byte loads, eight per thread in flight before the first LDS store.
+// (Round 2 staged with dword loads and a store after each: a chain of dependent round trips to HBM.  A persistent,
+// double-buffered form -- tile k+1 in registers while tile k is scored -- was tried in round 3 and lost: the 64 registers of
+// the prefetch cost the occupancy the scoring phase needs.)
+__device__ __forceinline__ void spc_stage(const unsigned char *src_bytes, int nb, int cw, int pw) {
+    const int total = nb * cw;                                  // dwords
+    const int nq = total >> 2;                                  // whole 16-byte chunks (a tile starts 16-byte aligned)
+    const uint4 *src4 = (const uint4 *)src_bytes;
+    const unsigned magic = (unsigned)((0x100000000ull + (unsigned)cw - 1) / (unsigned)cw);
+    for (int base = 0; base < nq; base += 256 * 8) {
+        uint4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int q = base + u * 256 + (int)threadIdx.x;
+            if (q < nq) v[u] = src4[q];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int q = base + u * 256 + (int)threadIdx.x;
+            if (q < nq) {
+                const unsigned vals[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const unsigned g = 4u * (unsigned)q + (unsigned)k;
+                    const unsigned cand = __umulhi(g, magic);      // g / cw (exact: g (cw - 1) < 2^32)
+                    spc_lds[cand * (unsigned)pw + (g - cand * (unsigned)cw)] = vals[k];
+                }
+            }
+        }
+    }
+    const unsigned int *src = (const unsigned int *)src_bytes;
+    for (int idx = (nq << 2) + (int)threadIdx.x; idx < total; idx += 256) {          // (a last tile's tail of < 4 dwords)
+        const unsigned cand = __umulhi((unsigned)idx, magic);
+        spc_lds[cand * (unsigned)pw + ((unsigned)idx - cand * (unsigned)cw)] = src[idx];
+    }
+}
+
+// TABLE (n = 2 only): with one tumour column the row term is C.mu = w_i (tau mu0 + x mu1); its logarithm is
+// ln w_i + ln(tau mu0 + x mu1) -- the first part a constant of the problem (sum r_i ln w_i, summed once on the host), the
+// second one of a handful of values per candidate (x is a copy number).  A thread computes SPT_VALUES logarithms once, keeps
+// them in its column of an LDS table [value][thread] (the bank depends on the thread only: conflict-free) and walks its m rows
+// with one 8-byte table read and three FMAs each: ~10 vector instructions per interval instead of 28.  Requires every w_i > 0
+// (else the direct form, whose per-interval order of operations then decides between inf and NaN).
+template <int NC, bool TABLE>
 __global__ __launch_bounds__(256) void score_plain_kernel(int m, int tau, int B, const unsigned char *C, const double *w, const double *r,
-                                                          const double *mu, double rsum, double *nll) {
+                                                          const double *mu, double rsum, double rlogw, double *nll) {
+    static_assert(!TABLE || NC == 1, "the table form is for one tumour column");
     const int cb = m * NC;                       // bytes per candidate, a multiple of 4 (checked by the launcher)
     const int cw = cb >> 2, pw = cw | 1;         // words per candidate; odd LDS stride: lanes fall on distinct banks
-    const long long b0 = (long long)blockIdx.x * 256;
-    const int nb = (int)((long long)B - b0 < 256 ? (long long)B - b0 : 256);
-    const unsigned int *src = (const unsigned int *)(C + (size_t)b0 * cb);
-    const double2 *const tab = (const double2 *)(spc_lds + ((256 * pw + 3) & ~3));    // (16-byte aligned)
+    const int TS = cw <= 64 ? 256 : 128;         // candidates per tile (records beyond 256 bytes: half tiles, the LDS rows are what limits them)
+    const int tab_off = (TS * pw + 3) & ~3;
+    const double2 *const tab = (const double2 *)(spc_lds + tab_off);                       // smx_log's table (16-byte aligned)
+    double2 *const wr = (double2 *)(spc_lds + tab_off + SMX_TAB_BYTES / 4);                // {w_i, r_i}: every lane reads the same pair (a broadcast)
+    double *const T = (double *)(wr + ((m + 3) & ~3));                                     // TABLE: [SPT_VALUES][256]
+    const long long b0 = (long long)blockIdx.x * TS;
+    const int nb = (int)((long long)B - b0 < TS ? (long long)B - b0 : TS);
     smx_log_stage((double2 *)tab);
-    for (int idx = threadIdx.x; idx < nb * cw; idx += 256) {
-        const int cand = idx / cw, within = idx - cand * cw;
-        spc_lds[cand * pw + within] = src[idx];
-    }
+    for (int i = threadIdx.x; i < m; i += 256) wr[i] = double2{w[i], r[i]};
+    spc_stage(C + (size_t)b0 * cb, nb, cw, pw);
     __syncthreads();
     if ((int)threadIdx.x >= nb) return;
     const long long b = b0 + threadIdx.x;
     const double *mv = mu + (size_t)b * (NC + 1);
     const double m0 = (double)tau * mv[0], m1 = (NC == 1) ? 1.0 - mv[0] : mv[1], m2 = (NC == 2) ? mv[2] : 0.0;
-    const unsigned char *row = (const unsigned char *)(spc_lds + threadIdx.x * pw);
     double den = 0.0, tot = 0.0;
-    for (int i = 0; i < m; i++) {
-        const double x = (double)row[i * NC], y = (NC == 2) ? (double)row[i * NC + 1] : 0.0;
-        const double cm = w[i] * __builtin_fma(x, m1, __builtin_fma(y, m2, m0));
-        den += cm;
-        tot = __builtin_fma(r[i], smx_log(cm, tab), tot);
+    if constexpr (TABLE) {
+        double *const mine = T + threadIdx.x;
+#pragma unroll
+        for (int v = 0; v < SPT_VALUES; v++) mine[v * 256] = smx_log(__builtin_fma((double)v, m1, m0), tab);
+        const unsigned int *row = spc_lds + threadIdx.x * pw;
+        for (int q = 0; q < cw; q++) {
+            const unsigned int word = row[q];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const double2 wi = wr[4 * q + k];
+                const unsigned x = (word >> (8 * k)) & 0xffu;
+                const double inner = __builtin_fma((double)x, m1, m0);
+                den = __builtin_fma(wi.x, inner, den);
+                const double lg = x < SPT_VALUES ? mine[x * 256] : smx_log(inner, tab);
+                tot = __builtin_fma(wi.y, lg, tot);
+            }
+        }
+        nll[b] = -((tot + rlogw) - rsum * smx_log(den, tab));
+    } else {
+        const unsigned char *row = (const unsigned char *)(spc_lds + threadIdx.x * pw);
+#pragma unroll 4
+        for (int i = 0; i < m; i++) {
+            const double2 wi = wr[i];
+            const double x = (double)row[i * NC], y = (NC == 2) ? (double)row[i * NC + 1] : 0.0;
+            const double cm = wi.x * __builtin_fma(x, m1, __builtin_fma(y, m2, m0));
+            den += cm;
+            tot = __builtin_fma(wi.y, smx_log(cm, tab), tot);
+        }
+        nll[b] = -(tot - rsum * smx_log(den, tab));
     }
-    nll[b] = -(tot - rsum * smx_log(den, tab));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -590,7 +659,8 @@ void batch_launch_score(int n, int m, int B, const double *Cw, const double *mu,
 
 void batch_launch_score_masked(int n, int m, int tau, int B, int S, const unsigned char *C, const double *w,
                                const double *r, const double *mu, const unsigned long long *mask, double *nll,
-                               double *rsum_scratch, hipStream_t st, double rsum_host, bool rsum_host_valid) {
+                               double *rsum_scratch, hipStream_t st, double rsum_host, bool rsum_host_valid, double rlogw_host,
+                               bool rlogw_valid) {
     if (mask != nullptr && S >= 16 && rsum_scratch != nullptr) {   // enough masks to fill the 16-row MFMA tiles
         hipLaunchKernelGGL(mask_rsum_kernel, dim3(S), dim3(64), 0, st, m, S, r, mask, rsum_scratch);
         const size_t xa = (size_t)m * 256 + SMX_TAB_BYTES, xb = (size_t)((m + 15) & ~15) * 256;
@@ -608,15 +678,21 @@ void batch_launch_score_masked(int n, int m, int tau, int B, int S, const unsign
             SMX_LAUNCH(9) SMX_LAUNCH(10) SMX_LAUNCH(11) SMX_LAUNCH(12) SMX_LAUNCH(13) SMX_LAUNCH(14) SMX_LAUNCH(15) SMX_LAUNCH(16)
         }
 #undef SMX_LAUNCH
-    } else if (mask == nullptr && S == 1 && ((m * (n - 1)) & 3) == 0 && rsum_scratch != nullptr && rsum_host_valid) {
-        const size_t lds = (((size_t)256 * (((m * (n - 1)) >> 2) | 1) + 3) & ~(size_t)3) * 4 + SMX_TAB_BYTES;
-        const unsigned blocks = (unsigned)(((long long)B + 255) / 256);
-        if (n == 2) {
-            (void)hipFuncSetAttribute((const void *)score_plain_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL(score_plain_kernel<1>, dim3(blocks), dim3(256), lds, st, m, tau, B, C, w, r, mu, rsum_host, nll);
+    } else if (mask == nullptr && S == 1 && ((m * (n - 1)) & 3) == 0 && m * (n - 1) <= 512 && (((uintptr_t)C) & 15) == 0 && rsum_scratch != nullptr && rsum_host_valid) {
+        const int ts = (m * (n - 1)) / 4 <= 64 ? 256 : 128;           // candidates per tile (batch.hip: score_plain_kernel)
+        const size_t lds = (((size_t)ts * (((m * (n - 1)) >> 2) | 1) + 3) & ~(size_t)3) * 4 + SMX_TAB_BYTES + (size_t)((m + 3) & ~3) * 16;
+        const long long tiles = ((long long)B + ts - 1) / ts;
+        const unsigned blocks = (unsigned)tiles;
+        if (n == 2 && rlogw_valid && !getenv("THETA_SCORE_NO_TABLE")) {      // every w_i > 0: the table-driven form
+            const size_t ldt = lds + (size_t)SPT_VALUES * 256 * sizeof(double);
+            (void)hipFuncSetAttribute((const void *)score_plain_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldt);
+            hipLaunchKernelGGL((score_plain_kernel<1, true>), dim3(blocks), dim3(256), ldt, st, m, tau, B, C, w, r, mu, rsum_host, rlogw_host, nll);
+        } else if (n == 2) {
+            (void)hipFuncSetAttribute((const void *)score_plain_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL((score_plain_kernel<1, false>), dim3(blocks), dim3(256), lds, st, m, tau, B, C, w, r, mu, rsum_host, 0.0, nll);
         } else {
-            (void)hipFuncSetAttribute((const void *)score_plain_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL(score_plain_kernel<2>, dim3(blocks), dim3(256), lds, st, m, tau, B, C, w, r, mu, rsum_host, nll);
+            (void)hipFuncSetAttribute((const void *)score_plain_kernel<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL((score_plain_kernel<2, false>), dim3(blocks), dim3(256), lds, st, m, tau, B, C, w, r, mu, rsum_host, 0.0, nll);
         }
     } else {
         // (a HIP grid holds fewer than 2^32 threads: 2^24 candidates -- one wave each -- per launch)
