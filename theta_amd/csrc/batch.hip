@@ -445,17 +445,38 @@ __global__ __launch_bounds__(64 * SMX_WAVES) void score_masked_mfma_kernel(int n
         }
         const int st = (threadIdx.x >> 4) & 3;                                // = row & 3: the MFMA step that consumes the row
         const int ex = st == 0 ? 895 : st == 1 ? 767 : st == 2 ? 511 : -1;
-        for (int i = threadIdx.x >> 4; i < m; i += 32) {
-            double cm = 0.0, tl = 0.0;
-            if (live) {
+        // the candidate bytes of ALL of this thread's rows first (2-byte loads 400 bytes apart between lanes: uncoalesced, a round
+        // trip to HBM each) -- in flight together; issued one per pass of the loop below they were seven dependent round trips
+        // before the block's first MFMA
+        constexpr int NIT = (16 * NG + 31) / 32;
+        unsigned short cby[NIT];
+        double wv_[NIT], rv_[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; it++) {
+            const int i = (threadIdx.x >> 4) + 32 * it;
+            cby[it] = 0;
+            wv_[it] = rv_[it] = 0.0;
+            if (live && i < m) {
                 const unsigned char *cc = C + ((size_t)b * m + i) * nc;
-                const double x = (double)cc[0], y = (nc == 2) ? (double)cc[1] : 0.0;
-                const double tum = x * m1 + y * m2;
-                cm = w[i] * (m0 + tum);
-                tl = r[i] * smx_log(cm, tab);
-                if (!(w[i] * tum > 0.0)) atomicOr(&zrow[c][i >> 6], 1ull << (i & 63));
+                cby[it] = (unsigned short)(cc[0] | (nc == 2 ? (unsigned)cc[1] << 8 : 0u));
+                wv_[it] = w[i];
+                rv_[it] = r[i];
             }
-            X[i * 16 + c] = double2{ldexp(cm, ex), ldexp(tl, ex)};
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; it++) {
+            const int i = (threadIdx.x >> 4) + 32 * it;
+            if (i < m) {
+                double cm = 0.0, tl = 0.0;
+                if (live) {
+                    const double x = (double)(cby[it] & 0xffu), y = (double)(cby[it] >> 8);
+                    const double tum = x * m1 + y * m2;
+                    cm = wv_[it] * (m0 + tum);
+                    tl = rv_[it] * smx_log(cm, tab);
+                    if (!(wv_[it] * tum > 0.0)) atomicOr(&zrow[c][i >> 6], 1ull << (i & 63));
+                }
+                X[i * 16 + c] = double2{ldexp(cm, ex), ldexp(tl, ex)};
+            }
         }
     }
     __syncthreads();
