@@ -39,6 +39,7 @@
 #define HYBRJ4_MANAGE_CONTRACT     // this unit allows fused multiply-adds; the hybrj restatement must not use them
 #include "n3_refbfgs.hpp"
 #include "n3_sieve.hpp"
+#include "smx_log.hpp"             // the table-driven FP64 logarithm of the scorers (within one ulp; tests/test_smx_log_cpu.py)
 
 #define SV_WAVES 4
 #ifndef SV_CAP
@@ -987,9 +988,11 @@ __device__ __noinline__ int sv_reference_outcome(int m, double tau, const double
     return n3_ref_outcome(sys, nu);      // 1 own iterate (nu), 2 the nu = 1/3 fallback, 0 None
 }
 
+extern __shared__ unsigned short fin_rows[];     // [256][m | 1]: the block's contender rows, a | b << 8 (dynamic LDS)
 __global__ __launch_bounds__(256) void n3_finish_kernel(N3Dev P, SearchArgs A, const SvSurvivor *surv, unsigned surv_cap,
                                                         const unsigned *surv_count, unsigned *accepted_count) {
     __shared__ double rr[N3_MAX_M_WIDE], rn[N3_MAX_M_WIDE];
+    __shared__ double2 ltab[128];                    // smx_log's table: m exact logarithms per contender at ~15 instructions each
     const int m = P.m;
     unsigned n = *surv_count;
     if (n > surv_cap) n = surv_cap;
@@ -998,24 +1001,45 @@ __global__ __launch_bounds__(256) void n3_finish_kernel(N3Dev P, SearchArgs A, c
         rr[i] = P.r[i];
         rn[i] = P.rN[i];
     }
+    smx_log_stage(ltab);
+    // The rows of the block's 256 contenders go to LDS once, loaded by consecutive threads from consecutive addresses (a record's
+    // 2 m bytes are contiguous).  Round 2 read them from global memory in every pass over the intervals -- a dozen passes of
+    // byte loads 272 bytes apart between lanes: with millions of contenders (a step that runs into a region better than the
+    // minimum it was given) the kernel took 4 ns per contender, ten times what its arithmetic needs.
+    const int stride = m | 1;                        // (odd: the lanes' rows start on different banks)
+    {
+        const unsigned first = blockIdx.x * blockDim.x;
+        const unsigned nrec = n - first < 256u ? n - first : 256u;
+        const unsigned total = nrec * (unsigned)m;
+        const unsigned magic = (unsigned)((0x100000000ull + (unsigned)m - 1) / (unsigned)m);
+        for (unsigned d = threadIdx.x; d < total; d += 256u) {
+            const unsigned rec = __umulhi(d, magic), i = d - rec * (unsigned)m;          // d / m (exact: d (m - 1) < 2^32)
+            fin_rows[rec * (unsigned)stride + i] = ((const unsigned short *)surv[first + rec].rows)[i];
+        }
+    }
     __syncthreads();
     const unsigned idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n) return;
     const SvSurvivor *sv = surv + idx;
-    const unsigned char *rows = sv->rows;            // [m][2] bytes {a, b}
+    const unsigned char *rows = sv->rows;            // [m][2] bytes {a, b} (global: for the reference's procedure below)
+    const unsigned short *myrows = fin_rows + threadIdx.x * stride;
     const u128 rank = ((u128)sv->rank_hi << 64) | sv->rank_lo;
     const double tau = (double)P.tau, inv_Rtot = 1.0 / P.Rtot;
     double S1 = 0.0, S2 = 0.0, Rmin = __builtin_inf();
     for (int i = 0; i < m; i++) {
-        S1 = __builtin_fma((double)rows[2 * i], rn[i], S1);
-        S2 = __builtin_fma((double)rows[2 * i + 1], rn[i], S2);
+        const unsigned rw = myrows[i];
+        S1 = __builtin_fma((double)(rw & 0xffu), rn[i], S1);
+        S2 = __builtin_fma((double)(rw >> 8), rn[i], S2);
         if (rr[i] > 0.0) Rmin = fmin(Rmin, rr[i]);
     }
     if (!(Rmin < __builtin_inf())) Rmin = 1.0;
     if (S1 == 0.0 || S2 == 0.0) return;              // (the sieve lists degenerate candidates elsewhere)
     const double s1 = S1 / P.N, s2 = S2 / P.N;
     auto terms = [&](auto &&body) {
-        for (int i = 0; i < m; i++) body((double)rows[2 * i], (double)rows[2 * i + 1], rr[i]);
+        for (int i = 0; i < m; i++) {
+            const unsigned rw = myrows[i];
+            body((double)(rw & 0xffu), (double)(rw >> 8), rr[i]);
+        }
     };
     // Newton from the simplex centre (interior for every candidate), to lambda^2 / Rtot < 1e-12
     N3Newton T;
@@ -1055,7 +1079,7 @@ __global__ __launch_bounds__(256) void n3_finish_kernel(N3Dev P, SearchArgs A, c
     }
     terms([&](double x, double y, double R) {
         const double q = __builtin_fma(x - s1, u1, __builtin_fma(y - s2, u2, 1.0));
-        acc = __builtin_fma(R, log(q), acc);
+        acc = __builtin_fma(R, smx_log(q, ltab), acc);
     });
     double nll = P.K0 - acc;
     if (accept) {
@@ -1071,7 +1095,7 @@ __global__ __launch_bounds__(256) void n3_finish_kernel(N3Dev P, SearchArgs A, c
         acc = 0.0;
         terms([&](double x, double y, double R) {
             const double q = __builtin_fma(x - s1, u1, __builtin_fma(y - s2, u2, 1.0));
-            acc = __builtin_fma(R, log(q), acc);
+            acc = __builtin_fma(R, smx_log(q, ltab), acc);
         });
         nll = P.K0 - acc;
         best = fmin(best, order_unbits(load_agent_u64(&A.ctr->best_bits)));
@@ -1151,5 +1175,7 @@ void n3_launch_sieve(const N3Dev &P, const SearchArgs &A, const N3Task *tasks, c
 void n3_launch_finish(const N3Dev &P, const SearchArgs &A, const SvSurvivor *surv, unsigned surv_cap, const unsigned *surv_count,
                       unsigned *accepted_count, hipStream_t st) {
     // (a grid for a full list: blocks beyond the count leave at once)
-    hipLaunchKernelGGL(n3_finish_kernel, dim3((surv_cap + 255) / 256), dim3(256), 0, st, P, A, surv, surv_cap, surv_count, accepted_count);
+    const size_t lds = (size_t)256 * (size_t)(P.m | 1) * sizeof(unsigned short);
+    (void)hipFuncSetAttribute((const void *)n3_finish_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(n3_finish_kernel, dim3((surv_cap + 255) / 256), dim3(256), lds, st, P, A, surv, surv_cap, surv_count, accepted_count);
 }
