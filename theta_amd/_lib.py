@@ -685,7 +685,7 @@ class Comm:
         # uneven shards (all-zero-column records cluster at low ranks) the per-rank guess of round 2 left ranks in different
         # collectives (round-2 advice).  The retry below is collective too: ERR_CAPACITY is returned on every rank.
         cap = max(64, int(self.allreduce_sum(float(k))[0]))
-        while True:
+        for attempt in range(8):
             o_nll, o_mu, o_vals = np.zeros(cap), np.zeros((cap, n)), np.zeros((cap, m))
             o_rk, o_C = np.zeros((cap, 2), np.uint64), np.zeros((cap, m * nc), np.uint8)
             n_out, gmin = C.c_int(), C.c_double()
@@ -693,7 +693,7 @@ class Comm:
                                                  _p(Cb, C.c_uint8), _p(vals, C.c_double), float(window), cap,
                                                  _p(o_nll, C.c_double), _p(o_mu, C.c_double), _p(o_rk, C.c_uint64),
                                                  _p(o_C, C.c_uint8), _p(o_vals, C.c_double), C.byref(n_out), C.byref(gmin))
-            if rc == ERR_CAPACITY:
+            if rc == ERR_CAPACITY and attempt < 7:
                 # (collective: every rank sees the same total, gets the same status and comes back with the same capacity)
                 cap = max(2 * cap, n_out.value)
                 continue
