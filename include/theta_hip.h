@@ -152,11 +152,14 @@ int theta_search_degenerate(theta_problem *p, int cap, uint64_t *rank, uint8_t *
  * Run-time switches of a search instance (no reference counterpart).  name / value:
  *   "n3_no_dismiss"  1: no candidate is finished by the lower bound of its optimum after one evaluation -- every one is
  *                    iterated to the coarse tolerance and valued ("passed through the full solve")
- *   "n3_force_f64"   1: every Newton iteration in FP64 (default: packed FP32 coarse pass, FP64 for contenders)
+ *   "n3_force_f64"   1: every evaluation in FP64 -- the sieve kernel's double instantiation (default: packed FP32 evaluations,
+ *                    FP64 for contenders); with "n3_no_dismiss" the full solve at the reference's precision
  *   "n3_conv_l2"     coarse-pass threshold on the squared Newton decrement (default 1e-4)
  *   "n3_warm_blend"  weight of the previous optimum in a chunk's first warm start
- *   "n3_sieve"       1 (default): the two-kernel fast path (sieve + finish, n3_sieve.hip) where it applies; 0: the fused
- *                    kernel of n3.hip throughout (also used for the dump, the FP64 mode and m < 8)
+ *   "n3_sieve"       1 (default): the two-kernel path (sieve + finish, n3_sieve.hip) where it applies; 0: the fused
+ *                    kernel of n3.hip throughout (also used for theta_search_values and m < 8; m <= 64)
+ *   "n3_contender_cap"  contenders a slice of the sieve may list before it counts as overflowed and is redone (0 = the
+ *                    list's real capacity, 2^24); small values let tests walk the redo ladder
  *   "n3_per_task"    candidates per wave task (0 = automatic), "n2_per_thread" candidates per thread (0 = automatic)
  * The THETA_N3_* environment variables of the same names only set the defaults at theta_problem_create.
  */

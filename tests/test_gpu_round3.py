@@ -232,3 +232,36 @@ def test_plain_scorer_pipeline_over_tile_shapes(ctx):
         sub = np.sort(rng.choice(B, min(B, 300), replace=False))
         ref, _ = ctx.score_masked(n, tau, np.ascontiguousarray(C[sub]), w, r, np.ascontiguousarray(mu[sub]), ones)
         assert np.allclose(ref[:, 0], got[sub, 0], rtol=1e-13, atol=0)
+
+
+def test_overflowed_contender_lists_walk_the_redo_ladder_without_changing_a_result(ctx):
+    """A slice of the sieve that lists more contenders than its list holds is sieved again (the finish kernel has lowered the
+    minimum meanwhile), then cut in 8 parts, and only a part that still overflows goes to the fused kernel (api.hip:
+    run_search).  With the real capacity (2^24) that takes 10^8 near-contenders -- the bench meets them, the tests cannot -- so
+    the capacity is an option here: 2000, 50 and 1 contenders per slice walk every rung of the ladder on ranges full of near-ties,
+    in the search and in both full-solve modes, and finalists, fallback-relevant suspects, all-zero-column lists and the
+    once-per-candidate counters stay what they are with the real capacity."""
+    import bench
+    import theta_amd
+    r, rN, order = bench.synth()
+    p = theta_amd.Problem(ctx, 3, 50, 2, r, rN, [0] * 50, [6] * 50, 1.0)
+    r14, rN14, _ = bench.synth(seed=9, m=14, n=3, k=3)
+    p14 = theta_amd.Problem(ctx, 3, 14, 2, r14, rN14, [0] * 14, [3] * 14, 1.0)
+    walked = 0
+    for prob, rr, rn, b, e in ((p, r, rN, 0, 1 << 21), (p, r, rN, p.count // 3, p.count // 3 + (1 << 22)), (p14, r14, rN14, 0, p14.count)):
+        base, fb0, deg0 = _search_mode(ctx, prob, b, e, rr, rn, {})
+        for mode in ({}, {"n3_no_dismiss": 1}, {"n3_no_dismiss": 1, "n3_force_f64": 1}):
+            for cap in (2000, 50, 1):
+                opts = dict(mode, n3_contender_cap=cap)
+                got, fb, deg = _search_mode(ctx, prob, b, e, rr, rn, opts)
+                st = got["stats"]
+                assert st["evaluated"] == e - b and st["dismissed"] <= st["evaluated"], (cap, mode, st["evaluated"], st["dismissed"])
+                assert got["rank"] == base["rank"], (cap, mode, len(got["rank"]), len(base["rank"]))
+                assert np.array_equal(got["C"], base["C"]) and np.allclose(got["nll"], base["nll"], rtol=1e-11, atol=0)
+                assert fb == fb0 and deg == deg0, (cap, mode)
+                if st["fallback_candidates"]:
+                    walked += 1
+                    assert st["redo_kernel_ms"] > 0.0
+    assert walked >= 12                                          # (the small capacities really overflowed)
+    p.close()
+    p14.close()

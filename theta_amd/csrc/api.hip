@@ -145,6 +145,8 @@ struct theta_problem {
     uint64_t opt_per_task = 0;         // n=3 candidates per wave task (0: automatic), theta_problem_set_option
     int opt_per_thread = 0;            // n=2 candidates per thread (0: automatic)
     int opt_sieve = 1;                 // n=3: sieve + finish kernels (n3_sieve.hip); 0 = the fused kernel of n3.hip only
+    unsigned opt_surv_cap = 0;         // n=3: contenders a slice may list before it counts as overflowed (0: SURV_CAP; smaller
+                                       // values make the tests walk the redo ladder: sieve again -> 8 parts -> fused kernel)
     int device = 0;                                     // (= ctx->device: the destructor must not need the context)
     uint64_t last_survivors = 0, last_fallback = 0;   // of the last search: contenders listed by the sieve / candidates redone fused
     SearchCounters last_redo{};                        // ... what the fused kernel did on the redone slices (kept apart from the main counters)
@@ -393,6 +395,7 @@ extern "C" int theta_problem_set_option(theta_problem *p, const char *name, doub
     else if (k == "n3_conv_l2" && value > 0.0) p->n3.conv_l2 = value;
     else if (k == "n3_warm_blend" && value >= 0.0 && value <= 1.0) p->n3.warm_blend = value;
     else if (k == "n3_sieve") p->opt_sieve = value != 0.0;
+    else if (k == "n3_contender_cap" && value >= 0.0 && value <= (double)SURV_CAP) p->opt_surv_cap = (unsigned)value;
     else if (k == "n3_per_task" && (value == 0.0 || (value >= 64 && value <= 65535))) p->opt_per_task = (uint64_t)value;
     else if (k == "n2_per_thread" && (value == 0.0 || (value >= 1 && value <= 512))) p->opt_per_thread = (int)value;
     else {
@@ -461,6 +464,7 @@ static int run_search(theta_problem *p, u128 b, u128 e, double window, double *d
     p->last_sieve64 = false;
     p->last_fallback = 0;
     p->last_launches = 0;
+    const unsigned surv_cap = p->opt_surv_cap ? p->opt_surv_cap : SURV_CAP;      // (the list is allocated for SURV_CAP)
     for (int pass = 0; pass < 3; pass++) {
         std::vector<std::pair<int, int>> slices;     // n=3 fast path: (first task, tasks) of every sieve launch of this pass
         uint64_t sieve_per_task = 0;
@@ -550,8 +554,8 @@ static int run_search(theta_problem *p, u128 b, u128 e, double window, double *d
                 for (size_t sl = 0; sl < slices.size(); sl++) {
                     const int t0 = slices[sl].first, nts = slices[sl].second;
                     n3_launch_sieve(PS, A, (const N3Task *)p->d_tasks.p + t0, (const unsigned *)p->d_stbuf.p + (size_t)t0 * N3_STB, nts,
-                                    (SvSurvivor *)p->d_surv.p, SURV_CAP, cnts + sl, st);
-                    n3_launch_finish(PS, A, (const SvSurvivor *)p->d_surv.p, SURV_CAP, cnts + sl, (unsigned *)p->d_survacc.p + sl, st);
+                                    (SvSurvivor *)p->d_surv.p, surv_cap, cnts + sl, st);
+                    n3_launch_finish(PS, A, (const SvSurvivor *)p->d_surv.p, surv_cap, cnts + sl, (unsigned *)p->d_survacc.p + sl, st);
                 }
                 sieve_per_task = per_task;
                 p->last_sieve64 = p->n3.force64 != 0;
@@ -594,7 +598,7 @@ static int run_search(theta_problem *p, u128 b, u128 e, double window, double *d
         uint64_t redone = 0, redone_accepted_by_finish = 0;
         double redo_ms = 0.0;
         for (size_t sl = 0; sl < slices.size(); sl++) {
-            if (hcnt[sl] <= SURV_CAP) continue;
+            if (hcnt[sl] <= surv_cap) continue;
             redone_accepted_by_finish += hacc[sl];
             const int t0 = slices[sl].first, nts = slices[sl].second;
             const u128 sb = b + (u128)t0 * sieve_per_task;
@@ -609,8 +613,8 @@ static int run_search(theta_problem *p, u128 b, u128 e, double window, double *d
                 HIP_TRY(hipMemsetAsync(cnt2, 0, sizeof(unsigned), st));
                 HIP_TRY(hipEventRecord(ctx->ev1, st));
                 n3_launch_sieve(PS, A, (const N3Task *)p->d_tasks.p + ta, (const unsigned *)p->d_stbuf.p + (size_t)ta * N3_STB, na,
-                                (SvSurvivor *)p->d_surv.p, SURV_CAP, cnt2, st);
-                n3_launch_finish(PS, A, (const SvSurvivor *)p->d_surv.p, SURV_CAP, cnt2, acc2, st);
+                                (SvSurvivor *)p->d_surv.p, surv_cap, cnt2, st);
+                n3_launch_finish(PS, A, (const SvSurvivor *)p->d_surv.p, surv_cap, cnt2, acc2, st);
                 HIP_TRY(hipEventRecord(ctx->ev2, st));
                 HIP_TRY(hipMemcpyAsync(&count, cnt2, sizeof(unsigned), hipMemcpyDeviceToHost, st));
                 HIP_TRY(hipStreamSynchronize(st));
@@ -623,15 +627,15 @@ static int run_search(theta_problem *p, u128 b, u128 e, double window, double *d
             unsigned count = 0;
             int rc2 = again(0, nts, count);
             if (rc2) return rc2;
-            if (count <= SURV_CAP) continue;
+            if (count <= surv_cap) continue;
             const int part = (nts + 7) / 8;
             for (int ta = 0; ta < nts; ta += part) {
                 const int na = std::min(part, nts - ta);
                 if ((rc2 = again(ta, na, count))) return rc2;
-                if (count <= SURV_CAP) continue;
+                if (count <= surv_cap) continue;
                 if (p->m > N3_MAX_M) {      // (the fused kernel holds one interval per lane)
                     theta_set_error("n=3, m = %d: %u contenders in one slice exceed the list (%u): pass a hint (theta_problem_hint) or "
-                                    "search a shorter range", p->m, count, SURV_CAP);
+                                    "search a shorter range", p->m, count, surv_cap);
                     return THETA_ERR_CAPACITY;
                 }
                 const u128 fb = sb + (u128)ta * sieve_per_task;
