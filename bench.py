@@ -25,7 +25,7 @@ Prints ONE JSON line (rank 0).
              of the sieve + finish kernels; `peak` = the FP64 vector peak (78.6 TFLOP/s; the v_log_f32 of the screened value is
              weighted with the FP32 peak).  Executed FLOP FALL when the algorithm improves (sharing an evaluation between
              siblings removed half of them), so `frac` is a statement about the kernel, not about progress.
-             legs (N = 1, after the timed region, on the same rank ranges; each with its own kernel time, FLOP and frac):
+             legs (N = 1, after the timed region, on ALL of its rank ranges; each with its own kernel time, FLOP and frac):
                full_solve_f64   the headline, again as a leg record (per-step kernel ms min / median / max, counters)
                full_solve_f32   the same in packed single precision (n3_no_dismiss)
                search           the shipped branch-and-bound: a candidate whose rigorous lower bound lies beyond the window of
@@ -458,7 +458,7 @@ def main():
                 lg.step(0, count=False)
                 ctx.synchronize()
                 t1 = time.time()
-                for i in range(min(4, len(lg.begins))):
+                for i in range(len(lg.begins)):                # (every stretch of the timed region: the legs are comparable with the headline and with each other)
                     lg.step(i)
                 ctx.synchronize()
                 legs[name] = lg.summary(time.time() - t1, name, dtype, kern)

@@ -42,9 +42,9 @@ txt.append("| leg | what runs | candidates/s | kernel ms per step (min / median 
 txt.append("|---|---|---|---|---|---|---|---|")
 txt += rows
 txt.append("")
-txt.append("(The legs other than the headline run after the timed region on the first four of the same stretches.  `survivors` %d, "
+txt.append("(The legs other than the headline run after the timed region, on the same %d stretches.  `survivors` %d, "
            "`fallback_candidates` %d, `redo_kernel_ms` %.1f over the headline's %d steps: no timed step fell back.)\n" % (
-               h["survivors"], h["fallback_candidates"], h["redo_kernel_ms"], h["launches"]))
+               b["steps"], h["survivors"], h["fallback_candidates"], h["redo_kernel_ms"], h["launches"]))
 txt.append("HBM traffic (`roofline.traffic`, two `rocprofv3 --pmc` passes of the same command): %.2f GB per launch against 0 algorithmic "
            "bytes — %.1f B per candidate: the counting table at task starts, contender records, counters.\n" % (
                (rf["traffic"] or 0) / 1e9, (rf["traffic"] or 0) / 2 ** 31))
