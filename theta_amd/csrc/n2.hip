@@ -482,7 +482,7 @@ __global__ __launch_bounds__(256) void n2_enumerate_lines_kernel(N2Dev P, unsign
 // ------------------------------------------------------------------------------------------------
 // The whole-line generator with the records RENDERED by scatter + prefix sum (n2_render.hpp) instead of summed break-point by
 // break-point into every word.  Same run / tile / store scheme as n2_enumerate_lines_kernel.  The default since round 3
-// (THETA_N2_ENUM_RENDER=0 selects the summing writer): 2.6 / 3.6 TB/s at m = 50 / 100 against 1.5 / 2.1.  Its per-lane logic is
+// (THETA_N2_ENUM_RENDER=0 selects the summing writer): 4.2 / 4.7 TB/s at m = 50 / 100 against 1.5 / 2.1 (word-major LDS tile, n2_render.hpp).  Its per-lane logic is
 // also verified on the CPU -- tools/n2_render_emul.hip runs this very code lane by lane against the oracle's enumeration
 // (tests/test_n2_render_cpu.py) -- and on the device against the other two generators (tests/test_gpu_zzz_render.py).
 // ------------------------------------------------------------------------------------------------
@@ -495,12 +495,12 @@ __global__ __launch_bounds__(256) void n2_enumerate_render_kernel(N2Dev P, unsig
     short *lbposl = (short *)(Pl + (size_t)P.m * N2_KVS);
     unsigned char *ubl = (unsigned char *)(lbposl + (N2_KVS + 1) + 3);
     unsigned *tile = (unsigned *)(smem + (((size_t)P.m * N2_KVS * 8 + (N2_KVS + 1 + 3) * 2 + P.m + 15) & ~(size_t)15)) +
-                     (threadIdx.x >> 6) * (WAVE * N2L_STRIDE);
+                     (threadIdx.x >> 6) * N2R_TILE_DWORDS;
     for (int i = threadIdx.x; i < P.m * N2_KVS; i += blockDim.x) Pl[i] = P.P[i];
     for (int i = threadIdx.x; i <= N2_KVS; i += blockDim.x) lbposl[i] = P.lbpos[i];
     for (int i = threadIdx.x; i < P.m; i += blockDim.x) ubl[i] = P.ub[i];
     __syncthreads();
-    short *ubposl = (short *)(tile - (threadIdx.x >> 6) * (WAVE * N2L_STRIDE) + 4 * WAVE * N2L_STRIDE);   // behind the four tiles
+    short *ubposl = (short *)(tile - (threadIdx.x >> 6) * N2R_TILE_DWORDS + 4 * N2R_TILE_DWORDS);   // behind the four tiles
     if (threadIdx.x <= KV) ubposl[threadIdx.x] = n2r_ubpos(ubl, P.m, (int)threadIdx.x);
     __syncthreads();
     const int lane = threadIdx.x & 63, m = P.m;
@@ -516,12 +516,11 @@ __global__ __launch_bounds__(256) void n2_enumerate_render_kernel(N2Dev P, unsig
 #pragma unroll
         for (int v = 0; v <= KV; v++) R.c.s[v] = m;
     }
-    unsigned *row = tile + lane * N2L_STRIDE;
     N2RStore S;
     n2r_store_prepare(lane, wave_first, T, m, count, out, S);
     for (int line = 0; line < lines; line++) {
-        n2r_scatter_line<KV>(m, lbposl, ubposl, R, row);
-        n2r_prefix_line(row);
+        n2r_scatter_line<KV>(m, lbposl, ubposl, R, tile, lane);
+        n2r_prefix_line(tile, lane);
         wave_lds_sync();
         n2r_store_line(lane, line, S, tile);
         wave_lds_sync();
@@ -581,13 +580,14 @@ void n2_launch_enumerate(const N2Dev &P, unsigned long long begin, unsigned long
             const unsigned blocks = (unsigned)((threads + 255) / 256);
             const size_t base = (((size_t)P.m * N2_KVS * 8 + (N2_KVS + 1 + 3) * 2 + P.m + 15) & ~(size_t)15);
             const size_t sm2 = base + (size_t)4 * WAVE * N2L_STRIDE * 4;
+            const size_t smr = base + (size_t)4 * N2R_TILE_DWORDS * 4 + 64;            // render kernel: word-major tiles + ubpos
             if (const char *e = getenv("THETA_N2_ENUM_RENDER"); !e || atoi(e) > 0) {      // the default since round 3 (0: the summing whole-line writer)
                 if (P.kv <= 8) {
-                    (void)hipFuncSetAttribute((const void *)n2_enumerate_render_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sm2 + 64));
-                    hipLaunchKernelGGL(n2_enumerate_render_kernel<8>, dim3(blocks), dim3(256), sm2 + 64, st, P, begin, count, T, out);
+                    (void)hipFuncSetAttribute((const void *)n2_enumerate_render_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smr);
+                    hipLaunchKernelGGL(n2_enumerate_render_kernel<8>, dim3(blocks), dim3(256), smr, st, P, begin, count, T, out);
                 } else {
-                    (void)hipFuncSetAttribute((const void *)n2_enumerate_render_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sm2 + 64));
-                    hipLaunchKernelGGL(n2_enumerate_render_kernel<16>, dim3(blocks), dim3(256), sm2 + 64, st, P, begin, count, T, out);
+                    (void)hipFuncSetAttribute((const void *)n2_enumerate_render_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smr);
+                    hipLaunchKernelGGL(n2_enumerate_render_kernel<16>, dim3(blocks), dim3(256), smr, st, P, begin, count, T, out);
                 }
                 return;
             }

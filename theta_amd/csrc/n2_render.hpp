@@ -23,6 +23,18 @@
 
 #define N2R_LINE 128       // bytes per output line
 #define N2R_WORDS 32       // dwords of payload per LDS row
+// The per-wave LDS tile is kept WORD-MAJOR: word w of lane l's row lives at dword w * N2R_PITCH + l.  Every access of steps
+// 1-3 is "all lanes, (nearly) the same w": with the rows laid lane-major (stride 36 dwords, round 2) those hit 8 banks 8
+// deep -- PMC: 2.9 bank-conflict cycles per active LDS cycle, the LDS busy for more than half of the kernel -- here they
+// fall on consecutive banks.  The odd pitch makes the store stage's transposed read (lane (r8, ch) reads words 4ch..4ch+3
+// of row r8 + 8 sidx: bank = 4 ch + j + r mod 32) conflict-free per half-wave as well.
+#define N2R_PITCH 65
+#define N2R_TILE_DWORDS (N2R_WORDS * N2R_PITCH)
+N2_HD inline unsigned &n2r_word(unsigned *tile, int lane, int w) { return tile[w * N2R_PITCH + lane]; }
+N2_HD inline const unsigned &n2r_word(const unsigned *tile, int lane, int w) { return tile[w * N2R_PITCH + lane]; }
+N2_HD inline unsigned char &n2r_byte(unsigned *tile, int lane, int pos) {
+    return ((unsigned char *)(tile + (pos >> 2) * N2R_PITCH + lane))[pos & 3];
+}
 
 template <int KV>
 struct N2Run {
@@ -88,12 +100,11 @@ N2_HD inline void n2r_advance(const short *lbp, const short *ubp, N2Run<KV> &R) 
     }
 }
 
-// Steps 1 and 2 for one line.  `row` is the lane's row of the tile (N2R_WORDS dwords, 16-byte aligned).
+// Steps 1 and 2 for one line.  `tile` is the wave's tile, `lane` selects the row.
 template <int KV>
-N2_HD inline void n2r_scatter_line(int m, const short *lbp, const short *ubp, N2Run<KV> &R, unsigned *row) {
+N2_HD inline void n2r_scatter_line(int m, const short *lbp, const short *ubp, N2Run<KV> &R, unsigned *tile, int lane) {
 #pragma unroll
-    for (int w = 0; w < N2R_WORDS; w++) row[w] = 0u;
-    unsigned char *bytes = (unsigned char *)row;
+    for (int w = 0; w < N2R_WORDS; w++) n2r_word(tile, lane, w) = 0u;
     while (R.recstart < N2R_LINE) {                              // (uniform: recstart and m are the same in every lane)
         const bool live = R.left > 0;
         int curpos = R.recstart > 0 ? R.recstart : 0;
@@ -108,11 +119,11 @@ N2_HD inline void n2r_scatter_line(int m, const short *lbp, const short *ubp, N2
             p = p < 0 ? 0 : p;
             const bool act = inrec && p < N2R_LINE;
             const bool same = !act || p == curpos;
-            if (!same) bytes[curpos] = (unsigned char)(cnt & 15); // (predicated byte store: positions are visited in order)
+            if (!same) n2r_byte(tile, lane, curpos) = (unsigned char)(cnt & 15); // (predicated byte store: positions are visited in order)
             cnt = same ? cnt + (act ? 1 : 0) : 1;
             curpos = same ? curpos : p;
         }
-        bytes[curpos] = (unsigned char)(cnt & 15);
+        n2r_byte(tile, lane, curpos) = (unsigned char)(cnt & 15);
         const int e = R.recstart + m;
         if (e > N2R_LINE) break;                                  // the record continues in the next line
         n2r_advance<KV>(lbp, ubp, R);
@@ -125,25 +136,22 @@ N2_HD inline void n2r_scatter_line(int m, const short *lbp, const short *ubp, N2
 }
 
 // Step 3: running sums (mod 16 per byte) over the row.
-N2_HD inline void n2r_prefix_line(unsigned *row) {
+N2_HD inline void n2r_prefix_line(unsigned *tile, int lane) {
     unsigned carry = 0u;
 #pragma unroll
     for (int w = 0; w < N2R_WORDS; w++) {
-        unsigned x = row[w];                                      // every byte <= 15
+        unsigned x = n2r_word(tile, lane, w);                                      // every byte <= 15
         x = (x + (x << 8)) & 0x0f0f0f0fu;
         x = (x + (x << 16)) & 0x0f0f0f0fu;
         x = (x + carry * 0x01010101u) & 0x0f0f0f0fu;
-        row[w] = x;
+        n2r_word(tile, lane, w) = x;
         carry = x >> 24;
     }
 }
 
 // Store stage of one line (after every lane of the wave has finished steps 1-3 and the tile is visible): lane (r8, ch) of
 // pass `sidx` moves the 16-byte chunk `ch` of row r = r8 + 8 sidx -- one store instruction of the wave = 8 complete 128-byte
-// lines.  `tile` is the wave's tile (64 rows of N2L_STRIDE dwords), wave_first the global index of the wave's first thread.
-#ifndef N2L_STRIDE
-#define N2L_STRIDE 36      // dwords per LDS row (128 bytes of payload + 16 of padding: spreads the rows over the banks)
-#endif
+// lines.  `tile` is the wave's tile (word-major, see N2R_PITCH), wave_first the global index of the wave's first thread.
 struct n2r_u4 {
     unsigned x, y, z, w;
 };
@@ -171,12 +179,18 @@ N2_HD inline void n2r_store_line(int lane, int line, const N2RStore &S, const un
     for (int sidx = 0; sidx < 8; sidx++) {
         const unsigned nv = S.nv[sidx];
         if (off < nv) {
-            const unsigned *src = tile + ((lane >> 3) + 8 * sidx) * N2L_STRIDE + 4 * (lane & 7);
+            const int r = (lane >> 3) + 8 * sidx, w0 = 4 * (lane & 7);
+            n2r_u4 v;
+            v.x = n2r_word(tile, r, w0);
+            v.y = n2r_word(tile, r, w0 + 1);
+            v.z = n2r_word(tile, r, w0 + 2);
+            v.w = n2r_word(tile, r, w0 + 3);
             unsigned char *dst = S.dst[sidx] + ((size_t)line << 7);
             if (off + 16 <= nv) {
-                *(n2r_u4 *)dst = *(const n2r_u4 *)src;
+                *(n2r_u4 *)dst = v;
             } else {                                             // the tail of the very last record
-                for (int bidx = 0; bidx < (int)(nv - off); bidx++) dst[bidx] = (unsigned char)(src[bidx >> 2] >> (8 * (bidx & 3)));
+                const unsigned w4[4] = {v.x, v.y, v.z, v.w};
+                for (int bidx = 0; bidx < (int)(nv - off); bidx++) dst[bidx] = (unsigned char)(w4[bidx >> 2] >> (8 * (bidx & 3)));
             }
         }
     }

@@ -14,7 +14,7 @@ static void emulate(const N2Dev &P, unsigned long long begin, unsigned long long
     const unsigned long long threads = (count + T - 1) / T;
     const unsigned long long waves = (threads + 63) / 64;
     const int lines = (int)(((unsigned long long)T * m) >> 7);
-    std::vector<unsigned> tile((size_t)64 * N2L_STRIDE);
+    std::vector<unsigned> tile((size_t)N2R_TILE_DWORDS);
     std::vector<N2Run<KV>> R(64);
     std::vector<N2RStore> S(64);
     short ubp[KV + 1];
@@ -32,9 +32,8 @@ static void emulate(const N2Dev &P, unsigned long long begin, unsigned long long
         }
         for (int line = 0; line < lines; line++) {
             for (int lane = 0; lane < 64; lane++) {
-                unsigned *row = tile.data() + (size_t)lane * N2L_STRIDE;
-                n2r_scatter_line<KV>(m, P.lbpos, ubp, R[lane], row);
-                n2r_prefix_line(row);
+                n2r_scatter_line<KV>(m, P.lbpos, ubp, R[lane], tile.data(), lane);
+                n2r_prefix_line(tile.data(), lane);
             }
             for (int lane = 0; lane < 64; lane++) n2r_store_line(lane, line, S[lane], tile.data());
         }
