@@ -232,6 +232,34 @@ def test_plain_scorer_pipeline_over_tile_shapes(ctx):
         sub = np.sort(rng.choice(B, min(B, 300), replace=False))
         ref, _ = ctx.score_masked(n, tau, np.ascontiguousarray(C[sub]), w, r, np.ascontiguousarray(mu[sub]), ones)
         assert np.allclose(ref[:, 0], got[sub, 0], rtol=1e-13, atol=0)
+    # row terms that are not positive normal numbers (w_i = 0: ln 0, times r_i = 0 or not): the branch-free walk redoes such a
+    # candidate with the guarded logarithm -- the same inf / NaN as the masked kernel and the oracle's numpy arithmetic
+    for n, m, B in ((3, 50, 700), (2, 100, 300)):
+        C = rng.randint(0, 8, (B, m, n - 1)).astype(np.uint8)
+        if n == 2:
+            C = C[:, :, 0]
+        C[::3, 7] = 0                                                   # (w_7 > 0 but C = 0 in every tumour column: a plain finite row)
+        w = rng.randint(1000, 90000, m).astype(float)
+        r = rng.randint(1000, 90000, m).astype(float)
+        w[5] = 0.0
+        w[9] = 0.0
+        r[9] = 0.0
+        mu = rng.dirichlet(np.ones(n) * 3, B)
+        got, _ = ctx.score_masked(n, 2, C, w, r, mu, None)
+        words = (m + 63) // 64
+        ones = np.zeros((16, words), np.uint64)
+        for i in range(m):
+            ones[:, i // 64] |= np.uint64(1) << np.uint64(i % 64)
+        ref, _ = ctx.score_masked(n, 2, C, w, r, mu, ones)
+        assert np.array_equal(np.isnan(got[:, 0]), np.isnan(ref[:, 0])) and np.array_equal(np.isinf(got[:, 0]), np.isinf(ref[:, 0]))
+        assert not np.isfinite(got).any()                                # (ln 0 with r_5 > 0 in every candidate)
+        with np.errstate(all="ignore"):
+            for b in (0, 1, B - 1):
+                Cw = np.zeros((m, n))
+                Cw[:, 0] = 2 * w
+                Cw[:, 1:] = C[b].reshape(m, n - 1) * w[:, None]
+                want = orc.calc_L3(mu[b], Cw, m, r, n)[0] if n == 3 else orc.calc_L2(mu[b, 0], Cw, m, r)[0]
+                assert (np.isnan(want) and np.isnan(got[b, 0])) or want == got[b, 0], (n, b, want, got[b, 0])
 
 
 def test_overflowed_contender_lists_walk_the_redo_ladder_without_changing_a_result(ctx):

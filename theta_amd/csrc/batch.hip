@@ -564,6 +564,28 @@ __device__ __forceinline__ void spc_stage(const unsigned char *src_bytes, int nb
     const int nq = total >> 2;                                  // whole 16-byte chunks (a tile starts 16-byte aligned)
     const uint4 *src4 = (const uint4 *)src_bytes;
     const unsigned magic = (unsigned)((0x100000000ull + (unsigned)cw - 1) / (unsigned)cw);
+    if (pw == cw) {                                             // odd record length: the LDS image IS the global one -- a straight copy
+        uint4 *const dst4 = (uint4 *)spc_lds;
+        for (int base = 0; base < nq; base += 256 * 8) {
+            uint4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int q = base + u * 256 + (int)threadIdx.x;
+                v[u] = src4[q < nq ? q : nq - 1];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++)                         // (all eight loads in flight before the first store: the optimizer would sink each load to its store)
+                asm volatile("" : "+v"(v[u].x), "+v"(v[u].y), "+v"(v[u].z), "+v"(v[u].w));
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int q = base + u * 256 + (int)threadIdx.x;
+                if (q < nq) dst4[q] = v[u];
+            }
+        }
+        const unsigned int *src = (const unsigned int *)src_bytes;
+        for (int idx = (nq << 2) + (int)threadIdx.x; idx < total; idx += 256) spc_lds[idx] = src[idx];
+        return;
+    }
     for (int base = 0; base < nq; base += 256 * 8) {
         uint4 v[8];
 #pragma unroll
@@ -625,28 +647,65 @@ __global__ __launch_bounds__(256) void score_plain_kernel(int m, int tau, int B,
 #pragma unroll
         for (int v = 0; v < SPT_VALUES; v++) mine[v * 256] = smx_log(__builtin_fma((double)v, m1, m0), tab);
         const unsigned int *row = spc_lds + threadIdx.x * pw;
+        // Branch-free walk: the table index is the value's low three bits, and values beyond the table are noticed word by
+        // word (one and + compare per four rows); a candidate that has one -- copy numbers 8..15, rare -- is redone below
+        // with the direct logarithm.  (A test and branch per row cost more than the row's arithmetic.)
+        bool big = false;
         for (int q = 0; q < cw; q++) {
             const unsigned int word = row[q];
+            big |= (word & ~(0x01010101u * (SPT_VALUES - 1))) != 0u;
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 const double2 wi = wr[4 * q + k];
                 const unsigned x = (word >> (8 * k)) & 0xffu;
                 const double inner = __builtin_fma((double)x, m1, m0);
                 den = __builtin_fma(wi.x, inner, den);
-                const double lg = x < SPT_VALUES ? mine[x * 256] : smx_log(inner, tab);
-                tot = __builtin_fma(wi.y, lg, tot);
+                tot = __builtin_fma(wi.y, mine[((word >> (8 * k)) & (SPT_VALUES - 1)) * 256], tot);
+            }
+        }
+        if (big) {
+            tot = 0.0;
+            for (int q = 0; q < cw; q++) {
+                const unsigned int word = row[q];
+                for (int k = 0; k < 4; k++) {
+                    const unsigned x = (word >> (8 * k)) & 0xffu;
+                    const double lg = x < SPT_VALUES ? mine[x * 256] : smx_log(__builtin_fma((double)x, m1, m0), tab);
+                    tot = __builtin_fma(wr[4 * q + k].y, lg, tot);
+                }
             }
         }
         nll[b] = -((tot + rlogw) - rsum * smx_log(den, tab));
     } else {
         const unsigned char *row = (const unsigned char *)(spc_lds + threadIdx.x * pw);
-#pragma unroll 4
-        for (int i = 0; i < m; i++) {
+        // Branch-free walk with the unguarded logarithm; a row term that is not a positive normal number (w_i = 0, ...) raises
+        // a flag, and such a candidate is redone below with the guarded one -- same operations, same order, so the same bits.
+        bool odd = false;
+        auto term = [&](int i) {
             const double2 wi = wr[i];
             const double x = (double)row[i * NC], y = (NC == 2) ? (double)row[i * NC + 1] : 0.0;
             const double cm = wi.x * __builtin_fma(x, m1, __builtin_fma(y, m2, m0));
             den += cm;
-            tot = __builtin_fma(wi.y, smx_log(cm, tab), tot);
+            odd |= !smx_log_fast_ok(cm);
+            tot = __builtin_fma(wi.y, smx_log_fast(cm, tab), tot);
+        };
+        int i = 0;
+        for (; i + 4 <= m; i += 4) {                             // (unrolled by hand: smx_log's asm statements keep the optimizer from it)
+            term(i);
+            term(i + 1);
+            term(i + 2);
+            term(i + 3);
+        }
+        for (; i < m; i++) term(i);
+        if (odd) {
+            den = 0.0;
+            tot = 0.0;
+            for (i = 0; i < m; i++) {
+                const double2 wi = wr[i];
+                const double x = (double)row[i * NC], y = (NC == 2) ? (double)row[i * NC + 1] : 0.0;
+                const double cm = wi.x * __builtin_fma(x, m1, __builtin_fma(y, m2, m0));
+                den += cm;
+                tot = __builtin_fma(wi.y, smx_log(cm, tab), tot);
+            }
         }
         nll[b] = -(tot - rsum * smx_log(den, tab));
     }
