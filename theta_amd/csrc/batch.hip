@@ -633,14 +633,56 @@ __global__ __launch_bounds__(256) void score_plain_kernel(int m, int tau, int B,
     double *const T = (double *)(wr + ((m + 3) & ~3));                                     // TABLE: [SPT_VALUES][256]
     const long long b0 = (long long)blockIdx.x * TS;
     const int nb = (int)((long long)B - b0 < TS ? (long long)B - b0 : TS);
-    smx_log_stage((double2 *)tab);
-    for (int i = threadIdx.x; i < m; i += 256) wr[i] = double2{w[i], r[i]};
-    spc_stage(C + (size_t)b0 * cb, nb, cw, pw);
-    __syncthreads();
-    if ((int)threadIdx.x >= nb) return;
+    double mu_a, mu_b, mu_c = 0.0;
+    const int nq = (nb * cw) >> 2;                                                         // whole 16-byte chunks of the tile
+    if (pw == cw && nq >= 1 && nq <= 8 * 256 && m <= 512) {
+        // The common shape (odd record length in words, a tile of at most 32 KB): EVERYTHING the block reads from global memory
+        // -- its tile, the logarithm table, {w, r}, this thread's mu -- is requested before the first wait: one exposed round
+        // trip per block instead of four in a row (table, {w, r}, tile, and mu behind the barrier).  A block lives ~15 us.
+        const int tid = threadIdx.x;
+        const uint4 *src4 = (const uint4 *)(C + (size_t)b0 * cb);
+        uint4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int q = u * 256 + tid;
+            v[u] = src4[q < nq ? q : nq - 1];
+        }
+        double2 tv = ((const double2 *)smx_log_table)[tid & 127];
+        const int i0 = tid < m ? tid : m - 1, i1 = tid + 256 < m ? tid + 256 : m - 1;
+        double w0 = w[i0], r0 = r[i0], w1 = w[i1], r1 = r[i1];
+        const double *mv = mu + (size_t)(b0 + (tid < nb ? tid : 0)) * (NC + 1);
+        mu_a = mv[0];
+        mu_b = mv[1];
+        if (NC == 2) mu_c = mv[2];
+#pragma unroll
+        for (int u = 0; u < 8; u++) asm volatile("" : "+v"(v[u].x), "+v"(v[u].y), "+v"(v[u].z), "+v"(v[u].w));
+        asm volatile("" : "+v"(tv.x), "+v"(tv.y), "+v"(w0), "+v"(r0), "+v"(w1), "+v"(r1), "+v"(mu_a), "+v"(mu_b), "+v"(mu_c));
+        if (tid < 128) ((double2 *)tab)[tid] = double2{2.0 * tv.x, tv.y};                  // (smx_log_stage)
+        if (tid < m) wr[tid] = double2{w0, r0};
+        if (tid + 256 < m) wr[tid + 256] = double2{w1, r1};
+        uint4 *const dst4 = (uint4 *)spc_lds;
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int q = u * 256 + tid;
+            if (q < nq) dst4[q] = v[u];
+        }
+        const unsigned int *src = (const unsigned int *)src4;
+        for (int idx = (nq << 2) + tid; idx < nb * cw; idx += 256) spc_lds[idx] = src[idx];
+        __syncthreads();
+        if (tid >= nb) return;
+    } else {
+        smx_log_stage((double2 *)tab);
+        for (int i = threadIdx.x; i < m; i += 256) wr[i] = double2{w[i], r[i]};
+        spc_stage(C + (size_t)b0 * cb, nb, cw, pw);
+        __syncthreads();
+        if ((int)threadIdx.x >= nb) return;
+        const double *mv = mu + (size_t)(b0 + threadIdx.x) * (NC + 1);
+        mu_a = mv[0];
+        mu_b = mv[1];
+        if (NC == 2) mu_c = mv[2];
+    }
     const long long b = b0 + threadIdx.x;
-    const double *mv = mu + (size_t)b * (NC + 1);
-    const double m0 = (double)tau * mv[0], m1 = (NC == 1) ? 1.0 - mv[0] : mv[1], m2 = (NC == 2) ? mv[2] : 0.0;
+    const double m0 = (double)tau * mu_a, m1 = (NC == 1) ? 1.0 - mu_a : mu_b, m2 = mu_c;
     double den = 0.0, tot = 0.0;
     if constexpr (TABLE) {
         double *const mine = T + threadIdx.x;

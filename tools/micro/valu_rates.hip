@@ -34,6 +34,18 @@ __global__ void k(double *out, double seed) {
             if (OP == 9) asm volatile("v_cvt_f32_f64 %0, %1" : "=v"(f[i]) : "v"(d[i]));
             if (OP == 10) asm volatile("v_and_b32 %0, %0, %1" : "+v"(f[i]) : "v"(cf));
             if (OP == 11) asm volatile("v_lshlrev_b64 %0, 1, %0" : "+v"(d[i]));
+            if (OP == 12) asm volatile("v_cvt_f64_u32 %0, %1" : "=v"(d[i]) : "v"(f[i]));
+            if (OP == 13) asm volatile("v_cvt_f64_i32 %0, %1" : "=v"(d[i]) : "v"(f[i]));
+            if (OP == 14) asm volatile("v_frexp_mant_f64 %0, %0" : "+v"(d[i]));
+            if (OP == 15) asm volatile("v_frexp_exp_i32_f64 %0, %1" : "=v"(f[i]) : "v"(d[i]));
+            if (OP == 16) asm volatile("v_cmp_class_f64 vcc, %0, %1" : : "v"(d[i]), "v"(f[i]) : "vcc");
+            if (OP == 17) asm volatile("v_bfe_u32 %0, %0, 13, 7" : "+v"(f[i]));
+            if (OP == 18) asm volatile("v_lshl_add_u32 %0, %0, 4, %1" : "+v"(f[i]) : "v"(cf));
+            if (OP == 19) asm volatile("v_cvt_f32_ubyte1 %0, %0" : "+v"(f[i]));
+            if (OP == 20) asm volatile("v_cvt_f64_f32 %0, %1" : "=v"(d[i]) : "v"(f[i]));
+            if (OP == 21) asm volatile("v_mov_b64 %0, %1" : "=v"(d[i]) : "v"(cd));
+            if (OP == 22) asm volatile("v_add_u32 %0, %0, %1" : "+v"(f[i]) : "v"(cf));
+            if (OP == 23) asm volatile("v_and_b32_sdwa %0, %1, %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "+v"(f[i]) : "v"(cf));
         }
     }
     unsigned long long t1 = __builtin_readcyclecounter();
@@ -81,5 +93,17 @@ int main() {
     run<9>("v_cvt_f32_f64");
     run<10>("v_and_b32");
     run<11>("v_lshlrev_b64");
+    run<12>("v_cvt_f64_u32");
+    run<13>("v_cvt_f64_i32");
+    run<14>("v_frexp_mant_f64");
+    run<15>("v_frexp_exp_i32_f64");
+    run<16>("v_cmp_class_f64");
+    run<17>("v_bfe_u32");
+    run<18>("v_lshl_add_u32");
+    run<19>("v_cvt_f32_ubyte1");
+    run<20>("v_cvt_f64_f32");
+    run<21>("v_mov_b64");
+    run<22>("v_add_u32");
+    run<23>("v_and_b32_sdwa");
     return 0;
 }
