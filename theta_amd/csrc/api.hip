@@ -42,7 +42,7 @@ void batch_launch_boundary_min(int m, int tau, const double *r, const double *rN
 void batch_launch_score_masked(int n, int m, int tau, int B, int S, const unsigned char *C, const double *w,
                                const double *r, const double *mu, const unsigned long long *mask, double *nll,
                                double *rsum_scratch, hipStream_t st, double rsum_host, bool rsum_host_valid, double rlogw_host,
-                               bool rlogw_valid);
+                               bool rlogw_valid, double wsum_host);
 
 // ---- error string ---------------------------------------------------------------------------------
 static thread_local char g_err[512] = "";
@@ -1305,7 +1305,7 @@ extern "C" int theta_score_masked_device(theta_ctx *ctx, int n, int m, int tau, 
     HIP_TRY(hipEventRecord(ctx->ev0, st));
     batch_launch_score_masked(n, m, tau, B, S, (const unsigned char *)d_C, (const double *)d_w.p, (const double *)d_r.p,
                               (const double *)d_mu, mask ? (const unsigned long long *)d_mask.p : nullptr, (double *)d_nll,
-                              (double *)d_rsum.p, st, host_sum(r, m), true, rlogw, rlogw_ok);
+                              (double *)d_rsum.p, st, host_sum(r, m), true, rlogw, rlogw_ok, host_sum(w, m));
     HIP_TRY(hipEventRecord(ctx->ev1, st));
     HIP_TRY(hipStreamSynchronize(st));
     HIP_TRY(hipGetLastError());
@@ -1346,7 +1346,7 @@ extern "C" int theta_score_masked(theta_ctx *ctx, int n, int m, int tau, int B, 
     HIP_TRY(hipEventRecord(ctx->ev0, st));
     batch_launch_score_masked(n, m, tau, B, S, (const unsigned char *)d_C.p, (const double *)d_w.p, (const double *)d_r.p,
                               (const double *)d_mu.p, mask ? (const unsigned long long *)d_mask.p : nullptr,
-                              (double *)d_nll.p, (double *)d_rsum.p, st, host_sum(r, m), true, rlogw, rlogw_ok);
+                              (double *)d_nll.p, (double *)d_rsum.p, st, host_sum(r, m), true, rlogw, rlogw_ok, host_sum(w, m));
     HIP_TRY(hipEventRecord(ctx->ev1, st));
     HIP_TRY(hipMemcpyAsync(nll, d_nll.p, (size_t)B * S * sizeof(double), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));

@@ -618,11 +618,12 @@ __device__ __forceinline__ void spc_stage(const unsigned char *src_bytes, int nb
 // ln w_i + ln(tau mu0 + x mu1) -- the first part a constant of the problem (sum r_i ln w_i, summed once on the host), the
 // second one of a handful of values per candidate (x is a copy number).  A thread computes SPT_VALUES logarithms once, keeps
 // them in its column of an LDS table [value][thread] (the bank depends on the thread only: conflict-free) and walks its m rows
-// with one 8-byte table read and three FMAs each: ~10 vector instructions per interval instead of 28.  Requires every w_i > 0
-// (else the direct form, whose per-interval order of operations then decides between inf and NaN).
+// with one 8-byte table read and two FMAs each (r_i ln(..) into the total, w_i x into sum w_i x_i: the sum of C.mu is
+// tau mu0 sum w_i + mu1 sum w_i x_i, sum w_i from the host): ~6 vector instructions per interval instead of 24.  Requires every
+// w_i > 0 (else the direct form, whose per-interval order of operations then decides between inf and NaN).
 template <int NC, bool TABLE>
-__global__ __launch_bounds__(256) void score_plain_kernel(int m, int tau, int B, const unsigned char *C, const double *w, const double *r,
-                                                          const double *mu, double rsum, double rlogw, double *nll) {
+__global__ __launch_bounds__(256) void score_plain_kernel(int m, int tau, int B, const unsigned char *C, const double *__restrict__ w,
+                                                          const double *__restrict__ r, const double *mu, double rsum, double rlogw, double wsum, double *nll) {
     static_assert(!TABLE || NC == 1, "the table form is for one tumour column");
     const int cb = m * NC;                       // bytes per candidate, a multiple of 4 (checked by the launcher)
     const int cw = cb >> 2, pw = cw | 1;         // words per candidate; odd LDS stride: lanes fall on distinct banks
@@ -693,18 +694,18 @@ __global__ __launch_bounds__(256) void score_plain_kernel(int m, int tau, int B,
         // word (one and + compare per four rows); a candidate that has one -- copy numbers 8..15, rare -- is redone below
         // with the direct logarithm.  (A test and branch per row cost more than the row's arithmetic.)
         bool big = false;
+        double wx = 0.0;                                         // sum w_i x_i: sum C.mu = tau mu0 sum w_i + mu1 sum w_i x_i
         for (int q = 0; q < cw; q++) {
             const unsigned int word = row[q];
             big |= (word & ~(0x01010101u * (SPT_VALUES - 1))) != 0u;
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                const double2 wi = wr[4 * q + k];
-                const unsigned x = (word >> (8 * k)) & 0xffu;
-                const double inner = __builtin_fma((double)x, m1, m0);
-                den = __builtin_fma(wi.x, inner, den);
-                tot = __builtin_fma(wi.y, mine[((word >> (8 * k)) & (SPT_VALUES - 1)) * 256], tot);
+                const double2 wi = double2{w[4 * q + k], r[4 * q + k]};       // (wave-uniform: scalar loads, SGPR operands)
+                wx = __builtin_fma(wi.x, (double)((word >> (8 * k)) & 0xffu), wx);
+                tot = __builtin_fma(wi.y, mine[__builtin_amdgcn_ubfe(word, 8 * k, 3) * 256], tot);
             }
         }
+        den = __builtin_fma(m1, wx, m0 * wsum);
         if (big) {
             tot = 0.0;
             for (int q = 0; q < cw; q++) {
@@ -723,7 +724,7 @@ __global__ __launch_bounds__(256) void score_plain_kernel(int m, int tau, int B,
         // a flag, and such a candidate is redone below with the guarded one -- same operations, same order, so the same bits.
         bool odd = false;
         auto term = [&](int i) {
-            const double2 wi = wr[i];
+            const double2 wi = double2{w[i], r[i]};                   // (wave-uniform: scalar loads, SGPR operands)
             const double x = (double)row[i * NC], y = (NC == 2) ? (double)row[i * NC + 1] : 0.0;
             const double cm = wi.x * __builtin_fma(x, m1, __builtin_fma(y, m2, m0));
             den += cm;
@@ -782,7 +783,7 @@ void batch_launch_score(int n, int m, int B, const double *Cw, const double *mu,
 void batch_launch_score_masked(int n, int m, int tau, int B, int S, const unsigned char *C, const double *w,
                                const double *r, const double *mu, const unsigned long long *mask, double *nll,
                                double *rsum_scratch, hipStream_t st, double rsum_host, bool rsum_host_valid, double rlogw_host,
-                               bool rlogw_valid) {
+                               bool rlogw_valid, double wsum_host) {
     if (mask != nullptr && S >= 16 && rsum_scratch != nullptr) {   // enough masks to fill the 16-row MFMA tiles
         hipLaunchKernelGGL(mask_rsum_kernel, dim3(S), dim3(64), 0, st, m, S, r, mask, rsum_scratch);
         const size_t xa = (size_t)m * 256 + SMX_TAB_BYTES, xb = (size_t)((m + 15) & ~15) * 256;
@@ -808,13 +809,13 @@ void batch_launch_score_masked(int n, int m, int tau, int B, int S, const unsign
         if (n == 2 && rlogw_valid && !getenv("THETA_SCORE_NO_TABLE")) {      // every w_i > 0: the table-driven form
             const size_t ldt = lds + (size_t)SPT_VALUES * 256 * sizeof(double);
             (void)hipFuncSetAttribute((const void *)score_plain_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldt);
-            hipLaunchKernelGGL((score_plain_kernel<1, true>), dim3(blocks), dim3(256), ldt, st, m, tau, B, C, w, r, mu, rsum_host, rlogw_host, nll);
+            hipLaunchKernelGGL((score_plain_kernel<1, true>), dim3(blocks), dim3(256), ldt, st, m, tau, B, C, w, r, mu, rsum_host, rlogw_host, wsum_host, nll);
         } else if (n == 2) {
             (void)hipFuncSetAttribute((const void *)score_plain_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL((score_plain_kernel<1, false>), dim3(blocks), dim3(256), lds, st, m, tau, B, C, w, r, mu, rsum_host, 0.0, nll);
+            hipLaunchKernelGGL((score_plain_kernel<1, false>), dim3(blocks), dim3(256), lds, st, m, tau, B, C, w, r, mu, rsum_host, 0.0, 0.0, nll);
         } else {
             (void)hipFuncSetAttribute((const void *)score_plain_kernel<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL((score_plain_kernel<2, false>), dim3(blocks), dim3(256), lds, st, m, tau, B, C, w, r, mu, rsum_host, 0.0, nll);
+            hipLaunchKernelGGL((score_plain_kernel<2, false>), dim3(blocks), dim3(256), lds, st, m, tau, B, C, w, r, mu, rsum_host, 0.0, 0.0, nll);
         }
     } else {
         // (a HIP grid holds fewer than 2^32 threads: 2^24 candidates -- one wave each -- per launch)
