@@ -42,7 +42,7 @@ void batch_launch_boundary_min(int m, int tau, const double *r, const double *rN
 void batch_launch_score_masked(int n, int m, int tau, int B, int S, const unsigned char *C, const double *w,
                                const double *r, const double *mu, const unsigned long long *mask, double *nll,
                                double *rsum_scratch, hipStream_t st, double rsum_host, bool rsum_host_valid, double rlogw_host,
-                               bool rlogw_valid, double wsum_host);
+                               bool rlogw_valid, double wsum_host, double wmin_host, double wmax_host);
 
 // ---- error string ---------------------------------------------------------------------------------
 static thread_local char g_err[512] = "";
@@ -1195,6 +1195,17 @@ static double host_sum(const double *v, int m) {
     for (int i = 0; i < m; i++) s += v[i];
     return s;
 }
+// smallest / largest weight (NaN if any is): the plain scorer's per-candidate test that every row term is a positive normal number
+static double host_min(const double *v, int m) {
+    double s = INFINITY;
+    for (int i = 0; i < m; i++) s = (v[i] < s || v[i] != v[i]) ? v[i] : s;
+    return s;
+}
+static double host_max(const double *v, int m) {
+    double s = -INFINITY;
+    for (int i = 0; i < m; i++) s = (v[i] > s || v[i] != v[i]) ? v[i] : s;
+    return s;
+}
 // sum r_i ln w_i for the n = 2 table-driven scorer (batch.hip): valid iff every weight is a positive finite number
 static bool host_rlogw(const double *w, const double *r, int m, double &out) {
     double s = 0.0;
@@ -1305,7 +1316,7 @@ extern "C" int theta_score_masked_device(theta_ctx *ctx, int n, int m, int tau, 
     HIP_TRY(hipEventRecord(ctx->ev0, st));
     batch_launch_score_masked(n, m, tau, B, S, (const unsigned char *)d_C, (const double *)d_w.p, (const double *)d_r.p,
                               (const double *)d_mu, mask ? (const unsigned long long *)d_mask.p : nullptr, (double *)d_nll,
-                              (double *)d_rsum.p, st, host_sum(r, m), true, rlogw, rlogw_ok, host_sum(w, m));
+                              (double *)d_rsum.p, st, host_sum(r, m), true, rlogw, rlogw_ok, host_sum(w, m), host_min(w, m), host_max(w, m));
     HIP_TRY(hipEventRecord(ctx->ev1, st));
     HIP_TRY(hipStreamSynchronize(st));
     HIP_TRY(hipGetLastError());
@@ -1346,7 +1357,7 @@ extern "C" int theta_score_masked(theta_ctx *ctx, int n, int m, int tau, int B, 
     HIP_TRY(hipEventRecord(ctx->ev0, st));
     batch_launch_score_masked(n, m, tau, B, S, (const unsigned char *)d_C.p, (const double *)d_w.p, (const double *)d_r.p,
                               (const double *)d_mu.p, mask ? (const unsigned long long *)d_mask.p : nullptr,
-                              (double *)d_nll.p, (double *)d_rsum.p, st, host_sum(r, m), true, rlogw, rlogw_ok, host_sum(w, m));
+                              (double *)d_nll.p, (double *)d_rsum.p, st, host_sum(r, m), true, rlogw, rlogw_ok, host_sum(w, m), host_min(w, m), host_max(w, m));
     HIP_TRY(hipEventRecord(ctx->ev1, st));
     HIP_TRY(hipMemcpyAsync(nll, d_nll.p, (size_t)B * S * sizeof(double), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));

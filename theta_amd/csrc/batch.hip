@@ -623,7 +623,7 @@ __device__ __forceinline__ void spc_stage(const unsigned char *src_bytes, int nb
 // w_i > 0 (else the direct form, whose per-interval order of operations then decides between inf and NaN).
 template <int NC, bool TABLE>
 __global__ __launch_bounds__(256) void score_plain_kernel(int m, int tau, int B, const unsigned char *C, const double *__restrict__ w,
-                                                          const double *__restrict__ r, const double *mu, double rsum, double rlogw, double wsum, double *nll) {
+                                                          const double *__restrict__ r, const double *mu, double rsum, double rlogw, double wsum, double wmin, double wmax, double *nll) {
     static_assert(!TABLE || NC == 1, "the table form is for one tumour column");
     const int cb = m * NC;                       // bytes per candidate, a multiple of 4 (checked by the launcher)
     const int cw = cb >> 2, pw = cw | 1;         // words per candidate; odd LDS stride: lanes fall on distinct banks
@@ -720,15 +720,18 @@ __global__ __launch_bounds__(256) void score_plain_kernel(int m, int tau, int B,
         nll[b] = -((tot + rlogw) - rsum * smx_log(den, tab));
     } else {
         const unsigned char *row = (const unsigned char *)(spc_lds + threadIdx.x * pw);
-        // Branch-free walk with the unguarded logarithm; a row term that is not a positive normal number (w_i = 0, ...) raises
-        // a flag, and such a candidate is redone below with the guarded one -- same operations, same order, so the same bits.
-        bool odd = false;
+        // Branch-free walk with the unguarded logarithm.  That needs every row term w_i (m0 + x m1 + y m2) to be a positive normal
+        // number, which is decided per candidate from the extremes -- weights in [wmin, wmax] (from the host), copy numbers in
+        // 0..255, m1, m2 >= 0: the terms lie between wmin m0 and wmax (m0 + 255 (m1 + m2)), and rounding is monotone -- instead
+        // of a test per row.  A candidate that fails (w_i = 0, mu outside the simplex, ...) is done with the guarded logarithm
+        // below: same operations in the same order, so the same bits.
+        const bool odd = !(m1 >= 0.0 && m2 >= 0.0 && smx_log_fast_ok(wmin * m0) &&
+                           smx_log_fast_ok(wmax * __builtin_fma(255.0, m1, __builtin_fma(255.0, m2, m0))));
         auto term = [&](int i) {
             const double2 wi = double2{w[i], r[i]};                   // (wave-uniform: scalar loads, SGPR operands)
             const double x = (double)row[i * NC], y = (NC == 2) ? (double)row[i * NC + 1] : 0.0;
             const double cm = wi.x * __builtin_fma(x, m1, __builtin_fma(y, m2, m0));
             den += cm;
-            odd |= !smx_log_fast_ok(cm);
             tot = __builtin_fma(wi.y, smx_log_fast(cm, tab), tot);
         };
         int i = 0;
@@ -783,7 +786,7 @@ void batch_launch_score(int n, int m, int B, const double *Cw, const double *mu,
 void batch_launch_score_masked(int n, int m, int tau, int B, int S, const unsigned char *C, const double *w,
                                const double *r, const double *mu, const unsigned long long *mask, double *nll,
                                double *rsum_scratch, hipStream_t st, double rsum_host, bool rsum_host_valid, double rlogw_host,
-                               bool rlogw_valid, double wsum_host) {
+                               bool rlogw_valid, double wsum_host, double wmin_host, double wmax_host) {
     if (mask != nullptr && S >= 16 && rsum_scratch != nullptr) {   // enough masks to fill the 16-row MFMA tiles
         hipLaunchKernelGGL(mask_rsum_kernel, dim3(S), dim3(64), 0, st, m, S, r, mask, rsum_scratch);
         const size_t xa = (size_t)m * 256 + SMX_TAB_BYTES, xb = (size_t)((m + 15) & ~15) * 256;
@@ -809,13 +812,13 @@ void batch_launch_score_masked(int n, int m, int tau, int B, int S, const unsign
         if (n == 2 && rlogw_valid && !getenv("THETA_SCORE_NO_TABLE")) {      // every w_i > 0: the table-driven form
             const size_t ldt = lds + (size_t)SPT_VALUES * 256 * sizeof(double);
             (void)hipFuncSetAttribute((const void *)score_plain_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldt);
-            hipLaunchKernelGGL((score_plain_kernel<1, true>), dim3(blocks), dim3(256), ldt, st, m, tau, B, C, w, r, mu, rsum_host, rlogw_host, wsum_host, nll);
+            hipLaunchKernelGGL((score_plain_kernel<1, true>), dim3(blocks), dim3(256), ldt, st, m, tau, B, C, w, r, mu, rsum_host, rlogw_host, wsum_host, wmin_host, wmax_host, nll);
         } else if (n == 2) {
             (void)hipFuncSetAttribute((const void *)score_plain_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL((score_plain_kernel<1, false>), dim3(blocks), dim3(256), lds, st, m, tau, B, C, w, r, mu, rsum_host, 0.0, 0.0, nll);
+            hipLaunchKernelGGL((score_plain_kernel<1, false>), dim3(blocks), dim3(256), lds, st, m, tau, B, C, w, r, mu, rsum_host, 0.0, 0.0, wmin_host, wmax_host, nll);
         } else {
             (void)hipFuncSetAttribute((const void *)score_plain_kernel<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL((score_plain_kernel<2, false>), dim3(blocks), dim3(256), lds, st, m, tau, B, C, w, r, mu, rsum_host, 0.0, 0.0, nll);
+            hipLaunchKernelGGL((score_plain_kernel<2, false>), dim3(blocks), dim3(256), lds, st, m, tau, B, C, w, r, mu, rsum_host, 0.0, 0.0, wmin_host, wmax_host, nll);
         }
     } else {
         // (a HIP grid holds fewer than 2^32 threads: 2^24 candidates -- one wave each -- per launch)
