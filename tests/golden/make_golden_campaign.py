@@ -5,7 +5,8 @@ lib2to3 copy under /tmp, three shims) on seeded random instances of tests/campai
 entries with a NaN likelihood the reference appends through isClose(NaN) (Misc.py:44-46) for matrices with an all-zero tumour
 column.  Runs only in the build container (needs /root/reference).  Data only is written: tests/golden/best_campaign.json.
 
-    python tests/golden/make_golden_campaign.py
+    python tests/golden/make_golden_campaign.py              # best_campaign.json  (seeds 5001.., 50..15 000 candidates per n=3 instance)
+    python tests/golden/make_golden_campaign.py second       # best_campaign2.json (seeds 7001.., larger spaces: up to 60 000 / 200 000)
 """
 import json
 import multiprocessing as mp
@@ -42,15 +43,22 @@ def run(inst):
     return out
 
 
+SECOND = {"want": {(2, "toy"): 20, (2, "mid"): 20, (3, "toy"): 40, (3, "mid"): 40}, "limit": {2: (2000, 200000), 3: (2000, 60000)},
+          "seed0": 7000, "out": "best_campaign2.json"}
+
+
 def main():
     insts = []
-    for (n, shape), want in WANT.items():
-        seed, got = 5000, 0
+    want_tab, limit, seed0, out_name = WANT, LIMIT, 5000, "best_campaign.json"
+    if len(sys.argv) > 1 and sys.argv[1] == "second":
+        want_tab, limit, seed0, out_name = SECOND["want"], SECOND["limit"], SECOND["seed0"], SECOND["out"]
+    for (n, shape), want in want_tab.items():
+        seed, got = seed0, 0
         while got < want:
             seed += 1
             inst = campaign.instance(seed, n, shape)
             cnt = campaign.count_candidates(inst)
-            if not (LIMIT[n][0] <= cnt <= LIMIT[n][1]):
+            if not (limit[n][0] <= cnt <= limit[n][1]):
                 continue
             inst["count"] = int(cnt)
             insts.append(inst)
@@ -59,10 +67,10 @@ def main():
     with mp.get_context("fork").Pool(os.cpu_count() or 1) as pool:
         res = pool.map(run, insts, chunksize=1)
     res.sort(key=lambda i: (i["n"], i["shape"], i["seed"]))
-    with open(os.path.join(HERE, "best_campaign.json"), "w") as f:
+    with open(os.path.join(HERE, out_name), "w") as f:
         json.dump({"cases": res}, f, separators=(",", ":"))
     nan_entries = sum(1 for c in res for b in c["best"] if b["nll"] == "nan")
-    print("wrote best_campaign.json: %d instances, %d candidates, %d NaN entries in the best lists, %.0f s of reference time"
+    print("wrote " + out_name + ": %d instances, %d candidates, %d NaN entries in the best lists, %.0f s of reference time"
           % (len(res), sum(c["count"] for c in res), nan_entries, sum(c["ref_seconds"] for c in res)))
 
 
