@@ -46,8 +46,11 @@ def _gpu_best(inst):
 # ---------------------------------------------------------------------------------------------------
 # `best` against the reference's own lists (fixtures) -- complete lists, NaN entries included
 # ---------------------------------------------------------------------------------------------------
-def test_best_identical_to_reference_lists_on_campaign_fixtures(ctx):
-    cases = load_json("best_campaign.json")["cases"]
+@pytest.mark.parametrize("fixture", ["best_campaign.json", "best_campaign2.json"])
+def test_best_identical_to_reference_lists_on_campaign_fixtures(ctx, fixture):
+    """(best_campaign2.json: a second set of seeds on larger spaces -- up to 60 000 candidates for n=3, 200 000 for n=2 --
+    written by the reference after the hybrj restatement was settled: tests/golden/make_golden_campaign.py second)"""
+    cases = load_json(fixture)["cases"]
     assert len(cases) >= 40
     bad, n_nan, n_cand = [], 0, 0
     for c in cases:

@@ -591,8 +591,10 @@ __device__ __forceinline__ void spc_stage(const unsigned char *src_bytes, int nb
 #pragma unroll
         for (int u = 0; u < 8; u++) {
             const int q = base + u * 256 + (int)threadIdx.x;
-            if (q < nq) v[u] = src4[q];
+            v[u] = src4[q < nq ? q : nq - 1];
         }
+#pragma unroll
+        for (int u = 0; u < 8; u++) asm volatile("" : "+v"(v[u].x), "+v"(v[u].y), "+v"(v[u].z), "+v"(v[u].w));   // (as above)
 #pragma unroll
         for (int u = 0; u < 8; u++) {
             const int q = base + u * 256 + (int)threadIdx.x;
