@@ -78,7 +78,7 @@ typedef struct theta_search_stats {
     uint64_t evaluated;      /* candidates enumerated and solved                                */
     uint64_t accepted;       /* candidates with an admissible optimum (Optimizer.solve != None);
                                 n=3 fused search: among the candidates that were not `dismissed`   */
-    uint64_t degenerate;     /* candidates with an all-zero tumour column (reference: NaN)      */
+    uint64_t degenerate;     /* rank-deficient candidates: listed, not solved (theta_search_degenerate) */
     uint64_t iterations;     /* solver iterations summed over candidates                        */
     uint64_t terms;          /* likelihood terms (interval groups) summed over candidates       */
     uint64_t list_overflow;  /* records dropped because the device tie list was full            */
@@ -138,13 +138,18 @@ int theta_search(theta_problem *p, const uint64_t rank_begin[2], const uint64_t 
 int theta_search_suspects(theta_problem *p, int cap, uint64_t *rank, double *lbound, uint8_t *C, int *n_out);
 
 /*
- * n=3 candidates of the last theta_search call with an ALL-ZERO TUMOUR COLUMN, in rank order (at most C(m + tau, tau) of
- * them exist in a whole space: every row is (0, b) with b non-decreasing and b <= tau).  The fused kernel cannot value
- * them -- the reference's arithmetic is NaN from normalize_C on (Optimizer.py:167-174) -- but the reference still REPORTS
- * something for each: its fsolve returns the start unchanged, (1/3,1/3,1/3) passes inRange (Misc.py:49-57), M3's second
- * fsolve call (Optimizer.py:318-330) lands on a unit vector plus rounding residue, and L3 turns that into a finite NLL or
- * NaN -- which the driver appends to `best` either way (isClose(NaN), Misc.py:44-46).  Feed C to theta_solve_batch, which
- * reproduces that outcome, and replay.  rank[cap*2], C[cap*m*2]; cap = -1 queries how many did not fit the device list.
+ * n=3 RANK-DEFICIENT candidates of the last theta_search call, in rank order: matrices whose columns (tau, x, y) are linearly
+ * dependent, i.e. whose rows (x_i, y_i) lie on one line -- two equal tumour columns, x + y = const, a constant column, an
+ * ALL-ZERO tumour column.  The search kernels do not solve them: what the reference reports for such a matrix is not its
+ * optimum.  The bordered Jacobian of Optimizer.py:288-301 is exactly singular, MINPACK's hybrj may stop unconverged at a nu
+ * inside [0,1]^3 whose components do not sum to one, _solve_n3plus takes it (Optimizer.py:150-153), M3 makes a mu with a
+ * negative entry of it and L3 reports NaN (or a finite value below the matrix's true minimum); with an all-zero column the
+ * arithmetic is NaN from normalize_C on (Optimizer.py:167-174), fsolve returns its start, M3's second fsolve call lands on a
+ * unit vector plus rounding residue and L3 turns that into a finite NLL or NaN.  The reference's driver takes whatever comes
+ * out -- a NaN likelihood is "close" to anything (Misc.py:44-46) and is appended to `best` wherever it stands.  Feed C to
+ * theta_solve_batch, which reproduces the reference's outcome for each, and replay ALL of them with the finalists
+ * (theta_amd/search.py: degenerate_records).  rank[cap*2], C[cap*m*2]; cap = -1 queries how many did not fit the device
+ * list (2^20 per call: search a shorter range then, as theta_amd.Problem.search does).
  */
 int theta_search_degenerate(theta_problem *p, int cap, uint64_t *rank, uint8_t *C, int *n_out);
 

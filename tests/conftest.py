@@ -21,6 +21,20 @@ def unfl(x):
     return x
 
 
+def rank_deficient(C):
+    """C: (B, m, 2) tumour columns.  True where the points (x_i, y_i) of a matrix lie on one line, i.e. (tau, x, y) are linearly
+    dependent -- the candidates the search hands to the reference's own procedure (csrc/n3_core.hpp: N3Line).  Exact: the
+    rank of the integer matrix [1, x, y] through its 3x3 Gram determinant."""
+    import numpy as np
+    C = np.asarray(C, np.int64)
+    A = np.concatenate([np.ones(C.shape[:2] + (1,), np.int64), C], axis=2)          # (B, m, 3)
+    G = np.einsum("bij,bik->bjk", A, A)                                               # (B, 3, 3) integer Gram matrices
+    det = (G[:, 0, 0] * (G[:, 1, 1] * G[:, 2, 2] - G[:, 1, 2] * G[:, 2, 1])
+           - G[:, 0, 1] * (G[:, 1, 0] * G[:, 2, 2] - G[:, 1, 2] * G[:, 2, 0])
+           + G[:, 0, 2] * (G[:, 1, 0] * G[:, 2, 1] - G[:, 1, 1] * G[:, 2, 0]))
+    return det == 0
+
+
 def load_json(name):
     with open(os.path.join(GOLD, name)) as f:
         return json.load(f)

@@ -214,9 +214,14 @@ def test_n3_fused_values_m6k3_all_candidates(ctx):
     assert (ok & ~fb).sum() == 16300 and (ok & fb).sum() == 4466 and (~ok).sum() == 284      # own iterate / fallback / None
     # the fused kernel's dump reports the optimum of every candidate whose minimum lies in the simplex; where the batch
     # solver reports an own optimum too, the two agree to rounding (group sums against per-interval sums)
+    # (rank-deficient candidates -- rows on one line -- are not solved by the search kernels at all: they are listed for the
+    # reference's own procedure, and the dump has NaN for them)
+    from conftest import rank_deficient
+    deficient = rank_deficient(got)
     fused_ok = ~np.isnan(nll)
+    assert not fused_ok[deficient].any() and 500 < deficient.sum() < 2000
     both = ok & ~fb & fused_ok
-    assert both.sum() >= 16200
+    assert both.sum() >= 16200 - (ok & ~fb & deficient).sum()
     assert ((np.abs(nll_b[both] - nll[both]) / nll[both]) >= 1e-9).sum() <= 25     # (hybrj stopped short of the optimum, in range)
     p.close()
 
@@ -473,7 +478,9 @@ def test_config3_shape_rank_ranges_and_tight_bounds_parity(ctx):
             assert start + k in res["rank"] or (start + k in p.last_suspects[0]) or (start + k in p.last_degenerate[0])
             a = p.search(start, start + 7001, window=0.5)
             b = p.search(start + 7001, start + 20000, window=0.5)
-            assert min(a["nll"].min() if len(a["nll"]) else np.inf, b["nll"].min() if len(b["nll"]) else np.inf) == res["nll"].min()
+            # (at the start of the space every matrix of the range may be rank-deficient -- rows on one line --: no finalists at all)
+            assert min(a["nll"].min() if len(a["nll"]) else np.inf, b["nll"].min() if len(b["nll"]) else np.inf) == \
+                (res["nll"].min() if len(res["nll"]) else np.inf)
         # consecutive enumerated matrices are in strictly increasing DFS order: re-ranking by search ranks
         assert np.array_equal(p.enumerate(start + 123, 1)[0], C[123])
     p.close()

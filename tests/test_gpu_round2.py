@@ -62,7 +62,7 @@ def test_best_identical_to_reference_lists_on_campaign_fixtures(ctx, fixture):
         n_nan += sum(1 for b in ref if b[2] != b[2])
         n_cand += c["count"]
     assert not bad, bad
-    assert n_nan >= 5                 # the fixtures do exercise the isClose(NaN) entries
+    assert n_nan >= (5 if fixture == "best_campaign.json" else 1)      # the fixtures do exercise the isClose(NaN) entries
 
 
 def _oracle_side(inst):
@@ -118,14 +118,20 @@ def test_all_zero_tumour_column_outcomes_match_the_reference_table(ctx):
     assert (np.abs(nll[fin] - ref_nll[fin]) <= 1e-9 * np.abs(ref_nll[fin])).all()
     # mu is a unit vector plus MINPACK's rounding residue (1e-24 .. 1e-39): the residue itself is reproduced
     assert np.allclose(mu, ref_mu, rtol=1e-6, atol=0.0)
-    # ... and the fused search hands exactly these matrices to the host (theta_search_degenerate)
+    # ... and the search hands exactly the RANK-DEFICIENT matrices -- rows (x_i, y_i) on one line, the 28 among them -- to the
+    # host (theta_search_degenerate): what the reference reports for those is not their optimum (n3_core.hpp: N3Line)
+    from conftest import rank_deficient
+    d = np.nonzero(rank_deficient(C))[0]
+    assert set(z.tolist()) <= set(d.tolist()) and 500 < len(d) < 2000
     p = theta_amd.Problem(ctx, 3, 6, 2, g["r"].tolist(), g["rN"].tolist(), g["lb"].tolist(), g["ub"].tolist())
-    p.search(0, p.count, window=0.5)
-    ranks, Cd = p.last_degenerate
-    assert ranks == [int(k) for k in z] and np.array_equal(Cd, C[z])
-    # a sub-range holds its own share, in rank order
-    p.search(100, 5000, window=0.5)
-    assert p.last_degenerate[0] == [int(k) for k in z if 100 <= k < 5000]
+    for sieve in (1, 0):                                            # (m = 6 runs on the fused kernel either way; both settings)
+        p.set_option("n3_sieve", sieve)
+        p.search(0, p.count, window=0.5)
+        ranks, Cd = p.last_degenerate
+        assert ranks == [int(k) for k in d] and np.array_equal(Cd, C[d])
+        # a sub-range holds its own share, in rank order
+        p.search(100, 5000, window=0.5)
+        assert p.last_degenerate[0] == [int(k) for k in d if 100 <= k < 5000]
     p.close()
 
 

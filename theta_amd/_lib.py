@@ -21,6 +21,10 @@ class ThetaError(RuntimeError):
         self.code = code
 
 
+class DegenerateOverflow(ThetaError):
+    """More rank-deficient candidates in one theta_search than its device list holds: Problem.search halves the piece."""
+
+
 class NoCandidates(ThetaError):
     """The bounds admit no matrix (the reference prints an error and exits, RunTHetA.py:217-219)."""
 
@@ -459,16 +463,29 @@ class Problem:
         # (finalists and suspects within `window` of the minimum so far, the all-zero-column list), not one entry per piece.
         acc = _Merged(self.n, self.m)
         redo = []                                        # pieces whose device suspect list overflowed: (index, b, e, hint used)
-        b, piece = begin, 0
+        nxt, piece = begin, 0
+        halves = []                                      # (stack) halves of a piece whose rank-deficient list overflowed, in rank order
         rss0 = _rss_bytes()
-        while b < end:
-            e = min(b + step, end)
+        while nxt < end or halves:
+            if halves:
+                b, e = halves.pop()
+            else:
+                b, e = nxt, min(nxt + step, end)
+                nxt = e
             if piece and piece % 256 == 0 and _rss_bytes() - rss0 > self.MAX_HOST_GROWTH:
                 # a guard, not a code path: the merge keeps what can still matter, so the host footprint of a search does not
                 # grow with its length -- if it does (round 2 lost three GPU boxes to a list of 1e25 pieces), stop here
                 raise ThetaError(ERR_CAPACITY, "host memory grew by %.1f GB while walking ranks [%d, %d): refusing to go on"
                                  % ((_rss_bytes() - rss0) / 2.0 ** 30, begin, b))
-            part = self._piece(b, e, window, cap, running)           # later pieces start from the minimum found so far
+            try:
+                part = self._piece(b, e, window, cap, running)       # later pieces start from the minimum found so far
+            except DegenerateOverflow:
+                if e - b <= (1 << 20):                               # (cannot happen: the list holds 2^20)
+                    raise
+                mid = (b + e) // 2
+                halves.append((mid, e))
+                halves.append((b, mid))
+                continue
             nl = part[0]["nll"]
             hint_used = running
             if len(nl):
@@ -477,7 +494,7 @@ class Problem:
                 redo.append((piece, b, e, hint_used, part[2]))       # (its lists are incomplete: searched again below)
             else:
                 acc.add(part, piece, running, window)
-            b, piece = e, piece + 1
+            piece += 1
         self.suspect_reruns = 0
         for piece, b, e, hint_used, dropped in redo:
             if not running < hint_used:
@@ -564,11 +581,12 @@ class Problem:
         return [int(rank[i, 0]) | (int(rank[i, 1]) << 64) for i in range(k)], lb, self._shape_C(Cb, k)
 
     def degenerate(self):
-        """n=3 candidates of the last theta_search with an all-zero tumour column: (ranks, C)."""
+        """n=3 rank-deficient candidates of the last theta_search (rows (x_i, y_i) on one line -- an all-zero tumour column among
+        them --: the reference's outcome for those is not their optimum, csrc/n3_core.hpp: N3Line): (ranks, C)."""
         n_out = C.c_int()
         load().theta_search_degenerate(self._h, -1, None, None, C.byref(n_out))
         if n_out.value:
-            raise ThetaError(ERR_CAPACITY, "%d degenerate candidates did not fit the device list" % n_out.value)
+            raise DegenerateOverflow(ERR_CAPACITY, "%d rank-deficient candidates did not fit the device list" % n_out.value)
         load().theta_search_degenerate(self._h, 0, None, None, C.byref(n_out))
         k = n_out.value
         if k == 0:

@@ -122,7 +122,7 @@ extern "C" int theta_device_info(theta_ctx *c, char *name, int cap, int *cu, uin
 // ---- search instance ------------------------------------------------------------------------------
 #define LIST_CAP (1u << 20)
 #define SUS_CAP (1u << 20)
-#define DEG_CAP (1u << 16)
+#define DEG_CAP (1u << 20)
 #define N3_MAX_TASKS (1 << 18)
 #define SURV_CAP (1u << 24)           /* contenders per slice of the sieve (2.4 GB of the 288 GB, allocated on first use) */
 #define SIEVE_SLICE (1ull << 31)     /* candidates per sieve launch; the finish kernel runs in between and lowers the minimum */
@@ -139,7 +139,7 @@ struct theta_problem {
     uint64_t total[2] = {0, 0};
     std::vector<TieRecord> suspects;   // rejected candidates near the minimum, from the last theta_search
     uint64_t suspects_dropped = 0;     // ... and how many more did not fit the device list
-    std::vector<TieRecord> degenerate; // n=3 candidates with an all-zero tumour column, from the last theta_search
+    std::vector<TieRecord> degenerate; // n=3 rank-deficient candidates (collinear rows; all-zero tumour columns among them), from the last theta_search
     uint64_t degenerate_dropped = 0;
     double hint = INFINITY;            // upper bound of the minimum known to the caller (theta_problem_hint), one-shot
     uint64_t opt_per_task = 0;         // n=3 candidates per wave task (0: automatic), theta_problem_set_option

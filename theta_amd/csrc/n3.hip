@@ -594,6 +594,7 @@ __global__ __launch_bounds__(64 * N3_WAVES, N3_OCC) void n3_search_kernel(N3Dev 
         // ---------------- group tile of the prefix --------------------------------------------
         int G = 0;
         double S1p = 0.0, S2p = 0.0, Rmin = __builtin_inf();   // Rmin: smallest weight of a likelihood term
+        N3Line pline = {0, 0, 0, 0, 0};                        // collinearity state of the prefix rows (n3_core.hpp)
         {
             const bool inp = lane < D;
             const unsigned myrow = st >> 24;  // a | b << 4
@@ -613,6 +614,7 @@ __global__ __launch_bounds__(64 * N3_WAVES, N3_OCC) void n3_search_kernel(N3Dev 
                     Ns += __shfl_xor(Ns, o, WAVE);
                 }
                 double a = (double)(q & 15u), b = (double)(q >> 4);
+                n3_line_add(pline, (int)(q & 15u), (int)(q >> 4));        // (scalar: q is wave-uniform)
                 if (lane == 0) {
                     gX[G] = a;
                     gY[G] = b;
@@ -830,7 +832,15 @@ __global__ __launch_bounds__(64 * N3_WAVES, N3_OCC) void n3_search_kernel(N3Dev 
                         push = true;
                         const double S1 = __builtin_fma((double)(rw & 15u), leafN[L - 1], S1u);
                         const double S2 = __builtin_fma((double)(rw >> 4), leafN[L - 1], S2u);
-                        if (!direct && S1 != 0.0 && S2 != 0.0) {
+                        bool deficient = false;
+                        if (pline.kind < 3) {         // (wave-uniform and rare: the prefix rows lie on one line -- does the whole candidate?)
+                            N3Line ln = pline;
+#pragma unroll
+                            for (int l = 0; l < L; l++) n3_line_add(ln, (int)((full >> (8 * l)) & 15u), (int)((full >> (8 * l + 4)) & 15u));
+                            deficient = ln.kind < 3;
+                        }
+                        if (deficient) full = ~0ull;  // rank-deficient: the queue lists it (RES_DEGEN) for the reference's own procedure
+                        if (!direct && !deficient && S1 != 0.0 && S2 != 0.0) {
                             ev = true;
                             flx[L - 1] = (float)(rw & 15u);
                             fly[L - 1] = (float)(rw >> 4);

@@ -43,6 +43,35 @@ struct N3Task {
     uint64_t skip;               // leaves of the first prefix that precede base
 };
 
+// Are the points (x_i, y_i) of a candidate's rows collinear?  Then its three columns (tau, x, y) are linearly dependent, the
+// bordered Jacobian of the reference's Lagrangian system is exactly singular at every iterate, and what MINPACK makes of it
+// has nothing to do with the candidate's optimum: hybrj may stop, unconverged, at a nu inside [0,1]^3 whose components do not
+// sum to one -- Optimizer._solve_n3plus takes it (Optimizer.py:150-153), M3 turns it into a mu with a negative entry, and L3
+// reports NaN (or a finite value below the candidate's true minimum).  Such a candidate takes part in the reference's result
+// wherever it stands (a NaN likelihood is "close" to anything, Misc.py:44-46), so the search hands EVERY rank-deficient
+// candidate to the reference's own procedure (n3_ref_solve) instead of its own solver: the kernels list them next to the
+// candidates with an all-zero tumour column (x = 0 or y = 0 for all rows: a special case of collinear).
+// Incremental test in integers: kind 0 = no point yet, 1 = one distinct point, 2 = a line through (a0, b0) with direction
+// (da, db), 3 = three points not on a line (full rank; final).
+struct N3Line {
+    int kind, a0, b0, da, db;
+};
+__host__ __device__ inline void n3_line_add(N3Line &s, int a, int b) {
+    if (s.kind == 0) {
+        s.a0 = a;
+        s.b0 = b;
+        s.kind = 1;
+    } else if (s.kind == 1) {
+        if (a != s.a0 || b != s.b0) {
+            s.da = a - s.a0;
+            s.db = b - s.b0;
+            s.kind = 2;
+        }
+    } else if (s.kind == 2) {
+        if (s.da * (b - s.b0) - s.db * (a - s.a0) != 0) s.kind = 3;
+    }
+}
+
 struct N3Host {
     int m = 0, K = 0, Q = 0, NT = 0;
     std::vector<int> lb, ub;

@@ -182,6 +182,7 @@ struct SvCtx {
     unsigned long long skip;         // leaves of the task's first prefix that precede its first candidate
     // likelihood data of the current prefix
     F S1p, S2p;                      // column sums of the prefix rows (weighted by the normal counts), / N
+    N3Line line;                     // collinearity state of the prefix rows (n3_core.hpp): kind 3 = the prefix alone has full rank
     F leafN[ML];                     // normal counts of the leaf rows / N
     F leafRf[ML];                    // tumour counts of the leaf rows
     F rtot_f, rtot_over_rmin, inv_Rtot, conv_l2, fine_l2;
@@ -537,6 +538,17 @@ __device__ __forceinline__ void sv_child_eval(const SvCtx<ML, F> &c, int lo, int
     const F x = (F)(r16 & 0xffu), y = (F)(r16 >> 8);
     const F s1 = sv_fma(x, Nl, P[10]), s2 = sv_fma(y, Nl, P[11]);
     o.regular = s1 > F(0) && s2 > F(0);
+    if (c.line.kind < 3) {            // (wave-uniform and rare: the prefix rows lie on one line -- does the whole candidate?)
+        unsigned rw[ML / 2];
+        sv_child_rows<ML, F>(c, o.code, o.slot, rw);
+        N3Line ln = c.line;
+#pragma unroll
+        for (int j = 0; j < ML / 2; j++) {
+            n3_line_add(ln, (int)(rw[j] & 0xffu), (int)((rw[j] >> 8) & 0xffu));
+            n3_line_add(ln, (int)((rw[j] >> 16) & 0xffu), (int)(rw[j] >> 24));
+        }
+        o.regular = o.regular && ln.kind == 3;          // rank-deficient: listed for the reference's own procedure, like an all-zero column
+    }
     o.off = c.done + (unsigned)k;
     const F w0 = P[12], u1 = P[13], u2 = P[14];
     const F q = sv_fma(x, u1, sv_fma(y, u2, w0));
@@ -887,6 +899,7 @@ __global__ __launch_bounds__(64 * SV_WAVES, sizeof(F) == 4 ? SV_OCC : SV_OCC64) 
 #endif
         int G = 0;
         double S1p = 0.0, S2p = 0.0, Rmin = __builtin_inf();
+        N3Line pline = {0, 0, 0, 0, 0};
         {
             // lane i stands for interval i and, for matrices of more than 64 + ML rows, for interval 64 + i as well
             const bool inp = lane < D, inp1 = lane + WAVE < D;
@@ -910,6 +923,7 @@ __global__ __launch_bounds__(64 * SV_WAVES, sizeof(F) == 4 ? SV_OCC : SV_OCC64) 
                     Ns += __shfl_xor(Ns, o, WAVE);
                 }
                 const F a = (F)(q & 15u), b = (F)(q >> 4);
+                n3_line_add(pline, (int)(q & 15u), (int)(q >> 4));        // (scalar: q is wave-uniform)
                 if (lane == 0) {
                     F *xy = (F *)&c.W->fXY[G >> 1];
                     F *rr = (F *)&c.W->fRR[G >> 1];
@@ -931,6 +945,7 @@ __global__ __launch_bounds__(64 * SV_WAVES, sizeof(F) == 4 ? SV_OCC : SV_OCC64) 
         if (!(Rmin < __builtin_inf())) Rmin = 1.0;
         c.G = G;
         c.GP = (G + 1) >> 1;
+        c.line = pline;
         c.S1p = (F)(S1p * inv_N);
         c.S2p = (F)(S2p * inv_N);
         c.rtot_over_rmin = (F)(Pg.Rtot / Rmin);

@@ -15,11 +15,14 @@ How the reference's per-candidate outcome is followed:
   * n=3 candidates are reported the way Optimizer._solve_n3plus reports them: their own optimum where the reference's
     fsolve run (MINPACK hybrj, restated in csrc/hybrj4.hpp) ends inside [0,1]^3, else the nu = (1/3,1/3,1/3) fallback
     (`fallback_records`), or None where its BFGS line search walks out of the domain;
-  * candidates with an all-zero tumour column -- whose arithmetic is NaN in the reference from normalize_C on -- take part
-    with what the reference makes of them (`degenerate_records`): a finite NLL or NaN, decided by the rounding residue of
-    M3's fsolve call (MINPACK hybrd, restated too).  A NaN likelihood counts as "close" to anything (Misc.py:44-46), so the
-    reference appends such entries to `best` wherever they stand after the last replacement of the minimum; so does the
-    replay here.
+  * rank-deficient candidates -- rows (x_i, y_i) on one line: equal tumour columns, x + y = const, an all-zero column
+    (whose arithmetic is NaN in the reference from normalize_C on) -- are not solved by the search kernels at all: the
+    reference's hybrj runs on an exactly singular Jacobian there and what it reports is not the candidate's optimum (an
+    unconverged nu in [0,1]^3 that does not sum to one, hence a mu with a negative entry and a NaN likelihood, or a finite
+    one below the true minimum).  They take part with what the reference makes of them (`degenerate_records`:
+    theta_solve_batch, the reference's procedure restated).  A NaN likelihood counts as "close" to anything
+    (Misc.py:44-46), so the reference appends such entries to `best` wherever they stand after the last replacement of the
+    minimum; so does the replay here.
 """
 import sys
 
@@ -93,7 +96,7 @@ class SearchReport(object):
         self.suspect_bound = float("inf")  # smallest NLL any of them can take on the simplex boundary
         self.certificate_complete = True   # False if the device suspect list overflowed (poor sub-range without a hint)
         self.fallback_finalists = 0        # n=3: rejected candidates that joined the finalists with the reference's nu = 1/3 value
-        self.degenerate = 0                # n=3: candidates with an all-zero tumour column (reported like the reference does)
+        self.degenerate = 0                # n=3: rank-deficient candidates (reported like the reference does)
         self.dropped_not_ok = 0            # finalists of the fused kernel the reference-order re-solve returned None for
         self.suspect_reruns = 0            # pieces of the range searched again because their suspect list overflowed
         self.seconds = 0.0
@@ -138,10 +141,11 @@ def collect_finalists(problem, ctx, r, rN, max_normal, begin, end, window=COLLEC
 
 def degenerate_records(problem, ctx, r, rN, max_normal, report=None):
     """
-    n=3 candidates of the searched range with an all-zero tumour column, valued the way the reference values them
-    (theta_solve_batch: hybrj on the NaN system returns its start, M3's hybrd call lands on a unit vector plus residue, L3
-    makes a finite number or NaN of it).  All of them are returned: the finite ones are ordinary finalists if they come
-    within the window, the NaN ones interact with the running minimum wherever they stand.
+    n=3 rank-deficient candidates of the searched range (rows on one line; all-zero tumour columns among them), valued the way
+    the reference values them (theta_solve_batch: hybrj on the singular / NaN system, M3's hybrd call, L3's sums -- a finite
+    number or NaN).  All of them are returned: the finite ones are ordinary entries of the replay whatever their value (the
+    reference may report one BELOW the candidate's true minimum), the NaN ones interact with the running minimum wherever
+    they stand.
     """
     ranks, Cs = problem.last_degenerate
     if not len(ranks):
