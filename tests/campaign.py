@@ -4,7 +4,9 @@ tests/golden/make_golden_campaign.py and the -m gpu tests).  An instance is ever
 
 Shapes: "toy" (n=2: m 4-13, k 2-5, tau 1-3, max_normal 0.5-1; n=3: m 4-7, k 2-3; ragged bounds with lb in {0,1}, so the
 n=3 spaces hold matrices with an all-zero tumour column) and "mid" (m 10-18, k 3-5, bounds tight around a planted truth,
-30 % of the n=3 instances with ONE tumour population -- the shape interval selection + the bounds heuristics produce).
+30 % of the n=3 instances with ONE tumour population -- the shape interval selection + the bounds heuristics produce) and
+"low" (n=3 only: like "mid" with m 8-14, k 3-6, LOW coverage -- a few to a few hundred reads per interval, flat likelihoods --
+and ONE tumour population in half of the instances: the spaces where near-dependent columns and unconverged solver runs live).
 """
 import numpy as np
 
@@ -61,8 +63,31 @@ def instance_toy(seed, n):
     return dict(seed=seed, n=n, m=m, k=k, tau=tau, mx=mx, r=rs, rN=rNs, order=order, lb=lb, ub=ub, shape="toy")
 
 
+def instance_low(seed, n):
+    rng = np.random.RandomState(seed)
+    m, k = int(rng.randint(8, 15)), int(rng.randint(3, 7))
+    tau = 2
+    rN = np.maximum(rng.poisson(rng.choice([8, 40, 150, 400]) * rng.uniform(0.3, 1.7, m)), 3)
+    C = np.full((m, n), float(tau))
+    for j in range(1, n):
+        C[:, j] = rng.randint(0, k + 1, m)
+    if n == 3 and rng.rand() < 0.5:
+        C[:, 2] = C[:, 1]
+    mu = rng.dirichlet(np.ones(n) * 3)
+    p = (C * rN[:, None]) @ mu
+    p = p / p.sum()
+    r = np.maximum(rng.multinomial(int(rN.sum() * rng.uniform(0.8, 1.5)), p), 1)
+    rs, rNs, order = _sort_r(rN, r)
+    cs = np.maximum(C[:, 1:].max(axis=1), 0)[order]
+    cmin = C[:, 1:].min(axis=1)[order]
+    free = rng.rand(m) < 0.35
+    lb = [int(max(0, a - (1 if f else 0))) for a, f in zip(cmin, free)]
+    ub = [int(min(k, b + (1 if f else 0))) for b, f in zip(cs, free)]
+    return dict(seed=seed, n=n, m=m, k=k, tau=tau, mx=1.0, r=rs, rN=rNs, order=order, lb=lb, ub=ub, shape="low")
+
+
 def instance(seed, n, shape="toy"):
-    return instance_mid(seed, n) if shape == "mid" else instance_toy(seed, n)
+    return instance_mid(seed, n) if shape == "mid" else instance_low(seed, n) if shape == "low" else instance_toy(seed, n)
 
 
 def count_candidates(inst):

@@ -31,6 +31,8 @@ void n3_launch_enumerate_burst(const N3Dev &P, const N3Task *tasks, const unsign
                                unsigned char *out, hipStream_t st);
 void n3_launch_enumerate(const N3Dev &P, const N3Task *tasks, const unsigned *stbuf, int ntasks, uint64_t per_task,
                          unsigned char *out, hipStream_t st);
+void n3_launch_collinear_scan(const unsigned char *C, unsigned long long count, int m, u128 base, SearchCounters *ctr, TieRecord *deg,
+                              unsigned deg_cap, hipStream_t st);
 
 void batch_launch_solve(int n, int m, int tau, const double *r, const double *rN, double max_normal, int B,
                         const unsigned char *C, unsigned char *ok, double *mu, double *nll, double *vals,
@@ -123,6 +125,7 @@ extern "C" int theta_device_info(theta_ctx *c, char *name, int cap, int *cu, uin
 #define LIST_CAP (1u << 20)
 #define SUS_CAP (1u << 20)
 #define DEG_CAP (1u << 20)
+#define LINE_CAP (1u << 19)      // n=3 sieve: tasks per call that may report a prefix with collinear rows (a call holds at most 2^18 tasks; redone slices report again)
 #define N3_MAX_TASKS (1 << 18)
 #define SURV_CAP (1u << 24)           /* contenders per slice of the sieve (2.4 GB of the 288 GB, allocated on first use) */
 #define SIEVE_SLICE (1ull << 31)     /* candidates per sieve launch; the finish kernel runs in between and lowers the minimum */
@@ -153,7 +156,7 @@ struct theta_problem {
     double last_redo_ms = 0.0;
     bool last_sieve64 = false;                         // ... and whether the sieve ran in FP64 (n3_force_f64)
     uint64_t last_launches = 0;                        // launches of the search kernel behind kernel_ms (sieve: one per slice)
-    DevBuf d_r, d_rN, d_small, d_P, d_PR, d_PN, d_cnt, d_ctr, d_list, d_tasks, d_stbuf, d_misc, d_smask, d_dynmask, d_sus, d_deg, d_surv, d_survcnt, d_survacc;
+    DevBuf d_r, d_rN, d_small, d_P, d_PR, d_PN, d_cnt, d_ctr, d_list, d_tasks, d_stbuf, d_misc, d_smask, d_dynmask, d_sus, d_deg, d_surv, d_survcnt, d_survacc, d_line, d_scan;
 };
 
 static int upload(DevBuf &b, const void *src, size_t bytes, hipStream_t st) {
@@ -238,6 +241,7 @@ extern "C" int theta_problem_create(theta_ctx *ctx, int n, int m, int tau, const
     TRY(p->d_list.alloc((size_t)LIST_CAP * sizeof(TieRecord)));
     TRY(p->d_sus.alloc((size_t)SUS_CAP * sizeof(TieRecord)));
     TRY(p->d_deg.alloc((size_t)DEG_CAP * sizeof(TieRecord)));
+    if (n == 3) TRY(p->d_line.alloc((size_t)LINE_CAP * 2 * sizeof(unsigned long long)));
 
     if (n == 2) {
         TRY(n2_build_host(m, lb, ub, p->n2h));
@@ -437,6 +441,49 @@ static int check_range(theta_problem *p, const uint64_t rb[2], const uint64_t re
 }
 
 // Runs the fused kernel over [b, e).  dump arrays are device pointers or null.
+static int enumerate_device(theta_problem *p, u128 b, uint64_t count, unsigned char *d_out, double *kernel_ms);
+
+// n=3 sieve path: the rank-deficient candidates (n3_core.hpp: N3Line) of the tasks that met a prefix with collinear rows.  The
+// sieve kernel only reports such tasks (a per-candidate test in its hot loops cost 1-5 % of the kernel); here their rank
+// ranges -- runs of consecutive tasks -- are materialised with the generator and scanned, one thread per candidate, and the
+// ranks of the candidates whose rows all lie on one line join the degenerate list on the device.  Rare: none of the 2^31
+// candidates of a bench step, 873 of the 21 050 matrices of the m=6, K=3 space.
+static int list_deficient(theta_problem *p, u128 b, u128 e, uint64_t per_task, unsigned line_count, SearchCounters &hc) {
+    theta_ctx *ctx = p->ctx;
+    hipStream_t st = ctx->stream;
+    std::vector<unsigned long long> raw((size_t)2 * line_count);
+    HIP_TRY(hipMemcpyAsync(raw.data(), p->d_line.p, raw.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    std::vector<uint64_t> tix(line_count);
+    for (unsigned i = 0; i < line_count; i++) tix[i] = (uint64_t)(((((u128)raw[2 * i + 1]) << 64 | raw[2 * i]) - b) / per_task);
+    std::sort(tix.begin(), tix.end());
+    tix.erase(std::unique(tix.begin(), tix.end()), tix.end());
+    const size_t cb = (size_t)p->m * 2;
+    const uint64_t run_max = std::max<uint64_t>(1, ((uint64_t)256 << 20) / (per_task * cb));      // <= 256 MB of records at a time
+    for (size_t i = 0; i < tix.size();) {
+        size_t j = i + 1;
+        while (j < tix.size() && tix[j] == tix[j - 1] + 1 && tix[j] - tix[i] < run_max) j++;
+        const u128 rb = b + (u128)tix[i] * per_task;
+        u128 re = b + (u128)(tix[j - 1] + 1) * per_task;
+        if (re > e) re = e;
+        const uint64_t count = (uint64_t)(re - rb);
+        if (p->d_scan.bytes < count * cb) {
+            p->d_scan.release();
+            int rc = p->d_scan.alloc(count * cb);
+            if (rc) return rc;
+        }
+        int rc = enumerate_device(p, rb, count, (unsigned char *)p->d_scan.p, nullptr);
+        if (rc) return rc;
+        n3_launch_collinear_scan((const unsigned char *)p->d_scan.p, count, p->m, rb, (SearchCounters *)p->d_ctr.p, (TieRecord *)p->d_deg.p,
+                                 DEG_CAP, st);
+        i = j;
+    }
+    HIP_TRY(hipMemcpyAsync(&hc.deg_count, (char *)p->d_ctr.p + offsetof(SearchCounters, deg_count), sizeof(unsigned), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(hipGetLastError());
+    return THETA_OK;
+}
+
 static int run_search(theta_problem *p, u128 b, u128 e, double window, double *dump_nll, double *dump_mu,
                       SearchCounters &hc, std::vector<TieRecord> &recs, double &kernel_ms, double &setup_ms,
                       unsigned long long &dropped_out) {
@@ -450,6 +497,8 @@ static int run_search(theta_problem *p, u128 b, u128 e, double window, double *d
     A.sus_cap = SUS_CAP;
     A.deg = (TieRecord *)p->d_deg.p;
     A.deg_cap = DEG_CAP;
+    A.line = (unsigned long long *)p->d_line.p;
+    A.line_cap = p->d_line.p ? LINE_CAP : 0;
     A.window = window;
     A.dump_nll = dump_nll;
     A.dump_mu = dump_mu;
@@ -465,6 +514,7 @@ static int run_search(theta_problem *p, u128 b, u128 e, double window, double *d
     p->last_fallback = 0;
     p->last_launches = 0;
     const unsigned surv_cap = p->opt_surv_cap ? p->opt_surv_cap : SURV_CAP;      // (the list is allocated for SURV_CAP)
+    uint64_t sieve_per_task_last = 0;                                            // candidates per task of the last pass, if the sieve ran it
     for (int pass = 0; pass < 3; pass++) {
         std::vector<std::pair<int, int>> slices;     // n=3 fast path: (first task, tasks) of every sieve launch of this pass
         uint64_t sieve_per_task = 0;
@@ -558,6 +608,7 @@ static int run_search(theta_problem *p, u128 b, u128 e, double window, double *d
                     n3_launch_finish(PS, A, (const SvSurvivor *)p->d_surv.p, surv_cap, cnts + sl, (unsigned *)p->d_survacc.p + sl, st);
                 }
                 sieve_per_task = per_task;
+                sieve_per_task_last = per_task;
                 p->last_sieve64 = p->n3.force64 != 0;
             } else {
                 n3_launch_tasks(p->n3, b, e, per_task, ntasks, (N3Task *)p->d_tasks.p, (unsigned *)p->d_stbuf.p, st);
@@ -714,9 +765,17 @@ static int run_search(theta_problem *p, u128 b, u128 e, double window, double *d
     p->suspects.resize(nsus);
     p->suspects_dropped = hc.sus_count > SUS_CAP ? hc.sus_count - SUS_CAP : 0;
     if (nsus) HIP_TRY(hipMemcpyAsync(p->suspects.data(), p->d_sus.p, (size_t)nsus * sizeof(TieRecord), hipMemcpyDeviceToHost, st));
+    unsigned line_lost = 0;
+    if (p->n == 3 && sieve_per_task_last > 0 && hc.line_count > 0) {
+        if (hc.line_count > LINE_CAP) line_lost = hc.line_count - LINE_CAP;      // (reported like an overflow of the list itself)
+        else {
+            int rc = list_deficient(p, b, e, sieve_per_task_last, hc.line_count, hc);
+            if (rc) return rc;
+        }
+    }
     unsigned ndeg = std::min<unsigned>(hc.deg_count, DEG_CAP);
     p->degenerate.resize(ndeg);
-    p->degenerate_dropped = hc.deg_count > DEG_CAP ? hc.deg_count - DEG_CAP : 0;
+    p->degenerate_dropped = (hc.deg_count > DEG_CAP ? hc.deg_count - DEG_CAP : 0) + line_lost;
     if (ndeg) HIP_TRY(hipMemcpyAsync(p->degenerate.data(), p->d_deg.p, (size_t)ndeg * sizeof(TieRecord), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     dropped_out = list_dropped;

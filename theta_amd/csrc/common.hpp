@@ -88,7 +88,7 @@ struct SearchCounters {
     unsigned int list_count;           // records appended (may exceed capacity)
     unsigned int sus_count;            // suspects appended (may exceed capacity; never triggers a re-run)
     unsigned int deg_count;            // n=3: candidates with an all-zero tumour column appended to the degenerate list
-    unsigned int pad0;
+    unsigned int line_count;           // n=3 sieve: tasks with a prefix whose rows lie on one line (SearchArgs::line), may exceed capacity
     unsigned long long sieve_survivors;   // n=3 fast path: contenders the sieve kernel handed to the finish kernel
     unsigned long long finish_iterations; // ... and the FP64 Newton iterations (m terms each) that kernel ran on them
     unsigned long long sieve_pterms;      // sieve: likelihood terms evaluated for last-level nodes (shared by a node's children)
@@ -103,8 +103,10 @@ struct SearchArgs {
     unsigned list_cap;
     TieRecord *sus;                    // rejected candidates near the minimum (n=3 certificate)
     unsigned sus_cap;
-    TieRecord *deg;                    // n=3 candidates with an all-zero tumour column (rank only): what the reference reports
-    unsigned deg_cap;                  // for them hangs on MINPACK's rounding residue, reproduced by theta_solve_batch
+    TieRecord *deg;                    // n=3 rank-deficient candidates (rank only; all-zero tumour columns among them): what the reference
+    unsigned deg_cap;                  // reports for them is not their optimum; valued by theta_solve_batch, its procedure restated
+    unsigned long long *line;          // n=3 sieve: first rank {lo, hi} of every task that met a prefix with collinear rows: the host
+    unsigned line_cap;                 // materialises those tasks and lists their rank-deficient candidates (api.hip: list_deficient)
     double window;
     double *dump_nll;  // optional per-candidate dump (the reference's --GET_VALUES), else null
     double *dump_mu;
@@ -199,7 +201,8 @@ __device__ __forceinline__ void suspect_append(SearchCounters *ctr, TieRecord *l
     }
 }
 
-// Append one degenerate candidate (all-zero tumour column): its rank is all the host needs.
+// Append one rank-deficient candidate (rows on one line; an all-zero tumour column is the special case the kernels see
+// directly): its rank is all the host needs.
 __device__ __forceinline__ void degenerate_append(SearchCounters *ctr, TieRecord *list, unsigned cap, u128 rank) {
     unsigned idx = atomicAdd(&ctr->deg_count, 1u);
     if (idx < cap) {

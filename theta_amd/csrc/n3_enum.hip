@@ -378,3 +378,25 @@ void n3_launch_enumerate_burst(const N3Dev &P, const N3Task *tasks, const unsign
     }
 #undef EB_LAUNCH
 }
+
+// ------------------------------------------------------------------------------------------------
+// Rank-deficient candidates of a materialised rank range (n3_core.hpp: N3Line): one thread per record walks its rows through the
+// collinearity test and appends the rank of a record whose rows all lie on one line to the degenerate list.  Used by the
+// sieve path of theta_search on the (rare) tasks that met a prefix with collinear rows -- api.hip: list_deficient.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void n3_collinear_scan_kernel(const unsigned char *C, unsigned long long count, int m, uint64_t base_lo,
+                                                                uint64_t base_hi, SearchCounters *ctr, TieRecord *deg, unsigned deg_cap) {
+    const unsigned long long k = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
+    if (k >= count) return;
+    const unsigned char *row = C + (size_t)k * 2 * m;
+    N3Line ln = {0, 0, 0, 0, 0};
+    for (int i = 0; i < m && ln.kind < 3; i++) n3_line_add(ln, (int)row[2 * i], (int)row[2 * i + 1]);
+    if (ln.kind < 3) degenerate_append(ctr, deg, deg_cap, (((u128)base_hi << 64) | base_lo) + k);
+}
+
+void n3_launch_collinear_scan(const unsigned char *C, unsigned long long count, int m, u128 base, SearchCounters *ctr, TieRecord *deg,
+                              unsigned deg_cap, hipStream_t st) {
+    if (count == 0) return;
+    hipLaunchKernelGGL(n3_collinear_scan_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, C, count, m, (uint64_t)base,
+                       (uint64_t)(base >> 64), ctr, deg, deg_cap);
+}

@@ -132,6 +132,7 @@ struct SvWave {
     unsigned short kid[SV_KIDS];                        // candidates of the current round: last row's slot | parent lane << 8
     SvPlanes<F> par;                                    // per last-level node of the round: shared sums, column sums, point
     unsigned pcode[WAVE];                               // ... and the slots of its path rows (6 bits each) | usable << 31
+    unsigned task_line;                                 // a prefix of the task had collinear rows (n3_core.hpp: N3Line)
     Sv4<F> fXY[(N3_MAX_Q + 2) / 2];                     // group tile of the prefix, two terms per entry {a0, a1, b0, b1}
     Sv2<F> fRR[(N3_MAX_Q + 2) / 2];                     // ... and their weights {R0, R1} (an odd last term is paired with weight 0)
     Sv2<F> fRL[ML / 2];                                 // weights of the leaf rows, paired
@@ -182,7 +183,6 @@ struct SvCtx {
     unsigned long long skip;         // leaves of the task's first prefix that precede its first candidate
     // likelihood data of the current prefix
     F S1p, S2p;                      // column sums of the prefix rows (weighted by the normal counts), / N
-    N3Line line;                     // collinearity state of the prefix rows (n3_core.hpp): kind 3 = the prefix alone has full rank
     F leafN[ML];                     // normal counts of the leaf rows / N
     F leafRf[ML];                    // tumour counts of the leaf rows
     F rtot_f, rtot_over_rmin, inv_Rtot, conv_l2, fine_l2;
@@ -538,17 +538,6 @@ __device__ __forceinline__ void sv_child_eval(const SvCtx<ML, F> &c, int lo, int
     const F x = (F)(r16 & 0xffu), y = (F)(r16 >> 8);
     const F s1 = sv_fma(x, Nl, P[10]), s2 = sv_fma(y, Nl, P[11]);
     o.regular = s1 > F(0) && s2 > F(0);
-    if (c.line.kind < 3) {            // (wave-uniform and rare: the prefix rows lie on one line -- does the whole candidate?)
-        unsigned rw[ML / 2];
-        sv_child_rows<ML, F>(c, o.code, o.slot, rw);
-        N3Line ln = c.line;
-#pragma unroll
-        for (int j = 0; j < ML / 2; j++) {
-            n3_line_add(ln, (int)(rw[j] & 0xffu), (int)((rw[j] >> 8) & 0xffu));
-            n3_line_add(ln, (int)((rw[j] >> 16) & 0xffu), (int)(rw[j] >> 24));
-        }
-        o.regular = o.regular && ln.kind == 3;          // rank-deficient: listed for the reference's own procedure, like an all-zero column
-    }
     o.off = c.done + (unsigned)k;
     const F w0 = P[12], u1 = P[13], u2 = P[14];
     const F q = sv_fma(x, u1, sv_fma(y, u2, w0));
@@ -890,6 +879,12 @@ __global__ __launch_bounds__(64 * SV_WAVES, sizeof(F) == 4 ? SV_OCC : SV_OCC64) 
     }
     unsigned long long n_terms = 0, n_pterms = 0;
 
+    // Rank-deficient candidates (rows on one line, n3_core.hpp: N3Line) are the host's to list: testing every child here --
+    // even behind a wave-uniform flag, in a second instantiation of the expansion or out of line -- cost 1-5 % of the kernel
+    // through the registers and the layout of its hot loops.  A wave only notes whether one of its prefixes is collinear (a few
+    // scalar instructions in the group-tile loop); api.hip materialises such tasks and scans them (list_deficient).
+    // (The note lives in LDS: one more scalar held across the expansion cost 2 % of the kernel -- it runs out of scalar registers.)
+    if (lane == 0) c.W->task_line = 0u;
     // the device-wide running minimum: only the finish kernel lowers it, between sieve launches -- one load per task
     sv_set_threshold<ML, F>(c, order_unbits(load_agent_u64(&A.ctr->best_bits)) + A.window);
     while (c.remaining > 0) {
@@ -899,7 +894,6 @@ __global__ __launch_bounds__(64 * SV_WAVES, sizeof(F) == 4 ? SV_OCC : SV_OCC64) 
 #endif
         int G = 0;
         double S1p = 0.0, S2p = 0.0, Rmin = __builtin_inf();
-        N3Line pline = {0, 0, 0, 0, 0};
         {
             // lane i stands for interval i and, for matrices of more than 64 + ML rows, for interval 64 + i as well
             const bool inp = lane < D, inp1 = lane + WAVE < D;
@@ -908,6 +902,22 @@ __global__ __launch_bounds__(64 * SV_WAVES, sizeof(F) == 4 ? SV_OCC : SV_OCC64) 
             if (inp1) c.W->pre[WAVE + lane] = (unsigned short)((myrow1 & 15u) | ((myrow1 >> 4) << 8));
             const double r_i = inp ? Pg.r[lane] : 0.0, rN_i = inp ? Pg.rN[lane] : 0.0;
             const double r_j = inp1 ? Pg.r[WAVE + lane] : 0.0, rN_j = inp1 ? Pg.rN[WAVE + lane] : 0.0;
+            {   // Do the prefix rows (x_i, y_i) lie on one line?  (Rare.)  Then some children may be rank-deficient (n3_core.hpp:
+                // N3Line): the task is noted for the host.  Lane-parallel -- the first row, the first row that differs, one cross
+                // product per lane -- so that nothing is carried through the loop below (a running test there cost 1.4 %).
+                const unsigned p0 = (unsigned)__builtin_amdgcn_readlane((int)myrow, 0);
+                const unsigned long long df = ballot64(inp && myrow != p0), df1 = ballot64(inp1 && myrow1 != p0);
+                bool on_line = true;
+                if (df | df1) {
+                    const unsigned p1 = df ? (unsigned)__builtin_amdgcn_readlane((int)myrow, __builtin_ctzll(df))
+                                           : (unsigned)__builtin_amdgcn_readlane((int)myrow1, __builtin_ctzll(df1));
+                    const int a0 = (int)(p0 & 15u), b0 = (int)(p0 >> 4), da = (int)(p1 & 15u) - a0, db = (int)(p1 >> 4) - b0;
+                    const int cr = da * ((int)(myrow >> 4) - b0) - db * ((int)(myrow & 15u) - a0);
+                    const int cr1 = da * ((int)(myrow1 >> 4) - b0) - db * ((int)(myrow1 & 15u) - a0);
+                    on_line = !(ballot64(inp && cr != 0) | ballot64(inp1 && cr1 != 0));
+                }
+                if (on_line && lane == 0) c.W->task_line = 1u;
+            }
             unsigned long long todo = ballot64(inp), todo1 = ballot64(inp1);
             while (todo | todo1) {
                 unsigned q;
@@ -923,7 +933,6 @@ __global__ __launch_bounds__(64 * SV_WAVES, sizeof(F) == 4 ? SV_OCC : SV_OCC64) 
                     Ns += __shfl_xor(Ns, o, WAVE);
                 }
                 const F a = (F)(q & 15u), b = (F)(q >> 4);
-                n3_line_add(pline, (int)(q & 15u), (int)(q >> 4));        // (scalar: q is wave-uniform)
                 if (lane == 0) {
                     F *xy = (F *)&c.W->fXY[G >> 1];
                     F *rr = (F *)&c.W->fRR[G >> 1];
@@ -945,7 +954,6 @@ __global__ __launch_bounds__(64 * SV_WAVES, sizeof(F) == 4 ? SV_OCC : SV_OCC64) 
         if (!(Rmin < __builtin_inf())) Rmin = 1.0;
         c.G = G;
         c.GP = (G + 1) >> 1;
-        c.line = pline;
         c.S1p = (F)(S1p * inv_N);
         c.S2p = (F)(S2p * inv_N);
         c.rtot_over_rmin = (F)(Pg.Rtot / Rmin);
@@ -972,6 +980,13 @@ __global__ __launch_bounds__(64 * SV_WAVES, sizeof(F) == 4 ? SV_OCC : SV_OCC64) 
         if (!sv_next_prefix(P, st, st1, D, lane)) break;
 #endif
         wave_lds_sync();                               // the prefix rows in LDS are rewritten next
+    }
+    if (lane == 0 && c.W->task_line) {
+        const unsigned idx = atomicAdd(&A.ctr->line_count, 1u);
+        if (idx < A.line_cap) {
+            A.line[2 * idx] = (unsigned long long)c.base;
+            A.line[2 * idx + 1] = (unsigned long long)(c.base >> 64);
+        }
     }
     if (lane == 0) {
         atomicAdd(&A.ctr->evaluated, (unsigned long long)c.done);

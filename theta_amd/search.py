@@ -301,6 +301,11 @@ def _search_local(n, m, tau, lower_bounds, upper_bounds, r, rN, max_normal, shar
     recs, stats = collect_finalists(problem, ctx, r, rN, max_normal, begin, end, report=report)
     if n == 3:
         recs = recs + fallback_records(problem, ctx, r, rN, max_normal, recs, report=report)
+        # rank-deficient candidates: the listed outcome (the reference's own procedure) is THE outcome -- a None included --,
+        # whatever the search kernels made of the same matrix as a finalist or a suspect (the sieve evaluates them like any other)
+        listed = set(problem.last_degenerate[0])
+        if listed:
+            recs = [t for t in recs if t["rank"] not in listed]
         recs = recs + degenerate_records(problem, ctx, r, rN, max_normal, report=report)
     return problem, ctx, recs, stats
 

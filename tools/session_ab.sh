@@ -9,7 +9,7 @@ timeout 900 python -m pytest tests/test_gpu_round3.py::test_fp64_sieve_and_full_
 tail -4 $OUT/pytest_gpu.log
 for lib in main $ABS; do
   if [ $lib = main ]; then unset THETA_HIP_LIB; else export THETA_HIP_LIB=$ROOT/build_ab/lib$lib.so; fi
-  THETA_BENCH_VERBOSE=1 timeout 500 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-traffic --no-extras > $OUT/bench_$lib.json 2> $OUT/bench_$lib.err
+  THETA_BENCH_VERBOSE=1 timeout 500 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-traffic --no-extras > $OUT/bench_$lib.json 2> $OUT/bench_$lib.err
   echo "== $lib"
   python - <<PY
 import json
