@@ -293,3 +293,34 @@ def test_overflowed_contender_lists_walk_the_redo_ladder_without_changing_a_resu
     assert walked >= 12                                          # (the small capacities really overflowed)
     p.close()
     p14.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("m,K,seed", [(11, 3, 1), (12, 2, 2), (9, 4, 3)])
+def test_rank_deficient_candidates_are_listed_exactly_by_both_search_paths(ctx, m, K, seed):
+    """theta_search_degenerate after a search = exactly the matrices of the range whose rows (x_i, y_i) lie on one line (brute
+    force over the enumerated space, conftest.rank_deficient) -- on the sieve path (tasks with a collinear prefix noted by the
+    kernel, materialised and scanned by api.hip: list_deficient) and on the fused kernel (tested leaf by leaf), over the whole
+    space and over a sub-range that cuts tasks."""
+    import theta_amd
+    from conftest import rank_deficient
+    import bench
+    r, rN, _order = bench.synth(seed=seed, m=m, n=3, k=K)
+    p = theta_amd.Problem(ctx, 3, m, 2, r, rN, [0] * m, [K] * m, 1.0)
+    assert 10 ** 5 < p.count < 3 * 10 ** 7, p.count
+    want = []
+    step = 1 << 20
+    for b in range(0, p.count, step):
+        C = p.enumerate(b, min(step, p.count - b))
+        want += (b + np.nonzero(rank_deficient(C))[0]).tolist()
+    assert len(want) > 50
+    for sieve in (1, 0):
+        p.set_option("n3_sieve", sieve)
+        res = p.search(0, p.count, window=0.5)
+        assert p.last_degenerate[0] == want, (sieve, len(p.last_degenerate[0]), len(want))
+        if sieve:
+            assert res["stats"]["kernel_launches"] >= 2              # (the sieve path did run: sieve + finish)
+        lo, hi = p.count // 7 + 13, p.count // 2 + 5
+        p.search(lo, hi, window=0.5)
+        assert p.last_degenerate[0] == [k for k in want if lo <= k < hi], sieve
+    p.close()
