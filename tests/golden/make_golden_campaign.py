@@ -8,6 +8,7 @@ column.  Runs only in the build container (needs /root/reference).  Data only is
     python tests/golden/make_golden_campaign.py              # best_campaign.json  (seeds 5001.., 50..15 000 candidates per n=3 instance)
     python tests/golden/make_golden_campaign.py second       # best_campaign2.json (seeds 7001.., larger spaces: up to 60 000 / 200 000)
     python tests/golden/make_golden_campaign.py third        # best_campaign3.json (seeds 8001.., n=3, the low-coverage shape + mid)
+    python tests/golden/make_golden_campaign.py fourth       # best_campaign4.json (whole spaces with full-rank NaN outcomes, tools/nan_hunt.py)
 """
 import json
 import multiprocessing as mp
@@ -51,6 +52,11 @@ SECOND = {"want": {(2, "toy"): 20, (2, "mid"): 20, (3, "toy"): 40, (3, "mid"): 4
 THIRD = {"want": {(3, "low"): 80, (3, "mid"): 30}, "limit": {3: (500, 40000)}, "seed0": 8000, "out": "best_campaign3.json"}
 
 
+# instances tools/nan_hunt.py found to hold FULL-RANK matrices the reference reports with a NaN likelihood (whole spaces of 4e5..5e5
+# matrices: a quarter of an hour of the reference each)
+FOURTH = {"list": [(20036, 3, "mid"), (20123, 3, "mid")], "out": "best_campaign4.json"}
+
+
 def main():
     insts = []
     want_tab, limit, seed0, out_name = WANT, LIMIT, 5000, "best_campaign.json"
@@ -58,6 +64,12 @@ def main():
         want_tab, limit, seed0, out_name = SECOND["want"], SECOND["limit"], SECOND["seed0"], SECOND["out"]
     if len(sys.argv) > 1 and sys.argv[1] == "third":
         want_tab, limit, seed0, out_name = THIRD["want"], THIRD["limit"], THIRD["seed0"], THIRD["out"]
+    if len(sys.argv) > 1 and sys.argv[1] == "fourth":
+        out_name, want_tab = FOURTH["out"], {}
+        for seed, n, shape in FOURTH["list"] + [(int(a), 3, "mid") for a in sys.argv[2:]]:
+            inst = campaign.instance(seed, n, shape)
+            inst["count"] = int(campaign.count_candidates(inst))
+            insts.append(inst)
     for (n, shape), want in want_tab.items():
         seed, got = seed0, 0
         while got < want:

@@ -324,3 +324,39 @@ def test_rank_deficient_candidates_are_listed_exactly_by_both_search_paths(ctx, 
         p.search(lo, hi, window=0.5)
         assert p.last_degenerate[0] == [k for k in want if lo <= k < hi], sieve
     p.close()
+
+
+@pytest.mark.gpu
+def test_nan_sweep_lists_every_candidate_the_reference_reports_with_a_nan_likelihood(ctx):
+    """Option "n3_nan_sweep" (api.hip: nan_sweep): after the search, theta_search_degenerate holds the rank-deficient candidates AND
+    every other candidate the reference's procedure reports with a NaN likelihood -- here the whole space through theta_solve_batch
+    is the check.  The instance (tools/nan_hunt.py found it) holds full-rank matrices of that kind; none of them is anywhere near
+    the minimum, so the search alone never looks at them."""
+    import campaign
+    import theta_amd
+    from conftest import rank_deficient
+    inst = campaign.instance(20123, 3, "mid")
+    p = theta_amd.Problem(ctx, 3, inst["m"], inst["tau"], inst["r"], inst["rN"], inst["lb"], inst["ub"], inst["mx"])
+    assert 10 ** 5 < p.count < 5 * 10 ** 6
+    want, full_rank_nan = [], 0
+    for b in range(0, p.count, 1 << 19):
+        C = p.enumerate(b, min(1 << 19, p.count - b))
+        ok, _mu, nll, _ = ctx.solve_batch(3, inst["tau"], inst["r"], inst["rN"], C, inst["mx"], want_vals=False)
+        d = rank_deficient(C)
+        bad = (ok != 0) & np.isnan(nll)
+        full_rank_nan += int((bad & ~d).sum())
+        want += (b + np.nonzero(d | bad)[0]).tolist()
+    assert full_rank_nan >= 3
+    p.search(0, p.count, window=0.5)
+    without = p.last_degenerate[0]
+    p.set_option("n3_nan_sweep", 1)
+    p.search(0, p.count, window=0.5)
+    assert p.last_degenerate[0] == want and len(without) == len(want) - full_rank_nan
+    lo, hi = p.count // 3, p.count // 3 + 70001
+    p.search(lo, hi, window=0.5)
+    assert p.last_degenerate[0] == [k for k in want if lo <= k < hi]
+    p.close()
+    # ... and the driver switches the sweep on for a space of this size
+    import theta_amd.search as ts
+    ts.do_optimization_single(3, inst["m"], inst["k"], inst["tau"], inst["lb"], inst["ub"], inst["r"], inst["rN"], inst["mx"], inst["order"])
+    assert ts.last_report.nan_sweep is True and ts.last_report.degenerate >= full_rank_nan

@@ -31,6 +31,8 @@ void n3_launch_enumerate_burst(const N3Dev &P, const N3Task *tasks, const unsign
                                unsigned char *out, hipStream_t st);
 void n3_launch_enumerate(const N3Dev &P, const N3Task *tasks, const unsigned *stbuf, int ntasks, uint64_t per_task,
                          unsigned char *out, hipStream_t st);
+void n3_launch_nan_scan(const unsigned char *ok, const double *nll, unsigned long long count, u128 base, SearchCounters *ctr, TieRecord *deg,
+                        unsigned deg_cap, hipStream_t st);
 void n3_launch_collinear_scan(const unsigned char *C, unsigned long long count, int m, u128 base, SearchCounters *ctr, TieRecord *deg,
                               unsigned deg_cap, hipStream_t st);
 
@@ -147,6 +149,8 @@ struct theta_problem {
     double hint = INFINITY;            // upper bound of the minimum known to the caller (theta_problem_hint), one-shot
     uint64_t opt_per_task = 0;         // n=3 candidates per wave task (0: automatic), theta_problem_set_option
     int opt_per_thread = 0;            // n=2 candidates per thread (0: automatic)
+    int opt_nan_sweep = 0;             // n=3: after a search, every candidate of the range through the reference's own procedure; the ones it
+                                       // reports with a NaN likelihood join the degenerate list (nan_sweep below; 2e8-5e8 candidates/s)
     int opt_sieve = 1;                 // n=3: sieve + finish kernels (n3_sieve.hip); 0 = the fused kernel of n3.hip only
     unsigned opt_surv_cap = 0;         // n=3: contenders a slice may list before it counts as overflowed (0: SURV_CAP; smaller
                                        // values make the tests walk the redo ladder: sieve again -> 8 parts -> fused kernel)
@@ -156,7 +160,7 @@ struct theta_problem {
     double last_redo_ms = 0.0;
     bool last_sieve64 = false;                         // ... and whether the sieve ran in FP64 (n3_force_f64)
     uint64_t last_launches = 0;                        // launches of the search kernel behind kernel_ms (sieve: one per slice)
-    DevBuf d_r, d_rN, d_small, d_P, d_PR, d_PN, d_cnt, d_ctr, d_list, d_tasks, d_stbuf, d_misc, d_smask, d_dynmask, d_sus, d_deg, d_surv, d_survcnt, d_survacc, d_line, d_scan;
+    DevBuf d_r, d_rN, d_small, d_P, d_PR, d_PN, d_cnt, d_ctr, d_list, d_tasks, d_stbuf, d_misc, d_smask, d_dynmask, d_sus, d_deg, d_surv, d_survcnt, d_survacc, d_line, d_scan, d_sweep;
 };
 
 static int upload(DevBuf &b, const void *src, size_t bytes, hipStream_t st) {
@@ -399,6 +403,7 @@ extern "C" int theta_problem_set_option(theta_problem *p, const char *name, doub
     else if (k == "n3_conv_l2" && value > 0.0) p->n3.conv_l2 = value;
     else if (k == "n3_warm_blend" && value >= 0.0 && value <= 1.0) p->n3.warm_blend = value;
     else if (k == "n3_sieve") p->opt_sieve = value != 0.0;
+    else if (k == "n3_nan_sweep") p->opt_nan_sweep = value != 0.0;
     else if (k == "n3_contender_cap" && value >= 0.0 && value <= (double)SURV_CAP) p->opt_surv_cap = (unsigned)value;
     else if (k == "n3_per_task" && (value == 0.0 || (value >= 64 && value <= 65535))) p->opt_per_task = (uint64_t)value;
     else if (k == "n2_per_thread" && (value == 0.0 || (value >= 1 && value <= 512))) p->opt_per_thread = (int)value;
@@ -477,6 +482,45 @@ static int list_deficient(theta_problem *p, u128 b, u128 e, uint64_t per_task, u
         n3_launch_collinear_scan((const unsigned char *)p->d_scan.p, count, p->m, rb, (SearchCounters *)p->d_ctr.p, (TieRecord *)p->d_deg.p,
                                  DEG_CAP, st);
         i = j;
+    }
+    HIP_TRY(hipMemcpyAsync(&hc.deg_count, (char *)p->d_ctr.p + offsetof(SearchCounters, deg_count), sizeof(unsigned), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(hipGetLastError());
+    return THETA_OK;
+}
+
+// n=3: the candidates of [b, e) the reference reports with a NaN likelihood.  For about one full-rank candidate in a million the
+// reference's hybrj stops, unconverged, at a nu inside [0,1]^3 whose components do not sum to one; _solve_n3plus takes it
+// (Optimizer.py:150-153), M3 makes a mu with a negative entry of it, L3 the logarithm of a negative number -- and the NaN tuple
+// joins `best` wherever it stands (Misc.py:44-46).  Which candidates those are hangs on the trajectory of MINPACK's iteration;
+// nothing short of running it tells (tools/nan_hunt.py: 89 of 1.4e8 candidates, none of them near its space's minimum).  So
+// this sweep runs the reference's procedure, restated (solve_batch_n3_kernel), over EVERY candidate of the range -- generator ->
+// solver -> scan, device resident, 2e8-5e8 candidates/s against the search's 3e10-9e10 -- and appends the ranks to the degenerate
+// list.  Option "n3_nan_sweep"; theta_amd.search switches it on for spaces of up to 2^33 matrices (more than the reference could
+// walk in a year) and reports when it did not.
+static int nan_sweep(theta_problem *p, u128 b, u128 e, SearchCounters &hc) {
+    theta_ctx *ctx = p->ctx;
+    hipStream_t st = ctx->stream;
+    const size_t cb = (size_t)p->m * 2;
+    const uint64_t chunk = (uint64_t)1 << 20;
+    if (p->d_scan.bytes < chunk * cb) {
+        p->d_scan.release();
+        int rc = p->d_scan.alloc(chunk * cb);
+        if (rc) return rc;
+    }
+    if (p->d_sweep.bytes < chunk * (1 + 3 * 8 + 8)) {
+        int rc = p->d_sweep.alloc(chunk * (1 + 3 * 8 + 8));
+        if (rc) return rc;
+    }
+    double *d_nll = (double *)p->d_sweep.p, *d_mu = d_nll + chunk;
+    unsigned char *d_ok = (unsigned char *)(d_mu + 3 * chunk);
+    for (u128 at = b; at < e; at += chunk) {
+        const uint64_t c = (uint64_t)std::min<u128>((u128)chunk, e - at);
+        int rc = enumerate_device(p, at, c, (unsigned char *)p->d_scan.p, nullptr);
+        if (rc) return rc;
+        batch_launch_solve(3, p->m, p->tau, (const double *)p->d_r.p, (const double *)p->d_rN.p, p->max_normal, (int)c,
+                           (const unsigned char *)p->d_scan.p, d_ok, d_mu, d_nll, nullptr, st);
+        n3_launch_nan_scan(d_ok, d_nll, c, at, (SearchCounters *)p->d_ctr.p, (TieRecord *)p->d_deg.p, DEG_CAP, st);
     }
     HIP_TRY(hipMemcpyAsync(&hc.deg_count, (char *)p->d_ctr.p + offsetof(SearchCounters, deg_count), sizeof(unsigned), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
@@ -772,6 +816,10 @@ static int run_search(theta_problem *p, u128 b, u128 e, double window, double *d
             int rc = list_deficient(p, b, e, sieve_per_task_last, hc.line_count, hc);
             if (rc) return rc;
         }
+    }
+    if (p->n == 3 && p->opt_nan_sweep && !dump_nll && e > b) {
+        int rc = nan_sweep(p, b, e, hc);
+        if (rc) return rc;
     }
     unsigned ndeg = std::min<unsigned>(hc.deg_count, DEG_CAP);
     p->degenerate.resize(ndeg);

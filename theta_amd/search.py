@@ -23,7 +23,12 @@ How the reference's per-candidate outcome is followed:
     theta_solve_batch, the reference's procedure restated).  A NaN likelihood counts as "close" to anything
     (Misc.py:44-46), so the reference appends such entries to `best` wherever they stand after the last replacement of the
     minimum; so does the replay here.
+  * about one FULL-RANK candidate in a million gets a NaN likelihood from the reference as well (its hybrj stops unconverged at a
+    nu in [0,1]^3 that does not sum to one; which candidates, only the iteration itself tells).  Spaces of up to NAN_SWEEP_MAX
+    matrices are therefore swept: every candidate through the restated procedure on the GPU, the NaN ones listed with the
+    rank-deficient ones (option "n3_nan_sweep", csrc/api.hip: nan_sweep).  Beyond that size `last_report.nan_sweep` is False.
 """
+import os
 import sys
 
 import numpy as np
@@ -31,6 +36,9 @@ import numpy as np
 from . import _lib
 
 TIE_MARGIN = 10e-4        # Misc.py:36
+# n=3 spaces of up to this many matrices are swept for the candidates the reference reports with a NaN likelihood (csrc/api.hip:
+# nan_sweep; 2e8 - 5e8 candidates/s, so 2^33 take about half a minute -- the reference itself walks 4e2 candidates/s per process)
+NAN_SWEEP_MAX = int(float(os.environ.get("THETA_NAN_SWEEP_MAX", 2 ** 33)))
 COLLECT_WINDOW = 0.5      # how far above the minimum the GPU reports candidates (>> TIE_MARGIN)
 
 pre = "theta"             # prefix of the --GET_VALUES dump (the reference keeps it in a module global, RunTHetA.py:307-308)
@@ -99,6 +107,10 @@ class SearchReport(object):
         self.degenerate = 0                # n=3: rank-deficient candidates (reported like the reference does)
         self.dropped_not_ok = 0            # finalists of the fused kernel the reference-order re-solve returned None for
         self.suspect_reruns = 0            # pieces of the range searched again because their suspect list overflowed
+        self.nan_sweep = None              # n=3: True = every candidate also went through the reference's own procedure and the ones it
+                                           # reports with a NaN likelihood joined the replay; False = the space was too large for that
+                                           # (NAN_SWEEP_MAX): `best` then lacks the NaN tuples the reference appends for about one full-rank
+                                           # matrix in a million (the finite entries and the chosen C are not affected)
         self.seconds = 0.0
 
 
@@ -298,6 +310,11 @@ def _search_local(n, m, tau, lower_bounds, upper_bounds, r, rN, max_normal, shar
         shared = hint_exchange(local)
         if shared < float("inf"):
             problem.hint(shared)
+    if n == 3:
+        sweep = problem.count <= NAN_SWEEP_MAX
+        problem.set_option("n3_nan_sweep", 1 if sweep else 0)
+        if report is not None:
+            report.nan_sweep = sweep
     recs, stats = collect_finalists(problem, ctx, r, rN, max_normal, begin, end, report=report)
     if n == 3:
         recs = recs + fallback_records(problem, ctx, r, rN, max_normal, recs, report=report)
