@@ -25,11 +25,12 @@ for shape in ("low", "mid", "toy"):
         seed += 1
         inst = campaign.instance(seed, 3, shape)
         cnt = campaign.count_candidates(inst)
-        if not (2000 <= cnt <= 4_000_000):
+        if not (2000 <= cnt <= int(os.environ.get("NAN_HUNT_MAX", 4_000_000))):
             continue
         got += 1
         p = theta_amd.Problem(ctx, 3, inst["m"], inst["tau"], inst["r"], inst["rN"], inst["lb"], inst["ub"], inst["mx"])
         assert p.count == cnt
+        inst_nan = 0
         for b in range(0, cnt, 1 << 19):
             c = min(1 << 19, cnt - b)
             C = p.enumerate(b, c)
@@ -44,9 +45,12 @@ for shape in ("low", "mid", "toy"):
             n_def += int(d.sum())
             nan_def += int((isnan & d).sum())
             nan_full += int((isnan & ~d).sum())
+            inst_nan += int((isnan & ~d).sum())
             low_full += int((below & ~d).sum())
             for k in np.nonzero((isnan | below) & ~d)[0][:3]:
                 print("FULL-RANK exception: shape %s seed %d rank %d nll %r dump %r mu %r C %s" % (shape, seed, b + k, nll[k], dump[k], mu[k].tolist(), C[k].tolist()))
         p.close()
+        if inst_nan:
+            print("instance shape %s seed %d: %d matrices, %d full-rank NaN outcomes" % (shape, seed, cnt, inst_nan))
 print("candidates %d, rank-deficient %d (NaN outcome %d); full-rank with NaN outcome %d, full-rank reported below their minimum %d"
       % (tot, n_def, nan_def, nan_full, low_full))
