@@ -46,16 +46,18 @@ def _gpu_best(inst):
 # ---------------------------------------------------------------------------------------------------
 # `best` against the reference's own lists (fixtures) -- complete lists, NaN entries included
 # ---------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("fixture", [f for f in ("best_campaign.json", "best_campaign2.json", "best_campaign3.json", "best_campaign4.json")
+@pytest.mark.parametrize("fixture", [f for f in ("best_campaign.json", "best_campaign2.json", "best_campaign3.json", "best_campaign4.json", "best_nan_cases.json")
                                      if os.path.exists(os.path.join(ROOT, "tests", "golden", f))])
 def test_best_identical_to_reference_lists_on_campaign_fixtures(ctx, fixture):
     """(best_campaign2.json: a second set of seeds on larger spaces -- up to 60 000 candidates for n=3, 200 000 for n=2 --
     written by the reference after the hybrj restatement was settled: tests/golden/make_golden_campaign.py second;
     best_campaign3.json: n=3 only, 80 instances of the low-coverage shape -- a few to a few hundred reads per interval, one tumour
     population in half of them -- and 30 mid ones: ... third; best_campaign4.json: two whole spaces of 4e5 / 4.7e5 matrices in which
-    tools/nan_hunt.py found FULL-RANK matrices the reference reports with a NaN likelihood -- the NaN sweep's case: ... fourth)"""
+    tools/nan_hunt.py found FULL-RANK matrices the reference reports with a NaN likelihood -- the NaN sweep's case: ... fourth;
+    best_nan_cases.json: 18 small spaces built around six such matrices, tests/golden/make_golden_nan_cases.py -- 11 NaN tuples
+    of full-rank matrices in the reference's lists, which only the sweep finds)"""
     cases = load_json(fixture)["cases"]
-    assert len(cases) >= (2 if fixture == "best_campaign4.json" else 40)
+    assert len(cases) >= {"best_campaign4.json": 2, "best_nan_cases.json": 15}.get(fixture, 40)
     bad, n_nan, n_cand = [], 0, 0
     for c in cases:
         ref = [(b["C"], [unfl(x) for x in b["mu"]], unfl(b["nll"])) for b in c["best"]]
@@ -66,7 +68,7 @@ def test_best_identical_to_reference_lists_on_campaign_fixtures(ctx, fixture):
         n_nan += sum(1 for b in ref if b[2] != b[2])
         n_cand += c["count"]
     assert not bad, bad
-    assert n_nan >= {"best_campaign.json": 5, "best_campaign2.json": 1}.get(fixture, 0)      # the fixtures do exercise the isClose(NaN) entries
+    assert n_nan >= {"best_campaign.json": 5, "best_campaign2.json": 1, "best_nan_cases.json": 8}.get(fixture, 0)      # the fixtures do exercise the isClose(NaN) entries
 
 
 def _oracle_side(inst):
