@@ -4,12 +4,15 @@ GPU parity tests added in round 3 (`-m gpu`, through the C ABI):
   * every rank-deficient n=3 candidate of six seeded spaces through theta_solve_batch against the oracle -- class, NLL, mu, no
     allowance (round 2's verdict, What's weak #1: the reference's `**2` is libm's pow, refpow.hpp);
 """
+import os
+import sys
 import warnings
 
 import numpy as np
 import pytest
 
 import theta_oracle as orc
+from conftest import ROOT
 
 pytestmark = pytest.mark.gpu
 
@@ -360,3 +363,14 @@ def test_nan_sweep_lists_every_candidate_the_reference_reports_with_a_nan_likeli
     import theta_amd.search as ts
     ts.do_optimization_single(3, inst["m"], inst["k"], inst["tau"], inst["lb"], inst["ub"], inst["r"], inst["rN"], inst["mx"], inst["order"])
     assert ts.last_report.nan_sweep is True and ts.last_report.degenerate >= full_rank_nan
+
+
+@pytest.mark.gpu
+def test_driver_against_the_replay_over_every_candidates_outcome(ctx):
+    """tools/exact_replay_check.py on a few whole spaces: `best` of the shipped driver (sieve + finish kernels, suspects, rank-deficient
+    list, NaN sweep, replay over the finalists) against the reference's sequential rule replayed over the outcome of EVERY candidate
+    (theta_solve_batch).  (600 spaces, 1.5e9 candidates: profiles/r3/exact_replay_check.txt.)"""
+    import subprocess
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "exact_replay_check.py"), "6", "2e6"], capture_output=True, text=True, timeout=800)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "lists that differ 0" in out.stdout and "instances 12" in out.stdout, out.stdout[-500:]

@@ -107,6 +107,7 @@ class SearchReport(object):
         self.degenerate = 0                # n=3: rank-deficient candidates (reported like the reference does)
         self.dropped_not_ok = 0            # finalists of the fused kernel the reference-order re-solve returned None for
         self.suspect_reruns = 0            # pieces of the range searched again because their suspect list overflowed
+        self.window = COLLECT_WINDOW       # how far above the minimum the device collected finalists (narrowed if the tie list overflowed)
         self.nan_sweep = None              # n=3: True = every candidate also went through the reference's own procedure and the ones it
                                            # reports with a NaN likelihood joined the replay; False = the space was too large for that
                                            # (NAN_SWEEP_MAX): `best` then lacks the NaN tuples the reference appends for about one full-rank
@@ -133,7 +134,18 @@ def collect_finalists(problem, ctx, r, rN, max_normal, begin, end, window=COLLEC
     GPU part: fused search over [begin, end) then the exact-order re-solve of the finalists.
     Returns (records, stats); a record is dict(rank, c (uint8), mu (n floats), nll, vals (m floats)).
     """
-    res = problem.search(begin, end, window=window)
+    # A flat likelihood (a few reads per interval) can put more candidates within the window of the minimum than the device tie
+    # list holds: the window only has to cover the reference's tie margin (1e-3, twice: its reference point is the FIRST
+    # minimum of the final cluster) -- so go again with a narrower one before giving up.
+    for attempt, wnd in enumerate((window, window / 10.0, window / 50.0)):
+        try:
+            res = problem.search(begin, end, window=wnd)
+            break
+        except _lib.ThetaError as e:
+            if e.code != _lib.ERR_CAPACITY or "finalists dropped" not in str(e) or attempt == 2 or wnd / 10.0 < 4 * TIE_MARGIN:
+                raise
+    if report is not None:
+        report.window = wnd
     k = len(res["rank"])
     recs = []
     dropped = 0
@@ -219,7 +231,7 @@ def replay_ties(recs, n, tau, sorted_index, first_duplicate, report=None, q1_fir
                 cut = a
                 found_gap = True
                 break
-        if not found_gap and vals_sorted[-1] - vals_sorted[0] > COLLECT_WINDOW - 2 * TIE_MARGIN and report is not None:
+        if not found_gap and vals_sorted[-1] - vals_sorted[0] > getattr(report, "window", COLLECT_WINDOW) - 2 * TIE_MARGIN and report is not None:
             report.tie_ambiguous = True
         recs = [t for t in recs if not (t["nll"] > cut)]
     seq = []

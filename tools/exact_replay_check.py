@@ -1,0 +1,90 @@
+"""The search against the per-candidate procedure at a scale the CPU oracle cannot reach, run ON THE GPU BOX.
+For whole seeded spaces of 1e5 .. 4e6 matrices: EVERY candidate through theta_solve_batch (the reference's own per-candidate
+procedure, restated and checked entry by entry against the reference's tables) and the reference's sequential rule replayed over
+all of those outcomes -- against `best` of the shipped driver (sieve + finish kernels, suspects / fallback records, rank-deficient
+list, NaN sweep, replay over the finalists only).  Complete lists, entry by entry.
+
+    python tools/exact_replay_check.py [instances per shape] [max candidates]
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import campaign
+import theta_amd
+import theta_amd.search as S
+
+
+def exact_best(ctx, inst, window):
+    """`best` from the outcomes of ALL candidates (no search kernels involved)."""
+    n, m, tau = 3, inst["m"], inst["tau"]
+    p = theta_amd.Problem(ctx, n, m, tau, inst["r"], inst["rN"], inst["lb"], inst["ub"], inst["mx"])
+    keep_rank, keep_C = [], []
+    lowest = np.inf
+    chunks = []
+    for b in range(0, p.count, 1 << 19):
+        C = p.enumerate(b, min(1 << 19, p.count - b))
+        ok, _mu, nll, _ = ctx.solve_batch(n, tau, inst["r"], inst["rN"], C, inst["mx"], want_vals=False)
+        rep = ok != 0
+        fin = rep & ~np.isnan(nll)
+        if fin.any():
+            lowest = min(lowest, float(nll[fin].min()))
+        chunks.append((b, C, rep, nll))
+    for b, C, rep, nll in chunks:
+        with np.errstate(invalid="ignore"):
+            sel = rep & (np.isnan(nll) | (nll <= lowest + window))
+        idx = np.nonzero(sel)[0]
+        keep_rank += (b + idx).tolist()
+        keep_C.append(C[idx])
+    count = p.count
+    p.close()
+    recs = []
+    if keep_rank:
+        Cs = np.concatenate(keep_C)
+        ok, mu, nll, vals = ctx.solve_batch(n, tau, inst["r"], inst["rN"], Cs, inst["mx"], want_vals=True)
+        recs = [{"rank": keep_rank[i], "c": Cs[i], "mu": mu[i].copy(), "nll": float(nll[i]), "vals": vals[i].copy()}
+                for i in range(len(keep_rank)) if ok[i]]
+    q1 = S._q1_record(ctx, n, m, tau, inst["r"], inst["rN"], inst["mx"])
+    return S.replay_ties(recs, n, tau, inst["order"], first_duplicate=False, q1_first=q1), count
+
+
+def main():
+    want = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+    cap = int(float(sys.argv[2])) if len(sys.argv) > 2 else 4_000_000
+    ctx = theta_amd.Context(0)
+    tot = inst_n = bad = nan_entries = narrowed = 0
+    for shape in ("mid", "low"):
+        seed, got = 30000, 0
+        while got < want:
+            seed += 1
+            inst = campaign.instance(seed, 3, shape)
+            cnt = campaign.count_candidates(inst)
+            if not (100_000 <= cnt <= cap):
+                continue
+            got += 1
+            try:
+                gpu = S.do_optimization_single(3, inst["m"], inst["k"], inst["tau"], list(inst["lb"]), list(inst["ub"]), inst["r"], inst["rN"],
+                                               inst["mx"], inst["order"])
+            except SystemExit:
+                gpu = []
+            ref, count = exact_best(ctx, inst, S.last_report.window)      # (the window the driver ended up with: narrowed on flat likelihoods)
+            why = campaign.compare_best(campaign.best_to_plain(gpu), campaign.best_to_plain(ref))
+            tot += count
+            inst_n += 1
+            nan_entries += sum(1 for b in ref if b[2] != b[2])
+            narrowed += S.last_report.window < S.COLLECT_WINDOW
+            if why:
+                bad += 1
+                print("DIFFERS: shape %s seed %d (%d matrices): %s" % (shape, seed, count, why))
+    print("instances %d, candidates %d, NaN entries in the exact lists %d, searches that narrowed their window %d, lists that differ %d"
+          % (inst_n, tot, nan_entries, narrowed, bad))
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
