@@ -20,9 +20,9 @@ import theta_amd
 import theta_amd.search as S
 
 
-def exact_best(ctx, inst, window):
+def exact_best(ctx, inst, window, n=3):
     """`best` from the outcomes of ALL candidates (no search kernels involved)."""
-    n, m, tau = 3, inst["m"], inst["tau"]
+    m, tau = inst["m"], inst["tau"]
     p = theta_amd.Problem(ctx, n, m, tau, inst["r"], inst["rN"], inst["lb"], inst["ub"], inst["mx"])
     keep_rank, keep_C = [], []
     lowest = np.inf
@@ -49,8 +49,8 @@ def exact_best(ctx, inst, window):
         ok, mu, nll, vals = ctx.solve_batch(n, tau, inst["r"], inst["rN"], Cs, inst["mx"], want_vals=True)
         recs = [{"rank": keep_rank[i], "c": Cs[i], "mu": mu[i].copy(), "nll": float(nll[i]), "vals": vals[i].copy()}
                 for i in range(len(keep_rank)) if ok[i]]
-    q1 = S._q1_record(ctx, n, m, tau, inst["r"], inst["rN"], inst["mx"])
-    return S.replay_ties(recs, n, tau, inst["order"], first_duplicate=False, q1_first=q1), count
+    q1 = S._q1_record(ctx, n, m, tau, inst["r"], inst["rN"], inst["mx"]) if n == 3 else None
+    return S.replay_ties(recs, n, tau, inst["order"], first_duplicate=(n == 2), q1_first=q1), count
 
 
 def main():
@@ -58,21 +58,30 @@ def main():
     cap = int(float(sys.argv[2])) if len(sys.argv) > 2 else 4_000_000
     ctx = theta_amd.Context(0)
     tot = inst_n = bad = nan_entries = narrowed = 0
-    for shape in ("mid", "low"):
+    for n, shape in ((3, "mid"), (3, "low"), (2, "synth")):
         seed, got = 30000, 0
         while got < want:
             seed += 1
-            inst = campaign.instance(seed, 3, shape)
+            if n == 2 and seed > 30000 + 40 * want:
+                break                                   # (few n=2 instances are this large)
+            if shape == "synth":                        # n=2: the campaign shapes are tiny; the bench's generator with full bounds
+                import bench
+                rng = np.random.RandomState(seed)
+                m, k = int(rng.randint(18, 45)), int(rng.randint(3, 7))
+                r, rN, order = bench.synth(seed=seed, m=m, n=2, k=k)
+                inst = dict(seed=seed, n=2, m=m, k=k, tau=2, mx=float(rng.choice([1.0, 1.0, 0.6])), r=r, rN=rN, order=order, lb=[0] * m, ub=[k] * m, shape=shape)
+            else:
+                inst = campaign.instance(seed, n, shape)
             cnt = campaign.count_candidates(inst)
-            if not (100_000 <= cnt <= cap):
+            if not ((100_000 if n == 3 else 20_000) <= cnt <= cap):
                 continue
             got += 1
             try:
-                gpu = S.do_optimization_single(3, inst["m"], inst["k"], inst["tau"], list(inst["lb"]), list(inst["ub"]), inst["r"], inst["rN"],
+                gpu = S.do_optimization_single(n, inst["m"], inst["k"], inst["tau"], list(inst["lb"]), list(inst["ub"]), inst["r"], inst["rN"],
                                                inst["mx"], inst["order"])
             except SystemExit:
                 gpu = []
-            ref, count = exact_best(ctx, inst, S.last_report.window)      # (the window the driver ended up with: narrowed on flat likelihoods)
+            ref, count = exact_best(ctx, inst, S.last_report.window, n)      # (the window the driver ended up with: narrowed on flat likelihoods)
             why = campaign.compare_best(campaign.best_to_plain(gpu), campaign.best_to_plain(ref))
             tot += count
             inst_n += 1
@@ -80,7 +89,7 @@ def main():
             narrowed += S.last_report.window < S.COLLECT_WINDOW
             if why:
                 bad += 1
-                print("DIFFERS: shape %s seed %d (%d matrices): %s" % (shape, seed, count, why))
+                print("DIFFERS: n=%d shape %s seed %d (%d matrices): %s" % (n, shape, seed, count, why))
     print("instances %d, candidates %d, NaN entries in the exact lists %d, searches that narrowed their window %d, lists that differ %d"
           % (inst_n, tot, nan_entries, narrowed, bad))
     return 1 if bad else 0
