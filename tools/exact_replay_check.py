@@ -5,6 +5,7 @@ all of those outcomes -- against `best` of the shipped driver (sieve + finish ke
 list, NaN sweep, replay over the finalists only).  Complete lists, entry by entry.
 
     python tools/exact_replay_check.py [instances per shape] [max candidates]
+    python tools/exact_replay_check.py bench [ranges] [candidates per range]     # rank ranges of the bench's own m=50, K=6 space
 """
 import os
 import sys
@@ -53,7 +54,63 @@ def exact_best(ctx, inst, window, n=3):
     return S.replay_ties(recs, n, tau, inst["order"], first_duplicate=(n == 2), q1_first=q1), count
 
 
+def exact_range(ctx, p, inst, begin, end, window):
+    """replay over the outcomes of the candidates of the rank range [begin, end) (no quirk-Q1 matrix: a sub-range)"""
+    n, tau = 3, inst["tau"]
+    lowest, chunks = np.inf, []
+    for b in range(begin, end, 1 << 20):
+        C = p.enumerate(b, min(1 << 20, end - b))
+        ok, _mu, nll, _ = ctx.solve_batch(n, tau, inst["r"], inst["rN"], C, inst["mx"], want_vals=False)
+        rep = ok != 0
+        fin = rep & ~np.isnan(nll)
+        if fin.any():
+            lowest = min(lowest, float(nll[fin].min()))
+        with np.errstate(invalid="ignore"):
+            near = rep & (np.isnan(nll) | (nll <= lowest + 2 * window))      # (lowest only falls: a superset of the final selection)
+        idx = np.nonzero(near)[0]
+        chunks.append(([b + int(i) for i in idx], C[idx], nll[idx]))          # (ranks beyond 64 bits: python ints)
+    recs = []
+    for ranks, Cs, nl in chunks:
+        with np.errstate(invalid="ignore"):
+            sel = np.isnan(nl) | (nl <= lowest + window)
+        if sel.any():
+            Cs, ranks = Cs[sel], [rk for rk, t in zip(ranks, sel) if t]
+            ok, mu, nll, vals = ctx.solve_batch(n, tau, inst["r"], inst["rN"], Cs, inst["mx"], want_vals=True)
+            recs += [{"rank": int(ranks[i]), "c": Cs[i], "mu": mu[i].copy(), "nll": float(nll[i]), "vals": vals[i].copy()}
+                     for i in range(len(ranks)) if ok[i]]
+    return S.replay_ties(recs, n, tau, inst["order"], first_duplicate=False, q1_first=None)
+
+
+def bench_ranges(ctx, nranges, size):
+    """the bench's own instance (m = 50, K = 6, full bounds: the sieve at its full depth): rank ranges of `size` candidates spread
+    over the space, the driver's per-shard pipeline (theta_amd.search._search_local) against the replay over every outcome"""
+    import bench
+    r, rN, order = bench.synth()
+    m, k = bench.M, bench.K_MAX
+    inst = dict(m=m, k=k, tau=bench.TAU, mx=1.0, r=r, rN=rN, order=order, lb=[0] * m, ub=[k] * m)
+    S.NAN_SWEEP_MAX = 1 << 200                        # (the ranges are swept although the space is not)
+    bad = 0
+    for j in range(nranges):
+        probe = theta_amd.Problem(ctx, 3, m, bench.TAU, r, rN, inst["lb"], inst["ub"], 1.0)
+        count = probe.count
+        G = count // size
+        g = (G * (2 * j + 1)) // (2 * nranges)
+        begin, end = count * g // G, count * (g + 1) // G
+        rep = S.SearchReport()
+        problem, _ctx, recs, _stats = S._search_local(3, m, bench.TAU, inst["lb"], inst["ub"], r, rN, 1.0, shard=(g, G), ctx=ctx, report=rep)
+        problem.close()
+        got = S.replay_ties(recs, 3, bench.TAU, order, first_duplicate=False, q1_first=None)
+        ref = exact_range(ctx, probe, inst, begin, end, rep.window)
+        probe.close()
+        why = campaign.compare_best(campaign.best_to_plain(got), campaign.best_to_plain(ref))
+        print("bench range %d: ranks [%d, +%d): %d entries%s" % (j, begin, end - begin, len(ref), (" DIFFERS: " + why) if why else ""))
+        bad += bool(why)
+    return bad
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "bench":
+        return 1 if bench_ranges(theta_amd.Context(0), int(sys.argv[2]) if len(sys.argv) > 2 else 6, int(float(sys.argv[3])) if len(sys.argv) > 3 else 1 << 24) else 0
     want = int(sys.argv[1]) if len(sys.argv) > 1 else 8
     cap = int(float(sys.argv[2])) if len(sys.argv) > 2 else 4_000_000
     ctx = theta_amd.Context(0)
