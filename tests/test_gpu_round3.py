@@ -377,3 +377,6 @@ def test_driver_against_the_replay_over_every_candidates_outcome(ctx):
     # ... and rank ranges of the bench's own space (m = 50, K = 6: the sieve at its full depth) through the driver's per-shard pipeline
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "exact_replay_check.py"), "bench", "4", "4e6"], capture_output=True, text=True, timeout=800)
     assert out.returncode == 0 and out.stdout.count("entries") == 4 and "DIFFERS" not in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+    # ... and spaces of more than 64 intervals
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "exact_replay_check.py"), "wide", "6", "2e6"], capture_output=True, text=True, timeout=800)
+    assert out.returncode == 0 and "wide instances 6," in out.stdout and "lists that differ 0" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]

@@ -108,7 +108,35 @@ def bench_ranges(ctx, nranges, size):
     return bad
 
 
+def wide_spaces(ctx, want, cap):
+    """n=3 with more than 64 intervals (two rows per lane in the sieve, the wide generator): tests/test_gpu_wide.py's instances with
+    more free rows, whole spaces of 1e4 .. cap matrices"""
+    import test_gpu_wide as tw
+    bad = done = tot = 0
+    seed = 600
+    while done < want and seed < 600 + 60 * want:
+        seed += 1
+        m = (72, 100, 128, 90)[seed % 4]
+        r, rN, order, _truth, lb, ub = tw._wide_instance(m, seed, 2 + seed % 3, kmax=3)
+        inst = dict(n=3, m=m, k=int(max(ub)), tau=2, mx=1.0, r=r, rN=rN, order=order, lb=[int(v) for v in lb], ub=[int(v) for v in ub])
+        cnt = campaign.count_candidates(inst)
+        if not (10_000 <= cnt <= cap):
+            continue
+        done += 1
+        gpu = S.do_optimization_single(3, m, inst["k"], 2, inst["lb"], inst["ub"], r, rN, 1.0, order)
+        ref, count = exact_best(ctx, inst, S.last_report.window)
+        why = campaign.compare_best(campaign.best_to_plain(gpu), campaign.best_to_plain(ref))
+        tot += count
+        if why:
+            bad += 1
+            print("DIFFERS: wide m=%d seed %d (%d matrices): %s" % (m, seed, count, why))
+    print("wide instances %d, candidates %d, lists that differ %d" % (done, tot, bad))
+    return bad
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "wide":
+        return 1 if wide_spaces(theta_amd.Context(0), int(sys.argv[2]) if len(sys.argv) > 2 else 8, int(float(sys.argv[3])) if len(sys.argv) > 3 else 4_000_000) else 0
     if len(sys.argv) > 1 and sys.argv[1] == "bench":
         return 1 if bench_ranges(theta_amd.Context(0), int(sys.argv[2]) if len(sys.argv) > 2 else 6, int(float(sys.argv[3])) if len(sys.argv) > 3 else 1 << 24) else 0
     want = int(sys.argv[1]) if len(sys.argv) > 1 else 8
