@@ -143,7 +143,10 @@ def main():
     cap = int(float(sys.argv[2])) if len(sys.argv) > 2 else 4_000_000
     ctx = theta_amd.Context(0)
     tot = inst_n = bad = nan_entries = narrowed = lost = 0
-    for n, shape in ((3, "mid"), (3, "low"), (2, "synth")):
+    shapes = ((3, "mid"), (3, "low"), (2, "synth"))
+    if len(sys.argv) > 3 and sys.argv[3] == "toy":         # (small spaces, m = 4..7: the fused kernel's path)
+        shapes = ((3, "toy"),)
+    for n, shape in shapes:
         seed, got = 30000, 0
         while got < want:
             seed += 1
@@ -158,7 +161,7 @@ def main():
             else:
                 inst = campaign.instance(seed, n, shape)
             cnt = campaign.count_candidates(inst)
-            if not ((100_000 if n == 3 else 20_000) <= cnt <= cap):
+            if not ((200 if shape == "toy" else 100_000 if n == 3 else 20_000) <= cnt <= cap):
                 continue
             got += 1
             try:
