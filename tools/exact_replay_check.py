@@ -145,13 +145,13 @@ def main():
     tot = inst_n = bad = nan_entries = narrowed = lost = 0
     shapes = ((3, "mid"), (3, "low"), (2, "synth"))
     if len(sys.argv) > 3 and sys.argv[3] == "toy":         # (small spaces, m = 4..7: the fused kernel's path)
-        shapes = ((3, "toy"),)
+        shapes = ((3, "toy"), (2, "toy"), (2, "mid"))
     for n, shape in shapes:
         seed, got = 30000, 0
         while got < want:
             seed += 1
-            if n == 2 and seed > 30000 + 40 * want:
-                break                                   # (few n=2 instances are this large)
+            if seed > 30000 + 60 * want:
+                break                                   # (few instances of this shape are this large)
             if shape == "synth":                        # n=2: the campaign shapes are tiny; the bench's generator with full bounds
                 import bench
                 rng = np.random.RandomState(seed)
@@ -161,7 +161,7 @@ def main():
             else:
                 inst = campaign.instance(seed, n, shape)
             cnt = campaign.count_candidates(inst)
-            if not ((200 if shape == "toy" else 100_000 if n == 3 else 20_000) <= cnt <= cap):
+            if not ((200 if shape == "toy" or (n == 2 and shape == "mid") else 100_000 if n == 3 else 20_000) <= cnt <= cap):
                 continue
             got += 1
             try:
