@@ -380,3 +380,14 @@ def test_driver_against_the_replay_over_every_candidates_outcome(ctx):
     # ... and spaces of more than 64 intervals
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "exact_replay_check.py"), "wide", "6", "2e6"], capture_output=True, text=True, timeout=800)
     assert out.returncode == 0 and "wide instances 6," in out.stdout and "lists that differ 0" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
+@pytest.mark.gpu
+def test_solve_batch_against_scipy_candidate_by_candidate(ctx):
+    """tools/solve_differential.py on 20 000 candidates: theta_solve_batch (hybrj, the BFGS decision, M3's hybrd, L3 restated) against
+    the oracle's calls into scipy -- the routines the reference itself calls -- candidate by candidate: reported or None, NaN or not,
+    NLL to 1e-9, mu to 1e-6.  (8.0 million candidates, zero exceptions: profiles/r3/solve_differential.txt.)"""
+    import subprocess
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "solve_differential.py"), "2e4", "300"], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "unfinished 0; outcome class differs 0, NaN on one side 0, NLL beyond 1e-9 0, mu beyond 1e-6 0" in out.stdout, out.stdout[-600:]
