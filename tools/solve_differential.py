@@ -27,6 +27,11 @@ def oracle_chunk(job):
     import theta_oracle as orc
     m, tau = inst["m"], inst["tau"]
     out = []
+    if inst["n"] == 2:
+        for c in C:
+            s = orc.solve_n2(orc.col_to_matrix_n2([int(v) for v in c], tau), inst["r"], inst["rN"], inst["mx"])
+            out.append(None if s is None else ([float(s[0][0]), float(s[0][1])], float(s[1])))
+        return out
     for c in C:
         M = np.zeros((m, 3))
         M[:, 0] = tau
@@ -42,6 +47,7 @@ def oracle_chunk(job):
 def main():
     want = int(float(sys.argv[1])) if len(sys.argv) > 1 else 3_000_000
     seconds = float(sys.argv[2]) if len(sys.argv) > 2 else 420.0
+    n = 2 if (len(sys.argv) > 3 and sys.argv[3] == "n2") else 3          # (n2: theta_solve_batch's brenth restatement against scipy's brenth)
     import theta_amd
     from conftest import rank_deficient
     ctx = theta_amd.Context(0)
@@ -51,18 +57,24 @@ def main():
     CH = 256
     while total < want:
         seed += 1
-        shape = ("low", "mid", "toy")[seed % 3]
-        inst = campaign.instance(seed, 3, shape)
+        shape = ("low", "mid", "toy")[seed % 3] if n == 3 else ("mid", "toy", "synth")[seed % 3]
+        if shape == "synth":
+            import bench
+            mm, kk = int(rng.randint(18, 45)), int(rng.randint(3, 7))
+            r_, rN_, order_ = bench.synth(seed=seed, m=mm, n=2, k=kk)
+            inst = dict(seed=seed, n=2, m=mm, k=kk, tau=2, mx=float(rng.choice([1.0, 0.6])), r=r_, rN=rN_, order=order_, lb=[0] * mm, ub=[kk] * mm)
+        else:
+            inst = campaign.instance(seed, n, shape)
         cnt = campaign.count_candidates(inst)
         if cnt < 300:
             continue
-        p = theta_amd.Problem(ctx, 3, inst["m"], inst["tau"], inst["r"], inst["rN"], inst["lb"], inst["ub"], inst["mx"])
+        p = theta_amd.Problem(ctx, n, inst["m"], inst["tau"], inst["r"], inst["rN"], inst["lb"], inst["ub"], inst["mx"])
         nch = int(min(24, max(1, cnt // CH)))
         for _ in range(nch):
             b = int(rng.randint(0, max(1, cnt - CH)))
             c = int(min(CH, cnt - b))
             C = p.enumerate(b, c)
-            ok, mu, nll, _ = ctx.solve_batch(3, inst["tau"], inst["r"], inst["rN"], C, inst["mx"], want_vals=False)
+            ok, mu, nll, _ = ctx.solve_batch(n, inst["tau"], inst["r"], inst["rN"], C, inst["mx"], want_vals=False)
             jobs.append((inst, C))
             gpu.append((ok.copy(), mu.copy(), nll.copy()))
             total += c
@@ -78,7 +90,7 @@ def main():
         except mp.TimeoutError:
             unfinished += len(C)
             continue
-        d = rank_deficient(C)
+        d = rank_deficient(C) if n == 3 else np.zeros(len(C), bool)
         for k, s in enumerate(ref):
             checked += 1
             n_def += int(d[k])
