@@ -135,14 +135,15 @@ def collect_finalists(problem, ctx, r, rN, max_normal, begin, end, window=COLLEC
     Returns (records, stats); a record is dict(rank, c (uint8), mu (n floats), nll, vals (m floats)).
     """
     # A flat likelihood (a few reads per interval) can put more candidates within the window of the minimum than the device tie
-    # list holds: the window only has to cover the reference's tie margin (1e-3, twice: its reference point is the FIRST
+    # list (or the list of rejected candidates near it) holds: the window only has to cover the reference's tie margin (1e-3, twice: its reference point is the FIRST
     # minimum of the final cluster) -- so go again with a narrower one before giving up.
     for attempt, wnd in enumerate((window, window / 10.0, window / 50.0)):
         try:
             res = problem.search(begin, end, window=wnd)
             break
         except _lib.ThetaError as e:
-            if e.code != _lib.ERR_CAPACITY or "finalists dropped" not in str(e) or attempt == 2 or wnd / 10.0 < 4 * TIE_MARGIN:
+            listed_too_many = "finalists dropped" in str(e) or "suspect list overflowed" in str(e)      # (either device list: both shrink with the window)
+            if e.code != _lib.ERR_CAPACITY or not listed_too_many or attempt == 2 or wnd / 10.0 < 4 * TIE_MARGIN:
                 raise
     if report is not None:
         report.window = wnd
