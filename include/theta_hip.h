@@ -167,7 +167,8 @@ int theta_search_degenerate(theta_problem *p, int cap, uint64_t *rank, uint8_t *
  *                    list's real capacity, 2^24); small values let tests walk the redo ladder
  *   "n3_nan_sweep"   1: after the search every candidate of the range also goes through the reference's own per-candidate procedure
  *                    (as theta_solve_batch runs it, device resident, 2e8-5e8 candidates/s), and the ones the reference reports with a
- *                    NaN likelihood -- about one full-rank matrix in a million, decided by where MINPACK's iteration stops -- join
+ *                    NaN likelihood -- about one full-rank matrix in a million, decided by where MINPACK's iteration stops --, and the ones
+ *                    it reports at or below the search's minimum + window, join
  *                    the list of theta_search_degenerate.  0 (default).  theta_amd.search sets it for spaces up to 2^33 matrices
  *   "n3_per_task"    candidates per wave task (0 = automatic), "n2_per_thread" candidates per thread (0 = automatic)
  * The THETA_N3_* environment variables of the same names only set the defaults at theta_problem_create.

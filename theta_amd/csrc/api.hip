@@ -31,8 +31,8 @@ void n3_launch_enumerate_burst(const N3Dev &P, const N3Task *tasks, const unsign
                                unsigned char *out, hipStream_t st);
 void n3_launch_enumerate(const N3Dev &P, const N3Task *tasks, const unsigned *stbuf, int ntasks, uint64_t per_task,
                          unsigned char *out, hipStream_t st);
-void n3_launch_nan_scan(const unsigned char *ok, const double *nll, unsigned long long count, u128 base, SearchCounters *ctr, TieRecord *deg,
-                        unsigned deg_cap, hipStream_t st);
+void n3_launch_nan_scan(const unsigned char *ok, const double *nll, unsigned long long count, u128 base, double near, SearchCounters *ctr,
+                        TieRecord *deg, unsigned deg_cap, hipStream_t st);
 void n3_launch_collinear_scan(const unsigned char *C, unsigned long long count, int m, u128 base, SearchCounters *ctr, TieRecord *deg,
                               unsigned deg_cap, hipStream_t st);
 
@@ -498,7 +498,7 @@ static int list_deficient(theta_problem *p, u128 b, u128 e, uint64_t per_task, u
 // solver -> scan, device resident, 2e8-5e8 candidates/s against the search's 3e10-9e10 -- and appends the ranks to the degenerate
 // list.  Option "n3_nan_sweep"; theta_amd.search switches it on for spaces of up to 2^33 matrices (more than the reference could
 // walk in a year) and reports when it did not.
-static int nan_sweep(theta_problem *p, u128 b, u128 e, SearchCounters &hc) {
+static int nan_sweep(theta_problem *p, u128 b, u128 e, double near, SearchCounters &hc) {
     theta_ctx *ctx = p->ctx;
     hipStream_t st = ctx->stream;
     const size_t cb = (size_t)p->m * 2;
@@ -520,7 +520,7 @@ static int nan_sweep(theta_problem *p, u128 b, u128 e, SearchCounters &hc) {
         if (rc) return rc;
         batch_launch_solve(3, p->m, p->tau, (const double *)p->d_r.p, (const double *)p->d_rN.p, p->max_normal, (int)c,
                            (const unsigned char *)p->d_scan.p, d_ok, d_mu, d_nll, nullptr, st);
-        n3_launch_nan_scan(d_ok, d_nll, c, at, (SearchCounters *)p->d_ctr.p, (TieRecord *)p->d_deg.p, DEG_CAP, st);
+        n3_launch_nan_scan(d_ok, d_nll, c, at, near, (SearchCounters *)p->d_ctr.p, (TieRecord *)p->d_deg.p, DEG_CAP, st);
     }
     HIP_TRY(hipMemcpyAsync(&hc.deg_count, (char *)p->d_ctr.p + offsetof(SearchCounters, deg_count), sizeof(unsigned), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
@@ -818,7 +818,10 @@ static int run_search(theta_problem *p, u128 b, u128 e, double window, double *d
         }
     }
     if (p->n == 3 && p->opt_nan_sweep && !dump_nll && e > b) {
-        int rc = nan_sweep(p, b, e, hc);
+        // (listed as well: whatever the procedure reports at or below the search's minimum + window -- the sweep then settles the
+        // range's result by itself; without a finite minimum only the NaN outcomes are listed)
+        const double best = order_unbits(hc.best_bits);
+        int rc = nan_sweep(p, b, e, best < INFINITY ? best + window : -INFINITY, hc);
         if (rc) return rc;
     }
     unsigned ndeg = std::min<unsigned>(hc.deg_count, DEG_CAP);

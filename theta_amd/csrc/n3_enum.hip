@@ -404,19 +404,21 @@ void n3_launch_collinear_scan(const unsigned char *C, unsigned long long count, 
 // ------------------------------------------------------------------------------------------------
 // The sweep for NaN outcomes (api.hip: nan_sweep): after the reference's own per-candidate procedure (solve_batch_n3_kernel) has
 // run over a materialised rank range, append the rank of every candidate the reference REPORTS (ok != 0) with a NaN likelihood
-// to the degenerate list -- such a tuple joins `best` wherever it stands (Misc.py:44-46).
+// to the degenerate list -- such a tuple joins `best` wherever it stands (Misc.py:44-46) -- and of every candidate it reports at or
+// below `near` (the search's minimum + the collection window): whatever the search kernels made of those, the swept range's
+// result is then the replay over the procedure's own outcomes by construction.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void n3_nan_scan_kernel(const unsigned char *ok, const double *nll, unsigned long long count, uint64_t base_lo,
-                                                          uint64_t base_hi, SearchCounters *ctr, TieRecord *deg, unsigned deg_cap) {
+                                                          uint64_t base_hi, double near, SearchCounters *ctr, TieRecord *deg, unsigned deg_cap) {
     const unsigned long long k = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
     if (k >= count) return;
     const double v = nll[k];
-    if (ok[k] && v != v) degenerate_append(ctr, deg, deg_cap, (((u128)base_hi << 64) | base_lo) + k);
+    if (ok[k] && (v != v || v <= near)) degenerate_append(ctr, deg, deg_cap, (((u128)base_hi << 64) | base_lo) + k);
 }
 
-void n3_launch_nan_scan(const unsigned char *ok, const double *nll, unsigned long long count, u128 base, SearchCounters *ctr, TieRecord *deg,
-                        unsigned deg_cap, hipStream_t st) {
+void n3_launch_nan_scan(const unsigned char *ok, const double *nll, unsigned long long count, u128 base, double near, SearchCounters *ctr,
+                        TieRecord *deg, unsigned deg_cap, hipStream_t st) {
     if (count == 0) return;
     hipLaunchKernelGGL(n3_nan_scan_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, ok, nll, count, (uint64_t)base,
-                       (uint64_t)(base >> 64), ctr, deg, deg_cap);
+                       (uint64_t)(base >> 64), near, ctr, deg, deg_cap);
 }

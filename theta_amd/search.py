@@ -25,8 +25,10 @@ How the reference's per-candidate outcome is followed:
     minimum; so does the replay here.
   * about one FULL-RANK candidate in a million gets a NaN likelihood from the reference as well (its hybrj stops unconverged at a
     nu in [0,1]^3 that does not sum to one; which candidates, only the iteration itself tells).  Spaces of up to NAN_SWEEP_MAX
-    matrices are therefore swept: every candidate through the restated procedure on the GPU, the NaN ones listed with the
-    rank-deficient ones (option "n3_nan_sweep", csrc/api.hip: nan_sweep).  Beyond that size `last_report.nan_sweep` is False.
+    matrices are therefore swept: every candidate through the restated procedure on the GPU, the NaN ones -- and whatever it
+    reports within the window of the search's minimum -- listed with the rank-deficient ones (option "n3_nan_sweep",
+    csrc/api.hip: nan_sweep): the listed outcome is THE outcome, so a swept space's `best` is the replay over the procedure's own
+    outcomes by construction.  Beyond that size `last_report.nan_sweep` is False.
 """
 import os
 import sys
