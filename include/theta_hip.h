@@ -50,6 +50,9 @@ typedef struct theta_problem theta_problem; /* one search instance resident in H
 
 /* ---- context ------------------------------------------------------------------------------ */
 int theta_create(int device_id, theta_ctx **out);
+/* number of GPUs this process can see (0 and THETA_ERR_HIP when there is none): what `do_optimization(..., max_processes)`
+ * (RunTHetA.py:124-171) shards a search over -- one worker process per GPU instead of the reference's forked CPU workers */
+int theta_device_count(int *n_out);
 void theta_destroy(theta_ctx *ctx);
 const char *theta_last_error(void);
 /* name[cap] receives the device name; cu = compute units; hbm_bytes = total device memory.    */

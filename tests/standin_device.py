@@ -203,3 +203,11 @@ class StandinProblem(_lib.Problem):
     def enumerate(self, begin, count):
         shape = (count, self.m) if self.n == 2 else (count, self.m, 2)
         return np.array(self.cands[begin:begin + count], np.uint8).reshape(shape)
+
+
+def worker_context(rank):
+    """`search.WORKER_INIT = "standin_device:worker_context"`: what a rank of do_optimization(..., max_processes) runs on in the
+    CPU tests -- this process's Problem class becomes the stand-in, the context is the stand-in's."""
+    warnings.simplefilter("ignore")
+    _lib.Problem = StandinProblem
+    return StandinContext()

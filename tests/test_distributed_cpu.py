@@ -307,3 +307,71 @@ def test_a_rank_that_never_connects_is_reported_not_waited_for(monkeypatch):
     with pytest.raises(theta_amd.ThetaError) as e:
         theta_amd.Comm(None, rank=1, world=2, addr="127.0.0.1", port=_free_port(), transport="host")
     assert "cannot reach rank 0" in str(e.value) and time.time() - t < 30
+
+
+# ---------------------------------------------------------------------------------------------------
+# the reference's OWN parallel entry: do_optimization(..., max_processes) (RunTHetA.py:124-171) starts one worker process per
+# further GPU itself (theta_amd/shard_worker.py) -- here over the stand-in device and the host transport
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n,seed,procs", [(3, 10044, 4), (2, 9512, 3), (3, 10010, 2)])
+def test_do_optimization_with_max_processes_spawns_the_shards_itself(monkeypatch, n, seed, procs):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import warnings
+    import campaign
+    import standin_device as sd
+    import theta_oracle as orc
+    from theta_amd import _lib, search as S
+    inst = campaign.instance(seed, n, "toy")
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ref, cnt = orc.search_single(n, inst["m"], inst["tau"], list(inst["lb"]), list(inst["ub"]), inst["r"], inst["rN"], inst["mx"],
+                                     inst["order"])
+    ref = campaign.best_to_plain(ref)
+    monkeypatch.setattr(_lib, "Problem", sd.StandinProblem)
+    monkeypatch.setattr(S, "WORKER_INIT", "standin_device:worker_context")
+    monkeypatch.setenv("THETA_NGPU", str(procs))            # (no GPU to count here: the number of ranks is given)
+    best = S.do_optimization(inst["n"], inst["m"], inst["k"], inst["tau"], list(inst["lb"]), list(inst["ub"]), inst["r"], inst["rN"],
+                             inst["mx"], inst["order"], procs)
+    assert campaign.compare_best(campaign.best_to_plain(best), ref) == ""
+    assert S.last_report.gpus == procs and S.last_report.transport == "host"
+    # ... and equals the single-process driver's list, entry by entry
+    single = S.do_optimization_single(inst["n"], inst["m"], inst["k"], inst["tau"], list(inst["lb"]), list(inst["ub"]), inst["r"],
+                                      inst["rN"], inst["mx"], inst["order"], _ctx=sd.StandinContext())
+    assert campaign.compare_best(campaign.best_to_plain(best), campaign.best_to_plain(single)) == ""
+
+
+def test_do_optimization_caps_the_gpus_by_the_size_of_the_space(monkeypatch):
+    from theta_amd import _lib, search as S
+    monkeypatch.delenv("THETA_NGPU", raising=False)
+    monkeypatch.setattr(_lib, "device_count", lambda: 8)
+    assert S.gpus_for(8) == 8 and S.gpus_for(3) == 3 and S.gpus_for(1) == 1 and S.gpus_for(64) == 8
+    assert S.gpus_for(8, count=10 ** 6) == 1                       # a small space is not worth a second process
+    assert S.gpus_for(8, count=3 * S.MIN_CANDIDATES_PER_GPU) == 3
+    assert S.gpus_for(8, count=1 << 100) == 8
+    monkeypatch.setenv("THETA_NGPU", "2")
+    assert S.gpus_for(8, count=10) == 2
+
+
+def test_a_failing_worker_is_reported_by_do_optimization(monkeypatch):
+    """A worker that cannot start (its init hook raises) must end the call with an error, not leave rank 0 in the rendezvous."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import campaign
+    import standin_device as sd
+    from theta_amd import _lib, search as S
+    inst = campaign.instance(10044, 3, "toy")
+    monkeypatch.setattr(_lib, "Problem", sd.StandinProblem)
+    monkeypatch.setattr(S, "WORKER_INIT", "standin_device:worker_context")
+    monkeypatch.setenv("THETA_NGPU", "2")
+    monkeypatch.setenv("THETA_COMM_TIMEOUT_S", "5")
+    real = S._spawn_shards
+
+    def broken(world, args, transport, ndev):
+        monkeypatch.setattr(S, "WORKER_INIT", "standin_device:no_such_function")
+        try:
+            return real(world, args, transport, ndev)
+        finally:
+            monkeypatch.setattr(S, "WORKER_INIT", "standin_device:worker_context")
+    monkeypatch.setattr(S, "_spawn_shards", broken)
+    with pytest.raises(_lib.ThetaError):
+        S.do_optimization(inst["n"], inst["m"], inst["k"], inst["tau"], list(inst["lb"]), list(inst["ub"]), inst["r"], inst["rN"],
+                          inst["mx"], inst["order"], 2)

@@ -142,3 +142,49 @@ def test_bench_with_two_ranks_on_one_gpu():
     assert single["n_gpus"] == 1
     # whole-job rate of two ranks time-sharing ONE GPU: about the single-rank rate (not twice, the GPU is the same); within 2x
     assert 0.5 * single["value"] <= line["value"] <= 2.0 * single["value"], (line["value"], single["value"])
+
+
+def test_do_optimization_with_max_processes_shards_over_worker_processes(ctx, monkeypatch):
+    """The reference's parallel entry (RunTHetA.py:124-171): do_optimization(..., max_processes) starts its own worker
+    process per further GPU.  On this one-GPU box THETA_NGPU=2 / 3 makes the ranks share the device (host transport); every
+    list equals do_optimization_single's, n=2 and n=3."""
+    from theta_amd import search as S
+    done = 0
+    for n, seeds, world in ((2, range(9500, 9600), 2), (3, range(9600, 9800), 3)):
+        for seed in seeds:
+            inst = campaign.instance(seed, n, "mid" if seed % 2 else "toy")
+            cnt = campaign.count_candidates(inst)
+            if not (300 <= cnt <= 100000):
+                continue
+            single = _gpu_best(inst)
+            monkeypatch.setenv("THETA_NGPU", str(world))
+            best = S.do_optimization(inst["n"], inst["m"], inst["k"], inst["tau"], list(inst["lb"]), list(inst["ub"]), inst["r"],
+                                     inst["rN"], inst["mx"], inst["order"], 8)
+            monkeypatch.delenv("THETA_NGPU")
+            assert S.last_report.gpus == world and S.last_report.transport == "host"
+            assert len(S.last_report.shard_kernel_ms) == world
+            assert campaign.compare_best(campaign.best_to_plain(best), single) == "", (n, seed)
+            done += 1
+            break
+    assert done == 2
+    # without the override: one GPU here, so max_processes = 8 runs on it alone (and a small space would anyway)
+    assert S.gpus_for(8) == 1
+    best = S.do_optimization(inst["n"], inst["m"], inst["k"], inst["tau"], list(inst["lb"]), list(inst["ub"]), inst["r"],
+                             inst["rN"], inst["mx"], inst["order"], 8)
+    assert campaign.compare_best(campaign.best_to_plain(best), single) == "" and S.last_report.gpus == 1
+
+
+def test_cli_num_processes_reaches_the_sharded_driver(tmp_path, monkeypatch):
+    """`RunTHetA <file> -n 2 --NUM_PROCESSES 2` (the reference's flag) under THETA_NGPU=2: same result file as one process."""
+    import subprocess
+    src = os.path.join(ROOT, "tests", "golden", "cli", "Example.intervals")
+    outs = []
+    for tag, extra, env in (("one", [], {}), ("two", ["--NUM_PROCESSES", "2"], {"THETA_NGPU": "2"})):
+        d = tmp_path / tag
+        d.mkdir()
+        p = subprocess.run([sys.executable, "-m", "theta_amd.RunTHetA", src, "-n", "2", "-k", "3", "-d", str(d), "-p", "ex"] + extra,
+                           cwd=ROOT, env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stdout[-600:] + p.stderr[-600:]
+        outs.append((p.stdout, open(d / "ex.n2.results").read()))
+    assert outs[0][1] == outs[1][1]
+    assert "on 2 GPU ranks" in outs[1][0]

@@ -100,8 +100,8 @@ def run_fixed_N(n, args, intervals, resultsfile=None):
         print("ERROR: Maximum Likelihood Solution not found within given bounds.")
         sys.exit(1)
     rep = _search.last_report
-    print("\tSearched %d candidate matrices in %.2f s on the GPU (%d finalists)%s" % (
-        rep.candidates, rep.seconds, rep.finalists,
+    print("\tSearched %d candidate matrices in %.2f s on %s (%d finalists)%s" % (
+        rep.candidates, rep.seconds, "the GPU" if getattr(rep, "gpus", 1) == 1 else "%d GPU ranks" % rep.gpus, rep.finalists,
         "" if rep.certificate_complete else "; suspect list overflowed: rerun with a tighter rank range (see DESIGN.md section 5)"))
 
     if n == 2 and best_near_max_contamination(best, max_normal):

@@ -47,7 +47,7 @@ class SearchStats(C.Structure):
 _lib = None
 
 # every symbol include/theta_hip.h declares
-EXPORTS = ["theta_create", "theta_destroy", "theta_last_error", "theta_device_info", "theta_problem_create",
+EXPORTS = ["theta_create", "theta_device_count", "theta_destroy", "theta_last_error", "theta_device_info", "theta_problem_create",
            "theta_problem_destroy", "theta_problem_count", "theta_search", "theta_search_values", "theta_enumerate", "theta_enumerate_device",
            "theta_solve_batch", "theta_score_batch", "theta_score_masked", "theta_search_suspects", "theta_boundary_min", "theta_problem_hint",
            "theta_search_degenerate", "theta_problem_set_option", "theta_synchronize",
@@ -70,6 +70,7 @@ def load():
     i64p, i32p = C.POINTER(C.c_int64), C.POINTER(C.c_int32)
     lib.theta_last_error.restype = C.c_char_p
     lib.theta_create.argtypes = [i32, C.POINTER(vp)]
+    lib.theta_device_count.argtypes = [C.POINTER(i32)]
     lib.theta_destroy.argtypes = [vp]
     lib.theta_destroy.restype = None
     lib.theta_device_info.argtypes = [vp, C.c_char_p, i32, C.POINTER(i32), u64p]
@@ -124,6 +125,13 @@ def _p(arr, ctype):
 def _u128(v):
     v = int(v)
     return (C.c_uint64 * 2)(v & 0xFFFFFFFFFFFFFFFF, v >> 64)
+
+
+def device_count():
+    """GPUs visible to this process (theta_device_count); 0 when there is none."""
+    n = C.c_int()
+    load().theta_device_count(C.byref(n))
+    return n.value
 
 
 class Context:

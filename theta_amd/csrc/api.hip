@@ -92,6 +92,22 @@ extern "C" int theta_create(int device_id, theta_ctx **out) {
     return THETA_OK;
 }
 
+extern "C" int theta_device_count(int *n_out) {
+    if (!n_out) {
+        theta_set_error("theta_device_count: null output pointer");
+        return THETA_ERR_ARG;
+    }
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    *n_out = e == hipSuccess ? ndev : 0;
+    if (e != hipSuccess || ndev == 0) {
+        (void)hipGetLastError();
+        theta_set_error("no HIP device available (%s)", e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+        return THETA_ERR_HIP;
+    }
+    return THETA_OK;
+}
+
 extern "C" void theta_destroy(theta_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);

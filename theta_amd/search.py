@@ -115,6 +115,7 @@ class SearchReport(object):
                                            # (NAN_SWEEP_MAX): `best` then lacks the NaN tuples the reference appends for about one full-rank
                                            # matrix in a million (the finite entries and the chosen C are not affected)
         self.seconds = 0.0
+        self.gpus = 1                      # ranks the search was sharded over (do_optimization with max_processes > 1)
 
 
 last_report = SearchReport()
@@ -302,7 +303,16 @@ def _dump_values(problem, n, m, q1=None):
                     f.write(line * 2 if (n == 2 and b + i == 0) else line)
 
 
-def _search_local(n, m, tau, lower_bounds, upper_bounds, r, rN, max_normal, shard=(0, 1), ctx=None, report=None, hint_exchange=None):
+def _make_problem(ctx, n, m, tau, lower_bounds, upper_bounds, r, rN, max_normal):
+    problem = _lib.Problem(ctx, n, m, tau, [int(x) for x in r], [int(x) for x in rN], [int(v) for v in lower_bounds],
+                           [int(v) for v in upper_bounds], max_normal)
+    if problem.count == 0:
+        raise _lib.NoCandidates(_lib.ERR_NO_CANDIDATES, "no valid copy number profiles within the bounds")
+    return problem
+
+
+def _search_local(n, m, tau, lower_bounds, upper_bounds, r, rN, max_normal, shard=(0, 1), ctx=None, report=None, hint_exchange=None,
+                  problem=None):
     """
     Everything one GPU does for its shard: the fused search, the finalists in reference arithmetic, and -- n=3 -- the
     records the reference reports away from a candidate's own optimum (nu = 1/3 fallbacks, all-zero columns).
@@ -313,10 +323,8 @@ def _search_local(n, m, tau, lower_bounds, upper_bounds, r, rN, max_normal, shar
     ctx = ctx or _lib.default_context()
     r = [int(x) for x in r]
     rN = [int(x) for x in rN]
-    problem = _lib.Problem(ctx, n, m, tau, r, rN, [int(v) for v in lower_bounds], [int(v) for v in upper_bounds],
-                           max_normal)
-    if problem.count == 0:
-        raise _lib.NoCandidates(_lib.ERR_NO_CANDIDATES, "no valid copy number profiles within the bounds")
+    if problem is None:               # (do_optimization builds it first: the size of the space decides how many GPUs pay)
+        problem = _make_problem(ctx, n, m, tau, lower_bounds, upper_bounds, r, rN, max_normal)
     g, G = shard
     begin = problem.count * g // G
     end = problem.count * (g + 1) // G
@@ -365,7 +373,7 @@ def _certificate(rep, problem, ctx, tau, r, rN, best):
 
 
 def do_optimization_single(n, m, k, tau, lower_bounds, upper_bounds, r, rN, max_normal, sorted_index, multi_event=False,
-                           get_values=False):
+                           get_values=False, _problem=None, _ctx=None):
     """
     RunTHetA.py:173-220 -- same arguments, same return value: list of
     (C in the ORIGINAL interval order as float64 (m, n) with column 0 == tau, mu, NLL, vals).
@@ -375,7 +383,8 @@ def do_optimization_single(n, m, k, tau, lower_bounds, upper_bounds, r, rN, max_
     global last_report
     rep = SearchReport()
     try:
-        problem, ctx, recs, stats = _search_local(n, m, tau, lower_bounds, upper_bounds, r, rN, max_normal, report=rep)
+        problem, ctx, recs, stats = _search_local(n, m, tau, lower_bounds, upper_bounds, r, rN, max_normal, report=rep, ctx=_ctx,
+                                                  problem=_problem)
     except _lib.NoCandidates:
         print("Error: No valid Copy Number Profiles exist for these intervals within the bounds specified. Exiting...")
         sys.exit(1)
@@ -397,21 +406,152 @@ def do_optimization_single(n, m, k, tau, lower_bounds, upper_bounds, r, rN, max_
     return best
 
 
+# below this many candidates per GPU a further GPU costs more (a process, a context, the counting tables) than it saves: a
+# second of start-up against 3e10 - 9e10 candidates a second
+MIN_CANDIDATES_PER_GPU = int(float(os.environ.get("THETA_MIN_CANDIDATES_PER_GPU", 2 ** 33)))
+
+
+def gpus_for(max_processes, count=None):
+    """
+    How many GPUs a do_optimization(..., max_processes) call shards over: the reference's process count (--NUM_PROCESSES,
+    RunTHetA.py:124-141) capped by the GPUs this process sees and by what the space is worth (MIN_CANDIDATES_PER_GPU).
+    THETA_NGPU overrides everything (several ranks then share a GPU if there are fewer: tests on a one-GPU box).
+    """
+    env = os.environ.get("THETA_NGPU")
+    if env:
+        return max(1, int(env))
+    g = max(1, min(int(max_processes), _lib.device_count()))
+    if count is not None:
+        g = max(1, min(g, int(count // MIN_CANDIDATES_PER_GPU)))
+    return g
+
+
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+WORKER_INIT = None        # tests only: "module:function" returning a worker's context (a stand-in device), see shard_worker.py
+
+
+def _spawn_shards(world, args, transport, ndev):
+    """Starts ranks 1 .. world-1 as fresh interpreters (python -m theta_amd.shard_worker), one per GPU; returns
+    (port, [(Popen, status path)], temp dir)."""
+    import pickle
+    import subprocess
+    import tempfile
+    tmp = tempfile.mkdtemp(prefix="theta_shards_")
+    port = _free_port()
+    procs = []
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    env["PYTHONPATH"] = root + os.pathsep + env.get("PYTHONPATH", "")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # (dmabuf IPC: what RCCL needs between processes on these hosts)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "THETA_NGPU"):
+        env.pop(k, None)                                   # the workers' ranks come from the payload, not from a launcher
+    for rank in range(1, world):
+        job = {"rank": rank, "world": world, "port": port, "transport": transport, "device": rank % max(1, ndev), "args": args,
+               "init": WORKER_INIT, "sys_path": [p for p in sys.path if p]}
+        pay, st = os.path.join(tmp, "job%d.pickle" % rank), os.path.join(tmp, "status%d.pickle" % rank)
+        with open(pay, "wb") as f:
+            pickle.dump(job, f)
+        procs.append((subprocess.Popen([sys.executable, "-m", "theta_amd.shard_worker", pay, st], env=env, cwd=tmp), st))
+    return port, procs, tmp
+
+
+def _join_shards(procs, tmp, timeout=600.0):
+    """Waits for the workers and returns their status records (a worker that vanished without one is reported as such)."""
+    import pickle
+    import shutil
+    import subprocess
+    out = []
+    for p, st in procs:
+        try:
+            p.wait(timeout)
+        except subprocess.TimeoutExpired:
+            p.kill()
+        if os.path.exists(st):
+            with open(st, "rb") as f:
+                out.append(pickle.load(f))
+        else:
+            out.append({"state": "error", "code": -1, "message": "worker exited with %r and left no status" % (p.returncode,)})
+    shutil.rmtree(tmp, ignore_errors=True)
+    return out
+
+
 def do_optimization(n, m, k, tau, lower_bounds, upper_bounds, r, rN, max_normal, sorted_index, max_processes=1,
                     multi_event=False, get_values=False):
     """
-    RunTHetA.py:124-171.  The reference fans candidates out to max_processes-1 workers through a
-    multiprocessing.Queue; here one GPU evaluates them all, so max_processes only keeps the
-    signature.  (Several GPUs: do_optimization_distributed.)
+    RunTHetA.py:124-171 -- same arguments, same return value.  The reference feeds max_processes - 1 forked workers from a
+    queue and merges their lists with find_mins; here `max_processes` is the number of GPUs of this node the candidate ranks
+    are sharded over (capped by the GPUs present and by the size of the space, gpus_for): this process is rank 0 on GPU 0 and
+    starts one worker process per further GPU (theta_amd.shard_worker), every rank searches its contiguous rank range
+    (do_optimization_distributed), and the library's own collectives -- an all-reduce(min) of the probe minima before, ONE
+    theta_exchange_finalists after, RCCL over xGMI -- replace the queue and find_mins.  The result is the list
+    do_optimization_single returns (the reference's multi-process run lists tied solutions in worker order; the
+    single-process order is the one reproduced).
     """
-    return do_optimization_single(n, m, k, tau, lower_bounds, upper_bounds, r, rN, max_normal, sorted_index,
-                                  multi_event, get_values)
+    import time
+    t0 = time.time()
+    global last_report
+    ctx = _lib.default_context() if WORKER_INIT is None else None
+    if WORKER_INIT is not None:
+        mod, fn = WORKER_INIT.split(":")
+        ctx = getattr(__import__(mod), fn)(0)
+    try:
+        problem = _make_problem(ctx, n, m, tau, lower_bounds, upper_bounds, r, rN, max_normal)
+    except _lib.NoCandidates:
+        print("Error: No valid Copy Number Profiles exist for these intervals within the bounds specified. Exiting...")
+        sys.exit(1)
+    except _lib.ThetaError as e:
+        if e.code in (_lib.ERR_OVERFLOW, _lib.ERR_ARG):
+            _friendly_exit(e)
+        raise
+    world = gpus_for(max_processes, problem.count)
+    if world <= 1:
+        return do_optimization_single(n, m, k, tau, lower_bounds, upper_bounds, r, rN, max_normal, sorted_index, multi_event,
+                                      get_values, _problem=problem, _ctx=ctx)
+    ndev = _lib.device_count() if WORKER_INIT is None else 0
+    transport = os.environ.get("THETA_COMM_TRANSPORT") or ("rccl" if 0 < world <= ndev else "host")     # RCCL refuses two ranks on one device
+    args = (n, m, k, tau, [int(v) for v in lower_bounds], [int(v) for v in upper_bounds], [int(x) for x in r], [int(x) for x in rN],
+            max_normal, list(sorted_index))
+    port, procs, tmp = _spawn_shards(world, args, transport, ndev)
+    failure = None
+    best = None
+    try:
+        comm = _lib.Comm(ctx if hasattr(ctx, "_h") else None, rank=0, world=world, addr="127.0.0.1", port=port, transport=transport)
+        try:
+            best = do_optimization_distributed(*args, comm=comm, ctx=ctx, problem=problem)
+        finally:
+            comm.close()
+    except BaseException as e:          # (SystemExit included: the workers are waited for whatever happened here)
+        failure = e
+    statuses = _join_shards(procs, tmp, timeout=60.0 if failure is not None else 600.0)
+    if failure is not None:
+        raise failure
+    bad = [s for s in statuses if s["state"] != "ok"]
+    if bad:
+        raise _lib.ThetaError(bad[0].get("code", -1) if isinstance(bad[0].get("code"), int) else -1,
+                              "shard worker failed: %s" % bad[0].get("message"))
+    rep = last_report
+    rep.gpus = world
+    rep.transport = transport
+    rep.shard_kernel_ms = [float(rep.stats.get("kernel_ms", 0.0))] + [s.get("kernel_ms", 0.0) for s in statuses]
+    if get_values:
+        q1 = _q1_record(ctx, n, m, tau, r, rN, max_normal) if n == 3 else None
+        _dump_values(problem, n, m, q1)
+    rep.seconds = time.time() - t0
+    return best
 
 
 # --------------------------------------------------------------------------------------------------
 # several GPUs: one process per GPU, candidate ranks sharded, ONE small exchange at the end
 # --------------------------------------------------------------------------------------------------
-def do_optimization_distributed(n, m, k, tau, lower_bounds, upper_bounds, r, rN, max_normal, sorted_index, comm, ctx=None):
+def do_optimization_distributed(n, m, k, tau, lower_bounds, upper_bounds, r, rN, max_normal, sorted_index, comm, ctx=None, problem=None):
     """
     One process per GPU; `comm` is a theta_amd.Comm (the library's communicator: RCCL over xGMI, or its host transport in
     CPU-side tests).  Rank g searches the candidate ranks [N*g/G, N*(g+1)/G); the only communication is an all-reduce(min)
@@ -436,7 +576,7 @@ def do_optimization_distributed(n, m, k, tau, lower_bounds, upper_bounds, r, rN,
     problem = recs = stats = None
     try:
         problem, ctx, recs, stats = _search_local(n, m, tau, lower_bounds, upper_bounds, r, rN, max_normal, shard=(g, G), ctx=ctx,
-                                                  report=rep, hint_exchange=share if G > 1 else None)
+                                                  report=rep, hint_exchange=share if G > 1 else None, problem=problem)
     except _lib.NoCandidates:
         print("Error: No valid Copy Number Profiles exist for these intervals within the bounds specified. Exiting...")
         sys.exit(1)                                           # (a property of the problem: the same on every rank)
@@ -454,7 +594,12 @@ def do_optimization_distributed(n, m, k, tau, lower_bounds, upper_bounds, r, rN,
             raise _lib.ThetaError(worst, "another rank's shard failed with this status; all ranks leave together")
     elif failure is not None:
         raise failure
-    merged, gmin = comm.exchange_finalists(n, m, recs, COLLECT_WINDOW)
+    # ONE window for the merged list: a shard whose device lists overflowed collected within a narrower window of its minimum
+    # (collect_finalists), so the merged list is only dense up to the narrowest one -- agree on it, exchange within it, and
+    # let the ambiguity check of the replay see it on every rank (round-3 advice)
+    if G > 1:
+        rep.window = float(comm.allreduce_min([rep.window])[0])
+    merged, gmin = comm.exchange_finalists(n, m, recs, rep.window)
     q1 = _q1_record(ctx, n, m, tau, r, rN, max_normal) if n == 3 else None
     best = replay_ties(merged, n, tau, sorted_index, first_duplicate=(n == 2), report=rep, q1_first=q1)
     rep.stats = stats
