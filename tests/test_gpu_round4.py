@@ -1,0 +1,69 @@
+"""
+Round 4 on the GPU box (run with `-m gpu`): the n=2 search's dismissal by a lower bound (n2.hip: n2_quick) against the same
+kernel solving every candidate, ...
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import campaign
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import theta_amd
+    return theta_amd.default_context()
+
+
+def _n2_cases():
+    import bench
+    cases = []
+    for seed, m, k, tau, mx, span in ((11, 25, 5, 2, 1.0, None), (11, 50, 6, 2, 1.0, None), (11, 100, 5, 2, 1.0, 1 << 26), (3, 40, 4, 2, 0.5, None),
+                                      (4, 30, 5, 3, 1.0, None), (5, 200, 7, 2, 1.0, 1 << 26), (6, 36, 9, 2, 1.0, 1 << 25)):
+        r, rN, _ = bench.synth(seed=seed, m=m, n=2, k=min(k, 6))
+        cases.append(("synth m%d k%d tau%d mx%g" % (m, k, tau, mx), m, tau, r, rN, [0] * m, [k] * m, mx, span))
+    # a few reads per interval (flat likelihood: many near-ties), ragged bounds, an interval without tumour reads
+    rng = np.random.RandomState(77)
+    m = 28
+    rN = [int(v) for v in rng.randint(20, 200, m)]
+    r = [int(v) for v in rng.poisson(np.array(rN) * rng.choice([0.6, 1.0, 1.5], m))]
+    r[3] = 0
+    o = np.argsort(np.array(r) / np.array(rN), kind="stable")
+    r, rN = [r[i] for i in o], [rN[i] for i in o]
+    lb = [0] * 10 + [1] * 10 + [2] * 8
+    ub = [2] * 6 + [3] * 12 + [5] * 10
+    cases.append(("low coverage ragged", m, 2, r, rN, lb, ub, 1.0, None))
+    return cases
+
+
+def test_n2_dismissal_by_the_lower_bound_changes_no_finalist(ctx):
+    """
+    The n=2 search dismisses a candidate whose rigorous lower bound (one evaluation at the thread's chain point,
+    self-concordance) lies beyond the window of the running minimum -- Optimizer._solve_n2's bracket test, root and exact NLL
+    (Optimizer.py:90-126) are only run for what remains.  Same finalists (rank, C, NLL, mu) as the kernel that solves every
+    candidate (option n2_no_dismiss), on whole spaces and rank ranges: full and ragged bounds, max_normal 0.5, tau 3, 200
+    intervals, copy numbers up to 9 (the 16-value instantiation), a few reads per interval, an interval without tumour reads.
+    """
+    import theta_amd
+    for name, m, tau, r, rN, lb, ub, mx, span in _n2_cases():
+        p = theta_amd.Problem(ctx, 2, m, tau, r, rN, lb, ub, mx)
+        b = 0 if span is None else p.count // 3
+        e = p.count if span is None else min(p.count, b + span)
+        for window in (0.5, 0.0):
+            p.set_option("n2_no_dismiss", 1)
+            a = p.search(b, e, window=window)
+            p.set_option("n2_no_dismiss", 0)
+            q = p.search(b, e, window=window)
+            assert a["stats"]["dismissed"] == 0 and a["stats"]["evaluated"] == q["stats"]["evaluated"] == e - b
+            assert a["rank"] == q["rank"], (name, window, len(a["rank"]), len(q["rank"]))
+            assert np.array_equal(a["C"], q["C"])
+            assert np.allclose(a["nll"], q["nll"], rtol=1e-13, atol=0) and np.allclose(a["mu"], q["mu"], rtol=0, atol=1e-11)   # (the same code path values them; the Newton start differs)
+            assert q["stats"]["dismissed"] <= q["stats"]["evaluated"]
+            if e - b > 1 << 20 and "low" not in name:
+                assert q["stats"]["dismissed"] > 0.9 * (e - b), (name, q["stats"]["dismissed"], e - b)
+        p.close()

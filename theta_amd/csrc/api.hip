@@ -14,7 +14,7 @@
 
 // ---- implemented in n2.hip / n3.hip / batch.hip ------------------------------------------------
 void n2_launch_search(const N2Dev &P, const SearchArgs &A, unsigned long long begin, unsigned long long end,
-                      int per_thread, hipStream_t st);
+                      int per_thread, hipStream_t st, unsigned long long sample_stride = 0);
 void n2_launch_enumerate(const N2Dev &P, unsigned long long begin, unsigned long long count, unsigned char *out,
                          hipStream_t st);
 void n2_launch_unrank_list(const N2Dev &P, const TieRecord *recs, int count, unsigned char *out, hipStream_t st);
@@ -176,7 +176,7 @@ struct theta_problem {
     double last_redo_ms = 0.0;
     bool last_sieve64 = false;                         // ... and whether the sieve ran in FP64 (n3_force_f64)
     uint64_t last_launches = 0;                        // launches of the search kernel behind kernel_ms (sieve: one per slice)
-    DevBuf d_r, d_rN, d_small, d_P, d_PR, d_PN, d_cnt, d_ctr, d_list, d_tasks, d_stbuf, d_misc, d_smask, d_dynmask, d_sus, d_deg, d_surv, d_survcnt, d_survacc, d_line, d_scan, d_sweep;
+    DevBuf d_r, d_rN, d_small, d_P, d_PR, d_PN, d_cnt, d_ctr, d_stat, d_list, d_tasks, d_stbuf, d_misc, d_smask, d_dynmask, d_sus, d_deg, d_surv, d_survcnt, d_survacc, d_line, d_scan, d_sweep;
 };
 
 static int upload(DevBuf &b, const void *src, size_t bytes, hipStream_t st) {
@@ -258,6 +258,7 @@ extern "C" int theta_problem_create(theta_ctx *ctx, int n, int m, int tau, const
     TRY(upload(p->d_r, rd.data(), m * sizeof(double), st));
     TRY(upload(p->d_rN, rnd.data(), m * sizeof(double), st));
     TRY(p->d_ctr.alloc(sizeof(SearchCounters)));
+    TRY(p->d_stat.alloc((size_t)THETA_STAT_SLOTS * THETA_STAT_STRIDE));
     TRY(p->d_list.alloc((size_t)LIST_CAP * sizeof(TieRecord)));
     TRY(p->d_sus.alloc((size_t)SUS_CAP * sizeof(TieRecord)));
     TRY(p->d_deg.alloc((size_t)DEG_CAP * sizeof(TieRecord)));
@@ -308,6 +309,9 @@ extern "C" int theta_problem_create(theta_ctx *ctx, int n, int m, int tau, const
         D.ub = D.lb + m;
         D.lbpos = (const short *)((const unsigned char *)p->d_small.p + off);
         D.total = h.total;
+        D.quick = 1;
+        if (const char *e = getenv("THETA_N2_NO_DISMISS")) D.quick = atoi(e) == 0;
+        if (const char *e = getenv("THETA_N2_QUICK_FLAGS")) D.quick = atoi(e);      // (experiments)
         D.first_zero_r = m;
         for (int i = m - 1; i >= 0; i--)
             if (r[i] == 0) D.first_zero_r = i;
@@ -422,6 +426,7 @@ extern "C" int theta_problem_set_option(theta_problem *p, const char *name, doub
     else if (k == "n3_nan_sweep") p->opt_nan_sweep = value != 0.0;
     else if (k == "n3_contender_cap" && value >= 0.0 && value <= (double)SURV_CAP) p->opt_surv_cap = (unsigned)value;
     else if (k == "n3_per_task" && (value == 0.0 || (value >= 64 && value <= 65535))) p->opt_per_task = (uint64_t)value;
+    else if (k == "n2_no_dismiss") p->n2.quick = value == 0.0;
     else if (k == "n2_per_thread" && (value == 0.0 || (value >= 1 && value <= 512))) p->opt_per_thread = (int)value;
     else {
         theta_set_error("unknown option or value out of range: %s = %g", name, value);
@@ -544,6 +549,26 @@ static int nan_sweep(theta_problem *p, u128 b, u128 e, double near, SearchCounte
     return THETA_OK;
 }
 
+// the per-wave statistics of the search kernels live in THETA_STAT_SLOTS copies of the counter block (SearchArgs::stat): add them up
+static void fold_stats(const unsigned char *slots, SearchCounters &c) {
+    for (int i = 0; i < THETA_STAT_SLOTS; i++) {
+        SearchCounters s;
+        memcpy(&s, slots + (size_t)i * THETA_STAT_STRIDE, sizeof(s));
+        c.evaluated += s.evaluated;
+        c.accepted += s.accepted;
+        c.degenerate += s.degenerate;
+        c.iterations += s.iterations;
+        c.terms += s.terms;
+        c.final_terms += s.final_terms;
+        c.dismissed += s.dismissed;
+        c.terms64 += s.terms64;
+        c.finish_iterations += s.finish_iterations;
+        c.sieve_pterms += s.sieve_pterms;
+        c.sieve_children += s.sieve_children;
+        for (int k = 0; k < 8; k++) c.prof[k] += s.prof[k];
+    }
+}
+
 static int run_search(theta_problem *p, u128 b, u128 e, double window, double *dump_nll, double *dump_mu,
                       SearchCounters &hc, std::vector<TieRecord> &recs, double &kernel_ms, double &setup_ms,
                       unsigned long long &dropped_out) {
@@ -551,6 +576,7 @@ static int run_search(theta_problem *p, u128 b, u128 e, double window, double *d
     hipStream_t st = ctx->stream;
     SearchArgs A;
     A.ctr = (SearchCounters *)p->d_ctr.p;
+    A.stat = (SearchCounters *)p->d_stat.p;
     A.list = (TieRecord *)p->d_list.p;
     A.list_cap = LIST_CAP;
     A.sus = (TieRecord *)p->d_sus.p;
@@ -575,10 +601,12 @@ static int run_search(theta_problem *p, u128 b, u128 e, double window, double *d
     p->last_launches = 0;
     const unsigned surv_cap = p->opt_surv_cap ? p->opt_surv_cap : SURV_CAP;      // (the list is allocated for SURV_CAP)
     uint64_t sieve_per_task_last = 0;                                            // candidates per task of the last pass, if the sieve ran it
+    std::vector<unsigned char> stat_host((size_t)THETA_STAT_SLOTS * THETA_STAT_STRIDE);
     for (int pass = 0; pass < 3; pass++) {
         std::vector<std::pair<int, int>> slices;     // n=3 fast path: (first task, tasks) of every sieve launch of this pass
         uint64_t sieve_per_task = 0;
         HIP_TRY(hipMemcpyAsync(p->d_ctr.p, &hc, sizeof(hc), hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemsetAsync(p->d_stat.p, 0, (size_t)THETA_STAT_SLOTS * THETA_STAT_STRIDE, st));
         HIP_TRY(hipEventRecord(ctx->ev0, st));
         if (p->n == 2) {
             unsigned long long nb = (unsigned long long)b, ne = (unsigned long long)e, cnt = ne - nb;
@@ -594,6 +622,11 @@ static int run_search(theta_problem *p, u128 b, u128 e, double window, double *d
             }
             if (p->opt_per_thread > 0) per = (unsigned long long)p->opt_per_thread;
             HIP_TRY(hipEventRecord(ctx->ev1, st));
+            // a search that starts without a minimum (no hint, first pass): a sample of 4096 candidates spread over the range
+            // gives it one first (n2.hip: sample launch), so that the threads of the search proper do not all begin "within the
+            // window" of +inf
+            if (hc.best_bits == order_bits(INFINITY) && !dump_nll && p->n2.quick && cnt >= 65536ull)
+                n2_launch_search(p->n2, A, nb, ne, (int)per, st, cnt / 4096ull);
             n2_launch_search(p->n2, A, nb, ne, (int)per, st);
         } else {
             u128 cnt = e - b;
@@ -681,12 +714,15 @@ static int run_search(theta_problem *p, u128 b, u128 e, double window, double *d
         SearchCounters got;
         unsigned hcnt[SIEVE_MAX_SLICES], hacc[SIEVE_MAX_SLICES];
         HIP_TRY(hipMemcpyAsync(&got, p->d_ctr.p, sizeof(got), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(stat_host.data(), p->d_stat.p, stat_host.size(), hipMemcpyDeviceToHost, st));
         if (!slices.empty()) {
             HIP_TRY(hipMemcpyAsync(hcnt, p->d_survcnt.p, slices.size() * sizeof(unsigned), hipMemcpyDeviceToHost, st));
             HIP_TRY(hipMemcpyAsync(hacc, p->d_survacc.p, slices.size() * sizeof(unsigned), hipMemcpyDeviceToHost, st));
         }
         HIP_TRY(hipStreamSynchronize(st));
         HIP_TRY(hipGetLastError());
+        fold_stats(stat_host.data(), got);
+        if (p->n == 2) got.terms64 = got.terms;
         float ms = 0;
         HIP_TRY(hipEventElapsedTime(&ms, ctx->ev1, ctx->ev2));
         kernel_ms += ms;
@@ -772,7 +808,9 @@ static int run_search(theta_problem *p, u128 b, u128 e, double window, double *d
             // fused kernel's, which saw the whole slice.
             SearchCounters after;
             HIP_TRY(hipMemcpyAsync(&after, p->d_ctr.p, sizeof(after), hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(stat_host.data(), p->d_stat.p, stat_host.size(), hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));
+            fold_stats(stat_host.data(), after);
             SearchCounters &R = p->last_redo;
             R.evaluated = after.evaluated - raw.evaluated;
             R.accepted = after.accepted - raw.accepted;
@@ -909,14 +947,19 @@ extern "C" int theta_search(theta_problem *p, const uint64_t rank_begin[2], cons
                 f64 = (uint64_t)(per * (double)k.terms + fin * (double)k.final_terms);
                 f32 = 0;
             } else if (p->last_sieve64) {
-                // n=3, the sieve in FP64 (n3_force_f64): every evaluation on doubles; the one single-precision operation per term is
-                // the logarithm of the screened value (v_log_f32).  FP64 reciprocals are v_rcp_f64 + one Newton-Raphson step (+ 4
-                // per reciprocal), the error bound of the logarithms one more FMA per term (+ 2).
+                // n=3, the sieve in FP64 (n3_force_f64): every evaluation on doubles.  Per term of a full evaluation (sv_step, round 4's
+                // form with rho = sqrt R): 2 sub, 2 fma (q), 2 fma (the Newton-Raphson step of the reciprocal), 2 fma (value and the
+                // error bound of its logarithms), 3 mul (rho / q, alpha, beta), 2 fma (gradient), 3 fma (Hessian) = 27; per term of a
+                // node's shared sums (sv_parent): 2 fma (q), 2 fma (reciprocal), 2 fma (L, LA), 3 mul, 3 fma (T), 6 fma (W) = 33.  The
+                // single-precision operations per term are the seed of the reciprocal and the logarithm of the screened value
+                // (v_rcp_f32, v_log_f32 of the same (float) q).  A child: its own term, the restriction to its slice, the 2x2 solve,
+                // decrement, value and bound (FLOPS_PER_SIEVE_CHILD) + the Newton-Raphson steps of its three reciprocals and the
+                // error-bound terms (+ 16), two logarithms and two reciprocal seeds in single precision.
                 const double full = (double)(k.terms - k.terms64);
                 f64 = (uint64_t)(per * ((double)k.terms64 + (double)k.finish_iterations * (double)p->m) +
-                                 (FLOPS_PER_TERM_ITER_N3_F32 + 5.0) * full + (FLOPS_PER_TERM_SIEVE_SHARED + 5.0) * (double)k.sieve_pterms +
-                                 (FLOPS_PER_SIEVE_CHILD + 18.0) * (double)k.sieve_children + fin * (double)k.final_terms);
-                f32 = (uint64_t)(full + (double)k.sieve_pterms + 2.0 * (double)k.sieve_children);
+                                 27.0 * full + 33.0 * (double)k.sieve_pterms +
+                                 (FLOPS_PER_SIEVE_CHILD + 16.0) * (double)k.sieve_children + fin * (double)k.final_terms);
+                f32 = (uint64_t)(2.0 * full + 2.0 * (double)k.sieve_pterms + 4.0 * (double)k.sieve_children);
             } else {   // n=3: FP64 iterations (dump, ill-conditioned candidates, the finish kernel: m terms each) + the packed-f32
                        // coarse pass and screen
                 f64 = (uint64_t)(per * ((double)k.terms64 + (double)k.finish_iterations * (double)p->m));

@@ -99,6 +99,10 @@ struct SearchCounters {
 // What a search kernel writes to (all device pointers).
 struct SearchArgs {
     SearchCounters *ctr;
+    SearchCounters *stat;              // THETA_STAT_SLOTS copies of the counter block, THETA_STAT_STRIDE bytes apart (each on cache lines of its
+                                       // own), for the per-wave STATISTICS (evaluated, iterations, terms, ...): the host adds them up.  Tens
+                                       // of thousands of waves adding to ONE line serialise in the memory-side atomic unit (~30 ns each --
+                                       // a third of the n=2 search's time before round 4).  null: the statistics go to `ctr` as well
     TieRecord *list;
     unsigned list_cap;
     TieRecord *sus;                    // rejected candidates near the minimum (n=3 certificate)
@@ -116,6 +120,10 @@ struct SearchArgs {
 // device side
 // ---------------------------------------------------------------------------------------------
 #define WAVE 64
+
+#define THETA_STAT_SLOTS 64
+#define THETA_STAT_STRIDE 256
+static_assert(sizeof(SearchCounters) <= THETA_STAT_STRIDE, "a statistics slot holds one SearchCounters");
 
 // Monotone map double -> uint64 (so unsigned atomicMin orders doubles, negatives included).
 __host__ __device__ inline unsigned long long order_bits(double x) {
@@ -179,6 +187,13 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+// the statistics slot of the calling wave (see SearchArgs::stat)
+__device__ __forceinline__ SearchCounters *stat_slot(const SearchArgs &A) {
+    if (!A.stat) return A.ctr;
+    const unsigned wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    return (SearchCounters *)((char *)A.stat + (size_t)(wave & (THETA_STAT_SLOTS - 1)) * THETA_STAT_STRIDE);
 }
 
 __device__ __forceinline__ unsigned long long load_agent_u64(const unsigned long long *p) {

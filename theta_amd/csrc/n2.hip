@@ -166,7 +166,9 @@ __device__ N2Result n2_solve(const N2Dev &P, const double *PRl, const double *PN
             double step = 1.0;
             if (l2 > 0.09) step = 1.0 / (1.0 + sqrt(l2));
             double xn = __builtin_fma(-step, dx, x);
-            if (!(xn > a && xn < b)) xn = 0.5 * (a + b);
+            // (a step below one ulp of x leaves xn == x == a or b: that is the root to machine precision, not a reason to bisect --
+            // with the strict test a start AT the root jumped to the middle of the bracket and, the decrement being tiny, stayed there)
+            if (!(xn >= a && xn <= b)) xn = 0.5 * (a + b);
             x = xn;
             if (l2 < 1e-12 || b - a <= 1e-300) break;     // the step just taken leaves an error ~ l2
         }
@@ -202,9 +204,78 @@ __device__ N2Result n2_solve(const N2Dev &P, const double *PRl, const double *PN
     return out;
 }
 
+
+// ---- dismissal by a lower bound (the search's fast path; the n=3 sieve's idea in one dimension) --------------------------
+// In nu-space the candidate's likelihood is  NLL(x) = K0 + Rtot ln sigma - sum_v R_v ln q_v,  q_v = v + x (sigma - v): an R-weighted
+// log barrier, self-concordant with parameter 2 / sqrt(Rmin).  ONE evaluation of value, slope f and curvature d at the thread's
+// chain point x (the Newton-stepped point of its previous candidate) gives, with lambda^2 = f^2 / d and t = lambda / sqrt(Rmin) < 1/2,
+//      min_x NLL >= NLL(x) - (lambda^2 / 2) (1 + t + 2 t^2)
+// -- a bound on ANYTHING the reference can report for the candidate (its root lies in the same domain; a candidate it rejects
+// reports nothing).  A candidate whose bound lies beyond the window of the running minimum is done: no bracket test (16 exact
+// divisions), no iteration to 1e-12, no exact logarithms.  What is undecided -- near-ties, a chain point that lost its
+// candidate at a carry of the successor -- goes to a per-wave queue in LDS and takes the full path (n2_solve, which alone decides
+// acceptance and lists finalists) 64 at a time: the two paths never share a wave instruction stream half empty.  Branch-free
+// over the KV runs (an empty run has R = 0 and contributes nothing).  The value is a single-precision screen behind the margin
+// the full path's screen uses (2e-5 Rtot + 1).
+template <int KV>
+__device__ __forceinline__ bool n2_quick(const N2Dev &P, double inv_N, const double2 *PRNl, const N2Cand<KV> &c, double &warm, double thr) {
+    double R[KV];
+    double S1 = 0.0;
+    float Rmin = __builtin_inff();
+    {
+        double2 pv[KV + 1];                                            // {sum r, sum rN} below every break-point: one 16-byte read each,
+#pragma unroll
+        for (int v = 0; v <= KV; v++) pv[v] = PRNl[c.s[v]];            // all in flight before the first is used
+#pragma unroll
+        for (int v = 0; v < KV; v++) {
+            R[v] = pv[v + 1].x - pv[v].x;
+            S1 = __builtin_fma((double)v, pv[v + 1].y - pv[v].y, S1);
+            const float rf = (float)R[v];
+            Rmin = fminf(Rmin, rf > 0.0f ? rf : __builtin_inff());
+        }
+    }
+    if (!(S1 > 0.0) || !(Rmin < __builtin_inff())) return false;       // all-zero column / no reads at all: the full path's business
+    const double sigma = S1 * inv_N;
+    const double x = (warm > 1e-30 && warm < 1.0) ? warm : 0.5;
+    double f = 0.0, d = 0.0;
+    float acc = 0.0f;
+#pragma unroll
+    for (int v = 0; v < KV; v++) {
+        const double w = sigma - (double)v;
+        const double q = __builtin_fma(x, w, (double)v);               // > 0 for x in (0, 1)
+        const float qf = (float)q;
+        double u = (double)__builtin_amdgcn_rcpf(qf);
+        u = __builtin_fma(u, __builtin_fma(-q, u, 1.0), u);            // 1 / q to ~3e-14
+        const double t = w * u;
+        f = __builtin_fma(-R[v], t, f);
+        d = __builtin_fma(R[v] * t, t, d);
+        acc = __builtin_fmaf((float)R[v], __builtin_amdgcn_logf(qf), acc);
+    }
+    const double dx = f * rcp_nr1(d);
+    const double l2 = f * dx;                                          // lambda^2 (0/0 = NaN for proportional columns: undecided)
+    const double t = (double)(__builtin_amdgcn_sqrtf((float)l2) * __builtin_amdgcn_rsqf(Rmin)) * 1.0001;
+    const double gap = 0.525 * l2 * __builtin_fma(t, __builtin_fma(2.0, t, 1.0), 1.0);
+    const double lower = P.K0 + 0.6931471805599453 * (P.Rtot * (double)__builtin_amdgcn_logf((float)sigma) - (double)acc) - gap;
+    // the Newton-stepped point (damped while the decrement is large), kept inside (0, 1): where the next candidate of this
+    // neighbourhood is evaluated, and where the full path starts if this one is undecided
+    double xn = x - dx * (t > 0.3 ? rcp_nr1(1.0 + t) : 1.0);
+    if (!(xn > 0.0 && xn < 1.0)) xn = 0.5 * (x + (dx > 0.0 ? 0.0 : 1.0));
+    warm = xn == xn ? xn : x;
+    return t < 0.5 && lower > thr;
+}
+
+#define N2_QCAP 96        // undecided candidates a wave holds (it runs the full path on 64 of them as soon as it has that many)
+// LDS of the dismissing search behind the tables every n=2 kernel stages: {sum r, sum rN} interleaved [m + 1] (one 16-byte read
+// per break-point), the chain points per successor level [kv][256], the per-wave queues [4][N2_QCAP][4 + (KV + 2) / 2 words]
+__host__ __device__ inline size_t n2_prn_offset(int m) {
+    return (((size_t)(m + 1) * 16 + (size_t)m * N2_KVS * 8 + (N2_KVS + 1 + 3) * 2 + (size_t)m + 16) + 15) & ~(size_t)15;
+}
+__host__ __device__ inline size_t n2_xs_offset(int m) { return n2_prn_offset(m) + (size_t)(m + 1) * 16; }
+__host__ __device__ inline size_t n2_queue_offset(int m, int kv) { return n2_xs_offset(m) + (size_t)kv * 256 * 8; }     // (chain points and their slopes: floats)
+
 template <int KV, bool DUMP>
 __global__ __launch_bounds__(256) void n2_search_kernel(N2Dev P, SearchArgs A, unsigned long long begin,
-                                                        unsigned long long end, int per_thread) {
+                                                        unsigned long long end, int per_thread, unsigned long long sample_stride) {
     extern __shared__ unsigned char smem[];
     // LDS staging of everything the candidates share
     double *PRl = (double *)smem;
@@ -219,49 +290,211 @@ __global__ __launch_bounds__(256) void n2_search_kernel(N2Dev P, SearchArgs A, u
     for (int i = threadIdx.x; i < P.m * N2_KVS; i += blockDim.x) Pl[i] = P.P[i];
     for (int i = threadIdx.x; i <= N2_KVS; i += blockDim.x) lbposl[i] = P.lbpos[i];
     for (int i = threadIdx.x; i < P.m; i += blockDim.x) ubl[i] = P.ub[i];
+    if (!DUMP && P.quick)
+        for (int i = threadIdx.x; i <= P.m; i += blockDim.x) ((double2 *)(smem + n2_prn_offset(P.m)))[i] = make_double2(P.PR[i], P.PN[i]);
     __syncthreads();
 
     unsigned long long tid = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (sample_stride) {
+        // SAMPLE launch of a search that starts without a minimum: every thread solves ONE candidate (ranks `sample_stride` apart)
+        // and the smallest NLL the reference's procedure reports among them becomes the running minimum -- nothing else is written.
+        // Without it every thread's first candidate is "within the window" of +inf: a million appends to the tie list and as
+        // many atomicMin on one address, 1 ms of a 3 ms search (PMC / timing in profiles/r4/NOTES.md).
+        const unsigned long long rank = begin + tid * sample_stride;
+        double v = __builtin_inf();
+        if (rank < end) {
+            N2Cand<KV> c;
+            n2_unrank<KV>(P, Pl, rank, c);
+            const N2Result rs = n2_solve<KV, true>(P, PRl, PNl, c, __builtin_nan(""), __builtin_inf());
+            if (rs.ok) v = rs.nll;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o, WAVE));
+        if (lane_id() == 0 && v < __builtin_inf()) atomicMin(&A.ctr->best_bits, order_bits(v));
+        return;
+    }
     unsigned long long t0 = begin + tid * (unsigned long long)per_thread;
-    unsigned long long n_eval = 0, n_acc = 0, n_deg = 0, n_it = 0, n_terms = 0, n_fin = 0;
-    if (t0 < end) {
-        unsigned long long t1 = t0 + (unsigned long long)per_thread;
-        if (t1 > end) t1 = end;
-        N2Cand<KV> c;
-        n2_unrank<KV>(P, Pl, t0, c);
-        double best = order_unbits(load_agent_u64(&A.ctr->best_bits));
-        double warm = __builtin_nan("");
-        // f32 screen: |error| <= ~1e-6 * Rtot * ln(range) -- a margin of 2e-5 Rtot is far outside it
-        const double margin = 2e-5 * P.Rtot + 1.0;
-        for (unsigned long long rank = t0; rank < t1; rank++) {
-            N2Result rs = n2_solve<KV, DUMP>(P, PRl, PNl, c, warm, best + A.window + margin);
-            if (rs.ok) warm = rs.x;
-            n_eval++;
-            n_it += rs.iters;
-            n_terms += (unsigned long long)rs.iters * rs.terms;
-            n_deg += rs.degenerate;
-            if (rs.ok) {
-                n_acc++;
-                n_fin += rs.terms + 1;
-                if (rs.exact && rs.nll <= best + A.window) {
-                    // refresh: another thread may have lowered the global minimum meanwhile
-                    best = fmin(best, order_unbits(load_agent_u64(&A.ctr->best_bits)));
-                    if (rs.nll <= best + A.window) {
-                        tie_append(A.ctr, A.list, A.list_cap, (u128)rank, rs.nll, rs.mu, 1.0 - rs.mu, 0.0);
-                        if (rs.nll < best) {
-                            atomicMin(&A.ctr->best_bits, order_bits(rs.nll));
-                            best = rs.nll;
-                        }
-                    }
+    unsigned long long n_eval = 0, n_acc = 0, n_deg = 0, n_it = 0, n_terms = 0, n_fin = 0, n_dis = 0;
+    const bool quick = !DUMP && P.quick;
+    const double inv_N = 1.0 / P.N;
+    // f32 screen: |error| <= ~1e-6 * Rtot * ln(range) -- a margin of 2e-5 Rtot is far outside it
+    const double margin = 2e-5 * P.Rtot + 1.0;
+    double best = order_unbits(load_agent_u64(&A.ctr->best_bits));
+    // one candidate through Optimizer._solve_n2 as restated above: acceptance, root, NLL, tie list, running minimum
+    auto full = [&](const N2Cand<KV> &cc, unsigned long long rank, double &wm) {
+        N2Result rs = n2_solve<KV, DUMP>(P, PRl, PNl, cc, wm, best + A.window + margin);
+        if (rs.ok) wm = rs.x;
+        n_it += rs.iters;
+        n_terms += (unsigned long long)rs.iters * rs.terms;
+        n_deg += rs.degenerate;
+        if (rs.ok) {
+            n_acc++;
+            n_fin += rs.terms + 1;
+            if (rs.exact && rs.nll <= best + A.window) {
+                // refresh: another thread may have lowered the global minimum meanwhile
+                best = fmin(best, order_unbits(load_agent_u64(&A.ctr->best_bits)));
+                if (rs.nll <= best + A.window) {
+                    tie_append(A.ctr, A.list, A.list_cap, (u128)rank, rs.nll, rs.mu, 1.0 - rs.mu, 0.0);
+                    if (rs.nll < best) atomicMin(&A.ctr->best_bits, order_bits(rs.nll));
                 }
             }
-            if (DUMP) {
-                A.dump_nll[rank - begin] = rs.ok ? rs.nll : __builtin_nan("");
-                A.dump_mu[(rank - begin) * 2] = rs.ok ? rs.mu : __builtin_nan("");
-                A.dump_mu[(rank - begin) * 2 + 1] = rs.ok ? 1.0 - rs.mu : __builtin_nan("");
-            }
-            if (rank + 1 < t1 && !n2_next<KV>(P, ubl, lbposl, c)) break;
+            if (rs.nll < best) best = rs.nll;        // (the thread's own minimum is an attained value too)
         }
+        if (DUMP) {
+            A.dump_nll[rank - begin] = rs.ok ? rs.nll : __builtin_nan("");
+            A.dump_mu[(rank - begin) * 2] = rs.ok ? rs.mu : __builtin_nan("");
+            A.dump_mu[(rank - begin) * 2 + 1] = rs.ok ? 1.0 - rs.mu : __builtin_nan("");
+        }
+    };
+    if (!quick) {
+        if (t0 < end) {
+            unsigned long long t1 = t0 + (unsigned long long)per_thread;
+            if (t1 > end) t1 = end;
+            N2Cand<KV> c;
+            n2_unrank<KV>(P, Pl, t0, c);
+            double warm = __builtin_nan("");
+            for (unsigned long long rank = t0; rank < t1; rank++) {
+                full(c, rank, warm);
+                n_eval++;
+                if (rank + 1 < t1 && !n2_next<KV>(P, ubl, lbposl, c)) break;
+            }
+        }
+    } else {
+        // Every lane of the wave runs the same number of trips (`on` says whether it still has a candidate), so that all 64 lanes
+        // are there when the queue of undecided candidates is drained.  Queue entry: rank, chain point, break-points (16 bits each).
+        constexpr int EW = 4 + (KV + 2) / 2;
+        unsigned *queue = (unsigned *)(smem + n2_queue_offset(P.m, KV)) + (threadIdx.x >> 6) * (N2_QCAP * EW);
+        const double2 *PRNl = (const double2 *)(smem + n2_prn_offset(P.m));
+        // Chain points: xs[w] = the stepped point of the candidate that followed the last successor step of level >= w.  A step of
+        // level nv moves break-points 1 .. nv to one position and leaves the rest: the candidate it makes differs by ONE interval
+        // from the one the previous step of that level made -- a far better start than the previous candidate, which a carry
+        // (nv > 1) leaves behind by a whole run of intervals.
+        float *xs = (float *)(smem + n2_xs_offset(P.m)) + threadIdx.x;             // xs[w * 256] (single precision: a start, nothing more)
+        // ... and how far the point moved between the last two steps of that level (consecutive steps of one level raise
+        // neighbouring positions by the same amount: the next optimum lies about as far on) -- xs + slope is where a step starts
+        float *xsl = (float *)(smem + n2_xs_offset(P.m) + (size_t)KV * 256 * 4) + threadIdx.x;
+        const int lane = threadIdx.x & 63;
+        int qcount = 0;                                                  // (wave-uniform)
+        auto drain = [&](int keep) {                                     // full path, 64 entries at a time, until <= keep are left
+            while (qcount > keep) {
+                const int take = qcount < WAVE ? qcount : WAVE;
+                const bool has = lane < take;
+                const unsigned *e = queue + (qcount - take + (has ? lane : 0)) * EW;
+                N2Cand<KV> cc;
+#pragma unroll
+                for (int v = 0; v <= KV; v++) cc.s[v] = (int)((e[4 + (v >> 1)] >> (16 * (v & 1))) & 0xffffu);
+                double wm = __longlong_as_double(((long long)e[3] << 32) | e[2]);
+                // most of the queue is candidates whose chain point was a step behind (a carry of the successor, a tiny run): two
+                // more evaluations, each from the Newton-stepped point of the last, dismiss them; what is left -- the near-ties --
+                // is what the full path is for
+                bool und = has;
+#pragma unroll 1
+                for (int k = 0; k < ((P.quick & 8) ? 0 : 2); k++) {
+                    if (!ballot64(und)) break;
+                    const bool dis = n2_quick<KV>(P, inv_N, PRNl, cc, wm, best + A.window + margin);
+                    if (und) {
+                        n_it++;
+                        n_terms += KV;
+                        n_fin += KV + 1;
+                        n_dis += dis;
+                    }
+                    und = und && !dis;
+                }
+                if (und) full(cc, ((unsigned long long)e[1] << 32) | e[0], wm);
+                qcount -= take;
+                wave_lds_sync();
+            }
+        };
+        unsigned long long t1 = t0 + (unsigned long long)per_thread;
+        if (t1 > end) t1 = end;
+        bool on = t0 < end;
+        N2Cand<KV> c;
+        if (on) n2_unrank<KV>(P, Pl, t0, c);
+        else {
+#pragma unroll
+            for (int v = 0; v <= KV; v++) c.s[v] = v ? P.m : 0;          // (a harmless candidate for idle lanes)
+        }
+        double warm = __builtin_nan("");
+        {   // the thread's first candidate: a few Newton steps from the centre settle the chain point of every level
+#pragma unroll 1
+            for (int k = 0; k < 4; k++) (void)n2_quick<KV>(P, inv_N, PRNl, c, warm, __builtin_inf());
+#pragma unroll
+            for (int w = 1; w < KV; w++) {
+                xs[w * 256] = (float)warm;
+                xsl[w * 256] = 0.0f;
+            }
+            if (on) {
+                n_it += 4;
+                n_terms += 4 * KV;
+            }
+        }
+        int nv = 1;
+        unsigned n_q = 0;                                                // (32 bits: a thread walks <= 512 candidates)
+        // bound tables of the successor, wave-uniform (scalar registers): lbp[w] / ubp[w] = first position whose lower / upper
+        // bound is >= w
+        int lbp[KV + 1], ubp[KV + 1];
+#pragma unroll
+        for (int w = 0; w <= KV; w++) {
+            lbp[w] = (int)P.lbpos[w];
+            int lo = 0, hi = P.m;
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if ((int)P.ub[mid] >= w) hi = mid;
+                else lo = mid + 1;
+            }
+            ubp[w] = lo;
+        }
+        for (int it = 0; it < per_thread; it++) {
+            if (!ballot64(on)) break;
+            const unsigned long long rank = t0 + (unsigned long long)it;
+            // what the other threads found meanwhile: often at the start (a search without a hint begins with no minimum at all)
+            if (!(P.quick & 2) && ((it & 31) == 31 || (it & (it - 1)) == 0)) best = fmin(best, order_unbits(load_agent_u64(&A.ctr->best_bits)));
+            const double xprev = (double)xs[nv * 256];
+            warm = xprev + ((P.quick & 4) ? 0.0 : (double)xsl[nv * 256]);
+            if (!(warm > 1e-30 && warm < 1.0)) warm = xprev;
+            const bool dis = n2_quick<KV>(P, inv_N, PRNl, c, warm, best + A.window + margin);
+            for (int w = 1; w < KV; w++) {                               // (wave-uniform trip count: the largest level of the wave)
+                if (!ballot64(w <= nv)) break;
+                if (w <= nv) {
+                    xs[w * 256] = (float)warm;
+                    xsl[w * 256] = w == nv ? (float)(warm - xprev) : 0.0f;
+                }
+            }
+            if (on) {
+                n_q++;
+                n_dis += dis;
+            }
+            const bool push = on && !dis;
+            const unsigned long long pm = ballot64(push);
+            if (pm) {
+                if (qcount + __builtin_popcountll(pm) > N2_QCAP) drain(0);
+                if (push) {
+                    unsigned *e = queue + (qcount + mbcnt(pm)) * EW;
+                    e[0] = (unsigned)rank;
+                    e[1] = (unsigned)(rank >> 32);
+                    const unsigned long long xb = (unsigned long long)__double_as_longlong(warm);
+                    e[2] = (unsigned)xb;
+                    e[3] = (unsigned)(xb >> 32);
+#pragma unroll
+                    for (int v = 0; v <= KV; v += 2) e[4 + (v >> 1)] = (unsigned)c.s[v] | (v + 1 <= KV ? (unsigned)c.s[v + 1] << 16 : 0u);
+                }
+                qcount += __builtin_popcountll(pm);
+                wave_lds_sync();
+                if (qcount >= WAVE) drain(WAVE - 1);
+            }
+            if (on) {
+                nv = rank + 1 < t1 ? n2_next_tab<KV>(lbp, ubp, c) : 0;
+                if (nv == 0) {
+                    on = false;
+                    nv = 1;
+                }
+            }
+        }
+        drain(0);
+        n_eval += n_q;                                                   // every candidate had its one shared-point evaluation: KV terms each
+        n_it += n_q;
+        n_terms += (unsigned long long)n_q * KV;
+        n_fin += (unsigned long long)n_q * (KV + 1);
     }
     // one atomic per wave per counter
     n_eval = wave_sum_u64(n_eval);
@@ -270,14 +503,16 @@ __global__ __launch_bounds__(256) void n2_search_kernel(N2Dev P, SearchArgs A, u
     n_it = wave_sum_u64(n_it);
     n_terms = wave_sum_u64(n_terms);
     n_fin = wave_sum_u64(n_fin);
+    n_dis = wave_sum_u64(n_dis);
     if (lane_id() == 0 && n_eval) {
-        atomicAdd(&A.ctr->evaluated, n_eval);
-        atomicAdd(&A.ctr->accepted, n_acc);
-        atomicAdd(&A.ctr->degenerate, n_deg);
-        atomicAdd(&A.ctr->iterations, n_it);
-        atomicAdd(&A.ctr->terms, n_terms);
-        atomicAdd(&A.ctr->terms64, n_terms);
-        atomicAdd(&A.ctr->final_terms, n_fin);
+        SearchCounters *sc = stat_slot(A);
+        if (n_dis) atomicAdd(&sc->dismissed, n_dis);
+        atomicAdd(&sc->evaluated, n_eval);
+        if (n_acc) atomicAdd(&sc->accepted, n_acc);
+        if (n_deg) atomicAdd(&sc->degenerate, n_deg);
+        atomicAdd(&sc->iterations, n_it);
+        atomicAdd(&sc->terms, n_terms);                 // (terms64 = terms for n=2: set by the host)
+        atomicAdd(&sc->final_terms, n_fin);
     }
 }
 
@@ -551,18 +786,26 @@ static size_t n2_smem_bytes(const N2Dev &P) {
 }
 
 void n2_launch_search(const N2Dev &P, const SearchArgs &A, unsigned long long begin, unsigned long long end,
-                      int per_thread, hipStream_t st) {
+                      int per_thread, hipStream_t st, unsigned long long sample_stride) {
     unsigned long long n = end - begin;
-    unsigned long long threads = (n + per_thread - 1) / per_thread;
+    unsigned long long threads = sample_stride ? (n + sample_stride - 1) / sample_stride : (n + per_thread - 1) / per_thread;
     unsigned blocks = (unsigned)((threads + 255) / 256);
-    size_t sm = n2_smem_bytes(P);
     const bool dump = A.dump_nll != nullptr;
+    // (+ the per-wave queues of the dismissing search: N2_QCAP entries of 4 + (KV + 2) / 2 words)
+    const int kvt = P.kv <= 8 ? 8 : 16;
+    const size_t sm = dump ? n2_smem_bytes(P) : n2_queue_offset(P.m, kvt) + (size_t)4 * N2_QCAP * (4 + (kvt + 2) / 2) * 4;
+    if (sm > 48 * 1024) {      // (m beyond ~300 intervals: more than the default dynamic LDS limit)
+        (void)hipFuncSetAttribute((const void *)n2_search_kernel<8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+        (void)hipFuncSetAttribute((const void *)n2_search_kernel<16, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+        (void)hipFuncSetAttribute((const void *)n2_search_kernel<8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+        (void)hipFuncSetAttribute((const void *)n2_search_kernel<16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+    }
     if (P.kv <= 8) {
-        if (dump) hipLaunchKernelGGL((n2_search_kernel<8, true>), dim3(blocks), dim3(256), sm, st, P, A, begin, end, per_thread);
-        else hipLaunchKernelGGL((n2_search_kernel<8, false>), dim3(blocks), dim3(256), sm, st, P, A, begin, end, per_thread);
+        if (dump) hipLaunchKernelGGL((n2_search_kernel<8, true>), dim3(blocks), dim3(256), sm, st, P, A, begin, end, per_thread, sample_stride);
+        else hipLaunchKernelGGL((n2_search_kernel<8, false>), dim3(blocks), dim3(256), sm, st, P, A, begin, end, per_thread, sample_stride);
     } else {
-        if (dump) hipLaunchKernelGGL((n2_search_kernel<16, true>), dim3(blocks), dim3(256), sm, st, P, A, begin, end, per_thread);
-        else hipLaunchKernelGGL((n2_search_kernel<16, false>), dim3(blocks), dim3(256), sm, st, P, A, begin, end, per_thread);
+        if (dump) hipLaunchKernelGGL((n2_search_kernel<16, true>), dim3(blocks), dim3(256), sm, st, P, A, begin, end, per_thread, sample_stride);
+        else hipLaunchKernelGGL((n2_search_kernel<16, false>), dim3(blocks), dim3(256), sm, st, P, A, begin, end, per_thread, sample_stride);
     }
 }
 

@@ -13,6 +13,8 @@ struct N2Dev {
     const short *lbpos;          // [N2_KVS+1] first index whose lb >= v (m if none)
     unsigned long long total;    // number of candidates
     int first_zero_r;            // smallest interval index with r_i == 0 (m if none)
+    int quick;                   // search: dismiss a candidate by a rigorous lower bound of its optimum after one evaluation at the
+                                 // thread's chain point (n2_quick); 0 = solve every candidate (option "n2_no_dismiss")
 };
 
 struct N2Host {

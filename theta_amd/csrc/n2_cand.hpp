@@ -31,9 +31,10 @@ N2_HD void n2_unrank(const N2Dev &P, const unsigned long long *Pl, unsigned long
     }
 }
 
-// The reference's successor (Enumerator.py:134-152) on the break-point form. Returns false at the end.
+// The reference's successor (Enumerator.py:134-152) on the break-point form.  Returns the LEVEL of the step -- the value nv the
+// raised position takes: break-points 1 .. nv move to that position, the others stay -- or 0 at the end of the space.
 template <int KV>
-N2_HD bool n2_next(const N2Dev &P, const unsigned char *ubl, const short *lbposl, N2Cand<KV> &c) {
+N2_HD int n2_next_level(const N2Dev &P, const unsigned char *ubl, const short *lbposl, N2Cand<KV> &c) {
     int e = -1, nv = 0;
 #pragma unroll
     for (int v = 0; v < KV; v++) {
@@ -43,15 +44,45 @@ N2_HD bool n2_next(const N2Dev &P, const unsigned char *ubl, const short *lbposl
                 e = end;
                 nv = v + 1;
             } else if (end == P.m - 1) {
-                return false;  // last run cannot be raised: enumeration exhausted
+                return 0;  // last run cannot be raised: enumeration exhausted
             }
         }
     }
-    if (e < 0) return false;
+    if (e < 0) return 0;
 #pragma unroll
     for (int w = 1; w < KV; w++) {
         int lp = lbposl[w];
         c.s[w] = (lp < e) ? lp : ((w <= nv) ? e : c.s[w]);
     }
-    return true;
+    return nv;
+}
+template <int KV>
+N2_HD bool n2_next(const N2Dev &P, const unsigned char *ubl, const short *lbposl, N2Cand<KV> &c) {
+    return n2_next_level<KV>(P, ubl, lbposl, c) != 0;
+}
+
+// The same successor with both bound tests on wave-uniform tables (the form of n2_render.hpp's n2r_next, returning the level):
+//   lbp[w] = first position whose lower bound is >= w (m if none),  ubp[w] = first position whose upper bound is >= w (m if none).
+// Run v = [s[v], s[v+1]) can be raised at its end iff that end lies at or behind ubp[v+1] (the bounds are non-decreasing after
+// _check_bound_order), i.e. iff s[v+1] > max(s[v], ubp[v+1]): no per-lane bound reads, no data-dependent chain of LDS round trips.
+template <int KV>
+N2_HD inline int n2_next_tab(const int (&lbp)[KV + 1], const int (&ubp)[KV + 1], N2Cand<KV> &c) {
+    int e = -1, nv = 0;
+    bool found = false;
+#pragma unroll
+    for (int v = 0; v < KV; v++) {
+        const int hi = c.s[v + 1], b = ubp[v + 1];
+        const int lo = c.s[v] > b ? c.s[v] : b;
+        const bool take = hi > lo && !found;
+        e = take ? hi - 1 : e;
+        nv = take ? v + 1 : nv;
+        found = found || hi > lo;
+    }
+    if (!found) return 0;
+#pragma unroll
+    for (int w = 1; w < KV; w++) {
+        const int lp = lbp[w];
+        c.s[w] = w <= nv ? (lp < e ? lp : e) : c.s[w];
+    }
+    return nv;
 }

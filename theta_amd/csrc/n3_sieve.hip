@@ -75,6 +75,20 @@ __device__ __forceinline__ float sv_fma(float a, float b, float c) { return __bu
 __device__ __forceinline__ double sv_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
 __device__ __forceinline__ float sv_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 __device__ __forceinline__ double sv_rcp(double x) { return rcp_nr1(x); }
+// 1/q and log2 q of a likelihood term from ONE conversion to single precision.  F = double: the reciprocal is v_rcp_f32 of
+// (float) q + one Newton-Raphson step in FP64 (relative error ~3e-14: v_rcp_f64 issues at a quarter of the rate and needs the
+// same step, tools/micro/valu_rates.hip); only iterates and decrements are built on it -- values come from the logarithms,
+// contenders are redone with exact arithmetic by the finish kernel.
+__device__ __forceinline__ void sv_rcp_lg2(float q, float &w, float &l) {
+    w = __builtin_amdgcn_rcpf(q);
+    l = __builtin_amdgcn_logf(q);
+}
+__device__ __forceinline__ void sv_rcp_lg2(double q, double &w, double &l) {
+    const float qf = (float)q;
+    const double y = (double)__builtin_amdgcn_rcpf(qf);
+    l = (double)__builtin_amdgcn_logf(qf);
+    w = __builtin_fma(y, __builtin_fma(-q, y, 1.0), y);
+}
 __device__ __forceinline__ float sv_lg2(float x) { return __builtin_amdgcn_logf(x); }
 __device__ __forceinline__ double sv_lg2(double x) { return (double)__builtin_amdgcn_logf((float)x); }
 __device__ __forceinline__ float sv_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
@@ -88,6 +102,20 @@ template <> struct SvVec<float> { typedef float v2 __attribute__((ext_vector_typ
 template <> struct SvVec<double> { typedef double v2 __attribute__((ext_vector_type(2))); };
 template <class F> struct alignas(16) Sv4 { F x, y, z, w; };
 template <class F> struct alignas(2 * sizeof(F)) Sv2 { F x, y; };
+// the weights of a pair of likelihood terms.  F = double: with their square roots rho -- per term alpha = rho a / q, beta = rho b / q,
+// gradient sum rho alpha, Hessian sum alpha alpha^T: one multiplication less than through t = R / q, t / q.  (F = float keeps
+// {R0, R1}: the extra 1.1 KB of LDS per block would cost the float kernel its third block per CU, measured 36.1 -> 45.2 ms.)
+template <class F> struct SvWt;
+template <> struct SvWt<float> {
+    typedef Sv2<float> T;
+    static __device__ __forceinline__ T make(float r0, float r1, double, double) { return T{r0, r1}; }
+};
+template <> struct SvWt<double> {
+    typedef Sv4<double> T;
+    static __device__ __forceinline__ T make(double r0, double r1, double h0, double h1) { return T{r0, r1, h0, h1}; }
+};
+template <class F> __device__ __forceinline__ typename SvVec<F>::v2 sv_rho(const Sv2<F> &) { return typename SvVec<F>::v2{F(0), F(0)}; }
+template <class F> __device__ __forceinline__ typename SvVec<F>::v2 sv_rho(const Sv4<F> &t) { return typename SvVec<F>::v2{t.z, t.w}; }
 // the record of a last-level node -- 15 numbers (shared sums L, T0..T2, W00..W22, column sums, the point) -- as planes of
 // 16-byte vectors indexed [plane][node]: a wave reads one plane with consecutive 16-byte addresses (round 2 held the record
 // node-major, 64 bytes apart: four lanes per bank group, SQ_LDS_BANK_CONFLICT / SQ_ACTIVE_INST_LDS = 0.79)
@@ -134,8 +162,8 @@ struct SvWave {
     unsigned pcode[WAVE];                               // ... and the slots of its path rows (6 bits each) | usable << 31
     unsigned task_line;                                 // a prefix of the task had collinear rows (n3_core.hpp: N3Line)
     Sv4<F> fXY[(N3_MAX_Q + 2) / 2];                     // group tile of the prefix, two terms per entry {a0, a1, b0, b1}
-    Sv2<F> fRR[(N3_MAX_Q + 2) / 2];                     // ... and their weights {R0, R1} (an odd last term is paired with weight 0)
-    Sv2<F> fRL[ML / 2];                                 // weights of the leaf rows, paired
+    typename SvWt<F>::T fRR[(N3_MAX_Q + 2) / 2];        // ... and their weights {R0, R1} (an odd last term is paired with weight 0); F = double:
+    typename SvWt<F>::T fRL[ML / 2];                    // {R0, R1, sqrt R0, sqrt R1}.  fRL: the weights of the leaf rows, paired likewise
     uint2 qRec[SV_QCAP];                                // queue of records that need more Newton steps: {slots of the path rows (6 bits
                                                         // each: the node's code), last row's slot | offset in the task << 8} -- the
                                                         // rows are decoded by the lane that takes the entry (sv_drain), not by the
@@ -185,6 +213,7 @@ struct SvCtx {
     F S1p, S2p;                      // column sums of the prefix rows (weighted by the normal counts), / N
     F leafN[ML];                     // normal counts of the leaf rows / N
     F leafRf[ML];                    // tumour counts of the leaf rows
+    F leafRho[ML];                   // ... and their square roots
     F rtot_f, rtot_over_rmin, inv_Rtot, conv_l2, fine_l2;
     double K0, screen_margin, thr;   // thr = running minimum + window, loaded per task; screen_margin: see sv_beyond
     F Tcmp;                          // the threshold of sv_beyond's comparison, in F (per task)
@@ -215,40 +244,54 @@ template <int ML, class F>
 __device__ __forceinline__ int sv_step(const SvCtx<ML, F> &c, const unsigned (&rw)[ML / 2], F s1, F s2, F &u1, F &u2, F &val2, F &l2, F &la) {
     typedef typename SvVec<F>::v2 v2;
     v2 g1 = {F(0), F(0)}, g2 = g1, h11 = g1, h12 = g1, h22 = g1, lg = g1, lga = g1;
-    F qmin = F(__builtin_inff());
     const v2 vs1 = {s1, s1}, vs2 = {s2, s2}, vu1 = {u1, u1}, vu2 = {u2, u2}, one = {F(1), F(1)};
-    auto body = [&](v2 x, v2 y, v2 R) {
+    // per term, with rho = sqrt R:  alpha = rho a / q, beta = rho b / q;  gradient sum rho alpha, Hessian sum alpha alpha^T
+    // (one multiplication less than through t = R / q, t / q).  A term outside the domain (q <= 0, or so close that its
+    // single-precision image is 0) leaves a NaN or an infinity in the sum of logarithms: no running minimum of q is kept.
+    auto body = [&](v2 x, v2 y, v2 R, v2 rho) {
         v2 a = x - vs1, b = y - vs2;
         v2 q = __builtin_elementwise_fma(a, vu1, __builtin_elementwise_fma(b, vu2, one));
-        qmin = sv_min(qmin, sv_min(q.x, q.y));
-        v2 w = {sv_rcp(q.x), sv_rcp(q.y)};
-        const v2 l = {sv_lg2(q.x), sv_lg2(q.y)};
+        F wx, wy, lx, ly;
+        sv_rcp_lg2(q.x, wx, lx);
+        sv_rcp_lg2(q.y, wy, ly);
+        const v2 w = {wx, wy}, l = {lx, ly};
         lg = __builtin_elementwise_fma(R, l, lg);
         if constexpr (sizeof(F) == 8) lga = __builtin_elementwise_fma(R, v2{sv_abs(l.x), sv_abs(l.y)}, lga);   // (error bound of the f32 logarithms, sv_beyond)
-        v2 t = R * w;
-        g1 = __builtin_elementwise_fma(t, a, g1);
-        g2 = __builtin_elementwise_fma(t, b, g2);
-        v2 tw = t * w;
-        v2 ta = tw * a, tb = tw * b;
-        h11 = __builtin_elementwise_fma(ta, a, h11);
-        h12 = __builtin_elementwise_fma(ta, b, h12);
-        h22 = __builtin_elementwise_fma(tb, b, h22);
+        if constexpr (sizeof(F) == 8) {
+            v2 gw = rho * w;
+            v2 al = gw * a, be = gw * b;
+            g1 = __builtin_elementwise_fma(rho, al, g1);
+            g2 = __builtin_elementwise_fma(rho, be, g2);
+            h11 = __builtin_elementwise_fma(al, al, h11);
+            h12 = __builtin_elementwise_fma(al, be, h12);
+            h22 = __builtin_elementwise_fma(be, be, h22);
+        } else {
+            v2 t = R * w;
+            g1 = __builtin_elementwise_fma(t, a, g1);
+            g2 = __builtin_elementwise_fma(t, b, g2);
+            v2 tw = t * w;
+            v2 ta = tw * a, tb = tw * b;
+            h11 = __builtin_elementwise_fma(ta, a, h11);
+            h12 = __builtin_elementwise_fma(ta, b, h12);
+            h22 = __builtin_elementwise_fma(tb, b, h22);
+        }
     };
     const Sv4<F> *fXY = c.W->fXY;
-    const Sv2<F> *fRR = c.W->fRR;
+    const typename SvWt<F>::T *fRR = c.W->fRR;
 #pragma unroll 2
     for (int p = 0; p < c.GP; p++) {
         const Sv4<F> xy = fXY[p];
-        const Sv2<F> rr = fRR[p];
-        body(v2{xy.x, xy.y}, v2{xy.z, xy.w}, v2{rr.x, rr.y});
+        const typename SvWt<F>::T rr = fRR[p];
+        body(v2{xy.x, xy.y}, v2{xy.z, xy.w}, v2{rr.x, rr.y}, sv_rho<F>(rr));
     }
 #pragma unroll
     for (int j = 0; j < ML / 2; j++) {
-        const Sv2<F> rr = c.W->fRL[j];
+        const typename SvWt<F>::T rr = c.W->fRL[j];
         const unsigned d = rw[j];      // bytes {a, b, a', b'}
-        body(v2{(F)(d & 0xffu), (F)((d >> 16) & 0xffu)}, v2{(F)((d >> 8) & 0xffu), (F)(d >> 24)}, v2{rr.x, rr.y});
+        body(v2{(F)(d & 0xffu), (F)((d >> 16) & 0xffu)}, v2{(F)((d >> 8) & 0xffu), (F)(d >> 24)}, v2{rr.x, rr.y}, sv_rho<F>(rr));
     }
-    if (!(qmin > F(0))) {
+    val2 = lg.x + lg.y;
+    if (!(sv_abs(val2) < F(__builtin_inff()))) {
         u1 *= F(0.5);
         u2 *= F(0.5);
         return 2;
@@ -262,7 +305,6 @@ __device__ __forceinline__ int sv_step(const SvCtx<ML, F> &c, const unsigned (&r
     const F d1 = (H22 * G1 - H12 * G2) * idet;
     const F d2 = (H11 * G2 - H12 * G1) * idet;
     l2 = (G1 * d1 + G2 * d2) * c.inv_Rtot;
-    val2 = lg.x + lg.y;
     la = lga.x + lga.y;
     if (!(l2 == l2) || !(sv_abs(d1) + sv_abs(d2) < F(1e30))) return 3;
     F step = F(1);
@@ -465,43 +507,61 @@ __device__ __forceinline__ void sv_parent(SvCtx<ML, F> &c, bool take, unsigned c
     const F w0 = F(1) - n1 - n2;
     const F u1 = n1 * sv_rcp(sums_ok ? S1 : F(1)), u2 = n2 * sv_rcp(sums_ok ? S2 : F(1));
     v2 L = {F(0), F(0)}, T0 = L, T1 = L, T2 = L, W00 = L, W01 = L, W02 = L, W11 = L, W12 = L, W22 = L, LA = L;
-    F qmin = F(__builtin_inff());
     const v2 vw0 = {w0, w0}, vu1 = {u1, u1}, vu2 = {u2, u2};
-    auto body = [&](v2 x, v2 y, v2 R) {
+    // (rho = sqrt R: gamma = rho / q, T = sum rho gamma (1, x, y), W = sum gamma^2 (1, x, y)(1, x, y)^T; a term outside the
+    // domain shows as a NaN / an infinity in L, see sv_step)
+    auto body = [&](v2 x, v2 y, v2 R, v2 rho) {
         v2 q = __builtin_elementwise_fma(x, vu1, __builtin_elementwise_fma(y, vu2, vw0));
-        qmin = sv_min(qmin, sv_min(q.x, q.y));
-        v2 w = {sv_rcp(q.x), sv_rcp(q.y)};
-        const v2 l = {sv_lg2(q.x), sv_lg2(q.y)};
+        F wx, wy, lx, ly;
+        sv_rcp_lg2(q.x, wx, lx);
+        sv_rcp_lg2(q.y, wy, ly);
+        const v2 w = {wx, wy}, l = {lx, ly};
         L = __builtin_elementwise_fma(R, l, L);
         if constexpr (sizeof(F) == 8) LA = __builtin_elementwise_fma(R, v2{sv_abs(l.x), sv_abs(l.y)}, LA);
-        v2 t = R * w;
-        T0 += t;
-        T1 = __builtin_elementwise_fma(t, x, T1);
-        T2 = __builtin_elementwise_fma(t, y, T2);
-        v2 tw = t * w;
-        W00 += tw;
-        v2 twx = tw * x, twy = tw * y;
-        W01 += twx;
-        W02 += twy;
-        W11 = __builtin_elementwise_fma(twx, x, W11);
-        W12 = __builtin_elementwise_fma(twx, y, W12);
-        W22 = __builtin_elementwise_fma(twy, y, W22);
+        if constexpr (sizeof(F) == 8) {
+            v2 ga = rho * w;
+            T0 = __builtin_elementwise_fma(rho, ga, T0);
+            v2 gx = ga * x, gy = ga * y;
+            T1 = __builtin_elementwise_fma(rho, gx, T1);
+            T2 = __builtin_elementwise_fma(rho, gy, T2);
+            W00 = __builtin_elementwise_fma(ga, ga, W00);
+            W01 = __builtin_elementwise_fma(ga, gx, W01);
+            W02 = __builtin_elementwise_fma(ga, gy, W02);
+            W11 = __builtin_elementwise_fma(gx, gx, W11);
+            W12 = __builtin_elementwise_fma(gx, gy, W12);
+            W22 = __builtin_elementwise_fma(gy, gy, W22);
+        } else {
+            v2 t = R * w;
+            T0 += t;
+            T1 = __builtin_elementwise_fma(t, x, T1);
+            T2 = __builtin_elementwise_fma(t, y, T2);
+            v2 tw = t * w;
+            W00 += tw;
+            v2 twx = tw * x, twy = tw * y;
+            W01 += twx;
+            W02 += twy;
+            W11 = __builtin_elementwise_fma(twx, x, W11);
+            W12 = __builtin_elementwise_fma(twx, y, W12);
+            W22 = __builtin_elementwise_fma(twy, y, W22);
+        }
     };
     if (take) {
         const Sv4<F> *fXY = c.W->fXY;
-        const Sv2<F> *fRR = c.W->fRR;
+        const typename SvWt<F>::T *fRR = c.W->fRR;
 #pragma unroll 2
         for (int p = 0; p < c.GP; p++) {
             const Sv4<F> xy = fXY[p];
-            const Sv2<F> rr = fRR[p];
-            body(v2{xy.x, xy.y}, v2{xy.z, xy.w}, v2{rr.x, rr.y});
+            const typename SvWt<F>::T rr = fRR[p];
+            body(v2{xy.x, xy.y}, v2{xy.z, xy.w}, v2{rr.x, rr.y}, sv_rho<F>(rr));
         }
         // the ML - 1 path rows: pairs, an odd one with a copy of itself of weight 0
 #pragma unroll
-        for (int j = 0; j + 1 < ML - 1; j += 2) body(v2{px[j], px[j + 1]}, v2{py[j], py[j + 1]}, v2{c.leafRf[j], c.leafRf[j + 1]});
-        if ((ML - 1) & 1) body(v2{px[ML - 2], px[ML - 2]}, v2{py[ML - 2], py[ML - 2]}, v2{c.leafRf[ML - 2], F(0)});
-        const bool usable = sums_ok && qmin > F(0);
-        const F rec[16] = {L.x + L.y, T0.x + T0.y, T1.x + T1.y, T2.x + T2.y, W00.x + W00.y, W01.x + W01.y, W02.x + W02.y, W11.x + W11.y,
+        for (int j = 0; j + 1 < ML - 1; j += 2)
+            body(v2{px[j], px[j + 1]}, v2{py[j], py[j + 1]}, v2{c.leafRf[j], c.leafRf[j + 1]}, v2{c.leafRho[j], c.leafRho[j + 1]});
+        if ((ML - 1) & 1) body(v2{px[ML - 2], px[ML - 2]}, v2{py[ML - 2], py[ML - 2]}, v2{c.leafRf[ML - 2], F(0)}, v2{c.leafRho[ML - 2], F(0)});
+        const F Lsum = L.x + L.y;
+        const bool usable = sums_ok && sv_abs(Lsum) < F(__builtin_inff());
+        const F rec[16] = {Lsum, T0.x + T0.y, T1.x + T1.y, T2.x + T2.y, W00.x + W00.y, W01.x + W01.y, W02.x + W02.y, W11.x + W11.y,
                            W12.x + W12.y, W22.x + W22.y, S1, S2, w0, u1, u2, LA.x + LA.y};
         c.W->par.put(c.lane, rec);
         c.W->pcode[c.lane] = code | (usable ? 0x80000000u : 0u);
@@ -543,8 +603,9 @@ __device__ __forceinline__ void sv_child_eval(const SvCtx<ML, F> &c, int lo, int
     const F q = sv_fma(x, u1, sv_fma(y, u2, w0));
     o.ev = o.act && o.regular && (o.code >> 31) && q > F(0);
     const F qs = o.ev ? q : F(1);                     // (lanes without a usable point compute on 1: no NaN factories)
-    const F w = sv_rcp(qs), t = Rl * w, tw = t * w, twx = tw * x, twy = tw * y;
-    const F lq = sv_lg2(qs);
+    F w, lq;
+    sv_rcp_lg2(qs, w, lq);
+    const F t = Rl * w, tw = t * w, twx = tw * x, twy = tw * y;
     const F L = sv_fma(Rl, lq, P[0]);
     const F T0 = P[1] + t, T1 = sv_fma(t, x, P[2]), T2 = sv_fma(t, y, P[3]);
     const F W00 = P[4] + tw, W01 = P[5] + twx, W02 = P[6] + twy;
@@ -562,7 +623,8 @@ __device__ __forceinline__ void sv_child_eval(const SvCtx<ML, F> &c, int lo, int
     const F d1 = (H22 * G1 - H12 * G2) * idet, d2 = (H11 * G2 - H12 * G1) * idet;
     const F l2 = (G1 * d1 + G2 * d2) * c.inv_Rtot;
     const F zs = cond_ok ? zw : F(1);
-    const F lz = sv_lg2(zs);
+    F sc, lz;
+    sv_rcp_lg2(zs, sc, lz);
     const F val2 = sv_fma(-c.rtot_f, lz, L);
     F la = F(0);
     if constexpr (sizeof(F) == 8) la = sv_fma(c.rtot_f, sv_abs(lz), sv_fma(Rl, sv_abs(lq), P[15]));
@@ -571,7 +633,6 @@ __device__ __forceinline__ void sv_child_eval(const SvCtx<ML, F> &c, int lo, int
     F step = F(1);
     if (ballot64(l2 > F(0.09))) step = l2 > F(0.09) ? sv_rcp(F(1) + sl) : F(1);      // (damped phase: rare, the branch is wave-uniform)
     // the stepped point on the child's own slice (z.d = 0, so z.w stays): mixture n_j = s_j u_j / z.w
-    const F sc = sv_rcp(zs);
     const F v1 = sv_fma(step, d1, u1) * sc, v2 = sv_fma(step, d2, u2) * sc;
     const bool good = o.ev && cond_ok && num_ok;
     o.n1 = s1 * v1;
@@ -871,11 +932,12 @@ __global__ __launch_bounds__(64 * SV_WAVES, sizeof(F) == 4 ? SV_OCC : SV_OCC64) 
     for (int l = 0; l < ML; l++) {
         leafR[l] = Pg.r[D + l];                        // (uniform address: scalar loads)
         c.leafRf[l] = (F)leafR[l];
+        c.leafRho[l] = (F)sqrt(leafR[l]);
         c.leafN[l] = (F)(Pg.rN[D + l] * inv_N);
     }
     if (lane == 0) {
 #pragma unroll
-        for (int l = 0; l < ML; l += 2) c.W->fRL[l >> 1] = Sv2<F>{(F)leafR[l], (F)leafR[l + 1]};
+        for (int l = 0; l < ML; l += 2) c.W->fRL[l >> 1] = SvWt<F>::make((F)leafR[l], (F)leafR[l + 1], sqrt(leafR[l]), sqrt(leafR[l + 1]));
     }
     unsigned long long n_terms = 0, n_pterms = 0;
 
@@ -941,6 +1003,10 @@ __global__ __launch_bounds__(64 * SV_WAVES, sizeof(F) == 4 ? SV_OCC : SV_OCC64) 
                     } else {   // also fills the second half: stays as the weight-0 pad when this is the last term
                         xy[0] = xy[1] = a; xy[2] = xy[3] = b; rr[0] = (F)Rs; rr[1] = F(0);
                     }
+                    if constexpr (sizeof(F) == 8) {
+                        rr[2 + (G & 1)] = sqrt(Rs);
+                        if (!(G & 1)) rr[3] = 0.0;
+                    }
                 }
                 S1p += (double)a * Ns;
                 S2p += (double)b * Ns;
@@ -989,18 +1055,19 @@ __global__ __launch_bounds__(64 * SV_WAVES, sizeof(F) == 4 ? SV_OCC : SV_OCC64) 
         }
     }
     if (lane == 0) {
-        atomicAdd(&A.ctr->evaluated, (unsigned long long)c.done);
-        atomicAdd(&A.ctr->iterations, (unsigned long long)c.n_child + c.n_dit);
-        atomicAdd(&A.ctr->terms, n_terms);
-        atomicAdd(&A.ctr->sieve_pterms, n_pterms);
-        atomicAdd(&A.ctr->sieve_children, (unsigned long long)c.n_child);
+        SearchCounters *sc = stat_slot(A);       // (one of 64 copies: a quarter of a million waves adding to one cache line serialise)
+        atomicAdd(&sc->evaluated, (unsigned long long)c.done);
+        atomicAdd(&sc->iterations, (unsigned long long)c.n_child + c.n_dit);
+        atomicAdd(&sc->terms, n_terms);
+        atomicAdd(&sc->sieve_pterms, n_pterms);
+        atomicAdd(&sc->sieve_children, (unsigned long long)c.n_child);
 #ifdef SV_PROF
         c.pt[5] = __builtin_amdgcn_s_memtime() - pw0;
-        for (int i = 0; i < 7; i++) atomicAdd(&A.ctr->prof[i], c.pt[i]);
+        for (int i = 0; i < 7; i++) atomicAdd(&sc->prof[i], c.pt[i]);
 #else
-        atomicAdd(&A.ctr->prof[0], (unsigned long long)c.n_par);
+        atomicAdd(&sc->prof[0], (unsigned long long)c.n_par);
 #endif
-        atomicAdd(&A.ctr->prof[7], (unsigned long long)c.n_prefix);
+        atomicAdd(&sc->prof[7], (unsigned long long)c.n_prefix);
     }
 }
 
