@@ -9,6 +9,8 @@ column.  Runs only in the build container (needs /root/reference).  Data only is
     python tests/golden/make_golden_campaign.py second       # best_campaign2.json (seeds 7001.., larger spaces: up to 60 000 / 200 000)
     python tests/golden/make_golden_campaign.py third        # best_campaign3.json (seeds 8001.., n=3, the low-coverage shape + mid)
     python tests/golden/make_golden_campaign.py fourth       # best_campaign4.json (whole spaces with full-rank NaN outcomes, tools/nan_hunt.py)
+    python tests/golden/make_golden_campaign.py fifth        # best_campaign5.json (seeds 9001.., n=3, bounds from the reference's own heuristic
+                                                             #   on counts with a strongly amplified interval: copy numbers 8 - 10)
 """
 import json
 import multiprocessing as mp
@@ -69,6 +71,17 @@ def main():
         for seed, n, shape in FOURTH["list"] + [(int(a), 3, "mid") for a in sys.argv[2:]]:
             inst = campaign.instance(seed, n, shape)
             inst["count"] = int(campaign.count_candidates(inst))
+            insts.append(inst)
+    if len(sys.argv) > 1 and sys.argv[1] == "fifth":
+        out_name, want_tab = "best_campaign5.json", {}
+        seed = 9000
+        while len(insts) < 14:
+            seed += 1
+            inst = campaign.instance(seed, 3, "amp")
+            cnt = campaign.count_candidates(inst)
+            if max(inst["ub"]) < 8 or cnt > 70000:
+                continue
+            inst["count"] = int(cnt)
             insts.append(inst)
     for (n, shape), want in want_tab.items():
         seed, got = seed0, 0

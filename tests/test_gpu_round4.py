@@ -67,3 +67,49 @@ def test_n2_dismissal_by_the_lower_bound_changes_no_finalist(ctx):
             if e - b > 1 << 20 and "low" not in name:
                 assert q["stats"]["dismissed"] > 0.9 * (e - b), (name, q["stats"]["dismissed"], e - b)
         p.close()
+
+
+def test_copy_numbers_above_seven_enumerate_in_the_reference_order_and_search_like_the_oracle(ctx):
+    """
+    The reference's own bounds heuristic exceeds k (DataTools.py:64-66: ub = max(k, y + 1), y = round(tau ratio)): an interval at
+    several times the normal ratio has bounds like [7, 9].  Such a search used to be refused (a row mask is one 64-bit word and the
+    alphabet was the grid (K+1)^2); now the alphabet is the valid rows that lie within the bounds of SOME interval, in grid order
+    (csrc/n3_core.hpp).  Enumeration order against the oracle's generator (Enumerator.py:172-242), the count, `best` against the
+    oracle's port of the driver; and what still is refused says so.
+    """
+    import warnings
+    import theta_amd
+    import theta_oracle as orc
+    from theta_amd.search import do_optimization_single
+    done = 0
+    for seed in range(9001, 9060):
+        inst = campaign.instance(seed, 3, "amp")
+        cnt = campaign.count_candidates(inst)
+        if max(inst["ub"]) < 8 or cnt > 6000:
+            continue
+        p = theta_amd.Problem(ctx, 3, inst["m"], inst["tau"], inst["r"], inst["rN"], inst["lb"], inst["ub"], 1.0)
+        assert p.count == cnt
+        got = p.enumerate(0, cnt)
+        ref = np.array([[[int(a), int(b)] for a, b in rows] for rows in orc.enumerate_n3(inst["m"], inst["tau"], list(inst["lb"]), list(inst["ub"]))], np.uint8)
+        assert got.shape == ref.shape and np.array_equal(got, ref), seed
+        # rank ranges in the middle of the space (unranking through the counting table)
+        mid = p.enumerate(cnt // 3, 100)
+        assert np.array_equal(mid, ref[cnt // 3: cnt // 3 + 100])
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            want, _ = orc.search_single(3, inst["m"], inst["tau"], list(inst["lb"]), list(inst["ub"]), inst["r"], inst["rN"], 1.0, inst["order"])
+        best = do_optimization_single(3, inst["m"], inst["k"], inst["tau"], list(inst["lb"]), list(inst["ub"]), inst["r"], inst["rN"], 1.0,
+                                      inst["order"])
+        assert campaign.compare_best(campaign.best_to_plain(best), campaign.best_to_plain(want)) == "", seed
+        p.close()
+        done += 1
+        if done >= 3:
+            break
+    assert done == 3
+    # full bounds [0, 9] on every interval leave 72 valid rows: more than the kernels hold -- refused with a message, not a crash
+    r, rN = inst["r"], inst["rN"]
+    with pytest.raises(theta_amd.ThetaError) as e:
+        theta_amd.Problem(ctx, 3, inst["m"], 2, r, rN, [0] * inst["m"], [9] * inst["m"], 1.0)
+    assert "distinct rows" in str(e.value)
+    with pytest.raises(theta_amd.ThetaError):
+        theta_amd.Problem(ctx, 3, inst["m"], 2, r, rN, [0] * inst["m"], [16] * inst["m"], 1.0)

@@ -144,7 +144,8 @@ def test_oracle_driver_matches_reference_best_lists_on_campaign_fixtures():
     cases = [c for c in load_json("best_campaign.json")["cases"] if c["count"] <= (600 if c["n"] == 3 else 6000)]
     cases += [c for c in load_json("best_campaign2.json")["cases"] if c["n"] == 2 and c["count"] <= 6000]     # (the second set: larger spaces)
     cases += sorted(load_json("best_tau.json")["cases"], key=lambda c: c["count"])[:8]                        # (n=3 under tau = 1 and 3)
-    assert len(cases) >= 30
+    cases += sorted(load_json("best_campaign5.json")["cases"], key=lambda c: c["count"])[:1]                  # (copy numbers above 7: bounds of the reference's own heuristic)
+    assert len(cases) >= 31 and max(max(c["ub"]) for c in cases) >= 8
     n_nan = 0
     for c in cases:
         with warnings.catch_warnings():

@@ -329,7 +329,12 @@ extern "C" int theta_problem_create(theta_ctx *ctx, int n, int m, int tau, const
         memcpy(small.data() + 2 * m + h.ridx.size(), h.rowtab.data(), h.rowtab.size());
         TRY(upload(p->d_small, small.data(), small.size(), st));
         TRY(upload(p->d_smask, h.smask.data(), h.smask.size() * sizeof(unsigned long long), st));
-        TRY(upload(p->d_dynmask, h.dynmask.data(), h.dynmask.size() * sizeof(unsigned long long), st));
+        {   // the ratio masks, and behind them the full ratio-rank table once more (n3_sieve.hip reads it there: sv_child_dyn)
+            std::vector<unsigned long long> dm(h.dynmask.size() + (h.ridx.size() + 7) / 8, 0ull);
+            memcpy(dm.data(), h.dynmask.data(), h.dynmask.size() * sizeof(unsigned long long));
+            memcpy(dm.data() + h.dynmask.size(), h.ridx.data(), h.ridx.size());
+            TRY(upload(p->d_dynmask, dm.data(), dm.size() * sizeof(unsigned long long), st));
+        }
         N3Dev &D = p->n3;
         D.m = m;
         D.K = h.K;

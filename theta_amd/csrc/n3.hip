@@ -40,18 +40,40 @@ int n3_build_host(int m, int tau, const int32_t *lb_in, const int32_t *ub_in, N3
         }
         top = std::max(top, h.ub[i]);
     }
-    if (top > N3_MAX_K) {
-        theta_set_error("n=3 search supports copy numbers up to %d (max upper bound is %d)", N3_MAX_K, top);
+    if (top > N3_MAX_COPY) {
+        theta_set_error("n=3 search supports copy numbers up to %d (max upper bound is %d)", N3_MAX_COPY, top);
         return THETA_ERR_ARG;
     }
     h.K = top;                    // Enumerator.py:58: k = max(upper_bound)
-    h.Q = (top + 1) * (top + 1);
-    // distinct values of dy/(-dx), dx,dy in +-[1..K], sorted ascending; compared by cross-multiplication
+    // The row alphabet (n3_core.hpp): the whole grid up to K = 7; beyond, the valid rows within the bounds of some interval,
+    // in grid order (a fastest: the order of Enumerator._create_graph, Enumerator.py:272-298).
+    const int K1g = top + 1;
+    std::vector<int> rows_a, rows_b;
+    for (int s = 0; s < K1g * K1g; s++) {
+        const int a = s % K1g, b = s / K1g;
+        bool use = top <= N3_GRID_K;
+        if (!use && n3_valid_row(a, b, tau))
+            for (int i = 0; i < m && !use; i++) use = a >= h.lb[i] && a <= h.ub[i] && b >= h.lb[i] && b <= h.ub[i];
+        if (use) {
+            rows_a.push_back(a);
+            rows_b.push_back(b);
+        }
+    }
+    if ((int)rows_a.size() > N3_MAX_Q) {
+        theta_set_error("n=3 search with copy numbers up to %d: %d distinct rows (a, b) lie within the bounds of some interval, the "
+                        "kernels hold %d", top, (int)rows_a.size(), N3_MAX_Q);
+        return THETA_ERR_ARG;
+    }
+    h.Q = (int)rows_a.size();
+    // distinct values of dy/(-dx) over the differences of two rows of the alphabet, sorted ascending; compared by cross-multiplication
     struct Fr { int n, d; };
     std::vector<Fr> fr;
-    for (int dx = -top; dx <= top; dx++)
-        for (int dy = -top; dy <= top; dy++) {
-            if (dx == 0 || dy == 0) continue;
+    std::vector<unsigned char> seen(N3_RIDX_W * N3_RIDX_W, 0);
+    for (int p = 0; p < h.Q; p++)
+        for (int s = 0; s < h.Q; s++) {
+            const int dx = rows_a[s] - rows_a[p], dy = rows_b[s] - rows_b[p];
+            if (dx == 0 || dy == 0 || seen[(dy + N3_MAX_COPY) * N3_RIDX_W + (dx + N3_MAX_COPY)]) continue;
+            seen[(dy + N3_MAX_COPY) * N3_RIDX_W + (dx + N3_MAX_COPY)] = 1;
             int n = dy, d = -dx;
             if (d < 0) { n = -n; d = -d; }
             fr.push_back({n, d});
@@ -68,28 +90,28 @@ int n3_build_host(int m, int tau, const int32_t *lb_in, const int32_t *ub_in, N3
     h.ridx.assign(N3_RIDX_W * N3_RIDX_W, 0);
     for (int dx = -top; dx <= top; dx++)
         for (int dy = -top; dy <= top; dy++) {
-            if (dx == 0 || dy == 0) continue;
+            if (dx == 0 || dy == 0 || !seen[(dy + N3_MAX_COPY) * N3_RIDX_W + (dx + N3_MAX_COPY)]) continue;
             Fr v{dy, -dx};
             if (v.d < 0) { v.n = -v.n; v.d = -v.d; }
             int idx = (int)(std::lower_bound(fr.begin(), fr.end(), v, less) - fr.begin());
-            h.ridx[(dy + N3_MAX_K) * N3_RIDX_W + (dx + N3_MAX_K)] = (unsigned char)(idx + 1);
+            h.ridx[(dy + N3_MAX_COPY) * N3_RIDX_W + (dx + N3_MAX_COPY)] = (unsigned char)(idx + 1);
         }
     // slot -> row; for every depth d and parent row the set of rows that may follow it by the static rules
     // (valid row, bounds of depth d, Enumerator._is_valid_edge); and for every (parent row, lo, hi) the set of
     // rows that keep the ratio window non-empty (Enumerator._get_mu_bounds + the lo <= hi test, :204-212).
-    const int K1 = top + 1, NT1 = h.NT + 1;
+    const int NT1 = h.NT + 1;
     h.rowtab.assign(h.Q, 0);
     for (int s = 0; s < h.Q; s++) {
-        int a = s % K1, b = s / K1;
+        const int a = rows_a[s], b = rows_b[s];
         h.rowtab[s] = (unsigned char)(a | (b << 4));
         if (a <= b) h.swmask |= 1ull << s;
     }
     h.smask.assign((size_t)m * N3_MAX_Q, 0ull);
     for (int d = 0; d < m; d++)
         for (int ps = 0; ps < h.Q; ps++) {
-            int pa = ps % K1, pb = ps / K1;
+            int pa = rows_a[ps], pb = rows_b[ps];
             for (int s = 0; s < h.Q; s++) {
-                int a = s % K1, b = s / K1;
+                int a = rows_a[s], b = rows_b[s];
                 bool ok = n3_valid_row(a, b, tau) && a >= h.lb[d] && a <= h.ub[d] && b >= h.lb[d] && b <= h.ub[d] &&
                           (s == ps || a > pa || b > pb);
                 if (ok) h.smask[(size_t)d * N3_MAX_Q + ps] |= 1ull << s;
@@ -97,16 +119,16 @@ int n3_build_host(int m, int tau, const int32_t *lb_in, const int32_t *ub_in, N3
         }
     h.dynmask.assign((size_t)h.Q * NT1 * NT1, 0ull);
     for (int ps = 0; ps < h.Q; ps++) {
-        int pa = ps % K1, pb = ps / K1;
+        int pa = rows_a[ps], pb = rows_b[ps];
         for (int lo = 0; lo <= h.NT; lo++)
             for (int hi = 1; hi <= h.NT + 1; hi++) {
                 if (lo > hi) continue;
                 unsigned long long mk = 0;
                 for (int s = 0; s < h.Q; s++) {
-                    int dx = s % K1 - pa, dy = s / K1 - pb;
+                    int dx = rows_a[s] - pa, dy = rows_b[s] - pb;
                     int l2 = lo, h2 = hi;
                     if (dx != 0 && dy != 0) {
-                        int t = h.ridx[(dy + N3_MAX_K) * N3_RIDX_W + (dx + N3_MAX_K)];
+                        int t = h.ridx[(dy + N3_MAX_COPY) * N3_RIDX_W + (dx + N3_MAX_COPY)];
                         if (dx > 0) l2 = std::max(lo, t); else h2 = std::min(hi, t);
                     }
                     if (l2 <= h2) mk |= 1ull << s;
@@ -134,7 +156,7 @@ __global__ __launch_bounds__(256) void n3_dp_kernel(N3Dev P, u128 *cnt, int d, u
         if (d == P.m - 1) {
             sum = 1;
         } else {
-            N3State par{slot, sw, lo, hi, slot % (P.K + 1), slot / (P.K + 1)}, ch;
+            N3State par{slot, sw, lo, hi, (int)(P.rowtab[slot] & 15u), (int)(P.rowtab[slot] >> 4)}, ch;
             for (int c = 0; c < P.Q; c++) {
                 if (n3_edge(P, par, c, d + 1, ch)) {
                     u128 v = cnt[n3_cnt_index(P, d + 1, ch.slot, ch.sw, ch.lo, ch.hi)];
@@ -192,7 +214,8 @@ __device__ bool n3_unrank(const N3Dev &P, u128 rho, int depth, N3State *st, u128
 // the wave then scans the feasible children in slot order.  Lane d ends up holding the packed node of depth d.
 // (depth <= 128: lane d holds the node of depth d in st_out, and that of depth 64 + d in st_out1)
 __device__ bool n3_unrank_wave(const N3Dev &P, u128 rho, int depth, int lane, unsigned &st_out, unsigned &st_out1, u128 &rem) {
-    const int K1 = P.K + 1, sa = lane % K1, sb = lane / K1;
+    const unsigned myrow = lane < P.Q ? P.rowtab[lane] : 0u;       // one alphabet slot per lane
+    const int sa = (int)(myrow & 15u), sb = (int)(myrow >> 4);
     N3State par{0, 0, 0, 0, 0, 0};
     st_out = 0u;
     st_out1 = 0u;
@@ -513,6 +536,7 @@ __global__ __launch_bounds__(64 * N3_WAVES, N3_OCC) void n3_search_kernel(N3Dev 
     P.lb = S.lb;
     P.ub = S.ub;
     P.ridx = S.ridx;
+    P.rowtab = S.rowtab;
 
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int task = blockIdx.x * N3_WAVES + wv;
@@ -533,8 +557,8 @@ __global__ __launch_bounds__(64 * N3_WAVES, N3_OCC) void n3_search_kernel(N3Dev 
 
     // lane i holds interval i; lane s (+64) also stands for alphabet slot s in the prefix successor
     unsigned st = lane < D ? stbuf[(size_t)task * N3_STB + lane] : 0u;
-    const int K1 = P.K + 1;
-    const int sa0 = lane % K1, sb0 = lane / K1, sa1 = (lane + WAVE) % K1, sb1 = (lane + WAVE) / K1;
+    const unsigned myrow0 = lane < P.Q ? P.rowtab[lane] : 0u;      // one alphabet slot per lane (Q <= 64: the second never exists)
+    const int sa0 = (int)(myrow0 & 15u), sb0 = (int)(myrow0 >> 4), sa1 = 0, sb1 = 0;
 
     const N3Task tk = tasks[task];
     const u128 base = ((u128)tk.base_hi << 64) | tk.base_lo;
@@ -1370,6 +1394,7 @@ __global__ __launch_bounds__(64 * N3_WAVES) void n3_enumerate_wave_kernel(N3Dev 
     P.lb = S.lb;
     P.ub = S.ub;
     P.ridx = S.ridx;
+    P.rowtab = S.rowtab;
 
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int task = blockIdx.x * N3_WAVES + wv;
@@ -1378,8 +1403,8 @@ __global__ __launch_bounds__(64 * N3_WAVES) void n3_enumerate_wave_kernel(N3Dev 
     const unsigned long long swm = Pg.swmask;
     const int NT1 = Pg.NT + 1;
     unsigned st = lane < D ? stbuf[(size_t)task * N3_STB + lane] : 0u;
-    const int K1 = P.K + 1;
-    const int sa0 = lane % K1, sb0 = lane / K1, sa1 = (lane + WAVE) % K1, sb1 = (lane + WAVE) / K1;
+    const unsigned myrow0 = lane < P.Q ? P.rowtab[lane] : 0u;      // one alphabet slot per lane (Q <= 64: the second never exists)
+    const int sa0 = (int)(myrow0 & 15u), sb0 = (int)(myrow0 >> 4), sa1 = 0, sb1 = 0;
     const N3Task tk = tasks[task];
     unsigned long long remaining = tk.count, skip = tk.skip, processed = 0;
     const size_t RS = (size_t)m * 2;                                      // bytes per candidate

@@ -4,16 +4,24 @@
 #pragma once
 #include "common.hpp"
 
-#define N3_MAX_K 7               // largest copy number in an n=3 search: the alphabet (K+1)^2 <= 64 fits one mask word
-#define N3_MAX_Q ((N3_MAX_K + 1) * (N3_MAX_K + 1))
+// The row alphabet of an n=3 search holds at most 64 rows (a, b): a child mask is one 64-bit word, an alphabet slot is one lane.
+// Up to K = 7 the alphabet is the whole grid (K+1)^2 (slot = a + (K+1) b, rows the reference's _is_valid_row rejects included,
+// masked out).  Beyond -- the reference's own bounds heuristic produces ub = max(k, y + 1) with y = round(tau ratio),
+// DataTools.py:64-66: an interval at four times the normal ratio has ub = 9 -- the alphabet is COMPACT: the valid rows that lie
+// within the bounds of at least one interval, in grid order (the order of Enumerator._create_graph, Enumerator.py:272-298, so
+// that the enumeration order is unchanged).  Such instances have narrow per-interval windows (lb = max(tau, y - 1)): a search
+// whose bounds leave more than 64 usable rows is refused.  Copy numbers themselves go up to 15 (4-bit fields of a packed node).
+#define N3_MAX_COPY 15
+#define N3_GRID_K 7              // up to this K the alphabet is the full grid
+#define N3_MAX_Q 64
 #define N3_MAX_M 64              // one interval per lane (fused kernel, generators)
 #define N3_MAX_M_WIDE 128        // two intervals per lane: the sieve path (n3_sieve.hip), task and unrank kernels
 #define N3_STB 128               // stride of the per-task prefix states (one packed DFS node per depth)
-#define N3_RIDX_W (2 * N3_MAX_K + 1)
+#define N3_RIDX_W (2 * N3_MAX_COPY + 1)
 
 // Wave-uniform description of one n=3 search instance.
 struct N3Dev {
-    int m, K, Q, tau;            // Q = (K+1)^2 grid slots; slot s <-> row (a, b) = (s % (K+1), s / (K+1))
+    int m, K, Q, tau;            // Q alphabet slots; slot s <-> row (a, b) through rowtab (K <= 7: the grid, a = s % (K+1), b = s / (K+1))
     int NT;                      // number of distinct finite ratio values; lo in [0..NT], hi in [1..NT+1]
     int L;                       // levels enumerated by lanes (leaf levels); D = m - L prefix levels
     double N, Rtot, K0;
@@ -105,8 +113,8 @@ __host__ __device__ inline bool n3_first_row_ab(const N3Dev &P, int a, int b, in
     return true;
 }
 __host__ __device__ inline bool n3_first_row(const N3Dev &P, int slot, N3State &out) {
-    int K1 = P.K + 1;
-    return n3_first_row_ab(P, slot % K1, slot / K1, slot, out);
+    const unsigned rw = P.rowtab[slot];
+    return n3_first_row_ab(P, (int)(rw & 15u), (int)(rw >> 4), slot, out);
 }
 
 // One DFS edge (Enumerator.py:192-212): may row (a, b) at depth d follow state `par`?
@@ -124,7 +132,7 @@ __host__ __device__ inline bool n3_edge_ab(const N3Dev &P, const N3State &par, i
     int lo = par.lo, hi = par.hi;
     int dx = a - pa, dy = b - pb;
     if (dx != 0 && dy != 0) {                                      // _get_mu_bounds, :225-239
-        int t = P.ridx[(dy + N3_MAX_K) * N3_RIDX_W + (dx + N3_MAX_K)];
+        int t = P.ridx[(dy + N3_MAX_COPY) * N3_RIDX_W + (dx + N3_MAX_COPY)];
         if (dx > 0) lo = (t > lo) ? t : lo; else hi = (t < hi) ? t : hi;
     }
     if (lo > hi) return false;                                     // :212
@@ -137,8 +145,8 @@ __host__ __device__ inline bool n3_edge_ab(const N3Dev &P, const N3State &par, i
     return true;
 }
 __host__ __device__ inline bool n3_edge(const N3Dev &P, const N3State &par, int slot, int d, N3State &out) {
-    int K1 = P.K + 1;
-    return n3_edge_ab(P, par, slot % K1, slot / K1, slot, d, out);
+    const unsigned rw = P.rowtab[slot];
+    return n3_edge_ab(P, par, (int)(rw & 15u), (int)(rw >> 4), slot, d, out);
 }
 
 #ifdef __HIPCC__
@@ -167,7 +175,7 @@ __device__ __forceinline__ bool n3_child_dyn(const unsigned char *ridx, const un
     int lo = par.lo, hi = par.hi;
     int dx = a - par.a, dy = b - par.b;
     if (dx != 0 && dy != 0) {
-        int t = ridx[(dy + N3_MAX_K) * N3_RIDX_W + (dx + N3_MAX_K)];
+        int t = ridx[(dy + N3_MAX_COPY) * N3_RIDX_W + (dx + N3_MAX_COPY)];
         if (dx > 0) lo = (t > lo) ? t : lo; else hi = (t < hi) ? t : hi;
     }
     out.slot = slot;

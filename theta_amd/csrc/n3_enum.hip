@@ -249,8 +249,9 @@ __device__ __forceinline__ unsigned eb_state(unsigned st0, unsigned st1, int d) 
     return (unsigned)__builtin_amdgcn_readlane((int)(d < WAVE ? st0 : st1), d & (WAVE - 1));
 }
 __device__ __forceinline__ bool eb_next_prefix(const N3Dev &P, unsigned &st0, unsigned &st1, int D, int lane) {
-    const int K1 = P.K + 1, Q = P.Q;
-    const int sa = lane % K1, sb = lane / K1;          // Q <= 64: one alphabet slot per lane
+    const int Q = P.Q;
+    const unsigned myrow = lane < Q ? P.rowtab[lane] : 0u;          // Q <= 64: one alphabet slot per lane
+    const int sa = (int)(myrow & 15u), sb = (int)(myrow >> 4);
     int d = D - 1;
     bool fresh = false;
     while (true) {
@@ -302,6 +303,7 @@ __global__ __launch_bounds__(64 * EB_WAVES, (ML <= 4 ? EB_OCC4 : EB_OCC6)) void 
     P.lb = S.lb;
     P.ub = S.ub;
     P.ridx = S.ridx;
+    P.rowtab = S.rowtab;
 
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int task = blockIdx.x * EB_WAVES + wv;

@@ -170,12 +170,17 @@ struct SvWave {
                                                         // whole wave at every push
     F qU1[SV_QCAP], qU2[SV_QCAP];                       // ... the iterate it continues from
 };
+// The ratio-rank table in LDS covers differences up to 7 copies: all there is up to K = 7, and nearly all beyond (the compact
+// alphabet of a K > 7 search holds a few far-apart rows); the rest is read from the full table in HBM, which api.hip keeps behind
+// the ratio masks (`dynmask`) so that the wave needs no pointer of its own for it.  (The full 31 x 31 table in LDS costs the float
+// instantiation its third block per CU: 36 -> 45 ms per 2^31 candidates.)
+#define SV_RIDX_W 15
 template <int ML, class F>
 struct SvLds {
     SvWave<ML, F> w[SV_WAVES];
     unsigned long long smask[ML][N3_MAX_Q];             // static child masks of the ML last depths
     unsigned char lb[N3_MAX_M_WIDE], ub[N3_MAX_M_WIDE];
-    unsigned char ridx[N3_RIDX_W * N3_RIDX_W + 3];
+    unsigned char ridx[SV_RIDX_W * SV_RIDX_W + 3];       // the central part of the ratio-rank table (|dx|, |dy| <= 7), see sv_child_dyn
     unsigned char rowtab[N3_MAX_Q + 3];
     unsigned short row16[N3_MAX_Q];                     // slot -> a | b << 8
 };
@@ -705,6 +710,30 @@ __device__ __forceinline__ void sv_children(SvCtx<ML, F> &c, int total) {
     c.remaining -= (unsigned)nrec;
 }
 
+// n3_child_dyn (n3_core.hpp) on the sieve's tables: the dynamic part of the edge test for a child that passed the masks
+template <int ML, class F>
+__device__ __forceinline__ bool sv_child_dyn(const SvCtx<ML, F> &c, const N3State &par, int slot, N3State &out) {
+    const unsigned rw = c.S->rowtab[slot];
+    const int a = rw & 15, b = rw >> 4;
+    int lo = par.lo, hi = par.hi;
+    const int dx = a - par.a, dy = b - par.b;
+    if (dx != 0 && dy != 0) {
+        int t;
+        if ((unsigned)(dx + SV_RIDX_W / 2) < (unsigned)SV_RIDX_W && (unsigned)(dy + SV_RIDX_W / 2) < (unsigned)SV_RIDX_W)
+            t = c.S->ridx[(dy + SV_RIDX_W / 2) * SV_RIDX_W + (dx + SV_RIDX_W / 2)];
+        else      // (only in searches with copy numbers above 7)
+            t = ((const unsigned char *)(c.dynmask + (size_t)c.Q * c.NT1 * c.NT1))[(dy + N3_MAX_COPY) * N3_RIDX_W + (dx + N3_MAX_COPY)];
+        if (dx > 0) lo = (t > lo) ? t : lo; else hi = (t < hi) ? t : hi;
+    }
+    out.slot = slot;
+    out.sw = par.sw && (a == b);
+    out.lo = lo;
+    out.hi = hi;
+    out.a = a;
+    out.b = b;
+    return lo <= hi;
+}
+
 template <int ML, class F>
 __device__ __forceinline__ unsigned long long sv_child_mask(const SvCtx<ML, F> &c, const N3State &node, int l) {
     unsigned long long mk = c.S->smask[l][node.slot] & c.dynmask[((size_t)node.slot * c.NT1 + node.lo) * c.NT1 + (node.hi - 1)];
@@ -730,7 +759,7 @@ __device__ __forceinline__ void sv_expand(SvCtx<ML, F> &c, int n_in) {
                 const uint2 e = (LVL == 1) ? c.W->list0[i] : (LVL == ML - 1) ? c.W->listL[i] : c.W->list[LVL >= 2 && LVL < ML - 1 ? LVL - 2 : 0][i];
                 const N3State pst = n3_unpack(e.x);
                 const unsigned slot = e.y >> 24;
-                n3_child_dyn(c.S->ridx, c.S->rowtab, pst, (int)slot, node);
+                sv_child_dyn<ML, F>(c, pst, (int)slot, node);
                 code = (e.y & 0xffffffu) | (slot << (6 * (LVL > 0 ? LVL - 1 : 0)));
             }
         } else {
@@ -830,8 +859,9 @@ __device__ __forceinline__ unsigned sv_state(unsigned st0, unsigned st1, int d) 
     return (unsigned)__builtin_amdgcn_readlane((int)(d < WAVE ? st0 : st1), d & (WAVE - 1));
 }
 __device__ __forceinline__ bool sv_next_prefix(const N3Dev &P, unsigned &st0, unsigned &st1, int D, int lane) {
-    const int K1 = P.K + 1, Q = P.Q;
-    const int sa = lane % K1, sb = lane / K1;          // Q <= 64: one alphabet slot per lane
+    const int Q = P.Q;
+    const unsigned myrow = lane < Q ? P.rowtab[lane] : 0u;          // Q <= 64: one alphabet slot per lane
+    const int sa = (int)(myrow & 15u), sb = (int)(myrow >> 4);
     int d = D - 1;
     bool fresh = false;
     while (true) {
@@ -872,7 +902,8 @@ __global__ __launch_bounds__(64 * SV_WAVES, sizeof(F) == 4 ? SV_OCC : SV_OCC64) 
         S.lb[i] = Pg.lb[i];
         S.ub[i] = Pg.ub[i];
     }
-    for (int i = threadIdx.x; i < N3_RIDX_W * N3_RIDX_W; i += blockDim.x) S.ridx[i] = Pg.ridx[i];
+    for (int i = threadIdx.x; i < SV_RIDX_W * SV_RIDX_W; i += blockDim.x)
+        S.ridx[i] = Pg.ridx[(i / SV_RIDX_W - SV_RIDX_W / 2 + N3_MAX_COPY) * N3_RIDX_W + (i % SV_RIDX_W - SV_RIDX_W / 2 + N3_MAX_COPY)];
     for (int i = threadIdx.x; i < Q; i += blockDim.x) {
         const unsigned rw = Pg.rowtab[i];
         S.rowtab[i] = (unsigned char)rw;
@@ -883,7 +914,7 @@ __global__ __launch_bounds__(64 * SV_WAVES, sizeof(F) == 4 ? SV_OCC : SV_OCC64) 
     N3Dev P = Pg;
     P.lb = S.lb;
     P.ub = S.ub;
-    P.ridx = S.ridx;
+    P.rowtab = S.rowtab;               // (P.ridx stays the full table in HBM: the prefix successor reads it once per prefix)
 
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int task = blockIdx.x * SV_WAVES + wv;
