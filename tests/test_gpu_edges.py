@@ -86,13 +86,14 @@ def test_largest_shapes(ctx):
     k = int(np.argmin(res["nll"]))
     s = orc.solve_n2(orc.col_to_matrix_n2(res["C"][k], 2), rs, rNs, 1)
     assert s is not None and abs(s[1] - res["nll"][k]) <= 1e-9 * abs(s[1])
-    # n=3: m=64 with the full K=7 alphabet has more than 2^128 matrices -> a clean overflow error
+    # n=3: m=64 with the full K=7 alphabet has more than 2^128 matrices: the count saturates (round 4; such a space is a legal
+    # problem whose rank ranges below 2^128 are searched like any others -- tests/test_gpu_round4.py)
     m = 64
     r3 = [int(x) for x in rng.randint(1000, 5000, m)]
     rN3 = [int(x) for x in rng.randint(1000, 5000, m)]
-    with pytest.raises(theta_amd.ThetaError) as e:
-        theta_amd.Problem(ctx, 3, m, 2, r3, rN3, [0] * m, [7] * m)
-    assert e.value.code == theta_amd._lib.ERR_OVERFLOW
+    psat = theta_amd.Problem(ctx, 3, m, 2, r3, rN3, [0] * m, [7] * m)
+    assert psat.count == 2 ** 128 - 1
+    psat.close()
     # ... m=64, K=7 with rising lower bounds fits
     lb3 = [min(6, i // 9) for i in range(m)]
     ub3 = [min(7, v + 1) for v in lb3]
@@ -124,9 +125,11 @@ def test_ragged_bounds_and_capacity_growth(ctx):
     nll, mu_, st = p.values(0, p.count)
     assert len(big["rank"]) == int((~np.isnan(nll)).sum()) > 4
     assert big["rank"] == sorted(big["rank"])
-    assert np.array_equal(big["nll"], nll[~np.isnan(nll)])
+    # (the search starts a candidate's Newton iteration where its bound evaluation left it, the dump from the previous root: the
+    # same root to the last bits, not to the last bit)
+    assert np.allclose(big["nll"], nll[~np.isnan(nll)], rtol=1e-13, atol=0)
     zero = p.search(0, p.count, window=0.0)
-    assert len(zero["rank"]) >= 1 and zero["nll"].min() == np.nanmin(nll)
+    assert len(zero["rank"]) >= 1 and abs(zero["nll"].min() - np.nanmin(nll)) <= 1e-13 * abs(np.nanmin(nll))
 
 
 def test_tie_list_overflow_is_recovered(ctx):

@@ -113,3 +113,46 @@ def test_copy_numbers_above_seven_enumerate_in_the_reference_order_and_search_li
     assert "distinct rows" in str(e.value)
     with pytest.raises(theta_amd.ThetaError):
         theta_amd.Problem(ctx, 3, inst["m"], 2, r, rN, [0] * inst["m"], [16] * inst["m"], 1.0)
+
+
+def test_rank_ranges_of_a_space_beyond_2_to_the_128_are_searched_like_any_other(ctx):
+    """
+    m = 100, K = 7 with full bounds holds ~1e75 matrices: the counting table saturates at 2^128 - 1 ("that many or more") instead
+    of refusing the problem.  Every rank below 2^128 still resolves exactly (rank -> path takes the first child whose count
+    exceeds what is left of the rank; the counts below a task's prefix are small): the first candidates equal the oracle's
+    generator (Enumerator.py:172-242), and rank ranges at 2^40, 2^100 and 2^127 give the same lists from the sieve path and from
+    the fused kernel, the listed C being the candidates the generator materialises at those ranks.
+    """
+    import itertools
+    import bench
+    import theta_amd
+    import theta_oracle as orc
+    m, K = 100, 7
+    r, rN, _ = bench.synth(seed=21, m=m, n=3, k=6)
+    p = theta_amd.Problem(ctx, 3, m, 2, r, rN, [0] * m, [K] * m, 1.0)
+    assert p.count == 2 ** 128 - 1
+    first = p.enumerate(0, 3000)
+    ref = np.array([[[int(a), int(b)] for a, b in rows] for rows in itertools.islice(orc.enumerate_n3(m, 2, [0] * m, [K] * m), 3000)], np.uint8)
+    assert np.array_equal(first, ref)
+    def check(p, second):
+        for where in (1 << 40, (1 << 100) + 12345, (1 << 127) + (1 << 90)):
+            span = 1 << 22
+            a = p.search(where, where + span, window=0.5)
+            assert a["stats"]["evaluated"] == span
+            p.set_option(*second)
+            f = p.search(where, where + span, window=0.5)
+            p.set_option(second[0], 1 - second[1])
+            assert a["rank"] == f["rank"] and np.array_equal(a["C"], f["C"]) and np.allclose(a["nll"], f["nll"], rtol=1e-11, atol=0)
+            for rk, C in zip(a["rank"], a["C"]):
+                assert where <= rk < where + span and np.array_equal(p.enumerate(rk, 1)[0], C)
+            # consecutive ranks are distinct consecutive candidates, across a task boundary too
+            blk = p.enumerate(where + 8190, 4)
+            assert len({tuple(x.reshape(-1)) for x in blk}) == 4
+    check(p, ("n3_force_f64", 1))                        # 100 intervals: the sieve path in both arithmetics
+    p.close()
+    m = 64                                               # 64 intervals: the sieve path against the fused kernel
+    r, rN, _ = bench.synth(seed=22, m=m, n=3, k=6)
+    p = theta_amd.Problem(ctx, 3, m, 2, r, rN, [0] * m, [K] * m, 1.0)
+    assert p.count == 2 ** 128 - 1
+    check(p, ("n3_sieve", 0))
+    p.close()

@@ -168,6 +168,7 @@ struct theta_problem {
     int opt_nan_sweep = 0;             // n=3: after a search, every candidate of the range through the reference's own procedure; the ones it
                                        // reports with a NaN likelihood join the degenerate list (nan_sweep below; 2e8-5e8 candidates/s)
     int opt_sieve = 1;                 // n=3: sieve + finish kernels (n3_sieve.hip); 0 = the fused kernel of n3.hip only
+    bool count_saturated = false;      // n=3: the space holds 2^128 matrices or more (total = 2^128 - 1)
     unsigned opt_surv_cap = 0;         // n=3: contenders a slice may list before it counts as overflowed (0: SURV_CAP; smaller
                                        // values make the tests walk the redo ladder: sieve again -> 8 parts -> fused kernel)
     int device = 0;                                     // (= ctx->device: the destructor must not need the context)
@@ -383,10 +384,9 @@ extern "C" int theta_problem_create(theta_ctx *ctx, int n, int m, int tau, const
         HIP_TRY(hipGetLastError());
         unsigned hov;
         memcpy(&hov, hostmisc, 4);
-        if (hov) {
-            theta_set_error("n=3 candidate count exceeds 128 bits; tighten the bounds or shard by prefix");
-            return THETA_ERR_OVERFLOW;
-        }
+        // (a space of 2^128 matrices or more: the counting table saturates -- n3_dp_kernel -- and theta_problem_count reports
+        // 2^128 - 1, "at least that many"; the first 2^128 - 1 ranks of the reference's order are searched like any others)
+        p->count_saturated = hov != 0;
         memcpy(p->total, hostmisc + 16, 16);
         D.total_lo = p->total[0];
         D.total_hi = p->total[1];

@@ -159,9 +159,16 @@ __global__ __launch_bounds__(256) void n3_dp_kernel(N3Dev P, u128 *cnt, int d, u
             N3State par{slot, sw, lo, hi, (int)(P.rowtab[slot] & 15u), (int)(P.rowtab[slot] >> 4)}, ch;
             for (int c = 0; c < P.Q; c++) {
                 if (n3_edge(P, par, c, d + 1, ch)) {
+                    // SATURATING: a count of 2^128 - 1 stands for "that many or more".  rank -> path (n3_unrank) takes the first child
+                    // whose count exceeds what is left of the rank, so every rank below 2^128 of such a space resolves exactly -- the
+                    // counts that matter below a task's prefix are small --, and rank ranges of a space whose TOTAL overflows 128 bits
+                    // (m = 100, K = 7 with full bounds: 1e75 matrices) are searched like any other.  `overflow` only says it happened.
                     u128 v = cnt[n3_cnt_index(P, d + 1, ch.slot, ch.sw, ch.lo, ch.hi)];
                     u128 ns = sum + v;
-                    if (ns < sum) atomicOr(overflow, 1u);
+                    if (ns < sum || v == ~(u128)0) {
+                        atomicOr(overflow, 1u);
+                        ns = ~(u128)0;
+                    }
                     sum = ns;
                 }
             }
@@ -177,7 +184,10 @@ __global__ void n3_total_kernel(N3Dev P, unsigned long long *total, unsigned *ov
         if (n3_first_row(P, c, s)) {
             u128 v = P.cnt[n3_cnt_index(P, 0, s.slot, s.sw, s.lo, s.hi)];
             u128 ns = sum + v;
-            if (ns < sum) atomicOr(overflow, 1u);
+            if (ns < sum || v == ~(u128)0) {
+                atomicOr(overflow, 1u);
+                ns = ~(u128)0;
+            }
             sum = ns;
         }
     total[0] = (unsigned long long)sum;
