@@ -57,6 +57,11 @@ void theta_destroy(theta_ctx *ctx);
 const char *theta_last_error(void);
 /* name[cap] receives the device name; cu = compute units; hbm_bytes = total device memory.    */
 int theta_device_info(theta_ctx *ctx, char *name, int cap, int *cu, uint64_t *hbm_bytes);
+/* Platform check of the n=3 parity claim for RANK-DEFICIENT candidates: what the reference reports for those hangs on the last
+ * bit of numpy's `x ** 2` (Optimizer.py:303-311), i.e. of libm's pow(x, 2.0) under its interpreter; the kernels restate glibc >= 2.28
+ * on x86-64 with FMA (csrc/refpow.hpp).  mismatches = how many of n seeded arguments THIS host's pow(x, 2.0) squares differently
+ * (0 on the platform the parity was established on; no GPU needed). */
+int theta_refpow_check(int n, int *mismatches);
 /* hipDeviceSynchronize on the context's GPU (every entry point below already returns with its work finished). */
 int theta_synchronize(theta_ctx *ctx);
 

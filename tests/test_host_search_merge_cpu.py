@@ -130,3 +130,79 @@ def test_a_range_beyond_reach_is_refused_at_once():
         p.search(5, 5 + lim)
     with pytest.raises(_lib.ThetaError):
         p.search(5, 6 + lim)
+
+
+# ---- the recovery ladders (round-3 advice: none of them had a test) -------------------------------------------------------
+class _DegOverflowProblem(_FakeProblem):
+    """A piece longer than `limit` candidates holds more rank-deficient candidates than the device list."""
+    limit = 1 << 21
+
+    def _piece(self, b, e, window, cap, hint):
+        if e - b > self.limit:
+            self.calls.append((b, e, "overflow"))
+            raise _lib.DegenerateOverflow(_lib.ERR_CAPACITY, "rank-deficient candidates did not fit the device list")
+        return super()._piece(b, e, window, cap, hint)
+
+
+def test_a_piece_with_too_many_rank_deficient_candidates_is_halved(monkeypatch):
+    monkeypatch.setattr(_lib.Problem, "MAX_PER_CALL", {2: 1 << 23, 3: 1 << 23})
+    p = _DegOverflowProblem(3, 5, (1 << 24) + 5)
+    out = p.search(0, p.count, window=0.5)
+    walked = [(b, e) for b, e, h in p.calls if h != "overflow"]
+    assert walked[0][0] == 0 and walked[-1][1] == p.count
+    assert all(x[1] == y[0] for x, y in zip(walked, walked[1:]))                 # the halves in rank order, nothing twice, nothing lost
+    assert all(e - b <= _DegOverflowProblem.limit for b, e in walked)
+    assert out["stats"]["evaluated"] == p.count
+    # ... also in the second pass of a piece whose suspect list overflowed
+    p = _DegOverflowProblem(3, 5, 3 << 21, overflow_first_pass=(1 << 21,))
+    monkeypatch.setattr(_lib.Problem, "MAX_PER_CALL", {2: 1 << 21, 3: 1 << 21})
+    hints = iter([900.0])
+
+    orig = _FakeProblem._data
+
+    def falling(self, b, e):                                                      # (the last piece lowers the minimum: the overflowed one is redone)
+        res, sus, deg = orig(self, b, e)
+        if b == 2 << 21 and len(res["nll"]):
+            res["nll"] = res["nll"] - 50.0
+        return res, sus, deg
+    monkeypatch.setattr(_FakeProblem, "_data", falling)
+    out = p.search(0, p.count, window=0.5)
+    assert out["stats"]["evaluated"] == p.count
+
+
+def test_overflow_kinds_are_exceptions_and_the_driver_narrows_the_window_for_each(monkeypatch):
+    from theta_amd import search as S
+
+    class Narrow:
+        n, m, tau = 3, 4, 2
+        suspect_reruns = 0
+
+        def __init__(self, kind, fits_below):
+            self.kind, self.fits_below, self.windows = kind, fits_below, []
+
+        def search(self, begin, end, window=0.5):
+            self.windows.append(window)
+            if window > self.fits_below:
+                if self.kind == "degenerate":
+                    raise _lib.DegenerateOverflow(_lib.ERR_CAPACITY, "too many")
+                raise _lib.ListOverflow("too many", self.kind)
+            return {"rank": [], "nll": np.zeros(0), "mu": np.zeros((0, 3)), "C": np.zeros((0, 4, 2), np.uint8), "stats": {}}
+
+    for kind in ("ties", "suspects", "degenerate"):
+        rep = S.SearchReport()
+        prob = Narrow(kind, 0.06)
+        recs, stats = S.collect_finalists(prob, None, [1] * 4, [1] * 4, 1.0, 0, 10, report=rep)
+        assert prob.windows == [0.5, 0.05] and rep.window == 0.05 and recs == []
+        prob = Narrow(kind, 0.001)                                                # never fits: the third attempt's error comes out
+        with pytest.raises(_lib.ListOverflow) as e:
+            S.collect_finalists(prob, None, [1] * 4, [1] * 4, 1.0, 0, 10, report=S.SearchReport())
+        assert prob.windows == [0.5, 0.05, 0.01] and e.value.kind == kind and e.value.code == _lib.ERR_CAPACITY
+    # any other error is not retried
+    class Broken(Narrow):
+        def search(self, begin, end, window=0.5):
+            self.windows.append(window)
+            raise _lib.ThetaError(_lib.ERR_HIP, "device lost")
+    prob = Broken("ties", 0)
+    with pytest.raises(_lib.ThetaError):
+        S.collect_finalists(prob, None, [1] * 4, [1] * 4, 1.0, 0, 10)
+    assert prob.windows == [0.5]

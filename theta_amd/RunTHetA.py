@@ -104,6 +104,9 @@ def run_fixed_N(n, args, intervals, resultsfile=None):
         rep.candidates, rep.seconds, "the GPU" if getattr(rep, "gpus", 1) == 1 else "%d GPU ranks" % rep.gpus, rep.finalists,
         "" if rep.certificate_complete else "; suspect list overflowed: rerun with a tighter rank range (see DESIGN.md section 5)"))
 
+    if getattr(rep, "libm_pow_matches", None) is False:
+        print("NOTE: this host's libm rounds pow(x, 2) differently from the one the n=3 kernels restate (glibc >= 2.28, x86-64 with "
+              "FMA): the reference run HERE would report other values for rank-deficient candidate matrices (INTEGRATION.md section 5).")
     if n == 2 and best_near_max_contamination(best, max_normal):
         print("WARNING: At least one of the top solutions is near the upper bound on normal contamination. Further "
               "analysis may required (see --MAX_NORMAL and the expected copy number --TAU).")

@@ -21,8 +21,25 @@ class ThetaError(RuntimeError):
         self.code = code
 
 
-class DegenerateOverflow(ThetaError):
+class ListOverflow(ThetaError):
+    """A device list of one theta_search stayed too short although the library did what it could (three passes, a redo with the
+    range's minimum as hint).  `kind`: "ties" (finalists within the window), "suspects" (rejected candidates near the minimum) or
+    "degenerate" (rank-deficient candidates, see DegenerateOverflow).  All three shrink with the collection window: the driver
+    narrows it before it gives up (search.collect_finalists)."""
+    kind = "ties"
+
+    def __init__(self, msg, kind=None):
+        super().__init__(ERR_CAPACITY, msg)
+        if kind:
+            self.kind = kind
+
+
+class DegenerateOverflow(ListOverflow):
     """More rank-deficient candidates in one theta_search than its device list holds: Problem.search halves the piece."""
+    kind = "degenerate"
+
+    def __init__(self, code, msg):
+        ListOverflow.__init__(self, msg, "degenerate")
 
 
 class NoCandidates(ThetaError):
@@ -53,7 +70,7 @@ EXPORTS = ["theta_create", "theta_device_count", "theta_destroy", "theta_last_er
            "theta_search_degenerate", "theta_problem_set_option", "theta_synchronize",
            "theta_score_batch_rows", "theta_device_alloc", "theta_device_free", "theta_device_copy", "theta_solve_batch_device",
            "theta_score_masked_device",
-           "theta_comm_create", "theta_comm_destroy", "theta_comm_info", "theta_comm_barrier", "theta_comm_allreduce_min",
+           "theta_refpow_check", "theta_comm_create", "theta_comm_destroy", "theta_comm_info", "theta_comm_barrier", "theta_comm_allreduce_min",
            "theta_comm_allreduce_max", "theta_comm_allreduce_sum", "theta_comm_allgather", "theta_exchange_finalists"]
 
 
@@ -71,6 +88,7 @@ def load():
     lib.theta_last_error.restype = C.c_char_p
     lib.theta_create.argtypes = [i32, C.POINTER(vp)]
     lib.theta_device_count.argtypes = [C.POINTER(i32)]
+    lib.theta_refpow_check.argtypes = [i32, C.POINTER(i32)]
     lib.theta_destroy.argtypes = [vp]
     lib.theta_destroy.restype = None
     lib.theta_device_info.argtypes = [vp, C.c_char_p, i32, C.POINTER(i32), u64p]
@@ -125,6 +143,20 @@ def _p(arr, ctype):
 def _u128(v):
     v = int(v)
     return (C.c_uint64 * 2)(v & 0xFFFFFFFFFFFFFFFF, v >> 64)
+
+
+_pow_check = None
+
+
+def libm_pow_matches():
+    """True if this host's libm squares like the restatement the n=3 kernels carry (theta_refpow_check: glibc >= 2.28, x86-64 with
+    FMA) -- the platform on which `best` equals the reference's entry by entry also for rank-deficient n=3 candidates."""
+    global _pow_check
+    if _pow_check is None:
+        n = C.c_int()
+        _check(load().theta_refpow_check(200000, C.byref(n)))
+        _pow_check = n.value == 0
+    return _pow_check
 
 
 def device_count():
@@ -434,17 +466,17 @@ class Problem:
         """One theta_search call with its side lists: (result, suspects, suspects_dropped, degenerate)."""
         if hint < float("inf"):
             _check(load().theta_problem_hint(self._h, hint))
-        res = self._search_once(b, e, window, cap)
+        res = self._search_once(b, e, window, cap, hint)
         if res["stats"]["list_overflow"]:
             # the device tie list stayed full after the library's three passes: finalists were lost
-            raise ThetaError(ERR_CAPACITY, "%d finalists dropped by the device tie list in ranks [%d, %d): narrow the "
-                             "window or split the range" % (res["stats"]["list_overflow"], b, e))
+            raise ListOverflow("%d finalists dropped by the device tie list in ranks [%d, %d): narrow the "
+                               "window or split the range" % (res["stats"]["list_overflow"], b, e), "ties")
         if self.n != 3:
             return res, ([], np.zeros(0), None), 0, ([], None)
         sus = self.suspects()
         return res, sus, self.suspects_dropped, self.degenerate()
 
-    def search(self, begin=0, end=None, window=0.5, cap=4096):
+    def search(self, begin=0, end=None, window=0.5, cap=16384):       # (room for 16 384 finalists per piece up front: a retry for more runs the piece a second time)
         """
         Fused search over ranks [begin, end).  Returns dict(nll, mu, rank (python ints), C, stats).
         Ranges larger than one call can take are walked in pieces; the pieces' finalists are merged here
@@ -506,14 +538,25 @@ class Problem:
         self.suspect_reruns = 0
         for piece, b, e, hint_used, dropped in redo:
             if not running < hint_used:
-                raise ThetaError(ERR_CAPACITY, "n=3 suspect list overflowed in ranks [%d, %d) (%d entries dropped) although "
-                                 "the search started from the range's own minimum" % (b, e, dropped))
-            part = self._piece(b, e, window, cap, running)
-            self.suspect_reruns += 1
-            if part[2] > 0:
-                raise ThetaError(ERR_CAPACITY, "n=3 suspect list overflowed in ranks [%d, %d) (%d entries dropped) with "
-                                 "the minimum of the whole range as hint" % (b, e, part[2]))
-            acc.add(part, piece, running, window)
+                raise ListOverflow("n=3 suspect list overflowed in ranks [%d, %d) (%d entries dropped) although "
+                                   "the search started from the range's own minimum" % (b, e, dropped), "suspects")
+            # (the redone piece may itself hold more rank-deficient candidates than the device list: halved like in the walk above)
+            todo = [(b, e)]
+            while todo:
+                hb, he = todo.pop()
+                try:
+                    part = self._piece(hb, he, window, cap, running)
+                except DegenerateOverflow:
+                    if he - hb <= (1 << 20):
+                        raise
+                    mid = (hb + he) // 2
+                    todo += [(mid, he), (hb, mid)]
+                    continue
+                self.suspect_reruns += 1
+                if part[2] > 0:
+                    raise ListOverflow("n=3 suspect list overflowed in ranks [%d, %d) (%d entries dropped) with "
+                                       "the minimum of the whole range as hint" % (hb, he, part[2]), "suspects")
+                acc.add(part, piece, running, window)
         self.suspects_dropped = 0
         out, self.last_suspects, self.last_degenerate = acc.result(window)
         return out
@@ -551,7 +594,7 @@ class Problem:
                 running = min(running, float(res["nll"].min()))
         return running
 
-    def _search_once(self, begin, end, window, cap):
+    def _search_once(self, begin, end, window, cap, hint=float("inf")):
         st = SearchStats()
         while True:
             nll = np.zeros(cap)
@@ -564,6 +607,8 @@ class Problem:
                                      C.byref(st))
             if rc == ERR_CAPACITY and n_out.value > cap:
                 cap = n_out.value
+                if hint < float("inf"):        # the device hint is one-shot: the retry starts from the same minimum (round-3 advice)
+                    _check(load().theta_problem_hint(self._h, hint))
                 continue
             _check(rc)
             break

@@ -1192,7 +1192,9 @@ static int enumerate_device(theta_problem *p, u128 b, uint64_t count, unsigned c
     } else {
         // the burst generator (n3_enum.hip: one contiguous output stream per wave) cuts its tasks at its own depth
         N3Dev PE = p->n3;
-        const int burst_levels = getenv("THETA_ENUM_LEGACY") ? 0 : n3_enumerate_burst_levels(PE);
+        // (THETA_ENUM_LEGACY, the lane-private generator kept as a second implementation, holds N3_MAX_M intervals: wider
+        // problems -- also the internal callers, list_deficient and the NaN sweep -- always take the burst generator)
+        const int burst_levels = (getenv("THETA_ENUM_LEGACY") && p->m <= N3_MAX_M) ? 0 : n3_enumerate_burst_levels(PE);
         if (burst_levels > 0) PE.L = burst_levels;
         // wave tasks of 8192 candidates (0.8 MB of output at m=50): a 2^28 request is 32768 tasks, 6.4 x the 5120 resident
         // waves, so the last round of blocks leaves little of the chip idle (measured: 16384 is as good at K=6, worse at

@@ -832,3 +832,30 @@ void batch_launch_score_masked(int n, int m, int tau, int B, int S, const unsign
         }
     }
 }
+
+
+// ------------------------------------------------------------------------------------------------------------------
+// Does THIS machine's libm square like the restatement (refpow.hpp)?  The reference's outcome on a rank-deficient n=3 candidate
+// hangs on the last bit of numpy's `x ** 2`, i.e. of libm's pow(x, 2.0) under its interpreter: the
+// kernels restate glibc >= 2.28 on x86-64 with FMA.  On another libm the reference itself reports other values for those
+// candidates; the Python driver says so in its report (search.last_report.libm_pow_matches).  Returns the number of arguments
+// (out of `n` seeded ones, including the ~1 in 1 300 where x * x differs from pow) on which the two disagree.
+// ------------------------------------------------------------------------------------------------------------------
+extern "C" int theta_refpow_check(int n, int *mismatches) {
+    if (!mismatches || n < 0) {
+        theta_set_error("theta_refpow_check: bad argument");
+        return THETA_ERR_ARG;
+    }
+    volatile double two = 2.0;                     // (keeps the call a call: the compiler must not fold pow(x, 2) into x * x)
+    unsigned long long s = 0x9e3779b97f4a7c15ull;
+    int bad = 0;
+    for (int i = 0; i < n; i++) {
+        s ^= s << 13; s ^= s >> 7; s ^= s << 17;
+        const int e = (int)((s >> 52) % 80) - 40;
+        const double x = ldexp(1.0 + (double)(s & 0xfffffffffffffull) / 4503599627370496.0, e);
+        const double a = refpow::square(x), b = pow(x, two);
+        if (memcmp(&a, &b, 8) != 0) bad++;
+    }
+    *mismatches = bad;
+    return THETA_OK;
+}

@@ -115,6 +115,9 @@ class SearchReport(object):
                                            # (NAN_SWEEP_MAX): `best` then lacks the NaN tuples the reference appends for about one full-rank
                                            # matrix in a million (the finite entries and the chosen C are not affected)
         self.seconds = 0.0
+        self.libm_pow_matches = None       # n=3: does this host's libm square like the restatement in the kernels (csrc/refpow.hpp)?  False: the
+                                           # reference RUN ON THIS HOST would report other values for rank-deficient candidates (its outcome there
+                                           # hangs on the last bit of libm's pow(x, 2)); everything else is unaffected
         self.gpus = 1                      # ranks the search was sharded over (do_optimization with max_processes > 1)
 
 
@@ -144,9 +147,10 @@ def collect_finalists(problem, ctx, r, rN, max_normal, begin, end, window=COLLEC
         try:
             res = problem.search(begin, end, window=wnd)
             break
-        except _lib.ThetaError as e:
-            listed_too_many = "finalists dropped" in str(e) or "suspect list overflowed" in str(e)      # (either device list: both shrink with the window)
-            if e.code != _lib.ERR_CAPACITY or not listed_too_many or attempt == 2 or wnd / 10.0 < 4 * TIE_MARGIN:
+        except _lib.ListOverflow:
+            # (ties, suspects or -- a piece of 2^20 candidates that still holds more rank-deficient ones than the list, with the
+            # sweep's near-minimum entries among them -- the degenerate list: all three shrink with the window)
+            if attempt == 2 or wnd / 10.0 < 4 * TIE_MARGIN:
                 raise
     if report is not None:
         report.window = wnd
@@ -401,6 +405,8 @@ def do_optimization_single(n, m, k, tau, lower_bounds, upper_bounds, r, rN, max_
     rep.finalists = len(recs)
     if n == 3 and best:
         _certificate(rep, problem, ctx, tau, r, rN, best)
+    if n == 3 and hasattr(ctx, "_h"):
+        rep.libm_pow_matches = _lib.libm_pow_matches()
     rep.seconds = time.time() - t0
     last_report = rep
     return best
