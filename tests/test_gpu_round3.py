@@ -217,7 +217,10 @@ def test_plain_scorer_pipeline_over_tile_shapes(ctx):
     (128-candidate tiles beyond 256 bytes), B below / at / above tile multiples and above one round of the persistent grid,
     n = 2 and n = 3 -- against the oracle's CalcAllC.L2 / L3 on a sample and against the masked kernel with an all-ones mask."""
     rng = np.random.RandomState(91)
-    for n, m, B in ((3, 200, 1000), (3, 200, 128), (3, 50, 256 * 1024 + 77), (2, 100, 256 * 1024 * 2 + 3), (3, 16, 300), (2, 256, 513), (3, 256, 129)):
+    # (records beyond 256 bytes go slice by slice since round 4, score_plain_sliced_kernel: 16-byte and 4-byte staging, a last slice
+    # of fewer than 32 words, one and two tumour columns, B around multiples of the 256-candidate blocks)
+    for n, m, B in ((3, 200, 1000), (3, 200, 128), (3, 50, 256 * 1024 + 77), (2, 100, 256 * 1024 * 2 + 3), (3, 16, 300), (2, 256, 513), (3, 256, 129),
+                    (3, 202, 700), (3, 200, 256 * 9 + 5), (3, 130, 255), (3, 256, 1025), (3, 147, 300)):
         tau = 2
         C = rng.randint(0, 8, (B, m, n - 1)).astype(np.uint8)
         if n == 2:
@@ -244,7 +247,7 @@ def test_plain_scorer_pipeline_over_tile_shapes(ctx):
         assert np.allclose(ref[:, 0], got[sub, 0], rtol=1e-13, atol=0)
     # row terms that are not positive normal numbers (w_i = 0: ln 0, times r_i = 0 or not): the branch-free walk redoes such a
     # candidate with the guarded logarithm -- the same inf / NaN as the masked kernel and the oracle's numpy arithmetic
-    for n, m, B in ((3, 50, 700), (2, 100, 300)):
+    for n, m, B in ((3, 50, 700), (2, 100, 300), (3, 200, 700)):
         C = rng.randint(0, 8, (B, m, n - 1)).astype(np.uint8)
         if n == 2:
             C = C[:, :, 0]

@@ -759,6 +759,109 @@ __global__ __launch_bounds__(256) void score_plain_kernel(int m, int tau, int B,
     }
 }
 
+
+// Records beyond 256 bytes (m = 200, n = 3: 400 bytes): the kernel above holds whole records in LDS, which caps a block at 128
+// candidates -- half of its threads idle, six waves per CU, 1.2 TB/s.  Here a block scores 256 candidates SLICE BY SLICE: equal
+// parts of at most 28 words of each record at a time, in LDS rows of odd stride; every thread walks its own row and carries
+// den / tot across the slices in registers.  All 256 threads work, < 32 KB of LDS per block (five blocks per CU), and the global
+// reads of a slice are 16-byte loads of consecutive lanes.  Same per-candidate operations in the same order as
+// score_plain_kernel: the same bits.  (m = 200, n = 3: 1.22 -> 1.97 TB/s of the algorithmic bytes; the row rate is that of the
+// m = 50 shape less the slices' barriers -- the kernel is bound by the logarithm's 15 vector instructions per interval, so the
+// byte rate of long records cannot exceed ~2.4 TB/s: their candidates carry fewer bytes of mu / NLL per interval.)
+#define SPS_MAXW 28        // most words of a slice: slices are equal parts of a record, multiples of 4 words (16-byte staging)
+__host__ __device__ inline int sps_slice_words(int cw, int maxw = SPS_MAXW) {
+    const int ns = (cw + maxw - 1) / maxw;
+    return (((cw + ns - 1) / ns) + 3) & ~3;
+}
+template <int NC>
+__global__ __launch_bounds__(256) void score_plain_sliced_kernel(int m, int tau, int B, const unsigned char *C, const double *__restrict__ w,
+                                                                 const double *__restrict__ r, const double *mu, double rsum, double wmin, double wmax, double *nll, int maxw) {
+    const int cb = m * NC, cw = cb >> 2;         // bytes / words per candidate (a multiple of 4 bytes: the launcher checks)
+    const int SW = sps_slice_words(cw, maxw), STR = SW | 1;                                      // words per slice; odd LDS stride: lanes on distinct banks
+    unsigned int *const tile = spc_lds;                                                    // [256][STR]
+    const int tid = threadIdx.x;
+    const long long b0 = (long long)blockIdx.x * 256;
+    const int nb = (int)((long long)B - b0 < 256 ? (long long)B - b0 : 256);
+    double2 *const tabw = (double2 *)(spc_lds + ((256 * STR + 3) & ~3));
+    smx_log_stage(tabw);
+    const double2 *const tb = tabw;
+    double mu_a = 0.0, mu_b = 0.0, mu_c = 0.0;
+    if (tid < nb) {
+        const double *mv = mu + (size_t)(b0 + tid) * (NC + 1);
+        mu_a = mv[0];
+        mu_b = mv[1];
+        if (NC == 2) mu_c = mv[2];
+    }
+    const double m0 = (double)tau * mu_a, m1 = (NC == 1) ? 1.0 - mu_a : mu_b, m2 = mu_c;
+    // (the unguarded logarithm needs positive normal row terms: decided per candidate from the extremes, see score_plain_kernel; a wave
+    // that holds one odd candidate takes the guarded logarithm for all of its lanes -- the same bits wherever both apply)
+    const bool odd = !(m1 >= 0.0 && m2 >= 0.0 && smx_log_fast_ok(wmin * m0) &&
+                       smx_log_fast_ok(wmax * __builtin_fma(255.0, m1, __builtin_fma(255.0, m2, m0))));
+    const bool guarded = __ballot(odd && tid < nb) != 0ull;
+    const bool vec = (cb & 15) == 0 && (((uintptr_t)C) & 15) == 0;      // records start 16-byte aligned: 16-byte loads
+    const unsigned int *const gsrc = (const unsigned int *)(C + (size_t)b0 * cb);
+    const unsigned int *const row = tile + tid * STR;
+    double den = 0.0, tot = 0.0;
+    for (int s0 = 0; s0 < cw; s0 += SW) {
+        const int sw = cw - s0 < SW ? cw - s0 : SW;                     // words of this slice
+        __syncthreads();                                                // (the previous slice has been walked)
+        if (vec && (sw & 3) == 0) {
+            const int per = sw >> 2, total = nb * per;                  // 16-byte chunks per record slice / of the tile slice
+            const unsigned magic = (unsigned)((0x100000000ull + (unsigned)per - 1) / (unsigned)per);
+            for (int q = tid; q < total; q += 256) {
+                const int cand = (int)__umulhi((unsigned)q, magic), ch = q - cand * per;       // q / per (exact: q (per - 1) < 2^32)
+                const uint4 v = *(const uint4 *)(gsrc + (size_t)cand * cw + s0 + 4 * ch);
+                unsigned int *d = tile + cand * STR + 4 * ch;
+                d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+            }
+        } else {
+            const int total = nb * sw;
+            const unsigned magic = (unsigned)((0x100000000ull + (unsigned)sw - 1) / (unsigned)sw);
+            for (int q = tid; q < total; q += 256) {
+                const int cand = (int)__umulhi((unsigned)q, magic), wd = q - cand * sw;
+                tile[cand * STR + wd] = gsrc[(size_t)cand * cw + s0 + wd];
+            }
+        }
+        __syncthreads();
+        if (tid < nb) {
+            auto term = [&](int i, unsigned x8, unsigned y8) {
+                const double2 wi = double2{w[i], r[i]};                   // (wave-uniform: scalar loads, SGPR operands)
+                const double x = (double)x8, y = (double)y8;
+                const double cm = wi.x * __builtin_fma(x, m1, __builtin_fma(y, m2, m0));
+                den += cm;
+                tot = __builtin_fma(wi.y, guarded ? smx_log(cm, tb) : smx_log_fast(cm, tb), tot);
+            };
+            if (guarded) {
+                for (int q = 0; q < sw; q++) {
+                    const unsigned word = row[q];
+                    const int i = ((s0 + q) * 4) / NC;
+                    if (NC == 2) {
+                        term(i, word & 0xffu, (word >> 8) & 0xffu);
+                        term(i + 1, (word >> 16) & 0xffu, word >> 24);
+                    } else {
+                        for (int k = 0; k < 4; k++) term(i + k, (word >> (8 * k)) & 0xffu, 0u);
+                    }
+                }
+            } else {
+                for (int q = 0; q < sw; q++) {
+                    const unsigned word = row[q];
+                    const int i = ((s0 + q) * 4) / NC;
+                    if (NC == 2) {
+                        term(i, word & 0xffu, (word >> 8) & 0xffu);
+                        term(i + 1, (word >> 16) & 0xffu, word >> 24);
+                    } else {
+                        term(i, word & 0xffu, 0u);
+                        term(i + 1, (word >> 8) & 0xffu, 0u);
+                        term(i + 2, (word >> 16) & 0xffu, 0u);
+                        term(i + 3, word >> 24, 0u);
+                    }
+                }
+            }
+        }
+    }
+    if (tid < nb) nll[b0 + tid] = -(tot - rsum * smx_log(den, tb));
+}
+
 // ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------
@@ -806,6 +909,15 @@ void batch_launch_score_masked(int n, int m, int tau, int B, int S, const unsign
             SMX_LAUNCH(9) SMX_LAUNCH(10) SMX_LAUNCH(11) SMX_LAUNCH(12) SMX_LAUNCH(13) SMX_LAUNCH(14) SMX_LAUNCH(15) SMX_LAUNCH(16)
         }
 #undef SMX_LAUNCH
+    } else if (mask == nullptr && S == 1 && ((m * (n - 1)) & 3) == 0 && m * (n - 1) > 256 && (((uintptr_t)C) & 3) == 0 && rsum_scratch != nullptr && rsum_host_valid &&
+               !getenv("THETA_SCORE_NO_SLICES")) {
+        // records beyond 256 bytes: 256 candidates per block, slice by slice (score_plain_sliced_kernel)
+        int maxw = SPS_MAXW;
+        if (const char *e = getenv("THETA_SPS_MAXW")) maxw = atoi(e) >= 4 && atoi(e) <= 64 ? atoi(e) & ~3 : maxw;
+        const size_t lds = (((size_t)256 * (sps_slice_words((m * (n - 1)) >> 2, maxw) | 1) + 3) & ~(size_t)3) * 4 + SMX_TAB_BYTES;
+        const unsigned blocks = (unsigned)(((long long)B + 255) / 256);
+        if (n == 2) hipLaunchKernelGGL((score_plain_sliced_kernel<1>), dim3(blocks), dim3(256), lds, st, m, tau, B, C, w, r, mu, rsum_host, wmin_host, wmax_host, nll, maxw);
+        else hipLaunchKernelGGL((score_plain_sliced_kernel<2>), dim3(blocks), dim3(256), lds, st, m, tau, B, C, w, r, mu, rsum_host, wmin_host, wmax_host, nll, maxw);
     } else if (mask == nullptr && S == 1 && ((m * (n - 1)) & 3) == 0 && m * (n - 1) <= 512 && (((uintptr_t)C) & 15) == 0 && rsum_scratch != nullptr && rsum_host_valid) {
         const int ts = (m * (n - 1)) / 4 <= 64 ? 256 : 128;           // candidates per tile (batch.hip: score_plain_kernel)
         const size_t lds = (((size_t)ts * (((m * (n - 1)) >> 2) | 1) + 3) & ~(size_t)3) * 4 + SMX_TAB_BYTES + (size_t)((m + 3) & ~3) * 16;
