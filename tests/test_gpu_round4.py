@@ -156,3 +156,30 @@ def test_rank_ranges_of_a_space_beyond_2_to_the_128_are_searched_like_any_other(
     assert p.count == 2 ** 128 - 1
     check(p, ("n3_sieve", 0))
     p.close()
+
+
+def test_a_space_too_large_to_sweep_whole_has_its_tail_swept(ctx, monkeypatch):
+    """
+    The reference keeps a NaN tuple only if it stands BEHIND the last replacement of its running minimum (a replacement starts
+    a new list, RunTHetA.py:198-206).  So where a space is beyond NAN_SWEEP_MAX, the driver sweeps the tail behind the first entry
+    of `best` alone -- if that is short enough -- and the list is complete after all.  Here: the reference's own lists with NaN
+    tuples of FULL-RANK matrices (tests/golden/best_nan_cases.json, which only the sweep finds) with the whole-space sweep switched
+    off by a limit one below each space's size.
+    """
+    from conftest import load_json, unfl
+    from theta_amd import search as S
+    cases = load_json("best_nan_cases.json")["cases"]
+    tails, n_nan = 0, 0
+    for c in cases:
+        ref = [(b["C"], [unfl(x) for x in b["mu"]], unfl(b["nll"])) for b in c["best"]]
+        monkeypatch.setattr(S, "NAN_SWEEP_MAX", int(c["count"]) - 1)
+        try:
+            best = S.do_optimization_single(c["n"], c["m"], c["k"], c["tau"], list(c["lb"]), list(c["ub"]), c["r"], c["rN"], c["mx"], c["order"])
+        except SystemExit:
+            best = []
+        rep = S.last_report
+        assert campaign.compare_best(campaign.best_to_plain(best), ref) == "", (c["seed"], rep.nan_sweep, rep.nan_sweep_from)
+        if rep.nan_sweep and rep.nan_sweep_from > 0:
+            tails += 1
+            n_nan += sum(1 for b in ref if b[2] != b[2])
+    assert tails >= 10 and n_nan >= 5, (tails, n_nan)

@@ -114,6 +114,8 @@ class SearchReport(object):
                                            # reports with a NaN likelihood joined the replay; False = the space was too large for that
                                            # (NAN_SWEEP_MAX): `best` then lacks the NaN tuples the reference appends for about one full-rank
                                            # matrix in a million (the finite entries and the chosen C are not affected)
+        self.nan_sweep_from = 0            # ... from this rank on (> 0: only the tail behind the last replacement of the minimum was swept -- all that
+                                           # can hold a NaN tuple the reference keeps)
         self.seconds = 0.0
         self.libm_pow_matches = None       # n=3: does this host's libm square like the restatement in the kernels (csrc/refpow.hpp)?  False: the
                                            # reference RUN ON THIS HOST would report other values for rank-deficient candidates (its outcome there
@@ -216,10 +218,10 @@ def fallback_records(problem, ctx, r, rN, max_normal, recs, window=COLLECT_WINDO
     return out
 
 
-def replay_ties(recs, n, tau, sorted_index, first_duplicate, report=None, q1_first=None):
+def replay_records(recs, first_duplicate, report=None, q1_first=None):
     """
-    Host part: the reference's running-minimum rule (RunTHetA.py:194-206) replayed in enumeration
-    order over the finalists.  `recs` must hold every candidate within COLLECT_WINDOW of the minimum.
+    The reference's running-minimum rule (RunTHetA.py:194-206) replayed in enumeration order over the finalists; returns the records
+    of `best`, in order.  `recs` must hold every candidate within COLLECT_WINDOW of the minimum.
     first_duplicate: n=2 evaluates the rank-0 matrix twice (quirk Q1, RunTHetA.py:188,208).
     q1_first: optional record of the n=3 [tau,0,0] matrix the reference evaluates first.
     """
@@ -258,8 +260,13 @@ def replay_ties(recs, n, tau, sorted_index, first_duplicate, report=None, q1_fir
         elif L < lowest:
             best = [t]
             lowest = L
+    return best
+
+
+def replay_ties(recs, n, tau, sorted_index, first_duplicate, report=None, q1_first=None):
+    """replay_records, with every entry in the reference's output form: (C in the ORIGINAL interval order, mu, NLL, vals)."""
     out = []
-    for t in best:
+    for t in replay_records(recs, first_duplicate, report, q1_first):
         C = reverse_sort_C(_full_matrix(t["c"], n, tau), sorted_index)
         vals = reverse_sort_list([float(v) for v in t["vals"]], sorted_index)
         mu = (float(t["mu"][0]), float(t["mu"][1])) if n == 2 else np.array(t["mu"], dtype=np.float64)
@@ -342,15 +349,37 @@ def _search_local(n, m, tau, lower_bounds, upper_bounds, r, rN, max_normal, shar
         problem.set_option("n3_nan_sweep", 1 if sweep else 0)
         if report is not None:
             report.nan_sweep = sweep
-    recs, stats = collect_finalists(problem, ctx, r, rN, max_normal, begin, end, report=report)
-    if n == 3:
-        recs = recs + fallback_records(problem, ctx, r, rN, max_normal, recs, report=report)
-        # rank-deficient candidates: the listed outcome (the reference's own procedure) is THE outcome -- a None included --,
-        # whatever the search kernels made of the same matrix as a finalist or a suspect (the sieve evaluates them like any other)
-        listed = set(problem.last_degenerate[0])
-        if listed:
-            recs = [t for t in recs if t["rank"] not in listed]
-        recs = recs + degenerate_records(problem, ctx, r, rN, max_normal, report=report)
+    def gather(b, e):
+        rc, st = collect_finalists(problem, ctx, r, rN, max_normal, b, e, report=report)
+        if n == 3:
+            rc = rc + fallback_records(problem, ctx, r, rN, max_normal, rc, report=report)
+            # rank-deficient candidates: the listed outcome (the reference's own procedure) is THE outcome -- a None included --,
+            # whatever the search kernels made of the same matrix as a finalist or a suspect (the sieve evaluates them like any other)
+            listed = set(problem.last_degenerate[0])
+            if listed:
+                rc = [t for t in rc if t["rank"] not in listed]
+            rc = rc + degenerate_records(problem, ctx, r, rN, max_normal, report=report)
+        return rc, st
+    recs, stats = gather(begin, end)
+    if n == 3 and not sweep and G == 1 and NAN_SWEEP_MAX > 0:
+        # A space too large to sweep whole.  The reference only KEEPS a NaN tuple that stands behind the last replacement of its
+        # running minimum (a replacement starts a new list, RunTHetA.py:198-206): the ranks before the first entry of `best`
+        # cannot contribute one.  If the tail behind that entry is short enough, it alone is swept -- searched once more with the
+        # sweep on -- and `best` is complete after all.
+        q1 = _q1_record(ctx, n, m, tau, r, rN, max_normal)
+        first = replay_records(recs, False, None, q1)
+        tail = max(begin, first[0]["rank"]) if first and first[0]["rank"] >= 0 else begin
+        if first and end - tail <= NAN_SWEEP_MAX:
+            problem.set_option("n3_nan_sweep", 1)
+            known = [t["nll"] for t in first if t["nll"] == t["nll"]]
+            if known:
+                problem.hint(min(known))
+            more, _st = gather(tail, end)
+            problem.set_option("n3_nan_sweep", 0)
+            recs = [t for t in recs if t["rank"] < tail] + more
+            if report is not None:
+                report.nan_sweep = True
+                report.nan_sweep_from = tail
     return problem, ctx, recs, stats
 
 
