@@ -235,7 +235,7 @@ def measure_traffic(args):
                        os.path.abspath(__file__), "--gpus", "1", "--steps", "3", "--warmup", "2", "--batch", str(args.batch),
                        "--leg", args.leg, "--no-cpu-baseline", "--no-legs", "--no-traffic", "--no-extras"]
                 subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240, check=True)
-                vals = []
+                rows = []
                 for dp, _d, fs in os.walk(out):
                     for f in fs:
                         if f.endswith("counter_collection.csv"):
@@ -243,17 +243,25 @@ def measure_traffic(args):
                             with open(os.path.join(dp, f)) as fh:
                                 for row in csv.DictReader(fh):
                                     if DOMINANT_KERNEL in row.get("Kernel_Name", "") and row.get("Counter_Name") == ctr:
-                                        vals.append(float(row["Counter_Value"]))
-                if not vals:
+                                        rows.append((int(row["Dispatch_Id"]), float(row.get("Grid_Size") or 0), float(row["Counter_Value"])))
+                if not rows:
                     return None, "rocprofv3 produced no %s rows for the search kernel" % ctr
-                # per launch: the job's first step also launches the kernel on a few short bootstrap slices, and its warm-up
-                # launches run against a poor minimum (many contenders written out) -- the median of the full-size launches
-                vals = sorted(v for v in vals if v >= 0.02 * max(vals)) or vals
-                got[ctr] = vals[len(vals) // 2] if len(vals) % 2 else 0.5 * (vals[len(vals) // 2 - 1] + vals[len(vals) // 2])
+                # per launch, summed over the counter's instances; the BULK launches are those with (about) the largest grid -- a step
+                # is a short first slice + the bulk --, and the timed steps are the last ones: the job's first step runs against a
+                # poor minimum and writes millions of contender records (round 3 took the median of the launches with the LARGEST
+                # VALUES, i.e. of exactly those: its "1.3 GB per launch" was the first step's contender list, profiles/r4/NOTES.md)
+                per = {}
+                for did, grid, val in rows:
+                    g, v = per.get(did, (0.0, 0.0))
+                    per[did] = (max(g, grid), v + val)
+                gmax = max(g for g, _v in per.values())
+                bulk = [per[d][1] for d in sorted(per) if per[d][0] >= 0.5 * gmax][-3:]
+                bulk.sort()
+                got[ctr] = bulk[len(bulk) // 2]
     except Exception as ex:
         return None, "rocprofv3 --pmc pass failed: %s" % (str(ex)[:200],)
     byt = (2.0 * got["FETCH_SIZE"] + got["WRITE_SIZE"]) * 1024.0
-    return byt, "(2 x FETCH_SIZE + WRITE_SIZE) KB, median over the full-size launches of the dominant kernel in two rocprofv3 --pmc passes of this command (2 warm-up + 3 timed steps)"
+    return byt, "(2 x FETCH_SIZE + WRITE_SIZE) KB, median over the bulk launches of the three TIMED steps of the dominant kernel in two rocprofv3 --pmc passes of this command (2 warm-up + 3 timed steps)"
 
 
 def extras(ctx, cpu_seconds):

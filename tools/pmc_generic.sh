@@ -7,8 +7,10 @@ mkdir -p $ROOT/$OUT
 export TMPDIR=/tmp
 cd /tmp
 i=0
-for grp in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" "SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY" \
-           "SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_WR" "SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD" "FETCH_SIZE" "WRITE_SIZE"; do
+# (PMC_GROUPS="A B;C D" replaces the default counter groups: one rocprofv3 run per group)
+DEFAULT_GROUPS="SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS;SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES;SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY;SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_WR;SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD;FETCH_SIZE;WRITE_SIZE"
+IFS=';' read -ra GRPS <<< "${PMC_GROUPS:-$DEFAULT_GROUPS}"
+for grp in "${GRPS[@]}"; do
     i=$((i+1))
     timeout 200 rocprofv3 --pmc $grp --output-format csv -d $ROOT/$OUT/p$i -o pmc -- "$@" > /dev/null 2> $ROOT/$OUT/p$i.err
     f=$(find $ROOT/$OUT/p$i -name '*counter_collection.csv' | head -1)

@@ -13,5 +13,6 @@ for row in csv.DictReader(open(path)):
 out = {}
 for c, d in acc.items():
     vals = list(d.values())
-    out[c] = {"launches": len(vals), "mean_per_launch": sum(vals) / len(vals), "min": min(vals), "max": max(vals)}
+    out[c] = {"launches": len(vals), "mean_per_launch": sum(vals) / len(vals), "min": min(vals), "max": max(vals),
+              "per_launch": [d[k] for k in sorted(d, key=lambda x: int(x))][:64]}      # (in dispatch order)
 print(json.dumps(out, indent=1))
