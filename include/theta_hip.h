@@ -10,7 +10,7 @@
  *
  * Conventions
  *   n        number of populations, 2 or 3 (column 0 of C is the normal genome, == tau)
- *   m        number of intervals of the search (rows of C), 2 <= m <= THETA_MAX_M (n=3: <= 128 -- search, FP64 mode,
+ *   m        number of intervals of the search (rows of C), 2 <= m <= THETA_MAX_M (n=3: <= 256 on the sieve path -- search, FP64 mode,
  *            materialised generator and theta_solve_batch alike; only theta_search_values, the fused kernel's own
  *            per-candidate dump, holds 64)
  *   r, rN    tumour / normal read counts AFTER the reference's sort_r (DataTools.py:95-118),

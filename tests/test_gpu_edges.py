@@ -256,7 +256,7 @@ def test_burst_generator_against_oracle_and_lane_private_generator(ctx, monkeypa
 
 
 def test_driver_exits_cleanly_when_the_search_is_beyond_the_library(ctx, capsys):
-    """n=3 with 130 intervals (the library holds 128), a space beyond 2^128 matrices (64 intervals, bounds [0, 7]), or one no
+    """n=3 with 260 intervals (the library holds 256), a space beyond 2^128 matrices (64 intervals, bounds [0, 7]: a legal problem since round 4, not a legal exhaustive search), or one no
     search can finish (70 intervals, bounds [0, 2]: 2.5e34 matrices -- refused at once, nothing of that size is materialised
     on the host): a message and exit(1) like the reference's other input errors, not a traceback."""
     import theta_amd
@@ -268,7 +268,7 @@ def test_driver_exits_cleanly_when_the_search_is_beyond_the_library(ctx, capsys)
         p.search(0, p.count)
     assert e.value.code == theta_amd._lib.ERR_OVERFLOW
     p.close()
-    for m, k in ((130, 2), (70, 2), (64, 7)):
+    for m, k in ((260, 2), (130, 2), (70, 2), (64, 7)):
         r = rng.randint(1000, 5000, m).tolist()
         rN = rng.randint(1000, 5000, m).tolist()
         with pytest.raises(SystemExit):

@@ -183,3 +183,71 @@ def test_a_space_too_large_to_sweep_whole_has_its_tail_swept(ctx, monkeypatch):
             tails += 1
             n_nan += sum(1 for b in ref if b[2] != b[2])
     assert tails >= 10 and n_nan >= 5, (tails, n_nan)
+
+
+def test_two_hundred_intervals_on_the_sieve_path(ctx):
+    """
+    BASELINE config 5's literal shape -- m = 200 intervals, n = 3, k = 7 -- as a SEARCH (round 3 held 128 intervals and refused the
+    space for its size): four prefix intervals per lane in the sieve kernel, the burst generator and the task / unrank kernels, a
+    saturating counting table.  (a) tight bounds around a planted truth (a few thousand matrices): count, enumeration order and the
+    complete `best` list against the oracle (every candidate through scipy); (b) full bounds [0, 7] (1e150 matrices): the first
+    candidates equal the oracle's generator, and rank ranges at 2^50 and 2^120 give identical lists in packed FP32 and in FP64, the
+    listed C being what the generator materialises at those ranks.
+    """
+    import itertools
+    import warnings
+    import bench
+    import theta_amd
+    import theta_oracle as orc
+    from theta_amd.search import do_optimization_single
+    m, K = 200, 7
+    rng = np.random.RandomState(202)
+    L = rng.randint(2_000_000, 20_000_000, m)
+    rN = np.maximum(rng.poisson(L * 0.002), 5)
+    C = np.full((m, 3), 2.0)
+    C[:, 1] = rng.randint(0, K + 1, m)
+    C[:, 2] = C[:, 1]                                  # (bounds apply to both tumour columns of a row: tight bounds = equal entries ...
+    for i in rng.choice(m, 6, replace=False):          # ... but for a few rows one copy apart)
+        C[i, 2] = min(K, C[i, 1] + 1)
+    mu = np.array([0.3, 0.45, 0.25])
+    pr = (C * rN[:, None]) @ mu
+    r = rng.multinomial(int(rN.sum() * 1.1), pr / pr.sum())
+    rs, rNs, order = orc.sort_r([int(x) for x in rN], [int(x) for x in np.maximum(r, 1)])
+    cs = C[:, 1:][order]
+    lb = [int(v) for v in cs.min(axis=1)]
+    ub = [int(v) for v in cs.max(axis=1)]
+    free = rng.choice(m, 3, replace=False)
+    for i in free:
+        lb[i], ub[i] = max(0, lb[i] - 1), min(K, ub[i] + 1)
+    cnt = orc.count_n3_exact(m, 2, list(lb), list(ub))
+    assert 100 <= cnt <= 20000, cnt
+    p = theta_amd.Problem(ctx, 3, m, 2, rs, rNs, lb, ub, 1.0)
+    assert p.count == cnt
+    ref = np.array([[[int(a), int(b)] for a, b in rows] for rows in orc.enumerate_n3(m, 2, list(lb), list(ub))], np.uint8)
+    assert np.array_equal(p.enumerate(0, cnt), ref)
+    p.close()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        want, _ = orc.search_single(3, m, 2, list(lb), list(ub), rs, rNs, 1.0, order)
+    best = do_optimization_single(3, m, K, 2, list(lb), list(ub), rs, rNs, 1.0, order)
+    assert campaign.compare_best(campaign.best_to_plain(best), campaign.best_to_plain(want)) == ""
+    # (b) the whole config-5 space
+    p = theta_amd.Problem(ctx, 3, m, 2, rs, rNs, [0] * m, [K] * m, 1.0)
+    assert p.count == 2 ** 128 - 1
+    first = p.enumerate(0, 2000)
+    ref = np.array([[[int(a), int(b)] for a, b in rows] for rows in itertools.islice(orc.enumerate_n3(m, 2, [0] * m, [K] * m), 2000)], np.uint8)
+    assert np.array_equal(first, ref)
+    for where in (1 << 50, (1 << 120) + 777):
+        span = 1 << 22
+        a = p.search(where, where + span, window=0.5)
+        assert a["stats"]["evaluated"] == span
+        p.set_option("n3_force_f64", 1)
+        f = p.search(where, where + span, window=0.5)
+        p.set_option("n3_force_f64", 0)
+        assert a["rank"] == f["rank"] and np.array_equal(a["C"], f["C"]) and np.allclose(a["nll"], f["nll"], rtol=1e-11, atol=0)
+        assert len(a["rank"]) >= 1
+        for rk, Cm in zip(a["rank"], a["C"]):
+            assert np.array_equal(p.enumerate(rk, 1)[0], Cm)
+        ok, mu_b, nll_b, _ = ctx.solve_batch(3, 2, rs, rNs, a["C"], 1.0, want_vals=False)
+        assert ok.all() and np.allclose(nll_b, a["nll"], rtol=1e-9, atol=0)
+    p.close()

@@ -69,7 +69,7 @@ def time_estimate(n, m, k, tau, lower_bounds, upper_bounds, r, rN, max_normal, s
         p = _lib.Problem(ctx, n, m, tau, r, rN, [int(v) for v in lower_bounds], [int(v) for v in upper_bounds], max_normal)
     except _lib.ThetaError as e:
         if e.code in (_lib.ERR_OVERFLOW, _lib.ERR_ARG):
-            # a search the library cannot hold (n=3: more than 128 intervals, more than 64 distinct rows (a, b) within the bounds, more than 2^128 matrices)
+            # a search the library cannot hold (n=3: more than 256 intervals, more than 64 distinct rows (a, b) within the bounds; a range of more than 2^56 matrices)
             print("ERROR: %s. Use fewer intervals (--NUM_INTERVALS) or tighter bounds. Exiting..." % e)
             sys.exit(1)
         raise

@@ -222,13 +222,11 @@ __device__ bool n3_unrank(const N3Dev &P, u128 rho, int depth, N3State *st, u128
 // Wave-cooperative rank -> DFS path: at every level the 64 lanes test the 64 alphabet slots and read their
 // children's counts in ONE memory round trip (the serial walk above chains ~5 dependent HBM reads per level);
 // the wave then scans the feasible children in slot order.  Lane d ends up holding the packed node of depth d.
-// (depth <= 128: lane d holds the node of depth d in st_out, and that of depth 64 + d in st_out1)
-__device__ bool n3_unrank_wave(const N3Dev &P, u128 rho, int depth, int lane, unsigned &st_out, unsigned &st_out1, u128 &rem) {
+// (the packed node of depth d is written to states[d] by lane 0 -- `states` may be global or shared memory)
+__device__ bool n3_unrank_wave(const N3Dev &P, u128 rho, int depth, int lane, unsigned *states, u128 &rem) {
     const unsigned myrow = lane < P.Q ? P.rowtab[lane] : 0u;       // one alphabet slot per lane
     const int sa = (int)(myrow & 15u), sb = (int)(myrow >> 4);
     N3State par{0, 0, 0, 0, 0, 0};
-    st_out = 0u;
-    st_out1 = 0u;
     for (int d = 0; d < depth; d++) {
         N3State nx{0, 0, 0, 0, 0, 0};
         bool ok = lane < P.Q && (d == 0 ? n3_first_row_ab(P, sa, sb, lane, nx) : n3_edge_ab(P, par, sa, sb, lane, d, nx));
@@ -254,8 +252,7 @@ __device__ bool n3_unrank_wave(const N3Dev &P, u128 rho, int depth, int lane, un
         unsigned mine = ok ? n3_pack(nx) : 0u;
         unsigned packed = (unsigned)__builtin_amdgcn_readlane((int)mine, chosen);
         par = n3_unpack(packed);
-        if (lane == d) st_out = packed;
-        if (lane + WAVE == d) st_out1 = packed;
+        if (lane == 0) states[d] = packed;
     }
     rem = rho;
     return true;
@@ -271,9 +268,8 @@ __global__ __launch_bounds__(256) void n3_task_kernel(N3Dev P, uint64_t b_lo, ui
     u128 left = end - base;
     uint64_t count = left < (u128)per_task ? (uint64_t)left : per_task;
     const int D = P.m - P.L;
-    unsigned st = 0, st1 = 0;
     u128 rem = 0;
-    bool ok = n3_unrank_wave(P, base, D, lane, st, st1, rem);
+    bool ok = n3_unrank_wave(P, base, D, lane, stbuf + (size_t)t * N3_STB, rem);
     if (lane == 0) {
         N3Task tk;
         tk.base_lo = (uint64_t)base;
@@ -282,26 +278,21 @@ __global__ __launch_bounds__(256) void n3_task_kernel(N3Dev P, uint64_t b_lo, ui
         tk.skip = (uint64_t)rem;
         tasks[t] = tk;
     }
-    if (lane < D) stbuf[(size_t)t * N3_STB + lane] = st;
-    if (lane + WAVE < D) stbuf[(size_t)t * N3_STB + WAVE + lane] = st1;
 }
 
 // one wave per tie record: its matrix
 __global__ __launch_bounds__(256) void n3_unrank_list_kernel(N3Dev P, const TieRecord *recs, int count, unsigned char *out) {
-    const int k = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    __shared__ unsigned path[4][N3_MAX_M_WIDE];       // the packed nodes of the wave's path
+    const int wv = threadIdx.x >> 6, k = blockIdx.x * 4 + wv, lane = threadIdx.x & 63;
     if (k >= count) return;
     u128 rho = ((u128)recs[k].rank_hi << 64) | recs[k].rank_lo, rem;
-    unsigned st = 0, st1 = 0;
-    bool ok = n3_unrank_wave(P, rho, P.m, lane, st, st1, rem);
-    if (lane < P.m) {
-        unsigned char *dst = out + (size_t)k * P.m * 2 + 2 * lane;
+    bool ok = n3_unrank_wave(P, rho, P.m, lane, path[wv], rem);
+    wave_lds_sync();
+    for (int i = lane; i < P.m; i += WAVE) {
+        unsigned char *dst = out + (size_t)k * P.m * 2 + 2 * i;
+        const unsigned st = path[wv][i];
         dst[0] = ok ? (unsigned char)((st >> 24) & 15u) : 255;
         dst[1] = ok ? (unsigned char)(st >> 28) : 255;
-    }
-    if (lane + WAVE < P.m) {
-        unsigned char *dst = out + (size_t)k * P.m * 2 + 2 * (lane + WAVE);
-        dst[0] = ok ? (unsigned char)((st1 >> 24) & 15u) : 255;
-        dst[1] = ok ? (unsigned char)(st1 >> 28) : 255;
     }
 }
 

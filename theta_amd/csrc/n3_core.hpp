@@ -15,8 +15,8 @@
 #define N3_GRID_K 7              // up to this K the alphabet is the full grid
 #define N3_MAX_Q 64
 #define N3_MAX_M 64              // one interval per lane (fused kernel, generators)
-#define N3_MAX_M_WIDE 128        // two intervals per lane: the sieve path (n3_sieve.hip), task and unrank kernels
-#define N3_STB 128               // stride of the per-task prefix states (one packed DFS node per depth)
+#define N3_MAX_M_WIDE 256        // up to four prefix intervals per lane: the sieve path (n3_sieve.hip), the burst generator, task and unrank kernels
+#define N3_STB 256               // stride of the per-task prefix states (one packed DFS node per depth)
 #define N3_RIDX_W (2 * N3_MAX_COPY + 1)
 
 // Wave-uniform description of one n=3 search instance.
@@ -187,6 +187,51 @@ __device__ __forceinline__ bool n3_child_dyn(const unsigned char *ridx, const un
     return lo <= hi;
 }
 
+// Next prefix in DFS order (wave-uniform): lane l holds the packed nodes of depths l, 64 + l, ... in st[0], st[1], ... (NS per lane:
+// m <= 64 NS + ML).  Returns false at the end of the space.
+template <int NS>
+__device__ __forceinline__ unsigned n3_lane_state(const unsigned (&st)[NS], int d) {
+    unsigned v = st[0];
+#pragma unroll
+    for (int j = 1; j < NS; j++) v = (d >> 6) == j ? st[j] : v;          // (d is wave-uniform)
+    return (unsigned)__builtin_amdgcn_readlane((int)v, d & (WAVE - 1));
+}
+template <int NS>
+__device__ __forceinline__ bool n3_next_prefix(const N3Dev &P, unsigned (&st)[NS], int D, int lane) {
+    const int Q = P.Q;
+    const unsigned myrow = lane < Q ? P.rowtab[lane] : 0u;          // Q <= 64: one alphabet slot per lane
+    const int sa = (int)(myrow & 15u), sb = (int)(myrow >> 4);
+    int d = D - 1;
+    bool fresh = false;
+    while (true) {
+        const int cur_slot = (int)(n3_lane_state<NS>(st, d) & 0x7fu);
+        const int start = fresh ? 0 : cur_slot + 1;
+        const N3State pst = n3_unpack(n3_lane_state<NS>(st, d > 0 ? d - 1 : 0));
+        N3State nx{0, 0, 0, 0, 0, 0};
+        const bool ok = lane >= start && lane < Q &&
+                        (d == 0 ? n3_first_row_ab(P, sa, sb, lane, nx) : n3_edge_ab(P, pst, sa, sb, lane, d, nx));
+        const unsigned long long mk = ballot64(ok);
+        if (mk) {
+            const int first = __builtin_ctzll(mk);
+            const unsigned mine = ok ? n3_pack(nx) : 0u;
+            const unsigned packed = (unsigned)__builtin_amdgcn_readlane((int)mine, first);
+#pragma unroll
+            for (int j = 0; j < NS; j++)
+                if ((d >> 6) == j && lane == (d & (WAVE - 1))) st[j] = packed;
+            if (d == D - 1) return true;
+            d++;
+            fresh = true;
+        } else {
+            d--;
+            fresh = false;
+            if (d < 0) return false;
+        }
+    }
+}
+
+#endif
+
+#ifdef __HIPCC__
 // ---------------------------------------------------------------------------------------------
 // Mixture solve for n = 3 in the scaled variables u_j = nu_j N / S_j (S_j = column sums of the
 // weighted matrix, sigma_j = S_j / N):  with u_0 eliminated through sum_j sigma_j u_j = 1,

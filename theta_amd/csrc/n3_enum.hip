@@ -243,44 +243,7 @@ __device__ void eb_expand(EbCtx<ML> &c, int n_in) {
     }
 }
 
-// Next prefix in DFS order (wave-uniform): lane d holds the packed node of depth d in st0 and that of depth 64 + d in st1
-// (up to 128 intervals, like the sieve kernel's prefix).  Returns false at the end of the space.
-__device__ __forceinline__ unsigned eb_state(unsigned st0, unsigned st1, int d) {
-    return (unsigned)__builtin_amdgcn_readlane((int)(d < WAVE ? st0 : st1), d & (WAVE - 1));
-}
-__device__ __forceinline__ bool eb_next_prefix(const N3Dev &P, unsigned &st0, unsigned &st1, int D, int lane) {
-    const int Q = P.Q;
-    const unsigned myrow = lane < Q ? P.rowtab[lane] : 0u;          // Q <= 64: one alphabet slot per lane
-    const int sa = (int)(myrow & 15u), sb = (int)(myrow >> 4);
-    int d = D - 1;
-    bool fresh = false;
-    while (true) {
-        const int cur_slot = (int)(eb_state(st0, st1, d) & 0x7fu);
-        const int start = fresh ? 0 : cur_slot + 1;
-        const N3State pst = n3_unpack(eb_state(st0, st1, d > 0 ? d - 1 : 0));
-        N3State nx{0, 0, 0, 0, 0, 0};
-        const bool ok = lane >= start && lane < Q &&
-                        (d == 0 ? n3_first_row_ab(P, sa, sb, lane, nx) : n3_edge_ab(P, pst, sa, sb, lane, d, nx));
-        const unsigned long long mk = ballot64(ok);
-        if (mk) {
-            const int first = __builtin_ctzll(mk);
-            const unsigned mine = ok ? n3_pack(nx) : 0u;
-            const unsigned packed = (unsigned)__builtin_amdgcn_readlane((int)mine, first);
-            if (d < WAVE) {
-                if (lane == d) st0 = packed;
-            } else if (lane == d - WAVE) {
-                st1 = packed;
-            }
-            if (d == D - 1) return true;
-            d++;
-            fresh = true;
-        } else {
-            d--;
-            fresh = false;
-            if (d < 0) return false;
-        }
-    }
-}
+#define EB_NS 4            // prefix intervals per lane (n3_core.hpp: n3_lane_state / n3_next_prefix): up to 256 + LB intervals
 
 template <int U, int ML>
 __global__ __launch_bounds__(64 * EB_WAVES, (ML <= 4 ? EB_OCC4 : EB_OCC6)) void n3_enumerate_burst_kernel(
@@ -309,8 +272,9 @@ __global__ __launch_bounds__(64 * EB_WAVES, (ML <= 4 ? EB_OCC4 : EB_OCC6)) void 
     const int task = blockIdx.x * EB_WAVES + wv;
     if (task >= ntasks) return;
     const N3Task tk = tasks[task];
-    unsigned st = lane < D ? stbuf[(size_t)task * N3_STB + lane] : 0u;
-    unsigned st1 = lane + WAVE < D ? stbuf[(size_t)task * N3_STB + WAVE + lane] : 0u;    // (m > 64 + LB: depths 64 .. D-1)
+    unsigned st[EB_NS];                                // lane l: the packed prefix nodes of depths l, 64 + l, ...
+#pragma unroll
+    for (int j = 0; j < EB_NS; j++) st[j] = WAVE * j + lane < D ? stbuf[(size_t)task * N3_STB + WAVE * j + lane] : 0u;
 
     EbCtx<ML> c;
     c.S = &S;
@@ -331,14 +295,15 @@ __global__ __launch_bounds__(64 * EB_WAVES, (ML <= 4 ? EB_OCC4 : EB_OCC6)) void 
     c.magic = (unsigned)((0x100000000ull + (unsigned)c.NU - 1) / (unsigned)c.NU);
 
     while (c.remaining > 0) {
-        if (lane < D) c.W->pre[lane] = (unsigned short)(((st >> 24) & 15u) | ((st >> 28) << 8));
-        if (lane + WAVE < D) c.W->pre[WAVE + lane] = (unsigned short)(((st1 >> 24) & 15u) | ((st1 >> 28) << 8));
+#pragma unroll
+        for (int j = 0; j < EB_NS; j++)
+            if (WAVE * j + lane < D) c.W->pre[WAVE * j + lane] = (unsigned short)(((st[j] >> 24) & 15u) | ((st[j] >> 28) << 8));
         wave_lds_sync();
-        c.par = n3_unpack(eb_state(st, st1, D - 1));
+        c.par = n3_unpack(n3_lane_state<EB_NS>(st, D - 1));
         eb_expand<U, ML, 0>(c, 1);
         c.skip = 0;                                        // only the first prefix of a task starts mid-way
         if (c.remaining == 0) break;
-        if (!eb_next_prefix(P, st, st1, D, lane)) break;
+        if (!n3_next_prefix<EB_NS>(P, st, D, lane)) break;
         wave_lds_sync();                                   // the prefix rows in LDS are rewritten next
     }
 }

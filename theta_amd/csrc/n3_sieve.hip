@@ -149,9 +149,9 @@ template <> struct SvPlanes<double> {
     }
 };
 
-template <int ML, class F>
+template <int ML, class F, int NS>
 struct SvWave {
-    alignas(16) unsigned short pre[N3_MAX_M_WIDE + 8];  // rows of the prefix, a | b << 8
+    alignas(16) unsigned short pre[WAVE * NS + 8];      // rows of the prefix, a | b << 8 (NS intervals per lane: 128, or 256 in the wide instantiation)
     uint2 list0[N3_MAX_Q];                              // level 1 nodes (children of the prefix's last node)
     uint2 list[ML > 3 ? ML - 3 : 1][SV_CAP];            // level l = 2 .. ML-2: {packed parent node, ancestor slots (6 bits each) | slot << 24}
     uint2 listL[SvCapL<F>::v];                               // level ML-1 (the last-level nodes): longer, so that a round of the level above
@@ -175,11 +175,11 @@ struct SvWave {
 // the ratio masks (`dynmask`) so that the wave needs no pointer of its own for it.  (The full 31 x 31 table in LDS costs the float
 // instantiation its third block per CU: 36 -> 45 ms per 2^31 candidates.)
 #define SV_RIDX_W 15
-template <int ML, class F>
+template <int ML, class F, int NS>
 struct SvLds {
-    SvWave<ML, F> w[SV_WAVES];
+    SvWave<ML, F, NS> w[SV_WAVES];
     unsigned long long smask[ML][N3_MAX_Q];             // static child masks of the ML last depths
-    unsigned char lb[N3_MAX_M_WIDE], ub[N3_MAX_M_WIDE];
+    unsigned char lb[WAVE * NS], ub[WAVE * NS];
     unsigned char ridx[SV_RIDX_W * SV_RIDX_W + 3];       // the central part of the ratio-rank table (|dx|, |dy| <= 7), see sv_child_dyn
     unsigned char rowtab[N3_MAX_Q + 3];
     unsigned short row16[N3_MAX_Q];                     // slot -> a | b << 8
@@ -197,10 +197,10 @@ __device__ __forceinline__ int sv_incl_scan(int v) {
 }
 
 // Everything a wave carries through the expansion (wave-uniform unless noted).
-template <int ML, class F>
+template <int ML, class F, int NS>
 struct SvCtx {
-    SvLds<ML, F> *S;
-    SvWave<ML, F> *W;
+    SvLds<ML, F, NS> *S;
+    SvWave<ML, F, NS> *W;
     const unsigned long long *dynmask;
     const u128 *cnt;                 // counting table (only read while a task skips to its first candidate)
     int Q;
@@ -245,8 +245,8 @@ struct SvCtx {
 // q_i = 1 + (x_i - s1) u1 + (y_i - s2) u2, NLL = K0 - sum R_i ln q_i.  Returns 0 = stepped (u1, u2 hold the new iterate;
 // val2 = sum R log2 q and l2 = lambda^2 / Rtot at the OLD one), 1 = stepped and converged (l2 < conv), 2 = outside the domain
 // (u1, u2 halved towards 0), 3 = no usable step (ill-conditioned Hessian, NaN).
-template <int ML, class F>
-__device__ __forceinline__ int sv_step(const SvCtx<ML, F> &c, const unsigned (&rw)[ML / 2], F s1, F s2, F &u1, F &u2, F &val2, F &l2, F &la) {
+template <int ML, class F, int NS>
+__device__ __forceinline__ int sv_step(const SvCtx<ML, F, NS> &c, const unsigned (&rw)[ML / 2], F s1, F s2, F &u1, F &u2, F &val2, F &l2, F &la) {
     typedef typename SvVec<F>::v2 v2;
     v2 g1 = {F(0), F(0)}, g2 = g1, h11 = g1, h12 = g1, h22 = g1, lg = g1, lga = g1;
     const v2 vs1 = {s1, s1}, vs2 = {s2, s2}, vu1 = {u1, u1}, vu2 = {u2, u2}, one = {F(1), F(1)};
@@ -334,16 +334,16 @@ __device__ __forceinline__ int sv_step(const SvCtx<ML, F> &c, const unsigned (&r
 // The test  K0 - ln2 val2 - gap - margin > thr  is made as  ln2 val2 + gap (+ margin) < T  in F, with T = K0 - thr (- margin)
 // rounded DOWN into F by more than the comparison's own rounding (sv_set_threshold) -- no conversions in the hot path.
 // false when the bound does not apply (t >= 1/2).  sl = sqrt(l2), which the caller has anyway.
-template <int ML, class F>
-__device__ __forceinline__ bool sv_beyond(const SvCtx<ML, F> &c, F val2, F l2, F sl, F la) {
+template <int ML, class F, int NS>
+__device__ __forceinline__ bool sv_beyond(const SvCtx<ML, F, NS> &c, F val2, F l2, F sl, F la) {
     const F t = sl * c.sqrt_ror;
     const F gap = F(1.05 * 0.5) * (l2 * c.rtot_f) * sv_fma(t, sv_fma(F(2), t, F(1)), F(1));
     F lhs = sv_fma(F(0.6931471805599453), val2, gap);
     if constexpr (sizeof(F) == 8) lhs += 0.6931471805599453 * (8.7e-8 * c.rtot_f + 1.3e-7 * la) + 1e-3;
     return t < F(0.5) && lhs < c.Tcmp;
 }
-template <int ML, class F>
-__device__ __forceinline__ void sv_set_threshold(SvCtx<ML, F> &c, double thr) {
+template <int ML, class F, int NS>
+__device__ __forceinline__ void sv_set_threshold(SvCtx<ML, F, NS> &c, double thr) {
     c.thr = thr;
     if constexpr (sizeof(F) == 8) {
         c.Tcmp = c.K0 - thr;                            // (the margin depends on the evaluation: added to the left side)
@@ -355,8 +355,8 @@ __device__ __forceinline__ void sv_set_threshold(SvCtx<ML, F> &c, double thr) {
 }
 
 // column sums / N of a record: (s1, s2); false if a tumour column is all zero (degenerate: the reference's Chat is NaN)
-template <int ML, class F>
-__device__ __forceinline__ bool sv_sums(const SvCtx<ML, F> &c, const unsigned (&rw)[ML / 2], F &s1, F &s2) {
+template <int ML, class F, int NS>
+__device__ __forceinline__ bool sv_sums(const SvCtx<ML, F, NS> &c, const unsigned (&rw)[ML / 2], F &s1, F &s2) {
     F a = c.S1p, b = c.S2p;
 #pragma unroll
     for (int j = 0; j < ML / 2; j++) {
@@ -372,8 +372,8 @@ __device__ __forceinline__ bool sv_sums(const SvCtx<ML, F> &c, const unsigned (&
 }
 
 // A contender (or a record the sieve cannot handle): rows and rank to the device list; the finish kernel takes it from there.
-template <int ML, class F>
-__device__ __forceinline__ void sv_survivor(const SvCtx<ML, F> &c, const unsigned (&rw)[ML / 2], unsigned off) {
+template <int ML, class F, int NS>
+__device__ __forceinline__ void sv_survivor(const SvCtx<ML, F, NS> &c, const unsigned (&rw)[ML / 2], unsigned off) {
     const unsigned idx = atomicAdd(c.surv_count, 1u);
     atomicAdd(&c.A.ctr->sieve_survivors, 1ull);
     if (idx >= c.surv_cap) return;            // the host sees the count and redoes the slice
@@ -391,8 +391,8 @@ __device__ __forceinline__ void sv_survivor(const SvCtx<ML, F> &c, const unsigne
 }
 
 // leaf rows of a child as the queue / the contender list hold them: two rows {a, b, a', b'} per dword
-template <int ML, class F>
-__device__ __forceinline__ void sv_child_rows(const SvCtx<ML, F> &c, unsigned code, unsigned slot, unsigned (&rw)[ML / 2]) {
+template <int ML, class F, int NS>
+__device__ __forceinline__ void sv_child_rows(const SvCtx<ML, F, NS> &c, unsigned code, unsigned slot, unsigned (&rw)[ML / 2]) {
 #pragma unroll
     for (int j = 0; j < ML / 2; j++) {
         rw[j] = c.S->row16[(code >> (12 * j)) & 63u];
@@ -405,8 +405,8 @@ __device__ __forceinline__ void sv_child_rows(const SvCtx<ML, F> &c, unsigned co
 // whose record is finished takes the next queue entry at once (ballot + prefix count of the idle lanes), so the wave iterates
 // as long as there is work for most of its lanes -- round 2 took the queue 64 at a time in lock step, and with a third of the
 // records needing a second or third step every batch ran three iterations at a fraction of its lanes.
-template <int ML, class F>
-__device__ __forceinline__ void sv_drain(SvCtx<ML, F> &c) {
+template <int ML, class F, int NS>
+__device__ __forceinline__ void sv_drain(SvCtx<ML, F, NS> &c) {
 #ifdef SV_PROF
     const unsigned long long pt0 = __builtin_amdgcn_s_memtime();
 #endif
@@ -424,11 +424,11 @@ __device__ __forceinline__ void sv_drain(SvCtx<ML, F> &c) {
             const int idx = next + mbcnt(idle);
             if (!live && idx < c.qcount) {
                 const uint2 qr = c.W->qRec[idx];
-                sv_child_rows<ML, F>(c, qr.x, qr.y & 0xffu, rw);
+                sv_child_rows<ML, F, NS>(c, qr.x, qr.y & 0xffu, rw);
                 u1 = c.W->qU1[idx];
                 u2 = c.W->qU2[idx];
                 off = qr.y >> 8;
-                sv_sums<ML, F>(c, rw, s1, s2);
+                sv_sums<ML, F, NS>(c, rw, s1, s2);
                 if (!(u1 == u1)) {                    // (no usable first point: from the simplex centre)
                     u1 = F(1.0 / 3.0) * sv_rcp(s1);
                     u2 = F(1.0 / 3.0) * sv_rcp(s2);
@@ -445,7 +445,7 @@ __device__ __forceinline__ void sv_drain(SvCtx<ML, F> &c) {
         bool fin = false, surv = false;
         if (live) {
             F val2 = F(0), l2 = F(0), la = F(0);
-            const int st = sv_step<ML, F>(c, rw, s1, s2, u1, u2, val2, l2, la);
+            const int st = sv_step<ML, F, NS>(c, rw, s1, s2, u1, u2, val2, l2, la);
             iters++;
             if (st == 3 || iters >= 40) {
                 surv = fin = true;               // ill-conditioned / stuck: the finish kernel solves it in FP64
@@ -454,7 +454,7 @@ __device__ __forceinline__ void sv_drain(SvCtx<ML, F> &c) {
                 // candidate to the coarse tolerance first); a converged candidate it does not finish is a contender -- once
                 // the decrement is below fine_l2 (FP64: the gap of the bound is then a fraction of a unit; float: at once,
                 // the margin of the single-precision sums dominates anyway).  The finish kernel decides exactly.
-                const bool beyond = sv_beyond<ML, F>(c, val2, l2, sv_sqrt(l2), la);
+                const bool beyond = sv_beyond<ML, F, NS>(c, val2, l2, sv_sqrt(l2), la);
                 if (beyond && (!c.no_dismiss || st == 1)) {
                     fin = true;
                 } else if (st == 1 && l2 < c.fine_l2) {
@@ -462,7 +462,7 @@ __device__ __forceinline__ void sv_drain(SvCtx<ML, F> &c) {
                 }
             }
         }
-        if (surv) sv_survivor<ML, F>(c, rw, off);
+        if (surv) sv_survivor<ML, F, NS>(c, rw, off);
         if (fin) {
             // the lane keeps the last optimum it saw as a start for later records
             if (sv_abs(s1 * u1) + sv_abs(s2 * u2) < F(1e6)) {
@@ -491,8 +491,8 @@ __device__ __forceinline__ void sv_drain(SvCtx<ML, F> &c) {
 // normalisation.  Children the bound cannot finish go to the queue and continue with full evaluations at their own iterate.
 // Record of a node (SvPlanes, 16 numbers): 0 L, 1..3 T0 T1 T2, 4..9 W00 W01 W02 W11 W12 W22, 10 11 S1 S2, 12..14 w0 u1 u2,
 // 15 sum R |log2 q| (F = double: the error bound of the single-precision logarithms, sv_beyond).
-template <int ML, class F>
-__device__ __forceinline__ void sv_parent(SvCtx<ML, F> &c, bool take, unsigned code) {
+template <int ML, class F, int NS>
+__device__ __forceinline__ void sv_parent(SvCtx<ML, F, NS> &c, bool take, unsigned code) {
     typedef typename SvVec<F>::v2 v2;
     // path rows D .. D+ML-2 of the node (its ancestors in the expanded levels and itself)
     F px[ML - 1], py[ML - 1];
@@ -589,8 +589,8 @@ struct SvChild {
 // chain of ~100 dependent operations; with two or three waves per SIMD that chain's latency, not the issue rate, was what the
 // children phase cost (44 % of the search kernel's wave cycles, profiles/r3).  Without branches the scheduler interleaves the
 // chains of the SV_CPL children a lane takes per trip.
-template <int ML, class F>
-__device__ __forceinline__ void sv_child_eval(const SvCtx<ML, F> &c, int lo, int k, int nrec, SvChild<F> &o) {
+template <int ML, class F, int NS>
+__device__ __forceinline__ void sv_child_eval(const SvCtx<ML, F, NS> &c, int lo, int k, int nrec, SvChild<F> &o) {
     const F Rl = c.leafRf[ML - 1], Nl = c.leafN[ML - 1];
     o.act = k < nrec;
     const unsigned kd = o.act ? c.W->kid[lo + k] : 0u;
@@ -645,7 +645,7 @@ __device__ __forceinline__ void sv_child_eval(const SvCtx<ML, F> &c, int lo, int
     o.chain = good && sv_abs(o.n1) + sv_abs(o.n2) < F(1e6);
     // (same decisions as in sv_drain)
     const bool conv = l2 < c.conv_l2 && l2 * c.rtot_over_rmin < F(0.25);
-    const bool beyond = sv_beyond<ML, F>(c, val2, l2, sl, la);
+    const bool beyond = sv_beyond<ML, F, NS>(c, val2, l2, sl, la);
     const bool done = good && beyond && (!c.no_dismiss || conv);         // the bound (search) / converged and valued beyond the window (full solve)
     o.surv = good && !done && conv && l2 < c.fine_l2;
     // queued: another step from the stepped point -- or, without a usable shared point / with ill-conditioned sums, from the
@@ -660,8 +660,8 @@ __device__ __forceinline__ void sv_child_eval(const SvCtx<ML, F> &c, int lo, int
 #endif
 
 // The candidates [0, total) of the round (less the task window), SV_CPL children per lane and trip.
-template <int ML, class F>
-__device__ __forceinline__ void sv_children(SvCtx<ML, F> &c, int total) {
+template <int ML, class F, int NS>
+__device__ __forceinline__ void sv_children(SvCtx<ML, F, NS> &c, int total) {
     const unsigned long long sk = c.skip < (unsigned long long)total ? c.skip : (unsigned long long)total;
     c.skip -= sk;
     const int lo = (int)sk;
@@ -671,7 +671,7 @@ __device__ __forceinline__ void sv_children(SvCtx<ML, F> &c, int total) {
     for (int k0 = 0; k0 < nrec; k0 += WAVE * SV_CPL) {
         SvChild<F> ch[SV_CPL];
 #pragma unroll
-        for (int e = 0; e < SV_CPL; e++) sv_child_eval<ML, F>(c, lo, k0 + e * WAVE + c.lane, nrec, ch[e]);
+        for (int e = 0; e < SV_CPL; e++) sv_child_eval<ML, F, NS>(c, lo, k0 + e * WAVE + c.lane, nrec, ch[e]);
 #pragma unroll
         for (int e = 0; e < SV_CPL; e++) {
             const SvChild<F> &o = ch[e];
@@ -689,12 +689,12 @@ __device__ __forceinline__ void sv_children(SvCtx<ML, F> &c, int total) {
             if (sm) {                                     // (rare: a contender straight from the shared evaluation)
                 if (o.surv) {
                     unsigned rw[ML / 2];
-                    sv_child_rows<ML, F>(c, o.code, o.slot, rw);
-                    sv_survivor<ML, F>(c, rw, o.off);
+                    sv_child_rows<ML, F, NS>(c, o.code, o.slot, rw);
+                    sv_survivor<ML, F, NS>(c, rw, o.off);
                 }
             }
             if (pm) {
-                if (c.qcount + __builtin_popcountll(pm) > SV_QCAP) sv_drain<ML, F>(c);
+                if (c.qcount + __builtin_popcountll(pm) > SV_QCAP) sv_drain<ML, F, NS>(c);
                 if (o.push) {
                     const int pos = c.qcount + mbcnt(pm);
                     c.W->qRec[pos] = make_uint2(o.code, o.slot | (o.off << 8));
@@ -711,8 +711,8 @@ __device__ __forceinline__ void sv_children(SvCtx<ML, F> &c, int total) {
 }
 
 // n3_child_dyn (n3_core.hpp) on the sieve's tables: the dynamic part of the edge test for a child that passed the masks
-template <int ML, class F>
-__device__ __forceinline__ bool sv_child_dyn(const SvCtx<ML, F> &c, const N3State &par, int slot, N3State &out) {
+template <int ML, class F, int NS>
+__device__ __forceinline__ bool sv_child_dyn(const SvCtx<ML, F, NS> &c, const N3State &par, int slot, N3State &out) {
     const unsigned rw = c.S->rowtab[slot];
     const int a = rw & 15, b = rw >> 4;
     int lo = par.lo, hi = par.hi;
@@ -734,15 +734,15 @@ __device__ __forceinline__ bool sv_child_dyn(const SvCtx<ML, F> &c, const N3Stat
     return lo <= hi;
 }
 
-template <int ML, class F>
-__device__ __forceinline__ unsigned long long sv_child_mask(const SvCtx<ML, F> &c, const N3State &node, int l) {
+template <int ML, class F, int NS>
+__device__ __forceinline__ unsigned long long sv_child_mask(const SvCtx<ML, F, NS> &c, const N3State &node, int l) {
     unsigned long long mk = c.S->smask[l][node.slot] & c.dynmask[((size_t)node.slot * c.NT1 + node.lo) * c.NT1 + (node.hi - 1)];
     return node.sw ? (mk & c.swm) : mk;
 }
 
 // Expand the nodes of leaf level LVL (LVL = 0: the prefix's last node; else the level's list [0 .. n_in)) in rank order.
-template <int ML, int LVL, class F>
-__device__ __forceinline__ void sv_expand(SvCtx<ML, F> &c, int n_in) {
+template <int ML, int LVL, class F, int NS>
+__device__ __forceinline__ void sv_expand(SvCtx<ML, F, NS> &c, int n_in) {
     constexpr bool last = (LVL == ML - 1);
     const int cap = last ? SV_KIDS : (LVL == ML - 2 ? SvCapL<F>::v : (LVL == 0 ? N3_MAX_Q : SV_CAP));
     int pos = 0;
@@ -759,7 +759,7 @@ __device__ __forceinline__ void sv_expand(SvCtx<ML, F> &c, int n_in) {
                 const uint2 e = (LVL == 1) ? c.W->list0[i] : (LVL == ML - 1) ? c.W->listL[i] : c.W->list[LVL >= 2 && LVL < ML - 1 ? LVL - 2 : 0][i];
                 const N3State pst = n3_unpack(e.x);
                 const unsigned slot = e.y >> 24;
-                sv_child_dyn<ML, F>(c, pst, (int)slot, node);
+                sv_child_dyn<ML, F, NS>(c, pst, (int)slot, node);
                 code = (e.y & 0xffffffu) | (slot << (6 * (LVL > 0 ? LVL - 1 : 0)));
             }
         } else {
@@ -816,14 +816,14 @@ __device__ __forceinline__ void sv_expand(SvCtx<ML, F> &c, int n_in) {
             const unsigned long long pa = __builtin_amdgcn_s_memtime();
             c.pt[6] += pa - pi;
 #endif
-            sv_parent<ML, F>(c, take && cnt > 0, code);
+            sv_parent<ML, F, NS>(c, take && cnt > 0, code);
             c.n_par += (unsigned)__builtin_popcountll(ballot64(take && cnt > 0));
             wave_lds_sync();
 #ifdef SV_PROF
             const unsigned long long pb = __builtin_amdgcn_s_memtime(), dr0 = c.pt[3];
             c.pt[1] += pb - pa;
 #endif
-            sv_children<ML, F>(c, total);
+            sv_children<ML, F, NS>(c, total);
             wave_lds_sync();
 #ifdef SV_PROF
             c.pt[2] += (__builtin_amdgcn_s_memtime() - pb) - (c.pt[3] - dr0);
@@ -845,7 +845,7 @@ __device__ __forceinline__ void sv_expand(SvCtx<ML, F> &c, int n_in) {
                 }
             }
             wave_lds_sync();
-            sv_expand<ML, LVL + 1, F>(c, total);
+            sv_expand<ML, LVL + 1, F, NS>(c, total);
             wave_lds_sync();
         }
         if (c.remaining == 0) return;
@@ -853,50 +853,11 @@ __device__ __forceinline__ void sv_expand(SvCtx<ML, F> &c, int n_in) {
     }
 }
 
-// Next prefix in DFS order (wave-uniform): lane d holds the packed node of depth d in st0 and that of depth 64 + d in st1
-// (m <= 128).  Returns false at the end of the space.
-__device__ __forceinline__ unsigned sv_state(unsigned st0, unsigned st1, int d) {
-    return (unsigned)__builtin_amdgcn_readlane((int)(d < WAVE ? st0 : st1), d & (WAVE - 1));
-}
-__device__ __forceinline__ bool sv_next_prefix(const N3Dev &P, unsigned &st0, unsigned &st1, int D, int lane) {
-    const int Q = P.Q;
-    const unsigned myrow = lane < Q ? P.rowtab[lane] : 0u;          // Q <= 64: one alphabet slot per lane
-    const int sa = (int)(myrow & 15u), sb = (int)(myrow >> 4);
-    int d = D - 1;
-    bool fresh = false;
-    while (true) {
-        const int cur_slot = (int)(sv_state(st0, st1, d) & 0x7fu);
-        const int start = fresh ? 0 : cur_slot + 1;
-        const N3State pst = n3_unpack(sv_state(st0, st1, d > 0 ? d - 1 : 0));
-        N3State nx{0, 0, 0, 0, 0, 0};
-        const bool ok = lane >= start && lane < Q &&
-                        (d == 0 ? n3_first_row_ab(P, sa, sb, lane, nx) : n3_edge_ab(P, pst, sa, sb, lane, d, nx));
-        const unsigned long long mk = ballot64(ok);
-        if (mk) {
-            const int first = __builtin_ctzll(mk);
-            const unsigned mine = ok ? n3_pack(nx) : 0u;
-            const unsigned packed = (unsigned)__builtin_amdgcn_readlane((int)mine, first);
-            if (d < WAVE) {
-                if (lane == d) st0 = packed;
-            } else if (lane == d - WAVE) {
-                st1 = packed;
-            }
-            if (d == D - 1) return true;
-            d++;
-            fresh = true;
-        } else {
-            d--;
-            fresh = false;
-            if (d < 0) return false;
-        }
-    }
-}
-
-template <int ML, class F>
+template <int ML, class F, int NS>
 __global__ __launch_bounds__(64 * SV_WAVES, sizeof(F) == 4 ? SV_OCC : SV_OCC64) void n3_sieve_kernel(N3Dev Pg, SearchArgs A, const N3Task *tasks, const unsigned *stbuf,
                                                                           int ntasks, SvSurvivor *surv, unsigned surv_cap,
                                                                           unsigned *surv_count) {
-    __shared__ SvLds<ML, F> S;
+    __shared__ SvLds<ML, F, NS> S;
     const int m = Pg.m, D = m - ML, Q = Pg.Q;
     for (int i = threadIdx.x; i < m; i += blockDim.x) {
         S.lb[i] = Pg.lb[i];
@@ -920,10 +881,11 @@ __global__ __launch_bounds__(64 * SV_WAVES, sizeof(F) == 4 ? SV_OCC : SV_OCC64) 
     const int task = blockIdx.x * SV_WAVES + wv;
     if (task >= ntasks) return;                        // whole wave leaves together; no block barrier below
     const N3Task tk = tasks[task];
-    unsigned st = lane < D ? stbuf[(size_t)task * N3_STB + lane] : 0u;
-    unsigned st1 = lane + WAVE < D ? stbuf[(size_t)task * N3_STB + WAVE + lane] : 0u;    // (m > 70: depths 64 .. D-1)
+    unsigned st[NS];                                   // lane l: the packed prefix nodes of depths l, 64 + l, ...
+#pragma unroll
+    for (int j = 0; j < NS; j++) st[j] = WAVE * j + lane < D ? stbuf[(size_t)task * N3_STB + WAVE * j + lane] : 0u;
 
-    SvCtx<ML, F> c;
+    SvCtx<ML, F, NS> c;
     c.S = &S;
     c.W = &S.w[wv];
     c.dynmask = Pg.dynmask;
@@ -979,7 +941,7 @@ __global__ __launch_bounds__(64 * SV_WAVES, sizeof(F) == 4 ? SV_OCC : SV_OCC64) 
     // (The note lives in LDS: one more scalar held across the expansion cost 2 % of the kernel -- it runs out of scalar registers.)
     if (lane == 0) c.W->task_line = 0u;
     // the device-wide running minimum: only the finish kernel lowers it, between sieve launches -- one load per task
-    sv_set_threshold<ML, F>(c, order_unbits(load_agent_u64(&A.ctr->best_bits)) + A.window);
+    sv_set_threshold<ML, F, NS>(c, order_unbits(load_agent_u64(&A.ctr->best_bits)) + A.window);
     while (c.remaining > 0) {
         // ---- group tile of the prefix: intervals with the same row collapse into one likelihood term {a, b, sum r}
 #ifdef SV_PROF
@@ -988,9 +950,10 @@ __global__ __launch_bounds__(64 * SV_WAVES, sizeof(F) == 4 ? SV_OCC : SV_OCC64) 
         int G = 0;
         double S1p = 0.0, S2p = 0.0, Rmin = __builtin_inf();
         {
+            if constexpr (NS == 2) {      // (the two-per-lane form everything is tuned on, kept as it was: the generic form below compiles to a slower kernel, 62.3 -> 63.7 ms)
             // lane i stands for interval i and, for matrices of more than 64 + ML rows, for interval 64 + i as well
             const bool inp = lane < D, inp1 = lane + WAVE < D;
-            const unsigned myrow = st >> 24, myrow1 = st1 >> 24;           // a | b << 4
+            const unsigned myrow = st[0] >> 24, myrow1 = st[1] >> 24;           // a | b << 4
             if (inp) c.W->pre[lane] = (unsigned short)((myrow & 15u) | ((myrow >> 4) << 8));
             if (inp1) c.W->pre[WAVE + lane] = (unsigned short)((myrow1 & 15u) | ((myrow1 >> 4) << 8));
             const double r_i = inp ? Pg.r[lane] : 0.0, rN_i = inp ? Pg.rN[lane] : 0.0;
@@ -1044,6 +1007,97 @@ __global__ __launch_bounds__(64 * SV_WAVES, sizeof(F) == 4 ? SV_OCC : SV_OCC64) 
                 if (Rs > 0.0) Rmin = fmin(Rmin, Rs);
                 G++;
             }
+            } else {
+            // lane i stands for the intervals i, 64 + i, ... of the prefix (NS of them)
+            bool inp[NS];
+            unsigned myrow[NS];                                          // a | b << 4
+            double r_i[NS], rN_i[NS];
+#pragma unroll
+            for (int j = 0; j < NS; j++) {
+                inp[j] = WAVE * j + lane < D;
+                myrow[j] = st[j] >> 24;
+                if (inp[j]) c.W->pre[WAVE * j + lane] = (unsigned short)((myrow[j] & 15u) | ((myrow[j] >> 4) << 8));
+                r_i[j] = inp[j] ? Pg.r[WAVE * j + lane] : 0.0;
+                rN_i[j] = inp[j] ? Pg.rN[WAVE * j + lane] : 0.0;
+            }
+            {   // Do the prefix rows (x_i, y_i) lie on one line?  (Rare.)  Then some children may be rank-deficient (n3_core.hpp:
+                // N3Line): the task is noted for the host.  Lane-parallel -- the first row, the first row that differs, one cross
+                // product per lane -- so that nothing is carried through the loop below (a running test there cost 1.4 %).
+                const unsigned p0 = (unsigned)__builtin_amdgcn_readlane((int)myrow[0], 0);
+                unsigned p1 = p0;
+                bool differs = false;
+#pragma unroll
+                for (int j = NS - 1; j >= 0; j--) {                      // (the first row that differs: lowest j, lowest lane)
+                    const unsigned long long df = ballot64(inp[j] && myrow[j] != p0);
+                    if (df) {
+                        p1 = (unsigned)__builtin_amdgcn_readlane((int)myrow[j], __builtin_ctzll(df));
+                        differs = true;
+                    }
+                }
+                bool on_line = true;
+                if (differs) {
+                    const int a0 = (int)(p0 & 15u), b0 = (int)(p0 >> 4), da = (int)(p1 & 15u) - a0, db = (int)(p1 >> 4) - b0;
+                    unsigned long long off = 0ull;
+#pragma unroll
+                    for (int j = 0; j < NS; j++) {
+                        const int cr = da * ((int)(myrow[j] >> 4) - b0) - db * ((int)(myrow[j] & 15u) - a0);
+                        off |= ballot64(inp[j] && cr != 0);
+                    }
+                    on_line = !off;
+                }
+                if (on_line && lane == 0) c.W->task_line = 1u;
+            }
+            unsigned long long todo[NS];
+            bool any = false;
+#pragma unroll
+            for (int j = 0; j < NS; j++) {
+                todo[j] = ballot64(inp[j]);
+                any = any || todo[j] != 0ull;
+            }
+            while (any) {
+                unsigned q = 0u;
+                bool have = false;
+#pragma unroll
+                for (int j = 0; j < NS; j++)
+                    if (!have && todo[j]) {
+                        q = (unsigned)__builtin_amdgcn_readlane((int)myrow[j], __builtin_ctzll(todo[j]));
+                        have = true;
+                    }
+                double Rs = 0.0, Ns = 0.0;
+                any = false;
+#pragma unroll
+                for (int j = 0; j < NS; j++) {
+                    const bool match = inp[j] && myrow[j] == q;
+                    todo[j] &= ~ballot64(match);
+                    any = any || todo[j] != 0ull;
+                    Rs += match ? r_i[j] : 0.0;
+                    Ns += match ? rN_i[j] : 0.0;
+                }
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) {     // integer-valued doubles < 2^53: the sums are exact
+                    Rs += __shfl_xor(Rs, o, WAVE);
+                    Ns += __shfl_xor(Ns, o, WAVE);
+                }
+                const F a = (F)(q & 15u), b = (F)(q >> 4);
+                if (lane == 0) {
+                    F *xy = (F *)&c.W->fXY[G >> 1];
+                    F *rr = (F *)&c.W->fRR[G >> 1];
+                    if (G & 1) {
+                        xy[1] = a; xy[3] = b; rr[1] = (F)Rs;
+                    } else {   // also fills the second half: stays as the weight-0 pad when this is the last term
+                        xy[0] = xy[1] = a; xy[2] = xy[3] = b; rr[0] = (F)Rs; rr[1] = F(0);
+                    }
+                    if constexpr (sizeof(F) == 8) {
+                        rr[2 + (G & 1)] = sqrt(Rs);
+                        if (!(G & 1)) rr[3] = 0.0;
+                    }
+                }
+                S1p += (double)a * Ns;
+                S2p += (double)b * Ns;
+                if (Rs > 0.0) Rmin = fmin(Rmin, Rs);
+                G++;
+            }
+            }
         }
 #pragma unroll
         for (int l = 0; l < ML; l++)
@@ -1057,24 +1111,24 @@ __global__ __launch_bounds__(64 * SV_WAVES, sizeof(F) == 4 ? SV_OCC : SV_OCC64) 
         c.sqrt_ror = (F)sqrt(Pg.Rtot / Rmin);
         wave_lds_sync();
         const unsigned it0 = c.n_dit, par0 = c.n_par;
-        c.par = n3_unpack(sv_state(st, st1, D - 1));
+        c.par = n3_unpack(n3_lane_state<NS>(st, D - 1));
         c.n_prefix++;
 #ifdef SV_PROF
         c.pt[0] += __builtin_amdgcn_s_memtime() - pg0;
 #endif
-        sv_expand<ML, 0, F>(c, 1);
-        if (c.qcount) sv_drain<ML, F>(c);                 // the tile changes with the prefix: the queue is emptied first
+        sv_expand<ML, 0, F, NS>(c, 1);
+        if (c.qcount) sv_drain<ML, F, NS>(c);                 // the tile changes with the prefix: the queue is emptied first
         n_terms += (unsigned long long)(c.n_dit - it0) * (unsigned)(G + ML);          // full evaluations: every term of the candidate
         n_pterms += (unsigned long long)(c.n_par - par0) * (unsigned)(G + ML - 1);    // shared sums of a last-level node: all terms but its children's
         c.skip = 0;                                    // only the first prefix of a task starts mid-way
         if (c.remaining == 0) break;
 #ifdef SV_PROF
         const unsigned long long pn0 = __builtin_amdgcn_s_memtime();
-        const bool more = sv_next_prefix(P, st, st1, D, lane);
+        const bool more = n3_next_prefix<NS>(P, st, D, lane);
         c.pt[4] += __builtin_amdgcn_s_memtime() - pn0;
         if (!more) break;
 #else
-        if (!sv_next_prefix(P, st, st1, D, lane)) break;
+        if (!n3_next_prefix<NS>(P, st, D, lane)) break;
 #endif
         wave_lds_sync();                               // the prefix rows in LDS are rewritten next
     }
@@ -1291,13 +1345,18 @@ int n3_sieve_levels(const N3Dev &P) {
 void n3_launch_sieve(const N3Dev &P, const SearchArgs &A, const N3Task *tasks, const unsigned *stbuf, int ntasks, SvSurvivor *surv,
                      unsigned surv_cap, unsigned *surv_count, hipStream_t st) {
     dim3 grid((ntasks + SV_WAVES - 1) / SV_WAVES), block(64 * SV_WAVES);
+    // (NS = prefix intervals per lane: 2 up to 128 intervals -- the instantiation everything is tuned for --, 4 up to 256: BASELINE
+    // config 5's shape, m = 200; wider prefix tables in LDS, two blocks per CU)
+#define SV_LAUNCH(MLV, FT, NSV) hipLaunchKernelGGL((n3_sieve_kernel<MLV, FT, NSV>), grid, block, 0, st, P, A, tasks, stbuf, ntasks, surv, surv_cap, surv_count)
+    const bool wide = P.m - P.L > 2 * WAVE;
     if (P.force64) {       // FP64 throughout (n3_force_f64): the same kernel on doubles
-        if (P.L <= 4) hipLaunchKernelGGL((n3_sieve_kernel<4, double>), grid, block, 0, st, P, A, tasks, stbuf, ntasks, surv, surv_cap, surv_count);
-        else hipLaunchKernelGGL((n3_sieve_kernel<6, double>), grid, block, 0, st, P, A, tasks, stbuf, ntasks, surv, surv_cap, surv_count);
+        if (P.L <= 4) { if (wide) SV_LAUNCH(4, double, 4); else SV_LAUNCH(4, double, 2); }
+        else { if (wide) SV_LAUNCH(6, double, 4); else SV_LAUNCH(6, double, 2); }
     } else {
-        if (P.L <= 4) hipLaunchKernelGGL((n3_sieve_kernel<4, float>), grid, block, 0, st, P, A, tasks, stbuf, ntasks, surv, surv_cap, surv_count);
-        else hipLaunchKernelGGL((n3_sieve_kernel<6, float>), grid, block, 0, st, P, A, tasks, stbuf, ntasks, surv, surv_cap, surv_count);
+        if (P.L <= 4) { if (wide) SV_LAUNCH(4, float, 4); else SV_LAUNCH(4, float, 2); }
+        else { if (wide) SV_LAUNCH(6, float, 4); else SV_LAUNCH(6, float, 2); }
     }
+#undef SV_LAUNCH
 }
 
 void n3_launch_finish(const N3Dev &P, const SearchArgs &A, const SvSurvivor *surv, unsigned surv_cap, const unsigned *surv_count,

@@ -384,7 +384,7 @@ def _search_local(n, m, tau, lower_bounds, upper_bounds, r, rN, max_normal, shar
 
 
 def _friendly_exit(e):
-    # a search the library cannot hold (n=3: more than 128 intervals, more than 64 distinct rows (a, b) within the bounds, or more than 2^128 matrices -- the
+    # a search the library cannot hold (n=3: more than 256 intervals, more than 64 distinct rows (a, b) within the bounds, or a range no search finishes -- the
     # reference would enumerate such a space for years): say so instead of a traceback
     print("ERROR: %s. Use fewer intervals (--NUM_INTERVALS) or tighter bounds. Exiting..." % e)
     sys.exit(1)
