@@ -29,7 +29,7 @@ def test_error_codes_and_messages(ctx):
     with pytest.raises(theta_amd.ThetaError):
         theta_amd.Problem(ctx, 3, 3, 2, [1, 2, 3], [1, 1, 3], [0] * 3, [9] * 3)  # n=3 alphabet limit
     with pytest.raises(theta_amd.ThetaError):
-        theta_amd.Problem(ctx, 3, 129, 2, [1] * 129, [1] * 129, [0] * 129, [2] * 129)  # n=3: two intervals per lane at most
+        theta_amd.Problem(ctx, 3, 257, 2, [1] * 257, [1] * 257, [0] * 257, [2] * 257)  # n=3: four prefix intervals per lane at most (256 intervals)
     p = theta_amd.Problem(ctx, 2, 3, 2, [5, 6, 7], [5, 5, 5], [2, 2, 2], [1, 1, 1])  # lb > ub: nothing to enumerate
     assert p.count == 0
     with pytest.raises(theta_amd.NoCandidates):
