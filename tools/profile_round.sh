@@ -33,7 +33,7 @@ rm -rf $OUT/kt
 $ROOT/tools/pmc_kernel.sh gpurun_out/prof_$R/pmc_sieve n3_sieve_kernel > $OUT/pmc_sieve.log 2>&1
 cp $OUT/pmc_sieve/pmc.json $OUT/pmc_n3_sieve_kernel.json 2>/dev/null
 if [ -f $ROOT/build_ab/libprof.so ]; then
-  for leg in full_solve_f64 full_solve_f32 search; do
+  for leg in full_solve_f64 full_solve_f64_tight full_solve_f32 search; do
     echo "== $leg (cycles summed over waves: 0 group tile, 1 parent phase, 2 children phase, 3 queue drain, 4 prefix successor, 5 whole wave, 6 the last level's own expansion; 7 = prefixes walked)"
     THETA_HIP_LIB=$ROOT/build_ab/libprof.so THETA_BENCH_VERBOSE=1 timeout 300 python $ROOT/bench.py --steps 6 --warmup 2 --leg $leg --no-legs --no-cpu-baseline --no-traffic --no-extras 2>&1 >/dev/null | grep "^step"
   done > $OUT/phase_cycles.txt
@@ -43,4 +43,15 @@ timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kr -o k
 cp $(find $OUT/kr -name '*kernel_stats.csv' | head -1) $OUT/riders_kernel_stats.csv 2>/dev/null
 rm -rf $OUT/kr
 for shape in "131072 512 200" "65536 64 200"; do timeout 100 python $ROOT/tools/scorer_probe.py $shape; done > $OUT/scorer_probe.txt 2>&1
+# round 4: the n=2 search alone (with and without the dismissal by the lower bound) and its PMC passes; where the sieve's write traffic
+# comes from, launch by launch; the plain scorer over record lengths
+(timeout 100 python $ROOT/tools/n2_search_run.py; echo "-- THETA_N2_NO_DISMISS=1"; THETA_N2_NO_DISMISS=1 timeout 100 python $ROOT/tools/n2_search_run.py) > $OUT/n2_search.txt 2>&1
+bash $ROOT/tools/pmc_generic.sh gpurun_out/prof_$R/pmc_n2 n2_search_kernel -- python $ROOT/tools/n2_search_run.py m100_k5 > /dev/null 2>&1
+cp $OUT/pmc_n2/pmc.json $OUT/pmc_n2_search.json 2>/dev/null
+THETA_N2_NO_DISMISS=1 bash $ROOT/tools/pmc_generic.sh gpurun_out/prof_$R/pmc_n2nd n2_search_kernel -- python $ROOT/tools/n2_search_run.py m100_k5 > /dev/null 2>&1
+cp $OUT/pmc_n2nd/pmc.json $OUT/pmc_n2_search_no_dismiss.json 2>/dev/null
+PMC_GROUPS="WRITE_SIZE;FETCH_SIZE;TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum;SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD;TCC_EA0_ATOMIC_sum TCC_WRITE_sum" bash $ROOT/tools/pmc_generic.sh gpurun_out/prof_$R/pmc_w n3_sieve_kernel -- python $ROOT/bench.py --steps 4 --warmup 3 --no-cpu-baseline --no-legs --no-traffic --no-extras > /dev/null 2>&1
+cp $OUT/pmc_w/pmc.json $OUT/pmc_sieve_writes_per_launch.json 2>/dev/null
+timeout 200 python $ROOT/tools/plain_shapes.py > $OUT/plain_shapes.txt 2>&1
+rm -rf $OUT/pmc_n2 $OUT/pmc_n2nd $OUT/pmc_w $OUT/pmc_sieve
 ls -la $OUT

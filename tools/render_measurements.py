@@ -18,10 +18,13 @@ def e(x):
 
 
 rows = []
-what = {"full_solve_f64": "**headline**: `n3_no_dismiss` + `n3_force_f64` — every candidate iterated in FP64 to the coarse tolerance and valued, none dismissed (§8(d)'s definition)",
+what = {"full_solve_f64": "**headline**: `n3_no_dismiss` + `n3_force_f64` — every candidate iterated in FP64 to the COARSE tolerance (λ²/Σr < 1e-4 at an evaluation, then the step) and valued, none dismissed (§8(d)'s definition)",
+        "full_solve_f64_tight": "the same at the TIGHT tolerance (`n3_conv_l2` = 1e-12: every candidate's μ within 1e-6 of its optimum)",
         "full_solve_f32": "`n3_no_dismiss`: the same in packed single precision",
         "search": "as shipped: 99.9 % of the candidates finished by the lower bound after one shared evaluation (\"searched\", a rider)"}
-for name in ("full_solve_f64", "full_solve_f32", "search"):
+for name in ("full_solve_f64", "full_solve_f64_tight", "full_solve_f32", "search"):
+    if name not in legs:
+        continue
     l = legs[name]
     sm = l["step_kernel_ms"]
     rows.append("| `%s` | %s | %s | %.1f (%.1f / %.1f / %.1f) | %.2f | %.0f (%.0f %% FP64) | %.1f | %.3f of %.1f |" % (
@@ -30,6 +33,7 @@ for name in ("full_solve_f64", "full_solve_f32", "search"):
 cpu = b["cpu_baseline"]
 w = b["wall_clock_to_best"]
 rid = b["riders"]["config5_masked_scorer"]
+rs5 = b["riders"].get("config5_search")
 h = legs[b["config"]["leg"]]
 txt = []
 txt.append("`python bench.py --steps %d --warmup %d` (N=1, the driver's layout; `profiles/%s/bench_n1.json`; no torch): **%s candidates/s** "
@@ -45,9 +49,11 @@ txt.append("")
 txt.append("(The legs other than the headline run after the timed region, on the same %d stretches.  `survivors` %d, "
            "`fallback_candidates` %d, `redo_kernel_ms` %.1f over the headline's %d steps: no timed step fell back.)\n" % (
                b["steps"], h["survivors"], h["fallback_candidates"], h["redo_kernel_ms"], h["launches"]))
-txt.append("HBM traffic (`roofline.traffic`, two `rocprofv3 --pmc` passes of the same command): %.2f GB per launch against 0 algorithmic "
-           "bytes — %.1f B per candidate: the counting table at task starts, contender records, counters.\n" % (
-               (rf["traffic"] or 0) / 1e9, (rf["traffic"] or 0) / 2 ** 31))
+txt.append("HBM traffic (`roofline.traffic`, two `rocprofv3 --pmc` passes of the same command, bulk launches of the timed steps): %.1f MB per "
+           "launch against 0 algorithmic bytes — %.3f B per candidate: the counting table at task starts, the waves' statistics, the few "
+           "contender records of a step that starts from the job's minimum.  (Round 3 reported 1.3 GB: its filter kept the launches with "
+           "the LARGEST counters, i.e. the job's first step, whose 7.7 M contender records are 2.1 GB — `profiles/r4/pmc_sieve_writes_per_launch.json` "
+           "lists every launch.)\n" % ((rf["traffic"] or 0) / 1e6, (rf["traffic"] or 0) / 2 ** 31))
 txt.append("CPU beside it (`cpu_baseline`): %s — %s candidates/s on all %d cores, %.0f per process.\n" % (cpu["sample"], e(cpu["value"]), cpu["cores"], cpu["per_process"]))
 txt.append("`wall_clock_to_best` (second half of BASELINE's metric; end to end through `do_optimization_single`): config 1 "
            "(`Example.intervals -n 2 -k 3`, 142 560 candidates) %.1f ms against %.1f s of the reference's own search loop; config 2 (m=25, n=2, "
@@ -59,6 +65,10 @@ txt.append("`wall_clock_to_best` (second half of BASELINE's metric; end to end t
 txt.append("**Rider, config 5** (`riders.config5_masked_scorer`, m=200, n=3, k=7: 131 072 byte candidates × 512 interval masks): %s pairs/s = "
            "%.1f TFLOP/s FP64 MFMA = %.2f of the 78.6 dense peak, %.2f TB/s of algorithmic traffic — MFMA-bound, not HBM-bound as "
            "`north_star` labels it.\n" % (e(rid["value"]), rid["roofline"]["achieved"], rid["roofline"]["frac"], rid["roofline"]["hbm_algorithmic_GBps"] / 1e3))
+if rs5:
+    txt.append("**Rider, config 5 as a search** (`riders.config5_search`: m=200, n=3, k=7 with full bounds — the count saturates at 2^128 − 1 — "
+               "ranks [2^100, 2^100 + 2^30) as shipped): %s candidates/s searched (%.1f ms of kernel time, %.4f of the candidates finished by "
+               "their bound).\n" % (e(rs5["value"]), rs5["kernel_ms"], rs5["dismissed_fraction"]))
 try:
     rd = json.load(open(os.path.join(P, "riders.json")))
     en, dc, bc = rd["enum_profile.py"], rd["device_chain.py"], rd["bench_configs.py"]
