@@ -168,6 +168,9 @@ struct theta_problem {
     int opt_nan_sweep = 0;             // n=3: after a search, every candidate of the range through the reference's own procedure; the ones it
                                        // reports with a NaN likelihood join the degenerate list (nan_sweep below; 2e8-5e8 candidates/s)
     int opt_sieve = 1;                 // n=3: sieve + finish kernels (n3_sieve.hip); 0 = the fused kernel of n3.hip only
+    int auto64 = 0;                    // n=3 sieve: 1 = the packed-FP32 screen listed too many contenders on this problem (its margin, 2e-5 sum r + 1,
+                                       // is coarse against the spread of the NLL in a range): later calls run the double instantiation
+    bool opt_auto64 = true;            // ... unless switched off (option "n3_auto_f64")
     bool count_saturated = false;      // n=3: the space holds 2^128 matrices or more (total = 2^128 - 1)
     unsigned opt_surv_cap = 0;         // n=3: contenders a slice may list before it counts as overflowed (0: SURV_CAP; smaller
                                        // values make the tests walk the redo ladder: sieve again -> 8 parts -> fused kernel)
@@ -428,6 +431,10 @@ extern "C" int theta_problem_set_option(theta_problem *p, const char *name, doub
     else if (k == "n3_conv_l2" && value > 0.0) p->n3.conv_l2 = value;
     else if (k == "n3_warm_blend" && value >= 0.0 && value <= 1.0) p->n3.warm_blend = value;
     else if (k == "n3_sieve") p->opt_sieve = value != 0.0;
+    else if (k == "n3_auto_f64") {
+        p->opt_auto64 = value != 0.0;
+        p->auto64 = 0;
+    }
     else if (k == "n3_nan_sweep") p->opt_nan_sweep = value != 0.0;
     else if (k == "n3_contender_cap" && value >= 0.0 && value <= (double)SURV_CAP) p->opt_surv_cap = (unsigned)value;
     else if (k == "n3_per_task" && (value == 0.0 || (value >= 64 && value <= 65535))) p->opt_per_task = (uint64_t)value;
@@ -660,6 +667,7 @@ static int run_search(theta_problem *p, u128 b, u128 e, double window, double *d
             if (sieve_levels > 0) {
                 // fast path (n3_sieve.hip): sieve kernel per slice of the range, finish kernel on its contenders in between
                 PS.L = sieve_levels;
+                if (p->opt_auto64 && p->auto64) PS.force64 = 1;      // (same finalists either way: only the screen's margin differs)
                 if (!p->d_surv.p) {
                     int rc = p->d_surv.alloc((size_t)SURV_CAP * sizeof(SvSurvivor));
                     if (rc) return rc;
@@ -707,7 +715,7 @@ static int run_search(theta_problem *p, u128 b, u128 e, double window, double *d
                 }
                 sieve_per_task = per_task;
                 sieve_per_task_last = per_task;
-                p->last_sieve64 = p->n3.force64 != 0;
+                p->last_sieve64 = PS.force64 != 0;
             } else {
                 n3_launch_tasks(p->n3, b, e, per_task, ntasks, (N3Task *)p->d_tasks.p, (unsigned *)p->d_stbuf.p, st);
                 HIP_TRY(hipEventRecord(ctx->ev1, st));
@@ -741,6 +749,19 @@ static int run_search(theta_problem *p, u128 b, u128 e, double window, double *d
             return k.evaluated > gone ? k.evaluated - gone : 0ull;
         };
         if (!slices.empty()) got.dismissed = raw.dismissed + sieve_dismissed(raw);
+        // The packed-FP32 screen carries a margin of 2e-5 sum r + 1 NLL units; where the candidates of a range differ by less than
+        // that -- 200 intervals of which a range varies the last dozen: BASELINE config 5's shape -- it lists percent of them as
+        // contenders, the list overflows and the ladder below redoes slices.  The double instantiation's margin is a few units: from
+        // the next call on this problem runs it (6x faster there: 0.30 -> 0.05 s per 2^30 candidates).  Decided on the BULK slices
+        // (their minimum is fresh: a stale one is the short first slice's to absorb), and only with the list at its full capacity.
+        if (!slices.empty() && p->opt_auto64 && !p->auto64 && !p->n3.force64 && !p->n3.no_dismiss && !p->opt_surv_cap && slices.size() >= 2) {
+            unsigned long long listed = 0, tasks_bulk = 0;
+            for (size_t sl = 1; sl < slices.size(); sl++) {
+                listed += hcnt[sl];
+                tasks_bulk += (unsigned long long)slices[sl].second;
+            }
+            if (tasks_bulk >= 8 * 2048 && (double)listed > 0.005 * (double)tasks_bulk * (double)sieve_per_task) p->auto64 = 1;
+        }
         // A slice of the sieve whose contender list overflowed is redone.  The usual cause is a STALE minimum: the slice runs into
         // a region whose candidates beat the running minimum it was judged against, so a large share of them looks like a
         // contender.  The finish kernel has meanwhile gone through the 2^24 that were listed and lowered the minimum, so the same
@@ -759,6 +780,7 @@ static int run_search(theta_problem *p, u128 b, u128 e, double window, double *d
             redone += (uint64_t)(se - sb);
             N3Dev PS = p->n3;
             PS.L = n3_sieve_levels(p->n3);
+            if (p->opt_auto64 && p->auto64) PS.force64 = 1;
             unsigned *cnt2 = (unsigned *)p->d_survcnt.p + (SIEVE_MAX_SLICES - 1), *acc2 = (unsigned *)p->d_survacc.p + (SIEVE_MAX_SLICES - 1);
             // sieve + finish over tasks [ta, ta + na) of the rebuilt task list of this slice; returns the contender count
             auto again = [&](int ta, int na, unsigned &count) -> int {
