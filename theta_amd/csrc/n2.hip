@@ -273,8 +273,8 @@ __host__ __device__ inline size_t n2_prn_offset(int m) {
 __host__ __device__ inline size_t n2_xs_offset(int m) { return n2_prn_offset(m) + (size_t)(m + 1) * 16; }
 __host__ __device__ inline size_t n2_queue_offset(int m, int kv) { return n2_xs_offset(m) + (size_t)kv * 256 * 8; }     // (chain points and their slopes: floats)
 
-template <int KV, bool DUMP>
-__global__ __launch_bounds__(256) void n2_search_kernel(N2Dev P, SearchArgs A, unsigned long long begin,
+template <int KV, bool DUMP, bool QUICK = false>
+__global__ __launch_bounds__(256, (QUICK && KV <= 8) ? 3 : 1) void n2_search_kernel(N2Dev P, SearchArgs A, unsigned long long begin,
                                                         unsigned long long end, int per_thread, unsigned long long sample_stride) {
     extern __shared__ unsigned char smem[];
     // LDS staging of everything the candidates share
@@ -290,7 +290,7 @@ __global__ __launch_bounds__(256) void n2_search_kernel(N2Dev P, SearchArgs A, u
     for (int i = threadIdx.x; i < P.m * N2_KVS; i += blockDim.x) Pl[i] = P.P[i];
     for (int i = threadIdx.x; i <= N2_KVS; i += blockDim.x) lbposl[i] = P.lbpos[i];
     for (int i = threadIdx.x; i < P.m; i += blockDim.x) ubl[i] = P.ub[i];
-    if (!DUMP && P.quick)
+    if (QUICK)
         for (int i = threadIdx.x; i <= P.m; i += blockDim.x) ((double2 *)(smem + n2_prn_offset(P.m)))[i] = make_double2(P.PR[i], P.PN[i]);
     __syncthreads();
 
@@ -315,7 +315,7 @@ __global__ __launch_bounds__(256) void n2_search_kernel(N2Dev P, SearchArgs A, u
     }
     unsigned long long t0 = begin + tid * (unsigned long long)per_thread;
     unsigned long long n_eval = 0, n_acc = 0, n_deg = 0, n_it = 0, n_terms = 0, n_fin = 0, n_dis = 0;
-    const bool quick = !DUMP && P.quick;
+    constexpr bool quick = QUICK;        // (an instantiation of its own: the dismissing search does not carry the other loop's registers)
     const double inv_N = 1.0 / P.N;
     // f32 screen: |error| <= ~1e-6 * Rtot * ln(range) -- a margin of 2e-5 Rtot is far outside it
     const double margin = 2e-5 * P.Rtot + 1.0;
@@ -346,7 +346,7 @@ __global__ __launch_bounds__(256) void n2_search_kernel(N2Dev P, SearchArgs A, u
             A.dump_mu[(rank - begin) * 2 + 1] = rs.ok ? 1.0 - rs.mu : __builtin_nan("");
         }
     };
-    if (!quick) {
+    if constexpr (!QUICK) {
         if (t0 < end) {
             unsigned long long t1 = t0 + (unsigned long long)per_thread;
             if (t1 > end) t1 = end;
@@ -791,22 +791,24 @@ void n2_launch_search(const N2Dev &P, const SearchArgs &A, unsigned long long be
     unsigned long long threads = sample_stride ? (n + sample_stride - 1) / sample_stride : (n + per_thread - 1) / per_thread;
     unsigned blocks = (unsigned)((threads + 255) / 256);
     const bool dump = A.dump_nll != nullptr;
-    // (+ the per-wave queues of the dismissing search: N2_QCAP entries of 4 + (KV + 2) / 2 words)
-    const int kvt = P.kv <= 8 ? 8 : 16;
-    const size_t sm = dump ? n2_smem_bytes(P) : n2_queue_offset(P.m, kvt) + (size_t)4 * N2_QCAP * (4 + (kvt + 2) / 2) * 4;
-    if (sm > 48 * 1024) {      // (m beyond ~300 intervals: more than the default dynamic LDS limit)
-        (void)hipFuncSetAttribute((const void *)n2_search_kernel<8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
-        (void)hipFuncSetAttribute((const void *)n2_search_kernel<16, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
-        (void)hipFuncSetAttribute((const void *)n2_search_kernel<8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
-        (void)hipFuncSetAttribute((const void *)n2_search_kernel<16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
-    }
+    const bool quick = !dump && P.quick != 0;       // the dismissing search: an instantiation of its own (QUICK), with its per-wave queues,
+    const int kvt = P.kv <= 8 ? 8 : 16;             // chain points and interleaved prefix sums in LDS behind the common tables
+    const size_t sm = quick ? n2_queue_offset(P.m, kvt) + (size_t)4 * N2_QCAP * (4 + (kvt + 2) / 2) * 4 : n2_smem_bytes(P);
+#define N2_LAUNCH(KVV, DD, QQ)                                                                                                                    \
+    do {                                                                                                                                          \
+        if (sm > 48 * 1024) (void)hipFuncSetAttribute((const void *)n2_search_kernel<KVV, DD, QQ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); \
+        hipLaunchKernelGGL((n2_search_kernel<KVV, DD, QQ>), dim3(blocks), dim3(256), sm, st, P, A, begin, end, per_thread, sample_stride);       \
+    } while (0)
     if (P.kv <= 8) {
-        if (dump) hipLaunchKernelGGL((n2_search_kernel<8, true>), dim3(blocks), dim3(256), sm, st, P, A, begin, end, per_thread, sample_stride);
-        else hipLaunchKernelGGL((n2_search_kernel<8, false>), dim3(blocks), dim3(256), sm, st, P, A, begin, end, per_thread, sample_stride);
+        if (dump) N2_LAUNCH(8, true, false);
+        else if (quick) N2_LAUNCH(8, false, true);
+        else N2_LAUNCH(8, false, false);
     } else {
-        if (dump) hipLaunchKernelGGL((n2_search_kernel<16, true>), dim3(blocks), dim3(256), sm, st, P, A, begin, end, per_thread, sample_stride);
-        else hipLaunchKernelGGL((n2_search_kernel<16, false>), dim3(blocks), dim3(256), sm, st, P, A, begin, end, per_thread, sample_stride);
+        if (dump) N2_LAUNCH(16, true, false);
+        else if (quick) N2_LAUNCH(16, false, true);
+        else N2_LAUNCH(16, false, false);
     }
+#undef N2_LAUNCH
 }
 
 void n2_launch_enumerate(const N2Dev &P, unsigned long long begin, unsigned long long count, unsigned char *out,
