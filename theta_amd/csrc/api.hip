@@ -144,7 +144,6 @@ extern "C" int theta_device_info(theta_ctx *c, char *name, int cap, int *cu, uin
 #define SUS_CAP (1u << 20)
 #define DEG_CAP (1u << 20)
 #define LINE_CAP (1u << 19)      // n=3 sieve: tasks per call that may report a prefix with collinear rows (a call holds at most 2^18 tasks; redone slices report again)
-#define N3_MAX_TASKS (1 << 18)
 #define SURV_CAP (1u << 24)           /* contenders per slice of the sieve (2.4 GB of the 288 GB, allocated on first use) */
 #define SIEVE_SLICE (1ull << 31)     /* candidates per sieve launch; the finish kernel runs in between and lowers the minimum */
 #define SIEVE_MAX_SLICES 64
@@ -409,7 +408,7 @@ extern "C" int theta_problem_create(theta_ctx *ctx, int n, int m, int tau, const
         if (L > m - 1) L = m - 1;
         D.L = L;
         TRY(p->d_tasks.alloc((size_t)N3_MAX_TASKS * sizeof(N3Task)));
-        TRY(p->d_stbuf.alloc((size_t)N3_MAX_TASKS * N3_STB * sizeof(unsigned)));
+        TRY(p->d_stbuf.alloc(((size_t)N3_MAX_TASKS * N3_STB + 16 * N3_STB) * sizeof(unsigned)));      // (+ the anchor path of n3_launch_tasks)
     }
     HIP_TRY(hipStreamSynchronize(st));
 #undef TRY

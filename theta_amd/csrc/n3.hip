@@ -222,12 +222,15 @@ __device__ bool n3_unrank(const N3Dev &P, u128 rho, int depth, N3State *st, u128
 // Wave-cooperative rank -> DFS path: at every level the 64 lanes test the 64 alphabet slots and read their
 // children's counts in ONE memory round trip (the serial walk above chains ~5 dependent HBM reads per level);
 // the wave then scans the feasible children in slot order.  Lane d ends up holding the packed node of depth d.
-// (the packed node of depth d is written to states[d] by lane 0 -- `states` may be global or shared memory)
-__device__ bool n3_unrank_wave(const N3Dev &P, u128 rho, int depth, int lane, unsigned *states, u128 &rem) {
+// (the packed node of depth d is written to states[d] by lane 0 -- `states` may be global or shared memory).  The walk may start
+// below the root: depths [d0, depth) under the node `par` of depth d0 - 1, rho = the rank within that node's subtree.  With
+// `trail` the walk also records, per depth, the rank left inside the chosen node's subtree and that subtree's size
+// (trail[2 d], trail[2 d + 1]: what n3_task_kernel needs to start other ranks of the same neighbourhood half-way down).
+__device__ bool n3_unrank_wave(const N3Dev &P, u128 rho, int depth, int lane, unsigned *states, u128 &rem, int d0 = 0,
+                               N3State par = N3State{0, 0, 0, 0, 0, 0}, u128 *trail = nullptr) {
     const unsigned myrow = lane < P.Q ? P.rowtab[lane] : 0u;       // one alphabet slot per lane
     const int sa = (int)(myrow & 15u), sb = (int)(myrow >> 4);
-    N3State par{0, 0, 0, 0, 0, 0};
-    for (int d = 0; d < depth; d++) {
+    for (int d = d0; d < depth; d++) {
         N3State nx{0, 0, 0, 0, 0, 0};
         bool ok = lane < P.Q && (d == 0 ? n3_first_row_ab(P, sa, sb, lane, nx) : n3_edge_ab(P, par, sa, sb, lane, d, nx));
         u128 v = 0;
@@ -235,6 +238,7 @@ __device__ bool n3_unrank_wave(const N3Dev &P, u128 rho, int depth, int lane, un
         unsigned v0 = (unsigned)v, v1 = (unsigned)(v >> 32), v2 = (unsigned)(v >> 64), v3 = (unsigned)(v >> 96);
         unsigned long long mk = ballot64(ok);
         int chosen = -1;
+        u128 vsel = 0;
         while (mk) {
             int b = __builtin_ctzll(mk);
             mk &= mk - 1;
@@ -244,6 +248,7 @@ __device__ bool n3_unrank_wave(const N3Dev &P, u128 rho, int depth, int lane, un
                       (u128)(unsigned)__builtin_amdgcn_readlane((int)v0, b);
             if (rho < vb) {
                 chosen = b;
+                vsel = vb;
                 break;
             }
             rho -= vb;
@@ -252,24 +257,66 @@ __device__ bool n3_unrank_wave(const N3Dev &P, u128 rho, int depth, int lane, un
         unsigned mine = ok ? n3_pack(nx) : 0u;
         unsigned packed = (unsigned)__builtin_amdgcn_readlane((int)mine, chosen);
         par = n3_unpack(packed);
-        if (lane == 0) states[d] = packed;
+        if (lane == 0) {
+            states[d] = packed;
+            if (trail) {
+                trail[2 * d] = rho;
+                trail[2 * d + 1] = vsel;
+            }
+        }
     }
     rem = rho;
     return true;
 }
 
-// one wave per task: where does the task start?
+// The path of the range's FIRST rank, with its trail (one wave): the tasks of a call are consecutive rank ranges, so their paths
+// share all but the last few levels with it -- 2^31 candidates of the bench's space span twelve levels of forty-four.
+// anchor: [N3_STB] packed nodes, then [2 N3_STB] u128 trail, then one flag word (1 = valid)
+#define N3_ANCHOR_WORDS (N3_STB + 8 * N3_STB + 4)
+__global__ __launch_bounds__(64) void n3_anchor_kernel(N3Dev P, uint64_t b_lo, uint64_t b_hi, unsigned *anchor) {
+    const int lane = threadIdx.x & 63, D = P.m - P.L;
+    u128 rem = 0;
+    const bool ok = n3_unrank_wave(P, ((u128)b_hi << 64) | b_lo, D, lane, anchor, rem, 0, N3State{0, 0, 0, 0, 0, 0}, (u128 *)(anchor + N3_STB));
+    if (lane == 0) anchor[N3_STB + 8 * N3_STB] = ok ? 1u : 0u;
+}
+
+// one wave per task: where does the task start?  From the deepest node of the anchor path whose subtree still holds the task's
+// first rank (rank left in the subtree + the task's offset < the subtree's size: true for every shallower node too), not from the root.
 __global__ __launch_bounds__(256) void n3_task_kernel(N3Dev P, uint64_t b_lo, uint64_t b_hi, uint64_t e_lo, uint64_t e_hi,
-                                                      uint64_t per_task, int ntasks, N3Task *tasks, unsigned *stbuf) {
+                                                      uint64_t per_task, int ntasks, N3Task *tasks, unsigned *stbuf, const unsigned *anchor) {
     const int t = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (t >= ntasks) return;
     const u128 begin = ((u128)b_hi << 64) | b_lo, end = ((u128)e_hi << 64) | e_lo;
-    u128 base = begin + (u128)t * per_task;
+    const u128 off = (u128)t * per_task;
+    u128 base = begin + off;
     u128 left = end - base;
     uint64_t count = left < (u128)per_task ? (uint64_t)left : per_task;
     const int D = P.m - P.L;
+    unsigned *states = stbuf + (size_t)t * N3_STB;
     u128 rem = 0;
-    bool ok = n3_unrank_wave(P, base, D, lane, stbuf + (size_t)t * N3_STB, rem);
+    int d0 = 0;
+    N3State par{0, 0, 0, 0, 0, 0};
+    u128 rho = base;
+    if (anchor && anchor[N3_STB + 8 * N3_STB]) {
+        const u128 *trail = (const u128 *)(anchor + N3_STB);
+        int deepest = -1;                                  // deepest depth whose anchor node still holds this task's first rank
+        for (int d = lane; d < D; d += WAVE) {
+            const u128 r = trail[2 * d], sz = trail[2 * d + 1], sum = r + off;
+            if (sum >= r && sum < sz) deepest = d;         // (sum >= r: no wrap-around of the 128-bit addition)
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const int other = __shfl_xor(deepest, o, WAVE);
+            deepest = other > deepest ? other : deepest;
+        }
+        if (deepest >= 0) {
+            for (int d = lane; d <= deepest; d += WAVE) states[d] = anchor[d];
+            par = n3_unpack(anchor[deepest]);
+            rho = trail[2 * deepest] + off;
+            d0 = deepest + 1;
+        }
+    }
+    bool ok = n3_unrank_wave(P, rho, D, lane, states, rem, d0, par);
     if (lane == 0) {
         N3Task tk;
         tk.base_lo = (uint64_t)base;
@@ -1620,8 +1667,12 @@ int n3_run_dp(const N3Dev &P, u128 *cnt, unsigned *overflow_dev, unsigned long l
 
 void n3_launch_tasks(const N3Dev &P, u128 begin, u128 end, uint64_t per_task, int ntasks, N3Task *tasks,
                      unsigned *stbuf, hipStream_t st) {
+    // (the anchor lives behind the N3_MAX_TASKS state rows of `stbuf`, which api.hip allocates with room for it)
+    unsigned *anchor = getenv("THETA_N3_NO_ANCHOR") ? nullptr : stbuf + (size_t)N3_MAX_TASKS * N3_STB;
+    if (anchor && ntasks > 1) hipLaunchKernelGGL(n3_anchor_kernel, dim3(1), dim3(64), 0, st, P, (uint64_t)begin, (uint64_t)(begin >> 64), anchor);
+    else anchor = nullptr;
     hipLaunchKernelGGL(n3_task_kernel, dim3((ntasks + 3) / 4), dim3(256), 0, st, P, (uint64_t)begin, (uint64_t)(begin >> 64),
-                       (uint64_t)end, (uint64_t)(end >> 64), per_task, ntasks, tasks, stbuf);
+                       (uint64_t)end, (uint64_t)(end >> 64), per_task, ntasks, tasks, stbuf, (const unsigned *)anchor);
 }
 
 void n3_launch_search(const N3Dev &P, const SearchArgs &A, const N3Task *tasks, const unsigned *stbuf, int ntasks,

@@ -16,6 +16,7 @@
 #define N3_MAX_Q 64
 #define N3_MAX_M 64              // one interval per lane (fused kernel, generators)
 #define N3_MAX_M_WIDE 256        // up to four prefix intervals per lane: the sieve path (n3_sieve.hip), the burst generator, task and unrank kernels
+#define N3_MAX_TASKS (1 << 18)
 #define N3_STB 256               // stride of the per-task prefix states (one packed DFS node per depth)
 #define N3_RIDX_W (2 * N3_MAX_COPY + 1)
 

@@ -48,7 +48,7 @@ def main():
     ap.add_argument("--n2", type=int, default=240)
     ap.add_argument("--seconds", type=float, default=420.0)
     ap.add_argument("--max-candidates", type=int, default=25000)
-    ap.add_argument("--shape", choices=["toy", "mid", "low"], default="toy")
+    ap.add_argument("--shape", choices=["toy", "mid", "low", "amp"], default="toy")
     a = ap.parse_args()
     global SHAPE
     SHAPE = a.shape
