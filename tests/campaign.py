@@ -86,7 +86,7 @@ def instance_low(seed, n):
     return dict(seed=seed, n=n, m=m, k=k, tau=tau, mx=1.0, r=rs, rN=rNs, order=order, lb=lb, ub=ub, shape="low")
 
 
-def instance_amp(seed, n=3):
+def instance_amp(seed, n=3, wide=False):
     """n=3 with the bounds the reference's OWN heuristic derives (calculate_bounds_heuristic, DataTools.py:47-67) from counts that
     hold one or two strongly amplified intervals: ub = max(k, y + 1), y = round(tau ratio), exceeds k there -- an interval at four
     times the normal ratio gets [7, 9] -- while the others keep [0, tau].  Copy numbers above 7: the compact row alphabet
@@ -95,7 +95,7 @@ def instance_amp(seed, n=3):
     import contextlib
     import io
     rng = np.random.RandomState(seed)
-    m, k, tau = int(rng.randint(5, 8)), 3, 2
+    m, k, tau = (int(rng.randint(8, 11)) if wide else int(rng.randint(5, 8))), 3, 2       # (wide: m >= 8, the sieve path)
     rN = np.maximum(rng.poisson(rng.choice([300, 2000, 20000]) * rng.uniform(0.5, 1.5, m)), 20)
     ratio = rng.uniform(0.55, 1.15, m)
     amp = rng.choice(m, int(rng.choice([1, 1, 2])), replace=False)
@@ -106,12 +106,12 @@ def instance_amp(seed, n=3):
     with contextlib.redirect_stdout(io.StringIO()):
         ub, lb = DT.calculate_bounds_heuristic(0.5, rs, rNs, m, tau, k)
     return dict(seed=seed, n=3, m=m, k=k, tau=tau, mx=1.0, r=rs, rN=rNs, order=order, lb=[int(v) for v in lb], ub=[int(v) for v in ub],
-                shape="amp")
+                shape="ampw" if wide else "amp")
 
 
 def instance(seed, n, shape="toy"):
-    if shape == "amp":
-        return instance_amp(seed, n)
+    if shape in ("amp", "ampw"):
+        return instance_amp(seed, n, wide=shape == "ampw")
     return instance_mid(seed, n) if shape == "mid" else instance_low(seed, n) if shape == "low" else instance_toy(seed, n)
 
 

@@ -106,6 +106,29 @@ def test_copy_numbers_above_seven_enumerate_in_the_reference_order_and_search_li
         if done >= 3:
             break
     assert done == 3
+    # eight to ten intervals: the sieve path (its ratio table holds differences up to 7 copies in LDS, the rest in HBM) against the
+    # fused kernel and against the reference's own procedure on EVERY candidate (theta_solve_batch + the replay of its rule)
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import exact_replay_check as erc
+    from theta_amd import search as S
+    done = 0
+    for seed in range(9101, 9200):
+        inst = campaign.instance(seed, 3, "ampw")
+        if max(inst["ub"]) < 8 or not (20000 <= campaign.count_candidates(inst) <= 3_000_000):
+            continue
+        p = theta_amd.Problem(ctx, 3, inst["m"], 2, inst["r"], inst["rN"], inst["lb"], inst["ub"], 1.0)
+        a = p.search(0, p.count, window=0.5)
+        p.set_option("n3_sieve", 0)
+        f = p.search(0, p.count, window=0.5)
+        assert a["rank"] == f["rank"] and np.array_equal(a["C"], f["C"]) and np.allclose(a["nll"], f["nll"], rtol=1e-11, atol=0), seed
+        p.close()
+        best = do_optimization_single(3, inst["m"], inst["k"], 2, list(inst["lb"]), list(inst["ub"]), inst["r"], inst["rN"], 1.0, inst["order"])
+        ref, _cnt = erc.exact_best(ctx, inst, S.last_report.window, 3)
+        assert campaign.compare_best(campaign.best_to_plain(best), campaign.best_to_plain(ref)) == "", seed
+        done += 1
+        if done >= 4:
+            break
+    assert done == 4
     # full bounds [0, 9] on every interval leave 72 valid rows: more than the kernels hold -- refused with a message, not a crash
     r, rN = inst["r"], inst["rN"]
     with pytest.raises(theta_amd.ThetaError) as e:

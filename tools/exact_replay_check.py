@@ -146,8 +146,8 @@ def main():
     shapes = ((3, "mid"), (3, "low"), (2, "synth"))
     if len(sys.argv) > 3 and sys.argv[3] == "toy":         # (small spaces, m = 4..7: the fused kernel's path)
         shapes = ((3, "toy"), (2, "toy"), (2, "mid"))
-    if len(sys.argv) > 3 and sys.argv[3] == "amp":         # (copy numbers above 7: bounds of the reference's heuristic, the compact alphabet)
-        shapes = ((3, "amp"),)
+    if len(sys.argv) > 3 and sys.argv[3] in ("amp", "ampw"):   # (copy numbers above 7: bounds of the reference's heuristic, the compact alphabet;
+        shapes = ((3, sys.argv[3]),)                            #  ampw: 8-10 intervals, the sieve path)
     for n, shape in shapes:
         seed, got = int(os.environ.get("EXACT_SEED0", 30000)), 0
         while got < want:
@@ -163,9 +163,9 @@ def main():
             else:
                 inst = campaign.instance(seed, n, shape)
             cnt = campaign.count_candidates(inst)
-            if shape == "amp" and max(inst["ub"]) < 8:
+            if shape in ("amp", "ampw") and max(inst["ub"]) < 8:
                 continue
-            if not ((200 if shape in ("toy", "amp") or (n == 2 and shape == "mid") else 100_000 if n == 3 else 20_000) <= cnt <= cap):
+            if not ((200 if shape in ("toy", "amp", "ampw") or (n == 2 and shape == "mid") else 100_000 if n == 3 else 20_000) <= cnt <= cap):
                 continue
             got += 1
             if os.environ.get("EXACT_TAIL") and n == 3:     # (the whole-space NaN sweep off: only the tail behind the first entry of best is swept)
