@@ -41,7 +41,7 @@ enum {
     THETA_ERR_ARG = 1,           /* bad argument (shape, range, null pointer)                 */
     THETA_ERR_NO_CANDIDATES = 2, /* bounds admit no matrix (RunTHetA.py:217-219 exits here)   */
     THETA_ERR_HIP = 3,           /* HIP runtime failure (no device, launch error, OOM)        */
-    THETA_ERR_OVERFLOW = 4,      /* candidate count does not fit 128 bits (n=3) / 64 bits (n=2)*/
+    THETA_ERR_OVERFLOW = 4,      /* n=2 count beyond 64 bits; a rank range no search finishes   */
     THETA_ERR_CAPACITY = 5       /* output capacity too small; *n_out holds the needed size   */
 };
 
@@ -73,6 +73,10 @@ int theta_synchronize(theta_ctx *ctx);
  * of TimeEstimate.count_number_matrices_2, TimeEstimate.py:91-111; the n=3 table counts the
  * matrices Enumerator._generate_next_C_3 really yields, Enumerator.py:172-214).
  * max_normal is only enforced for n=2, like the reference (Optimizer.py:107-110).
+ * n=3: copy numbers (bounds) up to THETA_MAX_COPY, as long as at most 64 distinct valid rows (a, b) lie within the bounds of some
+ * interval (always so up to 7; beyond, the reference's own bounds heuristic -- ub = max(k, y + 1), DataTools.py:64-66 -- produces
+ * narrow windows that fit): THETA_ERR_ARG otherwise.  A space of 2^128 matrices or more is accepted: its count saturates at
+ * 2^128 - 1 (theta_problem_count: "that many or more") and rank ranges below that are searched like any other.
  */
 int theta_problem_create(theta_ctx *ctx, int n, int m, int tau, const int64_t *r, const int64_t *rN,
                          const int32_t *lb, const int32_t *ub, double max_normal,
@@ -178,6 +182,11 @@ int theta_search_degenerate(theta_problem *p, int cap, uint64_t *rank, uint8_t *
  *                    NaN likelihood -- about one full-rank matrix in a million, decided by where MINPACK's iteration stops --, and the ones
  *                    it reports at or below the search's minimum + window, join
  *                    the list of theta_search_degenerate.  0 (default).  theta_amd.search sets it for spaces up to 2^33 matrices
+ *   "n3_auto_f64"    1 (default): a problem on which the packed-FP32 screen lists more than 0.5 % of a call's candidates as contenders
+ *                    (its margin, 2e-5 sum r + 1, is coarse against the spread of the NLL within the range: 200 intervals of which a
+ *                    range varies the last dozen) runs the double instantiation from the next call on; 0: never (same finalists)
+ *   "n2_no_dismiss"  1: the n=2 search solves every candidate; 0 (default): a candidate whose rigorous lower bound -- one evaluation
+ *                    at a chain point, self-concordance -- lies beyond the window of the running minimum is done (same finalists)
  *   "n3_per_task"    candidates per wave task (0 = automatic), "n2_per_thread" candidates per thread (0 = automatic)
  * The THETA_N3_* environment variables of the same names only set the defaults at theta_problem_create.
  */
