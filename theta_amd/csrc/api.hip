@@ -641,10 +641,11 @@ static int run_search(theta_problem *p, u128 b, u128 e, double window, double *d
             n2_launch_search(p->n2, A, nb, ne, (int)per, st);
         } else {
             u128 cnt = e - b;
-            // candidates per wave task: 8192 for launches up to 2^29 candidates, growing to 32768 so that a launch has
-            // ~65536 tasks (about 21 per resident wave: a short tail, and a cheap task set-up); tuned, DESIGN.md
+            // candidates per wave task: 8192 for launches up to 2^29 candidates, 16384 beyond (the sieve's waves fetch tasks as
+            // they finish them, so the tail of a launch is one task long: 16384 measured 3 % faster than 32768 on the search
+            // leg, 8192 pays more for the task set-up than it wins); tuned, profiles/r4/NOTES.md
             uint64_t per_task = 8192;
-            while (per_task < 32768 && (u128)per_task * 65536u < cnt) per_task <<= 1;
+            while (per_task < 16384 && (u128)per_task * 65536u < cnt) per_task <<= 1;
             if (const char *e = getenv("THETA_N3_PER_TASK")) {
                 long long v = atoll(e);
                 if (v >= 64 && v <= 65535) per_task = (uint64_t)v;   // the kernel keeps in-task offsets in 16 bits
@@ -670,10 +671,10 @@ static int run_search(theta_problem *p, u128 b, u128 e, double window, double *d
                 if (!p->d_surv.p) {
                     int rc = p->d_surv.alloc((size_t)SURV_CAP * sizeof(SvSurvivor));
                     if (rc) return rc;
-                    if ((rc = p->d_survcnt.alloc(SIEVE_MAX_SLICES * sizeof(unsigned)))) return rc;
+                    if ((rc = p->d_survcnt.alloc((SV_TASKCTR_OFF + SIEVE_MAX_SLICES) * sizeof(unsigned)))) return rc;   // (+ the launches' task counters)
                     if ((rc = p->d_survacc.alloc(SIEVE_MAX_SLICES * sizeof(unsigned)))) return rc;
                 }
-                HIP_TRY(hipMemsetAsync(p->d_survcnt.p, 0, SIEVE_MAX_SLICES * sizeof(unsigned), st));
+                HIP_TRY(hipMemsetAsync(p->d_survcnt.p, 0, (SV_TASKCTR_OFF + SIEVE_MAX_SLICES) * sizeof(unsigned), st));
                 HIP_TRY(hipMemsetAsync(p->d_survacc.p, 0, SIEVE_MAX_SLICES * sizeof(unsigned), st));
                 n3_launch_tasks(PS, b, e, per_task, ntasks, (N3Task *)p->d_tasks.p, (unsigned *)p->d_stbuf.p, st);
                 HIP_TRY(hipEventRecord(ctx->ev1, st));
@@ -784,6 +785,7 @@ static int run_search(theta_problem *p, u128 b, u128 e, double window, double *d
             // sieve + finish over tasks [ta, ta + na) of the rebuilt task list of this slice; returns the contender count
             auto again = [&](int ta, int na, unsigned &count) -> int {
                 HIP_TRY(hipMemsetAsync(cnt2, 0, sizeof(unsigned), st));
+                HIP_TRY(hipMemsetAsync(cnt2 + SV_TASKCTR_OFF, 0, sizeof(unsigned), st));
                 HIP_TRY(hipEventRecord(ctx->ev1, st));
                 n3_launch_sieve(PS, A, (const N3Task *)p->d_tasks.p + ta, (const unsigned *)p->d_stbuf.p + (size_t)ta * N3_STB, na,
                                 (SvSurvivor *)p->d_surv.p, surv_cap, cnt2, st);

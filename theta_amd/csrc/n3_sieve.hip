@@ -97,6 +97,12 @@ __device__ __forceinline__ float sv_abs(float x) { return fabsf(x); }
 __device__ __forceinline__ double sv_abs(double x) { return fabs(x); }
 __device__ __forceinline__ float sv_min(float a, float b) { return fminf(a, b); }
 __device__ __forceinline__ double sv_min(double a, double b) { return fmin(a, b); }
+__device__ __forceinline__ float sv_bcast0(float x) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, x))); }
+__device__ __forceinline__ double sv_bcast0(double x) {
+    const unsigned long long b = __builtin_bit_cast(unsigned long long, x);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)b), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(b >> 32));
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
 template <class F> struct SvVec;
 template <> struct SvVec<float> { typedef float v2 __attribute__((ext_vector_type(2))); };
 template <> struct SvVec<double> { typedef double v2 __attribute__((ext_vector_type(2))); };
@@ -507,7 +513,10 @@ __device__ __forceinline__ void sv_parent(SvCtx<ML, F, NS> &c, bool take, unsign
     }
     // the lane's chain point as a direction: mixture (n1, n2) pulled slightly towards the simplex centre, u_j = n_j / s_j with
     // the node's own (partial) column sums -- any scale is as good as any other
-    const F n1 = sv_fma(F(0.98), c.wn1, F(0.02 / 3.0)), n2 = sv_fma(F(0.98), c.wn2, F(0.02 / 3.0));
+    // (lane 0's chain for the whole round -- it has had a child in every trip: one point per round does as well as one per lane
+    // [measured: 1 % fewer queue evaluations], holding it for 4 / 16 rounds or a whole prefix does not: +4 / +16 / +42 % time)
+    const F b1 = sv_bcast0(c.wn1), b2 = sv_bcast0(c.wn2);
+    const F n1 = sv_fma(F(0.98), b1, F(0.02 / 3.0)), n2 = sv_fma(F(0.98), b2, F(0.02 / 3.0));
     const bool sums_ok = S1 > F(0) && S2 > F(0);
     const F w0 = F(1) - n1 - n2;
     const F u1 = n1 * sv_rcp(sums_ok ? S1 : F(1)), u2 = n2 * sv_rcp(sums_ok ? S2 : F(1));
@@ -853,6 +862,15 @@ __device__ __forceinline__ void sv_expand(SvCtx<ML, F, NS> &c, int n_in) {
     }
 }
 
+// The next task of the launch, for the whole wave.  Out of line on purpose: with the fetch inlined into the kernel's task loop
+// (hipcc 7.2, -O3) the wave never left the loop -- one task per wave through the same counter, or a grid-stride loop without
+// the counter, both ran; bisected on the GPU, profiles/r4/NOTES.md.
+__device__ __noinline__ int sv_next_task(unsigned *ctr) {
+    int t = 0;
+    if ((threadIdx.x & 63) == 0) t = (int)__hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return __builtin_amdgcn_readfirstlane(t);
+}
+
 template <int ML, class F, int NS>
 __global__ __launch_bounds__(64 * SV_WAVES, sizeof(F) == 4 ? SV_OCC : SV_OCC64) void n3_sieve_kernel(N3Dev Pg, SearchArgs A, const N3Task *tasks, const unsigned *stbuf,
                                                                           int ntasks, SvSurvivor *surv, unsigned surv_cap,
@@ -878,8 +896,14 @@ __global__ __launch_bounds__(64 * SV_WAVES, sizeof(F) == 4 ? SV_OCC : SV_OCC64) 
     P.rowtab = S.rowtab;               // (P.ridx stays the full table in HBM: the prefix successor reads it once per prefix)
 
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int task = blockIdx.x * SV_WAVES + wv;
-    if (task >= ntasks) return;                        // whole wave leaves together; no block barrier below
+    // PERSISTENT WAVES: a wave takes the next task of the launch whenever it has finished one (one counter per launch, behind the
+    // launch's contender counter).  With one task per wave and four waves per block, a block held its registers and LDS until
+    // its slowest task was through, and the last blocks of a launch ran on a nearly empty chip: 10 % of the wave slots' time.
+    unsigned *const task_next = surv_count + SV_TASKCTR_OFF;
+    for (;;) {
+    const int task = sv_next_task(task_next);
+    if (task >= ntasks) break;                         // whole wave leaves together; no block barrier below
+    wave_lds_sync();                                   // (the wave's LDS areas are rewritten for the new task)
     const N3Task tk = tasks[task];
     unsigned st[NS];                                   // lane l: the packed prefix nodes of depths l, 64 + l, ...
 #pragma unroll
@@ -1154,6 +1178,7 @@ __global__ __launch_bounds__(64 * SV_WAVES, sizeof(F) == 4 ? SV_OCC : SV_OCC64) 
 #endif
         atomicAdd(&sc->prof[7], (unsigned long long)c.n_prefix);
     }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -1344,7 +1369,16 @@ int n3_sieve_levels(const N3Dev &P) {
 
 void n3_launch_sieve(const N3Dev &P, const SearchArgs &A, const N3Task *tasks, const unsigned *stbuf, int ntasks, SvSurvivor *surv,
                      unsigned surv_cap, unsigned *surv_count, hipStream_t st) {
-    dim3 grid((ntasks + SV_WAVES - 1) / SV_WAVES), block(64 * SV_WAVES);
+    // as many blocks as the chip holds at once (or as there are tasks for): the waves fetch their tasks themselves
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
+        if (n_cu <= 0) n_cu = 256;
+    }
+    const int need = (ntasks + SV_WAVES - 1) / SV_WAVES, resident = n_cu * (P.force64 ? SV_OCC64 : SV_OCC);
+    dim3 grid(need < resident ? need : resident), block(64 * SV_WAVES);
     // (NS = prefix intervals per lane: 2 up to 128 intervals -- the instantiation everything is tuned for --, 4 up to 256: BASELINE
     // config 5's shape, m = 200; wider prefix tables in LDS, two blocks per CU)
 #define SV_LAUNCH(MLV, FT, NSV) hipLaunchKernelGGL((n3_sieve_kernel<MLV, FT, NSV>), grid, block, 0, st, P, A, tasks, stbuf, ntasks, surv, surv_cap, surv_count)

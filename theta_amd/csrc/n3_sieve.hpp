@@ -9,6 +9,10 @@ struct SvSurvivor {
     unsigned char rows[2 * N3_MAX_M_WIDE];
 };
 
+// The sieve kernel's waves fetch their tasks from a counter of the launch: it sits SV_TASKCTR_OFF words behind the launch's
+// contender counter (`surv_count`), zero at launch.
+#define SV_TASKCTR_OFF 64
+
 int n3_sieve_levels(const N3Dev &P);
 void n3_launch_sieve(const N3Dev &P, const SearchArgs &A, const N3Task *tasks, const unsigned *stbuf, int ntasks, SvSurvivor *surv,
                      unsigned surv_cap, unsigned *surv_count, hipStream_t st);
