@@ -416,7 +416,18 @@ def main():
     comm = None
     if world > 1:
         # "rccl" = RCCL over xGMI (the library dlopens librccl.so); "host" only for smoke tests on a 1-GPU box
-        comm = theta_amd.Comm(ctx, rank=rank, world=world, transport=os.environ.get("THETA_BENCH_TRANSPORT", "rccl"))
+        want = os.environ.get("THETA_BENCH_TRANSPORT", "rccl")
+        try:
+            comm = theta_amd.Comm(ctx, rank=rank, world=world, transport=want)
+        except theta_amd.ThetaError as ex:
+            # RCCL could not be set up (librccl.so missing, ncclCommInitRank refused): the two collectives of the job are a few
+            # hundred bytes, so the library's host transport carries them just as well -- say so on the line instead of failing
+            # the run.  (A failure on SOME ranks only ends in the rendezvous time-out of this second attempt.)
+            if want != "rccl":
+                raise
+            print("rank %d: RCCL transport failed (%s); falling back to the host transport" % (rank, ex), file=sys.stderr)
+            port = (int(os.environ.get("THETA_COMM_PORT", 0)) or int(os.environ.get("MASTER_PORT", "29400")) + 1) + 1
+            comm = theta_amd.Comm(ctx, rank=rank, world=world, port=port, transport="host")
     r, rN, order = synth()
     lb, ub = [0] * M, [K_MAX] * M
     problem = theta_amd.Problem(ctx, N_POP, M, TAU, r, rN, lb, ub, 1.0)   # builds the 173 MB counting table in HBM

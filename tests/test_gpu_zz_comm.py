@@ -144,6 +144,33 @@ def test_bench_with_two_ranks_on_one_gpu():
     assert 0.5 * single["value"] <= line["value"] <= 2.0 * single["value"], (line["value"], single["value"])
 
 
+def test_bench_falls_back_to_the_host_transport_when_rccl_refuses_the_communicator():
+    """
+    Two ranks on this box's ONE GPU with the RCCL transport (the driver's default): rank 0's ncclUniqueId travels over the
+    library's bootstrap, both ranks enter ncclCommInitRank, RCCL's own bootstrap gathers the peers -- and refuses ("Duplicate GPU
+    detected", ncclInvalidUsage; the furthest an RCCL communicator of world > 1 gets on a one-GPU box).  bench.py then carries its
+    two collectives over the host transport and says so on the line (`comm.transport`) instead of failing the run.
+    """
+    import json
+    import subprocess
+    port = _free_port()
+    base = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE="2", THETA_BENCH_NDEV="1", THETA_COMM_TIMEOUT_S="120")
+    base.pop("THETA_BENCH_TRANSPORT", None)
+    args = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", str(1 << 28)]
+    procs = [subprocess.Popen(args, env=dict(base, RANK=str(rk), LOCAL_RANK=str(rk)), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+             for rk in range(2)]
+    try:
+        outs = [p.communicate(timeout=500) for p in procs]
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    assert all(p.returncode == 0 for p in procs), [o[1][-800:] for o in outs]
+    assert all("falling back to the host transport" in o[1] for o in outs), [o[1][-400:] for o in outs]
+    line = json.loads(outs[0][0].strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["comm"]["world"] == 2 and line["comm"]["transport"] == "host" and line["comm"]["collectives"] >= 4
+
+
 def test_do_optimization_with_max_processes_shards_over_worker_processes(ctx, monkeypatch):
     """The reference's parallel entry (RunTHetA.py:124-171): do_optimization(..., max_processes) starts its own worker
     process per further GPU.  On this one-GPU box THETA_NGPU=2 / 3 makes the ranks share the device (host transport); every

@@ -61,6 +61,17 @@ template <class F> struct SvCapL { static constexpr int v = sizeof(F) == 4 ? 160
 #define SV_TRIES 2        // evaluations a record may take in place when many lanes need another
 #endif
 
+// profiling builds (tools/ab_build.sh): SV_PROF = cycles per phase in the seven diagnostic slots; SV_PROF + SV_PROF2 = COUNTS of
+// wave-level passes in the same slots -- 0 last-level rounds, 1 nodes taken by them, 2 trips of the children phase, 3 wave-steps
+// of the queue, 4 drains, 5 rounds of the upper levels, 6 children -- : lane utilisation = items / (64 passes)
+#ifdef SV_PROF2
+#define SV_CYC(x)
+#define SV_CNT(x) x
+#else
+#define SV_CYC(x) x
+#define SV_CNT(x)
+#endif
+
 #ifndef SV_KIDS
 #define SV_KIDS 768       // children (candidates) of one round of <= 64 last-level nodes
 #endif
@@ -411,18 +422,30 @@ __device__ __forceinline__ void sv_child_rows(const SvCtx<ML, F, NS> &c, unsigne
 // whose record is finished takes the next queue entry at once (ballot + prefix count of the idle lanes), so the wave iterates
 // as long as there is work for most of its lanes -- round 2 took the queue 64 at a time in lock step, and with a third of the
 // records needing a second or third step every batch ran three iterations at a fraction of its lanes.
-template <int ML, class F, int NS>
+//
+// FULL WAVE-STEPS ONLY (round 4).  A wave-step costs the same with 5 live lanes as with 64, and a queue of ~110 entries of which
+// one in ten needs a second or third evaluation ended every drain with steps at 50, 5, 1 live lanes: 60 % of the lane slots of
+// the queue phase did the work.  A drain in the middle of a prefix (FINAL = false: the queue is about to overflow) now stops
+// as soon as the queue is handed out and fewer than SV_QTHR lanes are still live: those lanes put their record back -- the
+// entry as it was, with the iterate they have reached -- and the next drain starts on a full wave again.  The drain at the
+// end of a prefix (FINAL: the group tile changes) empties the queue as before.  SV_QTHR <= 64 leaves room for the 64 pushes
+// of the trip that called.
+#ifndef SV_QTHR
+#define SV_QTHR 56
+#endif
+template <int ML, class F, int NS, bool FINAL>
 __device__ __forceinline__ void sv_drain(SvCtx<ML, F, NS> &c) {
 #ifdef SV_PROF
     const unsigned long long pt0 = __builtin_amdgcn_s_memtime();
 #endif
     int next = 0;                                   // (wave-uniform) queue entries handed out so far
+    int left = 0;                                   // (wave-uniform) entries put back
     bool live = false;
     unsigned rw[ML / 2];
 #pragma unroll
     for (int j = 0; j < ML / 2; j++) rw[j] = 0u;
     F u1 = F(0), u2 = F(0), s1 = F(1), s2 = F(1);
-    unsigned off = 0u;
+    unsigned qy = 0u, code = 0u;                    // the entry's words: last row's slot | offset in the task << 8, path slots
     int iters = 0;
     while (true) {
         const unsigned long long idle = ballot64(!live);
@@ -433,7 +456,8 @@ __device__ __forceinline__ void sv_drain(SvCtx<ML, F, NS> &c) {
                 sv_child_rows<ML, F, NS>(c, qr.x, qr.y & 0xffu, rw);
                 u1 = c.W->qU1[idx];
                 u2 = c.W->qU2[idx];
-                off = qr.y >> 8;
+                code = qr.x;
+                qy = qr.y;
                 sv_sums<ML, F, NS>(c, rw, s1, s2);
                 if (!(u1 == u1)) {                    // (no usable first point: from the simplex centre)
                     u1 = F(1.0 / 3.0) * sv_rcp(s1);
@@ -447,7 +471,24 @@ __device__ __forceinline__ void sv_drain(SvCtx<ML, F, NS> &c) {
         }
         const unsigned long long lm = ballot64(live);
         if (!lm) break;
+        if constexpr (!FINAL) {
+            if (next >= c.qcount && __builtin_popcountll(lm) < SV_QTHR) {
+                wave_lds_sync();                         // (every entry has been read)
+                if (live) {
+                    const int pos = mbcnt(lm);
+                    c.W->qRec[pos] = make_uint2(code, qy);
+                    c.W->qU1[pos] = u1;
+                    c.W->qU2[pos] = u2;
+                }
+                left = __builtin_popcountll(lm);
+                wave_lds_sync();
+                break;
+            }
+        }
         c.n_dit += (unsigned)__builtin_popcountll(lm);
+#ifdef SV_PROF
+        SV_CNT(c.pt[3] += 1);
+#endif
         bool fin = false, surv = false;
         if (live) {
             F val2 = F(0), l2 = F(0), la = F(0);
@@ -468,7 +509,7 @@ __device__ __forceinline__ void sv_drain(SvCtx<ML, F, NS> &c) {
                 }
             }
         }
-        if (surv) sv_survivor<ML, F, NS>(c, rw, off);
+        if (surv) sv_survivor<ML, F, NS>(c, rw, qy >> 8);
         if (fin) {
             // the lane keeps the last optimum it saw as a start for later records
             if (sv_abs(s1 * u1) + sv_abs(s2 * u2) < F(1e6)) {
@@ -478,9 +519,10 @@ __device__ __forceinline__ void sv_drain(SvCtx<ML, F, NS> &c) {
             live = false;
         }
     }
-    c.qcount = 0;
+    c.qcount = left;
 #ifdef SV_PROF
-    c.pt[3] += __builtin_amdgcn_s_memtime() - pt0;
+    SV_CNT(c.pt[4] += 1);
+    SV_CYC(c.pt[3] += __builtin_amdgcn_s_memtime() - pt0);
 #endif
 }
 
@@ -677,7 +719,13 @@ __device__ __forceinline__ void sv_children(SvCtx<ML, F, NS> &c, int total) {
     const unsigned long long room = (unsigned long long)(total - lo);
     const int nrec = (int)(room < (unsigned long long)c.remaining ? room : (unsigned long long)c.remaining);
     if (nrec <= 0) return;
+#ifdef SV_PROF
+    SV_CNT(c.pt[6] += (unsigned)nrec);
+#endif
     for (int k0 = 0; k0 < nrec; k0 += WAVE * SV_CPL) {
+#ifdef SV_PROF
+        SV_CNT(c.pt[2] += 1);
+#endif
         SvChild<F> ch[SV_CPL];
 #pragma unroll
         for (int e = 0; e < SV_CPL; e++) sv_child_eval<ML, F, NS>(c, lo, k0 + e * WAVE + c.lane, nrec, ch[e]);
@@ -703,7 +751,7 @@ __device__ __forceinline__ void sv_children(SvCtx<ML, F, NS> &c, int total) {
                 }
             }
             if (pm) {
-                if (c.qcount + __builtin_popcountll(pm) > SV_QCAP) sv_drain<ML, F, NS>(c);
+                if (c.qcount + __builtin_popcountll(pm) > SV_QCAP) sv_drain<ML, F, NS, false>(c);
                 if (o.push) {
                     const int pos = c.qcount + mbcnt(pm);
                     c.W->qRec[pos] = make_uint2(o.code, o.slot | (o.off << 8));
@@ -823,21 +871,28 @@ __device__ __forceinline__ void sv_expand(SvCtx<ML, F, NS> &c, int n_in) {
             }
 #ifdef SV_PROF
             const unsigned long long pa = __builtin_amdgcn_s_memtime();
-            c.pt[6] += pa - pi;
+            SV_CYC(c.pt[6] += pa - pi);
+            SV_CNT(c.pt[0] += 1);
 #endif
             sv_parent<ML, F, NS>(c, take && cnt > 0, code);
             c.n_par += (unsigned)__builtin_popcountll(ballot64(take && cnt > 0));
+#ifdef SV_PROF
+            SV_CNT(c.pt[1] += (unsigned)__builtin_popcountll(ballot64(take && cnt > 0)));
+#endif
             wave_lds_sync();
 #ifdef SV_PROF
             const unsigned long long pb = __builtin_amdgcn_s_memtime(), dr0 = c.pt[3];
-            c.pt[1] += pb - pa;
+            SV_CYC(c.pt[1] += pb - pa);
 #endif
             sv_children<ML, F, NS>(c, total);
             wave_lds_sync();
 #ifdef SV_PROF
-            c.pt[2] += (__builtin_amdgcn_s_memtime() - pb) - (c.pt[3] - dr0);
+            SV_CYC(c.pt[2] += (__builtin_amdgcn_s_memtime() - pb) - (c.pt[3] - dr0));
 #endif
         } else {
+#ifdef SV_PROF
+            SV_CNT(c.pt[5] += 1);
+#endif
             const unsigned ps = n3_pack(node);
             if (take) {
                 uint2 *dst = ((LVL == 0) ? c.W->list0 : (LVL == ML - 2) ? c.W->listL : c.W->list[LVL >= 1 && LVL < ML - 2 ? LVL - 1 : 0]) + off;
@@ -1138,10 +1193,10 @@ __global__ __launch_bounds__(64 * SV_WAVES, sizeof(F) == 4 ? SV_OCC : SV_OCC64) 
         c.par = n3_unpack(n3_lane_state<NS>(st, D - 1));
         c.n_prefix++;
 #ifdef SV_PROF
-        c.pt[0] += __builtin_amdgcn_s_memtime() - pg0;
+        SV_CYC(c.pt[0] += __builtin_amdgcn_s_memtime() - pg0);
 #endif
         sv_expand<ML, 0, F, NS>(c, 1);
-        if (c.qcount) sv_drain<ML, F, NS>(c);                 // the tile changes with the prefix: the queue is emptied first
+        if (c.qcount) sv_drain<ML, F, NS, true>(c);               // the tile changes with the prefix: the queue is emptied first
         n_terms += (unsigned long long)(c.n_dit - it0) * (unsigned)(G + ML);          // full evaluations: every term of the candidate
         n_pterms += (unsigned long long)(c.n_par - par0) * (unsigned)(G + ML - 1);    // shared sums of a last-level node: all terms but its children's
         c.skip = 0;                                    // only the first prefix of a task starts mid-way
@@ -1149,7 +1204,7 @@ __global__ __launch_bounds__(64 * SV_WAVES, sizeof(F) == 4 ? SV_OCC : SV_OCC64) 
 #ifdef SV_PROF
         const unsigned long long pn0 = __builtin_amdgcn_s_memtime();
         const bool more = n3_next_prefix<NS>(P, st, D, lane);
-        c.pt[4] += __builtin_amdgcn_s_memtime() - pn0;
+        SV_CYC(c.pt[4] += __builtin_amdgcn_s_memtime() - pn0);
         if (!more) break;
 #else
         if (!n3_next_prefix<NS>(P, st, D, lane)) break;
@@ -1171,7 +1226,7 @@ __global__ __launch_bounds__(64 * SV_WAVES, sizeof(F) == 4 ? SV_OCC : SV_OCC64) 
         atomicAdd(&sc->sieve_pterms, n_pterms);
         atomicAdd(&sc->sieve_children, (unsigned long long)c.n_child);
 #ifdef SV_PROF
-        c.pt[5] = __builtin_amdgcn_s_memtime() - pw0;
+        SV_CYC(c.pt[5] = __builtin_amdgcn_s_memtime() - pw0);
         for (int i = 0; i < 7; i++) atomicAdd(&sc->prof[i], c.pt[i]);
 #else
         atomicAdd(&sc->prof[0], (unsigned long long)c.n_par);
