@@ -72,6 +72,9 @@ template <class F> struct SvCapL { static constexpr int v = sizeof(F) == 4 ? 160
 #define SV_CNT(x)
 #endif
 
+#ifndef SV_PULL
+#define SV_PULL 0.02      // the round's shared point = the chain point pulled this far towards the simplex centre
+#endif
 #ifndef SV_KIDS
 #define SV_KIDS 768       // children (candidates) of one round of <= 64 last-level nodes
 #endif
@@ -242,7 +245,7 @@ struct SvCtx {
     F sqrt_ror;                      // sqrt(Rtot / Rmin) (per prefix)
     int no_dismiss;
     // lane-private chain: mixture fractions of the optimum of the lane's previous record
-    F wn1, wn2;
+    F wn0, wn1, wn2;
     int qcount;
     // statistics (wave-uniform scalars)
     // (32 bits each: a task holds < 2^16 candidates.  Degenerate candidates and contenders are counted where they are listed --
@@ -513,8 +516,9 @@ __device__ __forceinline__ void sv_drain(SvCtx<ML, F, NS> &c) {
         if (fin) {
             // the lane keeps the last optimum it saw as a start for later records
             if (sv_abs(s1 * u1) + sv_abs(s2 * u2) < F(1e6)) {
-                c.wn1 = s1 * u1;
-                c.wn2 = s2 * u2;
+                c.wn1 = u1;
+                c.wn2 = u2;
+                c.wn0 = F(1) - s1 * u1 - s2 * u2;
             }
             live = false;
         }
@@ -557,11 +561,14 @@ __device__ __forceinline__ void sv_parent(SvCtx<ML, F, NS> &c, bool take, unsign
     // the node's own (partial) column sums -- any scale is as good as any other
     // (lane 0's chain for the whole round -- it has had a child in every trip: one point per round does as well as one per lane
     // [measured: 1 % fewer queue evaluations], holding it for 4 / 16 rounds or a whole prefix does not: +4 / +16 / +42 % time)
-    const F b1 = sv_bcast0(c.wn1), b2 = sv_bcast0(c.wn2);
-    const F n1 = sv_fma(F(0.98), b1, F(0.02 / 3.0)), n2 = sv_fma(F(0.98), b2, F(0.02 / 3.0));
+    const F S1c = sv_bcast0(S1), S2c = sv_bcast0(S2);
+    const bool c_ok = S1c > F(0) && S2c > F(0);
+    const F c1 = F(1.0 / 3.0) * sv_rcp(c_ok ? S1c : F(1)), c2 = F(1.0 / 3.0) * sv_rcp(c_ok ? S2c : F(1));
+    const F b0 = sv_bcast0(c.wn0), b1 = sv_bcast0(c.wn1), b2 = sv_bcast0(c.wn2);
+    const bool have = b0 == b0;
+    const F w0 = have ? sv_fma(F(1.0 - SV_PULL), b0, F(SV_PULL / 3.0)) : F(1.0 / 3.0);
+    const F u1 = have ? sv_fma(F(1.0 - SV_PULL), b1, F(SV_PULL) * c1) : c1, u2 = have ? sv_fma(F(1.0 - SV_PULL), b2, F(SV_PULL) * c2) : c2;
     const bool sums_ok = S1 > F(0) && S2 > F(0);
-    const F w0 = F(1) - n1 - n2;
-    const F u1 = n1 * sv_rcp(sums_ok ? S1 : F(1)), u2 = n2 * sv_rcp(sums_ok ? S2 : F(1));
     v2 L = {F(0), F(0)}, T0 = L, T1 = L, T2 = L, W00 = L, W01 = L, W02 = L, W11 = L, W12 = L, W22 = L, LA = L;
     const v2 vw0 = {w0, w0}, vu1 = {u1, u1}, vu2 = {u2, u2};
     // (rho = sqrt R: gamma = rho / q, T = sum rho gamma (1, x, y), W = sum gamma^2 (1, x, y)(1, x, y)^T; a term outside the
@@ -631,7 +638,8 @@ struct SvChild {
     bool act, regular, ev, push, surv;
     unsigned slot, code, off;
     F qu1, qu2;                // where the child continues in the queue
-    F n1, n2;                  // its stepped mixture (the lane's chain point), valid if `chain`
+    F n1, n2;                  // its stepped mixture, and the stepped point itself (u1, u2; w0 = 1 - n1 - n2): the lane's chain point, valid if `chain`
+    F c1, c2;
     bool chain;
 };
 
@@ -693,6 +701,8 @@ __device__ __forceinline__ void sv_child_eval(const SvCtx<ML, F, NS> &c, int lo,
     const bool good = o.ev && cond_ok && num_ok;
     o.n1 = s1 * v1;
     o.n2 = s2 * v2;
+    o.c1 = v1;
+    o.c2 = v2;
     o.chain = good && sv_abs(o.n1) + sv_abs(o.n2) < F(1e6);
     // (same decisions as in sv_drain)
     const bool conv = l2 < c.conv_l2 && l2 * c.rtot_over_rmin < F(0.25);
@@ -739,8 +749,9 @@ __device__ __forceinline__ void sv_children(SvCtx<ML, F, NS> &c, int total) {
             }
             c.n_child += (unsigned)__builtin_popcountll(ballot64(o.ev));
             if (o.chain) {
-                c.wn1 = o.n1;                             // the lane's chain: a recent optimum of this neighbourhood
-                c.wn2 = o.n2;
+                c.wn0 = F(1) - o.n1 - o.n2;               // the lane's chain: a recent optimum of this neighbourhood, as a POINT w
+                c.wn1 = o.c1;
+                c.wn2 = o.c2;
             }
             const unsigned long long pm = ballot64(o.push), sm = ballot64(o.surv);
             if (sm) {                                     // (rare: a contender straight from the shared evaluation)
@@ -990,7 +1001,8 @@ __global__ __launch_bounds__(64 * SV_WAVES, sizeof(F) == 4 ? SV_OCC : SV_OCC64) 
     c.conv_l2 = (F)Pg.conv_l2;
     c.fine_l2 = sizeof(F) == 8 ? (F)fmin(Pg.conv_l2, 1e-8) : c.conv_l2;
     c.no_dismiss = Pg.no_dismiss;
-    c.wn1 = c.wn2 = F(1.0 / 3.0);
+    c.wn0 = F(__builtin_nanf(""));                   // (no chain point yet: the simplex centre)
+    c.wn1 = c.wn2 = F(0);
     c.qcount = 0;
     c.n_par = c.n_prefix = 0;
     c.n_child = c.n_dit = 0;
