@@ -255,7 +255,7 @@ struct SvCtx {
     unsigned long long pt[7];        // cycles: 0 group tile, 1 parent phase, 2 children phase (less its drains), 3 drain, 4 prefix successor, 5 whole wave,
                                      // 6 the last level's own expansion (list read, child masks, scan, kid list) -- the upper levels are the rest
 #endif
-    unsigned n_par, n_prefix;        // last-level nodes evaluated (phase P), prefixes walked
+    unsigned n_par, n_prefix;        // likelihood terms of the shared sums (phase P), prefixes walked
     unsigned n_child, n_dit;         // shared first evaluations (children) / full evaluations (queue)
 };
 
@@ -608,15 +608,43 @@ __device__ __forceinline__ void sv_parent(SvCtx<ML, F, NS> &c, bool take, unsign
             W22 = __builtin_elementwise_fma(twy, y, W22);
         }
     };
-    if (take) {
-        const Sv4<F> *fXY = c.W->fXY;
-        const typename SvWt<F>::T *fRR = c.W->fRR;
-#pragma unroll 2
-        for (int p = 0; p < c.GP; p++) {
-            const Sv4<F> xy = fXY[p];
-            const typename SvWt<F>::T rr = fRR[p];
+    // ---- the group tile's part of the sums, ONCE PER ROUND (round 4): every node of the round evaluates at the same point, so
+    // the ~13 group terms of the prefix -- two thirds of a node's terms -- are the same numbers in all 64 lanes.  Lane p takes
+    // pair p of the tile; the partial sums meet in LDS (the record planes, free until the nodes' records are written below),
+    // twelve lanes add them up, and every lane starts its own path rows from the totals.
+    F tot[12];
+    {
+        F *scr = (F *)&c.W->par;
+        constexpr int TOT = 512;
+        if (c.lane < c.GP) {
+            const Sv4<F> xy = c.W->fXY[c.lane];
+            const typename SvWt<F>::T rr = c.W->fRR[c.lane];
             body(v2{xy.x, xy.y}, v2{xy.z, xy.w}, v2{rr.x, rr.y}, sv_rho<F>(rr));
+            const F part[12] = {L.x + L.y, T0.x + T0.y, T1.x + T1.y, T2.x + T2.y, W00.x + W00.y, W01.x + W01.y, W02.x + W02.y, W11.x + W11.y,
+                                W12.x + W12.y, W22.x + W22.y, LA.x + LA.y, F(0)};
+            Sv2<F> *dst = (Sv2<F> *)(scr + 12 * c.lane);
+#pragma unroll
+            for (int k = 0; k < 6; k++) dst[k] = Sv2<F>{part[2 * k], part[2 * k + 1]};
         }
+        wave_lds_sync();
+        if (c.lane < 12) {
+            F t = F(0);
+            for (int p = 0; p < c.GP; p++) t += scr[12 * p + c.lane];
+            scr[TOT + c.lane] = t;
+        }
+        wave_lds_sync();
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+            const Sv2<F> t2 = ((const Sv2<F> *)(scr + TOT))[k];
+            tot[2 * k] = t2.x;
+            tot[2 * k + 1] = t2.y;
+        }
+        wave_lds_sync();                                   // (the planes are rewritten next)
+    }
+    if (take) {
+        L = v2{tot[0], F(0)}; T0 = v2{tot[1], F(0)}; T1 = v2{tot[2], F(0)}; T2 = v2{tot[3], F(0)};
+        W00 = v2{tot[4], F(0)}; W01 = v2{tot[5], F(0)}; W02 = v2{tot[6], F(0)}; W11 = v2{tot[7], F(0)};
+        W12 = v2{tot[8], F(0)}; W22 = v2{tot[9], F(0)}; LA = v2{tot[10], F(0)};
         // the ML - 1 path rows: pairs, an odd one with a copy of itself of weight 0
 #pragma unroll
         for (int j = 0; j + 1 < ML - 1; j += 2)
@@ -748,11 +776,30 @@ __device__ __forceinline__ void sv_children(SvCtx<ML, F, NS> &c, int total) {
                 atomicAdd(&c.A.ctr->degenerate, 1ull);
             }
             c.n_child += (unsigned)__builtin_popcountll(ballot64(o.ev));
+#ifdef SV_MEANCHAIN
+            {
+                F a0 = o.chain ? F(1) - o.n1 - o.n2 : F(0), a1 = o.chain ? o.c1 : F(0), a2 = o.chain ? o.c2 : F(0), an = o.chain ? F(1) : F(0);
+#pragma unroll
+                for (int sh = 32; sh > 0; sh >>= 1) {
+                    a0 += __shfl_xor(a0, sh, WAVE);
+                    a1 += __shfl_xor(a1, sh, WAVE);
+                    a2 += __shfl_xor(a2, sh, WAVE);
+                    an += __shfl_xor(an, sh, WAVE);
+                }
+                if (an > F(0)) {
+                    const F inv = sv_rcp(an);
+                    c.wn0 = a0 * inv;
+                    c.wn1 = a1 * inv;
+                    c.wn2 = a2 * inv;
+                }
+            }
+#else
             if (o.chain) {
                 c.wn0 = F(1) - o.n1 - o.n2;               // the lane's chain: a recent optimum of this neighbourhood, as a POINT w
                 c.wn1 = o.c1;
                 c.wn2 = o.c2;
             }
+#endif
             const unsigned long long pm = ballot64(o.push), sm = ballot64(o.surv);
             if (sm) {                                     // (rare: a contender straight from the shared evaluation)
                 if (o.surv) {
@@ -886,7 +933,10 @@ __device__ __forceinline__ void sv_expand(SvCtx<ML, F, NS> &c, int n_in) {
             SV_CNT(c.pt[0] += 1);
 #endif
             sv_parent<ML, F, NS>(c, take && cnt > 0, code);
-            c.n_par += (unsigned)__builtin_popcountll(ballot64(take && cnt > 0));
+            {   // likelihood terms of the round's shared sums: ML - 1 path rows per node, the group tile once
+                const unsigned nn = (unsigned)__builtin_popcountll(ballot64(take && cnt > 0));
+                c.n_par += nn * (unsigned)(ML - 1) + (nn ? (unsigned)c.G : 0u);
+            }
 #ifdef SV_PROF
             SV_CNT(c.pt[1] += (unsigned)__builtin_popcountll(ballot64(take && cnt > 0)));
 #endif
@@ -1210,7 +1260,7 @@ __global__ __launch_bounds__(64 * SV_WAVES, sizeof(F) == 4 ? SV_OCC : SV_OCC64) 
         sv_expand<ML, 0, F, NS>(c, 1);
         if (c.qcount) sv_drain<ML, F, NS, true>(c);               // the tile changes with the prefix: the queue is emptied first
         n_terms += (unsigned long long)(c.n_dit - it0) * (unsigned)(G + ML);          // full evaluations: every term of the candidate
-        n_pterms += (unsigned long long)(c.n_par - par0) * (unsigned)(G + ML - 1);    // shared sums of a last-level node: all terms but its children's
+        n_pterms += (unsigned long long)(c.n_par - par0);                              // shared sums of the rounds: path rows per node + the group tile per round
         c.skip = 0;                                    // only the first prefix of a task starts mid-way
         if (c.remaining == 0) break;
 #ifdef SV_PROF
