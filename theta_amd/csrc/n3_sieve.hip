@@ -216,6 +216,19 @@ __device__ __forceinline__ int sv_incl_scan(int v) {
     return v;
 }
 
+// sum over the wave (every lane gets it), DPP row shifts / broadcasts
+__device__ __forceinline__ float sv_wave_sum_f32(float v) {
+#define SV_DPP_ADD(ctrl, rowmask) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, rowmask, 0xf, false))
+    SV_DPP_ADD(0x111, 0xf);   // row_shr:1
+    SV_DPP_ADD(0x112, 0xf);   // row_shr:2
+    SV_DPP_ADD(0x114, 0xf);   // row_shr:4
+    SV_DPP_ADD(0x118, 0xf);   // row_shr:8
+    SV_DPP_ADD(0x142, 0xa);   // row_bcast:15 into rows 1 and 3
+    SV_DPP_ADD(0x143, 0xc);   // row_bcast:31 into rows 2 and 3
+#undef SV_DPP_ADD
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
 // Everything a wave carries through the expansion (wave-uniform unless noted).
 template <int ML, class F, int NS>
 struct SvCtx {
@@ -244,7 +257,7 @@ struct SvCtx {
     F Tcmp;                          // the threshold of sv_beyond's comparison, in F (per task)
     F sqrt_ror;                      // sqrt(Rtot / Rmin) (per prefix)
     int no_dismiss;
-    // lane-private chain: mixture fractions of the optimum of the lane's previous record
+    // the chain point (wave-uniform): where the next round's shared sums are evaluated, see sv_parent
     F wn0, wn1, wn2;
     int qcount;
     // statistics (wave-uniform scalars)
@@ -514,12 +527,6 @@ __device__ __forceinline__ void sv_drain(SvCtx<ML, F, NS> &c) {
         }
         if (surv) sv_survivor<ML, F, NS>(c, rw, qy >> 8);
         if (fin) {
-            // the lane keeps the last optimum it saw as a start for later records
-            if (sv_abs(s1 * u1) + sv_abs(s2 * u2) < F(1e6)) {
-                c.wn1 = u1;
-                c.wn2 = u2;
-                c.wn0 = F(1) - s1 * u1 - s2 * u2;
-            }
             live = false;
         }
     }
@@ -557,10 +564,13 @@ __device__ __forceinline__ void sv_parent(SvCtx<ML, F, NS> &c, bool take, unsign
         S1 = sv_fma(px[j], c.leafN[j], S1);
         S2 = sv_fma(py[j], c.leafN[j], S2);
     }
-    // the lane's chain point as a direction: mixture (n1, n2) pulled slightly towards the simplex centre, u_j = n_j / s_j with
-    // the node's own (partial) column sums -- any scale is as good as any other
-    // (lane 0's chain for the whole round -- it has had a child in every trip: one point per round does as well as one per lane
-    // [measured: 1 % fewer queue evaluations], holding it for 4 / 16 rounds or a whole prefix does not: +4 / +16 / +42 % time)
+    // The round's shared POINT w = (w0, u1, u2): the chain point (sv_children: the mean of the stepped points of the previous
+    // round's last full trip), pulled slightly towards the simplex centre of the round's first node.  The same w for every node
+    // of the round -- any scale is as good as any other -- because w, not the mixture, is what neighbouring candidates have in
+    // common: q_i = w.(1, x_i, y_i) fits the same ratios r_i / rN_i whatever the last rows are, while the mixture s_j u_j moves
+    // with every candidate's column sums.  (Round 3 carried a mixture and re-scaled it by each node's own sums: 3 % off per copy
+    // of the last row, 1.55 instead of 1.31 evaluations per candidate.)  Holding the point for 4 / 16 rounds or a whole prefix
+    // costs +4 / +16 / +42 % time.
     const F S1c = sv_bcast0(S1), S2c = sv_bcast0(S2);
     const bool c_ok = S1c > F(0) && S2c > F(0);
     const F c1 = F(1.0 / 3.0) * sv_rcp(c_ok ? S1c : F(1)), c2 = F(1.0 / 3.0) * sv_rcp(c_ok ? S2c : F(1));
@@ -776,30 +786,22 @@ __device__ __forceinline__ void sv_children(SvCtx<ML, F, NS> &c, int total) {
                 atomicAdd(&c.A.ctr->degenerate, 1ull);
             }
             c.n_child += (unsigned)__builtin_popcountll(ballot64(o.ev));
-#ifdef SV_MEANCHAIN
-            {
-                F a0 = o.chain ? F(1) - o.n1 - o.n2 : F(0), a1 = o.chain ? o.c1 : F(0), a2 = o.chain ? o.c2 : F(0), an = o.chain ? F(1) : F(0);
-#pragma unroll
-                for (int sh = 32; sh > 0; sh >>= 1) {
-                    a0 += __shfl_xor(a0, sh, WAVE);
-                    a1 += __shfl_xor(a1, sh, WAVE);
-                    a2 += __shfl_xor(a2, sh, WAVE);
-                    an += __shfl_xor(an, sh, WAVE);
-                }
-                if (an > F(0)) {
-                    const F inv = sv_rcp(an);
-                    c.wn0 = a0 * inv;
-                    c.wn1 = a1 * inv;
-                    c.wn2 = a2 * inv;
+            // The chain point of the NEXT round: the mean of the stepped points of the children of this round's last FULL trip
+            // (single precision does: it is a starting point).  w is nearly the same for all candidates of a neighbourhood; the
+            // mean takes the siblings' own shifts out, and 64 samples do it better than fewer or older ones -- one lane's last
+            // child: 1.416 evaluations per candidate, a partial last trip 1.364, the first trip 1.447, the whole round 1.325,
+            // the last full trip 1.310 (profiles/r4/NOTES.md).
+            if (k0 + WAVE * SV_CPL <= nrec && k0 + 2 * WAVE * SV_CPL > nrec) {
+                const float a0 = sv_wave_sum_f32(o.chain ? (float)(F(1) - o.n1 - o.n2) : 0.0f);
+                const float a1 = sv_wave_sum_f32(o.chain ? (float)o.c1 : 0.0f), a2 = sv_wave_sum_f32(o.chain ? (float)o.c2 : 0.0f);
+                const int an = __builtin_popcountll(ballot64(o.chain));
+                if (an > 0) {
+                    const float inv = __builtin_amdgcn_rcpf((float)an);
+                    c.wn0 = (F)(a0 * inv);
+                    c.wn1 = (F)(a1 * inv);
+                    c.wn2 = (F)(a2 * inv);
                 }
             }
-#else
-            if (o.chain) {
-                c.wn0 = F(1) - o.n1 - o.n2;               // the lane's chain: a recent optimum of this neighbourhood, as a POINT w
-                c.wn1 = o.c1;
-                c.wn2 = o.c2;
-            }
-#endif
             const unsigned long long pm = ballot64(o.push), sm = ballot64(o.surv);
             if (sm) {                                     // (rare: a contender straight from the shared evaluation)
                 if (o.surv) {
