@@ -550,7 +550,14 @@ def main():
                 out["riders"] = {"config5_masked_scorer": config5_rider(ctx), "config5_search": config5_search_rider(ctx)}
             except Exception as ex:
                 out["extras_error"] = str(ex)
-        print(json.dumps(out))
+        # RCCL writes a version banner to the C stdout of the process that creates a communicator (buffered when piped): flush it
+        # now, so that the JSON line is the LAST line this process prints
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        print(json.dumps(out), flush=True)
     if comm is not None:
         comm.barrier()
         comm.close()

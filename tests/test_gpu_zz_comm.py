@@ -167,7 +167,7 @@ def test_bench_falls_back_to_the_host_transport_when_rccl_refuses_the_communicat
                 p.kill()
     assert all(p.returncode == 0 for p in procs), [o[1][-800:] for o in outs]
     assert all("falling back to the host transport" in o[1] for o in outs), [o[1][-400:] for o in outs]
-    line = json.loads(outs[0][0].strip().splitlines()[-1])
+    line = json.loads(outs[0][0].strip().splitlines()[-1])       # (RCCL's version banner, also on stdout, comes before: bench.py flushes it first)
     assert line["n_gpus"] == 2 and line["comm"]["world"] == 2 and line["comm"]["transport"] == "host" and line["comm"]["collectives"] >= 4
 
 

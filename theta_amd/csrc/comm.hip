@@ -340,6 +340,7 @@ extern "C" int theta_comm_create(theta_ctx *ctx, int rank, int world, const char
         }
         if (rc == THETA_OK) {
             ncclResult_t r = g_rccl.CommInitRank(&c->nccl, world, id, rank);
+            fflush(stdout);                      // (RCCL's version banner goes to the C stdout: out now, not at exit behind the caller's own last line)
             if (r != ncclSuccess) {
                 theta_set_error("ncclCommInitRank(rank %d of %d) failed: %s", rank, world, g_rccl.GetErrorString(r));
                 rc = THETA_ERR_HIP;

@@ -704,9 +704,10 @@ __device__ __forceinline__ void sv_child_eval(const SvCtx<ML, F, NS> &c, int lo,
     const F w0 = P[12], u1 = P[13], u2 = P[14];
     const F q = sv_fma(x, u1, sv_fma(y, u2, w0));
     o.ev = o.act && o.regular && (o.code >> 31) && q > F(0);
-    const F qs = o.ev ? q : F(1);                     // (lanes without a usable point compute on 1: no NaN factories)
+    // (a lane without a usable point, or with ill-conditioned sums, computes on whatever it has: infinities and NaNs cost nothing
+    // and every decision below is behind `good` = ev && cond_ok && num_ok -- no selects in the arithmetic)
     F w, lq;
-    sv_rcp_lg2(qs, w, lq);
+    sv_rcp_lg2(q, w, lq);
     const F t = Rl * w, tw = t * w, twx = tw * x, twy = tw * y;
     const F L = sv_fma(Rl, lq, P[0]);
     const F T0 = P[1] + t, T1 = sv_fma(t, x, P[2]), T2 = sv_fma(t, y, P[3]);
@@ -721,12 +722,11 @@ __device__ __forceinline__ void sv_child_eval(const SvCtx<ML, F, NS> &c, int lo,
     const F hh = H11 * H22, det = sv_fma(-H12, H12, hh);
     const F zw = sv_fma(s1, u1, sv_fma(s2, u2, w0));
     const bool cond_ok = det > (F)N3_COND_MIN * hh && zw > F(0);          // else: ill-conditioned for these sums
-    const F idet = sv_rcp(cond_ok ? det : F(1));
+    const F idet = sv_rcp(det);
     const F d1 = (H22 * G1 - H12 * G2) * idet, d2 = (H11 * G2 - H12 * G1) * idet;
     const F l2 = (G1 * d1 + G2 * d2) * c.inv_Rtot;
-    const F zs = cond_ok ? zw : F(1);
     F sc, lz;
-    sv_rcp_lg2(zs, sc, lz);
+    sv_rcp_lg2(zw, sc, lz);
     const F val2 = sv_fma(-c.rtot_f, lz, L);
     F la = F(0);
     if constexpr (sizeof(F) == 8) la = sv_fma(c.rtot_f, sv_abs(lz), sv_fma(Rl, sv_abs(lq), P[15]));
