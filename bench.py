@@ -218,7 +218,7 @@ def measure_traffic(args):
     HBM bytes per launch of the search kernel: two rocprofv3 --pmc passes (FETCH_SIZE, then WRITE_SIZE -- separate passes,
     the two do not fit the TCC's counter slots together) of THIS command on a warm-up step and two timed steps, no trace
     options.  Corrections of MI355X_MICROARCH.md (HBM section): both counters are in KB; on gfx950 FETCH_SIZE reports half
-    of the bytes read, so it is doubled; WRITE_SIZE is taken as is.  Returns (bytes per launch or None, note).
+    of the bytes read, so it is doubled; WRITE_SIZE is taken as is.  Returns (bytes per launch or None, note, issue figures or None).
     """
     exe = None
     for c in ("/opt/rocm/bin/rocprofv3", "rocprofv3"):
@@ -229,39 +229,56 @@ def measure_traffic(args):
     try:
         with tempfile.TemporaryDirectory(prefix="theta_pmc_", dir="/tmp") as td:
             env = dict(os.environ, TMPDIR="/tmp")
-            for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
-                out = os.path.join(td, ctr)
-                cmd = [exe, "--pmc", ctr, "--output-format", "csv", "-d", out, "-o", "pmc", "--", sys.executable,
+            # (third pass: what the kernel is bound by -- vector-ALU issue -- in the counters' own terms)
+            for grp in (("FETCH_SIZE",), ("WRITE_SIZE",), ("SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES")):
+                out = os.path.join(td, grp[0])
+                cmd = [exe, "--pmc"] + list(grp) + ["--output-format", "csv", "-d", out, "-o", "pmc", "--", sys.executable,
                        os.path.abspath(__file__), "--gpus", "1", "--steps", "3", "--warmup", "2", "--batch", str(args.batch),
                        "--leg", args.leg, "--no-cpu-baseline", "--no-legs", "--no-traffic", "--no-extras"]
-                subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240, check=True)
-                rows = []
+                try:
+                    subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240, check=True)
+                except Exception:
+                    if grp[0].startswith("SQ_"):
+                        continue                   # (the issue figures are an extra: the traffic stands without them)
+                    raise
+                rows = {c: [] for c in grp}
                 for dp, _d, fs in os.walk(out):
                     for f in fs:
                         if f.endswith("counter_collection.csv"):
                             import csv
                             with open(os.path.join(dp, f)) as fh:
                                 for row in csv.DictReader(fh):
-                                    if DOMINANT_KERNEL in row.get("Kernel_Name", "") and row.get("Counter_Name") == ctr:
-                                        rows.append((int(row["Dispatch_Id"]), float(row.get("Grid_Size") or 0), float(row["Counter_Value"])))
-                if not rows:
-                    return None, "rocprofv3 produced no %s rows for the search kernel" % ctr
-                # per launch, summed over the counter's instances; the BULK launches are those with (about) the largest grid -- a step
-                # is a short first slice + the bulk --, and the timed steps are the last ones: the job's first step runs against a
-                # poor minimum and writes millions of contender records (round 3 took the median of the launches with the LARGEST
-                # VALUES, i.e. of exactly those: its "1.3 GB per launch" was the first step's contender list, profiles/r4/NOTES.md)
-                per = {}
-                for did, grid, val in rows:
-                    g, v = per.get(did, (0.0, 0.0))
-                    per[did] = (max(g, grid), v + val)
-                gmax = max(g for g, _v in per.values())
-                bulk = [per[d][1] for d in sorted(per) if per[d][0] >= 0.5 * gmax][-3:]
-                bulk.sort()
-                got[ctr] = bulk[len(bulk) // 2]
+                                    if DOMINANT_KERNEL in row.get("Kernel_Name", "") and row.get("Counter_Name") in rows:
+                                        rows[row["Counter_Name"]].append((int(row["Dispatch_Id"]), float(row.get("Grid_Size") or 0), float(row["Counter_Value"])))
+                for ctr in grp:
+                    if not rows[ctr]:
+                        if ctr.startswith("SQ_"):
+                            continue
+                        return None, "rocprofv3 produced no %s rows for the search kernel" % ctr, None
+                    # per launch, summed over the counter's instances; the BULK launches are those with (about) the largest grid -- a step
+                    # is a short first slice + the bulk --, and the timed steps are the last ones: the job's first step runs against a
+                    # poor minimum and writes millions of contender records (round 3 took the median of the launches with the LARGEST
+                    # VALUES, i.e. of exactly those: its "1.3 GB per launch" was the first step's contender list, profiles/r4/NOTES.md)
+                    per = {}
+                    for did, grid, val in rows[ctr]:
+                        g, v = per.get(did, (0.0, 0.0))
+                        per[did] = (max(g, grid), v + val)
+                    gmax = max(g for g, _v in per.values())
+                    bulk = [per[d][1] for d in sorted(per) if per[d][0] >= 0.5 * gmax][-3:]
+                    bulk.sort()
+                    got[ctr] = bulk[len(bulk) // 2]
     except Exception as ex:
-        return None, "rocprofv3 --pmc pass failed: %s" % (str(ex)[:200],)
+        return None, "rocprofv3 --pmc pass failed: %s" % (str(ex)[:200],), None
     byt = (2.0 * got["FETCH_SIZE"] + got["WRITE_SIZE"]) * 1024.0
-    return byt, "(2 x FETCH_SIZE + WRITE_SIZE) KB, median over the bulk launches of the three TIMED steps of the dominant kernel in two rocprofv3 --pmc passes of this command (2 warm-up + 3 timed steps)"
+    issue = None
+    if all(k in got for k in ("SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES")) and got["SQ_WAVE_CYCLES"] > 0:
+        wps = 2 if "double" in LEGS[args.leg][2] else 3               # resident waves per SIMD of the instantiation (VGPR / LDS bound)
+        apw = got["SQ_ACTIVE_INST_VALU"] / got["SQ_WAVE_CYCLES"]
+        issue = {"valu_wave_instructions_per_launch": got["SQ_INSTS_VALU"], "valu_active_per_wave_cycle": apw, "waves_per_simd": wps,
+                 "valu_port_busy": min(1.0, apw * wps),
+                 "note": "median bulk launch of the timed steps; SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES is one wave's share of its SIMD's "
+                         "vector issue slots, x resident waves per SIMD = how busy the port the kernel is bound by is"}
+    return byt, "(2 x FETCH_SIZE + WRITE_SIZE) KB, median over the bulk launches of the three TIMED steps of the dominant kernel in rocprofv3 --pmc passes of this command (2 warm-up + 3 timed steps)", issue
 
 
 def extras(ctx, cpu_seconds):
@@ -520,16 +537,16 @@ def main():
                 legs[name] = lg.summary(time.time() - t1, name, dtype, kern)
                 set_opts(opts, False)
         s = legs[args.leg]
-        traffic, tnote = (None, "not measured (--no-traffic or N > 1)")
+        traffic, tnote, issue = (None, "not measured (--no-traffic or N > 1)", None)
         if world == 1 and not args.no_traffic:
-            traffic, tnote = measure_traffic(args)
+            traffic, tnote, issue = measure_traffic(args)
         out["roofline"] = {
             "bound": "valu", "bound_detail": "vector-ALU (VALU issue) bound, not HBM and not MFMA: candidates are generated on chip "
             "(~0 algorithmic HBM bytes) and the per-candidate C.mu is an (18 x 3).(3) product after group aggregation -- no GEMM. "
             "Kernel time = sieve + finish kernels of a step (HIP events around both). "
             "`peak` is the FP64 vector peak (78.6 TFLOP/s) weighted with the packed-FP32 vector peak (157.3) by the executed mix",
             "kernel": head_kernel, "achieved": s["achieved"], "peak": s["peak"], "unit": "TFLOP/s", "frac": s["frac"],
-            "traffic": traffic, "traffic_note": tnote, "algorithmic_bytes_per_launch": 0,
+            "traffic": traffic, "traffic_note": tnote, "algorithmic_bytes_per_launch": 0, "issue": issue,
             "kernel_ms_per_launch": s["kernel_ms_per_launch"], "legs": legs,
             "note": "`achieved` = FLOP executed by the likelihood arithmetic (counted in-kernel from the evaluations and terms "
                     "actually run; slices redone by the fused kernel are reported apart, redo_*) / HIP-event kernel time; "
