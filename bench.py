@@ -506,7 +506,8 @@ def main():
                                         "candidate generated, iterated in FP64 and valued; none dismissed by a bound",
                 "full_solve_f32": "COARSE tolerance lambda^2 / sum r < 1e-4 -- every candidate generated, iterated in packed FP32 and valued; "
                                   "none dismissed by a bound",
-                "search": "candidates SEARCHED by the shipped branch-and-bound (bound-pruned after one shared packed-FP32 evaluation)"}[args.leg]
+                "search": "candidates SEARCHED by the shipped branch-and-bound (a whole prefix finished by the bound of its relaxed problem, else "
+                          "bound-pruned after one shared packed-FP32 evaluation)"}[args.leg]
         out = {
             "metric": "candidate C-matrices evaluated/sec (whole node); " + what,
             "value": value, "unit": "candidates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

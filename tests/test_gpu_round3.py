@@ -76,7 +76,7 @@ def _search_mode(ctx, p, begin, end, r, rN, opts, window=0.5, hint=None):
         return res, fb, list(p.last_degenerate[0])
     finally:
         for k in opts:
-            p.set_option(k, 1e-4 if k == "n3_conv_l2" else 0)      # (1e-4: the library's default coarse tolerance)
+            p.set_option(k, 1e-4 if k == "n3_conv_l2" else 1 if k == "n3_prefix_bound" else 0)      # (the library's defaults: coarse tolerance 1e-4, prefix bound on)
 
 
 def test_fp64_sieve_and_full_solve_modes_return_the_lists_of_the_shipped_search(ctx):

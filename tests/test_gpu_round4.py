@@ -274,3 +274,63 @@ def test_two_hundred_intervals_on_the_sieve_path(ctx):
         ok, mu_b, nll_b, _ = ctx.solve_batch(3, 2, rs, rNs, a["C"], 1.0, want_vals=False)
         assert ok.all() and np.allclose(nll_b, a["nll"], rtol=1e-9, atol=0)
     p.close()
+
+
+def test_prefixes_finished_by_the_prefix_bound_change_no_list(ctx):
+    """
+    Search mode finishes a whole prefix (~13 000 leaves) when the lower bound of its relaxed problem -- every leaf interval fitted
+    perfectly, n3_sieve.hip: sv_prefix_beyond -- lies beyond the window of the running minimum.  With the option off every
+    candidate gets its own evaluation: same finalists (rank, C, NLL), same fallback-relevant suspects, same degenerate lists, every
+    candidate counted -- on the bench's space (start, middle, end; most prefixes of a far-off range go, none of a range around the
+    minimum it was given), a K = 4 space, ragged bounds, a tiny Rmin, tau = 3, 100 intervals, and both arithmetics.
+    """
+    import bench
+    import theta_amd
+    from test_gpu_round3 import _search_mode
+    from test_gpu_wide import _wide_instance
+    cases = []
+    r, rN, order = bench.synth()
+    cases.append(("bench m50 k6", 50, r, rN, [0] * 50, [6] * 50, [("mid", 1 << 24), (0, 1 << 22), ("end", 1 << 22)], 2))
+    r4, rN4, _ = bench.synth(seed=7, m=50, n=3, k=4)
+    cases.append(("m50 k4", 50, r4, rN4, [0] * 50, [4] * 50, [("mid", 1 << 23)], 2))
+    r6, rN6, _ = bench.synth(seed=9, m=14, n=3, k=3)
+    cases.append(("m14 k3 ragged", 14, r6, rN6, [0, 0, 0, 0, 1, 1, 1, 1, 1, 1, 1, 2, 2, 2], [2, 2, 3, 3, 3, 3, 3, 3, 3, 3, 3, 3, 3, 3], [("all", None)], 2))
+    r8, rN8, _ = bench.synth(seed=12, m=20, n=3, k=7)
+    cases.append(("m20 k7", 20, r8, rN8, [0] * 20, [7] * 20, [("mid", 1 << 23)], 2))
+    rs9, rNs9, _o, _t, lb9, ub9 = _wide_instance(100, 501, 2)
+    cases.append(("m100 wide", 100, rs9, rNs9, lb9, ub9, [("all", None)], 2))
+    ra, rNa, _ = bench.synth(seed=14, m=16, n=3, k=3)
+    ra = list(ra)
+    ra[0], ra[7] = 3, 11
+    cases.append(("m16 k3 tiny Rmin", 16, ra, rNa, [0] * 16, [3] * 16, [("mid", 1 << 24)], 2))
+    rb, rNb, _ = bench.synth(seed=15, m=12, n=3, k=4)
+    cases.append(("m12 k4 tau3", 12, rb, rNb, [0] * 12, [4] * 12, [("all", None)], 3))
+    pruned_total = 0
+    for name, m, rr, rn, lb, ub, ranges, tau in cases:
+        p = theta_amd.Problem(ctx, 3, m, tau, rr, rn, lb, ub, 1.0)
+        known = None
+        for where, span in ranges:
+            if where == "all":
+                b, e = 0, p.count
+            elif where == "mid":
+                b, e = p.count // 3, min(p.count, p.count // 3 + span)
+            elif where == "end":
+                b, e = p.count - span, p.count
+            else:
+                b, e = where, where + span
+            for arith in ({}, {"n3_force_f64": 1}):
+                on, fon, don = _search_mode(ctx, p, b, e, rr, rn, dict(arith), hint=known)
+                off, foff, doff = _search_mode(ctx, p, b, e, rr, rn, dict(arith, n3_prefix_bound=0), hint=known)
+                assert on["stats"]["evaluated"] == off["stats"]["evaluated"] == e - b, (name, where)
+                assert off["stats"]["phase_cycles"][1] == 0
+                pruned_total += on["stats"]["phase_cycles"][1]
+                assert on["stats"]["phase_cycles"][1] <= on["stats"]["dismissed"] <= e - b
+                assert on["rank"] == off["rank"], (name, where, arith, len(on["rank"]), len(off["rank"]))
+                assert np.array_equal(on["C"], off["C"])
+                assert np.allclose(on["nll"], off["nll"], rtol=1e-11, atol=0)
+                assert fon == foff, (name, where, arith, len(fon), len(foff))
+                assert don == doff
+            if len(on["nll"]):
+                known = float(on["nll"].min()) if known is None else min(known, float(on["nll"].min()))
+        p.close()
+    assert pruned_total > 1 << 22, pruned_total        # (the bound does finish prefixes: most of the bench's far-off ranges)

@@ -38,6 +38,7 @@ struct N3Dev {
     int force64;                 // 1: iterate every candidate in FP64 (THETA_N3_FORCE_F64; the packed-f32 pass is the default)
     double conv_l2;              // convergence threshold on the squared Newton decrement
     int no_dismiss;              // 1: never finish a candidate by its lower bound (THETA_N3_NO_DISMISS): every one is iterated to the coarse tolerance
+    int prefix_bound;            // 1: the sieve finishes a whole prefix by the lower bound of its relaxed problem (search mode; n3_sieve.hip: sv_prefix_beyond)
     unsigned long long total_lo, total_hi;
 };
 

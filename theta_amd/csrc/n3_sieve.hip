@@ -980,6 +980,103 @@ __device__ __forceinline__ void sv_expand(SvCtx<ML, F, NS> &c, int n_in) {
     }
 }
 
+// ---- a whole PREFIX finished by one bound (search mode; option "n3_prefix_bound") ----------------------------------------
+// For a candidate with the prefix's rows fixed, let every LEAF interval l fit perfectly: replace its term q_l = w.c_l by a free
+// t_l > 0.  NLL = K0 - sum' R_i ln q_i - sum_l R_l ln t_l + Rtot ln(z'.w + sum_l N_l t_l)  (sum' = the prefix's group terms, z' =
+// the prefix's column sums) is minimised over the t_l in closed form -- t_l = R_l B / (Rtot N_l), B = z'.w Rtot / R', R' = sum' R_i --
+// and what is left is the likelihood of the PREFIX ALONE plus a constant of the problem:
+//      min over the leaf rows  >=  min_w [K0 - sum' R_i ln q_i + R' ln(z''.w)] + R' ln(1 - Nrem) + R' ln(Rtot / R') - sum_l R_l ln(R_l / (Rtot N_l))
+// (z'' = z' / (1 - Nrem), Nrem = sum_l N_l).  The bracket is an 18-to-13-term problem of the kind the kernel solves all the time:
+// a few Newton steps from the chain point, lane g on group term g, sums over the wave, and its self-concordance lower bound
+// (exact FP64 logarithms here: once per prefix).  A prefix whose bound lies beyond the window of the running minimum holds no
+// finalist, no suspect (a rejected candidate's fallback value is above its minimum) and -- column sums positive -- no
+// degenerate candidate: its ~13 000 leaves are counted as dismissed and the wave moves on.  One evaluation decides for a prefix
+// that cannot be pruned (its value at the chain point is already within the window): ~0.5 % of such a prefix's work.
+__device__ __forceinline__ double sv_wave_sum_f64(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
+    return v;
+}
+template <class F>
+__device__ __noinline__ bool sv_prefix_beyond(const Sv4<F> *fXY, const typename SvWt<F>::T *fRR, int G, double s1n, double s2n, double Rmin_pre,
+                                              const double *r_leaf, const double *rN_leaf, int nleaf, double inv_N, double Rtot, double K0, double thr,
+                                              double w0c, double u1c, double u2c) {
+    const int lane = threadIdx.x & 63;
+    double Rrem = 0.0, Nrem = 0.0, Csum = 0.0;
+    for (int l = 0; l < nleaf; l++) {
+        const double Rl = r_leaf[l], Nl = rN_leaf[l] * inv_N;
+        Rrem += Rl;
+        Nrem += Nl;
+        if (Rl > 0.0) Csum += Rl * log(Rl / (Rtot * Nl));
+    }
+    const double Rp = Rtot - Rrem, om = 1.0 - Nrem;
+    if (!(Rp > 0.0) || !(om > 0.0) || G > WAVE) return false;
+    const double Cconst = Rp * log(om) + Rp * log(Rtot / Rp) - Csum;
+    const double s1 = s1n / om, s2 = s2n / om;
+    // lane g: group term g of the tile (pairs {x0, x1, y0, y1}, weights {R0, R1, ...})
+    const bool active = lane < G;
+    double x = 0.0, y = 0.0, R = 0.0;
+    if (active) {
+        const F *xy = (const F *)&fXY[lane >> 1];
+        const F *rr = (const F *)&fRR[lane >> 1];
+        x = (double)xy[lane & 1];
+        y = (double)xy[2 + (lane & 1)];
+        R = (double)rr[lane & 1];
+    }
+    const double a = x - s1, b = y - s2;
+    double u1 = (1.0 / 3.0) / s1, u2 = (1.0 / 3.0) / s2;
+    bool from_chain = false;
+    if (w0c == w0c) {
+        const double zw = w0c + s1 * u1c + s2 * u2c;
+        if (zw > 0.0 && zw < 1e300) {
+            u1 = u1c / zw;
+            u2 = u2c / zw;
+            from_chain = true;
+        }
+    }
+    for (int it = 0; it < 12; it++) {
+        const double q = 1.0 + a * u1 + b * u2;
+        if (ballot64(active && !(q > 0.0))) {
+            if (from_chain) {                       // (the chain point is outside this prefix's domain: from its simplex centre)
+                u1 = (1.0 / 3.0) / s1;
+                u2 = (1.0 / 3.0) / s2;
+                from_chain = false;
+            } else {
+                u1 *= 0.5;
+                u2 *= 0.5;
+            }
+            continue;
+        }
+        const double qq = active ? q : 1.0, w = 1.0 / qq, t = R * w, tw = t * w;
+        const double lq = log(qq);
+        const double val = sv_wave_sum_f64(R * lq);
+        // (the value at ANY point is above the prefix's minimum: within the window already -> no bound can finish the prefix)
+        if (!(K0 - val + Cconst > thr)) return false;
+        // F = float: the tile holds the group weights rounded to single precision (relative 2^-24): the value is that of a problem
+        // whose weights are off by as much -- at most 1.3e-7 sum R |ln q| away
+        double wmargin = 0.0;
+        if constexpr (sizeof(F) == 4) wmargin = 1.3e-7 * sv_wave_sum_f64(R * fabs(lq));
+        const double g1 = sv_wave_sum_f64(t * a), g2 = sv_wave_sum_f64(t * b);
+        const double h11 = sv_wave_sum_f64(tw * a * a), h12 = sv_wave_sum_f64(tw * a * b), h22 = sv_wave_sum_f64(tw * b * b);
+        const double hh = h11 * h22, det = hh - h12 * h12;
+        if (!(det > N3_COND_MIN * hh)) return false;
+        const double d1 = (h22 * g1 - h12 * g2) / det, d2 = (h11 * g2 - h12 * g1) / det;
+        const double lam2 = g1 * d1 + g2 * d2;
+        if (!(lam2 == lam2) || !(fabs(d1) + fabs(d2) < 1e30)) return false;
+        const double tt = sqrt(fmax(lam2, 0.0) / Rmin_pre);
+        if (tt < 0.25) {
+            // min >= value - (lambda^2 / 2)(1 + t + 2 t^2)   (self-concordance, t = lambda / sqrt(Rmin) < 1/2; 5 % on top like sv_beyond)
+            const double lb = K0 - val - 0.525 * lam2 * (1.0 + tt + 2.0 * tt * tt) + Cconst;
+            if (lb - wmargin - 1e-3 - 1e-12 * fabs(K0) > thr) return true;
+            if (lam2 < 1e-3) return false;          // (converged: the prefix's minimum is within the window)
+        }
+        const double step = tt > 0.25 ? 1.0 / (1.0 + tt) : 1.0;
+        u1 += step * d1;
+        u2 += step * d2;
+    }
+    return false;
+}
+
 // The next task of the launch, for the whole wave.  Out of line on purpose: with the fetch inlined into the kernel's task loop
 // (hipcc 7.2, -O3) the wave never left the loop -- one task per wave through the same counter, or a grid-stride loop without
 // the counter, both ran; bisected on the GPU, profiles/r4/NOTES.md.
@@ -1075,7 +1172,7 @@ __global__ __launch_bounds__(64 * SV_WAVES, sizeof(F) == 4 ? SV_OCC : SV_OCC64) 
 #pragma unroll
         for (int l = 0; l < ML; l += 2) c.W->fRL[l >> 1] = SvWt<F>::make((F)leafR[l], (F)leafR[l + 1], sqrt(leafR[l]), sqrt(leafR[l + 1]));
     }
-    unsigned long long n_terms = 0, n_pterms = 0;
+    unsigned long long n_terms = 0, n_pterms = 0, n_pruned = 0;
 
     // Rank-deficient candidates (rows on one line, n3_core.hpp: N3Line) are the host's to list: testing every child here --
     // even behind a wave-uniform flag, in a second instantiation of the expansion or out of line -- cost 1-5 % of the kernel
@@ -1242,6 +1339,7 @@ __global__ __launch_bounds__(64 * SV_WAVES, sizeof(F) == 4 ? SV_OCC : SV_OCC64) 
             }
             }
         }
+        const double Rmin_pre = Rmin < __builtin_inf() ? Rmin : 1.0;      // ... of the prefix's group terms alone (sv_prefix_beyond)
 #pragma unroll
         for (int l = 0; l < ML; l++)
             if (leafR[l] > 0.0) Rmin = fmin(Rmin, leafR[l]);
@@ -1256,11 +1354,30 @@ __global__ __launch_bounds__(64 * SV_WAVES, sizeof(F) == 4 ? SV_OCC : SV_OCC64) 
         const unsigned it0 = c.n_dit, par0 = c.n_par;
         c.par = n3_unpack(n3_lane_state<NS>(st, D - 1));
         c.n_prefix++;
+        bool pruned = false;
+        if (Pg.prefix_bound && !c.no_dismiss && c.thr < 1e300 && S1p > 0.0 && S2p > 0.0 &&
+            sv_prefix_beyond<F>(c.W->fXY, c.W->fRR, G, S1p * inv_N, S2p * inv_N, Rmin_pre, Pg.r + D, Pg.rN + D, ML, inv_N, Pg.Rtot, c.K0, c.thr,
+                                (double)c.wn0, (double)c.wn1, (double)c.wn2)) {
+            // the leaves below the prefix, from the counting table; the task's share of them is done
+            const N3State &pn = c.par;
+            const u128 tv = c.cnt[((((size_t)(D - 1) * c.Q + pn.slot) * 2 + pn.sw) * c.NT1 + pn.lo) * c.NT1 + (pn.hi - 1)];
+            const unsigned long long sz = (tv >> 64) ? ~0ull : (unsigned long long)tv;
+            if (sz > c.skip) {
+                const unsigned long long avail = sz - c.skip;
+                const unsigned here = avail < (unsigned long long)c.remaining ? (unsigned)avail : c.remaining;
+                c.done += here;
+                c.remaining -= here;
+                n_pruned += here;
+                pruned = true;
+            }
+        }
 #ifdef SV_PROF
         SV_CYC(c.pt[0] += __builtin_amdgcn_s_memtime() - pg0);
 #endif
-        sv_expand<ML, 0, F, NS>(c, 1);
-        if (c.qcount) sv_drain<ML, F, NS, true>(c);               // the tile changes with the prefix: the queue is emptied first
+        if (!pruned) {
+            sv_expand<ML, 0, F, NS>(c, 1);
+            if (c.qcount) sv_drain<ML, F, NS, true>(c);           // the tile changes with the prefix: the queue is emptied first
+        }
         n_terms += (unsigned long long)(c.n_dit - it0) * (unsigned)(G + ML);          // full evaluations: every term of the candidate
         n_pterms += (unsigned long long)(c.n_par - par0);                              // shared sums of the rounds: path rows per node + the group tile per round
         c.skip = 0;                                    // only the first prefix of a task starts mid-way
@@ -1294,6 +1411,7 @@ __global__ __launch_bounds__(64 * SV_WAVES, sizeof(F) == 4 ? SV_OCC : SV_OCC64) 
         for (int i = 0; i < 7; i++) atomicAdd(&sc->prof[i], c.pt[i]);
 #else
         atomicAdd(&sc->prof[0], (unsigned long long)c.n_par);
+        atomicAdd(&sc->prof[1], n_pruned);               // candidates of prefixes finished by the prefix bound
 #endif
         atomicAdd(&sc->prof[7], (unsigned long long)c.n_prefix);
     }
