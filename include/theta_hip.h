@@ -185,6 +185,10 @@ int theta_search_degenerate(theta_problem *p, int cap, uint64_t *rank, uint8_t *
  *   "n3_auto_f64"    1 (default): a problem on which the packed-FP32 screen lists more than 0.5 % of a call's candidates as contenders
  *                    (its margin, 2e-5 sum r + 1, is coarse against the spread of the NLL within the range: 200 intervals of which a
  *                    range varies the last dozen) runs the double instantiation from the next call on; 0: never (same finalists)
+ *   "n3_prefix_bound" 1 (default): the n=3 search finishes a whole prefix (the first m - 6 rows: ~13 000 candidates at m = 50, K = 6) when
+ *                    the lower bound of its relaxed problem -- every leaf interval fitted perfectly: the likelihood of the prefix alone plus
+ *                    a constant -- lies beyond the window of the running minimum; 0: every candidate gets its own evaluation (same
+ *                    finalists, suspects and degenerate lists).  Never applies under "n3_no_dismiss"
  *   "n2_no_dismiss"  1: the n=2 search solves every candidate; 0 (default): a candidate whose rigorous lower bound -- one evaluation
  *                    at a chain point, self-concordance -- lies beyond the window of the running minimum is done (same finalists)
  *   "n3_per_task"    candidates per wave task (0 = automatic), "n2_per_thread" candidates per thread (0 = automatic)
