@@ -143,7 +143,7 @@ class Leg:
         self.running = float("inf")
         self.best = None
         self.tot = {k: 0 for k in ("evaluated", "accepted", "dismissed", "flops", "flops_f32", "terms", "iterations", "survivors",
-                                   "fallback_candidates", "redo_flops", "redo_flops_f32", "degenerate", "kernel_launches")}
+                                   "fallback_candidates", "redo_flops", "redo_flops_f32", "degenerate", "kernel_launches", "pruned")}
         self.kernel_ms = self.setup_ms = self.redo_ms = 0.0
         self.step_ms = []
         self.launches = 0
@@ -205,6 +205,8 @@ class Leg:
                 "frac": ach / peak, "newton_iters_per_candidate": self.tot["iterations"] / max(ev, 1.0),
                 "terms_per_iteration": self.tot["terms"] / max(self.tot["iterations"], 1),
                 "dismissed_fraction": self.tot["dismissed"] / max(ev, 1.0),
+                # (search mode: candidates of whole prefixes finished by the prefix bound -- no evaluation of their own; 0 in the full-solve legs)
+                "prefix_bound_fraction": self.tot["pruned"] / max(ev, 1.0),
                 "accepted_fraction_of_solved": self.tot["accepted"] / max(ev - self.tot["dismissed"], 1.0),
                 # SURVEY.md 8(d)'s per-unit figure (a per-interval FP64 Newton solve, ~160 FP64 op per interval): what this
                 # leg's throughput would cost a kernel doing THAT work -- for the f64 full solve the distance to `achieved`

@@ -112,6 +112,8 @@ typedef struct theta_search_stats {
     uint64_t redo_flops_f32; /* ... every candidate is counted once in evaluated / dismissed / iterations / terms / flops,  */
     double redo_kernel_ms;   /* ... and kernel_ms is the sieve + finish kernels' only; the redo's time is here              */
     uint64_t kernel_launches;/* launches of the search kernel behind kernel_ms (n=3 sieve: one per slice of the range)      */
+    uint64_t pruned;         /* n=3 sieve: candidates of prefixes finished by the prefix bound ("n3_prefix_bound"): counted in
+                                evaluated and dismissed, no evaluation of their own in iterations / flops                   */
 } theta_search_stats;
 
 /*

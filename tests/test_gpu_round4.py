@@ -322,9 +322,9 @@ def test_prefixes_finished_by_the_prefix_bound_change_no_list(ctx):
                 on, fon, don = _search_mode(ctx, p, b, e, rr, rn, dict(arith), hint=known)
                 off, foff, doff = _search_mode(ctx, p, b, e, rr, rn, dict(arith, n3_prefix_bound=0), hint=known)
                 assert on["stats"]["evaluated"] == off["stats"]["evaluated"] == e - b, (name, where)
-                assert off["stats"]["phase_cycles"][1] == 0
-                pruned_total += on["stats"]["phase_cycles"][1]
-                assert on["stats"]["phase_cycles"][1] <= on["stats"]["dismissed"] <= e - b
+                assert off["stats"]["pruned"] == 0
+                pruned_total += on["stats"]["pruned"]
+                assert on["stats"]["pruned"] <= on["stats"]["dismissed"] <= e - b
                 assert on["rank"] == off["rank"], (name, where, arith, len(on["rank"]), len(off["rank"]))
                 assert np.array_equal(on["C"], off["C"])
                 assert np.allclose(on["nll"], off["nll"], rtol=1e-11, atol=0)

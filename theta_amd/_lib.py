@@ -52,7 +52,7 @@ class SearchStats(C.Structure):
                 ("flops", C.c_uint64), ("flops_f32", C.c_uint64), ("dismissed", C.c_uint64), ("best_nll", C.c_double), ("rejected_bound", C.c_double),
                 ("rejected_rank", C.c_uint64 * 2), ("kernel_ms", C.c_double), ("setup_ms", C.c_double),
                 ("phase_cycles", C.c_uint64 * 8), ("survivors", C.c_uint64), ("fallback_candidates", C.c_uint64),
-                ("redo_flops", C.c_uint64), ("redo_flops_f32", C.c_uint64), ("redo_kernel_ms", C.c_double), ("kernel_launches", C.c_uint64)]
+                ("redo_flops", C.c_uint64), ("redo_flops_f32", C.c_uint64), ("redo_kernel_ms", C.c_double), ("kernel_launches", C.c_uint64), ("pruned", C.c_uint64)]
 
     def as_dict(self):
         d = {k: getattr(self, k) for k, _ in self._fields_ if k not in ("rejected_rank", "phase_cycles")}
@@ -350,7 +350,7 @@ class _Merged:
     Every entry remembers the index of its piece: the lists come out in piece order whatever the order of the add() calls
     (a piece that had to be searched a second time is added last)."""
     SUMMED = ("evaluated", "accepted", "degenerate", "iterations", "terms", "list_overflow", "flops", "flops_f32", "dismissed",
-              "survivors", "fallback_candidates", "kernel_ms", "setup_ms", "redo_flops", "redo_flops_f32", "redo_kernel_ms", "kernel_launches")
+              "survivors", "fallback_candidates", "kernel_ms", "setup_ms", "redo_flops", "redo_flops_f32", "redo_kernel_ms", "kernel_launches", "pruned")
 
     def __init__(self, n, m):
         self.n, self.m = n, m

@@ -579,6 +579,7 @@ static void fold_stats(const unsigned char *slots, SearchCounters &c) {
         c.finish_iterations += s.finish_iterations;
         c.sieve_pterms += s.sieve_pterms;
         c.sieve_children += s.sieve_children;
+        c.sieve_pruned += s.sieve_pruned;
         for (int k = 0; k < 8; k++) c.prof[k] += s.prof[k];
     }
 }
@@ -852,6 +853,7 @@ static int run_search(theta_problem *p, u128 b, u128 e, double window, double *d
             R.terms64 = after.terms64 - raw.terms64;
             R.sieve_pterms = after.sieve_pterms - raw.sieve_pterms;
             R.sieve_children = after.sieve_children - raw.sieve_children;
+            R.sieve_pruned = after.sieve_pruned - raw.sieve_pruned;
             R.sieve_survivors = after.sieve_survivors - raw.sieve_survivors;
             R.finish_iterations = after.finish_iterations - raw.finish_iterations;
             R.dismissed = after.dismissed - raw.dismissed;
@@ -866,6 +868,7 @@ static int run_search(theta_problem *p, u128 b, u128 e, double window, double *d
             merged.terms64 = got.terms64;
             merged.sieve_pterms = got.sieve_pterms;
             merged.sieve_children = got.sieve_children;
+            merged.sieve_pruned = got.sieve_pruned;
             merged.sieve_survivors = got.sieve_survivors;
             merged.finish_iterations = got.finish_iterations;
             merged.accepted = acc;
@@ -1002,6 +1005,7 @@ extern "C" int theta_search(theta_problem *p, const uint64_t rank_begin[2], cons
         count_flops(p->last_redo, stats->redo_flops, stats->redo_flops_f32);    // slices redone (contender list full): apart
         stats->redo_kernel_ms = p->last_redo_ms;
         stats->kernel_launches = p->last_launches;
+        stats->pruned = hc.sieve_pruned;
         stats->survivors = hc.sieve_survivors;
         stats->fallback_candidates = p->last_fallback;
         stats->best_nll = best;

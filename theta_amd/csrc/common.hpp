@@ -93,6 +93,7 @@ struct SearchCounters {
     unsigned long long finish_iterations; // ... and the FP64 Newton iterations (m terms each) that kernel ran on them
     unsigned long long sieve_pterms;      // sieve: likelihood terms evaluated for last-level nodes (shared by a node's children)
     unsigned long long sieve_children;    // sieve: candidates given their shared first evaluation (one own term + the 2-D reduction)
+    unsigned long long sieve_pruned;      // sieve: candidates of prefixes finished by the prefix bound (sv_prefix_beyond): no evaluation of their own
     unsigned long long prof[8];        // shader cycles per kernel phase, summed over waves (diagnostic)
 };
 

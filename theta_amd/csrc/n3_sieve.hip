@@ -1406,12 +1406,12 @@ __global__ __launch_bounds__(64 * SV_WAVES, sizeof(F) == 4 ? SV_OCC : SV_OCC64) 
         atomicAdd(&sc->terms, n_terms);
         atomicAdd(&sc->sieve_pterms, n_pterms);
         atomicAdd(&sc->sieve_children, (unsigned long long)c.n_child);
+        if (n_pruned) atomicAdd(&sc->sieve_pruned, n_pruned);
 #ifdef SV_PROF
         SV_CYC(c.pt[5] = __builtin_amdgcn_s_memtime() - pw0);
         for (int i = 0; i < 7; i++) atomicAdd(&sc->prof[i], c.pt[i]);
 #else
         atomicAdd(&sc->prof[0], (unsigned long long)c.n_par);
-        atomicAdd(&sc->prof[1], n_pruned);               // candidates of prefixes finished by the prefix bound
 #endif
         atomicAdd(&sc->prof[7], (unsigned long long)c.n_prefix);
     }

@@ -47,7 +47,7 @@ def run(name, m, tau, rr, rn, lb, ub, b=None, e=None):
             st = res["stats"]
             out[pb] = res
             print(name, "pb", pb, "count", e - b, "min", (res["nll"].min() if len(res["nll"]) else None), "finalists", len(res["rank"]), "suspects", len(p.last_suspects[0]),
-                  "pruned", st["phase_cycles"][1], "survivors", st["survivors"], "kernel ms %.2f" % st["kernel_ms"], flush=True)
+                  "pruned", st["pruned"], "survivors", st["survivors"], "kernel ms %.2f" % st["kernel_ms"], flush=True)
         except Exception as ex:
             print(name, "pb", pb, "FAILED", str(ex)[:200], flush=True)
     if 0 in out and 1 in out and (out[0]["rank"] != out[1]["rank"]):
