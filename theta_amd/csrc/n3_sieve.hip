@@ -11,26 +11,30 @@
 // 0.002 % (queue solver, values pass, polish, the hybrj restatement of the reference's outcome): 168 VGPRs plus spills, and
 // 9 of its 12.5 vector instructions per candidate are lane-private DFS and queue bookkeeping (profiles/r1).  Here:
 //
-//   n3_sieve_kernel   one wave per rank range.  The last LB rows of the matrices are expanded breadth-first, level by level,
-//                     all 64 lanes on 64 nodes of one level (the scheme of the materialised generator, n3_enum.hip: child
-//                     mask = static rules & symmetry & ratio window, DPP scan of the child counts, children written to the
-//                     next level's list in LDS); the last level's list is a BURST of <= 512 records = candidates.  Lane l
-//                     takes records l G .. (l+1) G - 1 of the burst, so a lane walks consecutive leaves and starts each
-//                     from the optimum of its previous one; ONE packed-FP32 evaluation (value, gradient, Hessian over the
-//                     prefix's group tile + the record's own rows) gives the self-concordance lower bound
-//                         min NLL >= NLL(u) - lambda^2 / (2 (1 - lambda / sqrt(Rmin)))
-//                     and a candidate whose bound lies beyond the window of the running minimum is DONE.  The others take
-//                     further Newton steps from a small LDS queue (64 at a time); what is still within the window once
+//   n3_sieve_kernel   persistent waves, one rank range (task) at a time.  Per prefix (the first m - ML rows): the group tile
+//                     (intervals with the same row collapse into one likelihood term) and, in search mode, ONE bound that may
+//                     finish the whole prefix (sv_prefix_beyond).  Else the last ML rows of the matrices are expanded
+//                     breadth-first, level by level, all 64 lanes on 64 nodes of one level (the scheme of the materialised
+//                     generator, n3_enum.hip: child mask = static rules & symmetry & ratio window, DPP scan of the child
+//                     counts, children written to the next level's list in LDS).  A ROUND of <= 64 last-level nodes evaluates
+//                     value / gradient / Hessian sums at ONE point w for all of them (sv_parent: the group tile's part once
+//                     per round, the nodes' own path rows per lane), then one lane per CHILD adds its last row and has the
+//                     Newton decrement and the self-concordance lower bound
+//                         min NLL >= NLL(w) - (lambda^2 / 2)(1 + t + 2 t^2),   t = lambda / sqrt(Rmin) < 1/2
+//                     (sv_child_eval): a candidate whose bound lies beyond the window of the running minimum is DONE (search),
+//                     one within the coarse tolerance is converged (full solve).  The others take full evaluations at their own
+//                     point from a small LDS queue with persistent lanes (sv_drain); what is still within the window once
 //                     converged -- a contender -- is written, rows and rank, to a device list.  No DFS stack, no values
-//                     pass, no cold path: the hot loop is the evaluation and little else.
+//                     pass, no cold path: the hot loops are the arithmetic and little else.
 //   n3_finish_kernel  one LANE per listed contender: FP64 Newton per interval from the simplex centre, polish, admissibility
 //                     (Optimizer.py:150-160), exact NLL, and for what is within the window the reference's own outcome
 //                     (hybrj / BFGS restatement, n3_refbfgs.hpp) -- then the tie list, the suspect list and the device-wide
 //                     minimum exactly as n3.hip's cold path maintains them.
 //
-// The fused kernel of n3.hip stays: it is the --GET_VALUES dump, the FP64 / no-dismissal modes, the path for m < 8, the
-// fallback for a slice whose contender list overflows (a stretch of near-ties), and the second implementation the tests
-// compare this one with (identical finalists).
+// The fused kernel of n3.hip stays: it is the --GET_VALUES dump, the path for m < 8, the last resort for a slice part whose
+// contender list overflows three times (a stretch of near-ties), and the second implementation the tests compare this one
+// with (identical finalists).  F = float | double and "n3_no_dismiss" (every candidate iterated: the bench's full-solve
+// legs) are instantiations / modes of THIS kernel.
 #include <stddef.h>
 
 #include <type_traits>
