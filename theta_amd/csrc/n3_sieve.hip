@@ -185,6 +185,7 @@ struct SvWave {
     SvPlanes<F> par;                                    // per last-level node of the round: shared sums, column sums, point
     unsigned pcode[WAVE];                               // ... and the slots of its path rows (6 bits each) | usable << 31
     unsigned task_line;                                 // a prefix of the task had collinear rows (n3_core.hpp: N3Line)
+    double pb_pt[3];                                    // the prefix bound's last point (w0, u1, u2): where the next prefix's bound starts (sv_prefix_beyond)
     Sv4<F> fXY[(N3_MAX_Q + 2) / 2];                     // group tile of the prefix, two terms per entry {a0, a1, b0, b1}
     typename SvWt<F>::T fRR[(N3_MAX_Q + 2) / 2];        // ... and their weights {R0, R1} (an odd last term is paired with weight 0); F = double:
     typename SvWt<F>::T fRL[ML / 2];                    // {R0, R1, sqrt R0, sqrt R1}.  fRL: the weights of the leaf rows, paired likewise
@@ -1004,7 +1005,7 @@ __device__ __forceinline__ double sv_wave_sum_f64(double v) {
 template <class F>
 __device__ __noinline__ bool sv_prefix_beyond(const Sv4<F> *fXY, const typename SvWt<F>::T *fRR, int G, double s1n, double s2n, double Rmin_pre,
                                               const double *r_leaf, const double *rN_leaf, int nleaf, double inv_N, double Rtot, double K0, double thr,
-                                              double w0c, double u1c, double u2c) {
+                                              double w0c, double u1c, double u2c, double *pt) {
     const int lane = threadIdx.x & 63;
     double Rrem = 0.0, Nrem = 0.0, Csum = 0.0;
     for (int l = 0; l < nleaf; l++) {
@@ -1030,6 +1031,13 @@ __device__ __noinline__ bool sv_prefix_beyond(const Sv4<F> *fXY, const typename 
     const double a = x - s1, b = y - s2;
     double u1 = (1.0 / 3.0) / s1, u2 = (1.0 / 3.0) / s2;
     bool from_chain = false;
+    // start: where the previous prefix's bound ended (neighbouring prefixes differ in their last rows: one or two steps do), else
+    // the sieve's chain point, else the prefix's simplex centre
+    if (pt[0] == pt[0]) {
+        w0c = pt[0];
+        u1c = pt[1];
+        u2c = pt[2];
+    }
     if (w0c == w0c) {
         const double zw = w0c + s1 * u1c + s2 * u2c;
         if (zw > 0.0 && zw < 1e300) {
@@ -1068,6 +1076,11 @@ __device__ __noinline__ bool sv_prefix_beyond(const Sv4<F> *fXY, const typename 
         const double lam2 = g1 * d1 + g2 * d2;
         if (!(lam2 == lam2) || !(fabs(d1) + fabs(d2) < 1e30)) return false;
         const double tt = sqrt(fmax(lam2, 0.0) / Rmin_pre);
+        if (lane == 0) {                                 // (a point of the prefix's domain: the next prefix starts from it)
+            pt[0] = 1.0 - s1 * u1 - s2 * u2;
+            pt[1] = u1;
+            pt[2] = u2;
+        }
         if (tt < 0.25) {
             // min >= value - (lambda^2 / 2)(1 + t + 2 t^2)   (self-concordance, t = lambda / sqrt(Rmin) < 1/2; 5 % on top like sv_beyond)
             const double lb = K0 - val - 0.525 * lam2 * (1.0 + tt + 2.0 * tt * tt) + Cconst;
@@ -1119,6 +1132,7 @@ __global__ __launch_bounds__(64 * SV_WAVES, sizeof(F) == 4 ? SV_OCC : SV_OCC64) 
     // launch's contender counter).  With one task per wave and four waves per block, a block held its registers and LDS until
     // its slowest task was through, and the last blocks of a launch ran on a nearly empty chip: 10 % of the wave slots' time.
     unsigned *const task_next = surv_count + SV_TASKCTR_OFF;
+    if (lane == 0) S.w[wv].pb_pt[0] = __builtin_nan("");       // (the prefix bound's point lives across the wave's tasks: w fits the data's ratios, wherever in the space)
     for (;;) {
     const int task = sv_next_task(task_next);
     if (task >= ntasks) break;                         // whole wave leaves together; no block barrier below
@@ -1361,7 +1375,7 @@ __global__ __launch_bounds__(64 * SV_WAVES, sizeof(F) == 4 ? SV_OCC : SV_OCC64) 
         bool pruned = false;
         if (Pg.prefix_bound && !c.no_dismiss && c.thr < 1e300 && S1p > 0.0 && S2p > 0.0 &&
             sv_prefix_beyond<F>(c.W->fXY, c.W->fRR, G, S1p * inv_N, S2p * inv_N, Rmin_pre, Pg.r + D, Pg.rN + D, ML, inv_N, Pg.Rtot, c.K0, c.thr,
-                                (double)c.wn0, (double)c.wn1, (double)c.wn2)) {
+                                (double)c.wn0, (double)c.wn1, (double)c.wn2, c.W->pb_pt)) {
             // the leaves below the prefix, from the counting table; the task's share of them is done
             const N3State &pn = c.par;
             const u128 tv = c.cnt[((((size_t)(D - 1) * c.Q + pn.slot) * 2 + pn.sw) * c.NT1 + pn.lo) * c.NT1 + (pn.hi - 1)];
