@@ -1208,79 +1208,22 @@ __global__ __launch_bounds__(64 * SV_WAVES, sizeof(F) == 4 ? SV_OCC : SV_OCC64) 
         int G = 0;
         double S1p = 0.0, S2p = 0.0, Rmin = __builtin_inf();
         {
-            if constexpr (NS == 2) {      // (the two-per-lane form everything is tuned on, kept as it was: the generic form below compiles to a slower kernel, 62.3 -> 63.7 ms)
-            // lane i stands for interval i and, for matrices of more than 64 + ML rows, for interval 64 + i as well
-            const bool inp = lane < D, inp1 = lane + WAVE < D;
-            const unsigned myrow = st[0] >> 24, myrow1 = st[1] >> 24;           // a | b << 4
-            if (inp) c.W->pre[lane] = (unsigned short)((myrow & 15u) | ((myrow >> 4) << 8));
-            if (inp1) c.W->pre[WAVE + lane] = (unsigned short)((myrow1 & 15u) | ((myrow1 >> 4) << 8));
-            const double r_i = inp ? Pg.r[lane] : 0.0, rN_i = inp ? Pg.rN[lane] : 0.0;
-            const double r_j = inp1 ? Pg.r[WAVE + lane] : 0.0, rN_j = inp1 ? Pg.rN[WAVE + lane] : 0.0;
-            {   // Do the prefix rows (x_i, y_i) lie on one line?  (Rare.)  Then some children may be rank-deficient (n3_core.hpp:
-                // N3Line): the task is noted for the host.  Lane-parallel -- the first row, the first row that differs, one cross
-                // product per lane -- so that nothing is carried through the loop below (a running test there cost 1.4 %).
-                const unsigned p0 = (unsigned)__builtin_amdgcn_readlane((int)myrow, 0);
-                const unsigned long long df = ballot64(inp && myrow != p0), df1 = ballot64(inp1 && myrow1 != p0);
-                bool on_line = true;
-                if (df | df1) {
-                    const unsigned p1 = df ? (unsigned)__builtin_amdgcn_readlane((int)myrow, __builtin_ctzll(df))
-                                           : (unsigned)__builtin_amdgcn_readlane((int)myrow1, __builtin_ctzll(df1));
-                    const int a0 = (int)(p0 & 15u), b0 = (int)(p0 >> 4), da = (int)(p1 & 15u) - a0, db = (int)(p1 >> 4) - b0;
-                    const int cr = da * ((int)(myrow >> 4) - b0) - db * ((int)(myrow & 15u) - a0);
-                    const int cr1 = da * ((int)(myrow1 >> 4) - b0) - db * ((int)(myrow1 & 15u) - a0);
-                    on_line = !(ballot64(inp && cr != 0) | ballot64(inp1 && cr1 != 0));
-                }
-                if (on_line && lane == 0) c.W->task_line = 1u;
-            }
-            unsigned long long todo = ballot64(inp), todo1 = ballot64(inp1);
-            while (todo | todo1) {
-                unsigned q;
-                if (todo) q = (unsigned)__builtin_amdgcn_readlane((int)myrow, __builtin_ctzll(todo));
-                else q = (unsigned)__builtin_amdgcn_readlane((int)myrow1, __builtin_ctzll(todo1));
-                const bool match = inp && myrow == q, match1 = inp1 && myrow1 == q;
-                todo &= ~ballot64(match);
-                todo1 &= ~ballot64(match1);
-                double Rs = (match ? r_i : 0.0) + (match1 ? r_j : 0.0), Ns = (match ? rN_i : 0.0) + (match1 ? rN_j : 0.0);
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) {     // integer-valued doubles < 2^53: the sums are exact
-                    Rs += __shfl_xor(Rs, o, WAVE);
-                    Ns += __shfl_xor(Ns, o, WAVE);
-                }
-                const F a = (F)(q & 15u), b = (F)(q >> 4);
-                if (lane == 0) {
-                    F *xy = (F *)&c.W->fXY[G >> 1];
-                    F *rr = (F *)&c.W->fRR[G >> 1];
-                    if (G & 1) {
-                        xy[1] = a; xy[3] = b; rr[1] = (F)Rs;
-                    } else {   // also fills the second half: stays as the weight-0 pad when this is the last term
-                        xy[0] = xy[1] = a; xy[2] = xy[3] = b; rr[0] = (F)Rs; rr[1] = F(0);
-                    }
-                    if constexpr (sizeof(F) == 8) {
-                        rr[2 + (G & 1)] = sqrt(Rs);
-                        if (!(G & 1)) rr[3] = 0.0;
-                    }
-                }
-                S1p += (double)a * Ns;
-                S2p += (double)b * Ns;
-                if (Rs > 0.0) Rmin = fmin(Rmin, Rs);
-                G++;
-            }
-            } else {
-            // lane i stands for the intervals i, 64 + i, ... of the prefix (NS of them)
+            // One pass instead of one round of wave reductions per distinct row (13 rounds of six dependent shuffles: 18 000 cycles per
+            // prefix, half of what a prefix finished by its bound costs): every lane ADDS its intervals' counts to the bin of their row
+            // in LDS (ds_add_f64; integer-valued doubles below 2^53: exact in any order), then lane l looks at the bins l, 64 + l, ...
+            // and writes the tile entries of the rows that occur -- in row-code order.  The bins live in the record planes, which
+            // are free between prefixes.
             bool inp[NS];
             unsigned myrow[NS];                                          // a | b << 4
-            double r_i[NS], rN_i[NS];
 #pragma unroll
             for (int j = 0; j < NS; j++) {
                 inp[j] = WAVE * j + lane < D;
                 myrow[j] = st[j] >> 24;
                 if (inp[j]) c.W->pre[WAVE * j + lane] = (unsigned short)((myrow[j] & 15u) | ((myrow[j] >> 4) << 8));
-                r_i[j] = inp[j] ? Pg.r[WAVE * j + lane] : 0.0;
-                rN_i[j] = inp[j] ? Pg.rN[WAVE * j + lane] : 0.0;
             }
             {   // Do the prefix rows (x_i, y_i) lie on one line?  (Rare.)  Then some children may be rank-deficient (n3_core.hpp:
-                // N3Line): the task is noted for the host.  Lane-parallel -- the first row, the first row that differs, one cross
-                // product per lane -- so that nothing is carried through the loop below (a running test there cost 1.4 %).
+                // N3Line): the task is noted for the host.  Lane-parallel: the first row, the first row that differs, one cross
+                // product per lane.
                 const unsigned p0 = (unsigned)__builtin_amdgcn_readlane((int)myrow[0], 0);
                 unsigned p1 = p0;
                 bool differs = false;
@@ -1305,57 +1248,51 @@ __global__ __launch_bounds__(64 * SV_WAVES, sizeof(F) == 4 ? SV_OCC : SV_OCC64) 
                 }
                 if (on_line && lane == 0) c.W->task_line = 1u;
             }
-            unsigned long long todo[NS];
-            bool any = false;
+            double *binR = (double *)&c.W->par, *binN = binR + 256;       // 2 x 256 doubles = 4 KB (the float planes' size)
 #pragma unroll
-            for (int j = 0; j < NS; j++) {
-                todo[j] = ballot64(inp[j]);
-                any = any || todo[j] != 0ull;
-            }
-            while (any) {
-                unsigned q = 0u;
-                bool have = false;
+            for (int k = 0; k < 4; k++) ((double2 *)binR)[lane + WAVE * k] = make_double2(0.0, 0.0);
+            wave_lds_sync();
 #pragma unroll
-                for (int j = 0; j < NS; j++)
-                    if (!have && todo[j]) {
-                        q = (unsigned)__builtin_amdgcn_readlane((int)myrow[j], __builtin_ctzll(todo[j]));
-                        have = true;
-                    }
-                double Rs = 0.0, Ns = 0.0;
-                any = false;
-#pragma unroll
-                for (int j = 0; j < NS; j++) {
-                    const bool match = inp[j] && myrow[j] == q;
-                    todo[j] &= ~ballot64(match);
-                    any = any || todo[j] != 0ull;
-                    Rs += match ? r_i[j] : 0.0;
-                    Ns += match ? rN_i[j] : 0.0;
+            for (int j = 0; j < NS; j++)
+                if (inp[j]) {
+                    atomicAdd(&binR[myrow[j]], Pg.r[WAVE * j + lane]);
+                    atomicAdd(&binN[myrow[j]], Pg.rN[WAVE * j + lane]);
                 }
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) {     // integer-valued doubles < 2^53: the sums are exact
-                    Rs += __shfl_xor(Rs, o, WAVE);
-                    Ns += __shfl_xor(Ns, o, WAVE);
+            wave_lds_sync();
+            double s1l = 0.0, s2l = 0.0, rml = __builtin_inf();
+            for (int k = 0; k < 4; k++) {
+                const unsigned code = (unsigned)(lane + WAVE * k);
+                const double Ns = binN[code], Rs = binR[code];
+                const bool has = Ns > 0.0;                                // (normal counts are >= 1: a row that occurs has Ns > 0)
+                const unsigned long long hm = ballot64(has);
+                if (!hm) continue;
+                if (has) {
+                    const int idx = G + mbcnt(hm);
+                    const F a = (F)(code & 15u), b = (F)(code >> 4);
+                    F *xy = (F *)&c.W->fXY[idx >> 1];
+                    F *rr = (F *)&c.W->fRR[idx >> 1];
+                    xy[idx & 1] = a;
+                    xy[2 + (idx & 1)] = b;
+                    rr[idx & 1] = (F)Rs;
+                    if constexpr (sizeof(F) == 8) rr[2 + (idx & 1)] = sqrt(Rs);
+                    s1l += (double)(code & 15u) * Ns;
+                    s2l += (double)(code >> 4) * Ns;
+                    if (Rs > 0.0) rml = fmin(rml, Rs);
                 }
-                const F a = (F)(q & 15u), b = (F)(q >> 4);
-                if (lane == 0) {
-                    F *xy = (F *)&c.W->fXY[G >> 1];
-                    F *rr = (F *)&c.W->fRR[G >> 1];
-                    if (G & 1) {
-                        xy[1] = a; xy[3] = b; rr[1] = (F)Rs;
-                    } else {   // also fills the second half: stays as the weight-0 pad when this is the last term
-                        xy[0] = xy[1] = a; xy[2] = xy[3] = b; rr[0] = (F)Rs; rr[1] = F(0);
-                    }
-                    if constexpr (sizeof(F) == 8) {
-                        rr[2 + (G & 1)] = sqrt(Rs);
-                        if (!(G & 1)) rr[3] = 0.0;
-                    }
-                }
-                S1p += (double)a * Ns;
-                S2p += (double)b * Ns;
-                if (Rs > 0.0) Rmin = fmin(Rmin, Rs);
-                G++;
+                G += __builtin_popcountll(hm);
             }
+            wave_lds_sync();
+            if ((G & 1) && lane == 0) {          // an odd last term is paired with a copy of itself of weight 0
+                F *xy = (F *)&c.W->fXY[G >> 1];
+                F *rr = (F *)&c.W->fRR[G >> 1];
+                xy[1] = xy[0];
+                xy[3] = xy[2];
+                rr[1] = F(0);
+                if constexpr (sizeof(F) == 8) rr[3] = F(0);
             }
+            S1p = sv_wave_sum_f64(s1l);
+            S2p = sv_wave_sum_f64(s2l);
+            Rmin = wave_min(rml);
         }
         const double Rmin_pre = Rmin < __builtin_inf() ? Rmin : 1.0;      // ... of the prefix's group terms alone (sv_prefix_beyond)
 #pragma unroll
