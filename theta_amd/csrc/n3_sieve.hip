@@ -52,6 +52,11 @@
 // ... of the list of last-level nodes: as long as the block's LDS allows at the kernel's occupancy (float: 3 blocks of <= 52 KB
 // per CU -- one entry more and the third block no longer fits, measured: -15 %; double: 2 blocks of <= 80 KB)
 template <class F> struct SvCapL { static constexpr int v = sizeof(F) == 4 ? 160 : 192; };
+#ifndef SV_UNR
+#define SV_UNR 2          // unroll factor of the group-pair loop of a full evaluation (sv_step)
+#endif
+#define SV_PRAGMA(x) _Pragma(#x)
+#define SV_UNROLL(n) SV_PRAGMA(unroll n)
 #ifndef SV_QCAP
 #define SV_QCAP 128       // records waiting for further Newton steps
 #endif
@@ -321,7 +326,7 @@ __device__ __forceinline__ int sv_step(const SvCtx<ML, F, NS> &c, const unsigned
     };
     const Sv4<F> *fXY = c.W->fXY;
     const typename SvWt<F>::T *fRR = c.W->fRR;
-#pragma unroll 2
+SV_UNROLL(SV_UNR)
     for (int p = 0; p < c.GP; p++) {
         const Sv4<F> xy = fXY[p];
         const typename SvWt<F>::T rr = fRR[p];
