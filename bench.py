@@ -28,6 +28,8 @@ Prints ONE JSON line (rank 0).
              legs (N = 1, after the timed region, on ALL of its rank ranges; each with its own kernel time, FLOP and frac):
                full_solve_f64   the headline, again as a leg record (per-step kernel ms min / median / max, counters)
                full_solve_f64_tight  the same at the tight tolerance (lambda^2 / sum r < 1e-12: every candidate's mu to 1e-6)
+               full_solve_f64_tight_certified  the same guarantee met by certificate (the decrement of the point a candidate is LEFT at
+                                     is bounded below 1e-12 by the self-concordance bound of its last Newton step)
                full_solve_f32   the same in packed single precision (n3_no_dismiss)
                search           the shipped branch-and-bound: a candidate whose rigorous lower bound lies beyond the window of
                                 the running minimum is finished after one shared packed-FP32 evaluation ("searched", not
@@ -62,8 +64,25 @@ LEGS = {"full_solve_f64": ({"n3_no_dismiss": 1, "n3_force_f64": 1}, "f64", "n3_s
         # the same with the TIGHT tolerance: every candidate iterated until an evaluation finds lambda^2 / sum r < 1e-12 (then the
         # step): each candidate's mu within 1e-6 of its optimum -- north_star's tolerance for the CHOSEN candidate, here for all
         "full_solve_f64_tight": ({"n3_no_dismiss": 1, "n3_force_f64": 1, "n3_conv_l2": 1e-12}, "f64", "n3_sieve_kernel<6, double>"),
+        # the tight tolerance met by CERTIFICATE: the library leaves a candidate one Newton step beyond the evaluation that finds the
+        # tolerance.  The restricted likelihood is self-concordant with parameter 2 / sqrt(Rmin), so a full step from a point with
+        # t = lambda / sqrt(Rmin) <= 0.1 ends at lambda'^2 / sum r <= 1.53 (sum r / Rmin) (lambda^2 / sum r)^2 (certified_conv_l2
+        # below; tests/test_certified_tolerance_cpu.py).  An evaluation that finds lambda^2 / sum r below
+        # sqrt(1e-12 Rmin / (1.53 sum r)) therefore leaves the candidate at a point whose decrement is certified below 1e-12 --
+        # the same guarantee as full_solve_f64_tight (mu within 1e-6), without the evaluation that only confirms it
+        "full_solve_f64_tight_certified": ({"n3_no_dismiss": 1, "n3_force_f64": 1, "n3_conv_l2": "certified"}, "f64", "n3_sieve_kernel<6, double>"),
         "full_solve_f32": ({"n3_no_dismiss": 1}, "f32+f64", "n3_sieve_kernel<6, float>"),
         "search": ({}, "f32+f64", "n3_sieve_kernel<6, float>")}
+
+
+def certified_conv_l2(r, final_l2=1e-12):
+    """Largest lambda^2 / sum r at an evaluation from which ONE full Newton step is certified to end below `final_l2`.
+    f = -sum R_i log q_i(u) over the terms of a candidate (R_i >= min r: a term aggregates whole intervals) is self-concordant
+    after division by Rmin; with t = lambda / sqrt(Rmin) the step's decrement obeys t' <= (t / (1 - t))^2, i.e.
+    l2' <= l2^2 (sum r / Rmin) / (1 - t)^4 <= 1.53 l2^2 sum r / Rmin for t <= 0.1."""
+    r = np.asarray(r, dtype=np.float64)
+    ror = float(r.sum() / r[r > 0].min())
+    return min(float(np.sqrt(final_l2 / (1.53 * ror))), 0.01 / ror)
 
 
 def synth(seed=SEED, m=M, n=N_POP, k=K_MAX):
@@ -464,6 +483,8 @@ def main():
 
     def set_opts(opts, on):
         for k, v in opts.items():
+            if v == "certified":
+                v = certified_conv_l2(r)
             problem.set_option(k, v if on else (1e-4 if k == "n3_conv_l2" else 0))      # (1e-4: the library's default coarse tolerance)
 
     head_opts, head_dtype, head_kernel = LEGS[args.leg]
@@ -506,6 +527,9 @@ def main():
                                   "full_solve_f64_tight",
                 "full_solve_f64_tight": "TIGHT tolerance lambda^2 / sum r < 1e-12 (every candidate's mu within 1e-6 of its optimum) -- every "
                                         "candidate generated, iterated in FP64 and valued; none dismissed by a bound",
+                "full_solve_f64_tight_certified": "TIGHT tolerance by certificate: every candidate left at a point whose lambda^2 / sum r is "
+                                                  "below 1e-12 by the self-concordance bound of its last Newton step (mu within 1e-6 of its "
+                                                  "optimum) -- every candidate generated, iterated in FP64 and valued; none dismissed by a bound",
                 "full_solve_f32": "COARSE tolerance lambda^2 / sum r < 1e-4 -- every candidate generated, iterated in packed FP32 and valued; "
                                   "none dismissed by a bound",
                 "search": "candidates SEARCHED by the shipped branch-and-bound (a whole prefix finished by the bound of its relaxed problem, else "

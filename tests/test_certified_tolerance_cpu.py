@@ -1,0 +1,99 @@
+"""The certificate behind bench.py's leg full_solve_f64_tight_certified (CPU, numpy).
+
+A candidate's restricted likelihood in the sieve kernel (theta_amd/csrc/n3_sieve.hip, sv_step) is
+    f(u) = - sum_i R_i log q_i(u),   q_i(u) = 1 + a_i u1 + b_i u2,
+the reference's L3 (Optimizer.py:273-330) on the slice where its normalisation is constant.  f / Rmin is a sum of -log terms with
+coefficients >= 1, hence standard self-concordant: with lambda the Newton decrement and t = lambda / sqrt(Rmin) < 1, a FULL Newton
+step ends at t' <= (t / (1 - t))^2.  In the kernel's unit l2 = lambda^2 / sum R that reads
+    l2' <= l2^2 (sum R / Rmin) / (1 - t)^4 <= 1.53 l2^2 sum R / Rmin          for t <= 0.1,
+which is what bench.certified_conv_l2 inverts.  Checked here on random problems of the kernel's shape, at points whose decrement
+spans the range the leg uses."""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+
+
+def _problem(rng):
+    T = int(rng.integers(8, 30))
+    rmin = float(rng.integers(50, 30000))
+    R = np.floor(rmin * (1.0 + 40.0 * rng.random(T) ** 2))
+    R[int(rng.integers(T))] = rmin
+    x = rng.integers(0, 7, T).astype(float)
+    y = rng.integers(0, 7, T).astype(float)
+    if np.linalg.matrix_rank(np.stack([np.ones(T), x, y])) < 3:
+        return None
+    s1, s2 = float((R * x).sum() / R.sum()) + 0.3 * rng.random(), float((R * y).sum() / R.sum()) + 0.3 * rng.random()
+    return R, x - s1, y - s2
+
+
+def _eval(R, a, b, u):
+    q = 1.0 + a * u[0] + b * u[1]
+    if not (q > 0).all():
+        return None
+    al, be = a / q, b / q
+    g = -np.array([(R * al).sum(), (R * be).sum()])
+    H = np.array([[(R * al * al).sum(), (R * al * be).sum()], [(R * al * be).sum(), (R * be * be).sum()]])
+    d = np.linalg.solve(H, -g)
+    return float(-(g @ d)) / R.sum(), d          # (lambda^2 / sum R, the Newton step)
+
+
+def test_a_full_newton_step_ends_below_the_self_concordance_bound():
+    rng = np.random.default_rng(20260930)
+    checked = 0
+    worst = 0.0
+    while checked < 4000:
+        pr = _problem(rng)
+        if pr is None:
+            continue
+        R, a, b = pr
+        ror = R.sum() / R.min()
+        u = np.zeros(2)
+        ok = True
+        for _ in range(60):                        # the minimiser, by damped Newton from the centre of the slice
+            ev = _eval(R, a, b, u)
+            if ev is None:
+                ok = False
+                break
+            l2, d = ev
+            if l2 < 1e-30:
+                break
+            step = 1.0 if l2 * ror < 0.25 else 1.0 / (1.0 + np.sqrt(l2 * ror))
+            while _eval(R, a, b, u + step * d) is None:
+                step *= 0.5
+            u = u + step * d
+        if not ok:
+            continue
+        ustar = u
+        for _ in range(8):
+            # a point at a chosen distance from the minimiser: decrements from the leg's threshold range up to t = 0.1
+            scale = 10.0 ** rng.uniform(-5.5, -1.0)
+            p = ustar + scale * rng.standard_normal(2) / np.sqrt(R.sum())
+            ev = _eval(R, a, b, p)
+            if ev is None:
+                continue
+            l2, d = ev
+            if not (l2 * ror <= 0.01) or l2 < 1e-13:
+                continue
+            ev2 = _eval(R, a, b, p + d)
+            assert ev2 is not None, "a full step from t <= 0.1 stays in the domain"
+            bound = 1.53 * ror * l2 * l2
+            assert ev2[0] <= bound * (1 + 1e-6) + 1e-27, (l2, ev2[0], bound, ror)
+            worst = max(worst, ev2[0] / bound)
+            checked += 1
+    assert 0.0 < worst <= 1.0 + 1e-6
+
+
+def test_the_legs_threshold_certifies_the_tight_tolerance():
+    r, rN, order = bench.synth()
+    r = np.asarray(r, dtype=np.float64)
+    conv = bench.certified_conv_l2(r)
+    ror = r.sum() / r.min()
+    assert conv * ror <= 0.01 + 1e-15                       # t <= 0.1 at every evaluation that passes
+    assert 1.53 * ror * conv * conv <= 1e-12 * (1 + 1e-12)  # ... and the step from it ends below the tight tolerance
+    assert 1e-9 < conv < 1e-4                               # between the tight and the coarse tolerance of the other legs
+    # a problem whose smallest weight is tiny: the t <= 0.1 side binds
+    assert bench.certified_conv_l2(np.array([1.0, 1e9])) == 0.01 / (1e9 + 1.0)

@@ -110,7 +110,9 @@ def test_fp64_sieve_and_full_solve_modes_return_the_lists_of_the_shipped_search(
     cases.append(("m12 k4 tau3", 12, rb, rNb, [0] * 12, [4] * 12, [("all", None)], 3))
     modes = [("f64", {"n3_force_f64": 1}), ("f64 full solve", {"n3_force_f64": 1, "n3_no_dismiss": 1}), ("f32 full solve", {"n3_no_dismiss": 1}),
              # bench.py's leg full_solve_f64_tight: every candidate iterated to lambda^2 / sum r < 1e-12
-             ("f64 tight full solve", {"n3_force_f64": 1, "n3_no_dismiss": 1, "n3_conv_l2": 1e-12})]
+             ("f64 tight full solve", {"n3_force_f64": 1, "n3_no_dismiss": 1, "n3_conv_l2": 1e-12}),
+             # bench.py's leg full_solve_f64_tight_certified: the threshold from which ONE Newton step is certified to end below 1e-12
+             ("f64 certified full solve", {"n3_force_f64": 1, "n3_no_dismiss": 1, "n3_conv_l2": "certified"})]
     for name, m, rr, rn, lb, ub, ranges, tau in cases:
         p = theta_amd.Problem(ctx, 3, m, tau, rr, rn, lb, ub, 1.0)
         known = None
@@ -126,11 +128,18 @@ def test_fp64_sieve_and_full_solve_modes_return_the_lists_of_the_shipped_search(
             a, fa, da = _search_mode(ctx, p, b, e, rr, rn, {}, hint=known)
             assert a["stats"]["evaluated"] == e - b
             coarse_iters = None
+            tight_iters = None
             for mode, opts in modes:
+                if opts.get("n3_conv_l2") == "certified":
+                    opts = dict(opts, n3_conv_l2=bench.certified_conv_l2(rr))
                 f, ff, df = _search_mode(ctx, p, b, e, rr, rn, opts, hint=known)
                 st = f["stats"]
                 if mode == "f64 full solve":
                     coarse_iters = st["iterations"]
+                if mode == "f64 tight full solve":
+                    tight_iters = st["iterations"]
+                if mode == "f64 certified full solve" and m >= 8:
+                    assert coarse_iters <= st["iterations"] <= tight_iters, (name, where, coarse_iters, st["iterations"], tight_iters)   # (between the two tolerances)
                 if mode == "f64 tight full solve" and m >= 8:
                     assert st["iterations"] >= coarse_iters and (not name.startswith("bench") or st["iterations"] > 1.3 * coarse_iters), (name, where, st["iterations"], coarse_iters)   # (the tight tolerance costs evaluations; with a tiny Rmin the coarse mode is held to lambda^2 < Rmin / 4 anyway)
                 assert st["evaluated"] == e - b, (name, where, mode)

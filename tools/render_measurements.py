@@ -20,9 +20,10 @@ def e(x):
 rows = []
 what = {"full_solve_f64": "**headline**: `n3_no_dismiss` + `n3_force_f64` — every candidate iterated in FP64 to the COARSE tolerance (λ²/Σr < 1e-4 at an evaluation, then the step) and valued, none dismissed (§8(d)'s definition)",
         "full_solve_f64_tight": "the same at the TIGHT tolerance (`n3_conv_l2` = 1e-12: every candidate's μ within 1e-6 of its optimum)",
+        "full_solve_f64_tight_certified": "the same guarantee by CERTIFICATE: `n3_conv_l2` = the largest decrement from which one full Newton step is bounded below 1e-12 by self-concordance (`bench.certified_conv_l2`, 4.4e-8 here) — the candidate is left at a point that meets the tight tolerance, without the evaluation that would only confirm it",
         "full_solve_f32": "`n3_no_dismiss`: the same in packed single precision",
         "search": "as shipped: whole prefixes finished by the bound of their relaxed problem (every prefix of these far-off stretches), what is left by the lower bound after one shared evaluation (\"searched\", a rider; `THETA_N3_PREFIX_BOUND=0`: 9.9e10, the per-candidate machinery alone)"}
-for name in ("full_solve_f64", "full_solve_f64_tight", "full_solve_f32", "search"):
+for name in ("full_solve_f64", "full_solve_f64_tight", "full_solve_f64_tight_certified", "full_solve_f32", "search"):
     if name not in legs:
         continue
     l = legs[name]
