@@ -173,7 +173,10 @@ int theta_search_degenerate(theta_problem *p, int cap, uint64_t *rank, uint8_t *
  *                    iterated to the coarse tolerance and valued ("passed through the full solve")
  *   "n3_force_f64"   1: every evaluation in FP64 -- the sieve kernel's double instantiation (default: packed FP32 evaluations,
  *                    FP64 for contenders); with "n3_no_dismiss" the full solve at the reference's precision
- *   "n3_conv_l2"     coarse-pass threshold on the squared Newton decrement (default 1e-4)
+ *   "n3_conv_l2"     coarse-pass threshold on the squared Newton decrement / sum r (default 1e-4).  A candidate is left ONE full
+ *                    Newton step beyond the evaluation that finds it; with t = lambda / sqrt(Rmin) <= 0.1 that step ends at a
+ *                    decrement <= 1.53 (sum r / Rmin) l2^2 (self-concordance), so a tolerance T on the point a candidate is left at
+ *                    is met by the value sqrt(T Rmin / (1.53 sum r)) (bench.py: certified_conv_l2)
  *   "n3_warm_blend"  weight of the previous optimum in a chunk's first warm start
  *   "n3_sieve"       1 (default): the two-kernel path (sieve + finish, n3_sieve.hip) where it applies; 0: the fused
  *                    kernel of n3.hip throughout (also used for theta_search_values and m < 8; m <= 64)
