@@ -104,6 +104,44 @@ def bound(X, Y, r, Nn, K0, Rtot, W, iters=40):
     return K0 + safe + Rp * np.log(1.0) + const, u          # (z.w = 1 on the slice: the normalisation term vanishes)
 
 
+def walk(r, Nn, K0, Rtot, K, thr, cap=3_000_000, Ct=None, verbose=False):
+    """Depth by depth: every row tried on every live prefix, a prefix kept while its bound is <= thr.  Returns the complete
+    matrices within thr (X, Y: (n, m)), their minima, the number of bound solves, and whether the walk reached depth m."""
+    m = len(r)
+    rows = np.array([(x, y) for x in range(K + 1) for y in range(K + 1)], dtype=float)
+    X = np.zeros((1, 0))
+    Y = np.zeros((1, 0))
+    W = np.zeros((1, 2))
+    solves = 0
+    t0 = time.time()
+    lbs = keep = None
+    for d in range(1, m + 1):
+        B = X.shape[0]
+        Xc = np.concatenate([np.repeat(X, len(rows), axis=0), np.tile(rows[:, 0], B)[:, None]], axis=1)
+        Yc = np.concatenate([np.repeat(Y, len(rows), axis=0), np.tile(rows[:, 1], B)[:, None]], axis=1)
+        Wc = np.repeat(W, len(rows), axis=0)
+        lbs = np.empty(Xc.shape[0])
+        Us = np.empty((Xc.shape[0], 2))
+        for s in range(0, Xc.shape[0], 200_000):
+            lbs[s:s + 200_000], Us[s:s + 200_000] = bound(Xc[s:s + 200_000], Yc[s:s + 200_000], r, Nn, K0, Rtot, Wc[s:s + 200_000])
+        solves += Xc.shape[0]
+        keep = lbs <= thr
+        if d == m:                                        # a complete matrix needs both tumour columns non-zero
+            keep &= (Xc.sum(axis=1) > 0) & (Yc.sum(axis=1) > 0)
+        X, Y, W = Xc[keep], Yc[keep], Us[keep]
+        if Ct is not None:
+            truth_alive = bool(((X == Ct[:d, 0]).all(axis=1) & (Y == Ct[:d, 1]).all(axis=1)).any())
+            assert truth_alive, "the bound cut the incumbent: not a lower bound"
+        if verbose:
+            print("depth %2d: %9d prefixes bounded, %8d survive (%.3g of the (K+1)^(2d) = %.3g at this depth); %.1f s"
+                  % (d, Xc.shape[0], X.shape[0], X.shape[0] / float(K + 1) ** (2 * d), float(K + 1) ** (2 * d), time.time() - t0))
+        if X.shape[0] > cap:
+            if verbose:
+                print("more than %d live prefixes: stopping (the instance does not determine the matrix well enough at this depth)" % cap)
+            return X, Y, lbs[keep], solves, False
+    return X, Y, lbs[keep], solves, True
+
+
 def main():
     m = int(sys.argv[1]) if len(sys.argv) > 1 else 20
     K = int(sys.argv[2]) if len(sys.argv) > 2 else 4
@@ -138,37 +176,10 @@ def main():
     thr = best + WINDOW
     print("instance: m=%d K=%d seed=%d  Rtot=%.3g  planted NLL %.4f  threshold %.4f  space (K+1)^(2m) = %.3g matrices"
           % (m, K, seed, Rtot, inc[0], thr, float(K + 1) ** (2 * m)))
-    rows = np.array([(x, y) for x in range(K + 1) for y in range(K + 1)], dtype=float)
-    X = np.zeros((1, 0))
-    Y = np.zeros((1, 0))
-    W = np.zeros((1, 2))
-    solves = 0
-    t0 = time.time()
-    for d in range(1, m + 1):
-        B = X.shape[0]
-        Xc = np.concatenate([np.repeat(X, len(rows), axis=0), np.tile(rows[:, 0], B)[:, None]], axis=1)
-        Yc = np.concatenate([np.repeat(Y, len(rows), axis=0), np.tile(rows[:, 1], B)[:, None]], axis=1)
-        Wc = np.repeat(W, len(rows), axis=0)
-        lbs = np.empty(Xc.shape[0])
-        Us = np.empty((Xc.shape[0], 2))
-        for s in range(0, Xc.shape[0], 200_000):
-            lbs[s:s + 200_000], Us[s:s + 200_000] = bound(Xc[s:s + 200_000], Yc[s:s + 200_000], r, Nn, K0, Rtot, Wc[s:s + 200_000])
-        solves += Xc.shape[0]
-        keep = lbs <= thr
-        if d == m:                                        # a complete matrix needs both tumour columns non-zero
-            keep &= (Xc.sum(axis=1) > 0) & (Yc.sum(axis=1) > 0)
-        X, Y, W = Xc[keep], Yc[keep], Us[keep]
-        truth_alive = bool(((X == Ct[:d, 0]).all(axis=1) & (Y == Ct[:d, 1]).all(axis=1)).any())
-        print("depth %2d: %9d prefixes bounded, %8d survive (%.3g of the (K+1)^(2d) = %.3g at this depth); planted prefix alive: %s; %.1f s"
-              % (d, Xc.shape[0], X.shape[0], X.shape[0] / float(K + 1) ** (2 * d), float(K + 1) ** (2 * d), truth_alive, time.time() - t0))
-        assert truth_alive, "the bound cut the planted matrix: not a lower bound"
-        if X.shape[0] > cap:
-            print("more than %d live prefixes: stopping (the instance does not determine the matrix well enough at this depth)" % cap)
-            break
-    else:
-        best = lbs[keep]
+    X, Y, vals, solves, done = walk(r, Nn, K0, Rtot, K, thr, cap, Ct, True)
+    if done:
         print("complete matrices within the window: %d (best %.4f, planted %.4f); %d bound solves in total against %.3g matrices"
-              % (X.shape[0], best.min(), inc[0], solves, float(K + 1) ** (2 * m)))
+              % (X.shape[0], vals.min(), inc[0], solves, float(K + 1) ** (2 * m)))
 
 
 if __name__ == "__main__":
