@@ -21,7 +21,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench
 
-WINDOW = 0.5          # theta_amd.search.COLLECT_WINDOW
+WINDOW = float(os.environ.get("BNB_WINDOW", "0.5"))          # theta_amd.search.COLLECT_WINDOW (the reference's own tie margin is 1e-3: Misc.py:36)
 
 
 def synth_with_truth(seed, m, k):
