@@ -112,6 +112,19 @@ def _cpu_init(r, rN):
     _W["orc"], _W["r"], _W["rN"] = orc, r, rN
 
 
+def _cpu_init_quiet(r, rN):
+    """Worker start: one BLAS / OpenMP thread per process (P processes x T library threads on P cores is what round 4's
+    3 %-efficient figure measured), then the oracle."""
+    for k in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS", "NUMEXPR_NUM_THREADS"):
+        os.environ[k] = "1"
+    try:
+        import threadpoolctl
+        _W["tp"] = threadpoolctl.threadpool_limits(1)
+    except Exception:
+        pass
+    _cpu_init(r, rN)
+
+
 def _cpu_work(args):
     cands, budget = args
     orc = _W["orc"]
@@ -125,31 +138,123 @@ def _cpu_work(args):
     return done, time.time() - t0
 
 
+def host_cores():
+    """Cores this process may really use: the affinity mask, capped by the cgroup's CPU quota (os.cpu_count() reports the
+    machine's, which a container seldom owns)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]           # cgroup v2
+        if q != "max":
+            quota = float(q) / float(per)
+    except Exception:
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())     # cgroup v1
+            per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except Exception:
+            pass
+    if quota is not None:
+        n = max(1, min(n, int(quota + 0.5)))
+    return n, (os.cpu_count() or 1), quota
+
+
+def _restatement_lib():
+    """The build's own C++ restatement of the reference's per-candidate procedure (theta_amd/csrc/n3_refbfgs.hpp: hybrj, the BFGS
+    decision, M3's hybrd, L3's sums -- the function theta_solve_batch runs on the device), compiled for the host
+    (tools/hybrj_check.cpp; __graft_entry__.build() leaves it in build_ab/)."""
+    import ctypes as C
+    so = os.path.join(ROOT, "build_ab", "libhybrj_check.so")
+    if not os.path.exists(so):
+        os.makedirs(os.path.dirname(so), exist_ok=True)
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-fno-builtin-pow", "-shared", "-fPIC",
+                               os.path.join(ROOT, "tools", "hybrj_check.cpp"), "-o", so])
+    lib = C.CDLL(so)
+    dp, u8p = C.POINTER(C.c_double), C.POINTER(C.c_uint8)
+    lib.hybrj_check_table.argtypes = [C.c_int, C.c_int, C.c_int, dp, dp, u8p, u8p, dp, dp]
+    return lib
+
+
+def cpu_restatement(cands, r, rN, cores, budget_s=6.0):
+    """"the build's own CPU restatement, timed single-thread and all-cores".  ctypes releases the GIL, so the
+    all-core leg is `cores` threads of one process, each on its own chunk of the sample."""
+    import ctypes as C
+    from concurrent.futures import ThreadPoolExecutor
+    lib = _restatement_lib()
+    dp, u8p = C.POINTER(C.c_double), C.POINTER(C.c_uint8)
+    rr = np.ascontiguousarray(r, np.float64)
+    rn = np.ascontiguousarray(rN, np.float64)
+    cands = np.ascontiguousarray(cands, np.uint8)
+    m = cands.shape[1]
+
+    def run(chunk, budget):
+        """chunk through the procedure in blocks of 256 until the budget is spent; returns (candidates done, seconds)"""
+        ok, mu, nll = np.zeros(256, np.uint8), np.zeros((256, 3)), np.zeros(256)
+        done, t0 = 0, time.time()
+        while time.time() - t0 < budget:
+            blk = chunk[(done % max(len(chunk) - 255, 1)):][:256]
+            lib.hybrj_check_table(len(blk), m, TAU, rr.ctypes.data_as(dp), rn.ctypes.data_as(dp), blk.ctypes.data_as(u8p),
+                                  ok.ctypes.data_as(u8p), mu.ctypes.data_as(dp), nll.ctypes.data_as(dp))
+            done += len(blk)
+        return done, time.time() - t0
+
+    d1, t1 = run(cands, budget_s / 3)
+    chunks = [np.ascontiguousarray(cands[i::cores]) for i in range(cores)]
+    chunks = [c for c in chunks if len(c)] or [cands]
+    with ThreadPoolExecutor(len(chunks)) as ex:
+        res = list(ex.map(lambda c: run(c, budget_s * 2 / 3), chunks))
+    dn, tn = sum(x[0] for x in res), max(x[1] for x in res)
+    one, allc = d1 / t1, dn / tn
+    return {"value": allc, "unit": "candidates/s", "threads": len(chunks), "per_thread": one, "parallel_efficiency": allc / (len(chunks) * one),
+            "what": "n3_ref_solve (theta_amd/csrc/n3_refbfgs.hpp, the per-candidate procedure of theta_solve_batch) compiled for the host "
+                    "with g++ -O2 (tools/hybrj_check.cpp): %d candidates in %.1f s on one thread, %d in %.1f s on %d threads" % (d1, t1, dn, tn, len(chunks))}
+
+
 def cpu_baseline(cands, r, rN, budget_s=15.0):
-    """Oracle (port of the reference's Optimizer.solve) on the host cores, bounded by `budget_s` seconds."""
-    cores = os.cpu_count() or 1
+    """Oracle (port of the reference's Optimizer.solve) on the host cores, bounded by `budget_s` seconds: one process (the
+    reference's default NUM_PROCESSES = 1), then one process per usable core (its multiprocessing path, RunTHetA.py:96-105)."""
+    cores, machine, quota = host_cores()
+    for k in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS", "NUMEXPR_NUM_THREADS"):
+        os.environ[k] = "1"                            # (inherited by the workers; the libraries already loaded here are limited below)
+    try:
+        import threadpoolctl
+        limiter = threadpoolctl.threadpool_limits(1)
+    except Exception:
+        limiter = None
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import theta_oracle as orc
-    # single process first (the reference's default NUM_PROCESSES=1)
     t0 = time.time()
     n1 = 0
-    for c in cands[: max(8, len(cands) // (4 * cores))]:
+    for c in cands:
         orc.solve_n3(orc.rows_to_matrix_n3([tuple(x) for x in c], TAU), r, rN)
         n1 += 1
         if time.time() - t0 > budget_s / 3:
             break
     per_process = n1 / (time.time() - t0)
-    # all cores (the reference's multiprocessing path: NUM_PROCESSES = cores)
     chunks = [cands[i::cores] for i in range(cores)]
     ctx = mp.get_context("fork")
-    with ctx.Pool(cores, initializer=_cpu_init, initargs=(r, rN)) as pool:
+    with ctx.Pool(cores, initializer=_cpu_init_quiet, initargs=(r, rN)) as pool:
         res = pool.map(_cpu_work, [(ch, budget_s * 2 / 3) for ch in chunks], chunksize=1)
+    if limiter is not None:
+        limiter.restore_original_limits()
     done = sum(x[0] for x in res)
     dt = max(x[1] for x in res)          # workers run concurrently; process start-up is not charged to the CPU
-    return {"value": done / dt, "unit": "candidates/s", "cores": cores, "kind": "port",
-            "per_process": per_process,
-            "sample": "%d candidates drawn from the GPU run's own rank ranges, oracle.solve_n3 (scipy fsolve/BFGS), "
-                      "%d concurrent processes, %.1f s of solving each" % (done, cores, dt)}
+    eff = (done / dt) / (cores * per_process)
+    sample = ("%d candidates drawn from the GPU run's own rank ranges, oracle.solve_n3 (scipy fsolve/BFGS): one process %.0f/s "
+              "(%d candidates), then %d concurrent single-threaded processes -- one per usable core (affinity %d, cgroup quota %s, "
+              "machine %d) -- %.1f s of solving each: parallel efficiency %.2f" %
+              (done, per_process, n1, cores, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else cores,
+               "none" if quota is None else "%.1f" % quota, machine, dt, eff))
+    if eff < 0.5:
+        sample += " (below 0.5: the cores are shared with other tenants of the host, or SMT siblings count as cores)"
+    out = {"value": done / dt, "unit": "candidates/s", "cores": cores, "kind": "port", "per_process": per_process,
+           "parallel_efficiency": eff, "sample": sample}
+    try:
+        out["restatement"] = cpu_restatement(cands, r, rN, cores)
+    except Exception as ex:
+        out["restatement"] = {"error": str(ex)[:200]}
+    return out
 
 
 # ---- the legs --------------------------------------------------------------------------------------
@@ -581,7 +686,7 @@ def main():
         out["setup_ms_per_step"] = leg.setup_ms / max(leg.launches, 1)
         if world == 1 and not args.no_cpu_baseline:
             # bounded sample of the SAME candidates, materialised by the enumerate kernel, solved by the oracle on the host
-            n_s = 96 * (os.cpu_count() or 1)
+            n_s = min(1 << 16, 4096 * host_cores()[0])       # (more than the oracle gets through in its budget: the workers stop on time)
             per = max(1, n_s // nsteps)
             cands = np.concatenate([problem.enumerate(b + 12345, per) for b in begins])
             out["cpu_baseline"] = cpu_baseline(cands, r, rN, args.cpu_seconds)

@@ -226,6 +226,32 @@ int theta_search_values(theta_problem *p, const uint64_t rank_begin[2], uint64_t
                         double *mu, theta_search_stats *stats);
 
 /*
+ * WITNESS of the n=3 search kernel (no reference counterpart): what the sieve kernel leaves a candidate at.  Runs the search of
+ * theta_search over [rank_begin, rank_end) under the instance's current options (hint included) with the WITNESS build of the
+ * sieve kernel -- the same source compiled with one more macro, every decision made by the same code -- and returns one record
+ * for every 2^every_log2-th candidate of the range: record i belongs to rank rank_begin + (i << every_log2).  With
+ * "n3_no_dismiss" (the bench's full-solve legs) every regular candidate has a record with status 1, 2, 5 or 6; this is what
+ * "passed through the full solve" (Optimizer.solve per candidate, Optimizer.py:128-165; RunTHetA.py:191-208) comes to per
+ * candidate, checked against the oracle by tests/test_gpu_round5.py.  The finalists are theta_search's to return; `stats` are
+ * the call's counters (equal to theta_search's on the same range and options).  out[cap]; n_out = records written (or needed,
+ * with THETA_ERR_CAPACITY).  n = 3 on the sieve path only (m >= 8): THETA_ERR_ARG otherwise.
+ */
+typedef struct theta_witness {
+    double mu[3];          /* mixture at the point the candidate was LEFT at (after its last Newton step; nu -> mu as Optimizer.M3) */
+    double nll;            /* NLL the kernel computed at the candidate's LAST EVALUATION (single-precision logarithms)             */
+    float l2_last;         /* squared Newton decrement / sum r found by that evaluation                                            */
+    float l2_first;        /* ... by the shared first evaluation (NaN: the candidate had no usable shared point)                   */
+    uint16_t evaluations;  /* evaluations of value + gradient + Hessian the candidate took, the shared one included              */
+    uint16_t status;       /* 0 no record (rank-deficient candidate; prefix finished by its bound; slice redone by the fused kernel),
+                              1 converged at the shared evaluation, 2 converged in the queue, 3 / 4 finished by the lower bound
+                              (search mode) at the shared evaluation / in the queue, 5 contender (handed to the finish kernel),
+                              6 handed to the finish kernel unsolved (ill-conditioned, or 40 evaluations)                          */
+    uint32_t reserved;
+} theta_witness;
+int theta_search_witness(theta_problem *p, const uint64_t rank_begin[2], const uint64_t rank_end[2], double window,
+                         int every_log2, uint64_t cap, theta_witness *out, uint64_t *n_out, theta_search_stats *stats);
+
+/*
  * Materialised generator: writes candidates rank_begin .. rank_begin+count-1 in the reference's
  * order.  Replaces repeated Enumerator.generate_next_C() (Enumerator.py:74-87, 119-152, 172-214).
  * out[count * m * (n-1)].

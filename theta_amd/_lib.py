@@ -61,11 +61,15 @@ class SearchStats(C.Structure):
         return d
 
 
+# theta_witness (include/theta_hip.h): what the n=3 sieve kernel left a sampled candidate at
+WITNESS_DTYPE = np.dtype([("mu", np.float64, 3), ("nll", np.float64), ("l2_last", np.float32), ("l2_first", np.float32),
+                          ("evaluations", np.uint16), ("status", np.uint16), ("reserved", np.uint32)])
+
 _lib = None
 
 # every symbol include/theta_hip.h declares
 EXPORTS = ["theta_create", "theta_device_count", "theta_destroy", "theta_last_error", "theta_device_info", "theta_problem_create",
-           "theta_problem_destroy", "theta_problem_count", "theta_search", "theta_search_values", "theta_enumerate", "theta_enumerate_device",
+           "theta_problem_destroy", "theta_problem_count", "theta_search", "theta_search_values", "theta_search_witness", "theta_enumerate", "theta_enumerate_device",
            "theta_solve_batch", "theta_score_batch", "theta_score_masked", "theta_search_suspects", "theta_boundary_min", "theta_problem_hint",
            "theta_search_degenerate", "theta_problem_set_option", "theta_synchronize",
            "theta_score_batch_rows", "theta_device_alloc", "theta_device_free", "theta_device_copy", "theta_solve_batch_device",
@@ -98,6 +102,7 @@ def load():
     lib.theta_problem_count.argtypes = [vp, u64p]
     lib.theta_search.argtypes = [vp, u64p, u64p, C.c_double, i32, dp, dp, u64p, u8p, C.POINTER(i32), C.POINTER(SearchStats)]
     lib.theta_search_values.argtypes = [vp, u64p, C.c_uint64, dp, dp, C.POINTER(SearchStats)]
+    lib.theta_search_witness.argtypes = [vp, u64p, u64p, C.c_double, i32, C.c_uint64, vp, u64p, C.POINTER(SearchStats)]
     lib.theta_enumerate.argtypes = [vp, u64p, C.c_uint64, u8p]
     lib.theta_enumerate_device.argtypes = [vp, u64p, C.c_uint64, vp, dp]
     lib.theta_search_suspects.argtypes = [vp, i32, u64p, dp, u8p, C.POINTER(i32)]
@@ -657,6 +662,21 @@ class Problem:
         _check(load().theta_search_values(self._h, _u128(begin), int(count), _p(nll, C.c_double), _p(mu, C.c_double),
                                           C.byref(st)))
         return nll, mu, st.as_dict()
+
+    def witness(self, begin, end, every_log2=0, window=0.0):
+        """theta_search_witness: one record (WITNESS_DTYPE) per 2^every_log2-th candidate of [begin, end) -- what the n=3 sieve
+        kernel left it at under the instance's current options -- and the call's statistics.  Record i <-> rank begin + (i << every_log2)."""
+        need = ((int(end) - int(begin)) + (1 << every_log2) - 1) >> every_log2
+        out = np.zeros(max(need, 1), WITNESS_DTYPE)
+        running = getattr(self, "_hint", float("inf"))           # (a hint is one-shot, like in search())
+        self._hint = float("inf")
+        if running < float("inf"):
+            _check(load().theta_problem_hint(self._h, running))
+        n_out = C.c_uint64(0)
+        st = SearchStats()
+        _check(load().theta_search_witness(self._h, _u128(begin), _u128(end), float(window), int(every_log2), int(need),
+                                           out.ctypes.data_as(C.c_void_p), C.byref(n_out), C.byref(st)))
+        return out[:n_out.value], st.as_dict()
 
     def enumerate(self, begin, count):
         """Candidates begin .. begin+count-1 in the reference's order, as uint8 (count, m[, 2])."""

@@ -14,11 +14,14 @@ LIB = os.path.join(HERE, "libtheta_hip.so")
 ARCH = "gfx950"
 
 # batch.hip restates the reference's per-interval arithmetic: no fused multiply-add contraction.
+# (source, extra flags[, object name]): n3_sieve.hip is compiled twice -- the second object is the WITNESS build of the very same
+# kernel source (per-candidate records of what the sieve left a candidate at, theta_search_witness)
 UNITS = [
     ("n2.hip", []),
     ("n3.hip", []),
     ("n3_enum.hip", []),
     ("n3_sieve.hip", []),
+    ("n3_sieve.hip", ["-DSV_WITNESS=1", "-Wno-pass-failed"], "n3_sieve_witness.o"),
     ("batch.hip", ["-ffp-contract=off"]),
     ("api.hip", []),
     ("comm.hip", []),
@@ -47,16 +50,17 @@ def build(force=False, verbose=True):
     objs = []
     cc = hipcc()
     procs = []
-    for src, extra in UNITS:
+    for unit in UNITS:
+        src, extra = unit[0], unit[1]
         s = os.path.join(CSRC, src)
-        o = os.path.join(CSRC, src.replace(".hip", ".o"))
+        o = os.path.join(CSRC, unit[2] if len(unit) > 2 else src.replace(".hip", ".o"))
         objs.append(o)
         if not force and _newer(o, [s] + headers):
             continue
         cmd = [cc] + COMMON + extra + os.environ.get("THETA_HIPCC_FLAGS", "").split() + ["-c", s, "-o", o]   # (tuning builds: -DSV_OCC=4 ...)
         if verbose:
             print(" ".join(cmd), flush=True)
-        procs.append((src, subprocess.Popen(cmd)))
+        procs.append((os.path.basename(o), subprocess.Popen(cmd)))
     for src, p in procs:
         if p.wait() != 0:
             raise RuntimeError("hipcc failed on " + src)

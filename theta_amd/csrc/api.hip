@@ -584,9 +584,16 @@ static void fold_stats(const unsigned char *slots, SearchCounters &c) {
     }
 }
 
+// (a witnessed call, theta_search_witness: device buffer of the records, sampling shift, capacity)
+struct WitnessReq {
+    SvWitness *d;
+    unsigned shift;
+    unsigned long long cap;
+};
+
 static int run_search(theta_problem *p, u128 b, u128 e, double window, double *dump_nll, double *dump_mu,
                       SearchCounters &hc, std::vector<TieRecord> &recs, double &kernel_ms, double &setup_ms,
-                      unsigned long long &dropped_out) {
+                      unsigned long long &dropped_out, const WitnessReq *wit = nullptr) {
     theta_ctx *ctx = p->ctx;
     hipStream_t st = ctx->stream;
     SearchArgs A;
@@ -603,6 +610,11 @@ static int run_search(theta_problem *p, u128 b, u128 e, double window, double *d
     A.window = window;
     A.dump_nll = dump_nll;
     A.dump_mu = dump_mu;
+    A.wit = wit ? wit->d : nullptr;
+    A.wit_begin_lo = (unsigned long long)b;
+    A.wit_begin_hi = (unsigned long long)(b >> 64);
+    A.wit_cap = wit ? wit->cap : 0;
+    A.wit_shift = wit ? wit->shift : 0;
     memset(&hc, 0, sizeof(hc));
     hc.best_bits = order_bits(p->hint);   // a caller-supplied upper bound keeps tie and suspect lists short
     p->hint = INFINITY;
@@ -934,6 +946,60 @@ static const double FLOPS_PER_TERM_SIEVE_SHARED = 26.0;
 static const double FLOPS_PER_SIEVE_CHILD = 90.0;
 static const double FLOPS_PER_FINAL_TERM_N2 = 5.0;  // fma, log, fma
 
+// the per-call statistics of theta_search / theta_search_witness from the device counters
+static void fill_search_stats(theta_problem *p, const SearchCounters &hc, unsigned long long dropped, double kms, double sms,
+                              theta_search_stats *stats) {
+    const double best = order_unbits(hc.best_bits);
+    stats->evaluated = hc.evaluated;
+    stats->accepted = hc.accepted;
+    stats->degenerate = hc.degenerate;
+    stats->iterations = hc.iterations;
+    stats->terms = hc.terms;
+    stats->dismissed = hc.dismissed;
+    stats->list_overflow = dropped;
+    const double per = (p->n == 2) ? FLOPS_PER_TERM_ITER_N2 : FLOPS_PER_TERM_ITER_N3;
+    const double fin = (p->n == 2) ? FLOPS_PER_FINAL_TERM_N2 : FLOPS_PER_FINAL_TERM_N3;
+    auto count_flops = [&](const SearchCounters &k, uint64_t &f64, uint64_t &f32) {
+        if (p->n == 2) {
+            f64 = (uint64_t)(per * (double)k.terms + fin * (double)k.final_terms);
+            f32 = 0;
+        } else if (p->last_sieve64) {
+            // n=3, the sieve in FP64 (n3_force_f64): every evaluation on doubles.  Per term of a full evaluation (sv_step, round 4's
+            // form with rho = sqrt R): 2 sub, 2 fma (q), 2 fma (the Newton-Raphson step of the reciprocal), 2 fma (value and the
+            // error bound of its logarithms), 3 mul (rho / q, alpha, beta), 2 fma (gradient), 3 fma (Hessian) = 27; per term of a
+            // node's shared sums (sv_parent): 2 fma (q), 2 fma (reciprocal), 2 fma (L, LA), 3 mul, 3 fma (T), 6 fma (W) = 33.  The
+            // single-precision operations per term are the seed of the reciprocal and the logarithm of the screened value
+            // (v_rcp_f32, v_log_f32 of the same (float) q).  A child: its own term, the restriction to its slice, the 2x2 solve,
+            // decrement, value and bound (FLOPS_PER_SIEVE_CHILD) + the Newton-Raphson steps of its three reciprocals and the
+            // error-bound terms (+ 16), two logarithms and two reciprocal seeds in single precision.
+            const double full = (double)(k.terms - k.terms64);
+            f64 = (uint64_t)(per * ((double)k.terms64 + (double)k.finish_iterations * (double)p->m) +
+                             27.0 * full + 33.0 * (double)k.sieve_pterms +
+                             (FLOPS_PER_SIEVE_CHILD + 16.0) * (double)k.sieve_children + fin * (double)k.final_terms);
+            f32 = (uint64_t)(2.0 * full + 2.0 * (double)k.sieve_pterms + 4.0 * (double)k.sieve_children);
+        } else {   // n=3: FP64 iterations (dump, ill-conditioned candidates, the finish kernel: m terms each) + the packed-f32
+                   // coarse pass and screen
+            f64 = (uint64_t)(per * ((double)k.terms64 + (double)k.finish_iterations * (double)p->m));
+            f32 = (uint64_t)(FLOPS_PER_TERM_ITER_N3_F32 * (double)(k.terms - k.terms64) + fin * (double)k.final_terms +
+                             FLOPS_PER_TERM_SIEVE_SHARED * (double)k.sieve_pterms + FLOPS_PER_SIEVE_CHILD * (double)k.sieve_children);
+        }
+    };
+    count_flops(hc, stats->flops, stats->flops_f32);
+    count_flops(p->last_redo, stats->redo_flops, stats->redo_flops_f32);    // slices redone (contender list full): apart
+    stats->redo_kernel_ms = p->last_redo_ms;
+    stats->kernel_launches = p->last_launches;
+    stats->pruned = hc.sieve_pruned;
+    stats->survivors = hc.sieve_survivors;
+    stats->fallback_candidates = p->last_fallback;
+    stats->best_nll = best;
+    stats->rejected_bound = order_unbits(hc.rej_bits);
+    stats->rejected_rank[0] = hc.rej_rank_lo;
+    stats->rejected_rank[1] = hc.rej_rank_hi;
+    stats->kernel_ms = kms;
+    stats->setup_ms = sms;
+    for (int i = 0; i < 8; i++) stats->phase_cycles[i] = hc.prof[i];
+}
+
 extern "C" int theta_search(theta_problem *p, const uint64_t rank_begin[2], const uint64_t rank_end[2], double window,
                             int cap, double *nll, double *mu, uint64_t *rank, uint8_t *C, int *n_out,
                             theta_search_stats *stats) {
@@ -966,56 +1032,7 @@ extern "C" int theta_search(theta_problem *p, const uint64_t rank_begin[2], cons
     rc = run_search(p, b, e, window, nullptr, nullptr, hc, recs, kms, sms, dropped);
     if (rc) return rc;
     double best = order_unbits(hc.best_bits);
-    if (stats) {
-        stats->evaluated = hc.evaluated;
-        stats->accepted = hc.accepted;
-        stats->degenerate = hc.degenerate;
-        stats->iterations = hc.iterations;
-        stats->terms = hc.terms;
-        stats->dismissed = hc.dismissed;
-        stats->list_overflow = dropped;
-        const double per = (p->n == 2) ? FLOPS_PER_TERM_ITER_N2 : FLOPS_PER_TERM_ITER_N3;
-        const double fin = (p->n == 2) ? FLOPS_PER_FINAL_TERM_N2 : FLOPS_PER_FINAL_TERM_N3;
-        auto count_flops = [&](const SearchCounters &k, uint64_t &f64, uint64_t &f32) {
-            if (p->n == 2) {
-                f64 = (uint64_t)(per * (double)k.terms + fin * (double)k.final_terms);
-                f32 = 0;
-            } else if (p->last_sieve64) {
-                // n=3, the sieve in FP64 (n3_force_f64): every evaluation on doubles.  Per term of a full evaluation (sv_step, round 4's
-                // form with rho = sqrt R): 2 sub, 2 fma (q), 2 fma (the Newton-Raphson step of the reciprocal), 2 fma (value and the
-                // error bound of its logarithms), 3 mul (rho / q, alpha, beta), 2 fma (gradient), 3 fma (Hessian) = 27; per term of a
-                // node's shared sums (sv_parent): 2 fma (q), 2 fma (reciprocal), 2 fma (L, LA), 3 mul, 3 fma (T), 6 fma (W) = 33.  The
-                // single-precision operations per term are the seed of the reciprocal and the logarithm of the screened value
-                // (v_rcp_f32, v_log_f32 of the same (float) q).  A child: its own term, the restriction to its slice, the 2x2 solve,
-                // decrement, value and bound (FLOPS_PER_SIEVE_CHILD) + the Newton-Raphson steps of its three reciprocals and the
-                // error-bound terms (+ 16), two logarithms and two reciprocal seeds in single precision.
-                const double full = (double)(k.terms - k.terms64);
-                f64 = (uint64_t)(per * ((double)k.terms64 + (double)k.finish_iterations * (double)p->m) +
-                                 27.0 * full + 33.0 * (double)k.sieve_pterms +
-                                 (FLOPS_PER_SIEVE_CHILD + 16.0) * (double)k.sieve_children + fin * (double)k.final_terms);
-                f32 = (uint64_t)(2.0 * full + 2.0 * (double)k.sieve_pterms + 4.0 * (double)k.sieve_children);
-            } else {   // n=3: FP64 iterations (dump, ill-conditioned candidates, the finish kernel: m terms each) + the packed-f32
-                       // coarse pass and screen
-                f64 = (uint64_t)(per * ((double)k.terms64 + (double)k.finish_iterations * (double)p->m));
-                f32 = (uint64_t)(FLOPS_PER_TERM_ITER_N3_F32 * (double)(k.terms - k.terms64) + fin * (double)k.final_terms +
-                                 FLOPS_PER_TERM_SIEVE_SHARED * (double)k.sieve_pterms + FLOPS_PER_SIEVE_CHILD * (double)k.sieve_children);
-            }
-        };
-        count_flops(hc, stats->flops, stats->flops_f32);
-        count_flops(p->last_redo, stats->redo_flops, stats->redo_flops_f32);    // slices redone (contender list full): apart
-        stats->redo_kernel_ms = p->last_redo_ms;
-        stats->kernel_launches = p->last_launches;
-        stats->pruned = hc.sieve_pruned;
-        stats->survivors = hc.sieve_survivors;
-        stats->fallback_candidates = p->last_fallback;
-        stats->best_nll = best;
-        stats->rejected_bound = order_unbits(hc.rej_bits);
-        stats->rejected_rank[0] = hc.rej_rank_lo;
-        stats->rejected_rank[1] = hc.rej_rank_hi;
-        stats->kernel_ms = kms;
-        stats->setup_ms = sms;
-        for (int i = 0; i < 8; i++) stats->phase_cycles[i] = hc.prof[i];
-    }
+    if (stats) fill_search_stats(p, hc, dropped, kms, sms, stats);
     // keep what lies within the window of the final minimum, in rank order
     std::vector<TieRecord> keep;
     for (const TieRecord &t : recs)
@@ -1113,6 +1130,49 @@ extern "C" int theta_search_values(theta_problem *p, const uint64_t rank_begin[2
         stats->kernel_ms = kms;
         stats->setup_ms = sms;
     }
+    return THETA_OK;
+}
+
+// What the n=3 sieve kernel LEAVES a candidate at (no reference counterpart; the evidence behind the bench's unit of work, "a
+// candidate passed through the full solve": RunTHetA.py:191-208 per candidate, Optimizer.py:128-165).
+extern "C" int theta_search_witness(theta_problem *p, const uint64_t rank_begin[2], const uint64_t rank_end[2], double window,
+                                    int every_log2, uint64_t cap, theta_witness *out, uint64_t *n_out, theta_search_stats *stats) {
+    static_assert(sizeof(theta_witness) == sizeof(SvWitness), "theta_witness is the kernel's record");
+    u128 b, e;
+    int rc = check_range(p, rank_begin, rank_end, b, e);
+    if (rc) return rc;
+    if (!n_out || (cap > 0 && !out) || every_log2 < 0 || every_log2 > 40 || !(window >= 0.0)) {
+        theta_set_error("theta_search_witness: bad argument");
+        return THETA_ERR_ARG;
+    }
+    if (p->n != 3 || !p->opt_sieve || n3_sieve_levels(p->n3) == 0) {
+        theta_set_error("theta_search_witness: the n=3 sieve path only (n = 3, m >= 8, n3_sieve = 1)");
+        return THETA_ERR_ARG;
+    }
+    HIP_ENTER(p->ctx->device);
+    if (stats) memset(stats, 0, sizeof(*stats));
+    const u128 span = e - b;
+    const uint64_t need = (uint64_t)((span + (((u128)1 << every_log2) - 1)) >> every_log2);
+    *n_out = need;
+    if (need > cap) {
+        theta_set_error("theta_search_witness: %llu records but capacity is %llu", (unsigned long long)need, (unsigned long long)cap);
+        return THETA_ERR_CAPACITY;
+    }
+    if (need == 0) return THETA_OK;
+    hipStream_t st = p->ctx->stream;
+    DevBuf d_w;
+    if ((rc = d_w.alloc((size_t)need * sizeof(SvWitness)))) return rc;
+    HIP_TRY(hipMemsetAsync(d_w.p, 0, (size_t)need * sizeof(SvWitness), st));
+    WitnessReq wr{(SvWitness *)d_w.p, (unsigned)every_log2, need};
+    SearchCounters hc;
+    std::vector<TieRecord> recs;
+    double kms, sms;
+    unsigned long long dropped = 0;
+    rc = run_search(p, b, e, window, nullptr, nullptr, hc, recs, kms, sms, dropped, &wr);
+    if (rc) return rc;
+    if (stats) fill_search_stats(p, hc, dropped, kms, sms, stats);
+    HIP_TRY(hipMemcpyAsync(out, d_w.p, (size_t)need * sizeof(SvWitness), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
     return THETA_OK;
 }
 

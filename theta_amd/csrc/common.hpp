@@ -115,6 +115,26 @@ struct SearchArgs {
     double window;
     double *dump_nll;  // optional per-candidate dump (the reference's --GET_VALUES), else null
     double *dump_mu;
+    // n=3 sieve, WITNESS build of the kernel only (n3_sieve.hip compiled with -DSV_WITNESS, theta_search_witness): what the sieve
+    // LEFT every 2^wit_shift-th candidate of the call at.  Record i belongs to rank wit_begin + (i << wit_shift).  null otherwise.
+    struct SvWitness *wit;
+    unsigned long long wit_begin_lo, wit_begin_hi;
+    unsigned long long wit_cap;
+    unsigned wit_shift;
+};
+
+// One sampled candidate of a witnessed sieve run (theta_hip.h: theta_witness, same layout).
+struct SvWitness {
+    double mu[3];          // the mixture at the point the candidate was LEFT at (after its last Newton step), through M3's closed form
+    double nll;            // K0 - ln2 (sum R log2 q) as the kernel computed it at its LAST EVALUATION (single-precision logarithms)
+    float l2_last;         // lambda^2 / sum r found by that evaluation
+    float l2_first;        // ... by the shared first evaluation (NaN: the candidate had no usable shared point)
+    unsigned short evaluations;   // evaluations of the candidate: the shared one + its own
+    unsigned short status;        // 0 none (degenerate candidate, prefix finished by its bound, fused-kernel fallback), 1 converged at the
+                                  // shared evaluation, 2 converged in the queue, 3 / 4 finished by the lower bound (search mode) at the
+                                  // shared evaluation / in the queue, 5 contender (listed for the finish kernel), 6 handed to the finish
+                                  // kernel unsolved (ill-conditioned or 40 evaluations)
+    unsigned reserved;
 };
 
 // ---------------------------------------------------------------------------------------------

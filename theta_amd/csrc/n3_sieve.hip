@@ -199,6 +199,9 @@ struct SvWave {
                                                         // rows are decoded by the lane that takes the entry (sv_drain), not by the
                                                         // whole wave at every push
     F qU1[SV_QCAP], qU2[SV_QCAP];                       // ... the iterate it continues from
+#ifdef SV_WITNESS
+    float qL0[SV_QCAP];                                 // (witness build) lambda^2 / sum r of the record's shared first evaluation
+#endif
 };
 // The ratio-rank table in LDS covers differences up to 7 copies: all there is up to K = 7, and nearly all beyond (the compact
 // alphabet of a K > 7 search holds a few far-apart rows); the rest is read from the full table in HBM, which api.hip keeps behind
@@ -280,7 +283,45 @@ struct SvCtx {
 #endif
     unsigned n_par, n_prefix;        // likelihood terms of the shared sums (phase P), prefixes walked
     unsigned n_child, n_dit;         // shared first evaluations (children) / full evaluations (queue)
+#ifdef SV_WITNESS
+    unsigned long long wrel;         // rank of the task's first candidate - first rank of the call (a call walks < 2^56)
+    double tau;
+#endif
 };
+
+// ---- the witness build (-DSV_WITNESS: a second object of this very source, build.py; theta_search_witness) -----------------------
+// What did the sieve LEAVE a candidate at?  Every 2^wit_shift-th candidate of the call writes a record when it is finished --
+// converged, dismissed by its bound, or handed to the finish kernel: the mixture at the point it was left at (after the last
+// Newton step), the value and the decrement its last evaluation found, the decrement of the shared first evaluation, and how
+// many evaluations it took.  Every decision is made by the code the timed kernel runs (the records are written beside it; the
+// tests compare the two builds' counters on the same ranges), so the records are what the bench's unit of work comes to.
+#ifdef SV_WITNESS
+template <int ML, class F, int NS>
+__device__ __forceinline__ void sv_witness(const SvCtx<ML, F, NS> &c, unsigned off, unsigned status, unsigned evals, float l2_first, F l2_last,
+                                           F val2, F s1, F s2, F u1, F u2) {
+    if (!c.A.wit) return;
+    const unsigned long long rel = c.wrel + off;
+    if (rel & ((1ull << c.A.wit_shift) - 1ull)) return;
+    const unsigned long long idx = rel >> c.A.wit_shift;
+    if (idx >= c.A.wit_cap) return;
+    SvWitness *w = c.A.wit + idx;
+    // nu = (1 - s1 u1 - s2 u2, s1 u1, s2 u2); nu -> mu is M3's closed form (Optimizer.py:318-330), as the finish kernel applies it
+    const double d1 = (double)u1, d2 = (double)u2;
+    const double u0 = (1.0 - (double)s1 * d1 - (double)s2 * d2) / c.tau, us = u0 + d1 + d2;
+    w->mu[0] = u0 / us;
+    w->mu[1] = d1 / us;
+    w->mu[2] = d2 / us;
+    w->nll = c.K0 - 0.6931471805599453 * (double)val2;
+    w->l2_last = (float)l2_last;
+    w->l2_first = l2_first;
+    w->evaluations = (unsigned short)evals;
+    w->status = (unsigned short)status;
+    w->reserved = 0u;
+}
+#define SV_WIT(...) __VA_ARGS__
+#else
+#define SV_WIT(...)
+#endif
 
 
 // One evaluation of value, gradient and Hessian at (u1, u2) over the group tile and the record's rows, two terms at a time
@@ -471,8 +512,9 @@ __device__ __forceinline__ void sv_drain(SvCtx<ML, F, NS> &c) {
 #pragma unroll
     for (int j = 0; j < ML / 2; j++) rw[j] = 0u;
     F u1 = F(0), u2 = F(0), s1 = F(1), s2 = F(1);
-    unsigned qy = 0u, code = 0u;                    // the entry's words: last row's slot | offset in the task << 8, path slots
-    int iters = 0;
+    unsigned qy = 0u, code = 0u;                    // the entry's words: last row's slot | offset in the task << 8 | evaluations so far << 24, path slots
+    int iters = 0;                                  // evaluations of the record so far, the shared one included (kept across put-backs)
+    SV_WIT(float l0 = 0.0f;)
     while (true) {
         const unsigned long long idle = ballot64(!live);
         if (next < c.qcount && idle) {
@@ -483,13 +525,14 @@ __device__ __forceinline__ void sv_drain(SvCtx<ML, F, NS> &c) {
                 u1 = c.W->qU1[idx];
                 u2 = c.W->qU2[idx];
                 code = qr.x;
-                qy = qr.y;
+                qy = qr.y & 0xffffffu;
+                SV_WIT(l0 = c.W->qL0[idx];)
                 sv_sums<ML, F, NS>(c, rw, s1, s2);
                 if (!(u1 == u1)) {                    // (no usable first point: from the simplex centre)
                     u1 = F(1.0 / 3.0) * sv_rcp(s1);
                     u2 = F(1.0 / 3.0) * sv_rcp(s2);
                 }
-                iters = 0;
+                iters = (int)(qr.y >> 24);
                 live = true;
             }
             const int room = c.qcount - next, nid = __builtin_popcountll(idle);
@@ -502,9 +545,10 @@ __device__ __forceinline__ void sv_drain(SvCtx<ML, F, NS> &c) {
                 wave_lds_sync();                         // (every entry has been read)
                 if (live) {
                     const int pos = mbcnt(lm);
-                    c.W->qRec[pos] = make_uint2(code, qy);
+                    c.W->qRec[pos] = make_uint2(code, qy | ((unsigned)iters << 24));
                     c.W->qU1[pos] = u1;
                     c.W->qU2[pos] = u2;
+                    SV_WIT(c.W->qL0[pos] = l0;)
                 }
                 left = __builtin_popcountll(lm);
                 wave_lds_sync();
@@ -520,8 +564,10 @@ __device__ __forceinline__ void sv_drain(SvCtx<ML, F, NS> &c) {
             F val2 = F(0), l2 = F(0), la = F(0);
             const int st = sv_step<ML, F, NS>(c, rw, s1, s2, u1, u2, val2, l2, la);
             iters++;
+            SV_WIT(unsigned wst = 0u;)
             if (st == 3 || iters >= 40) {
                 surv = fin = true;               // ill-conditioned / stuck: the finish kernel solves it in FP64
+                SV_WIT(wst = 6u;)
             } else if (st != 2) {
                 // the bound finishes a candidate as soon as it applies (not in the full-solve mode, which iterates every
                 // candidate to the coarse tolerance first); a converged candidate it does not finish is a contender -- once
@@ -530,10 +576,13 @@ __device__ __forceinline__ void sv_drain(SvCtx<ML, F, NS> &c) {
                 const bool beyond = sv_beyond<ML, F, NS>(c, val2, l2, sv_sqrt(l2), la);
                 if (beyond && (!c.no_dismiss || st == 1)) {
                     fin = true;
+                    SV_WIT(wst = st == 1 ? 2u : 4u;)
                 } else if (st == 1 && l2 < c.fine_l2) {
                     surv = fin = true;
+                    SV_WIT(wst = 5u;)
                 }
             }
+            SV_WIT(if (fin) sv_witness<ML, F, NS>(c, qy >> 8, wst, (unsigned)iters, l0, l2, val2, s1, s2, u1, u2);)
         }
         if (surv) sv_survivor<ML, F, NS>(c, rw, qy >> 8);
         if (fin) {
@@ -689,6 +738,11 @@ struct SvChild {
     F n1, n2;                  // its stepped mixture, and the stepped point itself (u1, u2; w0 = 1 - n1 - n2): the lane's chain point, valid if `chain`
     F c1, c2;
     bool chain;
+#ifdef SV_WITNESS
+    bool wdone;                // finished by this evaluation (converged and valued / dismissed by the bound)
+    bool wconv;
+    F wl2, wval2, ws1, ws2;
+#endif
 };
 
 // Phase C arithmetic for the child k of the round, BRANCH-FREE: every lane computes everything (on harmless inputs where the
@@ -762,6 +816,14 @@ __device__ __forceinline__ void sv_child_eval(const SvCtx<ML, F, NS> &c, int lo,
     o.push = o.act && o.regular && !done && !o.surv;
     o.qu1 = good ? v1 : F(__builtin_nanf(""));
     o.qu2 = v2;
+#ifdef SV_WITNESS
+    o.wdone = done;
+    o.wconv = conv;
+    o.wl2 = l2;
+    o.wval2 = val2;
+    o.ws1 = s1;
+    o.ws2 = s2;
+#endif
 }
 
 #ifndef SV_CPL
@@ -812,6 +874,10 @@ __device__ __forceinline__ void sv_children(SvCtx<ML, F, NS> &c, int total) {
                     c.wn2 = (F)(a2 * inv);
                 }
             }
+#ifdef SV_WITNESS
+            if (o.wdone || o.surv)
+                sv_witness<ML, F, NS>(c, o.off, o.surv ? 5u : (o.wconv ? 1u : 3u), 1u, (float)o.wl2, o.wl2, o.wval2, o.ws1, o.ws2, o.c1, o.c2);
+#endif
             const unsigned long long pm = ballot64(o.push), sm = ballot64(o.surv);
             if (sm) {                                     // (rare: a contender straight from the shared evaluation)
                 if (o.surv) {
@@ -824,9 +890,10 @@ __device__ __forceinline__ void sv_children(SvCtx<ML, F, NS> &c, int total) {
                 if (c.qcount + __builtin_popcountll(pm) > SV_QCAP) sv_drain<ML, F, NS, false>(c);
                 if (o.push) {
                     const int pos = c.qcount + mbcnt(pm);
-                    c.W->qRec[pos] = make_uint2(o.code, o.slot | (o.off << 8));
+                    c.W->qRec[pos] = make_uint2(o.code, o.slot | (o.off << 8) | (o.ev ? 1u << 24 : 0u));   // (top byte: evaluations so far)
                     c.W->qU1[pos] = o.qu1;
                     c.W->qU2[pos] = o.qu2;
+                    SV_WIT(c.W->qL0[pos] = o.qu1 == o.qu1 ? (float)o.wl2 : __builtin_nanf("");)
                 }
                 c.qcount += __builtin_popcountll(pm);
                 wave_lds_sync();
@@ -1108,6 +1175,9 @@ __device__ __noinline__ int sv_next_task(unsigned *ctr) {
     return __builtin_amdgcn_readfirstlane(t);
 }
 
+#ifdef SV_WITNESS
+#define n3_sieve_kernel n3_sieve_witness_kernel
+#endif
 template <int ML, class F, int NS>
 __global__ __launch_bounds__(64 * SV_WAVES, sizeof(F) == 4 ? SV_OCC : SV_OCC64) void n3_sieve_kernel(N3Dev Pg, SearchArgs A, const N3Task *tasks, const unsigned *stbuf,
                                                                           int ntasks, SvSurvivor *surv, unsigned surv_cap,
@@ -1178,6 +1248,10 @@ __global__ __launch_bounds__(64 * SV_WAVES, sizeof(F) == 4 ? SV_OCC : SV_OCC64) 
     c.qcount = 0;
     c.n_par = c.n_prefix = 0;
     c.n_child = c.n_dit = 0;
+#ifdef SV_WITNESS
+    c.wrel = (unsigned long long)(c.base - (((u128)A.wit_begin_hi << 64) | A.wit_begin_lo));
+    c.tau = (double)Pg.tau;
+#endif
 #ifdef SV_PROF
     for (int i = 0; i < 7; i++) c.pt[i] = 0;
     const unsigned long long pw0 = __builtin_amdgcn_s_memtime();
@@ -1378,6 +1452,7 @@ __global__ __launch_bounds__(64 * SV_WAVES, sizeof(F) == 4 ? SV_OCC : SV_OCC64) 
     }
 }
 
+#ifndef SV_WITNESS      // (the witness object holds the sieve kernel and its launcher only)
 // ------------------------------------------------------------------------------------------------------------------
 // finish: one lane per contender
 // ------------------------------------------------------------------------------------------------------------------
@@ -1564,8 +1639,19 @@ int n3_sieve_levels(const N3Dev &P) {
     return want;
 }
 
+#endif   // !SV_WITNESS
+
+#ifdef SV_WITNESS
+#define n3_launch_sieve n3_launch_sieve_witness
+#endif
 void n3_launch_sieve(const N3Dev &P, const SearchArgs &A, const N3Task *tasks, const unsigned *stbuf, int ntasks, SvSurvivor *surv,
                      unsigned surv_cap, unsigned *surv_count, hipStream_t st) {
+#ifndef SV_WITNESS
+    if (A.wit) {           // a witnessed call (theta_search_witness): the same source compiled with -DSV_WITNESS
+        n3_launch_sieve_witness(P, A, tasks, stbuf, ntasks, surv, surv_cap, surv_count, st);
+        return;
+    }
+#endif
     // as many blocks as the chip holds at once (or as there are tasks for): the waves fetch their tasks themselves
     static int n_cu = 0;
     if (!n_cu) {
@@ -1590,6 +1676,7 @@ void n3_launch_sieve(const N3Dev &P, const SearchArgs &A, const N3Task *tasks, c
 #undef SV_LAUNCH
 }
 
+#ifndef SV_WITNESS
 void n3_launch_finish(const N3Dev &P, const SearchArgs &A, const SvSurvivor *surv, unsigned surv_cap, const unsigned *surv_count,
                       unsigned *accepted_count, hipStream_t st) {
     // (a grid for a full list: blocks beyond the count leave at once)
@@ -1597,3 +1684,4 @@ void n3_launch_finish(const N3Dev &P, const SearchArgs &A, const SvSurvivor *sur
     (void)hipFuncSetAttribute((const void *)n3_finish_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(n3_finish_kernel, dim3((surv_cap + 255) / 256), dim3(256), lds, st, P, A, surv, surv_cap, surv_count, accepted_count);
 }
+#endif   // !SV_WITNESS

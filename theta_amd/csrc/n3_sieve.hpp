@@ -16,5 +16,8 @@ struct SvSurvivor {
 int n3_sieve_levels(const N3Dev &P);
 void n3_launch_sieve(const N3Dev &P, const SearchArgs &A, const N3Task *tasks, const unsigned *stbuf, int ntasks, SvSurvivor *surv,
                      unsigned surv_cap, unsigned *surv_count, hipStream_t st);
+// the same kernel with the per-candidate records of theta_search_witness (n3_sieve.hip compiled with -DSV_WITNESS; A.wit set)
+void n3_launch_sieve_witness(const N3Dev &P, const SearchArgs &A, const N3Task *tasks, const unsigned *stbuf, int ntasks, SvSurvivor *surv,
+                             unsigned surv_cap, unsigned *surv_count, hipStream_t st);
 void n3_launch_finish(const N3Dev &P, const SearchArgs &A, const SvSurvivor *surv, unsigned surv_cap, const unsigned *surv_count,
                       unsigned *accepted_count, hipStream_t st);
