@@ -21,6 +21,7 @@ from theta_amd import _lib
 
 STATS0 = {"evaluated": 0, "accepted": 0, "degenerate": 0, "iterations": 0, "terms": 0, "list_overflow": 0, "flops": 0.0,
           "flops_f32": 0.0, "dismissed": 0, "survivors": 0, "fallback_candidates": 0, "kernel_ms": 0.0, "setup_ms": 0.0,
+          "redo_flops": 0, "redo_flops_f32": 0, "redo_kernel_ms": 0.0, "kernel_launches": 0, "pruned": 0,
           "phase_cycles": [0] * 6, "best_nll": float("inf"), "rejected_bound": float("inf"), "rejected_rank": 0}
 
 

@@ -350,6 +350,7 @@ def test_do_optimization_caps_the_gpus_by_the_size_of_the_space(monkeypatch):
     assert S.gpus_for(8, count=1 << 100) == 8
     monkeypatch.setenv("THETA_NGPU", "2")
     assert S.gpus_for(8, count=10) == 2
+    assert S.gpus_for(1, count=1 << 100) == 1                       # (a variable left over from a test never shards a max_processes = 1 call)
 
 
 def test_a_failing_worker_is_reported_by_do_optimization(monkeypatch):
@@ -375,3 +376,52 @@ def test_a_failing_worker_is_reported_by_do_optimization(monkeypatch):
     with pytest.raises(_lib.ThetaError):
         S.do_optimization(inst["n"], inst["m"], inst["k"], inst["tau"], list(inst["lb"]), list(inst["ub"]), inst["r"], inst["rN"],
                           inst["mx"], inst["order"], 2)
+
+
+def test_bench_with_eight_ranks_over_the_host_transport():
+    """bench.py launched as the driver launches it for N = 8 -- eight processes with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* --
+    on this GPU-less machine: every rank on the CPU stand-in device (THETA_BENCH_INIT, a space the oracle can walk through
+    THETA_BENCH_SHAPE), the collectives over the library's host transport.  The line must carry n_gpus = 8, the candidates of all
+    eight ranks in `value`, the transport and the ranks' devices at its top level; and with the transport left at its default
+    (RCCL) the run must FAIL rather than downgrade silently (round-4 verdict, Next 5)."""
+    import json
+    import subprocess
+    import sys as _sys
+    port = _free_port()
+    here = os.path.dirname(os.path.abspath(__file__))
+    base = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE="8", THETA_BENCH_TRANSPORT="host",
+                THETA_BENCH_INIT="standin_device:worker_context", THETA_BENCH_SHAPE="6,2", THETA_COMM_TIMEOUT_S="120",
+                PYTHONPATH=os.pathsep.join([here, os.path.join(ROOT, "oracle"), ROOT, os.environ.get("PYTHONPATH", "")]))
+    args = [_sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1", "--batch", "12",
+            "--leg", "full_solve_f64_tight_certified"]
+    procs = [subprocess.Popen(args, env=dict(base, RANK=str(rk), LOCAL_RANK=str(rk)), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+             for rk in range(8)]
+    try:
+        outs = [p.communicate(timeout=500) for p in procs]
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    assert all(p.returncode == 0 for p in procs), [o[1][-600:] for o in outs]
+    assert all(o[0].strip() == "" for o in outs[1:])                       # only rank 0 prints
+    line = json.loads(outs[0][0].strip().splitlines()[-1])
+    assert line["n_gpus"] == 8 and line["steps"] == 2 and line["scaling"] == "weak"
+    assert line["transport"] == "host" and line["rccl_version"] == 0 and len(line["rank_devices"]) == 8
+    assert line["candidates_per_rank"] == [24.0] * 8                        # 2 timed steps x 12 candidates on every rank
+    assert abs(line["value"] * line["ms_per_step"] * 1e-3 * 2 - 8 * 24) < 1e-6 * 8 * 24      # value = all ranks' candidates / the slowest rank's time
+    assert line["comm"]["world"] == 8 and line["comm"]["collectives"] >= 4
+    # the default transport (RCCL) cannot be set up here (no GPU, no context): the run must end non-zero, not downgrade
+    port2 = _free_port()
+    base2 = dict(base, MASTER_PORT=str(port2), WORLD_SIZE="2")
+    base2.pop("THETA_BENCH_TRANSPORT")
+    procs = [subprocess.Popen(args[:2] + ["--gpus", "2", "--steps", "1", "--warmup", "0", "--batch", "8"], env=dict(base2, RANK=str(rk), LOCAL_RANK=str(rk)),
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for rk in range(2)]
+    try:
+        outs = [p.communicate(timeout=300) for p in procs]
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    assert all(p.returncode != 0 for p in procs), [o[1][-300:] for o in outs]
+    assert all("not falling back" in o[1] for o in outs), [o[1][-300:] for o in outs]
+    assert all(o[0].strip() == "" for o in outs)                              # and no JSON line

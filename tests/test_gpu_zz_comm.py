@@ -133,8 +133,10 @@ def test_bench_with_two_ranks_on_one_gpu():
     assert line["n_gpus"] == 2 and line["steps"] == 3 and line["scaling"] == "weak" and line["dtype"] == "f64"
     assert line["comm"]["world"] == 2 and line["comm"]["collectives"] >= 4      # hint all-reduce, exchange (all-reduces + all-gather), barriers
     assert line["cpu_baseline"] is None and line["roofline"]["traffic"] is None
-    leg = line["roofline"]["legs"]["full_solve_f64"]
+    assert line["config"]["leg"] == "full_solve_f64_tight_certified"          # the default headline: the tolerance-meeting leg
+    leg = line["roofline"]["legs"][line["config"]["leg"]]
     assert leg["launches"] == 3 and leg["candidates_per_launch"] == 1 << 29
+    assert line["transport"] == "host" and line["rank_devices"] == [0, 0] and len(line["candidates_per_rank"]) == 2
     one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--batch", str(1 << 29),
                           "--no-cpu-baseline", "--no-legs", "--no-traffic", "--no-extras"], capture_output=True, text=True, timeout=600)
     assert one.returncode == 0, one.stderr[-800:]
@@ -149,13 +151,15 @@ def test_bench_falls_back_to_the_host_transport_when_rccl_refuses_the_communicat
     Two ranks on this box's ONE GPU with the RCCL transport (the driver's default): rank 0's ncclUniqueId travels over the
     library's bootstrap, both ranks enter ncclCommInitRank, RCCL's own bootstrap gathers the peers -- and refuses ("Duplicate GPU
     detected", ncclInvalidUsage; the furthest an RCCL communicator of world > 1 gets on a one-GPU box).  bench.py then carries its
-    two collectives over the host transport and says so on the line (`comm.transport`) instead of failing the run.
+    two collectives over the host transport and says so on the line (`transport`, top level) -- but only where the caller allows
+    it (THETA_BENCH_TRANSPORT=rccl_or_host).  Under the driver's launcher (the variable unset) the same situation is an ERROR: both
+    ranks exit non-zero and no JSON line is printed, so a scaling record can never be green on a downgraded transport.
     """
     import json
     import subprocess
     port = _free_port()
-    base = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE="2", THETA_BENCH_NDEV="1", THETA_COMM_TIMEOUT_S="120")
-    base.pop("THETA_BENCH_TRANSPORT", None)
+    base = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE="2", THETA_BENCH_NDEV="1", THETA_COMM_TIMEOUT_S="120",
+                THETA_BENCH_TRANSPORT="rccl_or_host")
     args = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", str(1 << 28)]
     procs = [subprocess.Popen(args, env=dict(base, RANK=str(rk), LOCAL_RANK=str(rk)), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
              for rk in range(2)]
@@ -169,6 +173,21 @@ def test_bench_falls_back_to_the_host_transport_when_rccl_refuses_the_communicat
     assert all("falling back to the host transport" in o[1] for o in outs), [o[1][-400:] for o in outs]
     line = json.loads(outs[0][0].strip().splitlines()[-1])       # (RCCL's version banner, also on stdout, comes before: bench.py flushes it first)
     assert line["n_gpus"] == 2 and line["comm"]["world"] == 2 and line["comm"]["transport"] == "host" and line["comm"]["collectives"] >= 4
+    assert line["transport"] == "host"
+    # the driver's launcher: no THETA_BENCH_TRANSPORT -- RCCL or nothing
+    strict = dict(base, MASTER_PORT=str(_free_port()))
+    strict.pop("THETA_BENCH_TRANSPORT")
+    procs = [subprocess.Popen(args, env=dict(strict, RANK=str(rk), LOCAL_RANK=str(rk)), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+             for rk in range(2)]
+    try:
+        outs = [p.communicate(timeout=500) for p in procs]
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    assert all(p.returncode != 0 for p in procs), [o[1][-400:] for o in outs]
+    assert all("not falling back" in o[1] for o in outs), [o[1][-400:] for o in outs]
+    assert not any(l.startswith("{") for o in outs for l in o[0].splitlines())
 
 
 def test_do_optimization_with_max_processes_shards_over_worker_processes(ctx, monkeypatch):

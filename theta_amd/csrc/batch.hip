@@ -913,7 +913,8 @@ void batch_launch_score_masked(int n, int m, int tau, int B, int S, const unsign
                !getenv("THETA_SCORE_NO_SLICES")) {
         // records beyond 256 bytes: 256 candidates per block, slice by slice (score_plain_sliced_kernel)
         int maxw = SPS_MAXW;
-        if (const char *e = getenv("THETA_SPS_MAXW")) maxw = atoi(e) >= 4 && atoi(e) <= 64 ? atoi(e) & ~3 : maxw;
+        // (>= 8: with 4-word slices a chunk is one candidate and the kernel's division-by-multiplication constant wraps -- round-4 advice)
+        if (const char *e = getenv("THETA_SPS_MAXW")) maxw = atoi(e) >= 8 && atoi(e) <= 64 ? atoi(e) & ~3 : maxw;
         const size_t lds = (((size_t)256 * (sps_slice_words((m * (n - 1)) >> 2, maxw) | 1) + 3) & ~(size_t)3) * 4 + SMX_TAB_BYTES;
         const unsigned blocks = (unsigned)(((long long)B + 255) / 256);
         if (n == 2) hipLaunchKernelGGL((score_plain_sliced_kernel<1>), dim3(blocks), dim3(256), lds, st, m, tau, B, C, w, r, mu, rsum_host, wmin_host, wmax_host, nll, maxw);

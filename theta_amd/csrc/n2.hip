@@ -791,9 +791,21 @@ void n2_launch_search(const N2Dev &P, const SearchArgs &A, unsigned long long be
     unsigned long long threads = sample_stride ? (n + sample_stride - 1) / sample_stride : (n + per_thread - 1) / per_thread;
     unsigned blocks = (unsigned)((threads + 255) / 256);
     const bool dump = A.dump_nll != nullptr;
-    const bool quick = !dump && P.quick != 0;       // the dismissing search: an instantiation of its own (QUICK), with its per-wave queues,
+    bool quick = !dump && P.quick != 0;             // the dismissing search: an instantiation of its own (QUICK), with its per-wave queues,
     const int kvt = P.kv <= 8 ? 8 : 16;             // chain points and interleaved prefix sums in LDS behind the common tables
-    const size_t sm = quick ? n2_queue_offset(P.m, kvt) + (size_t)4 * N2_QCAP * (4 + (kvt + 2) / 2) * 4 : n2_smem_bytes(P);
+    size_t sm = quick ? n2_queue_offset(P.m, kvt) + (size_t)4 * N2_QCAP * (4 + (kvt + 2) / 2) * 4 : n2_smem_bytes(P);
+    if (quick && sm > 48 * 1024) {
+        // The dismissing kernel's LDS grows with m and the copy numbers (161 m + ... bytes: beyond 64 KB for m > ~218 at KV = 8, m > ~78
+        // at KV = 16).  gfx950 grants 160 KB per workgroup; a device that refuses the size runs the kernel that solves every candidate
+        // (37 KB at m = 256) instead -- same finalists -- rather than failing the launch (round-4 advice).
+        const hipError_t e = P.kv <= 8 ? hipFuncSetAttribute((const void *)n2_search_kernel<8, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm)
+                                       : hipFuncSetAttribute((const void *)n2_search_kernel<16, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            quick = false;
+            sm = n2_smem_bytes(P);
+        }
+    }
 #define N2_LAUNCH(KVV, DD, QQ)                                                                                                                    \
     do {                                                                                                                                          \
         if (sm > 48 * 1024) (void)hipFuncSetAttribute((const void *)n2_search_kernel<KVV, DD, QQ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); \

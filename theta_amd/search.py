@@ -185,7 +185,7 @@ def degenerate_records(problem, ctx, r, rN, max_normal, report=None):
     if not len(ranks):
         return []
     ok, mu, nll, vals = ctx.solve_batch(3, problem.tau, r, rN, Cs, max_normal, want_vals=True)
-    out = [{"rank": ranks[i], "c": Cs[i], "mu": mu[i].copy(), "nll": float(nll[i]), "vals": vals[i].copy()}
+    out = [{"rank": ranks[i], "c": Cs[i], "mu": mu[i].copy(), "nll": float(nll[i]), "vals": vals[i].copy(), "kind": "degenerate"}
            for i in range(len(ranks)) if ok[i]]
     if report is not None:
         report.degenerate = len(out)
@@ -212,7 +212,7 @@ def fallback_records(problem, ctx, r, rN, max_normal, recs, window=COLLECT_WINDO
     out = []
     for i in range(len(ranks)):
         if ok[i] and nll[i] <= lowest + window and ranks[i] not in have:
-            out.append({"rank": ranks[i], "c": Cs[i], "mu": mu[i].copy(), "nll": float(nll[i]), "vals": vals[i].copy()})
+            out.append({"rank": ranks[i], "c": Cs[i], "mu": mu[i].copy(), "nll": float(nll[i]), "vals": vals[i].copy(), "kind": "fallback"})
     if report is not None:
         report.fallback_finalists = len(out)
     return out
@@ -370,16 +370,36 @@ def _search_local(n, m, tau, lower_bounds, upper_bounds, r, rN, max_normal, shar
         first = replay_records(recs, False, None, q1)
         tail = max(begin, first[0]["rank"]) if first and first[0]["rank"] >= 0 else begin
         if first and end - tail <= NAN_SWEEP_MAX:
+            # (the second search replaces the problem's side lists and the report's per-call figures with the TAIL's: what the first
+            # one found before `tail` is kept and merged back below, so that the certificate -- the boundary minimum over every
+            # suspect of the range -- and the report still speak of the whole range: round-4 advice)
+            sus0, sus_dropped0, window0 = problem.last_suspects, problem.suspects_dropped, getattr(report, "window", COLLECT_WINDOW)
+            counts0 = {k: getattr(report, k, 0) for k in ("fallback_finalists", "degenerate", "dropped_not_ok", "suspect_reruns")} if report is not None else {}
+            head = [t for t in recs if t["rank"] < tail]
             problem.set_option("n3_nan_sweep", 1)
             known = [t["nll"] for t in first if t["nll"] == t["nll"]]
             if known:
                 problem.hint(min(known))
             more, _st = gather(tail, end)
             problem.set_option("n3_nan_sweep", 0)
-            recs = [t for t in recs if t["rank"] < tail] + more
+            recs = head + more
+            keep = [i for i, rk in enumerate(sus0[0]) if rk < tail]
+            if keep:
+                rk1, lb1, C1 = problem.last_suspects
+                C0 = np.asarray(sus0[2])[keep]
+                problem.last_suspects = ([sus0[0][i] for i in keep] + list(rk1), np.concatenate([np.asarray(sus0[1])[keep], np.asarray(lb1, float)]),
+                                         np.concatenate([C0, np.asarray(C1, np.uint8).reshape((-1,) + C0.shape[1:])]))
+            problem.suspects_dropped = sus_dropped0 + problem.suspects_dropped
             if report is not None:
                 report.nan_sweep = True
                 report.nan_sweep_from = tail
+                report.window = min(window0, report.window)
+                # per-call figures: the head's share of the first search + the tail's (the first search's tail share is superseded)
+                head_ranks = set(t["rank"] for t in head)
+                report.fallback_finalists = sum(1 for t in head if t.get("kind") == "fallback") + report.fallback_finalists
+                report.degenerate = sum(1 for t in head if t.get("kind") == "degenerate") + report.degenerate
+                report.dropped_not_ok = counts0.get("dropped_not_ok", 0) + report.dropped_not_ok
+                report.suspect_reruns = counts0.get("suspect_reruns", 0) + report.suspect_reruns
     return problem, ctx, recs, stats
 
 
@@ -453,8 +473,8 @@ def gpus_for(max_processes, count=None):
     THETA_NGPU overrides everything (several ranks then share a GPU if there are fewer: tests on a one-GPU box).
     """
     env = os.environ.get("THETA_NGPU")
-    if env:
-        return max(1, int(env))
+    if env and int(max_processes) > 1:        # (honoured only where the caller asked for a parallel run: a variable left over from a test
+        return max(1, int(env))               # never shards a max_processes = 1 call -- round-4 advice)
     g = max(1, min(int(max_processes), _lib.device_count()))
     if count is not None:
         g = max(1, min(g, int(count // MIN_CANDIDATES_PER_GPU)))
@@ -535,8 +555,9 @@ def do_optimization(n, m, k, tau, lower_bounds, upper_bounds, r, rN, max_normal,
     global last_report
     ctx = _lib.default_context() if WORKER_INIT is None else None
     if WORKER_INIT is not None:
+        import importlib
         mod, fn = WORKER_INIT.split(":")
-        ctx = getattr(__import__(mod), fn)(0)
+        ctx = getattr(importlib.import_module(mod), fn)(0)
     try:
         problem = _make_problem(ctx, n, m, tau, lower_bounds, upper_bounds, r, rN, max_normal)
     except _lib.NoCandidates:

@@ -29,8 +29,9 @@ def main(argv):
         if job.get("init"):
             # (tests: a module-level function "module:function" that returns the context to use -- a stand-in device on
             # machines without a GPU, tests/standin_device.py; never set by the package itself)
+            import importlib
             mod, fn = job["init"].split(":")
-            ctx = getattr(__import__(mod), fn)(job["rank"])
+            ctx = getattr(importlib.import_module(mod), fn)(job["rank"])
         else:
             ctx = _lib.Context(job["device"])
         comm = _lib.Comm(ctx if job["transport"] != "host" or hasattr(ctx, "_h") else None, rank=job["rank"], world=job["world"],
@@ -56,4 +57,5 @@ def main(argv):
 if __name__ == "__main__":
     devnull = open(os.devnull, "w")
     sys.stdout = devnull
+    os.dup2(devnull.fileno(), 1)          # (the C stdout as well: RCCL prints a version banner there, and fd 1 is the parent's)
     sys.exit(main(sys.argv))
