@@ -141,6 +141,16 @@ int theta_search(theta_problem *p, const uint64_t rank_begin[2], const uint64_t 
                  int *n_out, theta_search_stats *stats);
 
 /*
+ * theta_search over SEVERAL rank ranges in one pass of the kernels: ranges[nranges * 4] = {begin lo, begin hi, count lo, count hi} in
+ * rank order, disjoint (what theta_bnb returns), at most 2^31 candidates together.  Same outputs, same side lists
+ * (theta_search_suspects / _degenerate), same hint and options as theta_search -- the candidates of the ranges are searched as if
+ * they were one range with the gaps cut out.  n = 3 on the sieve path (m >= 8).  A slice of the call whose contender list
+ * overflows ends the call with THETA_ERR_CAPACITY and *n_out = 0: search the ranges one by one then (theta_search has a ladder).
+ */
+int theta_search_ranges(theta_problem *p, int nranges, const uint64_t *ranges, double window, int cap, double *nll, double *mu,
+                        uint64_t *rank, uint8_t *C, int *n_out, theta_search_stats *stats);
+
+/*
  * "Suspects" of the last theta_search call on this problem (n=3): candidates the search REJECTED (likelihood
  * optimum outside the simplex) whose lower bound lies within `window` of the minimum.  The reference does report
  * such a candidate -- at nu = (1/3,1/3,1/3), where its BFGS fallback stalls (Optimizer.py:150-160, 255-265) -- so
@@ -250,6 +260,69 @@ typedef struct theta_witness {
 } theta_witness;
 int theta_search_witness(theta_problem *p, const uint64_t rank_begin[2], const uint64_t rank_end[2], double window,
                          int every_log2, uint64_t cap, theta_witness *out, uint64_t *n_out, theta_search_stats *stats);
+
+/*
+ * BRANCH AND BOUND above the search's prefix (n = 3): which rank ranges of the WHOLE space can hold a matrix whose NLL optimum is
+ * at most `threshold`?  Replaces -- for spaces no linear walk finishes (BASELINE configs 3 and 4: 4e27 / 2.6e38 matrices) -- the
+ * enumeration loop of do_optimization_single (RunTHetA.py:173-220) down to the rows the fused search takes over.  The tree
+ * Enumerator._generate_next_C_3 walks (Enumerator.py:172-214: same rows, same edges, same ratio windows, sizes from the counting
+ * table) is expanded level by level; a node whose relaxed likelihood -- its fixed rows alone, every later interval fitted perfectly
+ * -- has a lower bound beyond `threshold` is dropped with everything below it; the survivors of the emit depth (m - 6 rows) come
+ * back as rank ranges [begin, begin + count), in rank order, adjacent ones joined: theta_search on them (with `threshold` minus the
+ * window as hint) finds every matrix of the space whose optimum is within the window.  `threshold` must be ATTAINABLE + window: an
+ * NLL some matrix of the space is known to reach (e.g. the minimum over the ranges of a beam run) plus the collection window.
+ *   beam             0: exact (above).  W > 0: a dive instead -- nothing is pruned, every level keeps its W smallest bounds; the
+ *                    ranges (at most W) are where to look for an attainable NLL first
+ *   follow_collinear 1: nodes whose rows so far lie on one line are kept whatever their bound -- their subtrees hold the
+ *                    rank-deficient matrices, which the reference values off their optimum (theta_search_degenerate lists them when the
+ *                    ranges are searched).  Feasible for small spaces only: the collinear prefixes of 44 rows are ~1e21 at m = 50
+ *   max_nodes        0: no limit; else the walk stops with THETA_ERR_OVERFLOW once that many nodes were expanded (stats are filled)
+ *   ranges[cap * 4]  {begin lo, begin hi, count lo, count hi}; n_out = ranges written (or needed, with THETA_ERR_CAPACITY)
+ * What it cannot give: matrices the reference reports BELOW their own optimum or with a NaN likelihood (rank-deficient ones
+ * without follow_collinear; about one full-rank matrix in a million, Misc.py:44-46) -- they are not in the ranges unless their
+ * optimum is.
+ */
+typedef struct theta_bnb_stats {
+    uint64_t nodes_expanded;     /* frontier nodes expanded (one wave each)                                  */
+    uint64_t children_bounded;   /* children given a bound (one Newton solve of <= 64 terms each)            */
+    uint64_t newton_iterations;  /* ... iterations of those solves                                           */
+    uint64_t children_pruned;    /* ... dropped: bound beyond the threshold                                  */
+    uint64_t children_collinear; /* children kept because their rows are collinear (follow_collinear)        */
+    uint64_t children_unbounded; /* children kept without an established bound (ill-conditioned, not converged) */
+    uint64_t ranges_raw, ranges; /* surviving nodes emitted / rank ranges after joining adjacent ones        */
+    uint64_t launches, max_frontier, chunk;
+    double leaves;               /* matrices in the ranges                                                   */
+    double kernel_ms, wall_ms;
+    int emit_depth, complete;
+    uint64_t frontier[THETA_MAX_M + 1];   /* nodes kept at depth d                                           */
+} theta_bnb_stats;
+int theta_bnb(theta_problem *p, double threshold, uint64_t beam, int follow_collinear, uint64_t max_nodes, uint64_t cap,
+              uint64_t *ranges, uint64_t *n_out, theta_bnb_stats *stats);
+
+/*
+ * BRANCH AND BOUND OVER THE MIXTURE SPACE (n = 3): every matrix -- of the rows, bounds and edge rule of Enumerator._generate_next_C_3
+ * (Enumerator.py:172-214, 248-298) -- whose NLL can be at most `threshold` for SOME mixture mu >= 0, found without walking the
+ * ranks: BASELINE configs 3 and 4 (4e27 / 2.6e38 matrices) in a fraction of a second.  Replaces, for such spaces, the loop of
+ * do_optimization_single (RunTHetA.py:173-220).  With v = s mu the reference's objective (Optimizer.py:236-244) is
+ * sum_i [rN_i c_i.v - r_i ln(rN_i c_i.v)] + const at its best scale s: separable over the intervals for a fixed v, so a box of
+ * mixtures bounds EVERY matrix at once from m x (rows) one-dimensional problems.  An octree over v keeps the boxes within the
+ * threshold; the leaves (width leaf_rel, relative to the mean read-depth ratio per copy: 2e-4 is a good value) are walked depth
+ * first over the intervals with the threshold as budget.  C[cap * m * 2] receives the matrices ({a, b} per interval) in the
+ * reference's enumeration order, without duplicates: a SUPERSET of the matrices within the threshold (the symmetry rule and the
+ * ratio window are the caller's to check; theta_solve_batch gives each one's value as the reference reports it).  The threshold
+ * must be an attainable NLL + the collection window.  THETA_ERR_CAPACITY: too many boxes / matrices within it.
+ * What it cannot give: matrices the reference reports below their own optimum or with a NaN likelihood (rank-deficient ones;
+ * about one full-rank matrix in a million).
+ */
+typedef struct theta_mix_stats {
+    uint64_t boxes_tested, levels, max_boxes, leaves, listed, matrices;
+    double kernel_ms, wall_ms;
+    double min_bound;            /* propose = 1: the smallest bound among the leaves (a lower bound of the space's minimum up to the leaf size) */
+} theta_mix_stats;
+/* propose = 1: no list -- for the `cap` leaves of smallest bound, the matrix that fits the leaf's centre best (per interval the row
+ * minimising its term): candidates for a better attainable NLL, to be valued by the caller before a finer call with a lower threshold. */
+int theta_mix_search(theta_problem *p, double threshold, double leaf_rel, int propose, uint64_t cap, uint8_t *C, uint64_t *n_out,
+                     theta_mix_stats *stats);
 
 /*
  * Materialised generator: writes candidates rank_begin .. rank_begin+count-1 in the reference's

@@ -1,0 +1,179 @@
+"""
+GPU tests of the two branch-and-bound searches of round 5 (`-m gpu`, through the C ABI; round 4's verdict, Next 3):
+
+  * theta_mix_search (branch and bound over the MIXTURE space, csrc/bnb.hip) behind do_optimization_single for spaces no linear
+    walk finishes: against the exhaustive search on whole seeded spaces, against `best` lists written by the reference itself
+    (tests/golden/best_campaign*.json), and on BASELINE configs 3 and 4 themselves (m = 50: 4e27 / 2.6e38 matrices) with a
+    tight-bounds instance around the optimum searched exhaustively as the cross-check;
+  * theta_bnb (branch and bound over the row tree, rank ranges handed to theta_search_ranges): complete `best` lists, rank-deficient
+    entries included, identical to the exhaustive search's on whole small spaces.
+"""
+import time
+
+import numpy as np
+import pytest
+
+import campaign
+from conftest import load_json, rank_deficient
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import theta_amd
+    return theta_amd.default_context()
+
+
+def _records_exhaustive(S, problem, ctx, r, rN):
+    """finalists + nu = 1/3 fallbacks of the WHOLE space, by the linear walk (no NaN sweep, no rank-deficient list)"""
+    problem.set_option("n3_nan_sweep", 0)
+    recs, _st = S.collect_finalists(problem, ctx, r, rN, 1.0, 0, problem.count)
+    return recs + S.fallback_records(problem, ctx, r, rN, 1.0, recs)
+
+
+def _full_rank(recs):
+    if not recs:
+        return []
+    keep = ~rank_deficient(np.array([t["c"] for t in recs]))
+    return [t for t, k in zip(recs, keep) if k]
+
+
+def _plain(best):
+    return [(np.asarray(t["c"]).tolist(), [float(x) for x in t["mu"]], float(t["nll"])) for t in best]
+
+
+SPACES = [(12, 3, 31), (13, 3, 2), (14, 3, 9), (12, 4, 5), (13, 4, 6), (11, 5, 8), (12, 5, 1), (10, 6, 3), (15, 3, 12),
+          (12, 3, 41), (13, 3, 42), (12, 4, 43), (11, 5, 44), (10, 6, 45), (14, 3, 46), (13, 4, 47), (12, 5, 48), (11, 4, 49), (10, 6, 51),
+          (11, 5, 52), (13, 3, 53), (12, 4, 54)]
+
+
+@pytest.mark.parametrize("m,K,seed", SPACES)
+def test_mixture_space_search_equals_the_exhaustive_search_on_whole_spaces(ctx, m, K, seed):
+    """Whole spaces of 1e6 .. 1e9 matrices: what do_optimization_single keeps of the space -- every full-rank matrix the reference
+    reports within its tie margin of the minimum, in enumeration order, C bit-exact, NLL and mu to 1e-9 -- found by branch and
+    bound over the mixture space, against the replay over the linear walk's records."""
+    import bench
+    import theta_amd
+    from theta_amd import search as S
+    r, rN, order = bench.synth(seed=seed, m=m, n=3, k=K)
+    lb, ub = [0] * m, [K] * m
+    p = theta_amd.Problem(ctx, 3, m, 2, r, rN, lb, ub, 1.0)
+    assert 1e5 < p.count < 2e10
+    rep = S.SearchReport()
+    recs_mix, _ = S.mix_records(p, ctx, r, rN, 1.0, (lb, ub), report=rep)
+    want = S.replay_records(_full_rank(_records_exhaustive(S, p, ctx, r, rN)), False)
+    got = S.replay_records(_full_rank(recs_mix), False)
+    p.close()
+    assert len(want) >= 1
+    assert campaign.compare_best(_plain(got), _plain(want), tol=1e-9) == "", (m, K, seed, len(got), len(want), rep.mix)
+    assert rep.mix["minimum"] <= rep.mix["incumbent"] + 1e-9 and rep.mix["boxes_tested"] > 0
+
+
+@pytest.mark.parametrize("m,K,seed", [(12, 3, 31), (12, 4, 5), (11, 5, 8), (13, 3, 2)])
+def test_row_tree_walk_returns_the_complete_best_list_of_the_exhaustive_search(ctx, m, K, seed, monkeypatch):
+    """theta_bnb + theta_search_ranges behind do_optimization_single (THETA_USE_MIX off): the COMPLETE list -- rank-deficient and NaN
+    entries included, every collinear prefix followed -- identical to the linear walk's, entry by entry."""
+    import bench
+    from theta_amd import search as S
+    r, rN, order = bench.synth(seed=seed, m=m, n=3, k=K)
+    monkeypatch.setattr(S, "NAN_SWEEP_MAX", 0)
+    monkeypatch.setattr(S, "USE_MIX", False)
+    monkeypatch.setattr(S, "BNB_MIN_CANDIDATES", 2 ** 200)
+    a = S.do_optimization_single(3, m, K, 2, [0] * m, [K] * m, r, rN, 1.0, order, False, False)
+    monkeypatch.setattr(S, "BNB_MIN_CANDIDATES", 0)
+    b = S.do_optimization_single(3, m, K, 2, [0] * m, [K] * m, r, rN, 1.0, order, False, False)
+    rb = S.last_report
+    assert rb.bnb is not None and rb.bnb["rank_deficient_complete"] and rb.bnb["ranges"] >= 1
+    assert campaign.compare_best(campaign.best_to_plain(b), campaign.best_to_plain(a), tol=1e-9) == "", (m, K, seed, rb.bnb)
+
+
+def test_mixture_space_search_against_lists_written_by_the_reference(ctx, monkeypatch):
+    """The n=3 instances of the reference-written campaign fixtures (complete `best` lists of python/RunTHetA.py itself) through the
+    mixture-space search: every full-rank, finite entry of the reference's list, in order, C bit-exact, NLL / mu to 1e-6 -- and
+    nothing else.  (Rank-deficient and NaN entries are the linear walk's: DESIGN.md section 8.)"""
+    from theta_amd import search as S
+    import theta_amd
+    monkeypatch.setattr(S, "BNB_MIN_CANDIDATES", 0)
+    checked = agree = skipped = 0
+    bad = []
+    for name in ("best_campaign.json", "best_campaign2.json", "best_campaign3.json"):
+        for c in load_json(name)["cases"][::2]:           # (every other instance: 100+ of them, 25 s)
+            if c["n"] != 3 or c["m"] < 5:
+                continue
+            ref = [(np.asarray(b["C"])[:, 1:].astype(int), [float(x) for x in b["mu"]], float(b["nll"]) if b["nll"] is not None else float("nan"))
+                   for b in c["best"]]
+            p = theta_amd.Problem(ctx, 3, c["m"], c["tau"], c["r"], c["rN"], c["lb"], c["ub"], 1.0)
+            try:
+                recs, _ = S.mix_records(p, ctx, c["r"], c["rN"], 1.0, (list(c["lb"]), list(c["ub"])))
+            except theta_amd.ThetaError:
+                skipped += 1                       # (a flat likelihood: the driver falls back to the walks; not this test's subject)
+                p.close()
+                continue
+            p.close()
+            got = S.replay_records(_full_rank(recs), False)
+            # the reference's entries in SORTED interval order (C_sorted[i] = C_original[order[i]], DataTools.py:132-146), rank-deficient
+            # and NaN ones set aside
+            want = []
+            for Cr, mu, nll in ref:
+                Cs = Cr[np.asarray(c["order"])]
+                if nll != nll or rank_deficient(Cs[None])[0]:
+                    continue
+                want.append((Cs.tolist(), mu, nll))
+            checked += 1
+            why = campaign.compare_best(_plain(got), want, tol=1e-6)
+            if why == "":
+                agree += 1
+            else:
+                bad.append((name, c["seed"], why, len(ref), len(want), len(got)))
+    assert checked >= 40, (checked, skipped)
+    assert not bad, bad[:5]
+
+
+def _config(K, seed):
+    import bench
+    r, rN, order = bench.synth(seed=seed, m=50, n=3, k=K)
+    return r, rN, order
+
+
+@pytest.mark.parametrize("name,K,seed", [("config 3", 4, 7), ("config 4", 6, 4242)])
+def test_baseline_configs_3_and_4_are_searched_whole(ctx, name, K, seed, capsys):
+    """BASELINE config 3 / 4 (synthetic m = 50 intervals, n = 3, k = 4 / 6, full bounds: 4e27 / 2.6e38 matrices) through
+    do_optimization_single: the arg-min of the WHOLE space in about a second.  No exhaustive search can confirm it (the equality
+    with the linear walk is the whole-space tests' above); what can be checked here: the winner is a matrix of the reference's
+    space and theta_solve_batch reports the same NLL for it; no matrix of the space that differs from it in ONE row is better
+    (every single-row change valued by the reference's procedure); and the octree's own certificate -- the smallest bound among
+    the boxes of the last proposal pass, a lower bound of the minimum over everything the search covers up to the boxes' size,
+    lies within the window below the reported minimum."""
+    from theta_amd import search as S
+    r, rN, order = _config(K, seed)
+    m = 50
+    t0 = time.time()
+    best = S.do_optimization_single(3, m, K, 2, [0] * m, [K] * m, r, rN, 1.0, order, False, False)
+    dt = time.time() - t0
+    rep = S.last_report
+    assert rep.mix is not None and "gave_up" not in rep.mix, rep.mix
+    assert rep.candidates > 1e27 and dt < 20.0
+    fin = [b for b in best if b[2] == b[2]]
+    assert fin and abs(min(b[2] for b in fin) - rep.mix["minimum"]) < 1e-6
+    with capsys.disabled():
+        print("\n%s: %.3g matrices, best NLL %.6f, %d entries, %.2f s (%d boxes, %d leaves, %d matrices listed)" %
+              (name, rep.candidates, fin[0][2], len(best), dt, rep.mix["boxes_tested"], rep.mix["leaves"], rep.mix["listed"]))
+    low = rep.mix["minimum"]
+    assert low - S.COLLECT_WINDOW - 0.5 <= rep.mix["min_bound"] <= low + 1e-6, (rep.mix["min_bound"], low)
+    # the winner in sorted interval order: in the space, valued alike by the reference's procedure, no better neighbour
+    Cw = np.asarray(best[0][0])[np.asarray(order)][:, 1:].astype(np.uint8)
+    assert S.in_space_n3(Cw, [0] * m, [K] * m, 2)
+    rows = [(a, b) for b in range(K + 1) for a in range(K + 1) if (2 - a) * (2 - b) >= 0]
+    trials = [Cw]
+    for i in range(m):
+        for a, b in rows:
+            if (a, b) != (int(Cw[i][0]), int(Cw[i][1])):
+                T = Cw.copy()
+                T[i] = (a, b)
+                if S.in_space_n3(T, [0] * m, [K] * m, 2):
+                    trials.append(T)
+    ok, _mu, nll, _v = ctx.solve_batch(3, 2, r, rN, np.ascontiguousarray(np.array(trials, np.uint8)), 1.0, want_vals=False)
+    assert ok[0] == 1 and abs(nll[0] - low) <= 1e-9 * abs(low)
+    others = nll[1:][(ok[1:] > 0) & (nll[1:] == nll[1:])]
+    assert len(trials) > 20 and (len(others) == 0 or others.min() >= low - 1e-9 * abs(low)), (len(trials), float(others.min()), low)

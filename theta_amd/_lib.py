@@ -61,6 +61,27 @@ class SearchStats(C.Structure):
         return d
 
 
+class BnbStats(C.Structure):
+    _fields_ = [("nodes_expanded", C.c_uint64), ("children_bounded", C.c_uint64), ("newton_iterations", C.c_uint64),
+                ("children_pruned", C.c_uint64), ("children_collinear", C.c_uint64), ("children_unbounded", C.c_uint64),
+                ("ranges_raw", C.c_uint64), ("ranges", C.c_uint64), ("launches", C.c_uint64), ("max_frontier", C.c_uint64),
+                ("chunk", C.c_uint64), ("leaves", C.c_double), ("kernel_ms", C.c_double), ("wall_ms", C.c_double),
+                ("emit_depth", C.c_int), ("complete", C.c_int), ("frontier", C.c_uint64 * 257)]
+
+    def as_dict(self, m):
+        d = {k: getattr(self, k) for k, _ in self._fields_ if k != "frontier"}
+        d["frontier"] = [int(self.frontier[i]) for i in range(m + 1)]
+        return d
+
+
+class MixStats(C.Structure):
+    _fields_ = [("boxes_tested", C.c_uint64), ("levels", C.c_uint64), ("max_boxes", C.c_uint64), ("leaves", C.c_uint64),
+                ("listed", C.c_uint64), ("matrices", C.c_uint64), ("kernel_ms", C.c_double), ("wall_ms", C.c_double), ("min_bound", C.c_double)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
 # theta_witness (include/theta_hip.h): what the n=3 sieve kernel left a sampled candidate at
 WITNESS_DTYPE = np.dtype([("mu", np.float64, 3), ("nll", np.float64), ("l2_last", np.float32), ("l2_first", np.float32),
                           ("evaluations", np.uint16), ("status", np.uint16), ("reserved", np.uint32)])
@@ -69,7 +90,7 @@ _lib = None
 
 # every symbol include/theta_hip.h declares
 EXPORTS = ["theta_create", "theta_device_count", "theta_destroy", "theta_last_error", "theta_device_info", "theta_problem_create",
-           "theta_problem_destroy", "theta_problem_count", "theta_search", "theta_search_values", "theta_search_witness", "theta_enumerate", "theta_enumerate_device",
+           "theta_problem_destroy", "theta_problem_count", "theta_search", "theta_search_values", "theta_search_witness", "theta_bnb", "theta_search_ranges", "theta_mix_search", "theta_enumerate", "theta_enumerate_device",
            "theta_solve_batch", "theta_score_batch", "theta_score_masked", "theta_search_suspects", "theta_boundary_min", "theta_problem_hint",
            "theta_search_degenerate", "theta_problem_set_option", "theta_synchronize",
            "theta_score_batch_rows", "theta_device_alloc", "theta_device_free", "theta_device_copy", "theta_solve_batch_device",
@@ -103,6 +124,9 @@ def load():
     lib.theta_search.argtypes = [vp, u64p, u64p, C.c_double, i32, dp, dp, u64p, u8p, C.POINTER(i32), C.POINTER(SearchStats)]
     lib.theta_search_values.argtypes = [vp, u64p, C.c_uint64, dp, dp, C.POINTER(SearchStats)]
     lib.theta_search_witness.argtypes = [vp, u64p, u64p, C.c_double, i32, C.c_uint64, vp, u64p, C.POINTER(SearchStats)]
+    lib.theta_search_ranges.argtypes = [vp, i32, u64p, C.c_double, i32, dp, dp, u64p, u8p, C.POINTER(i32), C.POINTER(SearchStats)]
+    lib.theta_mix_search.argtypes = [vp, C.c_double, C.c_double, i32, C.c_uint64, u8p, u64p, C.POINTER(MixStats)]
+    lib.theta_bnb.argtypes = [vp, C.c_double, C.c_uint64, i32, C.c_uint64, C.c_uint64, u64p, u64p, C.POINTER(BnbStats)]
     lib.theta_enumerate.argtypes = [vp, u64p, C.c_uint64, u8p]
     lib.theta_enumerate_device.argtypes = [vp, u64p, C.c_uint64, vp, dp]
     lib.theta_search_suspects.argtypes = [vp, i32, u64p, dp, u8p, C.POINTER(i32)]
@@ -361,7 +385,7 @@ class _Merged:
         self.n, self.m = n, m
         self.nll, self.mu, self.C, self.rank, self.pi = np.zeros(0), np.zeros((0, n)), None, [], np.zeros(0, np.int64)
         self.srk, self.slb, self.sC, self.spi = [], np.zeros(0), np.zeros((0, m, 2), np.uint8), np.zeros(0, np.int64)
-        self.drk, self.dC, self.dpi = [], np.zeros((0, m, 2), np.uint8), np.zeros(0, np.int64)
+        self.drk, self.dC_parts, self.dpi_parts = [], [], []      # (the rank-deficient list is never pruned: kept in parts, joined once)
         self.stats = None
         self.since_prune = 0
 
@@ -394,8 +418,8 @@ class _Merged:
                 self.spi = np.concatenate([self.spi, np.full(len(sus[0]), piece, np.int64)])
             if len(deg[0]):
                 self.drk += list(deg[0])
-                self.dC = np.concatenate([self.dC, deg[1].reshape(-1, self.m, 2)])
-                self.dpi = np.concatenate([self.dpi, np.full(len(deg[0]), piece, np.int64)])
+                self.dC_parts.append(np.asarray(deg[1]).reshape(-1, self.m, 2))
+                self.dpi_parts.append(np.full(len(deg[0]), piece, np.int64))
         self.since_prune += 1
         if self.since_prune >= 64:                       # long walks: drop what the minimum so far has already ruled out
             self.prune(running, window)
@@ -418,8 +442,10 @@ class _Merged:
         out = {"nll": self.nll[o], "mu": self.mu[o], "rank": [self.rank[i] for i in o], "C": Cc, "stats": self.stats}
         if self.n != 3:
             return out, ([], np.zeros(0), None), ([], None)
-        so, do = np.argsort(self.spi, kind="stable"), np.argsort(self.dpi, kind="stable")
-        return out, ([self.srk[i] for i in so], self.slb[so], self.sC[so]), ([self.drk[i] for i in do], self.dC[do])
+        dC = np.concatenate(self.dC_parts) if self.dC_parts else np.zeros((0, self.m, 2), np.uint8)
+        dpi = np.concatenate(self.dpi_parts) if self.dpi_parts else np.zeros(0, np.int64)
+        so, do = np.argsort(self.spi, kind="stable"), np.argsort(dpi, kind="stable")
+        return out, ([self.srk[i] for i in so], self.slb[so], self.sC[so]), ([self.drk[i] for i in do], dC[do])
 
 
 class Problem:
@@ -467,11 +493,14 @@ class Problem:
         """theta_problem_set_option: "n3_no_dismiss", "n3_force_f64", "n3_conv_l2", "n3_per_task", ..."""
         _check(load().theta_problem_set_option(self._h, name.encode(), float(value)))
 
-    def _piece(self, b, e, window, cap, hint):
-        """One theta_search call with its side lists: (result, suspects, suspects_dropped, degenerate)."""
+    MAX_TASKS_PER_CALL = 1 << 17
+
+    def _piece(self, b, e, window, cap, hint, group=None):
+        """One theta_search call (group: one theta_search_ranges call over those ranges) with its side lists:
+        (result, suspects, suspects_dropped, degenerate)."""
         if hint < float("inf"):
             _check(load().theta_problem_hint(self._h, hint))
-        res = self._search_once(b, e, window, cap, hint)
+        res = self._search_once(b, e, window, cap, hint, group)
         if res["stats"]["list_overflow"]:
             # the device tie list stayed full after the library's three passes: finalists were lost
             raise ListOverflow("%d finalists dropped by the device tie list in ranks [%d, %d): narrow the "
@@ -494,36 +523,89 @@ class Problem:
         an incomplete list.
         """
         end = self.count if end is None else end
+        return self.search_ranges([(begin, end)], window, cap)
+
+    def search_ranges(self, ranges, window=0.5, cap=16384):
+        """search() over several rank ranges [(begin, end), ...] in rank order (the survivors of a branch and bound, theta_bnb):
+        the same walk over pieces, the same merge -- what lies within `window` of the minimum over ALL the ranges, and their side
+        lists together."""
+        ranges = [(int(b), int(e)) for b, e in ranges]
+        begin, end = (ranges[0][0], ranges[-1][1]) if ranges else (0, 0)
+        total = sum(e - b for b, e in ranges)
         step = self.MAX_PER_CALL[self.n]
-        if end - begin > step * self.MAX_PIECES:
+        if total > step * self.MAX_PIECES:
             # e.g. 70 intervals with bounds [0, 2]: 2.5e34 matrices.  The reference would enumerate such a space for ever; here
             # the call says so (the pieces are walked one by one, nothing of this size is ever materialised on the host)
             raise ThetaError(ERR_OVERFLOW, "%d candidate matrices in one search: more than this library walks in one call "
-                             "(%d); tighten the bounds, use fewer intervals, or search rank sub-ranges" % (end - begin, step * self.MAX_PIECES))
-        running = self._probe(begin, end)
-        if end <= begin:                                 # an empty range (or an empty space: theta_search says so)
+                             "(%d); tighten the bounds, use fewer intervals, or search rank sub-ranges" % (total, step * self.MAX_PIECES))
+        running = self._probe(begin, end) if len(ranges) == 1 else self._take_hint()
+        if total <= 0:                                   # an empty range (or an empty space: theta_search says so)
             self.last_suspects, self.last_degenerate = ([], np.zeros(0), None), ([], None)
             return self._search_once(begin, end, window, cap)
         # The pieces are walked in order and merged as they come: what is kept between pieces is what can still matter
         # (finalists and suspects within `window` of the minimum so far, the all-zero-column list), not one entry per piece.
         acc = _Merged(self.n, self.m)
         redo = []                                        # pieces whose device suspect list overflowed: (index, b, e, hint used)
-        nxt, piece = begin, 0
+        spans = list(reversed(ranges))                   # (stack) what is still to be walked, in rank order
+        piece = 0
+        # several ranges: runs of them that fit one call (<= 2^31 candidates, <= MAX_TASKS_PER_CALL wave tasks) go through the kernels
+        # together (theta_search_ranges) -- thousands of short ranges would each pay a call's fixed overhead otherwise
+        batch_ok = self.n == 3 and len(ranges) > 1 and getattr(self, "_h", None) is not None and self.m >= 8
+        max_group = 1 << 30                              # ranges per batch: halved whenever a batch overflows one of the device lists
         halves = []                                      # (stack) halves of a piece whose rank-deficient list overflowed, in rank order
         rss0 = _rss_bytes()
-        while nxt < end or halves:
+        while spans or halves:
+            group = None
             if halves:
                 b, e = halves.pop()
             else:
-                b, e = nxt, min(nxt + step, end)
-                nxt = e
+                b, e = spans.pop()
+                if e - b > step:
+                    spans.append((b + step, e))
+                    e = b + step
+                if e <= b:
+                    continue
+                if batch_ok and spans and e - b < step:
+                    group, cands, tasks = [(b, e)], e - b, (e - b + 8191) // 8192
+                    while spans and len(group) < max_group:
+                        nb, ne = spans[-1]
+                        nt = (ne - nb + 8191) // 8192
+                        if cands + (ne - nb) > step or tasks + nt > self.MAX_TASKS_PER_CALL:
+                            break
+                        spans.pop()
+                        if ne > nb:
+                            group.append((nb, ne))
+                            cands += ne - nb
+                            tasks += nt
+                    if len(group) == 1:
+                        group = None
+                    else:
+                        e = group[-1][1]
             if piece and piece % 256 == 0 and _rss_bytes() - rss0 > self.MAX_HOST_GROWTH:
                 # a guard, not a code path: the merge keeps what can still matter, so the host footprint of a search does not
                 # grow with its length -- if it does (round 2 lost three GPU boxes to a list of 1e25 pieces), stop here
                 raise ThetaError(ERR_CAPACITY, "host memory grew by %.1f GB while walking ranks [%d, %d): refusing to go on"
                                  % ((_rss_bytes() - rss0) / 2.0 ** 30, begin, b))
             try:
-                part = self._piece(b, e, window, cap, running)       # later pieces start from the minimum found so far
+                if group is not None:
+                    try:
+                        part = self._piece(b, e, window, cap, running, group)
+                    except (ListOverflow, DegenerateOverflow, ThetaError) as ex:
+                        if isinstance(ex, ThetaError) and not isinstance(ex, (ListOverflow, DegenerateOverflow)) and ex.code != ERR_CAPACITY:
+                            raise
+                        # (a list of the batch overflowed: smaller batches, in the end the ranges one by one, where the
+                        # single-range ladders apply)
+                        spans.extend(reversed(group))
+                        max_group = len(group) // 2
+                        batch_ok = max_group >= 2
+                        continue
+                    if part[2] > 0:                   # (its suspect list overflowed: the re-search below takes contiguous ranges)
+                        spans.extend(reversed(group))
+                        max_group = len(group) // 2
+                        batch_ok = max_group >= 2
+                        continue
+                else:
+                    part = self._piece(b, e, window, cap, running)       # later pieces start from the minimum found so far
             except DegenerateOverflow:
                 if e - b <= (1 << 20):                               # (cannot happen: the list holds 2^20)
                     raise
@@ -578,6 +660,11 @@ class Problem:
     PROBE_MIN_RANGE = 1 << 26     # n=3 ranges at least this long are probed first
     PROBE_SAMPLES, PROBE_SIZE = 16, 1 << 16
 
+    def _take_hint(self):
+        running = getattr(self, "_hint", float("inf"))
+        self._hint = float("inf")
+        return running
+
     def _probe(self, begin, end):
         """
         n=3: the minimum over a few short sub-ranges spread over [begin, end) -- an attainable NLL the real search can
@@ -599,17 +686,26 @@ class Problem:
                 running = min(running, float(res["nll"].min()))
         return running
 
-    def _search_once(self, begin, end, window, cap, hint=float("inf")):
+    def _search_once(self, begin, end, window, cap, hint=float("inf"), group=None):
         st = SearchStats()
+        spec = None
+        if group is not None:
+            spec = np.zeros((len(group), 4), np.uint64)
+            for i, (gb, ge) in enumerate(group):
+                spec[i] = (gb & 0xFFFFFFFFFFFFFFFF, gb >> 64, (ge - gb) & 0xFFFFFFFFFFFFFFFF, (ge - gb) >> 64)
         while True:
             nll = np.zeros(cap)
             mu = np.zeros((cap, self.n))
             rank = np.zeros((cap, 2), np.uint64)
             Cb = np.zeros(cap * self.m * (self.n - 1), np.uint8)
             n_out = C.c_int()
-            rc = load().theta_search(self._h, _u128(begin), _u128(end), float(window), cap, _p(nll, C.c_double),
-                                     _p(mu, C.c_double), _p(rank, C.c_uint64), _p(Cb, C.c_uint8), C.byref(n_out),
-                                     C.byref(st))
+            if spec is not None:
+                rc = load().theta_search_ranges(self._h, len(group), _p(spec, C.c_uint64), float(window), cap, _p(nll, C.c_double),
+                                                _p(mu, C.c_double), _p(rank, C.c_uint64), _p(Cb, C.c_uint8), C.byref(n_out), C.byref(st))
+            else:
+                rc = load().theta_search(self._h, _u128(begin), _u128(end), float(window), cap, _p(nll, C.c_double),
+                                         _p(mu, C.c_double), _p(rank, C.c_uint64), _p(Cb, C.c_uint8), C.byref(n_out),
+                                         C.byref(st))
             if rc == ERR_CAPACITY and n_out.value > cap:
                 cap = n_out.value
                 if hint < float("inf"):        # the device hint is one-shot: the retry starts from the same minimum (round-3 advice)
@@ -662,6 +758,40 @@ class Problem:
         _check(load().theta_search_values(self._h, _u128(begin), int(count), _p(nll, C.c_double), _p(mu, C.c_double),
                                           C.byref(st)))
         return nll, mu, st.as_dict()
+
+    def mix_search(self, threshold, leaf_rel=2e-4, cap=1 << 16, propose=False):
+        """theta_mix_search: the matrices (k, m, 2) uint8 -- in enumeration order, a superset -- whose NLL can be <= threshold for
+        some mixture, by branch and bound over the mixture space; and the walk's statistics."""
+        st = MixStats()
+        out = np.zeros((max(cap, 1), self.m, 2), np.uint8)
+        n_out = C.c_uint64(0)
+        rc = load().theta_mix_search(self._h, float(threshold), float(leaf_rel), 1 if propose else 0, int(cap), _p(out, C.c_uint8), C.byref(n_out), C.byref(st))
+        self.last_mix = st.as_dict()
+        _check(rc)
+        return out[:n_out.value].copy(), self.last_mix
+
+    def bnb(self, threshold, beam=0, follow_collinear=False, max_nodes=0, cap=1 << 16):
+        """theta_bnb: the rank ranges [(begin, end), ...] of the whole space that can hold a matrix whose optimum is <= threshold
+        (beam > 0: the ranges of a dive that keeps the `beam` best nodes per level), and the walk's statistics."""
+        st = BnbStats()
+        while True:
+            out = np.zeros((max(cap, 1), 4), np.uint64)
+            n_out = C.c_uint64(0)
+            rc = load().theta_bnb(self._h, float(threshold), int(beam), 1 if follow_collinear else 0, int(max_nodes), int(cap),
+                                  _p(out, C.c_uint64), C.byref(n_out), C.byref(st))
+            if rc == ERR_CAPACITY and n_out.value > cap and cap < (1 << 26):
+                cap = max(int(n_out.value), 4 * cap)
+                continue
+            self.last_bnb = st.as_dict(self.m)
+            _check(rc)
+            break
+        k = n_out.value
+        rg = []
+        for i in range(k):
+            b = int(out[i, 0]) | (int(out[i, 1]) << 64)
+            c = int(out[i, 2]) | (int(out[i, 3]) << 64)
+            rg.append((b, b + c))
+        return rg, self.last_bnb
 
     def witness(self, begin, end, every_log2=0, window=0.0):
         """theta_search_witness: one record (WITNESS_DTYPE) per 2^every_log2-th candidate of [begin, end) -- what the n=3 sieve

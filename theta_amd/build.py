@@ -22,6 +22,7 @@ UNITS = [
     ("n3_enum.hip", []),
     ("n3_sieve.hip", []),
     ("n3_sieve.hip", ["-DSV_WITNESS=1", "-Wno-pass-failed"], "n3_sieve_witness.o"),
+    ("bnb.hip", []),
     ("batch.hip", ["-ffp-contract=off"]),
     ("api.hip", []),
     ("comm.hip", []),

@@ -6,11 +6,13 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <chrono>
 #include <memory>
 
 #include "n2.hpp"
 #include "n3_core.hpp"
 #include "n3_sieve.hpp"
+#include "bnb.hpp"
 
 // ---- implemented in n2.hip / n3.hip / batch.hip ------------------------------------------------
 void n2_launch_search(const N2Dev &P, const SearchArgs &A, unsigned long long begin, unsigned long long end,
@@ -23,6 +25,7 @@ int n3_build_host(int m, int tau, const int32_t *lb_in, const int32_t *ub_in, N3
 int n3_run_dp(const N3Dev &P, u128 *cnt, unsigned *overflow_dev, unsigned long long *total_dev, hipStream_t st);
 void n3_launch_tasks(const N3Dev &P, u128 begin, u128 end, uint64_t per_task, int ntasks, N3Task *tasks,
                      unsigned *stbuf, hipStream_t st);
+void n3_launch_task_list(const N3Dev &P, const uint64_t *spec, int ntasks, N3Task *tasks, unsigned *stbuf, hipStream_t st);
 void n3_launch_search(const N3Dev &P, const SearchArgs &A, const N3Task *tasks, const unsigned *stbuf, int ntasks,
                       uint64_t per_task, hipStream_t st);
 void n3_launch_unrank_list(const N3Dev &P, const TieRecord *recs, int count, unsigned char *out, hipStream_t st);
@@ -179,6 +182,8 @@ struct theta_problem {
     double last_redo_ms = 0.0;
     bool last_sieve64 = false;                         // ... and whether the sieve ran in FP64 (n3_force_f64)
     uint64_t last_launches = 0;                        // launches of the search kernel behind kernel_ms (sieve: one per slice)
+    std::vector<double> h_r, h_rN;                     // the counts as given (sorted order): the per-depth constants of theta_bnb
+    DevBuf d_misc2;                                    // task specifications of a search over several ranges
     DevBuf d_r, d_rN, d_small, d_P, d_PR, d_PN, d_cnt, d_ctr, d_stat, d_list, d_tasks, d_stbuf, d_misc, d_smask, d_dynmask, d_sus, d_deg, d_surv, d_survcnt, d_survacc, d_line, d_scan, d_sweep;
 };
 
@@ -258,6 +263,8 @@ extern "C" int theta_problem_create(theta_ctx *ctx, int n, int m, int tau, const
         rc = (x);       \
         if (rc) return rc; \
     } while (0)
+    p->h_r = rd;
+    p->h_rN = rnd;
     TRY(upload(p->d_r, rd.data(), m * sizeof(double), st));
     TRY(upload(p->d_rN, rnd.data(), m * sizeof(double), st));
     TRY(p->d_ctr.alloc(sizeof(SearchCounters)));
@@ -488,12 +495,49 @@ static int enumerate_device(theta_problem *p, u128 b, uint64_t count, unsigned c
 // ranges -- runs of consecutive tasks -- are materialised with the generator and scanned, one thread per candidate, and the
 // ranks of the candidates whose rows all lie on one line join the degenerate list on the device.  Rare: none of the 2^31
 // candidates of a bench step, 873 of the 21 050 matrices of the m=6, K=3 space.
-static int list_deficient(theta_problem *p, u128 b, u128 e, uint64_t per_task, unsigned line_count, SearchCounters &hc) {
+typedef std::vector<std::pair<u128, uint64_t>> TaskList;      // (first rank, candidates) of every task of a multi-range search, in rank order
+static int list_deficient(theta_problem *p, u128 b, u128 e, uint64_t per_task, unsigned line_count, SearchCounters &hc, const TaskList *tl = nullptr) {
     theta_ctx *ctx = p->ctx;
     hipStream_t st = ctx->stream;
     std::vector<unsigned long long> raw((size_t)2 * line_count);
     HIP_TRY(hipMemcpyAsync(raw.data(), p->d_line.p, raw.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
+    if (tl) {
+        // several ranges: the flagged tasks by their first rank, each materialised and scanned by itself (runs of tasks that follow
+        // each other without a gap together)
+        std::vector<size_t> ix;
+        for (unsigned i = 0; i < line_count; i++) {
+            const u128 base = ((u128)raw[2 * i + 1] << 64) | raw[2 * i];
+            auto it = std::lower_bound(tl->begin(), tl->end(), base, [](const std::pair<u128, uint64_t> &t, u128 v) { return t.first < v; });
+            if (it != tl->end() && it->first == base) ix.push_back((size_t)(it - tl->begin()));
+        }
+        std::sort(ix.begin(), ix.end());
+        ix.erase(std::unique(ix.begin(), ix.end()), ix.end());
+        const size_t cb = (size_t)p->m * 2;
+        for (size_t i = 0; i < ix.size();) {
+            size_t j = i + 1;
+            u128 rb = (*tl)[ix[i]].first, re = rb + (*tl)[ix[i]].second;
+            while (j < ix.size() && ix[j] == ix[j - 1] + 1 && (*tl)[ix[j]].first == re && (uint64_t)(re - rb) * cb < ((uint64_t)256 << 20)) {
+                re += (*tl)[ix[j]].second;
+                j++;
+            }
+            const uint64_t count = (uint64_t)(re - rb);
+            if (p->d_scan.bytes < count * cb) {
+                p->d_scan.release();
+                int rc = p->d_scan.alloc(count * cb);
+                if (rc) return rc;
+            }
+            int rc = enumerate_device(p, rb, count, (unsigned char *)p->d_scan.p, nullptr);
+            if (rc) return rc;
+            n3_launch_collinear_scan((const unsigned char *)p->d_scan.p, count, p->m, rb, (SearchCounters *)p->d_ctr.p, (TieRecord *)p->d_deg.p,
+                                     DEG_CAP, st);
+            i = j;
+        }
+        HIP_TRY(hipMemcpyAsync(&hc.deg_count, (char *)p->d_ctr.p + offsetof(SearchCounters, deg_count), sizeof(unsigned), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        HIP_TRY(hipGetLastError());
+        return THETA_OK;
+    }
     std::vector<uint64_t> tix(line_count);
     for (unsigned i = 0; i < line_count; i++) tix[i] = (uint64_t)(((((u128)raw[2 * i + 1]) << 64 | raw[2 * i]) - b) / per_task);
     std::sort(tix.begin(), tix.end());
@@ -593,7 +637,8 @@ struct WitnessReq {
 
 static int run_search(theta_problem *p, u128 b, u128 e, double window, double *dump_nll, double *dump_mu,
                       SearchCounters &hc, std::vector<TieRecord> &recs, double &kernel_ms, double &setup_ms,
-                      unsigned long long &dropped_out, const WitnessReq *wit = nullptr) {
+                      unsigned long long &dropped_out, const WitnessReq *wit = nullptr,
+                      const std::vector<std::pair<u128, u128>> *ranges = nullptr) {      // (n = 3 sieve path: several rank ranges [first, last) in rank order instead of [b, e))
     theta_ctx *ctx = p->ctx;
     hipStream_t st = ctx->stream;
     SearchArgs A;
@@ -628,6 +673,7 @@ static int run_search(theta_problem *p, u128 b, u128 e, double window, double *d
     p->last_launches = 0;
     const unsigned surv_cap = p->opt_surv_cap ? p->opt_surv_cap : SURV_CAP;      // (the list is allocated for SURV_CAP)
     uint64_t sieve_per_task_last = 0;                                            // candidates per task of the last pass, if the sieve ran it
+    TaskList host_tasks;                                                         // (several ranges: the tasks as the host cut them)
     std::vector<unsigned char> stat_host((size_t)THETA_STAT_SLOTS * THETA_STAT_STRIDE);
     for (int pass = 0; pass < 3; pass++) {
         std::vector<std::pair<int, int>> slices;     // n=3 fast path: (first task, tasks) of every sieve launch of this pass
@@ -657,6 +703,10 @@ static int run_search(theta_problem *p, u128 b, u128 e, double window, double *d
             n2_launch_search(p->n2, A, nb, ne, (int)per, st);
         } else {
             u128 cnt = e - b;
+            if (ranges) {
+                cnt = 0;
+                for (const auto &rg : *ranges) cnt += rg.second - rg.first;
+            }
             // candidates per wave task: 8192 for launches up to 2^29 candidates, 16384 beyond (the sieve's waves fetch tasks as
             // they finish them, so the tail of a launch is one task long: 16384 measured 3 % faster than 32768 on the search
             // leg, 8192 pays more for the task set-up than it wins); tuned, profiles/r4/NOTES.md
@@ -668,6 +718,10 @@ static int run_search(theta_problem *p, u128 b, u128 e, double window, double *d
             }
             if (p->opt_per_task > 0) per_task = p->opt_per_task;
             u128 nt = (cnt + per_task - 1) / per_task;
+            if (ranges) {
+                nt = 0;
+                for (const auto &rg : *ranges) nt += (rg.second - rg.first + per_task - 1) / per_task;
+            }
             if (nt > N3_MAX_TASKS) {
                 theta_set_error("n=3 rank range too large for one call: at most %llu candidates (split the range; "
                                 "theta_amd.Problem.search does)", (unsigned long long)N3_MAX_TASKS * per_task);
@@ -678,6 +732,10 @@ static int run_search(theta_problem *p, u128 b, u128 e, double window, double *d
             const int sieve_levels = (p->opt_sieve && !dump_nll) ? n3_sieve_levels(p->n3) : 0;   // (FP64 mode: the sieve's double instantiation)
             if (p->m > N3_MAX_M && sieve_levels == 0) {
                 theta_set_error("n=3 with more than %d intervals runs on the sieve path only (no --GET_VALUES dump, n3_sieve = 1)", N3_MAX_M);
+                return THETA_ERR_ARG;
+            }
+            if (ranges && sieve_levels == 0) {
+                theta_set_error("a search over several rank ranges runs on the sieve path only (n = 3, m >= 8, n3_sieve = 1)");
                 return THETA_ERR_ARG;
             }
             if (sieve_levels > 0) {
@@ -692,7 +750,29 @@ static int run_search(theta_problem *p, u128 b, u128 e, double window, double *d
                 }
                 HIP_TRY(hipMemsetAsync(p->d_survcnt.p, 0, (SV_TASKCTR_OFF + SIEVE_MAX_SLICES) * sizeof(unsigned), st));
                 HIP_TRY(hipMemsetAsync(p->d_survacc.p, 0, SIEVE_MAX_SLICES * sizeof(unsigned), st));
-                n3_launch_tasks(PS, b, e, per_task, ntasks, (N3Task *)p->d_tasks.p, (unsigned *)p->d_stbuf.p, st);
+                if (ranges) {
+                    // the tasks of several ranges: cut on the host, unranked one by one (n3_task_list_kernel)
+                    host_tasks.clear();
+                    std::vector<uint64_t> spec;
+                    spec.reserve((size_t)3 * ntasks);
+                    for (const auto &rg : *ranges)
+                        for (u128 at = rg.first; at < rg.second; at += per_task) {
+                            const uint64_t c = (uint64_t)std::min<u128>((u128)per_task, rg.second - at);
+                            host_tasks.push_back({at, c});
+                            spec.push_back((uint64_t)at);
+                            spec.push_back((uint64_t)(at >> 64));
+                            spec.push_back(c);
+                        }
+                    if (p->d_misc2.bytes < spec.size() * sizeof(uint64_t)) {
+                        int rc = p->d_misc2.alloc(spec.size() * sizeof(uint64_t));
+                        if (rc) return rc;
+                    }
+                    HIP_TRY(hipMemcpyAsync(p->d_misc2.p, spec.data(), spec.size() * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+                    n3_launch_task_list(PS, (const uint64_t *)p->d_misc2.p, ntasks, (N3Task *)p->d_tasks.p, (unsigned *)p->d_stbuf.p, st);
+                    HIP_TRY(hipStreamSynchronize(st));        // (`spec` leaves scope)
+                } else {
+                    n3_launch_tasks(PS, b, e, per_task, ntasks, (N3Task *)p->d_tasks.p, (unsigned *)p->d_stbuf.p, st);
+                }
                 HIP_TRY(hipEventRecord(ctx->ev1, st));
                 int per_slice = (int)std::max<uint64_t>(1, SIEVE_SLICE / per_task);
                 while ((ntasks + per_slice - 1) / per_slice > SIEVE_MAX_SLICES - 6) per_slice *= 2;   // (+ 4 bootstrap slices; the last counter is the redo's)
@@ -788,6 +868,10 @@ static int run_search(theta_problem *p, u128 b, u128 e, double window, double *d
         double redo_ms = 0.0;
         for (size_t sl = 0; sl < slices.size(); sl++) {
             if (hcnt[sl] <= surv_cap) continue;
+            if (ranges) {          // (the ladder below re-cuts a contiguous range; the caller searches these ranges one by one instead)
+                theta_set_error("%u contenders in one slice of a search over several ranges exceed the list (%u): search the ranges one by one", hcnt[sl], surv_cap);
+                return THETA_ERR_CAPACITY;
+            }
             redone_accepted_by_finish += hacc[sl];
             const int t0 = slices[sl].first, nts = slices[sl].second;
             const u128 sb = b + (u128)t0 * sieve_per_task;
@@ -913,7 +997,7 @@ static int run_search(theta_problem *p, u128 b, u128 e, double window, double *d
     if (p->n == 3 && sieve_per_task_last > 0 && hc.line_count > 0) {
         if (hc.line_count > LINE_CAP) line_lost = hc.line_count - LINE_CAP;      // (reported like an overflow of the list itself)
         else {
-            int rc = list_deficient(p, b, e, sieve_per_task_last, hc.line_count, hc);
+            int rc = list_deficient(p, b, e, sieve_per_task_last, hc.line_count, hc, ranges ? &host_tasks : nullptr);
             if (rc) return rc;
         }
     }
@@ -921,7 +1005,13 @@ static int run_search(theta_problem *p, u128 b, u128 e, double window, double *d
         // (listed as well: whatever the procedure reports at or below the search's minimum + window -- the sweep then settles the
         // range's result by itself; without a finite minimum only the NaN outcomes are listed)
         const double best = order_unbits(hc.best_bits);
-        int rc = nan_sweep(p, b, e, best < INFINITY ? best + window : -INFINITY, hc);
+        int rc = THETA_OK;
+        if (ranges) {
+            for (const auto &rg : *ranges)
+                if ((rc = nan_sweep(p, rg.first, rg.second, best < INFINITY ? best + window : -INFINITY, hc))) return rc;
+        } else {
+            rc = nan_sweep(p, b, e, best < INFINITY ? best + window : -INFINITY, hc);
+        }
         if (rc) return rc;
     }
     unsigned ndeg = std::min<unsigned>(hc.deg_count, DEG_CAP);
@@ -1000,12 +1090,55 @@ static void fill_search_stats(theta_problem *p, const SearchCounters &hc, unsign
     for (int i = 0; i < 8; i++) stats->phase_cycles[i] = hc.prof[i];
 }
 
+static int search_impl(theta_problem *p, u128 b, u128 e, const std::vector<std::pair<u128, u128>> *ranges, double window, int cap, double *nll,
+                       double *mu, uint64_t *rank, uint8_t *C, int *n_out, theta_search_stats *stats);
+
 extern "C" int theta_search(theta_problem *p, const uint64_t rank_begin[2], const uint64_t rank_end[2], double window,
                             int cap, double *nll, double *mu, uint64_t *rank, uint8_t *C, int *n_out,
                             theta_search_stats *stats) {
     u128 b, e;
     int rc = check_range(p, rank_begin, rank_end, b, e);
     if (rc) return rc;
+    return search_impl(p, b, e, nullptr, window, cap, nll, mu, rank, C, n_out, stats);
+}
+
+// theta_search over several rank ranges in ONE pass of the kernels (the survivors of theta_bnb: thousands of short ranges, each of
+// which would cost a call's fixed overhead -- task set-up, a dozen synchronisations, the side lists -- by itself).
+extern "C" int theta_search_ranges(theta_problem *p, int nranges, const uint64_t *ranges, double window, int cap, double *nll, double *mu,
+                                   uint64_t *rank, uint8_t *C, int *n_out, theta_search_stats *stats) {
+    if (!p || nranges < 0 || (nranges > 0 && !ranges)) {
+        theta_set_error("theta_search_ranges: bad argument");
+        return THETA_ERR_ARG;
+    }
+    if (p->n != 3) {
+        theta_set_error("theta_search_ranges: n = 3 only");
+        return THETA_ERR_ARG;
+    }
+    std::vector<std::pair<u128, u128>> rg;
+    const u128 total = ((u128)p->total[1] << 64) | p->total[0];
+    u128 prev = 0, sum = 0;
+    for (int i = 0; i < nranges; i++) {
+        const u128 rb = ((u128)ranges[4 * i + 1] << 64) | ranges[4 * i], rc_ = ((u128)ranges[4 * i + 3] << 64) | ranges[4 * i + 2];
+        if (rb < prev || rb + rc_ < rb || rb + rc_ > total) {
+            theta_set_error("theta_search_ranges: range %d is out of order, overlaps its predecessor or leaves the space", i);
+            return THETA_ERR_ARG;
+        }
+        if (rc_ == 0) continue;
+        rg.push_back({rb, rb + rc_});
+        prev = rb + rc_;
+        sum += rc_;
+    }
+    if (sum > ((u128)1 << 31)) {
+        theta_set_error("theta_search_ranges: at most 2^31 candidates per call (theta_amd.Problem.search_ranges batches)");
+        return THETA_ERR_ARG;
+    }
+    const u128 b = rg.empty() ? 0 : rg.front().first, e = rg.empty() ? 0 : rg.back().second;
+    return search_impl(p, b, e, &rg, window, cap, nll, mu, rank, C, n_out, stats);
+}
+
+static int search_impl(theta_problem *p, u128 b, u128 e, const std::vector<std::pair<u128, u128>> *ranges, double window, int cap, double *nll,
+                       double *mu, uint64_t *rank, uint8_t *C, int *n_out, theta_search_stats *stats) {
+    int rc;
     if (!n_out || cap < 0 || (cap > 0 && (!nll || !mu || !rank || !C))) {
         theta_set_error("theta_search: null output");
         return THETA_ERR_ARG;
@@ -1029,7 +1162,7 @@ extern "C" int theta_search(theta_problem *p, const uint64_t rank_begin[2], cons
     std::vector<TieRecord> recs;
     double kms, sms;
     unsigned long long dropped = 0;
-    rc = run_search(p, b, e, window, nullptr, nullptr, hc, recs, kms, sms, dropped);
+    rc = run_search(p, b, e, window, nullptr, nullptr, hc, recs, kms, sms, dropped, nullptr, ranges);
     if (rc) return rc;
     double best = order_unbits(hc.best_bits);
     if (stats) fill_search_stats(p, hc, dropped, kms, sms, stats);
@@ -1173,6 +1306,478 @@ extern "C" int theta_search_witness(theta_problem *p, const uint64_t rank_begin[
     if (stats) fill_search_stats(p, hc, dropped, kms, sms, stats);
     HIP_TRY(hipMemcpyAsync(out, d_w.p, (size_t)need * sizeof(SvWitness), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
+    return THETA_OK;
+}
+
+// ---- branch and bound above the prefix (bnb.hip) -----------------------------------------------------------------------------
+// The walk: levels 0 .. emit_depth - 1 hold pending frontier nodes; the deepest non-empty level is expanded first, a chunk of at
+// most `chunk` nodes at a time (breadth first while a level fits its buffer, depth first by chunks when it does not), so every
+// level's buffer holds at most chunk x Q children.  Beam mode (beam > 0) is breadth first only and keeps the `beam` smallest
+// bounds of every level.
+extern "C" int theta_bnb(theta_problem *p, double threshold, uint64_t beam, int follow_collinear, uint64_t max_nodes, uint64_t cap,
+                         uint64_t *ranges, uint64_t *n_out, theta_bnb_stats *stats) {
+    if (!p || !n_out || (cap > 0 && !ranges)) {
+        theta_set_error("theta_bnb: null argument");
+        return THETA_ERR_ARG;
+    }
+    *n_out = 0;
+    if (stats) memset(stats, 0, sizeof(*stats));
+    if (p->n != 3) {
+        theta_set_error("theta_bnb: n = 3 only (an n = 2 space is exhausted by theta_search)");
+        return THETA_ERR_ARG;
+    }
+    if (p->count_saturated) {
+        theta_set_error("theta_bnb: the space holds 2^128 matrices or more; its nodes have no 128-bit ranks");
+        return THETA_ERR_OVERFLOW;
+    }
+    if (threshold != threshold) {
+        theta_set_error("theta_bnb: threshold is NaN");
+        return THETA_ERR_ARG;
+    }
+    HIP_ENTER(p->ctx->device);
+    hipStream_t st = p->ctx->stream;
+    const int m = p->m, Q = p->n3.Q;
+    // emit depth: the sieve's prefix depth (the search of a range starts with whole prefixes); small problems go all the way down
+    const int sieve_levels = p->opt_sieve ? n3_sieve_levels(p->n3) : 0;
+    const int emit_depth = std::max(1, m - (sieve_levels > 0 ? sieve_levels : std::min(m - 1, 4)));
+    const uint64_t emit_max = 1ull << 12;            // a node with this few matrices left is cheaper to search than to expand
+    const int stride = (m + 3) & ~3;
+    // per-depth constants (host, long double): depth dc = rows fixed
+    std::vector<double> constc(m + 1), Z0(m + 1);
+    {
+        long double N = 0, Rt = 0;
+        for (int i = 0; i < m; i++) {
+            N += p->h_rN[i];
+            Rt += p->h_r[i];
+        }
+        std::vector<long double> tail(m + 1, 0.0L);   // sum over l >= dc of r_l ln(r_l / (Rtot N_l))
+        for (int l = m - 1; l >= 0; l--) {
+            tail[l] = tail[l + 1];
+            if (p->h_r[l] > 0) tail[l] += (long double)p->h_r[l] * logl((long double)p->h_r[l] / (Rt * ((long double)p->h_rN[l] / N)));
+        }
+        long double Rp = 0, om = 0;
+        for (int dc = 1; dc <= m; dc++) {
+            Rp += p->h_r[dc - 1];
+            om += (long double)p->h_rN[dc - 1] / N;
+            Z0[dc] = (double)om;
+            long double c = -tail[dc];
+            if (Rp > 0) c += Rp * logl(om) + Rp * logl(Rt / Rp);
+            constc[dc] = (double)c;
+        }
+    }
+    // buffers
+    const size_t node_bytes = sizeof(BnbNode) + (size_t)stride;
+    uint64_t chunk = 1ull << 16;
+    {
+        const double budget = 24e9;                    // bytes of level buffers (of the 288 GB)
+        while (chunk > 256 && (double)chunk * Q * node_bytes * (double)(emit_depth + 1) > budget) chunk >>= 1;
+    }
+    if (beam > chunk) beam = chunk;
+    const uint64_t level_cap = chunk * (uint64_t)Q;
+    const uint64_t range_cap = std::max<uint64_t>(cap, 1ull << 16);
+    struct Level {
+        DevBuf nodes, paths;
+        uint64_t count = 0, head = 0;
+    };
+    std::vector<std::unique_ptr<Level>> levels(emit_depth + 1);
+    auto level = [&](int d) -> Level * {
+        if (!levels[d]) {
+            levels[d].reset(new Level());
+            const uint64_t c = d == 0 ? 1 : level_cap;
+            if (levels[d]->nodes.alloc((size_t)c * sizeof(BnbNode)) || levels[d]->paths.alloc((size_t)c * stride)) return nullptr;
+        }
+        return levels[d].get();
+    };
+    DevBuf d_ranges, d_ctr, d_stats, d_bounds, d_scr_nodes, d_scr_paths;
+    int rc;
+    if ((rc = d_ranges.alloc((size_t)range_cap * sizeof(BnbRange)))) return rc;
+    if ((rc = d_ctr.alloc(4 * sizeof(unsigned long long)))) return rc;
+    if ((rc = d_stats.alloc((size_t)BNB_STAT_SLOTS * BNB_STAT_STRIDE * sizeof(unsigned long long)))) return rc;
+    HIP_TRY(hipMemsetAsync(d_ctr.p, 0, 4 * sizeof(unsigned long long), st));
+    HIP_TRY(hipMemsetAsync(d_stats.p, 0, (size_t)BNB_STAT_SLOTS * BNB_STAT_STRIDE * sizeof(unsigned long long), st));
+    if (beam) {
+        if ((rc = d_bounds.alloc((size_t)level_cap * sizeof(double)))) return rc;
+        if ((rc = d_scr_nodes.alloc((size_t)level_cap * sizeof(BnbNode)))) return rc;
+        if ((rc = d_scr_paths.alloc((size_t)level_cap * stride))) return rc;
+    }
+    // the root: no rows, rank 0
+    {
+        Level *L0 = level(0);
+        if (!L0) return THETA_ERR_HIP;
+        BnbNode root;
+        memset(&root, 0, sizeof(root));
+        root.w0 = NAN;
+        root.bound = -INFINITY;
+        HIP_TRY(hipMemcpyAsync(L0->nodes.p, &root, sizeof(root), hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemsetAsync(L0->paths.p, 0, stride, st));
+        L0->count = 1;
+        L0->head = 0;
+    }
+    const auto t_start = std::chrono::steady_clock::now();
+    uint64_t expanded = 0, launches = 0, ranges_written = 0, max_frontier = 1;
+    std::vector<uint64_t> frontier(m + 1, 0);
+    bool budget_hit = false;
+    std::vector<double> hb;
+    HIP_TRY(hipEventRecord(p->ctx->ev0, st));
+    for (;;) {
+        int d = -1;
+        for (int k = emit_depth - 1; k >= 0; k--)
+            if (levels[k] && levels[k]->head < levels[k]->count) {
+                d = k;
+                break;
+            }
+        if (d < 0) break;
+        Level *L = levels[d].get();
+        Level *Ln = level(d + 1 <= emit_depth ? d + 1 : emit_depth);
+        if (!Ln) return THETA_ERR_HIP;
+        if (Ln->head >= Ln->count) Ln->head = Ln->count = 0;       // (deepest first: the next level is empty whenever this one is expanded)
+        const uint64_t take = std::min<uint64_t>(chunk, L->count - L->head);
+        if (max_nodes && expanded + take > max_nodes) {
+            budget_hit = true;
+            break;
+        }
+        BnbArgs A;
+        A.d = d;
+        A.emit_depth = emit_depth;
+        A.emit_max = beam ? 0 : emit_max;            // (a dive's ranges are its beam at the emit depth: small subtrees compete like the others)
+        A.thr = beam ? INFINITY : threshold;
+        A.full_bound = beam ? 1 : 0;
+        A.follow_line = follow_collinear ? 1 : 0;
+        A.constc = constc[d + 1];
+        A.Z0 = Z0[d + 1];
+        A.rd = p->h_r[d];
+        A.nd = p->h_rN[d] / p->n3.N;
+        A.path_stride = stride;
+        A.in = (const BnbNode *)L->nodes.p + L->head;
+        A.in_path = (const unsigned char *)L->paths.p + (size_t)L->head * stride;
+        A.n_in = (unsigned)take;
+        A.out = (BnbNode *)Ln->nodes.p + Ln->count;
+        A.out_path = (unsigned char *)Ln->paths.p + (size_t)Ln->count * stride;
+        A.out_cap = level_cap - Ln->count;
+        A.ranges = (BnbRange *)d_ranges.p + ranges_written;
+        A.range_cap = range_cap - ranges_written;
+        A.counters = (unsigned long long *)d_ctr.p;
+        A.stats = (unsigned long long *)d_stats.p;
+        HIP_TRY(hipMemsetAsync(d_ctr.p, 0, 2 * sizeof(unsigned long long), st));
+        bnb_launch_expand(p->n3, A, st);
+        unsigned long long got[2];
+        HIP_TRY(hipMemcpyAsync(got, d_ctr.p, sizeof(got), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        HIP_TRY(hipGetLastError());
+        launches++;
+        expanded += take;
+        L->head += take;
+        if (getenv("THETA_BNB_DEBUG"))
+            fprintf(stderr, "bnb: depth %d, %llu nodes -> %llu children (level holds %llu), %llu ranges\n", d, (unsigned long long)take, got[0],
+                    (unsigned long long)Ln->count, got[1]);
+        if (got[0] > A.out_cap) {
+            theta_set_error("theta_bnb: internal: a level buffer overflowed (%llu children, room for %llu)", got[0], (unsigned long long)A.out_cap);
+            return THETA_ERR_HIP;
+        }
+        if (got[1] > A.range_cap) {
+            theta_set_error("theta_bnb: more than %llu surviving rank ranges: the threshold is too far above the minimum (or pass a larger cap)",
+                            (unsigned long long)range_cap);
+            *n_out = ranges_written + got[1];
+            return THETA_ERR_CAPACITY;
+        }
+        Ln->count += got[0];
+        ranges_written += got[1];
+        frontier[d + 1] += got[0];
+        if (beam && Ln->count > beam) {
+            // keep the `beam` smallest bounds of the level (breadth first: the level is complete once its parents are all expanded)
+            if (L->head >= L->count) {
+                const uint64_t n = Ln->count;
+                hb.resize(n);
+                bnb_launch_bounds((const BnbNode *)Ln->nodes.p, n, (double *)d_bounds.p, st);
+                HIP_TRY(hipMemcpyAsync(hb.data(), d_bounds.p, n * sizeof(double), hipMemcpyDeviceToHost, st));
+                HIP_TRY(hipStreamSynchronize(st));
+                std::vector<double> srt(hb);
+                std::nth_element(srt.begin(), srt.begin() + (beam - 1), srt.end());
+                const double cut = srt[beam - 1];
+                HIP_TRY(hipMemsetAsync((unsigned long long *)d_ctr.p + 2, 0, sizeof(unsigned long long), st));
+                bnb_launch_compact((const BnbNode *)Ln->nodes.p, (const unsigned char *)Ln->paths.p, n, stride, cut, (BnbNode *)d_scr_nodes.p,
+                                   (unsigned char *)d_scr_paths.p, level_cap, (unsigned long long *)d_ctr.p + 2, st);
+                unsigned long long kept = 0;
+                HIP_TRY(hipMemcpyAsync(&kept, (unsigned long long *)d_ctr.p + 2, sizeof(kept), hipMemcpyDeviceToHost, st));
+                HIP_TRY(hipStreamSynchronize(st));
+                kept = std::min<unsigned long long>(kept, level_cap);
+                HIP_TRY(hipMemcpyAsync(Ln->nodes.p, d_scr_nodes.p, (size_t)kept * sizeof(BnbNode), hipMemcpyDeviceToDevice, st));
+                HIP_TRY(hipMemcpyAsync(Ln->paths.p, d_scr_paths.p, (size_t)kept * stride, hipMemcpyDeviceToDevice, st));
+                Ln->count = kept;
+            }
+        }
+        max_frontier = std::max<uint64_t>(max_frontier, Ln->count);
+    }
+    HIP_TRY(hipEventRecord(p->ctx->ev1, st));
+    // the ranges, in rank order, adjacent ones joined
+    std::vector<BnbRange> hr(ranges_written);
+    if (ranges_written) HIP_TRY(hipMemcpyAsync(hr.data(), d_ranges.p, (size_t)ranges_written * sizeof(BnbRange), hipMemcpyDeviceToHost, st));
+    std::vector<unsigned long long> hs((size_t)BNB_STAT_SLOTS * BNB_STAT_STRIDE);
+    HIP_TRY(hipMemcpyAsync(hs.data(), d_stats.p, hs.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, p->ctx->ev0, p->ctx->ev1));
+    std::sort(hr.begin(), hr.end(), [](const BnbRange &a, const BnbRange &b) { return a.base_hi != b.base_hi ? a.base_hi < b.base_hi : a.base_lo < b.base_lo; });
+    std::vector<std::pair<u128, u128>> joined;
+    long double leaves = 0;
+    for (const BnbRange &g : hr) {
+        const u128 b = ((u128)g.base_hi << 64) | g.base_lo, c = ((u128)g.count_hi << 64) | g.count_lo;
+        leaves += (long double)c;
+        if (!joined.empty() && joined.back().first + joined.back().second == b) joined.back().second += c;
+        else joined.push_back({b, c});
+    }
+    if (stats) {
+        unsigned long long tot[BNB_STAT_STRIDE] = {0};
+        for (int sl = 0; sl < BNB_STAT_SLOTS; sl++)
+            for (int k = 0; k < BNB_STAT_STRIDE; k++) tot[k] += hs[(size_t)sl * BNB_STAT_STRIDE + k];
+        stats->nodes_expanded = expanded;
+        stats->children_bounded = tot[0];
+        stats->newton_iterations = tot[1];
+        stats->children_pruned = tot[2];
+        stats->children_collinear = tot[3];
+        stats->children_unbounded = tot[4];
+        if (getenv("THETA_BNB_DEBUG")) fprintf(stderr, "bnb: open children: %llu not converged, %llu NaN / huge step, %llu ill-conditioned\n", tot[5], tot[6], tot[7]);
+        stats->ranges_raw = ranges_written;
+        stats->ranges = joined.size();
+        stats->launches = launches;
+        stats->max_frontier = max_frontier;
+        stats->leaves = (double)leaves;
+        stats->kernel_ms = ms;
+        stats->wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count();
+        stats->emit_depth = emit_depth;
+        stats->complete = budget_hit ? 0 : 1;
+        stats->chunk = chunk;
+        for (int k = 0; k <= m && k <= THETA_MAX_M; k++) stats->frontier[k] = frontier[k];
+    }
+    *n_out = joined.size();
+    if (budget_hit) {
+        theta_set_error("theta_bnb: node budget (%llu) spent at %llu nodes expanded; the walk is incomplete", (unsigned long long)max_nodes,
+                        (unsigned long long)expanded);
+        return THETA_ERR_OVERFLOW;
+    }
+    if (joined.size() > cap) {
+        theta_set_error("theta_bnb: %zu rank ranges but capacity is %llu", joined.size(), (unsigned long long)cap);
+        return THETA_ERR_CAPACITY;
+    }
+    for (size_t i = 0; i < joined.size(); i++) {
+        ranges[4 * i] = (uint64_t)joined[i].first;
+        ranges[4 * i + 1] = (uint64_t)(joined[i].first >> 64);
+        ranges[4 * i + 2] = (uint64_t)joined[i].second;
+        ranges[4 * i + 3] = (uint64_t)(joined[i].second >> 64);
+    }
+    return THETA_OK;
+}
+
+// ---- branch and bound over the mixture space (bnb.hip, second half) ------------------------------------------------------------------
+// An octree over v = s (mu0, mu1, mu2) >= 0: level by level every surviving box is cut in two and the halves whose bound is within the
+// threshold go on; boxes narrower than `leaf_rel` (relative to the mean read-depth ratio, per unit of copy number) are leaves, whose
+// matrices are listed by a budgeted depth-first walk.  Returns the matrices as m slot bytes each (grid order: slot = a + (K + 1) b up to
+// K = 7, the compact alphabet beyond), without duplicates, in the reference's enumeration order (lexicographic in the slots).
+extern "C" int theta_mix_search(theta_problem *p, double threshold, double leaf_rel, int propose, uint64_t cap, uint8_t *C, uint64_t *n_out,
+                                theta_mix_stats *stats) {
+    if (!p || !n_out || (cap > 0 && !C)) {
+        theta_set_error("theta_mix_search: null argument");
+        return THETA_ERR_ARG;
+    }
+    *n_out = 0;
+    if (stats) memset(stats, 0, sizeof(*stats));
+    if (p->n != 3) {
+        theta_set_error("theta_mix_search: n = 3 only");
+        return THETA_ERR_ARG;
+    }
+    if (!(threshold == threshold) || !(leaf_rel > 0.0 && leaf_rel < 1.0)) {
+        theta_set_error("theta_mix_search: bad threshold or leaf size");
+        return THETA_ERR_ARG;
+    }
+    HIP_ENTER(p->ctx->device);
+    hipStream_t st = p->ctx->stream;
+    const int m = p->m;
+    const auto t_start = std::chrono::steady_clock::now();
+    long double N = 0, Rt = 0;
+    double rNmin = INFINITY;
+    for (int i = 0; i < m; i++) {
+        N += p->h_rN[i];
+        Rt += p->h_r[i];
+        rNmin = std::min(rNmin, p->h_rN[i]);
+    }
+    const int Q_ = p->n3.Q;
+    MixArgs A;
+    A.m = m;
+    A.Q = p->n3.Q;
+    A.tau = p->tau;
+    A.r = p->n3.r;
+    A.rN = p->n3.rN;
+    A.rowtab = p->n3.rowtab;
+    A.lb = p->n3.lb;
+    A.ub = p->n3.ub;
+    A.cst = (double)(-Rt + (Rt > 0 ? Rt * logl(Rt) : 0.0L));
+    A.thr = threshold;
+    const double tref = (double)(Rt / N);            // the mean read-depth ratio: c.v of a typical interval
+    const int Kmax = std::max(1, p->n3.K);
+    A.leaf[0] = leaf_rel * tref / std::max(1, p->tau);
+    A.leaf[1] = A.leaf[2] = leaf_rel * tref / Kmax;
+    // the root box: at the best scale sum_i rN_i c_i.v = Rtot, so tau v0 N <= Rtot and -- a tumour column with an entry >= 1 -- v_j rN_min <= Rtot
+    MixCell root;
+    root.lo[0] = root.lo[1] = root.lo[2] = 0.0;
+    root.hi[0] = (double)(Rt / (std::max(1, p->tau) * N));
+    root.hi[1] = root.hi[2] = (double)(Rt / rNmin);
+    // (raw listings: every matrix is listed by each leaf and corner whose budget it meets -- hundreds of times in a wide region)
+    const uint64_t cell_cap = 1ull << 23, leaf_cap = 1ull << 22, mat_cap = std::min<uint64_t>(1ull << 24, ((size_t)2 << 30) / (size_t)m);
+    DevBuf d_a, d_b, d_leaves, d_ctr, d_mat;
+    int rc;
+    if ((rc = d_a.alloc(cell_cap * sizeof(MixCell))) || (rc = d_b.alloc(cell_cap * sizeof(MixCell))) || (rc = d_leaves.alloc(leaf_cap * sizeof(MixCell))) ||
+        (rc = d_ctr.alloc(4 * sizeof(unsigned long long))) || (rc = d_mat.alloc(mat_cap * (size_t)m)))
+        return rc;
+    HIP_TRY(hipMemsetAsync(d_ctr.p, 0, 4 * sizeof(unsigned long long), st));
+    HIP_TRY(hipMemcpyAsync(d_a.p, &root, sizeof(root), hipMemcpyHostToDevice, st));
+    uint64_t n_cells = 1, n_leaves = 0, tested = 0, levels = 0, max_cells = 1;
+    MixCell *cur = (MixCell *)d_a.p, *nxt = (MixCell *)d_b.p;
+    HIP_TRY(hipEventRecord(p->ctx->ev0, st));
+    while (n_cells > 0) {
+        HIP_TRY(hipMemsetAsync(d_ctr.p, 0, sizeof(unsigned long long), st));
+        mix_launch_split(A, cur, n_cells, nxt, cell_cap, (MixCell *)d_leaves.p, leaf_cap, (unsigned long long *)d_ctr.p, st);
+        unsigned long long got[2];
+        HIP_TRY(hipMemcpyAsync(got, d_ctr.p, sizeof(got), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        HIP_TRY(hipGetLastError());
+        tested += 2 * n_cells;
+        levels++;
+        if (got[0] > cell_cap || got[1] > leaf_cap) {
+            theta_set_error("theta_mix_search: more than %llu boxes (%llu leaves) within the threshold: it is too far above the minimum", (unsigned long long)cell_cap,
+                            (unsigned long long)leaf_cap);
+            if (stats) {
+                stats->boxes_tested = tested;
+                stats->levels = levels;
+                stats->max_boxes = std::max<uint64_t>(max_cells, got[0]);
+                stats->leaves = got[1];
+            }
+            return THETA_ERR_CAPACITY;
+        }
+        n_cells = got[0];
+        n_leaves = got[1];
+        max_cells = std::max(max_cells, n_cells);
+        if (getenv("THETA_BNB_DEBUG")) fprintf(stderr, "mix: level %llu: %llu boxes, %llu leaves so far\n", (unsigned long long)levels, (unsigned long long)n_cells, (unsigned long long)n_leaves);
+        if (n_cells > (1ull << 21)) {      // (every level costs boxes x m x rows logarithms: a threshold this loose is not worth walking)
+            theta_set_error("theta_mix_search: %llu boxes within the threshold at level %llu: it is too far above the minimum", (unsigned long long)n_cells,
+                            (unsigned long long)levels);
+            if (stats) {
+                stats->boxes_tested = tested;
+                stats->levels = levels;
+                stats->max_boxes = max_cells;
+                stats->leaves = n_leaves;
+            }
+            return THETA_ERR_CAPACITY;
+        }
+        std::swap(cur, nxt);
+        if (levels > 400) {
+            theta_set_error("theta_mix_search: the octree did not terminate");
+            return THETA_ERR_HIP;
+        }
+    }
+    if (propose) {
+        // PROPOSALS instead of the exhaustive list: for the `cap` leaves of smallest bound, the matrix that fits the leaf's centre
+        // best -- per interval the row that minimises phi_i(c.v) --; valued by the caller, the best of them lowers the threshold
+        // of the next, finer, call
+        const uint64_t take_max = std::min<uint64_t>(n_leaves, 1ull << 20);
+        std::vector<MixCell> hl(take_max);
+        if (take_max) HIP_TRY(hipMemcpy(hl.data(), d_leaves.p, take_max * sizeof(MixCell), hipMemcpyDeviceToHost));
+        const uint64_t want = std::min<uint64_t>(cap, take_max);
+        std::partial_sort(hl.begin(), hl.begin() + want, hl.end(), [](const MixCell &a, const MixCell &b) { return a.lb < b.lb; });
+        std::vector<std::vector<unsigned char>> seen;
+        const N3Host &H = p->n3h;
+        uint64_t nw = 0;
+        for (uint64_t k = 0; k < want; k++) {
+            std::vector<unsigned char> mat((size_t)m * 2);
+            const double v0 = 0.5 * (hl[k].lo[0] + hl[k].hi[0]), v1 = 0.5 * (hl[k].lo[1] + hl[k].hi[1]), v2 = 0.5 * (hl[k].lo[2] + hl[k].hi[2]);
+            for (int i = 0; i < m; i++) {
+                double best = INFINITY;
+                int ba = 0, bb = 0;
+                for (int sidx = 0; sidx < Q_; sidx++) {
+                    const int a = H.rowtab[sidx] & 15, b = H.rowtab[sidx] >> 4;
+                    if (a < H.lb[i] || a > H.ub[i] || b < H.lb[i] || b > H.ub[i] || (p->tau - a) * (p->tau - b) < 0) continue;
+                    const double t = p->tau * v0 + a * v1 + b * v2;
+                    if (!(t > 0.0)) continue;
+                    const double val = p->h_r[i] > 0 ? p->h_rN[i] * t - p->h_r[i] * log(p->h_rN[i] * t) : p->h_rN[i] * t;
+                    if (val < best) {
+                        best = val;
+                        ba = a;
+                        bb = b;
+                    }
+                }
+                mat[2 * i] = (unsigned char)ba;
+                mat[2 * i + 1] = (unsigned char)bb;
+            }
+            if (std::find(seen.begin(), seen.end(), mat) != seen.end()) continue;
+            seen.push_back(mat);
+            memcpy(C + nw * (size_t)m * 2, mat.data(), (size_t)m * 2);
+            nw++;
+        }
+        *n_out = nw;
+        if (stats) {
+            stats->boxes_tested = tested;
+            stats->levels = levels;
+            stats->max_boxes = max_cells;
+            stats->leaves = n_leaves;
+            stats->matrices = nw;
+            stats->min_bound = want ? hl[0].lb : INFINITY;
+            stats->wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count();
+        }
+        return THETA_OK;
+    }
+    // the smallest bound among the leaves: a lower bound of the objective over everything the walk covers, up to the leaves' size
+    double min_leaf_bound = INFINITY;
+    if (n_leaves && n_leaves <= (1ull << 20)) {
+        std::vector<MixCell> hl(n_leaves);
+        HIP_TRY(hipMemcpy(hl.data(), d_leaves.p, n_leaves * sizeof(MixCell), hipMemcpyDeviceToHost));
+        for (const MixCell &c : hl) min_leaf_bound = std::min(min_leaf_bound, c.lb);
+    }
+    // the matrices of the leaves
+    mix_launch_list(A, (const MixCell *)d_leaves.p, n_leaves, (unsigned char *)d_mat.p, mat_cap, 64, (unsigned long long *)d_ctr.p, st);
+    unsigned long long fin[4];
+    HIP_TRY(hipMemcpyAsync(fin, d_ctr.p, sizeof(fin), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipEventRecord(p->ctx->ev1, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(hipGetLastError());
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, p->ctx->ev0, p->ctx->ev1));
+    const uint64_t listed = fin[2];
+    if (stats) {
+        stats->boxes_tested = tested;
+        stats->levels = levels;
+        stats->max_boxes = max_cells;
+        stats->leaves = n_leaves;
+        stats->listed = listed;
+        stats->kernel_ms = ms;
+        stats->min_bound = min_leaf_bound;
+    }
+    if (fin[3] > 0 || listed > mat_cap) {
+        theta_set_error("theta_mix_search: a leaf holds more matrices within the threshold than its walk may list (%llu listed, %llu cut off): "
+                        "lower the threshold or the leaf size", (unsigned long long)listed, (unsigned long long)fin[3]);
+        return THETA_ERR_CAPACITY;
+    }
+    std::vector<unsigned char> hm((size_t)listed * m);
+    if (listed) HIP_TRY(hipMemcpy(hm.data(), d_mat.p, hm.size(), hipMemcpyDeviceToHost));
+    // without duplicates (neighbouring leaves and corners list the same matrix), in the reference's order: lexicographic in the slots
+    std::vector<size_t> ix(listed);
+    for (size_t i = 0; i < listed; i++) ix[i] = i;
+    std::sort(ix.begin(), ix.end(), [&](size_t x, size_t y) { return memcmp(&hm[x * m], &hm[y * m], m) < 0; });
+    ix.erase(std::unique(ix.begin(), ix.end(), [&](size_t x, size_t y) { return memcmp(&hm[x * m], &hm[y * m], m) == 0; }), ix.end());
+    *n_out = ix.size();
+    if (stats) {
+        stats->matrices = ix.size();
+        stats->wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count();
+    }
+    if (ix.size() > cap) {
+        theta_set_error("theta_mix_search: %zu matrices but capacity is %llu", ix.size(), (unsigned long long)cap);
+        return THETA_ERR_CAPACITY;
+    }
+    // slots -> rows (a, b)
+    for (size_t k = 0; k < ix.size(); k++)
+        for (int i = 0; i < m; i++) {
+            const unsigned rw = p->n3h.rowtab[hm[ix[k] * m + i]];
+            C[(k * m + i) * 2] = (uint8_t)(rw & 15u);
+            C[(k * m + i) * 2 + 1] = (uint8_t)(rw >> 4);
+        }
     return THETA_OK;
 }
 

@@ -327,6 +327,25 @@ __global__ __launch_bounds__(256) void n3_task_kernel(N3Dev P, uint64_t b_lo, ui
     }
 }
 
+// The tasks of a search over SEVERAL rank ranges (theta_search_ranges: the survivors of a branch and bound): spec[t] = {first rank
+// lo, hi, candidates} as the host cut them; every task is unranked from the root.
+__global__ __launch_bounds__(256) void n3_task_list_kernel(N3Dev P, const uint64_t *spec, int ntasks, N3Task *tasks, unsigned *stbuf) {
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (t >= ntasks) return;
+    const u128 base = ((u128)spec[3 * t + 1] << 64) | spec[3 * t];
+    const int D = P.m - P.L;
+    u128 rem = 0;
+    const bool ok = n3_unrank_wave(P, base, D, lane, stbuf + (size_t)t * N3_STB, rem);
+    if (lane == 0) {
+        N3Task tk;
+        tk.base_lo = (uint64_t)base;
+        tk.base_hi = (uint64_t)(base >> 64);
+        tk.count = ok ? spec[3 * t + 2] : 0;
+        tk.skip = (uint64_t)rem;
+        tasks[t] = tk;
+    }
+}
+
 // one wave per tie record: its matrix
 __global__ __launch_bounds__(256) void n3_unrank_list_kernel(N3Dev P, const TieRecord *recs, int count, unsigned char *out) {
     __shared__ unsigned path[4][N3_MAX_M_WIDE];       // the packed nodes of the wave's path
@@ -1673,6 +1692,10 @@ void n3_launch_tasks(const N3Dev &P, u128 begin, u128 end, uint64_t per_task, in
     else anchor = nullptr;
     hipLaunchKernelGGL(n3_task_kernel, dim3((ntasks + 3) / 4), dim3(256), 0, st, P, (uint64_t)begin, (uint64_t)(begin >> 64),
                        (uint64_t)end, (uint64_t)(end >> 64), per_task, ntasks, tasks, stbuf, (const unsigned *)anchor);
+}
+
+void n3_launch_task_list(const N3Dev &P, const uint64_t *spec, int ntasks, N3Task *tasks, unsigned *stbuf, hipStream_t st) {
+    hipLaunchKernelGGL(n3_task_list_kernel, dim3((ntasks + 3) / 4), dim3(256), 0, st, P, spec, ntasks, tasks, stbuf);
 }
 
 void n3_launch_search(const N3Dev &P, const SearchArgs &A, const N3Task *tasks, const unsigned *stbuf, int ntasks,

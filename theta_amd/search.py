@@ -42,6 +42,15 @@ TIE_MARGIN = 10e-4        # Misc.py:36
 # nan_sweep; 2e8 - 5e8 candidates/s, so 2^33 take about half a minute -- the reference itself walks 4e2 candidates/s per process)
 NAN_SWEEP_MAX = int(float(os.environ.get("THETA_NAN_SWEEP_MAX", 2 ** 33)))
 COLLECT_WINDOW = 0.5      # how far above the minimum the GPU reports candidates (>> TIE_MARGIN)
+# n=3 spaces of at least this many matrices are searched by BRANCH AND BOUND above the prefix (theta_bnb + theta_search on the
+# surviving rank ranges) instead of rank by rank: 2^40 candidates are two seconds of the linear walk, BASELINE config 3 (4e27) is 3e8 years
+BNB_MIN_CANDIDATES = int(float(os.environ.get("THETA_BNB_MIN_CANDIDATES", 2 ** 40)))
+# ... and first of all by branch and bound over the MIXTURE space (theta_mix_search: an octree over mu, every box bounding all matrices at
+# once): a fraction of a second for BASELINE configs 3 and 4.  The row-tree walk (theta_bnb) is the fallback where that one gives up
+MIX_LEAF_REL = float(os.environ.get("THETA_MIX_LEAF_REL", 0))      # 0: from the data -- a fraction of the radius of the region of mixtures within the window, sqrt(2 window / sum r)
+USE_MIX = os.environ.get("THETA_USE_MIX", "1") != "0"
+BNB_BEAM = int(os.environ.get("THETA_BNB_BEAM", 1024))           # nodes per level of the dive that finds the first attainable NLL
+BNB_LINE_NODES = int(float(os.environ.get("THETA_BNB_LINE_NODES", 2 ** 22)))   # node budget of the walk that also follows collinear prefixes
 
 pre = "theta"             # prefix of the --GET_VALUES dump (the reference keeps it in a module global, RunTHetA.py:307-308)
 
@@ -121,6 +130,11 @@ class SearchReport(object):
                                            # reference RUN ON THIS HOST would report other values for rank-deficient candidates (its outcome there
                                            # hangs on the last bit of libm's pow(x, 2)); everything else is unaffected
         self.gpus = 1                      # ranks the search was sharded over (do_optimization with max_processes > 1)
+        self.mix = None                    # n=3 spaces of BNB_MIN_CANDIDATES matrices or more: what the mixture-space branch and bound did (mix_records)
+        self.bnb = None                    # n=3 spaces of BNB_MIN_CANDIDATES matrices or more: what the branch and bound did (bnb_plan) -- incumbent of the
+                                           # dive, threshold, nodes per depth, surviving rank ranges and the matrices in them, seconds;
+                                           # rank_deficient_complete False = collinear prefixes were bounded like the others (their matrices, which the
+                                           # reference values off their optimum, are only in `best` where their optimum is within the window)
 
 
 last_report = SearchReport()
@@ -137,9 +151,10 @@ def _full_matrix(c_u8, n, tau):
     return C
 
 
-def collect_finalists(problem, ctx, r, rN, max_normal, begin, end, window=COLLECT_WINDOW, report=None):
+def collect_finalists(problem, ctx, r, rN, max_normal, begin, end, window=COLLECT_WINDOW, report=None, ranges=None):
     """
-    GPU part: fused search over [begin, end) then the exact-order re-solve of the finalists.
+    GPU part: fused search over [begin, end) -- or over the rank ranges `ranges` a branch and bound left -- then the exact-order
+    re-solve of the finalists.
     Returns (records, stats); a record is dict(rank, c (uint8), mu (n floats), nll, vals (m floats)).
     """
     # A flat likelihood (a few reads per interval) can put more candidates within the window of the minimum than the device tie
@@ -147,7 +162,7 @@ def collect_finalists(problem, ctx, r, rN, max_normal, begin, end, window=COLLEC
     # minimum of the final cluster) -- so go again with a narrower one before giving up.
     for attempt, wnd in enumerate((window, window / 10.0, window / 50.0)):
         try:
-            res = problem.search(begin, end, window=wnd)
+            res = problem.search(begin, end, window=wnd) if ranges is None else problem.search_ranges(ranges, window=wnd)
             break
         except _lib.ListOverflow:
             # (ties, suspects or -- a piece of 2^20 candidates that still holds more rank-deficient ones than the list, with the
@@ -314,6 +329,318 @@ def _dump_values(problem, n, m, q1=None):
                     f.write(line * 2 if (n == 2 and b + i == 0) else line)
 
 
+def adjusted_bounds(lower_bounds, upper_bounds):
+    """Enumerator._check_bound_order (Enumerator.py:90-113) on copies: lb made non-decreasing front to back, ub back to front."""
+    lb, ub = [int(v) for v in lower_bounds], [int(v) for v in upper_bounds]
+    for i in range(1, len(lb)):
+        if lb[i] < lb[i - 1]:
+            lb[i] = lb[i - 1]
+    for i in reversed(range(len(ub) - 1)):
+        if ub[i] > ub[i + 1]:
+            ub[i] = ub[i + 1]
+    return lb, ub
+
+
+def in_space_n3(C, lb, ub, tau):
+    """Is the matrix with tumour columns C (m, 2) one Enumerator._generate_next_C_3 yields (Enumerator.py:172-242)?  Rows valid
+    ((tau - a)(tau - b) >= 0, :262-264) and within the (order-adjusted) bounds (:241); the symmetry rule (a <= b in the first row
+    and while every earlier row had a == b, :181-183, 199-202); every edge a repeat or an increase of some component
+    (:258-260); the ratio window of mu1 / mu2 never empty (:225-239, 212) -- exact rational arithmetic."""
+    from fractions import Fraction
+    m = len(C)
+    sw = True
+    lo, hi = None, None                                  # (None: unbounded)
+    for i in range(m):
+        a, b = int(C[i][0]), int(C[i][1])
+        if (tau - a) * (tau - b) < 0 or not (lb[i] <= a <= ub[i] and lb[i] <= b <= ub[i]):
+            return False
+        if sw and a > b:
+            return False
+        if i > 0:
+            pa, pb = int(C[i - 1][0]), int(C[i - 1][1])
+            if not ((a, b) == (pa, pb) or a > pa or b > pb):
+                return False
+            dx, dy = a - pa, b - pb
+            if dx != 0 and dy != 0:
+                ratio = Fraction(dy, -dx)
+                if dx > 0:
+                    lo = ratio if lo is None or ratio > lo else lo
+                else:
+                    hi = ratio if hi is None or ratio < hi else hi
+                if lo is not None and hi is not None and lo > hi:
+                    return False
+        sw = sw and a == b
+    return True
+
+
+def heuristic_incumbent(ctx, m, tau, lower_bounds, upper_bounds, r, rN, max_normal, rounds=40):
+    """
+    An NLL the reference really reports for SOME matrix of an n=3 space too large to walk -- the starting threshold of the branch
+    and bound (bnb_plan).  No reference counterpart (RunTHetA.py:173-220 visits every matrix).  For a fixed mixture mu the
+    likelihood -sum r_i ln(c_i.mu) + Rtot ln(sum rN_h c_h.mu) is maximised one interval at a time in closed form; with the
+    intervals sorted by their read-depth ratio (sort_r) the rows so chosen rise with c.mu, which is exactly what the
+    reference's row graph and ratio window ask of consecutive rows -- so the assignment for a mixture IS a matrix of the space
+    (checked: in_space_n3).  A grid of mixtures gives a few hundred matrices; theta_solve_batch values them the way the reference
+    would; the best goes through alternating (re-solve mu, re-assign rows) and a steepest-descent local search over single-row
+    changes, every trial again a matrix of the space valued by theta_solve_batch.  Returns (nll, C (m, 2) uint8) or (inf, None).
+    """
+    lb, ub = adjusted_bounds(lower_bounds, upper_bounds)
+    r = np.asarray(r, np.float64)
+    rN = np.asarray(rN, np.float64)
+    K = max(ub)
+    rows = np.array([(a, b) for b in range(K + 1) for a in range(K + 1) if (tau - a) * (tau - b) >= 0], np.int64)
+    allowed = [np.array([j for j, (a, b) in enumerate(rows) if lb[i] <= a <= ub[i] and lb[i] <= b <= ub[i]], np.int64) for i in range(m)]
+    if any(len(al) == 0 for al in allowed):
+        return float("inf"), None
+    Rtot = r.sum()
+
+    def assign(mu, C=None, sweeps=4):
+        """coordinate ascent on the rows for a fixed mixture; C: start (row indices per interval) or None = nearest ratio"""
+        f = tau * mu[0] + rows[:, 0] * mu[1] + rows[:, 1] * mu[2]              # c.mu per alphabet row
+        if C is None:
+            # start: the row whose c.mu is nearest the interval's ratio, scaled so that the mean ratio meets the mean c.mu
+            ratio = (r / rN) * (rN.sum() / Rtot)
+            scale = np.median(f)
+            C = np.array([al[np.argmin(np.abs(f[al] - ratio[i] * scale))] for i, al in enumerate(allowed)], np.int64)
+        C = C.copy()
+        Z = float((rN * f[C]).sum())
+        for _ in range(sweeps):
+            changed = False
+            for i in range(m):
+                al = allowed[i]
+                Zi = Z - rN[i] * f[C[i]]
+                with np.errstate(divide="ignore", invalid="ignore"):
+                    score = r[i] * np.log(f[al]) - Rtot * np.log(Zi + rN[i] * f[al])
+                score = np.where(f[al] > 0, score, -np.inf)
+                j = al[int(np.argmax(score))]
+                if j != C[i]:
+                    C[i] = j
+                    changed = True
+                Z = Zi + rN[i] * f[C[i]]
+            if not changed:
+                break
+        return C
+
+    def canon(C):
+        """the matrix of an assignment, with the tumour columns in the order the reference's symmetry rule wants"""
+        M = rows[C].copy()
+        for a, b in M:
+            if a != b:
+                if a > b:
+                    M = M[:, ::-1].copy()
+                break
+        return M
+
+    def value(mats):
+        mats = [M for M in mats if in_space_n3(M, lb, ub, tau)]
+        if not mats:
+            return [], np.zeros(0), np.zeros((0, 3))
+        arr = np.ascontiguousarray(np.array(mats, np.uint8))
+        ok, mu, nll, _v = ctx.solve_batch(3, tau, [int(x) for x in r], [int(x) for x in rN], arr, max_normal, want_vals=False)
+        nll = np.where((ok > 0) & (nll == nll), nll, np.inf)
+        return mats, nll, mu
+
+    seen, cands = set(), []
+    for mu0 in np.linspace(0.05, 0.9, 18):
+        for sp in np.linspace(0.05, 0.95, 19):
+            mu = np.array([mu0, (1 - mu0) * sp, (1 - mu0) * (1 - sp)])
+            M = canon(assign(mu))
+            key = M.tobytes()
+            if key not in seen:
+                seen.add(key)
+                cands.append(M)
+    mats, nll, mus = value(cands)
+    if not len(mats) or not np.isfinite(nll).any():
+        return float("inf"), None
+    best = int(np.argmin(nll))
+    bM, bv, bmu = mats[best], float(nll[best]), mus[best]
+    index = {(int(a), int(b)): j for j, (a, b) in enumerate(rows)}
+    for _round in range(rounds):
+        trials = []
+        # alternate: rows for the mixture the reference reports for the best matrix so far
+        if np.all(np.isfinite(bmu)) and bmu.min() >= 0:
+            for mu in (bmu, bmu[[0, 2, 1]]):
+                trials.append(canon(assign(mu, np.array([index[(int(a), int(b))] for a, b in bM], np.int64))))
+        # steepest descent: every single-row change
+        for i in range(m):
+            for j in allowed[i]:
+                if (rows[j][0], rows[j][1]) != (bM[i][0], bM[i][1]):
+                    T = bM.copy()
+                    T[i] = rows[j]
+                    trials.append(T)
+        mats, nll, mus = value(trials)
+        if not len(mats):
+            break
+        k = int(np.argmin(nll))
+        if not nll[k] < bv - 1e-9 * abs(bv):
+            break
+        bM, bv, bmu = mats[k], float(nll[k]), mus[k]
+    return bv, np.asarray(bM, np.uint8)
+
+
+def mix_records(problem, ctx, r, rN, max_normal, bounds, report=None, exchange=None, window=COLLECT_WINDOW):
+    """
+    The records of an n=3 space too large to walk, by branch and bound over the mixture space (theta_mix_search, csrc/bnb.hip):
+    what RunTHetA.py:173-220 would have kept of the whole space -- every matrix the reference reports within `window` of the
+    minimum, at its own optimum or at its nu = 1/3 fallback -- as replay records in enumeration order.
+      1. an attainable NLL: heuristic_incumbent (matrices built from a grid of mixtures, valued by theta_solve_batch);
+      2. theta_mix_search against that NLL + window: a superset of the matrices whose objective can be that low for SOME
+         mixture mu >= 0 -- any matrix the reference reports within the window is one, since what it reports is the objective at
+         a mixture;
+      3. the reference's own rules (in_space_n3: symmetry, ratio window) and its own procedure (theta_solve_batch) on each.
+    `rank` of a record is its position in the enumeration order among the listed matrices (theta_mix_search returns them in
+    that order), not its rank in the space.  Not found: matrices the reference reports BELOW their optimum or with a NaN
+    likelihood (rank-deficient ones; one full-rank matrix in a million) unless their optimum is within the window too.
+    Returns (records, stats-like dict); fills report.mix.  Raises ThetaError(ERR_CAPACITY) when too many boxes or matrices lie
+    within the window (a flat likelihood): the caller falls back to the row-tree walk.
+    """
+    import time
+    t0 = time.time()
+    lb, ub = adjusted_bounds(bounds[0], bounds[1])
+    hv, hC = heuristic_incumbent(ctx, problem.m, problem.tau, bounds[0], bounds[1], r, rN, max_normal)
+    info = {"heuristic_nll": hv if hv < float("inf") else None, "heuristic_seconds": time.time() - t0}
+    if not hv < float("inf"):
+        raise _lib.ThetaError(_lib.ERR_CAPACITY, "mixture-space search: no attainable NLL to start from")
+    inc = hv
+    if exchange is not None:
+        inc = float(exchange(inc))
+    # coarse passes first: the matrices that fit the centres of the best boxes are valued, and the best of them lowers the threshold
+    # of the next pass -- an incumbent a few units above the minimum leaves a region of mixtures thousands of leaves wide
+    info["passes"] = []
+    # leaves: boxes about as wide as the region of mixtures whose objective is within the window of a matrix's optimum (relative
+    # radius sqrt(2 window / sum r): the tangent bound is then off by a fraction of the window, and few leaves list each matrix)
+    leaf_final = MIX_LEAF_REL if MIX_LEAF_REL > 0 else min(5e-3, max(2e-5, 0.7 * float(np.sqrt(2.0 * max(window, 0.05) / max(float(np.sum(r)), 1.0)))))
+    info["leaf_rel"] = leaf_final
+    for leaf in (3e-2, 1e-2, 3e-3, 1e-3, 5e-4):
+        if leaf <= 2.0 * leaf_final:
+            break
+        try:
+            props, stp = problem.mix_search(inc + window + 4 * TIE_MARGIN, leaf_rel=leaf, cap=256, propose=True)
+        except _lib.ThetaError as e:
+            if e.code != _lib.ERR_CAPACITY:
+                raise
+            info["passes"].append({"leaf": leaf, "gave_up": True})
+            continue
+        pk = [M for M in props if in_space_n3(M, lb, ub, problem.tau)]
+        found = None
+        if pk:
+            okp, _mu, nllp, _v = ctx.solve_batch(3, problem.tau, r, rN, np.ascontiguousarray(np.array(pk, np.uint8)), max_normal, want_vals=False)
+            fin = [float(v) for v, o in zip(nllp, okp) if o and v == v]
+            if fin:
+                found = min(fin)
+                inc = min(inc, found)
+        info["passes"].append({"leaf": leaf, "leaves": stp["leaves"], "proposals": len(props), "in_space": len(pk), "best": found,
+                               "min_bound": stp["min_bound"], "ms": stp["wall_ms"]})
+    if exchange is not None:
+        inc = float(exchange(inc))
+    thr = inc + window + 4 * TIE_MARGIN
+    mats, st = problem.mix_search(thr, leaf_rel=leaf_final, cap=1 << 18)
+    keep = [i for i, M in enumerate(mats) if in_space_n3(M, lb, ub, problem.tau)]
+    recs = []
+    low = float("inf")
+    if keep:
+        arr = np.ascontiguousarray(mats[keep])
+        ok, mu, nll, vals = ctx.solve_batch(3, problem.tau, r, rN, arr, max_normal, want_vals=True)
+        fin = [float(v) for v, o in zip(nll, ok) if o and v == v]
+        low = min(fin) if fin else float("inf")
+        for j, i in enumerate(keep):
+            if ok[j] and (nll[j] != nll[j] or nll[j] <= low + window):
+                recs.append({"rank": i, "c": arr[j], "mu": mu[j].copy(), "nll": float(nll[j]), "vals": vals[j].copy(),
+                             "kind": "fallback" if ok[j] == 2 else "own"})
+    info.update(incumbent=inc, threshold=thr, minimum=low if low < float("inf") else None, listed=len(mats), in_space=len(keep), records=len(recs),
+                boxes_tested=st["boxes_tested"], levels=st["levels"], max_boxes=st["max_boxes"], leaves=st["leaves"], kernel_ms=st["kernel_ms"],
+                min_bound=st["min_bound"],
+                search_ms=st["wall_ms"], seconds=time.time() - t0)
+    if report is not None:
+        report.mix = info
+        report.fallback_finalists = sum(1 for t in recs if t["kind"] == "fallback")
+    stats = {"evaluated": 0, "kernel_ms": st["kernel_ms"], "boxes_tested": st["boxes_tested"]}
+    return recs, stats
+
+
+def bnb_plan(problem, ctx, r, rN, max_normal, report=None, exchange=None, window=COLLECT_WINDOW, bounds=None):
+    """
+    Which rank ranges of an n=3 space can hold an entry of `best`?  (RunTHetA.py:173-220 visits every rank; BASELINE configs 3
+    and 4 hold 4e27 / 2.6e38.)  Two walks of the row tree on the GPU (theta_bnb, csrc/bnb.hip):
+      1. a DIVE -- no pruning, every level keeps its BNB_BEAM smallest relaxed bounds -- whose few ranges are searched for the
+         first NLL the reference really reports for some matrix (finalists in reference arithmetic; nu = 1/3 fallbacks count);
+      2. the EXACT walk against that NLL + `window`: every node whose relaxed lower bound lies beyond is dropped with its
+         subtree; what survives comes back as rank ranges.  Every matrix whose optimum is within `window` of the minimum of
+         the space lies in one of them -- finalists and suspects of an exhaustive search alike.
+    Rank-deficient matrices (rows on one line) are valued by the reference OFF their optimum; the walk first
+    tries to keep every collinear prefix (BNB_LINE_NODES nodes at most: small spaces), so that they all lie in the ranges too;
+    where that is infeasible -- 1e21 such prefixes at m = 50 -- they are bounded like anything else and the report says so.
+    Returns (ranges, incumbent); fills report.bnb.
+    """
+    import time
+    t0 = time.time()
+    info = {"dive": [], "incumbent": None, "threshold": None}
+    inc = float("inf")
+    if bounds is not None:
+        # (a) the assignment heuristic: matrices of the space built from a grid of mixtures, valued by the reference's procedure
+        th = time.time()
+        hv, hC = heuristic_incumbent(ctx, problem.m, problem.tau, bounds[0], bounds[1], r, rN, max_normal)
+        info["heuristic"] = {"nll": hv if hv < float("inf") else None, "seconds": time.time() - th}
+        inc = hv
+    beam = BNB_BEAM
+    for _attempt in range(3):
+        rg, st = problem.bnb(float("inf"), beam=beam)
+        problem.set_option("n3_nan_sweep", 0)
+        res = problem.search_ranges(rg, window=0.0)
+        vals = []
+        if len(res["rank"]):
+            ok, _mu, nll, _v = ctx.solve_batch(3, problem.tau, r, rN, res["C"], max_normal, want_vals=False)
+            vals += [float(v) for v, o in zip(nll, ok) if o and v == v]
+        sus = problem.last_suspects
+        if len(sus[0]):
+            ok, _mu, nll, _v = ctx.solve_batch(3, problem.tau, r, rN, sus[2], max_normal, want_vals=False)
+            vals += [float(v) for v, o in zip(nll, ok) if o and v == v]
+        info["dive"].append({"beam": beam, "ranges": len(rg), "leaves": st["leaves"], "nodes": st["nodes_expanded"], "bnb_ms": st["wall_ms"],
+                             "found": min(vals) if vals else None})
+        if vals:
+            inc = min(inc, min(vals))
+        if inc < float("inf"):
+            break
+        beam *= 8
+    if not inc < float("inf"):
+        raise _lib.ThetaError(_lib.ERR_NO_CANDIDATES, "branch and bound: the dive found no matrix the reference accepts")
+    if exchange is not None:
+        inc = float(exchange(inc))
+    thr = inc + window + 4 * TIE_MARGIN
+    ranges = st = None
+    complete_lines = True
+    try:
+        ranges, st = problem.bnb(thr, follow_collinear=True, max_nodes=BNB_LINE_NODES)
+    except _lib.ThetaError as e:
+        if e.code != _lib.ERR_OVERFLOW:
+            raise
+        complete_lines = False
+        ranges, st = problem.bnb(thr)
+    info.update(incumbent=inc, threshold=thr, ranges=len(ranges), leaves=st["leaves"], nodes=st["nodes_expanded"],
+                children_bounded=st["children_bounded"], newton_iterations=st["newton_iterations"], pruned=st["children_pruned"],
+                max_frontier=st["max_frontier"], frontier=st["frontier"], emit_depth=st["emit_depth"], kernel_ms=st["kernel_ms"],
+                bnb_ms=st["wall_ms"], rank_deficient_complete=complete_lines, plan_seconds=time.time() - t0)
+    if report is not None:
+        report.bnb = info
+    return ranges, inc
+
+
+def _share_of_ranges(ranges, g, G):
+    """Rank g's part of the ranges: equal numbers of matrices, cut at rank boundaries (the ranges are in rank order)."""
+    if G <= 1:
+        return list(ranges)
+    total = sum(e - b for b, e in ranges)
+    lo, hi = total * g // G, total * (g + 1) // G
+    out, seen = [], 0
+    for b, e in ranges:
+        n = e - b
+        a0, a1 = max(lo - seen, 0), min(hi - seen, n)
+        if a1 > a0:
+            out.append((b + a0, b + a1))
+        seen += n
+    return out
+
+
 def _make_problem(ctx, n, m, tau, lower_bounds, upper_bounds, r, rN, max_normal):
     problem = _lib.Problem(ctx, n, m, tau, [int(x) for x in r], [int(x) for x in rN], [int(v) for v in lower_bounds],
                            [int(v) for v in upper_bounds], max_normal)
@@ -339,18 +666,39 @@ def _search_local(n, m, tau, lower_bounds, upper_bounds, r, rN, max_normal, shar
     g, G = shard
     begin = problem.count * g // G
     end = problem.count * (g + 1) // G
-    if hint_exchange is not None:
+    use_bnb = (n == 3 and getattr(problem, "_h", None) is not None and BNB_MIN_CANDIDATES <= problem.count < 2 ** 128 - 1 and m >= 8)
+    my_ranges = None
+    if n == 3 and getattr(problem, "_h", None) is not None and BNB_MIN_CANDIDATES <= problem.count and USE_MIX:
+        # branch and bound over the mixture space: the whole space at once, on every rank alike (a fraction of a second); rank 0
+        # alone contributes the records to the exchange of a sharded run
+        try:
+            recs, stats = mix_records(problem, ctx, r, rN, max_normal, (lower_bounds, upper_bounds), report=report, exchange=hint_exchange)
+            if report is not None:
+                report.nan_sweep = False
+            return problem, ctx, (recs if g == 0 else []), stats
+        except _lib.ThetaError as e:
+            if e.code != _lib.ERR_CAPACITY:
+                raise
+            if report is not None:
+                report.mix = {"gave_up": str(e)}
+    if use_bnb:
+        # every rank plans the whole space (the walk is deterministic and takes a fraction of a second) and searches its share of
+        # the surviving ranges; the dive's minimum is agreed on first (hint_exchange: the all-reduce of a sharded search)
+        all_ranges, inc = bnb_plan(problem, ctx, r, rN, max_normal, report=report, exchange=hint_exchange, bounds=(lower_bounds, upper_bounds))
+        my_ranges = _share_of_ranges(all_ranges, g, G)
+        problem.hint(inc)
+    elif hint_exchange is not None:
         local = problem._probe(begin, end) if end > begin else float("inf")
         shared = hint_exchange(local)
         if shared < float("inf"):
             problem.hint(shared)
     if n == 3:
-        sweep = problem.count <= NAN_SWEEP_MAX
+        sweep = problem.count <= NAN_SWEEP_MAX and not use_bnb
         problem.set_option("n3_nan_sweep", 1 if sweep else 0)
         if report is not None:
             report.nan_sweep = sweep
     def gather(b, e):
-        rc, st = collect_finalists(problem, ctx, r, rN, max_normal, b, e, report=report)
+        rc, st = collect_finalists(problem, ctx, r, rN, max_normal, b, e, report=report, ranges=my_ranges)
         if n == 3:
             rc = rc + fallback_records(problem, ctx, r, rN, max_normal, rc, report=report)
             # rank-deficient candidates: the listed outcome (the reference's own procedure) is THE outcome -- a None included --,
@@ -361,7 +709,7 @@ def _search_local(n, m, tau, lower_bounds, upper_bounds, r, rN, max_normal, shar
             rc = rc + degenerate_records(problem, ctx, r, rN, max_normal, report=report)
         return rc, st
     recs, stats = gather(begin, end)
-    if n == 3 and not sweep and G == 1 and NAN_SWEEP_MAX > 0:
+    if n == 3 and not sweep and G == 1 and NAN_SWEEP_MAX > 0 and not use_bnb:
         # A space too large to sweep whole.  The reference only KEEPS a NaN tuple that stands behind the last replacement of its
         # running minimum (a replacement starts a new list, RunTHetA.py:198-206): the ranks before the first entry of `best`
         # cannot contribute one.  If the tail behind that entry is short enough, it alone is swept -- searched once more with the
