@@ -456,6 +456,31 @@ def extras(ctx, cpu_seconds):
                                "reference_note": "the reference CLI's n=3 stage on this input, one process, build container"}
     except Exception as ex:
         w["syn14_n3_stage"] = {"error": str(ex)}
+    # BASELINE configs 3 and 4 -- synthetic m = 50 intervals, n = 3, k = 4 / 6, FULL bounds: 4e27 / 2.6e38 matrices, which neither the
+    # reference's loop nor any rank-by-rank kernel finishes -- searched WHOLE by branch and bound over the mixture space
+    # (theta_mix_search behind do_optimization_single, csrc/bnb.hip; tests/test_gpu_bnb.py: identical to the exhaustive search on
+    # whole spaces of 1e6-1e9 matrices and to reference-written lists).  config 4 is this bench's own instance.
+    from theta_amd import search as _S
+    for key, kk, sd in (("config3_m50_n3_k4", 4, 7), ("config4_m50_n3_k6", K_MAX, SEED)):
+        try:
+            r3, rN3, order3 = synth(seed=sd, m=50, n=3, k=kk)
+            ts = []
+            for _ in range(3):
+                t = time.time()
+                b3 = do_optimization_single(3, 50, kk, TAU, [0] * 50, [kk] * 50, r3, rN3, 1.0, order3, False, False)
+                ts.append(time.time() - t)
+            rp = _S.last_report
+            mx = rp.mix or {}
+            w[key] = {"candidates": float(rp.candidates), "gpu_wall_s": min(ts), "nll": b3[0][2], "entries": len(b3),
+                      "mu": [float(x) for x in b3[0][1]],
+                      "method": "branch and bound over the mixture space (theta_mix_search) + the reference's procedure on the listed matrices",
+                      "boxes_tested": mx.get("boxes_tested"), "leaves": mx.get("leaves"), "matrices_listed": mx.get("listed"),
+                      "octree_kernel_ms": mx.get("kernel_ms"), "smallest_leaf_bound": mx.get("min_bound"), "incumbent_heuristic": mx.get("heuristic_nll"),
+                      "reference_estimate_s": float(rp.candidates) / 30.0,
+                      "reference_note": "the reference visits every matrix at ~30 per second and process (BASELINE.md): no run of it can finish",
+                      "not_included": "matrices the reference reports off their optimum: rank-deficient ones, NaN outcomes (DESIGN.md section 8)"}
+        except Exception as ex:
+            w[key] = {"error": str(ex)[:200]}
     r2, rN2, order2 = synth(seed=11, m=25, n=2, k=5)
     ts = []
     for _ in range(3):
@@ -735,7 +760,6 @@ def main():
                                   "l2_last_max": float(np.nanmax(rec["l2_last"][reg])) if reg.any() else 0.0,
                                   "l2_first_median": float(np.nanmedian(rec["l2_first"][reg])) if reg.any() else 0.0,
                                   "conv_l2": certified_conv_l2(r) if head_opts.get("n3_conv_l2") == "certified" else head_opts.get("n3_conv_l2", 1e-4),
-                                  "counters_equal_timed_kernel": None,
                                   "note": "l2_last = lambda^2 / sum r found by a candidate's LAST evaluation; the candidate is left one full "
                                           "Newton step beyond it (certified below 1e-12 when l2_last <= conv_l2)"}
             except Exception as ex:

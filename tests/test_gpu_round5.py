@@ -77,14 +77,14 @@ def _check_leg(ctx, p, name, opts, left_l2, b, e, shift, rr, rn, tau, hint, n_or
         _set(p, opts, False)
     ps = plain["stats"]
     # The witness build makes the decisions of the timed kernel: the two runs' counters agree -- to the last candidate for the
-    # FP64 legs.  (The packed-FP32 instantiation is allowed 2e-4: the two objects are separate compilations whose single-precision
+    # FP64 legs.  (The packed-FP32 instantiation is allowed 1e-3: the two objects are separate compilations whose single-precision
     # sums round differently here and there, and where the arithmetic is ill-conditioned -- the first ranks of the space, whose
     # prefix rows are all (0, 0); the last ones, whose optima lie outside the simplex -- a candidate in 10^4 takes one evaluation
     # more or fewer, or is listed as a contender by one build only (the finish kernel then counts it in `accepted`).  Run to
     # run each build is exactly reproducible.)
     for k in ("evaluated", "iterations", "terms", "flops", "flops_f32", "dismissed", "survivors", "degenerate", "accepted"):
         if "f32" in name and k in ("iterations", "terms", "flops", "flops_f32", "survivors", "accepted"):
-            assert abs(st[k] - ps[k]) <= 2e-4 * ps[k] + 2, (what, name, k, st[k], ps[k])
+            assert abs(st[k] - ps[k]) <= 1e-3 * ps[k] + 2, (what, name, k, st[k], ps[k])
         else:
             assert st[k] == ps[k], (what, name, k, st[k], ps[k])
     assert st["evaluated"] == e - b and st["dismissed"] == 0 and st["fallback_candidates"] == 0, (what, name, st)

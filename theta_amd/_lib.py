@@ -779,7 +779,7 @@ class Problem:
             n_out = C.c_uint64(0)
             rc = load().theta_bnb(self._h, float(threshold), int(beam), 1 if follow_collinear else 0, int(max_nodes), int(cap),
                                   _p(out, C.c_uint64), C.byref(n_out), C.byref(st))
-            if rc == ERR_CAPACITY and n_out.value > cap and cap < (1 << 26):
+            if rc == ERR_CAPACITY and n_out.value > cap and cap < (1 << 22):
                 cap = max(int(n_out.value), 4 * cap)
                 continue
             self.last_bnb = st.as_dict(self.m)

@@ -792,8 +792,12 @@ static int run_search(theta_problem *p, u128 b, u128 e, double window, double *d
                     // tenth of the bench's candidates looked like contenders in one stretch of twenty).  One short slice first --
                     // 2048 tasks, one round of the resident waves, 1/32 of a full call -- lets the finish kernel lower the
                     // minimum on a sample of the range before the bulk is judged against it.
+                    // (round 5: and before that one, FOUR tasks -- 2^16 candidates of the range, a fraction of a millisecond --, so that even the
+                    // short slice is judged against a minimum this range attains: with a stale hint it listed a tenth of its 3e7
+                    // candidates as contenders, which is what made one step in twenty cost twice the median)
                     if (t == 0 && ntasks >= 8 * 2048) {
-                        slices.push_back({0, 2048});
+                        slices.push_back({0, 4});
+                        slices.push_back({4, 2044});
                         t = 2048;
                     }
                     while (t < ntasks) {

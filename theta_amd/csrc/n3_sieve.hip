@@ -457,7 +457,7 @@ __device__ __forceinline__ bool sv_sums(const SvCtx<ML, F, NS> &c, const unsigne
 
 // A contender (or a record the sieve cannot handle): rows and rank to the device list; the finish kernel takes it from there.
 template <int ML, class F, int NS>
-__device__ __forceinline__ void sv_survivor(const SvCtx<ML, F, NS> &c, const unsigned (&rw)[ML / 2], unsigned off) {
+__device__ __forceinline__ void sv_survivor(const SvCtx<ML, F, NS> &c, const unsigned (&rw)[ML / 2], unsigned off, F u1, F u2) {
     const unsigned idx = atomicAdd(c.surv_count, 1u);
     atomicAdd(&c.A.ctr->sieve_survivors, 1ull);
     if (idx >= c.surv_cap) return;            // the host sees the count and redoes the slice
@@ -465,6 +465,8 @@ __device__ __forceinline__ void sv_survivor(const SvCtx<ML, F, NS> &c, const uns
     const u128 rk = c.base + off;
     s->rank_lo = (uint64_t)rk;
     s->rank_hi = (uint64_t)(rk >> 64);
+    s->u1 = (double)u1;                       // (round 5: the finish kernel starts its FP64 Newton from the sieve's iterate, not from the simplex centre)
+    s->u2 = (double)u2;
     unsigned short *dst = (unsigned short *)s->rows;
     for (int i = 0; i < c.D; i++) dst[i] = c.W->pre[i];
 #pragma unroll
@@ -584,7 +586,7 @@ __device__ __forceinline__ void sv_drain(SvCtx<ML, F, NS> &c) {
             }
             SV_WIT(if (fin) sv_witness<ML, F, NS>(c, qy >> 8, wst, (unsigned)iters, l0, l2, val2, s1, s2, u1, u2);)
         }
-        if (surv) sv_survivor<ML, F, NS>(c, rw, qy >> 8);
+        if (surv) sv_survivor<ML, F, NS>(c, rw, qy >> 8, iters >= 40 ? F(__builtin_nanf("")) : u1, u2);
         if (fin) {
             live = false;
         }
@@ -883,7 +885,7 @@ __device__ __forceinline__ void sv_children(SvCtx<ML, F, NS> &c, int total) {
                 if (o.surv) {
                     unsigned rw[ML / 2];
                     sv_child_rows<ML, F, NS>(c, o.code, o.slot, rw);
-                    sv_survivor<ML, F, NS>(c, rw, o.off);
+                    sv_survivor<ML, F, NS>(c, rw, o.off, o.c1, o.c2);
                 }
             }
             if (pm) {
@@ -1521,9 +1523,23 @@ __global__ __launch_bounds__(256) void n3_finish_kernel(N3Dev P, SearchArgs A, c
         }
     };
     // Newton from the simplex centre (interior for every candidate), to lambda^2 / Rtot < 1e-12
+    // Newton from the iterate the sieve left the contender at (converged to its tolerance there: one or two steps to 1e-12 instead of
+    // six to eight from the simplex centre -- a step that runs into a region better than its hint lists millions of contenders);
+    // the centre where there is none, or where it is not a point of the domain
     N3Newton T;
     T.u1 = T.p1 = (1.0 / 3.0) / s1;
     T.u2 = T.p2 = (1.0 / 3.0) / s2;
+    if (sv->u1 == sv->u1 && sv->u2 == sv->u2 && fabs(sv->u1) + fabs(sv->u2) < 1e30) {
+        bool inside = true;
+        for (int i = 0; i < m; i++) {
+            const unsigned rw = myrows[i];
+            inside = inside && (rr[i] <= 0.0 || __builtin_fma((double)(rw & 0xffu) - s1, sv->u1, __builtin_fma((double)(rw >> 8) - s2, sv->u2, 1.0)) > 0.0);
+        }
+        if (inside) {
+            T.u1 = T.p1 = sv->u1;
+            T.u2 = T.p2 = sv->u2;
+        }
+    }
     T.iters = 0;
     T.status = 0;
     T.singular = false;

@@ -6,6 +6,7 @@
 // sieve could not handle).  rows = the whole matrix, m x {a, b} bytes.
 struct SvSurvivor {
     uint64_t rank_lo, rank_hi;
+    double u1, u2;               // the iterate the sieve left it at (the finish kernel's Newton starts there; NaN: from the simplex centre)
     unsigned char rows[2 * N3_MAX_M_WIDE];
 };
 

@@ -50,6 +50,7 @@ BNB_MIN_CANDIDATES = int(float(os.environ.get("THETA_BNB_MIN_CANDIDATES", 2 ** 4
 MIX_LEAF_REL = float(os.environ.get("THETA_MIX_LEAF_REL", 0))      # 0: from the data -- a fraction of the radius of the region of mixtures within the window, sqrt(2 window / sum r)
 USE_MIX = os.environ.get("THETA_USE_MIX", "1") != "0"
 BNB_BEAM = int(os.environ.get("THETA_BNB_BEAM", 1024))           # nodes per level of the dive that finds the first attainable NLL
+BNB_MAX_NODES = int(float(os.environ.get("THETA_BNB_MAX_NODES", 2 ** 27)))     # node budget of the row-tree walk (a minute of the GPU): beyond, the call gives up
 BNB_LINE_NODES = int(float(os.environ.get("THETA_BNB_LINE_NODES", 2 ** 22)))   # node budget of the walk that also follows collinear prefixes
 
 pre = "theta"             # prefix of the --GET_VALUES dump (the reference keeps it in a module global, RunTHetA.py:307-308)
@@ -615,7 +616,7 @@ def bnb_plan(problem, ctx, r, rN, max_normal, report=None, exchange=None, window
         if e.code != _lib.ERR_OVERFLOW:
             raise
         complete_lines = False
-        ranges, st = problem.bnb(thr)
+        ranges, st = problem.bnb(thr, max_nodes=BNB_MAX_NODES)
     info.update(incumbent=inc, threshold=thr, ranges=len(ranges), leaves=st["leaves"], nodes=st["nodes_expanded"],
                 children_bounded=st["children_bounded"], newton_iterations=st["newton_iterations"], pruned=st["children_pruned"],
                 max_frontier=st["max_frontier"], frontier=st["frontier"], emit_depth=st["emit_depth"], kernel_ms=st["kernel_ms"],
@@ -666,9 +667,11 @@ def _search_local(n, m, tau, lower_bounds, upper_bounds, r, rN, max_normal, shar
     g, G = shard
     begin = problem.count * g // G
     end = problem.count * (g + 1) // G
-    use_bnb = (n == 3 and getattr(problem, "_h", None) is not None and BNB_MIN_CANDIDATES <= problem.count < 2 ** 128 - 1 and m >= 8)
+    # (what decides is the size of THIS rank's share: a shard of a few million ranks of a huge space is walked like any range)
+    big = n == 3 and getattr(problem, "_h", None) is not None and end - begin >= BNB_MIN_CANDIDATES
+    use_bnb = big and problem.count < 2 ** 128 - 1 and m >= 8
     my_ranges = None
-    if n == 3 and getattr(problem, "_h", None) is not None and BNB_MIN_CANDIDATES <= problem.count and USE_MIX:
+    if big and USE_MIX:
         # branch and bound over the mixture space: the whole space at once, on every rank alike (a fraction of a second); rank 0
         # alone contributes the records to the exchange of a sharded run
         try:
@@ -684,7 +687,14 @@ def _search_local(n, m, tau, lower_bounds, upper_bounds, r, rN, max_normal, shar
     if use_bnb:
         # every rank plans the whole space (the walk is deterministic and takes a fraction of a second) and searches its share of
         # the surviving ranges; the dive's minimum is agreed on first (hint_exchange: the all-reduce of a sharded search)
-        all_ranges, inc = bnb_plan(problem, ctx, r, rN, max_normal, report=report, exchange=hint_exchange, bounds=(lower_bounds, upper_bounds))
+        try:
+            all_ranges, inc = bnb_plan(problem, ctx, r, rN, max_normal, report=report, exchange=hint_exchange, bounds=(lower_bounds, upper_bounds))
+        except _lib.ThetaError as e:
+            if e.code not in (_lib.ERR_CAPACITY, _lib.ERR_OVERFLOW):
+                raise
+            # neither branch and bound gets through (a likelihood too flat to prune by: few reads, or many intervals of equal ratio)
+            raise _lib.ThetaError(_lib.ERR_OVERFLOW, "%d candidate matrices, and the likelihood is too flat for either branch and bound to "
+                                  "prune the space (%s)" % (problem.count, str(e)[:120]))
         my_ranges = _share_of_ranges(all_ranges, g, G)
         problem.hint(inc)
     elif hint_exchange is not None:

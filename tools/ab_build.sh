@@ -8,7 +8,7 @@ mkdir -p build_ab
 unit=${UNIT:-n3}
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -fno-gpu-rdc -Wno-unused-function "$@" -c theta_amd/csrc/$unit.hip -o build_ab/${unit}_$name.o
 objs=""
-for u in n2 n3 n3_enum n3_sieve batch api comm; do
+for u in n2 n3 n3_enum n3_sieve n3_sieve_witness bnb batch api comm; do
     if [ "$u" = "$unit" ]; then objs="$objs build_ab/${unit}_$name.o"; else objs="$objs theta_amd/csrc/$u.o"; fi
 done
 /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o build_ab/lib$name.so $objs
