@@ -302,9 +302,11 @@ def test_prefixes_finished_by_the_prefix_bound_change_no_list(ctx):
     ra, rNa, _ = bench.synth(seed=14, m=16, n=3, k=3)
     ra = list(ra)
     ra[0], ra[7] = 3, 11
-    cases.append(("m16 k3 tiny Rmin", 16, ra, rNa, [0] * 16, [3] * 16, [("mid", 1 << 24)], 2))
+    # (round 5: the GPU suite's time -- 2^21 instead of 2^24 candidates here, a third of the tau = 3 space instead of the whole: the host
+    # side of these two, suspects and rank-deficient lists by the million, was 130 of the suite's 620 seconds)
+    cases.append(("m16 k3 tiny Rmin", 16, ra, rNa, [0] * 16, [3] * 16, [("mid", 1 << 21)], 2))
     rb, rNb, _ = bench.synth(seed=15, m=12, n=3, k=4)
-    cases.append(("m12 k4 tau3", 12, rb, rNb, [0] * 12, [4] * 12, [("all", None)], 3))
+    cases.append(("m12 k4 tau3", 12, rb, rNb, [0] * 12, [4] * 12, [("mid", 1 << 27)], 3))
     pruned_total = 0
     for name, m, rr, rn, lb, ub, ranges, tau in cases:
         p = theta_amd.Problem(ctx, 3, m, tau, rr, rn, lb, ub, 1.0)
