@@ -410,8 +410,15 @@ void bnb_launch_compact(const BnbNode *nodes, const unsigned char *paths, unsign
 // below, and a depth-first walk over the intervals with the budget `threshold` lists the few matrices that fit (mix_list_kernel).
 // The host values those with the reference's own procedure (theta_solve_batch) and replays them in enumeration order.
 // ====================================================================================================================================
-// the bound of a box: max of the two (see above).  rows in LDS as (a, b); one THREAD per box.
-__device__ double mix_cell_bound(const MixArgs &A, const MixCell &c, const float2 *rows, const unsigned long long *allowed_unused) {
+// the bound of a box: max of the two (see above).  One WAVE per box: lane l takes the intervals l, 64 + l, ... (m x rows x 2 logarithms
+// are half a millisecond of one thread -- a level of the octree holds a handful of boxes as often as a million, and its 60 levels
+// are walked one launch after the other), the nine partial sums meet by shuffles.
+__device__ __forceinline__ double mix_wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
+    return v;
+}
+__device__ double mix_cell_bound(const MixArgs &A, const MixCell &c, const float2 *rows, int lane) {
     const double tau = (double)A.tau;
     double vc[3], h[3];
     for (int j = 0; j < 3; j++) {
@@ -420,7 +427,7 @@ __device__ double mix_cell_bound(const MixArgs &A, const MixCell &c, const float
     }
     double lb1 = 0.0, lbv[8];
     for (int k = 0; k < 8; k++) lbv[k] = 0.0;
-    for (int i = 0; i < A.m; i++) {
+    for (int i = lane; i < A.m; i += WAVE) {
         const double r = A.r[i], N = A.rN[i], ts = r / N;
         const int l = A.lb[i], u = A.ub[i];
         double best1 = __builtin_inf(), bestv[8];
@@ -432,7 +439,7 @@ __device__ double mix_cell_bound(const MixArgs &A, const MixCell &c, const float
             const double x = (double)a, y = (double)b;
             const double tlo = tau * c.lo[0] + x * c.lo[1] + y * c.lo[2], thi = tau * c.hi[0] + x * c.hi[1] + y * c.hi[2];
             // (1) phi at the point of [tlo, thi] nearest ts
-            double t = ts < tlo ? tlo : (ts > thi ? thi : ts);
+            const double t = ts < tlo ? tlo : (ts > thi ? thi : ts);
             double v1;
             if (r > 0.0) v1 = t > 0.0 ? N * t - r * log(N * t) : __builtin_inf();
             else v1 = N * t;
@@ -454,20 +461,22 @@ __device__ double mix_cell_bound(const MixArgs &A, const MixCell &c, const float
         lb1 += best1;
         for (int k = 0; k < 8; k++) lbv[k] += bestv[k];
     }
-    double lb2 = lbv[0];
-    for (int k = 1; k < 8; k++) lb2 = fmin(lb2, lbv[k]);
+    lb1 = mix_wave_sum(lb1);
+    double lb2 = __builtin_inf();
+    for (int k = 0; k < 8; k++) lb2 = fmin(lb2, mix_wave_sum(lbv[k]));
     return fmax(lb1, lb2) + A.cst;
 }
 
-// One thread per CHILD of a surviving box: the parent is cut in two along its widest side (widths weighted by the largest copy
+// One wave per CHILD of a surviving box: the parent is cut in two along its widest side (widths weighted by the largest copy
 // number they multiply), the child's bound decides whether it goes on -- to the next level's list, or, small enough, to the leaves.
-__global__ __launch_bounds__(128) void mix_split_kernel(MixArgs A, const MixCell *in, unsigned long long n_in, MixCell *out, unsigned long long out_cap,
+__global__ __launch_bounds__(256) void mix_split_kernel(MixArgs A, const MixCell *in, unsigned long long n_in, MixCell *out, unsigned long long out_cap,
                                                         MixCell *leaves, unsigned long long leaf_cap, unsigned long long *counters) {
     __shared__ float2 rows[N3_MAX_Q];
     for (int s = threadIdx.x; s < A.Q; s += blockDim.x) rows[s] = make_float2((float)(A.rowtab[s] & 15u), (float)(A.rowtab[s] >> 4));
     __syncthreads();
-    const unsigned long long k = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= 2 * n_in) return;
+    const int lane = threadIdx.x & 63;
+    const unsigned long long k = (unsigned long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (k >= 2 * n_in) return;            // (whole waves leave)
     MixCell c = in[k >> 1];
     int ax = 0;
     double wbest = -1.0;
@@ -480,8 +489,8 @@ __global__ __launch_bounds__(128) void mix_split_kernel(MixArgs A, const MixCell
     }
     const double mid = 0.5 * (c.lo[ax] + c.hi[ax]);
     if (k & 1) c.lo[ax] = mid; else c.hi[ax] = mid;
-    const double lb = mix_cell_bound(A, c, rows, nullptr);
-    if (!(lb <= A.thr)) return;
+    const double lb = mix_cell_bound(A, c, rows, lane);
+    if (!(lb <= A.thr) || lane != 0) return;
     c.lb = lb;
     bool leaf = true;
     for (int j = 0; j < 3; j++) leaf = leaf && (c.hi[j] - c.lo[j]) <= A.leaf[j];
@@ -585,7 +594,7 @@ __global__ __launch_bounds__(64) void mix_list_kernel(MixArgs A, const MixCell *
 void mix_launch_split(const MixArgs &A, const MixCell *in, unsigned long long n_in, MixCell *out, unsigned long long out_cap, MixCell *leaves,
                       unsigned long long leaf_cap, unsigned long long *counters, hipStream_t st) {
     if (!n_in) return;
-    hipLaunchKernelGGL(mix_split_kernel, dim3((unsigned)((2 * n_in + 127) / 128)), dim3(128), 0, st, A, in, n_in, out, out_cap, leaves, leaf_cap, counters);
+    hipLaunchKernelGGL(mix_split_kernel, dim3((unsigned)((2 * n_in + 3) / 4)), dim3(256), 0, st, A, in, n_in, out, out_cap, leaves, leaf_cap, counters);
 }
 void mix_launch_list(const MixArgs &A, const MixCell *leaves, unsigned long long n_leaves, unsigned char *out, unsigned long long out_cap, int per_thread_cap,
                      unsigned long long *counters, hipStream_t st) {

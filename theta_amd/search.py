@@ -346,11 +346,10 @@ def in_space_n3(C, lb, ub, tau):
     """Is the matrix with tumour columns C (m, 2) one Enumerator._generate_next_C_3 yields (Enumerator.py:172-242)?  Rows valid
     ((tau - a)(tau - b) >= 0, :262-264) and within the (order-adjusted) bounds (:241); the symmetry rule (a <= b in the first row
     and while every earlier row had a == b, :181-183, 199-202); every edge a repeat or an increase of some component
-    (:258-260); the ratio window of mu1 / mu2 never empty (:225-239, 212) -- exact rational arithmetic."""
-    from fractions import Fraction
+    (:258-260); the ratio window of mu1 / mu2 never empty (:225-239, 212) -- exact: ratios compared by cross-multiplication."""
     m = len(C)
     sw = True
-    lo, hi = None, None                                  # (None: unbounded)
+    lo = hi = None                                       # ratio bounds as (numerator, denominator > 0); None: unbounded
     for i in range(m):
         a, b = int(C[i][0]), int(C[i][1])
         if (tau - a) * (tau - b) < 0 or not (lb[i] <= a <= ub[i] and lb[i] <= b <= ub[i]):
@@ -363,12 +362,14 @@ def in_space_n3(C, lb, ub, tau):
                 return False
             dx, dy = a - pa, b - pb
             if dx != 0 and dy != 0:
-                ratio = Fraction(dy, -dx)
+                ratio = (dy, -dx) if dx < 0 else (-dy, dx)             # dy / (-dx) with a positive denominator
                 if dx > 0:
-                    lo = ratio if lo is None or ratio > lo else lo
+                    if lo is None or ratio[0] * lo[1] > lo[0] * ratio[1]:
+                        lo = ratio
                 else:
-                    hi = ratio if hi is None or ratio < hi else hi
-                if lo is not None and hi is not None and lo > hi:
+                    if hi is None or ratio[0] * hi[1] < hi[0] * ratio[1]:
+                        hi = ratio
+                if lo is not None and hi is not None and lo[0] * hi[1] > hi[0] * lo[1]:
                     return False
         sw = sw and a == b
     return True

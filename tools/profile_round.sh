@@ -38,6 +38,11 @@ if [ -f $ROOT/build_ab/libprof.so ]; then
     THETA_HIP_LIB=$ROOT/build_ab/libprof.so THETA_BENCH_VERBOSE=1 timeout 300 python $ROOT/bench.py --steps 6 --warmup 2 --leg $leg --no-legs --no-cpu-baseline --no-traffic --no-extras 2>&1 >/dev/null | grep "^step"
   done > $OUT/phase_cycles.txt
 fi
+# round 5: the branch and bound on BASELINE configs 3 and 4 (end to end through do_optimization_single), and its kernels under rocprofv3
+timeout 300 python -u $ROOT/tools/bnb_run.py c3 c4 > $OUT/bnb_configs_3_4.txt 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kb -o kb -- python $ROOT/tools/bnb_run.py c3 c4 > /dev/null 2> $OUT/kb.err
+cp $(find $OUT/kb -name '*kernel_stats.csv' | head -1) $OUT/bnb_kernel_stats.csv 2>/dev/null
+rm -rf $OUT/kb
 timeout 600 python $ROOT/tools/riders.py > $OUT/riders.json 2> $OUT/riders.err
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kr -o kr -- python $ROOT/tools/riders.py > /dev/null 2> $OUT/kr.err
 cp $(find $OUT/kr -name '*kernel_stats.csv' | head -1) $OUT/riders_kernel_stats.csv 2>/dev/null
