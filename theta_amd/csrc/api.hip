@@ -1736,7 +1736,7 @@ extern "C" int theta_mix_search(theta_problem *p, double threshold, double leaf_
         for (const MixCell &c : hl) min_leaf_bound = std::min(min_leaf_bound, c.lb);
     }
     // the matrices of the leaves
-    mix_launch_list(A, (const MixCell *)d_leaves.p, n_leaves, (unsigned char *)d_mat.p, mat_cap, 64, (unsigned long long *)d_ctr.p, st);
+    mix_launch_list(A, (const MixCell *)d_leaves.p, n_leaves, (unsigned char *)d_mat.p, mat_cap, 2048, (unsigned long long *)d_ctr.p, st);
     unsigned long long fin[4];
     HIP_TRY(hipMemcpyAsync(fin, d_ctr.p, sizeof(fin), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipEventRecord(p->ctx->ev1, st));
