@@ -204,6 +204,9 @@ int theta_search_degenerate(theta_problem *p, int cap, uint64_t *rank, uint8_t *
  *                    the lower bound of its relaxed problem -- every leaf interval fitted perfectly: the likelihood of the prefix alone plus
  *                    a constant -- lies beyond the window of the running minimum; 0: every candidate gets its own evaluation (same
  *                    finalists, suspects and degenerate lists).  Never applies under "n3_no_dismiss"
+ *   "n3_second"      1 (default): in the tight full-solve modes ("n3_no_dismiss" with "n3_conv_l2" < 1e-6), where every candidate needs a second
+ *                    evaluation, it is taken in place right after the shared one, by the lane that holds the child, instead of through
+ *                    the queue; 0: through the queue (same evaluations, same lists; an A/B switch)
  *   "n2_no_dismiss"  1: the n=2 search solves every candidate; 0 (default): a candidate whose rigorous lower bound -- one evaluation
  *                    at a chain point, self-concordance -- lies beyond the window of the running minimum is done (same finalists)
  *   "n3_per_task"    candidates per wave task (0 = automatic), "n2_per_thread" candidates per thread (0 = automatic)

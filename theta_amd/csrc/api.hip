@@ -362,6 +362,8 @@ extern "C" int theta_problem_create(theta_ctx *ctx, int n, int m, int tau, const
         if (const char *e = getenv("THETA_N3_NO_DISMISS")) D.no_dismiss = atoi(e) != 0;
         D.prefix_bound = 1;
         if (const char *e = getenv("THETA_N3_PREFIX_BOUND")) D.prefix_bound = atoi(e) != 0;
+        D.no_second = 0;
+        if (const char *e = getenv("THETA_N3_SECOND")) D.no_second = atoi(e) == 0;
         if (const char *e = getenv("THETA_N3_SIEVE")) p->opt_sieve = atoi(e) != 0;
         D.N = (double)N;
         D.Rtot = (double)Rt;
@@ -437,6 +439,7 @@ extern "C" int theta_problem_set_option(theta_problem *p, const char *name, doub
     if (k == "n3_force_f64") p->n3.force64 = value != 0.0;
     else if (k == "n3_no_dismiss") p->n3.no_dismiss = value != 0.0;
     else if (k == "n3_prefix_bound") p->n3.prefix_bound = value != 0.0;
+    else if (k == "n3_second") p->n3.no_second = value == 0.0;
     else if (k == "n3_conv_l2" && value > 0.0) p->n3.conv_l2 = value;
     else if (k == "n3_warm_blend" && value >= 0.0 && value <= 1.0) p->n3.warm_blend = value;
     else if (k == "n3_sieve") p->opt_sieve = value != 0.0;

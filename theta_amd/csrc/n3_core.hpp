@@ -39,6 +39,7 @@ struct N3Dev {
     double conv_l2;              // convergence threshold on the squared Newton decrement
     int no_dismiss;              // 1: never finish a candidate by its lower bound (THETA_N3_NO_DISMISS): every one is iterated to the coarse tolerance
     int prefix_bound;            // 1: the sieve finishes a whole prefix by the lower bound of its relaxed problem (search mode; n3_sieve.hip: sv_prefix_beyond)
+    int no_second;               // 1: no second evaluation in place in the tight full-solve modes (n3_sieve.hip: sv_children; option "n3_second" = 0: A/B)
     unsigned long long total_lo, total_hi;
 };
 

@@ -270,6 +270,8 @@ struct SvCtx {
     F Tcmp;                          // the threshold of sv_beyond's comparison, in F (per task)
     F sqrt_ror;                      // sqrt(Rtot / Rmin) (per prefix)
     int no_dismiss;
+    int second;                      // 1: children that need another evaluation take it IN PLACE, right after the shared one (sv_children): the tight
+                                     // full-solve modes, where every child does -- the queue then only holds what needs a third
     // the chain point (wave-uniform): where the next round's shared sums are evaluated, see sv_parent
     F wn0, wn1, wn2;
     int qcount;
@@ -740,6 +742,7 @@ struct SvChild {
     F n1, n2;                  // its stepped mixture, and the stepped point itself (u1, u2; w0 = 1 - n1 - n2): the lane's chain point, valid if `chain`
     F c1, c2;
     bool chain;
+    F s1, s2;                  // the child's column sums / N (sv_second: a second evaluation in place needs them)
 #ifdef SV_WITNESS
     bool wdone;                // finished by this evaluation (converged and valued / dismissed by the bound)
     bool wconv;
@@ -818,6 +821,8 @@ __device__ __forceinline__ void sv_child_eval(const SvCtx<ML, F, NS> &c, int lo,
     o.push = o.act && o.regular && !done && !o.surv;
     o.qu1 = good ? v1 : F(__builtin_nanf(""));
     o.qu2 = v2;
+    o.s1 = s1;
+    o.s2 = s2;
 #ifdef SV_WITNESS
     o.wdone = done;
     o.wconv = conv;
@@ -880,7 +885,8 @@ __device__ __forceinline__ void sv_children(SvCtx<ML, F, NS> &c, int total) {
             if (o.wdone || o.surv)
                 sv_witness<ML, F, NS>(c, o.off, o.surv ? 5u : (o.wconv ? 1u : 3u), 1u, (float)o.wl2, o.wl2, o.wval2, o.ws1, o.ws2, o.c1, o.c2);
 #endif
-            const unsigned long long pm = ballot64(o.push), sm = ballot64(o.surv);
+            unsigned long long pm = ballot64(o.push);
+            const unsigned long long sm = ballot64(o.surv);
             if (sm) {                                     // (rare: a contender straight from the shared evaluation)
                 if (o.surv) {
                     unsigned rw[ML / 2];
@@ -888,13 +894,55 @@ __device__ __forceinline__ void sv_children(SvCtx<ML, F, NS> &c, int total) {
                     sv_survivor<ML, F, NS>(c, rw, o.off, o.c1, o.c2);
                 }
             }
+            bool push = o.push;
+            F qu1 = o.qu1, qu2 = o.qu2;
+            unsigned evals = o.ev ? 1u : 0u;
+            if (c.second && pm) {
+                // The tight full-solve modes: (nearly) every child needs a second evaluation -- taken HERE, in lock step, by the lane that
+                // has the child at hand, instead of through the queue (push, pop, decode, column sums, a wave-step that may run half
+                // empty): the queue is left with the ~10 % that need a third.  Same arithmetic, same decisions as sv_drain.
+                unsigned rw[ML / 2];
+                sv_child_rows<ML, F, NS>(c, o.code, o.slot, rw);
+                F u1 = qu1, u2 = qu2;
+                if (!(u1 == u1)) {                      // (no usable shared point: from the simplex centre)
+                    u1 = F(1.0 / 3.0) * sv_rcp(o.s1);
+                    u2 = F(1.0 / 3.0) * sv_rcp(o.s2);
+                }
+                F val2 = F(0), l2 = F(0), la = F(0);
+                const int st = sv_step<ML, F, NS>(c, rw, o.s1, o.s2, u1, u2, val2, l2, la);
+                c.n_dit += (unsigned)__builtin_popcountll(pm);
+                if (push) {
+                    evals++;
+                    bool fin = false, surv = false;
+                    SV_WIT(unsigned wst = 0u;)
+                    if (st == 3) {
+                        surv = fin = true;
+                        SV_WIT(wst = 6u;)
+                    } else if (st != 2) {
+                        const bool beyond = sv_beyond<ML, F, NS>(c, val2, l2, sv_sqrt(l2), la);
+                        if (beyond && st == 1) {
+                            fin = true;
+                            SV_WIT(wst = 2u;)
+                        } else if (st == 1 && l2 < c.fine_l2) {
+                            surv = fin = true;
+                            SV_WIT(wst = 5u;)
+                        }
+                    }
+                    SV_WIT(if (fin) sv_witness<ML, F, NS>(c, o.off, wst, evals, o.qu1 == o.qu1 ? (float)o.wl2 : __builtin_nanf(""), l2, val2, o.s1, o.s2, u1, u2);)
+                    if (surv) sv_survivor<ML, F, NS>(c, rw, o.off, u1, u2);
+                    if (fin) push = false;
+                    qu1 = u1;
+                    qu2 = u2;
+                }
+                pm = ballot64(push);
+            }
             if (pm) {
                 if (c.qcount + __builtin_popcountll(pm) > SV_QCAP) sv_drain<ML, F, NS, false>(c);
-                if (o.push) {
+                if (push) {
                     const int pos = c.qcount + mbcnt(pm);
-                    c.W->qRec[pos] = make_uint2(o.code, o.slot | (o.off << 8) | (o.ev ? 1u << 24 : 0u));   // (top byte: evaluations so far)
-                    c.W->qU1[pos] = o.qu1;
-                    c.W->qU2[pos] = o.qu2;
+                    c.W->qRec[pos] = make_uint2(o.code, o.slot | (o.off << 8) | (evals << 24));   // (top byte: evaluations so far)
+                    c.W->qU1[pos] = qu1;
+                    c.W->qU2[pos] = qu2;
                     SV_WIT(c.W->qL0[pos] = o.qu1 == o.qu1 ? (float)o.wl2 : __builtin_nanf("");)
                 }
                 c.qcount += __builtin_popcountll(pm);
@@ -1245,6 +1293,7 @@ __global__ __launch_bounds__(64 * SV_WAVES, sizeof(F) == 4 ? SV_OCC : SV_OCC64) 
     c.conv_l2 = (F)Pg.conv_l2;
     c.fine_l2 = sizeof(F) == 8 ? (F)fmin(Pg.conv_l2, 1e-8) : c.conv_l2;
     c.no_dismiss = Pg.no_dismiss;
+    c.second = Pg.no_dismiss && Pg.conv_l2 < 1e-6 && !Pg.no_second;
     c.wn0 = F(__builtin_nanf(""));                   // (no chain point yet: the simplex centre)
     c.wn1 = c.wn2 = F(0);
     c.qcount = 0;
