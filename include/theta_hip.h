@@ -73,9 +73,11 @@ int theta_synchronize(theta_ctx *ctx);
  * of TimeEstimate.count_number_matrices_2, TimeEstimate.py:91-111; the n=3 table counts the
  * matrices Enumerator._generate_next_C_3 really yields, Enumerator.py:172-214).
  * max_normal is only enforced for n=2, like the reference (Optimizer.py:107-110).
- * n=3: copy numbers (bounds) up to THETA_MAX_COPY, as long as at most 64 distinct valid rows (a, b) lie within the bounds of some
- * interval (always so up to 7; beyond, the reference's own bounds heuristic -- ub = max(k, y + 1), DataTools.py:64-66 -- produces
- * narrow windows that fit): THETA_ERR_ARG otherwise.  A space of 2^128 matrices or more is accepted: its count saturates at
+ * n=3: copy numbers (bounds) up to THETA_MAX_COPY.  Ranks exist as long as at most 64 distinct valid rows (a, b) lie within the
+ * bounds of some interval (always so up to 7; beyond, the reference's own bounds heuristic -- ub = max(k, y + 1),
+ * DataTools.py:64-66 -- produces narrow windows that fit).  With more rows (full bounds [0, 9]: 72) the problem is MIX-ONLY:
+ * created all the same, theta_problem_count reports 2^128 - 1, every entry point that takes ranks (theta_search*, theta_enumerate,
+ * theta_bnb) answers THETA_ERR_ARG with a message, and theta_mix_search searches the space whole.  A space of 2^128 matrices or more is accepted: its count saturates at
  * 2^128 - 1 (theta_problem_count: "that many or more") and rank ranges below that are searched like any other.
  */
 int theta_problem_create(theta_ctx *ctx, int n, int m, int tau, const int64_t *r, const int64_t *rN,

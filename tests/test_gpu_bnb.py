@@ -177,3 +177,57 @@ def test_baseline_configs_3_and_4_are_searched_whole(ctx, name, K, seed, capsys)
     assert ok[0] == 1 and abs(nll[0] - low) <= 1e-9 * abs(low)
     others = nll[1:][(ok[1:] > 0) & (nll[1:] == nll[1:])]
     assert len(trials) > 20 and (len(others) == 0 or others.min() >= low - 1e-9 * abs(low)), (len(trials), float(others.min()), low)
+
+
+def test_more_than_64_rows_within_the_bounds_are_searched_whole(ctx, monkeypatch):
+    """Full bounds [0, 9] on every interval: 72 valid rows (a, b), more than a child mask of the rank-walking kernels holds -- round 4
+    refused such a problem (Enumerator._create_graph, Enumerator.py:272-298, has no such limit).  It has no ranks here either
+    (theta_search says so), but do_optimization_single searches it WHOLE over the mixture space: the winner is a matrix of the
+    reference's space valued alike by theta_solve_batch, not worse than the winner of the same instance under bounds tightened around
+    the planted truth (a space the linear walk exhausts), with no better matrix one row away."""
+    import bench
+    import theta_amd
+    from theta_amd import search as S
+    m, K = 12, 9
+    r, rN, order = bench.synth(seed=77, m=m, n=3, k=K)
+    p = theta_amd.Problem(ctx, 3, m, 2, r, rN, [0] * m, [K] * m, 1.0)
+    assert p.count == 2 ** 128 - 1
+    with pytest.raises(theta_amd.ThetaError):
+        p.search(0, 1000)
+    p.close()
+    best = S.do_optimization_single(3, m, K, 2, [0] * m, [K] * m, r, rN, 1.0, order, False, False)
+    rep = S.last_report
+    assert rep.mix is not None and "gave_up" not in rep.mix and rep.mix["records"] >= 1
+    low = min(b[2] for b in best if b[2] == b[2])
+    Cw = np.asarray(best[0][0])[np.asarray(order)][:, 1:].astype(np.uint8)
+    assert S.in_space_n3(Cw, [0] * m, [K] * m, 2)
+    rows = [(a, b) for b in range(K + 1) for a in range(K + 1) if (2 - a) * (2 - b) >= 0]
+    assert len(rows) > 64
+    trials = [Cw]
+    for i in range(m):
+        for a, b in rows:
+            T = Cw.copy()
+            T[i] = (a, b)
+            if (a, b) != (int(Cw[i][0]), int(Cw[i][1])) and S.in_space_n3(T, [0] * m, [K] * m, 2):
+                trials.append(T)
+    ok, _mu, nll, _v = ctx.solve_batch(3, 2, r, rN, np.ascontiguousarray(np.array(trials, np.uint8)), 1.0, want_vals=False)
+    assert ok[0] == 1 and abs(nll[0] - low) <= 1e-9 * abs(low)
+    others = nll[1:][(ok[1:] > 0) & (nll[1:] == nll[1:])]
+    assert len(others) == 0 or others.min() >= low - 1e-9 * abs(low)
+    # the same instance with bounds around the winner's rows that survive Enumerator._check_bound_order (lb the suffix minimum, ub the
+    # prefix maximum of the winner's entries: already monotone) -- at most 64 rows, a space the linear walk exhausts
+    lo_i = [int(min(Cw[i])) for i in range(m)]
+    hi_i = [int(max(Cw[i])) for i in range(m)]
+    lb = [min(lo_i[i:]) for i in range(m)]
+    ub = [max(hi_i[:i + 1]) for i in range(m)]
+    assert S.adjusted_bounds(lb, ub) == (lb, ub) and S.in_space_n3(Cw, lb, ub, 2)
+    q = theta_amd.Problem(ctx, 3, m, 2, r, rN, lb, ub, 1.0)
+    count = q.count
+    q.close()
+    assert 1 < count < 2e11, count
+    monkeypatch.setattr(S, "BNB_MIN_CANDIDATES", 2 ** 200)
+    monkeypatch.setattr(S, "NAN_SWEEP_MAX", 0)
+    tight = S.do_optimization_single(3, m, K, 2, list(lb), list(ub), r, rN, 1.0, order, False, False)
+    fin = [b for b in tight if b[2] == b[2]]
+    assert fin and abs(min(b[2] for b in fin) - low) <= 1e-9 * abs(low), (min(b[2] for b in fin), low, count)
+    assert np.array_equal(np.asarray(fin[0][0])[np.asarray(order)][:, 1:].astype(np.uint8), Cw) or len(fin) > 1

@@ -10,7 +10,7 @@ import sys
 
 N_VALS = [None, 2, 3]     # FileIO.py:42
 K_VALS = range(7)         # FileIO.py:43: k = 0 .. 6
-MAX_K_EXTENDED = 8        # with --ALLOW_LARGE_K (not a flag of the reference): what the kernels hold (n=3: copy numbers up to 15, at most 64 distinct rows within the bounds)
+MAX_K_EXTENDED = 8        # with --ALLOW_LARGE_K (not a flag of the reference): what the kernels hold (n=3: copy numbers up to 15; more than 64 distinct rows within the bounds: searched over the mixture space only)
 
 
 def parse_arguments(argv=None, silent=False):

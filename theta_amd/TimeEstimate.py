@@ -8,6 +8,7 @@ import sys
 import time
 
 from . import _lib
+from . import search as S
 
 
 def count_number_matrices(n, m, tau, upper_bounds, lower_bounds, ctx=None):
@@ -69,7 +70,7 @@ def time_estimate(n, m, k, tau, lower_bounds, upper_bounds, r, rN, max_normal, s
         p = _lib.Problem(ctx, n, m, tau, r, rN, [int(v) for v in lower_bounds], [int(v) for v in upper_bounds], max_normal)
     except _lib.ThetaError as e:
         if e.code in (_lib.ERR_OVERFLOW, _lib.ERR_ARG):
-            # a search the library cannot hold (n=3: more than 256 intervals, more than 64 distinct rows (a, b) within the bounds; a range of more than 2^56 matrices)
+            # a search the library cannot hold (n=3: more than 256 intervals, copy numbers above 15)
             print("ERROR: %s. Use fewer intervals (--NUM_INTERVALS) or tighter bounds. Exiting..." % e)
             sys.exit(1)
         raise
@@ -77,15 +78,27 @@ def time_estimate(n, m, k, tau, lower_bounds, upper_bounds, r, rN, max_normal, s
     if count == 0:
         print("ERROR: No valid Copy Number Profiles exist for these intervals within the bounds specified. Exiting...")
         sys.exit(1)
-    probe = min(count, 1 << 20)
-    t0 = time.time()
-    try:
-        p.search(0, probe, window=0.0)
-    except _lib.ThetaError:
-        pass                      # (an estimate only: the search proper reports errors)
-    rate = probe / max(time.time() - t0, 1e-6)
+    seconds = None
+    if n == 3 and count >= S.BNB_MIN_CANDIDATES and S.USE_MIX:
+        # a space the search does not walk rank by rank (search.py: mix_records, branch and bound over the mixture space): the
+        # estimate is the search itself, timed -- about a second where it succeeds; where it gives up (a flat likelihood) the
+        # extrapolation below stands
+        t0 = time.time()
+        try:
+            S.mix_records(p, ctx, r, rN, max_normal, ([int(v) for v in lower_bounds], [int(v) for v in upper_bounds]))
+            seconds = 2.0 * (time.time() - t0)
+        except _lib.ThetaError:
+            pass
+    if seconds is None:
+        probe = min(count, 1 << 20)
+        t0 = time.time()
+        try:
+            p.search(0, probe, window=0.0)
+        except _lib.ThetaError:
+            pass                      # (an estimate only: the search proper reports errors)
+        rate = probe / max(time.time() - t0, 1e-6)
+        seconds = count / rate
     p.close()
-    seconds = count / rate
     if seconds < 60:
         print("\tEstimated Total Time:", int(seconds + .5), "second(s)")
     elif seconds < 3600:

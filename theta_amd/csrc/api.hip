@@ -174,6 +174,7 @@ struct theta_problem {
                                        // is coarse against the spread of the NLL in a range): later calls run the double instantiation
     bool opt_auto64 = true;            // ... unless switched off (option "n3_auto_f64")
     bool count_saturated = false;      // n=3: the space holds 2^128 matrices or more (total = 2^128 - 1)
+    bool mix_only = false;             // n=3: more than 64 rows within the bounds -- no ranks: theta_mix_search and the batch operators only
     unsigned opt_surv_cap = 0;         // n=3: contenders a slice may list before it counts as overflowed (0: SURV_CAP; smaller
                                        // values make the tests walk the redo ladder: sieve again -> 8 parts -> fused kernel)
     int device = 0;                                     // (= ctx->device: the destructor must not need the context)
@@ -330,6 +331,38 @@ extern "C" int theta_problem_create(theta_ctx *ctx, int n, int m, int tau, const
     } else {
         TRY(n3_build_host(m, tau, lb, ub, p->n3h));
         const N3Host &h = p->n3h;
+        if (h.mix_only) {
+            // more than 64 rows (a, b) within the bounds (full bounds [0, 8] and beyond): no child masks, no counting table, no ranks.
+            // What remains: the row table and the bounds on the device for theta_mix_search; the space counts as "2^128 or more".
+            std::vector<unsigned char> small(2 * (size_t)m + h.rowtab.size(), 0);
+            for (int i = 0; i < m; i++) {
+                small[i] = (unsigned char)h.lb[i];
+                small[m + i] = (unsigned char)h.ub[i];
+            }
+            memcpy(small.data() + 2 * m, h.rowtab.data(), h.rowtab.size());
+            TRY(upload(p->d_small, small.data(), small.size(), st));
+            N3Dev &D = p->n3;
+            memset(&D, 0, sizeof(D));
+            D.m = m;
+            D.K = h.K;
+            D.Q = h.Q;
+            D.tau = tau;
+            D.N = (double)N;
+            D.Rtot = (double)Rt;
+            D.K0 = (double)k0;
+            D.r = (const double *)p->d_r.p;
+            D.rN = (const double *)p->d_rN.p;
+            D.lb = (const unsigned char *)p->d_small.p;
+            D.ub = D.lb + m;
+            D.rowtab = D.lb + 2 * m;
+            p->mix_only = true;
+            p->count_saturated = true;
+            p->total[0] = p->total[1] = ~0ull;
+            p->opt_sieve = 0;
+            HIP_TRY(hipStreamSynchronize(st));
+            *out = owner.release();
+            return THETA_OK;
+        }
         std::vector<unsigned char> small(2 * (size_t)m + h.ridx.size() + h.rowtab.size(), 0);
         for (int i = 0; i < m; i++) {
             small[i] = (unsigned char)h.lb[i];
@@ -474,6 +507,11 @@ static inline u128 mk128(const uint64_t v[2]) { return ((u128)v[1] << 64) | v[0]
 static int check_range(theta_problem *p, const uint64_t rb[2], const uint64_t re[2], u128 &b, u128 &e) {
     if (!p || !rb || !re) {
         theta_set_error("null argument");
+        return THETA_ERR_ARG;
+    }
+    if (p->mix_only) {
+        theta_set_error("%d distinct rows (a, b) lie within the bounds: more than the 64 the rank-walking kernels hold; such a space is searched "
+                        "whole (theta_mix_search, do_optimization_single), it has no ranks", p->n3.Q);
         return THETA_ERR_ARG;
     }
     u128 tot = mk128(p->total);
@@ -1117,8 +1155,8 @@ extern "C" int theta_search_ranges(theta_problem *p, int nranges, const uint64_t
         theta_set_error("theta_search_ranges: bad argument");
         return THETA_ERR_ARG;
     }
-    if (p->n != 3) {
-        theta_set_error("theta_search_ranges: n = 3 only");
+    if (p->n != 3 || p->mix_only) {
+        theta_set_error("theta_search_ranges: n = 3 with at most 64 rows within the bounds only");
         return THETA_ERR_ARG;
     }
     std::vector<std::pair<u128, u128>> rg;
@@ -1333,8 +1371,8 @@ extern "C" int theta_bnb(theta_problem *p, double threshold, uint64_t beam, int 
         theta_set_error("theta_bnb: n = 3 only (an n = 2 space is exhausted by theta_search)");
         return THETA_ERR_ARG;
     }
-    if (p->count_saturated) {
-        theta_set_error("theta_bnb: the space holds 2^128 matrices or more; its nodes have no 128-bit ranks");
+    if (p->count_saturated || p->mix_only) {
+        theta_set_error("theta_bnb: the space holds 2^128 matrices or more (or more than 64 rows); its nodes have no 128-bit ranks");
         return THETA_ERR_OVERFLOW;
     }
     if (threshold != threshold) {

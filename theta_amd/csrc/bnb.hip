@@ -410,6 +410,7 @@ void bnb_launch_compact(const BnbNode *nodes, const unsigned char *paths, unsign
 // below, and a depth-first walk over the intervals with the budget `threshold` lists the few matrices that fit (mix_list_kernel).
 // The host values those with the reference's own procedure (theta_solve_batch) and replays them in enumeration order.
 // ====================================================================================================================================
+#define MIX_MAX_Q 256      // rows of the alphabet here (a search over mixtures needs no 64-bit child masks)
 // the bound of a box: max of the two (see above).  One WAVE per box: lane l takes the intervals l, 64 + l, ... (m x rows x 2 logarithms
 // are half a millisecond of one thread -- a level of the octree holds a handful of boxes as often as a million, and its 60 levels
 // are walked one launch after the other), the nine partial sums meet by shuffles.
@@ -471,7 +472,7 @@ __device__ double mix_cell_bound(const MixArgs &A, const MixCell &c, const float
 // number they multiply), the child's bound decides whether it goes on -- to the next level's list, or, small enough, to the leaves.
 __global__ __launch_bounds__(256) void mix_split_kernel(MixArgs A, const MixCell *in, unsigned long long n_in, MixCell *out, unsigned long long out_cap,
                                                         MixCell *leaves, unsigned long long leaf_cap, unsigned long long *counters) {
-    __shared__ float2 rows[N3_MAX_Q];
+    __shared__ float2 rows[MIX_MAX_Q];
     for (int s = threadIdx.x; s < A.Q; s += blockDim.x) rows[s] = make_float2((float)(A.rowtab[s] & 15u), (float)(A.rowtab[s] >> 4));
     __syncthreads();
     const int lane = threadIdx.x & 63;
@@ -511,7 +512,7 @@ __global__ __launch_bounds__(256) void mix_split_kernel(MixArgs A, const MixCell
 #define MIX_MAX_M 256
 __global__ __launch_bounds__(64) void mix_list_kernel(MixArgs A, const MixCell *leaves, unsigned long long n_leaves, unsigned char *out, unsigned long long out_cap,
                                                       int per_thread_cap, unsigned long long *counters) {
-    __shared__ float2 rows[N3_MAX_Q];
+    __shared__ float2 rows[MIX_MAX_Q];
     for (int s = threadIdx.x; s < A.Q; s += blockDim.x) rows[s] = make_float2((float)(A.rowtab[s] & 15u), (float)(A.rowtab[s] >> 4));
     __syncthreads();
     const unsigned long long k = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;

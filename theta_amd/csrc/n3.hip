@@ -59,12 +59,20 @@ int n3_build_host(int m, int tau, const int32_t *lb_in, const int32_t *ub_in, N3
             rows_b.push_back(b);
         }
     }
-    if ((int)rows_a.size() > N3_MAX_Q) {
-        theta_set_error("n=3 search with copy numbers up to %d: %d distinct rows (a, b) lie within the bounds of some interval, the "
-                        "kernels hold %d", top, (int)rows_a.size(), N3_MAX_Q);
-        return THETA_ERR_ARG;
-    }
     h.Q = (int)rows_a.size();
+    if (h.Q > N3_MAX_Q) {
+        // more rows than a child mask holds (one 64-bit word: the rank-walking kernels).  Round 5: such a problem still has its row
+        // table -- the valid rows in grid order -- and is served by the search that needs no ranks (theta_mix_search, bnb.hip)
+        if (h.Q > 255) {
+            theta_set_error("n=3 search with copy numbers up to %d: %d distinct rows", top, h.Q);
+            return THETA_ERR_ARG;
+        }
+        h.mix_only = true;
+        h.rowtab.assign(h.Q, 0);
+        for (int s = 0; s < h.Q; s++) h.rowtab[s] = (unsigned char)(rows_a[s] | (rows_b[s] << 4));
+        h.NT = 0;
+        return THETA_OK;
+    }
     // distinct values of dy/(-dx) over the differences of two rows of the alphabet, sorted ascending; compared by cross-multiplication
     struct Fr { int n, d; };
     std::vector<Fr> fr;

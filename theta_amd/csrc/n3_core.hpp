@@ -85,6 +85,8 @@ __host__ __device__ inline void n3_line_add(N3Line &s, int a, int b) {
 
 struct N3Host {
     int m = 0, K = 0, Q = 0, NT = 0;
+    bool mix_only = false;       // more than N3_MAX_Q rows within the bounds: no masks, no counting table -- only the searches that need no
+                                 // ranks (theta_mix_search) and the batch operators serve such a problem
     std::vector<int> lb, ub;
     std::vector<unsigned char> ridx, rowtab;
     std::vector<unsigned long long> smask, dynmask;

@@ -691,9 +691,10 @@ def _search_local(n, m, tau, lower_bounds, upper_bounds, r, rN, max_normal, shar
         try:
             all_ranges, inc = bnb_plan(problem, ctx, r, rN, max_normal, report=report, exchange=hint_exchange, bounds=(lower_bounds, upper_bounds))
         except _lib.ThetaError as e:
-            if e.code not in (_lib.ERR_CAPACITY, _lib.ERR_OVERFLOW):
+            if e.code not in (_lib.ERR_CAPACITY, _lib.ERR_OVERFLOW, _lib.ERR_ARG):
                 raise
-            # neither branch and bound gets through (a likelihood too flat to prune by: few reads, or many intervals of equal ratio)
+            # neither branch and bound gets through (ERR_ARG: a mix-only problem -- more than 64 rows within the bounds -- has no row-tree walk)
+            # -- neither branch and bound gets through (a likelihood too flat to prune by: few reads, or many intervals of equal ratio)
             raise _lib.ThetaError(_lib.ERR_OVERFLOW, "%d candidate matrices, and the likelihood is too flat for either branch and bound to "
                                   "prune the space (%s)" % (problem.count, str(e)[:120]))
         my_ranges = _share_of_ranges(all_ranges, g, G)
@@ -763,7 +764,7 @@ def _search_local(n, m, tau, lower_bounds, upper_bounds, r, rN, max_normal, shar
 
 
 def _friendly_exit(e):
-    # a search the library cannot hold (n=3: more than 256 intervals, more than 64 distinct rows (a, b) within the bounds, or a range no search finishes -- the
+    # a search the library cannot hold (n=3: more than 256 intervals, copy numbers above 15, or a range no search finishes -- the
     # reference would enumerate such a space for years): say so instead of a traceback
     print("ERROR: %s. Use fewer intervals (--NUM_INTERVALS) or tighter bounds. Exiting..." % e)
     sys.exit(1)
