@@ -461,13 +461,14 @@ def extras(ctx, cpu_seconds):
     # (theta_mix_search behind do_optimization_single, csrc/bnb.hip; tests/test_gpu_bnb.py: identical to the exhaustive search on
     # whole spaces of 1e6-1e9 matrices and to reference-written lists).  config 4 is this bench's own instance.
     from theta_amd import search as _S
-    for key, kk, sd in (("config3_m50_n3_k4", 4, 7), ("config4_m50_n3_k6", K_MAX, SEED)):
+    # ... and config 5's shape (m = 200, k = 7, full bounds: a space beyond 2^128) the same way.
+    for key, mm, kk, sd in (("config3_m50_n3_k4", 50, 4, 7), ("config4_m50_n3_k6", 50, K_MAX, SEED), ("config5_m200_n3_k7", 200, 7, 55)):
         try:
-            r3, rN3, order3 = synth(seed=sd, m=50, n=3, k=kk)
+            r3, rN3, order3 = synth(seed=sd, m=mm, n=3, k=kk)
             ts = []
             for _ in range(3):
                 t = time.time()
-                b3 = do_optimization_single(3, 50, kk, TAU, [0] * 50, [kk] * 50, r3, rN3, 1.0, order3, False, False)
+                b3 = do_optimization_single(3, mm, kk, TAU, [0] * mm, [kk] * mm, r3, rN3, 1.0, order3, False, False)
                 ts.append(time.time() - t)
             rp = _S.last_report
             mx = rp.mix or {}
@@ -476,6 +477,7 @@ def extras(ctx, cpu_seconds):
                       "method": "branch and bound over the mixture space (theta_mix_search) + the reference's procedure on the listed matrices",
                       "boxes_tested": mx.get("boxes_tested"), "leaves": mx.get("leaves"), "matrices_listed": mx.get("listed"),
                       "octree_kernel_ms": mx.get("kernel_ms"), "smallest_leaf_bound": mx.get("min_bound"), "incumbent_heuristic": mx.get("heuristic_nll"),
+                      "heuristic_s": mx.get("heuristic_seconds"), "count_saturated": bool(rp.candidates >= 2 ** 128 - 1),
                       "reference_estimate_s": float(rp.candidates) / 30.0,
                       "reference_note": "the reference visits every matrix at ~30 per second and process (BASELINE.md): no run of it can finish",
                       "not_included": "matrices the reference reports off their optimum: rank-deficient ones, NaN outcomes (DESIGN.md section 8)"}

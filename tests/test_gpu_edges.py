@@ -26,8 +26,15 @@ def test_error_codes_and_messages(ctx):
         theta_amd.Problem(ctx, 2, 1, 2, [1], [1], [0], [2])                      # m >= 2 (FileIO.py:437-439)
     with pytest.raises(theta_amd.ThetaError):
         theta_amd.Problem(ctx, 2, 3, 2, [1, 2, 3], [1, 0, 3], [0] * 3, [2] * 3)  # normal count 0
+    wide = theta_amd.Problem(ctx, 3, 3, 2, [1, 2, 3], [1, 1, 3], [0] * 3, [9] * 3)  # n=3, 72 rows within the bounds: a mix-only problem (no ranks)
+    assert wide.count == 2 ** 128 - 1
+    for call in (lambda: wide.search(0, 10), lambda: wide.enumerate(0, 10), lambda: wide.values(0, 10), lambda: wide.bnb(float("inf"))):
+        with pytest.raises(theta_amd.ThetaError) as e:
+            call()
+        assert e.value.code == _lib.ERR_ARG and "no ranks" in str(e.value)
+    wide.close()
     with pytest.raises(theta_amd.ThetaError):
-        theta_amd.Problem(ctx, 3, 3, 2, [1, 2, 3], [1, 1, 3], [0] * 3, [9] * 3)  # n=3 alphabet limit
+        theta_amd.Problem(ctx, 3, 3, 2, [1, 2, 3], [1, 1, 3], [0] * 3, [16] * 3)  # n=3: copy numbers up to 15
     with pytest.raises(theta_amd.ThetaError):
         theta_amd.Problem(ctx, 3, 257, 2, [1] * 257, [1] * 257, [0] * 257, [2] * 257)  # n=3: four prefix intervals per lane at most (256 intervals)
     p = theta_amd.Problem(ctx, 2, 3, 2, [5, 6, 7], [5, 5, 5], [2, 2, 2], [1, 1, 1])  # lb > ub: nothing to enumerate

@@ -129,11 +129,14 @@ def test_copy_numbers_above_seven_enumerate_in_the_reference_order_and_search_li
         if done >= 4:
             break
     assert done == 4
-    # full bounds [0, 9] on every interval leave 72 valid rows: more than the kernels hold -- refused with a message, not a crash
+    # full bounds [0, 9] on every interval leave 72 valid rows: more than a child mask holds -- since round 5 a mix-only problem: its
+    # ranks are refused with a message (the space is searched whole over the mixture space: tests/test_gpu_bnb.py)
     r, rN = inst["r"], inst["rN"]
+    wide = theta_amd.Problem(ctx, 3, inst["m"], 2, r, rN, [0] * inst["m"], [9] * inst["m"], 1.0)
     with pytest.raises(theta_amd.ThetaError) as e:
-        theta_amd.Problem(ctx, 3, inst["m"], 2, r, rN, [0] * inst["m"], [9] * inst["m"], 1.0)
+        wide.search(0, 100)
     assert "distinct rows" in str(e.value)
+    wide.close()
     with pytest.raises(theta_amd.ThetaError):
         theta_amd.Problem(ctx, 3, inst["m"], 2, r, rN, [0] * inst["m"], [16] * inst["m"], 1.0)
 

@@ -20,6 +20,11 @@ def test_in_space_is_exactly_the_set_the_reference_generator_yields(m, K, lb, ub
     bad = [c for c in itertools.product(itertools.product(range(K + 1), repeat=2), repeat=m)
            if S.in_space_n3(np.array(c), lb2, ub2, tau) != (tuple(c) in space)]
     assert not bad, bad[:3]
+    # the batch form (numpy, what the heuristic and mix_records call) says the same of every matrix
+    every = np.array(list(itertools.product(itertools.product(range(K + 1), repeat=2), repeat=m)), np.int64)
+    got = S.in_space_n3_batch(every, lb2, ub2, tau)
+    want = np.array([tuple(map(tuple, c)) in space for c in every.tolist()])
+    assert np.array_equal(got, want), np.nonzero(got != want)[0][:3]
     # ... and the generator's order is lexicographic in (b, a) per row, i.e. in the grid slot a + (K + 1) b: what theta_mix_search sorts by
     seq = [tuple(b * (K + 1) + a for a, b in rows) for rows in orc.enumerate_n3(m, tau, list(lb), list(ub))]
     assert seq == sorted(seq)

@@ -1156,7 +1156,7 @@ extern "C" int theta_search_ranges(theta_problem *p, int nranges, const uint64_t
         return THETA_ERR_ARG;
     }
     if (p->n != 3 || p->mix_only) {
-        theta_set_error("theta_search_ranges: n = 3 with at most 64 rows within the bounds only");
+        theta_set_error("theta_search_ranges: n = 3 with at most 64 rows within the bounds only (a space with more has no ranks)");
         return THETA_ERR_ARG;
     }
     std::vector<std::pair<u128, u128>> rg;
@@ -1371,8 +1371,13 @@ extern "C" int theta_bnb(theta_problem *p, double threshold, uint64_t beam, int 
         theta_set_error("theta_bnb: n = 3 only (an n = 2 space is exhausted by theta_search)");
         return THETA_ERR_ARG;
     }
-    if (p->count_saturated || p->mix_only) {
-        theta_set_error("theta_bnb: the space holds 2^128 matrices or more (or more than 64 rows); its nodes have no 128-bit ranks");
+    if (p->mix_only) {
+        theta_set_error("theta_bnb: %d distinct rows (a, b) lie within the bounds, more than the 64 a child mask holds: the row tree is not walked, "
+                        "the space has no ranks (theta_mix_search searches it whole)", p->n3.Q);
+        return THETA_ERR_ARG;
+    }
+    if (p->count_saturated) {
+        theta_set_error("theta_bnb: the space holds 2^128 matrices or more; its nodes have no 128-bit ranks");
         return THETA_ERR_OVERFLOW;
     }
     if (threshold != threshold) {

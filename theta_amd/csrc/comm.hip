@@ -17,6 +17,7 @@
 #include <netdb.h>
 #include <netinet/in.h>
 #include <netinet/tcp.h>
+#include <poll.h>
 #include <sys/socket.h>
 #include <sys/time.h>
 #include <time.h>
@@ -36,6 +37,7 @@ struct Rccl {
     decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
     decltype(&ncclCommInitRank) CommInitRank = nullptr;
     decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclCommAbort) CommAbort = nullptr;            // (optional: rccl_wait)
     decltype(&ncclAllReduce) AllReduce = nullptr;
     decltype(&ncclAllGather) AllGather = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
@@ -70,6 +72,7 @@ int rccl_load() {
     SYM(GetErrorString, "ncclGetErrorString")
     SYM(GetVersion, "ncclGetVersion")
 #undef SYM
+    g_rccl.CommAbort = (decltype(g_rccl.CommAbort))dlsym(h, "ncclCommAbort");
     g_rccl.handle = h;
     return THETA_OK;
 }
@@ -330,7 +333,9 @@ extern "C" int theta_comm_create(theta_ctx *ctx, int rank, int world, const char
             theta_set_error("comm: rank %d could not set up RCCL (librccl.so / ncclGetUniqueId): no rank joins the communicator", bad_rank);
             rc = THETA_ERR_HIP;
         }
-        close_star(c);                           // from here on everything goes over RCCL
+        // from here on everything goes over RCCL; the star stays open, silent, as the LIVENESS channel of the collectives: a rank
+        // that dies (out of memory, a HIP abort) closes its end, and the ranks waiting for it inside a collective notice (rccl_wait)
+        if (rc != THETA_OK) close_star(c);
         if (rc == THETA_OK) {
             hipError_t e = hipSetDevice(ctx->device);
             if (e != hipSuccess) {
@@ -347,6 +352,7 @@ extern "C" int theta_comm_create(theta_ctx *ctx, int rank, int world, const char
             }
         }
         if (rc) {
+            close_star(c);
             delete c;
             return rc;
         }
@@ -385,6 +391,94 @@ extern "C" int theta_comm_info(theta_comm *c, int *rank, int *world, int *transp
     return THETA_OK;
 }
 
+// Wait for the stream an RCCL collective was issued on -- with an eye on the other ranks.  hipStreamSynchronize alone waits for ever
+// when a rank has died (its peers' kernels spin on a flag nobody will set): the reference's counterpart, the result queue of
+// RunTHetA.py:96-105, at least ends with the parent.  Here the rendezvous sockets stay open and silent; while the stream is
+// busy they are polled, and a hang-up (the kernel closes a dead process's sockets) starts a grace period -- a rank that has
+// FINISHED its last collective may legitimately close first, and then this rank's stream completes within milliseconds --
+// after which the communicator is aborted (ncclCommAbort: the kernels leave), the star is closed so that the remaining ranks
+// notice in turn, and the call fails.  THETA_COMM_GRACE_S (default 20) is that period; THETA_COMM_COLLECTIVE_TIMEOUT_S, if
+// set, bounds the whole wait.  world = 1: a plain synchronisation.
+static double now_s() {
+    struct timeval tv;
+    gettimeofday(&tv, nullptr);
+    return (double)tv.tv_sec + 1e-6 * (double)tv.tv_usec;
+}
+static int env_seconds(const char *name, int dflt) {
+    if (const char *e = getenv(name)) {
+        const int v = atoi(e);
+        if (v > 0) return v;
+    }
+    return dflt;
+}
+static int rccl_wait(theta_comm *c, hipStream_t st) {
+    if (c->world == 1 || (c->peers.empty() && c->up < 0)) {
+        HIP_TRY(hipStreamSynchronize(st));
+        return THETA_OK;
+    }
+    const double t0 = now_s();
+    const int grace = env_seconds("THETA_COMM_GRACE_S", 20), limit = env_seconds("THETA_COMM_COLLECTIVE_TIMEOUT_S", 0);
+    double t_gone = -1.0;
+    int gone_rank = -1;
+    std::vector<struct pollfd> fds;
+    std::vector<int> who;
+    if (c->rank == 0) {
+        for (int k = 1; k < (int)c->peers.size(); k++)
+            if (c->peers[k] >= 0) {
+                fds.push_back({c->peers[k], (short)(POLLIN | POLLRDHUP), 0});
+                who.push_back(k);
+            }
+    } else if (c->up >= 0) {
+        fds.push_back({c->up, (short)(POLLIN | POLLRDHUP), 0});
+        who.push_back(0);
+    }
+    int spins = 0;
+    while (true) {
+        const hipError_t q = hipStreamQuery(st);
+        if (q == hipSuccess) return THETA_OK;
+        if (q != hipErrorNotReady) {
+            theta_set_error("comm: the collective's stream failed: %s", hipGetErrorString(q));
+            (void)hipGetLastError();
+            return THETA_ERR_HIP;
+        }
+        if (++spins < 200) continue;                       // (a collective of a few bytes: done within microseconds)
+        if (t_gone < 0.0 && !fds.empty()) {
+            const int n = ::poll(fds.data(), (nfds_t)fds.size(), 5);
+            for (size_t i = 0; n > 0 && i < fds.size() && t_gone < 0.0; i++) {
+                bool gone = (fds[i].revents & (POLLHUP | POLLERR | POLLRDHUP | POLLNVAL)) != 0;
+                if (!gone && (fds[i].revents & POLLIN)) {
+                    char b;
+                    gone = ::recv(fds[i].fd, &b, 1, MSG_PEEK | MSG_DONTWAIT) == 0;
+                }
+                if (gone) {
+                    t_gone = now_s();
+                    gone_rank = who[i];
+                }
+            }
+        } else {
+            struct timespec ts = {0, 5 * 1000 * 1000};
+            nanosleep(&ts, nullptr);
+        }
+        const double t = now_s();
+        const bool expired = limit > 0 && t - t0 > (double)limit;
+        if ((t_gone >= 0.0 && t - t_gone > (double)grace) || expired) {
+            if (expired)
+                theta_set_error("comm: rank %d waited %d s inside a collective (THETA_COMM_COLLECTIVE_TIMEOUT_S): communicator aborted", c->rank, limit);
+            else
+                theta_set_error("comm: rank %d left the job while rank %d was waiting for it inside a collective (its process ended: out of "
+                                "memory? a HIP abort?): communicator aborted", gone_rank, c->rank);
+            close_star(c);                                 // (the remaining ranks notice in turn)
+            if (c->nccl && g_rccl.CommAbort) {
+                (void)g_rccl.CommAbort(c->nccl);
+                c->nccl = nullptr;
+                (void)hipStreamSynchronize(st);
+            }
+            (void)hipGetLastError();
+            return THETA_ERR_HIP;
+        }
+    }
+}
+
 static int stage(theta_comm *c, size_t send_bytes, size_t recv_bytes) {
     int rc;
     if (c->d_send.bytes < send_bytes && (rc = c->d_send.alloc(std::max<size_t>(send_bytes, 4096)))) return rc;
@@ -400,6 +494,10 @@ extern "C" int theta_comm_allgather(theta_comm *c, const void *send, size_t byte
     c->collectives++;
     if (bytes == 0) return THETA_OK;
     if (c->transport == THETA_COMM_HOST) return star_allgather(c, send, bytes, recv);
+    if (!c->nccl) {
+        theta_set_error("comm: the communicator was aborted (a rank left the job)");
+        return THETA_ERR_HIP;
+    }
     HIP_TRY(hipSetDevice(c->ctx->device));
     hipStream_t st = c->ctx->stream;
     int rc = stage(c, bytes, bytes * (size_t)c->world);
@@ -407,8 +505,7 @@ extern "C" int theta_comm_allgather(theta_comm *c, const void *send, size_t byte
     HIP_TRY(hipMemcpyAsync(c->d_send.p, send, bytes, hipMemcpyHostToDevice, st));
     NCCL_TRY(g_rccl.AllGather(c->d_send.p, c->d_recv.p, bytes, ncclUint8, c->nccl, st));
     HIP_TRY(hipMemcpyAsync(recv, c->d_recv.p, bytes * (size_t)c->world, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    return THETA_OK;
+    return rccl_wait(c, st);
 }
 
 // op: 0 = min, 1 = sum, 2 = max; in place on host doubles
@@ -433,6 +530,10 @@ static int allreduce(theta_comm *c, double *v, int count, int op) {
         }
         return THETA_OK;
     }
+    if (!c->nccl) {
+        theta_set_error("comm: the communicator was aborted (a rank left the job)");
+        return THETA_ERR_HIP;
+    }
     HIP_TRY(hipSetDevice(c->ctx->device));
     hipStream_t st = c->ctx->stream;
     const size_t bytes = (size_t)count * sizeof(double);
@@ -442,8 +543,7 @@ static int allreduce(theta_comm *c, double *v, int count, int op) {
     NCCL_TRY(g_rccl.AllReduce(c->d_send.p, c->d_recv.p, (size_t)count, ncclDouble, op == 0 ? ncclMin : (op == 1 ? ncclSum : ncclMax),
                               c->nccl, st));
     HIP_TRY(hipMemcpyAsync(v, c->d_recv.p, bytes, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    return THETA_OK;
+    return rccl_wait(c, st);
 }
 
 extern "C" int theta_comm_allreduce_min(theta_comm *c, double *v, int count) { return allreduce(c, v, count, 0); }

@@ -375,108 +375,151 @@ def in_space_n3(C, lb, ub, tau):
     return True
 
 
-def heuristic_incumbent(ctx, m, tau, lower_bounds, upper_bounds, r, rN, max_normal, rounds=40):
+def in_space_n3_batch(Ms, lb, ub, tau):
+    """in_space_n3 for a batch of matrices (B, m, 2) at once -- the same five rules in numpy (Enumerator.py:172-264).  The ratio
+    window needs only its FINAL state: the lower end only rises and the upper end only falls along the rows, so it is empty at
+    some row exactly if it is empty at the last.  Ratios are quotients of integers below 16 in magnitude: correctly rounded
+    division maps equal ratios to equal doubles and distinct ones at least 1/225 apart."""
+    Ms = np.asarray(Ms, np.int64)
+    if Ms.ndim != 3 or Ms.shape[0] == 0:
+        return np.zeros(0, bool)
+    lbv, ubv = np.asarray(lb, np.int64)[None, :], np.asarray(ub, np.int64)[None, :]
+    a, b = Ms[:, :, 0], Ms[:, :, 1]
+    ok = np.all(((tau - a) * (tau - b) >= 0) & (a >= lbv) & (a <= ubv) & (b >= lbv) & (b <= ubv), axis=1)
+    # symmetry: the first row with a != b has a < b
+    ne = a != b
+    first = np.argmax(ne, axis=1)
+    idx = np.arange(Ms.shape[0])
+    ok &= ~ne.any(axis=1) | (a[idx, first] < b[idx, first])
+    if Ms.shape[1] > 1:
+        dx, dy = np.diff(a, axis=1), np.diff(b, axis=1)
+        ok &= np.all(((dx == 0) & (dy == 0)) | (dx > 0) | (dy > 0), axis=1)
+        both = (dx != 0) & (dy != 0)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            v = -dy.astype(np.float64) / dx.astype(np.float64)
+        lo = np.where(both & (dx > 0), v, -np.inf).max(axis=1)
+        hi = np.where(both & (dx < 0), v, np.inf).min(axis=1)
+        ok &= lo <= hi
+    return ok
+
+
+HEURISTIC_BUDGET_S = float(os.environ.get("THETA_HEURISTIC_BUDGET_S", 0.25))    # seconds of local search on top of the grid (the proposal passes of mix_records carry on from there)
+
+
+def heuristic_incumbent(ctx, m, tau, lower_bounds, upper_bounds, r, rN, max_normal, rounds=40, budget_s=None):
     """
     An NLL the reference really reports for SOME matrix of an n=3 space too large to walk -- the starting threshold of the branch
-    and bound (bnb_plan).  No reference counterpart (RunTHetA.py:173-220 visits every matrix).  For a fixed mixture mu the
+    and bound (mix_records, bnb_plan).  No reference counterpart (RunTHetA.py:173-220 visits every matrix).  For a fixed mixture mu the
     likelihood -sum r_i ln(c_i.mu) + Rtot ln(sum rN_h c_h.mu) is maximised one interval at a time in closed form; with the
     intervals sorted by their read-depth ratio (sort_r) the rows so chosen rise with c.mu, which is exactly what the
-    reference's row graph and ratio window ask of consecutive rows -- so the assignment for a mixture IS a matrix of the space
-    (checked: in_space_n3).  A grid of mixtures gives a few hundred matrices; theta_solve_batch values them the way the reference
-    would; the best goes through alternating (re-solve mu, re-assign rows) and a steepest-descent local search over single-row
-    changes, every trial again a matrix of the space valued by theta_solve_batch.  Returns (nll, C (m, 2) uint8) or (inf, None).
+    reference's row graph and ratio window ask of consecutive rows -- so the assignment for a mixture usually IS a matrix of the space
+    (checked: in_space_n3_batch).  A grid of mixtures (all of it at once, in numpy) gives a few hundred matrices; theta_solve_batch
+    values them the way the reference would; the best goes through alternating (re-solve mu, re-assign rows) and a steepest-descent
+    local search over single-row changes, every trial again a matrix of the space valued by theta_solve_batch -- for `budget_s`
+    seconds at most (m = 200: 12 800 trials per round).  Returns (nll, C (m, 2) uint8) or (inf, None).
     """
+    import time
+    t0 = time.time()
+    budget_s = HEURISTIC_BUDGET_S if budget_s is None else budget_s
     lb, ub = adjusted_bounds(lower_bounds, upper_bounds)
     r = np.asarray(r, np.float64)
     rN = np.asarray(rN, np.float64)
+    ri, rNi = [int(x) for x in r], [int(x) for x in rN]
     K = max(ub)
     rows = np.array([(a, b) for b in range(K + 1) for a in range(K + 1) if (tau - a) * (tau - b) >= 0], np.int64)
-    allowed = [np.array([j for j, (a, b) in enumerate(rows) if lb[i] <= a <= ub[i] and lb[i] <= b <= ub[i]], np.int64) for i in range(m)]
-    if any(len(al) == 0 for al in allowed):
+    lbv, ubv = np.asarray(lb, np.int64), np.asarray(ub, np.int64)
+    # allowed[i, j]: row j within the bounds of interval i
+    allowed = ((rows[None, :, 0] >= lbv[:, None]) & (rows[None, :, 0] <= ubv[:, None]) &
+               (rows[None, :, 1] >= lbv[:, None]) & (rows[None, :, 1] <= ubv[:, None]))
+    if not allowed.any(axis=1).all():
         return float("inf"), None
     Rtot = r.sum()
 
-    def assign(mu, C=None, sweeps=4):
-        """coordinate ascent on the rows for a fixed mixture; C: start (row indices per interval) or None = nearest ratio"""
-        f = tau * mu[0] + rows[:, 0] * mu[1] + rows[:, 1] * mu[2]              # c.mu per alphabet row
+    def assign(mus, C=None, sweeps=4):
+        """coordinate ascent on the rows for fixed mixtures mus (G, 3), all G at once; C (G, m): start (row indices) or None =
+        the row whose c.mu is nearest the interval's ratio.  Returns (G, m) row indices."""
+        f = tau * mus[:, 0:1] + rows[None, :, 0] * mus[:, 1:2] + rows[None, :, 1] * mus[:, 2:3]        # (G, Q): c.mu per alphabet row
+        G = f.shape[0]
+        gi = np.arange(G)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            lf = np.where(f > 0, np.log(f), -np.inf)
         if C is None:
-            # start: the row whose c.mu is nearest the interval's ratio, scaled so that the mean ratio meets the mean c.mu
             ratio = (r / rN) * (rN.sum() / Rtot)
-            scale = np.median(f)
-            C = np.array([al[np.argmin(np.abs(f[al] - ratio[i] * scale))] for i, al in enumerate(allowed)], np.int64)
+            scale = np.median(f, axis=1)
+            C = np.empty((G, m), np.int64)
+            for i in range(m):
+                d = np.abs(f - (ratio[i] * scale)[:, None])
+                C[:, i] = np.argmin(np.where(allowed[i][None, :], d, np.inf), axis=1)
         C = C.copy()
-        Z = float((rN * f[C]).sum())
+        Z = (rN[None, :] * f[gi[:, None], C]).sum(axis=1)
         for _ in range(sweeps):
             changed = False
             for i in range(m):
-                al = allowed[i]
-                Zi = Z - rN[i] * f[C[i]]
+                Zi = Z - rN[i] * f[gi, C[:, i]]
                 with np.errstate(divide="ignore", invalid="ignore"):
-                    score = r[i] * np.log(f[al]) - Rtot * np.log(Zi + rN[i] * f[al])
-                score = np.where(f[al] > 0, score, -np.inf)
-                j = al[int(np.argmax(score))]
-                if j != C[i]:
-                    C[i] = j
+                    score = r[i] * lf - Rtot * np.log(Zi[:, None] + rN[i] * f)
+                score = np.where(allowed[i][None, :] & (f > 0), score, -np.inf)
+                j = np.argmax(score, axis=1)
+                if not changed and np.any(j != C[:, i]):
                     changed = True
-                Z = Zi + rN[i] * f[C[i]]
+                C[:, i] = j
+                Z = Zi + rN[i] * f[gi, j]
             if not changed:
                 break
         return C
 
-    def canon(C):
-        """the matrix of an assignment, with the tumour columns in the order the reference's symmetry rule wants"""
-        M = rows[C].copy()
-        for a, b in M:
-            if a != b:
-                if a > b:
-                    M = M[:, ::-1].copy()
-                break
-        return M
+    def canon(Ms):
+        """matrices (B, m, 2) with the tumour columns in the order the reference's symmetry rule wants"""
+        Ms = Ms.copy()
+        ne = Ms[:, :, 0] != Ms[:, :, 1]
+        first = np.argmax(ne, axis=1)
+        idx = np.arange(len(Ms))
+        swap = ne.any(axis=1) & (Ms[idx, first, 0] > Ms[idx, first, 1])
+        Ms[swap] = Ms[swap][:, :, ::-1]
+        return Ms
 
-    def value(mats):
-        mats = [M for M in mats if in_space_n3(M, lb, ub, tau)]
-        if not mats:
-            return [], np.zeros(0), np.zeros((0, 3))
-        arr = np.ascontiguousarray(np.array(mats, np.uint8))
-        ok, mu, nll, _v = ctx.solve_batch(3, tau, [int(x) for x in r], [int(x) for x in rN], arr, max_normal, want_vals=False)
+    def value(Ms):
+        """(matrices of the space among Ms, without repeats; their NLL by the reference's procedure, inf where it reports none; mu)"""
+        if len(Ms) == 0:
+            return np.zeros((0, m, 2), np.uint8), np.zeros(0), np.zeros((0, 3))
+        Ms = Ms[in_space_n3_batch(Ms, lb, ub, tau)]
+        if len(Ms) == 0:
+            return np.zeros((0, m, 2), np.uint8), np.zeros(0), np.zeros((0, 3))
+        arr = np.unique(np.ascontiguousarray(Ms.astype(np.uint8)).reshape(len(Ms), -1), axis=0).reshape(-1, m, 2)
+        ok, mu, nll, _v = ctx.solve_batch(3, tau, ri, rNi, np.ascontiguousarray(arr), max_normal, want_vals=False)
         nll = np.where((ok > 0) & (nll == nll), nll, np.inf)
-        return mats, nll, mu
+        return arr, nll, mu
 
-    seen, cands = set(), []
-    for mu0 in np.linspace(0.05, 0.9, 18):
-        for sp in np.linspace(0.05, 0.95, 19):
-            mu = np.array([mu0, (1 - mu0) * sp, (1 - mu0) * (1 - sp)])
-            M = canon(assign(mu))
-            key = M.tobytes()
-            if key not in seen:
-                seen.add(key)
-                cands.append(M)
-    mats, nll, mus = value(cands)
+    mu0, sp = np.meshgrid(np.linspace(0.05, 0.9, 18), np.linspace(0.05, 0.95, 19), indexing="ij")
+    mu0, sp = mu0.ravel(), sp.ravel()
+    grid = np.stack([mu0, (1 - mu0) * sp, (1 - mu0) * (1 - sp)], axis=1)
+    mats, nll, mus = value(canon(rows[assign(grid)]))
     if not len(mats) or not np.isfinite(nll).any():
         return float("inf"), None
     best = int(np.argmin(nll))
-    bM, bv, bmu = mats[best], float(nll[best]), mus[best]
-    index = {(int(a), int(b)): j for j, (a, b) in enumerate(rows)}
+    bM, bv, bmu = mats[best].astype(np.int64), float(nll[best]), mus[best]
+    index = -np.ones((K + 1, K + 1), np.int64)
+    index[rows[:, 0], rows[:, 1]] = np.arange(len(rows))
+    ii, jj = np.nonzero(allowed)                                  # every (interval, row within its bounds)
     for _round in range(rounds):
-        trials = []
+        if time.time() - t0 > budget_s:
+            break
+        parts = []
         # alternate: rows for the mixture the reference reports for the best matrix so far
         if np.all(np.isfinite(bmu)) and bmu.min() >= 0:
-            for mu in (bmu, bmu[[0, 2, 1]]):
-                trials.append(canon(assign(mu, np.array([index[(int(a), int(b))] for a, b in bM], np.int64))))
+            start = index[bM[:, 0], bM[:, 1]]
+            parts.append(canon(rows[assign(np.stack([bmu, bmu[[0, 2, 1]]]), np.stack([start, start]))]))
         # steepest descent: every single-row change
-        for i in range(m):
-            for j in allowed[i]:
-                if (rows[j][0], rows[j][1]) != (bM[i][0], bM[i][1]):
-                    T = bM.copy()
-                    T[i] = rows[j]
-                    trials.append(T)
-        mats, nll, mus = value(trials)
+        T = np.repeat(bM[None, :, :], len(ii), axis=0)
+        T[np.arange(len(ii)), ii] = rows[jj]
+        parts.append(T[np.any(rows[jj] != bM[ii], axis=1)])
+        mats, nll, mus = value(np.concatenate(parts))
         if not len(mats):
             break
         k = int(np.argmin(nll))
         if not nll[k] < bv - 1e-9 * abs(bv):
             break
-        bM, bv, bmu = mats[k], float(nll[k]), mus[k]
+        bM, bv, bmu = mats[k].astype(np.int64), float(nll[k]), mus[k]
     return bv, np.asarray(bM, np.uint8)
 
 
@@ -523,7 +566,7 @@ def mix_records(problem, ctx, r, rN, max_normal, bounds, report=None, exchange=N
                 raise
             info["passes"].append({"leaf": leaf, "gave_up": True})
             continue
-        pk = [M for M in props if in_space_n3(M, lb, ub, problem.tau)]
+        pk = list(np.asarray(props)[in_space_n3_batch(props, lb, ub, problem.tau)]) if len(props) else []
         found = None
         if pk:
             okp, _mu, nllp, _v = ctx.solve_batch(3, problem.tau, r, rN, np.ascontiguousarray(np.array(pk, np.uint8)), max_normal, want_vals=False)
@@ -537,7 +580,7 @@ def mix_records(problem, ctx, r, rN, max_normal, bounds, report=None, exchange=N
         inc = float(exchange(inc))
     thr = inc + window + 4 * TIE_MARGIN
     mats, st = problem.mix_search(thr, leaf_rel=leaf_final, cap=1 << 18)
-    keep = [i for i, M in enumerate(mats) if in_space_n3(M, lb, ub, problem.tau)]
+    keep = [int(i) for i in np.nonzero(in_space_n3_batch(mats, lb, ub, problem.tau))[0]] if len(mats) else []
     recs = []
     low = float("inf")
     if keep:

@@ -1,5 +1,5 @@
 """Round 5: the branch and bound (theta_bnb + search of the surviving ranges) against the exhaustive search on whole small spaces,
-and on BASELINE configs 3 / 4.   python tools/bnb_run.py [small|c3|c4] ..."""
+and on BASELINE configs 3 / 4.   python tools/bnb_run.py [small|c3|c4|c5|c100] ..."""
 import json
 import os
 import sys
@@ -58,10 +58,10 @@ if __name__ == "__main__":
             print("m=%d K=%d seed=%d: space %.3g, exhaustive %.2fs, bnb %.2fs (plan %.2fs, %s ranges, %.3g leaves, %s nodes, lines complete %s) entries %d / %d  %s" %
                   (m, K, seed, ra.candidates, ta, tb, info.get("plan_seconds", -1), info.get("ranges"), info.get("leaves", 0), info.get("nodes"),
                    info.get("rank_deficient_complete"), len(a), len(b), same(a, b) or "IDENTICAL"), flush=True)
-    for cfg, K, seed in (("c3", 4, 7), ("c4", 6, 4242)):
+    for cfg, mm, K, seed in (("c3", 50, 4, 7), ("c4", 50, 6, 4242), ("c5", 200, 7, 55), ("c100", 100, 6, 11)):
         if cfg in what:
             t = time.time()
-            b, tb, rb = run(50, K, seed, bnb=True)
-            print(cfg, "m=50 K=%d: %.2f s end to end, best NLL %.6f, %d entries" % (K, tb, b[0][2], len(b)))
+            b, tb, rb = run(mm, K, seed, bnb=True)
+            print(cfg, "m=%d K=%d: %.2f s end to end, best NLL %.6f, %d entries" % (mm, K, tb, b[0][2], len(b)))
             print(json.dumps(rb.mix or rb.bnb, default=float))
             print("report: finalists %s fallback %s seconds %.2f" % (rb.finalists, rb.fallback_finalists, rb.seconds))

@@ -65,7 +65,8 @@ if "records" in wit:
     txt.append("Witness of the headline leg on the last timed range (`witness`: every 1024th of 2^24 candidates, the kernel's own records): %d records, "
                "status %s, %.2f evaluations per candidate (at most %d), largest λ²/Σr at a last evaluation %.3g against the certified threshold %.3g.\n" % (
                    wit["records"], wit["status"], wit["evaluations_mean"], wit["evaluations_max"], wit["l2_last_max"], wit["conv_l2"]))
-for key, label in (("config3_m50_n3_k4", "config 3 (m=50, n=3, k=4, full bounds)"), ("config4_m50_n3_k6", "config 4 (m=50, n=3, k=6, full bounds: this bench's instance)")):
+for key, label in (("config3_m50_n3_k4", "config 3 (m=50, n=3, k=4, full bounds)"), ("config4_m50_n3_k6", "config 4 (m=50, n=3, k=6, full bounds: this bench's instance)"),
+                   ("config5_m200_n3_k7", "config 5's shape (m=200, n=3, k=7, full bounds: the count saturates at 2^128 − 1, the space holds ~1e150 matrices)")):
     c = w.get(key) or {}
     if "gpu_wall_s" in c:
         txt.append("`wall_clock_to_best`, %s: **%.2f s** end to end for the arg-min of the WHOLE space of %.3g matrices (branch and bound over the mixture "
