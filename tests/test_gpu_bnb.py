@@ -231,3 +231,30 @@ def test_more_than_64_rows_within_the_bounds_are_searched_whole(ctx, monkeypatch
     fin = [b for b in tight if b[2] == b[2]]
     assert fin and abs(min(b[2] for b in fin) - low) <= 1e-9 * abs(low), (min(b[2] for b in fin), low, count)
     assert np.array_equal(np.asarray(fin[0][0])[np.asarray(order)][:, 1:].astype(np.uint8), Cw) or len(fin) > 1
+
+
+def test_command_line_on_a_space_no_walk_finishes(ctx, tmp_path, capsys):
+    """`RunTHetA file -n 3 -k 4 --NO_INTERVAL_SELECTION --FORCE` on BASELINE config 3 written as an .intervals file with full bounds
+    [0, 4] (4e27 matrices): the time estimate (the mixture-space search itself, timed: seconds, not the 1e19 years of a walk) lets
+    the run through, and the results file holds the winner do_optimization_single reports for the same instance."""
+    import bench
+    from theta_amd import RunTHetA
+    from theta_amd import search as S
+    r, rN, order = bench.synth(seed=7, m=50, n=3, k=4)
+    path = tmp_path / "c3.intervals"
+    with open(path, "w") as f:
+        f.write("#ID\tchrm\tstart\tend\ttumorCount\tnormalCount\tupperBound\tlowerBound\n")
+        for i in range(50):
+            f.write("i%d\t1\t%d\t%d\t%d\t%d\t4\t0\n" % (i, 1000 * i, 1000 * i + 900, r[i], rN[i]))
+    t0 = time.time()
+    RunTHetA.main([str(path), "-n", "3", "-k", "4", "--NO_INTERVAL_SELECTION", "--FORCE", "-p", "c3", "-d", str(tmp_path)])
+    wall = time.time() - t0
+    out = capsys.readouterr().out
+    assert "Estimated Total Time:" in out and "second(s)" in out.split("Estimated Total Time:")[1].splitlines()[0]
+    lines = [l for l in open(tmp_path / "c3.n3.results") if not l.startswith("#")]
+    nll_cli = float(lines[0].split("\t")[0])
+    best = S.do_optimization_single(3, 50, 4, 2, [0] * 50, [4] * 50, r, rN, 1.0, list(range(50)), False, False)
+    assert abs(nll_cli - best[0][2]) <= 1e-9 * abs(best[0][2]) and len(lines) == len(best)
+    rows = [[int(v) for v in row.split(",")] for row in lines[0].split("\t")[2].split(":")]
+    assert np.array_equal(np.array(rows), np.asarray(best[0][0])[:, 1:].astype(int))
+    assert wall < 30.0
