@@ -272,6 +272,7 @@ struct SvCtx {
     int no_dismiss;
     int second;                      // 1: children that need another evaluation take it IN PLACE, right after the shared one (sv_children): the tight
                                      // full-solve modes, where every child does -- the queue then only holds what needs a third
+    int third_min;                   // ... and a further one in place while at least this many lanes of the trip need it (65: never)
     // the chain point (wave-uniform): where the next round's shared sums are evaluated, see sv_parent
     F wn0, wn1, wn2;
     int qcount;
@@ -732,6 +733,12 @@ __device__ __forceinline__ void sv_parent(SvCtx<ML, F, NS> &c, bool take, unsign
     }
 }
 
+#ifndef SV_LEAN_FIRST
+#define SV_LEAN_FIRST 1   // tight full-solve modes: the shared evaluation without logarithms, value and bound (the second one has them)
+#endif
+#ifndef SV_THIRD_MIN
+#define SV_THIRD_MIN 48   // lanes that must still need an evaluation after the in-place second for a THIRD to be taken in place too (SvCtx.third_min; 65: never)
+#endif
 // What the shared first evaluation of one child comes to (sv_child_eval): all a lane carries from the arithmetic to the
 // bookkeeping, so that the arithmetic of SEVERAL children per lane can be one straight-line block.
 template <class F>
@@ -775,10 +782,12 @@ __device__ __forceinline__ void sv_child_eval(const SvCtx<ML, F, NS> &c, int lo,
     o.ev = o.act && o.regular && (o.code >> 31) && q > F(0);
     // (a lane without a usable point, or with ill-conditioned sums, computes on whatever it has: infinities and NaNs cost nothing
     // and every decision below is behind `good` = ev && cond_ok && num_ok -- no selects in the arithmetic)
-    F w, lq;
-    sv_rcp_lg2(q, w, lq);
+    // The tight full-solve modes (c.second) take a second evaluation of every child anyway and value it there: the shared one is
+    // for the STEP alone -- no logarithms, no value, no bound (SV_LEAN_FIRST; wave-uniform branches).
+    const bool lean = SV_LEAN_FIRST && c.second;
+    F w, lq = F(0);
+    if (lean) w = sv_rcp(q); else sv_rcp_lg2(q, w, lq);
     const F t = Rl * w, tw = t * w, twx = tw * x, twy = tw * y;
-    const F L = sv_fma(Rl, lq, P[0]);
     const F T0 = P[1] + t, T1 = sv_fma(t, x, P[2]), T2 = sv_fma(t, y, P[3]);
     const F W00 = P[4] + tw, W01 = P[5] + twx, W02 = P[6] + twy;
     const F W11 = sv_fma(twx, x, P[7]), W12 = sv_fma(twx, y, P[8]), W22 = sv_fma(twy, y, P[9]);
@@ -794,15 +803,11 @@ __device__ __forceinline__ void sv_child_eval(const SvCtx<ML, F, NS> &c, int lo,
     const F idet = sv_rcp(det);
     const F d1 = (H22 * G1 - H12 * G2) * idet, d2 = (H11 * G2 - H12 * G1) * idet;
     const F l2 = (G1 * d1 + G2 * d2) * c.inv_Rtot;
-    F sc, lz;
-    sv_rcp_lg2(zw, sc, lz);
-    const F val2 = sv_fma(-c.rtot_f, lz, L);
-    F la = F(0);
-    if constexpr (sizeof(F) == 8) la = sv_fma(c.rtot_f, sv_abs(lz), sv_fma(Rl, sv_abs(lq), P[15]));
+    F sc, lz = F(0);
+    if (lean) sc = sv_rcp(zw); else sv_rcp_lg2(zw, sc, lz);
     const bool num_ok = l2 == l2 && sv_abs(d1) + sv_abs(d2) < F(1e30);
-    const F sl = sv_sqrt(l2);
     F step = F(1);
-    if (ballot64(l2 > F(0.09))) step = l2 > F(0.09) ? sv_rcp(F(1) + sl) : F(1);      // (damped phase: rare, the branch is wave-uniform)
+    if (ballot64(l2 > F(0.09))) step = l2 > F(0.09) ? sv_rcp(F(1) + sv_sqrt(l2)) : F(1);      // (damped phase: rare, the branch is wave-uniform)
     // the stepped point on the child's own slice (z.d = 0, so z.w stays): mixture n_j = s_j u_j / z.w
     const F v1 = sv_fma(step, d1, u1) * sc, v2 = sv_fma(step, d2, u2) * sc;
     const bool good = o.ev && cond_ok && num_ok;
@@ -812,9 +817,17 @@ __device__ __forceinline__ void sv_child_eval(const SvCtx<ML, F, NS> &c, int lo,
     o.c2 = v2;
     o.chain = good && sv_abs(o.n1) + sv_abs(o.n2) < F(1e6);
     // (same decisions as in sv_drain)
-    const bool conv = l2 < c.conv_l2 && l2 * c.rtot_over_rmin < F(0.25);
-    const bool beyond = sv_beyond<ML, F, NS>(c, val2, l2, sl, la);
-    const bool done = good && beyond && (!c.no_dismiss || conv);         // the bound (search) / converged and valued beyond the window (full solve)
+    bool conv = false, done = false;
+    F val2 = F(0);
+    if (!lean) {
+        const F L = sv_fma(Rl, lq, P[0]);
+        val2 = sv_fma(-c.rtot_f, lz, L);
+        F la = F(0);
+        if constexpr (sizeof(F) == 8) la = sv_fma(c.rtot_f, sv_abs(lz), sv_fma(Rl, sv_abs(lq), P[15]));
+        conv = l2 < c.conv_l2 && l2 * c.rtot_over_rmin < F(0.25);
+        const bool beyond = sv_beyond<ML, F, NS>(c, val2, l2, sv_sqrt(l2), la);
+        done = good && beyond && (!c.no_dismiss || conv);         // the bound (search) / converged and valued beyond the window (full solve)
+    }
     o.surv = good && !done && conv && l2 < c.fine_l2;
     // queued: another step from the stepped point -- or, without a usable shared point / with ill-conditioned sums, from the
     // simplex centre (NaN marks that: sv_drain has the record's column sums anyway)
@@ -897,10 +910,11 @@ __device__ __forceinline__ void sv_children(SvCtx<ML, F, NS> &c, int total) {
             bool push = o.push;
             F qu1 = o.qu1, qu2 = o.qu2;
             unsigned evals = o.ev ? 1u : 0u;
-            if (c.second && pm) {
+            for (int pass = 0; c.second && pm && (pass == 0 || (pass < 3 && __builtin_popcountll(pm) >= c.third_min)); pass++) {
                 // The tight full-solve modes: (nearly) every child needs a second evaluation -- taken HERE, in lock step, by the lane that
                 // has the child at hand, instead of through the queue (push, pop, decode, column sums, a wave-step that may run half
-                // empty): the queue is left with the ~10 % that need a third.  Same arithmetic, same decisions as sv_drain.
+                // empty): the queue is left with the ~10 % that need a third (and where most of the trip's lanes do -- SV_THIRD_MIN --
+                // that one is taken here as well).  Same arithmetic, same decisions as sv_drain.
                 unsigned rw[ML / 2];
                 sv_child_rows<ML, F, NS>(c, o.code, o.slot, rw);
                 F u1 = qu1, u2 = qu2;
@@ -1294,6 +1308,9 @@ __global__ __launch_bounds__(64 * SV_WAVES, sizeof(F) == 4 ? SV_OCC : SV_OCC64) 
     c.fine_l2 = sizeof(F) == 8 ? (F)fmin(Pg.conv_l2, 1e-8) : c.conv_l2;
     c.no_dismiss = Pg.no_dismiss;
     c.second = Pg.no_dismiss && Pg.conv_l2 < 1e-6 && !Pg.no_second;
+    // a tolerance only a third evaluation meets (the tight leg, 1e-12): that one in place too where most lanes of a trip need it
+    // (measured: tight leg 128.5 -> 121.0 ms per 2^31; at the certified tolerance, where one lane in ten needs a third, +2 %: not taken)
+    c.third_min = Pg.conv_l2 < 1e-10 ? SV_THIRD_MIN : 65;
     c.wn0 = F(__builtin_nanf(""));                   // (no chain point yet: the simplex centre)
     c.wn1 = c.wn2 = F(0);
     c.qcount = 0;
