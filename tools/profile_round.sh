@@ -39,8 +39,8 @@ if [ -f $ROOT/build_ab/libprof.so ]; then
   done > $OUT/phase_cycles.txt
 fi
 # round 5: the branch and bound on BASELINE configs 3 and 4 (end to end through do_optimization_single), and its kernels under rocprofv3
-timeout 300 python -u $ROOT/tools/bnb_run.py c3 c4 > $OUT/bnb_configs_3_4.txt 2>&1
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kb -o kb -- python $ROOT/tools/bnb_run.py c3 c4 > /dev/null 2> $OUT/kb.err
+timeout 300 python -u $ROOT/tools/bnb_run.py c3 c4 c5 > $OUT/bnb_configs_3_4.txt 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kb -o kb -- python $ROOT/tools/bnb_run.py c3 c4 c5 > /dev/null 2> $OUT/kb.err
 cp $(find $OUT/kb -name '*kernel_stats.csv' | head -1) $OUT/bnb_kernel_stats.csv 2>/dev/null
 rm -rf $OUT/kb
 timeout 600 python $ROOT/tools/riders.py > $OUT/riders.json 2> $OUT/riders.err
