@@ -11,8 +11,8 @@
  * Conventions
  *   n        number of populations, 2 or 3 (column 0 of C is the normal genome, == tau)
  *   m        number of intervals of the search (rows of C), 2 <= m <= THETA_MAX_M (n=3: <= 256 on the sieve path -- search, FP64 mode,
- *            materialised generator and theta_solve_batch alike; only theta_search_values, the fused kernel's own
- *            per-candidate dump, holds 64)
+ *            materialised generator, theta_solve_batch and theta_search_values alike; the FUSED kernel's own per-candidate dump
+ *            holds 64, beyond that theta_search_values reports the reference's outcome per candidate)
  *   r, rN    tumour / normal read counts AFTER the reference's sort_r (DataTools.py:95-118),
  *            int64, rN[i] > 0
  *   lb, ub   per-interval copy-number bounds as given to Enumerator(...) (Enumerator.py:39);
@@ -236,6 +236,8 @@ int theta_boundary_min(theta_ctx *ctx, int m, int tau, const int64_t *r, const i
  * n=2: NaN where Optimizer.solve returns None.  n=3: the MINIMUM of each candidate's likelihood where it lies in the
  * simplex, else NaN -- a diagnostic of the fused arithmetic; what the reference REPORTS for an n=3 candidate (its own
  * optimum, the nu = 1/3 fallback, or None) comes from theta_solve_batch (the --GET_VALUES file is written from that).
+ * n=3 with more than 64 intervals (the fused kernel holds one per lane): the dump IS the reference's report for every candidate --
+ * the generator's matrices through theta_solve_batch's kernel, chunk by chunk in HBM; NaN where the reference reports nothing.
  */
 int theta_search_values(theta_problem *p, const uint64_t rank_begin[2], uint64_t count, double *nll,
                         double *mu, theta_search_stats *stats);

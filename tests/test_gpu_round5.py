@@ -199,3 +199,27 @@ def test_witness_of_whole_small_spaces(ctx, m, K, seed, tau):
     for name, opts, left in _legs(rr):
         _check_leg(ctx, p, name, opts, left, 0, total, 0, rr, rn, tau, None, 16, "m%d K%d" % (m, K), mu_tol=1e-5)
     p.close()
+
+
+def test_values_dump_over_more_than_64_intervals(ctx):
+    """theta_search_values on an n=3 space of 100 intervals (round 4: refused, the fused kernel holds 64): per candidate what the
+    reference reports -- equal to theta_solve_batch on the enumerated matrices entry by entry (NaN = nothing reported), and to the
+    oracle's scipy calls on a sub-sample (NLL 1e-9, mu 1e-6)."""
+    import theta_amd
+    from test_gpu_wide import _wide_instance
+    r, rN, _order, _truth, lb, ub = _wide_instance(100, 501, 1)
+    p = theta_amd.Problem(ctx, 3, 100, 2, r, rN, lb, ub, 1.0)
+    count = int(min(p.count, 3000))
+    b = (p.count - count) // 2
+    nll, mu, st = p.values(b, count)
+    Cs = p.enumerate(b, count)
+    p.close()
+    ok, mu_b, nll_b, _ = ctx.solve_batch(3, 2, r, rN, np.ascontiguousarray(Cs), 1.0, want_vals=False)
+    assert st["evaluated"] == count and st["accepted"] == int((ok > 0).sum()) and st["accepted"] > 0
+    rep = ok > 0
+    assert np.array_equal(np.isnan(nll), ~rep | np.isnan(nll_b))
+    both = rep & ~np.isnan(nll_b)
+    assert np.array_equal(nll[both], nll_b[both]) and np.array_equal(mu[both], mu_b[both])
+    idx = np.where(both)[0][:: max(1, both.sum() // 12)][:12]
+    for j, s in zip(idx, _oracle_rows(Cs[idx], 2, r, rN)):
+        assert s is not None and abs(s[1] - nll[j]) <= 1e-9 * abs(s[1]) and np.abs(np.asarray(s[0]) - mu[j]).max() < 1e-6, int(j)

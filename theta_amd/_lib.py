@@ -751,7 +751,8 @@ class Problem:
         return [int(rank[i, 0]) | (int(rank[i, 1]) << 64) for i in range(k)], self._shape_C(Cb, k)
 
     def values(self, begin, count):
-        """Per-candidate (nll, mu) of the fused kernel (NaN = None): the --GET_VALUES dump."""
+        """Per-candidate (nll, mu), NaN = None: the --GET_VALUES dump (the fused kernel's own; n=3 with more than 64 intervals: what
+        the reference reports for each candidate, through the generator and theta_solve_batch's kernel)."""
         nll = np.zeros(count)
         mu = np.zeros((count, self.n))
         st = SearchStats()

@@ -1280,6 +1280,57 @@ extern "C" int theta_search_values(theta_problem *p, const uint64_t rank_begin[2
     if (count == 0) return THETA_OK;
     HIP_ENTER(p->ctx->device);
     hipStream_t st = p->ctx->stream;
+    if (p->n == 3 && p->m > N3_MAX_M) {
+        // More intervals than the fused kernel holds (one per lane): the dump is what the REFERENCE reports for each candidate --
+        // the generator's matrices through theta_solve_batch's kernel (hybrj, the BFGS decision, M3, L3: RunTHetA.py:185-215 per
+        // candidate), chunk by chunk without leaving HBM.  NaN where the reference reports nothing (Optimizer.solve -> None).
+        const uint64_t chunk = std::min<uint64_t>(count, 1ull << 20);
+        const size_t cb = (size_t)p->m * 2;
+        DevBuf d_C, d_ok, d_nll, d_mu;
+        if ((rc = d_C.alloc(chunk * cb)) || (rc = d_ok.alloc(chunk)) || (rc = d_nll.alloc(chunk * sizeof(double))) ||
+            (rc = d_mu.alloc(chunk * 3 * sizeof(double))))
+            return rc;
+        std::vector<unsigned char> ok(chunk);
+        double kms = 0.0;
+        uint64_t accepted = 0;
+        for (uint64_t at = 0; at < count; at += chunk) {
+            const uint64_t c = std::min<uint64_t>(chunk, count - at);
+            double ems = 0.0;
+            rc = enumerate_device(p, b + at, c, (unsigned char *)d_C.p, &ems);
+            if (rc) return rc;
+            HIP_TRY(hipEventRecord(p->ctx->ev0, st));
+            batch_launch_solve(3, p->m, p->tau, (const double *)p->d_r.p, (const double *)p->d_rN.p, p->max_normal, (int)c,
+                               (const unsigned char *)d_C.p, (unsigned char *)d_ok.p, (double *)d_mu.p, (double *)d_nll.p, nullptr, st);
+            HIP_TRY(hipEventRecord(p->ctx->ev1, st));
+            HIP_TRY(hipMemcpyAsync(nll + at, d_nll.p, c * sizeof(double), hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(mu + 3 * at, d_mu.p, c * 3 * sizeof(double), hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(ok.data(), d_ok.p, c, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            HIP_TRY(hipGetLastError());
+            float ms = 0.0f;
+            HIP_TRY(hipEventElapsedTime(&ms, p->ctx->ev0, p->ctx->ev1));
+            kms += ems + (double)ms;
+            const double qnan = __builtin_nan("");
+            for (uint64_t i = 0; i < c; i++) {
+                if (ok[i]) {
+                    accepted++;
+                } else {
+                    nll[at + i] = qnan;
+                    mu[3 * (at + i)] = mu[3 * (at + i) + 1] = mu[3 * (at + i) + 2] = qnan;
+                }
+            }
+        }
+        if (stats) {
+            memset(stats, 0, sizeof(*stats));
+            stats->evaluated = count;
+            stats->accepted = accepted;
+            stats->kernel_ms = kms;
+            stats->best_nll = __builtin_inf();
+            for (uint64_t i = 0; i < count; i++)
+                if (nll[i] < stats->best_nll) stats->best_nll = nll[i];
+        }
+        return THETA_OK;
+    }
     DevBuf d_nll, d_mu;
     rc = d_nll.alloc(count * sizeof(double));
     if (rc) return rc;
