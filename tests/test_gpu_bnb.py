@@ -258,3 +258,19 @@ def test_command_line_on_a_space_no_walk_finishes(ctx, tmp_path, capsys):
     rows = [[int(v) for v in row.split(",")] for row in lines[0].split("\t")[2].split(":")]
     assert np.array_equal(np.array(rows), np.asarray(best[0][0])[:, 1:].astype(int))
     assert wall < 30.0
+
+
+def test_get_values_on_a_space_no_walk_finishes_is_skipped_with_a_warning(ctx, tmp_path, capsys):
+    """--GET_VALUES (RunTHetA.py:210-215) writes a line per candidate: on BASELINE config 3 (4e27 matrices) the search completes, the
+    dump is skipped with a warning (THETA_GET_VALUES_MAX) -- the reference would evaluate and write for 1e19 years."""
+    import bench
+    from theta_amd import search as S
+    r, rN, order = bench.synth(seed=7, m=50, n=3, k=4)
+    S.pre = str(tmp_path / "big")
+    try:
+        best = S.do_optimization_single(3, 50, 4, 2, [0] * 50, [4] * 50, r, rN, 1.0, order, False, True)
+    finally:
+        pre, S.pre = S.pre, "theta"
+    out = capsys.readouterr().out
+    assert "WARNING: --GET_VALUES" in out and not (tmp_path / "big.likelihoods").exists()
+    assert len(best) >= 1 and abs(best[0][2] - 22588904.807977) < 1e-3

@@ -49,6 +49,7 @@ BNB_MIN_CANDIDATES = int(float(os.environ.get("THETA_BNB_MIN_CANDIDATES", 2 ** 4
 # once): a fraction of a second for BASELINE configs 3 and 4.  The row-tree walk (theta_bnb) is the fallback where that one gives up
 MIX_LEAF_REL = float(os.environ.get("THETA_MIX_LEAF_REL", 0))      # 0: from the data -- a fraction of the radius of the region of mixtures within the window, sqrt(2 window / sum r)
 USE_MIX = os.environ.get("THETA_USE_MIX", "1") != "0"
+GET_VALUES_MAX = int(float(os.environ.get("THETA_GET_VALUES_MAX", 2 ** 32)))    # candidates a --GET_VALUES dump may hold (a line each)
 BNB_BEAM = int(os.environ.get("THETA_BNB_BEAM", 1024))           # nodes per level of the dive that finds the first attainable NLL
 BNB_MAX_NODES = int(float(os.environ.get("THETA_BNB_MAX_NODES", 2 ** 27)))     # node budget of the row-tree walk (a minute of the GPU): beyond, the call gives up
 BNB_LINE_NODES = int(float(os.environ.get("THETA_BNB_LINE_NODES", 2 ** 22)))   # node budget of the walk that also follows collinear prefixes
@@ -308,6 +309,12 @@ def _dump_values(problem, n, m, q1=None):
     """--GET_VALUES (RunTHetA.py:210-215): '<C column 1 as digits> TAB <mu0> TAB <NLL>' per accepted candidate, in the order
     the reference evaluates them -- quirk Q1 included: its first matrix (RunTHetA.py:188) is the first candidate once more
     for n=2 (that line appears twice) and the [tau,0,0] matrix for n=3 (`q1`: a line of m zeros with M3's residue as mu0)."""
+    if problem.count > GET_VALUES_MAX:
+        # one line per candidate: the reference would write (and evaluate) them all -- 1e27 lines for a space the branch and bound
+        # above searched in a second.  Said instead of done; the search's results stand.
+        print("WARNING: --GET_VALUES writes one line per candidate matrix; this search holds %.3g of them (limit %d: THETA_GET_VALUES_MAX). "
+              "No .likelihoods file is written; the search itself is complete." % (float(problem.count), GET_VALUES_MAX))
+        return
     with open(pre + ".likelihoods", "w") as f:
         if q1 is not None:
             f.write("0" * m + "\t" + str(float(q1["mu"][0])) + "\t" + str(float(q1["nll"])) + "\n")
