@@ -329,7 +329,13 @@ extern "C" int theta_problem_create(theta_ctx *ctx, int n, int m, int tau, const
         p->total[0] = h.total;
         p->total[1] = 0;
     } else {
+        const auto tc0 = std::chrono::steady_clock::now();
+        auto tc_say = [&](const char *what) {
+            if (getenv("THETA_CREATE_DEBUG"))
+                fprintf(stderr, "create: %s at %.1f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tc0).count());
+        };
         TRY(n3_build_host(m, tau, lb, ub, p->n3h));
+        tc_say("host tables");
         const N3Host &h = p->n3h;
         if (h.mix_only) {
             // more than 64 rows (a, b) within the bounds (full bounds [0, 8] and beyond): no child masks, no counting table, no ranks.
@@ -417,7 +423,9 @@ extern "C" int theta_problem_create(theta_ctx *ctx, int n, int m, int tau, const
                             (unsigned long long)ctx->hbm_bytes);
             return THETA_ERR_HIP;
         }
+        tc_say("uploads");
         TRY(p->d_cnt.alloc(cnt_bytes));
+        tc_say("table allocated");
         D.cnt = (const u128 *)p->d_cnt.p;
         TRY(p->d_misc.alloc(64));
         HIP_TRY(hipMemsetAsync(p->d_misc.p, 0, 64, st));
@@ -428,6 +436,7 @@ extern "C" int theta_problem_create(theta_ctx *ctx, int n, int m, int tau, const
         HIP_TRY(hipMemcpyAsync(hostmisc, p->d_misc.p, 64, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
         HIP_TRY(hipGetLastError());
+        tc_say("counting DP");
         unsigned hov;
         memcpy(&hov, hostmisc, 4);
         // (a space of 2^128 matrices or more: the counting table saturates -- n3_dp_kernel -- and theta_problem_count reports
@@ -453,6 +462,7 @@ extern "C" int theta_problem_create(theta_ctx *ctx, int n, int m, int tau, const
         D.L = L;
         TRY(p->d_tasks.alloc((size_t)N3_MAX_TASKS * sizeof(N3Task)));
         TRY(p->d_stbuf.alloc(((size_t)N3_MAX_TASKS * N3_STB + 16 * N3_STB) * sizeof(unsigned)));      // (+ the anchor path of n3_launch_tasks)
+        tc_say("task buffers");
     }
     HIP_TRY(hipStreamSynchronize(st));
 #undef TRY

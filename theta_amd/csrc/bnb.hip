@@ -21,6 +21,7 @@
 // as rank ranges, where the sieve's own bounds finish the job.  The host driver (api.hip: theta_bnb) walks the levels depth
 // first in chunks when a level outgrows its buffer, so memory is bounded by depth x chunk x alphabet.
 #include "bnb.hpp"
+#include "smx_log.hpp"            // the table-driven FP64 logarithm of the scorers (tests/test_smx_log_cpu.py)
 
 struct BnbWave {
     double binR[N3_MAX_Q], binN[N3_MAX_Q];      // tumour / normal counts of the prefix's intervals, per alphabet slot
@@ -419,7 +420,7 @@ __device__ __forceinline__ double mix_wave_sum(double v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
     return v;
 }
-__device__ double mix_cell_bound(const MixArgs &A, const MixCell &c, const float2 *rows, int lane) {
+__device__ double mix_cell_bound(const MixArgs &A, const MixCell &c, const float2 *rows, const double2 *ltab, int lane) {
     const double tau = (double)A.tau;
     double vc[3], h[3];
     for (int j = 0; j < 3; j++) {
@@ -431,24 +432,26 @@ __device__ double mix_cell_bound(const MixArgs &A, const MixCell &c, const float
     for (int i = lane; i < A.m; i += WAVE) {
         const double r = A.r[i], N = A.rN[i], ts = r / N;
         const int l = A.lb[i], u = A.ub[i];
-        double best1 = __builtin_inf(), bestv[8];
+        // (1): phi_i is convex with its minimum at ts, so over the rows the smallest clamped value is phi(ts) if some row's interval
+        // [tlo, thi] holds ts, else the better of phi(largest thi below ts) and phi(smallest tlo above it): two logarithms per
+        // interval, not one per row (round 5's first version: m x rows library logarithms were two thirds of the kernel)
+        bool any = false, holds = false;
+        double tbelow = -__builtin_inf(), tabove = __builtin_inf(), bestv[8];
         for (int k = 0; k < 8; k++) bestv[k] = __builtin_inf();
         for (int s = 0; s < A.Q; s++) {
             const float2 rw = rows[s];
             const int a = (int)rw.x, b = (int)rw.y;
             if (a < l || a > u || b < l || b > u || (A.tau - a) * (A.tau - b) < 0) continue;
+            any = true;
             const double x = (double)a, y = (double)b;
             const double tlo = tau * c.lo[0] + x * c.lo[1] + y * c.lo[2], thi = tau * c.hi[0] + x * c.hi[1] + y * c.hi[2];
-            // (1) phi at the point of [tlo, thi] nearest ts
-            const double t = ts < tlo ? tlo : (ts > thi ? thi : ts);
-            double v1;
-            if (r > 0.0) v1 = t > 0.0 ? N * t - r * log(N * t) : __builtin_inf();
-            else v1 = N * t;
-            best1 = fmin(best1, v1);
+            if (thi < ts) tbelow = fmax(tbelow, thi);
+            else if (tlo > ts) tabove = fmin(tabove, tlo);
+            else holds = true;
             // (2) tangent at the centre, at the eight corners
             const double tc = tau * vc[0] + x * vc[1] + y * vc[2];
             if (tc > 0.0) {
-                const double f0 = r > 0.0 ? N * tc - r * log(N * tc) : N * tc, f1 = N - r / tc;
+                const double f0 = r > 0.0 ? N * tc - r * smx_log(N * tc, ltab) : N * tc, f1 = N - r / tc;
                 const double d0 = f1 * tau * h[0], d1 = f1 * x * h[1], d2 = f1 * y * h[2];
 #pragma unroll
                 for (int k = 0; k < 8; k++) {
@@ -457,6 +460,16 @@ __device__ double mix_cell_bound(const MixArgs &A, const MixCell &c, const float
                 }
             } else {
                 for (int k = 0; k < 8; k++) bestv[k] = -__builtin_inf();
+            }
+        }
+        auto phi = [&](double t) { return r > 0.0 ? (t > 0.0 ? N * t - r * smx_log(N * t, ltab) : __builtin_inf()) : N * t; };
+        double best1 = __builtin_inf();
+        if (any) {
+            if (holds) {
+                best1 = phi(ts);
+            } else {
+                if (tbelow > -__builtin_inf()) best1 = phi(tbelow);
+                if (tabove < __builtin_inf()) best1 = fmin(best1, phi(tabove));
             }
         }
         lb1 += best1;
@@ -473,7 +486,9 @@ __device__ double mix_cell_bound(const MixArgs &A, const MixCell &c, const float
 __global__ __launch_bounds__(256) void mix_split_kernel(MixArgs A, const MixCell *in, unsigned long long n_in, MixCell *out, unsigned long long out_cap,
                                                         MixCell *leaves, unsigned long long leaf_cap, unsigned long long *counters) {
     __shared__ float2 rows[MIX_MAX_Q];
+    __shared__ double2 ltab[128];                    // smx_log's table (the scorers' logarithm: 15 vector instructions, within an ulp)
     for (int s = threadIdx.x; s < A.Q; s += blockDim.x) rows[s] = make_float2((float)(A.rowtab[s] & 15u), (float)(A.rowtab[s] >> 4));
+    smx_log_stage(ltab);
     __syncthreads();
     const int lane = threadIdx.x & 63;
     const unsigned long long k = (unsigned long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -490,7 +505,7 @@ __global__ __launch_bounds__(256) void mix_split_kernel(MixArgs A, const MixCell
     }
     const double mid = 0.5 * (c.lo[ax] + c.hi[ax]);
     if (k & 1) c.lo[ax] = mid; else c.hi[ax] = mid;
-    const double lb = mix_cell_bound(A, c, rows, lane);
+    const double lb = mix_cell_bound(A, c, rows, ltab, lane);
     if (!(lb <= A.thr) || lane != 0) return;
     c.lb = lb;
     bool leaf = true;
