@@ -84,6 +84,11 @@ int theta_problem_create(theta_ctx *ctx, int n, int m, int tau, const int64_t *r
                          const int32_t *lb, const int32_t *ub, double max_normal,
                          theta_problem **out);
 void theta_problem_destroy(theta_problem *p);
+/* log2 of a LOWER BOUND of the number of matrices of an n=3 space (host arithmetic, no GPU, a millisecond): the matrices whose rows
+ * keep a + b from decreasing -- all of them matrices Enumerator._generate_next_C_3 yields (Enumerator.py:172-264: the ratio window
+ * of such a matrix always holds the ratio 1); exponentially many in m.  theta_problem_create uses it to tell a space of 2^128 matrices or more WITHOUT its counting table (m = 200, k = 7:
+ * 2 GB, 0.4 s), which then waits for the first call that takes ranks; -inf when the bound is 0. */
+int theta_count_lower_bound(int m, int tau, const int32_t *lb, const int32_t *ub, double *log2_count);
 /* Number of candidates generate_next_C() would yield (excludes the Q1 duplicate first matrix). */
 int theta_problem_count(theta_problem *p, uint64_t count[2]);
 

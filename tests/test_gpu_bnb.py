@@ -274,3 +274,28 @@ def test_get_values_on_a_space_no_walk_finishes_is_skipped_with_a_warning(ctx, t
     out = capsys.readouterr().out
     assert "WARNING: --GET_VALUES" in out and not (tmp_path / "big.likelihoods").exists()
     assert len(best) >= 1 and abs(best[0][2] - 22588904.807977) < 1e-3
+
+
+def test_counting_table_of_a_space_beyond_2_to_the_128_waits_for_the_first_rank(ctx, monkeypatch):
+    """BASELINE config 5's shape (m = 200, k = 7, full bounds: ~1e150 matrices): theta_problem_create knows from a host-side lower
+    bound (theta_count_lower_bound, 2^530) that the count saturates and leaves the 2 GB counting table (200 launches, 0.4 s) to the
+    first call that takes ranks -- the mixture-space search never asks.  A rank range searched afterwards returns what the same
+    problem returns with the table built at creation (THETA_N3_LAZY_TABLE=0)."""
+    import bench
+    import theta_amd
+    r, rN, order = bench.synth(seed=55, m=200, n=3, k=7)
+    times = {}
+    out = {}
+    for lazy in ("1", "0"):
+        monkeypatch.setenv("THETA_N3_LAZY_TABLE", lazy)
+        t0 = time.time()
+        p = theta_amd.Problem(ctx, 3, 200, 2, r, rN, [0] * 200, [7] * 200, 1.0)
+        times[lazy] = time.time() - t0
+        assert p.count == 2 ** 128 - 1
+        b = 2 ** 100
+        res = p.search(b, b + (1 << 22), window=0.5)
+        out[lazy] = (res["rank"], res["nll"], p.enumerate(b + 12345, 3))
+        p.close()
+    assert times["1"] < 0.5 * times["0"], times
+    assert list(out["1"][0]) == list(out["0"][0]) and np.array_equal(out["1"][1], out["0"][1]) and np.array_equal(out["1"][2], out["0"][2])
+    assert len(out["1"][0]) >= 1

@@ -90,7 +90,7 @@ _lib = None
 
 # every symbol include/theta_hip.h declares
 EXPORTS = ["theta_create", "theta_device_count", "theta_destroy", "theta_last_error", "theta_device_info", "theta_problem_create",
-           "theta_problem_destroy", "theta_problem_count", "theta_search", "theta_search_values", "theta_search_witness", "theta_bnb", "theta_search_ranges", "theta_mix_search", "theta_enumerate", "theta_enumerate_device",
+           "theta_problem_destroy", "theta_problem_count", "theta_count_lower_bound", "theta_search", "theta_search_values", "theta_search_witness", "theta_bnb", "theta_search_ranges", "theta_mix_search", "theta_enumerate", "theta_enumerate_device",
            "theta_solve_batch", "theta_score_batch", "theta_score_masked", "theta_search_suspects", "theta_boundary_min", "theta_problem_hint",
            "theta_search_degenerate", "theta_problem_set_option", "theta_synchronize",
            "theta_score_batch_rows", "theta_device_alloc", "theta_device_free", "theta_device_copy", "theta_solve_batch_device",
@@ -114,6 +114,7 @@ def load():
     lib.theta_create.argtypes = [i32, C.POINTER(vp)]
     lib.theta_device_count.argtypes = [C.POINTER(i32)]
     lib.theta_refpow_check.argtypes = [i32, C.POINTER(i32)]
+    lib.theta_count_lower_bound.argtypes = [i32, i32, i32p, i32p, C.POINTER(C.c_double)]
     lib.theta_destroy.argtypes = [vp]
     lib.theta_destroy.restype = None
     lib.theta_device_info.argtypes = [vp, C.c_char_p, i32, C.POINTER(i32), u64p]
@@ -172,6 +173,15 @@ def _p(arr, ctype):
 def _u128(v):
     v = int(v)
     return (C.c_uint64 * 2)(v & 0xFFFFFFFFFFFFFFFF, v >> 64)
+
+
+def count_lower_bound_log2(m, tau, lower_bounds, upper_bounds):
+    """theta_count_lower_bound: log2 of a lower bound of the number of matrices of an n=3 space (host only, no GPU)."""
+    lb = np.ascontiguousarray(lower_bounds, np.int32)
+    ub = np.ascontiguousarray(upper_bounds, np.int32)
+    out = C.c_double(0.0)
+    _check(load().theta_count_lower_bound(int(m), int(tau), lb.ctypes.data_as(C.POINTER(C.c_int32)), ub.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(out)))
+    return out.value
 
 
 _pow_check = None

@@ -175,6 +175,8 @@ struct theta_problem {
     bool opt_auto64 = true;            // ... unless switched off (option "n3_auto_f64")
     bool count_saturated = false;      // n=3: the space holds 2^128 matrices or more (total = 2^128 - 1)
     bool mix_only = false;             // n=3: more than 64 rows within the bounds -- no ranks: theta_mix_search and the batch operators only
+    bool table_pending = false;        // n=3: the counting table is built at the first call that takes ranks (ensure_table): the space provably holds
+                                       // 2^128 matrices or more, so its count is known without it
     unsigned opt_surv_cap = 0;         // n=3: contenders a slice may list before it counts as overflowed (0: SURV_CAP; smaller
                                        // values make the tests walk the redo ladder: sieve again -> 8 parts -> fused kernel)
     int device = 0;                                     // (= ctx->device: the destructor must not need the context)
@@ -202,6 +204,106 @@ extern "C" void theta_problem_destroy(theta_problem *p) {
     (void)hipSetDevice(p->device);
     delete p;
     (void)hipGetLastError();
+}
+
+// A lower bound of the number of matrices of an n = 3 space, on the host in a millisecond: the matrices along which a + b never
+// decreases.  Every one of them is a matrix Enumerator._generate_next_C_3 yields, given valid rows within the adjusted bounds
+// and the symmetry rule (a <= b in the first off-diagonal row, Enumerator.py:181-183, 199-202): between consecutive rows either
+// nothing changes or some component increases (:258-260), and the ratio window (:225-239) always holds the ratio 1 -- a step with
+// dx > 0 > dy and dx + dy >= 0 raises its lower end to |dy| / dx <= 1, a step with dx < 0 < dy lowers its upper end to dy / |dx| >= 1,
+// all others leave it alone.  Unlike the matrices that are monotone in both components (polynomially many in m) this family is
+// exponential: 4^m on the anti-diagonal a + b = 7 alone.  log2 of the count, long double (1e4932 is room enough for any m <= 256).
+static double n3_count_lower_bound_log2(const N3Host &h, int m, int tau) {
+    struct Row { int a, b; };
+    std::vector<Row> rows;
+    for (int a = 0; a <= h.K; a++)
+        for (int b = 0; b <= h.K; b++)
+            if ((tau - a) * (tau - b) >= 0) rows.push_back({a, b});
+    const int R = (int)rows.size(), S = 2 * h.K + 1;
+    auto in = [&](int i, const Row &r) { return r.a >= h.lb[i] && r.a <= h.ub[i] && r.b >= h.lb[i] && r.b <= h.ub[i]; };
+    // f[0][r]: sequences ending in row r whose rows so far all have a == b (the symmetry rule still binds); f[1][r]: the others
+    std::vector<long double> f0(R, 0.0L), f1(R, 0.0L), c0(S + 1), c1(S + 1);
+    for (int r = 0; r < R; r++)
+        if (in(0, rows[r]) && rows[r].a <= rows[r].b) (rows[r].a == rows[r].b ? f0 : f1)[r] = 1.0L;
+    for (int i = 1; i < m; i++) {
+        // cumulative over a + b: c[s + 1] = sum of f over the rows with a + b <= s
+        std::fill(c0.begin(), c0.end(), 0.0L);
+        std::fill(c1.begin(), c1.end(), 0.0L);
+        for (int r = 0; r < R; r++) {
+            c0[rows[r].a + rows[r].b + 1] += f0[r];
+            c1[rows[r].a + rows[r].b + 1] += f1[r];
+        }
+        for (int s = 0; s < S; s++) {
+            c0[s + 1] += c0[s];
+            c1[s + 1] += c1[s];
+        }
+        for (int r = 0; r < R; r++) {
+            const Row &w = rows[r];
+            const long double below0 = c0[w.a + w.b + 1], below1 = c1[w.a + w.b + 1];
+            f0[r] = f1[r] = 0.0L;
+            if (!in(i, w)) continue;
+            if (w.a == w.b) {
+                f0[r] = below0;                       // still all-diagonal
+                f1[r] = below1;
+            } else {
+                f1[r] = below1 + (w.a < w.b ? below0 : 0.0L);      // the first off-diagonal row needs a < b
+            }
+        }
+    }
+    long double tot = 0.0L;
+    for (int r = 0; r < R; r++) tot += f0[r] + f1[r];
+    return tot > 0.0L ? (double)log2l(tot) : -INFINITY;
+}
+
+extern "C" int theta_count_lower_bound(int m, int tau, const int32_t *lb, const int32_t *ub, double *log2_count) {
+    if (m < 1 || m > N3_MAX_M_WIDE || !lb || !ub || !log2_count) {
+        theta_set_error("theta_count_lower_bound: bad argument");
+        return THETA_ERR_ARG;
+    }
+    N3Host h;
+    h.m = m;
+    h.lb.assign(lb, lb + m);
+    h.ub.assign(ub, ub + m);
+    for (int i = 1; i < m; i++)                       // Enumerator._check_bound_order (Enumerator.py:90-113), as n3_build_host does
+        if (h.lb[i] < h.lb[i - 1]) h.lb[i] = h.lb[i - 1];
+    for (int i = m - 2; i >= 0; i--)
+        if (h.ub[i] > h.ub[i + 1]) h.ub[i] = h.ub[i + 1];
+    h.K = 0;
+    for (int i = 0; i < m; i++) {
+        if (h.lb[i] < 0 || h.ub[i] > N3_MAX_COPY) {
+            theta_set_error("theta_count_lower_bound: bounds outside [0, %d]", N3_MAX_COPY);
+            return THETA_ERR_ARG;
+        }
+        h.K = std::max(h.K, h.ub[i]);
+    }
+    *log2_count = n3_count_lower_bound_log2(h, m, tau);
+    return THETA_OK;
+}
+
+// The counting table of an n = 3 problem whose creation deferred it (table_pending): built now, before the first kernel that reads it.
+static int ensure_table(theta_problem *p) {
+    if (!p || !p->table_pending) return THETA_OK;
+    HIP_ENTER(p->ctx->device);
+    hipStream_t st = p->ctx->stream;
+    N3Dev &D = p->n3;
+    const size_t per_level = (size_t)D.Q * 2 * (D.NT + 1) * (D.NT + 1);
+    int rc = p->d_cnt.alloc(per_level * p->m * sizeof(u128));
+    if (rc) return rc;
+    D.cnt = (const u128 *)p->d_cnt.p;
+    HIP_TRY(hipMemsetAsync(p->d_misc.p, 0, 64, st));
+    n3_run_dp(D, (u128 *)p->d_cnt.p, (unsigned *)p->d_misc.p, (unsigned long long *)((char *)p->d_misc.p + 16), st);
+    unsigned char hostmisc[64];
+    HIP_TRY(hipMemcpyAsync(hostmisc, p->d_misc.p, 64, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(hipGetLastError());
+    unsigned hov;
+    memcpy(&hov, hostmisc, 4);
+    if (!hov) {        // (the host's lower bound said 2^128 or more: the table must have saturated)
+        theta_set_error("internal: the counting table of a space counted as saturated did not saturate");
+        return THETA_ERR_HIP;
+    }
+    p->table_pending = false;
+    return THETA_OK;
 }
 
 extern "C" int theta_problem_create(theta_ctx *ctx, int n, int m, int tau, const int64_t *r, const int64_t *rN,
@@ -424,25 +526,37 @@ extern "C" int theta_problem_create(theta_ctx *ctx, int n, int m, int tau, const
             return THETA_ERR_HIP;
         }
         tc_say("uploads");
-        TRY(p->d_cnt.alloc(cnt_bytes));
-        tc_say("table allocated");
-        D.cnt = (const u128 *)p->d_cnt.p;
         TRY(p->d_misc.alloc(64));
-        HIP_TRY(hipMemsetAsync(p->d_misc.p, 0, 64, st));
-        unsigned *ovf = (unsigned *)p->d_misc.p;
-        unsigned long long *tot = (unsigned long long *)((char *)p->d_misc.p + 16);
-        n3_run_dp(D, (u128 *)p->d_cnt.p, ovf, tot, st);
-        unsigned char hostmisc[64];
-        HIP_TRY(hipMemcpyAsync(hostmisc, p->d_misc.p, 64, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
-        HIP_TRY(hipGetLastError());
-        tc_say("counting DP");
-        unsigned hov;
-        memcpy(&hov, hostmisc, 4);
-        // (a space of 2^128 matrices or more: the counting table saturates -- n3_dp_kernel -- and theta_problem_count reports
-        // 2^128 - 1, "at least that many"; the first 2^128 - 1 ranks of the reference's order are searched like any others)
-        p->count_saturated = hov != 0;
-        memcpy(p->total, hostmisc + 16, 16);
+        // A LARGE table (m = 200, K = 7: 2 GB, 200 launches of 2 ms) of a space that provably holds 2^128 matrices or more -- its count
+        // is "2^128 - 1: that many or more" whatever the table says -- waits for the first call that takes ranks (ensure_table):
+        // the mixture-space search, which serves such a space whole, never reads it.  (THETA_N3_LAZY_TABLE=0: always built here.)
+        const bool lazy_ok = !(getenv("THETA_N3_LAZY_TABLE") && atoi(getenv("THETA_N3_LAZY_TABLE")) == 0);
+        if (lazy_ok && cnt_bytes >= ((size_t)64 << 20) && n3_count_lower_bound_log2(h, m, tau) >= 130.0) {
+            p->table_pending = true;
+            p->count_saturated = true;
+            p->total[0] = p->total[1] = ~0ull;
+            D.cnt = nullptr;
+            tc_say("counting DP deferred");
+        } else {
+            TRY(p->d_cnt.alloc(cnt_bytes));
+            tc_say("table allocated");
+            D.cnt = (const u128 *)p->d_cnt.p;
+            HIP_TRY(hipMemsetAsync(p->d_misc.p, 0, 64, st));
+            unsigned *ovf = (unsigned *)p->d_misc.p;
+            unsigned long long *tot = (unsigned long long *)((char *)p->d_misc.p + 16);
+            n3_run_dp(D, (u128 *)p->d_cnt.p, ovf, tot, st);
+            unsigned char hostmisc[64];
+            HIP_TRY(hipMemcpyAsync(hostmisc, p->d_misc.p, 64, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            HIP_TRY(hipGetLastError());
+            tc_say("counting DP");
+            unsigned hov;
+            memcpy(&hov, hostmisc, 4);
+            // (a space of 2^128 matrices or more: the counting table saturates -- n3_dp_kernel -- and theta_problem_count reports
+            // 2^128 - 1, "at least that many"; the first 2^128 - 1 ranks of the reference's order are searched like any others)
+            p->count_saturated = hov != 0;
+            memcpy(p->total, hostmisc + 16, 16);
+        }
         D.total_lo = p->total[0];
         D.total_hi = p->total[1];
         // leaf levels enumerated by the lanes (one byte of the 64-bit leaf code each, at most 8): enough of them that a
@@ -523,6 +637,10 @@ static int check_range(theta_problem *p, const uint64_t rb[2], const uint64_t re
         theta_set_error("%d distinct rows (a, b) lie within the bounds: more than the 64 the rank-walking kernels hold; such a space is searched "
                         "whole (theta_mix_search, do_optimization_single), it has no ranks", p->n3.Q);
         return THETA_ERR_ARG;
+    }
+    if (p->table_pending) {
+        int rc = ensure_table(p);
+        if (rc) return rc;
     }
     u128 tot = mk128(p->total);
     if (tot == 0) {
@@ -1168,6 +1286,10 @@ extern "C" int theta_search_ranges(theta_problem *p, int nranges, const uint64_t
     if (p->n != 3 || p->mix_only) {
         theta_set_error("theta_search_ranges: n = 3 with at most 64 rows within the bounds only (a space with more has no ranks)");
         return THETA_ERR_ARG;
+    }
+    if (p->table_pending) {
+        int rc = ensure_table(p);
+        if (rc) return rc;
     }
     std::vector<std::pair<u128, u128>> rg;
     const u128 total = ((u128)p->total[1] << 64) | p->total[0];
