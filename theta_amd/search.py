@@ -508,6 +508,10 @@ def heuristic_incumbent(ctx, m, tau, lower_bounds, upper_bounds, r, rN, max_norm
     index = -np.ones((K + 1, K + 1), np.int64)
     index[rows[:, 0], rows[:, 1]] = np.arange(len(rows))
     ii, jj = np.nonzero(allowed)                                  # every (interval, row within its bounds)
+    if len(ii) > 4096:
+        # a round of single-row changes this large (m = 200, k = 7: 12 800 trials, 60 ms) buys one row at a time: the proposal
+        # passes of mix_records, which start from whatever this returns, move all rows at once -- a round or two, not a dozen
+        budget_s = min(budget_s, 0.05)
     for _round in range(rounds):
         if time.time() - t0 > budget_s:
             break
