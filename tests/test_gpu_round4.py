@@ -242,7 +242,7 @@ def test_two_hundred_intervals_on_the_sieve_path(ctx):
     cs = C[:, 1:][order]
     lb = [int(v) for v in cs.min(axis=1)]
     ub = [int(v) for v in cs.max(axis=1)]
-    free = rng.choice(m, 3, replace=False)
+    free = rng.choice(m, 3, replace=False)[:2]         # (two of the three: 986 matrices through scipy instead of 3 908 -- 12 s instead of 46)
     for i in free:
         lb[i], ub[i] = max(0, lb[i] - 1), min(K, ub[i] + 1)
     cnt = orc.count_n3_exact(m, 2, list(lb), list(ub))
