@@ -12,6 +12,7 @@ sys.path.insert(0, os.path.join(ROOT, "oracle"))  # the oracle is test infrastru
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "perf: timing assertions, apart from the parity tests (THETA_RUN_PERF=1)")
 
 
 def unfl(x):

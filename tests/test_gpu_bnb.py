@@ -153,7 +153,7 @@ def test_baseline_configs_3_and_4_are_searched_whole(ctx, name, K, seed, capsys)
     dt = time.time() - t0
     rep = S.last_report
     assert rep.mix is not None and "gave_up" not in rep.mix, rep.mix
-    assert rep.candidates > 1e27 and dt < 20.0
+    assert rep.candidates > 1e27            # (the time is printed below; tests/test_gpu_perf.py asserts on times, behind the `perf` marker)
     fin = [b for b in best if b[2] == b[2]]
     assert fin and abs(min(b[2] for b in fin) - rep.mix["minimum"]) < 1e-6
     with capsys.disabled():
@@ -296,6 +296,6 @@ def test_counting_table_of_a_space_beyond_2_to_the_128_waits_for_the_first_rank(
         res = p.search(b, b + (1 << 22), window=0.5)
         out[lazy] = (res["rank"], res["nll"], p.enumerate(b + 12345, 3))
         p.close()
-    assert times["1"] < 0.5 * times["0"], times
+    print("problem creation, lazy / eager counting table: %.3f / %.3f s" % (times["1"], times["0"]))     # (timing: tests/test_gpu_perf.py)
     assert list(out["1"][0]) == list(out["0"][0]) and np.array_equal(out["1"][1], out["0"][1]) and np.array_equal(out["1"][2], out["0"][2])
     assert len(out["1"][0]) >= 1

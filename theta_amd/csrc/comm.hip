@@ -150,6 +150,7 @@ struct theta_comm {
     ncclComm_t nccl = nullptr;
     DevBuf d_send, d_recv;
     uint64_t collectives = 0;      // collectives issued (diagnostic)
+    bool dead_stream = false;      // a collective was abandoned without ncclCommAbort: never synchronise the device for this communicator again
 };
 
 static void close_star(theta_comm *c) {
@@ -371,6 +372,10 @@ extern "C" void theta_comm_destroy(theta_comm *c) {
         (void)hipGetLastError();
     }
     close_star(c);
+    if (c->dead_stream) {          // (hipFree waits for the device: the staging buffers of an abandoned collective are leaked with it)
+        c->d_send.p = c->d_recv.p = nullptr;
+        c->d_send.bytes = c->d_recv.bytes = 0;
+    }
     delete c;
 }
 
@@ -472,6 +477,12 @@ static int rccl_wait(theta_comm *c, hipStream_t st) {
                 (void)g_rccl.CommAbort(c->nccl);
                 c->nccl = nullptr;
                 (void)hipStreamSynchronize(st);
+            } else if (c->nccl) {
+                // a librccl without ncclCommAbort: the stuck collective cannot be taken off the stream, and ncclCommDestroy on
+                // such a communicator may never return.  The communicator is LEAKED (marked dead: later collectives fail, the
+                // destructor skips it, nothing waits on the stream) -- the process is expected to exit on this error.
+                c->nccl = nullptr;
+                c->dead_stream = true;
             }
             (void)hipGetLastError();
             return THETA_ERR_HIP;

@@ -410,7 +410,8 @@ def in_space_n3_batch(Ms, lb, ub, tau):
     return ok
 
 
-HEURISTIC_BUDGET_S = float(os.environ.get("THETA_HEURISTIC_BUDGET_S", 0.25))    # seconds of local search on top of the grid (the proposal passes of mix_records carry on from there)
+HEURISTIC_BUDGET_S = float(os.environ.get("THETA_HEURISTIC_BUDGET_S", 10.0))    # safety cap (seconds) of the local search on top of the grid; what bounds it is the number of rounds
+HEURISTIC_ROUNDS_LARGE = int(os.environ.get("THETA_HEURISTIC_ROUNDS_LARGE", 1))  # ... of a problem with more than 4096 (interval, row) pairs (the proposal passes of mix_records carry on from there)
 
 
 def heuristic_incumbent(ctx, m, tau, lower_bounds, upper_bounds, r, rN, max_normal, rounds=40, budget_s=None):
@@ -422,8 +423,8 @@ def heuristic_incumbent(ctx, m, tau, lower_bounds, upper_bounds, r, rN, max_norm
     reference's row graph and ratio window ask of consecutive rows -- so the assignment for a mixture usually IS a matrix of the space
     (checked: in_space_n3_batch).  A grid of mixtures (all of it at once, in numpy) gives a few hundred matrices; theta_solve_batch
     values them the way the reference would; the best goes through alternating (re-solve mu, re-assign rows) and a steepest-descent
-    local search over single-row changes, every trial again a matrix of the space valued by theta_solve_batch -- for `budget_s`
-    seconds at most (m = 200: 12 800 trials per round).  Returns (nll, C (m, 2) uint8) or (inf, None).
+    local search over single-row changes, every trial again a matrix of the space valued by theta_solve_batch -- for `rounds`
+    rounds at most (m = 200: 12 800 trials per round, one round; `budget_s` is a safety cap on the clock).  Returns (nll, C (m, 2) uint8) or (inf, None).
     """
     import time
     t0 = time.time()
@@ -510,9 +511,11 @@ def heuristic_incumbent(ctx, m, tau, lower_bounds, upper_bounds, r, rN, max_norm
     ii, jj = np.nonzero(allowed)                                  # every (interval, row within its bounds)
     if len(ii) > 4096:
         # a round of single-row changes this large (m = 200, k = 7: 12 800 trials, 60 ms) buys one row at a time: the proposal
-        # passes of mix_records, which start from whatever this returns, move all rows at once -- a round or two, not a dozen
-        budget_s = min(budget_s, 0.05)
+        # passes of mix_records, which start from whatever this returns, move all rows at once -- ONE round, not a dozen
+        rounds = min(rounds, HEURISTIC_ROUNDS_LARGE)
     for _round in range(rounds):
+        # (the number of ROUNDS bounds the local search: the same input gives the same incumbent, hence the same octree threshold,
+        # whatever the host's load -- round-5 advice; the clock is a safety cap only)
         if time.time() - t0 > budget_s:
             break
         parts = []
@@ -722,8 +725,10 @@ def _search_local(n, m, tau, lower_bounds, upper_bounds, r, rN, max_normal, shar
     g, G = shard
     begin = problem.count * g // G
     end = problem.count * (g + 1) // G
-    # (what decides is the size of THIS rank's share: a shard of a few million ranks of a huge space is walked like any range)
-    big = n == 3 and getattr(problem, "_h", None) is not None and end - begin >= BNB_MIN_CANDIDATES
+    # (what decides is the size of a rank's share: a shard of a few million ranks of a huge space is walked like any range)
+    # (decided from a quantity every rank computes alike -- the shares differ by one across ranks, and a rank on the other side of the
+    # line would pair its collectives with the wrong ones of its peers: round-5 advice)
+    big = n == 3 and getattr(problem, "_h", None) is not None and problem.count // G >= BNB_MIN_CANDIDATES
     use_bnb = big and problem.count < 2 ** 128 - 1 and m >= 8
     my_ranges = None
     if big and USE_MIX:
