@@ -217,6 +217,11 @@ int theta_search_degenerate(theta_problem *p, int cap, uint64_t *rank, uint8_t *
  *   "n2_no_dismiss"  1: the n=2 search solves every candidate; 0 (default): a candidate whose rigorous lower bound -- one evaluation
  *                    at a chain point, self-concordance -- lies beyond the window of the running minimum is done (same finalists)
  *   "n3_per_task"    candidates per wave task (0 = automatic), "n2_per_thread" candidates per thread (0 = automatic)
+ *   "mix_shard_world", "mix_shard_rank"   theta_mix_search on G ranks: rank g keeps the boxes dealt to it a few cuts below the roots
+ *                    (set the world first); default 1 / 0: every box
+ *   "mix_max_steps"  steps the walk over the intervals of one (leaf, corner) may take before theta_mix_search gives up (default 2^22)
+ *   "mix_max_boxes"  theta_mix_search gives up (THETA_ERR_CAPACITY) once this many boxes have been bounded and more are waiting
+ *                    (0, the default: never -- a flat likelihood is walked to the end, however long it takes)
  * The THETA_N3_* environment variables of the same names only set the defaults at theta_problem_create.
  */
 int theta_problem_set_option(theta_problem *p, const char *name, double value);
@@ -313,27 +318,49 @@ int theta_bnb(theta_problem *p, double threshold, uint64_t beam, int follow_coll
 
 /*
  * BRANCH AND BOUND OVER THE MIXTURE SPACE (n = 3): every matrix -- of the rows, bounds and edge rule of Enumerator._generate_next_C_3
- * (Enumerator.py:172-214, 248-298) -- whose NLL can be at most `threshold` for SOME mixture mu >= 0, found without walking the
+ * (Enumerator.py:172-214, 248-298) -- whose NLL can be at most `threshold` for SOME mixture, found without walking the
  * ranks: BASELINE configs 3 and 4 (4e27 / 2.6e38 matrices) in a fraction of a second.  Replaces, for such spaces, the loop of
  * do_optimization_single (RunTHetA.py:173-220).  With v = s mu the reference's objective (Optimizer.py:236-244) is
  * sum_i [rN_i c_i.v - r_i ln(rN_i c_i.v)] + const at its best scale s: separable over the intervals for a fixed v, so a box of
- * mixtures bounds EVERY matrix at once from m x (rows) one-dimensional problems.  An octree over v keeps the boxes within the
- * threshold; the leaves (width leaf_rel, relative to the mean read-depth ratio per copy: 2e-4 is a good value) are walked depth
+ * mixtures bounds EVERY matrix at once from m x (rows) one-dimensional problems.  A tree of boxes over v >= 0 keeps those within
+ * the threshold; the leaves (width leaf_rel, relative to the mean read-depth ratio per copy: 2e-4 is a good value) are walked depth
  * first over the intervals with the threshold as budget.  C[cap * m * 2] receives the matrices ({a, b} per interval) in the
  * reference's enumeration order, without duplicates: a SUPERSET of the matrices within the threshold (the symmetry rule and the
  * ratio window are the caller's to check; theta_solve_batch gives each one's value as the reference reports it).  The threshold
- * must be an attainable NLL + the collection window.  THETA_ERR_CAPACITY: too many boxes / matrices within it.
- * What it cannot give: matrices the reference reports below their own optimum or with a NaN likelihood (rank-deficient ones;
- * about one full-rank matrix in a million).
+ * must be an attainable NLL + the collection window.
+ *
+ * mode, a sum of:
+ *   THETA_MIX_PROPOSE     no list -- for the `cap` leaves of smallest bound, the matrix that fits the leaf's centre best (per interval
+ *                         the row minimising its term): candidates for a better attainable NLL, to be valued by the caller before a
+ *                         finer call with a lower threshold.
+ *   THETA_MIX_LINES       also the RANK-DEFICIENT matrices the reference can report within the threshold at a mixture with negative
+ *                         entries (Optimizer.py:148-165: hybrj on a singular Jacobian; 318-330: M3's mu is never range-checked; L3 is
+ *                         finite wherever the products c_i.mu keep one sign).  The rows of such a matrix lie on one line of the
+ *                         alphabet's grid, c.v = alpha + t beta along it, and the value is the same separable objective at some
+ *                         (alpha, beta) of either sign: one more tree per line, over (alpha, beta), rows restricted to the line.
+ *                         stats->min_bound_lines is then a lower bound of everything finite the reference can report for a
+ *                         rank-deficient matrix with two distinct rows or more that the list does not hold (+inf: no box of a line
+ *                         came within the threshold).  NaN outcomes have no bound.
+ *   THETA_MIX_LINES_ONLY  the lines' trees alone.
+ * A sharded search (options "mix_shard_world" / "mix_shard_rank" of theta_problem_set_option): the boxes a few cuts below the roots
+ * are dealt out by their path, each rank lists the matrices of its own; the union over the ranks is the unsharded list.
+ *
+ * THETA_ERR_CAPACITY with *n_out > cap: the list holds *n_out matrices, come again with that capacity.  THETA_ERR_CAPACITY with
+ * *n_out == 0: the threshold leaves more boxes or matrices than the device holds (option "mix_max_boxes" bounds the work before).
+ * What it cannot give: matrices the reference reports with a NaN likelihood (some rank-deficient ones; about one full-rank matrix
+ * in a million).
  */
+#define THETA_MIX_PROPOSE 1
+#define THETA_MIX_LINES 2
+#define THETA_MIX_LINES_ONLY 4
 typedef struct theta_mix_stats {
     uint64_t boxes_tested, levels, max_boxes, leaves, listed, matrices;
+    uint64_t lines, line_leaves, syncs;   /* lines searched, leaves of lines, host synchronisations of the walk                    */
     double kernel_ms, wall_ms;
-    double min_bound;            /* propose = 1: the smallest bound among the leaves (a lower bound of the space's minimum up to the leaf size) */
+    double min_bound;            /* the smallest bound among the leaves of the whole alphabet (a lower bound of the space's minimum up to the leaf size) */
+    double min_bound_lines;      /* ... among the leaves of the lines */
 } theta_mix_stats;
-/* propose = 1: no list -- for the `cap` leaves of smallest bound, the matrix that fits the leaf's centre best (per interval the row
- * minimising its term): candidates for a better attainable NLL, to be valued by the caller before a finer call with a lower threshold. */
-int theta_mix_search(theta_problem *p, double threshold, double leaf_rel, int propose, uint64_t cap, uint8_t *C, uint64_t *n_out,
+int theta_mix_search(theta_problem *p, double threshold, double leaf_rel, int mode, uint64_t cap, uint8_t *C, uint64_t *n_out,
                      theta_mix_stats *stats);
 
 /*

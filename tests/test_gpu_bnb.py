@@ -32,6 +32,19 @@ def _records_exhaustive(S, problem, ctx, r, rN):
     return recs + S.fallback_records(problem, ctx, r, rN, 1.0, recs)
 
 
+def _records_exhaustive_complete(S, problem, ctx, r, rN):
+    """... and the COMPLETE records of the whole space as the driver gathers them (search._search_local: gather): finalists, nu = 1/3
+    fallbacks, and every rank-deficient matrix of the space valued by the reference's own procedure, whatever its value"""
+    recs = _records_exhaustive(S, problem, ctx, r, rN)
+    listed = set(problem.last_degenerate[0])
+    recs = [t for t in recs if t["rank"] not in listed]
+    return recs + S.degenerate_records(problem, ctx, r, rN, 1.0)
+
+
+def _finite(recs):
+    return [t for t in recs if t["nll"] == t["nll"]]
+
+
 def _full_rank(recs):
     if not recs:
         return []
@@ -62,12 +75,25 @@ def test_mixture_space_search_equals_the_exhaustive_search_on_whole_spaces(ctx, 
     assert 1e5 < p.count < 2e10
     rep = S.SearchReport()
     recs_mix, _ = S.mix_records(p, ctx, r, rN, 1.0, (lb, ub), report=rep)
-    want = S.replay_records(_full_rank(_records_exhaustive(S, p, ctx, r, rN)), False)
+    walk = _records_exhaustive_complete(S, p, ctx, r, rN)
+    want = S.replay_records(_full_rank(walk), False)
     got = S.replay_records(_full_rank(recs_mix), False)
+    # round 6: the COMPLETE list -- the rank-deficient matrices too, which the reference reports wherever its hybrj stops on their
+    # singular Jacobian (a finite value BELOW the matrix's minimum over mu >= 0 included): the lines' trees of theta_mix_search
+    # bound them all; only NaN outcomes are beyond any bound
+    want_all = S.replay_records(_finite(walk), False)
+    got_all = S.replay_records(_finite(recs_mix), False)
+    n_def = int(rank_deficient(np.array([t["c"] for t in walk])).sum()) if walk else 0
     p.close()
     assert len(want) >= 1
     assert campaign.compare_best(_plain(got), _plain(want), tol=1e-9) == "", (m, K, seed, len(got), len(want), rep.mix)
+    assert campaign.compare_best(_plain(got_all), _plain(want_all), tol=1e-9) == "", (m, K, seed, len(got_all), len(want_all), rep.mix)
     assert rep.mix["minimum"] <= rep.mix["incumbent"] + 1e-9 and rep.mix["boxes_tested"] > 0
+    assert rep.mix["rank_deficient_complete"] and rep.mix["lines"] > 0 and n_def > 0
+    # nothing finite below the bound the report states for the rank-deficient matrices that are NOT among its records
+    listed = set(np.asarray(t["c"]).tobytes() for t in recs_mix)
+    rest = [t["nll"] for t in _finite(walk) if rank_deficient(np.asarray(t["c"])[None])[0] and np.asarray(t["c"]).tobytes() not in listed]
+    assert not rest or min(rest) >= rep.mix["rank_deficient_bound"] - 1e-6, (min(rest), rep.mix["rank_deficient_bound"])
 
 
 @pytest.mark.parametrize("m,K,seed", [(12, 3, 31), (12, 4, 5), (11, 5, 8), (13, 3, 2)])
@@ -90,8 +116,8 @@ def test_row_tree_walk_returns_the_complete_best_list_of_the_exhaustive_search(c
 
 def test_mixture_space_search_against_lists_written_by_the_reference(ctx, monkeypatch):
     """The n=3 instances of the reference-written campaign fixtures (complete `best` lists of python/RunTHetA.py itself) through the
-    mixture-space search: every full-rank, finite entry of the reference's list, in order, C bit-exact, NLL / mu to 1e-6 -- and
-    nothing else.  (Rank-deficient and NaN entries are the linear walk's: DESIGN.md section 8.)"""
+    mixture-space search: every finite entry of the reference's list -- rank-deficient ones included (round 6) --, in order, C bit-exact,
+    NLL / mu to 1e-6 -- and nothing else.  (NaN entries are the linear walk's: DESIGN.md section 8.)"""
     from theta_amd import search as S
     import theta_amd
     monkeypatch.setattr(S, "BNB_MIN_CANDIDATES", 0)
@@ -111,13 +137,13 @@ def test_mixture_space_search_against_lists_written_by_the_reference(ctx, monkey
                 p.close()
                 continue
             p.close()
-            got = S.replay_records(_full_rank(recs), False)
-            # the reference's entries in SORTED interval order (C_sorted[i] = C_original[order[i]], DataTools.py:132-146), rank-deficient
-            # and NaN ones set aside
+            got = S.replay_records(_finite(recs), False)
+            # the reference's entries in SORTED interval order (C_sorted[i] = C_original[order[i]], DataTools.py:132-146), NaN ones set
+            # aside (round 6: the rank-deficient entries with a finite value are the search's too)
             want = []
             for Cr, mu, nll in ref:
                 Cs = Cr[np.asarray(c["order"])]
-                if nll != nll or rank_deficient(Cs[None])[0]:
+                if nll != nll:
                     continue
                 want.append((Cs.tolist(), mu, nll))
             checked += 1
@@ -130,14 +156,14 @@ def test_mixture_space_search_against_lists_written_by_the_reference(ctx, monkey
     assert not bad, bad[:5]
 
 
-def _config(K, seed):
+def _config(K, seed, m=50):
     import bench
-    r, rN, order = bench.synth(seed=seed, m=50, n=3, k=K)
+    r, rN, order = bench.synth(seed=seed, m=m, n=3, k=K)
     return r, rN, order
 
 
-@pytest.mark.parametrize("name,K,seed", [("config 3", 4, 7), ("config 4", 6, 4242)])
-def test_baseline_configs_3_and_4_are_searched_whole(ctx, name, K, seed, capsys):
+@pytest.mark.parametrize("name,m,K,seed", [("config 3", 50, 4, 7), ("config 4", 50, 6, 4242), ("config 5's shape", 200, 7, 55)])
+def test_baseline_configs_3_and_4_are_searched_whole(ctx, name, m, K, seed, capsys):
     """BASELINE config 3 / 4 (synthetic m = 50 intervals, n = 3, k = 4 / 6, full bounds: 4e27 / 2.6e38 matrices) through
     do_optimization_single: the arg-min of the WHOLE space in about a second.  No exhaustive search can confirm it (the equality
     with the linear walk is the whole-space tests' above); what can be checked here: the winner is a matrix of the reference's
@@ -146,8 +172,7 @@ def test_baseline_configs_3_and_4_are_searched_whole(ctx, name, K, seed, capsys)
     the boxes of the last proposal pass, a lower bound of the minimum over everything the search covers up to the boxes' size,
     lies within the window below the reported minimum."""
     from theta_amd import search as S
-    r, rN, order = _config(K, seed)
-    m = 50
+    r, rN, order = _config(K, seed, m)
     t0 = time.time()
     best = S.do_optimization_single(3, m, K, 2, [0] * m, [K] * m, r, rN, 1.0, order, False, False)
     dt = time.time() - t0
@@ -161,6 +186,13 @@ def test_baseline_configs_3_and_4_are_searched_whole(ctx, name, K, seed, capsys)
               (name, rep.candidates, fin[0][2], len(best), dt, rep.mix["boxes_tested"], rep.mix["leaves"], rep.mix["listed"]))
     low = rep.mix["minimum"]
     assert low - S.COLLECT_WINDOW - 0.5 <= rep.mix["min_bound"] <= low + 1e-6, (rep.mix["min_bound"], low)
+    # round 6: the rank-deficient matrices (1e21 of them in config 4) are bounded too -- nothing finite the reference could report
+    # for one of them lies below the stated bound, which is at least the threshold unless a line's box came within it
+    assert rep.mix["rank_deficient_complete"] and rep.mix["lines"] >= 100
+    assert rep.mix["rank_deficient_bound"] >= low - S.COLLECT_WINDOW - 0.5, rep.mix
+    with capsys.disabled():
+        print("    rank-deficient matrices: %d lines, %d leaves of lines, %d records, nothing finite below %.3f (threshold %.3f)" %
+              (rep.mix["lines"], rep.mix["line_leaves"], rep.mix["rank_deficient_records"], rep.mix["rank_deficient_bound"], rep.mix["threshold"]))
     # the winner in sorted interval order: in the space, valued alike by the reference's procedure, no better neighbour
     Cw = np.asarray(best[0][0])[np.asarray(order)][:, 1:].astype(np.uint8)
     assert S.in_space_n3(Cw, [0] * m, [K] * m, 2)

@@ -13,6 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("THETA_HIP_LIB") or os.path.join(_HERE, "libtheta_hip.so")   # THETA_HIP_LIB: A/B builds
 
 THETA_OK, ERR_ARG, ERR_NO_CANDIDATES, ERR_HIP, ERR_OVERFLOW, ERR_CAPACITY = range(6)
+MIX_PROPOSE, MIX_LINES, MIX_LINES_ONLY = 1, 2, 4          # theta_mix_search's mode bits (include/theta_hip.h)
 
 
 class ThetaError(RuntimeError):
@@ -76,7 +77,8 @@ class BnbStats(C.Structure):
 
 class MixStats(C.Structure):
     _fields_ = [("boxes_tested", C.c_uint64), ("levels", C.c_uint64), ("max_boxes", C.c_uint64), ("leaves", C.c_uint64),
-                ("listed", C.c_uint64), ("matrices", C.c_uint64), ("kernel_ms", C.c_double), ("wall_ms", C.c_double), ("min_bound", C.c_double)]
+                ("listed", C.c_uint64), ("matrices", C.c_uint64), ("lines", C.c_uint64), ("line_leaves", C.c_uint64), ("syncs", C.c_uint64),
+                ("kernel_ms", C.c_double), ("wall_ms", C.c_double), ("min_bound", C.c_double), ("min_bound_lines", C.c_double)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -474,6 +476,7 @@ class Problem:
                                            _p(lb, C.c_int32), _p(ub, C.c_int32), float(max_normal), C.byref(h)))
         self._h = h
         self.r, self.rN, self.max_normal = r, rN, float(max_normal)
+        self._bounds = ([int(v) for v in lb], [int(v) for v in ub])
         cnt = (C.c_uint64 * 2)()
         _check(load().theta_problem_count(h, cnt))
         self.count = int(cnt[0]) | (int(cnt[1]) << 64)
@@ -770,16 +773,35 @@ class Problem:
                                           C.byref(st)))
         return nll, mu, st.as_dict()
 
-    def mix_search(self, threshold, leaf_rel=2e-4, cap=1 << 16, propose=False):
+    def mix_search(self, threshold, leaf_rel=2e-4, cap=1 << 16, propose=False, lines=False, lines_only=False):
         """theta_mix_search: the matrices (k, m, 2) uint8 -- in enumeration order, a superset -- whose NLL can be <= threshold for
-        some mixture, by branch and bound over the mixture space; and the walk's statistics."""
-        st = MixStats()
-        out = np.zeros((max(cap, 1), self.m, 2), np.uint8)
-        n_out = C.c_uint64(0)
-        rc = load().theta_mix_search(self._h, float(threshold), float(leaf_rel), 1 if propose else 0, int(cap), _p(out, C.c_uint8), C.byref(n_out), C.byref(st))
-        self.last_mix = st.as_dict()
+        some mixture, by branch and bound over the mixture space; and the walk's statistics.  lines: also the rank-deficient
+        matrices the reference can report within the threshold at a mixture with negative entries (one more tree per line of the
+        alphabet's grid); lines_only: those trees alone."""
+        mode = (MIX_PROPOSE if propose else 0) | (MIX_LINES if lines else 0) | (MIX_LINES_ONLY if lines_only else 0)
+        for _attempt in range(2):
+            st = MixStats()
+            out = np.zeros((max(cap, 1), self.m, 2), np.uint8)
+            n_out = C.c_uint64(0)
+            rc = load().theta_mix_search(self._h, float(threshold), float(leaf_rel), mode, int(cap), _p(out, C.c_uint8), C.byref(n_out), C.byref(st))
+            self.last_mix = st.as_dict()
+            if rc == ERR_CAPACITY and n_out.value > cap:           # (the list is longer than the buffer: once more, with room)
+                cap = int(n_out.value)
+                continue
+            break
         _check(rc)
         return out[:n_out.value].copy(), self.last_mix
+
+    def constant_matrices(self):
+        """The matrices of ONE repeated row (a, b) within every interval's bounds, (k, m, 2) uint8: rank 1 -- whatever the mixture,
+        the model is p_i = rN_i / N --; the lines' trees of theta_mix_search leave them to the caller."""
+        lb, ub = max(self._bounds[0]), min(self._bounds[1])
+        rows = [(a, b) for b in range(lb, ub + 1) for a in range(lb, ub + 1) if (self.tau - a) * (self.tau - b) >= 0]
+        out = np.zeros((len(rows), self.m, 2), np.uint8)
+        for k, (a, b) in enumerate(rows):
+            out[k, :, 0] = a
+            out[k, :, 1] = b
+        return out
 
     def bnb(self, threshold, beam=0, follow_collinear=False, max_nodes=0, cap=1 << 16):
         """theta_bnb: the rank ranges [(begin, end), ...] of the whole space that can hold a matrix whose optimum is <= threshold

@@ -187,6 +187,15 @@ struct theta_problem {
     uint64_t last_launches = 0;                        // launches of the search kernel behind kernel_ms (sieve: one per slice)
     std::vector<double> h_r, h_rN;                     // the counts as given (sorted order): the per-depth constants of theta_bnb
     DevBuf d_misc2;                                    // task specifications of a search over several ranges
+    // the mixture-space search (theta_mix_search): its buffers, allocated at the first call and kept; the lines of the alphabet's grid
+    DevBuf d_mix_stack, d_mix_work, d_mix_leaves, d_mix_ctr, d_mix_mat, d_mix_lines, d_mix_slot;
+    std::vector<MixLine> mix_lines;
+    unsigned mix_chunk = 0;
+    unsigned long long mix_stack_cap = 0, mix_leaf_cap = 0;
+    uint64_t mix_mat_cap = 0;
+    int opt_mix_g = 0, opt_mix_G = 1;                  // options mix_shard_rank / mix_shard_world: this rank's share of the boxes
+    uint64_t opt_mix_max_steps = 1ull << 22;           // option mix_max_steps: steps one (leaf, corner) walk over the intervals may take
+    uint64_t opt_mix_max_boxes = 0;                    // option mix_max_boxes: give up (THETA_ERR_CAPACITY) beyond this many boxes tested (0: never)
     DevBuf d_r, d_rN, d_small, d_P, d_PR, d_PN, d_cnt, d_ctr, d_stat, d_list, d_tasks, d_stbuf, d_misc, d_smask, d_dynmask, d_sus, d_deg, d_surv, d_survcnt, d_survacc, d_line, d_scan, d_sweep;
 };
 
@@ -607,6 +616,13 @@ extern "C" int theta_problem_set_option(theta_problem *p, const char *name, doub
     else if (k == "n3_nan_sweep") p->opt_nan_sweep = value != 0.0;
     else if (k == "n3_contender_cap" && value >= 0.0 && value <= (double)SURV_CAP) p->opt_surv_cap = (unsigned)value;
     else if (k == "n3_per_task" && (value == 0.0 || (value >= 64 && value <= 65535))) p->opt_per_task = (uint64_t)value;
+    else if (k == "mix_shard_world" && value >= 1.0 && value <= 4096.0) {
+        p->opt_mix_G = (int)value;
+        if (p->opt_mix_g >= p->opt_mix_G) p->opt_mix_g = 0;
+    }
+    else if (k == "mix_shard_rank" && value >= 0.0 && value < (double)p->opt_mix_G) p->opt_mix_g = (int)value;
+    else if (k == "mix_max_boxes" && value >= 0.0) p->opt_mix_max_boxes = (uint64_t)value;
+    else if (k == "mix_max_steps" && value >= 1.0) p->opt_mix_max_steps = (uint64_t)value;
     else if (k == "n2_no_dismiss") p->n2.quick = value == 0.0;
     else if (k == "n2_per_thread" && (value == 0.0 || (value >= 1 && value <= 512))) p->opt_per_thread = (int)value;
     else {
@@ -1802,11 +1818,64 @@ extern "C" int theta_bnb(theta_problem *p, double threshold, uint64_t beam, int 
 }
 
 // ---- branch and bound over the mixture space (bnb.hip, second half) ------------------------------------------------------------------
-// An octree over v = s (mu0, mu1, mu2) >= 0: level by level every surviving box is cut in two and the halves whose bound is within the
-// threshold go on; boxes narrower than `leaf_rel` (relative to the mean read-depth ratio, per unit of copy number) are leaves, whose
-// matrices are listed by a budgeted depth-first walk.  Returns the matrices as m slot bytes each (grid order: slot = a + (K + 1) b up to
-// K = 7, the compact alphabet beyond), without duplicates, in the reference's enumeration order (lexicographic in the slots).
-extern "C" int theta_mix_search(theta_problem *p, double threshold, double leaf_rel, int propose, uint64_t cap, uint8_t *C, uint64_t *n_out,
+// The lines of the alphabet's grid [0, K]^2 that hold at least two rows of the alphabet: the rank-deficient matrices are those whose
+// rows all lie on one of them (a matrix of ONE repeated row lies on several).  Canonical direction: dx > 0, or dx = 0 and dy = 1.
+static void mix_build_lines(const theta_problem *p, std::vector<MixLine> &lines, unsigned char (&slot_of)[256]) {
+    memset(slot_of, 0xff, sizeof(slot_of));
+    const N3Host &H = p->n3h;
+    int K = 0;
+    for (int s = 0; s < p->n3.Q; s++) {
+        slot_of[H.rowtab[s]] = (unsigned char)s;
+        K = std::max(K, std::max<int>(H.rowtab[s] & 15, H.rowtab[s] >> 4));
+    }
+    auto gcd = [](int a, int b) { a = abs(a); b = abs(b); while (b) { int t = a % b; a = b; b = t; } return a; };
+    lines.clear();
+    for (int dx = 0; dx <= K; dx++)
+        for (int dy = (dx == 0 ? 1 : -K); dy <= (dx == 0 ? 1 : K); dy++) {
+            if (gcd(dx, dy) != 1) continue;
+            for (int x0 = 0; x0 <= K; x0++)
+                for (int y0 = 0; y0 <= K; y0++) {
+                    const int px = x0 - dx, py = y0 - dy;
+                    if (px >= 0 && px <= K && py >= 0 && py <= K) continue;           // not the line's first point
+                    int T = 0, rows = 0;
+                    for (int x = x0, y = y0; x >= 0 && x <= K && y >= 0 && y <= K; x += dx, y += dy) {
+                        T++;
+                        if (slot_of[x | (y << 4)] != 0xff) rows++;
+                    }
+                    if (rows < 2) continue;
+                    MixLine L;
+                    L.x0 = (signed char)x0; L.y0 = (signed char)y0; L.dx = (signed char)dx; L.dy = (signed char)dy; L.T = T;
+                    lines.push_back(L);
+                }
+        }
+}
+
+// The buffers of the search live with the problem (round 5 allocated and freed 3.4 GB per call, five or six calls per search).
+static int mix_buffers(theta_problem *p, hipStream_t st) {
+    if (p->d_mix_ctr.p) return THETA_OK;
+    int rc;
+    p->mix_chunk = 1u << 15;
+    if (const char *e = getenv("THETA_MIX_CHUNK")) p->mix_chunk = (unsigned)std::max(64, atoi(e));
+    p->mix_stack_cap = 1ull << 22;        // 256 MB: depth first, a few chunks per level of the tree
+    p->mix_leaf_cap = 1ull << 21;         // 128 MB; walked and emptied whenever a batch could fill it
+    if (const char *e = getenv("THETA_MIX_STACK")) p->mix_stack_cap = std::max<unsigned long long>(4ull * p->mix_chunk, strtoull(e, nullptr, 10));
+    if (const char *e = getenv("THETA_MIX_LEAVES")) p->mix_leaf_cap = std::max<unsigned long long>(4ull * p->mix_chunk, strtoull(e, nullptr, 10));
+    unsigned char slot_of[256];
+    mix_build_lines(p, p->mix_lines, slot_of);
+    if ((rc = p->d_mix_stack.alloc(p->mix_stack_cap * sizeof(MixCell))) || (rc = p->d_mix_work.alloc(2ull * p->mix_chunk * sizeof(MixCell))) ||
+        (rc = p->d_mix_leaves.alloc(p->mix_leaf_cap * sizeof(MixCell))) || (rc = p->d_mix_ctr.alloc(MIX_NCTR * sizeof(unsigned long long))) ||
+        (rc = upload(p->d_mix_slot, slot_of, sizeof(slot_of), st)) ||
+        (rc = upload(p->d_mix_lines, p->mix_lines.data(), std::max<size_t>(1, p->mix_lines.size()) * sizeof(MixLine), st)))
+        return rc;
+    HIP_TRY(hipStreamSynchronize(st));
+    return THETA_OK;
+}
+
+// A stack of boxes, walked depth first in chunks; boxes narrower than `leaf_rel` (relative to the mean read-depth ratio, per unit of
+// copy number) are leaves, whose matrices are listed by a budgeted depth-first walk.  Returns the matrices as {a, b} per interval,
+// without duplicates, in the reference's enumeration order (lexicographic in the slots).  mode: THETA_MIX_PROPOSE |
+// THETA_MIX_LINES | THETA_MIX_LINES_ONLY (include/theta_hip.h).
+extern "C" int theta_mix_search(theta_problem *p, double threshold, double leaf_rel, int mode, uint64_t cap, uint8_t *C, uint64_t *n_out,
                                 theta_mix_stats *stats) {
     if (!p || !n_out || (cap > 0 && !C)) {
         theta_set_error("theta_mix_search: null argument");
@@ -1818,14 +1887,21 @@ extern "C" int theta_mix_search(theta_problem *p, double threshold, double leaf_
         theta_set_error("theta_mix_search: n = 3 only");
         return THETA_ERR_ARG;
     }
-    if (!(threshold == threshold) || !(leaf_rel > 0.0 && leaf_rel < 1.0)) {
-        theta_set_error("theta_mix_search: bad threshold or leaf size");
+    if (!(threshold == threshold) || !(leaf_rel > 0.0 && leaf_rel < 1.0) || (mode & ~7)) {
+        theta_set_error("theta_mix_search: bad threshold, leaf size or mode");
+        return THETA_ERR_ARG;
+    }
+    const bool propose = mode & THETA_MIX_PROPOSE, lines_only = mode & THETA_MIX_LINES_ONLY, with_lines = (mode & THETA_MIX_LINES) || lines_only;
+    if (propose && with_lines) {
+        theta_set_error("theta_mix_search: proposals come from the whole alphabet's boxes (no THETA_MIX_LINES with THETA_MIX_PROPOSE)");
         return THETA_ERR_ARG;
     }
     HIP_ENTER(p->ctx->device);
     hipStream_t st = p->ctx->stream;
     const int m = p->m;
     const auto t_start = std::chrono::steady_clock::now();
+    int rc;
+    if ((rc = mix_buffers(p, st))) return rc;
     long double N = 0, Rt = 0;
     double rNmin = INFINITY;
     for (int i = 0; i < m; i++) {
@@ -1841,79 +1917,233 @@ extern "C" int theta_mix_search(theta_problem *p, double threshold, double leaf_
     A.r = p->n3.r;
     A.rN = p->n3.rN;
     A.rowtab = p->n3.rowtab;
+    A.slot_of = (const unsigned char *)p->d_mix_slot.p;
     A.lb = p->n3.lb;
     A.ub = p->n3.ub;
     A.cst = (double)(-Rt + (Rt > 0 ? Rt * logl(Rt) : 0.0L));
     A.thr = threshold;
+    A.lines = (const MixLine *)p->d_mix_lines.p;
+    A.n_lines = (int)p->mix_lines.size();
+    A.shard_g = p->opt_mix_g;
+    A.shard_G = p->opt_mix_G;
+    A.chunk = p->mix_chunk;
     const double tref = (double)(Rt / N);            // the mean read-depth ratio: c.v of a typical interval
     const int Kmax = std::max(1, p->n3.K);
     A.leaf[0] = leaf_rel * tref / std::max(1, p->tau);
     A.leaf[1] = A.leaf[2] = leaf_rel * tref / Kmax;
-    // the root box: at the best scale sum_i rN_i c_i.v = Rtot, so tau v0 N <= Rtot and -- a tumour column with an entry >= 1 -- v_j rN_min <= Rtot
-    MixCell root;
-    root.lo[0] = root.lo[1] = root.lo[2] = 0.0;
-    root.hi[0] = (double)(Rt / (std::max(1, p->tau) * N));
-    root.hi[1] = root.hi[2] = (double)(Rt / rNmin);
-    // (raw listings: every matrix is listed by each leaf and corner whose budget it meets -- hundreds of times in a wide region)
-    const uint64_t cell_cap = 1ull << 23, leaf_cap = 1ull << 22, mat_cap = std::min<uint64_t>(1ull << 24, ((size_t)2 << 30) / (size_t)m);
-    DevBuf d_a, d_b, d_leaves, d_ctr, d_mat;
-    int rc;
-    if ((rc = d_a.alloc(cell_cap * sizeof(MixCell))) || (rc = d_b.alloc(cell_cap * sizeof(MixCell))) || (rc = d_leaves.alloc(leaf_cap * sizeof(MixCell))) ||
-        (rc = d_ctr.alloc(4 * sizeof(unsigned long long))) || (rc = d_mat.alloc(mat_cap * (size_t)m)))
-        return rc;
-    HIP_TRY(hipMemsetAsync(d_ctr.p, 0, 4 * sizeof(unsigned long long), st));
-    HIP_TRY(hipMemcpyAsync(d_a.p, &root, sizeof(root), hipMemcpyHostToDevice, st));
-    uint64_t n_cells = 1, n_leaves = 0, tested = 0, levels = 0, max_cells = 1;
-    MixCell *cur = (MixCell *)d_a.p, *nxt = (MixCell *)d_b.p;
-    HIP_TRY(hipEventRecord(p->ctx->ev0, st));
-    while (n_cells > 0) {
-        HIP_TRY(hipMemsetAsync(d_ctr.p, 0, sizeof(unsigned long long), st));
-        mix_launch_split(A, cur, n_cells, nxt, cell_cap, (MixCell *)d_leaves.p, leaf_cap, (unsigned long long *)d_ctr.p, st);
-        unsigned long long got[2];
-        HIP_TRY(hipMemcpyAsync(got, d_ctr.p, sizeof(got), hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
-        HIP_TRY(hipGetLastError());
-        tested += 2 * n_cells;
-        levels++;
-        if (got[0] > cell_cap || got[1] > leaf_cap) {
-            theta_set_error("theta_mix_search: more than %llu boxes (%llu leaves) within the threshold: it is too far above the minimum", (unsigned long long)cell_cap,
-                            (unsigned long long)leaf_cap);
-            if (stats) {
-                stats->boxes_tested = tested;
-                stats->levels = levels;
-                stats->max_boxes = std::max<uint64_t>(max_cells, got[0]);
-                stats->leaves = got[1];
-            }
-            return THETA_ERR_CAPACITY;
+    A.leaf_line[0] = leaf_rel * tref;
+    A.leaf_line[1] = leaf_rel * tref / Kmax;
+    A.leaf_line[2] = 1.0;
+    // the roots.  Whole alphabet: at the best scale sum_i rN_i c_i.v = Rtot, so tau v0 N <= Rtot and -- a tumour column with an entry
+    // >= 1 -- v_j rN_min <= Rtot.  A line: every row in use has 0 < alpha + t beta <= U = Rtot / rN_min; with two distinct rows in use
+    // |beta| <= U and -(T - 1) U <= alpha <= T U -- tightened below.  (The matrices of ONE repeated row have the same value at every
+    // mixture, the model p_i = rN_i / N: they are listed and valued by the caller apart, Problem.constant_matrices.)
+    std::vector<MixCell> roots;
+    const double U = (double)(Rt / rNmin);
+    // ... and tighter for the lines: the objective is a sum of per-interval terms, each at least its own minimum phi_i(r_i / rN_i), so
+    // within the threshold NO interval's term may exceed its minimum by more than the slack S = thr - cst - sum_j phi_j(r_j / rN_j):
+    // with u = rN_i q / r_i that is r_i (u - 1 - ln u) <= S, an interval [qlo_i, qhi_i] around the interval's ratio.  Every row in
+    // use therefore has qmin <= q <= qmax (the extremes over the intervals), and with two distinct rows in use |beta| <= D = qmax - qmin,
+    // qmin - (T - 1) D <= alpha <= qmax + (T - 1) D.  (Against 0 < q <= U this cuts the valleys along which ONE row of the line meets
+    // the data -- the repeated-row matrices, valued apart -- from ~ N / rN_min boxes per scale to a handful: 14.0e6 of the 14.9e6 boxes
+    // of config 4's final pass were theirs.)
+    double qmin = 0.0, qmax = U;
+    {
+        long double sat = 0;
+        for (int i = 0; i < m; i++) {
+            const double r = p->h_r[i];
+            sat += r > 0 ? (long double)r - (long double)r * logl((long double)r) : 0.0L;       // phi_i at its minimiser: N t = r
         }
-        n_cells = got[0];
-        n_leaves = got[1];
-        max_cells = std::max(max_cells, n_cells);
-        if (getenv("THETA_BNB_DEBUG")) fprintf(stderr, "mix: level %llu: %llu boxes, %llu leaves so far\n", (unsigned long long)levels, (unsigned long long)n_cells, (unsigned long long)n_leaves);
-        if (n_cells > (1ull << 21)) {      // (every level costs boxes x m x rows logarithms: a threshold this loose is not worth walking)
-            theta_set_error("theta_mix_search: %llu boxes within the threshold at level %llu: it is too far above the minimum", (unsigned long long)n_cells,
-                            (unsigned long long)levels);
-            if (stats) {
-                stats->boxes_tested = tested;
-                stats->levels = levels;
-                stats->max_boxes = max_cells;
-                stats->leaves = n_leaves;
+        const double S = (double)((long double)threshold - (long double)A.cst - sat);
+        if (S >= 0.0) {
+            double lo_all = INFINITY, hi_all = 0.0;
+            for (int i = 0; i < m; i++) {
+                const double r = p->h_r[i], Nn = p->h_rN[i];
+                double qlo = 0.0, qhi = U;
+                if (r > 0.0) {
+                    const double sr = S / r;           // u - 1 - ln u <= sr
+                    double a = 0.0, b = 1.0;           // the root below 1
+                    for (int it = 0; it < 200; it++) {
+                        const double u = 0.5 * (a + b);
+                        if (u - 1.0 - log(u) > sr) a = u; else b = u;
+                    }
+                    qlo = a * (r / Nn);
+                    a = 1.0;
+                    b = 2.0 * sr + 12.0;               // ... and the one above
+                    for (int it = 0; it < 200; it++) {
+                        const double u = 0.5 * (a + b);
+                        if (u - 1.0 - log(u) > sr) b = u; else a = u;
+                    }
+                    qhi = b * (r / Nn);
+                } else {
+                    qhi = S / Nn;                      // phi = N q <= S
+                }
+                lo_all = std::min(lo_all, qlo);
+                hi_all = std::max(hi_all, qhi);
             }
-            return THETA_ERR_CAPACITY;
-        }
-        std::swap(cur, nxt);
-        if (levels > 400) {
-            theta_set_error("theta_mix_search: the octree did not terminate");
-            return THETA_ERR_HIP;
+            qmin = std::max(0.0, lo_all * (1.0 - 1e-9));
+            qmax = std::min(U, hi_all * (1.0 + 1e-9));
         }
     }
+    const double Dq = std::max(qmax - qmin, 0.0);
+    if (!lines_only) {
+        MixCell root;
+        memset(&root, 0, sizeof(root));
+        root.hi[0] = (double)(Rt / (std::max(1, p->tau) * N));
+        root.hi[1] = root.hi[2] = U;
+        roots.push_back(root);
+    }
+    if (with_lines)
+        for (size_t l = 0; l < p->mix_lines.size(); l++) {
+            MixCell root;
+            memset(&root, 0, sizeof(root));
+            const int T = p->mix_lines[l].T;
+            root.lo[0] = qmin - (double)(T - 1) * Dq;
+            root.hi[0] = qmax + (double)(T - 1) * Dq;
+            root.lo[1] = -Dq;
+            root.hi[1] = Dq;
+            root.line = (unsigned short)(l + 1);
+            roots.push_back(root);
+        }
+    // a sharded search (options mix_shard_rank / mix_shard_world): every rank walks the first cuts alike, then keeps its boxes
+    A.shard_depth = 0;
+    if (A.shard_G > 1) {
+        int d = 4;
+        while ((1 << d) < 16 * A.shard_G) d++;
+        A.shard_depth = d;
+    }
+    if (roots.size() > p->mix_stack_cap) {
+        theta_set_error("theta_mix_search: %zu roots", roots.size());
+        return THETA_ERR_CAPACITY;
+    }
+    unsigned long long h_ctr[MIX_NCTR];
+    memset(h_ctr, 0, sizeof(h_ctr));
+    h_ctr[MIX_TOP0] = roots.size();
+    h_ctr[MIX_MINB] = h_ctr[MIX_MINB_LINE] = ~0ull;
+    unsigned long long *d_ctr = (unsigned long long *)p->d_mix_ctr.p;
+    MixCell *d_stack = (MixCell *)p->d_mix_stack.p, *d_work = (MixCell *)p->d_mix_work.p, *d_leaves = (MixCell *)p->d_mix_leaves.p;
+    HIP_TRY(hipMemcpyAsync(d_ctr, h_ctr, sizeof(h_ctr), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_stack, roots.data(), roots.size() * sizeof(MixCell), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipEventRecord(p->ctx->ev0, st));
+    // the list of matrices grows with the need (raw listings: every matrix is listed by each leaf and corner whose budget it meets)
+    if (!propose && !p->d_mix_mat.p) {
+        p->mix_mat_cap = std::max<uint64_t>(1ull << 16, (64ull << 20) / (size_t)m);
+        if ((rc = p->d_mix_mat.alloc(p->mix_mat_cap * (size_t)m))) return rc;
+    }
+    const bool debug = getenv("THETA_BNB_DEBUG") != nullptr;
+    const uint64_t max_tested = p->opt_mix_max_boxes;
+    int parity = 0;
+    uint64_t syncs = 0, walked_leaves = 0, list_launches = 0;
+    // Walk the leaves collected so far (and empty the list).  The list of matrices is redone with a larger buffer when it overflows
+    // (the walk is deterministic; the counter is put back first).
+    auto walk_leaves = [&](unsigned long long n_leaves) -> int {
+        if (!n_leaves) return THETA_OK;
+        const unsigned long long before = h_ctr[MIX_LISTED];
+        for (;;) {
+            mix_launch_list(A, d_leaves, n_leaves, (unsigned char *)p->d_mix_mat.p, p->mix_mat_cap, ~0ull, p->opt_mix_max_steps, d_ctr, st);
+            list_launches++;
+            unsigned long long got[2];
+            HIP_TRY(hipMemcpyAsync(got, d_ctr + MIX_LISTED, sizeof(got), hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            HIP_TRY(hipGetLastError());
+            syncs++;
+            if (got[1] > 0) {
+                theta_set_error("theta_mix_search: %llu walks over the intervals of a leaf did not finish within their %llu steps (%llu matrices listed so "
+                                "far): the likelihood is too flat there (option mix_max_steps)", got[1], (unsigned long long)p->opt_mix_max_steps, got[0]);
+                return THETA_ERR_CAPACITY;
+            }
+            if (got[0] <= p->mix_mat_cap) {
+                h_ctr[MIX_LISTED] = got[0];
+                break;
+            }
+            // grow: what was listed before this walk is kept
+            size_t free_b = 0, total_b = 0;
+            (void)hipMemGetInfo(&free_b, &total_b);
+            const uint64_t want = std::max<uint64_t>(got[0] + got[0] / 4, 2 * p->mix_mat_cap);
+            if ((size_t)want * m > free_b / 2 + p->mix_mat_cap * (size_t)m) {
+                theta_set_error("theta_mix_search: %llu matrices listed within the threshold (%.1f GB of records): it is too far above the minimum",
+                                (unsigned long long)got[0], (double)got[0] * m / 1e9);
+                return THETA_ERR_CAPACITY;
+            }
+            DevBuf bigger;
+            if ((rc = bigger.alloc((size_t)want * m))) return rc;
+            if (before) HIP_TRY(hipMemcpyAsync(bigger.p, p->d_mix_mat.p, (size_t)before * m, hipMemcpyDeviceToDevice, st));
+            HIP_TRY(hipMemcpyAsync(d_ctr + MIX_LISTED, &before, sizeof(before), hipMemcpyHostToDevice, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            std::swap(p->d_mix_mat.p, bigger.p);
+            std::swap(p->d_mix_mat.bytes, bigger.bytes);
+            p->mix_mat_cap = want;
+            if (debug) fprintf(stderr, "mix: list buffer grown to %llu matrices\n", (unsigned long long)want);
+        }
+        walked_leaves += n_leaves;
+        const unsigned long long zero = 0;
+        HIP_TRY(hipMemcpyAsync(d_ctr + MIX_LEAVES, &zero, sizeof(zero), hipMemcpyHostToDevice, st));
+        h_ctr[MIX_LEAVES] = 0;
+        return THETA_OK;
+    };
+    // batches of iterations: as many as the leaf list has room for (an iteration adds at most 2 x chunk leaves)
+    for (;;) {
+        const unsigned long long room = p->mix_leaf_cap - h_ctr[MIX_LEAVES];
+        int batch = (int)std::min<unsigned long long>(propose ? 24 : room / (2ull * A.chunk), 24);
+        if (batch < 1) {
+            if ((rc = walk_leaves(h_ctr[MIX_LEAVES]))) return rc;
+            continue;
+        }
+        if (syncs == 0) batch = std::min(batch, 12);         // (the first cuts: a handful of boxes each)
+        for (int it = 0; it < batch; it++) {
+            mix_launch_iteration(A, d_stack, p->mix_stack_cap, d_work, d_leaves, p->mix_leaf_cap, d_ctr, parity, propose ? 1 : 0, st);
+            parity ^= 1;
+        }
+        HIP_TRY(hipMemcpyAsync(h_ctr, d_ctr, sizeof(h_ctr), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        HIP_TRY(hipGetLastError());
+        syncs++;
+        const unsigned long long top = h_ctr[MIX_TOP0 + parity];
+        if (debug)
+            fprintf(stderr, "mix: %llu iterations, %llu boxes tested, %llu on the stack (deepest %llu), %llu leaves (%llu of lines)\n", h_ctr[MIX_ITERS], h_ctr[MIX_TESTED],
+                    top, h_ctr[MIX_MAXTOP], h_ctr[MIX_LEAVES_ALL], h_ctr[MIX_LEAVES_LINE]);
+        auto fill = [&]() {
+            if (!stats) return;
+            stats->boxes_tested = h_ctr[MIX_TESTED];
+            stats->levels = h_ctr[MIX_ITERS];
+            stats->max_boxes = h_ctr[MIX_MAXTOP];
+            stats->leaves = h_ctr[MIX_LEAVES_ALL];
+            stats->line_leaves = h_ctr[MIX_LEAVES_LINE];
+            stats->lines = with_lines ? p->mix_lines.size() : 0;
+            stats->syncs = syncs;
+            stats->min_bound = h_ctr[MIX_MINB] == ~0ull ? INFINITY : mix_unord(h_ctr[MIX_MINB]);
+            stats->min_bound_lines = h_ctr[MIX_MINB_LINE] == ~0ull ? INFINITY : mix_unord(h_ctr[MIX_MINB_LINE]);
+        };
+        if ((h_ctr[MIX_OVERFLOW] & 2ull) && !propose) {       // (cannot happen: a batch is sized for the room the list has)
+            fill();
+            theta_set_error("theta_mix_search: leaves were dropped");
+            return THETA_ERR_HIP;
+        }
+        if (h_ctr[MIX_OVERFLOW] & 1ull) {
+            fill();
+            theta_set_error("theta_mix_search: more than %llu boxes on the stack (%llu tested): the threshold is too far above the minimum",
+                            (unsigned long long)p->mix_stack_cap, (unsigned long long)h_ctr[MIX_TESTED]);
+            return THETA_ERR_CAPACITY;
+        }
+        if (max_tested && h_ctr[MIX_TESTED] > max_tested && top > 0) {
+            fill();
+            theta_set_error("theta_mix_search: %llu boxes tested and %llu still on the stack (option mix_max_boxes): the threshold is too far above the minimum",
+                            (unsigned long long)h_ctr[MIX_TESTED], top);
+            return THETA_ERR_CAPACITY;
+        }
+        if (top == 0) {
+            fill();
+            break;
+        }
+    }
+    const uint64_t n_leaves_all = h_ctr[MIX_LEAVES_ALL];
     if (propose) {
         // PROPOSALS instead of the exhaustive list: for the `cap` leaves of smallest bound, the matrix that fits the leaf's centre
         // best -- per interval the row that minimises phi_i(c.v) --; valued by the caller, the best of them lowers the threshold
         // of the next, finer, call
-        const uint64_t take_max = std::min<uint64_t>(n_leaves, 1ull << 20);
+        const uint64_t take_max = std::min<uint64_t>(std::min<uint64_t>(h_ctr[MIX_LEAVES], p->mix_leaf_cap), 1ull << 20);
         std::vector<MixCell> hl(take_max);
-        if (take_max) HIP_TRY(hipMemcpy(hl.data(), d_leaves.p, take_max * sizeof(MixCell), hipMemcpyDeviceToHost));
+        if (take_max) HIP_TRY(hipMemcpy(hl.data(), d_leaves, take_max * sizeof(MixCell), hipMemcpyDeviceToHost));
         const uint64_t want = std::min<uint64_t>(cap, take_max);
         std::partial_sort(hl.begin(), hl.begin() + want, hl.end(), [](const MixCell &a, const MixCell &b) { return a.lb < b.lb; });
         std::vector<std::vector<unsigned char>> seen;
@@ -1959,49 +2189,27 @@ extern "C" int theta_mix_search(theta_problem *p, double threshold, double leaf_
         }
         *n_out = nw;
         if (stats) {
-            stats->boxes_tested = tested;
-            stats->levels = levels;
-            stats->max_boxes = max_cells;
-            stats->leaves = n_leaves;
             stats->matrices = nw;
-            stats->min_bound = want ? hl[0].lb : INFINITY;
             stats->wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count();
         }
         return THETA_OK;
     }
-    // the smallest bound among the leaves: a lower bound of the objective over everything the walk covers, up to the leaves' size
-    double min_leaf_bound = INFINITY;
-    if (n_leaves && n_leaves <= (1ull << 20)) {
-        std::vector<MixCell> hl(n_leaves);
-        HIP_TRY(hipMemcpy(hl.data(), d_leaves.p, n_leaves * sizeof(MixCell), hipMemcpyDeviceToHost));
-        for (const MixCell &c : hl) min_leaf_bound = std::min(min_leaf_bound, c.lb);
-    }
-    // the matrices of the leaves
-    mix_launch_list(A, (const MixCell *)d_leaves.p, n_leaves, (unsigned char *)d_mat.p, mat_cap, 2048, (unsigned long long *)d_ctr.p, st);
-    unsigned long long fin[4];
-    HIP_TRY(hipMemcpyAsync(fin, d_ctr.p, sizeof(fin), hipMemcpyDeviceToHost, st));
+    // the matrices of the leaves not walked yet
+    if ((rc = walk_leaves(h_ctr[MIX_LEAVES]))) return rc;
     HIP_TRY(hipEventRecord(p->ctx->ev1, st));
     HIP_TRY(hipStreamSynchronize(st));
     HIP_TRY(hipGetLastError());
     float ms = 0;
     HIP_TRY(hipEventElapsedTime(&ms, p->ctx->ev0, p->ctx->ev1));
-    const uint64_t listed = fin[2];
+    const uint64_t listed = h_ctr[MIX_LISTED];
     if (stats) {
-        stats->boxes_tested = tested;
-        stats->levels = levels;
-        stats->max_boxes = max_cells;
-        stats->leaves = n_leaves;
+        stats->leaves = n_leaves_all;
         stats->listed = listed;
         stats->kernel_ms = ms;
-        stats->min_bound = min_leaf_bound;
-    }
-    if (fin[3] > 0 || listed > mat_cap) {
-        theta_set_error("theta_mix_search: a leaf holds more matrices within the threshold than its walk may list (%llu listed, %llu cut off): "
-                        "lower the threshold or the leaf size", (unsigned long long)listed, (unsigned long long)fin[3]);
-        return THETA_ERR_CAPACITY;
+        stats->syncs = syncs;
     }
     std::vector<unsigned char> hm((size_t)listed * m);
-    if (listed) HIP_TRY(hipMemcpy(hm.data(), d_mat.p, hm.size(), hipMemcpyDeviceToHost));
+    if (listed) HIP_TRY(hipMemcpy(hm.data(), p->d_mix_mat.p, hm.size(), hipMemcpyDeviceToHost));
     // without duplicates (neighbouring leaves and corners list the same matrix), in the reference's order: lexicographic in the slots
     std::vector<size_t> ix(listed);
     for (size_t i = 0; i < listed; i++) ix[i] = i;
@@ -2014,7 +2222,7 @@ extern "C" int theta_mix_search(theta_problem *p, double threshold, double leaf_
     }
     if (ix.size() > cap) {
         theta_set_error("theta_mix_search: %zu matrices but capacity is %llu", ix.size(), (unsigned long long)cap);
-        return THETA_ERR_CAPACITY;
+        return THETA_ERR_CAPACITY;        // (*n_out holds the size needed: the caller may come again)
     }
     // slots -> rows (a, b)
     for (size_t k = 0; k < ix.size(); k++)

@@ -412,16 +412,76 @@ void bnb_launch_compact(const BnbNode *nodes, const unsigned char *paths, unsign
 // The host values those with the reference's own procedure (theta_solve_batch) and replays them in enumeration order.
 // ====================================================================================================================================
 #define MIX_MAX_Q 256      // rows of the alphabet here (a search over mixtures needs no 64-bit child masks)
+//
+// RANK-DEFICIENT MATRICES (round 6).  What the reference reports for a matrix is the objective at the mixture its solver stops at.
+// For a matrix of full rank that mixture is >= 0 (its own optimum, the nu = 1/3 fallback) or the value is NaN.  For a matrix whose
+// rows (x_i, y_i) lie on ONE LINE of the alphabet's grid hybrj runs on a singular Jacobian and may stop at a nu in [0,1]^3 that does
+// not sum to one; M3 (Optimizer.py:318-330) turns it into a mu with a negative entry, never range-checked, and L3 reports a FINITE
+// value wherever all products c_i.mu keep one sign -- a value BELOW the matrix's minimum over mu >= 0.  But for rows on the line
+// (x0, y0) + t (dx, dy) the product is c.v = alpha + t beta, alpha = tau v0 + x0 v1 + y0 v2, beta = dx v1 + dy v2: whatever the signs
+// of v, the value is the same separable objective at SOME (alpha, beta) in R^2 with alpha + t_i beta > 0.  So a quadtree over (alpha, beta)
+// per line of the grid, rows restricted to the line, bounds every such outcome: the same kernels, boxes with line != 0, coefficients
+// (1, t, 0) in place of (tau, a, b) -- non-negative, so [c.lo, c.hi] still brackets c.v on a box of either sign.
+//
+// THE LOOP (round 6).  Round 5 walked the octree level by level: a launch, a read-back and a host decision per level, ~60 levels of
+// ~0.1 ms for a handful of boxes each, two lists of 2^23 boxes allocated per call, and a give-up once a level held 2^21 boxes.
+// Now the boxes live on a STACK in HBM; one iteration = two launches, no host in between: mix_split_kernel takes the top `chunk`
+// boxes (depth first: the stack stays a few chunks deep however many boxes the threshold leaves), bounds both halves of each, and
+// appends the survivors to a work list; mix_push_kernel copies that list over the boxes just taken and publishes the new top.
+// The host enqueues a BATCH of iterations and reads the counters once per batch.
 // the bound of a box: max of the two (see above).  One WAVE per box: lane l takes the intervals l, 64 + l, ... (m x rows x 2 logarithms
-// are half a millisecond of one thread -- a level of the octree holds a handful of boxes as often as a million, and its 60 levels
-// are walked one launch after the other), the nine partial sums meet by shuffles.
+// are half a millisecond of one thread), the nine partial sums meet by shuffles.
 __device__ __forceinline__ double mix_wave_sum(double v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
     return v;
 }
-__device__ double mix_cell_bound(const MixArgs &A, const MixCell &c, const float2 *rows, const double2 *ltab, int lane) {
-    const double tau = (double)A.tau;
+// The rows a box ranges over and what multiplies its coordinates: the whole alphabet with (tau, a, b), or the points of its line
+// with (1, t, 0).  row(s, a, b, x, y): the s-th row's copy numbers and coefficients; false: not a row of the alphabet.
+struct MixRows {
+    int n;                       // rows to try
+    double c0;                   // coefficient of the first coordinate
+    bool ln;
+    int x0, y0, dx, dy;
+    const uchar2 *rows;          // LDS: slot -> (a, b)
+    const unsigned char *slot_of;    // LDS: a | b << 4 -> slot
+    __device__ __forceinline__ MixRows(const MixArgs &A, unsigned line, const uchar2 *rows_, const unsigned char *slot_of_) : rows(rows_), slot_of(slot_of_) {
+        ln = line != 0;
+        if (ln) {
+            const MixLine L = A.lines[line - 1];
+            n = L.T;
+            c0 = 1.0;
+            x0 = L.x0; y0 = L.y0; dx = L.dx; dy = L.dy;
+        } else {
+            n = A.Q;
+            c0 = (double)A.tau;
+            x0 = y0 = dx = dy = 0;
+        }
+    }
+    __device__ __forceinline__ bool row(int s, int &a, int &b, double &x, double &y) const {
+        if (ln) {
+            a = x0 + s * dx;
+            b = y0 + s * dy;
+            x = (double)s;
+            y = 0.0;
+            return slot_of[a | (b << 4)] != 0xffu;
+        }
+        const uchar2 rw = rows[s];
+        a = rw.x;
+        b = rw.y;
+        x = (double)a;
+        y = (double)b;
+        return true;
+    }
+    __device__ __forceinline__ int slot(int s) const { return ln ? (int)slot_of[(x0 + s * dx) | ((y0 + s * dy) << 4)] : s; }
+};
+__device__ __forceinline__ void mix_stage_rows(const MixArgs &A, uchar2 *rows, unsigned char *slot_of) {
+    for (int s = threadIdx.x; s < A.Q; s += blockDim.x) rows[s] = make_uchar2((unsigned char)(A.rowtab[s] & 15u), (unsigned char)(A.rowtab[s] >> 4));
+    for (int s = threadIdx.x; s < 256; s += blockDim.x) slot_of[s] = A.slot_of[s];
+}
+
+__device__ double mix_cell_bound(const MixArgs &A, const MixCell &c, const uchar2 *rows, const unsigned char *slot_of, const double2 *ltab, int lane) {
+    const MixRows R(A, c.line, rows, slot_of);
     double vc[3], h[3];
     for (int j = 0; j < 3; j++) {
         vc[j] = 0.5 * (c.lo[j] + c.hi[j]);
@@ -438,31 +498,36 @@ __device__ double mix_cell_bound(const MixArgs &A, const MixCell &c, const float
         bool any = false, holds = false;
         double tbelow = -__builtin_inf(), tabove = __builtin_inf(), bestv[8];
         for (int k = 0; k < 8; k++) bestv[k] = __builtin_inf();
-        for (int s = 0; s < A.Q; s++) {
-            const float2 rw = rows[s];
-            const int a = (int)rw.x, b = (int)rw.y;
+        auto phi = [&](double t) { return r > 0.0 ? (t > 0.0 ? N * t - r * smx_log(N * t, ltab) : __builtin_inf()) : (t > 0.0 ? N * t : __builtin_inf()); };
+        for (int s = 0; s < R.n; s++) {
+            int a, b;
+            double x, y;
+            if (!R.row(s, a, b, x, y)) continue;
             if (a < l || a > u || b < l || b > u || (A.tau - a) * (A.tau - b) < 0) continue;
             any = true;
-            const double x = (double)a, y = (double)b;
-            const double tlo = tau * c.lo[0] + x * c.lo[1] + y * c.lo[2], thi = tau * c.hi[0] + x * c.hi[1] + y * c.hi[2];
+            // (the coefficients are >= 0: c.lo <= c.v <= c.hi on the box whatever the signs of its corners)
+            const double tlo = R.c0 * c.lo[0] + x * c.lo[1] + y * c.lo[2], thi = R.c0 * c.hi[0] + x * c.hi[1] + y * c.hi[2];
             if (thi < ts) tbelow = fmax(tbelow, thi);
             else if (tlo > ts) tabove = fmin(tabove, tlo);
             else holds = true;
             // (2) tangent at the centre, at the eight corners
-            const double tc = tau * vc[0] + x * vc[1] + y * vc[2];
+            const double tc = R.c0 * vc[0] + x * vc[1] + y * vc[2];
             if (tc > 0.0) {
                 const double f0 = r > 0.0 ? N * tc - r * smx_log(N * tc, ltab) : N * tc, f1 = N - r / tc;
-                const double d0 = f1 * tau * h[0], d1 = f1 * x * h[1], d2 = f1 * y * h[2];
+                const double d0 = f1 * R.c0 * h[0], d1 = f1 * x * h[1], d2 = f1 * y * h[2];
 #pragma unroll
                 for (int k = 0; k < 8; k++) {
                     const double val = f0 + ((k & 1) ? d0 : -d0) + ((k & 2) ? d1 : -d1) + ((k & 4) ? d2 : -d2);
                     bestv[k] = fmin(bestv[k], val);
                 }
             } else {
-                for (int k = 0; k < 8; k++) bestv[k] = -__builtin_inf();
+                // not positive at the centre (a box of either sign astride the row's zero line): the CONSTANT bound phi_i at the point
+                // of (0, thi] nearest its minimiser -- finite, where -inf would let every matrix through -- or, never positive on the
+                // box, no row of a matrix with a value here
+                const double val = thi > 0.0 ? phi(fmin(thi, ts)) : __builtin_inf();
+                for (int k = 0; k < 8; k++) bestv[k] = fmin(bestv[k], val);
             }
         }
-        auto phi = [&](double t) { return r > 0.0 ? (t > 0.0 ? N * t - r * smx_log(N * t, ltab) : __builtin_inf()) : N * t; };
         double best1 = __builtin_inf();
         if (any) {
             if (holds) {
@@ -481,41 +546,85 @@ __device__ double mix_cell_bound(const MixArgs &A, const MixCell &c, const float
     return fmax(lb1, lb2) + A.cst;
 }
 
-// One wave per CHILD of a surviving box: the parent is cut in two along its widest side (widths weighted by the largest copy
-// number they multiply), the child's bound decides whether it goes on -- to the next level's list, or, small enough, to the leaves.
-__global__ __launch_bounds__(256) void mix_split_kernel(MixArgs A, const MixCell *in, unsigned long long n_in, MixCell *out, unsigned long long out_cap,
-                                                        MixCell *leaves, unsigned long long leaf_cap, unsigned long long *counters) {
-    __shared__ float2 rows[MIX_MAX_Q];
+// One wave per CHILD of a box off the stack: the parent is cut in two along its widest side (widths weighted by the leaf size of
+// the side), the child's bound decides whether it goes on -- to the work list, or, small enough, to the leaves.  A persistent
+// grid: the number of boxes is read from the device counters (ctr[MIX_TOP + parity], written by the previous iteration's push).
+#define MIX_WAVES 4
+__global__ __launch_bounds__(64 * MIX_WAVES) void mix_split_kernel(MixArgs A, const MixCell *stack, MixCell *work, MixCell *leaves, unsigned long long leaf_cap,
+                                                                    unsigned long long *ctr, int par, int drop_leaves) {
+    __shared__ uchar2 rows[MIX_MAX_Q];
+    __shared__ unsigned char slot_of[256];
     __shared__ double2 ltab[128];                    // smx_log's table (the scorers' logarithm: 15 vector instructions, within an ulp)
-    for (int s = threadIdx.x; s < A.Q; s += blockDim.x) rows[s] = make_float2((float)(A.rowtab[s] & 15u), (float)(A.rowtab[s] >> 4));
+    const unsigned long long top = ctr[MIX_TOP0 + par];
+    const unsigned long long n = top < (unsigned long long)A.chunk ? top : (unsigned long long)A.chunk;
+    const unsigned long long first = (unsigned long long)blockIdx.x * MIX_WAVES;
+    if (first >= 2 * n) return;                       // (whole blocks leave: the grid is sized for a full chunk)
+    mix_stage_rows(A, rows, slot_of);
     smx_log_stage(ltab);
     __syncthreads();
+    const MixCell *in = stack + (top - n);
     const int lane = threadIdx.x & 63;
-    const unsigned long long k = (unsigned long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (k >= 2 * n_in) return;            // (whole waves leave)
-    MixCell c = in[k >> 1];
-    int ax = 0;
-    double wbest = -1.0;
-    for (int j = 0; j < 3; j++) {
-        const double w = (c.hi[j] - c.lo[j]) / A.leaf[j];
-        if (w > wbest) {
-            wbest = w;
-            ax = j;
+    const unsigned long long stride = (unsigned long long)gridDim.x * MIX_WAVES;
+    for (unsigned long long k = first + (threadIdx.x >> 6); k < 2 * n; k += stride) {
+        MixCell c = in[k >> 1];
+        const double *lf = c.line ? A.leaf_line : A.leaf;
+        int ax = 0;
+        double wbest = -1.0;
+        for (int j = 0; j < 3; j++) {
+            const double w = (c.hi[j] - c.lo[j]) / lf[j];
+            if (w > wbest) {
+                wbest = w;
+                ax = j;
+            }
+        }
+        const double mid = 0.5 * (c.lo[ax] + c.hi[ax]);
+        if (k & 1) c.lo[ax] = mid; else c.hi[ax] = mid;
+        if (c.depth < 32) c.key = (c.key << 1) | (unsigned)(k & 1);
+        c.depth++;
+        // a sharded search: below `shard_depth` cuts every box belongs to ONE rank (by its path), above it all ranks walk alike
+        if (A.shard_G > 1 && (int)c.depth == A.shard_depth && (int)((c.key * 2654435761u + c.line * 40503u) % (unsigned)A.shard_G) != A.shard_g) continue;
+        const double lb = mix_cell_bound(A, c, rows, slot_of, ltab, lane);
+        if (!(lb <= A.thr) || lane != 0) continue;
+        c.lb = lb;
+        bool leaf = true;
+        for (int j = 0; j < 3; j++) leaf = leaf && (c.hi[j] - c.lo[j]) <= lf[j];
+        if (leaf) {
+            atomicAdd(&ctr[MIX_LEAVES_ALL], 1ull);
+            if (c.line) atomicAdd(&ctr[MIX_LEAVES_LINE], 1ull);
+            atomicMin(&ctr[c.line ? MIX_MINB_LINE : MIX_MINB], mix_ord(lb));
+            if (drop_leaves && ctr[MIX_LEAVES] >= leaf_cap) continue;       // (a proposal pass keeps the first leaf_cap leaves)
+            const unsigned long long idx = atomicAdd(&ctr[MIX_LEAVES], 1ull);
+            if (idx < leaf_cap) leaves[idx] = c;
+            else atomicOr(&ctr[MIX_OVERFLOW], 2ull);
+        } else {
+            const unsigned long long idx = atomicAdd(&ctr[MIX_WK0 + par], 1ull);
+            work[idx] = c;                                                     // (2 x chunk entries: cannot overflow)
         }
     }
-    const double mid = 0.5 * (c.lo[ax] + c.hi[ax]);
-    if (k & 1) c.lo[ax] = mid; else c.hi[ax] = mid;
-    const double lb = mix_cell_bound(A, c, rows, ltab, lane);
-    if (!(lb <= A.thr) || lane != 0) return;
-    c.lb = lb;
-    bool leaf = true;
-    for (int j = 0; j < 3; j++) leaf = leaf && (c.hi[j] - c.lo[j]) <= A.leaf[j];
-    if (leaf) {
-        const unsigned long long idx = atomicAdd(&counters[1], 1ull);
-        if (idx < leaf_cap) leaves[idx] = c;
-    } else {
-        const unsigned long long idx = atomicAdd(&counters[0], 1ull);
-        if (idx < out_cap) out[idx] = c;
+}
+
+// ... and the survivors go back on the stack, over the boxes the iteration took; the new top is published for the next iteration.
+__global__ __launch_bounds__(256) void mix_push_kernel(MixCell *stack, unsigned long long stack_cap, const MixCell *work, unsigned long long *ctr, unsigned chunk,
+                                                       int par) {
+    const unsigned long long top = ctr[MIX_TOP0 + par];
+    const unsigned long long n = top < (unsigned long long)chunk ? top : (unsigned long long)chunk;
+    const unsigned long long base = top - n;
+    unsigned long long c = ctr[MIX_WK0 + par];
+    const bool over = base + c > stack_cap;
+    if (over) c = stack_cap - base;
+    const uint4 *src = (const uint4 *)work;
+    uint4 *dst = (uint4 *)(stack + base);
+    const unsigned long long words = c * (sizeof(MixCell) / sizeof(uint4));
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < words; i += (unsigned long long)gridDim.x * blockDim.x) dst[i] = src[i];
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        ctr[MIX_TOP0 + 1 - par] = base + c;
+        ctr[MIX_WK0 + 1 - par] = 0ull;
+        if (n) {
+            ctr[MIX_TESTED] += 2 * n;
+            ctr[MIX_ITERS] += 1ull;
+            if (base + c > ctr[MIX_MAXTOP]) ctr[MIX_MAXTOP] = base + c;
+            if (over) ctr[MIX_OVERFLOW] |= 1ull;
+        }
     }
 }
 
@@ -523,79 +632,103 @@ __global__ __launch_bounds__(256) void mix_split_kernel(MixArgs A, const MixCell
 // phi_i(c.v) from below on the whole box for the v that minimises the matrix's (linear) tangent sum -- which is a corner.  So every
 // matrix whose objective is within `thr` somewhere in the box has sum_i cost_i(c_i) <= thr for at least one corner: a depth-first
 // walk over the intervals (rows in slot order, valid and within bounds, the reference's edge rule between consecutive rows) with
-// that budget and the suffix minima as look-ahead lists them.  One thread per (leaf, corner); a record is m slot bytes.
+// that budget and the suffix minima as look-ahead lists them.  One thread per (leaf, corner); a record is m slot bytes.  (A leaf of
+// a line walks the rows of its line only: every matrix it lists is rank deficient.)
 #define MIX_MAX_M 256
 __global__ __launch_bounds__(64) void mix_list_kernel(MixArgs A, const MixCell *leaves, unsigned long long n_leaves, unsigned char *out, unsigned long long out_cap,
-                                                      int per_thread_cap, unsigned long long *counters) {
-    __shared__ float2 rows[MIX_MAX_Q];
-    for (int s = threadIdx.x; s < A.Q; s += blockDim.x) rows[s] = make_float2((float)(A.rowtab[s] & 15u), (float)(A.rowtab[s] >> 4));
+                                                      unsigned long long per_thread_cap, unsigned long long max_steps, unsigned long long *ctr) {
+    __shared__ uchar2 rows[MIX_MAX_Q];
+    __shared__ unsigned char slot_of[256];
+    mix_stage_rows(A, rows, slot_of);
     __syncthreads();
     const unsigned long long k = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= 8 * n_leaves) return;
     const MixCell c = leaves[k >> 3];
     const int corner = (int)(k & 7);
-    const double tau = (double)A.tau;
+    if (c.line && (corner & 4)) return;               // (a line's box has two sides: four corners)
+    const MixRows R(A, c.line, rows, slot_of);
     double vc[3], dv[3];
     for (int j = 0; j < 3; j++) {
         vc[j] = 0.5 * (c.lo[j] + c.hi[j]);
         const double h = 0.5 * (c.hi[j] - c.lo[j]);
         dv[j] = ((corner >> j) & 1) ? h : -h;
     }
-    auto cost = [&](int i, int s, bool &ok) -> double {
-        const float2 rw = rows[s];
-        const int a = (int)rw.x, b = (int)rw.y, l = A.lb[i], u = A.ub[i];
-        ok = !(a < l || a > u || b < l || b > u || (A.tau - a) * (A.tau - b) < 0);
+    auto cost = [&](int i, int s, bool &ok, int &a, int &b) -> double {
+        double x, y;
+        const int l = A.lb[i], u = A.ub[i];
+        ok = R.row(s, a, b, x, y) && !(a < l || a > u || b < l || b > u || (A.tau - a) * (A.tau - b) < 0);
         if (!ok) return __builtin_inf();
-        const double x = (double)a, y = (double)b, r = A.r[i], N = A.rN[i];
-        const double tc = tau * vc[0] + x * vc[1] + y * vc[2];
-        if (!(tc > 0.0)) return -__builtin_inf();
+        const double r = A.r[i], N = A.rN[i];
+        const double tc = R.c0 * vc[0] + x * vc[1] + y * vc[2];
+        if (!(tc > 0.0)) {
+            // (see mix_cell_bound: the constant bound on (0, thi], or not a row of any matrix with a value in this box)
+            const double thi = R.c0 * c.hi[0] + x * c.hi[1] + y * c.hi[2];
+            if (!(thi > 0.0)) {
+                ok = false;
+                return __builtin_inf();
+            }
+            const double t = fmin(thi, r / N);
+            return r > 0.0 ? N * t - r * log(N * t) : 0.0;
+        }
         const double f0 = r > 0.0 ? N * tc - r * log(N * tc) : N * tc, f1 = N - r / tc;
-        return f0 + f1 * (tau * dv[0] + x * dv[1] + y * dv[2]);
+        return f0 + f1 * (R.c0 * dv[0] + x * dv[1] + y * dv[2]);
     };
     double suf[MIX_MAX_M + 1];
     suf[A.m] = A.cst;
     for (int i = A.m - 1; i >= 0; i--) {
         double best = __builtin_inf();
-        for (int s = 0; s < A.Q; s++) {
+        for (int s = 0; s < R.n; s++) {
             bool ok;
-            const double v = cost(i, s, ok);
+            int a, b;
+            const double v = cost(i, s, ok, a, b);
             if (ok) best = fmin(best, v);
         }
         suf[i] = suf[i + 1] + best;
     }
     if (!(suf[0] <= A.thr)) return;
-    unsigned char cur[MIX_MAX_M];      // slot chosen at each depth (the next to try while descending)
+    if (__hip_atomic_load(&ctr[MIX_CUT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull) return;
+    unsigned char cur[MIX_MAX_M];      // row chosen at each depth (the next to try while descending)
+    unsigned char pa[MIX_MAX_M], pb[MIX_MAX_M];   // ... its copy numbers
     double part[MIX_MAX_M + 1];        // cost of the rows chosen above each depth
-    int i = 0, found = 0;
+    int i = 0;
+    unsigned long long found = 0, steps = 0;
     cur[0] = 0;
     part[0] = 0.0;
     while (i >= 0) {
-        if ((int)cur[i] >= A.Q) {       // this depth is exhausted
+        // (a budget on the walk itself: no likelihood, however flat, may hang the device -- and once one walk has run out, the
+        // list is void: the others stop at their next look)
+        if (++steps > max_steps) {
+            atomicAdd(&ctr[MIX_CUT], 1ull);
+            return;
+        }
+        if ((steps & 4095ull) == 0 && __hip_atomic_load(&ctr[MIX_CUT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull) return;
+        if ((int)cur[i] >= R.n) {       // this depth is exhausted
             i--;
             if (i >= 0) cur[i]++;
             continue;
         }
         const int s = cur[i];
         bool ok;
-        const double v = cost(i, s, ok);
+        int a, b;
+        const double v = cost(i, s, ok, a, b);
         bool go = ok && part[i] + v + suf[i + 1] <= A.thr;
-        if (go && i > 0) {               // Enumerator._is_valid_edge (Enumerator.py:258-260): the same row, or some component larger
-            const float2 p = rows[cur[i - 1]], q = rows[s];
-            go = (cur[i - 1] == s) || q.x > p.x || q.y > p.y;
-        }
+        if (go && i > 0)                 // Enumerator._is_valid_edge (Enumerator.py:258-260): the same row, or some component larger
+            go = (a == (int)pa[i - 1] && b == (int)pb[i - 1]) || a > (int)pa[i - 1] || b > (int)pb[i - 1];
         if (!go) {
             cur[i]++;
             continue;
         }
+        pa[i] = (unsigned char)a;
+        pb[i] = (unsigned char)b;
         if (i == A.m - 1) {
             if (found < per_thread_cap) {
-                const unsigned long long idx = atomicAdd(&counters[2], 1ull);
+                const unsigned long long idx = atomicAdd(&ctr[MIX_LISTED], 1ull);
                 if (idx < out_cap) {
                     unsigned char *dst = out + idx * (size_t)A.m;
-                    for (int d = 0; d < A.m; d++) dst[d] = cur[d];
+                    for (int d = 0; d < A.m; d++) dst[d] = (unsigned char)R.slot(cur[d]);
                 }
             } else {
-                atomicAdd(&counters[3], 1ull);      // (this walk found more than its share: the host must not trust the list)
+                atomicAdd(&ctr[MIX_CUT], 1ull);      // (this walk found more than its share: the host must not trust the list)
             }
             found++;
             cur[i]++;
@@ -607,13 +740,16 @@ __global__ __launch_bounds__(64) void mix_list_kernel(MixArgs A, const MixCell *
     }
 }
 
-void mix_launch_split(const MixArgs &A, const MixCell *in, unsigned long long n_in, MixCell *out, unsigned long long out_cap, MixCell *leaves,
-                      unsigned long long leaf_cap, unsigned long long *counters, hipStream_t st) {
-    if (!n_in) return;
-    hipLaunchKernelGGL(mix_split_kernel, dim3((unsigned)((2 * n_in + 3) / 4)), dim3(256), 0, st, A, in, n_in, out, out_cap, leaves, leaf_cap, counters);
+void mix_launch_iteration(const MixArgs &A, MixCell *stack, unsigned long long stack_cap, MixCell *work, MixCell *leaves, unsigned long long leaf_cap,
+                          unsigned long long *ctr, int parity, int drop_leaves, hipStream_t st) {
+    // (a full chunk is 2 x chunk waves of work: one block of MIX_WAVES waves per 16 of them at most -- a wave bounds ~4 boxes)
+    const unsigned blocks = (unsigned)std::min<unsigned long long>(4096ull, (2ull * A.chunk + MIX_WAVES - 1) / MIX_WAVES);
+    hipLaunchKernelGGL(mix_split_kernel, dim3(blocks), dim3(64 * MIX_WAVES), 0, st, A, stack, work, leaves, leaf_cap, ctr, parity, drop_leaves);
+    hipLaunchKernelGGL(mix_push_kernel, dim3(256), dim3(256), 0, st, stack, stack_cap, work, ctr, A.chunk, parity);
 }
-void mix_launch_list(const MixArgs &A, const MixCell *leaves, unsigned long long n_leaves, unsigned char *out, unsigned long long out_cap, int per_thread_cap,
-                     unsigned long long *counters, hipStream_t st) {
+void mix_launch_list(const MixArgs &A, const MixCell *leaves, unsigned long long n_leaves, unsigned char *out, unsigned long long out_cap,
+                     unsigned long long per_thread_cap, unsigned long long max_steps, unsigned long long *ctr, hipStream_t st) {
     if (!n_leaves) return;
-    hipLaunchKernelGGL(mix_list_kernel, dim3((unsigned)((8 * n_leaves + 63) / 64)), dim3(64), 0, st, A, leaves, n_leaves, out, out_cap, per_thread_cap, counters);
+    hipLaunchKernelGGL(mix_list_kernel, dim3((unsigned)((8 * n_leaves + 63) / 64)), dim3(64), 0, st, A, leaves, n_leaves, out, out_cap, per_thread_cap, max_steps,
+                       ctr);
 }

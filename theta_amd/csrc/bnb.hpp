@@ -51,22 +51,65 @@ void bnb_launch_compact(const BnbNode *nodes, const unsigned char *paths, unsign
                         unsigned char *out_paths, unsigned long long out_cap, unsigned long long *counter, hipStream_t st);
 
 // ---- branch and bound over the mixture space (bnb.hip, second half) ----------------------------------------------------------
+// A box of the search.  line == 0: a box of mixtures v = s (mu0, mu1, mu2) >= 0 over the WHOLE alphabet (c.v = tau v0 + a v1 + b v2).
+// line == l + 1: a box of (alpha, beta) -- lo/hi[0], lo/hi[1]; the third side has no width -- over the rows of line l of the
+// alphabet alone (c.v = alpha + t beta for the row x0 + t dx, y0 + t dy): the matrices whose rows all lie on that line are
+// rank deficient, and the reference may report them at a mixture with NEGATIVE entries (Optimizer.py:148-165, 318-330: hybrj on a
+// singular Jacobian, M3's mu never range-checked); their objective depends on v through (alpha, beta) only, both of either sign.
 struct MixCell {
     double lo[3], hi[3];
     double lb;                     // the box's bound (set when it is kept)
+    unsigned key;                  // the path from its root: one bit per cut (the first 32) -- what a sharded search partitions by
+    unsigned short depth;          // cuts so far
+    unsigned short line;           // see above
 };
+static_assert(sizeof(MixCell) == 64, "MixCell is copied as four 16-byte words");
+
+// a line of the alphabet's grid: the points (x0 + t dx, y0 + t dy), t = 0 .. T-1
+struct MixLine {
+    signed char x0, y0, dx, dy;
+    int T;
+};
+
+// counters of a search (64-bit words on the device; the host reads them once per BATCH of iterations, not per level)
+enum {
+    MIX_TOP0 = 0, MIX_TOP1,        // boxes on the stack, by iteration parity
+    MIX_WK0, MIX_WK1,              // children kept by the iteration, by parity
+    MIX_LEAVES,                    // leaves in the list (reset when the list is walked)
+    MIX_LISTED, MIX_CUT,           // matrices written by the leaf walks / walks that went over their share
+    MIX_TESTED,                    // children bounded so far
+    MIX_MAXTOP, MIX_OVERFLOW,      // deepest stack; bit 0: the stack overflowed, bit 1: leaves were dropped (proposal passes may)
+    MIX_ITERS,                     // iterations that had work
+    MIX_MINB, MIX_MINB_LINE,       // smallest bound among the leaves (order-preserving image of the double, mix_ord), whole alphabet / lines
+    MIX_LEAVES_ALL, MIX_LEAVES_LINE,   // leaves found in total / those of lines
+    MIX_NCTR = 16
+};
+__host__ __device__ inline unsigned long long mix_ord(double x) {
+    unsigned long long u = __builtin_bit_cast(unsigned long long, x);
+    return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
+}
+__host__ __device__ inline double mix_unord(unsigned long long u) {
+    u = (u >> 63) ? (u & 0x7fffffffffffffffull) : ~u;
+    return __builtin_bit_cast(double, u);
+}
 
 struct MixArgs {
     int m, Q, tau;
     const double *r, *rN;          // [m]
     const unsigned char *rowtab;   // [Q] slot -> a | b << 4
+    const unsigned char *slot_of;  // [256] a | b << 4 -> slot, 0xff: not a row of the alphabet
     const unsigned char *lb, *ub;  // [m] order-adjusted bounds
     double cst;                    // -Rtot + Rtot ln Rtot
     double thr;
     double leaf[3];                // a box is a leaf when its widths are at most these
+    double leaf_line[3];           // ... a box of a line
+    const MixLine *lines;
+    int n_lines;
+    int shard_g, shard_G, shard_depth;   // G > 1: of the boxes `shard_depth` cuts below their root this rank keeps those with key % G == g
+    unsigned chunk;                // boxes taken off the stack per iteration
 };
 
-void mix_launch_split(const MixArgs &A, const MixCell *in, unsigned long long n_in, MixCell *out, unsigned long long out_cap, MixCell *leaves,
-                      unsigned long long leaf_cap, unsigned long long *counters, hipStream_t st);
-void mix_launch_list(const MixArgs &A, const MixCell *leaves, unsigned long long n_leaves, unsigned char *out, unsigned long long out_cap, int per_thread_cap,
-                     unsigned long long *counters, hipStream_t st);
+void mix_launch_iteration(const MixArgs &A, MixCell *stack, unsigned long long stack_cap, MixCell *work, MixCell *leaves, unsigned long long leaf_cap,
+                          unsigned long long *ctr, int parity, int drop_leaves, hipStream_t st);
+void mix_launch_list(const MixArgs &A, const MixCell *leaves, unsigned long long n_leaves, unsigned char *out, unsigned long long out_cap,
+                     unsigned long long per_thread_cap, unsigned long long max_steps, unsigned long long *ctr, hipStream_t st);

@@ -49,6 +49,7 @@ BNB_MIN_CANDIDATES = int(float(os.environ.get("THETA_BNB_MIN_CANDIDATES", 2 ** 4
 # once): a fraction of a second for BASELINE configs 3 and 4.  The row-tree walk (theta_bnb) is the fallback where that one gives up
 MIX_LEAF_REL = float(os.environ.get("THETA_MIX_LEAF_REL", 0))      # 0: from the data -- a fraction of the radius of the region of mixtures within the window, sqrt(2 window / sum r)
 USE_MIX = os.environ.get("THETA_USE_MIX", "1") != "0"
+MIX_LINES = os.environ.get("THETA_MIX_LINES", "1") != "0"      # the rank-deficient matrices too: one more tree per line of the alphabet's grid (round 6)
 GET_VALUES_MAX = int(float(os.environ.get("THETA_GET_VALUES_MAX", 2 ** 32)))    # candidates a --GET_VALUES dump may hold (a line each)
 BNB_BEAM = int(os.environ.get("THETA_BNB_BEAM", 1024))           # nodes per level of the dive that finds the first attainable NLL
 BNB_MAX_NODES = int(float(os.environ.get("THETA_BNB_MAX_NODES", 2 ** 27)))     # node budget of the row-tree walk (a minute of the GPU): beyond, the call gives up
@@ -548,8 +549,11 @@ def mix_records(problem, ctx, r, rN, max_normal, bounds, report=None, exchange=N
          a mixture;
       3. the reference's own rules (in_space_n3: symmetry, ratio window) and its own procedure (theta_solve_batch) on each.
     `rank` of a record is its position in the enumeration order among the listed matrices (theta_mix_search returns them in
-    that order), not its rank in the space.  Not found: matrices the reference reports BELOW their optimum or with a NaN
-    likelihood (rank-deficient ones; one full-rank matrix in a million) unless their optimum is within the window too.
+    that order), not its rank in the space.  RANK-DEFICIENT matrices (rows on one line), which the reference may report BELOW
+    their optimum -- at a mixture with negative entries --, are bounded by the trees of the lines (round 6: theta_mix_search with
+    THETA_MIX_LINES, one quadtree over (alpha, beta) per line of the alphabet's grid) and those of one repeated row are valued
+    outright: every FINITE outcome within the window is a record, and report.mix["rank_deficient_bound"] bounds the rest.  Not
+    found: NaN outcomes (some rank-deficient matrices; one full-rank matrix in a million) unless a tree happens to list the matrix.
     Returns (records, stats-like dict); fills report.mix.  Raises ThetaError(ERR_CAPACITY) when too many boxes or matrices lie
     within the window (a flat likelihood): the caller falls back to the row-tree walk.
     """
@@ -593,28 +597,71 @@ def mix_records(problem, ctx, r, rN, max_normal, bounds, report=None, exchange=N
     if exchange is not None:
         inc = float(exchange(inc))
     thr = inc + window + 4 * TIE_MARGIN
-    mats, st = problem.mix_search(thr, leaf_rel=leaf_final, cap=1 << 18)
+    # the final pass: the whole alphabet's tree AND one tree per line of the alphabet's grid (the rank-deficient matrices, which the
+    # reference may report at a mixture with negative entries -- below their own minimum over mu >= 0), in one walk
+    mats, st = problem.mix_search(thr, leaf_rel=leaf_final, cap=1 << 18, lines=MIX_LINES)
+    if MIX_LINES:
+        # ... and the matrices of one repeated row (rank 1: the same value at every mixture), which no tree bounds
+        const = problem.constant_matrices()
+        if len(const):
+            mats = _in_enumeration_order(np.concatenate([np.asarray(mats, np.uint8).reshape(-1, problem.m, 2), const]))
     keep = [int(i) for i in np.nonzero(in_space_n3_batch(mats, lb, ub, problem.tau))[0]] if len(mats) else []
     recs = []
     low = float("inf")
+    n_def = 0
     if keep:
         arr = np.ascontiguousarray(mats[keep])
         ok, mu, nll, vals = ctx.solve_batch(3, problem.tau, r, rN, arr, max_normal, want_vals=True)
         fin = [float(v) for v, o in zip(nll, ok) if o and v == v]
         low = min(fin) if fin else float("inf")
+        deficient = _rank_deficient(arr)
         for j, i in enumerate(keep):
             if ok[j] and (nll[j] != nll[j] or nll[j] <= low + window):
-                recs.append({"rank": i, "c": arr[j], "mu": mu[j].copy(), "nll": float(nll[j]), "vals": vals[j].copy(),
-                             "kind": "fallback" if ok[j] == 2 else "own"})
+                kind = "degenerate" if deficient[j] else ("fallback" if ok[j] == 2 else "own")
+                n_def += 1 if deficient[j] else 0
+                recs.append({"rank": i, "c": arr[j], "mu": mu[j].copy(), "nll": float(nll[j]), "vals": vals[j].copy(), "kind": kind})
+    mbl = st.get("min_bound_lines", float("inf"))
     info.update(incumbent=inc, threshold=thr, minimum=low if low < float("inf") else None, listed=len(mats), in_space=len(keep), records=len(recs),
                 boxes_tested=st["boxes_tested"], levels=st["levels"], max_boxes=st["max_boxes"], leaves=st["leaves"], kernel_ms=st["kernel_ms"],
-                min_bound=st["min_bound"],
+                min_bound=st["min_bound"], syncs=st.get("syncs"),
+                # rank-deficient matrices (rows on one line): every one the reference reports at a FINITE value <= threshold is among the
+                # records (valued by its own procedure); nothing finite can be reported for any other below `rank_deficient_bound`.
+                # Their NaN outcomes (and the NaN of one full-rank matrix in a million) are listed only where they happen to be bounded.
+                lines=st.get("lines", 0), line_leaves=st.get("line_leaves", 0), rank_deficient_records=n_def,
+                rank_deficient_complete=bool(MIX_LINES), nan_complete=False,
+                rank_deficient_bound=(min(mbl, thr) if MIX_LINES else None),
                 search_ms=st["wall_ms"], seconds=time.time() - t0)
     if report is not None:
         report.mix = info
         report.fallback_finalists = sum(1 for t in recs if t["kind"] == "fallback")
+        report.degenerate = n_def
     stats = {"evaluated": 0, "kernel_ms": st["kernel_ms"], "boxes_tested": st["boxes_tested"]}
     return recs, stats
+
+
+def _in_enumeration_order(mats):
+    """matrices (B, m, 2) without repeats, in the reference's enumeration order: lexicographic in the rows, a row by (b, a)
+    (Enumerator.py:248-256 builds the alphabet b-major)."""
+    mats = np.asarray(mats, np.uint8)
+    if len(mats) == 0:
+        return mats
+    keys = (mats[:, :, 1].astype(np.int64) << 4) | mats[:, :, 0].astype(np.int64)
+    order = np.lexsort(keys.T[::-1])
+    mats, keys = mats[order], keys[order]
+    first = np.ones(len(mats), bool)
+    first[1:] = np.any(keys[1:] != keys[:-1], axis=1)
+    return mats[first]
+
+
+def _rank_deficient(C):
+    """(B, m, 2) tumour columns -> True where the points (x_i, y_i) lie on one line (rank([tau, x, y]) < 3; exact, integers)."""
+    C = np.asarray(C, np.int64)
+    A = np.concatenate([np.ones(C.shape[:2] + (1,), np.int64), C], axis=2)
+    G = np.einsum("bij,bik->bjk", A, A)
+    det = (G[:, 0, 0] * (G[:, 1, 1] * G[:, 2, 2] - G[:, 1, 2] * G[:, 2, 1])
+           - G[:, 0, 1] * (G[:, 1, 0] * G[:, 2, 2] - G[:, 1, 2] * G[:, 2, 0])
+           + G[:, 0, 2] * (G[:, 1, 0] * G[:, 2, 1] - G[:, 1, 1] * G[:, 2, 0]))
+    return det == 0
 
 
 def bnb_plan(problem, ctx, r, rN, max_normal, report=None, exchange=None, window=COLLECT_WINDOW, bounds=None):
