@@ -62,6 +62,7 @@ FP64_MFMA_PEAK_TFLOPS = 78.6       # MI355X FP64 matrix peak (dense)
 HBM_PEAK_GBS = 8000.0
 
 M, N_POP, K_MAX, TAU, SEED = 50, 3, 6, 2, 4242
+MU_TOL = 1e-6                      # north_star: |delta mu| < 1e-6
 DOMINANT_KERNEL = "n3_sieve_kernel"         # (n3_sieve.hip; the headline runs its <6, double> instantiation); rocprofv3 summaries under profiles/
 # the legs: options of the search instance, arithmetic, kernel instantiation
 LEGS = {"full_solve_f64": ({"n3_no_dismiss": 1, "n3_force_f64": 1}, "f64", "n3_sieve_kernel<6, double>"),
@@ -74,7 +75,13 @@ LEGS = {"full_solve_f64": ({"n3_no_dismiss": 1, "n3_force_f64": 1}, "f64", "n3_s
         # below; tests/test_certified_tolerance_cpu.py).  An evaluation that finds lambda^2 / sum r below
         # sqrt(1e-12 Rmin / (1.53 sum r)) therefore leaves the candidate at a point whose decrement is certified below 1e-12 --
         # the same guarantee as full_solve_f64_tight (mu within 1e-6), without the evaluation that only confirms it
-        "full_solve_f64_tight_certified": ({"n3_no_dismiss": 1, "n3_force_f64": 1, "n3_conv_l2": "certified"}, "f64", "n3_sieve_kernel<6, double>"),
+        # Round 6: the tolerance is north_star's OWN -- mu within 1e-6 -- as a per-candidate certificate (option "n3_mu_tol", n3_sieve.hip:
+        # sv_mu_limit): besides the decrement, an evaluation only counts as the last one where the point one Newton step further is
+        # bounded within 1e-6 (less a 30 % margin) of the optimum in every component of mu, from the smaller eigenvalue of the tangent
+        # Hessian and the Jacobian of nu -> mu.  Round 5's leg (the decrement alone: mu to 8e-7 on this instance, to 1e-5 on a dozen
+        # intervals) is kept as full_solve_f64_l2_certified.
+        "full_solve_f64_tight_certified": ({"n3_no_dismiss": 1, "n3_force_f64": 1, "n3_conv_l2": "certified", "n3_mu_tol": MU_TOL}, "f64", "n3_sieve_kernel<6, double>"),
+        "full_solve_f64_l2_certified": ({"n3_no_dismiss": 1, "n3_force_f64": 1, "n3_conv_l2": "certified"}, "f64", "n3_sieve_kernel<6, double>"),
         "full_solve_f32": ({"n3_no_dismiss": 1}, "f32+f64", "n3_sieve_kernel<6, float>"),
         "search": ({}, "f32+f64", "n3_sieve_kernel<6, float>")}
 
@@ -684,9 +691,12 @@ def main():
                                   "full_solve_f64_tight",
                 "full_solve_f64_tight": "TIGHT tolerance lambda^2 / sum r < 1e-12 (every candidate's mu within 1e-6 of its optimum) -- every "
                                         "candidate generated, iterated in FP64 and valued; none dismissed by a bound",
-                "full_solve_f64_tight_certified": "TIGHT tolerance by certificate: every candidate left at a point whose lambda^2 / sum r is "
-                                                  "below 1e-12 by the self-concordance bound of its last Newton step (mu within 1e-6 of its "
-                                                  "optimum) -- every candidate generated, iterated in FP64 and valued; none dismissed by a bound",
+                "full_solve_f64_tight_certified": "north_star's tolerance by certificate: every candidate left at a point whose lambda^2 / sum r is "
+                                                  "below 1e-12 by the self-concordance bound of its last Newton step AND whose mu is bounded "
+                                                  "within 1e-6 of its optimum (per candidate: smaller Hessian eigenvalue, Jacobian of nu -> mu; "
+                                                  "option n3_mu_tol) -- every candidate generated, iterated in FP64 and valued; none dismissed by a bound",
+                "full_solve_f64_l2_certified": "round 5's headline: the decrement certificate alone (lambda^2 / sum r below 1e-12 at the point a "
+                                               "candidate is left at; mu to 8e-7 on this instance, not by construction)",
                 "full_solve_f32": "COARSE tolerance lambda^2 / sum r < 1e-4 -- every candidate generated, iterated in packed FP32 and valued; "
                                   "none dismissed by a bound",
                 "search": "candidates SEARCHED by the shipped branch-and-bound (a whole prefix finished by the bound of its relaxed problem, else "
@@ -762,6 +772,9 @@ def main():
                                   "l2_last_max": float(np.nanmax(rec["l2_last"][reg])) if reg.any() else 0.0,
                                   "l2_first_median": float(np.nanmedian(rec["l2_first"][reg])) if reg.any() else 0.0,
                                   "conv_l2": certified_conv_l2(r) if head_opts.get("n3_conv_l2") == "certified" else head_opts.get("n3_conv_l2", 1e-4),
+                                  "mu_tol": head_opts.get("n3_mu_tol"),
+                                  "mu_bound_max": float(np.nanmax(rec["mu_bound"][reg])) if reg.any() else 0.0,
+                                  "mu_bound_median": float(np.nanmedian(rec["mu_bound"][reg])) if reg.any() else 0.0,
                                   "note": "l2_last = lambda^2 / sum r found by a candidate's LAST evaluation; the candidate is left one full "
                                           "Newton step beyond it (certified below 1e-12 when l2_last <= conv_l2)"}
             except Exception as ex:

@@ -194,6 +194,13 @@ int theta_search_degenerate(theta_problem *p, int cap, uint64_t *rank, uint8_t *
  *                    Newton step beyond the evaluation that finds it; with t = lambda / sqrt(Rmin) <= 0.1 that step ends at a
  *                    decrement <= 1.53 (sum r / Rmin) l2^2 (self-concordance), so a tolerance T on the point a candidate is left at
  *                    is met by the value sqrt(T Rmin / (1.53 sum r)) (bench.py: certified_conv_l2)
+ *   "n3_mu_tol"      > 0 (with "n3_no_dismiss"): the tolerance as a CERTIFICATE ON MU.  An evaluation at u (decrement lambda, tangent Hessian H,
+ *                    t = lambda / sqrt(Rmin) <= 0.1) counts as converged only if, besides "n3_conv_l2", the point one full Newton step further
+ *                    is certified within this distance of the candidate's optimum in every component of mu: self-concordance bounds the
+ *                    step's decrement and the drift of H, det H / trace H bounds H's smaller eigenvalue from below, and d mu / d u is
+ *                    bounded by (1.5 + |k|) / U inside the simplex (tests/test_certified_tolerance_cpu.py restates the chain and checks it
+ *                    on 3 000 random problems).  Points outside the simplex -- where the reference reports no mixture of the candidate's
+ *                    own -- are left to "n3_conv_l2" alone.  0 (default): the decrement alone decides
  *   "n3_warm_blend"  weight of the previous optimum in a chunk's first warm start
  *   "n3_sieve"       1 (default): the two-kernel path (sieve + finish, n3_sieve.hip) where it applies; 0: the fused
  *                    kernel of n3.hip throughout (also used for theta_search_values and m < 8; m <= 64)
@@ -219,7 +226,9 @@ int theta_search_degenerate(theta_problem *p, int cap, uint64_t *rank, uint8_t *
  *   "n3_per_task"    candidates per wave task (0 = automatic), "n2_per_thread" candidates per thread (0 = automatic)
  *   "mix_shard_world", "mix_shard_rank"   theta_mix_search on G ranks: rank g keeps the boxes dealt to it a few cuts below the roots
  *                    (set the world first); default 1 / 0: every box
+ *   "mix_beam"       boxes per level of a THETA_MIX_DIVE (8 .. 1024, default 512)
  *   "mix_max_steps"  steps the walk over the intervals of one (leaf, corner) may take before theta_mix_search gives up (default 2^22)
+ *   "mix_max_ms"     theta_mix_search gives up (THETA_ERR_CAPACITY) once it has spent this much wall time with work left (0, the default: never)
  *   "mix_max_boxes"  theta_mix_search gives up (THETA_ERR_CAPACITY) once this many boxes have been bounded and more are waiting
  *                    (0, the default: never -- a flat likelihood is walked to the end, however long it takes)
  * The THETA_N3_* environment variables of the same names only set the defaults at theta_problem_create.
@@ -273,7 +282,8 @@ typedef struct theta_witness {
                               1 converged at the shared evaluation, 2 converged in the queue, 3 / 4 finished by the lower bound
                               (search mode) at the shared evaluation / in the queue, 5 contender (handed to the finish kernel),
                               6 handed to the finish kernel unsolved (ill-conditioned, or 40 evaluations)                          */
-    uint32_t reserved;
+    float mu_bound;        /* option "n3_mu_tol": what the certificate bounds the distance IN MU between that point and the candidate's
+                              optimum by (0: no certificate asked for, or the point lies outside the simplex)                      */
 } theta_witness;
 int theta_search_witness(theta_problem *p, const uint64_t rank_begin[2], const uint64_t rank_end[2], double window,
                          int every_log2, uint64_t cap, theta_witness *out, uint64_t *n_out, theta_search_stats *stats);
@@ -333,6 +343,9 @@ int theta_bnb(theta_problem *p, double threshold, uint64_t beam, int follow_coll
  *   THETA_MIX_PROPOSE     no list -- for the `cap` leaves of smallest bound, the matrix that fits the leaf's centre best (per interval
  *                         the row minimising its term): candidates for a better attainable NLL, to be valued by the caller before a
  *                         finer call with a lower threshold.
+ *   THETA_MIX_DIVE        (with THETA_MIX_PROPOSE) no threshold: every level of the tree keeps its "mix_beam" boxes of smallest bound
+ *                         (option, default 512), down to the leaf size -- a few thousand boxes in all; the proposals of its leaves
+ *                         give the attainable NLL the thresholded search starts from.
  *   THETA_MIX_LINES       also the RANK-DEFICIENT matrices the reference can report within the threshold at a mixture with negative
  *                         entries (Optimizer.py:148-165: hybrj on a singular Jacobian; 318-330: M3's mu is never range-checked; L3 is
  *                         finite wherever the products c_i.mu keep one sign).  The rows of such a matrix lie on one line of the
@@ -353,6 +366,7 @@ int theta_bnb(theta_problem *p, double threshold, uint64_t beam, int follow_coll
 #define THETA_MIX_PROPOSE 1
 #define THETA_MIX_LINES 2
 #define THETA_MIX_LINES_ONLY 4
+#define THETA_MIX_DIVE 8
 typedef struct theta_mix_stats {
     uint64_t boxes_tested, levels, max_boxes, leaves, listed, matrices;
     uint64_t lines, line_leaves, syncs;   /* lines searched, leaves of lines, host synchronisations of the walk                    */

@@ -120,13 +120,39 @@ class StandinProblem(_lib.Problem):
         self.suspects_dropped = 0
         self.suspect_reruns = 0
         self.search_calls = []
+        self.options = {}
+        self.mix_calls, self.mix_listed = [], []
+        self._bounds = (lb, ub)
         self._h = None
 
     def close(self):
         pass
 
     def set_option(self, name, value):
-        pass
+        self.options[name] = value
+
+    # ---- the mixture-space search (theta_mix_search), modelled on the enumerated space: what the HOST side of a sharded whole-space
+    # search sees -- proposals, a superset of the matrices within a threshold dealt out over the ranks, the statistics it reports
+    standin_mix = True
+
+    def mix_search(self, threshold, leaf_rel=2e-4, cap=1 << 16, propose=False, lines=False, lines_only=False, dive=False):
+        import zlib
+        g, G = int(self.options.get("mix_shard_rank", 0)), int(self.options.get("mix_shard_world", 1))
+        st = {"boxes_tested": 1000, "levels": 10, "max_boxes": 10, "leaves": 5, "listed": 0, "matrices": 0, "lines": 7 if lines else 0, "line_leaves": 0,
+              "syncs": 2, "kernel_ms": 0.0, "wall_ms": 0.0, "min_bound": float("inf"), "min_bound_lines": float("inf")}
+        self.mix_calls.append(("dive" if dive else "propose" if propose else "list", float(threshold), (g, G)))
+        if dive or propose:
+            # a few matrices of the space, not the best ones: the driver must get to the minimum from a poor start as well
+            out = [self.cands[k] for k in range(0, self.count, max(1, self.count // 5))][:cap]
+            return np.array(out, np.uint8).reshape(len(out), self.m, 2), st
+        out = []
+        for k in range(self.count):
+            o, _mu, nll = self._entry(k)
+            if o and nll == nll and nll <= threshold and zlib.crc32(self.cands[k].tobytes()) % G == g:
+                out.append(self.cands[k])
+        self.mix_listed.append([c.tobytes() for c in out])
+        st["listed"] = st["matrices"] = len(out)
+        return np.array(out, np.uint8).reshape(len(out), self.m, 2), st
 
     def _entry(self, k):
         """(outcome, mu, nll) of candidate k in the reference's arithmetic."""

@@ -97,3 +97,91 @@ def test_the_legs_threshold_certifies_the_tight_tolerance():
     assert 1e-9 < conv < 1e-4                               # between the tight and the coarse tolerance of the other legs
     # a problem whose smallest weight is tiny: the t <= 0.1 side binds
     assert bench.certified_conv_l2(np.array([1.0, 1e9])) == 0.01 / (1e9 + 1.0)
+
+
+# ---- round 6: the tolerance on MU as a certificate (n3_sieve.hip: sv_mu_limit; option "n3_mu_tol") ------------------------------
+def mu_of(u, s1, s2, tau):
+    """nu -> mu as the kernels do it (M3's closed form, Optimizer.py:318-330): u0 = (1 - s1 u1 - s2 u2) / tau, mu = (u0, u1, u2) / sum"""
+    u0 = (1.0 - s1 * u[0] - s2 * u[1]) / tau
+    v = np.array([u0, u[0], u[1]])
+    return v / v.sum()
+
+
+def mu_bound(l2, R, H, u, s1, s2, tau):
+    """The certificate's bound on |mu(u+) - mu(u*)|_inf, u+ = u + Newton step, from what the evaluation at u has at hand: with
+    t = lambda / sqrt(Rmin) <= 0.1 the step ends at lambda+^2 <= lambda^4 / (Rmin (1 - t)^4), the minimiser lies within
+    lambda+ / (1 - t+) of u+ in the norm of H(u+) >= (1 - t)^2 H(u), and the smaller eigenvalue of H(u) is at least det / trace;
+    d mu_j = (du_j - mu_j (k . du)) / U, k = (1 - s1 / tau, 1 - s2 / tau), U = u0 + u1 + u2, so |d mu|_inf <= |du|_2 (1.5 + |k|_2) / U
+    inside the simplex."""
+    Rtot, Rmin = R.sum(), R.min()
+    sig = np.linalg.det(H) / np.trace(H)
+    U = (1.0 - s1 * u[0] - s2 * u[1]) / tau + u[0] + u[1]
+    J = (1.5 + np.hypot(1.0 - s1 / tau, 1.0 - s2 / tau)) / U
+    return 1.01 * l2 * Rtot * J / (0.718 * np.sqrt(Rmin * sig))
+
+
+def test_the_mu_certificate_bounds_the_distance_to_the_optimum():
+    """What "n3_mu_tol" builds on: the bound above really bounds the distance in mu between the point a candidate is left at (one
+    full Newton step beyond the evaluation) and its optimum -- on random problems of the kernel's shape, at points inside the
+    simplex whose decrement spans the leg's range."""
+    rng = np.random.default_rng(20260931)
+    checked, worst = 0, 0.0
+    tau = 2.0
+    while checked < 3000:
+        T = int(rng.integers(8, 30))
+        rmin = float(rng.integers(50, 30000))
+        R = np.floor(rmin * (1.0 + 40.0 * rng.random(T) ** 2))
+        R[int(rng.integers(T))] = rmin
+        x = rng.integers(0, 7, T).astype(float)
+        y = rng.integers(0, 7, T).astype(float)
+        if np.linalg.matrix_rank(np.stack([np.ones(T), x, y])) < 3:
+            continue
+        w = rng.integers(1, 50, T).astype(float)              # normal counts behind the column sums
+        s1, s2 = float((w * x).sum() / w.sum()), float((w * y).sum() / w.sum())
+        if not (s1 > 0 and s2 > 0):
+            continue
+        a, b = x - s1, y - s2
+
+        def ev(u):
+            q = 1.0 + a * u[0] + b * u[1]
+            if not (q > 0).all():
+                return None
+            al, be = a / q, b / q
+            g = -np.array([(R * al).sum(), (R * be).sum()])
+            H = np.array([[(R * al * al).sum(), (R * al * be).sum()], [(R * al * be).sum(), (R * be * be).sum()]])
+            d = np.linalg.solve(H, -g)
+            return float(-(g @ d)) / R.sum(), d, H
+        u = np.array([(1.0 / 3.0) / s1, (1.0 / 3.0) / s2])
+        ok = True
+        for _ in range(80):
+            e = ev(u)
+            if e is None:
+                ok = False
+                break
+            l2, d, _H = e
+            if l2 < 1e-31:
+                break
+            step = 1.0 if l2 * R.sum() / R.min() < 0.25 else 1.0 / (1.0 + np.sqrt(l2 * R.sum() / R.min()))
+            while ev(u + step * d) is None:
+                step *= 0.5
+            u = u + step * d
+        if not ok:
+            continue
+        ustar = u
+        nu = np.array([1 - s1 * u[0] - s2 * u[1], s1 * u[0], s2 * u[1]])
+        if nu.min() < 0.02:                                    # (the certificate is for optima inside the simplex: the ones the reference reports)
+            continue
+        for _ in range(6):
+            p = ustar + 10.0 ** rng.uniform(-5.0, -1.5) * rng.standard_normal(2) / np.sqrt(R.sum())
+            e = ev(p)
+            if e is None:
+                continue
+            l2, d, H = e
+            if not (l2 * R.sum() / R.min() <= 0.01) or l2 < 1e-13:
+                continue
+            bound = mu_bound(l2, R, H, p, s1, s2, tau)
+            dist = np.abs(mu_of(p + d, s1, s2, tau) - mu_of(ustar, s1, s2, tau)).max()
+            assert dist <= bound + 1e-15, (dist, bound, l2)
+            worst = max(worst, dist / bound)
+            checked += 1
+    assert 0.0 < worst <= 1.0

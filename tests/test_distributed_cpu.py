@@ -238,6 +238,86 @@ def test_sharded_driver_over_the_standin_device_equals_the_reference_driver(n, s
         assert ncoll >= 2                                                            # the hint all-reduce and the exchange
 
 
+def _mix_driver_worker(rank, world, port, inst, q):
+    try:
+        for pth in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+            sys.path.insert(0, pth)
+        import warnings
+        warnings.simplefilter("ignore")
+        import theta_amd
+        import campaign as cp
+        import standin_device as sd
+        from theta_amd import _lib, search as S
+        S.BNB_MIN_CANDIDATES = 0                 # every n=3 space goes to the mixture-space search, as a 1e27-matrix one would
+        ctx = sd.StandinContext()
+        made = []
+
+        def make(c, *a, **k):
+            made.append(sd.StandinProblem(c, *a, **k))
+            return made[-1]
+        _lib.Problem = make
+        comm = theta_amd.Comm(None, rank=rank, world=world, addr="127.0.0.1", port=port, transport="host")
+        best = S.do_optimization_distributed(inst["n"], inst["m"], inst["k"], inst["tau"], inst["lb"], inst["ub"], inst["r"], inst["rN"],
+                                             inst["mx"], inst["order"], comm, ctx=ctx)
+        ncoll = comm.info()["collectives"]
+        comm.close()
+        q.put((rank, cp.best_to_plain(best), made[-1].mix_calls, made[-1].mix_listed, ncoll, S.last_report.mix))
+    except BaseException as e:
+        import traceback
+        q.put((rank, "error: %r %s" % (e, traceback.format_exc()[-600:]), None, None, None, None))
+
+
+@pytest.mark.parametrize("seed,world", [(10044, 2), (10010, 8)])
+def test_sharded_mixture_space_search_over_the_standin_device(seed, world):
+    """The whole-space search of a space no walk finishes, on several ranks (round 6: search._search_local deals the boxes out,
+    mix_records agrees on the attainable NLL by all-reduce after every step that can lower it, the records meet in
+    theta_exchange_finalists and merge_mix_records restores the enumeration order): over the host transport with the stand-in
+    device, whose mix_search deals the matrices within a threshold out over the ranks.  Every rank goes through the same
+    collectives and returns the reference's list (its NaN entries apart: no bound reaches those); the ranks' lists are disjoint,
+    their thresholds equal."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import warnings
+    import campaign
+    import theta_oracle as orc
+    inst = campaign.instance(seed, 3, "toy")
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ref, cnt = orc.search_single(3, inst["m"], inst["tau"], list(inst["lb"]), list(inst["ub"]), inst["r"], inst["rN"], inst["mx"],
+                                     inst["order"])
+    ref = [b for b in campaign.best_to_plain(ref) if b[2] == b[2]]
+    assert ref and 40 <= cnt <= 2000
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_mix_driver_worker, args=(rk, world, port, inst, q)) for rk in range(world)]
+    for p in procs:
+        p.start()
+    out = {}
+    for _ in range(world):
+        item = q.get(timeout=900)
+        out[item[0]] = item[1:]
+    for p in procs:
+        p.join(30)
+    thresholds, seen, ncolls = set(), [], set()
+    for rk in range(world):
+        best, calls, listed, ncoll, mix = out[rk]
+        assert not isinstance(best, str), best
+        got = [b for b in best if b[2] == b[2]]
+        assert campaign.compare_best(got, ref) == "", (rk, seed)
+        assert mix["shard"] == [rk, world] and all(c[2] == (rk, world) for c in calls)
+        finals = [c for c in calls if c[0] == "list"]
+        assert len(finals) >= 1
+        thresholds.add(round(finals[-1][1], 9))
+        seen.append(set(listed[-1]))
+        ncolls.add(ncoll)
+    assert len(thresholds) == 1, thresholds                  # one attainable NLL for all ranks
+    assert len(ncolls) == 1, ncolls                          # ... reached through the same collectives
+    for a in range(world):
+        for b in range(a + 1, world):
+            assert not (seen[a] & seen[b])                   # disjoint shares
+    assert sum(len(x) for x in seen) >= len(ref)
+
+
 def _failing_worker(rank, world, port, inst, fail_rank, fail_in_probe, q):
     try:
         for pth in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):

@@ -38,7 +38,9 @@ def _records_exhaustive_complete(S, problem, ctx, r, rN):
     recs = _records_exhaustive(S, problem, ctx, r, rN)
     listed = set(problem.last_degenerate[0])
     recs = [t for t in recs if t["rank"] not in listed]
-    return recs + S.degenerate_records(problem, ctx, r, rN, 1.0)
+    # (degenerate_records returns the NaN ones and the finite ones within the window of the smallest value known -- a space of 1e10
+    # matrices holds millions of rank-deficient ones, and a Python record each took the first GPU box of round 6 down)
+    return recs + S.degenerate_records(problem, ctx, r, rN, 1.0, recs=recs)
 
 
 def _finite(recs):
@@ -83,7 +85,7 @@ def test_mixture_space_search_equals_the_exhaustive_search_on_whole_spaces(ctx, 
     # bound them all; only NaN outcomes are beyond any bound
     want_all = S.replay_records(_finite(walk), False)
     got_all = S.replay_records(_finite(recs_mix), False)
-    n_def = int(rank_deficient(np.array([t["c"] for t in walk])).sum()) if walk else 0
+    n_def = len(p.last_degenerate[0])
     p.close()
     assert len(want) >= 1
     assert campaign.compare_best(_plain(got), _plain(want), tol=1e-9) == "", (m, K, seed, len(got), len(want), rep.mix)

@@ -42,7 +42,9 @@ def _legs(rr):
     import bench
     return [("full_solve_f64", {"n3_no_dismiss": 1, "n3_force_f64": 1}, coarse_left_l2(rr)),
             ("full_solve_f64_tight", {"n3_no_dismiss": 1, "n3_force_f64": 1, "n3_conv_l2": 1e-12}, TIGHT_LEFT_L2),
-            ("full_solve_f64_tight_certified", {"n3_no_dismiss": 1, "n3_force_f64": 1, "n3_conv_l2": bench.certified_conv_l2(rr)}, TIGHT_LEFT_L2),
+            ("full_solve_f64_tight_certified", {"n3_no_dismiss": 1, "n3_force_f64": 1, "n3_conv_l2": bench.certified_conv_l2(rr), "n3_mu_tol": bench.MU_TOL},
+             TIGHT_LEFT_L2),
+            ("full_solve_f64_l2_certified", {"n3_no_dismiss": 1, "n3_force_f64": 1, "n3_conv_l2": bench.certified_conv_l2(rr)}, TIGHT_LEFT_L2),
             ("full_solve_f32", {"n3_no_dismiss": 1}, None)]
 
 
@@ -134,7 +136,16 @@ def _check_leg(ctx, p, name, opts, left_l2, b, e, shift, rr, rn, tau, hint, n_or
     dnll = np.abs(nll_pt[on_opt] - nll_ref[on_opt]) / np.abs(nll_ref[on_opt]) if on_opt.any() else np.zeros(0)
     # (where every optimum lies outside the simplex -- the last ranks of the space -- the reference reports its nu = 1/3 fallback
     # or nothing: there is no mu of its to compare with, the decrement above is the whole statement)
-    if left_l2 == TIGHT_LEFT_L2 and on_opt.any():
+    certified_mu = "n3_mu_tol" in opts
+    if certified_mu and on_opt.any():
+        # round 6: the tolerance on mu is a CERTIFICATE (option n3_mu_tol): every solved candidate inside the simplex carries the bound
+        # its last evaluation established, the bound is within the tolerance, and the distance to the reference's mu within the bound
+        mb = rec["mu_bound"][reg].astype(np.float64)
+        assert np.all(mb[on_opt] > 0.0) and mb[on_opt].max() <= 0.7 * opts["n3_mu_tol"] * (1 + 1e-5), (what, name, float(mb[on_opt].max()))
+        assert np.all(dmu <= mb[on_opt] + 2e-9), (what, name, float((dmu - mb[on_opt]).max()))       # (2e-9: the reference's own xtol 1.5e-8 on nu)
+        assert dmu.max() < opts["n3_mu_tol"], (what, name, float(dmu.max()))
+        assert dnll.max() < 1e-6, (what, name, float(dnll.max()))
+    elif left_l2 == TIGHT_LEFT_L2 and on_opt.any():
         assert dmu.max() < mu_tol, (what, name, float(dmu.max()))
         assert dnll.max() < 1e-6, (what, name, float(dnll.max()))
     elif left_l2 is not None and on_opt.any():
@@ -150,10 +161,11 @@ def _check_leg(ctx, p, name, opts, left_l2, b, e, shift, rr, rn, tau, hint, n_or
         d = float(np.abs(np.asarray(s[0]) - mu[j]).max())
         worst_o = max(worst_o, d)
         if left_l2 == TIGHT_LEFT_L2:
-            assert d < mu_tol and abs(s[1] - nll_pt[j]) <= 1e-6 * abs(s[1]), (what, name, int(j), d, s[1], nll_pt[j])
+            assert d < (opts["n3_mu_tol"] if certified_mu else mu_tol) and abs(s[1] - nll_pt[j]) <= 1e-6 * abs(s[1]), (what, name, int(j), d, s[1], nll_pt[j])
     return {"leg": name, "samples": int(reg.sum()), "solved": int(solved.sum()), "contenders": int((status == 5).sum()),
             "evaluations_mean": float(mean_ev), "left_l2_max": worst, "left_l2_median": float(np.median(l2_pt[solved])) if solved.any() else 0.0,
             "on_optimum": int(on_opt.sum()), "dmu_max": float(dmu.max()) if len(dmu) else 0.0, "dmu_max_vs_scipy": worst_o,
+            "mu_bound_max": float(rec["mu_bound"][reg][on_opt].max()) if on_opt.any() else 0.0,
             "first_l2_quantiles": [float(x) for x in np.nanquantile(rec["l2_first"][reg].astype(np.float64), [0.1, 0.25, 0.5, 0.75, 0.9, 0.99])]}
 
 
@@ -190,7 +202,9 @@ def test_witness_of_whole_small_spaces(ctx, m, K, seed, tau):
     """Every candidate of a whole space (dense records): the four-level (m < 10) and six-level instantiations of the sieve.
     What a leg guarantees is the DECREMENT at the point a candidate is left at (checked exactly for every candidate); how far mu
     then is from the optimum depends on the candidate's conditioning -- distance <= lambda / sqrt(smallest Hessian eigenvalue) --,
-    and a dozen intervals determine a mixture less sharply than the bench's fifty: 1e-5 here where the bench instance meets 1e-6."""
+    and a dozen intervals determine a mixture less sharply than the bench's fifty: 1e-5 here where the bench instance meets 1e-6 -- for
+    the legs whose tolerance is on the decrement.  The certified leg (round 6: option n3_mu_tol) carries a bound on mu per candidate and
+    meets 1e-6 here as well (checked in _check_leg against the bound itself)."""
     import bench
     import theta_amd
     rr, rn, _order = bench.synth(seed=seed, m=m, n=3, k=K)

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("THETA_HIP_LIB") or os.path.join(_HERE, "libtheta_hip.so")   # THETA_HIP_LIB: A/B builds
 
 THETA_OK, ERR_ARG, ERR_NO_CANDIDATES, ERR_HIP, ERR_OVERFLOW, ERR_CAPACITY = range(6)
-MIX_PROPOSE, MIX_LINES, MIX_LINES_ONLY = 1, 2, 4          # theta_mix_search's mode bits (include/theta_hip.h)
+MIX_PROPOSE, MIX_LINES, MIX_LINES_ONLY, MIX_DIVE = 1, 2, 4, 8          # theta_mix_search's mode bits (include/theta_hip.h)
 
 
 class ThetaError(RuntimeError):
@@ -86,7 +86,7 @@ class MixStats(C.Structure):
 
 # theta_witness (include/theta_hip.h): what the n=3 sieve kernel left a sampled candidate at
 WITNESS_DTYPE = np.dtype([("mu", np.float64, 3), ("nll", np.float64), ("l2_last", np.float32), ("l2_first", np.float32),
-                          ("evaluations", np.uint16), ("status", np.uint16), ("reserved", np.uint32)])
+                          ("evaluations", np.uint16), ("status", np.uint16), ("mu_bound", np.float32)])
 
 _lib = None
 
@@ -773,12 +773,12 @@ class Problem:
                                           C.byref(st)))
         return nll, mu, st.as_dict()
 
-    def mix_search(self, threshold, leaf_rel=2e-4, cap=1 << 16, propose=False, lines=False, lines_only=False):
+    def mix_search(self, threshold, leaf_rel=2e-4, cap=1 << 16, propose=False, lines=False, lines_only=False, dive=False):
         """theta_mix_search: the matrices (k, m, 2) uint8 -- in enumeration order, a superset -- whose NLL can be <= threshold for
         some mixture, by branch and bound over the mixture space; and the walk's statistics.  lines: also the rank-deficient
         matrices the reference can report within the threshold at a mixture with negative entries (one more tree per line of the
-        alphabet's grid); lines_only: those trees alone."""
-        mode = (MIX_PROPOSE if propose else 0) | (MIX_LINES if lines else 0) | (MIX_LINES_ONLY if lines_only else 0)
+        alphabet's grid); lines_only: those trees alone; dive: proposals from a beam search without a threshold."""
+        mode = (MIX_PROPOSE if propose or dive else 0) | (MIX_LINES if lines else 0) | (MIX_LINES_ONLY if lines_only else 0) | (MIX_DIVE if dive else 0)
         for _attempt in range(2):
             st = MixStats()
             out = np.zeros((max(cap, 1), self.m, 2), np.uint8)

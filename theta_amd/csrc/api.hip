@@ -194,7 +194,11 @@ struct theta_problem {
     unsigned long long mix_stack_cap = 0, mix_leaf_cap = 0;
     uint64_t mix_mat_cap = 0;
     int opt_mix_g = 0, opt_mix_G = 1;                  // options mix_shard_rank / mix_shard_world: this rank's share of the boxes
+    int opt_mix_niches = 1;                            // option mix_dive_niches
+    double opt_mix_blend = 0.2;                        // option mix_dive_blend
+    uint64_t opt_mix_beam = 512;                       // option mix_beam: boxes a dive (THETA_MIX_DIVE) keeps per level
     uint64_t opt_mix_max_steps = 1ull << 22;           // option mix_max_steps: steps one (leaf, corner) walk over the intervals may take
+    double opt_mix_max_ms = 0.0;                       // option mix_max_ms: give up (THETA_ERR_CAPACITY) beyond this much wall time (0: never)
     uint64_t opt_mix_max_boxes = 0;                    // option mix_max_boxes: give up (THETA_ERR_CAPACITY) beyond this many boxes tested (0: never)
     DevBuf d_r, d_rN, d_small, d_P, d_PR, d_PN, d_cnt, d_ctr, d_stat, d_list, d_tasks, d_stbuf, d_misc, d_smask, d_dynmask, d_sus, d_deg, d_surv, d_survcnt, d_survacc, d_line, d_scan, d_sweep;
 };
@@ -503,6 +507,7 @@ extern "C" int theta_problem_create(theta_ctx *ctx, int n, int m, int tau, const
         D.NT = h.NT;
         D.L = 1;   // (decided below, once the candidate count is known; the counting DP does not depend on it)
         D.warm_blend = 0.9;
+        D.mu_tol = 0.0;
         D.conv_l2 = 1e-4;    // first-pass threshold on the squared decrement before the last step (contenders are polished)
         if (const char *e = getenv("THETA_N3_WARM_BLEND")) D.warm_blend = atof(e);
         D.force64 = 0;
@@ -607,6 +612,7 @@ extern "C" int theta_problem_set_option(theta_problem *p, const char *name, doub
     else if (k == "n3_prefix_bound") p->n3.prefix_bound = value != 0.0;
     else if (k == "n3_second") p->n3.no_second = value == 0.0;
     else if (k == "n3_conv_l2" && value > 0.0) p->n3.conv_l2 = value;
+    else if (k == "n3_mu_tol" && value >= 0.0) p->n3.mu_tol = value;
     else if (k == "n3_warm_blend" && value >= 0.0 && value <= 1.0) p->n3.warm_blend = value;
     else if (k == "n3_sieve") p->opt_sieve = value != 0.0;
     else if (k == "n3_auto_f64") {
@@ -622,7 +628,11 @@ extern "C" int theta_problem_set_option(theta_problem *p, const char *name, doub
     }
     else if (k == "mix_shard_rank" && value >= 0.0 && value < (double)p->opt_mix_G) p->opt_mix_g = (int)value;
     else if (k == "mix_max_boxes" && value >= 0.0) p->opt_mix_max_boxes = (uint64_t)value;
+    else if (k == "mix_max_ms" && value >= 0.0) p->opt_mix_max_ms = value;
     else if (k == "mix_max_steps" && value >= 1.0) p->opt_mix_max_steps = (uint64_t)value;
+    else if (k == "mix_dive_niches") p->opt_mix_niches = value != 0.0;
+    else if (k == "mix_dive_blend" && value >= 0.0 && value <= 1.0) p->opt_mix_blend = value;
+    else if (k == "mix_beam" && value >= 8.0 && value <= (double)MIX_BEAM_LIMIT) p->opt_mix_beam = (uint64_t)value;
     else if (k == "n2_no_dismiss") p->n2.quick = value == 0.0;
     else if (k == "n2_per_thread" && (value == 0.0 || (value >= 1 && value <= 512))) p->opt_per_thread = (int)value;
     else {
@@ -1862,7 +1872,7 @@ static int mix_buffers(theta_problem *p, hipStream_t st) {
     if (const char *e = getenv("THETA_MIX_LEAVES")) p->mix_leaf_cap = std::max<unsigned long long>(4ull * p->mix_chunk, strtoull(e, nullptr, 10));
     unsigned char slot_of[256];
     mix_build_lines(p, p->mix_lines, slot_of);
-    if ((rc = p->d_mix_stack.alloc(p->mix_stack_cap * sizeof(MixCell))) || (rc = p->d_mix_work.alloc(2ull * p->mix_chunk * sizeof(MixCell))) ||
+    if ((rc = p->d_mix_stack.alloc(p->mix_stack_cap * sizeof(MixCell))) || (rc = p->d_mix_work.alloc(2ull * p->mix_chunk * sizeof(MixCell) + 2 * MIX_BEAM_LIMIT * sizeof(unsigned short))) ||
         (rc = p->d_mix_leaves.alloc(p->mix_leaf_cap * sizeof(MixCell))) || (rc = p->d_mix_ctr.alloc(MIX_NCTR * sizeof(unsigned long long))) ||
         (rc = upload(p->d_mix_slot, slot_of, sizeof(slot_of), st)) ||
         (rc = upload(p->d_mix_lines, p->mix_lines.data(), std::max<size_t>(1, p->mix_lines.size()) * sizeof(MixLine), st)))
@@ -1887,15 +1897,18 @@ extern "C" int theta_mix_search(theta_problem *p, double threshold, double leaf_
         theta_set_error("theta_mix_search: n = 3 only");
         return THETA_ERR_ARG;
     }
-    if (!(threshold == threshold) || !(leaf_rel > 0.0 && leaf_rel < 1.0) || (mode & ~7)) {
+    if (!(threshold == threshold) || !(leaf_rel > 0.0 && leaf_rel < 1.0) || (mode & ~15)) {
         theta_set_error("theta_mix_search: bad threshold, leaf size or mode");
         return THETA_ERR_ARG;
     }
     const bool propose = mode & THETA_MIX_PROPOSE, lines_only = mode & THETA_MIX_LINES_ONLY, with_lines = (mode & THETA_MIX_LINES) || lines_only;
-    if (propose && with_lines) {
-        theta_set_error("theta_mix_search: proposals come from the whole alphabet's boxes (no THETA_MIX_LINES with THETA_MIX_PROPOSE)");
+    const bool dive = mode & THETA_MIX_DIVE;
+    if ((propose && with_lines) || (dive && !propose)) {
+        theta_set_error("theta_mix_search: proposals come from the whole alphabet's boxes (no THETA_MIX_LINES with THETA_MIX_PROPOSE), and a dive "
+                        "(THETA_MIX_DIVE) only proposes");
         return THETA_ERR_ARG;
     }
+    const unsigned beam = dive ? (unsigned)std::min<uint64_t>(std::max<uint64_t>(p->opt_mix_beam, 8), MIX_BEAM_LIMIT) : 0u;
     HIP_ENTER(p->ctx->device);
     hipStream_t st = p->ctx->stream;
     const int m = p->m;
@@ -1925,8 +1938,11 @@ extern "C" int theta_mix_search(theta_problem *p, double threshold, double leaf_
     A.lines = (const MixLine *)p->d_mix_lines.p;
     A.n_lines = (int)p->mix_lines.size();
     A.shard_g = p->opt_mix_g;
-    A.shard_G = p->opt_mix_G;
+    A.shard_G = dive ? 1 : p->opt_mix_G;              // (a dive is a few thousand boxes: every rank takes it whole, and alike)
     A.chunk = p->mix_chunk;
+    A.dive = dive ? 1 : 0;
+    A.dive_blend = p->opt_mix_blend;
+    A.dive_niches = p->opt_mix_niches;
     const double tref = (double)(Rt / N);            // the mean read-depth ratio: c.v of a typical interval
     const int Kmax = std::max(1, p->n3.K);
     A.leaf[0] = leaf_rel * tref / std::max(1, p->tau);
@@ -1955,7 +1971,7 @@ extern "C" int theta_mix_search(theta_problem *p, double threshold, double leaf_
             sat += r > 0 ? (long double)r - (long double)r * logl((long double)r) : 0.0L;       // phi_i at its minimiser: N t = r
         }
         const double S = (double)((long double)threshold - (long double)A.cst - sat);
-        if (S >= 0.0) {
+        if (S >= 0.0 && std::isfinite(S) && with_lines) {
             double lo_all = INFINITY, hi_all = 0.0;
             for (int i = 0; i < m; i++) {
                 const double r = p->h_r[i], Nn = p->h_rN[i];
@@ -2036,44 +2052,57 @@ extern "C" int theta_mix_search(theta_problem *p, double threshold, double leaf_
     uint64_t syncs = 0, walked_leaves = 0, list_launches = 0;
     // Walk the leaves collected so far (and empty the list).  The list of matrices is redone with a larger buffer when it overflows
     // (the walk is deterministic; the counter is put back first).
+    // The leaves are walked MIX_LEAF_LAUNCH at a time: a walk over the intervals is a serial affair of up to mix_max_steps steps per
+    // (leaf, corner), and a launch over a million leaves of a flat likelihood would hold the device for minutes (round 6 lost a box
+    // to one).  A launch of 4096 leaves is a second or two at the very worst; the host looks at the counters and the clock in between.
+    const unsigned long long MIX_LEAF_LAUNCH = 4096;
     auto walk_leaves = [&](unsigned long long n_leaves) -> int {
         if (!n_leaves) return THETA_OK;
-        const unsigned long long before = h_ctr[MIX_LISTED];
-        for (;;) {
-            mix_launch_list(A, d_leaves, n_leaves, (unsigned char *)p->d_mix_mat.p, p->mix_mat_cap, ~0ull, p->opt_mix_max_steps, d_ctr, st);
-            list_launches++;
-            unsigned long long got[2];
-            HIP_TRY(hipMemcpyAsync(got, d_ctr + MIX_LISTED, sizeof(got), hipMemcpyDeviceToHost, st));
-            HIP_TRY(hipStreamSynchronize(st));
-            HIP_TRY(hipGetLastError());
-            syncs++;
-            if (got[1] > 0) {
-                theta_set_error("theta_mix_search: %llu walks over the intervals of a leaf did not finish within their %llu steps (%llu matrices listed so "
-                                "far): the likelihood is too flat there (option mix_max_steps)", got[1], (unsigned long long)p->opt_mix_max_steps, got[0]);
+        for (unsigned long long first = 0; first < n_leaves; first += MIX_LEAF_LAUNCH) {
+            const unsigned long long part = std::min<unsigned long long>(MIX_LEAF_LAUNCH, n_leaves - first);
+            const unsigned long long before = h_ctr[MIX_LISTED];
+            for (;;) {
+                mix_launch_list(A, d_leaves + first, part, (unsigned char *)p->d_mix_mat.p, p->mix_mat_cap, ~0ull, p->opt_mix_max_steps, d_ctr, st);
+                list_launches++;
+                unsigned long long got[2];
+                HIP_TRY(hipMemcpyAsync(got, d_ctr + MIX_LISTED, sizeof(got), hipMemcpyDeviceToHost, st));
+                HIP_TRY(hipStreamSynchronize(st));
+                HIP_TRY(hipGetLastError());
+                syncs++;
+                if (got[1] > 0) {
+                    theta_set_error("theta_mix_search: %llu walks over the intervals of a leaf did not finish within their %llu steps (%llu matrices listed so "
+                                    "far): the likelihood is too flat there (option mix_max_steps)", got[1], (unsigned long long)p->opt_mix_max_steps, got[0]);
+                    return THETA_ERR_CAPACITY;
+                }
+                if (got[0] <= p->mix_mat_cap) {
+                    h_ctr[MIX_LISTED] = got[0];
+                    break;
+                }
+                // grow: what was listed before this launch is kept
+                size_t free_b = 0, total_b = 0;
+                (void)hipMemGetInfo(&free_b, &total_b);
+                const uint64_t want = std::max<uint64_t>(got[0] + got[0] / 4, 2 * p->mix_mat_cap);
+                if ((size_t)want * m > free_b / 2 + p->mix_mat_cap * (size_t)m) {
+                    theta_set_error("theta_mix_search: %llu matrices listed within the threshold (%.1f GB of records): it is too far above the minimum",
+                                    (unsigned long long)got[0], (double)got[0] * m / 1e9);
+                    return THETA_ERR_CAPACITY;
+                }
+                DevBuf bigger;
+                if ((rc = bigger.alloc((size_t)want * m))) return rc;
+                if (before) HIP_TRY(hipMemcpyAsync(bigger.p, p->d_mix_mat.p, (size_t)before * m, hipMemcpyDeviceToDevice, st));
+                HIP_TRY(hipMemcpyAsync(d_ctr + MIX_LISTED, &before, sizeof(before), hipMemcpyHostToDevice, st));
+                HIP_TRY(hipStreamSynchronize(st));
+                std::swap(p->d_mix_mat.p, bigger.p);
+                std::swap(p->d_mix_mat.bytes, bigger.bytes);
+                p->mix_mat_cap = want;
+                if (debug) fprintf(stderr, "mix: list buffer grown to %llu matrices\n", (unsigned long long)want);
+            }
+            const double spent = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count();
+            if (p->opt_mix_max_ms > 0.0 && spent > p->opt_mix_max_ms && first + part < n_leaves) {
+                theta_set_error("theta_mix_search: %.0f ms spent (option mix_max_ms) with %llu leaves still to walk, %llu matrices listed: the "
+                                "threshold is too far above the minimum", spent, n_leaves - first - part, (unsigned long long)h_ctr[MIX_LISTED]);
                 return THETA_ERR_CAPACITY;
             }
-            if (got[0] <= p->mix_mat_cap) {
-                h_ctr[MIX_LISTED] = got[0];
-                break;
-            }
-            // grow: what was listed before this walk is kept
-            size_t free_b = 0, total_b = 0;
-            (void)hipMemGetInfo(&free_b, &total_b);
-            const uint64_t want = std::max<uint64_t>(got[0] + got[0] / 4, 2 * p->mix_mat_cap);
-            if ((size_t)want * m > free_b / 2 + p->mix_mat_cap * (size_t)m) {
-                theta_set_error("theta_mix_search: %llu matrices listed within the threshold (%.1f GB of records): it is too far above the minimum",
-                                (unsigned long long)got[0], (double)got[0] * m / 1e9);
-                return THETA_ERR_CAPACITY;
-            }
-            DevBuf bigger;
-            if ((rc = bigger.alloc((size_t)want * m))) return rc;
-            if (before) HIP_TRY(hipMemcpyAsync(bigger.p, p->d_mix_mat.p, (size_t)before * m, hipMemcpyDeviceToDevice, st));
-            HIP_TRY(hipMemcpyAsync(d_ctr + MIX_LISTED, &before, sizeof(before), hipMemcpyHostToDevice, st));
-            HIP_TRY(hipStreamSynchronize(st));
-            std::swap(p->d_mix_mat.p, bigger.p);
-            std::swap(p->d_mix_mat.bytes, bigger.bytes);
-            p->mix_mat_cap = want;
-            if (debug) fprintf(stderr, "mix: list buffer grown to %llu matrices\n", (unsigned long long)want);
         }
         walked_leaves += n_leaves;
         const unsigned long long zero = 0;
@@ -2089,9 +2118,13 @@ extern "C" int theta_mix_search(theta_problem *p, double threshold, double leaf_
             if ((rc = walk_leaves(h_ctr[MIX_LEAVES]))) return rc;
             continue;
         }
-        if (syncs == 0) batch = std::min(batch, 12);         // (the first cuts: a handful of boxes each)
+        if (syncs == 0 && !dive) batch = std::min(batch, 12);         // (the first cuts: a handful of boxes each)
+        if (dive) batch = 40;                                          // (a beam's worth of boxes per level: the launches are the cost)
+        const unsigned long long top0 = h_ctr[MIX_TOP0 + parity];
         for (int it = 0; it < batch; it++) {
-            mix_launch_iteration(A, d_stack, p->mix_stack_cap, d_work, d_leaves, p->mix_leaf_cap, d_ctr, parity, propose ? 1 : 0, st);
+            unsigned long long n_max = it < 40 ? top0 << it : ~0ull;     // (an iteration at most doubles the stack)
+            if (dive) n_max = std::min<unsigned long long>(n_max, beam);
+            mix_launch_iteration(A, d_stack, p->mix_stack_cap, d_work, d_leaves, p->mix_leaf_cap, d_ctr, parity, propose ? 1 : 0, n_max, beam, st);
             parity ^= 1;
         }
         HIP_TRY(hipMemcpyAsync(h_ctr, d_ctr, sizeof(h_ctr), hipMemcpyDeviceToHost, st));
@@ -2123,6 +2156,21 @@ extern "C" int theta_mix_search(theta_problem *p, double threshold, double leaf_
             fill();
             theta_set_error("theta_mix_search: more than %llu boxes on the stack (%llu tested): the threshold is too far above the minimum",
                             (unsigned long long)p->mix_stack_cap, (unsigned long long)h_ctr[MIX_TESTED]);
+            return THETA_ERR_CAPACITY;
+        }
+        if (max_tested && h_ctr[MIX_LEAVES_ALL] > std::max<uint64_t>(max_tested / 128, 4096)) {
+            // (a bounded walk: its leaves would be walked over the intervals next, and with a threshold this far up each holds matrices
+            // by the thousand)
+            fill();
+            theta_set_error("theta_mix_search: %llu leaves within the threshold after %llu boxes (option mix_max_boxes): it is too far above the minimum",
+                            (unsigned long long)h_ctr[MIX_LEAVES_ALL], (unsigned long long)h_ctr[MIX_TESTED]);
+            return THETA_ERR_CAPACITY;
+        }
+        if (p->opt_mix_max_ms > 0.0 && top > 0 &&
+            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count() > p->opt_mix_max_ms) {
+            fill();
+            theta_set_error("theta_mix_search: %.0f ms spent (option mix_max_ms) with %llu boxes still on the stack, %llu tested: the threshold is too far "
+                            "above the minimum", p->opt_mix_max_ms, top, (unsigned long long)h_ctr[MIX_TESTED]);
             return THETA_ERR_CAPACITY;
         }
         if (max_tested && h_ctr[MIX_TESTED] > max_tested && top > 0) {

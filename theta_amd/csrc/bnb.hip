@@ -480,16 +480,17 @@ __device__ __forceinline__ void mix_stage_rows(const MixArgs &A, uchar2 *rows, u
     for (int s = threadIdx.x; s < 256; s += blockDim.x) slot_of[s] = A.slot_of[s];
 }
 
-__device__ double mix_cell_bound(const MixArgs &A, const MixCell &c, const uchar2 *rows, const unsigned char *slot_of, const double2 *ltab, int lane) {
+__device__ double mix_cell_bound(const MixArgs &A, const MixCell &c, const uchar2 *rows, const unsigned char *slot_of, const double2 *ltab, int lane, double &centre) {
     const MixRows R(A, c.line, rows, slot_of);
     double vc[3], h[3];
     for (int j = 0; j < 3; j++) {
         vc[j] = 0.5 * (c.lo[j] + c.hi[j]);
         h[j] = 0.5 * (c.hi[j] - c.lo[j]);
     }
-    double lb1 = 0.0, lbv[8];
+    double lb1 = 0.0, lbv[8], cs = 0.0;
     for (int k = 0; k < 8; k++) lbv[k] = 0.0;
     for (int i = lane; i < A.m; i += WAVE) {
+        double cbest = __builtin_inf();              // the interval's best term AT the centre: the relaxed objective there (what a dive ranks by)
         const double r = A.r[i], N = A.rN[i], ts = r / N;
         const int l = A.lb[i], u = A.ub[i];
         // (1): phi_i is convex with its minimum at ts, so over the rows the smallest clamped value is phi(ts) if some row's interval
@@ -514,6 +515,7 @@ __device__ double mix_cell_bound(const MixArgs &A, const MixCell &c, const uchar
             const double tc = R.c0 * vc[0] + x * vc[1] + y * vc[2];
             if (tc > 0.0) {
                 const double f0 = r > 0.0 ? N * tc - r * smx_log(N * tc, ltab) : N * tc, f1 = N - r / tc;
+                cbest = fmin(cbest, f0);
                 const double d0 = f1 * R.c0 * h[0], d1 = f1 * x * h[1], d2 = f1 * y * h[2];
 #pragma unroll
                 for (int k = 0; k < 8; k++) {
@@ -538,8 +540,10 @@ __device__ double mix_cell_bound(const MixArgs &A, const MixCell &c, const uchar
             }
         }
         lb1 += best1;
+        cs += cbest;
         for (int k = 0; k < 8; k++) lbv[k] += bestv[k];
     }
+    centre = mix_wave_sum(cs) + A.cst;
     lb1 = mix_wave_sum(lb1);
     double lb2 = __builtin_inf();
     for (int k = 0; k < 8; k++) lb2 = fmin(lb2, mix_wave_sum(lbv[k]));
@@ -583,9 +587,12 @@ __global__ __launch_bounds__(64 * MIX_WAVES) void mix_split_kernel(MixArgs A, co
         c.depth++;
         // a sharded search: below `shard_depth` cuts every box belongs to ONE rank (by its path), above it all ranks walk alike
         if (A.shard_G > 1 && (int)c.depth == A.shard_depth && (int)((c.key * 2654435761u + c.line * 40503u) % (unsigned)A.shard_G) != A.shard_g) continue;
-        const double lb = mix_cell_bound(A, c, rows, slot_of, ltab, lane);
-        if (!(lb <= A.thr) || lane != 0) continue;
-        c.lb = lb;
+        double centre;
+        const double lb = mix_cell_bound(A, c, rows, slot_of, ltab, lane, centre);
+        if (!(lb <= A.thr) || lb == __builtin_inf() || lane != 0) continue;      // (+inf: no row of some interval has a value in the box)
+        // a DIVE ranks by what the best assignment of rows comes to AT the box's centre -- an attainable value of the relaxed problem,
+        // where the bounds of large boxes are all the saturated model's and tell nothing apart
+        c.lb = A.dive ? lb + A.dive_blend * (centre - lb) : lb;
         bool leaf = true;
         for (int j = 0; j < 3; j++) leaf = leaf && (c.hi[j] - c.lo[j]) <= lf[j];
         if (leaf) {
@@ -740,12 +747,97 @@ __global__ __launch_bounds__(64) void mix_list_kernel(MixArgs A, const MixCell *
     }
 }
 
+// The best `beam` of the iteration's children (by their score) go back on the stack -- a DIVE: no threshold, a fixed number of boxes
+// per level of the tree, all the way down to the leaf size; its leaves propose the matrices whose value starts the real search.
+// c <= 2 x beam <= 2048 children ranked by counting.
+#define MIX_BEAM_MAX 1024
+#define MIX_SEL_ITEMS 64           // children ranked per block of 256 threads: four lanes share one child's comparisons
+// (ties -- the mirror image of a box under the exchange of the tumour columns scores alike -- are broken by the box's position, not by
+// where the atomics happened to put it in the list: the same input gives the same dive)
+// NICHES: the boxes are ranked within groups of like mixtures first -- 8 bands of the normal fraction mu0 x 4 of the split mu1 : mu2
+// at the box's centre -- and the beam takes the best of every group before the second best of any: on BASELINE config 4 the plain
+// beam settled in a basin at mu0 = 0.44, 58 units above the minimum at mu0 = 0.61, whatever its width and ranking.
+// Two launches (a rank needs every child's group rank): mix_rank_kernel<false> writes the rank within the group, <true> the final
+// position and the boxes; c <= 2048 children, four lanes per child, 64 children per block.
+struct MixSelLds {
+    unsigned long long key[2 * MIX_BEAM_MAX], key2[2 * MIX_BEAM_MAX];
+    unsigned short grp[2 * MIX_BEAM_MAX];
+};
+template <bool FINAL>
+__global__ __launch_bounds__(256) void mix_rank_kernel(MixCell *stack, const MixCell *work, unsigned long long *ctr, unsigned short *grank, unsigned beam, int par,
+                                                       int niches) {
+    __shared__ MixSelLds L;
+    const unsigned long long top = ctr[MIX_TOP0 + par];
+    unsigned long long c = ctr[MIX_WK0 + par];
+    if (c > 2ull * MIX_BEAM_MAX) c = 2ull * MIX_BEAM_MAX;
+    if ((unsigned long long)blockIdx.x * MIX_SEL_ITEMS < c) {
+        for (unsigned i = threadIdx.x; i < (unsigned)c; i += blockDim.x) {
+            const MixCell w = work[i];
+            L.key[i] = mix_ord(w.lb);
+            L.key2[i] = mix_ord(w.lo[0]) * 0x9E3779B97F4A7C15ull + mix_ord(w.lo[1]) * 0xC2B2AE3D27D4EB4Full + mix_ord(w.lo[2]) * 0x165667B19E3779F9ull + mix_ord(w.hi[0]);
+            if (FINAL) {
+                L.grp[i] = grank[i];                     // (the group rank takes the group's place in the order)
+            } else {
+                const double v0 = w.lo[0] + w.hi[0], v1 = w.lo[1] + w.hi[1], v2 = w.lo[2] + w.hi[2], sum = v0 + v1 + v2, t12 = v1 + v2;
+                int g0 = sum > 0.0 ? (int)(8.0 * v0 / sum) : 0, g1 = t12 > 0.0 ? (int)(4.0 * v1 / t12) : 0;
+                g0 = g0 < 0 ? 0 : (g0 > 7 ? 7 : g0);
+                g1 = g1 < 0 ? 0 : (g1 > 3 ? 3 : g1);
+                L.grp[i] = (unsigned short)(niches ? g0 * 4 + g1 : 0);
+            }
+        }
+        __syncthreads();
+        const unsigned i = blockIdx.x * MIX_SEL_ITEMS + (threadIdx.x >> 2), sub = threadIdx.x & 3u;
+        unsigned rank = 0;
+        if (i < (unsigned)c) {
+            const unsigned long long k = L.key[i], k2 = L.key2[i];
+            const unsigned short g = L.grp[i];
+            for (unsigned j = sub; j < (unsigned)c; j += 4) {
+                const bool better = L.key[j] < k || (L.key[j] == k && (L.key2[j] < k2 || (L.key2[j] == k2 && j < i)));
+                // <false>: among the children of the same group; <true>: a smaller group rank first, then the better child
+                const bool before = FINAL ? (L.grp[j] < g || (L.grp[j] == g && better)) : (L.grp[j] == g && better);
+                rank += before ? 1u : 0u;
+            }
+        }
+        rank += __shfl_xor(rank, 1, WAVE);
+        rank += __shfl_xor(rank, 2, WAVE);
+        if (i < (unsigned)c && sub == 0) {
+            if (FINAL) {
+                if (rank < beam) stack[rank] = work[i];
+            } else {
+                grank[i] = (unsigned short)rank;
+            }
+        }
+    }
+    if (FINAL && blockIdx.x == 0 && threadIdx.x == 0) {
+        ctr[MIX_TOP0 + 1 - par] = c < beam ? c : beam;
+        ctr[MIX_WK0 + 1 - par] = 0ull;
+        if (top) {
+            ctr[MIX_TESTED] += 2 * top;
+            ctr[MIX_ITERS] += 1ull;
+            if (c > ctr[MIX_MAXTOP]) ctr[MIX_MAXTOP] = c;
+        }
+    }
+}
+
+// n_max: an upper bound of the boxes this iteration can find on the stack (the host knows the top of the last batch; an iteration at
+// most doubles it) -- the grids are sized for that, not for a full chunk: a tree's first and last levels hold a handful of boxes,
+// and 4096 blocks that look at a counter and leave were most of a small search's time.
 void mix_launch_iteration(const MixArgs &A, MixCell *stack, unsigned long long stack_cap, MixCell *work, MixCell *leaves, unsigned long long leaf_cap,
-                          unsigned long long *ctr, int parity, int drop_leaves, hipStream_t st) {
-    // (a full chunk is 2 x chunk waves of work: one block of MIX_WAVES waves per 16 of them at most -- a wave bounds ~4 boxes)
-    const unsigned blocks = (unsigned)std::min<unsigned long long>(4096ull, (2ull * A.chunk + MIX_WAVES - 1) / MIX_WAVES);
+                          unsigned long long *ctr, int parity, int drop_leaves, unsigned long long n_max, unsigned beam, hipStream_t st) {
+    n_max = std::max<unsigned long long>(1, std::min<unsigned long long>(n_max, A.chunk));
+    // (a wave bounds up to ~4 boxes of a full chunk)
+    const unsigned blocks = (unsigned)std::min<unsigned long long>(4096ull, (2ull * n_max + MIX_WAVES - 1) / MIX_WAVES);
     hipLaunchKernelGGL(mix_split_kernel, dim3(blocks), dim3(64 * MIX_WAVES), 0, st, A, stack, work, leaves, leaf_cap, ctr, parity, drop_leaves);
-    hipLaunchKernelGGL(mix_push_kernel, dim3(256), dim3(256), 0, st, stack, stack_cap, work, ctr, A.chunk, parity);
+    if (beam) {
+        // (the group ranks live behind the work list's 2 x chunk boxes: 2 x MIX_BEAM_MAX shorts)
+        unsigned short *grank = (unsigned short *)(work + 2ull * A.chunk);
+        const unsigned sblocks = (2 * beam + MIX_SEL_ITEMS - 1) / MIX_SEL_ITEMS;
+        hipLaunchKernelGGL(mix_rank_kernel<false>, dim3(sblocks), dim3(256), 0, st, stack, work, ctr, grank, beam, parity, A.dive_niches);
+        hipLaunchKernelGGL(mix_rank_kernel<true>, dim3(sblocks), dim3(256), 0, st, stack, work, ctr, grank, beam, parity, A.dive_niches);
+    } else {
+        const unsigned pblocks = (unsigned)std::min<unsigned long long>(256ull, (2ull * n_max * (sizeof(MixCell) / 16) + 255) / 256);
+        hipLaunchKernelGGL(mix_push_kernel, dim3(pblocks), dim3(256), 0, st, stack, stack_cap, work, ctr, A.chunk, parity);
+    }
 }
 void mix_launch_list(const MixArgs &A, const MixCell *leaves, unsigned long long n_leaves, unsigned char *out, unsigned long long out_cap,
                      unsigned long long per_thread_cap, unsigned long long max_steps, unsigned long long *ctr, hipStream_t st) {

@@ -107,9 +107,13 @@ struct MixArgs {
     int n_lines;
     int shard_g, shard_G, shard_depth;   // G > 1: of the boxes `shard_depth` cuts below their root this rank keeps those with key % G == g
     unsigned chunk;                // boxes taken off the stack per iteration
+    double dive_blend;             // ... what a dive ranks by: bound + dive_blend x (relaxed objective at the centre - bound)
+    int dive_niches;               // ... within groups of like mixtures first (mix_select_kernel)
+    int dive;                      // 1: no threshold, boxes are RANKED (mix_select_kernel) by the relaxed objective at their centre, kept in `lb`
 };
 
 void mix_launch_iteration(const MixArgs &A, MixCell *stack, unsigned long long stack_cap, MixCell *work, MixCell *leaves, unsigned long long leaf_cap,
-                          unsigned long long *ctr, int parity, int drop_leaves, hipStream_t st);
+                          unsigned long long *ctr, int parity, int drop_leaves, unsigned long long n_max, unsigned beam, hipStream_t st);
+#define MIX_BEAM_LIMIT 1024
 void mix_launch_list(const MixArgs &A, const MixCell *leaves, unsigned long long n_leaves, unsigned char *out, unsigned long long out_cap,
                      unsigned long long per_thread_cap, unsigned long long max_steps, unsigned long long *ctr, hipStream_t st);

@@ -134,7 +134,8 @@ struct SvWitness {
                                   // shared evaluation, 2 converged in the queue, 3 / 4 finished by the lower bound (search mode) at the
                                   // shared evaluation / in the queue, 5 contender (listed for the finish kernel), 6 handed to the finish
                                   // kernel unsolved (ill-conditioned or 40 evaluations)
-    unsigned reserved;
+    float mu_bound;               // n3_mu_tol: what the certificate bounds the distance in mu between that point and the optimum by (0: none asked
+                                  // for, or a point outside the simplex -- the reference reports no mu of its own there)
 };
 
 // ---------------------------------------------------------------------------------------------

@@ -37,6 +37,8 @@ struct N3Dev {
     double warm_blend;           // weight of the previous optimum in the warm start (rest: simplex centre)
     int force64;                 // 1: iterate every candidate in FP64 (THETA_N3_FORCE_F64; the packed-f32 pass is the default)
     double conv_l2;              // convergence threshold on the squared Newton decrement
+    double mu_tol;               // > 0: a candidate also counts as converged only where ONE more Newton step is certified to end within this of its
+                                 // optimum IN MU (n3_sieve.hip: sv_mu_limit; option "n3_mu_tol"); 0: the decrement alone decides
     int no_dismiss;              // 1: never finish a candidate by its lower bound (THETA_N3_NO_DISMISS): every one is iterated to the coarse tolerance
     int prefix_bound;            // 1: the sieve finishes a whole prefix by the lower bound of its relaxed problem (search mode; n3_sieve.hip: sv_prefix_beyond)
     int no_second;               // 1: no second evaluation in place in the tight full-solve modes (n3_sieve.hip: sv_children; option "n3_second" = 0: A/B)

@@ -266,6 +266,8 @@ struct SvCtx {
     F leafRf[ML];                    // tumour counts of the leaf rows
     F leafRho[ML];                   // ... and their square roots
     F rtot_f, rtot_over_rmin, inv_Rtot, conv_l2, fine_l2;
+    double A_mu_tol;                 // ... the tolerance itself (witness records)
+    F mu_c, inv_tau;                 // option n3_mu_tol: 0.4976 tol sqrt(Rmin) / Rtot (per prefix; 0: off), 1 / tau -- see sv_mu_limit
     double K0, screen_margin, thr;   // thr = running minimum + window, loaded per task; screen_margin: see sv_beyond
     F Tcmp;                          // the threshold of sv_beyond's comparison, in F (per task)
     F sqrt_ror;                      // sqrt(Rtot / Rmin) (per prefix)
@@ -301,7 +303,7 @@ struct SvCtx {
 #ifdef SV_WITNESS
 template <int ML, class F, int NS>
 __device__ __forceinline__ void sv_witness(const SvCtx<ML, F, NS> &c, unsigned off, unsigned status, unsigned evals, float l2_first, F l2_last,
-                                           F val2, F s1, F s2, F u1, F u2) {
+                                           F val2, F s1, F s2, F u1, F u2, F mu_lim = F(0)) {
     if (!c.A.wit) return;
     const unsigned long long rel = c.wrel + off;
     if (rel & ((1ull << c.A.wit_shift) - 1ull)) return;
@@ -319,7 +321,8 @@ __device__ __forceinline__ void sv_witness(const SvCtx<ML, F, NS> &c, unsigned o
     w->l2_first = l2_first;
     w->evaluations = (unsigned short)evals;
     w->status = (unsigned short)status;
-    w->reserved = 0u;
+    // the certificate's bound on the distance in mu (sv_mu_limit: converged means l2 <= limit, and the bound is tol x 0.7 l2 / limit)
+    w->mu_bound = (c.mu_c > F(0) && mu_lim > F(0)) ? (float)(0.7 * (double)c.A_mu_tol * (double)l2_last / (double)mu_lim) : 0.0f;
 }
 #define SV_WIT(...) __VA_ARGS__
 #else
@@ -327,13 +330,34 @@ __device__ __forceinline__ void sv_witness(const SvCtx<ML, F, NS> &c, unsigned o
 #endif
 
 
+// ---- the tolerance ON MU as a certificate (option "n3_mu_tol"; round 6) ---------------------------------------------------------
+// An evaluation at u has the decrement lambda (l2 = lambda^2 / Rtot) and the tangent Hessian H.  With t = lambda / sqrt(Rmin) <= 0.1
+// (f / Rmin is self-concordant) one full Newton step ends at lambda+^2 <= lambda^4 / (Rmin (1 - t)^4); the minimiser u* then lies within
+// lambda+ / (1 - t+) of the new point in the norm of H(u+) >= (1 - t)^2 H(u), whose smaller eigenvalue is at least det H / trace H:
+//      |u+ - u*|_2 <= l2 Rtot / (0.718 sqrt(Rmin det / trace)).
+// nu -> mu is M3's closed form (Optimizer.py:318-330): mu_j = u_j / U, U = u0 + u1 + u2, u0 = (1 - s1 u1 - s2 u2) / tau, so
+// d mu_j = (du_j - mu_j k.du) / U with k = (1 - s1 / tau, 1 - s2 / tau), and inside the simplex |d mu|_inf <= |du|_2 (1.5 + |k|_2) / U.
+// Hence the step from this evaluation ends within `tol` of the optimum in every component of mu if
+//      l2 <= 0.4976 tol sqrt(Rmin) / Rtot x sqrt(det / trace) U / (1.5 + |k|)            (0.7 x 0.718 / 1.01: a 30 % margin)
+// -- the returned limit (c.mu_c holds the first factor).  Outside the simplex (a nu_j < 0: the reference reports no mixture of the
+// candidate's own there) there is no limit: +inf.  tests/test_certified_tolerance_cpu.py checks the chain on random problems.
+template <int ML, class F, int NS>
+__device__ __forceinline__ F sv_mu_limit(const SvCtx<ML, F, NS> &c, F H11, F H22, F det, F s1, F s2, F u1, F u2) {
+    const F n1 = s1 * u1, n2 = s2 * u2, n0 = F(1) - n1 - n2;
+    const F k1 = sv_fma(-s1, c.inv_tau, F(1)), k2 = sv_fma(-s2, c.inv_tau, F(1));
+    const F U = sv_fma(n0, c.inv_tau, u1 + u2);
+    const F sig = det * sv_rcp(H11 + H22);
+    const F lim = c.mu_c * sv_sqrt(sig) * U * sv_rcp(F(1.5) + sv_sqrt(sv_fma(k1, k1, k2 * k2)));
+    return (n0 >= F(0) && n1 >= F(0) && n2 >= F(0)) ? lim : F(__builtin_inff());
+}
+
 // One evaluation of value, gradient and Hessian at (u1, u2) over the group tile and the record's rows, two terms at a time
 // (F = float: packed instructions), and the Newton step.  The likelihood in the scaled variables of n3_core.hpp:
 // q_i = 1 + (x_i - s1) u1 + (y_i - s2) u2, NLL = K0 - sum R_i ln q_i.  Returns 0 = stepped (u1, u2 hold the new iterate;
 // val2 = sum R log2 q and l2 = lambda^2 / Rtot at the OLD one), 1 = stepped and converged (l2 < conv), 2 = outside the domain
 // (u1, u2 halved towards 0), 3 = no usable step (ill-conditioned Hessian, NaN).
 template <int ML, class F, int NS>
-__device__ __forceinline__ int sv_step(const SvCtx<ML, F, NS> &c, const unsigned (&rw)[ML / 2], F s1, F s2, F &u1, F &u2, F &val2, F &l2, F &la) {
+__device__ __forceinline__ int sv_step(const SvCtx<ML, F, NS> &c, const unsigned (&rw)[ML / 2], F s1, F s2, F &u1, F &u2, F &val2, F &l2, F &la, F &mlim) {
     typedef typename SvVec<F>::v2 v2;
     v2 g1 = {F(0), F(0)}, g2 = g1, h11 = g1, h12 = g1, h22 = g1, lg = g1, lga = g1;
     const v2 vs1 = {s1, s1}, vs2 = {s2, s2}, vu1 = {u1, u1}, vu2 = {u2, u2}, one = {F(1), F(1)};
@@ -401,11 +425,18 @@ SV_UNROLL(SV_UNR)
     if (!(l2 == l2) || !(sv_abs(d1) + sv_abs(d2) < F(1e30))) return 3;
     F step = F(1);
     if (l2 > F(0.09)) step = sv_rcp(F(1) + sv_sqrt(l2));
+    // (option n3_mu_tol, wave-uniform: the limit the certificate on mu puts on l2 at THIS point, before the step)
+    F conv = c.conv_l2;
+    mlim = F(0);
+    if (c.mu_c > F(0)) {
+        mlim = sv_mu_limit<ML, F, NS>(c, H11, H22, det, s1, s2, u1, u2);
+        conv = sv_min(conv, mlim);
+    }
     u1 = sv_fma(step, d1, u1);
     u2 = sv_fma(step, d2, u2);
     // "converged" = the coarse threshold on lambda^2 / sum r AND lambda^2 < Rmin / 4 (quadratic convergence is only granted
     // once the decrement is small against the smallest term weight)
-    return (l2 < c.conv_l2 && l2 * c.rtot_over_rmin < F(0.25)) ? 1 : 0;
+    return (l2 < conv && l2 * c.rtot_over_rmin < F(0.25)) ? 1 : 0;
 }
 
 // Is a rigorous LOWER BOUND of the candidate's optimum beyond the threshold (running minimum + window)?  From one evaluation
@@ -566,8 +597,8 @@ __device__ __forceinline__ void sv_drain(SvCtx<ML, F, NS> &c) {
 #endif
         bool fin = false, surv = false;
         if (live) {
-            F val2 = F(0), l2 = F(0), la = F(0);
-            const int st = sv_step<ML, F, NS>(c, rw, s1, s2, u1, u2, val2, l2, la);
+            F val2 = F(0), l2 = F(0), la = F(0), mlim = F(0);
+            const int st = sv_step<ML, F, NS>(c, rw, s1, s2, u1, u2, val2, l2, la, mlim);
             iters++;
             SV_WIT(unsigned wst = 0u;)
             if (st == 3 || iters >= 40) {
@@ -587,7 +618,7 @@ __device__ __forceinline__ void sv_drain(SvCtx<ML, F, NS> &c) {
                     SV_WIT(wst = 5u;)
                 }
             }
-            SV_WIT(if (fin) sv_witness<ML, F, NS>(c, qy >> 8, wst, (unsigned)iters, l0, l2, val2, s1, s2, u1, u2);)
+            SV_WIT(if (fin) sv_witness<ML, F, NS>(c, qy >> 8, wst, (unsigned)iters, l0, l2, val2, s1, s2, u1, u2, mlim);)
         }
         if (surv) sv_survivor<ML, F, NS>(c, rw, qy >> 8, iters >= 40 ? F(__builtin_nanf("")) : u1, u2);
         if (fin) {
@@ -753,7 +784,7 @@ struct SvChild {
 #ifdef SV_WITNESS
     bool wdone;                // finished by this evaluation (converged and valued / dismissed by the bound)
     bool wconv;
-    F wl2, wval2, ws1, ws2;
+    F wl2, wval2, ws1, ws2, wmlim;
 #endif
 };
 
@@ -824,7 +855,14 @@ __device__ __forceinline__ void sv_child_eval(const SvCtx<ML, F, NS> &c, int lo,
         val2 = sv_fma(-c.rtot_f, lz, L);
         F la = F(0);
         if constexpr (sizeof(F) == 8) la = sv_fma(c.rtot_f, sv_abs(lz), sv_fma(Rl, sv_abs(lq), P[15]));
-        conv = l2 < c.conv_l2 && l2 * c.rtot_over_rmin < F(0.25);
+        F cv = c.conv_l2;
+        if (c.mu_c > F(0)) {
+            // (n3_mu_tol: the child's own coordinates are the shared point's divided by z.w -- H scales with its square, u with its inverse)
+            const F ml = sv_mu_limit<ML, F, NS>(c, H11 * zw * zw, H22 * zw * zw, det * (zw * zw) * (zw * zw), s1, s2, u1 * sc, u2 * sc);
+            cv = sv_min(cv, ml);
+            SV_WIT(o.wmlim = ml;)
+        }
+        conv = l2 < cv && l2 * c.rtot_over_rmin < F(0.25);
         const bool beyond = sv_beyond<ML, F, NS>(c, val2, l2, sv_sqrt(l2), la);
         done = good && beyond && (!c.no_dismiss || conv);         // the bound (search) / converged and valued beyond the window (full solve)
     }
@@ -838,6 +876,7 @@ __device__ __forceinline__ void sv_child_eval(const SvCtx<ML, F, NS> &c, int lo,
     o.s2 = s2;
 #ifdef SV_WITNESS
     o.wdone = done;
+    if (!(c.mu_c > F(0)) || lean) o.wmlim = F(0);
     o.wconv = conv;
     o.wl2 = l2;
     o.wval2 = val2;
@@ -896,7 +935,7 @@ __device__ __forceinline__ void sv_children(SvCtx<ML, F, NS> &c, int total) {
             }
 #ifdef SV_WITNESS
             if (o.wdone || o.surv)
-                sv_witness<ML, F, NS>(c, o.off, o.surv ? 5u : (o.wconv ? 1u : 3u), 1u, (float)o.wl2, o.wl2, o.wval2, o.ws1, o.ws2, o.c1, o.c2);
+                sv_witness<ML, F, NS>(c, o.off, o.surv ? 5u : (o.wconv ? 1u : 3u), 1u, (float)o.wl2, o.wl2, o.wval2, o.ws1, o.ws2, o.c1, o.c2, o.wmlim);
 #endif
             unsigned long long pm = ballot64(o.push);
             const unsigned long long sm = ballot64(o.surv);
@@ -922,8 +961,8 @@ __device__ __forceinline__ void sv_children(SvCtx<ML, F, NS> &c, int total) {
                     u1 = F(1.0 / 3.0) * sv_rcp(o.s1);
                     u2 = F(1.0 / 3.0) * sv_rcp(o.s2);
                 }
-                F val2 = F(0), l2 = F(0), la = F(0);
-                const int st = sv_step<ML, F, NS>(c, rw, o.s1, o.s2, u1, u2, val2, l2, la);
+                F val2 = F(0), l2 = F(0), la = F(0), mlim = F(0);
+                const int st = sv_step<ML, F, NS>(c, rw, o.s1, o.s2, u1, u2, val2, l2, la, mlim);
                 c.n_dit += (unsigned)__builtin_popcountll(pm);
                 if (push) {
                     evals++;
@@ -942,7 +981,7 @@ __device__ __forceinline__ void sv_children(SvCtx<ML, F, NS> &c, int total) {
                             SV_WIT(wst = 5u;)
                         }
                     }
-                    SV_WIT(if (fin) sv_witness<ML, F, NS>(c, o.off, wst, evals, o.qu1 == o.qu1 ? (float)o.wl2 : __builtin_nanf(""), l2, val2, o.s1, o.s2, u1, u2);)
+                    SV_WIT(if (fin) sv_witness<ML, F, NS>(c, o.off, wst, evals, o.qu1 == o.qu1 ? (float)o.wl2 : __builtin_nanf(""), l2, val2, o.s1, o.s2, u1, u2, mlim);)
                     if (surv) sv_survivor<ML, F, NS>(c, rw, o.off, u1, u2);
                     if (fin) push = false;
                     qu1 = u1;
@@ -1304,6 +1343,9 @@ __global__ __launch_bounds__(64 * SV_WAVES, sizeof(F) == 4 ? SV_OCC : SV_OCC64) 
     c.screen_margin = 2e-5 * Pg.Rtot + 1.0;            // f32 sums: |error| <= Rtot (|ln q| 2^-23 + 2^-22) stays far below this
     c.rtot_f = (F)Pg.Rtot;
     c.inv_Rtot = (F)(1.0 / Pg.Rtot);
+    c.inv_tau = (F)(1.0 / (double)Pg.tau);
+    c.mu_c = F(0);
+    c.A_mu_tol = Pg.mu_tol;
     c.conv_l2 = (F)Pg.conv_l2;
     c.fine_l2 = sizeof(F) == 8 ? (F)fmin(Pg.conv_l2, 1e-8) : c.conv_l2;
     c.no_dismiss = Pg.no_dismiss;
@@ -1452,6 +1494,7 @@ __global__ __launch_bounds__(64 * SV_WAVES, sizeof(F) == 4 ? SV_OCC : SV_OCC64) 
         c.S2p = (F)(S2p * inv_N);
         c.rtot_over_rmin = (F)(Pg.Rtot / Rmin);
         c.sqrt_ror = (F)sqrt(Pg.Rtot / Rmin);
+        c.mu_c = (Pg.mu_tol > 0.0 && c.no_dismiss) ? (F)(0.4976 * Pg.mu_tol * sqrt(Rmin) / Pg.Rtot) : F(0);
         wave_lds_sync();
         const unsigned it0 = c.n_dit, par0 = c.n_par;
         c.par = n3_unpack(n3_lane_state<NS>(st, D - 1));

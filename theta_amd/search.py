@@ -49,6 +49,13 @@ BNB_MIN_CANDIDATES = int(float(os.environ.get("THETA_BNB_MIN_CANDIDATES", 2 ** 4
 # once): a fraction of a second for BASELINE configs 3 and 4.  The row-tree walk (theta_bnb) is the fallback where that one gives up
 MIX_LEAF_REL = float(os.environ.get("THETA_MIX_LEAF_REL", 0))      # 0: from the data -- a fraction of the radius of the region of mixtures within the window, sqrt(2 window / sum r)
 USE_MIX = os.environ.get("THETA_USE_MIX", "1") != "0"
+MIX_DIVE = os.environ.get("THETA_MIX_DIVE", "1") != "0"        # the attainable NLL the search starts from: a beam search down the tree first (round 6)
+MIX_DIVE_LEAF = float(os.environ.get("THETA_MIX_DIVE_LEAF", 1e-3))   # ... down to boxes of this relative size (the best row of every interval at their centres is proposed)
+MIX_FIRST_BOXES = int(float(os.environ.get("THETA_MIX_FIRST_BOXES", 6e6)))   # boxes the first thresholded walk may test before the incumbent is improved instead
+MIX_FIRST_MS = float(os.environ.get("THETA_MIX_FIRST_MS", 400.0))           # ... or run for this long
+MIX_MAX_MS_SMALL = float(os.environ.get("THETA_MIX_MAX_MS_SMALL", 20000.0))   # (and the clock of a walkable space's last walk)
+MIX_WALKABLE = int(float(os.environ.get("THETA_MIX_WALKABLE", 2 ** 46)))     # spaces up to this size fall back to the walks when the mixture-space search meets a flat likelihood ...
+MIX_MAX_BOXES_SMALL = int(float(os.environ.get("THETA_MIX_MAX_BOXES_SMALL", 6e7)))   # ... i.e. more boxes than this within the threshold
 MIX_LINES = os.environ.get("THETA_MIX_LINES", "1") != "0"      # the rank-deficient matrices too: one more tree per line of the alphabet's grid (round 6)
 GET_VALUES_MAX = int(float(os.environ.get("THETA_GET_VALUES_MAX", 2 ** 32)))    # candidates a --GET_VALUES dump may hold (a line each)
 BNB_BEAM = int(os.environ.get("THETA_BNB_BEAM", 1024))           # nodes per level of the dive that finds the first attainable NLL
@@ -191,22 +198,37 @@ def collect_finalists(problem, ctx, r, rN, max_normal, begin, end, window=COLLEC
     return recs, res["stats"]
 
 
-def degenerate_records(problem, ctx, r, rN, max_normal, report=None):
+def degenerate_records(problem, ctx, r, rN, max_normal, report=None, recs=None, window=COLLECT_WINDOW):
     """
     n=3 rank-deficient candidates of the searched range (rows on one line; all-zero tumour columns among them), valued the way
     the reference values them (theta_solve_batch: hybrj on the singular / NaN system, M3's hybrd call, L3's sums -- a finite
-    number or NaN).  All of them are returned: the finite ones are ordinary entries of the replay whatever their value (the
-    reference may report one BELOW the candidate's true minimum), the NaN ones interact with the running minimum wherever
-    they stand.
+    number or NaN).  The finite ones are ordinary entries of the replay whatever their value (the reference may report one BELOW
+    the candidate's true minimum), the NaN ones interact with the running minimum wherever they stand.
+    Returned: every NaN one, and the finite ones within `window` of the smallest value known -- theirs and `recs`' --: what lies
+    beyond cannot enter the replay (replay_records cuts at the first gap above the minimum, which the window covers), and a space of
+    1e10 matrices holds millions of them (round 6: a Python record each was gigabytes of host memory).
     """
     ranks, Cs = problem.last_degenerate
     if not len(ranks):
         return []
-    ok, mu, nll, vals = ctx.solve_batch(3, problem.tau, r, rN, Cs, max_normal, want_vals=True)
-    out = [{"rank": ranks[i], "c": Cs[i], "mu": mu[i].copy(), "nll": float(nll[i]), "vals": vals[i].copy(), "kind": "degenerate"}
-           for i in range(len(ranks)) if ok[i]]
+    ok, mu, nll, _vals = ctx.solve_batch(3, problem.tau, r, rN, Cs, max_normal, want_vals=False)
+    ok = np.asarray(ok) > 0
+    nll = np.asarray(nll, np.float64)
+    finite = ok & (nll == nll)
+    known = [t["nll"] for t in (recs or []) if t["nll"] == t["nll"]]
+    if finite.any():
+        known.append(float(nll[finite].min()))
+    low = min(known, default=float("inf"))
+    keep = np.nonzero(ok & ((nll != nll) | (nll <= low + window)))[0]
+    out = []
+    if len(keep):
+        Ck = np.ascontiguousarray(np.asarray(Cs)[keep])
+        ok2, mu2, nll2, vals2 = ctx.solve_batch(3, problem.tau, r, rN, Ck, max_normal, want_vals=True)
+        out = [{"rank": ranks[int(i)], "c": Ck[j], "mu": mu2[j].copy(), "nll": float(nll2[j]), "vals": vals2[j].copy(), "kind": "degenerate"}
+               for j, i in enumerate(keep) if ok2[j]]
     if report is not None:
-        report.degenerate = len(out)
+        report.degenerate = int(ok.sum())
+        report.degenerate_kept = len(out)
     return out
 
 
@@ -415,6 +437,20 @@ HEURISTIC_BUDGET_S = float(os.environ.get("THETA_HEURISTIC_BUDGET_S", 10.0))    
 HEURISTIC_ROUNDS_LARGE = int(os.environ.get("THETA_HEURISTIC_ROUNDS_LARGE", 1))  # ... of a problem with more than 4096 (interval, row) pairs (the proposal passes of mix_records carry on from there)
 
 
+def canonical_columns(Ms):
+    """matrices (B, m, 2) with the tumour columns in the order the reference's symmetry rule wants (Enumerator.py:181-183, 199-202):
+    the first row with a != b has a < b -- the mirror image of a matrix is the same model with mu1 and mu2 exchanged"""
+    Ms = np.asarray(Ms).copy()
+    if Ms.ndim != 3 or len(Ms) == 0:
+        return Ms
+    ne = Ms[:, :, 0] != Ms[:, :, 1]
+    first = np.argmax(ne, axis=1)
+    idx = np.arange(len(Ms))
+    swap = ne.any(axis=1) & (Ms[idx, first, 0] > Ms[idx, first, 1])
+    Ms[swap] = Ms[swap][:, :, ::-1]
+    return Ms
+
+
 def heuristic_incumbent(ctx, m, tau, lower_bounds, upper_bounds, r, rN, max_normal, rounds=40, budget_s=None):
     """
     An NLL the reference really reports for SOME matrix of an n=3 space too large to walk -- the starting threshold of the branch
@@ -560,46 +596,109 @@ def mix_records(problem, ctx, r, rN, max_normal, bounds, report=None, exchange=N
     import time
     t0 = time.time()
     lb, ub = adjusted_bounds(bounds[0], bounds[1])
-    hv, hC = heuristic_incumbent(ctx, problem.m, problem.tau, bounds[0], bounds[1], r, rN, max_normal)
-    info = {"heuristic_nll": hv if hv < float("inf") else None, "heuristic_seconds": time.time() - t0}
-    if not hv < float("inf"):
-        raise _lib.ThetaError(_lib.ERR_CAPACITY, "mixture-space search: no attainable NLL to start from")
-    inc = hv
-    if exchange is not None:
-        inc = float(exchange(inc))
-    # coarse passes first: the matrices that fit the centres of the best boxes are valued, and the best of them lowers the threshold
-    # of the next pass -- an incumbent a few units above the minimum leaves a region of mixtures thousands of leaves wide
-    info["passes"] = []
+    info = {"passes": []}
     # leaves: boxes about as wide as the region of mixtures whose objective is within the window of a matrix's optimum (relative
     # radius sqrt(2 window / sum r): the tangent bound is then off by a fraction of the window, and few leaves list each matrix)
     leaf_final = MIX_LEAF_REL if MIX_LEAF_REL > 0 else min(5e-3, max(2e-5, 0.7 * float(np.sqrt(2.0 * max(window, 0.05) / max(float(np.sum(r)), 1.0)))))
     info["leaf_rel"] = leaf_final
-    for leaf in (3e-2, 1e-2, 3e-3, 1e-3, 5e-4):
-        if leaf <= 2.0 * leaf_final:
-            break
+
+    def value(props):
+        """the smallest NLL the reference reports for a proposal that is a matrix of the space (None: for none of them)"""
+        props = canonical_columns(props)
+        pk = np.asarray(props)[in_space_n3_batch(props, lb, ub, problem.tau)] if len(props) else []
+        if not len(pk):
+            return None, 0
+        okp, _mu, nllp, _v = ctx.solve_batch(3, problem.tau, r, rN, np.ascontiguousarray(np.asarray(pk, np.uint8)), max_normal, want_vals=False)
+        fin = [float(v) for v, o in zip(nllp, okp) if o and v == v]
+        return (min(fin) if fin else None), len(pk)
+
+    def share(x):
+        return float(exchange(x)) if exchange is not None else x
+
+    # 1. an attainable NLL.  A DIVE first (round 6): no threshold, every level of the tree keeps its few hundred boxes of smallest bound
+    # down to the leaf size -- a few thousand boxes, two host synchronisations --, and the matrices that fit the centres of its best
+    # leaves are valued by the reference's procedure.  (How good that value is decides what the search COSTS, never what it finds.)
+    inc = float("inf")
+    if MIX_DIVE:
+        td = time.time()
+        props, std = problem.mix_search(float("inf"), leaf_rel=max(leaf_final, MIX_DIVE_LEAF), cap=256, dive=True)
+        found, n_in = value(props)
+        info["dive"] = {"proposals": len(props), "in_space": n_in, "best": found, "boxes": std["boxes_tested"], "ms": std["wall_ms"],
+                        "seconds": time.time() - td}
+        if found is not None:
+            inc = found
+    inc = share(inc)
+    heuristic_done = False
+
+    def heuristic():
+        th = time.time()
+        hv, _hC = heuristic_incumbent(ctx, problem.m, problem.tau, bounds[0], bounds[1], r, rN, max_normal)
+        info["heuristic_nll"] = hv if hv < float("inf") else None
+        info["heuristic_seconds"] = time.time() - th
+        return hv
+
+    if not inc < float("inf"):
+        # (the dive found no matrix of the space: the grid of mixtures of round 5)
+        inc = share(min(inc, heuristic()))
+        heuristic_done = True
+        if not inc < float("inf"):
+            raise _lib.ThetaError(_lib.ERR_CAPACITY, "mixture-space search: no attainable NLL to start from")
+
+    def final(thr, guard, guard_ms):
+        # the whole alphabet's tree AND one tree per line of the alphabet's grid (the rank-deficient matrices, which the reference may
+        # report at a mixture with negative entries -- below their own minimum over mu >= 0), in one walk
+        problem.set_option("mix_max_boxes", guard)
+        problem.set_option("mix_max_ms", guard_ms)
         try:
-            props, stp = problem.mix_search(inc + window + 4 * TIE_MARGIN, leaf_rel=leaf, cap=256, propose=True)
-        except _lib.ThetaError as e:
-            if e.code != _lib.ERR_CAPACITY:
-                raise
-            info["passes"].append({"leaf": leaf, "gave_up": True})
-            continue
-        pk = list(np.asarray(props)[in_space_n3_batch(props, lb, ub, problem.tau)]) if len(props) else []
-        found = None
-        if pk:
-            okp, _mu, nllp, _v = ctx.solve_batch(3, problem.tau, r, rN, np.ascontiguousarray(np.array(pk, np.uint8)), max_normal, want_vals=False)
-            fin = [float(v) for v, o in zip(nllp, okp) if o and v == v]
-            if fin:
-                found = min(fin)
-                inc = min(inc, found)
-        info["passes"].append({"leaf": leaf, "leaves": stp["leaves"], "proposals": len(props), "in_space": len(pk), "best": found,
-                               "min_bound": stp["min_bound"], "ms": stp["wall_ms"]})
-    if exchange is not None:
-        inc = float(exchange(inc))
+            return problem.mix_search(thr, leaf_rel=leaf_final, cap=1 << 18, lines=MIX_LINES)
+        finally:
+            problem.set_option("mix_max_boxes", 0)
+            problem.set_option("mix_max_ms", 0)
+
+    # 2. the search against that NLL + window.  With a good value it is a fraction of a second; should the value be poor (the dive
+    # went down the wrong basin) the walk is stopped after MIX_FIRST_BOXES boxes and the value improved first: coarse passes whose
+    # best boxes propose matrices, each lowering the threshold of the next -- round 5's ladder.
+    mats = st = None
     thr = inc + window + 4 * TIE_MARGIN
-    # the final pass: the whole alphabet's tree AND one tree per line of the alphabet's grid (the rank-deficient matrices, which the
-    # reference may report at a mixture with negative entries -- below their own minimum over mu >= 0), in one walk
-    mats, st = problem.mix_search(thr, leaf_rel=leaf_final, cap=1 << 18, lines=MIX_LINES)
+    exceeded = False
+    try:
+        mats, st = final(thr, MIX_FIRST_BOXES, MIX_FIRST_MS)
+    except _lib.ThetaError as e:
+        if e.code != _lib.ERR_CAPACITY:
+            raise
+        exceeded = True
+        info["first_walk"] = {"gave_up": str(e)[:160]}
+    if share(-1.0 if exceeded else 0.0) < 0.0:
+        mats = st = None
+        if not heuristic_done:
+            inc = min(inc, heuristic())
+        inc = share(inc)
+        walkable = problem.count <= MIX_WALKABLE
+        # (a space the linear walk can finish is not worth more of the clock than the walk itself would take: 2e10 matrices a second;
+        # a likelihood that flat -- a few reads per interval -- is the walk's.  A space no walk finishes is searched to the end.)
+        budget_ms = min(MIX_MAX_MS_SMALL, max(300.0, 1e3 * problem.count / 2e10)) if walkable else 0
+        for leaf in (3e-2, 1e-2, 3e-3, 1e-3, 5e-4):
+            if leaf <= 2.0 * leaf_final:
+                break
+            found = None
+            try:
+                problem.set_option("mix_max_ms", budget_ms)
+                try:
+                    props, stp = problem.mix_search(inc + window + 4 * TIE_MARGIN, leaf_rel=leaf, cap=256, propose=True)
+                finally:
+                    problem.set_option("mix_max_ms", 0)
+                found, n_in = value(props)
+                if found is not None:
+                    inc = min(inc, found)
+                info["passes"].append({"leaf": leaf, "leaves": stp["leaves"], "proposals": len(props), "in_space": n_in, "best": found,
+                                       "min_bound": stp["min_bound"], "ms": stp["wall_ms"]})
+            except _lib.ThetaError as e:
+                if e.code != _lib.ERR_CAPACITY:
+                    raise
+                info["passes"].append({"leaf": leaf, "gave_up": True})
+            inc = share(inc)
+        thr = inc + window + 4 * TIE_MARGIN
+        mats, st = final(thr, MIX_MAX_BOXES_SMALL if walkable else 0, budget_ms)
     if MIX_LINES:
         # ... and the matrices of one repeated row (rank 1: the same value at every mixture), which no tree bounds
         const = problem.constant_matrices()
@@ -637,6 +736,27 @@ def mix_records(problem, ctx, r, rN, max_normal, bounds, report=None, exchange=N
         report.degenerate = n_def
     stats = {"evaluated": 0, "kernel_ms": st["kernel_ms"], "boxes_tested": st["boxes_tested"]}
     return recs, stats
+
+
+def merge_mix_records(recs):
+    """The records of a SHARDED mixture-space search after the exchange: a matrix within reach of boxes of two ranks was listed
+    (and valued alike) by both -- once each; and the reference's enumeration order (RunTHetA.py:191-208 walks it) is the
+    lexicographic order of the rows, a row by (b, a), which the replay needs as `rank`."""
+    if not recs:
+        return recs
+    keys = [tuple((int(x[1]) << 4) | int(x[0]) for x in np.asarray(t["c"]).reshape(-1, 2)) for t in recs]
+    order = sorted(range(len(recs)), key=lambda i: keys[i])
+    out = []
+    for i in order:
+        if out and keys[i] == out[-1][0]:
+            continue
+        out.append((keys[i], recs[i]))
+    merged = []
+    for pos, (_k, t) in enumerate(out):
+        t = dict(t)
+        t["rank"] = pos
+        merged.append(t)
+    return merged
 
 
 def _in_enumeration_order(mats):
@@ -775,17 +895,28 @@ def _search_local(n, m, tau, lower_bounds, upper_bounds, r, rN, max_normal, shar
     # (what decides is the size of a rank's share: a shard of a few million ranks of a huge space is walked like any range)
     # (decided from a quantity every rank computes alike -- the shares differ by one across ranks, and a rank on the other side of the
     # line would pair its collectives with the wrong ones of its peers: round-5 advice)
-    big = n == 3 and getattr(problem, "_h", None) is not None and problem.count // G >= BNB_MIN_CANDIDATES
+    big = n == 3 and (getattr(problem, "_h", None) is not None or getattr(problem, "standin_mix", False)) and problem.count // G >= BNB_MIN_CANDIDATES
     use_bnb = big and problem.count < 2 ** 128 - 1 and m >= 8
     my_ranges = None
     if big and USE_MIX:
-        # branch and bound over the mixture space: the whole space at once, on every rank alike (a fraction of a second); rank 0
-        # alone contributes the records to the exchange of a sharded run
+        # branch and bound over the mixture space: the whole space at once.  Several ranks (round 6): the boxes a few cuts below the
+        # roots are dealt out by their path (options mix_shard_*: csrc/bnb.hip), every rank walks and lists its own, the attainable
+        # NLL is agreed on by all-reduce after every step that can lower it, and the records meet in the exchange -- north_star's
+        # sharding, G times the capacity for a flat likelihood (round 5 ran the whole search on every rank and used rank 0's records)
         try:
+            if G > 1:
+                problem.set_option("mix_shard_world", G)
+                problem.set_option("mix_shard_rank", g)
             recs, stats = mix_records(problem, ctx, r, rN, max_normal, (lower_bounds, upper_bounds), report=report, exchange=hint_exchange)
             if report is not None:
                 report.nan_sweep = False
-            return problem, ctx, (recs if g == 0 else []), stats
+                report.mix["shard"] = [g, G]
+            if G > 1:
+                # (positions in this rank's own list mean nothing to the others: unique keys for the exchange, the enumeration order
+                # is restored from the matrices afterwards -- merge_mix_records)
+                for t in recs:
+                    t["rank"] = t["rank"] * G + g
+            return problem, ctx, recs, stats
         except _lib.ThetaError as e:
             if e.code != _lib.ERR_CAPACITY:
                 raise
@@ -824,7 +955,7 @@ def _search_local(n, m, tau, lower_bounds, upper_bounds, r, rN, max_normal, shar
             listed = set(problem.last_degenerate[0])
             if listed:
                 rc = [t for t in rc if t["rank"] not in listed]
-            rc = rc + degenerate_records(problem, ctx, r, rN, max_normal, report=report)
+            rc = rc + degenerate_records(problem, ctx, r, rN, max_normal, report=report, recs=rc)
         return rc, st
     recs, stats = gather(begin, end)
     if n == 3 and not sweep and G == 1 and NAN_SWEEP_MAX > 0 and not use_bnb:
@@ -1122,6 +1253,8 @@ def do_optimization_distributed(n, m, k, tau, lower_bounds, upper_bounds, r, rN,
     if G > 1:
         rep.window = float(comm.allreduce_min([rep.window])[0])
     merged, gmin = comm.exchange_finalists(n, m, recs, rep.window)
+    if rep.mix is not None and "gave_up" not in rep.mix:
+        merged = merge_mix_records(merged)
     q1 = _q1_record(ctx, n, m, tau, r, rN, max_normal) if n == 3 else None
     best = replay_ties(merged, n, tau, sorted_index, first_duplicate=(n == 2), report=rep, q1_first=q1)
     rep.stats = stats

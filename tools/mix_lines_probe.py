@@ -33,12 +33,12 @@ def small(ctx, m, K, seed):
     walk, _st = S.collect_finalists(p, ctx, r, rN, 1.0, 0, p.count)
     walk = walk + S.fallback_records(p, ctx, r, rN, 1.0, walk)
     listed = set(p.last_degenerate[0])
-    walk = [t for t in walk if t["rank"] not in listed] + S.degenerate_records(p, ctx, r, rN, 1.0)
+    walk = [t for t in walk if t["rank"] not in listed] + S.degenerate_records(p, ctx, r, rN, 1.0, recs=walk)
     t2 = time.time()
     fin = lambda rc: [t for t in rc if t["nll"] == t["nll"]]
     want, got = S.replay_records(fin(walk), False), S.replay_records(fin(recs), False)
     why = campaign.compare_best(plain(got), plain(want), tol=1e-9)
-    ndef = int(rank_deficient(np.array([t["c"] for t in walk])).sum())
+    ndef = len(p.last_degenerate[0])
     k = rep.mix
     print("m=%d K=%d seed=%d: %.3g matrices (%d rank deficient), mix %.3f s (walk %.2f s): %s | boxes %d, lines %d, leaves %d (%d of lines), listed %d, "
           "records %d (%d rank deficient), syncs %s, bound %.3f thr %.3f min %.3f" %
@@ -55,9 +55,9 @@ def config(ctx, name, m, K, seed):
         best = S.do_optimization_single(3, m, K, 2, [0] * m, [K] * m, r, rN, 1.0, order, False, False)
         dt = time.time() - t0
         k = S.last_report.mix
-        print("%s: %.3f s end to end; heuristic %.3f s; passes %s; final: boxes %d leaves %d (%d of %d lines) listed %d records %d kernel %.1f ms search %.1f ms syncs %s; "
+        print("%s: %.3f s end to end; dive %s; heuristic %s s; passes %s; final: boxes %d leaves %d (%d of %d lines) listed %d records %d kernel %.1f ms search %.1f ms syncs %s; "
               "best %.6f; rank-deficient bound %.3f (threshold %.3f)" %
-              (name, dt, k["heuristic_seconds"], [(q.get("leaf"), round(q.get("ms", 0), 1)) for q in k["passes"]], k["boxes_tested"], k["leaves"], k["line_leaves"], k["lines"],
+              (name, dt, k.get("dive"), k.get("heuristic_seconds"), [(q.get("leaf"), round(q.get("ms", 0), 1)) for q in k["passes"]], k["boxes_tested"], k["leaves"], k["line_leaves"], k["lines"],
                k["listed"], k["records"], k["kernel_ms"], k["search_ms"], k["syncs"], best[0][2], k["rank_deficient_bound"], k["threshold"]), flush=True)
 
 
