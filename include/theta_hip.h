@@ -197,10 +197,10 @@ int theta_search_degenerate(theta_problem *p, int cap, uint64_t *rank, uint8_t *
  *   "n3_mu_tol"      > 0 (with "n3_no_dismiss"): the tolerance as a CERTIFICATE ON MU.  An evaluation at u (decrement lambda, tangent Hessian H,
  *                    t = lambda / sqrt(Rmin) <= 0.1) counts as converged only if, besides "n3_conv_l2", the point one full Newton step further
  *                    is certified within this distance of the candidate's optimum in every component of mu: self-concordance bounds the
- *                    step's decrement and the drift of H, det H / trace H bounds H's smaller eigenvalue from below, and d mu / d u is
- *                    bounded by (1.5 + |k|) / U inside the simplex (tests/test_certified_tolerance_cpu.py restates the chain and checks it
- *                    on 3 000 random problems).  Points outside the simplex -- where the reference reports no mixture of the candidate's
- *                    own -- are left to "n3_conv_l2" alone.  0 (default): the decrement alone decides
+ *                    step's decrement and the drift of H, H's smaller eigenvalue turns the Hessian norm into a distance in u, and
+ *                    d mu / d u is bounded by (1.5 + max(1, |mu1| + |mu2|) |k|) / U (tests/test_certified_tolerance_cpu.py restates the chain and
+ *                    checks it on 3 000 random problems; a 10 % margin on top).  Points away from the simplex (a nu_j < -0.05) -- where the
+ *                    reference reports no mixture of the candidate's own -- are left to "n3_conv_l2" alone.  0 (default): the decrement alone decides
  *   "n3_warm_blend"  weight of the previous optimum in a chunk's first warm start
  *   "n3_sieve"       1 (default): the two-kernel path (sieve + finish, n3_sieve.hip) where it applies; 0: the fused
  *                    kernel of n3.hip throughout (also used for theta_search_values and m < 8; m <= 64)

@@ -267,7 +267,7 @@ struct SvCtx {
     F leafRho[ML];                   // ... and their square roots
     F rtot_f, rtot_over_rmin, inv_Rtot, conv_l2, fine_l2;
     double A_mu_tol;                 // ... the tolerance itself (witness records)
-    F mu_c, inv_tau;                 // option n3_mu_tol: 0.4976 tol sqrt(Rmin) / Rtot (per prefix; 0: off), 1 / tau -- see sv_mu_limit
+    F mu_c, inv_tau;                 // option n3_mu_tol: 0.6398 tol sqrt(Rmin) / Rtot (per prefix; 0: off), 1 / tau -- see sv_mu_limit
     double K0, screen_margin, thr;   // thr = running minimum + window, loaded per task; screen_margin: see sv_beyond
     F Tcmp;                          // the threshold of sv_beyond's comparison, in F (per task)
     F sqrt_ror;                      // sqrt(Rtot / Rmin) (per prefix)
@@ -321,8 +321,8 @@ __device__ __forceinline__ void sv_witness(const SvCtx<ML, F, NS> &c, unsigned o
     w->l2_first = l2_first;
     w->evaluations = (unsigned short)evals;
     w->status = (unsigned short)status;
-    // the certificate's bound on the distance in mu (sv_mu_limit: converged means l2 <= limit, and the bound is tol x 0.7 l2 / limit)
-    w->mu_bound = (c.mu_c > F(0) && mu_lim > F(0)) ? (float)(0.7 * (double)c.A_mu_tol * (double)l2_last / (double)mu_lim) : 0.0f;
+    // the certificate's bound on the distance in mu (sv_mu_limit: converged means l2 <= limit, and the bound is tol x 0.9 l2 / limit)
+    w->mu_bound = (c.mu_c > F(0) && mu_lim > F(0)) ? (float)(0.9 * (double)c.A_mu_tol * (double)l2_last / (double)mu_lim) : 0.0f;
 }
 #define SV_WIT(...) __VA_ARGS__
 #else
@@ -333,22 +333,32 @@ __device__ __forceinline__ void sv_witness(const SvCtx<ML, F, NS> &c, unsigned o
 // ---- the tolerance ON MU as a certificate (option "n3_mu_tol"; round 6) ---------------------------------------------------------
 // An evaluation at u has the decrement lambda (l2 = lambda^2 / Rtot) and the tangent Hessian H.  With t = lambda / sqrt(Rmin) <= 0.1
 // (f / Rmin is self-concordant) one full Newton step ends at lambda+^2 <= lambda^4 / (Rmin (1 - t)^4); the minimiser u* then lies within
-// lambda+ / (1 - t+) of the new point in the norm of H(u+) >= (1 - t)^2 H(u), whose smaller eigenvalue is at least det H / trace H:
-//      |u+ - u*|_2 <= l2 Rtot / (0.718 sqrt(Rmin det / trace)).
+// lambda+ / (1 - t+) of the new point in the norm of H(u+) >= (1 - t)^2 H(u), whose smaller eigenvalue is sigma = 2 det / (tr + sqrt(tr^2 - 4 det)):
+//      |u+ - u*|_2 <= l2 Rtot / (0.718 sqrt(Rmin sigma)).
 // nu -> mu is M3's closed form (Optimizer.py:318-330): mu_j = u_j / U, U = u0 + u1 + u2, u0 = (1 - s1 u1 - s2 u2) / tau, so
-// d mu_j = (du_j - mu_j k.du) / U with k = (1 - s1 / tau, 1 - s2 / tau), and inside the simplex |d mu|_inf <= |du|_2 (1.5 + |k|_2) / U.
+// d mu_j = (du_j - mu_j k.du) / U with k = (1 - s1 / tau, 1 - s2 / tau), and |d mu|_inf <= |du|_2 (1.5 + max(1, |mu1| + |mu2|) |k|_2) / U.
 // Hence the step from this evaluation ends within `tol` of the optimum in every component of mu if
-//      l2 <= 0.4976 tol sqrt(Rmin) / Rtot x sqrt(det / trace) U / (1.5 + |k|)            (0.7 x 0.718 / 1.01: a 30 % margin)
-// -- the returned limit (c.mu_c holds the first factor).  Outside the simplex (a nu_j < 0: the reference reports no mixture of the
-// candidate's own there) there is no limit: +inf.  tests/test_certified_tolerance_cpu.py checks the chain on random problems.
+//      l2 <= 0.6398 tol sqrt(Rmin) / Rtot x sqrt(sigma) U / (1.5 + max(1, M) |k|)        (0.9 x 0.718 / 1.01: a 10 % margin)
+// -- the returned limit (c.mu_c holds the first factor).  Away from the simplex (a nu_j < -0.05, or U <= 0: the reference accepts
+// no nu out of [0, 1], Optimizer.py:150-160, so it reports no mixture of the candidate's own there) there is no limit: +inf.
+// tests/test_certified_tolerance_cpu.py checks the chain on random problems.
+// (Single precision throughout: the limit carries a 10 % margin, and the chain's only cancellation -- tr^2 - 4 det -- is taken in the
+// stable form.  A dozen vector instructions per evaluation, one reciprocal.)
 template <int ML, class F, int NS>
 __device__ __forceinline__ F sv_mu_limit(const SvCtx<ML, F, NS> &c, F H11, F H22, F det, F s1, F s2, F u1, F u2) {
-    const F n1 = s1 * u1, n2 = s2 * u2, n0 = F(1) - n1 - n2;
-    const F k1 = sv_fma(-s1, c.inv_tau, F(1)), k2 = sv_fma(-s2, c.inv_tau, F(1));
-    const F U = sv_fma(n0, c.inv_tau, u1 + u2);
-    const F sig = det * sv_rcp(H11 + H22);
-    const F lim = c.mu_c * sv_sqrt(sig) * U * sv_rcp(F(1.5) + sv_sqrt(sv_fma(k1, k1, k2 * k2)));
-    return (n0 >= F(0) && n1 >= F(0) && n2 >= F(0)) ? lim : F(__builtin_inff());
+    const float fs1 = (float)s1, fs2 = (float)s2, fu1 = (float)u1, fu2 = (float)u2, it = (float)c.inv_tau;
+    const float n1 = fs1 * fu1, n2 = fs2 * fu2, n0 = 1.0f - n1 - n2;
+    const float k1 = __builtin_fmaf(-fs1, it, 1.0f), k2 = __builtin_fmaf(-fs2, it, 1.0f);
+    const float U = __builtin_fmaf(n0, it, fu1 + fu2);
+    // (the Hessian's entries are sums of at most Rtot K^2: tr^2 and det stay far inside single precision's range)
+    const float tr = (float)(H11 + H22), dn = (float)det * __builtin_amdgcn_rcpf(tr * tr);           // det / tr^2 in (0, 1/4]
+    const float disc = __builtin_amdgcn_sqrtf(fmaxf(__builtin_fmaf(-4.0f, dn, 1.0f), 0.0f));
+    const float sig = tr * (dn + dn) / (1.0f + disc);                                               // 2 det / (tr + sqrt(tr^2 - 4 det))
+    const float au = fabsf(fu1) + fabsf(fu2);
+    const float kn = __builtin_amdgcn_sqrtf(__builtin_fmaf(k1, k1, k2 * k2));
+    const float den = __builtin_fmaf(fmaxf(U, au), kn, 1.5f * U);                                   // U (1.5 + max(1, M) |k|)
+    const float lim = (float)c.mu_c * __builtin_amdgcn_sqrtf(sig) * U * U * __builtin_amdgcn_rcpf(den);
+    return (n0 >= -0.05f && n1 >= -0.05f && n2 >= -0.05f && U > 0.0f) ? (F)lim : F(__builtin_inff());
 }
 
 // One evaluation of value, gradient and Hessian at (u1, u2) over the group tile and the record's rows, two terms at a time
@@ -1494,7 +1504,7 @@ __global__ __launch_bounds__(64 * SV_WAVES, sizeof(F) == 4 ? SV_OCC : SV_OCC64) 
         c.S2p = (F)(S2p * inv_N);
         c.rtot_over_rmin = (F)(Pg.Rtot / Rmin);
         c.sqrt_ror = (F)sqrt(Pg.Rtot / Rmin);
-        c.mu_c = (Pg.mu_tol > 0.0 && c.no_dismiss) ? (F)(0.4976 * Pg.mu_tol * sqrt(Rmin) / Pg.Rtot) : F(0);
+        c.mu_c = (Pg.mu_tol > 0.0 && c.no_dismiss) ? (F)(0.6398 * Pg.mu_tol * sqrt(Rmin) / Pg.Rtot) : F(0);
         wave_lds_sync();
         const unsigned it0 = c.n_dit, par0 = c.n_par;
         c.par = n3_unpack(n3_lane_state<NS>(st, D - 1));
