@@ -675,7 +675,12 @@ def main():
     dt = time.time() - t0
     set_opts(head_opts, False)
 
-    mine = np.array([float(leg.tot["evaluated"]), dt, float(getattr(ctx, "device", -1))], dtype=np.float64)
+    # (the device a rank runs on comes from LOCAL_RANK -- on a stand-in context, which has none, the one it WOULD select is reported;
+    # the ranks' searched ranges as fractions of the space: double precision separates 1e-16 of it, the shards are 1/8 each)
+    dev_of_rank = float(getattr(ctx, "device", (local % ndev if ndev else local)))
+    lo_frac, hi_frac = float(begins[0]) / float(total), float(begins[-1] + args.batch) / float(total)
+    mine = np.array([float(leg.tot["evaluated"]), dt, dev_of_rank, lo_frac, hi_frac, float(shard0) / float(total), float(shard1) / float(total)],
+                    dtype=np.float64)
     allv = comm.allgather(mine) if comm is not None else mine[None, :]
     if rank == 0:
         ev_all = allv[:, 0].sum()
@@ -719,6 +724,9 @@ def main():
         out["rccl_version"] = info["rccl_version"]
         out["rank_devices"] = devices
         out["candidates_per_rank"] = [float(v) for v in allv[:, 0]]
+        # what each rank searched, as fractions of the rank space: [first rank searched, last rank searched + 1) inside its shard
+        # [shard begin, shard end) -- disjoint by construction (shard g = [N g / G, N (g + 1) / G)); a reader can check it on the line
+        out["rank_ranges"] = [{"searched": [float(a), float(b)], "shard": [float(c), float(d)]} for a, b, c, d in allv[:, 3:7]]
         if comm is not None:
             out["comm"] = info
         if world == 1 and not args.no_legs:

@@ -488,6 +488,16 @@ def test_bench_with_eight_ranks_over_the_host_transport():
     assert line["n_gpus"] == 8 and line["steps"] == 2 and line["scaling"] == "weak"
     assert line["transport"] == "host" and line["rccl_version"] == 0 and len(line["rank_devices"]) == 8
     assert line["candidates_per_rank"] == [24.0] * 8                        # 2 timed steps x 12 candidates on every rank
+    # round 6 (verdict, Next 9): rank g runs on device LOCAL_RANK = g, searches inside its own shard, and no two shards overlap
+    assert line["rank_devices"] == list(range(8))
+    rr = line["rank_ranges"]
+    assert len(rr) == 8
+    for g in range(8):
+        a, b = rr[g]["searched"]
+        c, d = rr[g]["shard"]
+        assert abs(c - g / 8) < 1e-3 and abs(d - (g + 1) / 8) < 1e-3 and c <= a < b <= d, (g, rr[g])
+        if g:
+            assert rr[g - 1]["shard"][1] <= c + 1e-12 and rr[g - 1]["searched"][1] <= a, (g, rr[g - 1], rr[g])
     assert abs(line["value"] * line["ms_per_step"] * 1e-3 * 2 - 8 * 24) < 1e-6 * 8 * 24      # value = all ranks' candidates / the slowest rank's time
     assert line["comm"]["world"] == 8 and line["comm"]["collectives"] >= 4
     # the default transport (RCCL) cannot be set up here (no GPU, no context): the run must end non-zero, not downgrade
@@ -505,3 +515,30 @@ def test_bench_with_eight_ranks_over_the_host_transport():
     assert all(p.returncode != 0 for p in procs), [o[1][-300:] for o in outs]
     assert all("not falling back" in o[1] for o in outs), [o[1][-300:] for o in outs]
     assert all(o[0].strip() == "" for o in outs)                              # and no JSON line
+
+
+def test_launch_node_sets_what_the_drivers_launcher_sets(tmp_path):
+    """tools/launch_node.sh (one process per GPU without torchrun) against `python -m torch.distributed.run --nnodes=1
+    --nproc-per-node N --master-addr 127.0.0.1 --master-port P` -- the command the driver runs: every variable bench.py reads
+    (RANK, LOCAL_RANK, WORLD_SIZE, MASTER_ADDR, MASTER_PORT) has the same value rank by rank under both."""
+    import json
+    import subprocess
+    import sys as _sys
+    script = tmp_path / "print_env.py"
+    script.write_text("import json, os, sys\n"
+                      "keys = ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')\n"
+                      "open(os.path.join(sys.argv[1], 'rank%s.json' % os.environ['RANK']), 'w').write(json.dumps({k: os.environ.get(k) for k in keys}))\n")
+    got = {}
+    for name, cmd in (("launch_node", ["bash", os.path.join(ROOT, "tools", "launch_node.sh"), "3", str(script)]),
+                      ("torchrun", [_sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3", "--master-addr", "127.0.0.1",
+                                    "--master-port", "%d", str(script)])):
+        out = tmp_path / name
+        out.mkdir()
+        port = _free_port()
+        cmd = [c % port if c == "%d" else c for c in cmd] + [str(out)]
+        env = dict(os.environ, MASTER_PORT=str(port), MASTER_ADDR="127.0.0.1")
+        res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+        assert res.returncode == 0, (name, res.stderr[-800:])
+        got[name] = {rk: json.loads((out / ("rank%d.json" % rk)).read_text()) for rk in range(3)}
+        for rk in range(3):
+            assert got[name][rk] == {"RANK": str(rk), "LOCAL_RANK": str(rk), "WORLD_SIZE": "3", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)}, (name, rk)

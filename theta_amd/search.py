@@ -54,6 +54,7 @@ MIX_DIVE_LEAF = float(os.environ.get("THETA_MIX_DIVE_LEAF", 1e-3))   # ... down 
 MIX_FIRST_BOXES = int(float(os.environ.get("THETA_MIX_FIRST_BOXES", 6e6)))   # boxes the first thresholded walk may test before the incumbent is improved instead
 MIX_FIRST_MS = float(os.environ.get("THETA_MIX_FIRST_MS", 400.0))           # ... or run for this long
 MIX_MAX_MS_SMALL = float(os.environ.get("THETA_MIX_MAX_MS_SMALL", 20000.0))   # (and the clock of a walkable space's last walk)
+MIX_MAX_MS_LARGE = float(os.environ.get("THETA_MIX_MAX_MS_LARGE", 0.0))     # the clock of a space NO walk finishes: 0 = none, it is searched to the end
 MIX_WALKABLE = int(float(os.environ.get("THETA_MIX_WALKABLE", 2 ** 46)))     # spaces up to this size fall back to the walks when the mixture-space search meets a flat likelihood ...
 MIX_MAX_BOXES_SMALL = int(float(os.environ.get("THETA_MIX_MAX_BOXES_SMALL", 6e7)))   # ... i.e. more boxes than this within the threshold
 MIX_LINES = os.environ.get("THETA_MIX_LINES", "1") != "0"      # the rank-deficient matrices too: one more tree per line of the alphabet's grid (round 6)
@@ -676,7 +677,7 @@ def mix_records(problem, ctx, r, rN, max_normal, bounds, report=None, exchange=N
         walkable = problem.count <= MIX_WALKABLE
         # (a space the linear walk can finish is not worth more of the clock than the walk itself would take: 2e10 matrices a second;
         # a likelihood that flat -- a few reads per interval -- is the walk's.  A space no walk finishes is searched to the end.)
-        budget_ms = min(MIX_MAX_MS_SMALL, max(300.0, 1e3 * problem.count / 2e10)) if walkable else 0
+        budget_ms = min(MIX_MAX_MS_SMALL, max(300.0, 1e3 * problem.count / 2e10)) if walkable else MIX_MAX_MS_LARGE
         for leaf in (3e-2, 1e-2, 3e-3, 1e-3, 5e-4):
             if leaf <= 2.0 * leaf_final:
                 break

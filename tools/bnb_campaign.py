@@ -51,18 +51,30 @@ def plain(best):
 
 
 def main():
-    want = int(sys.argv[1]) if len(sys.argv) > 1 else 40
-    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 70000
-    cap = float(sys.argv[3]) if len(sys.argv) > 3 else 3e8
+    # --never-give-up (round 6): every space is treated like one no walk finishes -- the mixture-space search goes on however flat the
+    # likelihood (a clock of 60 s per walk protects the box) -- so that the instances earlier rounds gave up on are compared as well
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    if "--never-give-up" in sys.argv:
+        S.MIX_WALKABLE = 0
+        S.MIX_MAX_MS_LARGE = 60000.0
+    want = int(args[0]) if len(args) > 0 else 40
+    seed = int(args[1]) if len(args) > 1 else 70000
+    cap = float(args[2]) if len(args) > 2 else 3e8
+    only = None
+    for a in sys.argv[1:]:
+        if a.startswith("--seeds="):                      # exactly these instances (e.g. the ones an earlier campaign gave up on: tools/bnb_gave_up_seeds.txt)
+            v = a.split("=", 1)[1]
+            only = [int(x) for x in (open(v).read() if os.path.exists(v) else v).replace("\n", "").split(",") if x]
+            want = len(only)
     ctx = theta_amd.default_context()
     done = same = gave_up = differ = 0
     tot = 0.0
     t_mix = t_ex = 0.0
     while done < want:
-        seed += 1
+        seed = only[done] if only is not None else seed + 1
         inst = instance(seed)
         p = theta_amd.Problem(ctx, 3, inst["m"], inst["tau"], inst["r"], inst["rN"], inst["lb"], inst["ub"], 1.0)
-        if not (1e5 <= p.count <= cap):
+        if only is None and not (1e5 <= p.count <= cap):
             p.close()
             continue
         done += 1
@@ -76,13 +88,20 @@ def main():
             p.close()
             continue
         t_mix += time.time() - t
+        if only is not None:
+            print("seed %d m=%d K=%d tau=%d depth %g: %.3g matrices: searched in %.2f s, %d records" % (seed, inst["m"], inst["K"], inst["tau"], inst["depth"], p.count, time.time() - t, len(recs)), flush=True)
         t = time.time()
         p.set_option("n3_nan_sweep", 0)
         ex, _st = S.collect_finalists(p, ctx, inst["r"], inst["rN"], 1.0, 0, p.count)
         ex = ex + S.fallback_records(p, ctx, inst["r"], inst["rN"], 1.0, ex)
+        # round 6: the COMPLETE lists -- the rank-deficient matrices, valued by the reference's procedure, on both sides (NaN outcomes
+        # apart: no bound reaches those)
+        listed = set(p.last_degenerate[0])
+        ex = [t for t in ex if t["rank"] not in listed] + S.degenerate_records(p, ctx, inst["r"], inst["rN"], 1.0, recs=ex)
         t_ex += time.time() - t
         p.close()
-        why = campaign.compare_best(plain(S.replay_records(full_rank(recs), False)), plain(S.replay_records(full_rank(ex), False)), tol=1e-9)
+        fin = lambda rc: [t for t in rc if t["nll"] == t["nll"]]
+        why = campaign.compare_best(plain(S.replay_records(fin(recs), False)), plain(S.replay_records(fin(ex), False)), tol=1e-9)
         if why:
             differ += 1
             print("seed %d m=%d K=%d tau=%d depth %g: %.3g matrices: DIFFERS: %s" % (seed, inst["m"], inst["K"], inst["tau"], inst["depth"], p.count, why), flush=True)
