@@ -216,6 +216,11 @@ struct SvLds {
     unsigned char ridx[SV_RIDX_W * SV_RIDX_W + 3];       // the central part of the ratio-rank table (|dx|, |dy| <= 7), see sv_child_dyn
     unsigned char rowtab[N3_MAX_Q + 3];
     unsigned short row16[N3_MAX_Q];                     // slot -> a | b << 8
+    // F = double (round 6): slot -> (a, b) as numbers.  A full evaluation took the leaf rows of its record as bytes -- a table look-up,
+    // two field extractions and two conversions per row, every evaluation (sv_child_rows + the decode in sv_step: 7 vector
+    // instructions per row, 42 of an evaluation's ~480); one 16-byte LDS read by slot replaces them.  (The float instantiation keeps
+    // the bytes: 512 B more would cost it its third block per CU.)
+    Sv2<F> rowF[sizeof(F) == 8 ? N3_MAX_Q : 1];
 };
 
 // inclusive scan over the wave with DPP row shifts / broadcasts (no LDS traffic)
@@ -330,6 +335,16 @@ __device__ __forceinline__ void sv_witness(const SvCtx<ML, F, NS> &c, unsigned o
 #endif
 
 
+// The leaf rows of a record as a full evaluation takes them.  F = float: two rows {a, b, a', b'} per dword, decoded term by term.
+// F = double: the slots themselves -- the path code (6 bits per row) and the last row's slot --, looked up in SvLds::rowF.
+template <int ML, class F> struct SvRows;
+template <int ML> struct SvRows<ML, float> {
+    unsigned rw[ML / 2];
+};
+template <int ML> struct SvRows<ML, double> {
+    unsigned code, slot;
+};
+
 // ---- the tolerance ON MU as a certificate (option "n3_mu_tol"; round 6) ---------------------------------------------------------
 // An evaluation at u has the decrement lambda (l2 = lambda^2 / Rtot) and the tangent Hessian H.  With t = lambda / sqrt(Rmin) <= 0.1
 // (f / Rmin is self-concordant) one full Newton step ends at lambda+^2 <= lambda^4 / (Rmin (1 - t)^4); the minimiser u* then lies within
@@ -367,7 +382,7 @@ __device__ __forceinline__ F sv_mu_limit(const SvCtx<ML, F, NS> &c, F H11, F H22
 // val2 = sum R log2 q and l2 = lambda^2 / Rtot at the OLD one), 1 = stepped and converged (l2 < conv), 2 = outside the domain
 // (u1, u2 halved towards 0), 3 = no usable step (ill-conditioned Hessian, NaN).
 template <int ML, class F, int NS>
-__device__ __forceinline__ int sv_step(const SvCtx<ML, F, NS> &c, const unsigned (&rw)[ML / 2], F s1, F s2, F &u1, F &u2, F &val2, F &l2, F &la, F &mlim) {
+__device__ __forceinline__ int sv_step(const SvCtx<ML, F, NS> &c, const SvRows<ML, F> &rows, F s1, F s2, F &u1, F &u2, F &val2, F &l2, F &la, F &mlim) {
     typedef typename SvVec<F>::v2 v2;
     v2 g1 = {F(0), F(0)}, g2 = g1, h11 = g1, h12 = g1, h22 = g1, lg = g1, lga = g1;
     const v2 vs1 = {s1, s1}, vs2 = {s2, s2}, vu1 = {u1, u1}, vu2 = {u2, u2}, one = {F(1), F(1)};
@@ -413,8 +428,14 @@ SV_UNROLL(SV_UNR)
 #pragma unroll
     for (int j = 0; j < ML / 2; j++) {
         const typename SvWt<F>::T rr = c.W->fRL[j];
-        const unsigned d = rw[j];      // bytes {a, b, a', b'}
-        body(v2{(F)(d & 0xffu), (F)((d >> 16) & 0xffu)}, v2{(F)((d >> 8) & 0xffu), (F)(d >> 24)}, v2{rr.x, rr.y}, sv_rho<F>(rr));
+        if constexpr (sizeof(F) == 8) {
+            const Sv2<F> ra = c.S->rowF[(rows.code >> (12 * j)) & 63u];
+            const Sv2<F> rb = c.S->rowF[j < ML / 2 - 1 ? (rows.code >> (12 * j + 6)) & 63u : rows.slot];
+            body(v2{ra.x, rb.x}, v2{ra.y, rb.y}, v2{rr.x, rr.y}, sv_rho<F>(rr));
+        } else {
+            const unsigned d = rows.rw[j];      // bytes {a, b, a', b'}
+            body(v2{(F)(d & 0xffu), (F)((d >> 16) & 0xffu)}, v2{(F)((d >> 8) & 0xffu), (F)(d >> 24)}, v2{rr.x, rr.y}, sv_rho<F>(rr));
+        }
     }
     val2 = lg.x + lg.y;
     if (!(sv_abs(val2) < F(__builtin_inff()))) {
@@ -484,15 +505,24 @@ __device__ __forceinline__ void sv_set_threshold(SvCtx<ML, F, NS> &c, double thr
 
 // column sums / N of a record: (s1, s2); false if a tumour column is all zero (degenerate: the reference's Chat is NaN)
 template <int ML, class F, int NS>
-__device__ __forceinline__ bool sv_sums(const SvCtx<ML, F, NS> &c, const unsigned (&rw)[ML / 2], F &s1, F &s2) {
+__device__ __forceinline__ bool sv_sums(const SvCtx<ML, F, NS> &c, const SvRows<ML, F> &rows, F &s1, F &s2) {
     F a = c.S1p, b = c.S2p;
 #pragma unroll
     for (int j = 0; j < ML / 2; j++) {
-        const unsigned d = rw[j];
-        a = sv_fma((F)(d & 0xffu), c.leafN[2 * j], a);
-        b = sv_fma((F)((d >> 8) & 0xffu), c.leafN[2 * j], b);
-        a = sv_fma((F)((d >> 16) & 0xffu), c.leafN[2 * j + 1], a);
-        b = sv_fma((F)(d >> 24), c.leafN[2 * j + 1], b);
+        if constexpr (sizeof(F) == 8) {
+            const Sv2<F> ra = c.S->rowF[(rows.code >> (12 * j)) & 63u];
+            const Sv2<F> rb = c.S->rowF[j < ML / 2 - 1 ? (rows.code >> (12 * j + 6)) & 63u : rows.slot];
+            a = sv_fma(ra.x, c.leafN[2 * j], a);
+            b = sv_fma(ra.y, c.leafN[2 * j], b);
+            a = sv_fma(rb.x, c.leafN[2 * j + 1], a);
+            b = sv_fma(rb.y, c.leafN[2 * j + 1], b);
+        } else {
+            const unsigned d = rows.rw[j];
+            a = sv_fma((F)(d & 0xffu), c.leafN[2 * j], a);
+            b = sv_fma((F)((d >> 8) & 0xffu), c.leafN[2 * j], b);
+            a = sv_fma((F)((d >> 16) & 0xffu), c.leafN[2 * j + 1], a);
+            b = sv_fma((F)(d >> 24), c.leafN[2 * j + 1], b);
+        }
     }
     s1 = a;
     s2 = b;
@@ -531,6 +561,27 @@ __device__ __forceinline__ void sv_child_rows(const SvCtx<ML, F, NS> &c, unsigne
     rw[ML / 2 - 1] |= (unsigned)c.S->row16[slot] << 16;
 }
 
+template <int ML, class F, int NS>
+__device__ __forceinline__ void sv_rows_load(const SvCtx<ML, F, NS> &c, unsigned code, unsigned slot, SvRows<ML, F> &rows) {
+    if constexpr (sizeof(F) == 8) {
+        rows.code = code;
+        rows.slot = slot;
+    } else {
+        sv_child_rows<ML, F, NS>(c, code, slot, rows.rw);
+    }
+}
+// ... and a contender's rows for the list (rare path)
+template <int ML, class F, int NS>
+__device__ __forceinline__ void sv_survivor_rows(const SvCtx<ML, F, NS> &c, const SvRows<ML, F> &rows, unsigned off, F u1, F u2) {
+    if constexpr (sizeof(F) == 8) {
+        unsigned rw[ML / 2];
+        sv_child_rows<ML, F, NS>(c, rows.code, rows.slot, rw);
+        sv_survivor<ML, F, NS>(c, rw, off, u1, u2);
+    } else {
+        sv_survivor<ML, F, NS>(c, rows.rw, off, u1, u2);
+    }
+}
+
 // Further Newton steps for the queued records: until dismissed, converged (a contender) or given up.  PERSISTENT LANES: a lane
 // whose record is finished takes the next queue entry at once (ballot + prefix count of the idle lanes), so the wave iterates
 // as long as there is work for most of its lanes -- round 2 took the queue 64 at a time in lock step, and with a third of the
@@ -554,9 +605,8 @@ __device__ __forceinline__ void sv_drain(SvCtx<ML, F, NS> &c) {
     int next = 0;                                   // (wave-uniform) queue entries handed out so far
     int left = 0;                                   // (wave-uniform) entries put back
     bool live = false;
-    unsigned rw[ML / 2];
-#pragma unroll
-    for (int j = 0; j < ML / 2; j++) rw[j] = 0u;
+    SvRows<ML, F> rows;
+    sv_rows_load<ML, F, NS>(c, 0u, 0u, rows);
     F u1 = F(0), u2 = F(0), s1 = F(1), s2 = F(1);
     unsigned qy = 0u, code = 0u;                    // the entry's words: last row's slot | offset in the task << 8 | evaluations so far << 24, path slots
     int iters = 0;                                  // evaluations of the record so far, the shared one included (kept across put-backs)
@@ -567,13 +617,13 @@ __device__ __forceinline__ void sv_drain(SvCtx<ML, F, NS> &c) {
             const int idx = next + mbcnt(idle);
             if (!live && idx < c.qcount) {
                 const uint2 qr = c.W->qRec[idx];
-                sv_child_rows<ML, F, NS>(c, qr.x, qr.y & 0xffu, rw);
+                sv_rows_load<ML, F, NS>(c, qr.x, qr.y & 0xffu, rows);
                 u1 = c.W->qU1[idx];
                 u2 = c.W->qU2[idx];
                 code = qr.x;
                 qy = qr.y & 0xffffffu;
                 SV_WIT(l0 = c.W->qL0[idx];)
-                sv_sums<ML, F, NS>(c, rw, s1, s2);
+                sv_sums<ML, F, NS>(c, rows, s1, s2);
                 if (!(u1 == u1)) {                    // (no usable first point: from the simplex centre)
                     u1 = F(1.0 / 3.0) * sv_rcp(s1);
                     u2 = F(1.0 / 3.0) * sv_rcp(s2);
@@ -608,7 +658,7 @@ __device__ __forceinline__ void sv_drain(SvCtx<ML, F, NS> &c) {
         bool fin = false, surv = false;
         if (live) {
             F val2 = F(0), l2 = F(0), la = F(0), mlim = F(0);
-            const int st = sv_step<ML, F, NS>(c, rw, s1, s2, u1, u2, val2, l2, la, mlim);
+            const int st = sv_step<ML, F, NS>(c, rows, s1, s2, u1, u2, val2, l2, la, mlim);
             iters++;
             SV_WIT(unsigned wst = 0u;)
             if (st == 3 || iters >= 40) {
@@ -630,7 +680,7 @@ __device__ __forceinline__ void sv_drain(SvCtx<ML, F, NS> &c) {
             }
             SV_WIT(if (fin) sv_witness<ML, F, NS>(c, qy >> 8, wst, (unsigned)iters, l0, l2, val2, s1, s2, u1, u2, mlim);)
         }
-        if (surv) sv_survivor<ML, F, NS>(c, rw, qy >> 8, iters >= 40 ? F(__builtin_nanf("")) : u1, u2);
+        if (surv) sv_survivor_rows<ML, F, NS>(c, rows, qy >> 8, iters >= 40 ? F(__builtin_nanf("")) : u1, u2);
         if (fin) {
             live = false;
         }
@@ -964,15 +1014,15 @@ __device__ __forceinline__ void sv_children(SvCtx<ML, F, NS> &c, int total) {
                 // has the child at hand, instead of through the queue (push, pop, decode, column sums, a wave-step that may run half
                 // empty): the queue is left with the ~10 % that need a third (and where most of the trip's lanes do -- SV_THIRD_MIN --
                 // that one is taken here as well).  Same arithmetic, same decisions as sv_drain.
-                unsigned rw[ML / 2];
-                sv_child_rows<ML, F, NS>(c, o.code, o.slot, rw);
+                SvRows<ML, F> rows;
+                sv_rows_load<ML, F, NS>(c, o.code, o.slot, rows);
                 F u1 = qu1, u2 = qu2;
                 if (!(u1 == u1)) {                      // (no usable shared point: from the simplex centre)
                     u1 = F(1.0 / 3.0) * sv_rcp(o.s1);
                     u2 = F(1.0 / 3.0) * sv_rcp(o.s2);
                 }
                 F val2 = F(0), l2 = F(0), la = F(0), mlim = F(0);
-                const int st = sv_step<ML, F, NS>(c, rw, o.s1, o.s2, u1, u2, val2, l2, la, mlim);
+                const int st = sv_step<ML, F, NS>(c, rows, o.s1, o.s2, u1, u2, val2, l2, la, mlim);
                 c.n_dit += (unsigned)__builtin_popcountll(pm);
                 if (push) {
                     evals++;
@@ -992,7 +1042,7 @@ __device__ __forceinline__ void sv_children(SvCtx<ML, F, NS> &c, int total) {
                         }
                     }
                     SV_WIT(if (fin) sv_witness<ML, F, NS>(c, o.off, wst, evals, o.qu1 == o.qu1 ? (float)o.wl2 : __builtin_nanf(""), l2, val2, o.s1, o.s2, u1, u2, mlim);)
-                    if (surv) sv_survivor<ML, F, NS>(c, rw, o.off, u1, u2);
+                    if (surv) sv_survivor_rows<ML, F, NS>(c, rows, o.off, u1, u2);
                     if (fin) push = false;
                     qu1 = u1;
                     qu2 = u2;
@@ -1307,6 +1357,7 @@ __global__ __launch_bounds__(64 * SV_WAVES, sizeof(F) == 4 ? SV_OCC : SV_OCC64) 
         const unsigned rw = Pg.rowtab[i];
         S.rowtab[i] = (unsigned char)rw;
         S.row16[i] = (unsigned short)((rw & 15u) | ((rw >> 4) << 8));
+        if constexpr (sizeof(F) == 8) S.rowF[i] = Sv2<F>{(F)(rw & 15u), (F)(rw >> 4)};
     }
     for (int i = threadIdx.x; i < ML * N3_MAX_Q; i += blockDim.x) (&S.smask[0][0])[i] = Pg.smask[(size_t)D * N3_MAX_Q + i];
     __syncthreads();
