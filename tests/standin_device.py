@@ -133,7 +133,7 @@ class StandinProblem(_lib.Problem):
 
     # ---- the mixture-space search (theta_mix_search), modelled on the enumerated space: what the HOST side of a sharded whole-space
     # search sees -- proposals, a superset of the matrices within a threshold dealt out over the ranks, the statistics it reports
-    standin_mix = True
+    standin_mix = False            # (a test that wants the mixture-space path over this stand-in sets it on its instance: search._search_local asks)
 
     def mix_search(self, threshold, leaf_rel=2e-4, cap=1 << 16, propose=False, lines=False, lines_only=False, dive=False):
         import zlib

@@ -254,6 +254,7 @@ def _mix_driver_worker(rank, world, port, inst, q):
 
         def make(c, *a, **k):
             made.append(sd.StandinProblem(c, *a, **k))
+            made[-1].standin_mix = True
             return made[-1]
         _lib.Problem = make
         comm = theta_amd.Comm(None, rank=rank, world=world, addr="127.0.0.1", port=port, transport="host")

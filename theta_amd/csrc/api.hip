@@ -188,7 +188,7 @@ struct theta_problem {
     std::vector<double> h_r, h_rN;                     // the counts as given (sorted order): the per-depth constants of theta_bnb
     DevBuf d_misc2;                                    // task specifications of a search over several ranges
     // the mixture-space search (theta_mix_search): its buffers, allocated at the first call and kept; the lines of the alphabet's grid
-    DevBuf d_mix_stack, d_mix_work, d_mix_leaves, d_mix_ctr, d_mix_mat, d_mix_lines, d_mix_slot;
+    DevBuf d_mix_stack, d_mix_work, d_mix_leaves, d_mix_ctr, d_mix_mat, d_mix_lines, d_mix_slot, d_mix_iv;
     std::vector<MixLine> mix_lines;
     unsigned mix_chunk = 0;
     unsigned long long mix_stack_cap = 0, mix_leaf_cap = 0;
@@ -1872,9 +1872,18 @@ static int mix_buffers(theta_problem *p, hipStream_t st) {
     if (const char *e = getenv("THETA_MIX_LEAVES")) p->mix_leaf_cap = std::max<unsigned long long>(4ull * p->mix_chunk, strtoull(e, nullptr, 10));
     unsigned char slot_of[256];
     mix_build_lines(p, p->mix_lines, slot_of);
+    std::vector<MixIv> iv((size_t)p->m);
+    for (int i = 0; i < p->m; i++) {
+        const double r = p->h_r[i], N = p->h_rN[i];
+        iv[i].N = N;
+        iv[i].r = r;
+        iv[i].ts = r / N;
+        iv[i].lnN = (double)logl((long double)N);
+        iv[i].phimin = r > 0.0 ? (double)((long double)r - (long double)r * logl((long double)r)) : 0.0;
+    }
     if ((rc = p->d_mix_stack.alloc(p->mix_stack_cap * sizeof(MixCell))) || (rc = p->d_mix_work.alloc(2ull * p->mix_chunk * sizeof(MixCell) + 2 * MIX_BEAM_LIMIT * sizeof(unsigned short))) ||
         (rc = p->d_mix_leaves.alloc(p->mix_leaf_cap * sizeof(MixCell))) || (rc = p->d_mix_ctr.alloc(MIX_NCTR * sizeof(unsigned long long))) ||
-        (rc = upload(p->d_mix_slot, slot_of, sizeof(slot_of), st)) ||
+        (rc = upload(p->d_mix_slot, slot_of, sizeof(slot_of), st)) || (rc = upload(p->d_mix_iv, iv.data(), iv.size() * sizeof(MixIv), st)) ||
         (rc = upload(p->d_mix_lines, p->mix_lines.data(), std::max<size_t>(1, p->mix_lines.size()) * sizeof(MixLine), st)))
         return rc;
     HIP_TRY(hipStreamSynchronize(st));
@@ -1930,6 +1939,7 @@ extern "C" int theta_mix_search(theta_problem *p, double threshold, double leaf_
     A.r = p->n3.r;
     A.rN = p->n3.rN;
     A.rowtab = p->n3.rowtab;
+    A.iv = (const MixIv *)p->d_mix_iv.p;
     A.slot_of = (const unsigned char *)p->d_mix_slot.p;
     A.lb = p->n3.lb;
     A.ub = p->n3.ub;

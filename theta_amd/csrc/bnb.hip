@@ -411,6 +411,7 @@ void bnb_launch_compact(const BnbNode *nodes, const unsigned char *paths, unsign
 // below, and a depth-first walk over the intervals with the budget `threshold` lists the few matrices that fit (mix_list_kernel).
 // The host values those with the reference's own procedure (theta_solve_batch) and replays them in enumeration order.
 // ====================================================================================================================================
+#define MIX_MAX_M 256
 #define MIX_MAX_Q 256      // rows of the alphabet here (a search over mixtures needs no 64-bit child masks)
 //
 // RANK-DEFICIENT MATRICES (round 6).  What the reference reports for a matrix is the objective at the mixture its solver stops at.
@@ -480,74 +481,129 @@ __device__ __forceinline__ void mix_stage_rows(const MixArgs &A, uchar2 *rows, u
     for (int s = threadIdx.x; s < 256; s += blockDim.x) slot_of[s] = A.slot_of[s];
 }
 
-__device__ double mix_cell_bound(const MixArgs &A, const MixCell &c, const uchar2 *rows, const unsigned char *slot_of, const double2 *ltab, int lane, double &centre) {
+// What a box needs of a ROW, whatever the interval (round 6): c.v at the centre and at the two extreme corners, their LOGARITHMS --
+// ln(rN_i c.v) = ln rN_i + ln c.v: the logarithm of round 5's kernel, one per (interval, row, box), is one per (row, box) plus a
+// constant of the interval --, the reciprocal at the centre and the eight corner offsets of the tangent.  Lane s of the wave fills the
+// entry of row s0 + s; then every lane walks the table for its intervals (all lanes read the same entry: LDS broadcasts).
+#define MIX_CHUNK 64
+struct MixRowTab {
+    double tc[MIX_CHUNK], ltc[MIX_CHUNK], itc[MIX_CHUNK];
+    double tlo[MIX_CHUNK], ltlo[MIX_CHUNK], thi[MIX_CHUNK], lthi[MIX_CHUNK];
+    double E[8][MIX_CHUNK];                 // sum_j (+-) c_j h_j, the corner's offset from the centre in units of c.v
+    unsigned char a[MIX_CHUNK], b[MIX_CHUNK], ok[MIX_CHUNK];
+};
+
+__device__ double mix_cell_bound(const MixArgs &A, const MixCell &c, const uchar2 *rows, const unsigned char *slot_of, const double2 *ltab, int lane, double &centre,
+                                 MixRowTab &T) {
     const MixRows R(A, c.line, rows, slot_of);
     double vc[3], h[3];
     for (int j = 0; j < 3; j++) {
         vc[j] = 0.5 * (c.lo[j] + c.hi[j]);
         h[j] = 0.5 * (c.hi[j] - c.lo[j]);
     }
-    double lb1 = 0.0, lbv[8], cs = 0.0;
+    // per interval of this lane (at most MIX_IVL: m <= 256), across the chunks of rows
+    constexpr int MIX_IVL = (MIX_MAX_M + WAVE - 1) / WAVE;
+    const int nmine = (A.m - lane + WAVE - 1) / WAVE;          // intervals lane, lane + 64, ...
+    double lb1 = 0.0, cs = 0.0, lbv[8];
     for (int k = 0; k < 8; k++) lbv[k] = 0.0;
-    for (int i = lane; i < A.m; i += WAVE) {
-        double cbest = __builtin_inf();              // the interval's best term AT the centre: the relaxed objective there (what a dive ranks by)
-        const double r = A.r[i], N = A.rN[i], ts = r / N;
-        const int l = A.lb[i], u = A.ub[i];
-        // (1): phi_i is convex with its minimum at ts, so over the rows the smallest clamped value is phi(ts) if some row's interval
-        // [tlo, thi] holds ts, else the better of phi(largest thi below ts) and phi(smallest tlo above it): two logarithms per
-        // interval, not one per row (round 5's first version: m x rows library logarithms were two thirds of the kernel)
+    // (a box of m <= 64 intervals: one interval per lane, its state in registers across the chunks; more: the chunks are walked per
+    // interval -- the table of a chunk is rebuilt for each group of 64 intervals only when the alphabet has more than 64 rows)
+    for (int g = 0; g < MIX_IVL; g++) {
+        const int i = lane + WAVE * g;
+        if (g >= (A.m + WAVE - 1) / WAVE) break;            // (wave-uniform)
+        const bool mine = i < A.m;
+        const MixIv iv = mine ? A.iv[i] : MixIv{1.0, 0.0, 0.0, 0.0, 0.0};
+        const int l = mine ? A.lb[i] : 0, u = mine ? A.ub[i] : 0;
         bool any = false, holds = false;
-        double tbelow = -__builtin_inf(), tabove = __builtin_inf(), bestv[8];
+        double tbelow = -__builtin_inf(), lbelow = 0.0, tabove = __builtin_inf(), labove = 0.0, bestv[8], cbest = __builtin_inf();
         for (int k = 0; k < 8; k++) bestv[k] = __builtin_inf();
-        auto phi = [&](double t) { return r > 0.0 ? (t > 0.0 ? N * t - r * smx_log(N * t, ltab) : __builtin_inf()) : (t > 0.0 ? N * t : __builtin_inf()); };
-        for (int s = 0; s < R.n; s++) {
-            int a, b;
-            double x, y;
-            if (!R.row(s, a, b, x, y)) continue;
-            if (a < l || a > u || b < l || b > u || (A.tau - a) * (A.tau - b) < 0) continue;
-            any = true;
-            // (the coefficients are >= 0: c.lo <= c.v <= c.hi on the box whatever the signs of its corners)
-            const double tlo = R.c0 * c.lo[0] + x * c.lo[1] + y * c.lo[2], thi = R.c0 * c.hi[0] + x * c.hi[1] + y * c.hi[2];
-            if (thi < ts) tbelow = fmax(tbelow, thi);
-            else if (tlo > ts) tabove = fmin(tabove, tlo);
-            else holds = true;
-            // (2) tangent at the centre, at the eight corners
-            const double tc = R.c0 * vc[0] + x * vc[1] + y * vc[2];
-            if (tc > 0.0) {
-                const double f0 = r > 0.0 ? N * tc - r * smx_log(N * tc, ltab) : N * tc, f1 = N - r / tc;
-                cbest = fmin(cbest, f0);
-                const double d0 = f1 * R.c0 * h[0], d1 = f1 * x * h[1], d2 = f1 * y * h[2];
+        for (int s0 = 0; s0 < R.n; s0 += MIX_CHUNK) {
+            if (g == 0 || R.n > MIX_CHUNK) {
+                // ---- the table of rows s0 .. s0 + 63
+                wave_lds_sync();
+                const int s = s0 + lane;
+                int a = 0, b = 0;
+                double x = 0.0, y = 0.0;
+                const bool ok = s < R.n && R.row(s, a, b, x, y) && (A.tau - a) * (A.tau - b) >= 0;
+                const double tcs = R.c0 * vc[0] + x * vc[1] + y * vc[2];
+                const double tls = R.c0 * c.lo[0] + x * c.lo[1] + y * c.lo[2], ths = R.c0 * c.hi[0] + x * c.hi[1] + y * c.hi[2];
+                T.ok[lane] = ok ? 1 : 0;
+                T.a[lane] = (unsigned char)a;
+                T.b[lane] = (unsigned char)b;
+                T.tc[lane] = tcs;
+                T.ltc[lane] = tcs > 0.0 ? smx_log(tcs, ltab) : 0.0;
+                T.itc[lane] = tcs > 0.0 ? 1.0 / tcs : 0.0;
+                T.tlo[lane] = tls;
+                T.ltlo[lane] = tls > 0.0 ? smx_log(tls, ltab) : 0.0;
+                T.thi[lane] = ths;
+                T.lthi[lane] = ths > 0.0 ? smx_log(ths, ltab) : 0.0;
+                const double e0 = R.c0 * h[0], e1 = x * h[1], e2 = y * h[2];
 #pragma unroll
-                for (int k = 0; k < 8; k++) {
-                    const double val = f0 + ((k & 1) ? d0 : -d0) + ((k & 2) ? d1 : -d1) + ((k & 4) ? d2 : -d2);
-                    bestv[k] = fmin(bestv[k], val);
+                for (int k = 0; k < 8; k++) T.E[k][lane] = ((k & 1) ? e0 : -e0) + ((k & 2) ? e1 : -e1) + ((k & 4) ? e2 : -e2);
+                wave_lds_sync();
+            }
+            const int ns = R.n - s0 < MIX_CHUNK ? R.n - s0 : MIX_CHUNK;
+            for (int s = 0; s < ns; s++) {
+                if (!T.ok[s]) continue;                                  // (wave-uniform)
+                const int a = T.a[s], b = T.b[s];
+                if (a < l || a > u || b < l || b > u) continue;
+                any = true;
+                // (1) the clamp bound: phi_i is convex with its minimum at ts -- over the rows the smallest clamped value is phi(ts) if
+                // some row's interval [tlo, thi] holds ts, else the better of phi(largest thi below ts) and phi(smallest tlo above it).
+                // (The coefficients are >= 0: c.lo <= c.v <= c.hi on the box whatever the signs of its corners.)
+                const double tlo = T.tlo[s], thi = T.thi[s];
+                if (thi < iv.ts) {
+                    if (thi > tbelow) {
+                        tbelow = thi;
+                        lbelow = T.lthi[s];
+                    }
+                } else if (tlo > iv.ts) {
+                    if (tlo < tabove) {
+                        tabove = tlo;
+                        labove = T.ltlo[s];
+                    }
+                } else {
+                    holds = true;
                 }
-            } else {
-                // not positive at the centre (a box of either sign astride the row's zero line): the CONSTANT bound phi_i at the point
-                // of (0, thi] nearest its minimiser -- finite, where -inf would let every matrix through -- or, never positive on the
-                // box, no row of a matrix with a value here
-                const double val = thi > 0.0 ? phi(fmin(thi, ts)) : __builtin_inf();
-                for (int k = 0; k < 8; k++) bestv[k] = fmin(bestv[k], val);
+                // (2) the tangent at the centre, at the eight corners
+                const double tc = T.tc[s];
+                if (tc > 0.0) {
+                    const double f0 = __builtin_fma(iv.N, tc, -iv.r * (iv.lnN + T.ltc[s])), f1 = __builtin_fma(-iv.r, T.itc[s], iv.N);
+                    cbest = fmin(cbest, f0);
+#pragma unroll
+                    for (int k = 0; k < 8; k++) bestv[k] = fmin(bestv[k], __builtin_fma(f1, T.E[k][s], f0));
+                } else {
+                    // not positive at the centre (a box of either sign astride the row's zero line): the CONSTANT bound phi_i at the
+                    // point of (0, thi] nearest its minimiser -- finite, where -inf would let every matrix through -- or, never
+                    // positive on the box, no row of a matrix with a value here
+                    double val = __builtin_inf();
+                    if (thi > 0.0) val = thi < iv.ts ? __builtin_fma(iv.N, thi, -iv.r * (iv.lnN + T.lthi[s])) : iv.phimin;
+                    for (int k = 0; k < 8; k++) bestv[k] = fmin(bestv[k], val);
+                }
             }
         }
-        double best1 = __builtin_inf();
-        if (any) {
-            if (holds) {
-                best1 = phi(ts);
-            } else {
-                if (tbelow > -__builtin_inf()) best1 = phi(tbelow);
-                if (tabove < __builtin_inf()) best1 = fmin(best1, phi(tabove));
+        if (mine) {
+            double best1 = __builtin_inf();
+            if (any) {
+                if (holds) {
+                    best1 = iv.phimin;
+                } else {
+                    if (tbelow > 0.0) best1 = __builtin_fma(iv.N, tbelow, -iv.r * (iv.lnN + lbelow));
+                    if (tabove < __builtin_inf()) best1 = fmin(best1, __builtin_fma(iv.N, tabove, -iv.r * (iv.lnN + labove)));
+                }
             }
+            lb1 += best1;
+            cs += cbest;
+            for (int k = 0; k < 8; k++) lbv[k] += bestv[k];
         }
-        lb1 += best1;
-        cs += cbest;
-        for (int k = 0; k < 8; k++) lbv[k] += bestv[k];
     }
+    (void)nmine;
     centre = mix_wave_sum(cs) + A.cst;
     lb1 = mix_wave_sum(lb1);
     double lb2 = __builtin_inf();
     for (int k = 0; k < 8; k++) lb2 = fmin(lb2, mix_wave_sum(lbv[k]));
-    return fmax(lb1, lb2) + A.cst;
+    // (ln(rN c.v) is taken as ln rN + ln c.v: a few 1e-16 of r_i ln per term -- 1e-9 of the bound at most; the bound is a LOWER bound)
+    return fmax(lb1, lb2) + A.cst - 1e-7;
 }
 
 // One wave per CHILD of a box off the stack: the parent is cut in two along its widest side (widths weighted by the leaf size of
@@ -559,6 +615,7 @@ __global__ __launch_bounds__(64 * MIX_WAVES) void mix_split_kernel(MixArgs A, co
     __shared__ uchar2 rows[MIX_MAX_Q];
     __shared__ unsigned char slot_of[256];
     __shared__ double2 ltab[128];                    // smx_log's table (the scorers' logarithm: 15 vector instructions, within an ulp)
+    __shared__ MixRowTab rtab[MIX_WAVES];            // per wave: the rows of the box it bounds (mix_cell_bound)
     const unsigned long long top = ctr[MIX_TOP0 + par];
     const unsigned long long n = top < (unsigned long long)A.chunk ? top : (unsigned long long)A.chunk;
     const unsigned long long first = (unsigned long long)blockIdx.x * MIX_WAVES;
@@ -588,7 +645,7 @@ __global__ __launch_bounds__(64 * MIX_WAVES) void mix_split_kernel(MixArgs A, co
         // a sharded search: below `shard_depth` cuts every box belongs to ONE rank (by its path), above it all ranks walk alike
         if (A.shard_G > 1 && (int)c.depth == A.shard_depth && (int)((c.key * 2654435761u + c.line * 40503u) % (unsigned)A.shard_G) != A.shard_g) continue;
         double centre;
-        const double lb = mix_cell_bound(A, c, rows, slot_of, ltab, lane, centre);
+        const double lb = mix_cell_bound(A, c, rows, slot_of, ltab, lane, centre, rtab[threadIdx.x >> 6]);
         if (!(lb <= A.thr) || lb == __builtin_inf() || lane != 0) continue;      // (+inf: no row of some interval has a value in the box)
         // a DIVE ranks by what the best assignment of rows comes to AT the box's centre -- an attainable value of the relaxed problem,
         // where the bounds of large boxes are all the saturated model's and tell nothing apart
@@ -639,20 +696,40 @@ __global__ __launch_bounds__(256) void mix_push_kernel(MixCell *stack, unsigned 
 // phi_i(c.v) from below on the whole box for the v that minimises the matrix's (linear) tangent sum -- which is a corner.  So every
 // matrix whose objective is within `thr` somewhere in the box has sum_i cost_i(c_i) <= thr for at least one corner: a depth-first
 // walk over the intervals (rows in slot order, valid and within bounds, the reference's edge rule between consecutive rows) with
-// that budget and the suffix minima as look-ahead lists them.  One thread per (leaf, corner); a record is m slot bytes.  (A leaf of
-// a line walks the rows of its line only: every matrix it lists is rank deficient.)
-#define MIX_MAX_M 256
+// that budget and the suffix minima as look-ahead lists them.  A record is m slot bytes.  (A leaf of a line walks the rows of its
+// line only: every matrix it lists is rank deficient.)
+//
+// One WAVE per (leaf, corner) (round 6).  Round 5's walk -- one THREAD each -- evaluated cost_i(c) with its logarithm at every step
+// of the walk, for all rows of the alphabet at every depth: 25 ms for the 934 leaves of config 5's shape (a hundred waves on the
+// chip, each a serial chain of library logarithms), and the whole of a flat likelihood's minutes.  Now the lanes take the
+// intervals: every cost once (phase 1: the per-interval minima, their suffix sums), then per interval the VIABLE rows -- those
+// whose cost exceeds the interval's minimum by no more than the slack thr - (sum of the minima): no other row can be part of a
+// matrix within the budget -- are kept in LDS with their costs (phase 2: one to three rows per interval on the bench's data), and
+// lane 0 walks those lists (phase 3: table look-ups, no arithmetic beyond the running sum).  An interval with more than MIX_VIA
+// viable rows (a likelihood that flat) is walked over all its rows with the cost taken on the fly, as before.
+#define MIX_VIA 8
+struct MixWalk {
+    double suf[MIX_MAX_M + 1];
+    double cost[MIX_MAX_M][MIX_VIA];
+    unsigned char srow[MIX_MAX_M][MIX_VIA];   // the viable rows (row index: slot, or t on a line), ascending
+    unsigned char nvia[MIX_MAX_M];            // how many (0xff: more than MIX_VIA -- all rows, costs on the fly)
+    unsigned char cur[MIX_MAX_M], pa[MIX_MAX_M], pb[MIX_MAX_M];
+    double part[MIX_MAX_M + 1];
+};
 __global__ __launch_bounds__(64) void mix_list_kernel(MixArgs A, const MixCell *leaves, unsigned long long n_leaves, unsigned char *out, unsigned long long out_cap,
                                                       unsigned long long per_thread_cap, unsigned long long max_steps, unsigned long long *ctr) {
     __shared__ uchar2 rows[MIX_MAX_Q];
     __shared__ unsigned char slot_of[256];
+    __shared__ MixWalk W;
     mix_stage_rows(A, rows, slot_of);
     __syncthreads();
-    const unsigned long long k = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned long long k = blockIdx.x;
     if (k >= 8 * n_leaves) return;
     const MixCell c = leaves[k >> 3];
     const int corner = (int)(k & 7);
     if (c.line && (corner & 4)) return;               // (a line's box has two sides: four corners)
+    if (!(c.lb <= A.thr)) return;                     // (a leaf kept under an earlier, looser threshold)
+    const int lane = threadIdx.x;
     const MixRows R(A, c.line, rows, slot_of);
     double vc[3], dv[3];
     for (int j = 0; j < 3; j++) {
@@ -680,9 +757,8 @@ __global__ __launch_bounds__(64) void mix_list_kernel(MixArgs A, const MixCell *
         const double f0 = r > 0.0 ? N * tc - r * log(N * tc) : N * tc, f1 = N - r / tc;
         return f0 + f1 * (R.c0 * dv[0] + x * dv[1] + y * dv[2]);
     };
-    double suf[MIX_MAX_M + 1];
-    suf[A.m] = A.cst;
-    for (int i = A.m - 1; i >= 0; i--) {
+    // ---- phase 1: the cheapest row of every interval, the suffix sums of those minima
+    for (int i = lane; i < A.m; i += WAVE) {
         double best = __builtin_inf();
         for (int s = 0; s < R.n; s++) {
             bool ok;
@@ -690,17 +766,44 @@ __global__ __launch_bounds__(64) void mix_list_kernel(MixArgs A, const MixCell *
             const double v = cost(i, s, ok, a, b);
             if (ok) best = fmin(best, v);
         }
-        suf[i] = suf[i + 1] + best;
+        W.part[i] = best;                              // (the walk's own array: free until phase 3)
     }
-    if (!(suf[0] <= A.thr)) return;
+    wave_lds_sync();
+    if (lane == 0) {
+        W.suf[A.m] = A.cst;
+        for (int i = A.m - 1; i >= 0; i--) W.suf[i] = W.suf[i + 1] + W.part[i];
+    }
+    wave_lds_sync();
+    const double total0 = W.suf[0];
+    if (!(total0 <= A.thr)) return;
     if (__hip_atomic_load(&ctr[MIX_CUT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull) return;
-    unsigned char cur[MIX_MAX_M];      // row chosen at each depth (the next to try while descending)
-    unsigned char pa[MIX_MAX_M], pb[MIX_MAX_M];   // ... its copy numbers
-    double part[MIX_MAX_M + 1];        // cost of the rows chosen above each depth
+    // ---- phase 2: the viable rows of every interval.  A matrix within the budget pays at least the minimum in every OTHER interval,
+    // so its row in interval i costs at most that interval's minimum + the slack (less a rounding allowance on the sums).
+    const double slack = (A.thr - total0) + 1e-9 * (fabs(total0) + 1.0);
+    for (int i = lane; i < A.m; i += WAVE) {
+        const double lim = (W.suf[i] - W.suf[i + 1]) + slack;
+        int n = 0;
+        for (int s = 0; s < R.n; s++) {
+            bool ok;
+            int a, b;
+            const double v = cost(i, s, ok, a, b);
+            if (ok && v <= lim) {
+                if (n < MIX_VIA) {
+                    W.cost[i][n] = v;
+                    W.srow[i][n] = (unsigned char)s;
+                }
+                n++;
+            }
+        }
+        W.nvia[i] = n > MIX_VIA ? 0xffu : (unsigned char)n;
+    }
+    wave_lds_sync();
+    if (lane != 0) return;
+    // ---- phase 3: the walk (lane 0).  cur[i]: the next entry of interval i's list to try (or, list overflowed, the next row).
     int i = 0;
     unsigned long long found = 0, steps = 0;
-    cur[0] = 0;
-    part[0] = 0.0;
+    W.cur[0] = 0;
+    W.part[0] = 0.0;
     while (i >= 0) {
         // (a budget on the walk itself: no likelihood, however flat, may hang the device -- and once one walk has run out, the
         // list is void: the others stop at their next look)
@@ -709,41 +812,55 @@ __global__ __launch_bounds__(64) void mix_list_kernel(MixArgs A, const MixCell *
             return;
         }
         if ((steps & 4095ull) == 0 && __hip_atomic_load(&ctr[MIX_CUT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull) return;
-        if ((int)cur[i] >= R.n) {       // this depth is exhausted
+        const bool full = W.nvia[i] == 0xffu;
+        const int lim_n = full ? R.n : (int)W.nvia[i];
+        if ((int)W.cur[i] >= lim_n) {       // this depth is exhausted
             i--;
-            if (i >= 0) cur[i]++;
+            if (i >= 0) W.cur[i]++;
             continue;
         }
-        const int s = cur[i];
-        bool ok;
-        int a, b;
-        const double v = cost(i, s, ok, a, b);
-        bool go = ok && part[i] + v + suf[i + 1] <= A.thr;
+        const int e = W.cur[i];
+        int s, a, b;
+        double v;
+        bool ok = true;
+        if (full) {
+            s = e;
+            v = cost(i, s, ok, a, b);
+        } else {
+            s = W.srow[i][e];
+            v = W.cost[i][e];
+            double x, y;
+            (void)R.row(s, a, b, x, y);
+        }
+        bool go = ok && W.part[i] + v + W.suf[i + 1] <= A.thr;
         if (go && i > 0)                 // Enumerator._is_valid_edge (Enumerator.py:258-260): the same row, or some component larger
-            go = (a == (int)pa[i - 1] && b == (int)pb[i - 1]) || a > (int)pa[i - 1] || b > (int)pb[i - 1];
+            go = (a == (int)W.pa[i - 1] && b == (int)W.pb[i - 1]) || a > (int)W.pa[i - 1] || b > (int)W.pb[i - 1];
         if (!go) {
-            cur[i]++;
+            W.cur[i]++;
             continue;
         }
-        pa[i] = (unsigned char)a;
-        pb[i] = (unsigned char)b;
+        W.pa[i] = (unsigned char)a;
+        W.pb[i] = (unsigned char)b;
         if (i == A.m - 1) {
             if (found < per_thread_cap) {
                 const unsigned long long idx = atomicAdd(&ctr[MIX_LISTED], 1ull);
                 if (idx < out_cap) {
                     unsigned char *dst = out + idx * (size_t)A.m;
-                    for (int d = 0; d < A.m; d++) dst[d] = (unsigned char)R.slot(cur[d]);
+                    for (int d = 0; d < A.m; d++) {
+                        const int ed = W.cur[d];
+                        dst[d] = (unsigned char)R.slot(W.nvia[d] == 0xffu ? ed : (int)W.srow[d][ed]);
+                    }
                 }
             } else {
                 atomicAdd(&ctr[MIX_CUT], 1ull);      // (this walk found more than its share: the host must not trust the list)
             }
             found++;
-            cur[i]++;
+            W.cur[i]++;
             continue;
         }
-        part[i + 1] = part[i] + v;
+        W.part[i + 1] = W.part[i] + v;
         i++;
-        cur[i] = 0;
+        W.cur[i] = 0;
     }
 }
 
@@ -842,6 +959,5 @@ void mix_launch_iteration(const MixArgs &A, MixCell *stack, unsigned long long s
 void mix_launch_list(const MixArgs &A, const MixCell *leaves, unsigned long long n_leaves, unsigned char *out, unsigned long long out_cap,
                      unsigned long long per_thread_cap, unsigned long long max_steps, unsigned long long *ctr, hipStream_t st) {
     if (!n_leaves) return;
-    hipLaunchKernelGGL(mix_list_kernel, dim3((unsigned)((8 * n_leaves + 63) / 64)), dim3(64), 0, st, A, leaves, n_leaves, out, out_cap, per_thread_cap, max_steps,
-                       ctr);
+    hipLaunchKernelGGL(mix_list_kernel, dim3((unsigned)(8 * n_leaves)), dim3(64), 0, st, A, leaves, n_leaves, out, out_cap, per_thread_cap, max_steps, ctr);
 }

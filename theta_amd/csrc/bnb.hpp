@@ -93,9 +93,14 @@ __host__ __device__ inline double mix_unord(unsigned long long u) {
     return __builtin_bit_cast(double, u);
 }
 
+// constants of an interval: rN, r, r / rN, ln rN, and phi's minimum r - r ln r (phi_i(t) = rN t - r ln(rN t) at rN t = r; 0 for r = 0)
+struct MixIv {
+    double N, r, ts, lnN, phimin;
+};
 struct MixArgs {
     int m, Q, tau;
     const double *r, *rN;          // [m]
+    const MixIv *iv;               // [m] the intervals' constants (bnb.hip: MixIv)
     const unsigned char *rowtab;   // [Q] slot -> a | b << 4
     const unsigned char *slot_of;  // [256] a | b << 4 -> slot, 0xff: not a row of the alphabet
     const unsigned char *lb, *ub;  // [m] order-adjusted bounds

@@ -208,6 +208,8 @@ struct SvWave {
 // the ratio masks (`dynmask`) so that the wave needs no pointer of its own for it.  (The full 31 x 31 table in LDS costs the float
 // instantiation its third block per CU: 36 -> 45 ms per 2^31 candidates.)
 #define SV_RIDX_W 15
+// (TAB = the double instantiation of up to 128 intervals: the wide one's LDS is full -- two blocks per CU to the last kilobyte.)
+template <class F, int NS> struct SvTab { static constexpr bool v = sizeof(F) == 8 && NS == 2; };
 template <int ML, class F, int NS>
 struct SvLds {
     SvWave<ML, F, NS> w[SV_WAVES];
@@ -220,7 +222,7 @@ struct SvLds {
     // two field extractions and two conversions per row, every evaluation (sv_child_rows + the decode in sv_step: 7 vector
     // instructions per row, 42 of an evaluation's ~480); one 16-byte LDS read by slot replaces them.  (The float instantiation keeps
     // the bytes: 512 B more would cost it its third block per CU.)
-    Sv2<F> rowF[sizeof(F) == 8 ? N3_MAX_Q : 1];
+    Sv2<F> rowF[SvTab<F, NS>::v ? N3_MAX_Q : 1];
 };
 
 // inclusive scan over the wave with DPP row shifts / broadcasts (no LDS traffic)
@@ -337,11 +339,11 @@ __device__ __forceinline__ void sv_witness(const SvCtx<ML, F, NS> &c, unsigned o
 
 // The leaf rows of a record as a full evaluation takes them.  F = float: two rows {a, b, a', b'} per dword, decoded term by term.
 // F = double: the slots themselves -- the path code (6 bits per row) and the last row's slot --, looked up in SvLds::rowF.
-template <int ML, class F> struct SvRows;
-template <int ML> struct SvRows<ML, float> {
+template <int ML, bool TAB> struct SvRowsT;
+template <int ML> struct SvRowsT<ML, false> {
     unsigned rw[ML / 2];
 };
-template <int ML> struct SvRows<ML, double> {
+template <int ML> struct SvRowsT<ML, true> {
     unsigned code, slot;
 };
 
@@ -382,7 +384,7 @@ __device__ __forceinline__ F sv_mu_limit(const SvCtx<ML, F, NS> &c, F H11, F H22
 // val2 = sum R log2 q and l2 = lambda^2 / Rtot at the OLD one), 1 = stepped and converged (l2 < conv), 2 = outside the domain
 // (u1, u2 halved towards 0), 3 = no usable step (ill-conditioned Hessian, NaN).
 template <int ML, class F, int NS>
-__device__ __forceinline__ int sv_step(const SvCtx<ML, F, NS> &c, const SvRows<ML, F> &rows, F s1, F s2, F &u1, F &u2, F &val2, F &l2, F &la, F &mlim) {
+__device__ __forceinline__ int sv_step(const SvCtx<ML, F, NS> &c, const SvRowsT<ML, SvTab<F, NS>::v> &rows, F s1, F s2, F &u1, F &u2, F &val2, F &l2, F &la, F &mlim) {
     typedef typename SvVec<F>::v2 v2;
     v2 g1 = {F(0), F(0)}, g2 = g1, h11 = g1, h12 = g1, h22 = g1, lg = g1, lga = g1;
     const v2 vs1 = {s1, s1}, vs2 = {s2, s2}, vu1 = {u1, u1}, vu2 = {u2, u2}, one = {F(1), F(1)};
@@ -428,7 +430,7 @@ SV_UNROLL(SV_UNR)
 #pragma unroll
     for (int j = 0; j < ML / 2; j++) {
         const typename SvWt<F>::T rr = c.W->fRL[j];
-        if constexpr (sizeof(F) == 8) {
+        if constexpr (SvTab<F, NS>::v) {
             const Sv2<F> ra = c.S->rowF[(rows.code >> (12 * j)) & 63u];
             const Sv2<F> rb = c.S->rowF[j < ML / 2 - 1 ? (rows.code >> (12 * j + 6)) & 63u : rows.slot];
             body(v2{ra.x, rb.x}, v2{ra.y, rb.y}, v2{rr.x, rr.y}, sv_rho<F>(rr));
@@ -505,11 +507,11 @@ __device__ __forceinline__ void sv_set_threshold(SvCtx<ML, F, NS> &c, double thr
 
 // column sums / N of a record: (s1, s2); false if a tumour column is all zero (degenerate: the reference's Chat is NaN)
 template <int ML, class F, int NS>
-__device__ __forceinline__ bool sv_sums(const SvCtx<ML, F, NS> &c, const SvRows<ML, F> &rows, F &s1, F &s2) {
+__device__ __forceinline__ bool sv_sums(const SvCtx<ML, F, NS> &c, const SvRowsT<ML, SvTab<F, NS>::v> &rows, F &s1, F &s2) {
     F a = c.S1p, b = c.S2p;
 #pragma unroll
     for (int j = 0; j < ML / 2; j++) {
-        if constexpr (sizeof(F) == 8) {
+        if constexpr (SvTab<F, NS>::v) {
             const Sv2<F> ra = c.S->rowF[(rows.code >> (12 * j)) & 63u];
             const Sv2<F> rb = c.S->rowF[j < ML / 2 - 1 ? (rows.code >> (12 * j + 6)) & 63u : rows.slot];
             a = sv_fma(ra.x, c.leafN[2 * j], a);
@@ -562,8 +564,8 @@ __device__ __forceinline__ void sv_child_rows(const SvCtx<ML, F, NS> &c, unsigne
 }
 
 template <int ML, class F, int NS>
-__device__ __forceinline__ void sv_rows_load(const SvCtx<ML, F, NS> &c, unsigned code, unsigned slot, SvRows<ML, F> &rows) {
-    if constexpr (sizeof(F) == 8) {
+__device__ __forceinline__ void sv_rows_load(const SvCtx<ML, F, NS> &c, unsigned code, unsigned slot, SvRowsT<ML, SvTab<F, NS>::v> &rows) {
+    if constexpr (SvTab<F, NS>::v) {
         rows.code = code;
         rows.slot = slot;
     } else {
@@ -572,8 +574,8 @@ __device__ __forceinline__ void sv_rows_load(const SvCtx<ML, F, NS> &c, unsigned
 }
 // ... and a contender's rows for the list (rare path)
 template <int ML, class F, int NS>
-__device__ __forceinline__ void sv_survivor_rows(const SvCtx<ML, F, NS> &c, const SvRows<ML, F> &rows, unsigned off, F u1, F u2) {
-    if constexpr (sizeof(F) == 8) {
+__device__ __forceinline__ void sv_survivor_rows(const SvCtx<ML, F, NS> &c, const SvRowsT<ML, SvTab<F, NS>::v> &rows, unsigned off, F u1, F u2) {
+    if constexpr (SvTab<F, NS>::v) {
         unsigned rw[ML / 2];
         sv_child_rows<ML, F, NS>(c, rows.code, rows.slot, rw);
         sv_survivor<ML, F, NS>(c, rw, off, u1, u2);
@@ -605,7 +607,7 @@ __device__ __forceinline__ void sv_drain(SvCtx<ML, F, NS> &c) {
     int next = 0;                                   // (wave-uniform) queue entries handed out so far
     int left = 0;                                   // (wave-uniform) entries put back
     bool live = false;
-    SvRows<ML, F> rows;
+    SvRowsT<ML, SvTab<F, NS>::v> rows;
     sv_rows_load<ML, F, NS>(c, 0u, 0u, rows);
     F u1 = F(0), u2 = F(0), s1 = F(1), s2 = F(1);
     unsigned qy = 0u, code = 0u;                    // the entry's words: last row's slot | offset in the task << 8 | evaluations so far << 24, path slots
@@ -1014,7 +1016,7 @@ __device__ __forceinline__ void sv_children(SvCtx<ML, F, NS> &c, int total) {
                 // has the child at hand, instead of through the queue (push, pop, decode, column sums, a wave-step that may run half
                 // empty): the queue is left with the ~10 % that need a third (and where most of the trip's lanes do -- SV_THIRD_MIN --
                 // that one is taken here as well).  Same arithmetic, same decisions as sv_drain.
-                SvRows<ML, F> rows;
+                SvRowsT<ML, SvTab<F, NS>::v> rows;
                 sv_rows_load<ML, F, NS>(c, o.code, o.slot, rows);
                 F u1 = qu1, u2 = qu2;
                 if (!(u1 == u1)) {                      // (no usable shared point: from the simplex centre)
@@ -1357,7 +1359,7 @@ __global__ __launch_bounds__(64 * SV_WAVES, sizeof(F) == 4 ? SV_OCC : SV_OCC64) 
         const unsigned rw = Pg.rowtab[i];
         S.rowtab[i] = (unsigned char)rw;
         S.row16[i] = (unsigned short)((rw & 15u) | ((rw >> 4) << 8));
-        if constexpr (sizeof(F) == 8) S.rowF[i] = Sv2<F>{(F)(rw & 15u), (F)(rw >> 4)};
+        if constexpr (SvTab<F, NS>::v) S.rowF[i] = Sv2<F>{(F)(rw & 15u), (F)(rw >> 4)};
     }
     for (int i = threadIdx.x; i < ML * N3_MAX_Q; i += blockDim.x) (&S.smask[0][0])[i] = Pg.smask[(size_t)D * N3_MAX_Q + i];
     __syncthreads();
