@@ -483,11 +483,17 @@ def extras(ctx, cpu_seconds):
                       "mu": [float(x) for x in b3[0][1]],
                       "method": "branch and bound over the mixture space (theta_mix_search) + the reference's procedure on the listed matrices",
                       "boxes_tested": mx.get("boxes_tested"), "leaves": mx.get("leaves"), "matrices_listed": mx.get("listed"),
-                      "octree_kernel_ms": mx.get("kernel_ms"), "smallest_leaf_bound": mx.get("min_bound"), "incumbent_heuristic": mx.get("heuristic_nll"),
-                      "heuristic_s": mx.get("heuristic_seconds"), "count_saturated": bool(rp.candidates >= 2 ** 128 - 1),
+                      "octree_kernel_ms": mx.get("kernel_ms"), "smallest_leaf_bound": mx.get("min_bound"),
+                      "dive": mx.get("dive"), "incumbent_heuristic": mx.get("heuristic_nll"), "heuristic_s": mx.get("heuristic_seconds"),
+                      "ladder_passes": len(mx.get("passes") or []), "host_syncs_of_the_last_walk": mx.get("syncs"),
+                      "lines": mx.get("lines"), "line_leaves": mx.get("line_leaves"), "rank_deficient_records": mx.get("rank_deficient_records"),
+                      "rank_deficient_bound": mx.get("rank_deficient_bound"), "threshold": mx.get("threshold"),
+                      "count_saturated": bool(rp.candidates >= 2 ** 128 - 1),
                       "reference_estimate_s": float(rp.candidates) / 30.0,
                       "reference_note": "the reference visits every matrix at ~30 per second and process (BASELINE.md): no run of it can finish",
-                      "not_included": "matrices the reference reports off their optimum: rank-deficient ones, NaN outcomes (DESIGN.md section 8)"}
+                      "not_included": "NaN outcomes (some rank-deficient matrices, one full-rank matrix in a million): no bound reaches them. "
+                                      "Every FINITE outcome of a rank-deficient matrix within the threshold is among the records "
+                                      "(round 6: one tree per line of the alphabet's grid), and none lies below rank_deficient_bound"}
         except Exception as ex:
             w[key] = {"error": str(ex)[:200]}
     r2, rN2, order2 = synth(seed=11, m=25, n=2, k=5)

@@ -678,12 +678,22 @@ def mix_records(problem, ctx, r, rN, max_normal, bounds, report=None, exchange=N
         # (a space the linear walk can finish is not worth more of the clock than the walk itself would take: 2e10 matrices a second;
         # a likelihood that flat -- a few reads per interval -- is the walk's.  A space no walk finishes is searched to the end.)
         budget_ms = min(MIX_MAX_MS_SMALL, max(300.0, 1e3 * problem.count / 2e10)) if walkable else MIX_MAX_MS_LARGE
+        t_ladder = time.time()
+
+        def left_ms():
+            """what is left of the budget for ALL the passes and the last walk together (0: no budget)"""
+            if not budget_ms:
+                return 0
+            left = budget_ms - 1e3 * (time.time() - t_ladder)
+            if left <= 1.0:
+                raise _lib.ThetaError(_lib.ERR_CAPACITY, "mixture-space search: %.0f ms spent on a likelihood too flat to prune by" % budget_ms)
+            return left
         for leaf in (3e-2, 1e-2, 3e-3, 1e-3, 5e-4):
             if leaf <= 2.0 * leaf_final:
                 break
             found = None
             try:
-                problem.set_option("mix_max_ms", budget_ms)
+                problem.set_option("mix_max_ms", left_ms())
                 try:
                     props, stp = problem.mix_search(inc + window + 4 * TIE_MARGIN, leaf_rel=leaf, cap=256, propose=True)
                 finally:
@@ -699,7 +709,7 @@ def mix_records(problem, ctx, r, rN, max_normal, bounds, report=None, exchange=N
                 info["passes"].append({"leaf": leaf, "gave_up": True})
             inc = share(inc)
         thr = inc + window + 4 * TIE_MARGIN
-        mats, st = final(thr, MIX_MAX_BOXES_SMALL if walkable else 0, budget_ms)
+        mats, st = final(thr, MIX_MAX_BOXES_SMALL if walkable else 0, left_ms())
     if MIX_LINES:
         # ... and the matrices of one repeated row (rank 1: the same value at every mixture), which no tree bounds
         const = problem.constant_matrices()

@@ -33,7 +33,7 @@ rm -rf $OUT/kt
 $ROOT/tools/pmc_kernel.sh gpurun_out/prof_$R/pmc_sieve n3_sieve_kernel > $OUT/pmc_sieve.log 2>&1
 cp $OUT/pmc_sieve/pmc.json $OUT/pmc_n3_sieve_kernel.json 2>/dev/null
 if [ -f $ROOT/build_ab/libprof.so ]; then
-  for leg in full_solve_f64 full_solve_f64_tight full_solve_f64_tight_certified full_solve_f32 search; do
+  for leg in full_solve_f64 full_solve_f64_tight full_solve_f64_tight_certified full_solve_f64_l2_certified full_solve_f32 search; do
     echo "== $leg (cycles summed over waves: 0 group tile, 1 parent phase, 2 children phase, 3 queue drain, 4 prefix successor, 5 whole wave, 6 the last level's own expansion; 7 = prefixes walked)"
     THETA_HIP_LIB=$ROOT/build_ab/libprof.so THETA_BENCH_VERBOSE=1 timeout 300 python $ROOT/bench.py --steps 6 --warmup 2 --leg $leg --no-legs --no-cpu-baseline --no-traffic --no-extras 2>&1 >/dev/null | grep "^step"
   done > $OUT/phase_cycles.txt
