@@ -224,7 +224,7 @@ int theta_search_degenerate(theta_problem *p, int cap, uint64_t *rank, uint8_t *
  *   "n2_no_dismiss"  1: the n=2 search solves every candidate; 0 (default): a candidate whose rigorous lower bound -- one evaluation
  *                    at a chain point, self-concordance -- lies beyond the window of the running minimum is done (same finalists)
  *   "n3_per_task"    candidates per wave task (0 = automatic), "n2_per_thread" candidates per thread (0 = automatic)
- *   "mix_shard_world", "mix_shard_rank"   theta_mix_search on G ranks: rank g keeps the boxes dealt to it a few cuts below the roots
+ *   "mix_shard_world", "mix_shard_rank"   theta_mix_search on G ranks: rank g keeps the boxes dealt to it where they become as small as 8 leaves a side
  *                    (set the world first); default 1 / 0: every box
  *   "mix_beam"       boxes per level of a THETA_MIX_DIVE (8 .. 1024, default 512)
  *   "mix_max_steps"  steps the walk over the intervals of one (leaf, corner) may take before theta_mix_search gives up (default 2^22)
@@ -355,8 +355,8 @@ int theta_bnb(theta_problem *p, double threshold, uint64_t beam, int follow_coll
  *                         rank-deficient matrix with two distinct rows or more that the list does not hold (+inf: no box of a line
  *                         came within the threshold).  NaN outcomes have no bound.
  *   THETA_MIX_LINES_ONLY  the lines' trees alone.
- * A sharded search (options "mix_shard_world" / "mix_shard_rank" of theta_problem_set_option): the boxes a few cuts below the roots
- * are dealt out by their path, each rank lists the matrices of its own; the union over the ranks is the unsharded list.
+ * A sharded search (options "mix_shard_world" / "mix_shard_rank" of theta_problem_set_option): the boxes that have just become as small
+ * as 8 leaves a side are dealt out by their position, each rank lists the matrices of its own; the union over the ranks is the unsharded list.
  *
  * THETA_ERR_CAPACITY with *n_out > cap: the list holds *n_out matrices, come again with that capacity.  THETA_ERR_CAPACITY with
  * *n_out == 0: the threshold leaves more boxes or matrices than the device holds (option "mix_max_boxes" bounds the work before).

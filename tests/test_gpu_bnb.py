@@ -333,3 +333,34 @@ def test_counting_table_of_a_space_beyond_2_to_the_128_waits_for_the_first_rank(
     print("problem creation, lazy / eager counting table: %.3f / %.3f s" % (times["1"], times["0"]))     # (timing: tests/test_gpu_perf.py)
     assert list(out["1"][0]) == list(out["0"][0]) and np.array_equal(out["1"][1], out["0"][1]) and np.array_equal(out["1"][2], out["0"][2])
     assert len(out["1"][0]) >= 1
+
+
+@pytest.mark.parametrize("G", [2, 8])
+def test_sharded_boxes_partition_the_search(ctx, G):
+    """Options mix_shard_world / mix_shard_rank (round 6): the boxes a few cuts below the roots are dealt out over G ranks by their path.
+    On one GPU, rank after rank: the ranks' lists together are the unsharded list -- nothing lost at the cuts --, most ranks find leaves
+    of their own, the leaves add up to the unsharded search's (a leaf belongs to exactly one rank), and the boxes tested add up to the
+    unsharded count plus the few hundred every rank walks alike above the cut."""
+    import bench
+    import theta_amd
+    from theta_amd import search as S
+    m, K, seed = 50, 4, 7
+    r, rN, _order = bench.synth(seed=seed, m=m, n=3, k=K)
+    p = theta_amd.Problem(ctx, 3, m, 2, r, rN, [0] * m, [K] * m, 1.0)
+    thr = 22588904.807977 + S.COLLECT_WINDOW + 4 * S.TIE_MARGIN          # (config 3's minimum: test_baseline_configs_3_and_4_are_searched_whole)
+    whole, st0 = p.mix_search(thr, leaf_rel=1.3e-4, cap=1 << 16, lines=True)
+    assert len(whole) >= 2 and st0["leaves"] > 100
+    union, leaves, boxes, with_leaves = set(), 0, 0, 0
+    p.set_option("mix_shard_world", G)
+    for g in range(G):
+        p.set_option("mix_shard_rank", g)
+        part, st = p.mix_search(thr, leaf_rel=1.3e-4, cap=1 << 16, lines=True)
+        with_leaves += 1 if st["leaves"] > 0 else 0
+        leaves += st["leaves"]
+        boxes += st["boxes_tested"]
+        union |= set(np.asarray(c).tobytes() for c in part)
+    p.set_option("mix_shard_world", 1)
+    p.close()
+    assert union == set(np.asarray(c).tobytes() for c in whole)
+    assert leaves == st0["leaves"] and with_leaves >= (G + 1) // 2
+    assert st0["boxes_tested"] <= boxes <= st0["boxes_tested"] + G * 200000          # (what every rank walks alike above the cut)

@@ -2031,13 +2031,9 @@ extern "C" int theta_mix_search(theta_problem *p, double threshold, double leaf_
             root.line = (unsigned short)(l + 1);
             roots.push_back(root);
         }
-    // a sharded search (options mix_shard_rank / mix_shard_world): every rank walks the first cuts alike, then keeps its boxes
-    A.shard_depth = 0;
-    if (A.shard_G > 1) {
-        int d = 4;
-        while ((1 << d) < 16 * A.shard_G) d++;
-        A.shard_depth = d;
-    }
+    // a sharded search (options mix_shard_rank / mix_shard_world): every rank walks the large boxes alike, then keeps its own
+    A.shard_mult = 8.0;
+    if (const char *e = getenv("THETA_MIX_SHARD_MULT")) A.shard_mult = std::max(2.0, atof(e));
     if (roots.size() > p->mix_stack_cap) {
         theta_set_error("theta_mix_search: %zu roots", roots.size());
         return THETA_ERR_CAPACITY;

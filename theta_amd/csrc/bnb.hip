@@ -639,11 +639,25 @@ __global__ __launch_bounds__(64 * MIX_WAVES) void mix_split_kernel(MixArgs A, co
             }
         }
         const double mid = 0.5 * (c.lo[ax] + c.hi[ax]);
+        // a sharded search: the boxes that have just become as small as `shard_mult` leaves a side are dealt out -- each belongs to ONE rank,
+        // by its position --; above that size all ranks walk alike (a handful of boxes per level), below it a rank walks its own.  (A
+        // fixed number of cuts below the root would not do: the root is hundreds of times the region the data allows, and the first
+        // thirty levels hold one or two boxes each.)
+        bool was_small = true;
+        if (A.shard_G > 1)
+            for (int j = 0; j < 3; j++) was_small = was_small && (c.hi[j] - c.lo[j]) <= A.shard_mult * lf[j];
         if (k & 1) c.lo[ax] = mid; else c.hi[ax] = mid;
-        if (c.depth < 32) c.key = (c.key << 1) | (unsigned)(k & 1);
+        c.key = (c.key << 1) | (unsigned)(k & 1);
         c.depth++;
-        // a sharded search: below `shard_depth` cuts every box belongs to ONE rank (by its path), above it all ranks walk alike
-        if (A.shard_G > 1 && (int)c.depth == A.shard_depth && (int)((c.key * 2654435761u + c.line * 40503u) % (unsigned)A.shard_G) != A.shard_g) continue;
+        if (A.shard_G > 1 && !was_small) {
+            bool now_small = true;
+            for (int j = 0; j < 3; j++) now_small = now_small && (c.hi[j] - c.lo[j]) <= A.shard_mult * lf[j];
+            if (now_small) {
+                const unsigned long long hsh = mix_ord(c.lo[0]) * 0x9E3779B97F4A7C15ull + mix_ord(c.lo[1]) * 0xC2B2AE3D27D4EB4Full +
+                                               mix_ord(c.lo[2]) * 0x165667B19E3779F9ull + (unsigned long long)c.line * 0x27D4EB2F165667C5ull;
+                if ((int)((hsh >> 17) % (unsigned long long)A.shard_G) != A.shard_g) continue;
+            }
+        }
         double centre;
         const double lb = mix_cell_bound(A, c, rows, slot_of, ltab, lane, centre, rtab[threadIdx.x >> 6]);
         if (!(lb <= A.thr) || lb == __builtin_inf() || lane != 0) continue;      // (+inf: no row of some interval has a value in the box)

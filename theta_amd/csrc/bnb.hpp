@@ -110,7 +110,8 @@ struct MixArgs {
     double leaf_line[3];           // ... a box of a line
     const MixLine *lines;
     int n_lines;
-    int shard_g, shard_G, shard_depth;   // G > 1: of the boxes `shard_depth` cuts below their root this rank keeps those with key % G == g
+    int shard_g, shard_G;          // G > 1: of the boxes that have just become as small as shard_mult leaves a side this rank keeps those whose position hashes to g
+    double shard_mult;
     unsigned chunk;                // boxes taken off the stack per iteration
     double dive_blend;             // ... what a dive ranks by: bound + dive_blend x (relaxed objective at the centre - bound)
     int dive_niches;               // ... within groups of like mixtures first (mix_select_kernel)
