@@ -119,7 +119,9 @@ def mu_bound(l2, R, H, u, s1, s2, tau):
     U = (1.0 - s1 * u[0] - s2 * u[1]) / tau + u[0] + u[1]
     M = max(1.0, (abs(u[0]) + abs(u[1])) / U)
     J = (1.5 + M * np.hypot(1.0 - s1 / tau, 1.0 - s2 / tau)) / U
-    return 1.01 * l2 * Rtot * J / (0.718 * np.sqrt(Rmin * sig))
+    t = np.sqrt(l2 * Rtot / Rmin)
+    tp = (t / (1.0 - t)) ** 2
+    return 1.01 * l2 * Rtot * J / ((1.0 - t) ** 3 * (1.0 - tp) * np.sqrt(Rmin * sig))
 
 
 def test_the_mu_certificate_bounds_the_distance_to_the_optimum():

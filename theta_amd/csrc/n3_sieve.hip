@@ -274,7 +274,7 @@ struct SvCtx {
     F leafRho[ML];                   // ... and their square roots
     F rtot_f, rtot_over_rmin, inv_Rtot, conv_l2, fine_l2;
     double A_mu_tol;                 // ... the tolerance itself (witness records)
-    F mu_c, inv_tau;                 // option n3_mu_tol: 0.6398 tol sqrt(Rmin) / Rtot (per prefix; 0: off), 1 / tau -- see sv_mu_limit
+    F mu_c, mu_t2, inv_tau;          // option n3_mu_tol: 0.891 (1 - t)^3 (1 - t+) tol sqrt(Rmin) / Rtot (per prefix; 0: off), the l2 of that t, 1 / tau -- see sv_mu_limit
     double K0, screen_margin, thr;   // thr = running minimum + window, loaded per task; screen_margin: see sv_beyond
     F Tcmp;                          // the threshold of sv_beyond's comparison, in F (per task)
     F sqrt_ror;                      // sqrt(Rtot / Rmin) (per prefix)
@@ -351,11 +351,12 @@ template <int ML> struct SvRowsT<ML, true> {
 // An evaluation at u has the decrement lambda (l2 = lambda^2 / Rtot) and the tangent Hessian H.  With t = lambda / sqrt(Rmin) <= 0.1
 // (f / Rmin is self-concordant) one full Newton step ends at lambda+^2 <= lambda^4 / (Rmin (1 - t)^4); the minimiser u* then lies within
 // lambda+ / (1 - t+) of the new point in the norm of H(u+) >= (1 - t)^2 H(u), whose smaller eigenvalue is sigma = 2 det / (tr + sqrt(tr^2 - 4 det)):
-//      |u+ - u*|_2 <= l2 Rtot / (0.718 sqrt(Rmin sigma)).
+//      |u+ - u*|_2 <= l2 Rtot / ((1 - t)^3 (1 - t+) sqrt(Rmin sigma)).
 // nu -> mu is M3's closed form (Optimizer.py:318-330): mu_j = u_j / U, U = u0 + u1 + u2, u0 = (1 - s1 u1 - s2 u2) / tau, so
 // d mu_j = (du_j - mu_j k.du) / U with k = (1 - s1 / tau, 1 - s2 / tau), and |d mu|_inf <= |du|_2 (1.5 + max(1, |mu1| + |mu2|) |k|_2) / U.
 // Hence the step from this evaluation ends within `tol` of the optimum in every component of mu if
-//      l2 <= 0.6398 tol sqrt(Rmin) / Rtot x sqrt(sigma) U / (1.5 + max(1, M) |k|)        (0.9 x 0.718 / 1.01: a 10 % margin)
+//      l2 <= (0.9 / 1.01) (1 - t)^3 (1 - t+) tol sqrt(Rmin) / Rtot x sqrt(sigma) U / (1.5 + max(1, M) |k|)      (a 10 % margin; t taken at the
+//      largest value an evaluation that passes n3_conv_l2 can have on the prefix: 0.718 at t = 0.1, 0.988 on the bench's data)
 // -- the returned limit (c.mu_c holds the first factor).  Away from the simplex (a nu_j < -0.05, or U <= 0: the reference accepts
 // no nu out of [0, 1], Optimizer.py:150-160, so it reports no mixture of the candidate's own there) there is no limit: +inf.
 // tests/test_certified_tolerance_cpu.py checks the chain on random problems.
@@ -375,7 +376,8 @@ __device__ __forceinline__ F sv_mu_limit(const SvCtx<ML, F, NS> &c, F H11, F H22
     const float kn = __builtin_amdgcn_sqrtf(__builtin_fmaf(k1, k1, k2 * k2));
     const float den = __builtin_fmaf(fmaxf(U, au), kn, 1.5f * U);                                   // U (1.5 + max(1, M) |k|)
     const float lim = (float)c.mu_c * __builtin_amdgcn_sqrtf(sig) * U * U * __builtin_amdgcn_rcpf(den);
-    return (n0 >= -0.05f && n1 >= -0.05f && n2 >= -0.05f && U > 0.0f) ? (F)lim : F(__builtin_inff());
+    // (the constant in mu_c assumes t <= the prefix's largest: an evaluation beyond it -- a caller's own, looser n3_conv_l2 -- is not the last)
+    return (n0 >= -0.05f && n1 >= -0.05f && n2 >= -0.05f && U > 0.0f) ? (F)fminf(lim, (float)c.mu_t2) : F(__builtin_inff());
 }
 
 // One evaluation of value, gradient and Hessian at (u1, u2) over the group tile and the record's rows, two terms at a time
@@ -1557,7 +1559,15 @@ __global__ __launch_bounds__(64 * SV_WAVES, sizeof(F) == 4 ? SV_OCC : SV_OCC64) 
         c.S2p = (F)(S2p * inv_N);
         c.rtot_over_rmin = (F)(Pg.Rtot / Rmin);
         c.sqrt_ror = (F)sqrt(Pg.Rtot / Rmin);
-        c.mu_c = (Pg.mu_tol > 0.0 && c.no_dismiss) ? (F)(0.6398 * Pg.mu_tol * sqrt(Rmin) / Pg.Rtot) : F(0);
+        {
+            // (sv_mu_limit's constant: 0.9 / 1.01 x (1 - t)^3 (1 - t+) for the LARGEST t = lambda / sqrt(Rmin) an evaluation that passes
+            // "n3_conv_l2" can have on this prefix -- 0.004 on the bench's data, where the worst case t = 0.1 gave 0.718: the limit is
+            // 1.38 times larger and binds less often)
+            const double tm = fmin(sqrt(Pg.conv_l2 * Pg.Rtot / Rmin), 0.1), tp = (tm / (1.0 - tm)) * (tm / (1.0 - tm));
+            const double fchain = (1.0 - tm) * (1.0 - tm) * (1.0 - tm) * (1.0 - tp);
+            c.mu_c = (Pg.mu_tol > 0.0 && c.no_dismiss) ? (F)((0.9 / 1.01) * fchain * Pg.mu_tol * sqrt(Rmin) / Pg.Rtot) : F(0);
+            c.mu_t2 = (F)(tm * tm * Rmin / Pg.Rtot);                 // ... and the decrement that t corresponds to
+        }
         wave_lds_sync();
         const unsigned it0 = c.n_dit, par0 = c.n_par;
         c.par = n3_unpack(n3_lane_state<NS>(st, D - 1));
