@@ -15,6 +15,11 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "perf: timing assertions, apart from the parity tests (THETA_RUN_PERF=1)")
 
 
+# The full-size variants of the cases that were cut for the GPU suite's time (round-5 advice: kept, behind a switch):
+#   THETA_RUN_SLOW=1 python -m pytest tests -m gpu -k "redo_ladder or tiny or tau3 or two_hundred or prefix_bound or fp64_sieve"
+SLOW = os.environ.get("THETA_RUN_SLOW") == "1"
+
+
 def unfl(x):
     """Inverse of make_golden.fl: JSON-safe float back to float."""
     if isinstance(x, str):

@@ -12,7 +12,7 @@ import numpy as np
 import pytest
 
 import theta_oracle as orc
-from conftest import ROOT
+from conftest import ROOT, SLOW
 
 pytestmark = pytest.mark.gpu
 
@@ -107,7 +107,8 @@ def test_fp64_sieve_and_full_solve_modes_return_the_lists_of_the_shipped_search(
     ra[0], ra[7] = 3, 11
     cases.append(("m16 k3 tiny Rmin", 16, ra, rNa, [0] * 16, [3] * 16, [("mid", 1 << 21)], 2))
     rb, rNb, _ = bench.synth(seed=15, m=12, n=3, k=4)
-    cases.append(("m12 k4 tau3", 12, rb, rNb, [0] * 12, [4] * 12, [("mid", 1 << 27)], 3))      # (round 5: a part of the space, see test_gpu_round4.py)
+    # (round 5: a part of the space for the suite's time; THETA_RUN_SLOW=1: the whole space)
+    cases.append(("m12 k4 tau3", 12, rb, rNb, [0] * 12, [4] * 12, [("all", None)] if SLOW else [("mid", 1 << 27)], 3))
     modes = [("f64", {"n3_force_f64": 1}), ("f64 full solve", {"n3_force_f64": 1, "n3_no_dismiss": 1}), ("f32 full solve", {"n3_no_dismiss": 1}),
              # bench.py's leg full_solve_f64_tight: every candidate iterated to lambda^2 / sum r < 1e-12
              ("f64 tight full solve", {"n3_force_f64": 1, "n3_no_dismiss": 1, "n3_conv_l2": 1e-12}),
@@ -301,7 +302,7 @@ def test_overflowed_contender_lists_walk_the_redo_ladder_without_changing_a_resu
     for prob, rr, rn, b, e in ((p, r, rN, 0, 1 << 21), (p, r, rN, p.count // 3, p.count // 3 + (1 << 22)), (p14, r14, rN14, 0, p14.count)):
         base, fb0, deg0 = _search_mode(ctx, prob, b, e, rr, rn, {})
         for mode in ({}, {"n3_no_dismiss": 1}, {"n3_no_dismiss": 1, "n3_force_f64": 1}):
-            for cap in (2000, 1):                                # (round 5: 50 dropped -- 2000 and 1 walk every rung; the suite's time)
+            for cap in ((2000, 50, 1) if SLOW else (2000, 1)):   # (round 5: 50 dropped -- 2000 and 1 walk every rung; THETA_RUN_SLOW=1: all three)
                 opts = dict(mode, n3_contender_cap=cap)
                 got, fb, deg = _search_mode(ctx, prob, b, e, rr, rn, opts)
                 st = got["stats"]
@@ -312,7 +313,7 @@ def test_overflowed_contender_lists_walk_the_redo_ladder_without_changing_a_resu
                 if st["fallback_candidates"]:
                     walked += 1
                     assert st["redo_kernel_ms"] > 0.0
-    assert walked >= 8                                           # (the small capacities really overflowed)
+    assert walked >= (12 if SLOW else 8)                         # (the small capacities really overflowed)
     p.close()
     p14.close()
 

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 import campaign
-from conftest import ROOT
+from conftest import ROOT, SLOW
 
 pytestmark = pytest.mark.gpu
 
@@ -242,7 +242,7 @@ def test_two_hundred_intervals_on_the_sieve_path(ctx):
     cs = C[:, 1:][order]
     lb = [int(v) for v in cs.min(axis=1)]
     ub = [int(v) for v in cs.max(axis=1)]
-    free = rng.choice(m, 3, replace=False)[:2]         # (two of the three: 986 matrices through scipy instead of 3 908 -- 12 s instead of 46)
+    free = rng.choice(m, 3, replace=False)[:(3 if SLOW else 2)]     # (two of the three: 986 matrices through scipy instead of 3 908 -- 12 s instead of 46; THETA_RUN_SLOW=1: all)
     for i in free:
         lb[i], ub[i] = max(0, lb[i] - 1), min(K, ub[i] + 1)
     cnt = orc.count_n3_exact(m, 2, list(lb), list(ub))
@@ -307,9 +307,9 @@ def test_prefixes_finished_by_the_prefix_bound_change_no_list(ctx):
     ra[0], ra[7] = 3, 11
     # (round 5: the GPU suite's time -- 2^21 instead of 2^24 candidates here, a third of the tau = 3 space instead of the whole: the host
     # side of these two, suspects and rank-deficient lists by the million, was 130 of the suite's 620 seconds)
-    cases.append(("m16 k3 tiny Rmin", 16, ra, rNa, [0] * 16, [3] * 16, [("mid", 1 << 21)], 2))
+    cases.append(("m16 k3 tiny Rmin", 16, ra, rNa, [0] * 16, [3] * 16, [("mid", 1 << (24 if SLOW else 21))], 2))
     rb, rNb, _ = bench.synth(seed=15, m=12, n=3, k=4)
-    cases.append(("m12 k4 tau3", 12, rb, rNb, [0] * 12, [4] * 12, [("mid", 1 << 27)], 3))
+    cases.append(("m12 k4 tau3", 12, rb, rNb, [0] * 12, [4] * 12, [("all", None)] if SLOW else [("mid", 1 << 27)], 3))
     pruned_total = 0
     for name, m, rr, rn, lb, ub, ranges, tau in cases:
         p = theta_amd.Problem(ctx, 3, m, tau, rr, rn, lb, ub, 1.0)
