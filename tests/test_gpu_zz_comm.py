@@ -222,8 +222,9 @@ def test_do_optimization_with_max_processes_shards_over_worker_processes(ctx, mo
 
 def test_a_space_too_large_to_walk_is_searched_by_every_rank_of_a_sharded_run(ctx, monkeypatch):
     """BASELINE config 3 (m = 50, n = 3, k = 4: 4e27 matrices) through do_optimization(..., max_processes) with two ranks sharing this
-    box's GPU: every rank runs the mixture-space branch and bound over the whole space (its incumbent agreed on by the library's
-    all-reduce), rank 0 contributes the records to the ONE exchange, and every rank holds the `best` of do_optimization_single."""
+    box's GPU: every rank takes the dive whole, then walks ITS share of the boxes of the mixture-space branch and bound (round 6: dealt
+    out by position where they become small; the attainable NLL agreed on by the library's all-reduce after every step that can lower
+    it), every rank contributes its records to the ONE exchange, and every rank holds the `best` of do_optimization_single."""
     import bench
     from theta_amd import search as S
     r, rN, order = bench.synth(seed=7, m=50, n=3, k=4)
@@ -231,7 +232,7 @@ def test_a_space_too_large_to_walk_is_searched_by_every_rank_of_a_sharded_run(ct
     assert S.last_report.mix is not None and S.last_report.candidates > 1e27
     monkeypatch.setenv("THETA_NGPU", "2")
     best = S.do_optimization(3, 50, 4, 2, [0] * 50, [4] * 50, r, rN, 1.0, order, 8)
-    assert S.last_report.gpus == 2 and S.last_report.mix is not None
+    assert S.last_report.gpus == 2 and S.last_report.mix is not None and S.last_report.mix["shard"] == [0, 2]
     assert campaign.compare_best(campaign.best_to_plain(best), single) == ""
 
 

@@ -49,6 +49,7 @@ def main():
     ap.add_argument("--seconds", type=float, default=420.0)
     ap.add_argument("--max-candidates", type=int, default=25000)
     ap.add_argument("--shape", choices=["toy", "mid", "low", "amp"], default="toy")
+    ap.add_argument("--seed0", type=int, default=1000, help="first seed - 1 (other rounds' campaigns started at 1000)")
     a = ap.parse_args()
     global SHAPE
     SHAPE = a.shape
@@ -58,7 +59,7 @@ def main():
     ctx = theta_amd.Context(0)
     insts, gpu = [], {}
     t0 = time.time()
-    seed = 1000
+    seed = a.seed0
     want = {2: a.n2, 3: a.n3}
     got = {2: 0, 3: 0}
     while got[2] < want[2] or got[3] < want[3]:
