@@ -1973,7 +1973,7 @@ extern "C" int theta_mix_search(theta_problem *p, double threshold, double leaf_
     // qmin - (T - 1) D <= alpha <= qmax + (T - 1) D.  (Against 0 < q <= U this cuts the valleys along which ONE row of the line meets
     // the data -- the repeated-row matrices, valued apart -- from ~ N / rN_min boxes per scale to a handful: 14.0e6 of the 14.9e6 boxes
     // of config 4's final pass were theirs.)
-    double qmin = 0.0, qmax = U;
+    double qmin = 0.0, qmax = U, qhi_min = INFINITY;
     {
         long double sat = 0;
         for (int i = 0; i < m; i++) {
@@ -1981,7 +1981,7 @@ extern "C" int theta_mix_search(theta_problem *p, double threshold, double leaf_
             sat += r > 0 ? (long double)r - (long double)r * logl((long double)r) : 0.0L;       // phi_i at its minimiser: N t = r
         }
         const double S = (double)((long double)threshold - (long double)A.cst - sat);
-        if (S >= 0.0 && std::isfinite(S) && with_lines) {
+        if (S >= 0.0 && std::isfinite(S)) {
             double lo_all = INFINITY, hi_all = 0.0;
             for (int i = 0; i < m; i++) {
                 const double r = p->h_r[i], Nn = p->h_rN[i];
@@ -2006,17 +2006,31 @@ extern "C" int theta_mix_search(theta_problem *p, double threshold, double leaf_
                 }
                 lo_all = std::min(lo_all, qlo);
                 hi_all = std::max(hi_all, qhi);
+                qhi_min = std::min(qhi_min, qhi);
             }
             qmin = std::max(0.0, lo_all * (1.0 - 1e-9));
             qmax = std::min(U, hi_all * (1.0 + 1e-9));
+            qhi_min = qhi_min * (1.0 + 1e-9);
+        } else if (dive) {
+            // a dive has no threshold to take the ranges from: its root is four times the largest ratio of the data (a heuristic like
+            // the dive itself: the thresholded walk that follows has the rigorous root, and a guard should the dive have missed)
+            double tmax = 0.0;
+            for (int i = 0; i < m; i++) tmax = std::max(tmax, p->h_r[i] / p->h_rN[i]);
+            double mult = 4.0;
+            if (const char *e = getenv("THETA_MIX_DIVE_ROOT")) mult = std::max(1.5, atof(e));
+            qmax = std::min(U, mult * tmax);
+            qhi_min = qmax;
         }
     }
     const double Dq = std::max(qmax - qmin, 0.0);
     if (!lines_only) {
         MixCell root;
         memset(&root, 0, sizeof(root));
-        root.hi[0] = (double)(Rt / (std::max(1, p->tau) * N));
-        root.hi[1] = root.hi[2] = U;
+        // (the same ranges bound the whole alphabet's root: tau v0 <= c_i.v <= qhi_i for EVERY interval, and a v_j that multiplies a
+        // copy number >= 1 somewhere is at most the largest qhi; a column of zeros leaves its v_j without influence, any value does.
+        // Against Rtot / rN_min that is 300 times less per side on the bench's data: sixteen levels of one or two boxes each.)
+        root.hi[0] = std::min((double)(Rt / (std::max(1, p->tau) * N)), qhi_min / std::max(1, p->tau));
+        root.hi[1] = root.hi[2] = qmax;
         roots.push_back(root);
     }
     if (with_lines)

@@ -50,6 +50,7 @@ BNB_MIN_CANDIDATES = int(float(os.environ.get("THETA_BNB_MIN_CANDIDATES", 2 ** 4
 MIX_LEAF_REL = float(os.environ.get("THETA_MIX_LEAF_REL", 0))      # 0: from the data -- a fraction of the radius of the region of mixtures within the window, sqrt(2 window / sum r)
 USE_MIX = os.environ.get("THETA_USE_MIX", "1") != "0"
 MIX_DIVE = os.environ.get("THETA_MIX_DIVE", "1") != "0"        # the attainable NLL the search starts from: a beam search down the tree first (round 6)
+MIX_DIVE_BEAM = int(os.environ.get("THETA_MIX_DIVE_BEAM", 0))           # boxes per level of the dive (0: 512, 1024 for more than 64 intervals)
 MIX_DIVE_LEAF = float(os.environ.get("THETA_MIX_DIVE_LEAF", 1e-3))   # ... down to boxes of this relative size (the best row of every interval at their centres is proposed)
 MIX_FIRST_BOXES = int(float(os.environ.get("THETA_MIX_FIRST_BOXES", 6e6)))   # boxes the first thresholded walk may test before the incumbent is improved instead
 MIX_FIRST_MS = float(os.environ.get("THETA_MIX_FIRST_MS", 400.0))           # ... or run for this long
@@ -622,6 +623,9 @@ def mix_records(problem, ctx, r, rN, max_normal, bounds, report=None, exchange=N
     inc = float("inf")
     if MIX_DIVE:
         td = time.time()
+        # (the beam: 512 boxes per level; 1024 for more than 64 intervals -- on config 5's shape, m = 200, the narrower beam loses the
+        # minimum's basin by 15-40 units for most alignments of the tree, profiles/r6/dive_probe_roots.txt)
+        problem.set_option("mix_beam", MIX_DIVE_BEAM if MIX_DIVE_BEAM else (1024 if problem.m > 64 else 512))
         props, std = problem.mix_search(float("inf"), leaf_rel=max(leaf_final, MIX_DIVE_LEAF), cap=256, dive=True)
         found, n_in = value(props)
         info["dive"] = {"proposals": len(props), "in_space": n_in, "best": found, "boxes": std["boxes_tested"], "ms": std["wall_ms"],
@@ -671,8 +675,8 @@ def mix_records(problem, ctx, r, rN, max_normal, bounds, report=None, exchange=N
         info["first_walk"] = {"gave_up": str(e)[:160]}
     if share(-1.0 if exceeded else 0.0) < 0.0:
         mats = st = None
-        if not heuristic_done:
-            inc = min(inc, heuristic())
+        # (the dive's value is attainable: the ladder below starts from it; the host heuristic -- 20 ms at m = 50, 110 at m = 200 -- only
+        # where the dive found nothing, above)
         inc = share(inc)
         walkable = problem.count <= MIX_WALKABLE
         # (a space the linear walk can finish is not worth more of the clock than the walk itself would take: 2e10 matrices a second;

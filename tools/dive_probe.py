@@ -12,9 +12,9 @@ for name, m, K, seed in (("c3", 50, 4, 7), ("c4", 50, 6, 4242), ("c5", 200, 7, 5
     r, rN, order = bench.synth(seed=seed, m=m, n=3, k=K)
     p = theta_amd.Problem(ctx, 3, m, 2, r, rN, [0] * m, [K] * m, 1.0)
     lb, ub = [0] * m, [K] * m
-    for leaf in (2e-4, 1e-3):
-        for beam in (256, 512, 1024):
-            for w in (0.05, 0.2, 0.5):
+    for leaf in (1e-3,):
+        for beam in (512, 1024):
+            for w in (0.1, 0.2, 0.35, 0.5):
                 p.set_option("mix_beam", beam)
                 p.set_option("mix_dive_blend", w)
                 t0 = time.time()
