@@ -339,3 +339,26 @@ def test_prefixes_finished_by_the_prefix_bound_change_no_list(ctx):
                 known = float(on["nll"].min()) if known is None else min(known, float(on["nll"].min()))
         p.close()
     assert pruned_total > 1 << 22, pruned_total        # (the bound does finish prefixes: most of the bench's far-off ranges)
+
+
+def test_a_batch_of_ranges_whose_lists_overflow_is_split_again(ctx):
+    """Problem.search_ranges runs several rank ranges through the kernels in ONE pass (theta_search_ranges) and halves a batch whose
+    device lists overflow, down to single ranges (round-5 advice: that path had no test).  Forty short ranges, a window that keeps every
+    accepted candidate and a record capacity one range fits but no batch does: the result is the ranges' own searches put together."""
+    import bench
+    import theta_amd
+    m, K = 12, 3
+    r, rN, _order = bench.synth(seed=31, m=m, n=3, k=K)
+    p = theta_amd.Problem(ctx, 3, m, 2, r, rN, [0] * m, [K] * m, 1.0)
+    p.set_option("n3_nan_sweep", 0)
+    ranges = [(b, b + 48) for b in range(100000, 100000 + 40 * 5000, 5000)]
+    one_by_one = []
+    for b, e in ranges:
+        res = p.search(b, e, window=1e15, cap=64)
+        assert len(res["rank"]) <= 64
+        one_by_one += [(int(k), float(v)) for k, v in zip(res["rank"], res["nll"])]
+    assert len(one_by_one) > 64                       # (no batch of all forty fits 64 records)
+    got = p.search_ranges(ranges, window=1e15, cap=64)
+    p.close()
+    pairs = [(int(k), float(v)) for k, v in zip(got["rank"], got["nll"])]
+    assert pairs == sorted(one_by_one)
