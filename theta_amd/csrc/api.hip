@@ -188,7 +188,8 @@ struct theta_problem {
     std::vector<double> h_r, h_rN;                     // the counts as given (sorted order): the per-depth constants of theta_bnb
     DevBuf d_misc2;                                    // task specifications of a search over several ranges
     // the mixture-space search (theta_mix_search): its buffers, allocated at the first call and kept; the lines of the alphabet's grid
-    DevBuf d_mix_stack, d_mix_work, d_mix_leaves, d_mix_ctr, d_mix_mat, d_mix_lines, d_mix_slot, d_mix_iv;
+    DevBuf d_mix_stack, d_mix_work, d_mix_leaves, d_mix_ctr, d_mix_mat, d_mix_lines, d_mix_slot, d_mix_iv, d_mix_seen;
+    unsigned long long mix_seen_mask = 0;
     std::vector<MixLine> mix_lines;
     unsigned mix_chunk = 0;
     unsigned long long mix_stack_cap = 0, mix_leaf_cap = 0;
@@ -2065,7 +2066,11 @@ extern "C" int theta_mix_search(theta_problem *p, double threshold, double leaf_
     if (!propose && !p->d_mix_mat.p) {
         p->mix_mat_cap = std::max<uint64_t>(1ull << 16, (64ull << 20) / (size_t)m);
         if ((rc = p->d_mix_mat.alloc(p->mix_mat_cap * (size_t)m))) return rc;
+        // the table of records seen (mix_list_kernel): 2^24 indices, 64 MB -- room for eight million distinct matrices; beyond, raw
+        p->mix_seen_mask = (1ull << 24) - 1;
+        if ((rc = p->d_mix_seen.alloc((p->mix_seen_mask + 1) * sizeof(unsigned)))) return rc;
     }
+    if (!propose) HIP_TRY(hipMemsetAsync(p->d_mix_seen.p, 0, p->d_mix_seen.bytes, st));
     const bool debug = getenv("THETA_BNB_DEBUG") != nullptr;
     const uint64_t max_tested = p->opt_mix_max_boxes;
     int parity = 0;
@@ -2082,7 +2087,8 @@ extern "C" int theta_mix_search(theta_problem *p, double threshold, double leaf_
             const unsigned long long part = std::min<unsigned long long>(MIX_LEAF_LAUNCH, n_leaves - first);
             const unsigned long long before = h_ctr[MIX_LISTED];
             for (;;) {
-                mix_launch_list(A, d_leaves + first, part, (unsigned char *)p->d_mix_mat.p, p->mix_mat_cap, ~0ull, p->opt_mix_max_steps, d_ctr, st);
+                mix_launch_list(A, d_leaves + first, part, (unsigned char *)p->d_mix_mat.p, p->mix_mat_cap, ~0ull, p->opt_mix_max_steps, d_ctr,
+                                (unsigned *)p->d_mix_seen.p, p->mix_seen_mask, st);
                 list_launches++;
                 unsigned long long got[2];
                 HIP_TRY(hipMemcpyAsync(got, d_ctr + MIX_LISTED, sizeof(got), hipMemcpyDeviceToHost, st));
@@ -2111,6 +2117,9 @@ extern "C" int theta_mix_search(theta_problem *p, double threshold, double leaf_
                 if ((rc = bigger.alloc((size_t)want * m))) return rc;
                 if (before) HIP_TRY(hipMemcpyAsync(bigger.p, p->d_mix_mat.p, (size_t)before * m, hipMemcpyDeviceToDevice, st));
                 HIP_TRY(hipMemcpyAsync(d_ctr + MIX_LISTED, &before, sizeof(before), hipMemcpyHostToDevice, st));
+                // (the table of seen records points into the list: the entries of the launch that overflowed would point at records about
+                // to be rewritten -- the table starts afresh; matrices listed before come once more at worst, the host's sort takes them out)
+                if (p->d_mix_seen.p) HIP_TRY(hipMemsetAsync(p->d_mix_seen.p, 0, p->d_mix_seen.bytes, st));
                 HIP_TRY(hipStreamSynchronize(st));
                 std::swap(p->d_mix_mat.p, bigger.p);
                 std::swap(p->d_mix_mat.bytes, bigger.bytes);

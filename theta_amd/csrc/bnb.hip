@@ -727,11 +727,12 @@ struct MixWalk {
     double cost[MIX_MAX_M][MIX_VIA];
     unsigned char srow[MIX_MAX_M][MIX_VIA];   // the viable rows (row index: slot, or t on a line), ascending
     unsigned char nvia[MIX_MAX_M];            // how many (0xff: more than MIX_VIA -- all rows, costs on the fly)
-    unsigned char cur[MIX_MAX_M], pa[MIX_MAX_M], pb[MIX_MAX_M];
+    unsigned char cur[MIX_MAX_M], pa[MIX_MAX_M], pb[MIX_MAX_M], rec[MIX_MAX_M];
     double part[MIX_MAX_M + 1];
 };
 __global__ __launch_bounds__(64) void mix_list_kernel(MixArgs A, const MixCell *leaves, unsigned long long n_leaves, unsigned char *out, unsigned long long out_cap,
-                                                      unsigned long long per_thread_cap, unsigned long long max_steps, unsigned long long *ctr) {
+                                                      unsigned long long per_thread_cap, unsigned long long max_steps, unsigned long long *ctr, unsigned *seen_tab,
+                                                      unsigned long long seen_mask) {
     __shared__ uchar2 rows[MIX_MAX_Q];
     __shared__ unsigned char slot_of[256];
     __shared__ MixWalk W;
@@ -857,12 +858,54 @@ __global__ __launch_bounds__(64) void mix_list_kernel(MixArgs A, const MixCell *
         W.pb[i] = (unsigned char)b;
         if (i == A.m - 1) {
             if (found < per_thread_cap) {
-                const unsigned long long idx = atomicAdd(&ctr[MIX_LISTED], 1ull);
-                if (idx < out_cap) {
-                    unsigned char *dst = out + idx * (size_t)A.m;
-                    for (int d = 0; d < A.m; d++) {
-                        const int ed = W.cur[d];
-                        dst[d] = (unsigned char)R.slot(W.nvia[d] == 0xffu ? ed : (int)W.srow[d][ed]);
+                // the matrix as slot bytes (in LDS: the walk's own row-index array is needed on), and its hash
+                unsigned long long hsh = 0x9E3779B97F4A7C15ull;
+                for (int d = 0; d < A.m; d++) {
+                    const int ed = W.cur[d];
+                    const unsigned char sl = (unsigned char)R.slot(W.nvia[d] == 0xffu ? ed : (int)W.srow[d][ed]);
+                    W.rec[d] = sl;
+                    hsh = (hsh ^ sl) * 0x100000001B3ull;
+                    hsh ^= hsh >> 29;
+                }
+                // SEEN BEFORE?  Every (leaf, corner) whose budget a matrix meets lists it -- hundreds of times in a wide region, and
+                // a flat likelihood's ten million raw records were four seconds of sorting on the host.  A table of record indices,
+                // open addressing: an entry is published AFTER its record is written, a hit compares the BYTES (exact: a matrix is
+                // never dropped for another's hash), a lost race leaves a duplicate for the host's sort, which stays.
+                bool seen = false;
+                unsigned long long pos = (hsh * 0xD6E8FEB86659FD93ull) >> 32;
+                unsigned long long my = ~0ull;
+                if (seen_tab) {
+                    for (unsigned probe = 0; probe < 64u; probe++, pos++) {
+                        unsigned *slot = seen_tab + (pos & seen_mask);
+                        unsigned e = __hip_atomic_load(slot, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+                        if (e == 0u) {
+                            if (my == ~0ull) {                      // write the record first, then publish it
+                                my = atomicAdd(&ctr[MIX_LISTED], 1ull);
+                                if (my >= out_cap || my >= 0xfffffffeull) break;
+                                unsigned char *dst = out + my * (size_t)A.m;
+                                for (int d = 0; d < A.m; d++) dst[d] = W.rec[d];
+                                __threadfence();
+                            }
+                            const unsigned prev = atomicCAS(slot, 0u, (unsigned)my + 1u);
+                            if (prev == 0u) break;                   // published
+                            e = prev;                                // somebody else took the slot meanwhile: is it the same matrix?
+                        }
+                        if (my == ~0ull) {
+                            const unsigned char *other = out + (size_t)(e - 1u) * A.m;
+                            bool same = true;
+                            for (int d = 0; d < A.m && same; d++) same = other[d] == W.rec[d];
+                            if (same) {
+                                seen = true;
+                                break;
+                            }
+                        }
+                    }
+                }
+                if (!seen && my == ~0ull) {                          // (no table, or 64 probes without an answer: listed as it is)
+                    const unsigned long long idx = atomicAdd(&ctr[MIX_LISTED], 1ull);
+                    if (idx < out_cap) {
+                        unsigned char *dst = out + idx * (size_t)A.m;
+                        for (int d = 0; d < A.m; d++) dst[d] = W.rec[d];
                     }
                 }
             } else {
@@ -971,7 +1014,9 @@ void mix_launch_iteration(const MixArgs &A, MixCell *stack, unsigned long long s
     }
 }
 void mix_launch_list(const MixArgs &A, const MixCell *leaves, unsigned long long n_leaves, unsigned char *out, unsigned long long out_cap,
-                     unsigned long long per_thread_cap, unsigned long long max_steps, unsigned long long *ctr, hipStream_t st) {
+                     unsigned long long per_thread_cap, unsigned long long max_steps, unsigned long long *ctr, unsigned *seen_tab, unsigned long long seen_mask,
+                     hipStream_t st) {
     if (!n_leaves) return;
-    hipLaunchKernelGGL(mix_list_kernel, dim3((unsigned)(8 * n_leaves)), dim3(64), 0, st, A, leaves, n_leaves, out, out_cap, per_thread_cap, max_steps, ctr);
+    hipLaunchKernelGGL(mix_list_kernel, dim3((unsigned)(8 * n_leaves)), dim3(64), 0, st, A, leaves, n_leaves, out, out_cap, per_thread_cap, max_steps, ctr, seen_tab,
+                       seen_mask);
 }

@@ -122,4 +122,5 @@ void mix_launch_iteration(const MixArgs &A, MixCell *stack, unsigned long long s
                           unsigned long long *ctr, int parity, int drop_leaves, unsigned long long n_max, unsigned beam, hipStream_t st);
 #define MIX_BEAM_LIMIT 1024
 void mix_launch_list(const MixArgs &A, const MixCell *leaves, unsigned long long n_leaves, unsigned char *out, unsigned long long out_cap,
-                     unsigned long long per_thread_cap, unsigned long long max_steps, unsigned long long *ctr, hipStream_t st);
+                     unsigned long long per_thread_cap, unsigned long long max_steps, unsigned long long *ctr, unsigned *seen_tab, unsigned long long seen_mask,
+                     hipStream_t st);
