@@ -2074,7 +2074,7 @@ extern "C" int theta_mix_search(theta_problem *p, double threshold, double leaf_
     const bool debug = getenv("THETA_BNB_DEBUG") != nullptr;
     const uint64_t max_tested = p->opt_mix_max_boxes;
     int parity = 0;
-    uint64_t syncs = 0, walked_leaves = 0, list_launches = 0;
+    uint64_t syncs = 0;
     // Walk the leaves collected so far (and empty the list).  The list of matrices is redone with a larger buffer when it overflows
     // (the walk is deterministic; the counter is put back first).
     // The leaves are walked MIX_LEAF_LAUNCH at a time: a walk over the intervals is a serial affair of up to mix_max_steps steps per
@@ -2089,7 +2089,6 @@ extern "C" int theta_mix_search(theta_problem *p, double threshold, double leaf_
             for (;;) {
                 mix_launch_list(A, d_leaves + first, part, (unsigned char *)p->d_mix_mat.p, p->mix_mat_cap, ~0ull, p->opt_mix_max_steps, d_ctr,
                                 (unsigned *)p->d_mix_seen.p, p->mix_seen_mask, st);
-                list_launches++;
                 unsigned long long got[2];
                 HIP_TRY(hipMemcpyAsync(got, d_ctr + MIX_LISTED, sizeof(got), hipMemcpyDeviceToHost, st));
                 HIP_TRY(hipStreamSynchronize(st));
@@ -2133,7 +2132,6 @@ extern "C" int theta_mix_search(theta_problem *p, double threshold, double leaf_
                 return THETA_ERR_CAPACITY;
             }
         }
-        walked_leaves += n_leaves;
         const unsigned long long zero = 0;
         HIP_TRY(hipMemcpyAsync(d_ctr + MIX_LEAVES, &zero, sizeof(zero), hipMemcpyHostToDevice, st));
         h_ctr[MIX_LEAVES] = 0;

@@ -503,7 +503,6 @@ __device__ double mix_cell_bound(const MixArgs &A, const MixCell &c, const uchar
     }
     // per interval of this lane (at most MIX_IVL: m <= 256), across the chunks of rows
     constexpr int MIX_IVL = (MIX_MAX_M + WAVE - 1) / WAVE;
-    const int nmine = (A.m - lane + WAVE - 1) / WAVE;          // intervals lane, lane + 64, ...
     double lb1 = 0.0, cs = 0.0, lbv[8];
     for (int k = 0; k < 8; k++) lbv[k] = 0.0;
     // (a box of m <= 64 intervals: one interval per lane, its state in registers across the chunks; more: the chunks are walked per
@@ -597,7 +596,6 @@ __device__ double mix_cell_bound(const MixArgs &A, const MixCell &c, const uchar
             for (int k = 0; k < 8; k++) lbv[k] += bestv[k];
         }
     }
-    (void)nmine;
     centre = mix_wave_sum(cs) + A.cst;
     lb1 = mix_wave_sum(lb1);
     double lb2 = __builtin_inf();
