@@ -141,6 +141,8 @@ class StandinProblem(_lib.Problem):
         st = {"boxes_tested": 1000, "levels": 10, "max_boxes": 10, "leaves": 5, "listed": 0, "matrices": 0, "lines": 7 if lines else 0, "line_leaves": 0,
               "syncs": 2, "kernel_ms": 0.0, "wall_ms": 0.0, "min_bound": float("inf"), "min_bound_lines": float("inf")}
         self.mix_calls.append(("dive" if dive else "propose" if propose else "list", float(threshold), (g, G)))
+        if not (dive or propose) and getattr(self, "mix_fail_rank", None) == g:
+            raise _lib.ThetaError(_lib.ERR_CAPACITY, "stand-in: this rank's share of the boxes is too much for it")
         if dive or propose:
             # a few matrices of the space, not the best ones: the driver must get to the minimum from a poor start as well
             out = [self.cands[k] for k in range(0, self.count, max(1, self.count // 5))][:cap]

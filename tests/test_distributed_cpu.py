@@ -238,7 +238,7 @@ def test_sharded_driver_over_the_standin_device_equals_the_reference_driver(n, s
         assert ncoll >= 2                                                            # the hint all-reduce and the exchange
 
 
-def _mix_driver_worker(rank, world, port, inst, q):
+def _mix_driver_worker(rank, world, port, inst, q, fail_rank=None):
     try:
         for pth in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
             sys.path.insert(0, pth)
@@ -255,6 +255,7 @@ def _mix_driver_worker(rank, world, port, inst, q):
         def make(c, *a, **k):
             made.append(sd.StandinProblem(c, *a, **k))
             made[-1].standin_mix = True
+            made[-1].mix_fail_rank = fail_rank
             return made[-1]
         _lib.Problem = make
         comm = theta_amd.Comm(None, rank=rank, world=world, addr="127.0.0.1", port=port, transport="host")
@@ -317,6 +318,43 @@ def test_sharded_mixture_space_search_over_the_standin_device(seed, world):
         for b in range(a + 1, world):
             assert not (seen[a] & seen[b])                   # disjoint shares
     assert sum(len(x) for x in seen) >= len(ref)
+
+
+def test_a_rank_whose_share_of_the_boxes_is_too_much_takes_all_ranks_to_the_walks():
+    """Whether the mixture-space search gives up depends on a rank's OWN share of the boxes (round 6): one rank of three gives up in
+    its thresholded walks -- every rank must leave that search at the same collective and fall back to the rank walk together
+    (else the ranks' collectives pair up wrongly, or hang).  Every rank returns the reference's list."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import warnings
+    import campaign
+    import theta_oracle as orc
+    inst = campaign.instance(10010, 3, "toy")
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ref, cnt = orc.search_single(3, inst["m"], inst["tau"], list(inst["lb"]), list(inst["ub"]), inst["r"], inst["rN"], inst["mx"],
+                                     inst["order"])
+    ref = campaign.best_to_plain(ref)
+    world = 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_mix_driver_worker, args=(rk, world, port, inst, q, 1)) for rk in range(world)]
+    for p in procs:
+        p.start()
+    out = {}
+    for _ in range(world):
+        item = q.get(timeout=900)
+        out[item[0]] = item[1:]
+    for p in procs:
+        p.join(30)
+    ncolls = set()
+    for rk in range(world):
+        best, calls, listed, ncoll, mix = out[rk]
+        assert not isinstance(best, str), best
+        assert campaign.compare_best(best, ref) == "", rk                       # (the walk's list: NaN entries included)
+        assert mix is not None and "gave_up" in mix, mix
+        ncolls.add(ncoll)
+    assert len(ncolls) == 1, ncolls
 
 
 def _failing_worker(rank, world, port, inst, fail_rank, fail_in_probe, q):

@@ -713,7 +713,17 @@ def mix_records(problem, ctx, r, rN, max_normal, bounds, report=None, exchange=N
                 info["passes"].append({"leaf": leaf, "gave_up": True})
             inc = share(inc)
         thr = inc + window + 4 * TIE_MARGIN
-        mats, st = final(thr, MIX_MAX_BOXES_SMALL if walkable else 0, left_ms())
+        # (several ranks: whether this walk gives up -- a clock, a capacity -- depends on the rank's own share of the boxes; the ranks
+        # leave TOGETHER, or the one that falls back to the walks would pair its collectives with the wrong ones of the others)
+        err = None
+        try:
+            mats, st = final(thr, MIX_MAX_BOXES_SMALL if walkable else 0, left_ms())
+        except _lib.ThetaError as e:
+            if e.code != _lib.ERR_CAPACITY:
+                raise
+            err = e
+        if share(-1.0 if err is not None else 0.0) < 0.0:
+            raise err if err is not None else _lib.ThetaError(_lib.ERR_CAPACITY, "mixture-space search: another rank's share of the boxes was too much for it")
     if MIX_LINES:
         # ... and the matrices of one repeated row (rank 1: the same value at every mixture), which no tree bounds
         const = problem.constant_matrices()
