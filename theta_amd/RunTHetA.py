@@ -102,7 +102,13 @@ def run_fixed_N(n, args, intervals, resultsfile=None):
     rep = _search.last_report
     print("\tSearched %d candidate matrices in %.2f s on %s (%d finalists)%s" % (
         rep.candidates, rep.seconds, "the GPU" if getattr(rep, "gpus", 1) == 1 else "%d GPU ranks" % rep.gpus, rep.finalists,
-        "" if rep.certificate_complete else "; suspect list overflowed: rerun with a tighter rank range (see DESIGN.md section 5)"))
+        "" if rep.certificate_complete in (True, None) else "; suspect list overflowed: rerun with a tighter rank range (see DESIGN.md section 5)"))
+    mix = getattr(rep, "mix", None)
+    if mix and "gave_up" not in mix:
+        # a space no walk finishes, searched whole over the mixture space: what that covers
+        print("\tWhole space by branch and bound over the mixture space: %d boxes, %d matrices listed; every finite outcome within the tie "
+              "window is among the %d records (rank-deficient matrices: nothing finite below %.3f); NaN outcomes are not listed." % (
+                  mix.get("boxes_tested", 0), mix.get("listed", 0), mix.get("records", 0), mix.get("rank_deficient_bound") or float("nan")))
 
     if getattr(rep, "libm_pow_matches", None) is False:
         print("NOTE: this host's libm rounds pow(x, 2) differently from the one the n=3 kernels restate (glibc >= 2.28, x86-64 with "

@@ -1074,8 +1074,13 @@ def do_optimization_single(n, m, k, tau, lower_bounds, upper_bounds, r, rN, max_
     rep.stats = stats
     rep.candidates = problem.count
     rep.finalists = len(recs)
-    if n == 3 and best:
+    whole = rep.mix is not None and "gave_up" not in rep.mix
+    if n == 3 and best and not whole:
         _certificate(rep, problem, ctx, tau, r, rN, best)
+    elif whole:
+        # (the mixture-space search has no suspects to certify: what it covers and what it cannot is in report.mix -- every finite outcome
+        # within the window, rank-deficient ones included, `rank_deficient_bound`, `nan_complete: False`; round-5 advice)
+        rep.certificate_complete = None
     if n == 3 and hasattr(ctx, "_h"):
         rep.libm_pow_matches = _lib.libm_pow_matches()
     rep.seconds = time.time() - t0
