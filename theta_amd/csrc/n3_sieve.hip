@@ -401,7 +401,9 @@ __device__ __forceinline__ int sv_step(const SvCtx<ML, F, NS> &c, const SvRowsT<
         sv_rcp_lg2(q.y, wy, ly);
         const v2 w = {wx, wy}, l = {lx, ly};
         lg = __builtin_elementwise_fma(R, l, lg);
+#ifndef SV_NO_LGA      // (A/B build: what the error bound's accumulation costs -- tools/ab_build.sh nolga -DSV_NO_LGA; never shipped)
         if constexpr (sizeof(F) == 8) lga = __builtin_elementwise_fma(R, v2{sv_abs(l.x), sv_abs(l.y)}, lga);   // (error bound of the f32 logarithms, sv_beyond)
+#endif
         if constexpr (sizeof(F) == 8) {
             v2 gw = rho * w;
             v2 al = gw * a, be = gw * b;
