@@ -1419,7 +1419,11 @@ __global__ __launch_bounds__(64 * SV_WAVES, sizeof(F) == 4 ? SV_OCC : SV_OCC64) 
     c.second = Pg.no_dismiss && Pg.conv_l2 < 1e-6 && !Pg.no_second;
     // a tolerance only a third evaluation meets (the tight leg, 1e-12): that one in place too where most lanes of a trip need it
     // (measured: tight leg 128.5 -> 121.0 ms per 2^31; at the certified tolerance, where one lane in ten needs a third, +2 %: not taken)
-    c.third_min = Pg.conv_l2 < 1e-10 ? SV_THIRD_MIN : 65;
+    // (round 6: also under n3_mu_tol -- the limit on mu sends one lane in four to a third evaluation, not one in ten: 96.2 -> 95.0 ms)
+    c.third_min = (Pg.conv_l2 < 1e-10 || Pg.mu_tol > 0.0) ? SV_THIRD_MIN : 65;
+#ifdef SV_THIRD_FORCE      // (A/B build: the third evaluation in place from this many lanes on, whatever the tolerance)
+    c.third_min = SV_THIRD_FORCE;
+#endif
     c.wn0 = F(__builtin_nanf(""));                   // (no chain point yet: the simplex centre)
     c.wn1 = c.wn2 = F(0);
     c.qcount = 0;
