@@ -397,10 +397,16 @@ __device__ __forceinline__ int sv_step(const SvCtx<ML, F, NS> &c, const SvRowsT<
         v2 a = x - vs1, b = y - vs2;
         v2 q = __builtin_elementwise_fma(a, vu1, __builtin_elementwise_fma(b, vu2, one));
         F wx, wy, lx, ly;
+#ifdef SV_NO_LOGS      // (A/B build, timing only: what the logarithms of a private evaluation cost; its values are meaningless)
+        wx = sv_rcp(q.x); wy = sv_rcp(q.y); lx = ly = F(0);
+#else
         sv_rcp_lg2(q.x, wx, lx);
         sv_rcp_lg2(q.y, wy, ly);
+#endif
         const v2 w = {wx, wy}, l = {lx, ly};
+#ifndef SV_NO_LOGS
         lg = __builtin_elementwise_fma(R, l, lg);
+#endif
 #ifndef SV_NO_LGA      // (A/B build: what the error bound's accumulation costs -- tools/ab_build.sh nolga -DSV_NO_LGA; never shipped)
         if constexpr (sizeof(F) == 8) lga = __builtin_elementwise_fma(R, v2{sv_abs(l.x), sv_abs(l.y)}, lga);   // (error bound of the f32 logarithms, sv_beyond)
 #endif
