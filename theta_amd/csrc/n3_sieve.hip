@@ -178,6 +178,13 @@ template <> struct SvPlanes<double> {
     }
 };
 
+// (F = double only; the float instantiations' LDS is full to the last 16 bytes -- their holder sits in the padding before pb_pt)
+template <class F> struct SvShp { __device__ __forceinline__ F get(int) const { return F(0); } __device__ __forceinline__ void set(F, F, F) {} };
+template <> struct SvShp<double> {
+    double v[4];
+    __device__ __forceinline__ double get(int k) const { return v[k]; }
+    __device__ __forceinline__ void set(double a, double b, double c) { v[0] = a; v[1] = b; v[2] = c; }
+};
 template <int ML, class F, int NS>
 struct SvWave {
     alignas(16) unsigned short pre[WAVE * NS + 8];      // rows of the prefix, a | b << 8 (NS intervals per lane: 128, or 256 in the wide instantiation)
@@ -190,6 +197,7 @@ struct SvWave {
     SvPlanes<F> par;                                    // per last-level node of the round: shared sums, column sums, point
     unsigned pcode[WAVE];                               // ... and the slots of its path rows (6 bits each) | usable << 31
     unsigned task_line;                                 // a prefix of the task had collinear rows (n3_core.hpp: N3Line)
+    SvShp<F> shp;                                       // the round's shared point (w0, u1, u2) where the nodes' records have no room for it (sv_third)
     double pb_pt[3];                                    // the prefix bound's last point (w0, u1, u2): where the next prefix's bound starts (sv_prefix_beyond)
     Sv4<F> fXY[(N3_MAX_Q + 2) / 2];                     // group tile of the prefix, two terms per entry {a0, a1, b0, b1}
     typename SvWt<F>::T fRR[(N3_MAX_Q + 2) / 2];        // ... and their weights {R0, R1} (an odd last term is paired with weight 0); F = double:
@@ -717,6 +725,24 @@ __device__ __forceinline__ void sv_drain(SvCtx<ML, F, NS> &c) {
 // normalisation.  Children the bound cannot finish go to the queue and continue with full evaluations at their own iterate.
 // Record of a node (SvPlanes, 16 numbers): 0 L, 1..3 T0 T1 T2, 4..9 W00 W01 W02 W11 W12 W22, 10 11 S1 S2, 12..14 w0 u1 u2,
 // 15 sum R |log2 q| (F = double: the error bound of the single-precision logarithms, sv_beyond).
+#ifndef SV_LEAN_FIRST
+#define SV_LEAN_FIRST 1   // tight full-solve modes: the shared evaluation without logarithms, value and bound (the second one has them)
+#endif
+#ifndef SV_THIRD
+#define SV_THIRD 1        // ... and with the cubic correction of its step (third-order sums in the nodes' records; F = double)
+#endif
+template <int ML, class F, int NS>
+__device__ __forceinline__ bool sv_third(const SvCtx<ML, F, NS> &c) { return SV_THIRD && SV_LEAN_FIRST && sizeof(F) == 8 && c.second; }
+__device__ __forceinline__ double sv_pack2(float a, float b) {
+    return __builtin_bit_cast(double, make_uint2(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b)));
+}
+__device__ __forceinline__ void sv_unpack2(double p, float &a, float &b) {
+    const uint2 u = __builtin_bit_cast(uint2, p);
+    a = __builtin_bit_cast(float, u.x);
+    b = __builtin_bit_cast(float, u.y);
+}
+__device__ __forceinline__ void sv_unpack2(float, float &a, float &b) { a = b = 0.0f; }      // (never taken: the float instantiation has no third-order sums)
+
 template <int ML, class F, int NS>
 __device__ __forceinline__ void sv_parent(SvCtx<ML, F, NS> &c, bool take, unsigned code) {
     typedef typename SvVec<F>::v2 v2;
@@ -748,6 +774,15 @@ __device__ __forceinline__ void sv_parent(SvCtx<ML, F, NS> &c, bool take, unsign
     const bool sums_ok = S1 > F(0) && S2 > F(0);
     v2 L = {F(0), F(0)}, T0 = L, T1 = L, T2 = L, W00 = L, W01 = L, W02 = L, W11 = L, W12 = L, W22 = L, LA = L;
     const v2 vw0 = {w0, w0}, vu1 = {u1, u1}, vu2 = {u2, u2};
+    // Third-order sums V_abc = sum R z_a z_b z_c / q^3, z = (1, x, y) (round 6; F = double in the tight modes, sv_third): what the
+    // children's shared step takes its CUBIC correction from.  Single precision: they only shape a correction of a starting point.
+    // Order: 000 001 002 011 012 022 111 112 122 222.
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    const bool third = sv_third<ML, F, NS>(c);
+    f2 V[10];
+#pragma unroll
+    for (int k = 0; k < 10; k++) V[k] = f2{0.0f, 0.0f};
+    if (third && c.lane == 0) c.W->shp.set(w0, u1, u2);      // (read after the syncs below)
     // (rho = sqrt R: gamma = rho / q, T = sum rho gamma (1, x, y), W = sum gamma^2 (1, x, y)(1, x, y)^T; a term outside the
     // domain shows as a NaN / an infinity in L, see sv_step)
     auto body = [&](v2 x, v2 y, v2 R, v2 rho) {
@@ -770,6 +805,16 @@ __device__ __forceinline__ void sv_parent(SvCtx<ML, F, NS> &c, bool take, unsign
             W11 = __builtin_elementwise_fma(gx, gx, W11);
             W12 = __builtin_elementwise_fma(gx, gy, W12);
             W22 = __builtin_elementwise_fma(gy, gy, W22);
+            if (third) {
+                const f2 gf = {(float)ga.x, (float)ga.y}, wf = {(float)w.x, (float)w.y};
+                const f2 xf = {(float)x.x, (float)x.y}, yf = {(float)y.x, (float)y.y};
+                const f2 h = gf * gf * wf, hx = h * xf, hy = h * yf, hxx = hx * xf, hxy = hx * yf, hyy = hy * yf;
+                V[0] += h; V[1] += hx; V[2] += hy; V[3] += hxx; V[4] += hxy; V[5] += hyy;
+                V[6] = __builtin_elementwise_fma(hxx, xf, V[6]);
+                V[7] = __builtin_elementwise_fma(hxx, yf, V[7]);
+                V[8] = __builtin_elementwise_fma(hxy, yf, V[8]);
+                V[9] = __builtin_elementwise_fma(hyy, yf, V[9]);
+            }
         } else {
             v2 t = R * w;
             T0 += t;
@@ -789,24 +834,34 @@ __device__ __forceinline__ void sv_parent(SvCtx<ML, F, NS> &c, bool take, unsign
     // the ~13 group terms of the prefix -- two thirds of a node's terms -- are the same numbers in all 64 lanes.  Lane p takes
     // pair p of the tile; the partial sums meet in LDS (the record planes, free until the nodes' records are written below),
     // twelve lanes add them up, and every lane starts its own path rows from the totals.
-    F tot[12];
+    // (22 numbers per pair with the third-order sums: 33 pairs x 22 < 768, the totals behind them -- the planes hold 1024)
+    constexpr int NT = sizeof(F) == 8 ? 22 : 12;
+    const int nt = third ? 22 : 12;
+    F tot[NT];
     {
         F *scr = (F *)&c.W->par;
-        constexpr int TOT = 512;
+        constexpr int TOT = sizeof(F) == 8 ? 768 : 512;
         if (c.lane < c.GP) {
             const Sv4<F> xy = c.W->fXY[c.lane];
             const typename SvWt<F>::T rr = c.W->fRR[c.lane];
             body(v2{xy.x, xy.y}, v2{xy.z, xy.w}, v2{rr.x, rr.y}, sv_rho<F>(rr));
-            const F part[12] = {L.x + L.y, T0.x + T0.y, T1.x + T1.y, T2.x + T2.y, W00.x + W00.y, W01.x + W01.y, W02.x + W02.y, W11.x + W11.y,
-                                W12.x + W12.y, W22.x + W22.y, LA.x + LA.y, F(0)};
-            Sv2<F> *dst = (Sv2<F> *)(scr + 12 * c.lane);
+            F part[12];
+            part[0] = L.x + L.y; part[1] = T0.x + T0.y; part[2] = T1.x + T1.y; part[3] = T2.x + T2.y; part[4] = W00.x + W00.y; part[5] = W01.x + W01.y;
+            part[6] = W02.x + W02.y; part[7] = W11.x + W11.y; part[8] = W12.x + W12.y; part[9] = W22.x + W22.y; part[10] = LA.x + LA.y; part[11] = F(0);
+            Sv2<F> *dst = (Sv2<F> *)(scr + nt * c.lane);
 #pragma unroll
             for (int k = 0; k < 6; k++) dst[k] = Sv2<F>{part[2 * k], part[2 * k + 1]};
+            if constexpr (sizeof(F) == 8) {
+                if (third) {
+#pragma unroll
+                    for (int k = 0; k < 5; k++) dst[6 + k] = Sv2<F>{(F)(V[2 * k].x + V[2 * k].y), (F)(V[2 * k + 1].x + V[2 * k + 1].y)};
+                }
+            }
         }
         wave_lds_sync();
-        if (c.lane < 12) {
+        if (c.lane < nt) {
             F t = F(0);
-            for (int p = 0; p < c.GP; p++) t += scr[12 * p + c.lane];
+            for (int p = 0; p < c.GP; p++) t += scr[nt * p + c.lane];
             scr[TOT + c.lane] = t;
         }
         wave_lds_sync();
@@ -816,12 +871,28 @@ __device__ __forceinline__ void sv_parent(SvCtx<ML, F, NS> &c, bool take, unsign
             tot[2 * k] = t2.x;
             tot[2 * k + 1] = t2.y;
         }
+        if constexpr (sizeof(F) == 8) {
+            if (third) {
+#pragma unroll
+                for (int k = 6; k < 11; k++) {
+                    const Sv2<F> t2 = ((const Sv2<F> *)(scr + TOT))[k];
+                    tot[2 * k] = t2.x;
+                    tot[2 * k + 1] = t2.y;
+                }
+            }
+        }
         wave_lds_sync();                                   // (the planes are rewritten next)
     }
     if (take) {
         L = v2{tot[0], F(0)}; T0 = v2{tot[1], F(0)}; T1 = v2{tot[2], F(0)}; T2 = v2{tot[3], F(0)};
         W00 = v2{tot[4], F(0)}; W01 = v2{tot[5], F(0)}; W02 = v2{tot[6], F(0)}; W11 = v2{tot[7], F(0)};
         W12 = v2{tot[8], F(0)}; W22 = v2{tot[9], F(0)}; LA = v2{tot[10], F(0)};
+        if constexpr (sizeof(F) == 8) {
+            if (third) {
+#pragma unroll
+                for (int k = 0; k < 10; k++) V[k] = f2{(float)tot[12 + k], 0.0f};
+            }
+        }
         // the ML - 1 path rows: pairs, an odd one with a copy of itself of weight 0
 #pragma unroll
         for (int j = 0; j + 1 < ML - 1; j += 2)
@@ -829,16 +900,24 @@ __device__ __forceinline__ void sv_parent(SvCtx<ML, F, NS> &c, bool take, unsign
         if ((ML - 1) & 1) body(v2{px[ML - 2], px[ML - 2]}, v2{py[ML - 2], py[ML - 2]}, v2{c.leafRf[ML - 2], F(0)}, v2{c.leafRho[ML - 2], F(0)});
         const F Lsum = L.x + L.y;
         const bool usable = sums_ok && sv_abs(Lsum) < F(__builtin_inff());
-        const F rec[16] = {Lsum, T0.x + T0.y, T1.x + T1.y, T2.x + T2.y, W00.x + W00.y, W01.x + W01.y, W02.x + W02.y, W11.x + W11.y,
-                           W12.x + W12.y, W22.x + W22.y, S1, S2, w0, u1, u2, LA.x + LA.y};
+        F rec[16] = {Lsum, T0.x + T0.y, T1.x + T1.y, T2.x + T2.y, W00.x + W00.y, W01.x + W01.y, W02.x + W02.y, W11.x + W11.y,
+                     W12.x + W12.y, W22.x + W22.y, S1, S2, w0, u1, u2, LA.x + LA.y};
+        if constexpr (sizeof(F) == 8) {
+            // (the tight modes' record: neither the value nor its error bound is read, and the point is the wave's -- the five free
+            // slots take the ten third-order sums as pairs of floats)
+            if (third) {
+                rec[0] = sv_pack2(V[0].x + V[0].y, V[1].x + V[1].y);
+                rec[12] = sv_pack2(V[2].x + V[2].y, V[3].x + V[3].y);
+                rec[13] = sv_pack2(V[4].x + V[4].y, V[5].x + V[5].y);
+                rec[14] = sv_pack2(V[6].x + V[6].y, V[7].x + V[7].y);
+                rec[15] = sv_pack2(V[8].x + V[8].y, V[9].x + V[9].y);
+            }
+        }
         c.W->par.put(c.lane, rec);
         c.W->pcode[c.lane] = code | (usable ? 0x80000000u : 0u);
     }
 }
 
-#ifndef SV_LEAN_FIRST
-#define SV_LEAN_FIRST 1   // tight full-solve modes: the shared evaluation without logarithms, value and bound (the second one has them)
-#endif
 #ifndef SV_THIRD_MIN
 #define SV_THIRD_MIN 48   // lanes that must still need an evaluation after the in-place second for a THIRD to be taken in place too (SvCtx.third_min; 65: never)
 #endif
@@ -880,7 +959,11 @@ __device__ __forceinline__ void sv_child_eval(const SvCtx<ML, F, NS> &c, int lo,
     const F s1 = sv_fma(x, Nl, P[10]), s2 = sv_fma(y, Nl, P[11]);
     o.regular = s1 > F(0) && s2 > F(0);
     o.off = c.done + (unsigned)k;
-    const F w0 = P[12], u1 = P[13], u2 = P[14];
+    const bool third = sv_third<ML, F, NS>(c);
+    F w0 = P[12], u1 = P[13], u2 = P[14];
+    if constexpr (sizeof(F) == 8) {
+        if (third) { w0 = c.W->shp.get(0); u1 = c.W->shp.get(1); u2 = c.W->shp.get(2); }
+    }
     const F q = sv_fma(x, u1, sv_fma(y, u2, w0));
     o.ev = o.act && o.regular && (o.code >> 31) && q > F(0);
     // (a lane without a usable point, or with ill-conditioned sums, computes on whatever it has: infinities and NaNs cost nothing
@@ -904,8 +987,38 @@ __device__ __forceinline__ void sv_child_eval(const SvCtx<ML, F, NS> &c, int lo,
     const F zw = sv_fma(s1, u1, sv_fma(s2, u2, w0));
     const bool cond_ok = det > (F)N3_COND_MIN * hh && zw > F(0);          // else: ill-conditioned for these sums
     const F idet = sv_rcp(det);
-    const F d1 = (H22 * G1 - H12 * G2) * idet, d2 = (H11 * G2 - H12 * G1) * idet;
+    F d1 = (H22 * G1 - H12 * G2) * idet, d2 = (H11 * G2 - H12 * G1) * idet;
     const F l2 = (G1 * d1 + G2 * d2) * c.inv_Rtot;
+    if constexpr (sizeof(F) == 8) {
+        // The CUBIC correction of the shared step (Chebyshev's method; round 6).  With D = (-s1 d1 - s2 d2, d1, d2) the Newton direction in
+        // w, the third derivative of sum R ln q along it is 2 V[D, D] (V = the node's third-order sums + the child's own last row), and
+        // the step that cancels the error's quadratic term as well is d + H^-1 c, c_j = V[D, D]_j - s_j V[D, D]_0: the decrement the
+        // FIRST private evaluation finds falls from ~l2^2 to ~l2^3 -- below the certificates' limits for nine candidates in ten instead
+        // of five (profiles/r6/NOTES.md section 10).  Single precision; only with a full step, and dropped where it is not small
+        // against the Newton step itself (far from the optimum the cubic model says nothing).
+        if (third) {
+            float V[10];
+            sv_unpack2(P[0], V[0], V[1]);
+            sv_unpack2(P[12], V[2], V[3]);
+            sv_unpack2(P[13], V[4], V[5]);
+            sv_unpack2(P[14], V[6], V[7]);
+            sv_unpack2(P[15], V[8], V[9]);
+            const float fd1 = (float)d1, fd2 = (float)d2, fs1 = (float)s1, fs2 = (float)s2, fx = (float)x, fy = (float)y;
+            const float D0 = -fs1 * fd1 - fs2 * fd2;
+            const float e = __builtin_fmaf(fx, fd1, __builtin_fmaf(fy, fd2, D0));
+            const float he = (float)tw * (float)w * e * e;
+            const float p00 = D0 * D0, p01 = 2.0f * D0 * fd1, p02 = 2.0f * D0 * fd2, p11 = fd1 * fd1, p12 = 2.0f * fd1 * fd2, p22 = fd2 * fd2;
+            const float o0 = V[0] * p00 + V[1] * p01 + V[2] * p02 + V[3] * p11 + V[4] * p12 + V[5] * p22 + he;
+            const float o1 = V[1] * p00 + V[3] * p01 + V[4] * p02 + V[6] * p11 + V[7] * p12 + V[8] * p22 + he * fx;
+            const float o2 = V[2] * p00 + V[4] * p01 + V[5] * p02 + V[7] * p11 + V[8] * p12 + V[9] * p22 + he * fy;
+            const float c1 = __builtin_fmaf(-fs1, o0, o1), c2 = __builtin_fmaf(-fs2, o0, o2);
+            const float fi = (float)idet, f11 = (float)H11, f12 = (float)H12, f22 = (float)H22;
+            const float k1 = (f22 * c1 - f12 * c2) * fi, k2 = (f11 * c2 - f12 * c1) * fi;
+            const bool small = fabsf(k1) + fabsf(k2) < 0.5f * (fabsf(fd1) + fabsf(fd2)) && l2 <= F(0.09);
+            d1 += small ? (F)k1 : F(0);
+            d2 += small ? (F)k2 : F(0);
+        }
+    }
     F sc, lz = F(0);
     if (lean) sc = sv_rcp(zw); else sv_rcp_lg2(zw, sc, lz);
     const bool num_ok = l2 == l2 && sv_abs(d1) + sv_abs(d2) < F(1e30);
@@ -1353,7 +1466,11 @@ __device__ __noinline__ int sv_next_task(unsigned *ctr) {
 #ifdef SV_WITNESS
 #define n3_sieve_kernel n3_sieve_witness_kernel
 #endif
-template <int ML, class F, int NS>
+__host__ __device__ __forceinline__ bool sv_second_mode(const N3Dev &P) { return P.no_dismiss && P.conv_l2 < 1e-6 && !P.no_second; }
+// SEC = false: the instantiation of the launches that take no second evaluation in place (known on the host: sv_second_mode) -- the
+// tight modes' code (lean shared evaluation, third-order sums, cubic correction) folds away instead of riding along behind
+// wave-uniform branches (the coarse FP64 leg: 2 % with it).  The float instantiations decide at run time as before.
+template <int ML, class F, int NS, bool SEC>
 __global__ __launch_bounds__(64 * SV_WAVES, sizeof(F) == 4 ? SV_OCC : SV_OCC64) void n3_sieve_kernel(N3Dev Pg, SearchArgs A, const N3Task *tasks, const unsigned *stbuf,
                                                                           int ntasks, SvSurvivor *surv, unsigned surv_cap,
                                                                           unsigned *surv_count) {
@@ -1422,7 +1539,7 @@ __global__ __launch_bounds__(64 * SV_WAVES, sizeof(F) == 4 ? SV_OCC : SV_OCC64) 
     c.conv_l2 = (F)Pg.conv_l2;
     c.fine_l2 = sizeof(F) == 8 ? (F)fmin(Pg.conv_l2, 1e-8) : c.conv_l2;
     c.no_dismiss = Pg.no_dismiss;
-    c.second = Pg.no_dismiss && Pg.conv_l2 < 1e-6 && !Pg.no_second;
+    c.second = SEC && (sizeof(F) == 8 || sv_second_mode(Pg));      // (F = double: SEC is the launch's mode itself, n3_launch_sieve)
     // a tolerance only a third evaluation meets (the tight leg, 1e-12): that one in place too where most lanes of a trip need it
     // (measured: tight leg 128.5 -> 121.0 ms per 2^31; at the certified tolerance, where one lane in ten needs a third, +2 %: not taken)
     // (round 6: also under n3_mu_tol -- the limit on mu sends one lane in four to a third evaluation, not one in ten: 96.2 -> 95.0 ms)
@@ -1874,15 +1991,17 @@ void n3_launch_sieve(const N3Dev &P, const SearchArgs &A, const N3Task *tasks, c
     dim3 grid(need < resident ? need : resident), block(64 * SV_WAVES);
     // (NS = prefix intervals per lane: 2 up to 128 intervals -- the instantiation everything is tuned for --, 4 up to 256: BASELINE
     // config 5's shape, m = 200; wider prefix tables in LDS, two blocks per CU)
-#define SV_LAUNCH(MLV, FT, NSV) hipLaunchKernelGGL((n3_sieve_kernel<MLV, FT, NSV>), grid, block, 0, st, P, A, tasks, stbuf, ntasks, surv, surv_cap, surv_count)
-    const bool wide = P.m - P.L > 2 * WAVE;
+#define SV_LAUNCH(MLV, FT, NSV, SECV) hipLaunchKernelGGL((n3_sieve_kernel<MLV, FT, NSV, SECV>), grid, block, 0, st, P, A, tasks, stbuf, ntasks, surv, surv_cap, surv_count)
+#define SV_LAUNCH64(MLV, NSV) do { if (sec) SV_LAUNCH(MLV, double, NSV, true); else SV_LAUNCH(MLV, double, NSV, false); } while (0)
+    const bool wide = P.m - P.L > 2 * WAVE, sec = sv_second_mode(P);
     if (P.force64) {       // FP64 throughout (n3_force_f64): the same kernel on doubles
-        if (P.L <= 4) { if (wide) SV_LAUNCH(4, double, 4); else SV_LAUNCH(4, double, 2); }
-        else { if (wide) SV_LAUNCH(6, double, 4); else SV_LAUNCH(6, double, 2); }
+        if (P.L <= 4) { if (wide) SV_LAUNCH64(4, 4); else SV_LAUNCH64(4, 2); }
+        else { if (wide) SV_LAUNCH64(6, 4); else SV_LAUNCH64(6, 2); }
     } else {
-        if (P.L <= 4) { if (wide) SV_LAUNCH(4, float, 4); else SV_LAUNCH(4, float, 2); }
-        else { if (wide) SV_LAUNCH(6, float, 4); else SV_LAUNCH(6, float, 2); }
+        if (P.L <= 4) { if (wide) SV_LAUNCH(4, float, 4, true); else SV_LAUNCH(4, float, 2, true); }
+        else { if (wide) SV_LAUNCH(6, float, 4, true); else SV_LAUNCH(6, float, 2, true); }
     }
+#undef SV_LAUNCH64
 #undef SV_LAUNCH
 }
 
