@@ -151,6 +151,8 @@ template <class F> __device__ __forceinline__ typename SvVec<F>::v2 sv_rho(const
 template <class F> struct SvPlanes;
 template <> struct SvPlanes<float> {
     float4 q[4][WAVE];
+    __device__ __forceinline__ void put_third(int, float, float, const float (&)[20]) {}       // (never taken: sv_third is for F = double)
+    __device__ __forceinline__ void get_third(int, float &, float &, float (&)[20]) const {}
     __device__ __forceinline__ void put(int n, const float (&v)[16]) {
 #pragma unroll
         for (int k = 0; k < 4; k++) q[k][n] = make_float4(v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]);
@@ -176,14 +178,29 @@ template <> struct SvPlanes<double> {
             v[2 * k] = t.x; v[2 * k + 1] = t.y;
         }
     }
+    // (the tight modes' record: the column sums as doubles, then twenty floats -- six planes of the eight)
+    __device__ __forceinline__ void put_third(int n, double s1, double s2, const float (&f)[20]) {
+        q[0][n] = make_double2(s1, s2);
+#pragma unroll
+        for (int k = 0; k < 5; k++) ((float4 *)&q[1 + k][n])[0] = make_float4(f[4 * k], f[4 * k + 1], f[4 * k + 2], f[4 * k + 3]);
+    }
+    __device__ __forceinline__ void get_third(int n, double &s1, double &s2, float (&f)[20]) const {
+        const double2 t = q[0][n];
+        s1 = t.x; s2 = t.y;
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            const float4 u = ((const float4 *)&q[1 + k][n])[0];
+            f[4 * k] = u.x; f[4 * k + 1] = u.y; f[4 * k + 2] = u.z; f[4 * k + 3] = u.w;
+        }
+    }
 };
 
 // (F = double only; the float instantiations' LDS is full to the last 16 bytes -- their holder sits in the padding before pb_pt)
 template <class F> struct SvShp { __device__ __forceinline__ F get(int) const { return F(0); } __device__ __forceinline__ void set(F, F, F) {} };
 template <> struct SvShp<double> {
-    double v[4];
-    __device__ __forceinline__ double get(int k) const { return v[k]; }
-    __device__ __forceinline__ void set(double a, double b, double c) { v[0] = a; v[1] = b; v[2] = c; }
+    float f[4];            // (single precision: the tight modes' shared step is taken in it throughout, sv_child_eval_third)
+    __device__ __forceinline__ double get(int k) const { return (double)f[k]; }
+    __device__ __forceinline__ void set(double a, double b, double c) { f[0] = (float)a; f[1] = (float)b; f[2] = (float)c; }
 };
 template <int ML, class F, int NS>
 struct SvWave {
@@ -379,7 +396,7 @@ __device__ __forceinline__ F sv_mu_limit(const SvCtx<ML, F, NS> &c, F H11, F H22
     // (the Hessian's entries are sums of at most Rtot K^2: tr^2 and det stay far inside single precision's range)
     const float tr = (float)(H11 + H22), dn = (float)det * __builtin_amdgcn_rcpf(tr * tr);           // det / tr^2 in (0, 1/4]
     const float disc = __builtin_amdgcn_sqrtf(fmaxf(__builtin_fmaf(-4.0f, dn, 1.0f), 0.0f));
-    const float sig = tr * (dn + dn) / (1.0f + disc);                                               // 2 det / (tr + sqrt(tr^2 - 4 det))
+    const float sig = tr * (dn + dn) * __builtin_amdgcn_rcpf(1.0f + disc);                                               // 2 det / (tr + sqrt(tr^2 - 4 det))
     const float au = fabsf(fu1) + fabsf(fu2);
     const float kn = __builtin_amdgcn_sqrtf(__builtin_fmaf(k1, k1, k2 * k2));
     const float den = __builtin_fmaf(fmaxf(U, au), kn, 1.5f * U);                                   // U (1.5 + max(1, M) |k|)
@@ -475,7 +492,10 @@ SV_UNROLL(SV_UNR)
     la = lga.x + lga.y;
     if (!(l2 == l2) || !(sv_abs(d1) + sv_abs(d2) < F(1e30))) return 3;
     F step = F(1);
-    if (l2 > F(0.09)) step = sv_rcp(F(1) + sv_sqrt(l2));
+    if (ballot64(l2 > F(0.09))) {      // (damped phase: rare; a real branch -- if-converted, its square root and reciprocal ran for every evaluation)
+        asm volatile("" ::: "memory");
+        if (l2 > F(0.09)) step = sv_rcp(F(1) + sv_sqrt(l2));
+    }
     // (option n3_mu_tol, wave-uniform: the limit the certificate on mu puts on l2 at THIS point, before the step)
     F conv = c.conv_l2;
     mlim = F(0);
@@ -806,6 +826,7 @@ __device__ __forceinline__ void sv_parent(SvCtx<ML, F, NS> &c, bool take, unsign
             W12 = __builtin_elementwise_fma(gx, gy, W12);
             W22 = __builtin_elementwise_fma(gy, gy, W22);
             if (third) {
+#pragma clang fp contract(off)                                   // (as in sv_child_eval_third: the same roundings in both compilations of this source)
                 const f2 gf = {(float)ga.x, (float)ga.y}, wf = {(float)w.x, (float)w.y};
                 const f2 xf = {(float)x.x, (float)x.y}, yf = {(float)y.x, (float)y.y};
                 const f2 h = gf * gf * wf, hx = h * xf, hy = h * yf, hxx = hx * xf, hxy = hx * yf, hyy = hy * yf;
@@ -902,18 +923,16 @@ __device__ __forceinline__ void sv_parent(SvCtx<ML, F, NS> &c, bool take, unsign
         const bool usable = sums_ok && sv_abs(Lsum) < F(__builtin_inff());
         F rec[16] = {Lsum, T0.x + T0.y, T1.x + T1.y, T2.x + T2.y, W00.x + W00.y, W01.x + W01.y, W02.x + W02.y, W11.x + W11.y,
                      W12.x + W12.y, W22.x + W22.y, S1, S2, w0, u1, u2, LA.x + LA.y};
-        if constexpr (sizeof(F) == 8) {
-            // (the tight modes' record: neither the value nor its error bound is read, and the point is the wave's -- the five free
-            // slots take the ten third-order sums as pairs of floats)
-            if (third) {
-                rec[0] = sv_pack2(V[0].x + V[0].y, V[1].x + V[1].y);
-                rec[12] = sv_pack2(V[2].x + V[2].y, V[3].x + V[3].y);
-                rec[13] = sv_pack2(V[4].x + V[4].y, V[5].x + V[5].y);
-                rec[14] = sv_pack2(V[6].x + V[6].y, V[7].x + V[7].y);
-                rec[15] = sv_pack2(V[8].x + V[8].y, V[9].x + V[9].y);
-            }
+        if (third) {
+            // (the tight modes' record: neither the value nor its error bound is read, the point is the wave's, and the shared step is
+            // taken in single precision -- the sums as floats, the ten third-order sums behind them; the column sums stay doubles)
+            const float rf[20] = {(float)rec[1], (float)rec[2], (float)rec[3], (float)rec[4], (float)rec[5], (float)rec[6], (float)rec[7], (float)rec[8],
+                                  (float)rec[9], V[0].x + V[0].y, V[1].x + V[1].y, V[2].x + V[2].y, V[3].x + V[3].y, V[4].x + V[4].y, V[5].x + V[5].y,
+                                  V[6].x + V[6].y, V[7].x + V[7].y, V[8].x + V[8].y, V[9].x + V[9].y, 0.0f};
+            c.W->par.put_third(c.lane, S1, S2, rf);
+        } else {
+            c.W->par.put(c.lane, rec);
         }
-        c.W->par.put(c.lane, rec);
         c.W->pcode[c.lane] = code | (usable ? 0x80000000u : 0u);
     }
 }
@@ -944,8 +963,111 @@ struct SvChild {
 // chain of ~100 dependent operations; with two or three waves per SIMD that chain's latency, not the issue rate, was what the
 // children phase cost (44 % of the search kernel's wave cycles, profiles/r3).  Without branches the scheduler interleaves the
 // chains of the SV_CPL children a lane takes per trip.
+// The tight modes' shared step (sv_third; F = double), in SINGLE PRECISION throughout: it shapes a starting point -- the child is
+// iterated and valued by its private evaluations in FP64 -- and the cancellation in G = T_j - s_j T_0 (G / T ~ sqrt l2 ~ 1e-2) leaves
+// the step ~5e-6 of itself off, 1e-7 of the point: two orders below what the cubic correction leaves.  Against the FP64 form with the
+// correction in single precision: ~90 vector instructions instead of ~165 per child, six 16-byte LDS reads instead of eight.
+//   The CUBIC correction (Chebyshev's method; round 6): with D = (-s1 d1 - s2 d2, d1, d2) the Newton direction in w, the third
+// derivative of sum R ln q along it is 2 V[D, D] (V = the node's third-order sums + the child's own last row), and the step that
+// cancels the error's quadratic term as well is d + H^-1 c, c_j = V[D, D]_j - s_j V[D, D]_0: the decrement the FIRST private
+// evaluation finds falls from ~l2^2 to ~l2^3 -- below the certificates' limits for nine candidates in ten instead of five
+// (profiles/r6/NOTES.md section 10).  Only with a full step, and dropped where it is not small against the Newton step itself (far
+// from the optimum the cubic model says nothing).  No value, no bound, no convergence here: every child takes a private evaluation.
+template <int ML, class F, int NS>
+__device__ __forceinline__ void sv_child_eval_third(const SvCtx<ML, F, NS> &c, int lo, int k, int nrec, SvChild<F> &o) {
+    // (every multiply-add written out, none left to the optimizer: the witness build is a second compilation of this source, and the
+    // two must take the same roundings -- tests/test_gpu_round5.py compares their counters to the unit)
+#pragma clang fp contract(off)
+    const F Nl = c.leafN[ML - 1];
+    const float Rl = (float)c.leafRf[ML - 1];
+    o.act = k < nrec;
+    const unsigned kd = o.act ? c.W->kid[lo + k] : 0u;
+    o.slot = kd & 0xffu;
+    const unsigned pl = kd >> 8;
+    F S1, S2;
+    float f[20];
+    c.W->par.get_third(pl, S1, S2, f);
+    o.code = c.W->pcode[pl];
+    const unsigned r16 = c.S->row16[o.slot];
+    const float x = (float)(r16 & 0xffu), y = (float)(r16 >> 8);
+    const F s1 = sv_fma((F)(r16 & 0xffu), Nl, S1), s2 = sv_fma((F)(r16 >> 8), Nl, S2);       // (the column sums as every later evaluation takes them)
+    o.regular = s1 > F(0) && s2 > F(0);
+    o.off = c.done + (unsigned)k;
+    const float w0 = (float)c.W->shp.get(0), u1 = (float)c.W->shp.get(1), u2 = (float)c.W->shp.get(2);
+    const float fs1 = (float)s1, fs2 = (float)s2;
+    const float q = __builtin_fmaf(x, u1, __builtin_fmaf(y, u2, w0));
+    o.ev = o.act && o.regular && (o.code >> 31) && q > 0.0f;
+    const float w = __builtin_amdgcn_rcpf(q);
+    const float t = Rl * w, tw = t * w, twx = tw * x, twy = tw * y;
+    const float T0 = f[0] + t, T1 = __builtin_fmaf(t, x, f[1]), T2 = __builtin_fmaf(t, y, f[2]);
+    const float W00 = f[3] + tw, W01 = f[4] + twx, W02 = f[5] + twy;
+    const float W11 = __builtin_fmaf(twx, x, f[6]), W12 = __builtin_fmaf(twx, y, f[7]), W22 = __builtin_fmaf(twy, y, f[8]);
+    const float G1 = __builtin_fmaf(-fs1, T0, T1), G2 = __builtin_fmaf(-fs2, T0, T2);
+    const float A1 = __builtin_fmaf(-fs1, W00, W01), A2 = __builtin_fmaf(-fs2, W00, W02);
+    const float H11 = __builtin_fmaf(-fs1, A1, __builtin_fmaf(-fs1, W01, W11));
+    const float H12 = __builtin_fmaf(-fs2, A1, __builtin_fmaf(-fs1, W02, W12));
+    const float H22 = __builtin_fmaf(-fs2, A2, __builtin_fmaf(-fs2, W02, W22));
+    const float hh = H11 * H22, det = __builtin_fmaf(-H12, H12, hh);
+    const float zw = __builtin_fmaf(fs1, u1, __builtin_fmaf(fs2, u2, w0));
+    const bool cond_ok = det > (float)N3_COND_MIN * hh && zw > 0.0f;
+    const float idet = __builtin_amdgcn_rcpf(det);
+    float d1 = __builtin_fmaf(H22, G1, -(H12 * G2)) * idet, d2 = __builtin_fmaf(H11, G2, -(H12 * G1)) * idet;
+    const float l2 = __builtin_fmaf(G1, d1, G2 * d2) * (float)c.inv_Rtot;
+    const bool num_ok = l2 == l2 && fabsf(d1) + fabsf(d2) < 1e30f;
+    {
+        const float *V = f + 9;      // 000 001 002 011 012 022 111 112 122 222
+        const float D0 = __builtin_fmaf(-fs1, d1, -(fs2 * d2));
+        const float e = __builtin_fmaf(x, d1, __builtin_fmaf(y, d2, D0));
+        const float he = tw * w * e * e;
+        const float p00 = D0 * D0, p01 = 2.0f * D0 * d1, p02 = 2.0f * D0 * d2, p11 = d1 * d1, p12 = 2.0f * d1 * d2, p22 = d2 * d2;
+        const float o0 = __builtin_fmaf(V[0], p00, __builtin_fmaf(V[1], p01, __builtin_fmaf(V[2], p02, __builtin_fmaf(V[3], p11, __builtin_fmaf(V[4], p12, __builtin_fmaf(V[5], p22, he))))));
+        const float o1 = __builtin_fmaf(V[1], p00, __builtin_fmaf(V[3], p01, __builtin_fmaf(V[4], p02, __builtin_fmaf(V[6], p11, __builtin_fmaf(V[7], p12, __builtin_fmaf(V[8], p22, he * x))))));
+        const float o2 = __builtin_fmaf(V[2], p00, __builtin_fmaf(V[4], p01, __builtin_fmaf(V[5], p02, __builtin_fmaf(V[7], p11, __builtin_fmaf(V[8], p12, __builtin_fmaf(V[9], p22, he * y))))));
+        const float c1 = __builtin_fmaf(-fs1, o0, o1), c2 = __builtin_fmaf(-fs2, o0, o2);
+        const float k1 = __builtin_fmaf(H22, c1, -(H12 * c2)) * idet, k2 = __builtin_fmaf(H11, c2, -(H12 * c1)) * idet;
+        const bool small = fabsf(k1) + fabsf(k2) < 0.5f * (fabsf(d1) + fabsf(d2)) && l2 <= 0.09f;
+        d1 += small ? k1 : 0.0f;
+        d2 += small ? k2 : 0.0f;
+    }
+    float step = 1.0f;
+    if (ballot64(l2 > 0.09f)) {                                                                 // (damped phase: rare, the branch is wave-uniform)
+        asm volatile("" ::: "memory");
+        step = l2 > 0.09f ? __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_sqrtf(l2)) : 1.0f;
+    }
+    const float sc = __builtin_amdgcn_rcpf(zw);
+    const float v1 = __builtin_fmaf(step, d1, u1) * sc, v2 = __builtin_fmaf(step, d2, u2) * sc;
+    const bool good = o.ev && cond_ok && num_ok;
+    const float n1 = fs1 * v1, n2 = fs2 * v2;
+    o.n1 = (F)n1;
+    o.n2 = (F)n2;
+    o.c1 = (F)v1;
+    o.c2 = (F)v2;
+    o.chain = good && fabsf(n1) + fabsf(n2) < 1e6f;
+    o.surv = false;
+    o.push = o.act && o.regular;
+    o.qu1 = good ? (F)v1 : F(__builtin_nanf(""));
+    o.qu2 = (F)v2;
+    o.s1 = s1;
+    o.s2 = s2;
+#ifdef SV_WITNESS
+    o.wdone = false;
+    o.wmlim = F(0);
+    o.wconv = false;
+    o.wl2 = (F)l2;
+    o.wval2 = F(0);
+    o.ws1 = s1;
+    o.ws2 = s2;
+#endif
+}
+
 template <int ML, class F, int NS>
 __device__ __forceinline__ void sv_child_eval(const SvCtx<ML, F, NS> &c, int lo, int k, int nrec, SvChild<F> &o) {
+    if constexpr (sizeof(F) == 8) {
+        if (sv_third<ML, F, NS>(c)) {
+            sv_child_eval_third<ML, F, NS>(c, lo, k, nrec, o);
+            return;
+        }
+    }
     const F Rl = c.leafRf[ML - 1], Nl = c.leafN[ML - 1];
     o.act = k < nrec;
     const unsigned kd = o.act ? c.W->kid[lo + k] : 0u;
@@ -959,11 +1081,7 @@ __device__ __forceinline__ void sv_child_eval(const SvCtx<ML, F, NS> &c, int lo,
     const F s1 = sv_fma(x, Nl, P[10]), s2 = sv_fma(y, Nl, P[11]);
     o.regular = s1 > F(0) && s2 > F(0);
     o.off = c.done + (unsigned)k;
-    const bool third = sv_third<ML, F, NS>(c);
-    F w0 = P[12], u1 = P[13], u2 = P[14];
-    if constexpr (sizeof(F) == 8) {
-        if (third) { w0 = c.W->shp.get(0); u1 = c.W->shp.get(1); u2 = c.W->shp.get(2); }
-    }
+    const F w0 = P[12], u1 = P[13], u2 = P[14];
     const F q = sv_fma(x, u1, sv_fma(y, u2, w0));
     o.ev = o.act && o.regular && (o.code >> 31) && q > F(0);
     // (a lane without a usable point, or with ill-conditioned sums, computes on whatever it has: infinities and NaNs cost nothing
@@ -987,43 +1105,16 @@ __device__ __forceinline__ void sv_child_eval(const SvCtx<ML, F, NS> &c, int lo,
     const F zw = sv_fma(s1, u1, sv_fma(s2, u2, w0));
     const bool cond_ok = det > (F)N3_COND_MIN * hh && zw > F(0);          // else: ill-conditioned for these sums
     const F idet = sv_rcp(det);
-    F d1 = (H22 * G1 - H12 * G2) * idet, d2 = (H11 * G2 - H12 * G1) * idet;
+    const F d1 = (H22 * G1 - H12 * G2) * idet, d2 = (H11 * G2 - H12 * G1) * idet;
     const F l2 = (G1 * d1 + G2 * d2) * c.inv_Rtot;
-    if constexpr (sizeof(F) == 8) {
-        // The CUBIC correction of the shared step (Chebyshev's method; round 6).  With D = (-s1 d1 - s2 d2, d1, d2) the Newton direction in
-        // w, the third derivative of sum R ln q along it is 2 V[D, D] (V = the node's third-order sums + the child's own last row), and
-        // the step that cancels the error's quadratic term as well is d + H^-1 c, c_j = V[D, D]_j - s_j V[D, D]_0: the decrement the
-        // FIRST private evaluation finds falls from ~l2^2 to ~l2^3 -- below the certificates' limits for nine candidates in ten instead
-        // of five (profiles/r6/NOTES.md section 10).  Single precision; only with a full step, and dropped where it is not small
-        // against the Newton step itself (far from the optimum the cubic model says nothing).
-        if (third) {
-            float V[10];
-            sv_unpack2(P[0], V[0], V[1]);
-            sv_unpack2(P[12], V[2], V[3]);
-            sv_unpack2(P[13], V[4], V[5]);
-            sv_unpack2(P[14], V[6], V[7]);
-            sv_unpack2(P[15], V[8], V[9]);
-            const float fd1 = (float)d1, fd2 = (float)d2, fs1 = (float)s1, fs2 = (float)s2, fx = (float)x, fy = (float)y;
-            const float D0 = -fs1 * fd1 - fs2 * fd2;
-            const float e = __builtin_fmaf(fx, fd1, __builtin_fmaf(fy, fd2, D0));
-            const float he = (float)tw * (float)w * e * e;
-            const float p00 = D0 * D0, p01 = 2.0f * D0 * fd1, p02 = 2.0f * D0 * fd2, p11 = fd1 * fd1, p12 = 2.0f * fd1 * fd2, p22 = fd2 * fd2;
-            const float o0 = V[0] * p00 + V[1] * p01 + V[2] * p02 + V[3] * p11 + V[4] * p12 + V[5] * p22 + he;
-            const float o1 = V[1] * p00 + V[3] * p01 + V[4] * p02 + V[6] * p11 + V[7] * p12 + V[8] * p22 + he * fx;
-            const float o2 = V[2] * p00 + V[4] * p01 + V[5] * p02 + V[7] * p11 + V[8] * p12 + V[9] * p22 + he * fy;
-            const float c1 = __builtin_fmaf(-fs1, o0, o1), c2 = __builtin_fmaf(-fs2, o0, o2);
-            const float fi = (float)idet, f11 = (float)H11, f12 = (float)H12, f22 = (float)H22;
-            const float k1 = (f22 * c1 - f12 * c2) * fi, k2 = (f11 * c2 - f12 * c1) * fi;
-            const bool small = fabsf(k1) + fabsf(k2) < 0.5f * (fabsf(fd1) + fabsf(fd2)) && l2 <= F(0.09);
-            d1 += small ? (F)k1 : F(0);
-            d2 += small ? (F)k2 : F(0);
-        }
-    }
     F sc, lz = F(0);
     if (lean) sc = sv_rcp(zw); else sv_rcp_lg2(zw, sc, lz);
     const bool num_ok = l2 == l2 && sv_abs(d1) + sv_abs(d2) < F(1e30);
     F step = F(1);
-    if (ballot64(l2 > F(0.09))) step = l2 > F(0.09) ? sv_rcp(F(1) + sv_sqrt(l2)) : F(1);      // (damped phase: rare, the branch is wave-uniform)
+    if (ballot64(l2 > F(0.09))) {                                                              // (damped phase: rare, the branch is wave-uniform)
+        asm volatile("" ::: "memory");                                                          // (... and stays one: not if-converted)
+        step = l2 > F(0.09) ? sv_rcp(F(1) + sv_sqrt(l2)) : F(1);
+    }
     // the stepped point on the child's own slice (z.d = 0, so z.w stays): mixture n_j = s_j u_j / z.w
     const F v1 = sv_fma(step, d1, u1) * sc, v2 = sv_fma(step, d2, u2) * sc;
     const bool good = o.ev && cond_ok && num_ok;
@@ -1142,9 +1233,12 @@ __device__ __forceinline__ void sv_children(SvCtx<ML, F, NS> &c, int total) {
                 SvRowsT<ML, SvTab<F, NS>::v> rows;
                 sv_rows_load<ML, F, NS>(c, o.code, o.slot, rows);
                 F u1 = qu1, u2 = qu2;
-                if (!(u1 == u1)) {                      // (no usable shared point: from the simplex centre)
-                    u1 = F(1.0 / 3.0) * sv_rcp(o.s1);
-                    u2 = F(1.0 / 3.0) * sv_rcp(o.s2);
+                if (ballot64(!(u1 == u1))) {            // (no usable shared point: from the simplex centre -- rare, behind a wave-uniform branch)
+                    asm volatile("" ::: "memory");
+                    if (!(u1 == u1)) {
+                        u1 = F(1.0 / 3.0) * sv_rcp(o.s1);
+                        u2 = F(1.0 / 3.0) * sv_rcp(o.s2);
+                    }
                 }
                 F val2 = F(0), l2 = F(0), la = F(0), mlim = F(0);
                 const int st = sv_step<ML, F, NS>(c, rows, o.s1, o.s2, u1, u2, val2, l2, la, mlim);
