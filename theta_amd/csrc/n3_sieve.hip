@@ -84,6 +84,9 @@ template <class F> struct SvCapL { static constexpr int v = sizeof(F) == 4 ? 160
 #ifndef SV_PULL
 #define SV_PULL 0.02      // the round's shared point = the chain point pulled this far towards the simplex centre
 #endif
+#ifndef SV_FULL_TRIPS
+#define SV_FULL_TRIPS 1   // rounds of the last level in whole trips of 64 children (sv_expand)
+#endif
 #ifndef SV_KIDS
 #define SV_KIDS 768       // children (candidates) of one round of <= 64 last-level nodes
 #endif
@@ -310,6 +313,10 @@ struct SvCtx {
     // the chain point (wave-uniform): where the next round's shared sums are evaluated, see sv_parent
     F wn0, wn1, wn2;
     int qcount;
+    // full trips (round 6): a round of the last level takes only as many nodes as fill whole trips of 64 children; the nodes of its
+    // partial last trip wait for the next round -- at the end of a list at the front of listL, behind which the next fill is written
+    // (carryL of them).  final_path: this expansion is the prefix's last at every level above -- nothing follows, so nothing is held back.
+    int carryL, final_path;
     // statistics (wave-uniform scalars)
     // (32 bits each: a task holds < 2^16 candidates.  Degenerate candidates and contenders are counted where they are listed --
     // rare paths --, `dismissed` follows on the host: every regular candidate ends dismissed or listed.  Round 2 kept nine 64-bit
@@ -1330,9 +1337,10 @@ __device__ __forceinline__ void sv_expand(SvCtx<ML, F, NS> &c, int n_in) {
         bool live = i < n_in;
         N3State node = c.par;
         unsigned code = 0;                                 // slots of rows D .. D+LVL-1, 6 bits each
+        uint2 e = make_uint2(0u, 0u);
         if (LVL > 0) {
             if (live) {
-                const uint2 e = (LVL == 1) ? c.W->list0[i] : (LVL == ML - 1) ? c.W->listL[i] : c.W->list[LVL >= 2 && LVL < ML - 1 ? LVL - 2 : 0][i];
+                e = (LVL == 1) ? c.W->list0[i] : (LVL == ML - 1) ? c.W->listL[i] : c.W->list[LVL >= 2 && LVL < ML - 1 ? LVL - 2 : 0][i];
                 const N3State pst = n3_unpack(e.x);
                 const unsigned slot = e.y >> 24;
                 sv_child_dyn<ML, F, NS>(c, pst, (int)slot, node);
@@ -1367,9 +1375,37 @@ __device__ __forceinline__ void sv_expand(SvCtx<ML, F, NS> &c, int n_in) {
         unsigned long long mk = live ? sv_child_mask(c, node, LVL) : 0ull;
         const int cnt = __builtin_popcountll(mk);
         const int incl = sv_incl_scan(cnt);
-        const int t = __builtin_popcountll(ballot64(live && incl <= cap));   // nodes whose children all fit (a prefix of the lanes)
-        const int total = __builtin_amdgcn_readlane(incl, t - 1);
+        // (LVL = ML - 2: the list of last-level nodes starts behind the nodes carried over from the previous fill)
+        const int carry_in = (LVL == ML - 2 && !last) ? c.carryL : 0;
+        int t = __builtin_popcountll(ballot64(live && incl <= cap - carry_in));   // nodes whose children all fit (a prefix of the lanes)
+        int total = __builtin_amdgcn_readlane(incl, t - 1);
         const int off = incl - cnt;
+        int carry_out = 0;
+        if constexpr (last) {
+#if SV_FULL_TRIPS
+            // (The tight modes, where a child costs a private evaluation or more: 78.5 -> 76.4 ms per 2^31 on the certified leg.  Where most
+            // children are finished by the shared evaluation the fewer nodes per round cost the parent phase more than the trips gain:
+            // the coarse FP64 leg 45.2 -> 46.1 ms -- not taken there.)
+            // Whole trips only: with `full` = the largest multiple of 64 children the round's nodes reach, the nodes beyond it are left --
+            // to the next round of this list, or (the list's last round) carried to the next fill.  A node has < 64 children, so a
+            // round with >= 64 always keeps its first node; one with fewer is taken as it is when more nodes follow in the list (64
+            // nodes of at most one child each), and carried whole when they do not.
+            const bool more = pos + t < n_in;
+            const int full = total & ~63;
+            if (c.second && full != total && (more ? full >= 64 : !c.final_path)) {
+                const int tt = full >= 64 ? __builtin_popcountll(ballot64(live && incl <= full)) : 0;
+                if (!more) {
+                    carry_out = t - tt;
+                    wave_lds_sync();                                  // (every lane has read its entry)
+                    if (live && c.lane >= tt && c.lane < t) c.W->listL[c.lane - tt] = e;
+                }
+                t = tt;
+                total = tt ? __builtin_amdgcn_readlane(incl, tt - 1) : 0;
+            }
+            c.carryL = carry_out;
+            if (t == 0) break;                                        // (everything carried: the list is done)
+#endif
+        }
         const bool take = live && c.lane < t;
         if constexpr (last) {
             if (take) {
@@ -1417,7 +1453,7 @@ __device__ __forceinline__ void sv_expand(SvCtx<ML, F, NS> &c, int n_in) {
 #endif
             const unsigned ps = n3_pack(node);
             if (take) {
-                uint2 *dst = ((LVL == 0) ? c.W->list0 : (LVL == ML - 2) ? c.W->listL : c.W->list[LVL >= 1 && LVL < ML - 2 ? LVL - 1 : 0]) + off;
+                uint2 *dst = ((LVL == 0) ? c.W->list0 : (LVL == ML - 2) ? c.W->listL : c.W->list[LVL >= 1 && LVL < ML - 2 ? LVL - 1 : 0]) + off + carry_in;
                 unsigned mlo = (unsigned)mk, mhi = (unsigned)(mk >> 32);
                 while (mlo) {
                     const unsigned s = (unsigned)__builtin_ctz(mlo);
@@ -1431,11 +1467,16 @@ __device__ __forceinline__ void sv_expand(SvCtx<ML, F, NS> &c, int n_in) {
                 }
             }
             wave_lds_sync();
-            sv_expand<ML, LVL + 1, F, NS>(c, total);
+            {
+                const int fp = c.final_path;
+                c.final_path = fp && pos + t >= n_in;
+                sv_expand<ML, LVL + 1, F, NS>(c, total + carry_in);
+                c.final_path = fp;
+            }
             wave_lds_sync();
         }
         if (c.remaining == 0) return;
-        pos += t;
+        pos += t + carry_out;
     }
 }
 
@@ -1816,6 +1857,8 @@ __global__ __launch_bounds__(64 * SV_WAVES, sizeof(F) == 4 ? SV_OCC : SV_OCC64) 
         SV_CYC(c.pt[0] += __builtin_amdgcn_s_memtime() - pg0);
 #endif
         if (!pruned) {
+            c.carryL = 0;
+            c.final_path = 1;
             sv_expand<ML, 0, F, NS>(c, 1);
             if (c.qcount) sv_drain<ML, F, NS, true>(c);           // the tile changes with the prefix: the queue is emptied first
         }
