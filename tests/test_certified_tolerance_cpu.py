@@ -110,12 +110,12 @@ def mu_of(u, s1, s2, tau):
 def mu_bound(l2, R, H, u, s1, s2, tau):
     """The certificate's bound on |mu(u+) - mu(u*)|_inf, u+ = u + Newton step, from what the evaluation at u has at hand: with
     t = lambda / sqrt(Rmin) <= 0.1 the step ends at lambda+^2 <= lambda^4 / (Rmin (1 - t)^4), the minimiser lies within
-    lambda+ / (1 - t+) of u+ in the norm of H(u+) >= (1 - t)^2 H(u), whose smaller eigenvalue is 2 det / (tr + sqrt(tr^2 - 4 det));
+    lambda+ / (1 - t+) of u+ in the norm of H(u+) >= (1 - t)^2 H(u), whose smaller eigenvalue is 2 det / (tr + sqrt(tr^2 - 4 det)) >= det / tr;
     d mu_j = (du_j - mu_j (k . du)) / U, k = (1 - s1 / tau, 1 - s2 / tau), U = u0 + u1 + u2, so
     |d mu|_inf <= |du|_2 (1.5 + max(1, |mu1| + |mu2|) |k|_2) / U.  (n3_sieve.hip: sv_mu_limit is this bound solved for l2.)"""
     Rtot, Rmin = R.sum(), R.min()
     tr, det = np.trace(H), np.linalg.det(H)
-    sig = 2.0 * det / (tr + np.sqrt(tr * tr - 4.0 * det))
+    sig = det / tr                  # (<= the smaller eigenvalue 2 det / (tr + sqrt(tr^2 - 4 det)): what sv_mu_limit takes)
     U = (1.0 - s1 * u[0] - s2 * u[1]) / tau + u[0] + u[1]
     M = max(1.0, (abs(u[0]) + abs(u[1])) / U)
     J = (1.5 + M * np.hypot(1.0 - s1 / tau, 1.0 - s2 / tau)) / U

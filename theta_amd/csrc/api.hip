@@ -1263,14 +1263,15 @@ static void fill_search_stats(theta_problem *p, const SearchCounters &hc, unsign
             // decrement, value and bound (FLOPS_PER_SIEVE_CHILD) + the Newton-Raphson steps of its three reciprocals and the
             // error-bound terms (+ 16), two logarithms and two reciprocal seeds in single precision.
             const double full = (double)(k.terms - k.terms64);
-            // (round 6, the tight modes -- sv_third in n3_sieve.hip: a node's shared evaluation also takes the third-order sums, 7 mul,
-            // 6 add, 4 fma per term in single precision; a child's shared step is single precision throughout, ~150 operations with its
-            // cubic correction, and two FP64 fma for its column sums)
+            // (round 6, the tight modes -- sv_third in n3_sieve.hip: the shared evaluations only shape starting points and are single
+            // precision throughout.  A term of a node's sums, sv_parent_third: 2 fma (q), rcp, min, 3 mul + add + 2 fma (T), add, 2 mul,
+            // 2 add, 3 fma (W), 6 mul, 6 add, 4 fma (third-order sums) = 45; a child, sv_child_eval_third: ~150 with its cubic
+            // correction, and two FP64 fma for its column sums)
             const bool third = p->n3.no_dismiss && p->n3.conv_l2 < 1e-6 && !p->n3.no_second;
             f64 = (uint64_t)(per * ((double)k.terms64 + (double)k.finish_iterations * (double)p->m) +
-                             27.0 * full + 33.0 * (double)k.sieve_pterms +
+                             27.0 * full + (third ? 0.0 : 33.0) * (double)k.sieve_pterms +
                              (third ? 4.0 : FLOPS_PER_SIEVE_CHILD + 16.0) * (double)k.sieve_children + fin * (double)k.final_terms);
-            f32 = (uint64_t)((2.0 + (third ? 21.0 : 0.0)) * (double)k.sieve_pterms + 2.0 * full + (third ? 150.0 : 4.0) * (double)k.sieve_children);
+            f32 = (uint64_t)((third ? 45.0 : 2.0) * (double)k.sieve_pterms + 2.0 * full + (third ? 150.0 : 4.0) * (double)k.sieve_children);
         } else {   // n=3: FP64 iterations (dump, ill-conditioned candidates, the finish kernel: m terms each) + the packed-f32
                    // coarse pass and screen
             f64 = (uint64_t)(per * ((double)k.terms64 + (double)k.finish_iterations * (double)p->m));

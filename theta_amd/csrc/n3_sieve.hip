@@ -382,7 +382,7 @@ template <int ML> struct SvRowsT<ML, true> {
 // ---- the tolerance ON MU as a certificate (option "n3_mu_tol"; round 6) ---------------------------------------------------------
 // An evaluation at u has the decrement lambda (l2 = lambda^2 / Rtot) and the tangent Hessian H.  With t = lambda / sqrt(Rmin) <= 0.1
 // (f / Rmin is self-concordant) one full Newton step ends at lambda+^2 <= lambda^4 / (Rmin (1 - t)^4); the minimiser u* then lies within
-// lambda+ / (1 - t+) of the new point in the norm of H(u+) >= (1 - t)^2 H(u), whose smaller eigenvalue is sigma = 2 det / (tr + sqrt(tr^2 - 4 det)):
+// lambda+ / (1 - t+) of the new point in the norm of H(u+) >= (1 - t)^2 H(u), whose smaller eigenvalue is sigma = 2 det / (tr + sqrt(tr^2 - 4 det)) >= det / tr:
 //      |u+ - u*|_2 <= l2 Rtot / ((1 - t)^3 (1 - t+) sqrt(Rmin sigma)).
 // nu -> mu is M3's closed form (Optimizer.py:318-330): mu_j = u_j / U, U = u0 + u1 + u2, u0 = (1 - s1 u1 - s2 u2) / tau, so
 // d mu_j = (du_j - mu_j k.du) / U with k = (1 - s1 / tau, 1 - s2 / tau), and |d mu|_inf <= |du|_2 (1.5 + max(1, |mu1| + |mu2|) |k|_2) / U.
@@ -392,22 +392,24 @@ template <int ML> struct SvRowsT<ML, true> {
 // -- the returned limit (c.mu_c holds the first factor).  Away from the simplex (a nu_j < -0.05, or U <= 0: the reference accepts
 // no nu out of [0, 1], Optimizer.py:150-160, so it reports no mixture of the candidate's own there) there is no limit: +inf.
 // tests/test_certified_tolerance_cpu.py checks the chain on random problems.
-// (Single precision throughout: the limit carries a 10 % margin, and the chain's only cancellation -- tr^2 - 4 det -- is taken in the
-// stable form.  A dozen vector instructions per evaluation, one reciprocal.)
+// (Single precision throughout: the limit carries a 10 % margin and the chain has no cancellation.  The limit is taken with det / tr for
+// sigma.)
 template <int ML, class F, int NS>
 __device__ __forceinline__ F sv_mu_limit(const SvCtx<ML, F, NS> &c, F H11, F H22, F det, F s1, F s2, F u1, F u2) {
     const float fs1 = (float)s1, fs2 = (float)s2, fu1 = (float)u1, fu2 = (float)u2, it = (float)c.inv_tau;
     const float n1 = fs1 * fu1, n2 = fs2 * fu2, n0 = 1.0f - n1 - n2;
     const float k1 = __builtin_fmaf(-fs1, it, 1.0f), k2 = __builtin_fmaf(-fs2, it, 1.0f);
     const float U = __builtin_fmaf(n0, it, fu1 + fu2);
-    // (the Hessian's entries are sums of at most Rtot K^2: tr^2 and det stay far inside single precision's range)
-    const float tr = (float)(H11 + H22), dn = (float)det * __builtin_amdgcn_rcpf(tr * tr);           // det / tr^2 in (0, 1/4]
-    const float disc = __builtin_amdgcn_sqrtf(fmaxf(__builtin_fmaf(-4.0f, dn, 1.0f), 0.0f));
-    const float sig = tr * (dn + dn) * __builtin_amdgcn_rcpf(1.0f + disc);                                               // 2 det / (tr + sqrt(tr^2 - 4 det))
+    // (The smaller eigenvalue through its lower bound det / tr -- sigma = det / the larger one, and that one is below the trace: within
+    // a factor 2, and nearly exact where the Hessian is ill-conditioned, which is where the limit binds.  The whole limit then takes ONE
+    // reciprocal and ONE square root: mu_c U^2 sqrt(det / (tr den^2)).  Round 6's first form took the eigenvalue itself -- two square
+    // roots, three reciprocals: 4 % of the certified leg.  The Hessian's entries are sums of at most Rtot K^2, den is O(1): single
+    // precision's range holds tr den^2 and det.)
+    const float tr = (float)(H11 + H22);
     const float au = fabsf(fu1) + fabsf(fu2);
     const float kn = __builtin_amdgcn_sqrtf(__builtin_fmaf(k1, k1, k2 * k2));
     const float den = __builtin_fmaf(fmaxf(U, au), kn, 1.5f * U);                                   // U (1.5 + max(1, M) |k|)
-    const float lim = (float)c.mu_c * __builtin_amdgcn_sqrtf(sig) * U * U * __builtin_amdgcn_rcpf(den);
+    const float lim = (float)c.mu_c * (U * U) * __builtin_amdgcn_sqrtf((float)det * __builtin_amdgcn_rcpf(tr * (den * den)));
     // (the constant in mu_c assumes t <= the prefix's largest: an evaluation beyond it -- a caller's own, looser n3_conv_l2 -- is not the last)
     return (n0 >= -0.05f && n1 >= -0.05f && n2 >= -0.05f && U > 0.0f) ? (F)fminf(lim, (float)c.mu_t2) : F(__builtin_inff());
 }
@@ -500,8 +502,9 @@ SV_UNROLL(SV_UNR)
     if (!(l2 == l2) || !(sv_abs(d1) + sv_abs(d2) < F(1e30))) return 3;
     F step = F(1);
     if (ballot64(l2 > F(0.09))) {      // (damped phase: rare; a real branch -- if-converted, its square root and reciprocal ran for every evaluation)
-        asm volatile("" ::: "memory");
-        if (l2 > F(0.09)) step = sv_rcp(F(1) + sv_sqrt(l2));
+        F l2l = l2;
+        asm volatile("" : "+v"(l2l));
+        if (l2 > F(0.09)) step = sv_rcp(F(1) + sv_sqrt(l2l));
     }
     // (option n3_mu_tol, wave-uniform: the limit the certificate on mu puts on l2 at THIS point, before the step)
     F conv = c.conv_l2;
@@ -760,18 +763,127 @@ __device__ __forceinline__ void sv_drain(SvCtx<ML, F, NS> &c) {
 #endif
 template <int ML, class F, int NS>
 __device__ __forceinline__ bool sv_third(const SvCtx<ML, F, NS> &c) { return SV_THIRD && SV_LEAN_FIRST && sizeof(F) == 8 && c.second; }
-__device__ __forceinline__ double sv_pack2(float a, float b) {
-    return __builtin_bit_cast(double, make_uint2(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b)));
+template <int ML, class F, int NS>
+__device__ __forceinline__ void sv_shared_point(const SvCtx<ML, F, NS> &c, F S1, F S2, F &w0, F &u1, F &u2) {
+    const F S1c = sv_bcast0(S1), S2c = sv_bcast0(S2);
+    const bool c_ok = S1c > F(0) && S2c > F(0);
+    const F c1 = F(1.0 / 3.0) * sv_rcp(c_ok ? S1c : F(1)), c2 = F(1.0 / 3.0) * sv_rcp(c_ok ? S2c : F(1));
+    const F b0 = sv_bcast0(c.wn0), b1 = sv_bcast0(c.wn1), b2 = sv_bcast0(c.wn2);
+    const bool have = b0 == b0;
+    w0 = have ? sv_fma(F(1.0 - SV_PULL), b0, F(SV_PULL / 3.0)) : F(1.0 / 3.0);
+    u1 = have ? sv_fma(F(1.0 - SV_PULL), b1, F(SV_PULL) * c1) : c1;
+    u2 = have ? sv_fma(F(1.0 - SV_PULL), b2, F(SV_PULL) * c2) : c2;
 }
-__device__ __forceinline__ void sv_unpack2(double p, float &a, float &b) {
-    const uint2 u = __builtin_bit_cast(uint2, p);
-    a = __builtin_bit_cast(float, u.x);
-    b = __builtin_bit_cast(float, u.y);
+
+// The tight modes' nodes (sv_third; F = double): the shared sums only shape the children's starting points (sv_child_eval_third), so they
+// are taken in SINGLE PRECISION, two terms per packed instruction -- T = sum R z / q, W = sum R z z^T / q^2 and the third-order sums
+// V_abc = sum R z_a z_b z_c / q^3 (z = (1, x, y); order 000 001 002 011 012 022 111 112 122 222) the cubic correction is made of: 34
+// vector instructions per pair of terms where the FP64 sums with V in floats behind them took ~95.  Accumulation over ~19 terms leaves
+// the step ~2e-5 of itself off, 4e-7 of the point: below what the correction leaves.  No value: a term outside the domain shows in the
+// smallest q.  The column sums stay doubles (they are every later evaluation's).  Contraction off, every multiply-add written out:
+// the witness build must take the same roundings.
+template <int ML, class F, int NS>
+__device__ __forceinline__ void sv_parent_third(SvCtx<ML, F, NS> &c, bool take, unsigned code) {
+#pragma clang fp contract(off)
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    float px[ML - 1], py[ML - 1];
+    F S1 = c.S1p, S2 = c.S2p;
+#pragma unroll
+    for (int j = 0; j < ML - 1; j++) {
+        const unsigned r16 = c.S->row16[(code >> (6 * j)) & 63u];
+        px[j] = (float)(r16 & 0xffu);
+        py[j] = (float)(r16 >> 8);
+        S1 = sv_fma((F)(r16 & 0xffu), c.leafN[j], S1);
+        S2 = sv_fma((F)(r16 >> 8), c.leafN[j], S2);
+    }
+    F w0d, u1d, u2d;
+    sv_shared_point<ML, F, NS>(c, S1, S2, w0d, u1d, u2d);
+    const bool sums_ok = S1 > F(0) && S2 > F(0);
+    if (c.lane == 0) c.W->shp.set(w0d, u1d, u2d);             // (read by the children after the syncs below)
+    const float w0 = (float)w0d, u1 = (float)u1d, u2 = (float)u2d;
+    const f2 vw0 = {w0, w0}, vu1 = {u1, u1}, vu2 = {u2, u2}, zero = {0.0f, 0.0f};
+    f2 A[19];                                                  // T0 T1 T2 W00 W01 W02 W11 W12 W22 V000 .. V222
+#pragma unroll
+    for (int k = 0; k < 19; k++) A[k] = zero;
+    float qmin = __builtin_inff();
+    auto body = [&](f2 x, f2 y, f2 R) {
+        const f2 q = __builtin_elementwise_fma(x, vu1, __builtin_elementwise_fma(y, vu2, vw0));
+        qmin = __builtin_fminf(qmin, __builtin_fminf(q.x, q.y));
+        const f2 w = {__builtin_amdgcn_rcpf(q.x), __builtin_amdgcn_rcpf(q.y)};
+        const f2 t = R * w, tw = t * w, twx = tw * x, twy = tw * y;
+        A[0] += t;
+        A[1] = __builtin_elementwise_fma(t, x, A[1]);
+        A[2] = __builtin_elementwise_fma(t, y, A[2]);
+        A[3] += tw; A[4] += twx; A[5] += twy;
+        A[6] = __builtin_elementwise_fma(twx, x, A[6]);
+        A[7] = __builtin_elementwise_fma(twx, y, A[7]);
+        A[8] = __builtin_elementwise_fma(twy, y, A[8]);
+        const f2 h = tw * w, hx = h * x, hy = h * y, hxx = hx * x, hxy = hx * y, hyy = hy * y;
+        A[9] += h; A[10] += hx; A[11] += hy; A[12] += hxx; A[13] += hxy; A[14] += hyy;
+        A[15] = __builtin_elementwise_fma(hxx, x, A[15]);
+        A[16] = __builtin_elementwise_fma(hxx, y, A[16]);
+        A[17] = __builtin_elementwise_fma(hxy, y, A[17]);
+        A[18] = __builtin_elementwise_fma(hyy, y, A[18]);
+    };
+    // the group tile's part, once per round: lane p takes pair p, the partial sums (and the smallest q) meet in LDS -- the record
+    // planes, free until the records are written below --, twenty lanes add them up, every lane starts its path rows from the totals
+    float tot[20];
+    {
+        float *scr = (float *)&c.W->par;
+        constexpr int TOT = 704;                               // (33 pairs x 20 floats before it; the planes hold 2048)
+        if (c.lane < c.GP) {
+            const Sv4<F> xy = c.W->fXY[c.lane];
+            const typename SvWt<F>::T rr = c.W->fRR[c.lane];
+            body(f2{(float)xy.x, (float)xy.y}, f2{(float)xy.z, (float)xy.w}, f2{(float)rr.x, (float)rr.y});
+            float4 *dst = (float4 *)(scr + 20 * c.lane);
+#pragma unroll
+            for (int k = 0; k < 4; k++) dst[k] = make_float4(A[4 * k].x + A[4 * k].y, A[4 * k + 1].x + A[4 * k + 1].y, A[4 * k + 2].x + A[4 * k + 2].y, A[4 * k + 3].x + A[4 * k + 3].y);
+            dst[4] = make_float4(A[16].x + A[16].y, A[17].x + A[17].y, A[18].x + A[18].y, qmin);
+        }
+        wave_lds_sync();
+        if (c.lane < 20) {
+            float t = c.lane == 19 ? __builtin_inff() : 0.0f;
+            for (int p = 0; p < c.GP; p++) {
+                const float v = scr[20 * p + c.lane];
+                t = c.lane == 19 ? __builtin_fminf(t, v) : t + v;
+            }
+            scr[TOT + c.lane] = t;
+        }
+        wave_lds_sync();
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            const float4 t4 = ((const float4 *)(scr + TOT))[k];
+            tot[4 * k] = t4.x; tot[4 * k + 1] = t4.y; tot[4 * k + 2] = t4.z; tot[4 * k + 3] = t4.w;
+        }
+        wave_lds_sync();                                       // (the planes are rewritten next)
+    }
+    if (take) {
+#pragma unroll
+        for (int k = 0; k < 19; k++) A[k] = f2{tot[k], 0.0f};
+        qmin = tot[19];
+        // the ML - 1 path rows: pairs, an odd one with a copy of itself of weight 0
+#pragma unroll
+        for (int j = 0; j + 1 < ML - 1; j += 2)
+            body(f2{px[j], px[j + 1]}, f2{py[j], py[j + 1]}, f2{(float)c.leafRf[j], (float)c.leafRf[j + 1]});
+        if ((ML - 1) & 1) body(f2{px[ML - 2], px[ML - 2]}, f2{py[ML - 2], py[ML - 2]}, f2{(float)c.leafRf[ML - 2], 0.0f});
+        float rf[20];
+#pragma unroll
+        for (int k = 0; k < 19; k++) rf[k] = A[k].x + A[k].y;
+        rf[19] = 0.0f;
+        const bool usable = sums_ok && qmin > 0.0f && fabsf(rf[0]) < __builtin_inff();
+        c.W->par.put_third(c.lane, S1, S2, rf);
+        c.W->pcode[c.lane] = code | (usable ? 0x80000000u : 0u);
+    }
 }
-__device__ __forceinline__ void sv_unpack2(float, float &a, float &b) { a = b = 0.0f; }      // (never taken: the float instantiation has no third-order sums)
 
 template <int ML, class F, int NS>
 __device__ __forceinline__ void sv_parent(SvCtx<ML, F, NS> &c, bool take, unsigned code) {
+    if constexpr (sizeof(F) == 8) {
+        if (sv_third<ML, F, NS>(c)) {
+            sv_parent_third<ML, F, NS>(c, take, code);
+            return;
+        }
+    }
     typedef typename SvVec<F>::v2 v2;
     // path rows D .. D+ML-2 of the node (its ancestors in the expanded levels and itself)
     F px[ML - 1], py[ML - 1];
@@ -784,32 +896,11 @@ __device__ __forceinline__ void sv_parent(SvCtx<ML, F, NS> &c, bool take, unsign
         S1 = sv_fma(px[j], c.leafN[j], S1);
         S2 = sv_fma(py[j], c.leafN[j], S2);
     }
-    // The round's shared POINT w = (w0, u1, u2): the chain point (sv_children: the mean of the stepped points of the previous
-    // round's last full trip), pulled slightly towards the simplex centre of the round's first node.  The same w for every node
-    // of the round -- any scale is as good as any other -- because w, not the mixture, is what neighbouring candidates have in
-    // common: q_i = w.(1, x_i, y_i) fits the same ratios r_i / rN_i whatever the last rows are, while the mixture s_j u_j moves
-    // with every candidate's column sums.  (Round 3 carried a mixture and re-scaled it by each node's own sums: 3 % off per copy
-    // of the last row, 1.55 instead of 1.31 evaluations per candidate.)  Holding the point for 4 / 16 rounds or a whole prefix
-    // costs +4 / +16 / +42 % time.
-    const F S1c = sv_bcast0(S1), S2c = sv_bcast0(S2);
-    const bool c_ok = S1c > F(0) && S2c > F(0);
-    const F c1 = F(1.0 / 3.0) * sv_rcp(c_ok ? S1c : F(1)), c2 = F(1.0 / 3.0) * sv_rcp(c_ok ? S2c : F(1));
-    const F b0 = sv_bcast0(c.wn0), b1 = sv_bcast0(c.wn1), b2 = sv_bcast0(c.wn2);
-    const bool have = b0 == b0;
-    const F w0 = have ? sv_fma(F(1.0 - SV_PULL), b0, F(SV_PULL / 3.0)) : F(1.0 / 3.0);
-    const F u1 = have ? sv_fma(F(1.0 - SV_PULL), b1, F(SV_PULL) * c1) : c1, u2 = have ? sv_fma(F(1.0 - SV_PULL), b2, F(SV_PULL) * c2) : c2;
+    F w0, u1, u2;
+    sv_shared_point<ML, F, NS>(c, S1, S2, w0, u1, u2);         // (the same w for every node of the round)
     const bool sums_ok = S1 > F(0) && S2 > F(0);
     v2 L = {F(0), F(0)}, T0 = L, T1 = L, T2 = L, W00 = L, W01 = L, W02 = L, W11 = L, W12 = L, W22 = L, LA = L;
     const v2 vw0 = {w0, w0}, vu1 = {u1, u1}, vu2 = {u2, u2};
-    // Third-order sums V_abc = sum R z_a z_b z_c / q^3, z = (1, x, y) (round 6; F = double in the tight modes, sv_third): what the
-    // children's shared step takes its CUBIC correction from.  Single precision: they only shape a correction of a starting point.
-    // Order: 000 001 002 011 012 022 111 112 122 222.
-    typedef float f2 __attribute__((ext_vector_type(2)));
-    const bool third = sv_third<ML, F, NS>(c);
-    f2 V[10];
-#pragma unroll
-    for (int k = 0; k < 10; k++) V[k] = f2{0.0f, 0.0f};
-    if (third && c.lane == 0) c.W->shp.set(w0, u1, u2);      // (read after the syncs below)
     // (rho = sqrt R: gamma = rho / q, T = sum rho gamma (1, x, y), W = sum gamma^2 (1, x, y)(1, x, y)^T; a term outside the
     // domain shows as a NaN / an infinity in L, see sv_step)
     auto body = [&](v2 x, v2 y, v2 R, v2 rho) {
@@ -832,17 +923,6 @@ __device__ __forceinline__ void sv_parent(SvCtx<ML, F, NS> &c, bool take, unsign
             W11 = __builtin_elementwise_fma(gx, gx, W11);
             W12 = __builtin_elementwise_fma(gx, gy, W12);
             W22 = __builtin_elementwise_fma(gy, gy, W22);
-            if (third) {
-#pragma clang fp contract(off)                                   // (as in sv_child_eval_third: the same roundings in both compilations of this source)
-                const f2 gf = {(float)ga.x, (float)ga.y}, wf = {(float)w.x, (float)w.y};
-                const f2 xf = {(float)x.x, (float)x.y}, yf = {(float)y.x, (float)y.y};
-                const f2 h = gf * gf * wf, hx = h * xf, hy = h * yf, hxx = hx * xf, hxy = hx * yf, hyy = hy * yf;
-                V[0] += h; V[1] += hx; V[2] += hy; V[3] += hxx; V[4] += hxy; V[5] += hyy;
-                V[6] = __builtin_elementwise_fma(hxx, xf, V[6]);
-                V[7] = __builtin_elementwise_fma(hxx, yf, V[7]);
-                V[8] = __builtin_elementwise_fma(hxy, yf, V[8]);
-                V[9] = __builtin_elementwise_fma(hyy, yf, V[9]);
-            }
         } else {
             v2 t = R * w;
             T0 += t;
@@ -862,34 +942,24 @@ __device__ __forceinline__ void sv_parent(SvCtx<ML, F, NS> &c, bool take, unsign
     // the ~13 group terms of the prefix -- two thirds of a node's terms -- are the same numbers in all 64 lanes.  Lane p takes
     // pair p of the tile; the partial sums meet in LDS (the record planes, free until the nodes' records are written below),
     // twelve lanes add them up, and every lane starts its own path rows from the totals.
-    // (22 numbers per pair with the third-order sums: 33 pairs x 22 < 768, the totals behind them -- the planes hold 1024)
-    constexpr int NT = sizeof(F) == 8 ? 22 : 12;
-    const int nt = third ? 22 : 12;
-    F tot[NT];
+    F tot[12];
     {
         F *scr = (F *)&c.W->par;
-        constexpr int TOT = sizeof(F) == 8 ? 768 : 512;
+        constexpr int TOT = 512;
         if (c.lane < c.GP) {
             const Sv4<F> xy = c.W->fXY[c.lane];
             const typename SvWt<F>::T rr = c.W->fRR[c.lane];
             body(v2{xy.x, xy.y}, v2{xy.z, xy.w}, v2{rr.x, rr.y}, sv_rho<F>(rr));
-            F part[12];
-            part[0] = L.x + L.y; part[1] = T0.x + T0.y; part[2] = T1.x + T1.y; part[3] = T2.x + T2.y; part[4] = W00.x + W00.y; part[5] = W01.x + W01.y;
-            part[6] = W02.x + W02.y; part[7] = W11.x + W11.y; part[8] = W12.x + W12.y; part[9] = W22.x + W22.y; part[10] = LA.x + LA.y; part[11] = F(0);
-            Sv2<F> *dst = (Sv2<F> *)(scr + nt * c.lane);
+            const F part[12] = {L.x + L.y, T0.x + T0.y, T1.x + T1.y, T2.x + T2.y, W00.x + W00.y, W01.x + W01.y, W02.x + W02.y, W11.x + W11.y,
+                                W12.x + W12.y, W22.x + W22.y, LA.x + LA.y, F(0)};
+            Sv2<F> *dst = (Sv2<F> *)(scr + 12 * c.lane);
 #pragma unroll
             for (int k = 0; k < 6; k++) dst[k] = Sv2<F>{part[2 * k], part[2 * k + 1]};
-            if constexpr (sizeof(F) == 8) {
-                if (third) {
-#pragma unroll
-                    for (int k = 0; k < 5; k++) dst[6 + k] = Sv2<F>{(F)(V[2 * k].x + V[2 * k].y), (F)(V[2 * k + 1].x + V[2 * k + 1].y)};
-                }
-            }
         }
         wave_lds_sync();
-        if (c.lane < nt) {
+        if (c.lane < 12) {
             F t = F(0);
-            for (int p = 0; p < c.GP; p++) t += scr[nt * p + c.lane];
+            for (int p = 0; p < c.GP; p++) t += scr[12 * p + c.lane];
             scr[TOT + c.lane] = t;
         }
         wave_lds_sync();
@@ -899,28 +969,12 @@ __device__ __forceinline__ void sv_parent(SvCtx<ML, F, NS> &c, bool take, unsign
             tot[2 * k] = t2.x;
             tot[2 * k + 1] = t2.y;
         }
-        if constexpr (sizeof(F) == 8) {
-            if (third) {
-#pragma unroll
-                for (int k = 6; k < 11; k++) {
-                    const Sv2<F> t2 = ((const Sv2<F> *)(scr + TOT))[k];
-                    tot[2 * k] = t2.x;
-                    tot[2 * k + 1] = t2.y;
-                }
-            }
-        }
         wave_lds_sync();                                   // (the planes are rewritten next)
     }
     if (take) {
         L = v2{tot[0], F(0)}; T0 = v2{tot[1], F(0)}; T1 = v2{tot[2], F(0)}; T2 = v2{tot[3], F(0)};
         W00 = v2{tot[4], F(0)}; W01 = v2{tot[5], F(0)}; W02 = v2{tot[6], F(0)}; W11 = v2{tot[7], F(0)};
         W12 = v2{tot[8], F(0)}; W22 = v2{tot[9], F(0)}; LA = v2{tot[10], F(0)};
-        if constexpr (sizeof(F) == 8) {
-            if (third) {
-#pragma unroll
-                for (int k = 0; k < 10; k++) V[k] = f2{(float)tot[12 + k], 0.0f};
-            }
-        }
         // the ML - 1 path rows: pairs, an odd one with a copy of itself of weight 0
 #pragma unroll
         for (int j = 0; j + 1 < ML - 1; j += 2)
@@ -928,18 +982,9 @@ __device__ __forceinline__ void sv_parent(SvCtx<ML, F, NS> &c, bool take, unsign
         if ((ML - 1) & 1) body(v2{px[ML - 2], px[ML - 2]}, v2{py[ML - 2], py[ML - 2]}, v2{c.leafRf[ML - 2], F(0)}, v2{c.leafRho[ML - 2], F(0)});
         const F Lsum = L.x + L.y;
         const bool usable = sums_ok && sv_abs(Lsum) < F(__builtin_inff());
-        F rec[16] = {Lsum, T0.x + T0.y, T1.x + T1.y, T2.x + T2.y, W00.x + W00.y, W01.x + W01.y, W02.x + W02.y, W11.x + W11.y,
-                     W12.x + W12.y, W22.x + W22.y, S1, S2, w0, u1, u2, LA.x + LA.y};
-        if (third) {
-            // (the tight modes' record: neither the value nor its error bound is read, the point is the wave's, and the shared step is
-            // taken in single precision -- the sums as floats, the ten third-order sums behind them; the column sums stay doubles)
-            const float rf[20] = {(float)rec[1], (float)rec[2], (float)rec[3], (float)rec[4], (float)rec[5], (float)rec[6], (float)rec[7], (float)rec[8],
-                                  (float)rec[9], V[0].x + V[0].y, V[1].x + V[1].y, V[2].x + V[2].y, V[3].x + V[3].y, V[4].x + V[4].y, V[5].x + V[5].y,
-                                  V[6].x + V[6].y, V[7].x + V[7].y, V[8].x + V[8].y, V[9].x + V[9].y, 0.0f};
-            c.W->par.put_third(c.lane, S1, S2, rf);
-        } else {
-            c.W->par.put(c.lane, rec);
-        }
+        const F rec[16] = {Lsum, T0.x + T0.y, T1.x + T1.y, T2.x + T2.y, W00.x + W00.y, W01.x + W01.y, W02.x + W02.y, W11.x + W11.y,
+                           W12.x + W12.y, W22.x + W22.y, S1, S2, w0, u1, u2, LA.x + LA.y};
+        c.W->par.put(c.lane, rec);
         c.W->pcode[c.lane] = code | (usable ? 0x80000000u : 0u);
     }
 }
@@ -1038,8 +1083,9 @@ __device__ __forceinline__ void sv_child_eval_third(const SvCtx<ML, F, NS> &c, i
     }
     float step = 1.0f;
     if (ballot64(l2 > 0.09f)) {                                                                 // (damped phase: rare, the branch is wave-uniform)
-        asm volatile("" ::: "memory");
-        step = l2 > 0.09f ? __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_sqrtf(l2)) : 1.0f;
+        float l2l = l2;
+        asm volatile("" : "+v"(l2l));
+        step = l2 > 0.09f ? __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_sqrtf(l2l)) : 1.0f;
     }
     const float sc = __builtin_amdgcn_rcpf(zw);
     const float v1 = __builtin_fmaf(step, d1, u1) * sc, v2 = __builtin_fmaf(step, d2, u2) * sc;
@@ -1119,8 +1165,9 @@ __device__ __forceinline__ void sv_child_eval(const SvCtx<ML, F, NS> &c, int lo,
     const bool num_ok = l2 == l2 && sv_abs(d1) + sv_abs(d2) < F(1e30);
     F step = F(1);
     if (ballot64(l2 > F(0.09))) {                                                              // (damped phase: rare, the branch is wave-uniform)
-        asm volatile("" ::: "memory");                                                          // (... and stays one: not if-converted)
-        step = l2 > F(0.09) ? sv_rcp(F(1) + sv_sqrt(l2)) : F(1);
+        F l2l = l2;
+        asm volatile("" : "+v"(l2l));                                                           // (... and stays one: not if-converted)
+        step = l2 > F(0.09) ? sv_rcp(F(1) + sv_sqrt(l2l)) : F(1);
     }
     // the stepped point on the child's own slice (z.d = 0, so z.w stays): mixture n_j = s_j u_j / z.w
     const F v1 = sv_fma(step, d1, u1) * sc, v2 = sv_fma(step, d2, u2) * sc;
@@ -1241,10 +1288,11 @@ __device__ __forceinline__ void sv_children(SvCtx<ML, F, NS> &c, int total) {
                 sv_rows_load<ML, F, NS>(c, o.code, o.slot, rows);
                 F u1 = qu1, u2 = qu2;
                 if (ballot64(!(u1 == u1))) {            // (no usable shared point: from the simplex centre -- rare, behind a wave-uniform branch)
-                    asm volatile("" ::: "memory");
+                    F fs1 = o.s1, fs2 = o.s2;
+                    asm volatile("" : "+v"(fs1), "+v"(fs2));          // (the reciprocals stay in here: hoisted, they ran once per trip)
                     if (!(u1 == u1)) {
-                        u1 = F(1.0 / 3.0) * sv_rcp(o.s1);
-                        u2 = F(1.0 / 3.0) * sv_rcp(o.s2);
+                        u1 = F(1.0 / 3.0) * sv_rcp(fs1);
+                        u2 = F(1.0 / 3.0) * sv_rcp(fs2);
                     }
                 }
                 F val2 = F(0), l2 = F(0), la = F(0), mlim = F(0);
