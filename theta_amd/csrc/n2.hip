@@ -315,7 +315,7 @@ __global__ __launch_bounds__(256, (QUICK && KV <= 8) ? 3 : 1) void n2_search_ker
     }
     unsigned long long t0 = begin + tid * (unsigned long long)per_thread;
     unsigned long long n_eval = 0, n_acc = 0, n_deg = 0, n_it = 0, n_terms = 0, n_fin = 0, n_dis = 0;
-    constexpr bool quick = QUICK;        // (an instantiation of its own: the dismissing search does not carry the other loop's registers)
+    // (QUICK: an instantiation of its own -- the dismissing search does not carry the other loop's registers)
     const double inv_N = 1.0 / P.N;
     // f32 screen: |error| <= ~1e-6 * Rtot * ln(range) -- a margin of 2e-5 Rtot is far outside it
     const double margin = 2e-5 * P.Rtot + 1.0;
