@@ -56,6 +56,13 @@ txt.append("HBM traffic (`roofline.traffic`, two `rocprofv3 --pmc` passes of the
            "contender records of a step that starts from the job's minimum.  (Round 3 reported 1.3 GB: its filter kept the launches with "
            "the LARGEST counters, i.e. the job's first step, whose 7.7 M contender records are 2.1 GB — `profiles/r4/pmc_sieve_writes_per_launch.json` "
            "lists every launch.)\n" % ((rf["traffic"] or 0) / 1e6, (rf["traffic"] or 0) / 2 ** 31))
+iss = rf.get("issue") or {}
+if iss:
+    per = iss.get("valu_wave_instructions_per_candidate")
+    txt.append("Vector issue (`roofline.issue`, a third `--pmc` pass: `SQ_INSTS_VALU`, `SQ_ACTIVE_INST_VALU`, `SQ_WAVE_CYCLES`): %s vector wave-instructions "
+               "per bulk launch%s; one wave's instructions occupy %.2f of its cycles, x %d resident waves per SIMD = the vector port busy %.0f %% of the "
+               "time.\n" % (e(iss["valu_wave_instructions_per_launch"]), (" -- **%.1f per candidate** over all launches of the timed steps" % per) if per else "",
+                            iss["valu_active_per_wave_cycle"], iss["waves_per_simd"], 100 * iss["valu_port_busy"]))
 txt.append("CPU beside it (`cpu_baseline`): %s — %s candidates/s on %d cores, %.0f per process.\n" % (cpu["sample"], e(cpu["value"]), cpu["cores"], cpu["per_process"]))
 rs = cpu.get("restatement") or {}
 if "value" in rs:
