@@ -34,7 +34,10 @@
 // The fused kernel of n3.hip stays: it is the --GET_VALUES dump, the path for m < 8, the last resort for a slice part whose
 // contender list overflows three times (a stretch of near-ties), and the second implementation the tests compare this one
 // with (identical finalists).  F = float | double and "n3_no_dismiss" (every candidate iterated: the bench's full-solve
-// legs) are instantiations / modes of THIS kernel.
+// legs) are instantiations / modes of THIS kernel.  The TIGHT full-solve modes (a threshold below 1e-6: every child takes a private FP64
+// evaluation in place, sv_children) have a shared step of their own since round 6 -- single precision throughout, with a cubic
+// correction from third-order sums (sv_third, sv_parent_third, sv_child_eval_third), rounds in whole trips of 64 children (sv_expand)
+// -- and, for F = double, a kernel instantiation apart (SEC).
 #include <stddef.h>
 
 #include <type_traits>
