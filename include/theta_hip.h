@@ -197,7 +197,7 @@ int theta_search_degenerate(theta_problem *p, int cap, uint64_t *rank, uint8_t *
  *   "n3_mu_tol"      > 0 (with "n3_no_dismiss"): the tolerance as a CERTIFICATE ON MU.  An evaluation at u (decrement lambda, tangent Hessian H,
  *                    t = lambda / sqrt(Rmin) <= 0.1) counts as converged only if, besides "n3_conv_l2", the point one full Newton step further
  *                    is certified within this distance of the candidate's optimum in every component of mu: self-concordance bounds the
- *                    step's decrement and the drift of H, H's smaller eigenvalue turns the Hessian norm into a distance in u, and
+ *                    step's decrement and the drift of H, H's smaller eigenvalue (through its lower bound det / tr) turns the Hessian norm into a distance in u, and
  *                    d mu / d u is bounded by (1.5 + max(1, |mu1| + |mu2|) |k|) / U (tests/test_certified_tolerance_cpu.py restates the chain and
  *                    checks it on 3 000 random problems; a 10 % margin on top).  Points away from the simplex (a nu_j < -0.05) -- where the
  *                    reference reports no mixture of the candidate's own -- are left to "n3_conv_l2" alone.  0 (default): the decrement alone decides
@@ -220,7 +220,9 @@ int theta_search_degenerate(theta_problem *p, int cap, uint64_t *rank, uint8_t *
  *                    finalists, suspects and degenerate lists).  Never applies under "n3_no_dismiss"
  *   "n3_second"      1 (default): in the tight full-solve modes ("n3_no_dismiss" with "n3_conv_l2" < 1e-6), where every candidate needs a second
  *                    evaluation, it is taken in place right after the shared one, by the lane that holds the child, instead of through
- *                    the queue; 0: through the queue (same evaluations, same lists; an A/B switch)
+ *                    the queue; 0: through the queue (same lists; an A/B switch).  With 1 the shared first step of these modes is also taken
+ *                    in single precision with a cubic correction (it only shapes the start of the private FP64 evaluations) and the last
+ *                    level's rounds come in whole trips of 64 children: 2.07 instead of 2.49 evaluations per candidate on the bench's data
  *   "n2_no_dismiss"  1: the n=2 search solves every candidate; 0 (default): a candidate whose rigorous lower bound -- one evaluation
  *                    at a chain point, self-concordance -- lies beyond the window of the running minimum is done (same finalists)
  *   "n3_per_task"    candidates per wave task (0 = automatic), "n2_per_thread" candidates per thread (0 = automatic)
