@@ -61,7 +61,7 @@ if iss:
     per = iss.get("valu_wave_instructions_per_candidate")
     txt.append("Vector issue (`roofline.issue`, a third `--pmc` pass: `SQ_INSTS_VALU`, `SQ_ACTIVE_INST_VALU`, `SQ_WAVE_CYCLES`): %s vector wave-instructions "
                "per bulk launch%s; one wave's instructions occupy %.2f of its cycles, x %d resident waves per SIMD = the vector port busy %.0f %% of the "
-               "time.\n" % (e(iss["valu_wave_instructions_per_launch"]), (" -- **%.1f per candidate** over all launches of the timed steps" % per) if per else "",
+               "time.\n" % (e(iss["valu_wave_instructions_per_launch"]), (" -- **%.1f per candidate** a step's bulk launch and first slice over its 2^31 candidates" % per) if per else "",
                             iss["valu_active_per_wave_cycle"], iss["waves_per_simd"], 100 * iss["valu_port_busy"]))
 txt.append("CPU beside it (`cpu_baseline`): %s — %s candidates/s on %d cores, %.0f per process.\n" % (cpu["sample"], e(cpu["value"]), cpu["cores"], cpu["per_process"]))
 rs = cpu.get("restatement") or {}
