@@ -196,6 +196,12 @@ def test_witness_of_the_full_solve_legs_on_the_bench_instance(ctx, capsys):
             print("witness", row)
     for name in set(row["leg"] for row in rows):
         assert sum(row["on_optimum"] for row in rows if row["leg"] == name) >= 500, name        # (compared with the reference's own mu)
+    # round 6: the certified legs take one shared and (nearly always) ONE private evaluation per candidate -- the shared step's cubic
+    # correction (n3_sieve.hip: sv_child_eval_third); counters of the kernel's own records, not a timing.  (The start of the space is a
+    # stretch of degenerate prefixes -- rows (0, 0) throughout -- where nothing is near anything: 4.4 there.)
+    for row in rows:
+        if row["leg"].endswith("_certified") and row["range"] in ("middle", "end"):
+            assert row["evaluations_mean"] <= 2.2, row
 
 
 @pytest.mark.parametrize("m,K,seed,tau", [(9, 3, 10, 2), (11, 2, 21, 2), (12, 3, 15, 3)])
