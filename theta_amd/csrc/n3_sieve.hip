@@ -1655,7 +1655,7 @@ __device__ __noinline__ int sv_next_task(unsigned *ctr) {
 __host__ __device__ __forceinline__ bool sv_second_mode(const N3Dev &P) { return P.no_dismiss && P.conv_l2 < 1e-6 && !P.no_second; }
 // SEC = false: the instantiation of the launches that take no second evaluation in place (known on the host: sv_second_mode) -- the
 // tight modes' code (lean shared evaluation, third-order sums, cubic correction) folds away instead of riding along behind
-// wave-uniform branches (the coarse FP64 leg: 2 % with it).  The float instantiations decide at run time as before.
+// wave-uniform branches (the coarse FP64 leg: 2 % with it; the float instantiations -- the shipped search -- likewise).
 template <int ML, class F, int NS, bool SEC>
 __global__ __launch_bounds__(64 * SV_WAVES, sizeof(F) == 4 ? SV_OCC : SV_OCC64) void n3_sieve_kernel(N3Dev Pg, SearchArgs A, const N3Task *tasks, const unsigned *stbuf,
                                                                           int ntasks, SvSurvivor *surv, unsigned surv_cap,
@@ -1725,7 +1725,7 @@ __global__ __launch_bounds__(64 * SV_WAVES, sizeof(F) == 4 ? SV_OCC : SV_OCC64) 
     c.conv_l2 = (F)Pg.conv_l2;
     c.fine_l2 = sizeof(F) == 8 ? (F)fmin(Pg.conv_l2, 1e-8) : c.conv_l2;
     c.no_dismiss = Pg.no_dismiss;
-    c.second = SEC && (sizeof(F) == 8 || sv_second_mode(Pg));      // (F = double: SEC is the launch's mode itself, n3_launch_sieve)
+    c.second = SEC;                                    // (the launch's mode itself: n3_launch_sieve instantiates both)
     // a tolerance only a third evaluation meets (the tight leg, 1e-12): that one in place too where most lanes of a trip need it
     // (measured: tight leg 128.5 -> 121.0 ms per 2^31; at the certified tolerance, where one lane in ten needs a third, +2 %: not taken)
     // (round 6: also under n3_mu_tol -- the limit on mu sends one lane in four to a third evaluation, not one in ten: 96.2 -> 95.0 ms)
@@ -2180,16 +2180,16 @@ void n3_launch_sieve(const N3Dev &P, const SearchArgs &A, const N3Task *tasks, c
     // (NS = prefix intervals per lane: 2 up to 128 intervals -- the instantiation everything is tuned for --, 4 up to 256: BASELINE
     // config 5's shape, m = 200; wider prefix tables in LDS, two blocks per CU)
 #define SV_LAUNCH(MLV, FT, NSV, SECV) hipLaunchKernelGGL((n3_sieve_kernel<MLV, FT, NSV, SECV>), grid, block, 0, st, P, A, tasks, stbuf, ntasks, surv, surv_cap, surv_count)
-#define SV_LAUNCH64(MLV, NSV) do { if (sec) SV_LAUNCH(MLV, double, NSV, true); else SV_LAUNCH(MLV, double, NSV, false); } while (0)
+#define SV_LAUNCH2(MLV, FT, NSV) do { if (sec) SV_LAUNCH(MLV, FT, NSV, true); else SV_LAUNCH(MLV, FT, NSV, false); } while (0)
     const bool wide = P.m - P.L > 2 * WAVE, sec = sv_second_mode(P);
     if (P.force64) {       // FP64 throughout (n3_force_f64): the same kernel on doubles
-        if (P.L <= 4) { if (wide) SV_LAUNCH64(4, 4); else SV_LAUNCH64(4, 2); }
-        else { if (wide) SV_LAUNCH64(6, 4); else SV_LAUNCH64(6, 2); }
+        if (P.L <= 4) { if (wide) SV_LAUNCH2(4, double, 4); else SV_LAUNCH2(4, double, 2); }
+        else { if (wide) SV_LAUNCH2(6, double, 4); else SV_LAUNCH2(6, double, 2); }
     } else {
-        if (P.L <= 4) { if (wide) SV_LAUNCH(4, float, 4, true); else SV_LAUNCH(4, float, 2, true); }
-        else { if (wide) SV_LAUNCH(6, float, 4, true); else SV_LAUNCH(6, float, 2, true); }
+        if (P.L <= 4) { if (wide) SV_LAUNCH2(4, float, 4); else SV_LAUNCH2(4, float, 2); }
+        else { if (wide) SV_LAUNCH2(6, float, 4); else SV_LAUNCH2(6, float, 2); }
     }
-#undef SV_LAUNCH64
+#undef SV_LAUNCH2
 #undef SV_LAUNCH
 }
 
