@@ -777,18 +777,24 @@ def main():
         if world == 1 and real_device and M >= 8 and not args.no_legs:
             # what the headline's kernel leaves a candidate at: the witness build's records for every 1024th candidate of the first 2^24
             # ranks of the last timed range (tests/test_gpu_round5.py compares such records with the oracle one by one)
+            # (Tasks of 16 383 candidates for this call -- the job's are 16 384 --: a task starts from the simplex centre, its first round
+            # takes 5-6 evaluations, and with tasks of a power of two every 8th / 16th sampled candidate would be a task's first: round 5's
+            # witness read 2.9 evaluations per candidate for a job that took 2.35.  With an odd task size the samples fall on all offsets.)
             try:
-                set_opts(head_opts, True)
+                wit_opts = dict(head_opts, n3_per_task=16383)
+                set_opts(wit_opts, True)
                 problem.hint(leg.running)
                 wb = begins[-1]
                 rec, wst = problem.witness(wb, wb + min(args.batch, 1 << 24), every_log2=10, window=COLLECT_WINDOW)
-                set_opts(head_opts, False)
+                set_opts(wit_opts, False)
                 st_names = {0: "none", 1: "converged_at_shared_evaluation", 2: "converged_in_queue", 3: "bound_at_shared_evaluation",
                             4: "bound_in_queue", 5: "contender", 6: "unsolved_to_finish_kernel"}
                 reg = rec["status"] != 0
                 out["witness"] = {"leg": args.leg, "records": int(len(rec)), "every": 1024,
                                   "status": {st_names[int(k)]: int(v) for k, v in zip(*np.unique(rec["status"], return_counts=True))},
                                   "evaluations_mean": float(rec["evaluations"][reg].mean()) if reg.any() else 0.0,
+                                  # (... and over ALL candidates of the witnessed range, from the call's counters)
+                                  "evaluations_mean_of_the_range": float(wst["iterations"]) / max(float(wst["evaluated"]), 1.0),
                                   "evaluations_max": int(rec["evaluations"].max()),
                                   "l2_last_max": float(np.nanmax(rec["l2_last"][reg])) if reg.any() else 0.0,
                                   "l2_first_median": float(np.nanmedian(rec["l2_first"][reg])) if reg.any() else 0.0,
