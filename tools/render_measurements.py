@@ -71,9 +71,12 @@ if "value" in rs:
 wit = b.get("witness") or {}
 if "records" in wit:
     txt.append("Witness of the headline leg on the last timed range (`witness`: every 1024th of 2^24 candidates, the kernel's own records): %d records, "
-               "status %s, %.2f evaluations per candidate (at most %d), largest λ²/Σr at a last evaluation %.3g against the certified threshold %.3g; "
+               "status %s, %.2f evaluations per candidate%s (at most %d), largest λ²/Σr at a last evaluation %.3g against the certified threshold %.3g; "
                "largest certified bound on |Δμ| among the records %.3g (tolerance %s; 0 where the point lies outside the simplex: the end of the rank space).\n" % (
-                   wit["records"], wit["status"], wit["evaluations_mean"], wit["evaluations_max"], wit["l2_last_max"], wit["conv_l2"],
+                   wit["records"], wit["status"], wit["evaluations_mean"],
+                   (" -- the range's own mean over ALL its candidates: %.2f; the job's 25 stretches average %.2f, this is the last and heaviest" % (
+                       wit["evaluations_mean_of_the_range"], h["newton_iters_per_candidate"])) if "evaluations_mean_of_the_range" in wit else "",
+                   wit["evaluations_max"], wit["l2_last_max"], wit["conv_l2"],
                    wit.get("mu_bound_max", 0.0), wit.get("mu_tol")))
 for key, label in (("config3_m50_n3_k4", "config 3 (m=50, n=3, k=4, full bounds)"), ("config4_m50_n3_k6", "config 4 (m=50, n=3, k=6, full bounds: this bench's instance)"),
                    ("config5_m200_n3_k7", "config 5's shape (m=200, n=3, k=7, full bounds: the count saturates at 2^128 − 1, the space holds ~1e150 matrices)")):
