@@ -425,12 +425,15 @@ __device__ __forceinline__ F sv_mu_limit(const SvCtx<ML, F, NS> &c, F H11, F H22
 template <int ML, class F, int NS>
 __device__ __forceinline__ int sv_step(const SvCtx<ML, F, NS> &c, const SvRowsT<ML, SvTab<F, NS>::v> &rows, F s1, F s2, F &u1, F &u2, F &val2, F &l2, F &la, F &mlim) {
     typedef typename SvVec<F>::v2 v2;
-    v2 g1 = {F(0), F(0)}, g2 = g1, h11 = g1, h12 = g1, h22 = g1, lg = g1, lga = g1;
+    // (The sums START from the first pair of leaf rows -- products instead of multiply-adds onto zeros: fourteen FP64 accumulators set to
+    // zero were 28 vector moves per evaluation, 5 % of it -- and take the other leaf rows, then the group tile.)
+    v2 g1, g2, h11, h12, h22, lg, lga;
     const v2 vs1 = {s1, s1}, vs2 = {s2, s2}, vu1 = {u1, u1}, vu2 = {u2, u2}, one = {F(1), F(1)};
     // per term, with rho = sqrt R:  alpha = rho a / q, beta = rho b / q;  gradient sum rho alpha, Hessian sum alpha alpha^T
     // (one multiplication less than through t = R / q, t / q).  A term outside the domain (q <= 0, or so close that its
     // single-precision image is 0) leaves a NaN or an infinity in the sum of logarithms: no running minimum of q is kept.
-    auto body = [&](v2 x, v2 y, v2 R, v2 rho) {
+    auto body = [&](auto first, v2 x, v2 y, v2 R, v2 rho) {
+        constexpr bool FIRST = decltype(first)::value;
         v2 a = x - vs1, b = y - vs2;
         v2 q = __builtin_elementwise_fma(a, vu1, __builtin_elementwise_fma(b, vu2, one));
         F wx, wy, lx, ly;
@@ -441,50 +444,56 @@ __device__ __forceinline__ int sv_step(const SvCtx<ML, F, NS> &c, const SvRowsT<
         sv_rcp_lg2(q.y, wy, ly);
 #endif
         const v2 w = {wx, wy}, l = {lx, ly};
-#ifndef SV_NO_LOGS
-        lg = __builtin_elementwise_fma(R, l, lg);
-#endif
+        lg = FIRST ? R * l : __builtin_elementwise_fma(R, l, lg);
 #ifndef SV_NO_LGA      // (A/B build: what the error bound's accumulation costs -- tools/ab_build.sh nolga -DSV_NO_LGA; never shipped)
-        if constexpr (sizeof(F) == 8) lga = __builtin_elementwise_fma(R, v2{sv_abs(l.x), sv_abs(l.y)}, lga);   // (error bound of the f32 logarithms, sv_beyond)
+        if constexpr (sizeof(F) == 8) {                // (error bound of the f32 logarithms, sv_beyond)
+            const v2 la2 = {sv_abs(l.x), sv_abs(l.y)};
+            lga = FIRST ? R * la2 : __builtin_elementwise_fma(R, la2, lga);
+        }
+#else
+        if constexpr (FIRST) lga = v2{F(0), F(0)};
 #endif
         if constexpr (sizeof(F) == 8) {
             v2 gw = rho * w;
             v2 al = gw * a, be = gw * b;
-            g1 = __builtin_elementwise_fma(rho, al, g1);
-            g2 = __builtin_elementwise_fma(rho, be, g2);
-            h11 = __builtin_elementwise_fma(al, al, h11);
-            h12 = __builtin_elementwise_fma(al, be, h12);
-            h22 = __builtin_elementwise_fma(be, be, h22);
+            g1 = FIRST ? rho * al : __builtin_elementwise_fma(rho, al, g1);
+            g2 = FIRST ? rho * be : __builtin_elementwise_fma(rho, be, g2);
+            h11 = FIRST ? al * al : __builtin_elementwise_fma(al, al, h11);
+            h12 = FIRST ? al * be : __builtin_elementwise_fma(al, be, h12);
+            h22 = FIRST ? be * be : __builtin_elementwise_fma(be, be, h22);
         } else {
+            if constexpr (FIRST) lga = v2{F(0), F(0)};
             v2 t = R * w;
-            g1 = __builtin_elementwise_fma(t, a, g1);
-            g2 = __builtin_elementwise_fma(t, b, g2);
+            g1 = FIRST ? t * a : __builtin_elementwise_fma(t, a, g1);
+            g2 = FIRST ? t * b : __builtin_elementwise_fma(t, b, g2);
             v2 tw = t * w;
             v2 ta = tw * a, tb = tw * b;
-            h11 = __builtin_elementwise_fma(ta, a, h11);
-            h12 = __builtin_elementwise_fma(ta, b, h12);
-            h22 = __builtin_elementwise_fma(tb, b, h22);
+            h11 = FIRST ? ta * a : __builtin_elementwise_fma(ta, a, h11);
+            h12 = FIRST ? ta * b : __builtin_elementwise_fma(ta, b, h12);
+            h22 = FIRST ? tb * b : __builtin_elementwise_fma(tb, b, h22);
         }
     };
+    auto leaf = [&](auto first, int j) {
+        const typename SvWt<F>::T rr = c.W->fRL[j];
+        if constexpr (SvTab<F, NS>::v) {
+            const Sv2<F> ra = c.S->rowF[(rows.code >> (12 * j)) & 63u];
+            const Sv2<F> rb = c.S->rowF[j < ML / 2 - 1 ? (rows.code >> (12 * j + 6)) & 63u : rows.slot];
+            body(first, v2{ra.x, rb.x}, v2{ra.y, rb.y}, v2{rr.x, rr.y}, sv_rho<F>(rr));
+        } else {
+            const unsigned d = rows.rw[j];      // bytes {a, b, a', b'}
+            body(first, v2{(F)(d & 0xffu), (F)((d >> 16) & 0xffu)}, v2{(F)((d >> 8) & 0xffu), (F)(d >> 24)}, v2{rr.x, rr.y}, sv_rho<F>(rr));
+        }
+    };
+    leaf(std::true_type{}, 0);
+#pragma unroll
+    for (int j = 1; j < ML / 2; j++) leaf(std::false_type{}, j);
     const Sv4<F> *fXY = c.W->fXY;
     const typename SvWt<F>::T *fRR = c.W->fRR;
 SV_UNROLL(SV_UNR)
     for (int p = 0; p < c.GP; p++) {
         const Sv4<F> xy = fXY[p];
         const typename SvWt<F>::T rr = fRR[p];
-        body(v2{xy.x, xy.y}, v2{xy.z, xy.w}, v2{rr.x, rr.y}, sv_rho<F>(rr));
-    }
-#pragma unroll
-    for (int j = 0; j < ML / 2; j++) {
-        const typename SvWt<F>::T rr = c.W->fRL[j];
-        if constexpr (SvTab<F, NS>::v) {
-            const Sv2<F> ra = c.S->rowF[(rows.code >> (12 * j)) & 63u];
-            const Sv2<F> rb = c.S->rowF[j < ML / 2 - 1 ? (rows.code >> (12 * j + 6)) & 63u : rows.slot];
-            body(v2{ra.x, rb.x}, v2{ra.y, rb.y}, v2{rr.x, rr.y}, sv_rho<F>(rr));
-        } else {
-            const unsigned d = rows.rw[j];      // bytes {a, b, a', b'}
-            body(v2{(F)(d & 0xffu), (F)((d >> 16) & 0xffu)}, v2{(F)((d >> 8) & 0xffu), (F)(d >> 24)}, v2{rr.x, rr.y}, sv_rho<F>(rr));
-        }
+        body(std::false_type{}, v2{xy.x, xy.y}, v2{xy.z, xy.w}, v2{rr.x, rr.y}, sv_rho<F>(rr));
     }
     val2 = lg.x + lg.y;
     if (!(sv_abs(val2) < F(__builtin_inff()))) {
