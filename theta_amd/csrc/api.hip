@@ -187,6 +187,7 @@ struct theta_problem {
     uint64_t last_launches = 0;                        // launches of the search kernel behind kernel_ms (sieve: one per slice)
     std::vector<double> h_r, h_rN;                     // the counts as given (sorted order): the per-depth constants of theta_bnb
     DevBuf d_misc2;                                    // task specifications of a search over several ranges
+    std::vector<uint64_t> boot_spec;                   // ... and of the small first slice of a hinted n=3 call (kept: the copy is asynchronous)
     // the mixture-space search (theta_mix_search): its buffers, allocated at the first call and kept; the lines of the alphabet's grid
     DevBuf d_mix_stack, d_mix_work, d_mix_leaves, d_mix_ctr, d_mix_mat, d_mix_lines, d_mix_slot, d_mix_iv, d_mix_seen;
     unsigned long long mix_seen_mask = 0;
@@ -991,8 +992,32 @@ static int run_search(theta_problem *p, u128 b, u128 e, double window, double *d
                     // (round 5: and before that one, FOUR tasks -- 2^16 candidates of the range, a fraction of a millisecond --, so that even the
                     // short slice is judged against a minimum this range attains: with a stale hint it listed a tenth of its 3e7
                     // candidates as contenders, which is what made one step in twenty cost twice the median)
+                    // (round 6: those four tasks as 64 SMALL ones -- the same 4 per_task candidates, behind the call's task list --: four waves
+                    // of 16 384 candidates each held the chip for a millisecond, 1.4 % of a bench step, with 2 044 waves' slots idle; 64
+                    // waves of 1 024 take 70 us.  Not under "n3_contender_cap" (the redo ladder re-cuts slices by whole tasks).)
                     if (t == 0 && ntasks >= 8 * 2048) {
-                        slices.push_back({0, 4});
+                        const bool small_boot = !ranges && !p->opt_surv_cap && per_task % 16 == 0 && ntasks + 64 <= N3_MAX_TASKS &&
+                                                (u128)4 * per_task <= cnt && !getenv("THETA_N3_NO_SMALL_BOOT");
+                        if (small_boot) {
+                            p->boot_spec.resize(3 * 64);
+                            const uint64_t each = per_task / 16;
+                            for (int i = 0; i < 64; i++) {
+                                const u128 at = b + (u128)i * each;
+                                p->boot_spec[3 * i] = (uint64_t)at;
+                                p->boot_spec[3 * i + 1] = (uint64_t)(at >> 64);
+                                p->boot_spec[3 * i + 2] = each;
+                            }
+                            if (p->d_misc2.bytes < p->boot_spec.size() * sizeof(uint64_t)) {
+                                int rc = p->d_misc2.alloc(p->boot_spec.size() * sizeof(uint64_t));
+                                if (rc) return rc;
+                            }
+                            HIP_TRY(hipMemcpyAsync(p->d_misc2.p, p->boot_spec.data(), p->boot_spec.size() * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+                            n3_launch_task_list(PS, (const uint64_t *)p->d_misc2.p, 64, (N3Task *)p->d_tasks.p + ntasks,
+                                                (unsigned *)p->d_stbuf.p + (size_t)ntasks * N3_STB, st);
+                            slices.push_back({ntasks, 64});
+                        } else {
+                            slices.push_back({0, 4});
+                        }
                         slices.push_back({4, 2044});
                         t = 2048;
                     }

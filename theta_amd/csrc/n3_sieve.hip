@@ -636,8 +636,12 @@ __device__ __forceinline__ void sv_rows_load(const SvCtx<ML, F, NS> &c, unsigned
 template <int ML, class F, int NS>
 __device__ __forceinline__ void sv_survivor_rows(const SvCtx<ML, F, NS> &c, const SvRowsT<ML, SvTab<F, NS>::v> &rows, unsigned off, F u1, F u2) {
     if constexpr (SvTab<F, NS>::v) {
+        // (a contender is rare: its table addresses and its 128-bit rank are computed HERE -- laundered, or they are hoisted out of
+        // the branch and of the evaluation loop, ten vector instructions per trip for nothing)
+        unsigned code = rows.code;
+        asm volatile("" : "+v"(code), "+v"(off));
         unsigned rw[ML / 2];
-        sv_child_rows<ML, F, NS>(c, rows.code, rows.slot, rw);
+        sv_child_rows<ML, F, NS>(c, code, rows.slot, rw);
         sv_survivor<ML, F, NS>(c, rw, off, u1, u2);
     } else {
         sv_survivor<ML, F, NS>(c, rows.rw, off, u1, u2);
