@@ -559,3 +559,32 @@ def test_suspects_and_hint_on_a_poor_rank_range(ctx):
     if len(p.last_suspects[0]):
         b = ctx.boundary_min(2, rs, rNs, p.last_suspects[2])
         assert (b >= p.last_suspects[1] - 1e-6).all()                # suspects' bounds are lower bounds of the exact value
+
+
+@pytest.mark.gpu
+def test_wave_per_candidate_solver_returns_the_bits_of_the_lane_per_candidate_one(ctx, monkeypatch):
+    """theta_solve_batch, n = 3, small batches (round 6: solve_wave_n3_kernel -- the terms of an evaluation spread over a wave's lanes,
+    added up in the reference's order) against the lane-per-candidate kernel (THETA_SOLVE_NO_WAVE=1): outcome class, mu, NLL and the
+    per-interval values of every candidate, bit for bit -- random rows, sorted columns, all-zero tumour columns, one to two hundred
+    intervals, batches of one and of the kernel's limit."""
+    import bench
+    rng = np.random.RandomState(2026)
+    for m, K, B in ((6, 3, 300), (7, 2, 64), (21, 5, 257), (50, 6, 300), (200, 7, 180), (64, 4, 1), (12, 3, 2048)):
+        r, rN, _ = bench.synth(seed=100 + m, m=m, n=3, k=K)
+        C = rng.randint(0, K + 1, (B, m, 2)).astype(np.uint8)
+        C[::3] = np.sort(C[::3], axis=1)                              # (a third: non-decreasing columns, the shape of enumerated matrices)
+        if B > 8:
+            C[1, :, 0] = 0                                            # an all-zero tumour column
+            C[2, :, :] = 0
+            C[3, :, :] = 2                                            # proportional columns
+        monkeypatch.delenv("THETA_SOLVE_NO_WAVE", raising=False)
+        ok_w, mu_w, nll_w, vals_w = ctx.solve_batch(3, 2, r, rN, C, 1.0, want_vals=True)
+        fb_w = ctx.last_solve_fallback.copy()
+        monkeypatch.setenv("THETA_SOLVE_NO_WAVE", "1")
+        ok_l, mu_l, nll_l, vals_l = ctx.solve_batch(3, 2, r, rN, C, 1.0, want_vals=True)
+        fb_l = ctx.last_solve_fallback.copy()
+        monkeypatch.delenv("THETA_SOLVE_NO_WAVE", raising=False)
+        assert np.array_equal(ok_w, ok_l) and np.array_equal(fb_w, fb_l), (m, B)
+        for a, b in ((mu_w, mu_l), (nll_w, nll_l), (vals_w, vals_l)):
+            assert np.array_equal(a.view(np.uint64), b.view(np.uint64)), (m, B)      # (NaN patterns included)
+        assert ok_w.sum() > 0

@@ -190,6 +190,191 @@ __global__ __launch_bounds__(64) void solve_batch_n3_kernel(int m, int tau, cons
 }
 
 // ------------------------------------------------------------------------------------------------
+// The same procedure, ONE WAVE PER CANDIDATE (round 6): for the few dozen matrices a whole-space search hands over, the lane-per-candidate
+// kernel above is all latency -- every likelihood term costs 6 IEEE divisions in `f`, 12 in `jac`, one lane walks the m terms of every
+// evaluation, and one candidate in a hundred takes hundreds of evaluations (6 ms for 140 matrices of 200 intervals).  Here all 64 lanes
+// run the procedure's control flow on the same numbers, and an evaluation's TERMS are spread over them: lane l computes terms l, l + 64,
+// ... into LDS, then every lane adds the m values up in the reference's order, top to bottom -- the same operations on the same operands
+// in the same order as N3RefSystem's loops, so the same bits (tests/test_gpu_parity.py compares the two kernels entry by entry).
+// ------------------------------------------------------------------------------------------------
+struct N3RefSystemW {
+    int m, mp;
+    double tau;
+    const double *r, *rN;          // [m] (LDS)
+    const unsigned char *c;        // [m][2]
+    double *sc;                    // LDS scratch [9][mp]
+    double S[3];
+
+    __device__ void init() {
+        for (int i = threadIdx.x; i < m; i += 64) {
+            sc[i] = rN[i] * tau;
+            sc[mp + i] = rN[i] * (double)c[2 * i];
+            sc[2 * mp + i] = rN[i] * (double)c[2 * i + 1];
+        }
+        __syncthreads();
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+        for (int i = 0; i < m; i++) {
+            s0 = s0 + sc[i];
+            s1 = s1 + sc[mp + i];
+            s2 = s2 + sc[2 * mp + i];
+        }
+        __syncthreads();
+        S[0] = s0;
+        S[1] = s1;
+        S[2] = s2;
+    }
+    __device__ void chat(int i, double &h0, double &h1, double &h2) const {
+        h0 = (rN[i] * tau) / S[0];
+        h1 = (rN[i] * (double)c[2 * i]) / S[1];
+        h2 = (rN[i] * (double)c[2 * i + 1]) / S[2];
+    }
+    __device__ void f(const double *x, double *fv) const {
+        for (int i = threadIdx.x; i < m; i += 64) {
+            double h0, h1, h2;
+            chat(i, h0, h1, h2);
+            const double p = (h0 * x[1] + h1 * x[2]) + h2 * x[3];
+            sc[i] = (r[i] * h0) / p;
+            sc[mp + i] = (r[i] * h1) / p;
+            sc[2 * mp + i] = (r[i] * h2) / p;
+        }
+        __syncthreads();
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+        for (int i = 0; i < m; i++) {
+            a0 = a0 + sc[i];
+            a1 = a1 + sc[mp + i];
+            a2 = a2 + sc[2 * mp + i];
+        }
+        __syncthreads();
+        fv[1] = (-a0) - x[4];
+        fv[2] = (-a1) - x[4];
+        fv[3] = (-a2) - x[4];
+        fv[4] = 1.0 - ((x[1] + x[2]) + x[3]);
+    }
+    __device__ void jac(const double *x, double fj[hybrj4::N + 1][hybrj4::N + 1]) const {
+        for (int i = threadIdx.x; i < m; i += 64) {
+            double h[3];
+            chat(i, h[0], h[1], h[2]);
+            const double p = (h[0] * x[1] + h[1] * x[2]) + h[2] * x[3];
+            const double den = refpow::square(p);
+            for (int k = 0; k < 3; k++)
+                for (int q = 0; q < 3; q++) sc[(3 * k + q) * mp + i] = ((r[i] * h[k]) * h[q]) / den;
+        }
+        __syncthreads();
+        double J[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+        for (int i = 0; i < m; i++)
+            for (int k = 0; k < 3; k++)
+                for (int q = 0; q < 3; q++) J[k][q] = J[k][q] + sc[(3 * k + q) * mp + i];
+        __syncthreads();
+        for (int k = 0; k < 3; k++)
+            for (int q = 0; q < 3; q++) fj[k + 1][q + 1] = J[k][q];
+        for (int k = 1; k <= 3; k++) {
+            fj[4][k] = -1.0;
+            fj[k][4] = -1.0;
+        }
+        fj[4][4] = 0.0;
+    }
+    __device__ double fhat(double v0, double v1) const {
+        const double v2 = 1.0 - (v0 + v1);
+        bool bad = false;
+        for (int i = threadIdx.x; i < m; i += 64) {
+            double h0, h1, h2;
+            chat(i, h0, h1, h2);
+            const double p = (h0 * v0 + h1 * v1) + h2 * v2;
+            if (p < 0.0 || p != p) bad = true;
+            else sc[i] = r[i] * log(p);
+        }
+        const bool any_bad = __syncthreads_or(bad) != 0;         // (the serial loop returns NaN at its first such term: the same value)
+        double acc = 0.0;
+        if (!any_bad)
+            for (int i = 0; i < m; i++) acc = acc + sc[i];
+        __syncthreads();
+        return any_bad ? NAN : -acc;
+    }
+    __device__ void ghat(double v0, double v1, double &g0, double &g1) const {
+        for (int i = threadIdx.x; i < m; i += 64) {
+            double h0, h1, h2;
+            chat(i, h0, h1, h2);
+            const double n0 = h0 - h2, n1 = h1 - h2;
+            const double den = (n0 * v0 + n1 * v1) + h2;
+            sc[i] = r[i] * (n0 / den);
+            sc[mp + i] = r[i] * (n1 / den);
+        }
+        __syncthreads();
+        g0 = 0.0;
+        g1 = 0.0;
+        for (int i = 0; i < m; i++) {
+            g0 = g0 + sc[i];
+            g1 = g1 + sc[mp + i];
+        }
+        __syncthreads();
+    }
+    __device__ double l3(const double mu[3], double *vals) const {
+        const double m0 = mu[0], m1 = mu[1], m2 = mu[2];
+        for (int h = threadIdx.x; h < m; h += 64) {
+            sc[h] = (rN[h] * tau) * m0;
+            sc[mp + h] = (rN[h] * (double)c[2 * h]) * m1;
+            sc[2 * mp + h] = (rN[h] * (double)c[2 * h + 1]) * m2;
+        }
+        __syncthreads();
+        double den = 0.0;
+        for (int h = 0; h < m; h++) den = den + sc[h];
+        for (int h = 0; h < m; h++) den = den + sc[mp + h];
+        for (int h = 0; h < m; h++) den = den + sc[2 * mp + h];
+        __syncthreads();
+        for (int i = threadIdx.x; i < m; i += 64) {
+            const double nm = ((rN[i] * tau) * m0 + (rN[i] * (double)c[2 * i]) * m1) + (rN[i] * (double)c[2 * i + 1]) * m2;
+            const double p = nm / den;
+            sc[i] = r[i] * log(p);
+            if (vals) vals[i] = p;
+        }
+        __syncthreads();
+        double tot = 0.0;
+        for (int i = 0; i < m; i++) tot = tot + sc[i];
+        __syncthreads();
+        return -tot;
+    }
+};
+
+__global__ __launch_bounds__(64) void solve_wave_n3_kernel(int m, int tau, const double *r, const double *rN, int B, const unsigned char *C,
+                                                           unsigned char *ok, double *mu, double *nll, double *vals) {
+    extern __shared__ double sm[];
+    const int mp = (m + 1) & ~1;
+    double *rr = sm, *rn = sm + mp;
+    for (int i = threadIdx.x; i < m; i += 64) {
+        rr[i] = r[i];
+        rn[i] = rN[i];
+    }
+    __syncthreads();
+    const int b = blockIdx.x;
+    N3RefSystemW sys;
+    sys.m = m;
+    sys.mp = mp;
+    sys.tau = (double)tau;
+    sys.r = rr;
+    sys.rN = rn;
+    sys.c = C + (size_t)b * m * 2;
+    sys.sc = sm + 2 * mp;
+    sys.init();
+    double mv[3], value = 0.0;
+    const int outcome = n3_ref_solve(sys, mv, value, vals ? vals + (size_t)b * m : nullptr);
+    if (outcome == 0) {
+        if (threadIdx.x == 0) {
+            ok[b] = 0;
+            mu[3 * b] = mu[3 * b + 1] = mu[3 * b + 2] = nll[b] = __builtin_nan("");
+        }
+        if (vals) for (int i = threadIdx.x; i < m; i += 64) vals[(size_t)b * m + i] = __builtin_nan("");
+        return;
+    }
+    if (threadIdx.x == 0) {
+        ok[b] = (unsigned char)outcome;
+        mu[3 * b] = mv[0];
+        mu[3 * b + 1] = mv[1];
+        mu[3 * b + 2] = mv[2];
+        nll[b] = value;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Smallest NLL a candidate can take anywhere on the BOUNDARY of the simplex (some nu_j = 0), per-interval
 // sums.  For a candidate whose optimum lies outside the simplex this is the lowest value the reference's solver
 // could ever report for it (its iterates stay inside [0,1]^3 or are rejected, Optimizer.py:150-160), so
@@ -865,6 +1050,7 @@ __global__ __launch_bounds__(256) void score_plain_sliced_kernel(int m, int tau,
 // ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------
+#define SOLVE_WAVE_MAX_B 2048      // (the chip holds 4 096 waves of this kernel at once: beyond that a lane per candidate has the better rate)
 void batch_launch_solve(int n, int m, int tau, const double *r, const double *rN, double max_normal, int B,
                         const unsigned char *C, unsigned char *ok, double *mu, double *nll, double *vals,
                         hipStream_t st) {
@@ -872,6 +1058,10 @@ void batch_launch_solve(int n, int m, int tau, const double *r, const double *rN
     if (n == 2)
         hipLaunchKernelGGL(solve_batch_n2_kernel, dim3(blocks), dim3(64), (size_t)m * 3 * sizeof(double), st, m, tau, r, rN,
                            max_normal, B, C, ok, mu, nll, vals);
+    else if (B <= SOLVE_WAVE_MAX_B && m <= 512 && !getenv("THETA_SOLVE_NO_WAVE"))
+        // a small batch (the records of a whole-space search): one wave per candidate -- the same bits, a thirtieth of the latency
+        hipLaunchKernelGGL(solve_wave_n3_kernel, dim3((unsigned)B), dim3(64), (size_t)((m + 1) & ~1) * 11 * sizeof(double), st, m, tau, r, rN,
+                           B, C, ok, mu, nll, vals);
     else
         hipLaunchKernelGGL(solve_batch_n3_kernel, dim3(blocks), dim3(64), (size_t)m * 2 * sizeof(double), st, m, tau, r, rN,
                            B, C, ok, mu, nll, vals);

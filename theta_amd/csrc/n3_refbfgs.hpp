@@ -19,36 +19,13 @@
 #pragma clang fp contract(off)
 #endif
 
-struct N3RefBfgs {
-    const N3RefSystem &s;
+template <class SYS>
+struct N3RefBfgsT {
+    const SYS &s;
     double pk0, pk1, phi0, d0;
 
-    // L3_hat (Optimizer.py:246-252) at (v0, v1); NaN outside the domain like numpy's log
-    HYBRJ4_HD double fhat(double v0, double v1) const {
-        double acc = 0.0;
-        const double v2 = 1.0 - (v0 + v1);
-        for (int i = 0; i < s.m; i++) {
-            double h0, h1, h2;
-            s.chat(i, h0, h1, h2);
-            const double p = (h0 * v0 + h1 * v1) + h2 * v2;
-            if (p < 0.0 || p != p) return NAN;
-            acc = acc + s.r[i] * log(p);          // log(0) = -inf like numpy
-        }
-        return -acc;
-    }
-    // dL3_hat (Optimizer.py:255-265)
-    HYBRJ4_HD void ghat(double v0, double v1, double &g0, double &g1) const {
-        g0 = 0.0;
-        g1 = 0.0;
-        for (int i = 0; i < s.m; i++) {
-            double h0, h1, h2;
-            s.chat(i, h0, h1, h2);
-            const double n0 = h0 - h2, n1 = h1 - h2;
-            const double den = (n0 * v0 + n1 * v1) + h2;
-            g0 = g0 + s.r[i] * (n0 / den);
-            g1 = g1 + s.r[i] * (n1 / den);
-        }
-    }
+    HYBRJ4_HD double fhat(double v0, double v1) const { return s.fhat(v0, v1); }       // (L3_hat, dL3_hat: n3_refsys.hpp)
+    HYBRJ4_HD void ghat(double v0, double v1, double &g0, double &g1) const { s.ghat(v0, v1, g0, g1); }
     HYBRJ4_HD double phi(double a) const { return fhat(1.0 / 3.0 + a * pk0, 1.0 / 3.0 + a * pk1); }
     HYBRJ4_HD double dphi(double a) const {
         double g0, g1;
@@ -155,13 +132,14 @@ struct N3RefBfgs {
 
 // The reference's outcome class for one candidate: 1 = fsolve's iterate is in [0,1]^3 (nu filled in), 2 = the
 // nu = (1/3,1/3,1/3) fallback, 0 = None (BFGS left its start for a point out of range / with NaN likelihood).
-HYBRJ4_HD inline int n3_ref_outcome(N3RefSystem &sys, double nu[3]) {
+template <class SYS>
+HYBRJ4_HD inline int n3_ref_outcome(SYS &sys, double nu[3]) {
     n3_ref_fsolve(sys, nu, nullptr);
     bool in = true;
     for (int j = 0; j < 3; j++)
         if (nu[j] < 0.0 || nu[j] > 1.0) in = false;                   // (NaN passes, Misc.py:49-57)
     if (in) return 1;
-    N3RefBfgs b{sys, 0.0, 0.0, 0.0, 0.0};
+    N3RefBfgsT<SYS> b{sys, 0.0, 0.0, 0.0, 0.0};
     if (b.moves()) return 0;
     nu[0] = nu[1] = nu[2] = 1.0 / 3.0;
     return 2;
@@ -175,25 +153,13 @@ HYBRJ4_HD inline int n3_ref_outcome(N3RefSystem &sys, double nu[3]) {
 // An all-zero tumour column makes Chat NaN: hybrj then returns its start unchanged, exactly like the reference's fsolve
 // call, nu = (1/3,1/3,1/3) passes inRange, M3 lands on a unit vector plus rounding residue, and L3 makes a finite number
 // or NaN of it -- reproduced, not special-cased.  Host and device run this same code.
-HYBRJ4_HD inline int n3_ref_solve(N3RefSystem &sys, double mu[3], double &nll, double *vals) {
+template <class SYS>
+HYBRJ4_HD inline int n3_ref_solve(SYS &sys, double mu[3], double &nll, double *vals) {
     double nu[3];
     const int outcome = n3_ref_outcome(sys, nu);
     if (outcome == 0) return 0;
     n3_ref_M3(sys.S, nu, mu, nullptr);
-    const double m0 = mu[0], m1 = mu[1], m2 = mu[2];
-    const int m = sys.m;
-    double den = 0.0;
-    for (int h = 0; h < m; h++) den = den + (sys.rN[h] * sys.tau) * m0;
-    for (int h = 0; h < m; h++) den = den + (sys.rN[h] * (double)sys.c[2 * h]) * m1;
-    for (int h = 0; h < m; h++) den = den + (sys.rN[h] * (double)sys.c[2 * h + 1]) * m2;
-    double tot = 0.0;
-    for (int i = 0; i < m; i++) {
-        const double nm = ((sys.rN[i] * sys.tau) * m0 + (sys.rN[i] * (double)sys.c[2 * i]) * m1) + (sys.rN[i] * (double)sys.c[2 * i + 1]) * m2;
-        const double p = nm / den;
-        tot = tot + sys.r[i] * log(p);               // log of a negative number is NaN, like numpy's
-        if (vals) vals[i] = p;
-    }
-    nll = -tot;
+    nll = sys.l3(mu, vals);
     return outcome;
 }
 

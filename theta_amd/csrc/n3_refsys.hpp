@@ -65,10 +65,55 @@ struct N3RefSystem {
         }
         fj[4][4] = 0.0;
     }
+    // L3_hat (Optimizer.py:246-252) at (v0, v1); NaN outside the domain like numpy's log
+    HYBRJ4_HD double fhat(double v0, double v1) const {
+        double acc = 0.0;
+        const double v2 = 1.0 - (v0 + v1);
+        for (int i = 0; i < m; i++) {
+            double h0, h1, h2;
+            chat(i, h0, h1, h2);
+            const double p = (h0 * v0 + h1 * v1) + h2 * v2;
+            if (p < 0.0 || p != p) return NAN;
+            acc = acc + r[i] * log(p);          // log(0) = -inf like numpy
+        }
+        return -acc;
+    }
+    // dL3_hat (Optimizer.py:255-265)
+    HYBRJ4_HD void ghat(double v0, double v1, double &g0, double &g1) const {
+        g0 = 0.0;
+        g1 = 0.0;
+        for (int i = 0; i < m; i++) {
+            double h0, h1, h2;
+            chat(i, h0, h1, h2);
+            const double n0 = h0 - h2, n1 = h1 - h2;
+            const double den = (n0 * v0 + n1 * v1) + h2;
+            g0 = g0 + r[i] * (n0 / den);
+            g1 = g1 + r[i] * (n1 / den);
+        }
+    }
+    // Optimizer.L3's sums (Optimizer.py:236-244: the denominator accumulates column by column -- for j ... for h ... --, the numerators
+    // left to right); vals[m] may be null
+    HYBRJ4_HD double l3(const double mu[3], double *vals) const {
+        const double m0 = mu[0], m1 = mu[1], m2 = mu[2];
+        double den = 0.0;
+        for (int h = 0; h < m; h++) den = den + (rN[h] * tau) * m0;
+        for (int h = 0; h < m; h++) den = den + (rN[h] * (double)c[2 * h]) * m1;
+        for (int h = 0; h < m; h++) den = den + (rN[h] * (double)c[2 * h + 1]) * m2;
+        double tot = 0.0;
+        for (int i = 0; i < m; i++) {
+            const double nm = ((rN[i] * tau) * m0 + (rN[i] * (double)c[2 * i]) * m1) + (rN[i] * (double)c[2 * i + 1]) * m2;
+            const double p = nm / den;
+            tot = tot + r[i] * log(p);               // log of a negative number is NaN, like numpy's
+            if (vals) vals[i] = p;
+        }
+        return -tot;
+    }
 };
 
 // fsolve(equations, [1/3,1/3,1/3,1], fprime=jacobian) with scipy's defaults (xtol 1.49012e-8, maxfev 100 (n+1), factor 100).
-HYBRJ4_HD inline int n3_ref_fsolve(N3RefSystem &sys, double nu[3], int *nfev) {
+// (SYS: N3RefSystem, or the wave-cooperative system of batch.hip -- same interface, same operations in the same order)
+template <class SYS>
+HYBRJ4_HD inline int n3_ref_fsolve(SYS &sys, double nu[3], int *nfev) {
     double x[hybrj4::N + 1] = {0.0, 1.0 / 3.0, 1.0 / 3.0, 1.0 / 3.0, 1.0};
     const int info = hybrj4::hybrj(sys, x, 1.49012e-8, 100 * (hybrj4::N + 1), 100.0, nfev);
     nu[0] = x[1];
