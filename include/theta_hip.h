@@ -408,6 +408,8 @@ int theta_enumerate_device(theta_problem *p, const uint64_t rank_begin[2], uint6
  *              comes out NaN (an all-zero tumour column, mostly) keeps ok = 1 / 2: the reference returns that tuple too
  *   mu[B*n], nll[B]
  *   vals[B*m]  the per-interval p* (third element of the reference's tuple); may be NULL
+ * n=3: one lane per candidate, or -- B <= 2048 and m <= 512 -- one WAVE per candidate with the terms of an evaluation spread over its lanes
+ * and added up in the reference's order: the same bits either way (THETA_SOLVE_NO_WAVE=1: the lane kernel throughout).
  */
 int theta_solve_batch(theta_ctx *ctx, int n, int m, int tau, const int64_t *r, const int64_t *rN,
                       double max_normal, int B, const uint8_t *C, uint8_t *ok, double *mu,
